@@ -1,0 +1,76 @@
+/*
+ * nnuzoo_hip.h — C-ABI of libnnuzoo_hip.so, the MI355X (gfx950) kernels behind nnUZoo's per-patch
+ * forward/backward hot path.
+ *
+ * The reference (AI-in-Cardiovascular-Medicine/nnUZoo) has no FFI boundary of its own: it is pure Python and
+ * reaches device code through torch.nn / mamba_ssm.  Each entry point below therefore cites the Python call
+ * site whose device work it replaces (paths relative to /root/reference).  INTEGRATION.md shows the ctypes stub
+ * a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it is a `desc`/`ksel` table (host memory, read at launch);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered,
+ *     re-entrant, and allocation-free (graph-capturable); workspaces/outputs belong to the caller;
+ *   - return value: 0 on success, a positive hipError_t from the runtime, or -22 (EINVAL) for a shape /
+ *     alignment the kernels do not support.  Nothing is ever silently routed to a CPU path;
+ *   - activations are channels-last fp16 ((N, D, H, W, C), "ld" = elements between consecutive voxels, so a
+ *     tensor can be a channel-slice of a wider concat buffer); statistics, parameters and parameter
+ *     gradients are fp32.
+ */
+#ifndef NNUZOO_HIP_H
+#define NNUZOO_HIP_H
+
+#include <stdint.h>
+#include "../nnuzoo_amd/csrc/conv_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library / device probe: returns 0 and fills arch ("gfx950...") when a GPU is visible */
+int nnz_device_info(char* arch, int arch_len, int* num_cu, long* hbm_bytes);
+int nnz_version(void);
+
+/* ---- dense contractions of the PlainConvUNet ("nnUNet") --------------------------------------------------
+ * replaces torch.nn.Conv3d / ConvTranspose3d forward + autograd backward of
+ * dynamic_network_architectures.PlainConvUNet, instantiated at nnunetv2/utilities/get_network_from_plans.py:27-57
+ * and driven by nnUNetTrainer.train_step (nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1112-1144). */
+int nnz_conv_tap_forward(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
+                         const nnz_conv_desc* desc, void* stream);
+int nnz_conv_tap_wgrad(const void* boxed_f16, const void* plain_f16, float* dw /* [T][A][B] */,
+                       const nnz_conv_desc* desc, void* stream);
+int nnz_pack_conv_weight(const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
+                         const int* ksel, void* stream);
+int nnz_unpack_conv_wgrad(const float* dw, float* grad, int A, int B, int T, long sa, long sb, long sk,
+                          const int* ksel, int accumulate, void* stream);
+
+/* stem Conv3d(1 -> 32, k3, p1) on the fp32 input patch and the 1x1x1 deep-supervision heads */
+int nnz_stem_conv_forward(const float* x, const float* w, const float* bias, void* y_f16, int N, int D, int H, int W,
+                          int Cout, int ldy, void* stream);
+int nnz_stem_conv_wgrad(const float* x, const void* dy_f16, float* dw, int N, int D, int H, int W, int Cout, int lddy,
+                        void* stream);
+int nnz_seg_head_forward(const void* x_f16, const float* w, const float* bias, void* logits_f16_nc, int N, long V,
+                         int C, int K, int ldx, void* stream);
+int nnz_seg_head_dgrad(const void* dlogits_f16_nc, const float* w, void* dx_f16, int N, long V, int C, int K, int lddx,
+                       int accumulate, void* stream);
+int nnz_seg_head_wgrad(const void* x_f16, const void* dlogits_f16_nc, float* dw, float* db, int N, long V, int C,
+                       int K, int ldx, void* stream);
+
+/* ---- InstanceNorm(affine, eps) + LeakyReLU(slope) ---------------------------------------------------------
+ * replaces nn.InstanceNorm3d + nn.LeakyReLU of every conv block (arch kwargs at
+ * nnunetv2/experiment_planning/experiment_planners/default_experiment_planner.py:285-305). */
+int nnz_instnorm_stats(const void* x_f16, float* stats /* [N][C][2] sum,sumsq */, int N, long V, int C, int ldx,
+                       void* stream);
+int nnz_instnorm_lrelu_apply(const void* x_f16, const float* stats, const float* gamma, const float* beta, void* y_f16,
+                             int N, long V, int C, int ldx, int ldy, float eps, float slope, void* stream);
+int nnz_instnorm_lrelu_bwd_reduce(const void* x_f16, const void* g_f16, const float* stats, const float* gamma,
+                                  const float* beta, float* red /* [N][C][2] */, int N, long V, int C, int ldx,
+                                  int ldg, float eps, float slope, void* stream);
+int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const float* stats, const float* red,
+                                 const float* gamma, const float* beta, void* dx_f16, int N, long V, int C, int ldx,
+                                 int ldg, int lddx, float eps, float slope, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNUZOO_HIP_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libnnuzoo_hip.so (include/nnuzoo_hip.h).
+
+The HIP library IS the product: if it is missing or a call fails, this module raises.  There is no CPU or
+eager-PyTorch fallback anywhere in the package (the CPU restatements live under /oracle and are test-only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnnuzoo_hip.so")
+
+NNZ_MAX_GROUPS = 8
+NNZ_MAX_TAPS = 32
+
+
+class ConvTap(C.Structure):
+    _fields_ = [("off", C.c_int32 * 3), ("widx", C.c_int32)]
+
+
+class ConvGroup(C.Structure):
+    _fields_ = [("ooff", C.c_int32 * 3), ("tap_begin", C.c_int32), ("ntaps", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("in_dims", C.c_int32 * 3),
+        ("out_dims", C.c_int32 * 3),
+        ("m_dims", C.c_int32 * 3),
+        ("Cin", C.c_int32),
+        ("Cout", C.c_int32),
+        ("ldi", C.c_int32),
+        ("ldo", C.c_int32),
+        ("in_stride", C.c_int32),
+        ("out_stride", C.c_int32),
+        ("ext", C.c_int32),
+        ("lo", C.c_int32 * 3),
+        ("ntaps_total", C.c_int32),
+        ("ngroups", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("groups", ConvGroup * NNZ_MAX_GROUPS),
+        ("taps", ConvTap * NNZ_MAX_TAPS),
+    ]
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+_vp, _fp, _i, _l, _f = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float
+_ip = C.POINTER(C.c_int)
+_dp = C.POINTER(ConvDesc)
+
+# name -> argtypes; every symbol declared in include/nnuzoo_hip.h must appear here (tests check both ways)
+SIGNATURES = {
+    "nnz_version": [],
+    "nnz_device_info": [C.c_char_p, _i, _ip, C.POINTER(C.c_long)],
+    "nnz_conv_tap_forward": [_vp, _vp, _vp, _fp, _dp, _vp],
+    "nnz_conv_tap_wgrad": [_vp, _vp, _fp, _dp, _vp],
+    "nnz_pack_conv_weight": [_fp, _vp, _i, _i, _i, _l, _l, _l, _ip, _vp],
+    "nnz_unpack_conv_wgrad": [_fp, _fp, _i, _i, _i, _l, _l, _l, _ip, _i, _vp],
+    "nnz_stem_conv_forward": [_fp, _fp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "nnz_stem_conv_wgrad": [_fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp],
+    "nnz_seg_head_forward": [_vp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _vp],
+    "nnz_seg_head_dgrad": [_vp, _fp, _vp, _i, _l, _i, _i, _i, _i, _vp],
+    "nnz_seg_head_wgrad": [_vp, _vp, _fp, _fp, _i, _l, _i, _i, _i, _vp],
+    "nnz_instnorm_stats": [_vp, _fp, _i, _l, _i, _i, _vp],
+    "nnz_instnorm_lrelu_apply": [_vp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _f, _f, _vp],
+    "nnz_instnorm_lrelu_bwd_reduce": [_vp, _vp, _fp, _fp, _fp, _fp, _i, _l, _i, _i, _i, _f, _f, _vp],
+    "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _vp],
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises HipLibraryMissing with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m nnuzoo_amd.build` (hipcc --offload-arch=gfx950). "
+            "nnuzoo_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = "invalid argument / unsupported shape" if rc == -22 else f"hipError_t {rc}"
+        raise HipCallError(f"{what} failed: {kind}")
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    """data_ptr of a CUDA tensor (None -> NULL)."""
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise HipCallError("nnuzoo_amd kernels need device (HIP) tensors; there is no CPU path")
+    return t.data_ptr()

@@ -1,0 +1,61 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the nnUZoo hot path.
+// Everything here is wave64 / MFMA specific; there is no portability layer by design.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short i16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define NNZ_OK 0
+#define NNZ_EINVAL (-22)
+
+#define NNZ_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+namespace nnz {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// 32x32x16 f16 MFMA, fp32 accumulate.  A: lane l holds A[row l&31][k 8(l>>5)+j]; B: B[k 8(l>>5)+j][col l&31];
+// D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5)   (cdna_hip_programming.md §3).
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// Transposed LDS read (ds_read_b64_tr_b16): per 16-lane group a 4-row x 16-col block of 16-bit elements,
+// lane 4q+p supplies the address of row q / cols 4p..4p+3, lane i receives column i (rows 0..3).
+__device__ __forceinline__ i16x4 lds_read_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// XCD-aware bijective remap of a linear workgroup id: blocks that are neighbours in the remapped
+// order share an XCD (and its L2).  cdna_hip_programming.md §5.5 T1 (bijective variant).
+__device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
+  const unsigned nx = 8;
+  unsigned q = nwg / nx, r = nwg % nx, xcd = orig % nx;
+  unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + orig / nx;
+}
+
+}  // namespace nnz

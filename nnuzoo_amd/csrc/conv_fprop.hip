@@ -1,0 +1,330 @@
+// Tap-table implicit-GEMM convolution on MFMA (gfx950), channels-last fp16 activations, fp32 accumulate.
+//
+// One kernel family serves every dense contraction of the PlainConvUNet forward/backward except the
+// weight gradients (conv_wgrad.hip) and the Cin=1 stem (conv_stem.hip):
+//   * k3 s1 / k3 s2 forward convolutions                       (1 group, 27 taps)
+//   * data gradient of a k3 s1 convolution                      (1 group, 27 flipped taps)
+//   * data gradient of a k3 s2 convolution                      (8 output-parity groups, 1..8 taps each)
+//   * k2 s2 transposed convolution forward                      (8 groups of 1 tap, out_stride 2)
+//   * data gradient of the k2 s2 transposed convolution         (1 group, 8 taps, in_stride 2)
+//   * 1x1 convolutions                                           (1 group, 1 tap)
+// Reference op being replaced: torch.nn.Conv3d / ConvTranspose3d as wired by
+// dynamic_network_architectures.PlainConvUNet (instantiated at
+// /root/reference/nnunetv2/utilities/get_network_from_plans.py:27-57).
+//
+// Design (MI355X-first):
+//   * A workgroup owns an m-tile of TDxTHxTW voxels and NB*32 output channels.  Per 16-channel slice of
+//     the reduction it stages (a) the input *box* (tile + halo) and (b) all taps' weights for that slice
+//     into LDS once; all taps then read shifted windows of the box from LDS, so an input element crosses
+//     the L2->LDS path once per (tile, Cout-block) instead of 27 times.
+//   * v_mfma_f32_32x32x16_f16 with the weights as the A operand (rows = cout) and voxels on the lanes
+//     (B operand): every lane ends up with 4 consecutive couts of ONE voxel per accumulator quad, so the
+//     epilogue stores 8-byte channel runs with no LDS transpose.
+//   * 32-byte LDS rows (16 ch) for box and weights; a 1-bit XOR on the 16-byte half (box: h parity,
+//     weights: (cout>>4)&1) makes every ds_read_b128 lane group hit 16 distinct slots.
+//   * Next slice's global loads are issued before the MFMA loop of the current one (register staging,
+//     write after the barrier), >=2 workgroups per CU cover the barriers.
+//   * 1-D grid with a bijective XCD remap: consecutive m-tiles (which share halo and weights) run on
+//     one XCD's L2.
+#include "common.hpp"
+#include "conv_params.h"
+
+namespace nnz {
+
+struct TapDev {
+  int lds_off;  // byte offset of the tap inside the box
+  int hpar;     // parity of the tap's h offset (selects the swizzled half)
+};
+
+struct ConvDev {
+  const f16* in;
+  f16* out;
+  const f16* w;
+  const float* bias;
+  nnz_conv_desc d;
+  int tiles[3];
+  int gx, gy, gz;
+};
+
+template <int TD, int TH, int TW, int NB, int IS, int EXT>
+struct ConvCfg {
+  static constexpr int BD = (TD - 1) * IS + EXT + 1;
+  static constexpr int BH = (TH - 1) * IS + EXT + 1;
+  static constexpr int BW = (TW - 1) * IS + EXT + 1;
+  static constexpr int PW = (BW + 3) & ~3;  // row pitch in voxels (multiple of 4: see swizzle note)
+  static constexpr int BOX_BYTES = BD * BH * PW * 32;
+  static constexpr int NBOXLOAD = BD * BH * BW * 2;  // 16-byte pieces
+  static constexpr int LPT_BOX = (NBOXLOAD + 255) / 256;
+  static constexpr int W_BYTES_MAX = NB * 27 * 32 * 32;
+  static constexpr int LPT_W = (NB * 27 * 64 + 255) / 256;
+  static constexpr int MB = TD * TH * TW / 32;
+  static constexpr int WAVES_M = MB >= 4 ? 4 : MB;
+  static constexpr int WAVES_N = 4 / WAVES_M;
+  static constexpr int WM = MB / WAVES_M;
+  static constexpr int WN = NB / WAVES_N;
+  static_assert(TW == 8, "lane->voxel map assumes TW == 8");
+  static_assert(NB % WAVES_N == 0 && WN >= 1, "NB must cover the N-split of the waves");
+  static constexpr int LDS_BYTES = BOX_BYTES + W_BYTES_MAX;
+};
+
+template <int TD, int TH, int TW, int NB, int IS, int EXT>
+__global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
+  using C = ConvCfg<TD, TH, TW, NB, IS, EXT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* box = smem;
+  char* wl = smem + C::BOX_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int hh = lane >> 5;
+
+  // ---- workgroup -> (tile, cout block, sample, group) ---------------------------------------------
+  const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
+  unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const int bx = lin % p.gx;
+  lin /= p.gx;
+  const int by = lin % p.gy;
+  const int bz = lin / p.gy;
+  const int g = bz % p.d.ngroups;
+  const int n = bz / p.d.ngroups;
+  const int tw_i = bx % p.tiles[2];
+  const int th_i = (bx / p.tiles[2]) % p.tiles[1];
+  const int td_i = bx / (p.tiles[2] * p.tiles[1]);
+  const int m0d = td_i * TD, m0h = th_i * TH, m0w = tw_i * TW;
+  const int cb0 = by * NB;  // first 32-wide cout block
+
+  const nnz_conv_group grp = p.d.groups[g];
+  const int nt = grp.ntaps;
+  const int tb = grp.tap_begin;
+  const int T = p.d.ntaps_total;
+  const int Cin = p.d.Cin, Cout = p.d.Cout;
+  const int Di = p.d.in_dims[0], Hi = p.d.in_dims[1], Wi = p.d.in_dims[2];
+
+  // ---- per-thread staging addresses (independent of the channel slice) ----------------------------
+  int box_goff[C::LPT_BOX];  // element offset into `in` (without channel slice), -1 = zero fill
+  int box_loff[C::LPT_BOX];  // LDS byte offset, -1 = nothing to do
+  {
+    const int lod = m0d * IS + p.d.lo[0], loh = m0h * IS + p.d.lo[1], low = m0w * IS + p.d.lo[2];
+#pragma unroll
+    for (int i = 0; i < C::LPT_BOX; ++i) {
+      const int c = tid + i * 256;
+      box_goff[i] = -1;
+      box_loff[i] = -1;
+      if (c < C::NBOXLOAD) {
+        const int half = c & 1;
+        const int s = c >> 1;
+        const int bw = s % C::BW;
+        const int bh = (s / C::BW) % C::BH;
+        const int bd = s / (C::BW * C::BH);
+        const int id = lod + bd, ih = loh + bh, iw = low + bw;
+        box_loff[i] = ((bd * C::BH + bh) * C::PW + bw) * 32 + ((half ^ (bh & 1)) << 4);
+        if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
+          box_goff[i] = (((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + half * 8;
+      }
+    }
+  }
+  const int nwchunks = NB * nt * 64;
+
+  // ---- per-lane fragment addresses ----------------------------------------------------------------
+  const int wm = wave % C::WAVES_M;
+  const int wn = wave / C::WAVES_M;
+  int vox_off[2][C::WM];  // LDS byte offset of the lane's voxel row for tap h-parity 0 / 1
+  int out_vox[C::WM];     // element offset of the lane's output voxel, -1 if masked
+#pragma unroll
+  for (int i = 0; i < C::WM; ++i) {
+    const int v = (wm * C::WM + i) * 32 + l31;
+    const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+    const int base = (((td * IS) * C::BH + th * IS) * C::PW + tw * IS) * 32;
+    const int f = (th * IS) & 1;
+    vox_off[0][i] = base + ((hh ^ f) << 4);
+    vox_off[1][i] = base + ((hh ^ f ^ 1) << 4);
+    const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
+    const int od = md * p.d.out_stride + grp.ooff[0];
+    const int oh = mh * p.d.out_stride + grp.ooff[1];
+    const int ow = mw * p.d.out_stride + grp.ooff[2];
+    const bool ok = md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] &&
+                    od < p.d.out_dims[0] && oh < p.d.out_dims[1] && ow < p.d.out_dims[2];
+    out_vox[i] = ok ? (((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) * p.d.ldo
+                    : -1;
+  }
+  // weights: lane reads row (l&31) of [nb][t][32][32B]
+  const int w_lane = l31 * 32 + ((hh ^ ((lane >> 4) & 1)) << 4);
+
+  f32x16 acc[C::WN][C::WM];
+#pragma unroll
+  for (int a = 0; a < C::WN; ++a)
+#pragma unroll
+    for (int b = 0; b < C::WM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // per-tap LDS offsets (uniform)
+  const int lo0 = p.d.lo[0], lo1 = p.d.lo[1], lo2 = p.d.lo[2];
+
+  u32x4 breg[C::LPT_BOX];
+  u32x4 wreg[C::LPT_W];
+  const int nkc = Cin >> 4;
+
+  auto issue_loads = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < C::LPT_BOX; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (box_goff[i] >= 0) v = *reinterpret_cast<const u32x4*>(p.in + (size_t)box_goff[i] + kc * 16);
+      breg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < C::LPT_W; ++i) {
+      const int c = tid + i * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (c < nwchunks) {
+        const int nb = c / (nt * 64);
+        const int r = c - nb * nt * 64;
+        const size_t base = ((size_t)(kc * (Cout >> 5) + cb0 + nb) * T + tb) * 512;
+        v = *reinterpret_cast<const u32x4*>(p.w + base + (size_t)r * 8);
+      }
+      wreg[i] = v;
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::LPT_BOX; ++i)
+      if (box_loff[i] >= 0) *reinterpret_cast<u32x4*>(box + box_loff[i]) = breg[i];
+#pragma unroll
+    for (int i = 0; i < C::LPT_W; ++i) {
+      const int c = tid + i * 256;
+      if (c < nwchunks) {
+        const int half = c & 1;
+        const int row = c >> 1;  // (nb*nt + t)*32 + co
+        const int co = row & 31;
+        *reinterpret_cast<u32x4*>(wl + row * 32 + ((half ^ ((co >> 4) & 1)) << 4)) = wreg[i];
+      }
+    }
+  };
+
+  issue_loads(0);
+  for (int kc = 0; kc < nkc; ++kc) {
+    __syncthreads();  // all waves finished reading the previous slice
+    write_lds();
+    __syncthreads();
+    if (kc + 1 < nkc) issue_loads(kc + 1);
+
+    for (int t = 0; t < nt; ++t) {
+      const nnz_conv_tap tp = p.d.taps[tb + t];
+      const int o0 = tp.off[0] - lo0, o1 = tp.off[1] - lo1, o2 = tp.off[2] - lo2;
+      const int toff = ((o0 * C::BH + o1) * C::PW + o2) * 32;
+      const int par = o1 & 1;
+      f16x8 a[C::WN], b[C::WM];
+#pragma unroll
+      for (int i = 0; i < C::WN; ++i)
+        a[i] = *reinterpret_cast<const f16x8*>(wl + (((wn * C::WN + i) * nt + t) << 10) + w_lane);
+#pragma unroll
+      for (int i = 0; i < C::WM; ++i)
+        b[i] = *reinterpret_cast<const f16x8*>(box + (par ? vox_off[1][i] : vox_off[0][i]) + toff);
+#pragma unroll
+      for (int i = 0; i < C::WN; ++i)
+#pragma unroll
+        for (int j = 0; j < C::WM; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: D[row = cout][col = voxel]; lane holds couts (r&3) + 8(r>>2) + 4hh of its voxel -----
+#pragma unroll
+  for (int i = 0; i < C::WN; ++i) {
+    const int co_base = (cb0 + wn * C::WN + i) * 32 + 4 * hh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = co_base + 8 * q;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+      for (int j = 0; j < C::WM; ++j) {
+        if (out_vox[j] < 0) continue;
+        f16* dst = p.out + (size_t)out_vox[j] + co;
+        float v0 = acc[i][j][4 * q + 0] + bv[0], v1 = acc[i][j][4 * q + 1] + bv[1];
+        float v2 = acc[i][j][4 * q + 2] + bv[2], v3 = acc[i][j][4 * q + 3] + bv[3];
+        if (p.d.accumulate) {
+          const f16x4 old = *reinterpret_cast<const f16x4*>(dst);
+          v0 += (float)old[0];
+          v1 += (float)old[1];
+          v2 += (float)old[2];
+          v3 += (float)old[3];
+        }
+        f16x4 o = {(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+        *reinterpret_cast<f16x4*>(dst) = o;
+      }
+    }
+  }
+}
+
+template <int TD, int TH, int TW, int NB, int IS, int EXT>
+static int launch_cfg(const ConvDev& base, hipStream_t stream) {
+  using C = ConvCfg<TD, TH, TW, NB, IS, EXT>;
+  ConvDev p = base;
+  p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
+  p.tiles[1] = (p.d.m_dims[1] + TH - 1) / TH;
+  p.tiles[2] = (p.d.m_dims[2] + TW - 1) / TW;
+  p.gx = p.tiles[0] * p.tiles[1] * p.tiles[2];
+  p.gy = p.d.Cout / (32 * NB);
+  p.gz = p.d.N * p.d.ngroups;
+  auto kern = conv_box_kernel<TD, TH, TW, NB, IS, EXT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), C::LDS_BYTES, stream, p);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+template <int IS, int EXT>
+static int launch_tile(const ConvDev& p, hipStream_t stream) {
+  const long mvox = (long)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
+  const bool nb2 = (p.d.Cout % 64) == 0;
+  if constexpr (IS == 1) {
+    // big tile for the 32-channel full-resolution layers (more weight reuse per wave), otherwise 4x8x8
+    if (!nb2) {
+      if (mvox >= 64 * 64 * 64) return launch_cfg<8, 8, 8, 1, IS, EXT>(p, stream);
+      return launch_cfg<4, 8, 8, 1, IS, EXT>(p, stream);
+    }
+    return launch_cfg<4, 8, 8, 2, IS, EXT>(p, stream);
+  } else {
+    if (!nb2) return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);  // Cout=32 with IS=2: N-split needs NB>=2
+    return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);
+  }
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_packed, const float* bias,
+                                    const nnz_conv_desc* desc, void* stream) {
+  using namespace nnz;
+  if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
+  const nnz_conv_desc& d = *desc;
+  if (d.Cin % 32 || d.Cout % 32 || d.ngroups < 1 || d.ngroups > NNZ_MAX_GROUPS || d.ntaps_total > NNZ_MAX_TAPS ||
+      d.ldi % 8 || d.ldo % 4 || (d.in_stride != 1 && d.in_stride != 2) || d.ext < 0 || d.ext > 2)
+    return NNZ_EINVAL;
+  for (int g = 0; g < d.ngroups; ++g)
+    if (d.groups[g].ntaps > 27 || d.groups[g].ntaps < 1) return NNZ_EINVAL;
+  ConvDev p;
+  p.in = (const f16*)in;
+  p.out = (f16*)out;
+  p.w = (const f16*)w_packed;
+  p.bias = bias;
+  p.d = d;
+  hipStream_t s = (hipStream_t)stream;
+  if (d.in_stride == 1) {
+    if (d.ext == 0) return launch_tile<1, 0>(p, s);
+    if (d.ext == 1) return launch_tile<1, 1>(p, s);
+    return launch_tile<1, 2>(p, s);
+  } else {
+    if (d.Cout % 64) return NNZ_EINVAL;  // the IS=2 tiles split N over waves
+    if (d.ext <= 1) return launch_tile<2, 1>(p, s);
+    return launch_tile<2, 2>(p, s);
+  }
+}

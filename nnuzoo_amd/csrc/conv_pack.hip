@@ -1,0 +1,76 @@
+// Weight layout plumbing for the tap-table convolutions:
+//   nnz_pack_conv_weight   : torch fp32 parameter (any strides) -> Wp[R/16][C/32][T][32][16] fp16
+//   nnz_unpack_conv_wgrad  : dW[T][A][B] fp32 -> torch-layout fp32 gradient (any strides)
+// Parameters keep the reference's names and shapes (state_dict compatibility,
+// /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1291-1352); these kernels are the only place
+// that knows the packed layout.
+#include "common.hpp"
+
+namespace nnz {
+
+struct KselTable {
+  int ksel[32];
+};
+
+__global__ void pack_weight_kernel(const float* __restrict__ src, f16* __restrict__ dst, int R, int C, int T,
+                                   long sr, long sc, long sk, KselTable tab) {
+  // one thread per packed element
+  const long total = (long)R * C * T;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r16 = i & 15;
+    long q = i >> 4;
+    const int c32 = q & 31;
+    q >>= 5;
+    const int t = q % T;
+    q /= T;
+    const int cb = q % (C >> 5);
+    const int rb = q / (C >> 5);
+    const int r = rb * 16 + r16, c = cb * 32 + c32;
+    dst[i] = (f16)src[r * sr + c * sc + tab.ksel[t] * sk];
+  }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ grad, int A, int B, int T,
+                                    long sa, long sb, long sk, KselTable tab, int accumulate) {
+  const long total = (long)T * A * B;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = i % B;
+    const long q = i / B;
+    const int a = q % A;
+    const int t = q / A;
+    float* g = grad + a * sa + b * sb + tab.ksel[t] * sk;
+    *g = accumulate ? *g + dw[i] : dw[i];
+  }
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_pack_conv_weight(const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
+                                    const int* ksel, void* stream) {
+  using namespace nnz;
+  if (!src || !dst_f16 || !ksel || R % 16 || C % 32 || T < 1 || T > 32) return NNZ_EINVAL;
+  KselTable tab;
+  for (int i = 0; i < 32; ++i) tab.ksel[i] = i < T ? ksel[i] : 0;
+  const long total = (long)R * C * T;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (f16*)dst_f16, R, C, T,
+                     sr, sc, sk, tab);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_unpack_conv_wgrad(const float* dw, float* grad, int A, int B, int T, long sa, long sb, long sk,
+                                     const int* ksel, int accumulate, void* stream) {
+  using namespace nnz;
+  if (!dw || !grad || !ksel || T < 1 || T > 32) return NNZ_EINVAL;
+  KselTable tab;
+  for (int i = 0; i < 32; ++i) tab.ksel[i] = i < T ? ksel[i] : 0;
+  const long total = (long)A * B * T;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dw, grad, A, B, T, sa, sb,
+                     sk, tab, accumulate);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

@@ -1,0 +1,349 @@
+// The two HBM-bound ends of the PlainConvUNet that do not fit an MFMA tile (gfx950):
+//   * stem : Conv3d(1 -> 32, k3, p1) on the fp32 input patch, forward + weight gradient
+//            (first block of encoder stage 0; no data gradient is needed for the network input)
+//   * head : 1x1x1 segmentation convs (C -> K classes, K <= 8) writing NCDHW logits, forward,
+//            data gradient and weight/bias gradient (deep-supervision outputs,
+//            /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1010-1022 toggles them)
+// Arithmetic follows autocast: operands rounded to fp16, fp32 accumulate.
+#include "common.hpp"
+
+namespace nnz {
+
+// ------------------------------------------------------------------------------------------------ stem
+constexpr int ST_TD = 4, ST_TH = 8, ST_TW = 8;
+constexpr int ST_BD = ST_TD + 2, ST_BH = ST_TH + 2, ST_BW = ST_TW + 2;
+constexpr int ST_CO = 32;
+
+struct StemArgs {
+  const float* x;   // [N][D][H][W] fp32
+  const float* w;   // [32][27] fp32 (torch (32,1,3,3,3))
+  const float* b;   // [32]
+  f16* y;           // [N][V][ldy]
+  const f16* dy;    // [N][V][lddy]   (wgrad)
+  float* dw;        // [32][27] fp32  (wgrad, zeroed by launcher)
+  int N, D, H, W, ldy, lddy;
+  int tiles[3];
+};
+
+__device__ __forceinline__ void stem_load_tile(const StemArgs& a, int n, int m0d, int m0h, int m0w, float* xt) {
+  for (int i = threadIdx.x; i < ST_BD * ST_BH * ST_BW; i += 256) {
+    const int bw = i % ST_BW, bh = (i / ST_BW) % ST_BH, bd = i / (ST_BW * ST_BH);
+    const int id = m0d + bd - 1, ih = m0h + bh - 1, iw = m0w + bw - 1;
+    float v = 0.f;
+    if ((unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+      v = (float)(f16)a.x[(((long)n * a.D + id) * a.H + ih) * a.W + iw];  // autocast rounding of the input
+    xt[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
+  __shared__ float xt[ST_BD * ST_BH * ST_BW];
+  __shared__ __attribute__((aligned(16))) float wt[27 * ST_CO];  // [t][co]
+  const int tid = threadIdx.x;
+  int bx = blockIdx.x;
+  const int tw_i = bx % a.tiles[2];
+  bx /= a.tiles[2];
+  const int th_i = bx % a.tiles[1];
+  const int td_i = bx / a.tiles[1];
+  const int n = blockIdx.y;
+  const int m0d = td_i * ST_TD, m0h = th_i * ST_TH, m0w = tw_i * ST_TW;
+  for (int i = tid; i < 27 * ST_CO; i += 256) {
+    const int t = i / ST_CO, co = i % ST_CO;
+    wt[i] = (float)(f16)a.w[co * 27 + t];
+  }
+  stem_load_tile(a, n, m0d, m0h, m0w, xt);
+  __syncthreads();
+  const int tw = tid % ST_TW, th = (tid / ST_TW) % ST_TH, td = tid / (ST_TW * ST_TH);
+  float acc[ST_CO];
+#pragma unroll
+  for (int c = 0; c < ST_CO; ++c) acc[c] = a.b ? a.b[c] : 0.f;
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float xv = xt[((td + kd) * ST_BH + th + kh) * ST_BW + tw + kw];
+        const float* wr = wt + (kd * 9 + kh * 3 + kw) * ST_CO;
+#pragma unroll
+        for (int c4 = 0; c4 < ST_CO; c4 += 4) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c4);
+          acc[c4 + 0] += xv * w4[0];
+          acc[c4 + 1] += xv * w4[1];
+          acc[c4 + 2] += xv * w4[2];
+          acc[c4 + 3] += xv * w4[3];
+        }
+      }
+  const int od = m0d + td, oh = m0h + th, ow = m0w + tw;
+  if (od < a.D && oh < a.H && ow < a.W) {
+    f16* dst = a.y + ((((long)n * a.D + od) * a.H + oh) * a.W + ow) * a.ldy;
+#pragma unroll
+    for (int c8 = 0; c8 < ST_CO; c8 += 8) {
+      f16x8 h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = (f16)acc[c8 + i];
+      *reinterpret_cast<f16x8*>(dst + c8) = h;
+    }
+  }
+}
+
+// dW[co][t] = sum_v dy[v][co] * x[v + off_t].  thread = (co, tap group of 4); persistent over tiles.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles) {
+  __shared__ float xt[ST_BD * ST_BH * ST_BW];
+  __shared__ __attribute__((aligned(16))) f16 dyt[ST_TD * ST_TH * ST_TW * ST_CO];
+  const int tid = threadIdx.x;
+  const int co = tid & 31;
+  const int tg = tid >> 5;  // 0..7 -> taps tg, tg+8, tg+16, tg+24
+  int toff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int t = tg + 8 * i;
+    if (t > 26) t = 26;
+    toff[i] = ((t / 9) * ST_BH + (t / 3) % 3) * ST_BW + t % 3;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tiles_per_n = a.tiles[0] * a.tiles[1] * a.tiles[2];
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tiles_per_n;
+    int r = tile % tiles_per_n;
+    const int tw_i = r % a.tiles[2];
+    r /= a.tiles[2];
+    const int th_i = r % a.tiles[1];
+    const int td_i = r / a.tiles[1];
+    const int m0d = td_i * ST_TD, m0h = th_i * ST_TH, m0w = tw_i * ST_TW;
+    __syncthreads();
+    stem_load_tile(a, n, m0d, m0h, m0w, xt);
+    for (int i = tid; i < ST_TD * ST_TH * ST_TW * 4; i += 256) {
+      const int part = i & 3, v = i >> 2;
+      const int tw = v % ST_TW, th = (v / ST_TW) % ST_TH, td = v / (ST_TW * ST_TH);
+      const int od = m0d + td, oh = m0h + th, ow = m0w + tw;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (od < a.D && oh < a.H && ow < a.W)
+        val = *reinterpret_cast<const u32x4*>(a.dy + ((((long)n * a.D + od) * a.H + oh) * a.W + ow) * a.lddy + part * 8);
+      *reinterpret_cast<u32x4*>(dyt + v * ST_CO + part * 8) = val;
+    }
+    __syncthreads();
+    for (int v = 0; v < ST_TD * ST_TH * ST_TW; ++v) {
+      const float g = (float)dyt[v * ST_CO + co];
+      const int tw = v % ST_TW, th = (v / ST_TW) % ST_TH, td = v / (ST_TW * ST_TH);
+      const float* xb = xt + (td * ST_BH + th) * ST_BW + tw;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += g * xb[toff[i]];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = tg + 8 * i;
+    if (t < 27) atomicAdd(a.dw + co * 27 + t, acc[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ head
+constexpr int HD_MAXK = 8;
+
+struct HeadArgs {
+  const f16* x;      // [N][V][ldx], C channels
+  const float* w;    // [K][C] fp32
+  const float* b;    // [K]
+  f16* logits;       // [N][K][V] (NCDHW)
+  const f16* dl;     // [N][K][V] gradient of logits
+  f16* dx;           // [N][V][lddx]
+  float* dw;         // [K][C] (zeroed by launcher)
+  float* db;         // [K]
+  int N, C, K, ldx, lddx;
+  long V;
+};
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+  extern __shared__ float wsm[];  // [K][C]
+  for (int i = threadIdx.x; i < a.K * a.C; i += 256) wsm[i] = (float)(f16)a.w[i];
+  __syncthreads();
+  const long total = (long)a.N * a.V;
+  for (long row = blockIdx.x * 256L + threadIdx.x; row < total; row += (long)gridDim.x * 256) {
+    const long n = row / a.V, v = row % a.V;
+    float acc[HD_MAXK];
+#pragma unroll
+    for (int k = 0; k < HD_MAXK; ++k) acc[k] = (k < a.K && a.b) ? a.b[k] : 0.f;
+    const f16* xp = a.x + row * a.ldx;
+    for (int c8 = 0; c8 < a.C; c8 += 8) {
+      const f16x8 h = *reinterpret_cast<const f16x8*>(xp + c8);
+#pragma unroll
+      for (int k = 0; k < HD_MAXK; ++k)
+        if (k < a.K) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[k] += (float)h[i] * wsm[k * a.C + c8 + i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HD_MAXK; ++k)
+      if (k < a.K) a.logits[(n * a.K + k) * a.V + v] = (f16)acc[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void head_dgrad_kernel(HeadArgs a, int accumulate) {
+  extern __shared__ float wsm[];
+  for (int i = threadIdx.x; i < a.K * a.C; i += 256) wsm[i] = (float)(f16)a.w[i];
+  __syncthreads();
+  const long total = (long)a.N * a.V;
+  for (long row = blockIdx.x * 256L + threadIdx.x; row < total; row += (long)gridDim.x * 256) {
+    const long n = row / a.V, v = row % a.V;
+    float g[HD_MAXK];
+#pragma unroll
+    for (int k = 0; k < HD_MAXK; ++k) g[k] = k < a.K ? (float)a.dl[(n * a.K + k) * a.V + v] : 0.f;
+    f16* dp = a.dx + row * a.lddx;
+    for (int c8 = 0; c8 < a.C; c8 += 8) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < HD_MAXK; ++k)
+        if (k < a.K) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += g[k] * wsm[k * a.C + c8 + i];
+        }
+      f16x8 h;
+      if (accumulate) {
+        const f16x8 old = *reinterpret_cast<const f16x8*>(dp + c8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (f16)(o[i] + (float)old[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (f16)o[i];
+      }
+      *reinterpret_cast<f16x8*>(dp + c8) = h;
+    }
+  }
+}
+
+// dW[k][c] = sum_{n,v} dl[n][k][v] * x[n][v][c];  db[k] = sum dl.   thread = (row r, channel group cg)
+__global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
+  extern __shared__ float lred[];  // [K][C] + [K]
+  const int CG = a.C >> 3;
+  const int rows = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, r = tid / CG;
+  const int n = blockIdx.y;
+  for (int i = tid; i < a.K * a.C + a.K; i += 256) lred[i] = 0.f;
+  __syncthreads();
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
+  if (v1 > a.V) v1 = a.V;
+  float acc[HD_MAXK][8];
+  float accb[HD_MAXK];
+#pragma unroll
+  for (int k = 0; k < HD_MAXK; ++k) {
+    accb[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[k][i] = 0.f;
+  }
+  if (r < rows) {
+    for (long v = v0 + r; v < v1; v += rows) {
+      const f16x8 h = *reinterpret_cast<const f16x8*>(a.x + ((long)n * a.V + v) * a.ldx + cg * 8);
+#pragma unroll
+      for (int k = 0; k < HD_MAXK; ++k)
+        if (k < a.K) {
+          const float g = (float)a.dl[((long)n * a.K + k) * a.V + v];
+          accb[k] += g;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[k][i] += g * (float)h[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HD_MAXK; ++k)
+      if (k < a.K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&lred[k * a.C + cg * 8 + i], acc[k][i]);
+        if (cg == 0) atomicAdd(&lred[a.K * a.C + k], accb[k]);
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < a.K * a.C; i += 256) atomicAdd(a.dw + i, lred[i]);
+  for (int i = tid; i < a.K; i += 256) atomicAdd(a.db + i, lred[a.K * a.C + i]);
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_stem_conv_forward(const float* x, const float* w, const float* bias, void* y, int N, int D, int H,
+                                     int W, int Cout, int ldy, void* stream) {
+  using namespace nnz;
+  if (!x || !w || !y || Cout != ST_CO || ldy % 8) return NNZ_EINVAL;
+  StemArgs a = {};
+  a.x = x; a.w = w; a.b = bias; a.y = (f16*)y;
+  a.N = N; a.D = D; a.H = H; a.W = W; a.ldy = ldy;
+  a.tiles[0] = (D + ST_TD - 1) / ST_TD;
+  a.tiles[1] = (H + ST_TH - 1) / ST_TH;
+  a.tiles[2] = (W + ST_TW - 1) / ST_TW;
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(a.tiles[0] * a.tiles[1] * a.tiles[2], N), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_stem_conv_wgrad(const float* x, const void* dy, float* dw, int N, int D, int H, int W, int Cout,
+                                   int lddy, void* stream) {
+  using namespace nnz;
+  if (!x || !dy || !dw || Cout != ST_CO || lddy % 8) return NNZ_EINVAL;
+  StemArgs a = {};
+  a.x = x; a.dy = (const f16*)dy; a.dw = dw;
+  a.N = N; a.D = D; a.H = H; a.W = W; a.lddy = lddy;
+  a.tiles[0] = (D + ST_TD - 1) / ST_TD;
+  a.tiles[1] = (H + ST_TH - 1) / ST_TH;
+  a.tiles[2] = (W + ST_TW - 1) / ST_TW;
+  const int ntiles = N * a.tiles[0] * a.tiles[1] * a.tiles[2];
+  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * ST_CO * 27, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const int grid = ntiles < 2048 ? ntiles : 2048;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ntiles);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_seg_head_forward(const void* x, const float* w, const float* bias, void* logits, int N, long V,
+                                    int C, int K, int ldx, void* stream) {
+  using namespace nnz;
+  if (!x || !w || !logits || K < 1 || K > HD_MAXK || C % 8 || ldx % 8) return NNZ_EINVAL;
+  HeadArgs a = {};
+  a.x = (const f16*)x; a.w = w; a.b = bias; a.logits = (f16*)logits;
+  a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;
+  long blocks = (N * V + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_seg_head_dgrad(const void* dlogits, const float* w, void* dx, int N, long V, int C, int K, int lddx,
+                                  int accumulate, void* stream) {
+  using namespace nnz;
+  if (!dlogits || !w || !dx || K < 1 || K > HD_MAXK || C % 8 || lddx % 8) return NNZ_EINVAL;
+  HeadArgs a = {};
+  a.dl = (const f16*)dlogits; a.w = w; a.dx = (f16*)dx;
+  a.N = N; a.V = V; a.C = C; a.K = K; a.lddx = lddx;
+  long blocks = (N * V + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(head_dgrad_kernel, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a,
+                     accumulate);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw, float* db, int N, long V, int C, int K,
+                                  int ldx, void* stream) {
+  using namespace nnz;
+  if (!x || !dlogits || !dw || !db || K < 1 || K > HD_MAXK || C % 8 || C > 640 || ldx % 8) return NNZ_EINVAL;
+  HeadArgs a = {};
+  a.x = (const f16*)x; a.dl = (const f16*)dlogits; a.dw = dw; a.db = db;
+  a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * K * C, s);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(db, 0, sizeof(float) * K, s);
+  if (e != hipSuccess) return (int)e;
+  long vpb = (V * N + 1023) / 1024;
+  if (vpb < 256) vpb = 256;
+  if (vpb > V) vpb = V;
+  const int gx = (int)((V + vpb - 1) / vpb);
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(gx, N), dim3(256), sizeof(float) * (K * C + K), s, a, (int)vpb);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

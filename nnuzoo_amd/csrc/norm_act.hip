@@ -1,0 +1,213 @@
+// InstanceNorm(affine) + LeakyReLU on channels-last fp16 activations, forward and backward (gfx950).
+// Replaces nn.InstanceNorm3d/2d + nn.LeakyReLU(0.01, inplace) of every PlainConvUNet conv block (arch kwargs at
+// /root/reference/nnunetv2/experiment_planning/experiment_planners/default_experiment_planner.py:285-305:
+// norm_op_kwargs {'eps': 1e-5, 'affine': True}, nonlin LeakyReLU).
+//
+// HBM-bound: every kernel moves 16 bytes per lane (8 fp16 channels of one voxel) and keeps the per-(n, c)
+// statistics in fp32.  Statistics are biased (population) variance like torch's instance_norm.
+//   stats   : x -> {sum, sumsq}[n][c]                                   (1 read)
+//   apply   : y = lrelu((x - mean) * rstd * gamma + beta)               (1 read, 1 write)
+//   bwd_red : {sum g', sum g' * xhat}[n][c], g' = g * lrelu'(y)         (2 reads)
+//   bwd_app : dx = gamma * rstd * (g' - mean(g') - xhat * mean(g' xhat)) (2 reads, 1 write)
+#include "common.hpp"
+
+namespace nnz {
+
+struct NormArgs {
+  const f16* x;      // raw conv output [N][V][ldx]
+  const f16* g;      // upstream gradient [N][V][ldg] (bwd only)
+  f16* y;            // output [N][V][ldy] (y for fwd, dx for bwd)
+  float* stats;      // [N][C][2] {sum, sumsq}
+  float* red;        // [N][C][2] {sum g', sum g' xhat} (bwd)
+  const float* gamma;
+  const float* beta;
+  int N, C, ldx, ldg, ldy;
+  long V;
+  int vpb;           // voxels per block
+  float eps, slope;
+};
+
+__device__ __forceinline__ void load8(const f16* p, float (&v)[8]) {
+  const f16x8 h = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+__device__ __forceinline__ void store8(f16* p, const float (&v)[8]) {
+  f16x8 h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (f16)v[i];
+  *reinterpret_cast<f16x8*>(p) = h;
+}
+
+// MODE 0: stats, 1: apply fwd, 2: bwd reduce, 3: bwd apply
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
+  __shared__ float lred[2 * 640];  // up to 640 channels
+  const int CG = a.C >> 3;
+  const int rows = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG;
+  const int r = tid / CG;
+  const int n = blockIdx.y;
+  const long v0 = (long)blockIdx.x * a.vpb;
+  long v1 = v0 + a.vpb;
+  if (v1 > a.V) v1 = a.V;
+  const bool active = r < rows;
+
+  if (MODE == 0 || MODE == 2) {
+    for (int i = tid; i < 2 * a.C; i += 256) lred[i] = 0.f;
+    __syncthreads();
+  }
+
+  float scale[8], shift[8], mean[8], rstd[8], m1[8], m2[8];
+  if (MODE != 0 && active) {
+    const float invV = 1.f / (float)a.V;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cg * 8 + i;
+      const float s = a.stats[((long)n * a.C + c) * 2 + 0];
+      const float ss = a.stats[((long)n * a.C + c) * 2 + 1];
+      const float mu = s * invV;
+      float var = ss * invV - mu * mu;
+      var = var < 0.f ? 0.f : var;
+      mean[i] = mu;
+      rstd[i] = rsqrtf(var + a.eps);
+      scale[i] = rstd[i] * a.gamma[c];
+      shift[i] = a.beta[c] - mu * scale[i];
+      if (MODE == 3) {
+        m1[i] = a.red[((long)n * a.C + c) * 2 + 0] * invV;
+        m2[i] = a.red[((long)n * a.C + c) * 2 + 1] * invV;
+      }
+    }
+  }
+
+  float acc0[8], acc1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc0[i] = acc1[i] = 0.f;
+
+  if (active) {
+    for (long v = v0 + r; v < v1; v += rows) {
+      const long row = (long)n * a.V + v;
+      float x[8];
+      load8(a.x + row * a.ldx + cg * 8, x);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc0[i] += x[i];
+          acc1[i] += x[i] * x[i];
+        }
+      } else if (MODE == 1) {
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = leaky(x[i] * scale[i] + shift[i], a.slope);
+        store8(a.y + row * a.ldy + cg * 8, y);
+      } else {
+        float g[8];
+        load8(a.g + row * a.ldg + cg * 8, g);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float pre = x[i] * scale[i] + shift[i];
+          const float gp = pre > 0.f ? g[i] : g[i] * a.slope;
+          const float xh = (x[i] - mean[i]) * rstd[i];
+          if (MODE == 2) {
+            acc0[i] += gp;
+            acc1[i] += gp * xh;
+          } else {
+            o[i] = scale[i] * (gp - m1[i] - xh * m2[i]);
+          }
+        }
+        if (MODE == 3) store8(a.y + row * a.ldy + cg * 8, o);
+      }
+    }
+  }
+
+  if (MODE == 0 || MODE == 2) {
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        atomicAdd(&lred[(cg * 8 + i) * 2 + 0], acc0[i]);
+        atomicAdd(&lred[(cg * 8 + i) * 2 + 1], acc1[i]);
+      }
+    }
+    __syncthreads();
+    float* dst = (MODE == 0 ? a.stats : a.red) + (long)n * a.C * 2;
+    for (int i = tid; i < 2 * a.C; i += 256) atomicAdd(dst + i, lred[i]);
+  }
+}
+
+template <int MODE>
+static int launch_norm(NormArgs a, hipStream_t s) {
+  if (a.C % 8 || a.C > 640 || a.C < 8) return NNZ_EINVAL;
+  // aim for >= 2048 blocks of >= 512 voxels
+  long vpb = (a.V * a.N + 2047) / 2048;
+  if (vpb < 512) vpb = 512;
+  if (vpb > a.V) vpb = a.V;
+  a.vpb = (int)vpb;
+  const int gx = (int)((a.V + vpb - 1) / vpb);
+  if (MODE == 0 || MODE == 2) {
+    hipError_t e = hipMemsetAsync(MODE == 0 ? a.stats : a.red, 0, sizeof(float) * 2 * a.N * a.C, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(norm_kernel<MODE>, dim3(gx, a.N), dim3(256), 0, s, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_instnorm_stats(const void* x, float* stats, int N, long V, int C, int ldx, void* stream) {
+  using namespace nnz;
+  if (!x || !stats) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x;
+  a.stats = stats;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx;
+  return launch_norm<0>(a, (hipStream_t)stream);
+}
+
+extern "C" int nnz_instnorm_lrelu_apply(const void* x, const float* stats, const float* gamma, const float* beta,
+                                        void* y, int N, long V, int C, int ldx, int ldy, float eps, float slope,
+                                        void* stream) {
+  using namespace nnz;
+  if (!x || !stats || !gamma || !beta || !y) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x;
+  a.stats = const_cast<float*>(stats);
+  a.gamma = gamma; a.beta = beta;
+  a.y = (f16*)y;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldy = ldy;
+  a.eps = eps; a.slope = slope;
+  return launch_norm<1>(a, (hipStream_t)stream);
+}
+
+extern "C" int nnz_instnorm_lrelu_bwd_reduce(const void* x, const void* g, const float* stats, const float* gamma,
+                                             const float* beta, float* red, int N, long V, int C, int ldx, int ldg,
+                                             float eps, float slope, void* stream) {
+  using namespace nnz;
+  if (!x || !g || !stats || !gamma || !beta || !red) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x; a.g = (const f16*)g;
+  a.stats = const_cast<float*>(stats);
+  a.red = red;
+  a.gamma = gamma; a.beta = beta;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldg = ldg;
+  a.eps = eps; a.slope = slope;
+  return launch_norm<2>(a, (hipStream_t)stream);
+}
+
+extern "C" int nnz_instnorm_lrelu_bwd_apply(const void* x, const void* g, const float* stats, const float* red,
+                                            const float* gamma, const float* beta, void* dx, int N, long V, int C,
+                                            int ldx, int ldg, int lddx, float eps, float slope, void* stream) {
+  using namespace nnz;
+  if (!x || !g || !stats || !red || !gamma || !beta || !dx) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x; a.g = (const f16*)g;
+  a.stats = const_cast<float*>(stats);
+  a.red = const_cast<float*>(red);
+  a.gamma = gamma; a.beta = beta;
+  a.y = (f16*)dx;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldg = ldg; a.ldy = lddx;
+  a.eps = eps; a.slope = slope;
+  return launch_norm<3>(a, (hipStream_t)stream);
+}

@@ -1,0 +1,115 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/nnuzoo_hip.h).  No arithmetic happens here: every
+function validates dtype/device, hands raw device pointers + the current HIP stream to libnnuzoo_hip.so and
+raises if the library reports an error.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+from .conv_plan import TapTable, ksel_array
+
+
+def _f16(t: torch.Tensor, name: str):
+    if t.dtype != torch.float16 or not t.is_cuda:
+        raise _lib.HipCallError(f"{name}: expected a float16 device tensor, got {t.dtype} on {t.device}")
+
+
+def _f32(t: Optional[torch.Tensor], name: str):
+    if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+        raise _lib.HipCallError(f"{name}: expected a float32 device tensor, got {t.dtype} on {t.device}")
+
+
+class PreparedTable:
+    """TapTable + its ctypes descriptor (built once, reused every step)."""
+
+    def __init__(self, table: TapTable):
+        self.table = table
+        self.desc = table.to_desc()
+        self.pack_ksel = ksel_array(table.pack_ksel)
+        self.ident_ksel = ksel_array(list(range(32)))
+
+    def with_accumulate(self, acc: bool) -> "PreparedTable":
+        import copy
+        t = copy.copy(self.table)
+        t.accumulate = acc
+        return PreparedTable(t)
+
+
+def pack_weight(param: torch.Tensor, pt: PreparedTable, R: int, Cc: int, sr: int, sc: int, sk: int,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 torch parameter -> packed fp16 [R/16][Cc/32][T][32][16] (R = reduction channels, Cc = output channels)."""
+    _f32(param, "pack_weight.param")
+    T = pt.table.ntaps
+    if out is None:
+        out = torch.empty(R * Cc * T, dtype=torch.float16, device=param.device)
+    call("nnz_pack_conv_weight", ptr(param), ptr(out), R, Cc, T, sr, sc, sk, pt.pack_ksel, stream_ptr())
+    return out
+
+
+def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                     out: torch.Tensor) -> None:
+    _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
+    call("nnz_conv_tap_forward", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc), stream_ptr())
+
+
+def conv_tap_wgrad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, dw: torch.Tensor) -> None:
+    _f16(boxed, "wgrad.boxed"); _f16(plain, "wgrad.plain"); _f32(dw, "wgrad.dw")
+    call("nnz_conv_tap_wgrad", ptr(boxed), ptr(plain), ptr(dw), C.byref(pt.desc), stream_ptr())
+
+
+def unpack_wgrad(dw: torch.Tensor, grad: torch.Tensor, A: int, B: int, T: int, sa: int, sb: int, sk: int,
+                 pt: PreparedTable, accumulate: bool = False) -> None:
+    _f32(dw, "unpack.dw"); _f32(grad, "unpack.grad")
+    call("nnz_unpack_conv_wgrad", ptr(dw), ptr(grad), A, B, T, sa, sb, sk, pt.ident_ksel, int(accumulate),
+         stream_ptr())
+
+
+def stem_forward(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], y: torch.Tensor, dims, ldy: int):
+    _f32(x, "stem.x"); _f32(w, "stem.w"); _f32(b, "stem.b"); _f16(y, "stem.y")
+    N, D, H, W = dims
+    call("nnz_stem_conv_forward", ptr(x), ptr(w), ptr(b), ptr(y), N, D, H, W, w.shape[0], ldy, stream_ptr())
+
+
+def stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dims, lddy: int):
+    _f32(x, "stem.x"); _f16(dy, "stem.dy"); _f32(dw, "stem.dw")
+    N, D, H, W = dims
+    call("nnz_stem_conv_wgrad", ptr(x), ptr(dy), ptr(dw), N, D, H, W, dw.shape[0], lddy, stream_ptr())
+
+
+def head_forward(x, w, b, logits, N, V, Cc, K, ldx):
+    _f16(x, "head.x"); _f32(w, "head.w"); _f32(b, "head.b"); _f16(logits, "head.logits")
+    call("nnz_seg_head_forward", ptr(x), ptr(w), ptr(b), ptr(logits), N, V, Cc, K, ldx, stream_ptr())
+
+
+def head_dgrad(dlogits, w, dx, N, V, Cc, K, lddx, accumulate):
+    _f16(dlogits, "head.dlogits"); _f32(w, "head.w"); _f16(dx, "head.dx")
+    call("nnz_seg_head_dgrad", ptr(dlogits), ptr(w), ptr(dx), N, V, Cc, K, lddx, int(accumulate), stream_ptr())
+
+
+def head_wgrad(x, dlogits, dw, db, N, V, Cc, K, ldx):
+    _f16(x, "head.x"); _f16(dlogits, "head.dlogits"); _f32(dw, "head.dw"); _f32(db, "head.db")
+    call("nnz_seg_head_wgrad", ptr(x), ptr(dlogits), ptr(dw), ptr(db), N, V, Cc, K, ldx, stream_ptr())
+
+
+def instnorm_stats(x, stats, N, V, Cc, ldx):
+    _f16(x, "in.x"); _f32(stats, "in.stats")
+    call("nnz_instnorm_stats", ptr(x), ptr(stats), N, V, Cc, ldx, stream_ptr())
+
+
+def instnorm_lrelu_apply(x, stats, gamma, beta, y, N, V, Cc, ldx, ldy, eps, slope):
+    _f16(x, "in.x"); _f16(y, "in.y"); _f32(stats, "in.stats"); _f32(gamma, "in.gamma"); _f32(beta, "in.beta")
+    call("nnz_instnorm_lrelu_apply", ptr(x), ptr(stats), ptr(gamma), ptr(beta), ptr(y), N, V, Cc, ldx, ldy,
+         eps, slope, stream_ptr())
+
+
+def instnorm_lrelu_bwd(x, g, stats, gamma, beta, red, dx, N, V, Cc, ldx, ldg, lddx, eps, slope):
+    _f16(x, "in.x"); _f16(g, "in.g"); _f16(dx, "in.dx"); _f32(stats, "in.stats"); _f32(red, "in.red")
+    call("nnz_instnorm_lrelu_bwd_reduce", ptr(x), ptr(g), ptr(stats), ptr(gamma), ptr(beta), ptr(red), N, V, Cc,
+         ldx, ldg, eps, slope, stream_ptr())
+    call("nnz_instnorm_lrelu_bwd_apply", ptr(x), ptr(g), ptr(stats), ptr(red), ptr(gamma), ptr(beta), ptr(dx), N, V,
+         Cc, ldx, ldg, lddx, eps, slope, stream_ptr())

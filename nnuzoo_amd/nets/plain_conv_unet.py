@@ -1,0 +1,529 @@
+"""PlainConvUNet ("nnUNet") for MI355X: same constructor, attributes and state_dict layout as
+dynamic_network_architectures.architectures.unet.PlainConvUNet (0.3.x), which the reference instantiates by name
+in /root/reference/nnunetv2/utilities/get_network_from_plans.py:18-62 from the planner's arch kwargs
+(/root/reference/nnunetv2/experiment_planning/experiment_planners/default_experiment_planner.py:285-305).
+
+The torch sub-modules (nn.Conv3d, nn.InstanceNorm3d, ...) exist ONLY as parameter holders so that
+`network.apply(InitWeights_He)`, `state_dict()/load_state_dict()`, DDP wrapping and optimizers see the reference's
+names and shapes.  Compute never goes through them: `forward` runs a fixed schedule of hand-written HIP kernels
+(libnnuzoo_hip.so) on channels-last fp16 activations with fp32 accumulation - the numerics of the reference's
+autocast step (/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1128-1139) - inside ONE
+autograd.Function whose backward is an explicit reverse schedule.  CPU tensors raise: there is no fallback.
+
+Data layout in HBM (per resolution level s, C_s features):
+  raw_b   [N, V_s, C_s]  fp16  conv output before norm, one per conv block (saved for backward)
+  stats_b [N, C_s, 2]    fp32  per-instance sum / sum of squares
+  cat_s   [N, V_s, 2C_s] fp16  decoder input: [..., :C_s] = transposed-conv output, [..., C_s:] = encoder skip
+                               (the last encoder block of the level writes its activation straight into the
+                               second half: torch.cat is never materialised)
+  act_b   [N, V_s, C_s]  fp16  activated output of the other blocks
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple, Type, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import conv_plan as cp
+from .. import hip_ops as ops
+from ..hip_ops import PreparedTable
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parameter-holder modules (names mirror dynamic_network_architectures.building_blocks)
+# ------------------------------------------------------------------------------------------------------------------
+def _no_direct_call(self, *a, **k):
+    raise RuntimeError(f"{type(self).__name__} is a parameter holder of nnuzoo_amd.PlainConvUNet; call the network")
+
+
+class ConvDropoutNormReLU(nn.Module):
+    def __init__(self, conv_op, cin, cout, kernel_size, stride, conv_bias, norm_op, norm_op_kwargs, nonlin,
+                 nonlin_kwargs):
+        super().__init__()
+        self.input_channels, self.output_channels = cin, cout
+        ks = [kernel_size] * 3 if isinstance(kernel_size, int) else list(kernel_size)
+        st = [stride] * 3 if isinstance(stride, int) else list(stride)
+        self.stride = st
+        self.conv = conv_op(cin, cout, ks, st, padding=[(k - 1) // 2 for k in ks], dilation=1, bias=conv_bias)
+        mods = [self.conv]
+        self.norm = norm_op(cout, **(norm_op_kwargs or {}))
+        mods.append(self.norm)
+        self.nonlin = nonlin(**(nonlin_kwargs or {}))
+        mods.append(self.nonlin)
+        self.all_modules = nn.Sequential(*mods)
+
+    forward = _no_direct_call
+
+
+class StackedConvBlocks(nn.Module):
+    def __init__(self, num_convs, conv_op, cin, cout, kernel_size, initial_stride, conv_bias, norm_op,
+                 norm_op_kwargs, nonlin, nonlin_kwargs):
+        super().__init__()
+        if not isinstance(cout, (tuple, list)):
+            cout = [cout] * num_convs
+        blocks = [ConvDropoutNormReLU(conv_op, cin, cout[0], kernel_size, initial_stride, conv_bias, norm_op,
+                                      norm_op_kwargs, nonlin, nonlin_kwargs)]
+        for i in range(1, num_convs):
+            blocks.append(ConvDropoutNormReLU(conv_op, cout[i - 1], cout[i], kernel_size, 1, conv_bias, norm_op,
+                                              norm_op_kwargs, nonlin, nonlin_kwargs))
+        self.convs = nn.Sequential(*blocks)
+        self.output_channels = cout[-1]
+
+    forward = _no_direct_call
+
+
+class PlainConvEncoder(nn.Module):
+    def __init__(self, input_channels, n_stages, features_per_stage, conv_op, kernel_sizes, strides, n_conv_per_stage,
+                 conv_bias, norm_op, norm_op_kwargs, nonlin, nonlin_kwargs):
+        super().__init__()
+        stages = []
+        cin = input_channels
+        for s in range(n_stages):
+            stages.append(nn.Sequential(StackedConvBlocks(n_conv_per_stage[s], conv_op, cin, features_per_stage[s],
+                                                          kernel_sizes[s], strides[s], conv_bias, norm_op,
+                                                          norm_op_kwargs, nonlin, nonlin_kwargs)))
+            cin = features_per_stage[s]
+        self.stages = nn.Sequential(*stages)
+        self.output_channels = list(features_per_stage)
+        self.strides = [[s] * 3 if isinstance(s, int) else list(s) for s in strides]
+        self.return_skips = True
+        self.conv_op, self.norm_op, self.norm_op_kwargs = conv_op, norm_op, norm_op_kwargs
+        self.nonlin, self.nonlin_kwargs, self.conv_bias = nonlin, nonlin_kwargs, conv_bias
+        self.kernel_sizes = kernel_sizes
+
+    forward = _no_direct_call
+
+
+class UNetDecoder(nn.Module):
+    def __init__(self, encoder: PlainConvEncoder, num_classes, n_conv_per_stage, deep_supervision):
+        super().__init__()
+        self.deep_supervision = deep_supervision
+        self.encoder = encoder
+        self.num_classes = num_classes
+        n_enc = len(encoder.output_channels)
+        if isinstance(n_conv_per_stage, int):
+            n_conv_per_stage = [n_conv_per_stage] * (n_enc - 1)
+        assert len(n_conv_per_stage) == n_enc - 1
+        transp_op = {nn.Conv3d: nn.ConvTranspose3d, nn.Conv2d: nn.ConvTranspose2d}[encoder.conv_op]
+        stages, transpconvs, seg_layers = [], [], []
+        for s in range(1, n_enc):
+            below, skip = encoder.output_channels[-s], encoder.output_channels[-(s + 1)]
+            st = encoder.strides[-s]
+            transpconvs.append(transp_op(below, skip, st, st, bias=encoder.conv_bias))
+            stages.append(StackedConvBlocks(n_conv_per_stage[s - 1], encoder.conv_op, 2 * skip, skip,
+                                            encoder.kernel_sizes[-(s + 1)], 1, encoder.conv_bias, encoder.norm_op,
+                                            encoder.norm_op_kwargs, encoder.nonlin, encoder.nonlin_kwargs))
+            seg_layers.append(encoder.conv_op(skip, num_classes, 1, 1, 0, bias=True))
+        self.stages = nn.ModuleList(stages)
+        self.transpconvs = nn.ModuleList(transpconvs)
+        self.seg_layers = nn.ModuleList(seg_layers)
+
+    forward = _no_direct_call
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# execution plan
+# ------------------------------------------------------------------------------------------------------------------
+class _Block:
+    """One conv -> InstanceNorm -> LeakyReLU block of the schedule."""
+
+    def __init__(self, holder: ConvDropoutNormReLU, N, in_dims, stem: bool):
+        self.h = holder
+        self.stem = stem
+        self.cin, self.cout = holder.input_channels, holder.output_channels
+        self.stride = holder.stride[0]
+        self.in_dims = tuple(in_dims)
+        self.out_dims = cp.conv_out_dims(in_dims, (3, 3, 3), self.stride)
+        self.N = N
+        self.V = int(np.prod(self.out_dims))
+        self.eps = float(holder.norm.eps)
+        self.slope = float(getattr(holder.nonlin, "negative_slope", 0.01))
+        # filled by the planner
+        self.x_ld = self.cin      # channel stride of the input activation
+        self.y_ld = self.cout     # channel stride of the output activation (2C when written into a cat buffer)
+        self.fwd = self.dgrad = self.wgrad = None
+
+    def prepare(self):
+        if not self.stem:
+            self.fwd = PreparedTable(cp.conv_forward(self.N, self.in_dims, self.cin, self.cout, stride=self.stride,
+                                                     ldi=self.x_ld, ldo=self.cout))
+            self.wgrad = PreparedTable(cp.conv_wgrad(self.N, self.in_dims, self.cin, self.cout, stride=self.stride,
+                                                     ldx=self.x_ld, lddy=self.cout))
+            # dgrad: in = d(raw) [ld cout] -> out = d(input activation) [ld x_ld]
+            self.dgrad = PreparedTable(cp.conv_dgrad(self.N, self.in_dims, self.cin, self.cout, stride=self.stride,
+                                                     ldi=self.cout, ldo=self.x_ld))
+            self.dgrad_acc = self.dgrad.with_accumulate(True)
+
+
+class _Up:
+    def __init__(self, tconv: nn.Module, N, in_dims, cin, cout, ldo):
+        self.m = tconv
+        self.N, self.in_dims, self.cin, self.cout = N, tuple(in_dims), cin, cout
+        self.out_dims = tuple(2 * d for d in in_dims)
+        self.fwd = PreparedTable(cp.convT_forward(N, in_dims, cin, cout, ldi=cin, ldo=ldo))
+        self.dgrad = PreparedTable(cp.convT_dgrad(N, in_dims, cin, cout, ldi=ldo, ldo=cin))
+        self.wgrad = PreparedTable(cp.convT_wgrad(N, in_dims, cin, cout, lddout=ldo, ldin=cin))
+        self.ldo = ldo
+
+
+class _Plan:
+    def __init__(self, net: "PlainConvUNet", N: int, dims: Tuple[int, int, int]):
+        enc, dec = net.encoder, net.decoder
+        self.N, self.dims = N, tuple(dims)
+        S = len(enc.stages)
+        self.S = S
+        feats = enc.output_channels
+        # ---- encoder blocks
+        self.enc_blocks: List[List[_Block]] = []
+        d = tuple(dims)
+        self.level_dims = []
+        for s in range(S):
+            blocks = []
+            for i, h in enumerate(enc.stages[s][0].convs):
+                b = _Block(h, N, d, stem=(s == 0 and i == 0))
+                d = b.out_dims
+                blocks.append(b)
+            self.level_dims.append(d)
+            self.enc_blocks.append(blocks)
+        # skip of level s (< S-1) lives in cat_s[..., C:2C]
+        for s in range(S - 1):
+            self.enc_blocks[s][-1].y_ld = 2 * feats[s]
+        # ---- decoder (index j = 0 is the deepest decoder stage, like decoder.stages)
+        self.ups: List[_Up] = []
+        self.dec_blocks: List[List[_Block]] = []
+        for j in range(S - 1):
+            lvl = S - 2 - j
+            below, skip = feats[lvl + 1], feats[lvl]
+            self.ups.append(_Up(dec.transpconvs[j], N, self.level_dims[lvl + 1], below, skip, ldo=2 * skip))
+            blocks = []
+            for i, h in enumerate(dec.stages[j].convs):
+                b = _Block(h, N, self.level_dims[lvl], stem=False)
+                if i == 0:
+                    b.x_ld = 2 * skip
+                blocks.append(b)
+            self.dec_blocks.append(blocks)
+        # input strides of encoder blocks that read a skip stored inside a cat buffer
+        for s in range(1, S):
+            self.enc_blocks[s][0].x_ld = 2 * feats[s - 1] if s - 1 < S - 1 else feats[s - 1]
+        for s in range(S):
+            for i, b in enumerate(self.enc_blocks[s]):
+                if i > 0:
+                    b.x_ld = self.enc_blocks[s][i - 1].y_ld
+        for blocks in self.enc_blocks + self.dec_blocks:
+            for b in blocks:
+                b.prepare()
+
+
+def _check_supported(net: "PlainConvUNet"):
+    enc = net.encoder
+    if enc.conv_op is not nn.Conv3d:
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: the HIP schedule covers conv_op=torch.nn.Conv3d")
+    if not issubclass(enc.norm_op, nn.InstanceNorm3d) or not (enc.norm_op_kwargs or {}).get("affine", False):
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: norm_op must be InstanceNorm3d(affine=True)")
+    if enc.nonlin is not nn.LeakyReLU:
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: nonlin must be torch.nn.LeakyReLU")
+    for s, ks in enumerate(enc.kernel_sizes):
+        ks = [ks] * 3 if isinstance(ks, int) else list(ks)
+        st = enc.strides[s]
+        if ks != [3, 3, 3] or st[0] != st[1] or st[1] != st[2] or st[0] not in (1, 2):
+            raise NotImplementedError("nnuzoo_amd.PlainConvUNet: kernel 3x3x3 and isotropic stride 1/2 only")
+    feats = enc.output_channels
+    if net.input_channels != 1 or feats[0] != 32 or any(f % 32 for f in feats):
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: input_channels=1, features multiple of 32, first = 32")
+    if not enc.conv_bias:
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: conv_bias=True expected (planner default)")
+
+
+class _UNetFunction(torch.autograd.Function):
+    """Whole-network forward/backward as one autograd node (explicit schedule, no per-op autograd graph)."""
+
+    @staticmethod
+    def forward(ctx, net: "PlainConvUNet", save: bool, x: torch.Tensor, *params: torch.Tensor):
+        outs, saved = net._run_forward(x, save=save)
+        ctx.net = net
+        ctx.saved = saved
+        ctx.set_materialize_grads(False)  # unused deep-supervision outputs arrive as None, not as zero tensors
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        net = ctx.net
+        grads = net._run_backward(ctx.saved, gouts)
+        ctx.saved = None
+        return (None, None, None, *grads)
+
+
+class PlainConvUNet(nn.Module):
+    def __init__(self,
+                 input_channels: int,
+                 n_stages: int,
+                 features_per_stage: Union[int, Sequence[int]],
+                 conv_op: Type[nn.Module],
+                 kernel_sizes,
+                 strides,
+                 n_conv_per_stage: Union[int, Sequence[int]],
+                 num_classes: int,
+                 n_conv_per_stage_decoder: Union[int, Sequence[int]],
+                 conv_bias: bool = False,
+                 norm_op=None,
+                 norm_op_kwargs: dict = None,
+                 dropout_op=None,
+                 dropout_op_kwargs: dict = None,
+                 nonlin=None,
+                 nonlin_kwargs: dict = None,
+                 deep_supervision: bool = False,
+                 nonlin_first: bool = False):
+        super().__init__()
+        if isinstance(n_conv_per_stage, int):
+            n_conv_per_stage = [n_conv_per_stage] * n_stages
+        if isinstance(n_conv_per_stage_decoder, int):
+            n_conv_per_stage_decoder = [n_conv_per_stage_decoder] * (n_stages - 1)
+        if isinstance(features_per_stage, int):
+            features_per_stage = [features_per_stage] * n_stages
+        if isinstance(kernel_sizes, int):
+            kernel_sizes = [kernel_sizes] * n_stages
+        if isinstance(strides, int):
+            strides = [strides] * n_stages
+        if dropout_op is not None:
+            raise NotImplementedError("nnuzoo_amd.PlainConvUNet: dropout_op must be None (planner default)")
+        if nonlin_first:
+            raise NotImplementedError("nnuzoo_amd.PlainConvUNet: nonlin_first=False only")
+        self.input_channels = input_channels
+        self.num_classes = num_classes
+        self.encoder = PlainConvEncoder(input_channels, n_stages, list(features_per_stage), conv_op, list(kernel_sizes),
+                                        list(strides), list(n_conv_per_stage), conv_bias, norm_op, norm_op_kwargs,
+                                        nonlin, nonlin_kwargs)
+        self.decoder = UNetDecoder(self.encoder, num_classes, list(n_conv_per_stage_decoder), deep_supervision)
+        _check_supported(self)
+        self._plans = {}
+        self._param_list: Optional[List[nn.Parameter]] = None
+        self.grad_reducer = None  # set by nnuzoo_amd.ddp.attach_bucketed_allreduce
+
+    # reference API: `network.apply(network.initialize)` (get_network_from_plans.py:59-60)
+    @staticmethod
+    def initialize(module):
+        from ..utilities.network_initialization import InitWeights_He
+        InitWeights_He(1e-2)(module)
+
+    # ---- plumbing ------------------------------------------------------------------------------------------------
+    def _params(self) -> List[nn.Parameter]:
+        if self._param_list is None:
+            self._param_list = list(self.parameters())
+        return self._param_list
+
+    def _plan(self, N, dims) -> _Plan:
+        key = (N, tuple(dims))
+        if key not in self._plans:
+            self._plans[key] = _Plan(self, N, dims)
+        return self._plans[key]
+
+    def forward(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError("nnuzoo_amd.PlainConvUNet runs on MI355X through libnnuzoo_hip.so only; got a CPU "
+                               "tensor and there is deliberately no CPU fallback (see oracle/ for the test-only "
+                               "CPU restatement)")
+        if x.dim() != 5 or x.shape[1] != 1:
+            raise ValueError(f"expected (B, 1, D, H, W) input, got {tuple(x.shape)}")
+        x = x.float().contiguous()
+        params = self._params()
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs = _UNetFunction.apply(self, save, x, *params)
+        if self.decoder.deep_supervision:
+            return list(outs)
+        return outs[0]
+
+    # ---- forward schedule ----------------------------------------------------------------------------------------
+    def _conv_block_fwd(self, b: _Block, x_act: torch.Tensor, act_out: torch.Tensor, dev):
+        h = b.h
+        raw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
+        stats = torch.empty((b.N, b.cout, 2), dtype=torch.float32, device=dev)
+        if b.stem:
+            ops.stem_forward(x_act, h.conv.weight, h.conv.bias, raw, (b.N, *b.in_dims), b.cout)
+        else:
+            wp = ops.pack_weight(h.conv.weight, b.fwd, b.cin, b.cout, 27, b.cin * 27, 1)
+            ops.conv_tap_forward(b.fwd, x_act, wp, h.conv.bias, raw)
+        ops.instnorm_stats(raw, stats, b.N, b.V, b.cout, b.cout)
+        ops.instnorm_lrelu_apply(raw, stats, h.norm.weight, h.norm.bias, act_out, b.N, b.V, b.cout, b.cout, b.y_ld,
+                                 b.eps, b.slope)
+        return raw, stats
+
+    def _run_forward(self, x: torch.Tensor, save: bool):
+        N = x.shape[0]
+        dims = tuple(x.shape[2:])
+        plan = self._plan(N, dims)
+        dev = x.device
+        S = plan.S
+        feats = self.encoder.output_channels
+        K = self.num_classes
+        f16 = torch.float16
+        cats = [torch.empty((N, int(np.prod(plan.level_dims[s])), 2 * feats[s]), dtype=f16, device=dev)
+                for s in range(S - 1)]
+        rec = {"x": x, "plan": plan, "cats": cats, "enc": [], "dec": [], "heads": []}
+        cur = x
+        for s in range(S):
+            stage_rec = []
+            for i, b in enumerate(plan.enc_blocks[s]):
+                last = i == len(plan.enc_blocks[s]) - 1
+                if last and s < S - 1:
+                    act = cats[s][:, :, feats[s]:]
+                else:
+                    act = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
+                raw, stats = self._conv_block_fwd(b, cur, act, dev)
+                stage_rec.append((cur, raw, stats, act))
+                cur = act
+            rec["enc"].append(stage_rec)
+        outs = [None] * (S - 1)
+        lres = cur
+        for j in range(S - 1):
+            lvl = S - 2 - j
+            up = plan.ups[j]
+            wp = ops.pack_weight(up.m.weight, up.fwd, up.cin, up.cout, up.cout * 8, 8, 1)
+            ops.conv_tap_forward(up.fwd, lres, wp, up.m.bias, cats[lvl])
+            cur = cats[lvl]
+            stage_rec = []
+            for b in plan.dec_blocks[j]:
+                act = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
+                raw, stats = self._conv_block_fwd(b, cur, act, dev)
+                stage_rec.append((cur, raw, stats, act))
+                cur = act
+            rec["dec"].append((lres, stage_rec))
+            if self.decoder.deep_supervision or j == S - 2:
+                seg = self.decoder.seg_layers[j]
+                V = int(np.prod(plan.level_dims[lvl]))
+                logits = torch.empty((N, K, *plan.level_dims[lvl]), dtype=f16, device=dev)
+                ops.head_forward(cur, seg.weight, seg.bias, logits, N, V, feats[lvl], K, feats[lvl])
+                outs[lvl] = logits
+            lres = cur
+        out_list = [o for o in outs if o is not None]  # highest resolution first
+        rec["out_levels"] = [lvl for lvl, o in enumerate(outs) if o is not None]
+        return out_list, (rec if save else None)
+
+    # ---- backward schedule ---------------------------------------------------------------------------------------
+    def _conv_block_bwd(self, b: _Block, recd, g_act: torch.Tensor, g_ld: int, grads: dict, dx_out, dx_acc: bool, dev):
+        """g_act: gradient wrt the block's activated output (channel stride g_ld).  Writes the gradient wrt the
+        block input into dx_out (None for the stem) and the parameter gradients into `grads`."""
+        x_in, raw, stats, _ = recd
+        h = b.h
+        red = torch.empty((b.N, b.cout, 2), dtype=torch.float32, device=dev)
+        draw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
+        ops.instnorm_lrelu_bwd(raw, g_act, stats, h.norm.weight, h.norm.bias, red, draw, b.N, b.V, b.cout, b.cout, g_ld,
+                               b.cout, b.eps, b.slope)
+        rs = red.sum(0)
+        grads[h.norm.weight] = rs[:, 1].contiguous()
+        grads[h.norm.bias] = rs[:, 0].contiguous()
+        # the bias of a conv followed by InstanceNorm has an identically zero gradient (mean removal)
+        grads[h.conv.bias] = torch.zeros_like(h.conv.bias)
+        gw = torch.empty_like(h.conv.weight)
+        if b.stem:
+            ops.stem_wgrad(x_in, draw, gw, (b.N, *b.in_dims), b.cout)
+        else:
+            dw = torch.empty((27, b.cin, b.cout), dtype=torch.float32, device=dev)
+            ops.conv_tap_wgrad(b.wgrad, x_in, draw, dw)
+            ops.unpack_wgrad(dw, gw, b.cin, b.cout, 27, 27, b.cin * 27, 1, b.wgrad)
+            wp = ops.pack_weight(h.conv.weight, b.dgrad, b.cout, b.cin, b.cin * 27, 27, 1)
+            ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, wp, None, dx_out)
+        grads[h.conv.weight] = gw
+
+    def _run_backward(self, rec, gouts):
+        plan: _Plan = rec["plan"]
+        N, S = plan.N, plan.S
+        feats = self.encoder.output_channels
+        K = self.num_classes
+        dev = rec["x"].device
+        f16 = torch.float16
+        grads = {}
+        gout_by_level = {lvl: g for lvl, g in zip(rec["out_levels"], gouts)}
+        g_cur = None  # gradient wrt the current decoder stage output (act), contiguous [N, V, C]
+        g_cats = [None] * (S - 1)
+        for j in range(S - 2, -1, -1):
+            lvl = S - 2 - j
+            C_ = feats[lvl]
+            V = int(np.prod(plan.level_dims[lvl]))
+            lres, stage_rec = rec["dec"][j]
+            out_act = stage_rec[-1][3]
+            seg = self.decoder.seg_layers[j]
+            g = gout_by_level.get(lvl)
+            if g_cur is None:
+                g_cur = torch.empty((N, V, C_), dtype=f16, device=dev)
+                have = False
+            else:
+                have = True
+            if g is not None:
+                g = g.contiguous()
+                if g.dtype != f16:
+                    g = g.to(f16)
+                gw = torch.empty_like(seg.weight)
+                gb = torch.empty_like(seg.bias)
+                ops.head_wgrad(out_act, g, gw, gb, N, V, C_, K, C_)
+                ops.head_dgrad(g, seg.weight, g_cur, N, V, C_, K, C_, accumulate=have)
+                grads[seg.weight], grads[seg.bias] = gw, gb
+            else:
+                if not have:
+                    g_cur.zero_()
+                if self.decoder.deep_supervision or j == S - 2:
+                    grads[seg.weight] = torch.zeros_like(seg.weight)
+                    grads[seg.bias] = torch.zeros_like(seg.bias)
+            # conv blocks of the stage, last to first
+            blocks = plan.dec_blocks[j]
+            g_act, g_ld = g_cur, C_
+            for i in range(len(blocks) - 1, -1, -1):
+                b = blocks[i]
+                dx = torch.empty((N, V, b.cin), dtype=f16, device=dev)
+                self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, False, dev)
+                g_act, g_ld = dx, b.cin
+            g_cats[lvl] = g_act  # [N, V, 2C]: [..., :C] -> transposed conv, [..., C:] -> encoder skip
+            # transposed conv backward
+            up = plan.ups[j]
+            g_up = g_act  # channel slice [:C] of the cat gradient, ld = 2C
+            Vb = int(np.prod(up.in_dims))
+            dwt = torch.empty((8, up.cout, up.cin), dtype=torch.float32, device=dev)
+            ops.conv_tap_wgrad(up.wgrad, g_up, lres, dwt)
+            gw = torch.empty_like(up.m.weight)
+            ops.unpack_wgrad(dwt, gw, up.cout, up.cin, 8, 8, up.cout * 8, 1, up.wgrad)
+            grads[up.m.weight] = gw
+            if up.m.bias is not None:
+                st = torch.empty((N, up.cout, 2), dtype=torch.float32, device=dev)
+                ops.instnorm_stats(g_up, st, N, V, up.cout, 2 * up.cout)
+                grads[up.m.bias] = st[:, :, 0].sum(0).contiguous()
+            g_below = torch.empty((N, Vb, up.cin), dtype=f16, device=dev)
+            wp = ops.pack_weight(up.m.weight, up.dgrad, up.cout, up.cin, 8, up.cout * 8, 1)
+            ops.conv_tap_forward(up.dgrad, g_up, wp, None, g_below)
+            g_cur = g_below
+            if self.grad_reducer is not None:
+                self.grad_reducer.stage_done(grads)
+        # encoder, deepest first.  g_cur = gradient wrt the bottleneck activation.
+        g_act, g_ld = g_cur, feats[S - 1]
+        for s in range(S - 1, -1, -1):
+            blocks = plan.enc_blocks[s]
+            stage_rec = rec["enc"][s]
+            for i in range(len(blocks) - 1, -1, -1):
+                b = blocks[i]
+                first_of_stage = i == 0
+                if b.stem:
+                    self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, None, False, dev)
+                    continue
+                if first_of_stage:
+                    # input is the skip of level s-1 living in cat_{s-1}[..., C:]: accumulate into its gradient
+                    Cp = feats[s - 1]
+                    dx = g_cats[s - 1][:, :, Cp:]
+                    self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, True, dev)
+                    g_act, g_ld = dx, 2 * Cp
+                else:
+                    dx = torch.empty((N, b.V, b.cin), dtype=f16, device=dev)
+                    self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, False, dev)
+                    g_act, g_ld = dx, b.cin
+            if self.grad_reducer is not None:
+                self.grad_reducer.stage_done(grads)
+        out = []
+        for p in self._params():
+            gp = grads.get(p)
+            out.append(gp if gp is not None else torch.zeros_like(p))
+        if self.grad_reducer is not None:
+            self.grad_reducer.finish(out)
+        return out
+
+    # reference API (dynamic_network_architectures): used by the planner's VRAM estimate only
+    def compute_conv_feature_map_size(self, input_size):
+        raise NotImplementedError("planner-side VRAM estimate is out of scope (SURVEY.md §2 row 13)")

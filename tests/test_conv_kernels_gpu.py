@@ -1,0 +1,247 @@
+"""GPU parity of the tap-table conv kernels, norm, stem and head kernels (through the C-ABI) against torch CPU
+fp32 on the same fp16-rounded inputs.  Tolerances: outputs are fp16 (rel 2^-11 rounding) of fp32 accumulations
+whose summation order differs from the CPU's -> rtol 4e-3, atol scaled to the output magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from nnuzoo_amd import conv_plan as cp
+from nnuzoo_amd import hip_ops as ops
+from nnuzoo_amd.hip_ops import PreparedTable
+
+DEV = "cuda"
+
+
+def to_cl(x):  # (N, C, D, H, W) fp32 -> [N, V, C] fp16 on device
+    N, C = x.shape[:2]
+    return x.permute(0, 2, 3, 4, 1).reshape(N, -1, C).contiguous().to(torch.float16).to(DEV)
+
+
+def from_cl(y, dims):  # [N, V, C] -> (N, C, D, H, W) fp32 cpu
+    N, _, C = y.shape
+    return y.float().cpu().reshape(N, *dims, C).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def h(x):  # fp16 rounding, kept in fp32
+    return x.to(torch.float16).float()
+
+
+def close(got, ref, rtol=4e-3, atol_frac=2e-3):
+    atol = atol_frac * ref.abs().max().item() + 1e-6
+    ok = torch.allclose(got, ref, rtol=rtol, atol=atol)
+    if not ok:
+        err = (got - ref).abs()
+        idx = err.argmax()
+        raise AssertionError(f"max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g}, atol {atol:.3g}) "
+                             f"at flat {idx.item()}: got {got.flatten()[idx].item()} ref {ref.flatten()[idx].item()}; "
+                             f"mismatch frac {(err > atol + rtol * ref.abs()).float().mean().item():.4f}")
+
+
+CONV_CASES = [
+    # N, dims, cin, cout, stride
+    (2, (8, 16, 16), 32, 32, 1),
+    (1, (12, 8, 24), 64, 32, 1),     # ragged vs the 4x8x8 / 8x8x8 tiles
+    (1, (8, 8, 8), 32, 64, 1),
+    (1, (4, 4, 4), 64, 128, 1),      # smaller than one tile
+    (2, (16, 16, 16), 32, 64, 2),
+    (1, (8, 8, 8), 64, 128, 2),
+    (1, (64, 64, 64), 32, 32, 1),    # exercises the 8x8x8 tile
+]
+
+
+@pytest.mark.parametrize("N,dims,cin,cout,stride", CONV_CASES)
+def test_conv_forward(hip_lib, N, dims, cin, cout, stride):
+    g = torch.Generator().manual_seed(1)
+    x = h(torch.randn(N, cin, *dims, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv3d(x, w, b, stride=stride, padding=1)
+    odims = tuple(ref.shape[2:])
+    pt = PreparedTable(cp.conv_forward(N, dims, cin, cout, stride=stride))
+    wp = ops.pack_weight(w.to(DEV), pt, cin, cout, 27, cin * 27, 1)
+    out = torch.full((N, int(np.prod(odims)), cout), float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(pt, to_cl(x), wp, b.to(DEV), out)
+    torch.cuda.synchronize()
+    close(from_cl(out, odims), ref)
+
+
+def test_conv_forward_strided_channels(hip_lib):
+    """input read from / output written into channel slices of wider buffers (the zero-copy concat layout)."""
+    g = torch.Generator().manual_seed(2)
+    N, dims, cin, cout = 1, (8, 8, 16), 32, 32
+    x = h(torch.randn(N, cin, *dims, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05)
+    ref = F.conv3d(x, w, None, padding=1)
+    V = int(np.prod(dims))
+    xin = torch.randn(N, V, 2 * cin, generator=g).to(torch.float16).to(DEV)
+    xin[:, :, cin:] = to_cl(x)
+    out = torch.zeros((N, V, 3 * cout), dtype=torch.float16, device=DEV)
+    pt = PreparedTable(cp.conv_forward(N, dims, cin, cout, ldi=2 * cin, ldo=3 * cout))
+    wp = ops.pack_weight(w.to(DEV), pt, cin, cout, 27, cin * 27, 1)
+    ops.conv_tap_forward(pt, xin[:, :, cin:], wp, None, out[:, :, cout:2 * cout])
+    torch.cuda.synchronize()
+    close(from_cl(out[:, :, cout:2 * cout].contiguous(), dims), ref)
+    assert out[:, :, :cout].abs().max().item() == 0 and out[:, :, 2 * cout:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("N,dims,cin,cout,stride", CONV_CASES[:6])
+def test_conv_dgrad(hip_lib, N, dims, cin, cout, stride):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, cin, *dims, generator=g, requires_grad=True)
+    w = h(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05)
+    y = F.conv3d(x, w, None, stride=stride, padding=1)
+    dy = h(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    ref = x.grad
+    pt = PreparedTable(cp.conv_dgrad(N, dims, cin, cout, stride=stride))
+    wp = ops.pack_weight(w.to(DEV), pt, cout, cin, cin * 27, 27, 1)
+    out = torch.full((N, int(np.prod(dims)), cin), float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(pt, to_cl(dy), wp, None, out)
+    torch.cuda.synchronize()
+    close(from_cl(out, dims), ref)
+    # accumulate variant: out += result
+    base = h(torch.randn(N, cin, *dims, generator=g))
+    out2 = to_cl(base)
+    ops.conv_tap_forward(pt.with_accumulate(True), to_cl(dy), wp, None, out2)
+    torch.cuda.synchronize()
+    close(from_cl(out2, dims), ref + base)
+
+
+@pytest.mark.parametrize("N,dims,cin,cout,stride", CONV_CASES[:6])
+def test_conv_wgrad(hip_lib, N, dims, cin, cout, stride):
+    g = torch.Generator().manual_seed(4)
+    x = h(torch.randn(N, cin, *dims, generator=g))
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    y = F.conv3d(x, w, None, stride=stride, padding=1)
+    dy = h(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    ref = w.grad
+    pt = PreparedTable(cp.conv_wgrad(N, dims, cin, cout, stride=stride))
+    dw = torch.empty((27, cin, cout), dtype=torch.float32, device=DEV)
+    ops.conv_tap_wgrad(pt, to_cl(x), to_cl(dy), dw)
+    gw = torch.full((cout, cin, 3, 3, 3), float("nan"), dtype=torch.float32, device=DEV)
+    ops.unpack_wgrad(dw, gw, cin, cout, 27, 27, cin * 27, 1, pt)
+    torch.cuda.synchronize()
+    close(gw.cpu(), ref, rtol=2e-3, atol_frac=1e-3)
+
+
+@pytest.mark.parametrize("N,dims,cin,cout", [(2, (4, 4, 8), 64, 32), (1, (8, 8, 8), 128, 64), (1, (2, 2, 2), 320, 320)])
+def test_conv_transpose(hip_lib, N, dims, cin, cout):
+    g = torch.Generator().manual_seed(5)
+    x = h(torch.randn(N, cin, *dims, generator=g)).requires_grad_(True)
+    w = h(torch.randn(cin, cout, 2, 2, 2, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv_transpose3d(x, w, b, stride=2)
+    odims = tuple(y.shape[2:])
+    dy = h(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    # forward, written into the first half of a 2*cout wide buffer
+    V, Vo = int(np.prod(dims)), int(np.prod(odims))
+    pt = PreparedTable(cp.convT_forward(N, dims, cin, cout, ldo=2 * cout))
+    wd = w.detach().to(DEV)
+    wp = ops.pack_weight(wd, pt, cin, cout, cout * 8, 8, 1)
+    cat = torch.zeros((N, Vo, 2 * cout), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(pt, to_cl(x.detach()), wp, b.to(DEV), cat)
+    torch.cuda.synchronize()
+    close(from_cl(cat[:, :, :cout].contiguous(), odims), y.detach())
+    assert cat[:, :, cout:].abs().max().item() == 0
+    # dgrad
+    gcat = torch.zeros((N, Vo, 2 * cout), dtype=torch.float16, device=DEV)
+    gcat[:, :, :cout] = to_cl(dy)
+    gcat[:, :, cout:] = 7.0  # must be ignored
+    ptd = PreparedTable(cp.convT_dgrad(N, dims, cin, cout, ldi=2 * cout))
+    wpd = ops.pack_weight(wd, ptd, cout, cin, 8, cout * 8, 1)
+    dx = torch.full((N, V, cin), float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(ptd, gcat, wpd, None, dx)
+    torch.cuda.synchronize()
+    close(from_cl(dx, dims), x.grad)
+    # wgrad
+    ptw = PreparedTable(cp.convT_wgrad(N, dims, cin, cout, lddout=2 * cout))
+    dwt = torch.empty((8, cout, cin), dtype=torch.float32, device=DEV)
+    ops.conv_tap_wgrad(ptw, gcat, to_cl(x.detach()), dwt)
+    gw = torch.full((cin, cout, 2, 2, 2), float("nan"), dtype=torch.float32, device=DEV)
+    ops.unpack_wgrad(dwt, gw, cout, cin, 8, 8, cout * 8, 1, ptw)
+    torch.cuda.synchronize()
+    close(gw.cpu(), w.grad, rtol=2e-3, atol_frac=1e-3)
+
+
+@pytest.mark.parametrize("N,dims,C,ldy", [(2, (8, 8, 8), 32, 32), (1, (6, 10, 12), 64, 128), (2, (4, 4, 4), 320, 320)])
+def test_instnorm_lrelu(hip_lib, N, dims, C, ldy):
+    g = torch.Generator().manual_seed(6)
+    x = (h(torch.randn(N, C, *dims, generator=g) * 2 + 0.5)).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.3).requires_grad_(True)
+    y = F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    dy = h(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    V = int(np.prod(dims))
+    xr = to_cl(x.detach())
+    stats = torch.empty((N, C, 2), dtype=torch.float32, device=DEV)
+    ybuf = torch.zeros((N, V, ldy), dtype=torch.float16, device=DEV)
+    yv = ybuf[:, :, ldy - C:]
+    ops.instnorm_stats(xr, stats, N, V, C, C)
+    ops.instnorm_lrelu_apply(xr, stats, gamma.detach().to(DEV), beta.detach().to(DEV), yv, N, V, C, C, ldy, 1e-5, 0.01)
+    torch.cuda.synchronize()
+    close(from_cl(yv.contiguous(), dims), y.detach(), rtol=3e-3, atol_frac=1e-3)
+    red = torch.empty((N, C, 2), dtype=torch.float32, device=DEV)
+    dx = torch.empty((N, V, C), dtype=torch.float16, device=DEV)
+    gbuf = torch.zeros((N, V, ldy), dtype=torch.float16, device=DEV)
+    gbuf[:, :, ldy - C:] = to_cl(dy)
+    ops.instnorm_lrelu_bwd(xr, gbuf[:, :, ldy - C:], stats, gamma.detach().to(DEV), beta.detach().to(DEV), red, dx, N,
+                           V, C, C, ldy, C, 1e-5, 0.01)
+    torch.cuda.synchronize()
+    close(from_cl(dx, dims), x.grad, rtol=5e-3, atol_frac=2e-3)
+    rs = red.sum(0).cpu()
+    close(rs[:, 1], gamma.grad, rtol=2e-3, atol_frac=1e-3)
+    close(rs[:, 0], beta.grad, rtol=2e-3, atol_frac=1e-3)
+
+
+@pytest.mark.parametrize("N,dims", [(2, (8, 8, 8)), (1, (6, 12, 20))])
+def test_stem(hip_lib, N, dims):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, 1, *dims, generator=g)
+    w = (torch.randn(32, 1, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(32, generator=g)
+    y = F.conv3d(h(x), h(w), b, padding=1)
+    dy = h(torch.randn(y.shape, generator=g))
+    (gw_ref,) = torch.autograd.grad(F.conv3d(h(x), w, None, padding=1), w, dy)
+    V = int(np.prod(dims))
+    out = torch.empty((N, V, 32), dtype=torch.float16, device=DEV)
+    ops.stem_forward(x.to(DEV), w.detach().to(DEV), b.to(DEV), out, (N, *dims), 32)
+    torch.cuda.synchronize()
+    close(from_cl(out, dims), y.detach())
+    gw = torch.empty((32, 1, 3, 3, 3), dtype=torch.float32, device=DEV)
+    ops.stem_wgrad(x.to(DEV), to_cl(dy), gw, (N, *dims), 32)
+    torch.cuda.synchronize()
+    close(gw.cpu(), gw_ref, rtol=2e-3, atol_frac=1e-3)
+
+
+@pytest.mark.parametrize("N,dims,C,K", [(2, (8, 8, 8), 32, 2), (1, (5, 6, 7), 64, 3), (2, (4, 4, 4), 320, 2)])
+def test_seg_head(hip_lib, N, dims, C, K):
+    g = torch.Generator().manual_seed(8)
+    x = h(torch.randn(N, C, *dims, generator=g)).requires_grad_(True)
+    w = (torch.randn(K, C, 1, 1, 1, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(K, generator=g).requires_grad_(True)
+    y = F.conv3d(x, h(w.detach()).requires_grad_(False) + (w - w.detach()), b)
+    dl = h(torch.randn(y.shape, generator=g))
+    y.backward(dl)
+    V = int(np.prod(dims))
+    xr = to_cl(x.detach())
+    wd, bd = w.detach().to(DEV).reshape(K, C).contiguous(), b.detach().to(DEV)
+    logits = torch.empty((N, K, *dims), dtype=torch.float16, device=DEV)
+    ops.head_forward(xr, wd, bd, logits, N, V, C, K, C)
+    torch.cuda.synchronize()
+    close(logits.float().cpu(), y.detach())
+    dlg = dl.to(torch.float16).to(DEV).contiguous()
+    dx = torch.empty((N, V, C), dtype=torch.float16, device=DEV)
+    ops.head_dgrad(dlg, wd, dx, N, V, C, K, C, False)
+    gw = torch.empty((K, C), dtype=torch.float32, device=DEV)
+    gb = torch.empty((K,), dtype=torch.float32, device=DEV)
+    ops.head_wgrad(xr, dlg, gw, gb, N, V, C, K, C)
+    torch.cuda.synchronize()
+    close(from_cl(dx, dims), x.grad)
+    close(gw.cpu(), w.grad.reshape(K, C), rtol=2e-3, atol_frac=1e-3)
+    close(gb.cpu(), b.grad, rtol=2e-3, atol_frac=1e-3)

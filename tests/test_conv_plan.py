@@ -1,0 +1,132 @@
+"""CPU tests of the host-side tap tables (nnuzoo_amd/conv_plan.py): a slow, literal interpreter of the
+nnz_conv_desc semantics (include/nnuzoo_hip.h) is run on the tables and compared with torch's conv ops.
+Exactly what the HIP kernels are specified to compute, so a failure here is a host bug, not a kernel bug."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from nnuzoo_amd import conv_plan as cp
+
+
+def _gather(x, m_dims, stride, off):
+    """x: (N, D, H, W, C) -> values at m*stride + off for all m (zero outside)."""
+    N, D, H, W, C = x.shape
+    out = torch.zeros((N, *m_dims, C), dtype=x.dtype)
+    idx = []
+    for a, (n_m, dim) in enumerate(zip(m_dims, (D, H, W))):
+        coords = torch.arange(n_m) * stride + off[a]
+        ok = (coords >= 0) & (coords < dim)
+        idx.append((coords, ok))
+    sel = [torch.nonzero(ok).flatten() for _, ok in idx]
+    if any(len(s) == 0 for s in sel):
+        return out
+    src = [idx[a][0][sel[a]] for a in range(3)]
+    out[:, sel[0][:, None, None], sel[1][None, :, None], sel[2][None, None, :]] = \
+        x[:, src[0][:, None, None], src[1][None, :, None], src[2][None, None, :]]
+    return out
+
+
+def interp_forward(t: cp.TapTable, x, wslices, bias=None, out=None):
+    """x (N, *in_dims, Cin); wslices[j] (Cin, Cout) for tap position j in table order."""
+    if out is None:
+        out = torch.zeros((t.N, *t.out_dims, t.Cout), dtype=torch.float64)
+    j = 0
+    for ooff, taps in t.groups:
+        acc = torch.zeros((t.N, *t.m_dims, t.Cout), dtype=torch.float64)
+        if bias is not None:
+            acc += bias
+        for off, _ in taps:
+            acc += _gather(x, t.m_dims, t.in_stride, off) @ wslices[j]
+            j += 1
+        for m in itertools.product(*[range(d) for d in t.m_dims]):
+            o = tuple(m[a] * t.out_stride + ooff[a] for a in range(3))
+            if all(o[a] < t.out_dims[a] for a in range(3)):
+                if t.accumulate:
+                    out[:, o[0], o[1], o[2]] += acc[:, m[0], m[1], m[2]]
+                else:
+                    out[:, o[0], o[1], o[2]] = acc[:, m[0], m[1], m[2]]
+    return out
+
+
+def interp_wgrad(t: cp.TapTable, boxed, plain):
+    """dW[widx][a][b] = sum_m boxed[m*IS + off][a] * plain[m*OS + ooff][b]."""
+    assert len(t.groups) == 1
+    ooff, taps = t.groups[0]
+    T = max(w for _, w in taps) + 1
+    dw = torch.zeros((T, t.Cin, t.Cout), dtype=torch.float64)
+    q = _gather(plain, t.m_dims, t.out_stride, ooff)
+    for off, widx in taps:
+        p = _gather(boxed, t.m_dims, t.in_stride, off)
+        dw[widx] += torch.einsum("ndhwa,ndhwb->ab", p, q)
+    return dw
+
+
+def cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous().double()
+
+
+def ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("dims,stride", [((4, 6, 8), 1), ((4, 6, 8), 2), ((5, 7, 6), 2), ((2, 2, 2), 1)])
+def test_conv_tables(dims, stride):
+    g = torch.Generator().manual_seed(0)
+    N, cin, cout = 2, 3, 4
+    x = torch.randn(N, cin, *dims, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    y = F.conv3d(x, w, b, stride=stride, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    wflat = w.detach().reshape(cout, cin, 27)
+    # forward
+    t = cp.conv_forward(N, dims, cin, cout, stride=stride)
+    assert t.out_dims == tuple(y.shape[2:])
+    ws = [wflat[:, :, k].t() for k in t.pack_ksel]
+    got = interp_forward(t, cl(x.detach()), ws, b)
+    assert torch.allclose(ncdhw(got), y.detach(), atol=1e-10)
+    # dgrad
+    t = cp.conv_dgrad(N, dims, cin, cout, stride=stride)
+    ws = [wflat[:, :, k] for k in t.pack_ksel]  # (Cout, Cin): reduction over cout
+    got = interp_forward(t, cl(dy), ws)
+    assert torch.allclose(ncdhw(got), x.grad, atol=1e-10)
+    d = t.to_desc()
+    assert d.ext == (2 if stride == 1 else 1) and d.ntaps_total == 27
+    # wgrad
+    t = cp.conv_wgrad(N, dims, cin, cout, stride=stride)
+    dw = interp_wgrad(t, cl(x.detach()), cl(dy))  # [27][cin][cout]
+    assert torch.allclose(dw.permute(2, 1, 0).reshape(cout, cin, 3, 3, 3), w.grad, atol=1e-10)
+
+
+@pytest.mark.parametrize("dims", [(2, 3, 4), (1, 1, 1)])
+def test_conv_transpose_tables(dims):
+    g = torch.Generator().manual_seed(1)
+    N, cin, cout = 2, 3, 5
+    x = torch.randn(N, cin, *dims, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cin, cout, 2, 2, 2, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    y = F.conv_transpose3d(x, w, b, stride=2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    wflat = w.detach().reshape(cin, cout, 8)
+    t = cp.convT_forward(N, dims, cin, cout)
+    got = interp_forward(t, cl(x.detach()), [wflat[:, :, k] for k in t.pack_ksel], b)
+    assert torch.allclose(ncdhw(got), y.detach(), atol=1e-10)
+    t = cp.convT_dgrad(N, dims, cin, cout)
+    got = interp_forward(t, cl(dy), [wflat[:, :, k].t() for k in t.pack_ksel])
+    assert torch.allclose(ncdhw(got), x.grad, atol=1e-10)
+    t = cp.convT_wgrad(N, dims, cin, cout)
+    dw = interp_wgrad(t, cl(dy), cl(x.detach()))  # [8][cout][cin]
+    assert torch.allclose(dw.permute(2, 1, 0).reshape(cin, cout, 2, 2, 2), w.grad, atol=1e-10)
+
+
+def test_desc_roundtrip_limits():
+    t = cp.conv_dgrad(1, (8, 8, 8), 32, 64, stride=2)
+    d = t.to_desc()
+    assert d.ngroups == 8 and d.out_stride == 2 and d.in_stride == 1
+    assert sorted(g.ntaps for g in list(d.groups)[:8]) == [1, 2, 2, 2, 4, 4, 4, 8]
+    assert [d.lo[i] for i in range(3)] == [0, 0, 0]
