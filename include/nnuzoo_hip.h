@@ -70,6 +70,15 @@ int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const flo
                                  const float* gamma, const float* beta, void* dx_f16, int N, long V, int C, int ldx,
                                  int ldg, int lddx, float eps, float slope, void* stream);
 
+/* ---- fused soft-Dice + cross-entropy statistics on NC(D)HW logits --------------------------------------------
+ * replaces softmax + one-hot + reductions + CE of DC_and_CE_loss (nnunetv2/training/loss/compound_losses.py:31-56,
+ * dice.py:72-119, robust_ce_loss.py:12-16).  sums[b] = {intersect[C], sum_pred[C], sum_gt[C], ce_sum};
+ * coef[b] = {dL/dintersect[C], dL/dsum_pred[C], dL/dce_sum}.  target: int16 class ids [B][V]. */
+int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target, float* sums, int B, int C,
+                           long V, void* stream);
+int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
+                            void* dlogits, int B, int C, long V, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,8 @@ SIGNATURES = {
     "nnz_instnorm_lrelu_apply": [_vp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _f, _f, _vp],
     "nnz_instnorm_lrelu_bwd_reduce": [_vp, _vp, _fp, _fp, _fp, _fp, _i, _l, _i, _i, _i, _f, _f, _vp],
     "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _vp],
+    "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _vp],
+    "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _vp],
 }
 
 _lib = None

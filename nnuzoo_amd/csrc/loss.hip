@@ -1,0 +1,181 @@
+// Fused soft-Dice + cross-entropy statistics over NC(D)HW logits (gfx950), forward and backward.
+// Replaces, for one deep-supervision output, the chain softmax -> one-hot scatter -> 3 reductions (Dice) plus
+// log_softmax + nll (CE) that the reference runs as separate full-resolution torch passes:
+//   DC_and_CE_loss.forward               /root/reference/nnunetv2/training/loss/compound_losses.py:31-56
+//   MemoryEfficientSoftDiceLoss.forward  /root/reference/nnunetv2/training/loss/dice.py:72-119
+//   RobustCrossEntropyLoss.forward       /root/reference/nnunetv2/training/loss/robust_ce_loss.py:12-16
+// HBM-bound: forward = one read of logits + target; backward = one read + one write.  All math in fp32 from the
+// fp16 (autocast) or fp32 logits, exactly the dtype flow of the reference (softmax / CE run in fp32 under autocast).
+//   sums[b] = { intersect[c] (C), sum_pred[c] (C), sum_gt[c] (C), ce_sum (1) }
+//   coef[b] = { dL/d intersect[c] (C), dL/d sum_pred[c] (C), dL/d ce_sum (1) }
+#include "common.hpp"
+
+namespace nnz {
+
+constexpr int LS_MAXC = 8;
+
+template <typename T>
+struct LossArgs {
+  const T* logits;      // [B][C][V]
+  const int16_t* tgt;   // [B][V]
+  float* sums;          // [B][3C+1]
+  const float* coef;    // [B][2C+1]
+  T* dlogits;           // [B][C][V]
+  int B, C;
+  long V;
+  int vpb;
+};
+
+template <typename T>
+__device__ __forceinline__ void softmax_at(const LossArgs<T>& a, long base, long v, float (&p)[LS_MAXC], float& lse) {
+  float z[LS_MAXC];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c)
+    if (c < a.C) {
+      z[c] = (float)a.logits[base + (long)c * a.V + v];
+      m = fmaxf(m, z[c]);
+    }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c)
+    if (c < a.C) {
+      p[c] = __expf(z[c] - m);
+      s += p[c];
+    }
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c)
+    if (c < a.C) p[c] *= inv;
+  lse = m + __logf(s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
+  __shared__ float lred[3 * LS_MAXC + 1];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  if (tid < 3 * LS_MAXC + 1) lred[tid] = 0.f;
+  __syncthreads();
+  const long v0 = (long)blockIdx.x * a.vpb;
+  long v1 = v0 + a.vpb;
+  if (v1 > a.V) v1 = a.V;
+  const long base = (long)b * a.C * a.V;
+  float inter[LS_MAXC], sp[LS_MAXC], sg[LS_MAXC], ce = 0.f;
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c) inter[c] = sp[c] = sg[c] = 0.f;
+  for (long v = v0 + tid; v < v1; v += 256) {
+    float p[LS_MAXC], lse;
+    softmax_at(a, base, v, p, lse);
+    const int t = a.tgt[(long)b * a.V + v];
+#pragma unroll
+    for (int c = 0; c < LS_MAXC; ++c)
+      if (c < a.C) {
+        sp[c] += p[c];
+        if (c == t) {
+          inter[c] += p[c];
+          sg[c] += 1.f;
+          ce += lse - (float)a.logits[base + (long)c * a.V + v];
+        }
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c)
+    if (c < a.C) {
+      const float x0 = wave_sum(inter[c]), x1 = wave_sum(sp[c]), x2 = wave_sum(sg[c]);
+      if ((tid & 63) == 0) {
+        atomicAdd(&lred[c], x0);
+        atomicAdd(&lred[a.C + c], x1);
+        atomicAdd(&lred[2 * a.C + c], x2);
+      }
+    }
+  const float xc = wave_sum(ce);
+  if ((tid & 63) == 0) atomicAdd(&lred[3 * a.C], xc);
+  __syncthreads();
+  if (tid < 3 * a.C + 1) atomicAdd(a.sums + (long)b * (3 * a.C + 1) + tid, lred[tid]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dc_ce_bwd_kernel(LossArgs<T> a) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const long v0 = (long)blockIdx.x * a.vpb;
+  long v1 = v0 + a.vpb;
+  if (v1 > a.V) v1 = a.V;
+  const long base = (long)b * a.C * a.V;
+  float gi[LS_MAXC], gp[LS_MAXC];
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c) {
+    gi[c] = c < a.C ? a.coef[(long)b * (2 * a.C + 1) + c] : 0.f;
+    gp[c] = c < a.C ? a.coef[(long)b * (2 * a.C + 1) + a.C + c] : 0.f;
+  }
+  const float gce = a.coef[(long)b * (2 * a.C + 1) + 2 * a.C];
+  for (long v = v0 + tid; v < v1; v += 256) {
+    float p[LS_MAXC], lse;
+    softmax_at(a, base, v, p, lse);
+    const int t = a.tgt[(long)b * a.V + v];
+    float S = 0.f;
+    float ac[LS_MAXC];
+#pragma unroll
+    for (int c = 0; c < LS_MAXC; ++c)
+      if (c < a.C) {
+        ac[c] = gp[c] + (c == t ? gi[c] : 0.f);
+        S += ac[c] * p[c];
+      }
+#pragma unroll
+    for (int c = 0; c < LS_MAXC; ++c)
+      if (c < a.C) {
+        const float d = p[c] * (ac[c] - S) + gce * (p[c] - (c == t ? 1.f : 0.f));
+        a.dlogits[base + (long)c * a.V + v] = (T)d;
+      }
+  }
+}
+
+template <typename T>
+static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
+  if (a.C < 1 || a.C > LS_MAXC || a.B < 1 || a.V < 1) return NNZ_EINVAL;
+  long vpb = (a.V * a.B + 2047) / 2048;
+  if (vpb < 1024) vpb = 1024;
+  if (vpb > a.V) vpb = a.V;
+  a.vpb = (int)vpb;
+  const int gx = (int)((a.V + vpb - 1) / vpb);
+  if (!bwd) {
+    hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(float) * a.B * (3 * a.C + 1), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dc_ce_fwd_kernel<T>, dim3(gx, a.B), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(dc_ce_bwd_kernel<T>, dim3(gx, a.B), dim3(256), 0, s, a);
+  }
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target, float* sums, int B,
+                                      int C, long V, void* stream) {
+  using namespace nnz;
+  if (!logits || !target || !sums) return NNZ_EINVAL;
+  if (logits_is_f16) {
+    LossArgs<f16> a = {};
+    a.logits = (const f16*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V;
+    return launch_loss(a, false, (hipStream_t)stream);
+  }
+  LossArgs<float> a = {};
+  a.logits = (const float*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V;
+  return launch_loss(a, false, (hipStream_t)stream);
+}
+
+extern "C" int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
+                                       void* dlogits, int B, int C, long V, void* stream) {
+  using namespace nnz;
+  if (!logits || !target || !coef || !dlogits) return NNZ_EINVAL;
+  if (logits_is_f16) {
+    LossArgs<f16> a = {};
+    a.logits = (const f16*)logits; a.tgt = target; a.coef = coef; a.dlogits = (f16*)dlogits; a.B = B; a.C = C; a.V = V;
+    return launch_loss(a, true, (hipStream_t)stream);
+  }
+  LossArgs<float> a = {};
+  a.logits = (const float*)logits; a.tgt = target; a.coef = coef; a.dlogits = (float*)dlogits; a.B = B; a.C = C; a.V = V;
+  return launch_loss(a, true, (hipStream_t)stream);
+}

@@ -1,0 +1,81 @@
+"""Data-parallel gradient exchange for the explicit-schedule networks: one process per GPU, RCCL over xGMI.
+
+The reference wraps the network in torch DDP (/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:278-280)
+and relies on autograd hooks to overlap the bucketed NCCL all-reduce with backward.  Our backward is ONE autograd
+node with an explicit reverse schedule, so the overlap is explicit too: after every decoder/encoder stage the
+schedule hands the finished parameter gradients to `BucketedAllReduce.stage_done`, which launches an asynchronous
+all-reduce (backend "nccl" == RCCL on ROCm; its own stream) as soon as a bucket is full, while the next stage's
+kernels keep the compute stream busy.  `finish` waits (stream-ordered, no host sync on RCCL) and averages.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of S bytes costs ~2*(7/8)*S/153 GB/s,
+i.e. ~1.4 ms for the 124.8 MB of fp32 gradients of the 3d_fullres PlainConvUNet - buckets of >= 16 MB keep the
+per-collective latency (~20-30 us) negligible while still giving 6-8 collectives to overlap with backward.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class BucketedAllReduce:
+    def __init__(self, params: List[torch.nn.Parameter], process_group=None, bucket_bytes: int = 16 << 20):
+        self.group = process_group
+        self.bucket_bytes = bucket_bytes
+        self.world = dist.get_world_size(process_group)
+        self._seen = set()
+        self._pending: List[torch.Tensor] = []
+        self._pending_bytes = 0
+        self._inflight = []
+
+    def _launch(self):
+        if not self._pending:
+            return
+        flat = torch.cat([g.reshape(-1) for g in self._pending])
+        handle = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((handle, flat, self._pending))
+        self._pending, self._pending_bytes = [], 0
+
+    def stage_done(self, grads: Dict[torch.nn.Parameter, torch.Tensor]):
+        """Called by the backward schedule with the dict of all gradients computed so far."""
+        for p, g in grads.items():
+            if p in self._seen:
+                continue
+            self._seen.add(p)
+            self._pending.append(g)
+            self._pending_bytes += g.numel() * g.element_size()
+        if self._pending_bytes >= self.bucket_bytes:
+            self._launch()
+
+    def finish(self, all_grads: List[torch.Tensor]):
+        """Flush, wait for every collective and write the averaged gradients back in place."""
+        seen_ids = {id(g) for _, _, gs in self._inflight for g in gs} | {id(g) for g in self._pending}
+        for g in all_grads:  # gradients that never went through stage_done (e.g. zero-filled unused heads)
+            if id(g) not in seen_ids:
+                self._pending.append(g)
+        self._launch()
+        inv = 1.0 / self.world
+        for handle, flat, gs in self._inflight:
+            handle.wait()
+            off = 0
+            for g in gs:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                g.mul_(inv)
+                off += n
+        self._inflight = []
+        self._seen = set()
+
+
+def attach_bucketed_allreduce(network, process_group=None, bucket_bytes: int = 16 << 20) -> BucketedAllReduce:
+    """DDP for nnuzoo_amd networks: broadcast rank-0 parameters, then reduce gradients inside backward."""
+    params = list(network.parameters())
+    with torch.no_grad():
+        for p in params:
+            dist.broadcast(p.data, src=0, group=process_group)
+        for b in network.buffers():
+            dist.broadcast(b.data, src=0, group=process_group)
+    red = BucketedAllReduce(params, process_group, bucket_bytes)
+    network.grad_reducer = red
+    return red

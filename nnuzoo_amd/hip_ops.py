@@ -32,12 +32,44 @@ class PreparedTable:
         self.desc = table.to_desc()
         self.pack_ksel = ksel_array(table.pack_ksel)
         self.ident_ksel = ksel_array(list(range(32)))
+        m = table.m_dims[0] * table.m_dims[1] * table.m_dims[2]
+        # algorithmic FLOPs of one launch (2 * MAC): every m-voxel x tap x Cin x Cout
+        self.flops = 2.0 * table.N * m * table.ntaps * table.Cin * table.Cout
 
     def with_accumulate(self, acc: bool) -> "PreparedTable":
         import copy
         t = copy.copy(self.table)
         t.accumulate = acc
         return PreparedTable(t)
+
+
+class LaunchTimer:
+    """HIP-event timing of the MFMA conv launches on the stream they run on (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []  # (kind, flops, start, end)
+
+    def wrap(self, kind: str, flops: float, fn):
+        if not self.enabled:
+            fn()
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((kind, flops, s, e))
+
+    def summary(self):
+        """{kind: (launches, total_flops, total_seconds)} - call after torch.cuda.synchronize()."""
+        out = {}
+        for kind, fl, s, e in self.records:
+            n, f, t = out.get(kind, (0, 0.0, 0.0))
+            out[kind] = (n + 1, f + fl, t + s.elapsed_time(e) * 1e-3)
+        return out
+
+
+TIMER = LaunchTimer()
 
 
 def pack_weight(param: torch.Tensor, pt: PreparedTable, R: int, Cc: int, sr: int, sc: int, sk: int,
@@ -54,12 +86,15 @@ def pack_weight(param: torch.Tensor, pt: PreparedTable, R: int, Cc: int, sr: int
 def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
                      out: torch.Tensor) -> None:
     _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
-    call("nnz_conv_tap_forward", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc), stream_ptr())
+    TIMER.wrap("conv_box_kernel", pt.flops,
+               lambda: call("nnz_conv_tap_forward", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
+                            stream_ptr()))
 
 
 def conv_tap_wgrad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, dw: torch.Tensor) -> None:
     _f16(boxed, "wgrad.boxed"); _f16(plain, "wgrad.plain"); _f32(dw, "wgrad.dw")
-    call("nnz_conv_tap_wgrad", ptr(boxed), ptr(plain), ptr(dw), C.byref(pt.desc), stream_ptr())
+    TIMER.wrap("conv_wgrad_kernel", pt.flops,
+               lambda: call("nnz_conv_tap_wgrad", ptr(boxed), ptr(plain), ptr(dw), C.byref(pt.desc), stream_ptr()))
 
 
 def unpack_wgrad(dw: torch.Tensor, grad: torch.Tensor, A: int, B: int, T: int, sa: int, sb: int, sk: int,
@@ -113,3 +148,25 @@ def instnorm_lrelu_bwd(x, g, stats, gamma, beta, red, dx, N, V, Cc, ldx, ldg, ld
          ldx, ldg, eps, slope, stream_ptr())
     call("nnz_instnorm_lrelu_bwd_apply", ptr(x), ptr(g), ptr(stats), ptr(red), ptr(gamma), ptr(beta), ptr(dx), N, V,
          Cc, ldx, ldg, lddx, eps, slope, stream_ptr())
+
+
+def _logits_kind(t: torch.Tensor) -> int:
+    if not t.is_cuda or t.dtype not in (torch.float16, torch.float32):
+        raise _lib.HipCallError(f"loss: logits must be fp16/fp32 device tensors, got {t.dtype} on {t.device}")
+    return 1 if t.dtype == torch.float16 else 0
+
+
+def dc_ce_forward(logits, target_i16, sums, B, Cc, V):
+    if target_i16.dtype != torch.int16 or not target_i16.is_cuda:
+        raise _lib.HipCallError("loss: target must be an int16 device tensor")
+    _f32(sums, "loss.sums")
+    call("nnz_dc_ce_loss_forward", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(sums), B, Cc, V,
+         stream_ptr())
+
+
+def dc_ce_backward(logits, target_i16, coef, dlogits, B, Cc, V):
+    _f32(coef, "loss.coef")
+    if dlogits.dtype != logits.dtype:
+        raise _lib.HipCallError("loss: dlogits dtype must equal logits dtype")
+    call("nnz_dc_ce_loss_backward", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(coef), ptr(dlogits), B, Cc,
+         V, stream_ptr())

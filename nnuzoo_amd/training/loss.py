@@ -1,0 +1,156 @@
+"""Loss stack of the nnU-Net training step, same class names / constructor arguments / semantics as the reference:
+  DC_and_CE_loss                /root/reference/nnunetv2/training/loss/compound_losses.py:8-56
+  MemoryEfficientSoftDiceLoss   /root/reference/nnunetv2/training/loss/dice.py:58-119
+  RobustCrossEntropyLoss        /root/reference/nnunetv2/training/loss/robust_ce_loss.py:6-16
+  DeepSupervisionWrapper        /root/reference/nnunetv2/training/loss/deep_supervision.py:5-30
+  AllGatherGrad                 /root/reference/nnunetv2/utilities/ddp_allgather.py:25-48
+
+Device arithmetic: DC_and_CE_loss runs ONE fused HIP kernel per deep-supervision output (nnz_dc_ce_loss_* in
+csrc/loss.hip: softmax, CE sum, Dice sums in one read of the logits; the logit gradient in one more); only the
+tiny (B, C) Dice algebra and the DDP all-gather of those statistics stay in torch.  There is no CPU path: CPU
+tensors raise (the CPU restatement of the reference formulas is oracle/losses.py, test-only).
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Optional, Tuple
+
+import torch
+from torch import nn
+
+
+class AllGatherGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx: Any, tensor: torch.Tensor, group=None) -> torch.Tensor:
+        ctx.group = group
+        gathered = [torch.zeros_like(tensor) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(gathered, tensor, group=group)
+        return torch.stack(gathered, dim=0)
+
+    @staticmethod
+    def backward(ctx: Any, *grad_output: torch.Tensor) -> Tuple[torch.Tensor, None]:
+        g = torch.cat(grad_output)
+        torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, async_op=False, group=ctx.group)
+        return g[torch.distributed.get_rank()], None
+
+
+def softmax_helper_dim1(x: torch.Tensor) -> torch.Tensor:
+    return torch.softmax(x, 1)
+
+
+class RobustCrossEntropyLoss(nn.CrossEntropyLoss):
+    def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if target.ndim == input.ndim:
+            assert target.shape[1] == 1
+            target = target[:, 0]
+        return super().forward(input, target.long())
+
+
+class MemoryEfficientSoftDiceLoss(nn.Module):
+    def __init__(self, apply_nonlin: Callable = None, batch_dice: bool = False, do_bg: bool = True,
+                 smooth: float = 1., ddp: bool = True):
+        super().__init__()
+        self.do_bg, self.batch_dice, self.apply_nonlin, self.smooth, self.ddp = do_bg, batch_dice, apply_nonlin, smooth, ddp
+
+    def dice_from_sums(self, intersect, sum_pred, sum_gt):
+        """(b, c) statistics -> -mean dice; shared by the torch path and the fused-kernel path."""
+        if self.batch_dice:
+            if self.ddp:
+                intersect = AllGatherGrad.apply(intersect).sum(0)
+                sum_pred = AllGatherGrad.apply(sum_pred).sum(0)
+                sum_gt = AllGatherGrad.apply(sum_gt).sum(0)
+            intersect, sum_pred, sum_gt = intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)
+        dc = (2 * intersect + self.smooth) / (torch.clip(sum_gt + sum_pred + self.smooth, 1e-8))
+        return -dc.mean()
+
+    def forward(self, x, y, loss_mask=None):
+        if loss_mask is not None:
+            raise NotImplementedError("loss_mask / ignore_label is outside the hot-path scope")
+        if self.apply_nonlin is not softmax_helper_dim1:
+            raise NotImplementedError("the fused HIP Dice statistics assume apply_nonlin=softmax_helper_dim1")
+        intersect, sum_pred, sum_gt, _ = _fused_stats(x, y)
+        if not self.do_bg:
+            intersect, sum_pred, sum_gt = intersect[:, 1:], sum_pred[:, 1:], sum_gt[:, 1:]
+        return self.dice_from_sums(intersect, sum_pred, sum_gt.detach())
+
+
+def _fused_stats(net_output: torch.Tensor, target: torch.Tensor):
+    if not net_output.is_cuda:
+        raise RuntimeError("nnuzoo_amd losses run on MI355X through libnnuzoo_hip.so only (no CPU fallback); "
+                           "the CPU restatement is oracle/losses.py (test-only)")
+    if net_output.shape[1] > 8:
+        raise NotImplementedError("fused Dice+CE kernel supports up to 8 classes")
+    if target.ndim == net_output.ndim:
+        assert target.shape[1] == 1, "target must be a label map (b, 1, ...)"
+    tgt = target if target.dtype == torch.int16 else target.to(torch.int16)
+    return _FusedDiceCE.apply(net_output.contiguous(), tgt.contiguous())
+
+
+class _FusedDiceCE(torch.autograd.Function):
+    """softmax + CE-sum + Dice sums in one pass over the logits; backward is one more pass (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits: torch.Tensor, target: torch.Tensor):
+        from .. import hip_ops as ops
+        B, C = logits.shape[:2]
+        V = logits[0, 0].numel()
+        sums = torch.empty((B, 3 * C + 1), dtype=torch.float32, device=logits.device)
+        ops.dc_ce_forward(logits, target, sums, B, C, V)
+        ctx.save_for_backward(logits, target)
+        ctx.dims = (B, C, V)
+        intersect, sum_pred, sum_gt = sums[:, :C], sums[:, C:2 * C], sums[:, 2 * C:3 * C]
+        ce_sum = sums[:, 3 * C]
+        return intersect, sum_pred, sum_gt, ce_sum
+
+    @staticmethod
+    def backward(ctx, g_int, g_pred, g_gt, g_ce):
+        from .. import hip_ops as ops
+        logits, target = ctx.saved_tensors
+        B, C, V = ctx.dims
+        dev = logits.device
+        coef = torch.zeros((B, 2 * C + 1), dtype=torch.float32, device=dev)
+        if g_int is not None:
+            coef[:, :C] = g_int
+        if g_pred is not None:
+            coef[:, C:2 * C] = g_pred
+        if g_ce is not None:
+            coef[:, 2 * C] = g_ce
+        dlogits = torch.empty_like(logits)
+        ops.dc_ce_backward(logits, target, coef, dlogits, B, C, V)
+        return dlogits, None
+
+
+class DC_and_CE_loss(nn.Module):
+    def __init__(self, soft_dice_kwargs, ce_kwargs, weight_ce=1, weight_dice=1, ignore_label=None,
+                 dice_class=MemoryEfficientSoftDiceLoss):
+        super().__init__()
+        if ignore_label is not None:
+            raise NotImplementedError("ignore_label is outside the hot-path scope (SURVEY.md §8a a-11)")
+        self.weight_dice, self.weight_ce, self.ignore_label = weight_dice, weight_ce, ignore_label
+        self.ce = RobustCrossEntropyLoss(**ce_kwargs)
+        self.dc = dice_class(apply_nonlin=softmax_helper_dim1, **soft_dice_kwargs)
+        self._plain_ce = not ce_kwargs
+
+    def forward(self, net_output: torch.Tensor, target: torch.Tensor):
+        if not self._plain_ce or not isinstance(self.dc, MemoryEfficientSoftDiceLoss):
+            raise NotImplementedError("fused HIP loss: ce_kwargs must be {} and dice_class MemoryEfficientSoftDiceLoss")
+        intersect, sum_pred, sum_gt, ce_sum = _fused_stats(net_output, target)
+        if not self.dc.do_bg:
+            intersect, sum_pred, sum_gt = intersect[:, 1:], sum_pred[:, 1:], sum_gt[:, 1:]
+        dc_loss = self.dc.dice_from_sums(intersect, sum_pred, sum_gt.detach()) if self.weight_dice != 0 else 0
+        n_vox = net_output.shape[0] * net_output[0, 0].numel()
+        ce_loss = ce_sum.sum() / n_vox if self.weight_ce != 0 else 0
+        return self.weight_ce * ce_loss + self.weight_dice * dc_loss
+
+
+class DeepSupervisionWrapper(nn.Module):
+    def __init__(self, loss, weight_factors=None):
+        super().__init__()
+        assert any([x != 0 for x in weight_factors]), "At least one weight factor should be != 0.0"
+        self.weight_factors = tuple(weight_factors)
+        self.loss = loss
+
+    def forward(self, *args):
+        assert all([isinstance(i, (tuple, list)) for i in args]), \
+            f"all args must be either tuple or list, got {[type(i) for i in args]}"
+        weights = (1,) * len(args[0]) if self.weight_factors is None else self.weight_factors
+        return sum([weights[i] * self.loss(*inputs) for i, inputs in enumerate(zip(*args)) if weights[i] != 0.0])

@@ -1,0 +1,313 @@
+"""nnUNetTrainer - the hot-path subset of the reference's trainer plugin surface, MI355X-native.
+
+Mirrors /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py for everything the per-patch
+forward/backward step touches, with the same names, argument meaning and numerics:
+  __init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs, initial_lr, ...)   :80-239
+  initialize()                                         :242-294   (network, optimizer, DDP, loss)
+  build_network_architecture(...) (staticmethod, live AND legacy calling convention)   :360-399, SURVEY.md §8b
+  _get_deep_supervision_scales()                       :401-408
+  _build_loss()                                        :455-489
+  configure_optimizers()                               :571-575   SGD(lr, wd 3e-5, momentum .99, nesterov) + PolyLR
+  set_deep_supervision_enabled()                       :1010-1022
+  train_step(batch) / validation_step(batch)           :1112-1144 / :1161-1226
+  on_validation_epoch_end pseudo-Dice formula          :1255-1259
+  save_checkpoint / load_checkpoint (same dict keys)   :1291-1352
+Out of scope: data loading/augmentation, planning, sliding-window validation, logging/plots.
+Data parallelism: one process per GPU; gradients are exchanged by nnuzoo_amd.ddp.BucketedAllReduce (RCCL over
+xGMI, overlapped with the explicit backward schedule) instead of torch DDP's autograd hooks.
+"""
+from __future__ import annotations
+
+import inspect
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..ddp import attach_bucketed_allreduce
+from ..utilities.get_network_from_plans import get_network_from_plans
+from .loss import DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
+from .lr_scheduler import PolyLRScheduler
+
+
+class ConfigurationView:
+    """The few ConfigurationManager properties the step needs (plans_handler.py:30-230)."""
+
+    def __init__(self, cfg: dict):
+        self.configuration = cfg
+
+    @property
+    def patch_size(self) -> List[int]:
+        return self.configuration['patch_size']
+
+    @property
+    def batch_size(self) -> int:
+        return self.configuration['batch_size']
+
+    @property
+    def batch_dice(self) -> bool:
+        return self.configuration['batch_dice']
+
+    @property
+    def network_arch_class_name(self) -> str:
+        return self.configuration['architecture']['network_class_name']
+
+    @property
+    def network_arch_init_kwargs(self) -> dict:
+        return self.configuration['architecture']['arch_kwargs']
+
+    @property
+    def network_arch_init_kwargs_req_import(self):
+        return self.configuration['architecture']['_kw_requires_import']
+
+    @property
+    def pool_op_kernel_sizes(self):
+        return self.network_arch_init_kwargs['strides']
+
+
+def _num_segmentation_heads(dataset_json: dict) -> int:
+    labels = dataset_json['labels']
+    if any(isinstance(v, (list, tuple)) for v in labels.values()):
+        raise NotImplementedError("region-based training is outside the hot-path scope")
+    if 'ignore' in labels:
+        raise NotImplementedError("ignore label is outside the hot-path scope")
+    return len(labels)
+
+
+def _num_input_channels(dataset_json: dict) -> int:
+    names = dataset_json.get('channel_names', dataset_json.get('modality', {'0': 'x'}))
+    return len(names)
+
+
+class nnUNetTrainer:
+    def __init__(self, plans: dict, configuration: str, fold: Union[int, str], dataset_json: dict,
+                 unpack_dataset: bool = True, device: torch.device = torch.device('cuda'), num_epochs: int = 1000,
+                 initial_lr: float = 1e-2, up_sample_type: str = 'convtranspose', batch_size: int = None, **kwargs):
+        plans["configurations"][configuration]["batch_size"] = batch_size or \
+            plans["configurations"][configuration]["batch_size"]
+        self.up_sample_type = up_sample_type
+        self.is_ddp = dist.is_available() and dist.is_initialized()
+        self.local_rank = 0 if not self.is_ddp else dist.get_rank()
+        self.device = device
+        if self.device.type == 'cuda':
+            idx = int(torch.cuda.current_device()) if self.is_ddp else 0
+            self.device = torch.device(type='cuda', index=idx)
+        self.my_init_kwargs = {}
+        for k in inspect.signature(self.__init__).parameters.keys():
+            if k in locals():
+                self.my_init_kwargs[k] = locals()[k]
+        self.plans = plans
+        self.configuration_name = configuration
+        self.configuration_manager = ConfigurationView(plans["configurations"][configuration])
+        self.dataset_json = dataset_json
+        self.fold = fold
+        # hyper-parameters (nnUNetTrainer.py:178-188)
+        self.initial_lr = initial_lr
+        self.weight_decay = 3e-5
+        self.oversample_foreground_percent = 0.33
+        self.num_iterations_per_epoch = 250
+        self.num_val_iterations_per_epoch = 50
+        self.num_epochs = num_epochs
+        self.current_epoch = 0
+        self.enable_deep_supervision = True
+        self.num_input_channels = None
+        self.network = None
+        self.optimizer = self.lr_scheduler = None
+        self.grad_scaler = torch.amp.GradScaler("cuda") if self.device.type == 'cuda' else None
+        self.loss = None
+        self._best_ema = None
+        self.inference_allowed_mirroring_axes = None
+        self.was_initialized = False
+        self.batch_size = self.configuration_manager.batch_size
+
+    # ---- set-up ------------------------------------------------------------------------------------------------
+    def initialize(self):
+        if self.was_initialized:
+            raise RuntimeError("You have called self.initialize even though the trainer was already initialized.")
+        self._set_batch_size_and_oversample()
+        self.num_input_channels = _num_input_channels(self.dataset_json)
+        cm = self.configuration_manager
+        self.network = self.build_network_architecture(
+            cm.network_arch_class_name, cm.network_arch_init_kwargs, cm.network_arch_init_kwargs_req_import,
+            self.num_input_channels, _num_segmentation_heads(self.dataset_json), self.enable_deep_supervision,
+            up_sample_type=self.up_sample_type, configuration_manager=cm).to(self.device)
+        self.optimizer, self.lr_scheduler = self.configure_optimizers()
+        if self.is_ddp:
+            attach_bucketed_allreduce(self.network)
+        self.loss = self._build_loss()
+        self.was_initialized = True
+
+    def _set_batch_size_and_oversample(self):
+        """global batch split evenly over ranks, remainder to the low ranks (nnUNetTrainer.py:410-453)."""
+        if not self.is_ddp:
+            self.batch_size = self.configuration_manager.batch_size
+            return
+        world, rank = dist.get_world_size(), dist.get_rank()
+        gbs = self.configuration_manager.batch_size
+        assert gbs >= world, 'Cannot run DDP if the batch size is smaller than the number of GPUs'
+        per = gbs // world
+        self.batch_size = per + (1 if rank < gbs % world else 0)
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs) -> torch.nn.Module:
+        """Accepts BOTH calling conventions found in the reference:
+        live   (architecture_class_name, arch_init_kwargs, arch_init_kwargs_req_import, num_input_channels,
+                num_output_channels, enable_deep_supervision=True, *, up_sample_type=..., configuration_manager=None)
+        legacy (plans_manager, dataset_json, configuration_manager, num_input_channels, enable_deep_supervision=True)
+        """
+        if len(args) >= 1 and isinstance(args[0], str):
+            names = ["architecture_class_name", "arch_init_kwargs", "arch_init_kwargs_req_import",
+                     "num_input_channels", "num_output_channels", "enable_deep_supervision"]
+            a = dict(zip(names, args))
+            a.update(kwargs)
+            return get_network_from_plans(a["architecture_class_name"], a["arch_init_kwargs"],
+                                          a["arch_init_kwargs_req_import"], a["num_input_channels"],
+                                          a["num_output_channels"], allow_init=True,
+                                          deep_supervision=a.get("enable_deep_supervision", True),
+                                          up_sample_type=a.get("up_sample_type", "convtranspose"))
+        names = ["plans_manager", "dataset_json", "configuration_manager", "num_input_channels",
+                 "enable_deep_supervision"]
+        a = dict(zip(names, args))
+        a.update(kwargs)
+        cm = a["configuration_manager"]
+        return get_network_from_plans(cm.network_arch_class_name, cm.network_arch_init_kwargs,
+                                      cm.network_arch_init_kwargs_req_import, a["num_input_channels"],
+                                      _num_segmentation_heads(a["dataset_json"]), allow_init=True,
+                                      deep_supervision=a.get("enable_deep_supervision", True))
+
+    def _get_deep_supervision_scales(self):
+        if not self.enable_deep_supervision:
+            return None
+        return list(list(i) for i in 1 / np.cumprod(np.vstack(self.configuration_manager.pool_op_kernel_sizes),
+                                                     axis=0))[:-1]
+
+    def _do_i_compile(self) -> bool:
+        return False  # the explicit HIP schedule replaces torch.compile (nnUNetTrainer.py:296-322)
+
+    def _build_loss(self):
+        loss = DC_and_CE_loss({'batch_dice': self.configuration_manager.batch_dice, 'smooth': 1e-5, 'do_bg': False,
+                               'ddp': self.is_ddp}, {}, weight_ce=1, weight_dice=1, ignore_label=None,
+                              dice_class=MemoryEfficientSoftDiceLoss)
+        if self.enable_deep_supervision:
+            scales = self._get_deep_supervision_scales()
+            weights = np.array([1 / (2 ** i) for i in range(len(scales))])
+            # the reference needs 1e-6 under DDP because torch DDP rejects unused parameters (:476-482); our
+            # reducer zero-fills the unused head instead, so the mathematically intended 0 is kept on every rank
+            weights[-1] = 0
+            weights = weights / weights.sum()
+            loss = DeepSupervisionWrapper(loss, weights)
+        return loss
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.SGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay,
+                                    momentum=0.99, nesterov=True)
+        lr_scheduler = PolyLRScheduler(optimizer, self.initial_lr, self.num_epochs)
+        return optimizer, lr_scheduler
+
+    def set_deep_supervision_enabled(self, enabled: bool):
+        self.network.decoder.deep_supervision = enabled
+
+    # ---- the hot loop ------------------------------------------------------------------------------------------
+    def train_step(self, batch: dict) -> dict:
+        data = batch['data'].to(self.device, non_blocking=True)
+        target = batch['target']
+        if isinstance(target, list):
+            target = [i.to(self.device, non_blocking=True) for i in target]
+        else:
+            target = target.to(self.device, non_blocking=True)
+        self.optimizer.zero_grad(set_to_none=True)
+        # the HIP schedule has the numerics of the reference's autocast region (fp16 operands, fp32 accumulate),
+        # so no torch.autocast context is needed around it
+        output = self.network(data)
+        l = self.loss(output, target)
+        if self.grad_scaler is not None:
+            self.grad_scaler.scale(l).backward()
+            self.grad_scaler.unscale_(self.optimizer)
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+            self.grad_scaler.step(self.optimizer)
+            self.grad_scaler.update()
+        else:
+            l.backward()
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+            self.optimizer.step()
+        return {'loss': l.detach().cpu().numpy()}
+
+    def validation_step(self, batch: dict) -> dict:
+        data = batch['data'].to(self.device, non_blocking=True)
+        target = batch['target']
+        if isinstance(target, list):
+            target = [i.to(self.device, non_blocking=True) for i in target]
+        else:
+            target = target.to(self.device, non_blocking=True)
+        with torch.no_grad():
+            output = self.network(data)
+            l = self.loss(output, target)
+        if self.enable_deep_supervision:
+            output, target = output[0], target[0]
+        axes = [0] + list(range(2, output.ndim))
+        output_seg = output.argmax(1)[:, None]
+        onehot = torch.zeros(output.shape, device=output.device, dtype=torch.float32)
+        onehot.scatter_(1, output_seg, 1)
+        tp, fp, fn = tp_fp_fn(onehot, target, axes)
+        return {'loss': l.detach().cpu().numpy(), 'tp_hard': tp.cpu().numpy()[1:], 'fp_hard': fp.cpu().numpy()[1:],
+                'fn_hard': fn.cpu().numpy()[1:]}
+
+    @staticmethod
+    def pseudo_dice(val_outputs: List[dict]) -> List[float]:
+        """2TP / (2TP + FP + FN) per foreground class over the validation batches (nnUNetTrainer.py:1229-1259)."""
+        tp = np.sum([o['tp_hard'] for o in val_outputs], 0)
+        fp = np.sum([o['fp_hard'] for o in val_outputs], 0)
+        fn = np.sum([o['fn_hard'] for o in val_outputs], 0)
+        return [float(i) for i in [2 * i / (2 * i + j + k) for i, j, k in zip(tp, fp, fn)]]
+
+    # ---- checkpoints (same dictionary layout as the reference) -------------------------------------------------
+    def save_checkpoint(self, filename: str) -> None:
+        if self.local_rank != 0:
+            return
+        checkpoint = {
+            'network_weights': self.network.state_dict(),
+            'optimizer_state': self.optimizer.state_dict(),
+            'grad_scaler_state': self.grad_scaler.state_dict() if self.grad_scaler is not None else None,
+            'logging': {},
+            '_best_ema': self._best_ema,
+            'current_epoch': self.current_epoch + 1,
+            'init_args': self.my_init_kwargs,
+            'trainer_name': self.__class__.__name__,
+            'inference_allowed_mirroring_axes': self.inference_allowed_mirroring_axes,
+        }
+        torch.save(checkpoint, filename)
+
+    def load_checkpoint(self, filename_or_checkpoint: Union[dict, str]) -> None:
+        if not self.was_initialized:
+            self.initialize()
+        ckpt = filename_or_checkpoint
+        if isinstance(ckpt, str):
+            ckpt = torch.load(ckpt, map_location=self.device, weights_only=False)
+        new_state_dict = {}
+        own = self.network.state_dict().keys()
+        for k, value in ckpt['network_weights'].items():
+            key = k
+            if key not in own and key.startswith('module.'):
+                key = key[7:]
+            new_state_dict[key] = value
+        self.my_init_kwargs = ckpt['init_args']
+        self.current_epoch = ckpt['current_epoch']
+        self._best_ema = ckpt['_best_ema']
+        self.inference_allowed_mirroring_axes = ckpt.get('inference_allowed_mirroring_axes',
+                                                         self.inference_allowed_mirroring_axes)
+        self.network.load_state_dict(new_state_dict)
+        self.optimizer.load_state_dict(ckpt['optimizer_state'])
+        if self.grad_scaler is not None and ckpt['grad_scaler_state'] is not None:
+            self.grad_scaler.load_state_dict(ckpt['grad_scaler_state'])
+
+
+def tp_fp_fn(onehot_pred: torch.Tensor, gt: torch.Tensor, axes) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """get_tp_fp_fn_tn of the reference (dice.py:122-180) for label-map targets, no mask."""
+    with torch.no_grad():
+        y_onehot = torch.zeros(onehot_pred.shape, device=onehot_pred.device, dtype=torch.bool)
+        y_onehot.scatter_(1, gt.long(), 1)
+    tp = (onehot_pred * y_onehot).sum(axes)
+    fp = (onehot_pred * (~y_onehot)).sum(axes)
+    fn = ((1 - onehot_pred) * y_onehot).sum(axes)
+    return tp, fp, fn

@@ -1,0 +1,50 @@
+"""TEST INFRASTRUCTURE ONLY - CPU restatement (plain torch) of the reference's loss stack.
+
+Follows, line by line in meaning:
+  DC_and_CE_loss.forward               /root/reference/nnunetv2/training/loss/compound_losses.py:31-56
+  MemoryEfficientSoftDiceLoss.forward  /root/reference/nnunetv2/training/loss/dice.py:72-119 (ddp=False branch)
+  RobustCrossEntropyLoss.forward       /root/reference/nnunetv2/training/loss/robust_ce_loss.py:12-16
+  DeepSupervisionWrapper.forward       /root/reference/nnunetv2/training/loss/deep_supervision.py:19-30
+  deep-supervision weights             /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:473-487
+Pinned by KAT-2 / KAT-3 of SURVEY.md §8c and by tests/golden/loss_*.npz, which were produced by importing the
+reference's own modules in the build container (tools/make_golden.py).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def soft_dice(x_logits, y, batch_dice, do_bg=False, smooth=1e-5):
+    x = torch.softmax(x_logits.float(), 1)
+    axes = tuple(range(2, x.ndim))
+    with torch.no_grad():
+        y_onehot = torch.zeros(x.shape, dtype=torch.bool)
+        y_onehot.scatter_(1, y.long(), 1)
+        if not do_bg:
+            y_onehot = y_onehot[:, 1:]
+        sum_gt = y_onehot.sum(axes)
+    if not do_bg:
+        x = x[:, 1:]
+    intersect = (x * y_onehot).sum(axes)
+    sum_pred = x.sum(axes)
+    if batch_dice:
+        intersect, sum_pred, sum_gt = intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)
+    dc = (2 * intersect + smooth) / torch.clip(sum_gt + sum_pred + smooth, 1e-8)
+    return -dc.mean()
+
+
+def dc_and_ce(x_logits, y, batch_dice, weight_ce=1.0, weight_dice=1.0):
+    ce = F.cross_entropy(x_logits.float(), y[:, 0].long())
+    return weight_ce * ce + weight_dice * soft_dice(x_logits, y, batch_dice)
+
+
+def ds_weights(n_outputs, ddp_no_compile=False):
+    w = np.array([1 / (2 ** i) for i in range(n_outputs)])
+    w[-1] = 1e-6 if ddp_no_compile else 0
+    return w / w.sum()
+
+
+def deep_supervision_loss(outputs, targets, batch_dice, weights=None):
+    if weights is None:
+        weights = ds_weights(len(outputs))
+    return sum(w * dc_and_ce(o, t, batch_dice) for w, o, t in zip(weights, outputs, targets) if w != 0)

@@ -1,0 +1,54 @@
+"""GPU parity of the fused Dice+CE HIP loss (through the C-ABI) against the CPU oracle (oracle/losses.py, which is
+pinned to the reference by KAT-2/KAT-3 and tests/golden/loss_*.npz).  fp32 logits: rtol 1e-5 on the loss,
+1e-4 on the gradient (the kernel uses __expf/__logf); fp16 logits: gradient compared after fp16 rounding."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import losses as O
+from nnuzoo_amd.training.loss import DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
+
+
+def make(batch_dice):
+    return DC_and_CE_loss({'batch_dice': batch_dice, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+
+
+def test_kat2_kat3(hip_lib):
+    logits = torch.stack([torch.linspace(-2, 2, 32).view(2, 4, 4), torch.linspace(1, -1, 32).view(2, 4, 4)], 1)
+    target = (torch.arange(32).view(2, 1, 4, 4) % 3 == 0).to(torch.int16)
+    l = make(True)(logits.cuda(), target.cuda())
+    assert abs(float(l) - 0.5730621) < 2e-6
+    outs = [logits, logits[..., ::2, ::2].contiguous(), logits[..., ::4, ::4].contiguous()]
+    tg = [target, target[..., ::2, ::2].contiguous(), target[..., ::4, ::4].contiguous()]
+    w = DeepSupervisionWrapper(make(True), [2 / 3, 1 / 3, 0])
+    l3 = w([o.cuda() for o in outs], [t.cuda() for t in tg])
+    assert abs(float(l3) - 0.6382819) < 2e-6
+
+
+@pytest.mark.parametrize("shape,C,batch_dice", [((2, 17, 19, 23), 2, False), ((3, 64, 48), 4, True), ((2, 8, 8, 8), 3, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_loss_value_and_grad(hip_lib, shape, C, batch_dice, dtype):
+    g = torch.Generator().manual_seed(3)
+    B, sp = shape[0], shape[1:]
+    logits = (torch.randn(B, C, *sp, generator=g) * 2).to(dtype)
+    target = torch.randint(0, C, (B, 1, *sp), generator=g).to(torch.int16)
+    ref_in = logits.float().requires_grad_(True)
+    ref = O.dc_and_ce(ref_in, target, batch_dice)
+    ref.backward()
+    x = logits.cuda().requires_grad_(True)
+    l = make(batch_dice)(x, target.cuda())
+    l.backward()
+    torch.cuda.synchronize()
+    assert abs(float(l) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+    got = x.grad.float().cpu()
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    scale = ref_in.grad.abs().max().item()
+    assert torch.allclose(got, ref_in.grad, rtol=tol, atol=tol * scale), (got - ref_in.grad).abs().max().item()
+
+
+def test_cpu_tensor_raises():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        make(False)(torch.zeros(1, 2, 4, 4), torch.zeros(1, 1, 4, 4, dtype=torch.int16))
