@@ -97,8 +97,9 @@ class _FusedDiceCE(torch.autograd.Function):
         ops.dc_ce_forward(logits, target, sums, B, C, V)
         ctx.save_for_backward(logits, target)
         ctx.dims = (B, C, V)
-        intersect, sum_pred, sum_gt = sums[:, :C], sums[:, C:2 * C], sums[:, 2 * C:3 * C]
-        ce_sum = sums[:, 3 * C]
+        intersect, sum_pred, sum_gt = (sums[:, :C].clone(), sums[:, C:2 * C].clone(), sums[:, 2 * C:3 * C].clone())
+        ce_sum = sums[:, 3 * C].clone()
+        ctx.mark_non_differentiable(sum_gt)
         return intersect, sum_pred, sum_gt, ce_sum
 
     @staticmethod

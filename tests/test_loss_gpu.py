@@ -38,11 +38,11 @@ def test_loss_value_and_grad(hip_lib, shape, C, batch_dice, dtype):
     ref_in = logits.float().requires_grad_(True)
     ref = O.dc_and_ce(ref_in, target, batch_dice)
     ref.backward()
-    x = logits.cuda().requires_grad_(True)
+    x = logits.cuda().detach().clone().requires_grad_(True)
     l = make(batch_dice)(x, target.cuda())
     l.backward()
     torch.cuda.synchronize()
-    assert abs(float(l) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+    assert abs(l.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item())), (l.item(), ref.item())
     got = x.grad.float().cpu()
     tol = 1e-4 if dtype == torch.float32 else 2e-3
     scale = ref_in.grad.abs().max().item()
