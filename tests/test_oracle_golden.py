@@ -1,0 +1,68 @@
+"""CPU tests: the oracle restatements (oracle/) against the golden vectors produced from the reference's own code
+(tests/golden/*.npz, tools/make_golden.py) and the known-answer values of SURVEY.md §8c."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as OL
+from oracle.selective_scan import selective_scan_loop, selective_scan_torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_scan_kat1():
+    u = np.linspace(-1, 1, 8, dtype=np.float32).reshape(1, 2, 4)
+    delta = np.linspace(.1, .8, 8, dtype=np.float32).reshape(1, 2, 4)
+    A = -np.array([[1., 2.], [1., 2.]], np.float32)
+    B = np.linspace(.5, 1.5, 8, dtype=np.float32).reshape(1, 1, 2, 4)
+    C = np.linspace(1, -1, 8, dtype=np.float32).reshape(1, 1, 2, 4)
+    y = selective_scan_loop(u, delta, A, B, C, np.array([1., .5]), np.array([0., -.5]), True)
+    kat = [-1.2582601, -0.7297925, -0.1838676, 0.1108990, 0.1057828, 0.2012926, -0.0189671, -0.7899251]
+    assert np.allclose(y.flatten(), kat, atol=2e-7)
+    assert np.allclose(np.load(os.path.join(G, "selective_scan_kat1.npz"))["y"].flatten(), kat, atol=2e-7)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "selective_scan_[a-d].npz"))))
+def test_scan_oracle_vs_reference_golden(path):
+    z = np.load(path)
+    y = selective_scan_loop(z["u"], z["delta"], z["A"], z["B"], z["C"], z["D"], z["delta_bias"], True)
+    assert np.allclose(y, z["y"], rtol=2e-5, atol=2e-5)
+    t = {k: torch.tensor(z[k], requires_grad=True) for k in ["u", "delta", "A", "B", "C", "D", "delta_bias"]}
+    yt = selective_scan_torch(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["delta_bias"], True)
+    assert torch.allclose(yt, torch.tensor(z["y"]), rtol=2e-5, atol=2e-5)
+    grads = torch.autograd.grad(yt, list(t.values()), torch.tensor(z["dy"]))
+    for name, g in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], grads):
+        ref = torch.tensor(z[name])
+        assert torch.allclose(g, ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item()), name
+
+
+def test_loss_kats():
+    logits = torch.stack([torch.linspace(-2, 2, 32).view(2, 4, 4), torch.linspace(1, -1, 32).view(2, 4, 4)], 1)
+    target = (torch.arange(32).view(2, 1, 4, 4) % 3 == 0).to(torch.int16)
+    assert abs(float(OL.dc_and_ce(logits, target, True)) - 0.5730621) < 1e-6
+    outs = [logits, logits[..., ::2, ::2], logits[..., ::4, ::4]]
+    tg = [target, target[..., ::2, ::2], target[..., ::4, ::4]]
+    assert abs(float(OL.deep_supervision_loss(outs, tg, True, [2 / 3, 1 / 3, 0])) - 0.6382819) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_loss_oracle_vs_reference_golden(tag):
+    z = np.load(os.path.join(G, f"loss_{tag}.npz"))
+    logits = torch.tensor(z["logits"], requires_grad=True)
+    target = torch.tensor(z["target"])
+    l = OL.dc_and_ce(logits, target, bool(z["batch_dice"]))
+    assert abs(float(l) - float(z["loss"])) < 1e-6
+    (g,) = torch.autograd.grad(l, logits)
+    assert torch.allclose(g, torch.tensor(z["dlogits"]), atol=1e-7, rtol=1e-5)
+    nd = logits.dim() - 2
+    sl = (..., *([slice(None, None, 2)] * nd))
+    outs = [logits.detach(), logits.detach()[sl]]
+    tgs = [target, target[sl]]
+    outs.append(outs[1][sl])
+    tgs.append(tgs[1][sl])
+    lds = OL.deep_supervision_loss(outs, tgs, bool(z["batch_dice"]), z["ds_weights"])
+    assert abs(float(lds) - float(z["ds_loss"])) < 1e-6
+    assert np.allclose(OL.ds_weights(3), z["ds_weights"])

@@ -1,0 +1,180 @@
+"""Generates tests/golden/*.npz from the REFERENCE's own code (imported from /root/reference under tools/ref_shim.py).
+Run in the build container only:  python tools/make_golden.py
+The fixtures are data (inputs, deterministic parameter fills, outputs, gradients); no reference source is copied."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def det_fill(module, skip=("A_logs", "Ds", "relative_position_index")):
+    """Deterministic, RNG-free parameter fill shared with the tests (tests/golden_util.py restates it):
+    k-th parameter (named_parameters order) <- scale_k * cos(0.7071 * i + k), i = flat index."""
+    with torch.no_grad():
+        for k, (name, p) in enumerate(module.named_parameters()):
+            if name.split(".")[-1] in skip:
+                continue
+            n = p.numel()
+            i = torch.arange(n, dtype=torch.float64)
+            base = torch.cos(0.7071 * i + k).to(torch.float32).view_as(p)
+            last = name.split(".")[-1]
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(base * (1.0 / fan_in ** 0.5))
+            elif "norm" in name or last in ("weight",) and p.dim() == 1:
+                p.copy_(1.0 + 0.1 * base if last == "weight" else 0.05 * base)
+            else:
+                p.copy_(0.05 * base)
+        for k, (name, b) in enumerate(module.named_buffers()):
+            if name.endswith("running_mean"):
+                b.copy_(0.02 * torch.cos(torch.arange(b.numel(), dtype=torch.float32) + k))
+            elif name.endswith("running_var"):
+                b.copy_(1.0 + 0.1 * torch.cos(torch.arange(b.numel(), dtype=torch.float32) * 0.3 + k) ** 2)
+
+
+def gen_selective_scan(ref):
+    cases = {"a": (2, 4, 8, 16, 37), "b": (1, 4, 16, 16, 300), "c": (2, 6, 16, 16, 64), "d": (1, 4, 16, 16, 520)}
+    for tag, (b, K, Dg, N, L) in cases.items():
+        g = torch.Generator().manual_seed(ord(tag) + 7)
+        KD = K * Dg
+        u = torch.randn(b, KD, L, generator=g, requires_grad=True)
+        delta = (torch.randn(b, KD, L, generator=g) * 0.5).requires_grad_(True)
+        A = (-torch.exp(torch.log(torch.arange(1, N + 1, dtype=torch.float32))[None].repeat(KD, 1) +
+                        0.1 * torch.randn(KD, N, generator=g))).requires_grad_(True)
+        B = torch.randn(b, K, N, L, generator=g, requires_grad=True)
+        C = torch.randn(b, K, N, L, generator=g, requires_grad=True)
+        D = torch.randn(KD, generator=g, requires_grad=True)
+        bias = (torch.randn(KD, generator=g) * 0.5 - 1.0).requires_grad_(True)
+        y = ref(u, delta, A, B, C, D, None, bias, True)
+        dy = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad(y, [u, delta, A, B, C, D, bias], dy)
+        np.savez_compressed(os.path.join(OUT, f"selective_scan_{tag}.npz"),
+                            u=u.detach().numpy(), delta=delta.detach().numpy(), A=A.detach().numpy(),
+                            B=B.detach().numpy(), C=C.detach().numpy(), D=D.detach().numpy(),
+                            delta_bias=bias.detach().numpy(), y=y.detach().numpy(), dy=dy.numpy(),
+                            **{f"d{n}": gr.numpy() for n, gr in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads)})
+    # KAT-1 of SURVEY.md §8c
+    u = torch.linspace(-1, 1, 8).view(1, 2, 4)
+    delta = torch.linspace(.1, .8, 8).view(1, 2, 4)
+    y = ref(u, delta, -torch.tensor([[1., 2.], [1., 2.]]), torch.linspace(.5, 1.5, 8).view(1, 1, 2, 4),
+            torch.linspace(1, -1, 8).view(1, 1, 2, 4), torch.tensor([1., .5]), None, torch.tensor([0., -.5]), True)
+    np.savez(os.path.join(OUT, "selective_scan_kat1.npz"), y=y.numpy())
+
+
+def gen_losses():
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    for tag, (shape, C, batch_dice) in {"3d": ((2, 9, 10, 11), 2, False), "2d": ((3, 24, 20), 4, True)}.items():
+        g = torch.Generator().manual_seed(11)
+        B, sp = shape[0], shape[1:]
+        logits = (torch.randn(B, C, *sp, generator=g) * 2).requires_grad_(True)
+        target = torch.randint(0, C, (B, 1, *sp), generator=g).to(torch.int16)
+        loss = DC_and_CE_loss({'batch_dice': batch_dice, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                              weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+        l = loss(logits, target)
+        (gl,) = torch.autograd.grad(l, logits)
+        # deep supervision on strided copies
+        outs = [logits.detach(), logits.detach()[(..., *([slice(None, None, 2)] * len(sp)))].contiguous()]
+        tgs = [target, target[(..., *([slice(None, None, 2)] * len(sp)))].contiguous()]
+        outs.append(outs[1][(..., *([slice(None, None, 2)] * len(sp)))].contiguous())
+        tgs.append(tgs[1][(..., *([slice(None, None, 2)] * len(sp)))].contiguous())
+        w = np.array([1, 0.5, 0.0])
+        w = w / w.sum()
+        lds = DeepSupervisionWrapper(loss, w)(outs, tgs)
+        np.savez_compressed(os.path.join(OUT, f"loss_{tag}.npz"), logits=logits.detach().numpy(), target=target.numpy(),
+                            loss=l.detach().numpy(), dlogits=gl.numpy(), ds_loss=lds.detach().numpy(), ds_weights=w,
+                            batch_dice=np.array(batch_dice))
+
+
+def gen_window_attention():
+    from nnunetv2.nets import swt2net
+    for tag, (dim, heads, shift, HW) in {"s": (32, 2, True, 14), "n": (64, 4, False, 21)}.items():
+        m = swt2net.WindowAttention(dim=dim, window_size=7, num_heads=heads, shift=shift)
+        det_fill(m)
+        m.eval()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, HW, HW, dim, generator=g, requires_grad=True)
+        y = m(x)
+        dy = torch.randn(y.shape, generator=g)
+        params = [p for _, p in m.named_parameters()]
+        grads = torch.autograd.grad(y, [x] + params, dy)
+        np.savez_compressed(os.path.join(OUT, f"window_attention_{tag}.npz"), x=x.detach().numpy(), y=y.detach().numpy(),
+                            dy=dy.numpy(), dx=grads[0].numpy(), cfg=np.array([dim, heads, int(shift), HW]),
+                            **{"g_" + n: gr.numpy() for (n, _), gr in zip(m.named_parameters(), grads[1:])})
+    # KAT-4 of SURVEY.md §8c
+    m = swt2net.WindowAttention(dim=4, window_size=7, num_heads=2, shift=True).eval()
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            p.copy_(torch.linspace(-.5, .5, p.numel()).view_as(p))
+    out = m(torch.linspace(-1, 1, 784).view(1, 14, 14, 4))
+    np.savez(os.path.join(OUT, "window_attention_kat4.npz"), out=out.detach().numpy())
+    # a whole SwinTransformerBlock incl. the top/left padding quirk (19 is not a multiple of 7)
+    blk = swt2net.SwinTransformerBlock(dim=32, num_heads=2, window_size=7, shift=True, drop_path=0.0) \
+        if "shift" in swt2net.SwinTransformerBlock.__init__.__code__.co_varnames else None
+    if blk is not None:
+        det_fill(blk)
+        blk.eval()
+        x = torch.randn(1, 19, 19, 32, generator=torch.Generator().manual_seed(5))
+        np.savez_compressed(os.path.join(OUT, "swin_block.npz"), x=x.numpy(), y=blk(x).detach().numpy())
+
+
+def gen_ss2d():
+    from nnunetv2.nets import m2net
+    m = m2net.SS2D(d_model=16)
+    det_fill(m)
+    m.eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 12, 10, 16, generator=g, requires_grad=True)
+    y = m(x)
+    dy = torch.randn(y.shape, generator=g)
+    params = list(m.named_parameters())
+    grads = torch.autograd.grad(y, [x] + [p for _, p in params], dy)
+    np.savez_compressed(os.path.join(OUT, "ss2d.npz"), x=x.detach().numpy(), y=y.detach().numpy(), dy=dy.numpy(),
+                        dx=grads[0].numpy(), names=np.array([n for n, _ in params]),
+                        **{"g_" + n: gr.numpy() for (n, _), gr in zip(params, grads[1:])})
+
+
+def gen_nets():
+    from nnunetv2.nets import m2net, swt2net
+    man = {}
+    for name, ctor, size in [("M2NetP", lambda: m2net.M2NetP(1, 2, True), 64), ("SwT2Net", lambda: swt2net.SwT2Net(1, 2, True), 64)]:
+        torch.manual_seed(0)
+        net = ctor()
+        det_fill(net)
+        net.eval()
+        x = torch.randn(1, 1, size, size, generator=torch.Generator().manual_seed(21))
+        with torch.no_grad():
+            outs = net(x)
+        np.savez_compressed(os.path.join(OUT, f"net_{name}_{size}.npz"), x=x.numpy(),
+                            **{f"out{i}": o.numpy() for i, o in enumerate(outs)})
+        man[name] = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    torch.manual_seed(0)
+    man["M2Net"] = [(k, tuple(v.shape)) for k, v in m2net.M2Net(1, 2, True).state_dict().items()]
+    import json
+    with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
+        json.dump({k: [[n, list(s)] for n, s in v] for k, v in man.items()}, f)
+
+
+if __name__ == "__main__":
+    ref = ref_shim.install()
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "nets"]
+    if "scan" in which:
+        gen_selective_scan(ref)
+    if "loss" in which:
+        gen_losses()
+    if "attn" in which:
+        gen_window_attention()
+    if "ss2d" in which:
+        gen_ss2d()
+    if "nets" in which:
+        gen_nets()
+    print(sorted(os.listdir(OUT)))
