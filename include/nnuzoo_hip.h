@@ -79,6 +79,24 @@ int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t*
 int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
                             void* dlogits, int B, int C, long V, void* stream);
 
+/* ---- selective scan (Mamba S6), fp32, N = 16, B/C of shape (B, K, N, L), z = None ----------------------------
+ * replaces mamba_ssm's selective_scan_cuda.fwd/bwd behind selective_scan_fn as called at
+ * nnunetv2/nets/m2net.py:193-199 and ssnd2net.py:271-277 (definition: selective_scan_ref,
+ * nnunetv2/nets/seg_mamba/selective_scan_interface.py:86-152).  u, delta, y: (B, K*Dg, L); A: (K*Dg, N).
+ * chunk_state (forward checkpoints, kept for backward) and grad_state: nnz_selective_scan_state_floats floats;
+ * workspace: nnz_selective_scan_workspace_floats floats. */
+long nnz_selective_scan_workspace_floats(int Bt, int KD, int L);
+long nnz_selective_scan_state_floats(int Bt, int KD, int L);
+int nnz_selective_scan_forward(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
+                               const float* D, const float* delta_bias, float* y, float* chunk_state,
+                               float* workspace, int Bt, int K, int Dg, int N, int L, int delta_softplus,
+                               void* stream);
+int nnz_selective_scan_backward(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
+                                const float* D, const float* delta_bias, const float* dy, const float* chunk_state,
+                                float* grad_state, float* workspace, float* du, float* ddelta, float* dA, float* dB,
+                                float* dC, float* dD, float* dbias, int Bt, int K, int Dg, int N, int L,
+                                int delta_softplus, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,8 +76,13 @@ SIGNATURES = {
     "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _vp],
     "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _vp],
     "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _vp],
+    "nnz_selective_scan_workspace_floats": [_i, _i, _i],
+    "nnz_selective_scan_state_floats": [_i, _i, _i],
+    "nnz_selective_scan_forward": [_fp] * 10 + [_i] * 6 + [_vp],
+    "nnz_selective_scan_backward": [_fp] * 18 + [_i] * 6 + [_vp],
 }
 
+_LONG_RESULT = {"nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats"}
 _lib = None
 
 
@@ -94,7 +99,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_long if name in _LONG_RESULT else C.c_int
     _lib = lib
     return lib
 

@@ -1,0 +1,525 @@
+// Selective scan (Mamba S6 recurrence) forward + backward as a wavefront-parallel chunk scan on gfx950.
+// Replaces mamba_ssm's `selective_scan_cuda.fwd/bwd` behind `selective_scan_fn` as called by the reference's SS2D /
+// SSND blocks (/root/reference/nnunetv2/nets/m2net.py:193-199, ssnd2net.py:271-277; semantics = the in-tree
+// selective_scan_ref, nets/seg_mamba/selective_scan_interface.py:86-152): real A, B/C of shape (B, K, N, L), z = None,
+//     dl = softplus(delta + bias);  h_t = exp(dl_t A) h_{t-1} + dl_t B_t u_t;  y_t = <h_t, C_t> + D u_t.
+//
+// Design (MI355X-first; HBM-bound, fp32, N = 16):
+//   * Time on the lanes: a wave owns 256 consecutive steps of one (b, d) row (4 per lane), so u / delta / y move as
+//     fully coalesced 16-byte-per-lane accesses; the affine pairs (a, b) are combined in-lane, then across the 64
+//     lanes by a 6-step DPP scan (row_shr 1/2/4/8, row_bcast15, row_bcast31: no LDS traffic, no bpermute).
+//   * L up to 262 144 with only a few hundred (b, d) rows: the sequence is cut into 256-step chunks that run in
+//     parallel; pass 1 reduces every chunk to its affine summary, a tiny carry kernel scans the summaries, pass 3
+//     replays the chunk from its true entry state.  The entry states are kept as the backward's checkpoints.
+//   * B_t / C_t are shared by all D channels of a direction group: a workgroup stages the chunk's [16][256] B and C
+//     tiles in LDS once and loops its 4 waves over the group's channels (the stock kernel re-reads them per channel).
+//   * Backward: same structure run in reverse for g_t = C_t dy_t + a_{t+1} g_{t+1}; h is recomputed per chunk from
+//     the checkpoint; dB / dC are reduced over the group's channels in LDS and leave the workgroup as one atomic
+//     add per element; dA / dD / dbias by wave reduction + one atomic per (row, chunk).
+#include "common.hpp"
+
+namespace nnz {
+
+constexpr int SS_N = 16;
+constexpr int SS_KI = 4;
+constexpr int SS_CL = 64 * SS_KI;  // chunk length
+constexpr int SS_NW = 4;           // waves per workgroup
+
+struct ScanArgs {
+  const float* u;      // [B][KD][L]
+  const float* delta;  // [B][KD][L]
+  const float* A;      // [KD][N]
+  const float* Bm;     // [B][K][N][L]
+  const float* Cm;     // [B][K][N][L]
+  const float* D;      // [KD] or null
+  const float* bias;   // [KD] or null
+  float* y;            // [B][KD][L]
+  float* P;            // [rows][N][nchunks]   chunk summaries (multiplier)
+  float* S;            // [rows][N][nchunks]   chunk summaries (offset)
+  float* Hin;          // [rows][nchunks][N]   state entering each chunk (forward checkpoints)
+  float* Gin;          // [rows][nchunks][N]   gradient state entering each chunk from the right
+  const float* dy;     // [B][KD][L]
+  float* du;
+  float* ddelta;
+  float* dA;           // [KD][N]   (atomic, zeroed by launcher)
+  float* dB;           // [B][K][N][L] (atomic)
+  float* dC;
+  float* dD;           // [KD]
+  float* dbias;        // [KD]
+  int Bt, K, Dg, KD, L, nchunks;
+  int rows_per_wg;     // multiple of SS_NW, divides Dg
+  int softplus;
+};
+
+// ---- DPP helpers -----------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                CTRL, ROW_MASK, 0xF, false));
+}
+
+// inclusive scan over the 64 lanes of the affine maps x -> a x + b (lower lanes applied first)
+__device__ __forceinline__ void wave_scan_affine(float& a, float& b) {
+#define NNZ_STEP(CTRL, MASK)                       \
+  {                                                \
+    const float pa = dpp<CTRL, MASK>(1.f, a);      \
+    const float pb = dpp<CTRL, MASK>(0.f, b);      \
+    b = a * pb + b;                                \
+    a = a * pa;                                    \
+  }
+  NNZ_STEP(0x111, 0xF)  // row_shr:1
+  NNZ_STEP(0x112, 0xF)  // row_shr:2
+  NNZ_STEP(0x114, 0xF)  // row_shr:4
+  NNZ_STEP(0x118, 0xF)  // row_shr:8
+  NNZ_STEP(0x142, 0xA)  // row_bcast:15 -> rows 1, 3
+  NNZ_STEP(0x143, 0xC)  // row_bcast:31 -> rows 2, 3
+#undef NNZ_STEP
+}
+
+// inclusive SUFFIX scan (higher lanes applied first): lane l gets F_l o F_{l+1} o ... o F_63
+__device__ __forceinline__ void wave_rscan_affine(float& a, float& b, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float pa = __shfl_down(a, off, 64);
+    float pb = __shfl_down(b, off, 64);
+    if (lane + off >= 64) {
+      pa = 1.f;
+      pb = 0.f;
+    }
+    b = a * pb + b;
+    a = a * pa;
+  }
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+
+// load 4 consecutive elements of a row starting at t (vector when the row is 16-byte aligned and fully in range)
+__device__ __forceinline__ void load4(const float* row, int t, int L, bool vec, float (&v)[SS_KI]) {
+  if (vec && t + SS_KI <= L) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(row + t);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i) v[i] = (t + i < L) ? row[t + i] : 0.f;
+  }
+}
+__device__ __forceinline__ void store4(float* row, int t, int L, bool vec, const float (&v)[SS_KI]) {
+  if (vec && t + SS_KI <= L) {
+    f32x4 x = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(row + t) = x;
+  } else {
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i)
+      if (t + i < L) row[t + i] = v[i];
+  }
+}
+
+// stage the [N][CL] tile of one (b, k) group for chunk c into LDS (zero beyond L)
+__device__ __forceinline__ void stage_tile(const float* src /* [N][L] */, float* dst /* [N][CL] */, int t0, int L) {
+  for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
+    const int n = i / SS_CL, tt = i % SS_CL;
+    const int t = t0 + tt;
+    dst[i] = t < L ? src[(long)n * L + t] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: FINAL = false -> chunk summaries (P, S); FINAL = true -> y from the entry state Hin
+// ---------------------------------------------------------------------------------------------------------------
+template <bool FINAL>
+__global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) float sB[SS_N * SS_CL];
+  __shared__ __attribute__((aligned(16))) float sC[FINAL ? SS_N * SS_CL : 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c = blockIdx.x;                  // chunk
+  const int wgs_per_group = a.Dg / a.rows_per_wg;
+  const int grp = blockIdx.y / wgs_per_group;  // b*K + k
+  const int sub = blockIdx.y % wgs_per_group;
+  const int b = grp / a.K, k = grp % a.K;
+  const int t0 = c * SS_CL;
+  const int t = t0 + lane * SS_KI;
+  const bool vec = (a.L & 3) == 0;
+
+  stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
+  if (FINAL) stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
+  __syncthreads();
+
+  for (int r = sub * a.rows_per_wg + wave; r < (sub + 1) * a.rows_per_wg; r += SS_NW) {
+    const int kd = k * a.Dg + r;
+    const long row = (long)b * a.KD + kd;
+    float u[SS_KI], dl[SS_KI], yv[SS_KI];
+    load4(a.u + row * a.L, t, a.L, vec, u);
+    load4(a.delta + row * a.L, t, a.L, vec, dl);
+    const float bias = a.bias ? a.bias[kd] : 0.f;
+    const float Dv = a.D ? a.D[kd] : 0.f;
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i) {
+      float d = dl[i] + bias;
+      if (a.softplus) d = softplus_f(d);
+      dl[i] = (t + i < a.L) ? d : 0.f;  // identity step beyond L
+      yv[i] = Dv * u[i];
+    }
+    const float* Arow = a.A + (long)kd * SS_N;
+    const float* hin = FINAL ? a.Hin + (row * a.nchunks + c) * SS_N : nullptr;
+#pragma unroll 4
+    for (int n = 0; n < SS_N; ++n) {
+      const float An = Arow[n];
+      const f32x4 Bv = *reinterpret_cast<const f32x4*>(sB + n * SS_CL + lane * SS_KI);
+      float ai[SS_KI], bi[SS_KI];
+#pragma unroll
+      for (int i = 0; i < SS_KI; ++i) {
+        ai[i] = __expf(dl[i] * An);
+        bi[i] = dl[i] * u[i] * Bv[i];
+      }
+      float pa = ai[0], pb = bi[0];
+#pragma unroll
+      for (int i = 1; i < SS_KI; ++i) {
+        pb = ai[i] * pb + bi[i];
+        pa *= ai[i];
+      }
+      wave_scan_affine(pa, pb);
+      if (!FINAL) {
+        if (lane == 63) {
+          a.P[(row * SS_N + n) * a.nchunks + c] = pa;
+          a.S[(row * SS_N + n) * a.nchunks + c] = pb;
+        }
+      } else {
+        float ea = __shfl_up(pa, 1, 64), eb = __shfl_up(pb, 1, 64);
+        if (lane == 0) {
+          ea = 1.f;
+          eb = 0.f;
+        }
+        float h = ea * hin[n] + eb;
+        const f32x4 Cv = *reinterpret_cast<const f32x4*>(sC + n * SS_CL + lane * SS_KI);
+#pragma unroll
+        for (int i = 0; i < SS_KI; ++i) {
+          h = ai[i] * h + bi[i];
+          yv[i] += Cv[i] * h;
+        }
+      }
+    }
+    if (FINAL) store4(a.y + row * a.L, t, a.L, vec, yv);
+  }
+}
+
+// carry over the chunk summaries.  One wave per (row, n); lanes split the chunks.
+//   forward : X[0] = 0, X[c+1] = P[c] X[c] + S[c]          -> out[row][c][n] = X[c]
+//   reverse : X[nch-1] = 0, X[c-1] = P[c] X[c] + S[c]      -> out[row][c][n] = X[c]
+template <bool REVERSE>
+__global__ __launch_bounds__(256) void scan_carry_kernel(const float* __restrict__ P, const float* __restrict__ S,
+                                                         float* __restrict__ out, long rows_n, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (row * N + n)
+  if (w >= rows_n) return;
+  const long row = w / SS_N;
+  const int n = w % SS_N;
+  const float* p = P + w * nchunks;
+  const float* s = S + w * nchunks;
+  const int cpl = (nchunks + 63) / 64;
+  // position j = 0 .. nchunks-1 in processing order; chunk index c = REVERSE ? nchunks-1-j : j
+  const int j0 = lane * cpl;
+  float pa = 1.f, pb = 0.f;
+  for (int j = j0; j < j0 + cpl && j < nchunks; ++j) {
+    const int c = REVERSE ? nchunks - 1 - j : j;
+    pb = p[c] * pb + s[c];
+    pa = p[c] * pa;
+  }
+  wave_scan_affine(pa, pb);
+  float eb = __shfl_up(pb, 1, 64);
+  if (lane == 0) eb = 0.f;
+  float x = eb;  // X at processing position j0 (entry value is 0, so only the offset part matters)
+  for (int j = j0; j < j0 + cpl && j < nchunks; ++j) {
+    const int c = REVERSE ? nchunks - 1 - j : j;
+    out[(row * nchunks + c) * SS_N + n] = x;
+    x = p[c] * x + s[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward: FINAL = false -> reverse chunk summaries; FINAL = true -> all gradients
+// reverse recurrence  g_t = a_{t+1} g_{t+1} + C_t dy_t
+// ---------------------------------------------------------------------------------------------------------------
+template <bool FINAL>
+__global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) float sB[FINAL ? SS_N * SS_CL : 4];
+  __shared__ __attribute__((aligned(16))) float sC[SS_N * SS_CL];
+  __shared__ __attribute__((aligned(16))) float sdB[FINAL ? SS_N * SS_CL : 4];
+  __shared__ __attribute__((aligned(16))) float sdC[FINAL ? SS_N * SS_CL : 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c = blockIdx.x;
+  const int wgs_per_group = a.Dg / a.rows_per_wg;
+  const int grp = blockIdx.y / wgs_per_group;
+  const int sub = blockIdx.y % wgs_per_group;
+  const int b = grp / a.K, k = grp % a.K;
+  const int t0 = c * SS_CL;
+  const int t = t0 + lane * SS_KI;
+  const bool vec = (a.L & 3) == 0;
+
+  stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
+  if (FINAL) {
+    stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
+    for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
+      sdB[i] = 0.f;
+      sdC[i] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  for (int r = sub * a.rows_per_wg + wave; r < (sub + 1) * a.rows_per_wg; r += SS_NW) {
+    const int kd = k * a.Dg + r;
+    const long row = (long)b * a.KD + kd;
+    float u[SS_KI], draw[SS_KI], dl[SS_KI], dyv[SS_KI];
+    load4(a.delta + row * a.L, t, a.L, vec, draw);
+    load4(a.dy + row * a.L, t, a.L, vec, dyv);
+    const float bias = a.bias ? a.bias[kd] : 0.f;
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i) {
+      float d = draw[i] + bias;
+      draw[i] = d;
+      if (a.softplus) d = softplus_f(d);
+      dl[i] = (t + i < a.L) ? d : 0.f;
+    }
+    // dl of the step right after this lane's items (first item of lane+1; for lane 63 the next chunk's first step)
+    float dl_next = __shfl_down(dl[0], 1, 64);
+    if (lane == 63) {
+      const int tn = t0 + SS_CL;
+      float d = 0.f;
+      if (tn < a.L) {
+        d = a.delta[row * a.L + tn] + bias;
+        if (a.softplus) d = softplus_f(d);
+      }
+      dl_next = d;
+    }
+    float duv[SS_KI], ddl[SS_KI];
+    if (FINAL) {
+      load4(a.u + row * a.L, t, a.L, vec, u);
+      const float Dv = a.D ? a.D[kd] : 0.f;
+#pragma unroll
+      for (int i = 0; i < SS_KI; ++i) {
+        duv[i] = Dv * dyv[i];
+        ddl[i] = 0.f;
+      }
+    }
+    const float* Arow = a.A + (long)kd * SS_N;
+    const float* hin = FINAL ? a.Hin + (row * a.nchunks + c) * SS_N : nullptr;
+    const float* gin = FINAL ? a.Gin + (row * a.nchunks + c) * SS_N : nullptr;
+#pragma unroll 2
+    for (int n = 0; n < SS_N; ++n) {
+      const float An = Arow[n];
+      const f32x4 Cv = *reinterpret_cast<const f32x4*>(sC + n * SS_CL + lane * SS_KI);
+      float ai[SS_KI + 1];
+#pragma unroll
+      for (int i = 0; i < SS_KI; ++i) ai[i] = __expf(dl[i] * An);
+      ai[SS_KI] = __expf(dl_next * An);
+      // F(g) = g of this lane's first item as a function of the g entering after its last item:
+      //   G_i(g) = ai[i+1] * g + C_i dy_i,  F = G_0 o G_1 o ... o G_{K-1}, built from the inside (i = K-1) outwards
+      float ra, rb;
+      {
+        float fa = 1.f, fb = 0.f;  // identity, will become F
+#pragma unroll
+        for (int i = SS_KI - 1; i >= 0; --i) {
+          // F_new(g) = G_i(F_old(g))
+          fb = ai[i + 1] * fb + Cv[i] * dyv[i];
+          fa = ai[i + 1] * fa;
+        }
+        ra = fa;
+        rb = fb;
+      }
+      if (!FINAL) {
+        wave_rscan_affine(ra, rb, lane);
+        if (lane == 0) {
+          a.P[(row * SS_N + n) * a.nchunks + c] = ra;
+          a.S[(row * SS_N + n) * a.nchunks + c] = rb;
+        }
+        continue;
+      }
+      // ---- forward recompute of h over the chunk ------------------------------------------------------------
+      const f32x4 Bv = *reinterpret_cast<const f32x4*>(sB + n * SS_CL + lane * SS_KI);
+      float bi[SS_KI];
+#pragma unroll
+      for (int i = 0; i < SS_KI; ++i) bi[i] = dl[i] * u[i] * Bv[i];
+      float pa = ai[0], pb = bi[0];
+#pragma unroll
+      for (int i = 1; i < SS_KI; ++i) {
+        pb = ai[i] * pb + bi[i];
+        pa *= ai[i];
+      }
+      wave_scan_affine(pa, pb);
+      float ea = __shfl_up(pa, 1, 64), eb = __shfl_up(pb, 1, 64);
+      if (lane == 0) {
+        ea = 1.f;
+        eb = 0.f;
+      }
+      float hprev[SS_KI], hcur[SS_KI];
+      float h = ea * hin[n] + eb;
+#pragma unroll
+      for (int i = 0; i < SS_KI; ++i) {
+        hprev[i] = h;
+        h = ai[i] * h + bi[i];
+        hcur[i] = h;
+      }
+      // ---- reverse scan of g -------------------------------------------------------------------------------
+      wave_rscan_affine(ra, rb, lane);
+      float xa = __shfl_down(ra, 1, 64), xb = __shfl_down(rb, 1, 64);
+      if (lane == 63) {
+        xa = 1.f;
+        xb = 0.f;
+      }
+      float g = xa * gin[n] + xb;  // g of the first item of lane+1 (or of the next chunk)
+      float dAn = 0.f;
+      float dBv[SS_KI], dCv[SS_KI];
+#pragma unroll
+      for (int i = SS_KI - 1; i >= 0; --i) {
+        g = ai[i + 1] * g + Cv[i] * dyv[i];  // g_i
+        dCv[i] = dyv[i] * hcur[i];
+        dBv[i] = g * dl[i] * u[i];
+        duv[i] += g * dl[i] * Bv[i];
+        const float gah = g * ai[i] * hprev[i];
+        ddl[i] += g * Bv[i] * u[i] + An * gah;
+        dAn += dl[i] * gah;
+      }
+#pragma unroll
+      for (int i = 0; i < SS_KI; ++i) {
+        atomicAdd(&sdB[n * SS_CL + lane * SS_KI + i], dBv[i]);
+        atomicAdd(&sdC[n * SS_CL + lane * SS_KI + i], dCv[i]);
+      }
+      dAn = wave_sum(dAn);
+      if (lane == 0) atomicAdd(a.dA + (long)kd * SS_N + n, dAn);
+    }
+    if (FINAL) {
+      float sdb = 0.f, sdD = 0.f;
+      float dd[SS_KI];
+#pragma unroll
+      for (int i = 0; i < SS_KI; ++i) {
+        float gsp = 1.f;
+        if (a.softplus) gsp = draw[i] > 20.f ? 1.f : 1.f / (1.f + __expf(-draw[i]));
+        dd[i] = (t + i < a.L) ? ddl[i] * gsp : 0.f;
+        sdb += dd[i];
+        sdD += dyv[i] * u[i];
+      }
+      store4(a.du + row * a.L, t, a.L, vec, duv);
+      store4(a.ddelta + row * a.L, t, a.L, vec, dd);
+      sdb = wave_sum(sdb);
+      sdD = wave_sum(sdD);
+      if (lane == 0) {
+        if (a.dbias) atomicAdd(a.dbias + kd, sdb);
+        if (a.dD) atomicAdd(a.dD + kd, sdD);
+      }
+    }
+  }
+  if (FINAL) {
+    __syncthreads();
+    float* gB = a.dB + (long)grp * SS_N * a.L;
+    float* gC = a.dC + (long)grp * SS_N * a.L;
+    for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
+      const int n = i / SS_CL, tt = i % SS_CL;
+      if (t0 + tt < a.L) {
+        atomicAdd(gB + (long)n * a.L + t0 + tt, sdB[i]);
+        atomicAdd(gC + (long)n * a.L + t0 + tt, sdC[i]);
+      }
+    }
+  }
+}
+
+static int pick_rows_per_wg(int Dg, long groups_chunks) {
+  // whole group per workgroup when there are plenty of (group, chunk) pairs, else split the group's channels
+  int r = Dg;
+  while (r > SS_NW && groups_chunks * (Dg / r) < 1024 && (r / 2) % SS_NW == 0) r /= 2;
+  return r;
+}
+
+static int check(const ScanArgs& a) {
+  if (a.Bt < 1 || a.K < 1 || a.Dg < SS_NW || a.Dg % SS_NW || a.KD != a.K * a.Dg || a.L < 1) return NNZ_EINVAL;
+  return NNZ_OK;
+}
+
+}  // namespace nnz
+
+extern "C" long nnz_selective_scan_workspace_floats(int Bt, int KD, int L) {
+  const long nch = (L + nnz::SS_CL - 1) / nnz::SS_CL;
+  return 2L * Bt * KD * nnz::SS_N * nch;  // P and S
+}
+extern "C" long nnz_selective_scan_state_floats(int Bt, int KD, int L) {
+  const long nch = (L + nnz::SS_CL - 1) / nnz::SS_CL;
+  return (long)Bt * KD * nnz::SS_N * nch;  // Hin (and Gin)
+}
+
+extern "C" int nnz_selective_scan_forward(const float* u, const float* delta, const float* A, const float* Bm,
+                                          const float* Cm, const float* D, const float* delta_bias, float* y,
+                                          float* chunk_state, float* workspace, int Bt, int K, int Dg, int N, int L,
+                                          int delta_softplus, void* stream) {
+  using namespace nnz;
+  if (!u || !delta || !A || !Bm || !Cm || !y || !chunk_state || !workspace || N != SS_N) return NNZ_EINVAL;
+  ScanArgs a = {};
+  a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.y = y;
+  a.Bt = Bt; a.K = K; a.Dg = Dg; a.KD = K * Dg; a.L = L; a.softplus = delta_softplus;
+  if (int rc = check(a)) return rc;
+  a.nchunks = (L + SS_CL - 1) / SS_CL;
+  const long rows = (long)Bt * a.KD;
+  a.P = workspace;
+  a.S = workspace + rows * SS_N * a.nchunks;
+  a.Hin = chunk_state;
+  a.rows_per_wg = pick_rows_per_wg(Dg, (long)Bt * K * a.nchunks);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(a.nchunks, Bt * K * (Dg / a.rows_per_wg));
+  if (a.nchunks > 1) {
+    hipLaunchKernelGGL(scan_fwd_kernel<false>, grid, dim3(SS_NW * 64), 0, s, a);
+    NNZ_LAUNCH_CHECK();
+    const long rows_n = rows * SS_N;
+    hipLaunchKernelGGL(scan_carry_kernel<false>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Hin,
+                       rows_n, a.nchunks);
+    NNZ_LAUNCH_CHECK();
+  } else {
+    hipError_t e = hipMemsetAsync(a.Hin, 0, sizeof(float) * rows * SS_N, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(scan_fwd_kernel<true>, grid, dim3(SS_NW * 64), 0, s, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_selective_scan_backward(const float* u, const float* delta, const float* A, const float* Bm,
+                                           const float* Cm, const float* D, const float* delta_bias, const float* dy,
+                                           const float* chunk_state, float* grad_state, float* workspace, float* du,
+                                           float* ddelta, float* dA, float* dB, float* dC, float* dD, float* dbias,
+                                           int Bt, int K, int Dg, int N, int L, int delta_softplus, void* stream) {
+  using namespace nnz;
+  if (!u || !delta || !A || !Bm || !Cm || !dy || !chunk_state || !grad_state || !workspace || !du || !ddelta || !dA ||
+      !dB || !dC || N != SS_N)
+    return NNZ_EINVAL;
+  ScanArgs a = {};
+  a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.dy = dy;
+  a.du = du; a.ddelta = ddelta; a.dA = dA; a.dB = dB; a.dC = dC; a.dD = dD; a.dbias = dbias;
+  a.Bt = Bt; a.K = K; a.Dg = Dg; a.KD = K * Dg; a.L = L; a.softplus = delta_softplus;
+  if (int rc = check(a)) return rc;
+  a.nchunks = (L + SS_CL - 1) / SS_CL;
+  const long rows = (long)Bt * a.KD;
+  a.P = workspace;
+  a.S = workspace + rows * SS_N * a.nchunks;
+  a.Hin = const_cast<float*>(chunk_state);
+  a.Gin = grad_state;
+  a.rows_per_wg = pick_rows_per_wg(Dg, (long)Bt * K * a.nchunks);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if ((e = hipMemsetAsync(dA, 0, sizeof(float) * a.KD * SS_N, s)) != hipSuccess) return (int)e;
+  if ((e = hipMemsetAsync(dB, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
+  if ((e = hipMemsetAsync(dC, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
+  if (dD && (e = hipMemsetAsync(dD, 0, sizeof(float) * a.KD, s)) != hipSuccess) return (int)e;
+  if (dbias && (e = hipMemsetAsync(dbias, 0, sizeof(float) * a.KD, s)) != hipSuccess) return (int)e;
+  dim3 grid(a.nchunks, Bt * K * (Dg / a.rows_per_wg));
+  if (a.nchunks > 1) {
+    hipLaunchKernelGGL(scan_bwd_kernel<false>, grid, dim3(SS_NW * 64), 0, s, a);
+    NNZ_LAUNCH_CHECK();
+    const long rows_n = rows * SS_N;
+    hipLaunchKernelGGL(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin,
+                       rows_n, a.nchunks);
+    NNZ_LAUNCH_CHECK();
+  } else {
+    if ((e = hipMemsetAsync(a.Gin, 0, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(scan_bwd_kernel<true>, grid, dim3(SS_NW * 64), 0, s, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
