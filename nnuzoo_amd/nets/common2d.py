@@ -1,0 +1,157 @@
+"""Building blocks shared by the X^2-Net zoo models (M2Net / SS2D^2Net and SwT2Net): the U^2-Net residual conv
+blocks, patch merge/expand and small helpers.  Same class names, constructor arguments, sub-module names and
+parameter shapes as the reference so that state_dicts interchange:
+  REBNCONV, RSU4F            /root/reference/nnunetv2/nets/m2net.py:18-30, 769-801 (== swt2net.py:17-31, 873-905)
+  PatchMerging2D, PatchExpand  m2net.py:228-319
+  _upsample_like             m2net.py:33-36 (bilinear, align_corners=False)
+  Convolution(conv_only)     monai.networks.blocks.Convolution as used at swt2net.py:1058-1066: an nn.Sequential whose
+                             only child is named `conv`
+  DropPath                   timm.layers.DropPath (m2net) - per-sample stochastic depth
+These are thin wrappers over library ops (cuDNN/MIOpen-class convs, rocBLAS GEMMs, LayerNorm); the hand-written
+kernels of the zoo path are the selective scan and the window-attention core.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+
+class Convolution(nn.Sequential):
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, strides=1, kernel_size=3, bias=True,
+                 conv_only: bool = True, groups: int = 1, dilation: int = 1, padding=None):
+        super().__init__()
+        if not conv_only:
+            raise NotImplementedError("only the conv_only form is used by the zoo")
+        conv = {2: nn.Conv2d, 3: nn.Conv3d}[spatial_dims]
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        pad = (k - 1) // 2 * dilation if padding is None else padding
+        self.add_module("conv", conv(in_channels, out_channels, kernel_size, strides, pad, dilation, groups, bias))
+
+
+def get_dwconv_layer(spatial_dims: int, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1,
+                     bias: bool = False):
+    depth = Convolution(spatial_dims, in_channels, in_channels, strides=stride, kernel_size=kernel_size, bias=bias,
+                        conv_only=True, groups=in_channels)
+    point = Convolution(spatial_dims, in_channels, out_channels, strides=stride, kernel_size=1, bias=bias,
+                        conv_only=True, groups=1)
+    return nn.Sequential(depth, point)
+
+
+def _upsample_like(src, tar_shape):
+    return F.interpolate(src, size=tar_shape, mode='bilinear', align_corners=False)
+
+
+class REBNCONV(nn.Module):
+    def __init__(self, in_ch=3, out_ch=3, dirate=1):
+        super().__init__()
+        self.conv_s1 = nn.Conv2d(in_ch, out_ch, 3, padding=dirate, dilation=dirate)
+        self.bn_s1 = nn.BatchNorm2d(out_ch)
+        self.relu_s1 = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu_s1(self.bn_s1(self.conv_s1(x)))
+
+
+class RSU4F(nn.Module):
+    """dilated residual U block (dilations 1, 2, 4, 8 and back).  `block` is the conv-BN-ReLU unit: the dilated
+    REBNCONV of m2net.py, or the depthwise-separable (dilation-free) one swt2net.py:17-31 defines under the same name."""
+    block = REBNCONV
+
+    def __init__(self, in_ch=3, mid_ch=12, out_ch=3):
+        super().__init__()
+        B = self.block
+        self.rebnconvin = B(in_ch, out_ch, dirate=1)
+        self.rebnconv1 = B(out_ch, mid_ch, dirate=1)
+        self.rebnconv2 = B(mid_ch, mid_ch, dirate=2)
+        self.rebnconv3 = B(mid_ch, mid_ch, dirate=4)
+        self.rebnconv4 = B(mid_ch, mid_ch, dirate=8)
+        self.rebnconv3d = B(mid_ch * 2, mid_ch, dirate=4)
+        self.rebnconv2d = B(mid_ch * 2, mid_ch, dirate=2)
+        self.rebnconv1d = B(mid_ch * 2, out_ch, dirate=1)
+
+    def forward(self, x):
+        xin = self.rebnconvin(x)
+        e1 = self.rebnconv1(xin)
+        e2 = self.rebnconv2(e1)
+        e3 = self.rebnconv3(e2)
+        e4 = self.rebnconv4(e3)
+        d3 = self.rebnconv3d(torch.cat((e4, e3), 1))
+        d2 = self.rebnconv2d(torch.cat((d3, e2), 1))
+        d1 = self.rebnconv1d(torch.cat((d2, e1), 1))
+        return d1 + xin
+
+
+class PatchMerging2D(nn.Module):
+    """scale x scale space-to-depth -> LayerNorm -> Linear (token-major in/out; `permute` for NCHW callers)."""
+
+    def __init__(self, input_dim: int, scale: int, output_features: int = None, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_feature_size = (scale ** 2) * input_dim
+        self.output_features = output_features or input_dim * scale
+        self.scale = scale
+        self.reduction = nn.Linear(self.input_feature_size, self.output_features, bias=False)
+        self.norm = norm_layer(self.input_feature_size)
+
+    def forward(self, x, permute=False):
+        if permute:
+            x = x.permute(0, 2, 3, 1)
+        B, H, W, C = x.shape
+        s = self.scale
+        Hs, Ws = H // s, W // s
+        if s != 2:
+            raise NotImplementedError("the zoo only merges 2x2 patches")
+        # channel order of the reference: (0,0), (1,0), (0,1), (1,1)  (m2net.py:254-267)
+        parts = [x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]]
+        x = torch.cat([p[:, :Hs, :Ws] for p in parts], -1)
+        x = self.reduction(self.norm(x))
+        if permute:
+            x = x.permute(0, 3, 1, 2).contiguous()
+        return x
+
+
+class PatchExpand(nn.Module):
+    """NCHW in -> token-major out.  output_dim None: Linear(dim -> scale*dim) then depth-to-space (dim/scale ch);
+    output_dim given: depth-to-space first (dim/scale^2 ch) then Linear to output_dim.  LayerNorm last."""
+
+    def __init__(self, dim: int, scale, output_dim: int = None, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim, self.scale, self.output_dim = dim, scale, output_dim
+        if output_dim is None:
+            self.expand = nn.Linear(dim, scale * dim, bias=False)
+            self.norm = norm_layer(dim // scale)
+        else:
+            self.expand = nn.Linear(dim // (scale ** 2), output_dim, bias=False)
+            self.norm = norm_layer(output_dim)
+
+    def _d2s(self, x):
+        B, H, W, C = x.shape
+        s = self.scale
+        c = C // (s * s)
+        return x.view(B, H, W, s, s, c).permute(0, 1, 3, 2, 4, 5).reshape(B, H * s, W * s, c)
+
+    def forward(self, x, permute=False):
+        x = x.permute(0, 2, 3, 1)
+        if self.output_dim is None:
+            x = self._d2s(self.expand(x))
+        else:
+            x = self.expand(self._d2s(x))
+        x = self.norm(x)
+        if permute:
+            x = x.permute(0, 3, 1, 2).contiguous()
+        return x

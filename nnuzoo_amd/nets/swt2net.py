@@ -1,0 +1,347 @@
+"""SwT2Net (Swin-transformer U^2-Net) for MI355X - same public classes, constructor signatures, sub-module /
+parameter / buffer names and shapes as /root/reference/nnunetv2/nets/swt2net.py, so checkpoints interchange:
+
+  PatchEmbedding :412-432, PatchMerging :435-464, PatchExpanding :467-478, FinalPatchExpanding :481-493, Mlp :496-515
+  WindowAttention :518-619 (incl. the int64 buffer `relative_position_index`)
+  SwinTransformerBlock :622-661 (pads TOP/LEFT to a multiple of 7 and crops from the end; shift mask -100)
+  BasicBlock / BasicBlockUp :664-740,  SwinTransformerUnet :743-869,  SwT2Net :909-1156
+  get_swt2net_from_plans :1372-1393
+
+The attention core (roll, window partition, per-head softmax(q k^T + bias + mask) v, merge, un-partition, roll back)
+is ONE hand-written gfx950 MFMA kernel (nnuzoo_amd.window_attention, csrc/window_attention.hip) in fp32, as the
+reference's Swin trainers run without autocast; qkv/proj/MLP Linears and LayerNorms are library ops.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..utilities.network_initialization import InitWeights_He
+from ..window_attention import window_attention_core
+from .common2d import Convolution, PatchExpand, PatchMerging2D, _upsample_like, get_dwconv_layer
+from .common2d import RSU4F as _RSU4F
+from .m2net import _U2Forward, _heads
+
+
+class REBNCONV(nn.Module):
+    """swt2net.py:17-31: depthwise 3x3 + pointwise 1x1 (both bias-free, `dirate` accepted but unused) -> BN -> ReLU"""
+
+    def __init__(self, in_ch=3, out_ch=3, dirate=1):
+        super().__init__()
+        self.conv_s1 = get_dwconv_layer(spatial_dims=2, in_channels=in_ch, out_channels=out_ch)
+        self.bn_s1 = nn.BatchNorm2d(out_ch)
+        self.relu_s1 = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu_s1(self.bn_s1(self.conv_s1(x)))
+
+
+class RSU4F(_RSU4F):
+    block = REBNCONV
+
+
+class DropPath(nn.Module):
+    """per-sample stochastic depth, floor(keep + U[0,1)) form of swt2net.py:395-409"""
+
+    def __init__(self, drop_prob: float = 0.):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)).floor_()
+        return x.div(keep) * mask
+
+
+class PatchEmbedding(nn.Module):
+    def __init__(self, patch_size: int = 4, in_c: int = 3, embed_dim: int = 96, norm_layer=None):
+        super().__init__()
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(in_c, embed_dim, kernel_size=(patch_size,) * 2, stride=(patch_size,) * 2)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def forward(self, x):
+        _, _, H, W = x.shape
+        p = self.patch_size
+        if H % p or W % p:
+            x = F.pad(x, (0, p - W % p, 0, p - H % p, 0, 0))  # right/bottom, full extra patch when one side divides
+        return self.norm(self.proj(x).permute(0, 2, 3, 1))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim: int, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.norm = norm_layer(4 * dim)
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+
+    def forward(self, x):
+        _, H, W, _ = x.shape
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        return self.reduction(self.norm(x))
+
+
+def _depth_to_space(x, p):
+    B, H, W, C = x.shape
+    c = C // (p * p)
+    return x.view(B, H, W, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(B, H * p, W * p, c)
+
+
+class PatchExpanding(nn.Module):
+    def __init__(self, dim: int, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.expand = nn.Linear(dim, 2 * dim, bias=False)
+        self.norm = norm_layer(dim // 2)
+
+    def forward(self, x):
+        return self.norm(_depth_to_space(self.expand(x), 2))
+
+
+class FinalPatchExpanding(nn.Module):
+    def __init__(self, dim: int, norm_layer=nn.LayerNorm, patch_size: int = 4):
+        super().__init__()
+        self.dim = dim
+        self.expand = nn.Linear(dim, (patch_size ** 2) * dim, bias=False)
+        self.norm = norm_layer(dim)
+        self.patch_size = patch_size
+
+    def forward(self, x):
+        return self.norm(_depth_to_space(self.expand(x), self.patch_size))
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features: int, hidden_features: int = None, out_features: int = None, act_layer=nn.GELU,
+                 drop: float = 0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.drop1 = nn.Dropout(drop)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop2 = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim: int, window_size: int, num_heads: int, qkv_bias: Optional[bool] = True,
+                 attn_drop: Optional[float] = 0., proj_drop: Optional[float] = 0., shift: bool = False):
+        super().__init__()
+        if window_size != 7:
+            raise NotImplementedError("the HIP window-attention kernel is specialised to the zoo's 7x7 windows")
+        if attn_drop:
+            raise NotImplementedError("attention dropout is 0 everywhere in the zoo and not implemented in the kernel")
+        self.window_size, self.num_heads = window_size, num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.shift_size = window_size // 2 if shift else 0
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * window_size - 1) ** 2, num_heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+        ar = torch.arange(window_size)
+        coords = torch.stack(torch.meshgrid([ar, ar], indexing="ij")).flatten(1)       # (2, 49)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + (window_size - 1)
+        self.register_buffer("relative_position_index", rel[:, :, 0] * (2 * window_size - 1) + rel[:, :, 1])
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.softmax = nn.Softmax(dim=-1)
+
+    def dense_bias(self) -> torch.Tensor:
+        L = self.window_size ** 2
+        return self.relative_position_bias_table[self.relative_position_index.view(-1)].view(L, L, -1) \
+            .permute(2, 0, 1).contiguous()
+
+    def forward(self, x):
+        """x: (B, H, W, C) with H, W multiples of the window size (the block pads)."""
+        qkv = self.qkv(x)  # per-token Linear: commutes with the roll / window partition the kernel folds in
+        out = window_attention_core(qkv, self.dense_bias(), self.num_heads, self.shift_size, self.scale)
+        return self.proj_drop(self.proj(out))
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size=7, shift=False, mlp_ratio=4., qkv_bias=True, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.window_size = window_size
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, window_size=window_size, num_heads=num_heads, qkv_bias=qkv_bias,
+                                    attn_drop=attn_drop, proj_drop=drop, shift=shift)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x):
+        _, H, W, _ = x.shape
+        ws = self.window_size
+        pad = H % ws != 0 or W % ws != 0
+        if pad:  # top/left padding, a full extra window on an axis that already divides (reference quirk, :643-645)
+            x = F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0))
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        return x[:, -H:, -W:, :] if pad else x
+
+
+def _stage_drop_path(depths, drop_path, index):
+    dpr = [r.item() for r in torch.linspace(0, drop_path, sum(depths))]
+    return dpr[sum(depths[:index]):sum(depths[:index + 1])]
+
+
+def _swin_blocks(dim, depth, num_head, window_size, mlp_ratio, qkv_bias, drop_rate, attn_drop_rate, rates, norm_layer):
+    return nn.ModuleList([
+        SwinTransformerBlock(dim=dim, num_heads=num_head, window_size=window_size, shift=bool(i % 2),
+                             mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate, attn_drop=attn_drop_rate,
+                             drop_path=rates[i], norm_layer=norm_layer) for i in range(depth)])
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, index: int, embed_dim: int = 96, window_size: int = 7, depths: tuple = (2, 2, 6, 2),
+                 num_heads: tuple = (3, 6, 12, 24), mlp_ratio: float = 4., qkv_bias: bool = True, drop_rate: float = 0.,
+                 attn_drop_rate: float = 0., drop_path: float = 0.1, norm_layer=nn.LayerNorm,
+                 patch_merging: bool = True):
+        super().__init__()
+        dim = embed_dim * 2 ** index
+        self.blocks = _swin_blocks(dim, depths[index], num_heads[index], window_size, mlp_ratio, qkv_bias, drop_rate,
+                                   attn_drop_rate, _stage_drop_path(depths, drop_path, index), norm_layer)
+        self.downsample = PatchMerging(dim=dim, norm_layer=norm_layer) if patch_merging else None
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return self.downsample(x) if self.downsample is not None else x
+
+
+class BasicBlockUp(nn.Module):
+    def __init__(self, index: int, embed_dim: int = 96, window_size: int = 7, depths: tuple = (2, 2, 6, 2),
+                 num_heads: tuple = (3, 6, 12, 24), mlp_ratio: float = 4., qkv_bias: bool = True, drop_rate: float = 0.,
+                 attn_drop_rate: float = 0., drop_path: float = 0.1, patch_expanding: bool = True,
+                 norm_layer=nn.LayerNorm):
+        super().__init__()
+        index = len(depths) - index - 2
+        dim = embed_dim * 2 ** index
+        self.blocks = _swin_blocks(dim, depths[index], num_heads[index], window_size, mlp_ratio, qkv_bias, drop_rate,
+                                   attn_drop_rate, _stage_drop_path(depths, drop_path, index), norm_layer)
+        self.upsample = PatchExpanding(dim=dim, norm_layer=norm_layer) if patch_expanding else nn.Identity()
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return self.upsample(x)
+
+
+class SwinTransformerUnet(nn.Module):
+    def __init__(self, patch_size: int = 4, in_ch: int = 3, out_ch: int = 1000, embed_dim: int = 96,
+                 window_size: int = 7, depths: tuple = (2, 2, 6, 2), num_heads: tuple = (3, 6, 12, 24),
+                 mlp_ratio: float = 4., qkv_bias: bool = True, drop_rate: float = 0., attn_drop_rate: float = 0.,
+                 drop_path_rate: float = 0.1, norm_layer=nn.LayerNorm, patch_norm: bool = True, add_last: bool = False):
+        super().__init__()
+        self.add_last, self.window_size, self.depths, self.num_heads = add_last, window_size, depths, num_heads
+        self.num_layers, self.embed_dim = len(depths), embed_dim
+        common = dict(depths=depths, embed_dim=embed_dim, num_heads=num_heads, drop_path=drop_path_rate,
+                      window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop_rate=drop_rate,
+                      attn_drop_rate=attn_drop_rate, norm_layer=norm_layer)
+        if add_last:
+            self.rebnconvin = get_dwconv_layer(2, in_ch, out_ch)
+        self.patch_embed = PatchEmbedding(patch_size=patch_size, in_c=in_ch, embed_dim=embed_dim,
+                                          norm_layer=norm_layer if patch_norm else None)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        n = self.num_layers
+        self.layers = nn.ModuleList([BasicBlock(index=i, patch_merging=i != n - 1, **common) for i in range(n)])
+        self.first_patch_expanding = PatchExpanding(dim=embed_dim * 2 ** (n - 1), norm_layer=norm_layer)
+        self.layers_up = nn.ModuleList([BasicBlockUp(index=i, patch_expanding=i < n - 2, **common)
+                                        for i in range(n - 1)])
+        self.skip_connection_layers = nn.ModuleList([
+            nn.Linear(embed_dim * 2 ** (n - 2 - i) * 2, embed_dim * 2 ** (n - 2 - i)) for i in range(n - 1)])
+        self.norm_up = norm_layer(embed_dim)
+        self.final_patch_expanding = FinalPatchExpanding(dim=embed_dim, norm_layer=norm_layer, patch_size=patch_size)
+        self.head = nn.Conv2d(embed_dim, out_ch, kernel_size=(1, 1), bias=False)
+        self.apply(self.init_weights)
+
+    @staticmethod
+    def init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, x):
+        res = self.rebnconvin(x) if self.add_last else None
+        x = self.pos_drop(self.patch_embed(x))
+        saved = []
+        for layer in self.layers:
+            saved.append(x)
+            x = layer(x)
+        x = self.first_patch_expanding(x)
+        for i, layer in enumerate(self.layers_up):
+            skip = saved[len(saved) - i - 2]
+            x = x[:, :skip.shape[1], :skip.shape[2], :]  # drop the rows/cols that came from odd-size padding
+            x = layer(self.skip_connection_layers[i](torch.cat([x, skip], -1)))
+        x = self.final_patch_expanding(self.norm_up(x))
+        x = self.head(x.permute(0, 3, 1, 2))
+        return x + res if self.add_last else x
+
+
+class SwT2Net(_U2Forward, nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, deep_supervision: bool):
+        nn.Module.__init__(self)
+        self.spatial_dims = 2
+        self.deep_supervision = deep_supervision
+        ln = partial(nn.LayerNorm, eps=1e-6)
+
+        def su(patch, i, o, embed, heads):
+            return SwinTransformerUnet(patch_size=patch, in_ch=i, out_ch=o, depths=(2, 2, 4, 2), embed_dim=embed,
+                                       num_heads=heads, window_size=7, qkv_bias=True, mlp_ratio=4, drop_path_rate=0.1,
+                                       drop_rate=0, attn_drop_rate=0, norm_layer=ln, add_last=True)
+
+        self.stage1 = su(4, in_ch, 32, 32, (2, 2, 4, 8))
+        self.patch_merging1 = PatchMerging2D(32, scale=2)
+        self.stage2 = su(4, 64, 64, 64, (2, 4, 8, 16))
+        self.patch_merging2 = PatchMerging2D(64, scale=2)
+        self.stage3 = su(2, 128, 128, 96, (3, 6, 12, 24))
+        self.patch_merging3 = PatchMerging2D(128, scale=2)
+        self.stage4 = su(1, 256, 256, 96, (3, 6, 12, 24))
+        self.patch_merging4 = PatchMerging2D(256, scale=2)
+        self.stage5 = RSU4F(512, 256, 512)
+        self.pool56 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
+        self.stage6 = RSU4F(512, 256, 512)
+        self.stage5d = RSU4F(1024, 256, 512)
+        self.patch_expand4d = PatchExpand(dim=512, scale=2, norm_layer=nn.LayerNorm)
+        self.concat_back_dim4d = nn.Linear(512, 256)
+        self.stage4d = su(1, 256, 256, 96, (3, 6, 12, 24))
+        self.patch_expand3d = PatchExpand(dim=256, scale=2, norm_layer=nn.LayerNorm)
+        self.concat_back_dim3d = nn.Linear(256, 128)
+        self.stage3d = su(2, 128, 128, 96, (3, 6, 12, 24))
+        self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=nn.LayerNorm)
+        self.concat_back_dim2d = nn.Linear(128, 64)
+        self.stage2d = su(4, 64, 64, 64, (2, 4, 8, 16))
+        self.patch_expand1d = PatchExpand(dim=64, scale=2, norm_layer=nn.LayerNorm)
+        self.concat_back_dim1d = nn.Linear(64, 32)
+        self.stage1d = su(4, 32, 32, 32, (2, 2, 4, 8))
+        for i, c in enumerate([32, 64, 128, 256, 512, 512], 1):
+            setattr(self, f"side{i}", Convolution(2, c, out_ch, kernel_size=1, padding=0, conv_only=True))
+        self.outconv = Convolution(2, 6 * out_ch, out_ch, kernel_size=1, conv_only=True)
+
+    def _fuse(self, k, up_tokens, skip_nchw):
+        lin = getattr(self, f"concat_back_dim{k}d")
+        return lin(torch.cat((up_tokens, skip_nchw.permute(0, 2, 3, 1)), -1)).permute(0, 3, 1, 2)
+
+
+def get_swt2net_from_plans(plans_manager, dataset_json: dict, configuration_manager, num_input_channels: int,
+                           deep_supervision: bool = True, use_pretrain: bool = True):
+    model = SwT2Net(in_ch=num_input_channels, out_ch=_heads(plans_manager, dataset_json),
+                    deep_supervision=deep_supervision)
+    model.apply(InitWeights_He(1e-2))
+    return model
