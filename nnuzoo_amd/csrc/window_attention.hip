@@ -66,13 +66,38 @@ __device__ __forceinline__ void stage(const AttnArgs& a, const float* src, int r
                                       float* dst, int lane) {
   for (int i = lane; i < 64 * WA_LD; i += 64) dst[i] = 0.f;
   __syncthreads();
-  const int q4 = a.hd >> 2;
-  for (int i = lane; i < WA_L * q4; i += 64) {
-    const int l = i / q4, c4 = (i % q4) * 4;
-    const TokenMap m = token_map(a, win, l);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + m.base * row_len + ch0 + c4);
-    float* d = dst + l * WA_LD + c4;
-    d[0] = v[0] * mul; d[1] = v[1] * mul; d[2] = v[2] * mul; d[3] = v[3] * mul;
+  if ((a.hd & 3) == 0) {
+    const int q4 = a.hd >> 2;
+    for (int i = lane; i < WA_L * q4; i += 64) {
+      const int l = i / q4, c4 = (i % q4) * 4;
+      const TokenMap m = token_map(a, win, l);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + m.base * row_len + ch0 + c4);
+      float* d = dst + l * WA_LD + c4;
+      d[0] = v[0] * mul; d[1] = v[1] * mul; d[2] = v[2] * mul; d[3] = v[3] * mul;
+    }
+  } else {  // head_dim not a multiple of 4: scalar staging
+    for (int i = lane; i < WA_L * a.hd; i += 64) {
+      const int l = i / a.hd, c = i % a.hd;
+      dst[l * WA_LD + c] = src[token_map(a, win, l).base * row_len + ch0 + c] * mul;
+    }
+  }
+}
+
+// store the 16 accumulator rows of one lane (channels 8*g4 + 4*hh + e) of a [channel][token] tile to dst[channel]
+__device__ __forceinline__ void store_cols(float* dst, const f32x16& o, int hh, int hd, float mul) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int c0 = 8 * g4 + 4 * hh;
+    if ((hd & 3) == 0) {
+      if (c0 < hd) {
+        f32x4 v = {o[4 * g4] * mul, o[4 * g4 + 1] * mul, o[4 * g4 + 2] * mul, o[4 * g4 + 3] * mul};
+        *reinterpret_cast<f32x4*>(dst + c0) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + e < hd) dst[c0 + e] = o[4 * g4 + e] * mul;
+    }
   }
 }
 
@@ -167,15 +192,7 @@ __global__ __launch_bounds__(64) void win_attn_fwd_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) o = mfma_f32(sv[(tk * 32 + crow(r, hh)) * WA_LD + l31], p[tk][tq][r], o);
     const int i = tq * 32 + l31;
     if (i < WA_L) {
-      float* dst = a.out + token_map(a, win, i).base * a.C + head * a.hd;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int c0 = 8 * g4 + 4 * hh;
-        if (c0 < a.hd) {
-          f32x4 v = {o[4 * g4], o[4 * g4 + 1], o[4 * g4 + 2], o[4 * g4 + 3]};
-          *reinterpret_cast<f32x4*>(dst + c0) = v;
-        }
-      }
+      store_cols(a.out + token_map(a, win, i).base * a.C + head * a.hd, o, hh, a.hd, 1.f);
     }
   }
 }
@@ -284,15 +301,7 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o = mfma_f32(sk[(tk * 32 + crow(r, hh)) * WA_LD + l31], s[tk][tq][r], o);
       if (i < WA_L) {
-        float* dst = a.dqkv + token_map(a, win, i).base * C3 + head * a.hd;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int c0 = 8 * g4 + 4 * hh;
-          if (c0 < a.hd) {
-            f32x4 v = {o[4 * g4] * a.scale, o[4 * g4 + 1] * a.scale, o[4 * g4 + 2] * a.scale, o[4 * g4 + 3] * a.scale};
-            *reinterpret_cast<f32x4*>(dst + c0) = v;
-          }
-        }
+        store_cols(a.dqkv + token_map(a, win, i).base * C3 + head * a.hd, o, hh, a.hd, a.scale);
       }
     }
   }
@@ -364,24 +373,16 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
         }
       if (j < WA_L) {
         float* dst = a.dqkv + token_map(a, win, j).base * C3 + head * a.hd;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int c0 = 8 * g4 + 4 * hh;
-          if (c0 < a.hd) {
-            f32x4 vk = {ok[4 * g4], ok[4 * g4 + 1], ok[4 * g4 + 2], ok[4 * g4 + 3]};
-            f32x4 vv = {ov[4 * g4], ov[4 * g4 + 1], ov[4 * g4 + 2], ov[4 * g4 + 3]};
-            *reinterpret_cast<f32x4*>(dst + a.C + c0) = vk;
-            *reinterpret_cast<f32x4*>(dst + 2 * a.C + c0) = vv;
-          }
-        }
+        store_cols(dst + a.C, ok, hh, a.hd, 1.f);
+        store_cols(dst + 2 * a.C, ov, hh, a.hd, 1.f);
       }
     }
   }
 }
 
 static int check(const AttnArgs& a) {
-  if (a.B < 1 || a.H % WA_WS || a.W % WA_WS || a.heads < 1 || a.C != a.heads * a.hd || a.hd % 4 || a.hd > 32 ||
-      a.hd < 4 || (a.shift != 0 && a.shift != WA_WS / 2))
+  if (a.B < 1 || a.H % WA_WS || a.W % WA_WS || a.heads < 1 || a.C != a.heads * a.hd || a.hd % 2 || a.hd > 32 ||
+      a.hd < 2 || (a.shift != 0 && a.shift != WA_WS / 2))
     return NNZ_EINVAL;
   return NNZ_OK;
 }

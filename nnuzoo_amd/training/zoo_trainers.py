@@ -1,0 +1,117 @@
+"""Trainer plugins of the X^2-Net zoo models, same class names and hooks as the reference's plugin files:
+  nnUNetTrainerM2Net / nnUNetTrainerM2NetP   /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainerM2Net.py
+  nnUNetTrainerSwT2Net                        /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainerSwT2Net.py
+Overrides, as there: build_network_architecture (legacy signature; the live one is accepted too, SURVEY.md §8b
+quirk 2), AdamW(lr 1e-4, wd 5e-2, eps 1e-5) + CosineAnnealingLR(eta_min 1e-6), the fixed 7-entry deep-supervision
+scale list, `network.deep_supervision` toggle, and - for the Swin model - the fp32 train_step without autocast or
+GradScaler (nnUNetTrainerSwT2Net.py:112-130).  The M2Net plugins inherit the autocast step like the reference.
+"""
+from __future__ import annotations
+
+import torch
+from torch.optim import AdamW
+from torch.optim.lr_scheduler import CosineAnnealingLR
+
+from ..nets.m2net import get_m2net_from_plans, get_m2netp_from_plans
+from ..nets.swt2net import get_swt2net_from_plans
+from .nnUNetTrainer import nnUNetTrainer, _num_input_channels
+
+_X2_SCALES = [[1.0, 1.0], [1.0, 1.0], [0.5, 0.5], [0.25, 0.25], [0.125, 0.125], [0.0625, 0.0625], [0.03125, 0.03125]]
+
+
+def _legacy_or_live(factory, args, kwargs):
+    """(plans_manager, dataset_json, configuration_manager, num_input_channels, enable_deep_supervision=True) or the
+    live (architecture_class_name, arch_init_kwargs, req_import, num_input_channels, num_output_channels, ds)."""
+    if args and isinstance(args[0], str):
+        num_in, num_out = args[3], args[4]
+        ds = args[5] if len(args) > 5 else kwargs.get("enable_deep_supervision", True)
+        dataset_json = {"labels": {str(i): i for i in range(num_out)}}
+        return factory(None, dataset_json, kwargs.get("configuration_manager"), num_in, deep_supervision=ds)
+    names = ["plans_manager", "dataset_json", "configuration_manager", "num_input_channels", "enable_deep_supervision"]
+    a = dict(zip(names, args))
+    a.update(kwargs)
+    return factory(a.get("plans_manager"), a["dataset_json"], a.get("configuration_manager"), a["num_input_channels"],
+                   deep_supervision=a.get("enable_deep_supervision", True))
+
+
+class _X2Trainer(nnUNetTrainer):
+    _factory = None
+    _fp32_step = False
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.initial_lr = 1e-4
+        self.weight_decay = 5e-2
+        self.freeze_encoder_epochs = -1
+        self.early_stop_epoch = 25
+        if self._fp32_step:
+            self.grad_scaler = None
+
+    def initialize(self):
+        if self.was_initialized:
+            raise RuntimeError("You have called self.initialize even though the trainer was already initialized.")
+        self._set_batch_size_and_oversample()
+        self.num_input_channels = _num_input_channels(self.dataset_json)
+        self.network = self.build_network_architecture(None, self.dataset_json, self.configuration_manager,
+                                                       self.num_input_channels, self.enable_deep_supervision
+                                                       ).to(self.device)
+        self.optimizer, self.lr_scheduler = self.configure_optimizers()
+        if self.is_ddp:
+            raise NotImplementedError("X^2-Net plugins: data-parallel training needs unused-parameter handling "
+                                      "(inner seg_layers never receive gradients); single-GPU only in this round")
+        self.loss = self._build_loss()
+        self.was_initialized = True
+
+    def _get_deep_supervision_scales(self):
+        return [list(s) for s in _X2_SCALES] if self.enable_deep_supervision else None
+
+    def configure_optimizers(self):
+        optimizer = AdamW(self.network.parameters(), lr=self.initial_lr, weight_decay=self.weight_decay, eps=1e-5,
+                          betas=(0.9, 0.999))
+        return optimizer, CosineAnnealingLR(optimizer, T_max=self.num_epochs, eta_min=1e-6)
+
+    def set_deep_supervision_enabled(self, enabled: bool):
+        self.network.deep_supervision = enabled
+
+    def train_step(self, batch: dict) -> dict:
+        data = batch['data'].to(self.device, non_blocking=True)
+        target = [i.to(self.device, non_blocking=True) for i in batch['target']] \
+            if isinstance(batch['target'], list) else batch['target'].to(self.device, non_blocking=True)
+        self.optimizer.zero_grad(set_to_none=True)
+        if self._fp32_step:
+            output = self.network(data)
+            l = self.loss(list(output), target)
+            l.backward()
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+            self.optimizer.step()
+        else:
+            with torch.autocast('cuda'):
+                output = self.network(data)
+                l = self.loss(list(output), target)
+            self.grad_scaler.scale(l).backward()
+            self.grad_scaler.unscale_(self.optimizer)
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+            self.grad_scaler.step(self.optimizer)
+            self.grad_scaler.update()
+        return {'loss': l.detach().cpu().numpy()}
+
+
+class nnUNetTrainerM2Net(_X2Trainer):
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        return _legacy_or_live(get_m2net_from_plans, args, kwargs)
+
+
+class nnUNetTrainerM2NetP(_X2Trainer):
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        return _legacy_or_live(get_m2netp_from_plans, args, kwargs)
+
+
+class nnUNetTrainerSwT2Net(_X2Trainer):
+    _fp32_step = True
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        return _legacy_or_live(get_swt2net_from_plans, args, kwargs)

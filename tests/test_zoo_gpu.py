@@ -108,5 +108,9 @@ def test_whole_net_training_step(hip_lib, name):
     x = torch.randn(2, 1, 64, 64, device="cuda")
     outs = net(x)
     sum((o.float() ** 2).mean() for o in outs).backward()
-    missing = [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
-    assert not missing, missing[:5]
+    bad = [n for n, p in net.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    assert not bad, bad[:5]
+    # as in the reference, the inner U-nets run with deep_supervision=False, so all but the last of their
+    # seg_layers are never used and get no gradient (the X^2Net plugins therefore cannot use plain torch DDP)
+    unused = [n for n, p in net.named_parameters() if p.grad is None]
+    assert all("vssm_decoder.seg_layers" in n for n in unused), unused[:5]

@@ -1,0 +1,50 @@
+"""Training patches/s of the zoo models on synthetic 1x512^2 patches (BASELINE.json configs[2], configs[3]).
+Usage (GPU box): python tools/bench_zoo.py [--models M2Net,SwT2Net] [--batch 2] [--steps 5] [--size 512]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+from nnuzoo_amd.training import zoo_trainers as Z
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--models", default="M2NetP,M2Net,SwT2Net")
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512)
+    a = ap.parse_args()
+    for name in a.models.split(","):
+        cls = getattr(Z, "nnUNetTrainer" + name)
+        plans, cfg, dj = nnunet_plans(2, (a.size, a.size), batch_size=a.batch)
+        torch.manual_seed(0)
+        tr = cls(plans, cfg, 0, dj, device=torch.device("cuda"))
+        tr.initialize()
+        b = synthetic_batch(a.batch, (a.size, a.size), tr._get_deep_supervision_scales(), seed=3)
+        b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+        losses = []
+        for _ in range(a.warmup):
+            losses.append(float(tr.train_step(b)["loss"]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            losses.append(float(tr.train_step(b)["loss"]))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(json.dumps({"model": name, "patch": a.size, "batch": a.batch, "ms_per_step": round(dt * 1e3, 2),
+                          "patches_per_s": round(a.batch / dt, 3), "losses": [round(x, 4) for x in losses],
+                          "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+        del tr
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+
+
+if __name__ == "__main__":
+    main()
