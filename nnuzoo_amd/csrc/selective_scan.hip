@@ -91,7 +91,13 @@ __device__ __forceinline__ void wave_rscan_affine(float& a, float& b, int lane) 
   }
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+// softplus(x) = max(x, 0) + log1p(exp(-|x|)); log1p by its series for tiny arguments (keeps relative accuracy
+// where exp(-|x|) << 1) and by the fast log otherwise.  The libm log1pf expands to ~100 instructions on gfx950.
+__device__ __forceinline__ float softplus_f(float x) {
+  const float e = __expf(-fabsf(x));
+  const float l = e < 1.0e-3f ? e * (1.f - e * (0.5f - 0.33333334f * e)) : __logf(1.f + e);
+  return fmaxf(x, 0.f) + l;
+}
 
 // load 4 consecutive elements of a row starting at t (vector when the row is 16-byte aligned and fully in range)
 __device__ __forceinline__ void load4(const float* row, int t, int L, bool vec, float (&v)[SS_KI]) {
@@ -124,14 +130,47 @@ __device__ __forceinline__ void stage_tile(const float* src /* [N][L] */, float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// per-row inputs of one wave, prefetched one row ahead (the loads of row r+1 fly under the n-loop of row r)
+// ---------------------------------------------------------------------------------------------------------------
+struct RowIn {
+  float u[SS_KI], dl[SS_KI], dy[SS_KI];
+  float dl_next;  // raw delta of the step after the lane's last item (backward only; lane 63: next chunk's first)
+  float aux;      // lanes 0-15: A[kd][n]; 16-31: Hin[n]; 32-47: Gin[n]  (one coalesced load per wave)
+  float bias, Dv;
+};
+
+template <bool BWD, bool FINAL>
+__device__ __forceinline__ void load_row(const ScanArgs& a, int b, int k, int r, int c, int t, int lane, bool vec,
+                                         RowIn& x) {
+  const int kd = k * a.Dg + r;
+  const long row = (long)b * a.KD + kd;
+  load4(a.delta + row * a.L, t, a.L, vec, x.dl);
+  if (!BWD || FINAL) load4(a.u + row * a.L, t, a.L, vec, x.u);
+  if (BWD) {
+    load4(a.dy + row * a.L, t, a.L, vec, x.dy);
+    const int tn = t + SS_KI;
+    x.dl_next = tn < a.L ? a.delta[row * a.L + tn] : 0.f;
+  }
+  const int n = lane & 15;
+  float v = 0.f;
+  if (lane < 16) v = a.A[(long)kd * SS_N + n];
+  else if (lane < 32) { if (FINAL) v = a.Hin[(row * a.nchunks + c) * SS_N + n]; }
+  else if (lane < 48) { if (BWD && FINAL) v = a.Gin[(row * a.nchunks + c) * SS_N + n]; }
+  x.aux = v;
+  x.bias = a.bias ? a.bias[kd] : 0.f;
+  x.Dv = a.D ? a.D[kd] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // forward: FINAL = false -> chunk summaries (P, S); FINAL = true -> y from the entry state Hin
 // ---------------------------------------------------------------------------------------------------------------
 template <bool FINAL>
 __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) float sB[SS_N * SS_CL];
   __shared__ __attribute__((aligned(16))) float sC[FINAL ? SS_N * SS_CL : 4];
+  __shared__ float sw[SS_NW][64];  // per wave: A row, entry state
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.x;                  // chunk
   const int wgs_per_group = a.Dg / a.rows_per_wg;
   const int grp = blockIdx.y / wgs_per_group;  // b*K + k
@@ -140,31 +179,32 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
   const int t0 = c * SS_CL;
   const int t = t0 + lane * SS_KI;
   const bool vec = (a.L & 3) == 0;
+  const int r_end = (sub + 1) * a.rows_per_wg;
 
+  RowIn cur, nxt;
+  int r = sub * a.rows_per_wg + wave;
+  load_row<false, FINAL>(a, b, k, r, c, t, lane, vec, cur);
   stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
   if (FINAL) stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
   __syncthreads();
 
-  for (int r = sub * a.rows_per_wg + wave; r < (sub + 1) * a.rows_per_wg; r += SS_NW) {
+  for (; r < r_end; r += SS_NW) {
     const int kd = k * a.Dg + r;
     const long row = (long)b * a.KD + kd;
+    if (r + SS_NW < r_end) load_row<false, FINAL>(a, b, k, r + SS_NW, c, t, lane, vec, nxt);
+    sw[wave][lane] = cur.aux;  // same-wave LDS: program order is enough
     float u[SS_KI], dl[SS_KI], yv[SS_KI];
-    load4(a.u + row * a.L, t, a.L, vec, u);
-    load4(a.delta + row * a.L, t, a.L, vec, dl);
-    const float bias = a.bias ? a.bias[kd] : 0.f;
-    const float Dv = a.D ? a.D[kd] : 0.f;
 #pragma unroll
     for (int i = 0; i < SS_KI; ++i) {
-      float d = dl[i] + bias;
+      float d = cur.dl[i] + cur.bias;
       if (a.softplus) d = softplus_f(d);
       dl[i] = (t + i < a.L) ? d : 0.f;  // identity step beyond L
-      yv[i] = Dv * u[i];
+      u[i] = cur.u[i];
+      yv[i] = cur.Dv * u[i];
     }
-    const float* Arow = a.A + (long)kd * SS_N;
-    const float* hin = FINAL ? a.Hin + (row * a.nchunks + c) * SS_N : nullptr;
 #pragma unroll 4
     for (int n = 0; n < SS_N; ++n) {
-      const float An = Arow[n];
+      const float An = sw[wave][n];
       const f32x4 Bv = *reinterpret_cast<const f32x4*>(sB + n * SS_CL + lane * SS_KI);
       float ai[SS_KI], bi[SS_KI];
 #pragma unroll
@@ -190,7 +230,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
           ea = 1.f;
           eb = 0.f;
         }
-        float h = ea * hin[n] + eb;
+        float h = ea * sw[wave][16 + n] + eb;
         const f32x4 Cv = *reinterpret_cast<const f32x4*>(sC + n * SS_CL + lane * SS_KI);
 #pragma unroll
         for (int i = 0; i < SS_KI; ++i) {
@@ -200,6 +240,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
       }
     }
     if (FINAL) store4(a.y + row * a.L, t, a.L, vec, yv);
+    cur = nxt;
   }
 }
 
@@ -242,12 +283,14 @@ __global__ __launch_bounds__(256) void scan_carry_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 template <bool FINAL>
 __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) float sB[FINAL ? SS_N * SS_CL : 4];
-  __shared__ __attribute__((aligned(16))) float sC[SS_N * SS_CL];
-  __shared__ __attribute__((aligned(16))) float sdB[FINAL ? SS_N * SS_CL : 4];
-  __shared__ __attribute__((aligned(16))) float sdC[FINAL ? SS_N * SS_CL : 4];
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  float* sC = dyn_lds;                                   // [N][CL]
+  float* sw = sC + SS_N * SS_CL;                         // [NW][64] per wave: A row, Hin, Gin
+  float* sB = sw + SS_NW * 64;                           // FINAL only: [N][CL]
+  float* sdB = sB + SS_N * SS_CL;                        // FINAL only
+  float* sdC = sdB + SS_N * SS_CL;                       // FINAL only
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.x;
   const int wgs_per_group = a.Dg / a.rows_per_wg;
   const int grp = blockIdx.y / wgs_per_group;
@@ -256,7 +299,12 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
   const int t0 = c * SS_CL;
   const int t = t0 + lane * SS_KI;
   const bool vec = (a.L & 3) == 0;
+  const int r_end = (sub + 1) * a.rows_per_wg;
+  float* swv = sw + wave * 64;
 
+  RowIn cur, nxt;
+  int r = sub * a.rows_per_wg + wave;
+  load_row<true, FINAL>(a, b, k, r, c, t, lane, vec, cur);
   stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
   if (FINAL) {
     stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
@@ -267,46 +315,41 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
   }
   __syncthreads();
 
-  for (int r = sub * a.rows_per_wg + wave; r < (sub + 1) * a.rows_per_wg; r += SS_NW) {
+  for (; r < r_end; r += SS_NW) {
     const int kd = k * a.Dg + r;
     const long row = (long)b * a.KD + kd;
+    if (r + SS_NW < r_end) load_row<true, FINAL>(a, b, k, r + SS_NW, c, t, lane, vec, nxt);
+    swv[lane] = cur.aux;  // same-wave LDS: program order is enough
     float u[SS_KI], draw[SS_KI], dl[SS_KI], dyv[SS_KI];
-    load4(a.delta + row * a.L, t, a.L, vec, draw);
-    load4(a.dy + row * a.L, t, a.L, vec, dyv);
-    const float bias = a.bias ? a.bias[kd] : 0.f;
 #pragma unroll
     for (int i = 0; i < SS_KI; ++i) {
-      float d = draw[i] + bias;
+      float d = cur.dl[i] + cur.bias;
       draw[i] = d;
       if (a.softplus) d = softplus_f(d);
       dl[i] = (t + i < a.L) ? d : 0.f;
+      dyv[i] = cur.dy[i];
+      u[i] = FINAL ? cur.u[i] : 0.f;
     }
     // dl of the step right after this lane's items (first item of lane+1; for lane 63 the next chunk's first step)
-    float dl_next = __shfl_down(dl[0], 1, 64);
-    if (lane == 63) {
-      const int tn = t0 + SS_CL;
-      float d = 0.f;
-      if (tn < a.L) {
-        d = a.delta[row * a.L + tn] + bias;
-        if (a.softplus) d = softplus_f(d);
-      }
-      dl_next = d;
+    float dl_next = 0.f;
+    if (t + SS_KI < a.L) {
+      dl_next = cur.dl_next + cur.bias;
+      if (a.softplus) dl_next = softplus_f(dl_next);
     }
     float duv[SS_KI], ddl[SS_KI];
-    if (FINAL) {
-      load4(a.u + row * a.L, t, a.L, vec, u);
-      const float Dv = a.D ? a.D[kd] : 0.f;
 #pragma unroll
-      for (int i = 0; i < SS_KI; ++i) {
-        duv[i] = Dv * dyv[i];
-        ddl[i] = 0.f;
-      }
+    for (int i = 0; i < SS_KI; ++i) {
+      duv[i] = cur.Dv * dyv[i];
+      ddl[i] = 0.f;
     }
-    const float* Arow = a.A + (long)kd * SS_N;
-    const float* hin = FINAL ? a.Hin + (row * a.nchunks + c) * SS_N : nullptr;
-    const float* gin = FINAL ? a.Gin + (row * a.nchunks + c) * SS_N : nullptr;
-#pragma unroll 2
-    for (int n = 0; n < SS_N; ++n) {
+    const float* Arow = swv;       // LDS broadcasts: nothing inside the n-loop waits on vector memory
+    const float* hin = swv + 16;
+    const float* gin = swv + 32;
+    // The 4 waves of the workgroup walk the states in a skewed order (wave w starts at n = 4w) and meet at a
+    // barrier after every state: at any moment they update DIFFERENT rows of the dB/dC accumulation tiles, so the
+    // cross-channel reduction is a plain LDS read-modify-write (ds_add_f32 atomics measured ~4x slower in total).
+    for (int j = 0; j < SS_N; ++j) {
+      const int n = FINAL ? ((j + 4 * wave) & (SS_N - 1)) : j;
       const float An = Arow[n];
       const f32x4 Cv = *reinterpret_cast<const f32x4*>(sC + n * SS_CL + lane * SS_KI);
       float ai[SS_KI + 1];
@@ -380,13 +423,23 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
         ddl[i] += g * Bv[i] * u[i] + An * gah;
         dAn += dl[i] * gah;
       }
+      {
+        f32x4* pB = reinterpret_cast<f32x4*>(sdB + n * SS_CL + lane * SS_KI);
+        f32x4* pC = reinterpret_cast<f32x4*>(sdC + n * SS_CL + lane * SS_KI);
+        f32x4 vB = *pB, vC = *pC;
 #pragma unroll
-      for (int i = 0; i < SS_KI; ++i) {
-        atomicAdd(&sdB[n * SS_CL + lane * SS_KI + i], dBv[i]);
-        atomicAdd(&sdC[n * SS_CL + lane * SS_KI + i], dCv[i]);
+        for (int i = 0; i < SS_KI; ++i) {
+          vB[i] += dBv[i];
+          vC[i] += dCv[i];
+        }
+        *pB = vB;
+        *pC = vC;
       }
+      // per-(row, chunk) partial of dA goes to the (now free) summary workspace with a plain store; a finalize
+      // kernel sums over chunks and batch: no contended atomic (and no vector-memory wait) inside this loop
       dAn = wave_sum(dAn);
-      if (lane == 0) atomicAdd(a.dA + (long)kd * SS_N + n, dAn);
+      if (lane == 0) a.P[(row * SS_N + n) * a.nchunks + c] = dAn;
+      __syncthreads();  // keeps the waves' skewed n-order disjoint (all waves run the same trip counts)
     }
     if (FINAL) {
       float sdb = 0.f, sdD = 0.f;
@@ -404,24 +457,60 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
       sdb = wave_sum(sdb);
       sdD = wave_sum(sdD);
       if (lane == 0) {
-        if (a.dbias) atomicAdd(a.dbias + kd, sdb);
-        if (a.dD) atomicAdd(a.dD + kd, sdD);
+        a.S[(row * SS_N + 0) * a.nchunks + c] = sdb;
+        a.S[(row * SS_N + 1) * a.nchunks + c] = sdD;
       }
     }
+    cur = nxt;
   }
   if (FINAL) {
     __syncthreads();
     float* gB = a.dB + (long)grp * SS_N * a.L;
     float* gC = a.dC + (long)grp * SS_N * a.L;
+    const bool sole = wgs_per_group == 1;  // this workgroup is the only writer of the tile: plain stores
     for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
       const int n = i / SS_CL, tt = i % SS_CL;
+      const int li = i;
       if (t0 + tt < a.L) {
-        atomicAdd(gB + (long)n * a.L + t0 + tt, sdB[i]);
-        atomicAdd(gC + (long)n * a.L + t0 + tt, sdC[i]);
+        if (sole) {
+          gB[(long)n * a.L + t0 + tt] = sdB[li];
+          gC[(long)n * a.L + t0 + tt] = sdC[li];
+        } else {
+          atomicAdd(gB + (long)n * a.L + t0 + tt, sdB[li]);
+          atomicAdd(gC + (long)n * a.L + t0 + tt, sdC[li]);
+        }
       }
     }
   }
 }
+
+// dA[kd][n] = sum_{b, c} P[(b*KD + kd)*N + n][c];  dbias / dD from rows 0 / 1 of S.  One wave per (kd, n).
+__global__ __launch_bounds__(256) void scan_bwd_finalize_kernel(const float* __restrict__ P, const float* __restrict__ S,
+                                                                float* __restrict__ dA, float* __restrict__ dbias,
+                                                                float* __restrict__ dD, int Bt, int KD, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long)KD * SS_N) return;
+  const int kd = w / SS_N, n = w % SS_N;
+  float sa = 0.f, s0 = 0.f;
+  for (int b = 0; b < Bt; ++b) {
+    const long base = (((long)b * KD + kd) * SS_N + n) * nchunks;
+    for (int c = lane; c < nchunks; c += 64) {
+      sa += P[base + c];
+      if (n < 2) s0 += S[base + c];
+    }
+  }
+  sa = wave_sum(sa);
+  s0 = wave_sum(s0);
+  if (lane == 0) {
+    dA[w] = sa;
+    if (n == 0 && dbias) dbias[kd] = s0;
+    if (n == 1 && dD) dD[kd] = s0;
+  }
+}
+
+constexpr int SS_BWD_LDS_SUMMARY = (SS_N * SS_CL + SS_NW * 64) * 4;
+constexpr int SS_BWD_LDS_FINAL = (4 * SS_N * SS_CL + SS_NW * 64) * 4;
 
 static int pick_rows_per_wg(int Dg, long groups_chunks) {
   // whole group per workgroup when there are plenty of (group, chunk) pairs, else split the group's channels
@@ -503,14 +592,13 @@ extern "C" int nnz_selective_scan_backward(const float* u, const float* delta, c
   a.rows_per_wg = pick_rows_per_wg(Dg, (long)Bt * K * a.nchunks);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
-  if ((e = hipMemsetAsync(dA, 0, sizeof(float) * a.KD * SS_N, s)) != hipSuccess) return (int)e;
-  if ((e = hipMemsetAsync(dB, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
-  if ((e = hipMemsetAsync(dC, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
-  if (dD && (e = hipMemsetAsync(dD, 0, sizeof(float) * a.KD, s)) != hipSuccess) return (int)e;
-  if (dbias && (e = hipMemsetAsync(dbias, 0, sizeof(float) * a.KD, s)) != hipSuccess) return (int)e;
+  if (a.rows_per_wg != Dg) {  // several workgroups add into one dB/dC tile
+    if ((e = hipMemsetAsync(dB, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(dC, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
+  }
   dim3 grid(a.nchunks, Bt * K * (Dg / a.rows_per_wg));
   if (a.nchunks > 1) {
-    hipLaunchKernelGGL(scan_bwd_kernel<false>, grid, dim3(SS_NW * 64), 0, s, a);
+    hipLaunchKernelGGL(scan_bwd_kernel<false>, grid, dim3(SS_NW * 64), SS_BWD_LDS_SUMMARY, s, a);
     NNZ_LAUNCH_CHECK();
     const long rows_n = rows * SS_N;
     hipLaunchKernelGGL(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin,
@@ -519,7 +607,17 @@ extern "C" int nnz_selective_scan_backward(const float* u, const float* delta, c
   } else {
     if ((e = hipMemsetAsync(a.Gin, 0, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(scan_bwd_kernel<true>, grid, dim3(SS_NW * 64), 0, s, a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bwd_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SS_BWD_LDS_FINAL);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(scan_bwd_kernel<true>, grid, dim3(SS_NW * 64), SS_BWD_LDS_FINAL, s, a);
+  NNZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, dA,
+                     dbias, dD, Bt, a.KD, a.nchunks);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
