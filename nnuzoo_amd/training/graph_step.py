@@ -1,0 +1,69 @@
+"""hipGraph capture of the forward + loss + backward part of a training step.
+
+The zoo models issue ~15 000 small kernels per step (profiles/r01_m2net_step_window.txt): eager launch overhead, not
+GPU time, sets the step time.  MI355X-first answer (task brief: "capture launch-bound inner loops in hipGraphs"):
+record the step once on a side stream and replay it as ONE graph launch.  torch.cuda.CUDAGraph is hipGraph on ROCm;
+our C-ABI launchers are capture-safe by construction (stream-ordered, allocation-free, no host sync;
+include/nnuzoo_hip.h conventions).
+
+What is captured: zero-grad-free forward, loss, (scaled) backward into static .grad buffers.  What stays eager: the
+GradScaler unscale / inf check, clip_grad_norm_, optimizer step and the loss read-back - the reference's train_step
+semantics (/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1128-1144) are unchanged.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+
+class GraphedForwardBackward:
+    def __init__(self, network: torch.nn.Module, loss_fn: Callable, grad_scaler, autocast: bool, warmup_iters: int = 3):
+        self.network, self.loss_fn, self.scaler, self.autocast = network, loss_fn, grad_scaler, autocast
+        self.warmup_iters = warmup_iters
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static_data = None
+        self.static_target: List[torch.Tensor] = []
+        self.static_loss = None
+        self._key = None
+
+    def _fwd_bwd(self, data, target):
+        if self.autocast:
+            with torch.autocast('cuda'):
+                out = self.network(data)
+                loss = self.loss_fn(list(out) if isinstance(out, (tuple, list)) else out, target)
+        else:
+            out = self.network(data)
+            loss = self.loss_fn(list(out) if isinstance(out, (tuple, list)) else out, target)
+        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
+        return loss
+
+    def _capture(self, data, target):
+        self.static_data = data.clone()
+        self.static_target = [t.clone() for t in target]
+        params = [p for p in self.network.parameters()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup_iters):  # eager warm-up: MIOpen/rocBLAS find, lazy attribute set-up, allocator
+                for p in params:
+                    p.grad = None
+                self._fwd_bwd(self.static_data, self.static_target)
+        torch.cuda.current_stream().wait_stream(side)
+        for p in params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._fwd_bwd(self.static_data, self.static_target)
+        self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
+
+    def __call__(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
+        """Runs forward+backward for (data, target); gradients are in p.grad afterwards.  Returns the loss tensor."""
+        key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
+        if self.graph is None or key != self._key:
+            self._capture(data, target)
+        self.static_data.copy_(data, non_blocking=True)
+        for s, t in zip(self.static_target, target):
+            s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.static_loss

@@ -47,6 +47,8 @@ class _X2Trainer(nnUNetTrainer):
         self.early_stop_epoch = 25
         if self._fp32_step:
             self.grad_scaler = None
+        self.use_hip_graph = False  # opt-in: replay forward+loss+backward as one hipGraph (training/graph_step.py)
+        self._graphed = None
 
     def initialize(self):
         if self.was_initialized:
@@ -78,6 +80,22 @@ class _X2Trainer(nnUNetTrainer):
         data = batch['data'].to(self.device, non_blocking=True)
         target = [i.to(self.device, non_blocking=True) for i in batch['target']] \
             if isinstance(batch['target'], list) else batch['target'].to(self.device, non_blocking=True)
+        if self.use_hip_graph:
+            from .graph_step import GraphedForwardBackward
+            if self._graphed is None:
+                self._graphed = GraphedForwardBackward(self.network, self.loss, self.grad_scaler,
+                                                       autocast=not self._fp32_step)
+            tl = target if isinstance(target, list) else [target]
+            l = self._graphed(data, tl)
+            if self.grad_scaler is not None:
+                self.grad_scaler.unscale_(self.optimizer)
+                torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+                self.grad_scaler.step(self.optimizer)
+                self.grad_scaler.update()
+            else:
+                torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+                self.optimizer.step()
+            return {'loss': l.detach().cpu().numpy()}
         self.optimizer.zero_grad(set_to_none=True)
         if self._fp32_step:
             output = self.network(data)

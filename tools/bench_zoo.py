@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--graph", type=int, default=1)
     a = ap.parse_args()
     for name in a.models.split(","):
         cls = getattr(Z, "nnUNetTrainer" + name)
@@ -27,6 +28,7 @@ def main():
         torch.manual_seed(0)
         tr = cls(plans, cfg, 0, dj, device=torch.device("cuda"))
         tr.initialize()
+        tr.use_hip_graph = bool(a.graph)
         b = synthetic_batch(a.batch, (a.size, a.size), tr._get_deep_supervision_scales(), seed=3)
         b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
         losses = []
@@ -40,7 +42,7 @@ def main():
         dt = (time.perf_counter() - t0) / a.steps
         print(json.dumps({"model": name, "patch": a.size, "batch": a.batch, "ms_per_step": round(dt * 1e3, 2),
                           "patches_per_s": round(a.batch / dt, 3), "losses": [round(x, 4) for x in losses],
-                          "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+                          "hip_graph": bool(a.graph), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
         del tr
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
