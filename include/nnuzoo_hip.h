@@ -100,13 +100,14 @@ int nnz_selective_scan_backward(const float* u, const float* delta, const float*
 /* ---- Swin window attention core (7x7 windows, fp32, head_dim <= 32) ------------------------------------------
  * replaces roll + window partition + softmax(q*scale k^T + bias (+ shift mask)) v + un-partition + roll back of
  * WindowAttention.forward (nnunetv2/nets/swt2net.py:584-619 == nets/swt.py:346-383).  qkv: (B, H, W, 3C) output of
- * the qkv Linear, channel order (3, heads, head_dim); bias_dense: (heads, 49, 49); out: (B, H, W, C) input of proj.
+ * the qkv Linear, channel order (3, heads, head_dim); bias_table: the (169, heads) relative_position_bias_table
+ * parameter, bias_index: relative_position_index as int32 (49 x 49); out: (B, H, W, C) input of proj.
  * H, W multiples of 7; shift = 0 or 3. */
-int nnz_window_attention_forward(const float* qkv, const float* bias_dense, float* out, int B, int H, int W, int C,
-                                 int heads, int shift, float scale, void* stream);
-int nnz_window_attention_backward(const float* qkv, const float* bias_dense, const float* dout, float* dqkv,
-                                  float* dbias_dense, int B, int H, int W, int C, int heads, int shift, float scale,
-                                  void* stream);
+int nnz_window_attention_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out, int B,
+                                 int H, int W, int C, int heads, int shift, float scale, void* stream);
+int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index, const float* dout,
+                                  float* dqkv, float* dbias_table, int B, int H, int W, int C, int heads, int shift,
+                                  float scale, void* stream);
 
 #ifdef __cplusplus
 }

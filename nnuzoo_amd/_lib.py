@@ -76,8 +76,8 @@ SIGNATURES = {
     "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _vp],
     "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _vp],
     "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _vp],
-    "nnz_window_attention_forward": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
-    "nnz_window_attention_backward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "nnz_window_attention_forward": [_fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "nnz_window_attention_backward": [_fp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_selective_scan_workspace_floats": [_i, _i, _i],
     "nnz_selective_scan_state_floats": [_i, _i, _i],
     "nnz_selective_scan_forward": [_fp] * 10 + [_i] * 6 + [_vp],

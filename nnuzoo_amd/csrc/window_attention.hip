@@ -23,11 +23,12 @@ constexpr int WA_LD = 33;  // LDS row stride (floats): head_dim <= 32, +1 pad ->
 
 struct AttnArgs {
   const float* qkv;    // [B][H][W][3C]
-  const float* bias;   // [heads][49][49] dense relative-position bias (query i, key j)
+  const float* bias;   // relative_position_bias_table [(2*7-1)^2][heads]
+  const int* bidx;     // relative_position_index [49][49] (int32)
   float* out;          // [B][H][W][C]
   const float* dout;   // [B][H][W][C]
   float* dqkv;         // [B][H][W][3C]
-  float* dbias;        // [heads][49][49] (atomic, zeroed by launcher)
+  float* dbias;        // gradient of the table [169][heads] (atomic, zeroed by launcher)
   int B, H, W, C, heads, hd, shift;
   float scale;
 };
@@ -126,7 +127,7 @@ __device__ __forceinline__ void scores_T(const AttnArgs& a, const float* sq, con
     p[1][0] = mfma_f32(k1, q0, p[1][0]);
     p[1][1] = mfma_f32(k1, q1, p[1][1]);
   }
-  const float* bias = a.bias + (long)head * WA_L * WA_L;
+  const float* bias = a.bias + head;
 #pragma unroll
   for (int tq = 0; tq < 2; ++tq) {
     const int i = tq * 32 + l31;
@@ -140,7 +141,7 @@ __device__ __forceinline__ void scores_T(const AttnArgs& a, const float* sq, con
         const int j = tk * 32 + crow(r, hh);
         float s = -3.0e38f;
         if (j < WA_L) {
-          s = p[tk][tq][r] + bias[ic * WA_L + j];
+          s = p[tk][tq][r] + bias[a.bidx[ic * WA_L + j] * a.heads];
           if (sreg[j] != reg_i) s += -100.f;
         }
         p[tk][tq][r] = s;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
   stage(a, a.qkv, C3, 2 * a.C + head * a.hd, win, 1.f, sv, lane);
   stage(a, a.dout, a.C, head * a.hd, win, 1.f, sdo, lane);
   __syncthreads();
-  const float* bias = a.bias + (long)head * WA_L * WA_L;
+  const float* bias = a.bias + head;
 
   // ---------------- pass A ------------------------------------------------------------------------------------
   {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
           const int j = tk * 32 + crow(r, hh);
           float x = -3.0e38f;
           if (j < WA_L) {
-            x = s[tk][tq][r] + bias[ic * WA_L + j];
+            x = s[tk][tq][r] + bias[a.bidx[ic * WA_L + j] * a.heads];
             if (sreg[j] != reg_i) x += -100.f;
           }
           s[tk][tq][r] = x;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
       dp[1][0] = mfma_f32(g1, v0, dp[1][0]);
       dp[1][1] = mfma_f32(g1, v1, dp[1][1]);
     }
-    float* dbias = a.dbias + (long)head * WA_L * WA_L;
+    float* dbias = a.dbias + head;
 #pragma unroll
     for (int tk = 0; tk < 2; ++tk) {
       const int j = tk * 32 + l31;
@@ -347,11 +348,12 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
           const int i = tq * 32 + crow(r, hh);
           float pv = 0.f, ds = 0.f;
           if (i < WA_L && j < WA_L) {
-            float x = s[tq][tk][r] + bias[i * WA_L + j];
+            const int bi = a.bidx[i * WA_L + j] * a.heads;
+            float x = s[tq][tk][r] + bias[bi];
             if (sreg[i] != reg_j) x += -100.f;
             pv = __expf(x - srow[0][i]) * srow[1][i];
             ds = pv * (dp[tq][tk][r] - srow[2][i]);
-            atomicAdd(dbias + i * WA_L + j, ds);
+            atomicAdd(dbias + bi, ds);
           }
           s[tq][tk][r] = pv;   // P[query][key]
           dp[tq][tk][r] = ds;  // dS[query][key]
@@ -389,12 +391,13 @@ static int check(const AttnArgs& a) {
 
 }  // namespace nnz
 
-extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_dense, float* out, int B, int H, int W,
-                                            int C, int heads, int shift, float scale, void* stream) {
+extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out,
+                                            int B, int H, int W, int C, int heads, int shift, float scale,
+                                            void* stream) {
   using namespace nnz;
-  if (!qkv || !bias_dense || !out) return NNZ_EINVAL;
+  if (!qkv || !bias_table || !bias_index || !out) return NNZ_EINVAL;
   AttnArgs a = {};
-  a.qkv = qkv; a.bias = bias_dense; a.out = out;
+  a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.out = out;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
   if (int rc = check(a)) return rc;
   const int nwin = B * (H / WA_WS) * (W / WA_WS);
@@ -403,16 +406,17 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
   return NNZ_OK;
 }
 
-extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias_dense, const float* dout, float* dqkv,
-                                             float* dbias_dense, int B, int H, int W, int C, int heads, int shift,
-                                             float scale, void* stream) {
+extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index,
+                                             const float* dout, float* dqkv, float* dbias_table, int B, int H, int W,
+                                             int C, int heads, int shift, float scale, void* stream) {
   using namespace nnz;
-  if (!qkv || !bias_dense || !dout || !dqkv || !dbias_dense) return NNZ_EINVAL;
+  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table) return NNZ_EINVAL;
   AttnArgs a = {};
-  a.qkv = qkv; a.bias = bias_dense; a.dout = dout; a.dqkv = dqkv; a.dbias = dbias_dense;
+  a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.dout = dout; a.dqkv = dqkv; a.dbias = dbias_table;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
   if (int rc = check(a)) return rc;
-  hipError_t e = hipMemsetAsync(dbias_dense, 0, sizeof(float) * heads * WA_L * WA_L, (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync(dbias_table, 0, sizeof(float) * heads * (2 * WA_WS - 1) * (2 * WA_WS - 1),
+                                (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   const int nwin = B * (H / WA_WS) * (W / WA_WS);
   hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, a);

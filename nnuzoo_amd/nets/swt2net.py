@@ -157,15 +157,18 @@ class WindowAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.softmax = nn.Softmax(dim=-1)
 
-    def dense_bias(self) -> torch.Tensor:
-        L = self.window_size ** 2
-        return self.relative_position_bias_table[self.relative_position_index.view(-1)].view(L, L, -1) \
-            .permute(2, 0, 1).contiguous()
+    def _index_i32(self) -> torch.Tensor:
+        idx = getattr(self, "_idx32", None)
+        if idx is None or idx.device != self.relative_position_index.device:
+            idx = self.relative_position_index.to(torch.int32).contiguous()
+            self._idx32 = idx  # plain attribute (not a buffer): the state_dict keeps only the reference's int64 buffer
+        return idx
 
     def forward(self, x):
         """x: (B, H, W, C) with H, W multiples of the window size (the block pads)."""
         qkv = self.qkv(x)  # per-token Linear: commutes with the roll / window partition the kernel folds in
-        out = window_attention_core(qkv, self.dense_bias(), self.num_heads, self.shift_size, self.scale)
+        out = window_attention_core(qkv, self.relative_position_bias_table, self._index_i32(), self.num_heads,
+                                    self.shift_size, self.scale)
         return self.proj_drop(self.proj(out))
 
 

@@ -53,7 +53,9 @@ class GraphedForwardBackward:
         for p in params:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the SAME side stream the warm-up ran on: library handles (MIOpen / rocBLAS keep one per stream)
+        # are then already initialised; a fresh capture stream made their lazy set-up run inside the capture (segfault)
+        with torch.cuda.graph(self.graph, stream=side):
             self.static_loss = self._fwd_bwd(self.static_data, self.static_target)
         self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
 
