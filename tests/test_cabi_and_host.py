@@ -1,0 +1,95 @@
+"""CPU: (1) libnnuzoo_hip.so loads and exports every symbol declared in include/nnuzoo_hip.h, and the ctypes
+signature table covers exactly those symbols (no compute calls without a GPU); (2) host-side plumbing of
+BASELINE.json configs[0] (nnUNet 2d, 1x512x512, batch 2, CPU): planner output, deep-supervision scales / weights,
+synthetic batch layout, the loud failure of the product path on CPU tensors, and one oracle step as the CPU
+reference of that configuration."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "nnuzoo_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nnuzoo_amd import _lib
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/nnuzoo_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, set(_lib.SIGNATURES) ^ set(syms)
+    assert lib.nnz_version() == 100
+    assert lib.nnz_selective_scan_state_floats(2, 128, 1000) == 2 * 128 * 16 * 4
+
+
+def test_invalid_arguments_are_rejected_without_gpu():
+    from nnuzoo_amd import _lib
+    lib = _lib.load()
+    # NULL pointers / unsupported shapes return EINVAL before any HIP call
+    assert lib.nnz_conv_tap_forward(None, None, None, None, None, None) == -22
+    assert lib.nnz_window_attention_forward(None, None, None, None, 1, 7, 7, 32, 2, 0, ctypes.c_float(1.0), None) == -22
+    assert lib.nnz_selective_scan_forward(*([None] * 10), 1, 4, 8, 16, 64, 1, None) == -22
+
+
+def test_config0_plumbing_2d_cpu():
+    from nnuzoo_amd.synthetic import conv_flops_forward, nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+    from oracle.losses import deep_supervision_loss, ds_weights
+    from oracle.plain_conv_unet import OraclePlainConvUNet, planner_arch_kwargs
+    plans, cfg, dj = nnunet_plans(2, (512, 512), batch_size=2)
+    arch = plans["configurations"][cfg]["architecture"]["arch_kwargs"]
+    assert cfg == "2d" and arch["n_stages"] == 8
+    assert arch["features_per_stage"] == [32, 64, 128, 256, 512, 512, 512, 512]
+    assert abs(sum(conv_flops_forward(arch, (512, 512)).values()) / 1e9 - 119.2) < 0.1
+    assert plans["configurations"][cfg]["batch_dice"] is True
+    tr = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cpu"))
+    scales = tr._get_deep_supervision_scales()
+    assert len(scales) == 7 and scales[0] == [1.0, 1.0] and scales[-1] == [1 / 64, 1 / 64]
+    w = ds_weights(7)
+    assert w[-1] == 0 and abs(w.sum() - 1) < 1e-12 and abs(w[0] / w[1] - 2) < 1e-12
+    batch = synthetic_batch(2, (512, 512), scales, seed=1234)
+    assert batch["data"].shape == (2, 1, 512, 512) and batch["data"].dtype == torch.float32
+    assert [tuple(t.shape[2:]) for t in batch["target"]] == [(512 >> i, 512 >> i) for i in range(7)]
+    assert all(t.dtype == torch.int16 for t in batch["target"])
+    # the product network exists only as a HIP schedule for 3-D patches; 2-D PlainConvUNet construction says so
+    with pytest.raises(NotImplementedError):
+        tr.initialize()
+    # oracle = the CPU reference of this configuration (reduced to 128^2 here to keep the CPU suite short)
+    torch.manual_seed(0)
+    net = OraclePlainConvUNet(1, num_classes=2, **planner_arch_kwargs(2, 6, [32, 64, 128, 256, 512, 512]))
+    small = synthetic_batch(2, (128, 128), [[1 / 2 ** i] * 2 for i in range(5)], seed=3)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        l = deep_supervision_loss(net(small["data"]), small["target"], batch_dice=True)
+        l.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+        opt.step()
+        losses.append(float(l))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_product_paths_refuse_cpu_tensors():
+    from nnuzoo_amd.selective_scan import selective_scan_fn
+    from nnuzoo_amd.training.loss import DC_and_CE_loss, MemoryEfficientSoftDiceLoss
+    from nnuzoo_amd.window_attention import window_attention_core
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        selective_scan_fn(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8), torch.zeros(4, 16), torch.zeros(1, 1, 16, 8),
+                          torch.zeros(1, 1, 16, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        window_attention_core(torch.zeros(1, 7, 7, 96), torch.zeros(169, 2), torch.zeros(49, 49, dtype=torch.int32), 2, 0, 1.0)
+    loss = DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        loss(torch.zeros(1, 2, 4, 4), torch.zeros(1, 1, 4, 4, dtype=torch.int16))

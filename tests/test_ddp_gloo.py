@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the data-parallel pieces of the hot path that do not need a GPU -
+  * BucketedAllReduce (nnuzoo_amd/ddp.py): gradients handed over stage by stage come back averaged over ranks,
+    whatever the bucket boundaries, including gradients that never passed through stage_done;
+  * attach_bucketed_allreduce broadcasts rank 0's parameters;
+  * AllGatherGrad + MemoryEfficientSoftDiceLoss.dice_from_sums with batch_dice and ddp=True
+    (/root/reference/nnunetv2/utilities/ddp_allgather.py:25-48, training/loss/dice.py:106-110) equals the
+    single-process Dice over the concatenated batch, forward and backward;
+  * the trainer's per-rank batch split (nnUNetTrainer.py:410-453)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nnuzoo_amd.ddp import BucketedAllReduce, attach_bucketed_allreduce
+        from nnuzoo_amd.training.loss import MemoryEfficientSoftDiceLoss
+        torch.manual_seed(100 + rank)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+        red = attach_bucketed_allreduce(net, bucket_bytes=64)  # tiny buckets -> several collectives
+        w0 = [p.detach().clone() for p in net.parameters()]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [w.tolist() for w in w0])
+        assert gathered[0] == gathered[1], "parameters must equal rank 0's after attach"
+        # gradients: rank-dependent, handed over in 2 stages + one straggler that never saw stage_done
+        params = list(net.parameters())
+        grads = {p: torch.full_like(p, float(rank + 1)) * (i + 1) for i, p in enumerate(params)}
+        staged = {}
+        for i, p in enumerate(params[:3]):
+            staged[p] = grads[p]
+        red.stage_done(staged)
+        for p in params[3:5]:
+            staged[p] = grads[p]
+        red.stage_done(staged)
+        out = [grads[p] for p in params]
+        red.finish(out)
+        for i, g in enumerate(out):
+            expect = (1 + 2) / 2.0 * (i + 1)
+            assert torch.allclose(g, torch.full_like(g, expect)), (i, g.flatten()[:3], expect)
+        # batch dice across ranks == dice over the concatenated batch
+        g = torch.Generator().manual_seed(5)
+        inter_all = torch.rand(4, 3, generator=g)
+        pred_all = inter_all + torch.rand(4, 3, generator=g)
+        gt_all = inter_all + torch.rand(4, 3, generator=g)
+        sl = slice(2 * rank, 2 * rank + 2)
+        a = inter_all[sl].clone().requires_grad_(True)
+        b = pred_all[sl].clone().requires_grad_(True)
+        dl = MemoryEfficientSoftDiceLoss(batch_dice=True, do_bg=False, smooth=1e-5, ddp=True)
+        loss = dl.dice_from_sums(a, b, gt_all[sl])
+        loss.backward()
+        ra, rb = inter_all.clone().requires_grad_(True), pred_all.clone().requires_grad_(True)
+        ref = MemoryEfficientSoftDiceLoss(batch_dice=True, do_bg=False, smooth=1e-5, ddp=False).dice_from_sums(ra, rb, gt_all)
+        ref.backward()
+        assert torch.allclose(loss, ref, atol=1e-6)
+        # AllGatherGrad.backward all-reduces (SUM) the identical per-rank gradients: world x the single-process
+        # gradient, which the 1/world of the parameter-gradient averaging cancels (reference semantics)
+        assert torch.allclose(a.grad, world * ra.grad[sl], atol=1e-6)
+        assert torch.allclose(b.grad, world * rb.grad[sl], atol=1e-6)
+        # trainer batch split: global 5 over 2 ranks -> 3 + 2
+        from nnuzoo_amd.synthetic import nnunet_plans
+        from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+        plans, cfg, dj = nnunet_plans(3, (32, 32, 32), batch_size=5)
+        tr = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cpu"))
+        tr._set_batch_size_and_oversample()
+        assert tr.is_ddp and tr.batch_size == (3 if rank == 0 else 2)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_pieces_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
