@@ -292,6 +292,11 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
       if (mvox >= 64 * 64 * 64) return launch_cfg<8, 8, 8, 1, IS, EXT>(p, stream);
       return launch_cfg<4, 8, 8, 1, IS, EXT>(p, stream);
     }
+    // deep, spatially small levels (<= 16^3): the 4x8x8 tile leaves most of the 256 CUs idle, so cut the m-tile
+    // to 2x4x8 (4x the workgroups, one 32x32 MFMA tile per wave)
+    const long wgs488 = (long)p.d.N * p.d.ngroups * (p.d.Cout / 64) * ((p.d.m_dims[0] + 3) / 4) *
+                        ((p.d.m_dims[1] + 7) / 8) * ((p.d.m_dims[2] + 7) / 8);
+    if (wgs488 < 256) return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);
     return launch_cfg<4, 8, 8, 2, IS, EXT>(p, stream);
   } else {
     if (!nb2) return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);  // Cout=32 with IS=2: N-split needs NB>=2

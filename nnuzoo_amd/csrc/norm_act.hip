@@ -40,9 +40,15 @@ __device__ __forceinline__ void store8(f16* p, const float (&v)[8]) {
 }
 
 // MODE 0: stats, 1: apply fwd, 2: bwd reduce, 3: bwd apply
+// Thread = (row r, channel group cg of 8 fp16 = 16 bytes).  Each thread keeps UNR independent 16-byte loads in
+// flight (the loop is latency-bound otherwise: Little's law needs ~64 KB in flight per CU for HBM3E); reductions
+// go lane -> LDS slab [rows][2C] -> one column sum per thread -> one global atomic per (block, channel).
+// (LDS float atomics are avoided: ds_add_f32 measured an order of magnitude slower than plain LDS traffic.)
+constexpr int NRM_UNR = 4;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
-  __shared__ float lred[2 * 640];  // up to 640 channels
+  extern __shared__ float lred[];  // [rows][2C] (MODE 0 / 2)
   const int CG = a.C >> 3;
   const int rows = 256 / CG;
   const int tid = threadIdx.x;
@@ -53,11 +59,6 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
   long v1 = v0 + a.vpb;
   if (v1 > a.V) v1 = a.V;
   const bool active = r < rows;
-
-  if (MODE == 0 || MODE == 2) {
-    for (int i = tid; i < 2 * a.C; i += 256) lred[i] = 0.f;
-    __syncthreads();
-  }
 
   float scale[8], shift[8], mean[8], rstd[8], m1[8], m2[8];
   if (MODE != 0 && active) {
@@ -86,70 +87,89 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
   for (int i = 0; i < 8; ++i) acc0[i] = acc1[i] = 0.f;
 
   if (active) {
-    for (long v = v0 + r; v < v1; v += rows) {
-      const long row = (long)n * a.V + v;
-      float x[8];
-      load8(a.x + row * a.ldx + cg * 8, x);
-      if (MODE == 0) {
+    const long base = (long)n * a.V;
+    for (long v = v0 + r; v < v1; v += (long)rows * NRM_UNR) {
+      f16x8 xh[NRM_UNR], gh[NRM_UNR];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc0[i] += x[i];
-          acc1[i] += x[i] * x[i];
+      for (int k = 0; k < NRM_UNR; ++k) {
+        const long vv = v + (long)k * rows;
+        if (vv < v1) {
+          xh[k] = *reinterpret_cast<const f16x8*>(a.x + (base + vv) * a.ldx + cg * 8);
+          if (MODE >= 2) gh[k] = *reinterpret_cast<const f16x8*>(a.g + (base + vv) * a.ldg + cg * 8);
         }
-      } else if (MODE == 1) {
-        float y[8];
+      }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = leaky(x[i] * scale[i] + shift[i], a.slope);
-        store8(a.y + row * a.ldy + cg * 8, y);
-      } else {
-        float g[8];
-        load8(a.g + row * a.ldg + cg * 8, g);
-        float o[8];
+      for (int k = 0; k < NRM_UNR; ++k) {
+        const long vv = v + (long)k * rows;
+        if (vv >= v1) continue;
+        if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float pre = x[i] * scale[i] + shift[i];
-          const float gp = pre > 0.f ? g[i] : g[i] * a.slope;
-          const float xh = (x[i] - mean[i]) * rstd[i];
-          if (MODE == 2) {
-            acc0[i] += gp;
-            acc1[i] += gp * xh;
-          } else {
-            o[i] = scale[i] * (gp - m1[i] - xh * m2[i]);
+          for (int i = 0; i < 8; ++i) {
+            const float x = (float)xh[k][i];
+            acc0[i] += x;
+            acc1[i] += x * x;
           }
+        } else if (MODE == 1) {
+          f16x8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (f16)leaky((float)xh[k][i] * scale[i] + shift[i], a.slope);
+          *reinterpret_cast<f16x8*>(a.y + (base + vv) * a.ldy + cg * 8) = o;
+        } else {
+          f16x8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float x = (float)xh[k][i], g = (float)gh[k][i];
+            const float pre = x * scale[i] + shift[i];
+            const float gp = pre > 0.f ? g : g * a.slope;
+            const float xn = (x - mean[i]) * rstd[i];
+            if (MODE == 2) {
+              acc0[i] += gp;
+              acc1[i] += gp * xn;
+            } else {
+              o[i] = (f16)(scale[i] * (gp - m1[i] - xn * m2[i]));
+            }
+          }
+          if (MODE == 3) *reinterpret_cast<f16x8*>(a.y + (base + vv) * a.ldy + cg * 8) = o;
         }
-        if (MODE == 3) store8(a.y + row * a.ldy + cg * 8, o);
       }
     }
   }
 
   if (MODE == 0 || MODE == 2) {
+    const int C2 = 2 * a.C;
     if (active) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        atomicAdd(&lred[(cg * 8 + i) * 2 + 0], acc0[i]);
-        atomicAdd(&lred[(cg * 8 + i) * 2 + 1], acc1[i]);
+        lred[r * C2 + (cg * 8 + i) * 2 + 0] = acc0[i];
+        lred[r * C2 + (cg * 8 + i) * 2 + 1] = acc1[i];
       }
     }
     __syncthreads();
-    float* dst = (MODE == 0 ? a.stats : a.red) + (long)n * a.C * 2;
-    for (int i = tid; i < 2 * a.C; i += 256) atomicAdd(dst + i, lred[i]);
+    float* dst = (MODE == 0 ? a.stats : a.red) + (long)n * C2;
+    for (int i = tid; i < C2; i += 256) {
+      float s = 0.f;
+      for (int rr = 0; rr < rows; ++rr) s += lred[rr * C2 + i];
+      atomicAdd(dst + i, s);
+    }
   }
 }
 
 template <int MODE>
 static int launch_norm(NormArgs a, hipStream_t s) {
   if (a.C % 8 || a.C > 640 || a.C < 8) return NNZ_EINVAL;
-  // aim for >= 2048 blocks of >= 512 voxels
+  // ~2048 blocks (8 per CU) of >= 512 voxels; each block sweeps its voxel range with NRM_UNR loads in flight per lane
   long vpb = (a.V * a.N + 2047) / 2048;
   if (vpb < 512) vpb = 512;
   if (vpb > a.V) vpb = a.V;
   a.vpb = (int)vpb;
   const int gx = (int)((a.V + vpb - 1) / vpb);
+  const int rows = 256 / (a.C >> 3);
+  const size_t lds = (MODE == 0 || MODE == 2) ? sizeof(float) * rows * 2 * a.C : 0;
   if (MODE == 0 || MODE == 2) {
     hipError_t e = hipMemsetAsync(MODE == 0 ? a.stats : a.red, 0, sizeof(float) * 2 * a.N * a.C, s);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(norm_kernel<MODE>, dim3(gx, a.N), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(norm_kernel<MODE>, dim3(gx, a.N), dim3(256), lds, s, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
