@@ -230,31 +230,52 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   }
 
   // ---- epilogue: D[row = cout][col = voxel]; lane holds couts (r&3) + 8(r>>2) + 4hh of its voxel -----
+  // The tile is transposed through LDS (the box/weight region is free now) so that global stores are whole
+  // 16-byte pieces in voxel-major order: a wave writes full 128-byte lines.  (Direct 8-byte stores from the
+  // accumulator layout measured WRITE_SIZE = 1.5x the output bytes: partial-line writes.)
+  constexpr int ROWB = NB * 64 + 16;  // LDS bytes per voxel row (+16: spreads the b64 writes over the banks)
+  static_assert(TD * TH * TW * ROWB <= C::LDS_BYTES, "output image must fit the staging LDS");
+  __syncthreads();  // every wave is done reading box / weights
 #pragma unroll
   for (int i = 0; i < C::WN; ++i) {
-    const int co_base = (cb0 + wn * C::WN + i) * 32 + 4 * hh;
+    const int nbl = wn * C::WN + i;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = co_base + 8 * q;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+    for (int j = 0; j < C::WM; ++j) {
+      const int v = (wm * C::WM + j) * 32 + l31;
+      char* row = smem + v * ROWB + (nbl * 32 + 4 * hh) * 2;
 #pragma unroll
-      for (int j = 0; j < C::WM; ++j) {
-        if (out_vox[j] < 0) continue;
-        f16* dst = p.out + (size_t)out_vox[j] + co;
-        float v0 = acc[i][j][4 * q + 0] + bv[0], v1 = acc[i][j][4 * q + 1] + bv[1];
-        float v2 = acc[i][j][4 * q + 2] + bv[2], v3 = acc[i][j][4 * q + 3] + bv[3];
-        if (p.d.accumulate) {
-          const f16x4 old = *reinterpret_cast<const f16x4*>(dst);
-          v0 += (float)old[0];
-          v1 += (float)old[1];
-          v2 += (float)old[2];
-          v3 += (float)old[3];
-        }
-        f16x4 o = {(f16)v0, (f16)v1, (f16)v2, (f16)v3};
-        *reinterpret_cast<f16x4*>(dst) = o;
+      for (int q = 0; q < 4; ++q) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};  // bias joins in fp32, before the single rounding to fp16
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (cb0 + nbl) * 32 + 4 * hh + 8 * q);
+        f16x4 o = {(f16)(acc[i][j][4 * q + 0] + bv[0]), (f16)(acc[i][j][4 * q + 1] + bv[1]),
+                   (f16)(acc[i][j][4 * q + 2] + bv[2]), (f16)(acc[i][j][4 * q + 3] + bv[3])};
+        *reinterpret_cast<f16x4*>(row + 16 * q) = o;
       }
     }
+  }
+  __syncthreads();
+  constexpr int PPV = NB * 4;  // 16-byte pieces per voxel
+  constexpr int NPIECE = TD * TH * TW * PPV;
+#pragma unroll 2
+  for (int c = tid; c < NPIECE; c += 256) {
+    const int v = c / PPV, part = c % PPV;
+    const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+    const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
+    const int od = md * p.d.out_stride + grp.ooff[0];
+    const int oh = mh * p.d.out_stride + grp.ooff[1];
+    const int ow = mw * p.d.out_stride + grp.ooff[2];
+    if (!(md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] && od < p.d.out_dims[0] &&
+          oh < p.d.out_dims[1] && ow < p.d.out_dims[2]))
+      continue;
+    const int co = cb0 * 32 + part * 8;
+    f16* dst = p.out + ((size_t)((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) * p.d.ldo + co;
+    f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + part * 16);
+    if (p.d.accumulate) {
+      const f16x8 old = *reinterpret_cast<const f16x8*>(dst);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) val[e] = (f16)((float)val[e] + (float)old[e]);
+    }
+    *reinterpret_cast<f16x8*>(dst) = val;
   }
 }
 
@@ -312,7 +333,7 @@ extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_pac
   if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
   if (d.Cin % 32 || d.Cout % 32 || d.ngroups < 1 || d.ngroups > NNZ_MAX_GROUPS || d.ntaps_total > NNZ_MAX_TAPS ||
-      d.ldi % 8 || d.ldo % 4 || (d.in_stride != 1 && d.in_stride != 2) || d.ext < 0 || d.ext > 2)
+      d.ldi % 8 || d.ldo % 8 || (d.in_stride != 1 && d.in_stride != 2) || d.ext < 0 || d.ext > 2)
     return NNZ_EINVAL;
   for (int g = 0; g < d.ngroups; ++g)
     if (d.groups[g].ntaps > 27 || d.groups[g].ntaps < 1) return NNZ_EINVAL;
