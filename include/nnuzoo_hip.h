@@ -38,9 +38,15 @@ int nnz_version(void);
 int nnz_conv_tap_forward(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
                          const nnz_conv_desc* desc, void* stream);
 int nnz_conv_tap_wgrad(const void* boxed_f16, const void* plain_f16, float* dw /* [T][A][B] */,
-                       const nnz_conv_desc* desc, void* stream);
+                       const nnz_conv_desc* desc, int dw_pre_zeroed, void* stream);
 int nnz_pack_conv_weight(const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
                          const int* ksel, void* stream);
+/* batched packing: a device-resident table of nnz_pack_job_bytes()-sized records (filled on the host with
+ * nnz_pack_job_fill, uploaded once) packs every layer's weights in one launch */
+int nnz_pack_job_bytes(void);
+int nnz_pack_job_fill(void* out_host, const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
+                      const int* ksel);
+int nnz_pack_conv_weights_batched(const void* jobs_device, int njobs, void* stream);
 int nnz_unpack_conv_wgrad(const float* dw, float* grad, int A, int B, int T, long sa, long sb, long sk,
                           const int* ksel, int accumulate, void* stream);
 
@@ -60,12 +66,12 @@ int nnz_seg_head_wgrad(const void* x_f16, const void* dlogits_f16_nc, float* dw,
  * replaces nn.InstanceNorm3d + nn.LeakyReLU of every conv block (arch kwargs at
  * nnunetv2/experiment_planning/experiment_planners/default_experiment_planner.py:285-305). */
 int nnz_instnorm_stats(const void* x_f16, float* stats /* [N][C][2] sum,sumsq */, int N, long V, int C, int ldx,
-                       void* stream);
+                       int stats_pre_zeroed, void* stream);
 int nnz_instnorm_lrelu_apply(const void* x_f16, const float* stats, const float* gamma, const float* beta, void* y_f16,
                              int N, long V, int C, int ldx, int ldy, float eps, float slope, void* stream);
 int nnz_instnorm_lrelu_bwd_reduce(const void* x_f16, const void* g_f16, const float* stats, const float* gamma,
                                   const float* beta, float* red /* [N][C][2] */, int N, long V, int C, int ldx,
-                                  int ldg, float eps, float slope, void* stream);
+                                  int ldg, float eps, float slope, int red_pre_zeroed, void* stream);
 int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const float* stats, const float* red,
                                  const float* gamma, const float* beta, void* dx_f16, int N, long V, int C, int ldx,
                                  int ldg, int lddx, float eps, float slope, void* stream);

@@ -5,6 +5,7 @@
 // /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1291-1352); these kernels are the only place
 // that knows the packed layout.
 #include "common.hpp"
+#include <string.h>
 
 namespace nnz {
 
@@ -43,7 +44,58 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dw, float* __restr
   }
 }
 
+// One launch packs every layer's weights: a device-resident job table (built once per plan: parameter and packed
+// buffer addresses are stable across steps) replaces ~50 tiny launches per step.
+struct PackJob {
+  const float* src;
+  f16* dst;
+  int R, C, T;
+  int pad;
+  long sr, sc, sk;
+  int ksel[32];
+};
+
+__global__ void pack_weight_batched_kernel(const PackJob* __restrict__ jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  const long total = (long)j.R * j.C * j.T;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r16 = i & 15;
+    long q = i >> 4;
+    const int c32 = q & 31;
+    q >>= 5;
+    const int t = q % j.T;
+    q /= j.T;
+    const int cb = q % (j.C >> 5);
+    const int rb = q / (j.C >> 5);
+    const int r = rb * 16 + r16, c = cb * 32 + c32;
+    j.dst[i] = (f16)j.src[r * j.sr + c * j.sc + j.ksel[t] * j.sk];
+  }
+}
+
 }  // namespace nnz
+
+extern "C" int nnz_pack_job_bytes(void) { return (int)sizeof(nnz::PackJob); }
+
+// host helper: serialise one job into `out` (nnz_pack_job_bytes() bytes) for upload into the device job table
+extern "C" int nnz_pack_job_fill(void* out, const float* src, void* dst_f16, int R, int C, int T, long sr, long sc,
+                                 long sk, const int* ksel) {
+  using namespace nnz;
+  if (!out || !src || !dst_f16 || !ksel || R % 16 || C % 32 || T < 1 || T > 32) return NNZ_EINVAL;
+  PackJob j = {};
+  j.src = src; j.dst = (f16*)dst_f16; j.R = R; j.C = C; j.T = T; j.sr = sr; j.sc = sc; j.sk = sk;
+  for (int i = 0; i < 32; ++i) j.ksel[i] = i < T ? ksel[i] : 0;
+  memcpy(out, &j, sizeof(j));
+  return NNZ_OK;
+}
+
+extern "C" int nnz_pack_conv_weights_batched(const void* jobs_device, int njobs, void* stream) {
+  using namespace nnz;
+  if (!jobs_device || njobs < 1) return NNZ_EINVAL;
+  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(256, njobs), dim3(256), 0, (hipStream_t)stream,
+                     (const PackJob*)jobs_device);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
 
 extern "C" int nnz_pack_conv_weight(const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
                                     const int* ksel, void* stream) {

@@ -87,21 +87,25 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   }
 }
 
-// dW[co][t] = sum_v dy[v][co] * x[v + off_t].  thread = (co, tap group of 4); persistent over tiles.
+// dW[co][t] = sum_v dy[v][co] * x[v + off_t] as an MFMA contraction over voxels (persistent over tiles):
+//   D[row = tap t (27 of 32)][col = co] += A[t][k] * B[k][co],  k = 16 voxels (two h-rows of 8 w)
+//   A: lane (t, hh) gathers x[v_k + off_t] for its 8 voxels (8 consecutive w of the fp16 x tile, 2-byte reads);
+//   B: dy tile [voxel][32 co] through the transposed LDS read (same addressing as conv_wgrad.hip).
+// HBM-bound (one read of dy): the VALU version it replaces ran at 0.45 TB/s.
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles) {
-  __shared__ float xt[ST_BD * ST_BH * ST_BW];
+  __shared__ __attribute__((aligned(16))) f16 xt[ST_BD * ST_BH * ST_BW + 8];
   __shared__ __attribute__((aligned(16))) f16 dyt[ST_TD * ST_TH * ST_TW * ST_CO];
   const int tid = threadIdx.x;
-  const int co = tid & 31;
-  const int tg = tid >> 5;  // 0..7 -> taps tg, tg+8, tg+16, tg+24
-  int toff[4];
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5;
+  const int t = lane & 31;
+  const int toff = t < 27 ? ((t / 9) * ST_BH + (t / 3) % 3) * ST_BW + t % 3 : 0;
+  const int qrow = (lane & 15) >> 2;
+  const int chan_byte = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int t = tg + 8 * i;
-    if (t > 26) t = 26;
-    toff[i] = ((t / 9) * ST_BH + (t / 3) % 3) * ST_BW + t % 3;
-  }
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int tiles_per_n = a.tiles[0] * a.tiles[1] * a.tiles[2];
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / tiles_per_n;
@@ -112,7 +116,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
     const int td_i = r / a.tiles[1];
     const int m0d = td_i * ST_TD, m0h = th_i * ST_TH, m0w = tw_i * ST_TW;
     __syncthreads();
-    stem_load_tile(a, n, m0d, m0h, m0w, xt);
+    for (int i = tid; i < ST_BD * ST_BH * ST_BW; i += 256) {
+      const int bw = i % ST_BW, bh = (i / ST_BW) % ST_BH, bd = i / (ST_BW * ST_BH);
+      const int id = m0d + bd - 1, ih = m0h + bh - 1, iw = m0w + bw - 1;
+      float v = 0.f;
+      if ((unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+        v = a.x[(((long)n * a.D + id) * a.H + ih) * a.W + iw];
+      xt[i] = (f16)v;
+    }
     for (int i = tid; i < ST_TD * ST_TH * ST_TW * 4; i += 256) {
       const int part = i & 3, v = i >> 2;
       const int tw = v % ST_TW, th = (v / ST_TW) % ST_TH, td = v / (ST_TW * ST_TH);
@@ -123,18 +134,39 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
       *reinterpret_cast<u32x4*>(dyt + v * ST_CO + part * 8) = val;
     }
     __syncthreads();
-    for (int v = 0; v < ST_TD * ST_TH * ST_TW; ++v) {
-      const float g = (float)dyt[v * ST_CO + co];
-      const int tw = v % ST_TW, th = (v / ST_TW) % ST_TH, td = v / (ST_TW * ST_TH);
-      const float* xb = xt + (td * ST_BH + th) * ST_BW + tw;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] += g * xb[toff[i]];
+    for (int kq = 0; kq < 4; ++kq) {
+      const int kb = wave * 4 + kq;        // 16 k-blocks of 16 voxels, 4 per wave
+      const int v0 = kb * 16 + 8 * hh;     // first voxel of this lane half's h-row (tw = 0)
+      const int th = (v0 / ST_TW) % ST_TH, td = v0 / (ST_TW * ST_TH);
+      const char* qb = reinterpret_cast<const char*>(dyt) + (v0 + qrow) * 64 + chan_byte;
+      union { i16x4 v[2]; f16x8 h; } ub;
+      ub.v[0] = lds_read_tr16(qb);
+      ub.v[1] = lds_read_tr16(qb + 4 * 64);
+      const f16* xr = xt + (td * ST_BH + th) * ST_BW + toff;
+      f16x8 av;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = xr[j];
+      acc = mfma32(av, ub.h, acc);
     }
   }
+  // D[row = t][col = co]: row = (r&3) + 8(r>>2) + 4hh, col = lane & 31.  The 4 waves' partial tiles are summed
+  // through LDS (reusing the dy tile) so that the workgroup issues ONE atomic per element: 864 hot addresses
+  // shared by every workgroup serialise badly otherwise (MI355X_MICROARCH.md, global float atomics, contention row).
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(dyt);  // [4 waves][32 t][32 co] fp32 = 16 KB
+  const int co = lane & 31;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int t = tg + 8 * i;
-    if (t < 27) atomicAdd(a.dw + co * 27 + t, acc[i]);
+  for (int r = 0; r < 16; ++r) {
+    const int tt = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    red[(wave * 32 + tt) * 32 + co] = acc[r];
+  }
+  __syncthreads();
+  for (int i = tid; i < 27 * 32; i += 256) {
+    const int tt = i / 32, c = i % 32;
+    const float s = red[(0 * 32 + tt) * 32 + c] + red[(1 * 32 + tt) * 32 + c] + red[(2 * 32 + tt) * 32 + c] +
+                    red[(3 * 32 + tt) * 32 + c];
+    atomicAdd(a.dw + c * 27 + tt, s);
   }
 }
 
@@ -292,7 +324,7 @@ extern "C" int nnz_stem_conv_wgrad(const float* x, const void* dy, float* dw, in
   const int ntiles = N * a.tiles[0] * a.tiles[1] * a.tiles[2];
   hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * ST_CO * 27, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  const int grid = ntiles < 2048 ? ntiles : 2048;
+  const int grid = ntiles < 512 ? ntiles : 512;  // persistent: 2 workgroups per CU, one atomic per element each
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ntiles);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
 }
 
 template <int TD, int TH, int TW, int IS, int EXT>
-static int launch_wg(const WgradDev& base, hipStream_t stream) {
+static int launch_wg(const WgradDev& base, hipStream_t stream, bool pre_zeroed) {
   using C = WgCfg<TD, TH, TW, IS, EXT>;
   WgradDev p = base;
   p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
@@ -232,8 +232,10 @@ static int launch_wg(const WgradDev& base, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.d.ntaps_total * p.d.Cin * p.d.Cout, stream);
-  if (e != hipSuccess) return (int)e;
+  if (!pre_zeroed) {
+    hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.d.ntaps_total * p.d.Cin * p.d.Cout, stream);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL(kern, dim3(pairs * splits), dim3(256), C::LDS_BYTES, stream, p);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -242,7 +244,7 @@ static int launch_wg(const WgradDev& base, hipStream_t stream) {
 }  // namespace nnz
 
 extern "C" int nnz_conv_tap_wgrad(const void* boxed, const void* plain, float* dw, const nnz_conv_desc* desc,
-                                  void* stream) {
+                                  int pre_zeroed, void* stream) {
   using namespace nnz;
   if (!boxed || !plain || !dw || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
@@ -256,11 +258,11 @@ extern "C" int nnz_conv_tap_wgrad(const void* boxed, const void* plain, float* d
   p.d = d;
   hipStream_t s = (hipStream_t)stream;
   if (d.in_stride == 1) {
-    if (d.ext == 0) return launch_wg<4, 8, 8, 1, 0>(p, s);
-    if (d.ext == 1) return launch_wg<4, 8, 8, 1, 1>(p, s);
-    return launch_wg<4, 8, 8, 1, 2>(p, s);
+    if (d.ext == 0) return launch_wg<4, 8, 8, 1, 0>(p, s, pre_zeroed != 0);
+    if (d.ext == 1) return launch_wg<4, 8, 8, 1, 1>(p, s, pre_zeroed != 0);
+    return launch_wg<4, 8, 8, 1, 2>(p, s, pre_zeroed != 0);
   } else {
-    if (d.ext <= 1) return launch_wg<2, 4, 8, 2, 1>(p, s);
-    return launch_wg<2, 4, 8, 2, 2>(p, s);
+    if (d.ext <= 1) return launch_wg<2, 4, 8, 2, 1>(p, s, pre_zeroed != 0);
+    return launch_wg<2, 4, 8, 2, 2>(p, s, pre_zeroed != 0);
   }
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
 }
 
 template <int MODE>
-static int launch_norm(NormArgs a, hipStream_t s) {
+static int launch_norm(NormArgs a, hipStream_t s, bool pre_zeroed = false) {
   if (a.C % 8 || a.C > 640 || a.C < 8) return NNZ_EINVAL;
   // ~2048 blocks (8 per CU) of >= 512 voxels; each block sweeps its voxel range with NRM_UNR loads in flight per lane
   long vpb = (a.V * a.N + 2047) / 2048;
@@ -165,7 +165,7 @@ static int launch_norm(NormArgs a, hipStream_t s) {
   const int gx = (int)((a.V + vpb - 1) / vpb);
   const int rows = 256 / (a.C >> 3);
   const size_t lds = (MODE == 0 || MODE == 2) ? sizeof(float) * rows * 2 * a.C : 0;
-  if (MODE == 0 || MODE == 2) {
+  if ((MODE == 0 || MODE == 2) && !pre_zeroed) {
     hipError_t e = hipMemsetAsync(MODE == 0 ? a.stats : a.red, 0, sizeof(float) * 2 * a.N * a.C, s);
     if (e != hipSuccess) return (int)e;
   }
@@ -176,14 +176,15 @@ static int launch_norm(NormArgs a, hipStream_t s) {
 
 }  // namespace nnz
 
-extern "C" int nnz_instnorm_stats(const void* x, float* stats, int N, long V, int C, int ldx, void* stream) {
+extern "C" int nnz_instnorm_stats(const void* x, float* stats, int N, long V, int C, int ldx, int pre_zeroed,
+                                  void* stream) {
   using namespace nnz;
   if (!x || !stats) return NNZ_EINVAL;
   NormArgs a = {};
   a.x = (const f16*)x;
   a.stats = stats;
   a.N = N; a.V = V; a.C = C; a.ldx = ldx;
-  return launch_norm<0>(a, (hipStream_t)stream);
+  return launch_norm<0>(a, (hipStream_t)stream, pre_zeroed != 0);
 }
 
 extern "C" int nnz_instnorm_lrelu_apply(const void* x, const float* stats, const float* gamma, const float* beta,
@@ -203,7 +204,7 @@ extern "C" int nnz_instnorm_lrelu_apply(const void* x, const float* stats, const
 
 extern "C" int nnz_instnorm_lrelu_bwd_reduce(const void* x, const void* g, const float* stats, const float* gamma,
                                              const float* beta, float* red, int N, long V, int C, int ldx, int ldg,
-                                             float eps, float slope, void* stream) {
+                                             float eps, float slope, int pre_zeroed, void* stream) {
   using namespace nnz;
   if (!x || !g || !stats || !gamma || !beta || !red) return NNZ_EINVAL;
   NormArgs a = {};
@@ -213,7 +214,7 @@ extern "C" int nnz_instnorm_lrelu_bwd_reduce(const void* x, const void* g, const
   a.gamma = gamma; a.beta = beta;
   a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldg = ldg;
   a.eps = eps; a.slope = slope;
-  return launch_norm<2>(a, (hipStream_t)stream);
+  return launch_norm<2>(a, (hipStream_t)stream, pre_zeroed != 0);
 }
 
 extern "C" int nnz_instnorm_lrelu_bwd_apply(const void* x, const void* g, const float* stats, const float* red,

@@ -91,10 +91,39 @@ def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor,
                             stream_ptr()))
 
 
-def conv_tap_wgrad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, dw: torch.Tensor) -> None:
+def conv_tap_wgrad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, dw: torch.Tensor,
+                   pre_zeroed: bool = False) -> None:
     _f16(boxed, "wgrad.boxed"); _f16(plain, "wgrad.plain"); _f32(dw, "wgrad.dw")
     TIMER.wrap("conv_wgrad_kernel", pt.flops,
-               lambda: call("nnz_conv_tap_wgrad", ptr(boxed), ptr(plain), ptr(dw), C.byref(pt.desc), stream_ptr()))
+               lambda: call("nnz_conv_tap_wgrad", ptr(boxed), ptr(plain), ptr(dw), C.byref(pt.desc), int(pre_zeroed),
+                            stream_ptr()))
+
+
+class PackJobTable:
+    """Device-resident table of weight-pack jobs (one launch packs all of them)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+        self.table = None
+
+    def add(self, param: torch.Tensor, dst: torch.Tensor, pt: PreparedTable, R: int, Cc: int, sr: int, sc: int, sk: int):
+        self.jobs.append((param, dst, pt, R, Cc, sr, sc, sk))
+        self.table = None
+
+    def run(self):
+        lib = _lib.load()
+        if self.table is None:
+            nb = lib.nnz_pack_job_bytes()
+            host = (C.c_char * (nb * len(self.jobs)))()
+            for i, (param, dst, pt, R, Cc, sr, sc, sk) in enumerate(self.jobs):
+                _lib.check(lib.nnz_pack_job_fill(C.byref(host, i * nb), ptr(param), ptr(dst), R, Cc, pt.table.ntaps, sr, sc,
+                                                 sk, pt.pack_ksel), "nnz_pack_job_fill")
+            self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+            self._ptrs = [(j[0].data_ptr(), j[1].data_ptr()) for j in self.jobs]
+        else:
+            assert self._ptrs == [(j[0].data_ptr(), j[1].data_ptr()) for j in self.jobs], "parameter storage moved"
+        call("nnz_pack_conv_weights_batched", ptr(self.table), len(self.jobs), stream_ptr())
 
 
 def unpack_wgrad(dw: torch.Tensor, grad: torch.Tensor, A: int, B: int, T: int, sa: int, sb: int, sk: int,
@@ -131,9 +160,9 @@ def head_wgrad(x, dlogits, dw, db, N, V, Cc, K, ldx):
     call("nnz_seg_head_wgrad", ptr(x), ptr(dlogits), ptr(dw), ptr(db), N, V, Cc, K, ldx, stream_ptr())
 
 
-def instnorm_stats(x, stats, N, V, Cc, ldx):
+def instnorm_stats(x, stats, N, V, Cc, ldx, pre_zeroed: bool = False):
     _f16(x, "in.x"); _f32(stats, "in.stats")
-    call("nnz_instnorm_stats", ptr(x), ptr(stats), N, V, Cc, ldx, stream_ptr())
+    call("nnz_instnorm_stats", ptr(x), ptr(stats), N, V, Cc, ldx, int(pre_zeroed), stream_ptr())
 
 
 def instnorm_lrelu_apply(x, stats, gamma, beta, y, N, V, Cc, ldx, ldy, eps, slope):
@@ -142,10 +171,11 @@ def instnorm_lrelu_apply(x, stats, gamma, beta, y, N, V, Cc, ldx, ldy, eps, slop
          eps, slope, stream_ptr())
 
 
-def instnorm_lrelu_bwd(x, g, stats, gamma, beta, red, dx, N, V, Cc, ldx, ldg, lddx, eps, slope):
+def instnorm_lrelu_bwd(x, g, stats, gamma, beta, red, dx, N, V, Cc, ldx, ldg, lddx, eps, slope,
+                       pre_zeroed: bool = False):
     _f16(x, "in.x"); _f16(g, "in.g"); _f16(dx, "in.dx"); _f32(stats, "in.stats"); _f32(red, "in.red")
     call("nnz_instnorm_lrelu_bwd_reduce", ptr(x), ptr(g), ptr(stats), ptr(gamma), ptr(beta), ptr(red), N, V, Cc,
-         ldx, ldg, eps, slope, stream_ptr())
+         ldx, ldg, eps, slope, int(pre_zeroed), stream_ptr())
     call("nnz_instnorm_lrelu_bwd_apply", ptr(x), ptr(g), ptr(stats), ptr(red), ptr(gamma), ptr(beta), ptr(dx), N, V,
          Cc, ldx, ldg, lddx, eps, slope, stream_ptr())
 

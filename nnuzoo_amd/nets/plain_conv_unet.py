@@ -211,9 +211,37 @@ class _Plan:
             for i, b in enumerate(self.enc_blocks[s]):
                 if i > 0:
                     b.x_ld = self.enc_blocks[s][i - 1].y_ld
-        for blocks in self.enc_blocks + self.dec_blocks:
-            for b in blocks:
-                b.prepare()
+        self.all_blocks: List[_Block] = [b for blocks in self.enc_blocks + self.dec_blocks for b in blocks]
+        so = do = 0
+        for b in self.all_blocks:
+            b.prepare()
+            b.stats_off, so = so, so + N * b.cout * 2          # slice of the per-step statistics buffer
+            b.dw_off = do
+            if not b.stem:
+                do += 27 * b.cin * b.cout                         # slice of the per-step dW buffer
+        for u in self.ups:
+            u.dw_off, do = do, do + 8 * u.cout * u.cin
+        self.stats_floats, self.dw_floats = so, do
+        self.pack_fwd = self.pack_bwd = None                      # built on first use (needs device pointers)
+
+    def build_pack_tables(self, dev):
+        """persistent packed-weight buffers + device job tables: ONE pack launch per forward and per backward"""
+        f16 = torch.float16
+        self.pack_fwd, self.pack_bwd = ops.PackJobTable(dev), ops.PackJobTable(dev)
+        for b in self.all_blocks:
+            if b.stem:
+                continue
+            w = b.h.conv.weight
+            b.wp_fwd = torch.empty(b.cin * b.cout * 27, dtype=f16, device=dev)
+            b.wp_dgrad = torch.empty(b.cin * b.cout * 27, dtype=f16, device=dev)
+            self.pack_fwd.add(w, b.wp_fwd, b.fwd, b.cin, b.cout, 27, b.cin * 27, 1)
+            self.pack_bwd.add(w, b.wp_dgrad, b.dgrad, b.cout, b.cin, b.cin * 27, 27, 1)
+        for u in self.ups:
+            w = u.m.weight
+            u.wp_fwd = torch.empty(u.cin * u.cout * 8, dtype=f16, device=dev)
+            u.wp_dgrad = torch.empty(u.cin * u.cout * 8, dtype=f16, device=dev)
+            self.pack_fwd.add(w, u.wp_fwd, u.fwd, u.cin, u.cout, u.cout * 8, 8, 1)
+            self.pack_bwd.add(w, u.wp_dgrad, u.dgrad, u.cout, u.cin, 8, u.cout * 8, 1)
 
 
 def _check_supported(net: "PlainConvUNet"):
@@ -335,16 +363,15 @@ class PlainConvUNet(nn.Module):
         return outs[0]
 
     # ---- forward schedule ----------------------------------------------------------------------------------------
-    def _conv_block_fwd(self, b: _Block, x_act: torch.Tensor, act_out: torch.Tensor, dev):
+    def _conv_block_fwd(self, b: _Block, x_act: torch.Tensor, act_out: torch.Tensor, dev, stats_all):
         h = b.h
         raw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
-        stats = torch.empty((b.N, b.cout, 2), dtype=torch.float32, device=dev)
+        stats = stats_all[b.stats_off:b.stats_off + b.N * b.cout * 2].view(b.N, b.cout, 2)  # zeroed once per step
         if b.stem:
             ops.stem_forward(x_act, h.conv.weight, h.conv.bias, raw, (b.N, *b.in_dims), b.cout)
         else:
-            wp = ops.pack_weight(h.conv.weight, b.fwd, b.cin, b.cout, 27, b.cin * 27, 1)
-            ops.conv_tap_forward(b.fwd, x_act, wp, h.conv.bias, raw)
-        ops.instnorm_stats(raw, stats, b.N, b.V, b.cout, b.cout)
+            ops.conv_tap_forward(b.fwd, x_act, b.wp_fwd, h.conv.bias, raw)
+        ops.instnorm_stats(raw, stats, b.N, b.V, b.cout, b.cout, pre_zeroed=True)
         ops.instnorm_lrelu_apply(raw, stats, h.norm.weight, h.norm.bias, act_out, b.N, b.V, b.cout, b.cout, b.y_ld,
                                  b.eps, b.slope)
         return raw, stats
@@ -358,6 +385,10 @@ class PlainConvUNet(nn.Module):
         feats = self.encoder.output_channels
         K = self.num_classes
         f16 = torch.float16
+        if plan.pack_fwd is None:
+            plan.build_pack_tables(dev)
+        plan.pack_fwd.run()
+        stats_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
         cats = [torch.empty((N, int(np.prod(plan.level_dims[s])), 2 * feats[s]), dtype=f16, device=dev)
                 for s in range(S - 1)]
         rec = {"x": x, "plan": plan, "cats": cats, "enc": [], "dec": [], "heads": []}
@@ -370,7 +401,7 @@ class PlainConvUNet(nn.Module):
                     act = cats[s][:, :, feats[s]:]
                 else:
                     act = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
-                raw, stats = self._conv_block_fwd(b, cur, act, dev)
+                raw, stats = self._conv_block_fwd(b, cur, act, dev, stats_all)
                 stage_rec.append((cur, raw, stats, act))
                 cur = act
             rec["enc"].append(stage_rec)
@@ -379,13 +410,12 @@ class PlainConvUNet(nn.Module):
         for j in range(S - 1):
             lvl = S - 2 - j
             up = plan.ups[j]
-            wp = ops.pack_weight(up.m.weight, up.fwd, up.cin, up.cout, up.cout * 8, 8, 1)
-            ops.conv_tap_forward(up.fwd, lres, wp, up.m.bias, cats[lvl])
+            ops.conv_tap_forward(up.fwd, lres, up.wp_fwd, up.m.bias, cats[lvl])
             cur = cats[lvl]
             stage_rec = []
             for b in plan.dec_blocks[j]:
                 act = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
-                raw, stats = self._conv_block_fwd(b, cur, act, dev)
+                raw, stats = self._conv_block_fwd(b, cur, act, dev, stats_all)
                 stage_rec.append((cur, raw, stats, act))
                 cur = act
             rec["dec"].append((lres, stage_rec))
@@ -406,10 +436,10 @@ class PlainConvUNet(nn.Module):
         block input into dx_out (None for the stem) and the parameter gradients into `grads`."""
         x_in, raw, stats, _ = recd
         h = b.h
-        red = torch.empty((b.N, b.cout, 2), dtype=torch.float32, device=dev)
+        red = self._red_all[b.stats_off:b.stats_off + b.N * b.cout * 2].view(b.N, b.cout, 2)  # zeroed once per step
         draw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
         ops.instnorm_lrelu_bwd(raw, g_act, stats, h.norm.weight, h.norm.bias, red, draw, b.N, b.V, b.cout, b.cout, g_ld,
-                               b.cout, b.eps, b.slope)
+                               b.cout, b.eps, b.slope, pre_zeroed=True)
         rs = red.sum(0)
         grads[h.norm.weight] = rs[:, 1].contiguous()
         grads[h.norm.bias] = rs[:, 0].contiguous()
@@ -419,11 +449,10 @@ class PlainConvUNet(nn.Module):
         if b.stem:
             ops.stem_wgrad(x_in, draw, gw, (b.N, *b.in_dims), b.cout)
         else:
-            dw = torch.empty((27, b.cin, b.cout), dtype=torch.float32, device=dev)
-            ops.conv_tap_wgrad(b.wgrad, x_in, draw, dw)
+            dw = self._dw_all[b.dw_off:b.dw_off + 27 * b.cin * b.cout].view(27, b.cin, b.cout)
+            ops.conv_tap_wgrad(b.wgrad, x_in, draw, dw, pre_zeroed=True)
             ops.unpack_wgrad(dw, gw, b.cin, b.cout, 27, 27, b.cin * 27, 1, b.wgrad)
-            wp = ops.pack_weight(h.conv.weight, b.dgrad, b.cout, b.cin, b.cin * 27, 27, 1)
-            ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, wp, None, dx_out)
+            ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
         grads[h.conv.weight] = gw
 
     def _run_backward(self, rec, gouts):
@@ -434,6 +463,9 @@ class PlainConvUNet(nn.Module):
         dev = rec["x"].device
         f16 = torch.float16
         grads = {}
+        plan.pack_bwd.run()
+        self._red_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
+        self._dw_all = torch.zeros(plan.dw_floats, dtype=torch.float32, device=dev)
         gout_by_level = {lvl: g for lvl, g in zip(rec["out_levels"], gouts)}
         g_cur = None  # gradient wrt the current decoder stage output (act), contiguous [N, V, C]
         g_cats = [None] * (S - 1)
@@ -478,8 +510,8 @@ class PlainConvUNet(nn.Module):
             up = plan.ups[j]
             g_up = g_act  # channel slice [:C] of the cat gradient, ld = 2C
             Vb = int(np.prod(up.in_dims))
-            dwt = torch.empty((8, up.cout, up.cin), dtype=torch.float32, device=dev)
-            ops.conv_tap_wgrad(up.wgrad, g_up, lres, dwt)
+            dwt = self._dw_all[up.dw_off:up.dw_off + 8 * up.cout * up.cin].view(8, up.cout, up.cin)
+            ops.conv_tap_wgrad(up.wgrad, g_up, lres, dwt, pre_zeroed=True)
             gw = torch.empty_like(up.m.weight)
             ops.unpack_wgrad(dwt, gw, up.cout, up.cin, 8, 8, up.cout * 8, 1, up.wgrad)
             grads[up.m.weight] = gw
@@ -488,8 +520,7 @@ class PlainConvUNet(nn.Module):
                 ops.instnorm_stats(g_up, st, N, V, up.cout, 2 * up.cout)
                 grads[up.m.bias] = st[:, :, 0].sum(0).contiguous()
             g_below = torch.empty((N, Vb, up.cin), dtype=f16, device=dev)
-            wp = ops.pack_weight(up.m.weight, up.dgrad, up.cout, up.cin, 8, up.cout * 8, 1)
-            ops.conv_tap_forward(up.dgrad, g_up, wp, None, g_below)
+            ops.conv_tap_forward(up.dgrad, g_up, up.wp_dgrad, None, g_below)
             g_cur = g_below
             if self.grad_reducer is not None:
                 self.grad_reducer.stage_done(grads)
@@ -522,6 +553,7 @@ class PlainConvUNet(nn.Module):
             out.append(gp if gp is not None else torch.zeros_like(p))
         if self.grad_reducer is not None:
             self.grad_reducer.finish(out)
+        self._red_all = self._dw_all = None
         return out
 
     # reference API (dynamic_network_architectures): used by the planner's VRAM estimate only
