@@ -55,20 +55,22 @@ struct PackJob {
   int ksel[32];
 };
 
-__global__ void pack_weight_batched_kernel(const PackJob* __restrict__ jobs) {
+// One wave per (output channel c, block of 16 reduction channels): the 16 x T source elements are read in source
+// order (runs of T contiguous floats for the conv layouts), transposed through LDS and written as T runs of 32 bytes.
+__global__ __launch_bounds__(256) void pack_weight_batched_kernel(const PackJob* __restrict__ jobs) {
+  __shared__ float tile[4][16 * 32];
   const PackJob j = jobs[blockIdx.y];
-  const long total = (long)j.R * j.C * j.T;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int r16 = i & 15;
-    long q = i >> 4;
-    const int c32 = q & 31;
-    q >>= 5;
-    const int t = q % j.T;
-    q /= j.T;
-    const int cb = q % (j.C >> 5);
-    const int rb = q / (j.C >> 5);
-    const int r = rb * 16 + r16, c = cb * 32 + c32;
-    j.dst[i] = (f16)j.src[r * j.sr + c * j.sc + j.ksel[t] * j.sk];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int units = j.C * (j.R >> 4);
+  const int n16 = 16 * j.T;
+  for (int u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+    const int c = u % j.C, rb = u / j.C;
+    for (int e = lane; e < n16; e += 64) {
+      const int r16 = e / j.T, t = e % j.T;
+      tile[wave][t * 16 + r16] = j.src[(long)(rb * 16 + r16) * j.sr + (long)c * j.sc + (long)j.ksel[t] * j.sk];
+    }
+    f16* dst = j.dst + ((long)(rb * (j.C >> 5) + (c >> 5)) * j.T) * 512 + (c & 31) * 16;
+    for (int o = lane; o < n16; o += 64) dst[(long)(o >> 4) * 512 + (o & 15)] = (f16)tile[wave][o];
   }
 }
 

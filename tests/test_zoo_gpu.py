@@ -77,6 +77,24 @@ def test_ss2d_golden(hip_lib):
         close(g, z["g_" + n], "g_" + n, rtol=3e-4)
 
 
+@pytest.mark.parametrize("tag,sd", [("3d", 3), ("2d", 2)])
+def test_ssnd_golden(hip_lib, tag, sd):
+    """N-D scan block incl. the reference's 3-D direction quirk (ssnd2net.py:291-298)."""
+    from nnuzoo_amd.nets.ssnd import SSND
+    z = np.load(os.path.join(G, f"ssnd{tag}.npz"))
+    x = torch.tensor(z["x"]).cuda().requires_grad_(True)
+    m = SSND(spatial_dims=sd, factorization_type="cross-scan", d_model=x.shape[-1]).cuda().eval()
+    det_fill(m)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in z["names"]]
+    y = m(x)
+    close(y, z["y"], "y")
+    params = list(m.named_parameters())
+    grads = torch.autograd.grad(y, [x] + [p for _, p in params], torch.tensor(z["dy"]).cuda())
+    close(grads[0], z["dx"], "dx", rtol=3e-4)
+    for (n, _), g in zip(params, grads[1:]):
+        close(g, z["g_" + n], "g_" + n, rtol=3e-4)
+
+
 @pytest.mark.parametrize("name", ["M2NetP", "SwT2Net"])
 def test_whole_net_forward_golden(hip_lib, name):
     from nnuzoo_amd.nets import m2net, swt2net

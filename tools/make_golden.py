@@ -143,6 +143,23 @@ def gen_ss2d():
                         **{"g_" + n: gr.numpy() for (n, _), gr in zip(params, grads[1:])})
 
 
+def gen_ssnd():
+    from nnunetv2.nets import ssnd2net
+    for tag, (sd, shp) in {"3d": (3, (1, 4, 6, 8, 8)), "2d": (2, (2, 6, 10, 8))}.items():
+        m = ssnd2net.SSND(spatial_dims=sd, factorization_type="cross-scan", d_model=shp[-1])
+        det_fill(m)
+        m.eval()
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn(*shp, generator=g, requires_grad=True)
+        y = m(x)
+        dy = torch.randn(y.shape, generator=g)
+        params = list(m.named_parameters())
+        grads = torch.autograd.grad(y, [x] + [p for _, p in params], dy)
+        np.savez_compressed(os.path.join(OUT, f"ssnd{tag}.npz"), x=x.detach().numpy(), y=y.detach().numpy(),
+                            dy=dy.numpy(), dx=grads[0].numpy(), names=np.array([n for n, _ in params]),
+                            **{"g_" + n: gr.numpy() for (n, _), gr in zip(params, grads[1:])})
+
+
 def gen_nets():
     from nnunetv2.nets import m2net, swt2net
     man = {}
@@ -166,7 +183,7 @@ def gen_nets():
 
 if __name__ == "__main__":
     ref = ref_shim.install()
-    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "nets"]
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets"]
     if "scan" in which:
         gen_selective_scan(ref)
     if "loss" in which:
@@ -175,6 +192,8 @@ if __name__ == "__main__":
         gen_window_attention()
     if "ss2d" in which:
         gen_ss2d()
+    if "ssnd" in which:
+        gen_ssnd()
     if "nets" in which:
         gen_nets()
     print(sorted(os.listdir(OUT)))
