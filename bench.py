@@ -28,7 +28,7 @@ import torch.distributed as dist
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-def cpu_baseline(edge: int = 96):
+def cpu_baseline(edge: int = 64):
     """One full training step of the CPU oracle (reference-equivalent torch-CPU path: fp32, no autocast, all host
     threads as run_training.py:256-260 does for -device cpu) on ONE patch of edge^3, scaled to 128^3 by voxels."""
     import multiprocessing

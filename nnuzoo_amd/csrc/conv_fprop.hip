@@ -64,7 +64,8 @@ struct ConvCfg {
   static constexpr int WN = NB / WAVES_N;
   static_assert(TW == 8, "lane->voxel map assumes TW == 8");
   static_assert(NB % WAVES_N == 0 && WN >= 1, "NB must cover the N-split of the waves");
-  static constexpr int LDS_BYTES = BOX_BYTES + W_BYTES_MAX;
+  static constexpr int OUT_BYTES = TD * TH * TW * (NB * 64 + 16);  // epilogue staging image
+  static constexpr int LDS_BYTES = BOX_BYTES + W_BYTES_MAX > OUT_BYTES ? BOX_BYTES + W_BYTES_MAX : OUT_BYTES;
 };
 
 template <int TD, int TH, int TW, int NB, int IS, int EXT>
@@ -318,6 +319,8 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
     const long wgs488 = (long)p.d.N * p.d.ngroups * (p.d.Cout / 64) * ((p.d.m_dims[0] + 3) / 4) *
                         ((p.d.m_dims[1] + 7) / 8) * ((p.d.m_dims[2] + 7) / 8);
     if (wgs488 < 256) return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);
+    // (an 8x8x8 x 64-cout tile was tried for the large levels to halve the weight staging per voxel: 210 VGPRs,
+    //  spills and 1 workgroup per CU made it 7-13 % slower than 4x8x8 - measured, round 1)
     return launch_cfg<4, 8, 8, 2, IS, EXT>(p, stream);
   } else {
     if (!nb2) return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);  // Cout=32 with IS=2: N-split needs NB>=2
