@@ -86,16 +86,9 @@ def test_full_length_properties(hip_lib):
     yp = selective_scan_fn(u[..., :Lp].contiguous(), delta[..., :Lp].contiguous(), A, B[..., :Lp].contiguous(),
                            C[..., :Lp].contiguous(), None, None, bias, True)
     assert torch.allclose(yp, y[..., :Lp], rtol=1e-4, atol=1e-4 * y.abs().max().item())
-    # (iii) exact oracle on the LAST 2000 steps of a few rows, restarted from zero state 6000 steps earlier:
+    # (iii) exact oracle on the LAST 2000 steps of one row, restarted from a zero state 6000 steps earlier:
     #       exp(delta*A) <= exp(-softplus(.)*|A|) decays any earlier state far below fp32 resolution
-    rows = [0, 37, 127]
-    t0, t1 = L - 8000, L - 2000
-    yo = selective_scan_torch(u[:, rows, t0:].cpu(), delta[:, rows, t0:].cpu(), A[rows].cpu(),
-                              B[:, [r // Dg for r in rows]][..., t0:].cpu().reshape(b, 3, N, -1)[:, :1].repeat(1, 1, 1, 1)
-                              if False else B[..., t0:].cpu()[:, [0]], C[..., t0:].cpu()[:, [0]], None,
-                              bias[rows].cpu(), True) if False else None
-    # simpler: single row of group 0
-    r = 5
+    r, t0, t1 = 5, L - 8000, L - 2000
     yo = selective_scan_torch(u[:, r:r + 1, t0:].cpu(), delta[:, r:r + 1, t0:].cpu(), A[r:r + 1].cpu(),
                               B[:, 0:1, :, t0:].cpu(), C[:, 0:1, :, t0:].cpu(), None, bias[r:r + 1].cpu(), True)
     got = y[:, r:r + 1, t1:].cpu()
