@@ -47,7 +47,7 @@ struct WgCfg {
   static_assert(TW == 8, "k-block map assumes TW == 8");
 };
 
-template <int TD, int TH, int TW, int IS, int EXT>
+template <int TD, int TH, int TW, int IS, int EXT, int MAXT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   using C = WgCfg<TD, TH, TW, IS, EXT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,8 +69,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   const int Do = p.d.out_dims[0], Ho = p.d.out_dims[1], Wo = p.d.out_dims[2];
   const int tiles_per_n = p.tiles[0] * p.tiles[1] * p.tiles[2];
 
-  // taps of this wave: wave, wave+4, ...  (at most 7 with T <= 27... 8 taps for the k2s2 transpose: 2 each)
-  constexpr int MAXT = 7;
+  // taps of this wave: wave, wave+4, ...  (MAXT = 7 for 27 taps, 2 for the 8 taps of the k2s2 transpose)
   int tap_off[MAXT];
   int ntw = 0;
 #pragma unroll
@@ -179,17 +178,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         bq = u.h;
       }
       const int bbase = ((((td * IS) * C::BH + th * IS) * C::BW) + qrow * IS) * 64 + chan_byte;
+      // branch-free over the wave's MAXT tap slots (a slot beyond the wave's taps re-reads tap offset 0 and is
+      // never flushed): all 2*MAXT transposed reads issue back to back ahead of the MFMAs instead of one
+      // read->wait->MFMA chain per tap (SQ_WAIT_INST_ANY was 36-58 % of the wave cycles with the guarded loop)
+      f16x8 xa[MAXT];
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
-        if (i < ntw) {
-          const i16x4 x0 = lds_read_tr16(box + bbase + tap_off[i]);
-          const i16x4 x1 = lds_read_tr16(box + bbase + tap_off[i] + 4 * IS * 64);
-          union { i16x4 v[2]; f16x8 h; } u;
-          u.v[0] = x0;
-          u.v[1] = x1;
-          acc[i] = mfma32(u.h, bq, acc[i]);
-        }
+        union { i16x4 v[2]; f16x8 h; } u;
+        u.v[0] = lds_read_tr16(box + bbase + tap_off[i]);
+        u.v[1] = lds_read_tr16(box + bbase + tap_off[i] + 4 * IS * 64);
+        xa[i] = u.h;
       }
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) acc[i] = mfma32(xa[i], bq, acc[i]);
     }
   }
 
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   }
 }
 
-template <int TD, int TH, int TW, int IS, int EXT>
-static int launch_wg(const WgradDev& base, hipStream_t stream, bool pre_zeroed) {
+template <int TD, int TH, int TW, int IS, int EXT, int MAXT>
+static int launch_wg_t(const WgradDev& base, hipStream_t stream, bool pre_zeroed) {
   using C = WgCfg<TD, TH, TW, IS, EXT>;
   WgradDev p = base;
   p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
@@ -224,7 +225,7 @@ static int launch_wg(const WgradDev& base, hipStream_t stream, bool pre_zeroed) 
   if (splits < 1) splits = 1;
   if (splits > p.ntiles) splits = p.ntiles;
   p.splits = splits;
-  auto kern = conv_wgrad_kernel<TD, TH, TW, IS, EXT>;
+  auto kern = conv_wgrad_kernel<TD, TH, TW, IS, EXT, MAXT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -239,6 +240,13 @@ static int launch_wg(const WgradDev& base, hipStream_t stream, bool pre_zeroed) 
   hipLaunchKernelGGL(kern, dim3(pairs * splits), dim3(256), C::LDS_BYTES, stream, p);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+
+template <int TD, int TH, int TW, int IS, int EXT>
+static int launch_wg(const WgradDev& p, hipStream_t stream, bool pre_zeroed) {
+  const int per_wave = (p.d.ntaps_total + 3) / 4;
+  if (per_wave <= 2) return launch_wg_t<TD, TH, TW, IS, EXT, 2>(p, stream, pre_zeroed);
+  return launch_wg_t<TD, TH, TW, IS, EXT, 7>(p, stream, pre_zeroed);
 }
 
 }  // namespace nnz
