@@ -81,8 +81,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} "
                          f"(WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_ddp = os.environ.get("NNZ_BENCH_FORCE_DDP") == "1"  # exercise the RCCL reducer path even at world size 1
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from nnuzoo_amd import hip_ops
@@ -101,7 +105,7 @@ def main():
     batch = {"data": batch["data"].to(dev), "target": [t.to(dev) for t in batch["target"]], "keys": batch["keys"]}
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -117,7 +121,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     hip_ops.TIMER.enabled = False
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -162,7 +166,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

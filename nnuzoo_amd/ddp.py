@@ -6,6 +6,9 @@ node with an explicit reverse schedule, so the overlap is explicit too: after ev
 schedule hands the finished parameter gradients to `BucketedAllReduce.stage_done`, which launches an asynchronous
 all-reduce (backend "nccl" == RCCL on ROCm; its own stream) as soon as a bucket is full, while the next stage's
 kernels keep the compute stream busy.  `finish` waits (stream-ordered, no host sync on RCCL) and averages.
+The PlainConvUNet schedule writes every parameter gradient into ONE flat arena in completion order, so a bucket is
+a slice of that arena reduced IN PLACE (`stage_done_arena` / `finish_arena`): no flatten / unflatten copies (the
+dict form below costs two extra passes over the 125 MB of gradients and is kept for generic callers).
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of S bytes costs ~2*(7/8)*S/153 GB/s,
 i.e. ~1.4 ms for the 124.8 MB of fp32 gradients of the 3d_fullres PlainConvUNet - buckets of >= 16 MB keep the
@@ -47,6 +50,27 @@ class BucketedAllReduce:
             self._pending_bytes += g.numel() * g.element_size()
         if self._pending_bytes >= self.bucket_bytes:
             self._launch()
+
+    # ---- arena form: gradients live in one flat buffer in completion order; buckets are slices of it --------------
+    def stage_done_arena(self, arena: torch.Tensor, filled: int):
+        """Everything in arena[:filled] is final.  Launch an in-place all-reduce for the not-yet-reduced part once it
+        is at least one bucket long."""
+        lo = getattr(self, "_arena_lo", 0)
+        if (filled - lo) * arena.element_size() >= self.bucket_bytes:
+            h = dist.all_reduce(arena[lo:filled], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._inflight.append((h, None, None))
+            self._arena_lo = filled
+
+    def finish_arena(self, arena: torch.Tensor, filled: int):
+        lo = getattr(self, "_arena_lo", 0)
+        if filled > lo:
+            h = dist.all_reduce(arena[lo:filled], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._inflight.append((h, None, None))
+        for h, _, _ in self._inflight:
+            h.wait()
+        arena[:filled].mul_(1.0 / self.world)
+        self._inflight = []
+        self._arena_lo = 0
 
     def finish(self, all_grads: List[torch.Tensor]):
         """Flush, wait for every collective and write the averaged gradients back in place."""

@@ -441,11 +441,13 @@ class PlainConvUNet(nn.Module):
         ops.instnorm_lrelu_bwd(raw, g_act, stats, h.norm.weight, h.norm.bias, red, draw, b.N, b.V, b.cout, b.cout, g_ld,
                                b.cout, b.eps, b.slope, pre_zeroed=True)
         rs = red.sum(0)
-        grads[h.norm.weight] = rs[:, 1].contiguous()
-        grads[h.norm.bias] = rs[:, 0].contiguous()
+        gnw, gnb = self._galloc(h.norm.weight), self._galloc(h.norm.bias)
+        gnw.copy_(rs[:, 1])
+        gnb.copy_(rs[:, 0])
+        grads[h.norm.weight], grads[h.norm.bias] = gnw, gnb
         # the bias of a conv followed by InstanceNorm has an identically zero gradient (mean removal)
-        grads[h.conv.bias] = torch.zeros_like(h.conv.bias)
-        gw = torch.empty_like(h.conv.weight)
+        grads[h.conv.bias] = self._galloc(h.conv.bias)  # arena is zero-initialised
+        gw = self._galloc(h.conv.weight)
         if b.stem:
             ops.stem_wgrad(x_in, draw, gw, (b.N, *b.in_dims), b.cout)
         else:
@@ -455,6 +457,14 @@ class PlainConvUNet(nn.Module):
             ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
         grads[h.conv.weight] = gw
 
+    def _galloc(self, like: torch.Tensor) -> torch.Tensor:
+        """Gradient storage comes from ONE flat fp32 arena, filled in backward-completion order: the data-parallel
+        reducer all-reduces contiguous slices of it in place (no flatten / unflatten copies)."""
+        n = like.numel()
+        off = self._arena_off
+        self._arena_off = off + n
+        return self._arena[off:off + n].view(like.shape)
+
     def _run_backward(self, rec, gouts):
         plan: _Plan = rec["plan"]
         N, S = plan.N, plan.S
@@ -463,6 +473,8 @@ class PlainConvUNet(nn.Module):
         dev = rec["x"].device
         f16 = torch.float16
         grads = {}
+        self._arena = torch.zeros(sum(p.numel() for p in self._params()), dtype=torch.float32, device=dev)
+        self._arena_off = 0
         plan.pack_bwd.run()
         self._red_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
         self._dw_all = torch.zeros(plan.dw_floats, dtype=torch.float32, device=dev)
@@ -486,8 +498,8 @@ class PlainConvUNet(nn.Module):
                 g = g.contiguous()
                 if g.dtype != f16:
                     g = g.to(f16)
-                gw = torch.empty_like(seg.weight)
-                gb = torch.empty_like(seg.bias)
+                gw = self._galloc(seg.weight)
+                gb = self._galloc(seg.bias)
                 ops.head_wgrad(out_act, g, gw, gb, N, V, C_, K, C_)
                 ops.head_dgrad(g, seg.weight, g_cur, N, V, C_, K, C_, accumulate=have)
                 grads[seg.weight], grads[seg.bias] = gw, gb
@@ -495,8 +507,8 @@ class PlainConvUNet(nn.Module):
                 if not have:
                     g_cur.zero_()
                 if self.decoder.deep_supervision or j == S - 2:
-                    grads[seg.weight] = torch.zeros_like(seg.weight)
-                    grads[seg.bias] = torch.zeros_like(seg.bias)
+                    grads[seg.weight] = self._galloc(seg.weight)
+                    grads[seg.bias] = self._galloc(seg.bias)
             # conv blocks of the stage, last to first
             blocks = plan.dec_blocks[j]
             g_act, g_ld = g_cur, C_
@@ -512,18 +524,20 @@ class PlainConvUNet(nn.Module):
             Vb = int(np.prod(up.in_dims))
             dwt = self._dw_all[up.dw_off:up.dw_off + 8 * up.cout * up.cin].view(8, up.cout, up.cin)
             ops.conv_tap_wgrad(up.wgrad, g_up, lres, dwt, pre_zeroed=True)
-            gw = torch.empty_like(up.m.weight)
+            gw = self._galloc(up.m.weight)
             ops.unpack_wgrad(dwt, gw, up.cout, up.cin, 8, 8, up.cout * 8, 1, up.wgrad)
             grads[up.m.weight] = gw
             if up.m.bias is not None:
                 st = torch.empty((N, up.cout, 2), dtype=torch.float32, device=dev)
                 ops.instnorm_stats(g_up, st, N, V, up.cout, 2 * up.cout)
-                grads[up.m.bias] = st[:, :, 0].sum(0).contiguous()
+                gub = self._galloc(up.m.bias)
+                gub.copy_(st[:, :, 0].sum(0))
+                grads[up.m.bias] = gub
             g_below = torch.empty((N, Vb, up.cin), dtype=f16, device=dev)
             ops.conv_tap_forward(up.dgrad, g_up, up.wp_dgrad, None, g_below)
             g_cur = g_below
             if self.grad_reducer is not None:
-                self.grad_reducer.stage_done(grads)
+                self.grad_reducer.stage_done_arena(self._arena, self._arena_off)
         # encoder, deepest first.  g_cur = gradient wrt the bottleneck activation.
         g_act, g_ld = g_cur, feats[S - 1]
         for s in range(S - 1, -1, -1):
@@ -546,14 +560,14 @@ class PlainConvUNet(nn.Module):
                     self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, False, dev)
                     g_act, g_ld = dx, b.cin
             if self.grad_reducer is not None:
-                self.grad_reducer.stage_done(grads)
+                self.grad_reducer.stage_done_arena(self._arena, self._arena_off)
         out = []
         for p in self._params():
             gp = grads.get(p)
-            out.append(gp if gp is not None else torch.zeros_like(p))
+            out.append(gp if gp is not None else self._galloc(p))
         if self.grad_reducer is not None:
-            self.grad_reducer.finish(out)
-        self._red_all = self._dw_all = None
+            self.grad_reducer.finish_arena(self._arena, self._arena_off)
+        self._red_all = self._dw_all = self._arena = None
         return out
 
     # reference API (dynamic_network_architectures): used by the planner's VRAM estimate only

@@ -52,6 +52,13 @@ def _worker(rank, world, port, q):
         for i, g in enumerate(out):
             expect = (1 + 2) / 2.0 * (i + 1)
             assert torch.allclose(g, torch.full_like(g, expect)), (i, g.flatten()[:3], expect)
+        # arena form: slices of one flat buffer reduced in place as they fill up
+        arena = torch.arange(40, dtype=torch.float32) * (rank + 1)
+        red.stage_done_arena(arena, 10)   # below one bucket (64 B): nothing launched yet
+        red.stage_done_arena(arena, 24)   # 96 B pending -> launches [0, 24)
+        red.stage_done_arena(arena, 30)
+        red.finish_arena(arena, 40)
+        assert torch.allclose(arena, torch.arange(40, dtype=torch.float32) * 1.5), arena[:6]
         # batch dice across ranks == dice over the concatenated batch
         g = torch.Generator().manual_seed(5)
         inter_all = torch.rand(4, 3, generator=g)
