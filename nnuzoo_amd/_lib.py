@@ -33,9 +33,9 @@ class ConvDesc(C.Structure):
         ("Cout", C.c_int32),
         ("ldi", C.c_int32),
         ("ldo", C.c_int32),
-        ("in_stride", C.c_int32),
-        ("out_stride", C.c_int32),
-        ("ext", C.c_int32),
+        ("in_stride", C.c_int32 * 3),
+        ("out_stride", C.c_int32 * 3),
+        ("ext", C.c_int32 * 3),
         ("lo", C.c_int32 * 3),
         ("ntaps_total", C.c_int32),
         ("ngroups", C.c_int32),

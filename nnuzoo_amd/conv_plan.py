@@ -28,8 +28,8 @@ class TapTable:
     Cout: int
     ldi: int
     ldo: int
-    in_stride: int
-    out_stride: int
+    in_stride: Tuple[int, int, int]
+    out_stride: Tuple[int, int, int]
     groups: List[Tuple[Tuple[int, int, int], List[Tuple[Tuple[int, int, int], int]]]]  # (ooff, [(off, widx)])
     accumulate: bool = False
 
@@ -49,14 +49,15 @@ class TapTable:
             d.in_dims[i] = self.in_dims[i]
             d.out_dims[i] = self.out_dims[i]
             d.m_dims[i] = self.m_dims[i]
+            d.in_stride[i] = self.in_stride[i]
+            d.out_stride[i] = self.out_stride[i]
         d.Cin, d.Cout, d.ldi, d.ldo = self.Cin, self.Cout, self.ldi, self.ldo
-        d.in_stride, d.out_stride = self.in_stride, self.out_stride
         offs = [t[0] for g in self.groups for t in g[1]]
         lo = [min(o[a] for o in offs) for a in range(3)]
         hi = [max(o[a] for o in offs) for a in range(3)]
-        d.ext = max(hi[a] - lo[a] for a in range(3))
         for a in range(3):
             d.lo[a] = lo[a]
+            d.ext[a] = hi[a] - lo[a]
         assert len(self.groups) <= NNZ_MAX_GROUPS and self.ntaps <= NNZ_MAX_TAPS
         d.ntaps_total = self.ntaps
         d.ngroups = len(self.groups)
@@ -79,62 +80,76 @@ def _flat(k: Sequence[int], ks: Sequence[int]) -> int:
     return (k[0] * ks[1] + k[1]) * ks[2] + k[2]
 
 
+def _triple(v) -> Tuple[int, int, int]:
+    """int -> (v, v, v); a 2-sequence (2-D layer) -> (1-ish leading axis handled by the caller); 3-sequence as is"""
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(i) for i in v)
+    assert len(v) == 3, v
+    return v
+
+
 def conv_out_dims(in_dims, ks, stride):
-    return tuple((in_dims[a] + 2 * (ks[a] // 2) - ks[a]) // stride + 1 for a in range(3))
+    ks, stride = _triple(ks), _triple(stride)
+    return tuple((in_dims[a] + 2 * (ks[a] // 2) - ks[a]) // stride[a] + 1 for a in range(3))
 
 
 def conv_forward(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldi=None, ldo=None) -> TapTable:
-    """Y[o] = sum_k X[s*o + k - pad] W[k]; packed slice widx == flat kernel index."""
+    """Y[o] = sum_k X[s*o + k - pad] W[k]; packed slice widx == flat kernel index.  ks in {1,3}, stride in {1,2},
+    both per axis (a 2-D layer is the D = 1 case with ks[0] = stride[0] = 1)."""
+    ks, stride = _triple(ks), _triple(stride)
     out_dims = conv_out_dims(in_dims, ks, stride)
     taps = []
     for k in itertools.product(range(ks[0]), range(ks[1]), range(ks[2])):
         off = tuple(k[a] - ks[a] // 2 for a in range(3))
         taps.append((off, _flat(k, ks)))
-    nk = ks[0] * ks[1] * ks[2]
-    return TapTable(N, tuple(in_dims), out_dims, out_dims, Cin, Cout, ldi or Cin, ldo or Cout, stride, 1,
+    return TapTable(N, tuple(in_dims), out_dims, out_dims, Cin, Cout, ldi or Cin, ldo or Cout, stride, (1, 1, 1),
                     [((0, 0, 0), taps)])
 
 
 def conv_dgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldi=None, ldo=None, accumulate=False) -> TapTable:
     """dX of the convolution above.  `in` of the table is dY (Cout channels), `out` is dX (Cin channels).
 
-    stride 1: dX[i] = sum_k dY[i - k + pad] W[k]
-    stride 2: i = 2m + p;  per axis p=0 -> {(k=1, o=m)},  p=1 -> {(k=0, o=m+1), (k=2, o=m)}   (k3, pad 1)
+    per axis, stride 1: dX[i] = sum_k dY[i - k + pad] W[k]
+    per axis, stride 2: i = 2m + p;  p=0 -> {(k=1, o=m)},  p=1 -> {(k=0, o=m+1), (k=2, o=m)}   (k3, pad 1)
+                                       k1: p=0 -> {(k=0, o=m)}, p=1 -> {} (those inputs were never read)
+    Output-parity groups are the product over the stride-2 axes (1, 2, 4 or 8 groups).
     ldi / ldo here are the channel strides of dY / dX.
     """
+    ks, stride = _triple(ks), _triple(stride)
     y_dims = conv_out_dims(in_dims, ks, stride)
-    nk = ks[0] * ks[1] * ks[2]
-    if stride == 1:
-        taps = []
-        for k in itertools.product(range(ks[0]), range(ks[1]), range(ks[2])):
-            off = tuple(ks[a] // 2 - k[a] for a in range(3))
-            taps.append((off, _flat(k, ks)))
-        groups = [((0, 0, 0), taps)]
-        m_dims = tuple(in_dims)
-        os_ = 1
-    else:
-        assert stride == 2
-        per_axis = []
-        for a in range(3):
+    per_axis = []  # parity -> [(off, k)]
+    for a in range(3):
+        if stride[a] == 1:
+            per_axis.append({0: [(ks[a] // 2 - k, k) for k in range(ks[a])]})
+        elif stride[a] == 2:
             if ks[a] == 3:
-                per_axis.append({0: [(0, 1)], 1: [(1, 0), (0, 2)]})  # parity -> [(off, k)]
+                per_axis.append({0: [(0, 1)], 1: [(1, 0), (0, 2)]})
             elif ks[a] == 1:
                 per_axis.append({0: [(0, 0)], 1: []})
             else:
                 raise ValueError("kernel size must be 1 or 3")
-        groups = []
-        for p in itertools.product((0, 1), (0, 1), (0, 1)):
-            taps = []
-            for c in itertools.product(per_axis[0][p[0]], per_axis[1][p[1]], per_axis[2][p[2]]):
-                off = tuple(c[a][0] for a in range(3))
-                k = tuple(c[a][1] for a in range(3))
-                taps.append((off, _flat(k, ks)))
-            if taps:
-                groups.append((p, taps))
-        m_dims = tuple((in_dims[a] + 1) // 2 for a in range(3))
-        os_ = 2
-    return TapTable(N, y_dims, tuple(in_dims), m_dims, Cout, Cin, ldi or Cout, ldo or Cin, 1, os_, groups,
+        else:
+            raise ValueError("stride must be 1 or 2")
+    groups = []
+    for p in itertools.product(*[sorted(pa) for pa in per_axis]):
+        taps = []
+        for c in itertools.product(per_axis[0][p[0]], per_axis[1][p[1]], per_axis[2][p[2]]):
+            off = tuple(c[a][0] for a in range(3))
+            k = tuple(c[a][1] for a in range(3))
+            taps.append((off, _flat(k, ks)))
+        if taps:
+            groups.append((p, taps))
+    m_dims = tuple((in_dims[a] + stride[a] - 1) // stride[a] for a in range(3))
+    return TapTable(N, y_dims, tuple(in_dims), m_dims, Cout, Cin, ldi or Cout, ldo or Cin, (1, 1, 1), stride, groups,
                     accumulate=accumulate)
+
+
+def dgrad_uncovered(ks, stride) -> bool:
+    """True if the data gradient of conv(ks, stride) leaves input positions unwritten (k1 s2 axes: odd positions get
+    no contribution) - the caller must zero the destination first."""
+    ks, stride = _triple(ks), _triple(stride)
+    return any(stride[a] == 2 and ks[a] == 1 for a in range(3))
 
 
 def conv_wgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldx=None, lddy=None) -> TapTable:
@@ -143,26 +158,30 @@ def conv_wgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldx=None, lddy=Non
     return t
 
 
-def convT_forward(N, in_dims, Cin, Cout, ldi=None, ldo=None) -> TapTable:
-    """ConvTranspose3d(k=2, s=2): out[2m + p] = bias + sum_ci in[m] W[ci][co][p]; 8 one-tap groups."""
-    out_dims = tuple(2 * d for d in in_dims)
+def convT_forward(N, in_dims, Cin, Cout, ldi=None, ldo=None, stride=2) -> TapTable:
+    """ConvTranspose(kernel = stride, per axis 1 or 2): out[s*m + p] = bias + sum_ci in[m] W[ci][co][p];
+    prod(stride) one-tap groups."""
+    st = _triple(stride)
+    out_dims = tuple(st[a] * in_dims[a] for a in range(3))
     groups = []
-    for p in itertools.product((0, 1), (0, 1), (0, 1)):
-        groups.append((p, [((0, 0, 0), _flat(p, (2, 2, 2)))]))
-    return TapTable(N, tuple(in_dims), out_dims, tuple(in_dims), Cin, Cout, ldi or Cin, ldo or Cout, 1, 2, groups)
+    for p in itertools.product(range(st[0]), range(st[1]), range(st[2])):
+        groups.append((p, [((0, 0, 0), _flat(p, st))]))
+    return TapTable(N, tuple(in_dims), out_dims, tuple(in_dims), Cin, Cout, ldi or Cin, ldo or Cout, (1, 1, 1), st,
+                    groups)
 
 
-def convT_dgrad(N, in_dims, Cin, Cout, ldi=None, ldo=None, accumulate=False) -> TapTable:
-    """dIn[m][ci] = sum_p sum_co dOut[2m + p][co] W[ci][co][p]; `in` = dOut (Cout ch), `out` = dIn (Cin ch)."""
-    out_dims = tuple(2 * d for d in in_dims)
-    taps = [(p, _flat(p, (2, 2, 2))) for p in itertools.product((0, 1), (0, 1), (0, 1))]
-    return TapTable(N, out_dims, tuple(in_dims), tuple(in_dims), Cout, Cin, ldi or Cout, ldo or Cin, 2, 1,
+def convT_dgrad(N, in_dims, Cin, Cout, ldi=None, ldo=None, accumulate=False, stride=2) -> TapTable:
+    """dIn[m][ci] = sum_p sum_co dOut[s*m + p][co] W[ci][co][p]; `in` = dOut (Cout ch), `out` = dIn (Cin ch)."""
+    st = _triple(stride)
+    out_dims = tuple(st[a] * in_dims[a] for a in range(3))
+    taps = [(p, _flat(p, st)) for p in itertools.product(range(st[0]), range(st[1]), range(st[2]))]
+    return TapTable(N, out_dims, tuple(in_dims), tuple(in_dims), Cout, Cin, ldi or Cout, ldo or Cin, st, (1, 1, 1),
                     [((0, 0, 0), taps)], accumulate=accumulate)
 
 
-def convT_wgrad(N, in_dims, Cin, Cout, lddout=None, ldin=None) -> TapTable:
-    """dW[ci][co][p] = sum_m in[m][ci] dOut[2m + p][co]: boxed = dOut (A = Cout), plain = in (B = Cin)."""
-    return convT_dgrad(N, in_dims, Cin, Cout, ldi=lddout or Cout, ldo=ldin or Cin)
+def convT_wgrad(N, in_dims, Cin, Cout, lddout=None, ldin=None, stride=2) -> TapTable:
+    """dW[ci][co][p] = sum_m in[m][ci] dOut[s*m + p][co]: boxed = dOut (A = Cout), plain = in (B = Cin)."""
+    return convT_dgrad(N, in_dims, Cin, Cout, ldi=lddout or Cout, ldo=ldin or Cin, stride=stride)
 
 
 def ksel_array(ksel: Sequence[int]):

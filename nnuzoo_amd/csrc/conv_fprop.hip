@@ -46,16 +46,39 @@ struct ConvDev {
   int gx, gy, gz;
 };
 
-template <int TD, int TH, int TW, int NB, int IS, int EXT>
+// Box geometry policies.  GeoIso: input stride and tap extent are compile-time and equal on the three axes (the
+// isotropic 3-D plans: every box dimension folds to a constant).  GeoDyn: per-axis values from the descriptor
+// (2-D plans = depth-1 volumes, anisotropic 3-D plans such as k(1,3,3) s(1,2,2)); the geometry only enters the
+// set-up code, the per-tap loop sees two extra scalar multiplies.
+template <int IS, int EXT>
+struct GeoIso {
+  __host__ __device__ explicit GeoIso(const nnz_conv_desc&) {}
+  __host__ __device__ constexpr int is(int) const { return IS; }
+  __host__ __device__ constexpr int ext(int) const { return EXT; }
+};
+struct GeoDyn {
+  int s[3], e[3];
+  __host__ __device__ explicit GeoDyn(const nnz_conv_desc& d)
+      : s{d.in_stride[0], d.in_stride[1], d.in_stride[2]}, e{d.ext[0], d.ext[1], d.ext[2]} {}
+  __host__ __device__ int is(int a) const { return s[a]; }
+  __host__ __device__ int ext(int a) const { return e[a]; }
+};
+
+template <int TD, int TH, int TW, class G>
+struct BoxGeom {
+  int BD, BH, BW, PW, BOX_BYTES, NBOXLOAD;
+  __host__ __device__ explicit BoxGeom(const G& g) {
+    BD = (TD - 1) * g.is(0) + g.ext(0) + 1;
+    BH = (TH - 1) * g.is(1) + g.ext(1) + 1;
+    BW = (TW - 1) * g.is(2) + g.ext(2) + 1;
+    PW = (BW + 3) & ~3;  // row pitch in voxels (multiple of 4: see swizzle note)
+    BOX_BYTES = BD * BH * PW * 32;
+    NBOXLOAD = BD * BH * BW * 2;  // 16-byte pieces
+  }
+};
+
+template <int TD, int TH, int TW, int NB>
 struct ConvCfg {
-  static constexpr int BD = (TD - 1) * IS + EXT + 1;
-  static constexpr int BH = (TH - 1) * IS + EXT + 1;
-  static constexpr int BW = (TW - 1) * IS + EXT + 1;
-  static constexpr int PW = (BW + 3) & ~3;  // row pitch in voxels (multiple of 4: see swizzle note)
-  static constexpr int BOX_BYTES = BD * BH * PW * 32;
-  static constexpr int NBOXLOAD = BD * BH * BW * 2;  // 16-byte pieces
-  static constexpr int LPT_BOX = (NBOXLOAD + 255) / 256;
-  static constexpr int W_BYTES_MAX = NB * 27 * 32 * 32;
   static constexpr int LPT_W = (NB * 27 * 64 + 255) / 256;
   static constexpr int MB = TD * TH * TW / 32;
   static constexpr int WAVES_M = MB >= 4 ? 4 : MB;
@@ -65,15 +88,18 @@ struct ConvCfg {
   static_assert(TW == 8, "lane->voxel map assumes TW == 8");
   static_assert(NB % WAVES_N == 0 && WN >= 1, "NB must cover the N-split of the waves");
   static constexpr int OUT_BYTES = TD * TH * TW * (NB * 64 + 16);  // epilogue staging image
-  static constexpr int LDS_BYTES = BOX_BYTES + W_BYTES_MAX > OUT_BYTES ? BOX_BYTES + W_BYTES_MAX : OUT_BYTES;
 };
 
-template <int TD, int TH, int TW, int NB, int IS, int EXT>
+// LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G>
 __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
-  using C = ConvCfg<TD, TH, TW, NB, IS, EXT>;
+  using C = ConvCfg<TD, TH, TW, NB>;
+  const G geo(p.d);
+  const BoxGeom<TD, TH, TW, G> bg(geo);
+  const int ISD = geo.is(0), ISH = geo.is(1), ISW = geo.is(2);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* box = smem;
-  char* wl = smem + C::BOX_BYTES;
+  char* wl = smem + bg.BOX_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -104,23 +130,23 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   const int Di = p.d.in_dims[0], Hi = p.d.in_dims[1], Wi = p.d.in_dims[2];
 
   // ---- per-thread staging addresses (independent of the channel slice) ----------------------------
-  int box_goff[C::LPT_BOX];  // element offset into `in` (without channel slice), -1 = zero fill
-  int box_loff[C::LPT_BOX];  // LDS byte offset, -1 = nothing to do
+  int box_goff[LPT_BOX];  // element offset into `in` (without channel slice), -1 = zero fill
+  int box_loff[LPT_BOX];  // LDS byte offset, -1 = nothing to do
   {
-    const int lod = m0d * IS + p.d.lo[0], loh = m0h * IS + p.d.lo[1], low = m0w * IS + p.d.lo[2];
+    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = m0w * ISW + p.d.lo[2];
 #pragma unroll
-    for (int i = 0; i < C::LPT_BOX; ++i) {
+    for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
       box_goff[i] = -1;
       box_loff[i] = -1;
-      if (c < C::NBOXLOAD) {
+      if (c < bg.NBOXLOAD) {
         const int half = c & 1;
         const int s = c >> 1;
-        const int bw = s % C::BW;
-        const int bh = (s / C::BW) % C::BH;
-        const int bd = s / (C::BW * C::BH);
+        const int bw = s % bg.BW;
+        const int bh = (s / bg.BW) % bg.BH;
+        const int bd = s / (bg.BW * bg.BH);
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
-        box_loff[i] = ((bd * C::BH + bh) * C::PW + bw) * 32 + ((half ^ (bh & 1)) << 4);
+        box_loff[i] = ((bd * bg.BH + bh) * bg.PW + bw) * 32 + ((half ^ (bh & 1)) << 4);
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
           box_goff[i] = (((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + half * 8;
       }
@@ -137,14 +163,14 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   for (int i = 0; i < C::WM; ++i) {
     const int v = (wm * C::WM + i) * 32 + l31;
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
-    const int base = (((td * IS) * C::BH + th * IS) * C::PW + tw * IS) * 32;
-    const int f = (th * IS) & 1;
+    const int base = (((td * ISD) * bg.BH + th * ISH) * bg.PW + tw * ISW) * 32;
+    const int f = (th * ISH) & 1;
     vox_off[0][i] = base + ((hh ^ f) << 4);
     vox_off[1][i] = base + ((hh ^ f ^ 1) << 4);
     const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-    const int od = md * p.d.out_stride + grp.ooff[0];
-    const int oh = mh * p.d.out_stride + grp.ooff[1];
-    const int ow = mw * p.d.out_stride + grp.ooff[2];
+    const int od = md * p.d.out_stride[0] + grp.ooff[0];
+    const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
+    const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
     const bool ok = md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] &&
                     od < p.d.out_dims[0] && oh < p.d.out_dims[1] && ow < p.d.out_dims[2];
     out_vox[i] = ok ? (((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) * p.d.ldo
@@ -164,13 +190,13 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   // per-tap LDS offsets (uniform)
   const int lo0 = p.d.lo[0], lo1 = p.d.lo[1], lo2 = p.d.lo[2];
 
-  u32x4 breg[C::LPT_BOX];
+  u32x4 breg[LPT_BOX];
   u32x4 wreg[C::LPT_W];
   const int nkc = Cin >> 4;
 
   auto issue_loads = [&](int kc) {
 #pragma unroll
-    for (int i = 0; i < C::LPT_BOX; ++i) {
+    for (int i = 0; i < LPT_BOX; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (box_goff[i] >= 0) v = *reinterpret_cast<const u32x4*>(p.in + (size_t)box_goff[i] + kc * 16);
       breg[i] = v;
@@ -190,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   };
   auto write_lds = [&]() {
 #pragma unroll
-    for (int i = 0; i < C::LPT_BOX; ++i)
+    for (int i = 0; i < LPT_BOX; ++i)
       if (box_loff[i] >= 0) *reinterpret_cast<u32x4*>(box + box_loff[i]) = breg[i];
 #pragma unroll
     for (int i = 0; i < C::LPT_W; ++i) {
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
     for (int t = 0; t < nt; ++t) {
       const nnz_conv_tap tp = p.d.taps[tb + t];
       const int o0 = tp.off[0] - lo0, o1 = tp.off[1] - lo1, o2 = tp.off[2] - lo2;
-      const int toff = ((o0 * C::BH + o1) * C::PW + o2) * 32;
+      const int toff = ((o0 * bg.BH + o1) * bg.PW + o2) * 32;
       const int par = o1 & 1;
       f16x8 a[C::WN], b[C::WM];
 #pragma unroll
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   // 16-byte pieces in voxel-major order: a wave writes full 128-byte lines.  (Direct 8-byte stores from the
   // accumulator layout measured WRITE_SIZE = 1.5x the output bytes: partial-line writes.)
   constexpr int ROWB = NB * 64 + 16;  // LDS bytes per voxel row (+16: spreads the b64 writes over the banks)
-  static_assert(TD * TH * TW * ROWB <= C::LDS_BYTES, "output image must fit the staging LDS");
+  static_assert(TD * TH * TW * ROWB <= C::OUT_BYTES, "output image must fit the staging LDS");
   __syncthreads();  // every wave is done reading box / weights
 #pragma unroll
   for (int i = 0; i < C::WN; ++i) {
@@ -262,9 +288,9 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
     const int v = c / PPV, part = c % PPV;
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
     const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-    const int od = md * p.d.out_stride + grp.ooff[0];
-    const int oh = mh * p.d.out_stride + grp.ooff[1];
-    const int ow = mw * p.d.out_stride + grp.ooff[2];
+    const int od = md * p.d.out_stride[0] + grp.ooff[0];
+    const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
+    const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
     if (!(md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] && od < p.d.out_dims[0] &&
           oh < p.d.out_dims[1] && ow < p.d.out_dims[2]))
       continue;
@@ -280,30 +306,48 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   }
 }
 
-template <int TD, int TH, int TW, int NB, int IS, int EXT>
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G>
 static int launch_cfg(const ConvDev& base, hipStream_t stream) {
-  using C = ConvCfg<TD, TH, TW, NB, IS, EXT>;
+  using C = ConvCfg<TD, TH, TW, NB>;
   ConvDev p = base;
+  const G geo(p.d);
+  const BoxGeom<TD, TH, TW, G> bg(geo);
+  if (bg.NBOXLOAD > LPT_BOX * 256) return NNZ_EINVAL;  // register staging cannot hold this box
+  int maxnt = 1;  // weights region: all taps of the largest group, one 16-channel slice
+  for (int g = 0; g < p.d.ngroups; ++g) maxnt = p.d.groups[g].ntaps > maxnt ? p.d.groups[g].ntaps : maxnt;
+  const int wbytes = NB * maxnt * 1024;
+  const int lds = bg.BOX_BYTES + wbytes > C::OUT_BYTES ? bg.BOX_BYTES + wbytes : C::OUT_BYTES;
+  if (lds > 160 * 1024) return NNZ_EINVAL;
   p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
   p.tiles[1] = (p.d.m_dims[1] + TH - 1) / TH;
   p.tiles[2] = (p.d.m_dims[2] + TW - 1) / TW;
   p.gx = p.tiles[0] * p.tiles[1] * p.tiles[2];
   p.gy = p.d.Cout / (32 * NB);
   p.gz = p.d.N * p.d.ngroups;
-  auto kern = conv_box_kernel<TD, TH, TW, NB, IS, EXT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G>;
+  static int attr_lds = 0;  // per instantiation: largest dynamic LDS size registered so far
+  if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_lds = lds;
   }
   const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, p);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
 
+template <int TD, int TH, int TW, int IS, int EXT>
+constexpr int iso_lpt() {
+  return (((TD - 1) * IS + EXT + 1) * ((TH - 1) * IS + EXT + 1) * ((TW - 1) * IS + EXT + 1) * 2 + 255) / 256;
+}
+template <int TD, int TH, int TW, int NB, int IS, int EXT>
+static int launch_iso(const ConvDev& p, hipStream_t stream) {
+  return launch_cfg<TD, TH, TW, NB, iso_lpt<TD, TH, TW, IS, EXT>(), GeoIso<IS, EXT>>(p, stream);
+}
+
+// isotropic 3-D plans (the tuned path: every box dimension is a compile-time constant)
 template <int IS, int EXT>
 static int launch_tile(const ConvDev& p, hipStream_t stream) {
   const long mvox = (long)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
@@ -311,21 +355,48 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
   if constexpr (IS == 1) {
     // big tile for the 32-channel full-resolution layers (more weight reuse per wave), otherwise 4x8x8
     if (!nb2) {
-      if (mvox >= 64 * 64 * 64) return launch_cfg<8, 8, 8, 1, IS, EXT>(p, stream);
-      return launch_cfg<4, 8, 8, 1, IS, EXT>(p, stream);
+      if (mvox >= 64 * 64 * 64) return launch_iso<8, 8, 8, 1, IS, EXT>(p, stream);
+      return launch_iso<4, 8, 8, 1, IS, EXT>(p, stream);
     }
     // deep, spatially small levels (<= 16^3): the 4x8x8 tile leaves most of the 256 CUs idle, so cut the m-tile
     // to 2x4x8 (4x the workgroups, one 32x32 MFMA tile per wave)
     const long wgs488 = (long)p.d.N * p.d.ngroups * (p.d.Cout / 64) * ((p.d.m_dims[0] + 3) / 4) *
                         ((p.d.m_dims[1] + 7) / 8) * ((p.d.m_dims[2] + 7) / 8);
-    if (wgs488 < 256) return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);
+    if (wgs488 < 256) return launch_iso<2, 4, 8, 2, IS, EXT>(p, stream);
     // (an 8x8x8 x 64-cout tile was tried for the large levels to halve the weight staging per voxel: 210 VGPRs,
     //  spills and 1 workgroup per CU made it 7-13 % slower than 4x8x8 - measured, round 1)
-    return launch_cfg<4, 8, 8, 2, IS, EXT>(p, stream);
+    return launch_iso<4, 8, 8, 2, IS, EXT>(p, stream);
   } else {
-    if (!nb2) return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);  // Cout=32 with IS=2: N-split needs NB>=2
-    return launch_cfg<2, 4, 8, 2, IS, EXT>(p, stream);
+    return launch_iso<2, 4, 8, 2, IS, EXT>(p, stream);  // N-split over waves: needs Cout % 64 == 0
   }
+}
+
+// per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) and anisotropic 3-D plans
+static int launch_dyn(const ConvDev& p, hipStream_t stream) {
+  const nnz_conv_desc& d = p.d;
+  const bool nb2 = (d.Cout % 64) == 0;
+  const bool strided = d.in_stride[0] == 2 || d.in_stride[1] == 2 || d.in_stride[2] == 2;
+  if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
+    // flat tiles: 1x32x8 voxels (stride 1), 1x16x8 (stride 2: the box is (2*TH+1) x 17), 1x8x8 for small maps
+    const long wgs = (long)d.N * d.ngroups * (d.Cout / (nb2 ? 64 : 32)) * ((d.m_dims[1] + 31) / 32) *
+                     ((d.m_dims[2] + 7) / 8);
+    if (nb2 && wgs < 256) return launch_cfg<1, 8, 8, 2, 3, GeoDyn>(p, stream);
+    if (strided) {
+      if (nb2) return launch_cfg<1, 16, 8, 2, 5, GeoDyn>(p, stream);
+      return launch_cfg<1, 16, 8, 1, 5, GeoDyn>(p, stream);
+    }
+    if (nb2) return launch_cfg<1, 32, 8, 2, 3, GeoDyn>(p, stream);
+    return launch_cfg<1, 32, 8, 1, 3, GeoDyn>(p, stream);
+  }
+  if (strided) {
+    if (!nb2) return NNZ_EINVAL;
+    return launch_cfg<2, 4, 8, 2, 6, GeoDyn>(p, stream);
+  }
+  if (!nb2) return launch_cfg<4, 8, 8, 1, 5, GeoDyn>(p, stream);
+  const long wgs488 = (long)d.N * d.ngroups * (d.Cout / 64) * ((d.m_dims[0] + 3) / 4) * ((d.m_dims[1] + 7) / 8) *
+                      ((d.m_dims[2] + 7) / 8);
+  if (wgs488 < 256) return launch_cfg<2, 4, 8, 2, 6, GeoDyn>(p, stream);
+  return launch_cfg<4, 8, 8, 2, 5, GeoDyn>(p, stream);
 }
 
 }  // namespace nnz
@@ -336,8 +407,12 @@ extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_pac
   if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
   if (d.Cin % 32 || d.Cout % 32 || d.ngroups < 1 || d.ngroups > NNZ_MAX_GROUPS || d.ntaps_total > NNZ_MAX_TAPS ||
-      d.ldi % 8 || d.ldo % 8 || (d.in_stride != 1 && d.in_stride != 2) || d.ext < 0 || d.ext > 2)
+      d.ldi % 8 || d.ldo % 8)
     return NNZ_EINVAL;
+  for (int a = 0; a < 3; ++a)
+    if ((d.in_stride[a] != 1 && d.in_stride[a] != 2) || (d.out_stride[a] != 1 && d.out_stride[a] != 2) ||
+        d.ext[a] < 0 || d.ext[a] > 2)
+      return NNZ_EINVAL;
   for (int g = 0; g < d.ngroups; ++g)
     if (d.groups[g].ntaps > 27 || d.groups[g].ntaps < 1) return NNZ_EINVAL;
   ConvDev p;
@@ -347,13 +422,17 @@ extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_pac
   p.bias = bias;
   p.d = d;
   hipStream_t s = (hipStream_t)stream;
-  if (d.in_stride == 1) {
-    if (d.ext == 0) return launch_tile<1, 0>(p, s);
-    if (d.ext == 1) return launch_tile<1, 1>(p, s);
+  const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&
+                   d.ext[1] == d.ext[2] && d.m_dims[0] > 1;
+  if (!iso) return launch_dyn(p, s);
+  const int is = d.in_stride[0], ext = d.ext[0];
+  if (is == 1) {
+    if (ext == 0) return launch_tile<1, 0>(p, s);
+    if (ext == 1) return launch_tile<1, 1>(p, s);
     return launch_tile<1, 2>(p, s);
   } else {
     if (d.Cout % 64) return NNZ_EINVAL;  // the IS=2 tiles split N over waves
-    if (d.ext <= 1) return launch_tile<2, 1>(p, s);
+    if (ext <= 1) return launch_tile<2, 1>(p, s);
     return launch_tile<2, 2>(p, s);
   }
 }

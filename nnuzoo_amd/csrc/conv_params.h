@@ -11,7 +11,8 @@ extern "C" {
 #define NNZ_MAX_TAPS 32
 
 // One tap of a (possibly strided / transposed) convolution:
-//   input voxel  = m * in_stride + off      (per axis, m = position on the launch's m-grid)
+//   input voxel  = m * in_stride + off      (per axis, m = position on the launch's m-grid; strides are per axis
+//                                            so that 2-D (D = 1) and anisotropic 3-D plans use the same tables)
 //   widx         = index of the [Cin x Cout] weight slice this tap multiplies with
 typedef struct nnz_conv_tap {
   int32_t off[3];
@@ -37,9 +38,9 @@ typedef struct nnz_conv_desc {
   int32_t m_dims[3];    // Dm, Hm, Wm  (launch grid in "m" space)
   int32_t Cin, Cout;    // both multiples of 32
   int32_t ldi, ldo;     // channel strides (elements per voxel) of in / out, >= Cin / Cout
-  int32_t in_stride;    // IS: 1 or 2
-  int32_t out_stride;   // OS: 1 or 2
-  int32_t ext;          // max_t off - min_t off over all groups and axes (0, 1 or 2)
+  int32_t in_stride[3];   // IS per axis: 1 or 2
+  int32_t out_stride[3];  // OS per axis: 1 or 2
+  int32_t ext[3];         // max_t off - min_t off over all groups, per axis (0, 1 or 2)
   int32_t lo[3];        // min_t off per axis (the box origin relative to m*IS)
   int32_t ntaps_total;  // T
   int32_t ngroups;

@@ -30,29 +30,64 @@ struct WgradDev {
   int pairs_b;  // B/32
 };
 
-template <int TD, int TH, int TW, int IS, int EXT>
+// Box geometry policies (same split as conv_fprop.hip): compile-time isotropic stride/extent for the 3-D plans the
+// bench runs, per-axis run-time values for 2-D (depth-1) and anisotropic plans.
+template <int IS, int EXT>
+struct WGeoIso {
+  static constexpr bool kStatic = true;
+  static constexpr int kIS = IS, kEXT = EXT;
+  __host__ __device__ explicit WGeoIso(const nnz_conv_desc&) {}
+  __host__ __device__ constexpr int is(int) const { return IS; }
+  __host__ __device__ constexpr int ext(int) const { return EXT; }
+};
+struct WGeoDyn {
+  static constexpr bool kStatic = false;
+  static constexpr int kIS = 0, kEXT = 0;
+  int s[3], e[3];
+  __host__ __device__ explicit WGeoDyn(const nnz_conv_desc& d)
+      : s{d.in_stride[0], d.in_stride[1], d.in_stride[2]}, e{d.ext[0], d.ext[1], d.ext[2]} {}
+  __host__ __device__ int is(int a) const { return s[a]; }
+  __host__ __device__ int ext(int a) const { return e[a]; }
+};
+
+template <int TD, int TH, int TW, class G>
+struct WBoxGeom {
+  int BD, BH, BW, BOX_BYTES, NBOXLOAD;
+  __host__ __device__ explicit WBoxGeom(const G& g) {
+    BD = (TD - 1) * g.is(0) + g.ext(0) + 1;
+    BH = (TH - 1) * g.is(1) + g.ext(1) + 1;
+    BW = (TW - 1) * g.is(2) + g.ext(2) + 1;
+    BOX_BYTES = BD * BH * BW * 64;
+    NBOXLOAD = BD * BH * BW * 4;
+  }
+};
+
+template <int TD, int TH, int TW>
 struct WgCfg {
-  static constexpr int BD = (TD - 1) * IS + EXT + 1;
-  static constexpr int BH = (TH - 1) * IS + EXT + 1;
-  static constexpr int BW = (TW - 1) * IS + EXT + 1;
   static constexpr int NVOX = TD * TH * TW;
-  static constexpr int BOX_BYTES = BD * BH * BW * 64;
   static constexpr int Q_BYTES = NVOX * 64;
-  static constexpr int NBOXLOAD = BD * BH * BW * 4;
   static constexpr int NQLOAD = NVOX * 4;
-  static constexpr int LPT_BOX = (NBOXLOAD + 255) / 256;
   static constexpr int LPT_Q = (NQLOAD + 255) / 256;
   static constexpr int KB = NVOX / 16;
-  static constexpr int LDS_BYTES = BOX_BYTES + Q_BYTES;
   static_assert(TW == 8, "k-block map assumes TW == 8");
 };
 
-template <int TD, int TH, int TW, int IS, int EXT, int MAXT>
+template <int TD, int TH, int TW, int LPT_BOX, int MAXT, class G>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
-  using C = WgCfg<TD, TH, TW, IS, EXT>;
+  using C = WgCfg<TD, TH, TW>;
+  const G geo(p.d);
+  const WBoxGeom<TD, TH, TW, G> bgd(geo);
+  // compile-time constants for the isotropic policy, run-time values otherwise
+  constexpr bool ST = G::kStatic;
+  const int gBD = ST ? (TD - 1) * G::kIS + G::kEXT + 1 : bgd.BD;
+  const int gBH = ST ? (TH - 1) * G::kIS + G::kEXT + 1 : bgd.BH;
+  const int gBW = ST ? (TW - 1) * G::kIS + G::kEXT + 1 : bgd.BW;
+  const int gBOX_BYTES = gBD * gBH * gBW * 64;
+  const int gNBOXLOAD = gBD * gBH * gBW * 4;
+  const int ISD = ST ? G::kIS : geo.is(0), ISH = ST ? G::kIS : geo.is(1), ISW = ST ? G::kIS : geo.is(2);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* box = smem;
-  char* qt = smem + C::BOX_BYTES;
+  char* qt = smem + gBOX_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -78,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     tap_off[i] = 0;
     if (t < T) {
       const nnz_conv_tap tp = p.d.taps[t];
-      tap_off[i] = (((tp.off[0] - p.d.lo[0]) * C::BH + (tp.off[1] - p.d.lo[1])) * C::BW + (tp.off[2] - p.d.lo[2])) * 64;
+      tap_off[i] = (((tp.off[0] - p.d.lo[0]) * gBH + (tp.off[1] - p.d.lo[1])) * gBW + (tp.off[2] - p.d.lo[2])) * 64;
       ntw = i + 1;
     }
   }
@@ -94,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  u32x4 breg[C::LPT_BOX];
+  u32x4 breg[LPT_BOX];
   u32x4 qreg[C::LPT_Q];
 
   auto issue_loads = [&](int tile) {
@@ -105,17 +140,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     const int th_i = r % p.tiles[1];
     const int td_i = r / p.tiles[1];
     const int m0d = td_i * TD, m0h = th_i * TH, m0w = tw_i * TW;
-    const int lod = m0d * IS + p.d.lo[0], loh = m0h * IS + p.d.lo[1], low = m0w * IS + p.d.lo[2];
+    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = m0w * ISW + p.d.lo[2];
 #pragma unroll
-    for (int i = 0; i < C::LPT_BOX; ++i) {
+    for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (c < C::NBOXLOAD) {
+      if (c < gNBOXLOAD) {
         const int part = c & 3;
         const int s = c >> 2;
-        const int bw = s % C::BW;
-        const int bh = (s / C::BW) % C::BH;
-        const int bd = s / (C::BW * C::BH);
+        const int bw = s % gBW;
+        const int bh = (s / gBW) % gBH;
+        const int bd = s / (gBW * gBH);
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
           v = *reinterpret_cast<const u32x4*>(p.p + ((size_t)((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + a0 +
@@ -132,9 +167,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         const int s = c >> 2;
         const int tw = s % TW, th = (s / TW) % TH, td = s / (TW * TH);
         const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-        const int od = md * p.d.out_stride + p.d.groups[0].ooff[0];
-        const int oh = mh * p.d.out_stride + p.d.groups[0].ooff[1];
-        const int ow = mw * p.d.out_stride + p.d.groups[0].ooff[2];
+        const int od = md * p.d.out_stride[0] + p.d.groups[0].ooff[0];
+        const int oh = mh * p.d.out_stride[1] + p.d.groups[0].ooff[1];
+        const int ow = mw * p.d.out_stride[2] + p.d.groups[0].ooff[2];
         if (md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] && od < Do && oh < Ho && ow < Wo)
           v = *reinterpret_cast<const u32x4*>(p.q + ((size_t)((n * Do + od) * Ho + oh) * Wo + ow) * p.d.ldo + b0 +
                                               part * 8);
@@ -144,9 +179,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   };
   auto write_lds = [&]() {
 #pragma unroll
-    for (int i = 0; i < C::LPT_BOX; ++i) {
+    for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
-      if (c < C::NBOXLOAD) *reinterpret_cast<u32x4*>(box + c * 16) = breg[i];
+      if (c < gNBOXLOAD) *reinterpret_cast<u32x4*>(box + c * 16) = breg[i];
     }
 #pragma unroll
     for (int i = 0; i < C::LPT_Q; ++i) {
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         u.v[1] = q1;
         bq = u.h;
       }
-      const int bbase = ((((td * IS) * C::BH + th * IS) * C::BW) + qrow * IS) * 64 + chan_byte;
+      const int bbase = ((((td * ISD) * gBH + th * ISH) * gBW) + qrow * ISW) * 64 + chan_byte;
       // branch-free over the wave's MAXT tap slots (a slot beyond the wave's taps re-reads tap offset 0 and is
       // never flushed): all 2*MAXT transposed reads issue back to back ahead of the MFMAs instead of one
       // read->wait->MFMA chain per tap (SQ_WAIT_INST_ANY was 36-58 % of the wave cycles with the guarded loop)
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
       for (int i = 0; i < MAXT; ++i) {
         union { i16x4 v[2]; f16x8 h; } u;
         u.v[0] = lds_read_tr16(box + bbase + tap_off[i]);
-        u.v[1] = lds_read_tr16(box + bbase + tap_off[i] + 4 * IS * 64);
+        u.v[1] = lds_read_tr16(box + bbase + tap_off[i] + 4 * ISW * 64);
         xa[i] = u.h;
       }
 #pragma unroll
@@ -211,10 +246,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   }
 }
 
-template <int TD, int TH, int TW, int IS, int EXT, int MAXT>
+template <int TD, int TH, int TW, int LPT_BOX, int MAXT, class G>
 static int launch_wg_t(const WgradDev& base, hipStream_t stream, bool pre_zeroed) {
-  using C = WgCfg<TD, TH, TW, IS, EXT>;
+  using C = WgCfg<TD, TH, TW>;
   WgradDev p = base;
+  const G geo(p.d);
+  const WBoxGeom<TD, TH, TW, G> bg(geo);
+  if (bg.NBOXLOAD > LPT_BOX * 256) return NNZ_EINVAL;  // register staging cannot hold this box
+  const int lds = bg.BOX_BYTES + C::Q_BYTES;
   p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
   p.tiles[1] = (p.d.m_dims[1] + TH - 1) / TH;
   p.tiles[2] = (p.d.m_dims[2] + TW - 1) / TW;
@@ -225,28 +264,35 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, bool pre_zeroed
   if (splits < 1) splits = 1;
   if (splits > p.ntiles) splits = p.ntiles;
   p.splits = splits;
-  auto kern = conv_wgrad_kernel<TD, TH, TW, IS, EXT, MAXT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  auto kern = conv_wgrad_kernel<TD, TH, TW, LPT_BOX, MAXT, G>;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_lds = lds;
   }
   if (!pre_zeroed) {
     hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.d.ntaps_total * p.d.Cin * p.d.Cout, stream);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3(pairs * splits), dim3(256), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3(pairs * splits), dim3(256), lds, stream, p);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
 
-template <int TD, int TH, int TW, int IS, int EXT>
+template <int TD, int TH, int TW, int LPT_BOX, class G>
 static int launch_wg(const WgradDev& p, hipStream_t stream, bool pre_zeroed) {
   const int per_wave = (p.d.ntaps_total + 3) / 4;
-  if (per_wave <= 2) return launch_wg_t<TD, TH, TW, IS, EXT, 2>(p, stream, pre_zeroed);
-  return launch_wg_t<TD, TH, TW, IS, EXT, 7>(p, stream, pre_zeroed);
+  if (per_wave <= 2) return launch_wg_t<TD, TH, TW, LPT_BOX, 2, G>(p, stream, pre_zeroed);
+  return launch_wg_t<TD, TH, TW, LPT_BOX, 7, G>(p, stream, pre_zeroed);
+}
+
+template <int TD, int TH, int TW, int IS, int EXT>
+static int launch_wg_iso(const WgradDev& p, hipStream_t stream, bool pre_zeroed) {
+  constexpr int lpt =
+      (((TD - 1) * IS + EXT + 1) * ((TH - 1) * IS + EXT + 1) * ((TW - 1) * IS + EXT + 1) * 4 + 255) / 256;
+  return launch_wg<TD, TH, TW, lpt, WGeoIso<IS, EXT>>(p, stream, pre_zeroed);
 }
 
 }  // namespace nnz
@@ -256,21 +302,37 @@ extern "C" int nnz_conv_tap_wgrad(const void* boxed, const void* plain, float* d
   using namespace nnz;
   if (!boxed || !plain || !dw || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
-  if (d.Cin % 32 || d.Cout % 32 || d.ngroups != 1 || d.ntaps_total > 28 || d.ntaps_total < 1 || d.ldi % 8 ||
-      d.ldo % 8 || (d.in_stride != 1 && d.in_stride != 2) || d.ext < 0 || d.ext > 2)
+  if (d.Cin % 32 || d.Cout % 32 || d.ngroups != 1 || d.ntaps_total > 28 || d.ntaps_total < 1 || d.ldi % 8 || d.ldo % 8)
     return NNZ_EINVAL;
+  for (int a = 0; a < 3; ++a)
+    if ((d.in_stride[a] != 1 && d.in_stride[a] != 2) || (d.out_stride[a] != 1 && d.out_stride[a] != 2) ||
+        d.ext[a] < 0 || d.ext[a] > 2)
+      return NNZ_EINVAL;
   WgradDev p;
   p.p = (const f16*)boxed;
   p.q = (const f16*)plain;
   p.dw = dw;
   p.d = d;
   hipStream_t s = (hipStream_t)stream;
-  if (d.in_stride == 1) {
-    if (d.ext == 0) return launch_wg<4, 8, 8, 1, 0>(p, s, pre_zeroed != 0);
-    if (d.ext == 1) return launch_wg<4, 8, 8, 1, 1>(p, s, pre_zeroed != 0);
-    return launch_wg<4, 8, 8, 1, 2>(p, s, pre_zeroed != 0);
-  } else {
-    if (d.ext <= 1) return launch_wg<2, 4, 8, 2, 1>(p, s, pre_zeroed != 0);
-    return launch_wg<2, 4, 8, 2, 2>(p, s, pre_zeroed != 0);
+  const bool z = pre_zeroed != 0;
+  const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&
+                   d.ext[1] == d.ext[2] && d.m_dims[0] > 1;
+  if (iso) {
+    const int ext = d.ext[0];
+    if (d.in_stride[0] == 1) {
+      if (ext == 0) return launch_wg_iso<4, 8, 8, 1, 0>(p, s, z);
+      if (ext == 1) return launch_wg_iso<4, 8, 8, 1, 1>(p, s, z);
+      return launch_wg_iso<4, 8, 8, 1, 2>(p, s, z);
+    }
+    if (ext <= 1) return launch_wg_iso<2, 4, 8, 2, 1>(p, s, z);
+    return launch_wg_iso<2, 4, 8, 2, 2>(p, s, z);
   }
+  // per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) and anisotropic 3-D plans
+  const bool strided = d.in_stride[0] == 2 || d.in_stride[1] == 2 || d.in_stride[2] == 2;
+  if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
+    if (strided) return launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, z);
+    return launch_wg<1, 32, 8, 6, WGeoDyn>(p, s, z);
+  }
+  if (strided) return launch_wg<2, 4, 8, 12, WGeoDyn>(p, s, z);
+  return launch_wg<4, 8, 8, 10, WGeoDyn>(p, s, z);
 }

@@ -34,6 +34,20 @@ from ..hip_ops import PreparedTable
 # ------------------------------------------------------------------------------------------------------------------
 # parameter-holder modules (names mirror dynamic_network_architectures.building_blocks)
 # ------------------------------------------------------------------------------------------------------------------
+def _nd(conv_op) -> int:
+    return {nn.Conv2d: 2, nn.Conv3d: 3}[conv_op]
+
+
+def _nlist(v, nd: int) -> List[int]:
+    return [int(v)] * nd if isinstance(v, int) else [int(i) for i in v]
+
+
+def _to3(v: Sequence[int], fill: int = 1) -> Tuple[int, int, int]:
+    """2-D layer geometry as a depth-1 volume: (h, w) -> (fill, h, w)"""
+    v = tuple(int(i) for i in v)
+    return v if len(v) == 3 else (fill, *v)
+
+
 def _no_direct_call(self, *a, **k):
     raise RuntimeError(f"{type(self).__name__} is a parameter holder of nnuzoo_amd.PlainConvUNet; call the network")
 
@@ -43,9 +57,9 @@ class ConvDropoutNormReLU(nn.Module):
                  nonlin_kwargs):
         super().__init__()
         self.input_channels, self.output_channels = cin, cout
-        ks = [kernel_size] * 3 if isinstance(kernel_size, int) else list(kernel_size)
-        st = [stride] * 3 if isinstance(stride, int) else list(stride)
-        self.stride = st
+        nd = _nd(conv_op)
+        ks, st = _nlist(kernel_size, nd), _nlist(stride, nd)
+        self.stride, self.kernel_size = st, ks
         self.conv = conv_op(cin, cout, ks, st, padding=[(k - 1) // 2 for k in ks], dilation=1, bias=conv_bias)
         mods = [self.conv]
         self.norm = norm_op(cout, **(norm_op_kwargs or {}))
@@ -87,7 +101,7 @@ class PlainConvEncoder(nn.Module):
             cin = features_per_stage[s]
         self.stages = nn.Sequential(*stages)
         self.output_channels = list(features_per_stage)
-        self.strides = [[s] * 3 if isinstance(s, int) else list(s) for s in strides]
+        self.strides = [_nlist(s, _nd(conv_op)) for s in strides]
         self.return_skips = True
         self.conv_op, self.norm_op, self.norm_op_kwargs = conv_op, norm_op, norm_op_kwargs
         self.nonlin, self.nonlin_kwargs, self.conv_bias = nonlin, nonlin_kwargs, conv_bias
@@ -127,15 +141,22 @@ class UNetDecoder(nn.Module):
 # execution plan
 # ------------------------------------------------------------------------------------------------------------------
 class _Block:
-    """One conv -> InstanceNorm -> LeakyReLU block of the schedule."""
+    """One conv -> InstanceNorm -> LeakyReLU block of the schedule.  Geometry is always 3-D: a 2-D layer is the
+    depth-1 volume with kernel (1, kh, kw) and stride (1, sh, sw)."""
 
-    def __init__(self, holder: ConvDropoutNormReLU, N, in_dims, stem: bool):
+    def __init__(self, holder: ConvDropoutNormReLU, N, in_dims, first: bool):
         self.h = holder
-        self.stem = stem
-        self.cin, self.cout = holder.input_channels, holder.output_channels
-        self.stride = holder.stride[0]
+        self.ks, self.stride = _to3(holder.kernel_size), _to3(holder.stride)
+        self.nk = self.ks[0] * self.ks[1] * self.ks[2]
+        self.cin_w, self.cout = holder.input_channels, holder.output_channels
+        # the network's first conv: Cin = 1, k3^3, 32 features runs the dedicated VALU/MFMA stem kernels (the input
+        # stays fp32 NCDHW); any other first conv (2-D, several modalities, other kernels) pads the input channels to
+        # 32 zeros-filled fp16 channels and runs the ordinary MFMA path.
+        self.stem = first and self.cin_w == 1 and self.ks == (3, 3, 3) and self.stride == (1, 1, 1) and self.cout == 32
+        self.padded = first and not self.stem
+        self.cin = 32 * ((self.cin_w + 31) // 32) if self.padded else self.cin_w
         self.in_dims = tuple(in_dims)
-        self.out_dims = cp.conv_out_dims(in_dims, (3, 3, 3), self.stride)
+        self.out_dims = cp.conv_out_dims(in_dims, self.ks, self.stride)
         self.N = N
         self.V = int(np.prod(self.out_dims))
         self.eps = float(holder.norm.eps)
@@ -144,16 +165,18 @@ class _Block:
         self.x_ld = self.cin      # channel stride of the input activation
         self.y_ld = self.cout     # channel stride of the output activation (2C when written into a cat buffer)
         self.fwd = self.dgrad = self.wgrad = None
+        self.zero_dx = cp.dgrad_uncovered(self.ks, self.stride)
 
     def prepare(self):
         if not self.stem:
-            self.fwd = PreparedTable(cp.conv_forward(self.N, self.in_dims, self.cin, self.cout, stride=self.stride,
-                                                     ldi=self.x_ld, ldo=self.cout))
-            self.wgrad = PreparedTable(cp.conv_wgrad(self.N, self.in_dims, self.cin, self.cout, stride=self.stride,
-                                                     ldx=self.x_ld, lddy=self.cout))
+            self.fwd = PreparedTable(cp.conv_forward(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
+                                                     stride=self.stride, ldi=self.x_ld, ldo=self.cout))
+            self.wgrad = PreparedTable(cp.conv_wgrad(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
+                                                     stride=self.stride, ldx=self.x_ld, lddy=self.cout))
+        if not self.stem and not self.padded:
             # dgrad: in = d(raw) [ld cout] -> out = d(input activation) [ld x_ld]
-            self.dgrad = PreparedTable(cp.conv_dgrad(self.N, self.in_dims, self.cin, self.cout, stride=self.stride,
-                                                     ldi=self.cout, ldo=self.x_ld))
+            self.dgrad = PreparedTable(cp.conv_dgrad(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
+                                                     stride=self.stride, ldi=self.cout, ldo=self.x_ld))
             self.dgrad_acc = self.dgrad.with_accumulate(True)
 
 
@@ -161,10 +184,13 @@ class _Up:
     def __init__(self, tconv: nn.Module, N, in_dims, cin, cout, ldo):
         self.m = tconv
         self.N, self.in_dims, self.cin, self.cout = N, tuple(in_dims), cin, cout
-        self.out_dims = tuple(2 * d for d in in_dims)
-        self.fwd = PreparedTable(cp.convT_forward(N, in_dims, cin, cout, ldi=cin, ldo=ldo))
-        self.dgrad = PreparedTable(cp.convT_dgrad(N, in_dims, cin, cout, ldi=ldo, ldo=cin))
-        self.wgrad = PreparedTable(cp.convT_wgrad(N, in_dims, cin, cout, lddout=ldo, ldin=cin))
+        st = self.stride = _to3(tconv.stride)
+        assert _to3(tconv.kernel_size) == st
+        self.nk = st[0] * st[1] * st[2]
+        self.out_dims = tuple(st[a] * in_dims[a] for a in range(3))
+        self.fwd = PreparedTable(cp.convT_forward(N, in_dims, cin, cout, ldi=cin, ldo=ldo, stride=st))
+        self.dgrad = PreparedTable(cp.convT_dgrad(N, in_dims, cin, cout, ldi=ldo, ldo=cin, stride=st))
+        self.wgrad = PreparedTable(cp.convT_wgrad(N, in_dims, cin, cout, lddout=ldo, ldin=cin, stride=st))
         self.ldo = ldo
 
 
@@ -182,7 +208,7 @@ class _Plan:
         for s in range(S):
             blocks = []
             for i, h in enumerate(enc.stages[s][0].convs):
-                b = _Block(h, N, d, stem=(s == 0 and i == 0))
+                b = _Block(h, N, d, first=(s == 0 and i == 0))
                 d = b.out_dims
                 blocks.append(b)
             self.level_dims.append(d)
@@ -196,10 +222,14 @@ class _Plan:
         for j in range(S - 1):
             lvl = S - 2 - j
             below, skip = feats[lvl + 1], feats[lvl]
-            self.ups.append(_Up(dec.transpconvs[j], N, self.level_dims[lvl + 1], below, skip, ldo=2 * skip))
+            up = _Up(dec.transpconvs[j], N, self.level_dims[lvl + 1], below, skip, ldo=2 * skip)
+            if up.out_dims != tuple(self.level_dims[lvl]):
+                raise ValueError(f"nnuzoo_amd.PlainConvUNet: patch size {tuple(dims)} is not divisible by the network's "
+                                 f"strides (level {lvl}: {up.out_dims} after upsampling vs {self.level_dims[lvl]})")
+            self.ups.append(up)
             blocks = []
             for i, h in enumerate(dec.stages[j].convs):
-                b = _Block(h, N, self.level_dims[lvl], stem=False)
+                b = _Block(h, N, self.level_dims[lvl], first=False)
                 if i == 0:
                     b.x_ld = 2 * skip
                 blocks.append(b)
@@ -218,9 +248,9 @@ class _Plan:
             b.stats_off, so = so, so + N * b.cout * 2          # slice of the per-step statistics buffer
             b.dw_off = do
             if not b.stem:
-                do += 27 * b.cin * b.cout                         # slice of the per-step dW buffer
+                do += b.nk * b.cin * b.cout                       # slice of the per-step dW buffer
         for u in self.ups:
-            u.dw_off, do = do, do + 8 * u.cout * u.cin
+            u.dw_off, do = do, do + u.nk * u.cout * u.cin
         self.stats_floats, self.dw_floats = so, do
         self.pack_fwd = self.pack_bwd = None                      # built on first use (needs device pointers)
 
@@ -232,34 +262,51 @@ class _Plan:
             if b.stem:
                 continue
             w = b.h.conv.weight
-            b.wp_fwd = torch.empty(b.cin * b.cout * 27, dtype=f16, device=dev)
-            b.wp_dgrad = torch.empty(b.cin * b.cout * 27, dtype=f16, device=dev)
-            self.pack_fwd.add(w, b.wp_fwd, b.fwd, b.cin, b.cout, 27, b.cin * 27, 1)
-            self.pack_bwd.add(w, b.wp_dgrad, b.dgrad, b.cout, b.cin, b.cin * 27, 27, 1)
+            nk = b.nk
+            b.wp_fwd = torch.empty(b.cin * b.cout * nk, dtype=f16, device=dev)
+            if b.padded:
+                # fp32 staging copy of the first conv's weight with the input channels padded to 32 (refreshed from
+                # the parameter before every pack; the padding rows stay zero)
+                b.w_pad = torch.zeros((b.cout, b.cin, *b.ks), dtype=torch.float32, device=dev)
+                b.gw_pad = torch.empty_like(b.w_pad)
+                self.pack_fwd.add(b.w_pad, b.wp_fwd, b.fwd, b.cin, b.cout, nk, b.cin * nk, 1)
+                continue
+            b.wp_dgrad = torch.empty(b.cin * b.cout * nk, dtype=f16, device=dev)
+            self.pack_fwd.add(w, b.wp_fwd, b.fwd, b.cin, b.cout, nk, b.cin * nk, 1)
+            self.pack_bwd.add(w, b.wp_dgrad, b.dgrad, b.cout, b.cin, b.cin * nk, nk, 1)
         for u in self.ups:
             w = u.m.weight
-            u.wp_fwd = torch.empty(u.cin * u.cout * 8, dtype=f16, device=dev)
-            u.wp_dgrad = torch.empty(u.cin * u.cout * 8, dtype=f16, device=dev)
-            self.pack_fwd.add(w, u.wp_fwd, u.fwd, u.cin, u.cout, u.cout * 8, 8, 1)
-            self.pack_bwd.add(w, u.wp_dgrad, u.dgrad, u.cout, u.cin, 8, u.cout * 8, 1)
+            nk = u.nk
+            u.wp_fwd = torch.empty(u.cin * u.cout * nk, dtype=f16, device=dev)
+            u.wp_dgrad = torch.empty(u.cin * u.cout * nk, dtype=f16, device=dev)
+            self.pack_fwd.add(w, u.wp_fwd, u.fwd, u.cin, u.cout, u.cout * nk, nk, 1)
+            self.pack_bwd.add(w, u.wp_dgrad, u.dgrad, u.cout, u.cin, nk, u.cout * nk, 1)
 
 
 def _check_supported(net: "PlainConvUNet"):
     enc = net.encoder
-    if enc.conv_op is not nn.Conv3d:
-        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: the HIP schedule covers conv_op=torch.nn.Conv3d")
-    if not issubclass(enc.norm_op, nn.InstanceNorm3d) or not (enc.norm_op_kwargs or {}).get("affine", False):
-        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: norm_op must be InstanceNorm3d(affine=True)")
+    if enc.conv_op not in (nn.Conv2d, nn.Conv3d):
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: conv_op must be torch.nn.Conv2d or torch.nn.Conv3d")
+    norm_cls = {nn.Conv2d: nn.InstanceNorm2d, nn.Conv3d: nn.InstanceNorm3d}[enc.conv_op]
+    if not (isinstance(enc.norm_op, type) and issubclass(enc.norm_op, norm_cls)) or \
+            not (enc.norm_op_kwargs or {}).get("affine", False):
+        raise NotImplementedError(f"nnuzoo_amd.PlainConvUNet: norm_op must be {norm_cls.__name__}(affine=True)")
     if enc.nonlin is not nn.LeakyReLU:
         raise NotImplementedError("nnuzoo_amd.PlainConvUNet: nonlin must be torch.nn.LeakyReLU")
+    nd = _nd(enc.conv_op)
     for s, ks in enumerate(enc.kernel_sizes):
-        ks = [ks] * 3 if isinstance(ks, int) else list(ks)
-        st = enc.strides[s]
-        if ks != [3, 3, 3] or st[0] != st[1] or st[1] != st[2] or st[0] not in (1, 2):
-            raise NotImplementedError("nnuzoo_amd.PlainConvUNet: kernel 3x3x3 and isotropic stride 1/2 only")
+        ks, st = _nlist(ks, nd), enc.strides[s]
+        if len(ks) != nd or len(st) != nd or any(k not in (1, 3) for k in ks) or any(v not in (1, 2) for v in st):
+            raise NotImplementedError("nnuzoo_amd.PlainConvUNet: per-axis kernel sizes 1/3 and strides 1/2 only "
+                                      f"(stage {s}: kernel {ks}, stride {st})")
+    if any(v != 1 for v in enc.strides[0]):
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: the first stage must have stride 1 (planner default)")
     feats = enc.output_channels
-    if net.input_channels != 1 or feats[0] != 32 or any(f % 32 for f in feats):
-        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: input_channels=1, features multiple of 32, first = 32")
+    if any(f % 32 for f in feats):
+        raise NotImplementedError("nnuzoo_amd.PlainConvUNet: features per stage must be multiples of 32")
+    for s in range(1, len(feats)):
+        if nd == 3 and any(v == 2 for v in enc.strides[s]) and feats[s] % 64:
+            raise NotImplementedError("nnuzoo_amd.PlainConvUNet: a strided 3-D stage needs features % 64 == 0")
     if not enc.conv_bias:
         raise NotImplementedError("nnuzoo_amd.PlainConvUNet: conv_bias=True expected (planner default)")
 
@@ -325,6 +372,7 @@ class PlainConvUNet(nn.Module):
                                         nonlin, nonlin_kwargs)
         self.decoder = UNetDecoder(self.encoder, num_classes, list(n_conv_per_stage_decoder), deep_supervision)
         _check_supported(self)
+        self._nd = _nd(conv_op)
         self._plans = {}
         self._param_list: Optional[List[nn.Parameter]] = None
         self.grad_reducer = None  # set by nnuzoo_amd.ddp.attach_bucketed_allreduce
@@ -352,8 +400,10 @@ class PlainConvUNet(nn.Module):
             raise RuntimeError("nnuzoo_amd.PlainConvUNet runs on MI355X through libnnuzoo_hip.so only; got a CPU "
                                "tensor and there is deliberately no CPU fallback (see oracle/ for the test-only "
                                "CPU restatement)")
-        if x.dim() != 5 or x.shape[1] != 1:
-            raise ValueError(f"expected (B, 1, D, H, W) input, got {tuple(x.shape)}")
+        nd = _nd(self.encoder.conv_op)
+        if x.dim() != nd + 2 or x.shape[1] != self.input_channels:
+            raise ValueError(f"expected (B, {self.input_channels}, {'D, H, W' if nd == 3 else 'H, W'}) input, got "
+                             f"{tuple(x.shape)}")
         x = x.float().contiguous()
         params = self._params()
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
@@ -369,6 +419,8 @@ class PlainConvUNet(nn.Module):
         stats = stats_all[b.stats_off:b.stats_off + b.N * b.cout * 2].view(b.N, b.cout, 2)  # zeroed once per step
         if b.stem:
             ops.stem_forward(x_act, h.conv.weight, h.conv.bias, raw, (b.N, *b.in_dims), b.cout)
+        elif b.padded:
+            ops.conv_tap_forward(b.fwd, self._padded_input(b, x_act), b.wp_fwd, h.conv.bias, raw)
         else:
             ops.conv_tap_forward(b.fwd, x_act, b.wp_fwd, h.conv.bias, raw)
         ops.instnorm_stats(raw, stats, b.N, b.V, b.cout, b.cout, pre_zeroed=True)
@@ -376,9 +428,17 @@ class PlainConvUNet(nn.Module):
                                  b.eps, b.slope)
         return raw, stats
 
+    @staticmethod
+    def _padded_input(b: _Block, x: torch.Tensor) -> torch.Tensor:
+        """fp32 (N, C, *dims) network input -> channels-last fp16 [N, V, 32k] with zero-filled padding channels
+        (layout plumbing for first convs the dedicated stem kernels do not cover)"""
+        xc = torch.zeros((b.N, int(np.prod(b.in_dims)), b.cin), dtype=torch.float16, device=x.device)
+        xc[:, :, :b.cin_w] = x.reshape(b.N, b.cin_w, -1).transpose(1, 2)
+        return xc
+
     def _run_forward(self, x: torch.Tensor, save: bool):
         N = x.shape[0]
-        dims = tuple(x.shape[2:])
+        dims = _to3(x.shape[2:])
         plan = self._plan(N, dims)
         dev = x.device
         S = plan.S
@@ -387,6 +447,9 @@ class PlainConvUNet(nn.Module):
         f16 = torch.float16
         if plan.pack_fwd is None:
             plan.build_pack_tables(dev)
+        b0 = plan.enc_blocks[0][0]
+        if b0.padded:
+            b0.w_pad[:, :b0.cin_w].copy_(b0.h.conv.weight.detach().reshape(b0.cout, b0.cin_w, *b0.ks))
         plan.pack_fwd.run()
         stats_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
         cats = [torch.empty((N, int(np.prod(plan.level_dims[s])), 2 * feats[s]), dtype=f16, device=dev)
@@ -422,7 +485,7 @@ class PlainConvUNet(nn.Module):
             if self.decoder.deep_supervision or j == S - 2:
                 seg = self.decoder.seg_layers[j]
                 V = int(np.prod(plan.level_dims[lvl]))
-                logits = torch.empty((N, K, *plan.level_dims[lvl]), dtype=f16, device=dev)
+                logits = torch.empty((N, K, *plan.level_dims[lvl][3 - self._nd:]), dtype=f16, device=dev)
                 ops.head_forward(cur, seg.weight, seg.bias, logits, N, V, feats[lvl], K, feats[lvl])
                 outs[lvl] = logits
             lres = cur
@@ -451,10 +514,18 @@ class PlainConvUNet(nn.Module):
         if b.stem:
             ops.stem_wgrad(x_in, draw, gw, (b.N, *b.in_dims), b.cout)
         else:
-            dw = self._dw_all[b.dw_off:b.dw_off + 27 * b.cin * b.cout].view(27, b.cin, b.cout)
-            ops.conv_tap_wgrad(b.wgrad, x_in, draw, dw, pre_zeroed=True)
-            ops.unpack_wgrad(dw, gw, b.cin, b.cout, 27, 27, b.cin * 27, 1, b.wgrad)
-            ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
+            nk = b.nk
+            dw = self._dw_all[b.dw_off:b.dw_off + nk * b.cin * b.cout].view(nk, b.cin, b.cout)
+            if b.padded:
+                ops.conv_tap_wgrad(b.wgrad, self._padded_input(b, x_in), draw, dw, pre_zeroed=True)
+                ops.unpack_wgrad(dw, b.gw_pad, b.cin, b.cout, nk, nk, b.cin * nk, 1, b.wgrad)
+                gw.copy_(b.gw_pad[:, :b.cin_w].reshape(gw.shape))
+            else:
+                ops.conv_tap_wgrad(b.wgrad, x_in, draw, dw, pre_zeroed=True)
+                ops.unpack_wgrad(dw, gw, b.cin, b.cout, nk, nk, b.cin * nk, 1, b.wgrad)
+                if b.zero_dx and not dx_acc:
+                    dx_out.zero_()  # k1 s2 axes: odd input positions are outside every output's footprint
+                ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
         grads[h.conv.weight] = gw
 
     def _galloc(self, like: torch.Tensor) -> torch.Tensor:
@@ -522,10 +593,11 @@ class PlainConvUNet(nn.Module):
             up = plan.ups[j]
             g_up = g_act  # channel slice [:C] of the cat gradient, ld = 2C
             Vb = int(np.prod(up.in_dims))
-            dwt = self._dw_all[up.dw_off:up.dw_off + 8 * up.cout * up.cin].view(8, up.cout, up.cin)
+            nk = up.nk
+            dwt = self._dw_all[up.dw_off:up.dw_off + nk * up.cout * up.cin].view(nk, up.cout, up.cin)
             ops.conv_tap_wgrad(up.wgrad, g_up, lres, dwt, pre_zeroed=True)
             gw = self._galloc(up.m.weight)
-            ops.unpack_wgrad(dwt, gw, up.cout, up.cin, 8, 8, up.cout * 8, 1, up.wgrad)
+            ops.unpack_wgrad(dwt, gw, up.cout, up.cin, nk, nk, up.cout * nk, 1, up.wgrad)
             grads[up.m.weight] = gw
             if up.m.bias is not None:
                 st = torch.empty((N, up.cout, 2), dtype=torch.float32, device=dev)
@@ -546,7 +618,7 @@ class PlainConvUNet(nn.Module):
             for i in range(len(blocks) - 1, -1, -1):
                 b = blocks[i]
                 first_of_stage = i == 0
-                if b.stem:
+                if b.stem or b.padded:  # the network's first conv: no data gradient
                     self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, None, False, dev)
                     continue
                 if first_of_stage:

@@ -61,9 +61,14 @@ def test_config0_plumbing_2d_cpu():
     assert batch["data"].shape == (2, 1, 512, 512) and batch["data"].dtype == torch.float32
     assert [tuple(t.shape[2:]) for t in batch["target"]] == [(512 >> i, 512 >> i) for i in range(7)]
     assert all(t.dtype == torch.int16 for t in batch["target"])
-    # the product network exists only as a HIP schedule for 3-D patches; 2-D PlainConvUNet construction says so
-    with pytest.raises(NotImplementedError):
-        tr.initialize()
+    # the product network is a HIP schedule (2-D plans run as depth-1 volumes): it builds anywhere, with the
+    # reference's state_dict, but a CPU tensor is refused - there is no CPU fallback
+    tr.initialize()
+    ref_keys = list(OraclePlainConvUNet(1, num_classes=2, **planner_arch_kwargs(2, 8, arch["features_per_stage"]))
+                    .state_dict().keys())
+    assert list(tr.network.state_dict().keys()) == ref_keys
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tr.network(batch["data"])
     # oracle = the CPU reference of this configuration (reduced to 128^2 here to keep the CPU suite short)
     torch.manual_seed(0)
     net = OraclePlainConvUNet(1, num_classes=2, **planner_arch_kwargs(2, 6, [32, 64, 128, 256, 512, 512]))

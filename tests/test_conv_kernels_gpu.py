@@ -245,3 +245,94 @@ def test_seg_head(hip_lib, N, dims, C, K):
     close(from_cl(dx, dims), x.grad)
     close(gw.cpu(), w.grad.reshape(K, C), rtol=2e-3, atol_frac=1e-3)
     close(gb.cpu(), b.grad, rtol=2e-3, atol_frac=1e-3)
+
+
+# ---- per-axis geometry: 2-D plans (depth-1 volumes) and anisotropic 3-D plans -----------------------------------------
+ANISO_CASES = [
+    # N, dims, cin, cout, ks, stride
+    (2, (1, 40, 24), 32, 32, (1, 3, 3), (1, 1, 1)),      # 2-D, flat 1x32x8 tile, ragged
+    (1, (1, 64, 64), 32, 64, (1, 3, 3), (1, 2, 2)),      # 2-D strided
+    (2, (1, 16, 16), 64, 128, (1, 3, 3), (1, 1, 1)),     # 2-D small map -> 1x8x8 tile
+    (1, (1, 12, 20), 64, 96, (1, 3, 3), (1, 2, 2)),      # 2-D strided, Cout % 64 != 0
+    (1, (6, 16, 24), 32, 64, (1, 3, 3), (1, 2, 2)),      # thick-slice 3-D stage
+    (1, (8, 16, 16), 64, 64, (3, 3, 3), (2, 2, 1)),      # pooling stopped on the last axis
+    (1, (5, 16, 16), 32, 32, (1, 3, 3), (1, 1, 1)),      # k(1,3,3) s1 in 3-D
+    (1, (8, 8, 12), 64, 64, (3, 3, 1), (2, 1, 2)),       # k1 s2 on one axis (uncovered odd positions)
+]
+
+
+def _w(cout, cin, ks, g, scale=0.05):
+    return h(torch.randn(cout, cin, *ks, generator=g) * scale)
+
+
+@pytest.mark.parametrize("N,dims,cin,cout,ks,stride", ANISO_CASES)
+def test_conv_aniso_forward_dgrad_wgrad(hip_lib, N, dims, cin, cout, ks, stride):
+    g = torch.Generator().manual_seed(11)
+    nk = ks[0] * ks[1] * ks[2]
+    pad = [k // 2 for k in ks]
+    x = h(torch.randn(N, cin, *dims, generator=g)).requires_grad_(True)
+    w = _w(cout, cin, ks, g).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv3d(x, w, b, stride=stride, padding=pad)
+    odims = tuple(y.shape[2:])
+    dy = h(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    wd = w.detach().to(DEV)
+    # forward
+    pt = PreparedTable(cp.conv_forward(N, dims, cin, cout, ks=ks, stride=stride))
+    wp = ops.pack_weight(wd, pt, cin, cout, nk, cin * nk, 1)
+    out = torch.full((N, int(np.prod(odims)), cout), float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(pt, to_cl(x.detach()), wp, b.to(DEV), out)
+    torch.cuda.synchronize()
+    close(from_cl(out, odims), y.detach())
+    # dgrad (destination zeroed when the table leaves positions unwritten)
+    ptd = PreparedTable(cp.conv_dgrad(N, dims, cin, cout, ks=ks, stride=stride))
+    wpd = ops.pack_weight(wd, ptd, cout, cin, cin * nk, nk, 1)
+    fill = 0.0 if cp.dgrad_uncovered(ks, stride) else float("nan")
+    dx = torch.full((N, int(np.prod(dims)), cin), fill, dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(ptd, to_cl(dy), wpd, None, dx)
+    torch.cuda.synchronize()
+    close(from_cl(dx, dims), x.grad)
+    # wgrad
+    ptw = PreparedTable(cp.conv_wgrad(N, dims, cin, cout, ks=ks, stride=stride))
+    dw = torch.empty((nk, cin, cout), dtype=torch.float32, device=DEV)
+    ops.conv_tap_wgrad(ptw, to_cl(x.detach()), to_cl(dy), dw)
+    gw = torch.full((cout, cin, *ks), float("nan"), dtype=torch.float32, device=DEV)
+    ops.unpack_wgrad(dw, gw, cin, cout, nk, nk, cin * nk, 1, ptw)
+    torch.cuda.synchronize()
+    close(gw.cpu(), w.grad, rtol=2e-3, atol_frac=1e-3)
+
+
+@pytest.mark.parametrize("N,dims,cin,cout,stride", [(2, (1, 12, 20), 64, 32, (1, 2, 2)), (1, (4, 6, 8), 128, 64, (1, 2, 2)),
+                                                    (1, (4, 4, 8), 64, 64, (2, 2, 1))])
+def test_conv_transpose_aniso(hip_lib, N, dims, cin, cout, stride):
+    g = torch.Generator().manual_seed(12)
+    nk = stride[0] * stride[1] * stride[2]
+    x = h(torch.randn(N, cin, *dims, generator=g)).requires_grad_(True)
+    w = h(torch.randn(cin, cout, *stride, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv_transpose3d(x, w, b, stride=stride)
+    odims = tuple(y.shape[2:])
+    dy = h(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    V, Vo = int(np.prod(dims)), int(np.prod(odims))
+    wd = w.detach().to(DEV)
+    pt = PreparedTable(cp.convT_forward(N, dims, cin, cout, stride=stride))
+    wp = ops.pack_weight(wd, pt, cin, cout, cout * nk, nk, 1)
+    out = torch.full((N, Vo, cout), float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(pt, to_cl(x.detach()), wp, b.to(DEV), out)
+    torch.cuda.synchronize()
+    close(from_cl(out, odims), y.detach())
+    ptd = PreparedTable(cp.convT_dgrad(N, dims, cin, cout, stride=stride))
+    wpd = ops.pack_weight(wd, ptd, cout, cin, nk, cout * nk, 1)
+    dx = torch.full((N, V, cin), float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(ptd, to_cl(dy), wpd, None, dx)
+    torch.cuda.synchronize()
+    close(from_cl(dx, dims), x.grad)
+    ptw = PreparedTable(cp.convT_wgrad(N, dims, cin, cout, stride=stride))
+    dwt = torch.empty((nk, cout, cin), dtype=torch.float32, device=DEV)
+    ops.conv_tap_wgrad(ptw, to_cl(dy), to_cl(x.detach()), dwt)
+    gw = torch.full((cin, cout, *stride), float("nan"), dtype=torch.float32, device=DEV)
+    ops.unpack_wgrad(dwt, gw, cout, cin, nk, nk, cout * nk, 1, ptw)
+    torch.cuda.synchronize()
+    close(gw.cpu(), w.grad, rtol=2e-3, atol_frac=1e-3)

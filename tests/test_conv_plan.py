@@ -17,7 +17,7 @@ def _gather(x, m_dims, stride, off):
     out = torch.zeros((N, *m_dims, C), dtype=x.dtype)
     idx = []
     for a, (n_m, dim) in enumerate(zip(m_dims, (D, H, W))):
-        coords = torch.arange(n_m) * stride + off[a]
+        coords = torch.arange(n_m) * stride[a] + off[a]
         ok = (coords >= 0) & (coords < dim)
         idx.append((coords, ok))
     sel = [torch.nonzero(ok).flatten() for _, ok in idx]
@@ -42,7 +42,7 @@ def interp_forward(t: cp.TapTable, x, wslices, bias=None, out=None):
             acc += _gather(x, t.m_dims, t.in_stride, off) @ wslices[j]
             j += 1
         for m in itertools.product(*[range(d) for d in t.m_dims]):
-            o = tuple(m[a] * t.out_stride + ooff[a] for a in range(3))
+            o = tuple(m[a] * t.out_stride[a] + ooff[a] for a in range(3))
             if all(o[a] < t.out_dims[a] for a in range(3)):
                 if t.accumulate:
                     out[:, o[0], o[1], o[2]] += acc[:, m[0], m[1], m[2]]
@@ -72,61 +72,75 @@ def ncdhw(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-@pytest.mark.parametrize("dims,stride", [((4, 6, 8), 1), ((4, 6, 8), 2), ((5, 7, 6), 2), ((2, 2, 2), 1)])
-def test_conv_tables(dims, stride):
+@pytest.mark.parametrize("dims,ks,stride", [
+    ((4, 6, 8), 3, 1), ((4, 6, 8), 3, 2), ((5, 7, 6), 3, 2), ((2, 2, 2), 3, 1),
+    ((4, 6, 8), (1, 3, 3), (1, 2, 2)),      # anisotropic 3-D stage (nnU-Net planner, thick slices)
+    ((4, 6, 8), (3, 3, 3), (2, 2, 1)),      # pooling stopped on the last axis
+    ((4, 6, 7), (3, 3, 1), (2, 1, 2)),      # k1 s2 on one axis: odd input positions receive no gradient
+    ((1, 10, 12), (1, 3, 3), (1, 1, 1)),    # 2-D layer = depth-1 volume
+    ((1, 9, 12), (1, 3, 3), (1, 2, 2)),
+])
+def test_conv_tables(dims, ks, stride):
     g = torch.Generator().manual_seed(0)
     N, cin, cout = 2, 3, 4
+    ks3, st3 = cp._triple(ks), cp._triple(stride)
+    nk = ks3[0] * ks3[1] * ks3[2]
     x = torch.randn(N, cin, *dims, generator=g, dtype=torch.float64, requires_grad=True)
-    w = torch.randn(cout, cin, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, *ks3, generator=g, dtype=torch.float64, requires_grad=True)
     b = torch.randn(cout, generator=g, dtype=torch.float64)
-    y = F.conv3d(x, w, b, stride=stride, padding=1)
+    y = F.conv3d(x, w, b, stride=st3, padding=[k // 2 for k in ks3])
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
-    wflat = w.detach().reshape(cout, cin, 27)
+    wflat = w.detach().reshape(cout, cin, nk)
     # forward
-    t = cp.conv_forward(N, dims, cin, cout, stride=stride)
+    t = cp.conv_forward(N, dims, cin, cout, ks=ks, stride=stride)
     assert t.out_dims == tuple(y.shape[2:])
     ws = [wflat[:, :, k].t() for k in t.pack_ksel]
     got = interp_forward(t, cl(x.detach()), ws, b)
     assert torch.allclose(ncdhw(got), y.detach(), atol=1e-10)
-    # dgrad
-    t = cp.conv_dgrad(N, dims, cin, cout, stride=stride)
+    # dgrad (destination zeroed first: interp_forward starts from zeros, as the caller must when dgrad_uncovered)
+    t = cp.conv_dgrad(N, dims, cin, cout, ks=ks, stride=stride)
     ws = [wflat[:, :, k] for k in t.pack_ksel]  # (Cout, Cin): reduction over cout
     got = interp_forward(t, cl(dy), ws)
     assert torch.allclose(ncdhw(got), x.grad, atol=1e-10)
     d = t.to_desc()
-    assert d.ext == (2 if stride == 1 else 1) and d.ntaps_total == 27
+    assert d.ntaps_total == nk
+    assert list(d.ext) == [(ks3[a] - 1) if st3[a] == 1 else (1 if ks3[a] == 3 else 0) for a in range(3)]
+    assert cp.dgrad_uncovered(ks, stride) == any(st3[a] == 2 and ks3[a] == 1 for a in range(3))
     # wgrad
-    t = cp.conv_wgrad(N, dims, cin, cout, stride=stride)
-    dw = interp_wgrad(t, cl(x.detach()), cl(dy))  # [27][cin][cout]
-    assert torch.allclose(dw.permute(2, 1, 0).reshape(cout, cin, 3, 3, 3), w.grad, atol=1e-10)
+    t = cp.conv_wgrad(N, dims, cin, cout, ks=ks, stride=stride)
+    dw = interp_wgrad(t, cl(x.detach()), cl(dy))  # [nk][cin][cout]
+    assert torch.allclose(dw.permute(2, 1, 0).reshape(cout, cin, *ks3), w.grad, atol=1e-10)
 
 
-@pytest.mark.parametrize("dims", [(2, 3, 4), (1, 1, 1)])
-def test_conv_transpose_tables(dims):
+@pytest.mark.parametrize("dims,stride", [((2, 3, 4), 2), ((1, 1, 1), 2), ((2, 3, 4), (1, 2, 2)), ((1, 5, 4), (1, 2, 2)),
+                                         ((3, 2, 4), (2, 2, 1))])
+def test_conv_transpose_tables(dims, stride):
     g = torch.Generator().manual_seed(1)
     N, cin, cout = 2, 3, 5
+    st = cp._triple(stride)
+    nk = st[0] * st[1] * st[2]
     x = torch.randn(N, cin, *dims, generator=g, dtype=torch.float64, requires_grad=True)
-    w = torch.randn(cin, cout, 2, 2, 2, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cin, cout, *st, generator=g, dtype=torch.float64, requires_grad=True)
     b = torch.randn(cout, generator=g, dtype=torch.float64)
-    y = F.conv_transpose3d(x, w, b, stride=2)
+    y = F.conv_transpose3d(x, w, b, stride=st)
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
-    wflat = w.detach().reshape(cin, cout, 8)
-    t = cp.convT_forward(N, dims, cin, cout)
+    wflat = w.detach().reshape(cin, cout, nk)
+    t = cp.convT_forward(N, dims, cin, cout, stride=stride)
     got = interp_forward(t, cl(x.detach()), [wflat[:, :, k] for k in t.pack_ksel], b)
     assert torch.allclose(ncdhw(got), y.detach(), atol=1e-10)
-    t = cp.convT_dgrad(N, dims, cin, cout)
+    t = cp.convT_dgrad(N, dims, cin, cout, stride=stride)
     got = interp_forward(t, cl(dy), [wflat[:, :, k].t() for k in t.pack_ksel])
     assert torch.allclose(ncdhw(got), x.grad, atol=1e-10)
-    t = cp.convT_wgrad(N, dims, cin, cout)
-    dw = interp_wgrad(t, cl(dy), cl(x.detach()))  # [8][cout][cin]
-    assert torch.allclose(dw.permute(2, 1, 0).reshape(cin, cout, 2, 2, 2), w.grad, atol=1e-10)
+    t = cp.convT_wgrad(N, dims, cin, cout, stride=stride)
+    dw = interp_wgrad(t, cl(dy), cl(x.detach()))  # [nk][cout][cin]
+    assert torch.allclose(dw.permute(2, 1, 0).reshape(cin, cout, *st), w.grad, atol=1e-10)
 
 
 def test_desc_roundtrip_limits():
     t = cp.conv_dgrad(1, (8, 8, 8), 32, 64, stride=2)
     d = t.to_desc()
-    assert d.ngroups == 8 and d.out_stride == 2 and d.in_stride == 1
+    assert d.ngroups == 8 and list(d.out_stride) == [2, 2, 2] and list(d.in_stride) == [1, 1, 1]
     assert sorted(g.ntaps for g in list(d.groups)[:8]) == [1, 2, 2, 2, 4, 4, 4, 8]
     assert [d.lo[i] for i in range(3)] == [0, 0, 0]

@@ -15,10 +15,14 @@ from nnuzoo_amd.nets.plain_conv_unet import PlainConvUNet
 from nnuzoo_amd.utilities.network_initialization import InitWeights_He
 
 
-def build_pair(n_stages, feats, seed=0):
+def build_pair(n_stages, feats, seed=0, dim=3, cin=1, kernel_sizes=None, strides=None):
     torch.manual_seed(seed)
-    kw = planner_arch_kwargs(3, n_stages, feats)
-    ref = OraclePlainConvUNet(1, num_classes=2, **kw)
+    kw = planner_arch_kwargs(dim, n_stages, feats)
+    if kernel_sizes is not None:
+        kw["kernel_sizes"] = kernel_sizes
+    if strides is not None:
+        kw["strides"] = strides
+    ref = OraclePlainConvUNet(cin, num_classes=2, **kw)
     ref.apply(InitWeights_He(1e-2))
     # non-trivial affine / bias so that every parameter gradient is exercised
     g = torch.Generator().manual_seed(seed + 1)
@@ -27,16 +31,32 @@ def build_pair(n_stages, feats, seed=0):
             p.data = 1 + 0.2 * torch.randn(p.shape, generator=g)
         elif "norm.bias" in n or n.endswith("bias"):
             p.data = 0.1 * torch.randn(p.shape, generator=g)
-    net = PlainConvUNet(1, num_classes=2, **kw)
+    net = PlainConvUNet(cin, num_classes=2, **kw)
     net.load_state_dict(ref.state_dict())
     return ref, net.cuda()
 
 
-@pytest.mark.parametrize("n_stages,feats,patch", [(3, [32, 64, 128], (16, 16, 16)), (4, [32, 64, 128, 256], (32, 16, 24))])
-def test_forward_backward_parity(hip_lib, n_stages, feats, patch):
-    ref, net = build_pair(n_stages, feats)
+# per-axis geometry cases: (dim, cin, kernel_sizes, strides)
+ISO = (3, 1, None, None)
+PLAN_2D = (2, 1, None, None)                                         # BASELINE configs[0]: nnUNet 2d
+PLAN_2D_RGB = (2, 3, None, None)                                     # several input channels
+PLAN_THICK = (3, 1, [[1, 3, 3], [3, 3, 3], [3, 3, 3]], [[1, 1, 1], [1, 2, 2], [2, 2, 2]])   # anisotropic spacing
+PLAN_STOP = (3, 2, None, [[1, 1, 1], [2, 2, 2], [2, 2, 1]])          # pooling stopped on one axis, 2 modalities
+
+
+@pytest.mark.parametrize("n_stages,feats,patch,geom", [
+    (3, [32, 64, 128], (16, 16, 16), ISO),
+    (4, [32, 64, 128, 256], (32, 16, 24), ISO),
+    (4, [32, 64, 128, 256], (64, 48), PLAN_2D),
+    (3, [32, 64, 128], (32, 40), PLAN_2D_RGB),
+    (3, [32, 64, 128], (6, 32, 24), PLAN_THICK),
+    (3, [32, 64, 128], (16, 16, 12), PLAN_STOP),
+])
+def test_forward_backward_parity(hip_lib, n_stages, feats, patch, geom):
+    dim, cin, kernel_sizes, strides = geom
+    ref, net = build_pair(n_stages, feats, dim=dim, cin=cin, kernel_sizes=kernel_sizes, strides=strides)
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(2, 1, *patch, generator=g)
+    x = torch.randn(2, cin, *patch, generator=g)
     outs_ref = ref(x)
     outs = net(x.cuda())
     assert len(outs) == len(outs_ref) == n_stages - 1
