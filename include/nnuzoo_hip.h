@@ -32,7 +32,8 @@ int nnz_device_info(char* arch, int arch_len, int* num_cu, long* hbm_bytes);
 int nnz_version(void);
 
 /* ---- dense contractions of the PlainConvUNet ("nnUNet") --------------------------------------------------
- * replaces torch.nn.Conv3d / ConvTranspose3d forward + autograd backward of
+ * replaces torch.nn.Conv3d / ConvTranspose3d (and Conv2d / ConvTranspose2d: a 2-D layer is the depth-1 volume with
+ * kernel (1,kh,kw), stride (1,sh,sw); per-axis kernel sizes 1/3 and strides 1/2) forward + autograd backward of
  * dynamic_network_architectures.PlainConvUNet, instantiated at nnunetv2/utilities/get_network_from_plans.py:27-57
  * and driven by nnUNetTrainer.train_step (nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1112-1144). */
 int nnz_conv_tap_forward(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,

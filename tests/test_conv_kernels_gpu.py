@@ -336,3 +336,28 @@ def test_conv_transpose_aniso(hip_lib, N, dims, cin, cout, stride):
     ops.unpack_wgrad(dwt, gw, cout, cin, nk, nk, cout * nk, 1, ptw)
     torch.cuda.synchronize()
     close(gw.cpu(), w.grad, rtol=2e-3, atol_frac=1e-3)
+
+
+def test_batched_weight_pack_matches_single(hip_lib):
+    """one launch packing several layers (all four parameter layouts of the schedule) == per-layer packing, bit-exact"""
+    g = torch.Generator().manual_seed(13)
+    jobs = ops.PackJobTable(torch.device(DEV))
+    expect = []
+    for cin, cout, ks in [(32, 64, (3, 3, 3)), (96, 32, (1, 3, 3)), (64, 320, (3, 3, 3))]:
+        nk = ks[0] * ks[1] * ks[2]
+        w = torch.randn(cout, cin, *ks, generator=g).to(DEV)
+        for pt, R, Cc, sr, sc in [(PreparedTable(cp.conv_forward(1, (4, 8, 8), cin, cout, ks=ks)), cin, cout, nk, cin * nk),
+                                  (PreparedTable(cp.conv_dgrad(1, (4, 8, 8), cin, cout, ks=ks)), cout, cin, cin * nk, nk)]:
+            dst = torch.zeros(cin * cout * nk, dtype=torch.float16, device=DEV)
+            jobs.add(w, dst, pt, R, Cc, sr, sc, 1)
+            expect.append((dst, ops.pack_weight(w, pt, R, Cc, sr, sc, 1)))
+    wt = torch.randn(128, 64, 2, 2, 2, generator=g).to(DEV)
+    for pt, R, Cc, sr, sc in [(PreparedTable(cp.convT_forward(1, (4, 4, 4), 128, 64)), 128, 64, 64 * 8, 8),
+                              (PreparedTable(cp.convT_dgrad(1, (4, 4, 4), 128, 64)), 64, 128, 8, 64 * 8)]:
+        dst = torch.zeros(128 * 64 * 8, dtype=torch.float16, device=DEV)
+        jobs.add(wt, dst, pt, R, Cc, sr, sc, 1)
+        expect.append((dst, ops.pack_weight(wt, pt, R, Cc, sr, sc, 1)))
+    jobs.run()
+    torch.cuda.synchronize()
+    for got, ref in expect:
+        assert torch.equal(got, ref)
