@@ -92,7 +92,7 @@ struct ConvCfg {
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 template <int TD, int TH, int TW, int NB, int LPT_BOX, class G>
-__global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
+__global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   using C = ConvCfg<TD, TH, TW, NB>;
   const G geo(p.d);
   const BoxGeom<TD, TH, TW, G> bg(geo);
@@ -157,16 +157,15 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
   // ---- per-lane fragment addresses ----------------------------------------------------------------
   const int wm = wave % C::WAVES_M;
   const int wn = wave / C::WAVES_M;
-  int vox_off[2][C::WM];  // LDS byte offset of the lane's voxel row for tap h-parity 0 / 1
-  int out_vox[C::WM];     // element offset of the lane's output voxel, -1 if masked
+  int vox_off[C::WM];  // LDS byte offset of the lane's voxel row for a tap of even h offset (odd: ^ 16)
+  int out_vox[C::WM];  // element offset of the lane's output voxel, -1 if masked
 #pragma unroll
   for (int i = 0; i < C::WM; ++i) {
     const int v = (wm * C::WM + i) * 32 + l31;
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
     const int base = (((td * ISD) * bg.BH + th * ISH) * bg.PW + tw * ISW) * 32;
     const int f = (th * ISH) & 1;
-    vox_off[0][i] = base + ((hh ^ f) << 4);
-    vox_off[1][i] = base + ((hh ^ f ^ 1) << 4);
+    vox_off[i] = base + ((hh ^ f) << 4);
     const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
     const int od = md * p.d.out_stride[0] + grp.ooff[0];
     const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
@@ -187,8 +186,16 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // per-tap LDS offsets (uniform)
-  const int lo0 = p.d.lo[0], lo1 = p.d.lo[1], lo2 = p.d.lo[2];
+  // Tap table in a VGPR: lane t holds tap t's box offset (bytes, multiple of 32) | h-offset parity (bit 4: the
+  // swizzle flips the 16-byte half).  The tap loop fetches it with v_readlane - no scalar loads (their lgkmcnt(0)
+  // would drain the LDS queue) and no memory at all inside the MFMA loop.
+  int tap_tab = 0;
+  for (int t = 0; t < nt; ++t) {
+    const nnz_conv_tap tp = p.d.taps[tb + t];
+    const int o0 = tp.off[0] - p.d.lo[0], o1 = tp.off[1] - p.d.lo[1], o2 = tp.off[2] - p.d.lo[2];
+    const int enc = (((o0 * bg.BH + o1) * bg.PW + o2) * 32) | ((o1 & 1) << 4);
+    tap_tab = lane == t ? enc : tap_tab;
+  }
 
   u32x4 breg[LPT_BOX];
   u32x4 wreg[C::LPT_W];
@@ -229,6 +236,22 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
       }
     }
   };
+  // fragments of tap t: A = weights (rows = cout), B = box window (voxels on the lanes)
+  auto load_frags = [&](int t, f16x8 (&a)[C::WN], f16x8 (&b)[C::WM]) {
+    const int enc = __builtin_amdgcn_readlane(tap_tab, t);
+    const int toff = enc & ~16, flip = enc & 16;
+#pragma unroll
+    for (int i = 0; i < C::WN; ++i)
+      a[i] = *reinterpret_cast<const f16x8*>(wl + (((wn * C::WN + i) * nt + t) << 10) + w_lane);
+#pragma unroll
+    for (int i = 0; i < C::WM; ++i) b[i] = *reinterpret_cast<const f16x8*>(box + ((vox_off[i] + toff) ^ flip));
+  };
+  auto mfma_all = [&](const f16x8 (&a)[C::WN], const f16x8 (&b)[C::WM]) {
+#pragma unroll
+    for (int i = 0; i < C::WN; ++i)
+#pragma unroll
+      for (int j = 0; j < C::WM; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+  };
 
   issue_loads(0);
   for (int kc = 0; kc < nkc; ++kc) {
@@ -237,23 +260,17 @@ __global__ __launch_bounds__(256) void conv_box_kernel(ConvDev p) {
     __syncthreads();
     if (kc + 1 < nkc) issue_loads(kc + 1);
 
-    for (int t = 0; t < nt; ++t) {
-      const nnz_conv_tap tp = p.d.taps[tb + t];
-      const int o0 = tp.off[0] - lo0, o1 = tp.off[1] - lo1, o2 = tp.off[2] - lo2;
-      const int toff = ((o0 * bg.BH + o1) * bg.PW + o2) * 32;
-      const int par = o1 & 1;
-      f16x8 a[C::WN], b[C::WM];
-#pragma unroll
-      for (int i = 0; i < C::WN; ++i)
-        a[i] = *reinterpret_cast<const f16x8*>(wl + (((wn * C::WN + i) * nt + t) << 10) + w_lane);
-#pragma unroll
-      for (int i = 0; i < C::WM; ++i)
-        b[i] = *reinterpret_cast<const f16x8*>(box + (par ? vox_off[1][i] : vox_off[0][i]) + toff);
-#pragma unroll
-      for (int i = 0; i < C::WN; ++i)
-#pragma unroll
-        for (int j = 0; j < C::WM; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    // software pipeline over the taps: the LDS reads of tap t+1 are in flight while tap t's MFMAs issue
+    f16x8 a0[C::WN], b0[C::WM], a1[C::WN], b1[C::WM];
+    load_frags(0, a0, b0);
+    int t = 0;
+    for (; t + 2 <= nt; t += 2) {
+      load_frags(t + 1, a1, b1);
+      mfma_all(a0, b0);
+      if (t + 2 < nt) load_frags(t + 2, a0, b0);
+      mfma_all(a1, b1);
     }
+    if (t < nt) mfma_all(a0, b0);
   }
 
   // ---- epilogue: D[row = cout][col = voxel]; lane holds couts (r&3) + 8(r>>2) + 4hh of its voxel -----
