@@ -58,4 +58,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
   return base + orig / nx;
 }
 
+// Pin a wave-uniform kernel argument in SGPRs.  LLVM treats kernarg loads as free to rematerialise and re-issues
+// s_load + s_waitcnt lgkmcnt(0) in front of every use inside hot loops (seen in conv_wgrad's prefetch: 14 scalar round
+// trips per tile); a v_readfirstlane result cannot be rematerialised from the kernarg segment.
+__device__ __forceinline__ int pin_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T* pin_uniform(T* ptr) {
+  const unsigned long long u = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 }  // namespace nnz

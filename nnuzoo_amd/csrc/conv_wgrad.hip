@@ -100,9 +100,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   const int b0 = (pair % p.pairs_b) * 32;
 
   const int T = p.d.ntaps_total;
-  const int Di = p.d.in_dims[0], Hi = p.d.in_dims[1], Wi = p.d.in_dims[2];
-  const int Do = p.d.out_dims[0], Ho = p.d.out_dims[1], Wo = p.d.out_dims[2];
-  const int tiles_per_n = p.tiles[0] * p.tiles[1] * p.tiles[2];
+  // everything the per-tile prefetch needs, pinned in SGPRs (see pin_uniform)
+  const int Di = pin_uniform(p.d.in_dims[0]), Hi = pin_uniform(p.d.in_dims[1]), Wi = pin_uniform(p.d.in_dims[2]);
+  const int Do = pin_uniform(p.d.out_dims[0]), Ho = pin_uniform(p.d.out_dims[1]), Wo = pin_uniform(p.d.out_dims[2]);
+  const int Dm = pin_uniform(p.d.m_dims[0]), Hm = pin_uniform(p.d.m_dims[1]), Wm = pin_uniform(p.d.m_dims[2]);
+  const int tiles1 = pin_uniform(p.tiles[1]), tiles2 = pin_uniform(p.tiles[2]);
+  const int tiles_per_n = pin_uniform(p.tiles[0] * p.tiles[1] * p.tiles[2]);
+  const int ldi = pin_uniform(p.d.ldi), ldo = pin_uniform(p.d.ldo);
+  const int lo0 = pin_uniform(p.d.lo[0]), lo1 = pin_uniform(p.d.lo[1]), lo2 = pin_uniform(p.d.lo[2]);
+  const int os0 = pin_uniform(p.d.out_stride[0]), os1 = pin_uniform(p.d.out_stride[1]),
+            os2 = pin_uniform(p.d.out_stride[2]);
+  const int oo0 = pin_uniform(p.d.groups[0].ooff[0]), oo1 = pin_uniform(p.d.groups[0].ooff[1]),
+            oo2 = pin_uniform(p.d.groups[0].ooff[2]);
+  const f16* Pp = pin_uniform(p.p) + a0;
+  const f16* Qp = pin_uniform(p.q) + b0;
+  const int ntiles = pin_uniform(p.ntiles), splits = pin_uniform(p.splits);
 
   // taps of this wave: wave, wave+4, ...  (MAXT = 7 for 27 taps, 2 for the 8 taps of the k2s2 transpose)
   int tap_off[MAXT];
@@ -135,12 +147,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   auto issue_loads = [&](int tile) {
     const int n = tile / tiles_per_n;
     int r = tile - n * tiles_per_n;
-    const int tw_i = r % p.tiles[2];
-    r /= p.tiles[2];
-    const int th_i = r % p.tiles[1];
-    const int td_i = r / p.tiles[1];
+    const int tw_i = r % tiles2;
+    r /= tiles2;
+    const int th_i = r % tiles1;
+    const int td_i = r / tiles1;
     const int m0d = td_i * TD, m0h = th_i * TH, m0w = tw_i * TW;
-    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = m0w * ISW + p.d.lo[2];
+    const int lod = m0d * ISD + lo0, loh = m0h * ISH + lo1, low = m0w * ISW + lo2;
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
@@ -153,8 +165,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         const int bd = s / (gBW * gBH);
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
-          v = *reinterpret_cast<const u32x4*>(p.p + ((size_t)((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + a0 +
-                                              part * 8);
+          v = *reinterpret_cast<const u32x4*>(Pp + ((size_t)((n * Di + id) * Hi + ih) * Wi + iw) * ldi + part * 8);
       }
       breg[i] = v;
     }
@@ -167,12 +178,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         const int s = c >> 2;
         const int tw = s % TW, th = (s / TW) % TH, td = s / (TW * TH);
         const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-        const int od = md * p.d.out_stride[0] + p.d.groups[0].ooff[0];
-        const int oh = mh * p.d.out_stride[1] + p.d.groups[0].ooff[1];
-        const int ow = mw * p.d.out_stride[2] + p.d.groups[0].ooff[2];
-        if (md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] && od < Do && oh < Ho && ow < Wo)
-          v = *reinterpret_cast<const u32x4*>(p.q + ((size_t)((n * Do + od) * Ho + oh) * Wo + ow) * p.d.ldo + b0 +
-                                              part * 8);
+        const int od = md * os0 + oo0;
+        const int oh = mh * os1 + oo1;
+        const int ow = mw * os2 + oo2;
+        if (md < Dm && mh < Hm && mw < Wm && od < Do && oh < Ho && ow < Wo)
+          v = *reinterpret_cast<const u32x4*>(Qp + ((size_t)((n * Do + od) * Ho + oh) * Wo + ow) * ldo + part * 8);
       }
       qreg[i] = v;
     }
@@ -191,12 +201,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   };
 
   int tile = split;
-  if (tile < p.ntiles) issue_loads(tile);
-  for (; tile < p.ntiles; tile += p.splits) {
+  if (tile < ntiles) issue_loads(tile);
+  for (; tile < ntiles; tile += splits) {
     __syncthreads();
     write_lds();
     __syncthreads();
-    if (tile + p.splits < p.ntiles) issue_loads(tile + p.splits);
+    if (tile + splits < ntiles) issue_loads(tile + splits);
 
     for (int kb = 0; kb < C::KB; ++kb) {
       // voxel of (kb, kk = 8*hh + 4*s + qrow): two h-rows of 8 w per k-block
@@ -260,10 +270,25 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, bool pre_zeroed
   p.ntiles = p.d.N * p.tiles[0] * p.tiles[1] * p.tiles[2];
   p.pairs_b = p.d.Cout / 32;
   const int pairs = (p.d.Cin / 32) * p.pairs_b;
-  int splits = 1024 / pairs;
-  if (splits < 1) splits = 1;
-  if (splits > p.ntiles) splits = p.ntiles;
-  p.splits = splits;
+  // Split choice by a two-term cost model (measured, round 1): a workgroup spends ~4 us per 4x8x8x27-tap tile when two
+  // workgroups share a CU (512 resident chip-wide), and the final fp32 atomic flush of its [T][32][32] block moves
+  // T*4 KiB at ~1.1 TB/s chip-wide.  More splits = fewer tiles each but more flush traffic: 1024 workgroups made the
+  // 128..320-channel layers flush-bound (113 MB of atomics for a 30 us contraction).
+  int best = 1;
+  double best_cost = 1e30;
+  const double t_tile = 4.0 * (C::KB / 16.0) * (MAXT / 7.0);
+  const double t_flush = p.d.ntaps_total * 4096.0 / 1.1e6;
+  for (int s = 1; s <= p.ntiles && (long)s * pairs <= 4096; s *= 2) {
+    const long wgs = (long)s * pairs;
+    const double rounds = (double)((wgs + 511) / 512);
+    const double cost = rounds * ((p.ntiles + s - 1) / s) * t_tile + wgs * t_flush;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = s;
+    }
+  }
+  p.splits = best;
+  const int splits = best;
   auto kern = conv_wgrad_kernel<TD, TH, TW, LPT_BOX, MAXT, G>;
   static int attr_lds = 0;
   if (lds > attr_lds) {
