@@ -38,6 +38,11 @@ int nnz_version(void);
  * and driven by nnUNetTrainer.train_step (nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1112-1144). */
 int nnz_conv_tap_forward(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
                          const nnz_conv_desc* desc, void* stream);
+/* same, and adds the per-(n, cout) {sum, sumsq} of the fp16 outputs into stats[N][Cout][2] (pre-zeroed by the caller):
+ * the InstanceNorm statistics pass (nnz_instnorm_stats) fused into the convolution's epilogue.  Plain forward
+ * convolutions only (one tap group, unit output stride, no accumulate); stats == NULL is nnz_conv_tap_forward. */
+int nnz_conv_tap_forward_stats(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
+                               const nnz_conv_desc* desc, float* stats, void* stream);
 int nnz_conv_tap_wgrad(const void* boxed_f16, const void* plain_f16, float* dw /* [T][A][B] */,
                        const nnz_conv_desc* desc, int dw_pre_zeroed, void* stream);
 int nnz_pack_conv_weight(const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
@@ -75,7 +80,9 @@ int nnz_instnorm_lrelu_bwd_reduce(const void* x_f16, const void* g_f16, const fl
                                   int ldg, float eps, float slope, int red_pre_zeroed, void* stream);
 int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const float* stats, const float* red,
                                  const float* gamma, const float* beta, void* dx_f16, int N, long V, int C, int ldx,
-                                 int ldg, int lddx, float eps, float slope, void* stream);
+                                 int ldg, int lddx, float eps, float slope,
+                                 float* dgamma /* [C] = sum_n red[n][c][1], may be NULL */,
+                                 float* dbeta /* [C] = sum_n red[n][c][0], NULL iff dgamma is */, void* stream);
 
 /* ---- fused soft-Dice + cross-entropy statistics on NC(D)HW logits --------------------------------------------
  * replaces softmax + one-hot + reductions + CE of DC_and_CE_loss (nnunetv2/training/loss/compound_losses.py:31-56,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "nnz_version": [],
     "nnz_device_info": [C.c_char_p, _i, _ip, C.POINTER(C.c_long)],
     "nnz_conv_tap_forward": [_vp, _vp, _vp, _fp, _dp, _vp],
+    "nnz_conv_tap_forward_stats": [_vp, _vp, _vp, _fp, _dp, _fp, _vp],
     "nnz_conv_tap_wgrad": [_vp, _vp, _fp, _dp, _i, _vp],
     "nnz_pack_conv_weight": [_fp, _vp, _i, _i, _i, _l, _l, _l, _ip, _vp],
     "nnz_pack_job_bytes": [],
@@ -76,7 +77,7 @@ SIGNATURES = {
     "nnz_instnorm_stats": [_vp, _fp, _i, _l, _i, _i, _i, _vp],
     "nnz_instnorm_lrelu_apply": [_vp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _f, _f, _vp],
     "nnz_instnorm_lrelu_bwd_reduce": [_vp, _vp, _fp, _fp, _fp, _fp, _i, _l, _i, _i, _i, _f, _f, _i, _vp],
-    "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _vp],
+    "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _fp, _fp, _vp],
     "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _vp],
     "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _vp],
     "nnz_window_attention_forward": [_fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],

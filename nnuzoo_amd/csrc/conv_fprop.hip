@@ -41,6 +41,7 @@ struct ConvDev {
   f16* out;
   const f16* w;
   const float* bias;
+  float* stats;  // optional [N][Cout][2] {sum, sumsq} of the fp16 outputs (InstanceNorm statistics), pre-zeroed
   nnz_conv_desc d;
   int tiles[3];
   int gx, gy, gz;
@@ -300,6 +301,41 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   __syncthreads();
   constexpr int PPV = NB * 4;  // 16-byte pieces per voxel
   constexpr int NPIECE = TD * TH * TW * PPV;
+  if (p.stats) {
+    // InstanceNorm statistics of this tile from the fp16 image (what the normalisation will read): a thread sums 8
+    // channels over its share of the voxels, a [parts][2*NC] slab behind the image folds the shares, one atomic per
+    // (tile, channel, moment).  Saves the separate read of the whole conv output.
+    constexpr int NC = NB * 32, NVOX = TD * TH * TW;
+    constexpr int PARTS = 256 / PPV;
+    float* slab = reinterpret_cast<float*>(smem + NVOX * ROWB);
+    const int part = tid / PPV, c8 = tid % PPV;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    for (int v = part; v < NVOX; v += PARTS) {
+      const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+      if (m0d + td < p.d.m_dims[0] && m0h + th < p.d.m_dims[1] && m0w + tw < p.d.m_dims[2]) {
+        const f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + c8 * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (float)val[e];
+          s1[e] += x;
+          s2[e] += x * x;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      slab[part * (2 * NC) + (c8 * 8 + e) * 2 + 0] = s1[e];
+      slab[part * (2 * NC) + (c8 * 8 + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    if (tid < 2 * NC) {
+      float t = 0.f;
+      for (int q = 0; q < PARTS; ++q) t += slab[q * (2 * NC) + tid];
+      atomicAdd(p.stats + ((size_t)n * Cout + cb0 * 32) * 2 + tid, t);
+    }
+  }
 #pragma unroll 2
   for (int c = tid; c < NPIECE; c += 256) {
     const int v = c / PPV, part = c % PPV;
@@ -333,7 +369,11 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   int maxnt = 1;  // weights region: all taps of the largest group, one 16-channel slice
   for (int g = 0; g < p.d.ngroups; ++g) maxnt = p.d.groups[g].ntaps > maxnt ? p.d.groups[g].ntaps : maxnt;
   const int wbytes = NB * maxnt * 1024;
-  const int lds = bg.BOX_BYTES + wbytes > C::OUT_BYTES ? bg.BOX_BYTES + wbytes : C::OUT_BYTES;
+  int lds = bg.BOX_BYTES + wbytes > C::OUT_BYTES ? bg.BOX_BYTES + wbytes : C::OUT_BYTES;
+  if (p.stats) {  // statistics slab [256 / (4 NB)][2 * 32 NB] floats behind the output image
+    const int need = C::OUT_BYTES + (256 / (NB * 4)) * (2 * NB * 32) * 4;
+    lds = lds > need ? lds : need;
+  }
   if (lds > 160 * 1024) return NNZ_EINVAL;
   p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
   p.tiles[1] = (p.d.m_dims[1] + TH - 1) / TH;
@@ -418,11 +458,22 @@ static int launch_dyn(const ConvDev& p, hipStream_t stream) {
 
 }  // namespace nnz
 
+extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void* w_packed, const float* bias,
+                                          const nnz_conv_desc* desc, float* stats, void* stream);
+
 extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_packed, const float* bias,
                                     const nnz_conv_desc* desc, void* stream) {
+  return nnz_conv_tap_forward_stats(in, out, w_packed, bias, desc, nullptr, stream);
+}
+
+extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void* w_packed, const float* bias,
+                                          const nnz_conv_desc* desc, float* stats, void* stream) {
   using namespace nnz;
   if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
+  // fused statistics: plain forward convolutions only (one group, output written once, unit output stride)
+  if (stats && (d.ngroups != 1 || d.accumulate || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1))
+    return NNZ_EINVAL;
   if (d.Cin % 32 || d.Cout % 32 || d.ngroups < 1 || d.ngroups > NNZ_MAX_GROUPS || d.ntaps_total > NNZ_MAX_TAPS ||
       d.ldi % 8 || d.ldo % 8)
     return NNZ_EINVAL;
@@ -437,6 +488,7 @@ extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_pac
   p.out = (f16*)out;
   p.w = (const f16*)w_packed;
   p.bias = bias;
+  p.stats = stats;
   p.d = d;
   hipStream_t s = (hipStream_t)stream;
   const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&

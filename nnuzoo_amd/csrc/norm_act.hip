@@ -21,6 +21,8 @@ struct NormArgs {
   float* red;        // [N][C][2] {sum g', sum g' xhat} (bwd)
   const float* gamma;
   const float* beta;
+  float* dgamma;     // optional outputs of bwd apply: sum over n of red[n][c][1] / red[n][c][0]
+  float* dbeta;
   int N, C, ldx, ldg, ldy;
   long V;
   int vpb;           // voxels per block
@@ -59,6 +61,20 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
   long v1 = v0 + a.vpb;
   if (v1 > a.V) v1 = a.V;
   const bool active = r < rows;
+
+  if (MODE == 3 && a.dgamma && blockIdx.x == 0 && blockIdx.y == 0) {
+    // parameter gradients of the affine: one workgroup folds the per-sample reductions (saves a torch reduction and
+    // two copies per conv block)
+    for (int c = tid; c < a.C; c += 256) {
+      float sg = 0.f, sb = 0.f;
+      for (int nn = 0; nn < a.N; ++nn) {
+        sb += a.red[((long)nn * a.C + c) * 2 + 0];
+        sg += a.red[((long)nn * a.C + c) * 2 + 1];
+      }
+      a.dgamma[c] = sg;
+      a.dbeta[c] = sb;
+    }
+  }
 
   float scale[8], shift[8], mean[8], rstd[8], m1[8], m2[8];
   if (MODE != 0 && active) {
@@ -219,15 +235,17 @@ extern "C" int nnz_instnorm_lrelu_bwd_reduce(const void* x, const void* g, const
 
 extern "C" int nnz_instnorm_lrelu_bwd_apply(const void* x, const void* g, const float* stats, const float* red,
                                             const float* gamma, const float* beta, void* dx, int N, long V, int C,
-                                            int ldx, int ldg, int lddx, float eps, float slope, void* stream) {
+                                            int ldx, int ldg, int lddx, float eps, float slope, float* dgamma,
+                                            float* dbeta, void* stream) {
   using namespace nnz;
-  if (!x || !g || !stats || !red || !gamma || !beta || !dx) return NNZ_EINVAL;
+  if (!x || !g || !stats || !red || !gamma || !beta || !dx || (!dgamma != !dbeta)) return NNZ_EINVAL;
   NormArgs a = {};
   a.x = (const f16*)x; a.g = (const f16*)g;
   a.stats = const_cast<float*>(stats);
   a.red = const_cast<float*>(red);
   a.gamma = gamma; a.beta = beta;
   a.y = (f16*)dx;
+  a.dgamma = dgamma; a.dbeta = dbeta;
   a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldg = ldg; a.ldy = lddx;
   a.eps = eps; a.slope = slope;
   return launch_norm<3>(a, (hipStream_t)stream);

@@ -84,11 +84,14 @@ def pack_weight(param: torch.Tensor, pt: PreparedTable, R: int, Cc: int, sr: int
 
 
 def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
-                     out: torch.Tensor) -> None:
+                     out: torch.Tensor, stats: Optional[torch.Tensor] = None) -> None:
+    """stats: optional pre-zeroed fp32 [N, Cout, 2]; the kernel adds {sum, sumsq} of its fp16 outputs (fused
+    InstanceNorm statistics)"""
     _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
+    _f32(stats, "conv.stats")
     TIMER.wrap("conv_box_kernel", pt.flops,
-               lambda: call("nnz_conv_tap_forward", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
-                            stream_ptr()))
+               lambda: call("nnz_conv_tap_forward_stats", ptr(x), ptr(out), ptr(w_packed), ptr(bias),
+                            C.byref(pt.desc), ptr(stats), stream_ptr()))
 
 
 def conv_tap_wgrad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, dw: torch.Tensor,
@@ -172,12 +175,13 @@ def instnorm_lrelu_apply(x, stats, gamma, beta, y, N, V, Cc, ldx, ldy, eps, slop
 
 
 def instnorm_lrelu_bwd(x, g, stats, gamma, beta, red, dx, N, V, Cc, ldx, ldg, lddx, eps, slope,
-                       pre_zeroed: bool = False):
+                       pre_zeroed: bool = False, dgamma=None, dbeta=None):
     _f16(x, "in.x"); _f16(g, "in.g"); _f16(dx, "in.dx"); _f32(stats, "in.stats"); _f32(red, "in.red")
+    _f32(dgamma, "in.dgamma"); _f32(dbeta, "in.dbeta")
     call("nnz_instnorm_lrelu_bwd_reduce", ptr(x), ptr(g), ptr(stats), ptr(gamma), ptr(beta), ptr(red), N, V, Cc,
          ldx, ldg, eps, slope, int(pre_zeroed), stream_ptr())
     call("nnz_instnorm_lrelu_bwd_apply", ptr(x), ptr(g), ptr(stats), ptr(red), ptr(gamma), ptr(beta), ptr(dx), N, V,
-         Cc, ldx, ldg, lddx, eps, slope, stream_ptr())
+         Cc, ldx, ldg, lddx, eps, slope, ptr(dgamma), ptr(dbeta), stream_ptr())
 
 
 def _logits_kind(t: torch.Tensor) -> int:

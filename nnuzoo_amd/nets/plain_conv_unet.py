@@ -419,11 +419,11 @@ class PlainConvUNet(nn.Module):
         stats = stats_all[b.stats_off:b.stats_off + b.N * b.cout * 2].view(b.N, b.cout, 2)  # zeroed once per step
         if b.stem:
             ops.stem_forward(x_act, h.conv.weight, h.conv.bias, raw, (b.N, *b.in_dims), b.cout)
-        elif b.padded:
-            ops.conv_tap_forward(b.fwd, self._padded_input(b, x_act), b.wp_fwd, h.conv.bias, raw)
+            ops.instnorm_stats(raw, stats, b.N, b.V, b.cout, b.cout, pre_zeroed=True)
         else:
-            ops.conv_tap_forward(b.fwd, x_act, b.wp_fwd, h.conv.bias, raw)
-        ops.instnorm_stats(raw, stats, b.N, b.V, b.cout, b.cout, pre_zeroed=True)
+            # the convolution's epilogue accumulates the InstanceNorm statistics of the tile it just produced
+            ops.conv_tap_forward(b.fwd, self._padded_input(b, x_act) if b.padded else x_act, b.wp_fwd, h.conv.bias,
+                                 raw, stats=stats)
         ops.instnorm_lrelu_apply(raw, stats, h.norm.weight, h.norm.bias, act_out, b.N, b.V, b.cout, b.cout, b.y_ld,
                                  b.eps, b.slope)
         return raw, stats
@@ -501,12 +501,9 @@ class PlainConvUNet(nn.Module):
         h = b.h
         red = self._red_all[b.stats_off:b.stats_off + b.N * b.cout * 2].view(b.N, b.cout, 2)  # zeroed once per step
         draw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
-        ops.instnorm_lrelu_bwd(raw, g_act, stats, h.norm.weight, h.norm.bias, red, draw, b.N, b.V, b.cout, b.cout, g_ld,
-                               b.cout, b.eps, b.slope, pre_zeroed=True)
-        rs = red.sum(0)
         gnw, gnb = self._galloc(h.norm.weight), self._galloc(h.norm.bias)
-        gnw.copy_(rs[:, 1])
-        gnb.copy_(rs[:, 0])
+        ops.instnorm_lrelu_bwd(raw, g_act, stats, h.norm.weight, h.norm.bias, red, draw, b.N, b.V, b.cout, b.cout, g_ld,
+                               b.cout, b.eps, b.slope, pre_zeroed=True, dgamma=gnw, dbeta=gnb)
         grads[h.norm.weight], grads[h.norm.bias] = gnw, gnb
         # the bias of a conv followed by InstanceNorm has an identically zero gradient (mean removal)
         grads[h.conv.bias] = self._galloc(h.conv.bias)  # arena is zero-initialised

@@ -66,6 +66,15 @@ def test_conv_forward(hip_lib, N, dims, cin, cout, stride):
     ops.conv_tap_forward(pt, to_cl(x), wp, b.to(DEV), out)
     torch.cuda.synchronize()
     close(from_cl(out, odims), ref)
+    # fused InstanceNorm statistics: {sum, sumsq} of exactly the fp16 values that were stored, added onto the buffer
+    out2 = torch.empty_like(out)
+    stats = torch.full((N, cout, 2), 3.0, dtype=torch.float32, device=DEV)
+    ops.conv_tap_forward(pt, to_cl(x), wp, b.to(DEV), out2, stats=stats)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    o64 = out.double().cpu()
+    exp = torch.stack([o64.sum(1), (o64 * o64).sum(1)], dim=-1) + 3.0
+    close(stats.cpu().double(), exp, rtol=1e-4, atol_frac=1e-5)
 
 
 def test_conv_forward_strided_channels(hip_lib):
@@ -197,6 +206,16 @@ def test_instnorm_lrelu(hip_lib, N, dims, C, ldy):
     rs = red.sum(0).cpu()
     close(rs[:, 1], gamma.grad, rtol=2e-3, atol_frac=1e-3)
     close(rs[:, 0], beta.grad, rtol=2e-3, atol_frac=1e-3)
+    # the apply kernel can fold the per-sample reductions into the affine's parameter gradients itself
+    dg, db = torch.full((C,), 9.0, device=DEV), torch.full((C,), 9.0, device=DEV)
+    red2 = torch.empty_like(red)
+    dx2 = torch.empty_like(dx)
+    ops.instnorm_lrelu_bwd(xr, gbuf[:, :, ldy - C:], stats, gamma.detach().to(DEV), beta.detach().to(DEV), red2, dx2, N,
+                           V, C, C, ldy, C, 1e-5, 0.01, dgamma=dg, dbeta=db)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    close(dg.cpu(), gamma.grad, rtol=2e-3, atol_frac=1e-3)
+    close(db.cpu(), beta.grad, rtol=2e-3, atol_frac=1e-3)
 
 
 @pytest.mark.parametrize("N,dims", [(2, (8, 8, 8)), (1, (6, 12, 20))])
