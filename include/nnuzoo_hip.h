@@ -84,6 +84,21 @@ int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const flo
                                  float* dgamma /* [C] = sum_n red[n][c][1], may be NULL */,
                                  float* dbeta /* [C] = sum_n red[n][c][0], NULL iff dgamma is */, void* stream);
 
+/* ---- sliding-window inference accumulation ---------------------------------------------------------------------
+ * replaces the tensor arithmetic of nnUNetPredictor._internal_maybe_mirror_and_predict
+ * (nnunetv2/inference/predict_from_raw_data.py:549-564: `prediction += torch.flip(...)`, `prediction /= n`) and of
+ * _internal_predict_sliding_window_return_logits (:566-643: `prediction *= gaussian`, `predicted_logits[sl] +=`,
+ * `n_predictions[sl[1:]] += gaussian`, `predicted_logits /= n_predictions`, isinf check) on half tensors, rounding to
+ * fp16 at the same points (bit-identical to the reference loop for equal network outputs).
+ * preds [M][K][td][th][tw]: the network outputs for the tile and its mirrored copies (flip_bits[m]: bit a = the input of
+ * prediction m was flipped along volume axis a; flip_bits[0] must be 0), in the reference's accumulation order;
+ * tile_dims / image_dims / offset are host int[3] (2-D tiles: depth 1); gaussian may be NULL (weight 1). */
+int nnz_sliding_window_accumulate(const void* preds_f16, int M, const int* flip_bits, const void* gaussian_f16,
+                                  void* logits_f16 /* [K][D][H][W] */, void* npred_f16 /* [D][H][W] */, int K,
+                                  const int* tile_dims, const int* image_dims, const int* offset, void* stream);
+int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, long V, int* inf_flag_device,
+                                void* stream);
+
 /* ---- fused soft-Dice + cross-entropy statistics on NC(D)HW logits --------------------------------------------
  * replaces softmax + one-hot + reductions + CE of DC_and_CE_loss (nnunetv2/training/loss/compound_losses.py:31-56,
  * dice.py:72-119, robust_ce_loss.py:12-16).  sums[b] = {intersect[C], sum_pred[C], sum_gt[C], ce_sum};

@@ -20,6 +20,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffast-math", "
          "-Wno-unused-result"]
 
 
+# Files whose results must be bit-identical to IEEE half/float arithmetic (exact division, denormals kept): no fast-math.
+STRICT_FP = {"sliding_window.hip"}
+
+
+def _flags(src: str):
+    if src in STRICT_FP:
+        return [f for f in FLAGS if f not in ("-ffast-math", "-fno-finite-math-only")] + \
+            ["-fno-fast-math", "-fno-gpu-flush-denormals-to-zero"]
+    return FLAGS
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -30,7 +41,7 @@ def _digest(path: str) -> str:
         if dep.endswith((".hpp", ".h")) or dep == os.path.basename(path):
             with open(os.path.join(CSRC, dep), "rb") as f:
                 h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(_flags(os.path.basename(path))).encode())
     return h.hexdigest()
 
 
@@ -41,7 +52,7 @@ def _compile(src: str) -> str:
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
+    cmd = [HIPCC, *_flags(src), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -170,13 +170,17 @@ class nnUNetPredictor(object):
 
     def _accumulate(self, preds: torch.Tensor, combos, gaussian: Optional[torch.Tensor], logits: torch.Tensor,
                     npred: torch.Tensor, origin: Sequence[int]):
-        """preds [M, K, *tile] fp16 (M = len(combos)); logits [K, *image], npred [*image] fp16; origin = tile offset"""
+        """preds [M, K, *tile] fp16 (M = len(combos)); logits [K, *image], npred [*image] fp16, contiguous.
+        origin has one entry per image axis; a 2-D tile inside a 3-D image is a depth-1 tile at origin (d, y, x)."""
         nsp = preds.dim() - 2
         if len(combos) > 8:
             raise ValueError("at most 3 mirror axes")
+        image = tuple(logits.shape[1:])
+        image = (1,) * (3 - len(image)) + image
         tile = (1,) * (3 - nsp) + tuple(preds.shape[2:])
-        image = (1,) * (3 - nsp) + tuple(logits.shape[1:])
-        off = (0,) * (3 - nsp) + tuple(int(o) for o in origin)
+        off = tuple(int(o) for o in origin)
+        off = (0,) * (3 - len(off)) + off
+        assert logits.is_contiguous() and npred.is_contiguous() and preds.is_contiguous()
         call("nnz_sliding_window_accumulate", ptr(preds), len(combos), self._flip_bits(combos, nsp), ptr(gaussian),
              ptr(logits), ptr(npred), int(preds.shape[1]), _int3(tile), _int3(image), _int3(off), stream_ptr())
 
@@ -203,23 +207,9 @@ class nnUNetPredictor(object):
             out = self._forward_logits(torch.cat(tiles).float())  # [len(group) * M, K, *tile]
             M = len(combos)
             for j, sl in enumerate(group):
-                # a 2-D network on a 3-D image addresses slice d of the volume: the tile's depth origin is d
-                spatial = [s for s in sl[1:]]
-                origin, lg, npd = [], predicted_logits, n_predictions
-                if len(spatial) > nsp:  # (d, slice, slice)
-                    d = spatial[0]
-                    lg, npd = predicted_logits[:, d], n_predictions[d]
-                    if not (lg.is_contiguous() or K == 1):
-                        # logits[:, d] is K strided planes: accumulate plane by plane
-                        for k in range(K):
-                            raise_if = None  # (kept simple: handled by the generic path below)
-                    spatial = spatial[1:]
-                origin = [s.start for s in spatial]
-                if lg.is_contiguous():
-                    self._accumulate(out[j * M:(j + 1) * M], combos, gaussian, lg, npd, origin)
-                else:
-                    self._accumulate_planes(out[j * M:(j + 1) * M], combos, gaussian, predicted_logits, n_predictions,
-                                            sl[1], origin)
+                # origin per image axis; a 2-D network on a 3-D image addresses slice d: depth-1 tile at (d, y, x)
+                origin = [s_.start if isinstance(s_, slice) else int(s_) for s_ in sl[1:]]
+                self._accumulate(out[j * M:(j + 1) * M], combos, gaussian, predicted_logits, n_predictions, origin)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         V = int(np.prod(data.shape[1:]))
         call("nnz_sliding_window_finalize", ptr(predicted_logits), ptr(n_predictions), K, V, ptr(flag), stream_ptr())
@@ -228,16 +218,6 @@ class nnUNetPredictor(object):
                                'reduce value_scaling_factor in compute_gaussian or increase the dtype of '
                                'predicted_logits to fp32')
         return predicted_logits
-
-    def _accumulate_planes(self, preds, combos, gaussian, logits, npred, d: int, origin):
-        """2-D network on a 3-D image: the K logit planes of depth d are not contiguous in [K, D, H, W]; the volume
-        view (tile depth 1 at depth offset d) addresses them without copies."""
-        nsp = 2
-        tile = (1, *preds.shape[2:])
-        image = tuple(logits.shape[1:])
-        off = (int(d), int(origin[0]), int(origin[1]))
-        call("nnz_sliding_window_accumulate", ptr(preds), len(combos), self._flip_bits(combos, nsp), ptr(gaussian),
-             ptr(logits), ptr(npred), int(preds.shape[1]), _int3(tile), _int3(image), _int3(off), stream_ptr())
 
     # ---- :645-692 ------------------------------------------------------------------------------------------------
     @torch.inference_mode()

@@ -25,3 +25,18 @@ def det_fill(module, skip=("A_logs", "Ds", "relative_position_index")):
                 b.copy_(0.02 * torch.cos(torch.arange(b.numel(), dtype=torch.float32) + k))
             elif name.endswith("running_var"):
                 b.copy_(1.0 + 0.1 * torch.cos(torch.arange(b.numel(), dtype=torch.float32) * 0.3 + k) ** 2)
+
+
+def toy_seg_network(x: torch.Tensor) -> torch.Tensor:
+    """Stand-in "network" of the sliding-window fixtures: (B, 1, *spatial) -> fp16 logits (B, 2, *spatial).
+    Position dependent and NOT mirror symmetric (rolls), built from operations that are exact in fp32 on inputs that
+    are multiples of 1/8 (|x| <= 4) so that CPU and GPU produce bit-identical half outputs."""
+    v = x[:, 0].float()
+    l0 = v + 0.5 * torch.roll(v, 1, dims=-1)
+    l1 = 0.25 * v - torch.roll(v, 1, dims=-2) + 1.0
+    return torch.stack([l0, l1], dim=1).to(torch.float16)
+
+
+def toy_image(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(-32, 33, (1, *shape), generator=g).float() / 8

@@ -181,9 +181,70 @@ def gen_nets():
         json.dump({k: [[n, list(s)] for n, s in v] for k, v in man.items()}, f)
 
 
+def gen_sliding_window():
+    """Reference tile geometry, importance maps and the reference's own accumulation loop on CPU half tensors
+    (nnUNetPredictor._internal_predict_sliding_window_return_logits with do_on_device=False) around a toy network
+    whose outputs are bit-reproducible (tests/golden_util.toy_seg_network)."""
+    import types
+    from nnunetv2.inference.sliding_window_prediction import compute_gaussian, compute_steps_for_sliding_window
+    from nnunetv2.inference.predict_from_raw_data import nnUNetPredictor
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from golden_util import toy_image, toy_seg_network
+    out = {}
+    step_cases = [((110,), (64,), 0.5), ((128, 128, 128), (128, 128, 128), 0.5), ((300, 257, 140), (128, 128, 96), 0.5),
+                  ((77, 512), (64, 128), 0.25), ((65, 64, 200), (64, 64, 64), 1.0), ((512, 512), (512, 512), 0.5),
+                  ((193, 130), (64, 96), 0.75)]
+    for i, (img, tile, st) in enumerate(step_cases):
+        steps = compute_steps_for_sliding_window(img, tile, st)
+        out[f"steps{i}_args"] = np.array(list(img) + list(tile) + [st], dtype=np.float64)
+        for a, s_ in enumerate(steps):
+            out[f"steps{i}_axis{a}"] = np.array(s_, dtype=np.int64)
+    out["n_step_cases"] = np.array(len(step_cases))
+    for i, tile in enumerate([(16, 24, 20), (32, 48), (128, 128, 128)]):
+        g = compute_gaussian(tuple(tile), sigma_scale=1. / 8, value_scaling_factor=10, device=torch.device("cpu"))
+        if i < 2:
+            out[f"gauss{i}"] = g.numpy()
+        else:  # 4 MB as fp16: keep a strided sample + checksums
+            out[f"gauss{i}_sample"] = g[::9, ::7, ::5].numpy()
+            out[f"gauss{i}_sum_min_max"] = np.array([float(g.double().sum()), float(g.min()), float(g.max())])
+        out[f"gauss{i}_tile"] = np.array(tile)
+
+    class _Net(torch.nn.Module):
+        def forward(self, x):
+            return toy_seg_network(x)
+
+    run_cases = [
+        # image (c, *dims), patch, step, gaussian, mirroring axes
+        ("3d_mirror", (20, 29, 27), (16, 16, 16), 0.5, True, (0, 1, 2)),
+        ("3d_plain", (17, 16, 40), (16, 16, 16), 0.5, False, None),
+        ("2d_on_3d", (3, 40, 37), (32, 24), 0.5, True, (0, 1)),
+        ("3d_mirror2", (24, 16, 16), (16, 16, 16), 0.25, True, (0, 2)),
+    ]
+    for name, dims, patch, st, gauss, mirror in run_cases:
+        pr = nnUNetPredictor(tile_step_size=st, use_gaussian=gauss, use_mirroring=mirror is not None,
+                             perform_everything_on_device=False, device=torch.device("cpu"), verbose=False,
+                             allow_tqdm=False)
+        pr.network = _Net()
+        pr.configuration_manager = types.SimpleNamespace(patch_size=list(patch))
+        pr.label_manager = types.SimpleNamespace(num_segmentation_heads=2)
+        pr.allowed_mirroring_axes = mirror
+        data = toy_image(dims, seed=len(name))
+        slicers = pr._internal_get_sliding_window_slicers(data.shape[1:])
+        with torch.no_grad():
+            logits = pr._internal_predict_sliding_window_return_logits(data, slicers, False)
+        assert logits.dtype == torch.float16
+        out[f"run_{name}_logits"] = logits.numpy()
+        out[f"run_{name}_cfg"] = np.array(list(dims) + list(patch) + [st, float(gauss), len(name)], dtype=np.float64)
+        out[f"run_{name}_mirror"] = np.array(mirror if mirror is not None else [], dtype=np.int64)
+        out[f"run_{name}_nslicers"] = np.array(len(slicers))
+    np.savez_compressed(os.path.join(OUT, "sliding_window.npz"), **out)
+
+
 if __name__ == "__main__":
     ref = ref_shim.install()
-    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets"]
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw"]
+    if "sw" in which:
+        gen_sliding_window()
     if "scan" in which:
         gen_selective_scan(ref)
     if "loss" in which:

@@ -10,6 +10,7 @@ Substitutions (arithmetic that is actually replaced):
   mamba_ssm selective_scan_fn     -> the reference's own selective_scan_ref
                                      (nnunetv2/nets/seg_mamba/selective_scan_interface.py:86-152, extracted by ast)
   dynamic_network_architectures init_last_bn_before_add_to_0 -> no-op (no residual-BN blocks in these nets)
+  batchgenerators ...file_and_folder_operations (star-imported) -> typing names + os.path helpers only
 Everything else that is missing becomes a MagicMock module (never executed on the fixture paths).
 """
 import ast
@@ -130,4 +131,14 @@ def install():
     wi.init_last_bn_before_add_to_0 = lambda m: None
     import mamba_ssm.ops.selective_scan_interface as ssi
     ssi.selective_scan_fn = load_selective_scan_ref()
+    # `from batchgenerators.utilities.file_and_folder_operations import *` is how several reference modules obtain the
+    # typing names and os.path helpers: give the mocked module a real namespace for the star import
+    import os
+    import typing
+    import batchgenerators.utilities.file_and_folder_operations as ffo
+    names = {n: getattr(typing, n) for n in ("List", "Tuple", "Union", "Optional", "Dict", "Callable", "Iterable")}
+    names.update(join=os.path.join, isdir=os.path.isdir, isfile=os.path.isfile, os=os)
+    for k, v in names.items():
+        setattr(ffo, k, v)
+    ffo.__all__ = list(names)
     return ssi.selective_scan_fn
