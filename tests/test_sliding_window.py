@@ -160,3 +160,46 @@ def test_accumulate_kernel_random_halves(hip_lib):
         npred[sl] += gauss
     torch.cuda.synchronize()
     assert torch.equal(d_logits.cpu(), logits) and torch.equal(d_npred.cpu(), npred)
+
+
+@pytest.mark.gpu
+def test_predictor_with_hip_network_matches_oracle_loop(hip_lib):
+    """the real hot path as the tile network: nnuzoo_amd.PlainConvUNet (HIP schedule) under the predictor (mirror
+    variants batched into one forward) against the oracle loop calling the same network tile by tile.  The network's
+    InstanceNorm statistics are summed with fp32 atomics, so logits agree to fp16 rounding, not bit for bit."""
+    from oracle.plain_conv_unet import planner_arch_kwargs
+    from nnuzoo_amd.inference.predict_from_raw_data import nnUNetPredictor
+    from nnuzoo_amd.nets.plain_conv_unet import PlainConvUNet
+    from nnuzoo_amd.utilities.network_initialization import InitWeights_He
+    torch.manual_seed(0)
+    net = PlainConvUNet(1, num_classes=3, **planner_arch_kwargs(3, 3, [32, 64, 128], deep_supervision=False))
+    net.apply(InitWeights_He(1e-2))
+    net = net.cuda().eval()
+    patch, mirror = (16, 32, 32), (0, 1, 2)
+    pr = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=True, device=torch.device("cuda"),
+                         allow_tqdm=False)
+    pr.manual_initialization(net, None, types.SimpleNamespace(patch_size=list(patch)), None, {}, "nnUNetTrainer", mirror,
+                             label_manager=types.SimpleNamespace(num_segmentation_heads=3))
+    data = torch.randn(1, 20, 40, 36, generator=torch.Generator().manual_seed(1))
+    out = pr.predict_sliding_window_return_logits(data)
+    assert out.shape == (3, 20, 40, 36)
+
+    def tile_net(x):
+        with torch.no_grad():
+            return net(x.cuda()).cpu()
+
+    g = compute_gaussian(patch, sigma_scale=1. / 8, value_scaling_factor=10, device=torch.device("cpu"))
+    ref = osw.predict_sliding_window(tile_net, data, _slicers(data.shape[1:], patch, 0.5), 3, g, mirror)
+    o, r = out.float().cpu(), ref.float()
+    # Where the summed importance weight is in fp16's subnormal range (image corners: only the far tail of one tile's
+    # gaussian) the reference's half accumulators hold 1-3 significant bits, so two network outputs that differ by
+    # one fp16 ulp give visibly different quotients - in the reference as here.  Compare where the weight is normal.
+    wsum = torch.zeros(data.shape[1:])
+    for sl in _slicers(data.shape[1:], patch, 0.5):
+        wsum[sl[1:]] += g.float()
+    ok = (wsum > 1e-3)[None].expand_as(o)
+    assert ok.float().mean().item() > 0.7, ok.float().mean().item()
+    err = ((o - r).abs() * ok).max().item()
+    assert err <= 1e-2 * r.abs().max().item() + 1e-2 * (r.abs() * ok).max().item(), err
+    agree = ((o.argmax(0) == r.argmax(0)) | ~ok[0]).float().mean().item()
+    assert agree > 0.999
