@@ -72,7 +72,10 @@ struct BoxGeom {
     BD = (TD - 1) * g.is(0) + g.ext(0) + 1;
     BH = (TH - 1) * g.is(1) + g.ext(1) + 1;
     BW = (TW - 1) * g.is(2) + g.ext(2) + 1;
-    PW = (BW + 3) & ~3;  // row pitch in voxels (multiple of 4: see swizzle note)
+    // row pitch in voxels: a multiple of 4 keeps the h-rows of a stride-1 tap read on alternating bank halves; with
+    // W-stride 2 (de-interleaved columns) an even pitch is conflict-free and lets the 2x4x8 stride-2 box + weights
+    // fit twice into a CU's LDS (81.2 KB instead of 84.1 KB per workgroup)
+    PW = g.is(2) == 2 ? (BW + 1) & ~1 : (BW + 3) & ~3;
     BOX_BYTES = BD * BH * PW * 32;
     NBOXLOAD = BD * BH * BW * 2;  // 16-byte pieces
   }
@@ -147,7 +150,12 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
         const int bh = (s / bg.BW) % bg.BH;
         const int bd = s / (bg.BW * bg.BH);
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
-        box_loff[i] = ((bd * bg.BH + bh) * bg.PW + bw) * 32 + ((half ^ (bh & 1)) << 4);
+        // LDS image: W-stride 2 de-interleaves the columns (even columns first) so that a tap's 8 lanes read 8
+        // adjacent rows again; the half swizzle follows the row index the lanes step through (bh, or bh/2 for
+        // H-stride 2).  Without this the stride-2 reads were 4-way bank conflicts (SQ_LDS_BANK_CONFLICT 48 %).
+        const int bwp = ISW == 2 ? (bw >> 1) + (bw & 1) * ((bg.BW + 1) >> 1) : bw;
+        const int swz = (ISH == 2 ? bh >> 1 : bh) & 1;
+        box_loff[i] = ((bd * bg.BH + bh) * bg.PW + bwp) * 32 + ((half ^ swz) << 4);
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
           box_goff[i] = (((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + half * 8;
       }
@@ -164,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   for (int i = 0; i < C::WM; ++i) {
     const int v = (wm * C::WM + i) * 32 + l31;
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
-    const int base = (((td * ISD) * bg.BH + th * ISH) * bg.PW + tw * ISW) * 32;
-    const int f = (th * ISH) & 1;
+    const int base = (((td * ISD) * bg.BH + th * ISH) * bg.PW + tw) * 32;  // column tw of the (de-interleaved) image
+    const int f = th & 1;
     vox_off[i] = base + ((hh ^ f) << 4);
     const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
     const int od = md * p.d.out_stride[0] + grp.ooff[0];
@@ -194,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   for (int t = 0; t < nt; ++t) {
     const nnz_conv_tap tp = p.d.taps[tb + t];
     const int o0 = tp.off[0] - p.d.lo[0], o1 = tp.off[1] - p.d.lo[1], o2 = tp.off[2] - p.d.lo[2];
-    const int enc = (((o0 * bg.BH + o1) * bg.PW + o2) * 32) | ((o1 & 1) << 4);
+    const int col = ISW == 2 ? (o2 >> 1) + (o2 & 1) * ((bg.BW + 1) >> 1) : o2;
+    const int flip = (ISH == 2 ? o1 >> 1 : o1) & 1;
+    const int enc = (((o0 * bg.BH + o1) * bg.PW + col) * 32) | (flip << 4);
     tap_tab = lane == t ? enc : tap_tab;
   }
 

@@ -125,7 +125,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     tap_off[i] = 0;
     if (t < T) {
       const nnz_conv_tap tp = p.d.taps[t];
-      tap_off[i] = (((tp.off[0] - p.d.lo[0]) * gBH + (tp.off[1] - p.d.lo[1])) * gBW + (tp.off[2] - p.d.lo[2])) * 64;
+      // W-stride 2: the LDS image holds the even box columns first, then the odd ones, so that the four voxels of a
+      // transposed read are adjacent 64-byte rows again (interleaved they were 2-way bank conflicts)
+      const int o2 = tp.off[2] - p.d.lo[2];
+      const int col = ISW == 2 ? (o2 >> 1) + (o2 & 1) * ((gBW + 1) >> 1) : o2;
+      tap_off[i] = (((tp.off[0] - p.d.lo[0]) * gBH + (tp.off[1] - p.d.lo[1])) * gBW + col) * 64;
       ntw = i + 1;
     }
   }
@@ -160,9 +164,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
       if (c < gNBOXLOAD) {
         const int part = c & 3;
         const int s = c >> 2;
-        const int bw = s % gBW;
+        const int bwl = s % gBW;  // column of the LDS image
         const int bh = (s / gBW) % gBH;
         const int bd = s / (gBW * gBH);
+        const int hw = (gBW + 1) >> 1;
+        const int bw = ISW == 2 ? (bwl < hw ? 2 * bwl : 2 * (bwl - hw) + 1) : bwl;
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
           v = *reinterpret_cast<const u32x4*>(Pp + ((size_t)((n * Di + id) * Hi + ih) * Wi + iw) * ldi + part * 8);
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         u.v[1] = q1;
         bq = u.h;
       }
-      const int bbase = ((((td * ISD) * gBH + th * ISH) * gBW) + qrow * ISW) * 64 + chan_byte;
+      const int bbase = ((((td * ISD) * gBH + th * ISH) * gBW) + qrow) * 64 + chan_byte;
       // branch-free over the wave's MAXT tap slots (a slot beyond the wave's taps re-reads tap offset 0 and is
       // never flushed): all 2*MAXT transposed reads issue back to back ahead of the MFMAs instead of one
       // read->wait->MFMA chain per tap (SQ_WAIT_INST_ANY was 36-58 % of the wave cycles with the guarded loop)
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
       for (int i = 0; i < MAXT; ++i) {
         union { i16x4 v[2]; f16x8 h; } u;
         u.v[0] = lds_read_tr16(box + bbase + tap_off[i]);
-        u.v[1] = lds_read_tr16(box + bbase + tap_off[i] + 4 * ISW * 64);
+        u.v[1] = lds_read_tr16(box + bbase + tap_off[i] + 4 * 64);
         xa[i] = u.h;
       }
 #pragma unroll
