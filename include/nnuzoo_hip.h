@@ -84,6 +84,12 @@ int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const flo
                                  float* dgamma /* [C] = sum_n red[n][c][1], may be NULL */,
                                  float* dbeta /* [C] = sum_n red[n][c][0], NULL iff dgamma is */, void* stream);
 
+/* online-Dice statistics of the validation step (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 +
+ * get_tp_fp_fn_tn, training/loss/dice.py:122-180, label-map targets): argmax over classes (first maximum on ties)
+ * against the int16 label map in one read; counts_u64[c] = {tp, fp, fn} exact (zeroed by the call). */
+int nnz_argmax_tp_fp_fn(const void* logits_nc, int logits_is_f16, const int16_t* target, void* counts_u64 /* [C][3] */,
+                        int B, int C, long V, void* stream);
+
 /* ---- sliding-window inference accumulation ---------------------------------------------------------------------
  * replaces the tensor arithmetic of nnUNetPredictor._internal_maybe_mirror_and_predict
  * (nnunetv2/inference/predict_from_raw_data.py:549-564: `prediction += torch.flip(...)`, `prediction /= n`) and of

@@ -78,6 +78,7 @@ SIGNATURES = {
     "nnz_instnorm_lrelu_apply": [_vp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _f, _f, _vp],
     "nnz_instnorm_lrelu_bwd_reduce": [_vp, _vp, _fp, _fp, _fp, _fp, _i, _l, _i, _i, _i, _f, _f, _i, _vp],
     "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _fp, _fp, _vp],
+    "nnz_argmax_tp_fp_fn": [_vp, _i, _vp, _vp, _i, _i, _l, _vp],
     "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _vp],
     "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _vp],
     "nnz_sliding_window_accumulate": [_vp, _i, _ip, _vp, _vp, _vp, _i, _ip, _ip, _ip, _vp],

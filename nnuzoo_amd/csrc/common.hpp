@@ -47,6 +47,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (unsigned int)__shfl_xor((int)v, o, 64);
+  return v;
+}
+
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // XCD-aware bijective remap of a linear workgroup id: blocks that are neighbours in the remapped

@@ -150,7 +150,82 @@ static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
   return NNZ_OK;
 }
 
+// Online-Dice statistics of the validation step: argmax over the class axis (first maximum on ties, like
+// torch.argmax) compared with the label map; one read of logits + target instead of argmax -> zeros -> scatter_ ->
+// three products -> three reductions (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 with
+// get_tp_fp_fn_tn, training/loss/dice.py:122-180).  counts[c] = {tp, fp, fn} as exact integers.
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__ logits, const int16_t* __restrict__ tgt,
+                                                           unsigned long long* __restrict__ counts, int C, long V,
+                                                           int vpb) {
+  __shared__ unsigned int lc[3 * LS_MAXC];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  if (tid < 3 * LS_MAXC) lc[tid] = 0u;
+  __syncthreads();
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
+  if (v1 > V) v1 = V;
+  unsigned int tp[LS_MAXC], fp[LS_MAXC], fn[LS_MAXC];
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c) tp[c] = fp[c] = fn[c] = 0u;
+  const long base = (long)b * C * V;
+  for (long v = v0 + tid; v < v1; v += 256) {
+    float best = (float)logits[base + v];
+    int arg = 0;
+#pragma unroll
+    for (int c = 1; c < LS_MAXC; ++c)
+      if (c < C) {
+        const float z = (float)logits[base + (long)c * V + v];
+        if (z > best) {
+          best = z;
+          arg = c;
+        }
+      }
+    const int t = tgt[(long)b * V + v];
+#pragma unroll
+    for (int c = 0; c < LS_MAXC; ++c) {
+      tp[c] += (arg == c) & (t == c);
+      fp[c] += (arg == c) & (t != c);
+      fn[c] += (arg != c) & (t == c);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c)
+    if (c < C) {
+      const unsigned int a0 = wave_sum_u32(tp[c]), a1 = wave_sum_u32(fp[c]), a2 = wave_sum_u32(fn[c]);
+      if ((tid & 63) == 0) {
+        atomicAdd(&lc[c * 3 + 0], a0);
+        atomicAdd(&lc[c * 3 + 1], a1);
+        atomicAdd(&lc[c * 3 + 2], a2);
+      }
+    }
+  __syncthreads();
+  if (tid < 3 * C && lc[tid]) atomicAdd(counts + tid, (unsigned long long)lc[tid]);
+}
+
 }  // namespace nnz
+
+extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const int16_t* target, void* counts_u64,
+                                   int B, int C, long V, void* stream) {
+  using namespace nnz;
+  if (!logits || !target || !counts_u64 || C < 1 || C > LS_MAXC || B < 1 || V < 1) return NNZ_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts_u64, 0, sizeof(unsigned long long) * 3 * C, s);
+  if (e != hipSuccess) return (int)e;
+  long vpb = (V * B + 2047) / 2048;
+  if (vpb < 2048) vpb = 2048;
+  if (vpb > V) vpb = V;
+  const int gx = (int)((V + vpb - 1) / vpb);
+  if (logits_is_f16)
+    hipLaunchKernelGGL(argmax_stats_kernel<f16>, dim3(gx, B), dim3(256), 0, s, (const f16*)logits, target,
+                       (unsigned long long*)counts_u64, C, V, (int)vpb);
+  else
+    hipLaunchKernelGGL(argmax_stats_kernel<float>, dim3(gx, B), dim3(256), 0, s, (const float*)logits, target,
+                       (unsigned long long*)counts_u64, C, V, (int)vpb);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
 
 extern "C" int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target, float* sums, int B,
                                       int C, long V, void* stream) {

@@ -204,3 +204,16 @@ def dc_ce_backward(logits, target_i16, coef, dlogits, B, Cc, V):
         raise _lib.HipCallError("loss: dlogits dtype must equal logits dtype")
     call("nnz_dc_ce_loss_backward", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(coef), ptr(dlogits), B, Cc,
          V, stream_ptr())
+
+
+def argmax_tp_fp_fn(logits: torch.Tensor, target_i16: torch.Tensor):
+    """(B, C, *spatial) logits + (B, 1, *spatial) int16 labels -> exact int64 (tp, fp, fn) per class, one pass"""
+    if target_i16.dtype != torch.int16 or not target_i16.is_cuda:
+        raise _lib.HipCallError("argmax_tp_fp_fn: target must be an int16 device tensor")
+    logits = logits.contiguous()
+    B, Cc = logits.shape[:2]
+    V = logits[0, 0].numel()
+    counts = torch.empty((Cc, 3), dtype=torch.int64, device=logits.device)
+    call("nnz_argmax_tp_fp_fn", ptr(logits), _logits_kind(logits), ptr(target_i16.contiguous()), ptr(counts), B, Cc, V,
+         stream_ptr())
+    return counts[:, 0], counts[:, 1], counts[:, 2]

@@ -25,6 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .. import hip_ops as ops
 from ..ddp import attach_bucketed_allreduce
 from ..utilities.get_network_from_plans import get_network_from_plans
 from .loss import DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
@@ -245,13 +246,13 @@ class nnUNetTrainer:
             l = self.loss(output, target)
         if self.enable_deep_supervision:
             output, target = output[0], target[0]
-        axes = [0] + list(range(2, output.ndim))
-        output_seg = output.argmax(1)[:, None]
-        onehot = torch.zeros(output.shape, device=output.device, dtype=torch.float32)
-        onehot.scatter_(1, output_seg, 1)
-        tp, fp, fn = tp_fp_fn(onehot, target, axes)
-        return {'loss': l.detach().cpu().numpy(), 'tp_hard': tp.cpu().numpy()[1:], 'fp_hard': fp.cpu().numpy()[1:],
-                'fn_hard': fn.cpu().numpy()[1:]}
+        # argmax + TP/FP/FN in one HIP pass over logits and labels (reference: argmax -> one-hot scatter ->
+        # get_tp_fp_fn_tn, nnUNetTrainer.py:1201-1221); float32 arrays like the reference's, background dropped
+        tgt = target if target.dtype == torch.int16 else target.to(torch.int16)
+        tp, fp, fn = ops.argmax_tp_fp_fn(output, tgt)
+        stats = torch.stack([tp, fp, fn]).to(torch.float32).cpu().numpy()
+        return {'loss': l.detach().cpu().numpy(), 'tp_hard': stats[0][1:], 'fp_hard': stats[1][1:],
+                'fn_hard': stats[2][1:]}
 
     @staticmethod
     def pseudo_dice(val_outputs: List[dict]) -> List[float]:
@@ -300,14 +301,3 @@ class nnUNetTrainer:
         self.optimizer.load_state_dict(ckpt['optimizer_state'])
         if self.grad_scaler is not None and ckpt['grad_scaler_state'] is not None:
             self.grad_scaler.load_state_dict(ckpt['grad_scaler_state'])
-
-
-def tp_fp_fn(onehot_pred: torch.Tensor, gt: torch.Tensor, axes) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """get_tp_fp_fn_tn of the reference (dice.py:122-180) for label-map targets, no mask."""
-    with torch.no_grad():
-        y_onehot = torch.zeros(onehot_pred.shape, device=onehot_pred.device, dtype=torch.bool)
-        y_onehot.scatter_(1, gt.long(), 1)
-    tp = (onehot_pred * y_onehot).sum(axes)
-    fp = (onehot_pred * (~y_onehot)).sum(axes)
-    fn = ((1 - onehot_pred) * y_onehot).sum(axes)
-    return tp, fp, fn

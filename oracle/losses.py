@@ -48,3 +48,18 @@ def deep_supervision_loss(outputs, targets, batch_dice, weights=None):
     if weights is None:
         weights = ds_weights(len(outputs))
     return sum(w * dc_and_ce(o, t, batch_dice) for w, o, t in zip(weights, outputs, targets) if w != 0)
+
+
+def tp_fp_fn_hard(logits: torch.Tensor, target: torch.Tensor):
+    """Online-Dice statistics of validation_step (nnUNetTrainer.py:1201-1221: argmax -> one-hot scatter ->
+    get_tp_fp_fn_tn, dice.py:122-180, label-map target, no mask): float32 tp / fp / fn per class."""
+    axes = [0] + list(range(2, logits.ndim))
+    seg = logits.argmax(1)[:, None]
+    onehot = torch.zeros(logits.shape, dtype=torch.float32)
+    onehot.scatter_(1, seg, 1)
+    y = torch.zeros(logits.shape, dtype=torch.bool)
+    y.scatter_(1, target.long(), 1)
+    tp = (onehot * y).sum(axes)
+    fp = (onehot * (~y)).sum(axes)
+    fn = ((1 - onehot) * y).sum(axes)
+    return tp, fp, fn

@@ -52,3 +52,19 @@ def test_loss_value_and_grad(hip_lib, shape, C, batch_dice, dtype):
 def test_cpu_tensor_raises():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         make(False)(torch.zeros(1, 2, 4, 4), torch.zeros(1, 1, 4, 4, dtype=torch.int16))
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 3, 9, 17, 11), torch.float16), ((3, 2, 64, 50), torch.float32),
+                                         ((1, 8, 5, 6, 7), torch.float16)])
+def test_argmax_tp_fp_fn_matches_reference_formula(hip_lib, shape, dtype):
+    """validation statistics kernel vs the reference's argmax -> scatter -> get_tp_fp_fn_tn chain (oracle), exact;
+    quantised logits force ties (first maximum wins, like torch.argmax)"""
+    from nnuzoo_amd import hip_ops as ops
+    from oracle.losses import tp_fp_fn_hard
+    g = torch.Generator().manual_seed(7)
+    logits = (torch.randn(shape, generator=g) * 2).round().to(dtype)       # many exact ties
+    target = torch.randint(0, shape[1], (shape[0], 1, *shape[2:]), generator=g).to(torch.int16)
+    tp, fp, fn = ops.argmax_tp_fp_fn(logits.cuda(), target.cuda())
+    rtp, rfp, rfn = tp_fp_fn_hard(logits.float(), target)
+    assert torch.equal(tp.cpu().float(), rtp) and torch.equal(fp.cpu().float(), rfp) and torch.equal(fn.cpu().float(), rfn)
+    assert int((tp + fn).sum()) == target.numel()
