@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
 
 // ------------------------------------------------------------------------------------------------ head
 constexpr int HD_MAXK = 8;
+constexpr int HD_UNR = 4;  // rows in flight per thread in the coalesced head kernels
 
 struct HeadArgs {
   const f16* x;      // [N][V][ldx], C channels
@@ -247,50 +248,165 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(HeadArgs a, int accumul
   }
 }
 
+// ---- coalesced variants for power-of-two channel-group counts (C = 32 ... 256) ---------------------------------------
+// Thread = (row r, channel group cg of 8 fp16 = 16 bytes): a wave's load instruction covers 1 KiB of consecutive
+// memory, HD_UNR rows are in flight per thread (the loop is latency-bound otherwise), the K x 8 weights of the
+// thread's channels sit in registers.  The row-per-thread kernels above stay for C = 320 (8^3 voxels: negligible).
+template <int K>
+__global__ __launch_bounds__(256) void head_fwd_cg_kernel(HeadArgs a, int cgs) {
+  const int tid = threadIdx.x;
+  const int cg = tid & (cgs - 1);
+  const int rows = 256 / cgs;
+  const int r = tid / cgs;
+  float w[K][8];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[k][i] = (float)(f16)a.w[k * a.C + cg * 8 + i];
+  float bias[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) bias[k] = a.b ? a.b[k] : 0.f;
+  const long total = (long)a.N * a.V;
+  for (long row0 = (long)blockIdx.x * rows * HD_UNR; row0 < total; row0 += (long)gridDim.x * rows * HD_UNR) {
+    f16x8 h[HD_UNR];
+#pragma unroll
+    for (int u = 0; u < HD_UNR; ++u) {
+      const long row = row0 + u * rows + r;
+      if (row < total) h[u] = *reinterpret_cast<const f16x8*>(a.x + row * a.ldx + cg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < HD_UNR; ++u) {
+      const long row = row0 + u * rows + r;
+      float acc[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        acc[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[k] += (float)h[u][i] * w[k][i];
+      }
+      // fold the channel groups of the row (consecutive lanes)
+      for (int o = 1; o < cgs; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+      if (cg == 0 && row < total) {
+        const long n = row / a.V, v = row - n * a.V;
+#pragma unroll
+        for (int k = 0; k < K; ++k) a.logits[(n * K + k) * a.V + v] = (f16)(acc[k] + bias[k]);
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void head_dgrad_cg_kernel(HeadArgs a, int cgs, int accumulate) {
+  const int tid = threadIdx.x;
+  const int cg = tid & (cgs - 1);
+  const int rows = 256 / cgs;
+  const int r = tid / cgs;
+  float w[K][8];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[k][i] = (float)(f16)a.w[k * a.C + cg * 8 + i];
+  const long total = (long)a.N * a.V;
+  for (long row0 = (long)blockIdx.x * rows * HD_UNR; row0 < total; row0 += (long)gridDim.x * rows * HD_UNR) {
+    float g[HD_UNR][K];
+    f16x8 old[HD_UNR];
+#pragma unroll
+    for (int u = 0; u < HD_UNR; ++u) {
+      const long row = row0 + u * rows + r;
+      if (row < total) {
+        const long n = row / a.V, v = row - n * a.V;
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[u][k] = (float)a.dl[(n * K + k) * a.V + v];
+        if (accumulate) old[u] = *reinterpret_cast<const f16x8*>(a.dx + row * a.lddx + cg * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < HD_UNR; ++u) {
+      const long row = row0 + u * rows + r;
+      if (row >= total) continue;
+      f16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = 0.f;  // same summation order over k as the row-per-thread kernel, accumulate added last
+#pragma unroll
+        for (int k = 0; k < K; ++k) t += g[u][k] * w[k][i];
+        o[i] = (f16)(accumulate ? t + (float)old[u][i] : t);
+      }
+      *reinterpret_cast<f16x8*>(a.dx + row * a.lddx + cg * 8) = o;
+    }
+  }
+}
+
 // dW[k][c] = sum_{n,v} dl[n][k][v] * x[n][v][c];  db[k] = sum dl.   thread = (row r, channel group cg)
+template <int K>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
-  extern __shared__ float lred[];  // [K][C] + [K]
+  extern __shared__ float lred[];  // [rows][K*C + K]
   const int CG = a.C >> 3;
   const int rows = 256 / CG;
   const int tid = threadIdx.x;
   const int cg = tid % CG, r = tid / CG;
   const int n = blockIdx.y;
-  for (int i = tid; i < a.K * a.C + a.K; i += 256) lred[i] = 0.f;
-  __syncthreads();
   const long v0 = (long)blockIdx.x * vpb;
   long v1 = v0 + vpb;
   if (v1 > a.V) v1 = a.V;
-  float acc[HD_MAXK][8];
-  float accb[HD_MAXK];
+  float acc[K][8];
+  float accb[K];
 #pragma unroll
-  for (int k = 0; k < HD_MAXK; ++k) {
+  for (int k = 0; k < K; ++k) {
     accb[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[k][i] = 0.f;
   }
   if (r < rows) {
-    for (long v = v0 + r; v < v1; v += rows) {
-      const f16x8 h = *reinterpret_cast<const f16x8*>(a.x + ((long)n * a.V + v) * a.ldx + cg * 8);
+    const f16* xp = a.x + (long)n * a.V * a.ldx + cg * 8;
+    const f16* gp = a.dl + (long)n * K * a.V;
+    for (long v = v0 + r; v < v1; v += (long)rows * HD_UNR) {
+      // HD_UNR rows in flight per thread (one 16-byte load + K 2-byte loads each): the loop was latency-bound
+      f16x8 h[HD_UNR];
+      float gk[HD_UNR][K];
 #pragma unroll
-      for (int k = 0; k < HD_MAXK; ++k)
-        if (k < a.K) {
-          const float g = (float)a.dl[((long)n * a.K + k) * a.V + v];
-          accb[k] += g;
+      for (int u = 0; u < HD_UNR; ++u) {
+        const long vv = v + (long)u * rows;
+        if (vv < v1) {
+          h[u] = *reinterpret_cast<const f16x8*>(xp + vv * a.ldx);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[k][i] += g * (float)h[i];
+          for (int k = 0; k < K; ++k) gk[u][k] = (float)gp[(long)k * a.V + vv];
         }
-    }
-#pragma unroll
-    for (int k = 0; k < HD_MAXK; ++k)
-      if (k < a.K) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&lred[k * a.C + cg * 8 + i], acc[k][i]);
-        if (cg == 0) atomicAdd(&lred[a.K * a.C + k], accb[k]);
       }
+#pragma unroll
+      for (int u = 0; u < HD_UNR; ++u) {
+        if (v + (long)u * rows >= v1) continue;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          accb[k] += gk[u][k];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[k][i] += gk[u][k] * (float)h[u][i];
+        }
+      }
+    }
+  }
+  // block reduction through an LDS slab [rows][K*C + K] and one column sum per thread (LDS float atomics with 64
+  // threads per address serialised: that tail was longer than the streaming loop)
+  const int KC = K * a.C + K;
+  if (r < rows) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lred[r * KC + k * a.C + cg * 8 + i] = acc[k][i];
+      if (cg == 0) lred[r * KC + K * a.C + k] = accb[k];
+    }
   }
   __syncthreads();
-  for (int i = tid; i < a.K * a.C; i += 256) atomicAdd(a.dw + i, lred[i]);
-  for (int i = tid; i < a.K; i += 256) atomicAdd(a.db + i, lred[a.K * a.C + i]);
+  for (int i = tid; i < KC; i += 256) {
+    float t = 0.f;
+    for (int rr = 0; rr < rows; ++rr) t += lred[rr * KC + i];
+    if (i < K * a.C)
+      atomicAdd(a.dw + i, t);
+    else
+      atomicAdd(a.db + (i - K * a.C), t);
+  }
 }
 
 }  // namespace nnz
@@ -330,6 +446,38 @@ extern "C" int nnz_stem_conv_wgrad(const float* x, const void* dy, float* dw, in
   return NNZ_OK;
 }
 
+namespace nnz {
+static inline bool head_cg_ok(int C) {
+  const int cgs = C >> 3;
+  return C % 8 == 0 && cgs >= 1 && cgs <= 32 && (cgs & (cgs - 1)) == 0;
+}
+template <int K>
+static void launch_head_fwd_cg(const HeadArgs& a, hipStream_t s) {
+  const int cgs = a.C >> 3, rows = 256 / cgs;
+  long blocks = ((long)a.N * a.V + rows * HD_UNR - 1) / (rows * HD_UNR);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(head_fwd_cg_kernel<K>, dim3((int)blocks), dim3(256), 0, s, a, cgs);
+}
+template <int K>
+static void launch_head_dgrad_cg(const HeadArgs& a, int accumulate, hipStream_t s) {
+  const int cgs = a.C >> 3, rows = 256 / cgs;
+  long blocks = ((long)a.N * a.V + rows * HD_UNR - 1) / (rows * HD_UNR);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(head_dgrad_cg_kernel<K>, dim3((int)blocks), dim3(256), 0, s, a, cgs, accumulate);
+}
+#define NNZ_HEAD_K_SWITCH(K, CALL) \
+  switch (K) {                      \
+    case 1: CALL(1); break;         \
+    case 2: CALL(2); break;         \
+    case 3: CALL(3); break;         \
+    case 4: CALL(4); break;         \
+    case 5: CALL(5); break;         \
+    case 6: CALL(6); break;         \
+    case 7: CALL(7); break;         \
+    default: CALL(8); break;        \
+  }
+}  // namespace nnz
+
 extern "C" int nnz_seg_head_forward(const void* x, const float* w, const float* bias, void* logits, int N, long V,
                                     int C, int K, int ldx, void* stream) {
   using namespace nnz;
@@ -337,6 +485,13 @@ extern "C" int nnz_seg_head_forward(const void* x, const float* w, const float* 
   HeadArgs a = {};
   a.x = (const f16*)x; a.w = w; a.b = bias; a.logits = (f16*)logits;
   a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;
+  if (head_cg_ok(C)) {
+#define NNZ_CALL(KK) launch_head_fwd_cg<KK>(a, (hipStream_t)stream)
+    NNZ_HEAD_K_SWITCH(K, NNZ_CALL)
+#undef NNZ_CALL
+    NNZ_LAUNCH_CHECK();
+    return NNZ_OK;
+  }
   long blocks = (N * V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a);
@@ -351,6 +506,13 @@ extern "C" int nnz_seg_head_dgrad(const void* dlogits, const float* w, void* dx,
   HeadArgs a = {};
   a.dl = (const f16*)dlogits; a.w = w; a.dx = (f16*)dx;
   a.N = N; a.V = V; a.C = C; a.K = K; a.lddx = lddx;
+  if (head_cg_ok(C)) {
+#define NNZ_CALL(KK) launch_head_dgrad_cg<KK>(a, accumulate, (hipStream_t)stream)
+    NNZ_HEAD_K_SWITCH(K, NNZ_CALL)
+#undef NNZ_CALL
+    NNZ_LAUNCH_CHECK();
+    return NNZ_OK;
+  }
   long blocks = (N * V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(head_dgrad_kernel, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a,
@@ -375,7 +537,12 @@ extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw,
   if (vpb < 256) vpb = 256;
   if (vpb > V) vpb = V;
   const int gx = (int)((V + vpb - 1) / vpb);
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(gx, N), dim3(256), sizeof(float) * (K * C + K), s, a, (int)vpb);
+  const int rows = 256 / (C >> 3) < 1 ? 1 : 256 / (C >> 3);
+  const size_t lds = sizeof(float) * rows * (K * C + K);
+  if (lds > 64 * 1024) return NNZ_EINVAL;  // K*C beyond the slab: not a segmentation head
+#define NNZ_CALL(KK) hipLaunchKernelGGL(head_wgrad_kernel<KK>, dim3(gx, N), dim3(256), lds, s, a, (int)vpb)
+  NNZ_HEAD_K_SWITCH(K, NNZ_CALL)
+#undef NNZ_CALL
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
