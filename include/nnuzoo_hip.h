@@ -84,6 +84,21 @@ int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const flo
                                  float* dgamma /* [C] = sum_n red[n][c][1], may be NULL */,
                                  float* dbeta /* [C] = sum_n red[n][c][0], NULL iff dgamma is */, void* stream);
 
+/* ---- fused optimizer tail of train_step (nnUNetTrainer.py:1131-1139: grad_scaler.unscale_ -> clip_grad_norm_(12) ->
+ * SGD(momentum, nesterov, weight decay) step, skipped when a gradient is not finite) over a flat fp32 gradient arena.
+ * nnz_grad_sumsq_nonfinite adds {sum of squares, count of non-finite elements} of grads[0..n) to out2 (caller zeroes).
+ * nnz_sgd_nesterov_fused: one workgroup per chunk record (nnz_sgd_chunk_bytes() bytes each, filled on the host by
+ * nnz_sgd_chunk_fill: parameter and momentum pointers of <= 16384 elements + their gradient offset in the arena):
+ *   g = grad * inv_scale * min(1, max_norm / (sqrt(sumsq) * inv_scale + 1e-6)) + weight_decay * p
+ *   buf = momentum * buf + g;  p -= lr * (g + momentum * buf)        (buf starts at 0 == torch's first-step rule)
+ * nothing is written when stats2[1] > 0 or the sum of squares is not finite.  inv_scale_device may be NULL (1). */
+int nnz_sgd_chunk_bytes(void);
+int nnz_sgd_chunk_fill(void* out_host, float* param, float* momentum, long arena_offset, int n);
+int nnz_grad_sumsq_nonfinite(const float* grads, long n, float* out2_zeroed, void* stream);
+int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* arena, const float* stats2,
+                           const float* inv_scale_device, float max_norm, float lr, float momentum, float weight_decay,
+                           int first_step, void* stream);
+
 /* online-Dice statistics of the validation step (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 +
  * get_tp_fp_fn_tn, training/loss/dice.py:122-180, label-map targets): argmax over classes (first maximum on ties)
  * against the int16 label map in one read; counts_u64[c] = {tp, fp, fn} exact (zeroed by the call). */

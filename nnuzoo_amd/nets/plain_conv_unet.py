@@ -527,11 +527,24 @@ class PlainConvUNet(nn.Module):
 
     def _galloc(self, like: torch.Tensor) -> torch.Tensor:
         """Gradient storage comes from ONE flat fp32 arena, filled in backward-completion order: the data-parallel
-        reducer all-reduces contiguous slices of it in place (no flatten / unflatten copies)."""
+        reducer all-reduces contiguous slices of it in place (no flatten / unflatten copies) and the fused optimizer
+        (training/fused_sgd.py) reads it directly."""
         n = like.numel()
         off = self._arena_off
         self._arena_off = off + n
+        self._arena_trace.append((like, off))
         return self._arena[off:off + n].view(like.shape)
+
+    # ---- gradient arena of the most recent backward (fused optimizer) ---------------------------------------------
+    def grad_arena(self) -> Optional[torch.Tensor]:
+        return getattr(self, "_last_arena", None)
+
+    def grad_arena_layout(self):
+        """[(parameter, element offset)] in arena order; fixed by the schedule (identical every step)"""
+        return list(self._arena_layout)
+
+    def release_grad_arena(self):
+        self._last_arena = None
 
     def _run_backward(self, rec, gouts):
         plan: _Plan = rec["plan"]
@@ -543,6 +556,7 @@ class PlainConvUNet(nn.Module):
         grads = {}
         self._arena = torch.zeros(sum(p.numel() for p in self._params()), dtype=torch.float32, device=dev)
         self._arena_off = 0
+        self._arena_trace = []
         plan.pack_bwd.run()
         self._red_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
         self._dw_all = torch.zeros(plan.dw_floats, dtype=torch.float32, device=dev)
@@ -636,7 +650,9 @@ class PlainConvUNet(nn.Module):
             out.append(gp if gp is not None else self._galloc(p))
         if self.grad_reducer is not None:
             self.grad_reducer.finish_arena(self._arena, self._arena_off)
-        self._red_all = self._dw_all = self._arena = None
+        self._arena_layout = self._arena_trace
+        self._last_arena = self._arena
+        self._red_all = self._dw_all = self._arena = self._arena_trace = None
         return out
 
     # reference API (dynamic_network_architectures): used by the planner's VRAM estimate only

@@ -28,6 +28,7 @@ import torch.distributed as dist
 from .. import hip_ops as ops
 from ..ddp import attach_bucketed_allreduce
 from ..utilities.get_network_from_plans import get_network_from_plans
+from .fused_sgd import FusedSGD
 from .loss import DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
 from .lr_scheduler import PolyLRScheduler
 
@@ -81,6 +82,12 @@ def _num_input_channels(dataset_json: dict) -> int:
     return len(names)
 
 
+def _scaler_internals_ok(scaler) -> bool:
+    """the fused tail drives torch.amp.GradScaler's state directly (what GradScaler.update() does internally)"""
+    return all(hasattr(scaler, a) for a in ("_scale", "_growth_tracker", "_growth_factor", "_backoff_factor",
+                                             "_growth_interval")) and scaler._scale is not None
+
+
 class nnUNetTrainer:
     def __init__(self, plans: dict, configuration: str, fold: Union[int, str], dataset_json: dict,
                  unpack_dataset: bool = True, device: torch.device = torch.device('cuda'), num_epochs: int = 1000,
@@ -116,6 +123,7 @@ class nnUNetTrainer:
         self.network = None
         self.optimizer = self.lr_scheduler = None
         self.grad_scaler = torch.amp.GradScaler("cuda") if self.device.type == 'cuda' else None
+        self.use_fused_optimizer = True  # unscale + clip + SGD as the fused HIP tail when the network has a gradient arena
         self.loss = None
         self._best_ema = None
         self.inference_allowed_mirroring_axes = None
@@ -201,8 +209,13 @@ class nnUNetTrainer:
         return loss
 
     def configure_optimizers(self):
-        optimizer = torch.optim.SGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay,
-                                    momentum=0.99, nesterov=True)
+        if hasattr(self.network, "grad_arena"):
+            # same optimizer (torch.optim.SGD subclass, identical state_dict); its step can run as the fused HIP tail
+            optimizer = FusedSGD(self.network, self.initial_lr, weight_decay=self.weight_decay, momentum=0.99,
+                                 nesterov=True)
+        else:
+            optimizer = torch.optim.SGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay,
+                                        momentum=0.99, nesterov=True)
         lr_scheduler = PolyLRScheduler(optimizer, self.initial_lr, self.num_epochs)
         return optimizer, lr_scheduler
 
@@ -222,16 +235,29 @@ class nnUNetTrainer:
         # so no torch.autocast context is needed around it
         output = self.network(data)
         l = self.loss(output, target)
+        fused = isinstance(self.optimizer, FusedSGD) and self.use_fused_optimizer
         if self.grad_scaler is not None:
             self.grad_scaler.scale(l).backward()
-            self.grad_scaler.unscale_(self.optimizer)
-            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
-            self.grad_scaler.step(self.optimizer)
-            self.grad_scaler.update()
+            if fused and self.optimizer.fused_available() and _scaler_internals_ok(self.grad_scaler):
+                # unscale_ + clip_grad_norm_(12) + step + update (nnUNetTrainer.py:1133-1138) without leaving the
+                # device: two kernels over the gradient arena, then torch's own scale-update op on the found_inf flag
+                sc = self.grad_scaler
+                inv_scale = sc._scale.double().reciprocal().float()
+                found_inf = self.optimizer.fused_step(inv_scale, 12)
+                torch._amp_update_scale_(sc._scale, sc._growth_tracker, found_inf, sc._growth_factor,
+                                         sc._backoff_factor, sc._growth_interval)
+            else:
+                self.grad_scaler.unscale_(self.optimizer)
+                torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+                self.grad_scaler.step(self.optimizer)
+                self.grad_scaler.update()
         else:
             l.backward()
-            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
-            self.optimizer.step()
+            if fused and self.optimizer.fused_available():
+                self.optimizer.fused_step(None, 12)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+                self.optimizer.step()
         return {'loss': l.detach().cpu().numpy()}
 
     def validation_step(self, batch: dict) -> dict:

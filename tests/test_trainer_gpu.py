@@ -67,3 +67,93 @@ def test_validation_step_and_checkpoint(hip_lib, tmp_path):
     tr2.load_checkpoint(f)
     for (k, a), (_, b) in zip(tr.network.state_dict().items(), tr2.network.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def _two_trainers(patch=(32, 32, 32)):
+    plans, cfg, dj = nnunet_plans(3, patch, batch_size=2)
+    torch.manual_seed(0)
+    a = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+    a.initialize()
+    b = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+    b.initialize()
+    b.network.load_state_dict(a.network.state_dict())
+    b.use_fused_optimizer = False
+    return a, b
+
+
+def test_fused_optimizer_matches_torch_tail(hip_lib):
+    """unscale + clip(12) + Nesterov SGD + scaler update as the fused HIP tail.
+
+    (1) exact check inside one trainer: after a fused step, momentum and parameters equal torch's update rule applied
+        to the very gradients of that step (p.grad are views of the arena);
+    (2) trajectory check against a second trainer running torch's GradScaler / clip_grad_norm_ / SGD.step sequence.
+        Two runs of the same step differ by fp16 rounding (fp32 atomics in the statistics) and LeakyReLU's gradient
+        amplifies sign flips of near-zero pre-activations to a few % of gradient norm, so (2) is a loose bound."""
+    from nnuzoo_amd.training.fused_sgd import FusedSGD
+    fused, plain = _two_trainers()
+    assert isinstance(fused.optimizer, FusedSGD) and isinstance(plain.optimizer, torch.optim.SGD)
+    batch = synthetic_batch(2, (32, 32, 32), fused._get_deep_supervision_scales(), seed=3)
+    params = list(fused.network.parameters())
+    before = [p.detach().clone() for p in params]
+    scale0 = 65536.0
+    fused.train_step(batch)
+    assert float(fused.grad_scaler.get_scale()) == scale0
+    lr, mom, wd = 1e-2, 0.99, 3e-5
+    grads = [p.grad.detach() / scale0 for p in params]
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).item()
+    clip = min(1.0, 12.0 / (total + 1e-6))
+    assert abs(float(fused.optimizer.total_grad_norm()) / scale0 - total) < 1e-4 * total
+    for p, p0, g in zip(params, before, grads):
+        d = g * clip + wd * p0
+        buf = fused.optimizer.state[p]["momentum_buffer"]
+        assert torch.allclose(buf, d, rtol=1e-5, atol=1e-7 * (d.abs().max().item() + 1e-12))
+        want = p0 - lr * (d + mom * d)
+        assert torch.allclose(p.detach(), want, rtol=1e-5, atol=1e-8)
+    plain.train_step(batch)
+    for it in range(3):
+        lf, lp = fused.train_step(batch)["loss"], plain.train_step(batch)["loss"]
+        assert abs(float(lf) - float(lp)) < 1e-2 * max(1.0, abs(float(lp)))
+    sf, sp = fused.network.state_dict(), plain.network.state_dict()
+    num = sum(((sf[k] - sp[k]).float() ** 2).sum().item() for k in sp)
+    den = sum((sp[k].float() ** 2).sum().item() for k in sp)
+    assert (num / den) ** 0.5 < 5e-3
+    stf, stp = fused.optimizer.state_dict(), plain.optimizer.state_dict()
+    assert stf["state"].keys() == stp["state"].keys()
+    assert all(stf["state"][k]["momentum_buffer"].shape == stp["state"][k]["momentum_buffer"].shape for k in stp["state"])
+    assert float(fused.grad_scaler.get_scale()) == float(plain.grad_scaler.get_scale())
+
+
+def test_fused_optimizer_skips_on_inf_and_relinks_after_load(hip_lib, tmp_path):
+    from nnuzoo_amd.training.fused_sgd import FusedSGD
+    plans, cfg, dj = nnunet_plans(3, (32, 32, 32), batch_size=2)
+    tr = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    batch = synthetic_batch(2, (32, 32, 32), tr._get_deep_supervision_scales(), seed=9)
+    tr.train_step(batch)
+    opt: FusedSGD = tr.optimizer
+    before = {k: v.clone() for k, v in tr.network.state_dict().items()}
+    mom_before = opt._flat_mom.clone()
+    scale_before = float(tr.grad_scaler.get_scale())
+    # poison one gradient element of the arena: the step must be skipped and the loss scale backed off
+    arena = tr.network.grad_arena()
+    arena[123] = float("inf")
+    inv = tr.grad_scaler._scale.double().reciprocal().float()
+    found = opt.fused_step(inv, 12)
+    torch._amp_update_scale_(tr.grad_scaler._scale, tr.grad_scaler._growth_tracker, found, 2.0, 0.5, 2000)
+    assert float(found) > 0
+    for k, v in tr.network.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert torch.equal(opt._flat_mom, mom_before)
+    assert float(tr.grad_scaler.get_scale()) == 0.5 * scale_before
+    # optimizer state survives a state_dict round trip and is re-linked into the flat buffer
+    import copy
+    sd = copy.deepcopy(opt.state_dict())          # what torch.load of a checkpoint hands over: fresh tensors
+    mom_saved = opt._flat_mom.clone()
+    opt.load_state_dict(sd)
+    assert not opt._linked()
+    opt._build(tr.network.grad_arena_layout(), mom_saved.device)
+    assert opt._linked() and torch.equal(opt._flat_mom, mom_saved)   # restored buffers were copied into the flat tensor
+    tr.train_step(batch)
+    assert opt._linked()
+    for p, off, _, _ in opt._links:
+        assert opt.state[p]["momentum_buffer"].data_ptr() == opt._flat_mom.data_ptr() + 4 * off
