@@ -105,6 +105,17 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
 int nnz_argmax_tp_fp_fn(const void* logits_nc, int logits_is_f16, const int16_t* target, void* counts_u64 /* [C][3] */,
                         int B, int C, long V, void* stream);
 
+/* ---- 1-D Mamba block pieces around the scan (nets/seg_mamba/mamba_simple.py:190-357, mamba_inner_ref in
+ * nets/seg_mamba/selective_scan_interface.py:640-674): causal depthwise conv1d (width W <= 8, padding W-1, truncated to
+ * L) + SiLU on fp32 (B, D, L) rows, and the z gate out = y * z * sigmoid(z) that selective_scan_fn(..., z=z) applies.
+ * Backward of the conv recomputes the pre-activation; dw [D][W] and dbias [D] are zeroed by the call. */
+int nnz_causal_conv1d_silu_forward(const float* x, const float* w /* [D][W] */, const float* bias, float* y, int B, int D,
+                                   int L, int W, void* stream);
+int nnz_causal_conv1d_silu_backward(const float* x, const float* w, const float* bias, const float* dy, float* dx,
+                                    float* dw, float* dbias, int B, int D, int L, int W, void* stream);
+int nnz_silu_gate_forward(const float* y, const float* z, float* out, long n, void* stream);
+int nnz_silu_gate_backward(const float* dout, const float* y, const float* z, float* dy, float* dz, long n, void* stream);
+
 /* ---- sliding-window inference accumulation ---------------------------------------------------------------------
  * replaces the tensor arithmetic of nnUNetPredictor._internal_maybe_mirror_and_predict
  * (nnunetv2/inference/predict_from_raw_data.py:549-564: `prediction += torch.flip(...)`, `prediction /= n`) and of

@@ -87,6 +87,10 @@ SIGNATURES = {
     "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _vp],
     "nnz_sliding_window_accumulate": [_vp, _i, _ip, _vp, _vp, _vp, _i, _ip, _ip, _ip, _vp],
     "nnz_sliding_window_finalize": [_vp, _vp, _i, _l, _vp, _vp],
+    "nnz_causal_conv1d_silu_forward": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
+    "nnz_causal_conv1d_silu_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
+    "nnz_silu_gate_forward": [_fp, _fp, _fp, _l, _vp],
+    "nnz_silu_gate_backward": [_fp, _fp, _fp, _fp, _fp, _l, _vp],
     "nnz_window_attention_forward": [_fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_window_attention_backward": [_fp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_selective_scan_workspace_floats": [_i, _i, _i],

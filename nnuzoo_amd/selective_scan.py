@@ -5,7 +5,7 @@ ssnd2net.py:18,176,271-277); the in-tree autograd wrapper it mirrors is
 /root/reference/nnunetv2/nets/seg_mamba/selective_scan_interface.py:14-83.
 
 Supported (exactly what those call sites use): real A of shape (K*D, 16), B and C of shape (B, K, 16, L) (or
-(B, 16, L) = one group), fp32, z=None.  Anything else raises - there is no eager fallback.
+(B, 16, L) = one group), fp32, optional z gate (1-D Mamba block).  Anything else raises - there is no eager fallback.
 """
 from __future__ import annotations
 
@@ -31,7 +31,7 @@ class SelectiveScanFn(torch.autograd.Function):
     def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                 return_last_state=False):
         if z is not None:
-            raise NotImplementedError("selective_scan_fn: z gating is not used by the SS2D/SSND call sites")
+            raise NotImplementedError("SelectiveScanFn: z gating is applied by selective_scan_fn (separate kernel)")
         if return_last_state:
             raise NotImplementedError("selective_scan_fn: return_last_state is not used by the SS2D/SSND call sites")
         if A.is_complex():
@@ -83,4 +83,9 @@ class SelectiveScanFn(torch.autograd.Function):
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                       return_last_state=False):
-    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    y = SelectiveScanFn.apply(u, delta, A, B, C, D, None, delta_bias, delta_softplus, return_last_state)
+    if z is not None:
+        # the Mamba block's gate: out = y * silu(z) (selective_scan_ref, selective_scan_interface.py:140-148)
+        from .mamba_block import silu_gate
+        y = silu_gate(y, z)
+    return y

@@ -240,11 +240,58 @@ def gen_sliding_window():
     np.savez_compressed(os.path.join(OUT, "sliding_window.npz"), **out)
 
 
+def gen_mamba(ref):
+    """1-D Mamba block: the reference's vendored module (nets/seg_mamba/mamba_simple.py) run on CPU.
+    bimamba "none" goes through its slow path (conv1d + act, x/dt projections, selective_scan_ref with z);
+    "v2" / "v3" go through its own fast-path composition code with mamba_inner_fn_no_out_proj bound to the reference's
+    mamba_inner_ref (identity out_proj), see tools/ref_shim.load_mamba_inner_ref."""
+    from nnunetv2.nets.seg_mamba import mamba_simple as ms
+    inner_ref = ref_shim.load_mamba_inner_ref()
+    ms.causal_conv1d_fn = None
+    ms.selective_scan_fn = ref
+
+    def no_out_proj(xz, cw, cb, xw, dw, A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                    C_proj_bias=None, delta_softplus=True):
+        eye = torch.eye(A.shape[0], dtype=xz.dtype)
+        return inner_ref(xz, cw, cb, xw, dw, eye, None, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
+                         delta_softplus).transpose(1, 2)
+
+    ms.mamba_inner_fn_no_out_proj = no_out_proj
+    out = {}
+    for tag, kind, fast, d_model, L, ns in [("none", "none", False, 48, 37, 5), ("v2", "v2", True, 32, 24, 5),
+                                            ("v3", "v3", True, 32, 40, 4)]:
+        torch.manual_seed(0)
+        m = ms.Mamba(d_model, bimamba_type=kind, nslices=ns, use_fast_path=fast)
+        det_fill(m, skip=())
+        with torch.no_grad():  # keep A = -exp(A_log) and softplus(dt bias) in a sane range
+            for n, p in m.named_parameters():
+                if "A_" in n or n == "A_log":
+                    p.copy_(torch.log(1.0 + torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) % 16) * 0.9 + 0.05 * p)
+        Bn = 2
+        i = torch.arange(Bn * L * d_model, dtype=torch.float64)
+        x = torch.cos(0.37 * i + 0.5).float().reshape(Bn, L, d_model).requires_grad_(True)
+        G = torch.sin(0.11 * i + 1.0).float().reshape(Bn, L, d_model)
+        y = m(x)
+        (y * G).sum().backward()
+        out[f"{tag}_x"] = x.detach().numpy()
+        out[f"{tag}_G"] = G.numpy()
+        out[f"{tag}_y"] = y.detach().numpy()
+        out[f"{tag}_dx"] = x.grad.numpy()
+        out[f"{tag}_cfg"] = np.array([d_model, L, ns])
+        for n, p in m.named_parameters():
+            out[f"{tag}_p_{n}"] = p.detach().numpy()
+            if p.grad is not None:
+                out[f"{tag}_g_{n}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "mamba_block.npz"), **out)
+
+
 if __name__ == "__main__":
     ref = ref_shim.install()
-    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw"]
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba"]
     if "sw" in which:
         gen_sliding_window()
+    if "mamba" in which:
+        gen_mamba(ref)
     if "scan" in which:
         gen_selective_scan(ref)
     if "loss" in which:

@@ -110,6 +110,29 @@ def load_selective_scan_ref():
     return ns["selective_scan_ref"]
 
 
+def load_mamba_inner_ref():
+    """The reference's mamba_inner_ref (selective_scan_interface.py:640-674), extracted by ast like selective_scan_ref
+    (the module itself needs the selective_scan_cuda extension).  Its two free names are bound to reference code:
+    selective_scan_fn := the reference's selective_scan_ref; causal_conv1d_fn := the fallback formula of the reference's
+    own Mamba.forward (mamba_simple.py:318-321): act(conv1d(x, padding=W-1)[..., :L])."""
+    src = open(f"{REF}/nnunetv2/nets/seg_mamba/selective_scan_interface.py").read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "mamba_inner_ref"][0]
+    mod = ast.Module(body=[fn], type_ignores=[])
+    import torch.nn.functional as F
+    from einops import rearrange, repeat
+
+    def causal_conv1d_fn(x, weight, bias, activation):
+        assert activation in ("silu", "swish")
+        W = weight.shape[-1]
+        return F.silu(F.conv1d(x, weight.unsqueeze(1), bias, padding=W - 1, groups=x.shape[1])[..., :x.shape[-1]])
+
+    ns = dict(torch=torch, F=F, rearrange=rearrange, repeat=repeat, causal_conv1d_fn=causal_conv1d_fn,
+              selective_scan_fn=load_selective_scan_ref())
+    exec(compile(mod, "mamba_inner_ref(reference)", "exec"), ns)
+    return ns["mamba_inner_ref"]
+
+
 def install():
     if REF not in sys.path:
         sys.path.insert(0, REF)
