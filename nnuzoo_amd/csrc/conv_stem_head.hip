@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
 }
 
 // ------------------------------------------------------------------------------------------------ head
-constexpr int HD_MAXK = 8;
+constexpr int HD_MAXK = 32;  // classes: <= 8 run the register-resident kernels, 9..32 the row-per-thread ones
 constexpr int HD_UNR = 4;  // rows in flight per thread in the coalesced head kernels
 
 struct HeadArgs {
@@ -185,8 +185,10 @@ struct HeadArgs {
   float* db;         // [K]
   int N, C, K, ldx, lddx;
   long V;
+  int Ktot, k0;      // weight-gradient launches cover classes k0 .. k0 + K - 1 of Ktot
 };
 
+template <int MAXK>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
   extern __shared__ float wsm[];  // [K][C]
   for (int i = threadIdx.x; i < a.K * a.C; i += 256) wsm[i] = (float)(f16)a.w[i];
@@ -194,25 +196,26 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
   const long total = (long)a.N * a.V;
   for (long row = blockIdx.x * 256L + threadIdx.x; row < total; row += (long)gridDim.x * 256) {
     const long n = row / a.V, v = row % a.V;
-    float acc[HD_MAXK];
+    float acc[MAXK];
 #pragma unroll
-    for (int k = 0; k < HD_MAXK; ++k) acc[k] = (k < a.K && a.b) ? a.b[k] : 0.f;
+    for (int k = 0; k < MAXK; ++k) acc[k] = (k < a.K && a.b) ? a.b[k] : 0.f;
     const f16* xp = a.x + row * a.ldx;
     for (int c8 = 0; c8 < a.C; c8 += 8) {
       const f16x8 h = *reinterpret_cast<const f16x8*>(xp + c8);
 #pragma unroll
-      for (int k = 0; k < HD_MAXK; ++k)
+      for (int k = 0; k < MAXK; ++k)
         if (k < a.K) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[k] += (float)h[i] * wsm[k * a.C + c8 + i];
         }
     }
 #pragma unroll
-    for (int k = 0; k < HD_MAXK; ++k)
+    for (int k = 0; k < MAXK; ++k)
       if (k < a.K) a.logits[(n * a.K + k) * a.V + v] = (f16)acc[k];
   }
 }
 
+template <int MAXK>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(HeadArgs a, int accumulate) {
   extern __shared__ float wsm[];
   for (int i = threadIdx.x; i < a.K * a.C; i += 256) wsm[i] = (float)(f16)a.w[i];
@@ -220,16 +223,16 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(HeadArgs a, int accumul
   const long total = (long)a.N * a.V;
   for (long row = blockIdx.x * 256L + threadIdx.x; row < total; row += (long)gridDim.x * 256) {
     const long n = row / a.V, v = row % a.V;
-    float g[HD_MAXK];
+    float g[MAXK];
 #pragma unroll
-    for (int k = 0; k < HD_MAXK; ++k) g[k] = k < a.K ? (float)a.dl[(n * a.K + k) * a.V + v] : 0.f;
+    for (int k = 0; k < MAXK; ++k) g[k] = k < a.K ? (float)a.dl[(n * a.K + k) * a.V + v] : 0.f;
     f16* dp = a.dx + row * a.lddx;
     for (int c8 = 0; c8 < a.C; c8 += 8) {
       float o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = 0.f;
 #pragma unroll
-      for (int k = 0; k < HD_MAXK; ++k)
+      for (int k = 0; k < MAXK; ++k)
         if (k < a.K) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] += g[k] * wsm[k * a.C + c8 + i];
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
   }
   if (r < rows) {
     const f16* xp = a.x + (long)n * a.V * a.ldx + cg * 8;
-    const f16* gp = a.dl + (long)n * K * a.V;
+    const f16* gp = a.dl + ((long)n * a.Ktot + a.k0) * a.V;
     for (long v = v0 + r; v < v1; v += (long)rows * HD_UNR) {
       // HD_UNR rows in flight per thread (one 16-byte load + K 2-byte loads each): the loop was latency-bound
       f16x8 h[HD_UNR];
@@ -403,9 +406,9 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
     float t = 0.f;
     for (int rr = 0; rr < rows; ++rr) t += lred[rr * KC + i];
     if (i < K * a.C)
-      atomicAdd(a.dw + i, t);
+      atomicAdd(a.dw + (long)a.k0 * a.C + i, t);
     else
-      atomicAdd(a.db + (i - K * a.C), t);
+      atomicAdd(a.db + a.k0 + (i - K * a.C), t);
   }
 }
 
@@ -485,7 +488,7 @@ extern "C" int nnz_seg_head_forward(const void* x, const float* w, const float* 
   HeadArgs a = {};
   a.x = (const f16*)x; a.w = w; a.b = bias; a.logits = (f16*)logits;
   a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;
-  if (head_cg_ok(C)) {
+  if (head_cg_ok(C) && K <= 8) {
 #define NNZ_CALL(KK) launch_head_fwd_cg<KK>(a, (hipStream_t)stream)
     NNZ_HEAD_K_SWITCH(K, NNZ_CALL)
 #undef NNZ_CALL
@@ -494,7 +497,11 @@ extern "C" int nnz_seg_head_forward(const void* x, const float* w, const float* 
   }
   long blocks = (N * V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a);
+  if (K <= 8)
+    hipLaunchKernelGGL(head_fwd_kernel<8>, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel<HD_MAXK>, dim3((int)blocks), dim3(256), sizeof(float) * K * C,
+                       (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -506,7 +513,7 @@ extern "C" int nnz_seg_head_dgrad(const void* dlogits, const float* w, void* dx,
   HeadArgs a = {};
   a.dl = (const f16*)dlogits; a.w = w; a.dx = (f16*)dx;
   a.N = N; a.V = V; a.C = C; a.K = K; a.lddx = lddx;
-  if (head_cg_ok(C)) {
+  if (head_cg_ok(C) && K <= 8) {
 #define NNZ_CALL(KK) launch_head_dgrad_cg<KK>(a, accumulate, (hipStream_t)stream)
     NNZ_HEAD_K_SWITCH(K, NNZ_CALL)
 #undef NNZ_CALL
@@ -515,8 +522,12 @@ extern "C" int nnz_seg_head_dgrad(const void* dlogits, const float* w, void* dx,
   }
   long blocks = (N * V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(head_dgrad_kernel, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a,
-                     accumulate);
+  if (K <= 8)
+    hipLaunchKernelGGL(head_dgrad_kernel<8>, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream,
+                       a, accumulate);
+  else
+    hipLaunchKernelGGL(head_dgrad_kernel<HD_MAXK>, dim3((int)blocks), dim3(256), sizeof(float) * K * C,
+                       (hipStream_t)stream, a, accumulate);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -538,11 +549,19 @@ extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw,
   if (vpb > V) vpb = V;
   const int gx = (int)((V + vpb - 1) / vpb);
   const int rows = 256 / (C >> 3) < 1 ? 1 : 256 / (C >> 3);
-  const size_t lds = sizeof(float) * rows * (K * C + K);
-  if (lds > 64 * 1024) return NNZ_EINVAL;  // K*C beyond the slab: not a segmentation head
+  // classes in groups of <= 8 (the accumulators of a group live in registers)
+  int kmax = (int)((64 * 1024 / sizeof(float)) / ((size_t)rows * (C + 1)));  // classes per launch the LDS slab holds
+  if (kmax > 8) kmax = 8;
+  if (kmax < 1) return NNZ_EINVAL;
+  for (int k0 = 0; k0 < K; k0 += kmax) {
+    const int kg = K - k0 < kmax ? K - k0 : kmax;
+    a.K = kg; a.Ktot = K; a.k0 = k0;
+    const size_t lds = sizeof(float) * rows * (kg * C + kg);
+    if (lds > 64 * 1024) return NNZ_EINVAL;  // K*C beyond the slab: not a segmentation head
 #define NNZ_CALL(KK) hipLaunchKernelGGL(head_wgrad_kernel<KK>, dim3(gx, N), dim3(256), lds, s, a, (int)vpb)
-  NNZ_HEAD_K_SWITCH(K, NNZ_CALL)
+    NNZ_HEAD_K_SWITCH(kg, NNZ_CALL)
 #undef NNZ_CALL
+  }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -12,7 +12,7 @@
 
 namespace nnz {
 
-constexpr int LS_MAXC = 8;
+constexpr int LS_MAXC_BIG = 32;  // class-count buckets: <= 8 (the tuned instantiation) and <= 32 (same code, larger register arrays)
 
 template <typename T>
 struct LossArgs {
@@ -26,7 +26,7 @@ struct LossArgs {
   int vpb;
 };
 
-template <typename T>
+template <typename T, int LS_MAXC>
 __device__ __forceinline__ void softmax_at(const LossArgs<T>& a, long base, long v, float (&p)[LS_MAXC], float& lse) {
   float z[LS_MAXC];
   float m = -3.0e38f;
@@ -50,7 +50,7 @@ __device__ __forceinline__ void softmax_at(const LossArgs<T>& a, long base, long
   lse = m + __logf(s);
 }
 
-template <typename T>
+template <typename T, int LS_MAXC>
 __global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
   __shared__ float lred[3 * LS_MAXC + 1];
   const int tid = threadIdx.x;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
   for (int c = 0; c < LS_MAXC; ++c) inter[c] = sp[c] = sg[c] = 0.f;
   for (long v = v0 + tid; v < v1; v += 256) {
     float p[LS_MAXC], lse;
-    softmax_at(a, base, v, p, lse);
+    softmax_at<T, LS_MAXC>(a, base, v, p, lse);
     const int t = a.tgt[(long)b * a.V + v];
 #pragma unroll
     for (int c = 0; c < LS_MAXC; ++c)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
   if (tid < 3 * a.C + 1) atomicAdd(a.sums + (long)b * (3 * a.C + 1) + tid, lred[tid]);
 }
 
-template <typename T>
+template <typename T, int LS_MAXC>
 __global__ __launch_bounds__(256) void dc_ce_bwd_kernel(LossArgs<T> a) {
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void dc_ce_bwd_kernel(LossArgs<T> a) {
   const float gce = a.coef[(long)b * (2 * a.C + 1) + 2 * a.C];
   for (long v = v0 + tid; v < v1; v += 256) {
     float p[LS_MAXC], lse;
-    softmax_at(a, base, v, p, lse);
+    softmax_at<T, LS_MAXC>(a, base, v, p, lse);
     const int t = a.tgt[(long)b * a.V + v];
     float S = 0.f;
     float ac[LS_MAXC];
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void dc_ce_bwd_kernel(LossArgs<T> a) {
 
 template <typename T>
 static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
-  if (a.C < 1 || a.C > LS_MAXC || a.B < 1 || a.V < 1) return NNZ_EINVAL;
+  if (a.C < 1 || a.C > LS_MAXC_BIG || a.B < 1 || a.V < 1) return NNZ_EINVAL;
+  const bool big = a.C > 8;
   long vpb = (a.V * a.B + 2047) / 2048;
   if (vpb < 1024) vpb = 1024;
   if (vpb > a.V) vpb = a.V;
@@ -142,9 +143,15 @@ static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
   if (!bwd) {
     hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(float) * a.B * (3 * a.C + 1), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dc_ce_fwd_kernel<T>, dim3(gx, a.B), dim3(256), 0, s, a);
+    if (big)
+      hipLaunchKernelGGL((dc_ce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((dc_ce_fwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL(dc_ce_bwd_kernel<T>, dim3(gx, a.B), dim3(256), 0, s, a);
+    if (big)
+      hipLaunchKernelGGL((dc_ce_bwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((dc_ce_bwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
   }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -154,7 +161,7 @@ static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
 // torch.argmax) compared with the label map; one read of logits + target instead of argmax -> zeros -> scatter_ ->
 // three products -> three reductions (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 with
 // get_tp_fp_fn_tn, training/loss/dice.py:122-180).  counts[c] = {tp, fp, fn} as exact integers.
-template <typename T>
+template <typename T, int LS_MAXC>
 __global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__ logits, const int16_t* __restrict__ tgt,
                                                            unsigned long long* __restrict__ counts, int C, long V,
                                                            int vpb) {
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__
 extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const int16_t* target, void* counts_u64,
                                    int B, int C, long V, void* stream) {
   using namespace nnz;
-  if (!logits || !target || !counts_u64 || C < 1 || C > LS_MAXC || B < 1 || V < 1) return NNZ_EINVAL;
+  if (!logits || !target || !counts_u64 || C < 1 || C > LS_MAXC_BIG || B < 1 || V < 1) return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(counts_u64, 0, sizeof(unsigned long long) * 3 * C, s);
   if (e != hipSuccess) return (int)e;
@@ -217,12 +224,15 @@ extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const 
   if (vpb < 2048) vpb = 2048;
   if (vpb > V) vpb = V;
   const int gx = (int)((V + vpb - 1) / vpb);
-  if (logits_is_f16)
-    hipLaunchKernelGGL(argmax_stats_kernel<f16>, dim3(gx, B), dim3(256), 0, s, (const f16*)logits, target,
-                       (unsigned long long*)counts_u64, C, V, (int)vpb);
-  else
-    hipLaunchKernelGGL(argmax_stats_kernel<float>, dim3(gx, B), dim3(256), 0, s, (const float*)logits, target,
-                       (unsigned long long*)counts_u64, C, V, (int)vpb);
+#define NNZ_ARGMAX(TT, MC)                                                                                       \
+  hipLaunchKernelGGL((argmax_stats_kernel<TT, MC>), dim3(gx, B), dim3(256), 0, s, (const TT*)logits, target, \
+                     (unsigned long long*)counts_u64, C, V, (int)vpb)
+  if (logits_is_f16) {
+    if (C > 8) NNZ_ARGMAX(f16, LS_MAXC_BIG); else NNZ_ARGMAX(f16, 8);
+  } else {
+    if (C > 8) NNZ_ARGMAX(float, LS_MAXC_BIG); else NNZ_ARGMAX(float, 8);
+  }
+#undef NNZ_ARGMAX
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -77,8 +77,8 @@ def _fused_stats(net_output: torch.Tensor, target: torch.Tensor):
     if not net_output.is_cuda:
         raise RuntimeError("nnuzoo_amd losses run on MI355X through libnnuzoo_hip.so only (no CPU fallback); "
                            "the CPU restatement is oracle/losses.py (test-only)")
-    if net_output.shape[1] > 8:
-        raise NotImplementedError("fused Dice+CE kernel supports up to 8 classes")
+    if net_output.shape[1] > 32:
+        raise NotImplementedError("fused Dice+CE kernel supports up to 32 classes (register-resident softmax)")
     if target.ndim == net_output.ndim:
         assert target.shape[1] == 1, "target must be a label map (b, 1, ...)"
     tgt = target if target.dtype == torch.int16 else target.to(torch.int16)

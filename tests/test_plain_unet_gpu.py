@@ -132,3 +132,43 @@ def test_cpu_input_raises():
     _, net = build_pair(3, [32, 64, 128])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net.cpu()(torch.zeros(1, 1, 16, 16, 16))
+
+
+@pytest.mark.parametrize("num_classes,dim,patch", [(14, 3, (16, 16, 16)), (20, 2, (32, 48))])
+def test_many_classes(hip_lib, num_classes, dim, patch):
+    """datasets with more than 8 labels (BTCV 14, AMOS 16, ...): heads and the fused Dice+CE loss up to 32 classes"""
+    from oracle.losses import deep_supervision_loss
+    from nnuzoo_amd.training.loss import DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
+    import numpy as np
+    torch.manual_seed(0)
+    kw = planner_arch_kwargs(dim, 3, [32, 64, 128])
+    ref = OraclePlainConvUNet(1, num_classes=num_classes, **kw)
+    ref.apply(InitWeights_He(1e-2))
+    net = PlainConvUNet(1, num_classes=num_classes, **kw)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 1, *patch, generator=g)
+    scales = [[1.0] * dim, [0.5] * dim]
+    target = [torch.randint(0, num_classes, (2, 1, *[int(p * s) for p in patch]), generator=g).to(torch.int16)
+              for s in (1.0, 0.5)]
+    outs_ref = ref(x)
+    loss_ref = deep_supervision_loss(outs_ref, target, batch_dice=False)
+    loss_ref.backward()
+    w = np.array([1.0, 0.0])  # last output weight 0 like the trainer (2 outputs)
+    loss_fn = DeepSupervisionWrapper(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False, 'ddp': False},
+                                                    {}, weight_ce=1, weight_dice=1, ignore_label=None,
+                                                    dice_class=MemoryEfficientSoftDiceLoss), w / w.sum())
+    outs = net(x.cuda())
+    assert outs[0].shape == outs_ref[0].shape
+    for o, r in zip(outs, outs_ref):
+        assert torch.allclose(o.float().cpu(), r, rtol=2e-2, atol=2e-2 * r.abs().max().item())
+    loss = loss_fn(outs, [t.cuda() for t in target])
+    assert abs(float(loss) - float(loss_ref)) < 2e-2 * max(1.0, abs(float(loss_ref)))
+    loss.backward()
+    refp = dict(ref.named_parameters())
+    for n, p in net.named_parameters():
+        if "seg_layers.1" in n:       # the full-resolution head: K x C weight and bias gradients of all classes
+            gr = refp[n].grad
+            rel = (p.grad.cpu() - gr).norm().item() / (gr.norm().item() + 1e-12)
+            assert rel < 5e-2, (n, rel)
