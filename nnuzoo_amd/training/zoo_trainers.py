@@ -66,7 +66,10 @@ class _X2Trainer(nnUNetTrainer):
         self.was_initialized = True
 
     def _get_deep_supervision_scales(self):
-        return [list(s) for s in _X2_SCALES] if self.enable_deep_supervision else None
+        if not self.enable_deep_supervision:
+            return None
+        nd = len(self.configuration_manager.patch_size)   # the N-D plugins (SSND2Net) use the same 7 scales per axis
+        return [[s[0]] * nd for s in _X2_SCALES]
 
     def configure_optimizers(self):
         optimizer = AdamW(self.network.parameters(), lr=self.initial_lr, weight_decay=self.weight_decay, eps=1e-5,
@@ -133,3 +136,21 @@ class nnUNetTrainerSwT2Net(_X2Trainer):
     @staticmethod
     def build_network_architecture(*args, **kwargs):
         return _legacy_or_live(get_swt2net_from_plans, args, kwargs)
+
+
+class nnUNetTrainerSSND2Net(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerSSND2Net.py:18-118 (2-D and 3-D, AdamW 1e-4 / wd 5e-2, cosine)"""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.ssnd2net import get_ssnd2net_from_plans
+        return _legacy_or_live(lambda *a, **k: get_ssnd2net_from_plans(*a, small_mode=False, **k), args, kwargs)
+
+
+class nnUNetTrainerSSND2NetP(nnUNetTrainerSSND2Net):
+    """reference: nnUNetTrainerSSND2Net.py:121-142 (small_mode=True)"""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.ssnd2net import get_ssnd2net_from_plans
+        return _legacy_or_live(lambda *a, **k: get_ssnd2net_from_plans(*a, small_mode=True, **k), args, kwargs)

@@ -240,6 +240,47 @@ def gen_sliding_window():
     np.savez_compressed(os.path.join(OUT, "sliding_window.npz"), **out)
 
 
+def gen_ssnd2net():
+    """MU-stage forward fixtures (2-D 96^2, 3-D 24^3) + state_dict manifests of SSND2Net / SSND2NetP in both
+    dimensionalities, from the reference's nets/ssnd2net.py under the shim."""
+    import json
+    from nnunetv2.nets import ssnd2net
+    man = {}
+    # One MU stage per dimensionality (encoder + decoder of VSS/SSND blocks, patch merge / expand incl. axes that stop
+    # pooling at odd extents).  Whole-network outputs are NOT used as fixtures: with ~100 LayerNorm / InstanceNorm
+    # layers in sequence a 1e-6 difference between two correct scan implementations grows to 20 % of the output
+    # (measured with selective_scan_ref vs the oracle scan on the same weights); the outer wiring is pinned by the
+    # state_dict manifests below and by tools/check_ssnd2net_wiring.py (bit-identical outputs when both nets share one
+    # scan implementation).
+    for tag, patch, cin, nl in [("2d", (96, 96), 1, 7), ("3d", (24, 24, 24), 8, 5)]:
+        torch.manual_seed(0)
+        mu = ssnd2net.MU(spatial_dims=len(patch), factorization_type="cross-scan", in_ch=cin, mid_ch=16, out_ch=64,
+                         n_layers=nl, input_patch_size=tuple(patch), patch_size=1, add_last=True)
+        det_fill(mu)
+        mu.eval()
+        i = torch.arange(cin * int(np.prod(patch)), dtype=torch.float64)
+        x = torch.cos(0.173 * i + 0.3).float().reshape(1, cin, *patch)
+        with torch.no_grad():
+            y = mu(x)
+        # x is regenerated from its formula by the test; of y keep every 8th channel + per-channel moments of all
+        np.savez_compressed(os.path.join(OUT, f"ssnd2net_MU_{tag}.npz"), y_sub=y[:, ::8].numpy(),
+                            y_mean=y.double().mean(dim=tuple(range(2, y.dim()))).numpy(),
+                            y_absmean=y.double().abs().mean(dim=tuple(range(2, y.dim()))).numpy(),
+                            cfg=np.array([cin, 16, 64, nl]))
+    for tag, patch in [("2d", (96, 96)), ("3d", (24, 24, 24))]:
+        torch.manual_seed(0)
+        net = ssnd2net.SSND2NetP(spatial_dims=len(patch), factorization_type="cross-scan", in_ch=1, out_ch=2,
+                                 deep_supervision=True, input_patch_size=list(patch))
+        man[f"SSND2NetP_{tag}"] = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        torch.manual_seed(0)
+        big = ssnd2net.SSND2Net(spatial_dims=len(patch), factorization_type="cross-scan", in_ch=1, out_ch=2,
+                                deep_supervision=True, input_patch_size=list(patch))
+        man[f"SSND2Net_{tag}"] = [(k, tuple(v.shape)) for k, v in big.state_dict().items()]
+    import gzip
+    with gzip.open(os.path.join(OUT, "state_dict_manifest_ssnd2net.json.gz"), "wt") as f:
+        json.dump({k: [[n, list(s_)] for n, s_ in v] for k, v in man.items()}, f)
+
+
 def gen_mamba(ref):
     """1-D Mamba block: the reference's vendored module (nets/seg_mamba/mamba_simple.py) run on CPU.
     bimamba "none" goes through its slow path (conv1d + act, x/dt projections, selective_scan_ref with z);
@@ -287,11 +328,13 @@ def gen_mamba(ref):
 
 if __name__ == "__main__":
     ref = ref_shim.install()
-    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba"]
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba", "ssnd2net"]
     if "sw" in which:
         gen_sliding_window()
     if "mamba" in which:
         gen_mamba(ref)
+    if "ssnd2net" in which:
+        gen_ssnd2net()
     if "scan" in which:
         gen_selective_scan(ref)
     if "loss" in which:

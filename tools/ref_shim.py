@@ -6,7 +6,7 @@ Substitutions (arithmetic that is actually replaced):
   timm.layers.DropPath            -> standard stochastic depth (identity in eval())
   timm.layers.trunc_normal_       -> torch.nn.init.trunc_normal_
   monai Convolution(conv_only)    -> nn.Sequential with a child named `conv` = nn.Conv{2,3}d(same padding)
-  monai UpSample(nontrainable)    -> nn.Upsample(size, mode, align_corners=False)
+  monai UpSample(nontrainable)    -> nn.Upsample(size, mode, align_corners=False); interp_mode LINEAR -> bi/trilinear by dims
   mamba_ssm selective_scan_fn     -> the reference's own selective_scan_ref
                                      (nnunetv2/nets/seg_mamba/selective_scan_interface.py:86-152, extracted by ast)
   dynamic_network_architectures init_last_bn_before_add_to_0 -> no-op (no residual-BN blocks in these nets)
@@ -80,6 +80,8 @@ class UpSample(nn.Module):
     def __init__(self, spatial_dims, size=None, mode="nontrainable", interp_mode="bilinear", align_corners=False, **kw):
         super().__init__()
         im = interp_mode.value if isinstance(interp_mode, enum.Enum) else interp_mode
+        if im == "linear":
+            im = {1: "linear", 2: "bilinear", 3: "trilinear"}[spatial_dims]
         self.up = nn.Upsample(size=size, mode=im, align_corners=align_corners)
 
     def forward(self, x):
@@ -95,6 +97,7 @@ class InterpolateMode(str, enum.Enum):
     BILINEAR = "bilinear"
     TRILINEAR = "trilinear"
     NEAREST = "nearest"
+    LINEAR = "linear"   # monai resolves "linear" by spatial_dims: bilinear (2-D) / trilinear (3-D)
 
 
 def load_selective_scan_ref():
@@ -147,6 +150,8 @@ def install():
     import monai.networks.blocks
     monai.networks.blocks.Convolution = Convolution
     monai.networks.blocks.UpSample = UpSample
+    import monai.networks.blocks.upsample
+    monai.networks.blocks.upsample.UpSample = UpSample
     import monai.utils
     monai.utils.UpsampleMode = UpsampleMode
     monai.utils.InterpolateMode = InterpolateMode
