@@ -493,25 +493,39 @@ extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void*
       return NNZ_EINVAL;
   for (int g = 0; g < d.ngroups; ++g)
     if (d.groups[g].ntaps > 27 || d.groups[g].ntaps < 1) return NNZ_EINVAL;
-  ConvDev p;
-  p.in = (const f16*)in;
-  p.out = (f16*)out;
-  p.w = (const f16*)w_packed;
-  p.bias = bias;
-  p.stats = stats;
-  p.d = d;
+  // The kernels index voxels with 32-bit element offsets: batches whose tensors pass 2^31 elements (288 GB of HBM make
+  // batch 16+ of 128^3 x 64 channels realistic) are launched in sample chunks that stay below it.
+  const long in_per_n = (long)d.in_dims[0] * d.in_dims[1] * d.in_dims[2] * d.ldi;
+  const long out_per_n = (long)d.out_dims[0] * d.out_dims[1] * d.out_dims[2] * d.ldo;
+  const long per_n = in_per_n > out_per_n ? in_per_n : out_per_n;
+  if (per_n >= (1L << 31)) return NNZ_EINVAL;
+  int chunk = (int)(((1L << 31) - 1) / per_n);
+  if (chunk > d.N) chunk = d.N;
   hipStream_t s = (hipStream_t)stream;
   const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&
                    d.ext[1] == d.ext[2] && d.m_dims[0] > 1;
-  if (!iso) return launch_dyn(p, s);
-  const int is = d.in_stride[0], ext = d.ext[0];
-  if (is == 1) {
-    if (ext == 0) return launch_tile<1, 0>(p, s);
-    if (ext == 1) return launch_tile<1, 1>(p, s);
-    return launch_tile<1, 2>(p, s);
-  } else {
-    if (d.Cout % 64) return NNZ_EINVAL;  // the IS=2 tiles split N over waves
-    if (ext <= 1) return launch_tile<2, 1>(p, s);
-    return launch_tile<2, 2>(p, s);
+  for (int n0 = 0; n0 < d.N; n0 += chunk) {
+    ConvDev p;
+    p.in = (const f16*)in + (size_t)n0 * in_per_n;
+    p.out = (f16*)out + (size_t)n0 * out_per_n;
+    p.w = (const f16*)w_packed;
+    p.bias = bias;
+    p.stats = stats ? stats + (size_t)n0 * d.Cout * 2 : nullptr;
+    p.d = d;
+    p.d.N = d.N - n0 < chunk ? d.N - n0 : chunk;
+    int rc;
+    if (!iso) {
+      rc = launch_dyn(p, s);
+    } else {
+      const int is = d.in_stride[0], ext = d.ext[0];
+      if (is == 1) {
+        rc = ext == 0 ? launch_tile<1, 0>(p, s) : ext == 1 ? launch_tile<1, 1>(p, s) : launch_tile<1, 2>(p, s);
+      } else {
+        if (d.Cout % 64) return NNZ_EINVAL;  // the IS=2 tiles split N over waves
+        rc = ext <= 1 ? launch_tile<2, 1>(p, s) : launch_tile<2, 2>(p, s);
+      }
+    }
+    if (rc != NNZ_OK) return rc;
   }
+  return NNZ_OK;
 }

@@ -339,31 +339,42 @@ extern "C" int nnz_conv_tap_wgrad(const void* boxed, const void* plain, float* d
     if ((d.in_stride[a] != 1 && d.in_stride[a] != 2) || (d.out_stride[a] != 1 && d.out_stride[a] != 2) ||
         d.ext[a] < 0 || d.ext[a] > 2)
       return NNZ_EINVAL;
-  WgradDev p;
-  p.p = (const f16*)boxed;
-  p.q = (const f16*)plain;
-  p.dw = dw;
-  p.d = d;
+  // 32-bit voxel offsets inside the kernel: batches beyond 2^31 elements per tensor run as sample chunks that
+  // accumulate into the same dW (zeroed once)
+  const long p_per_n = (long)d.in_dims[0] * d.in_dims[1] * d.in_dims[2] * d.ldi;
+  const long q_per_n = (long)d.out_dims[0] * d.out_dims[1] * d.out_dims[2] * d.ldo;
+  const long per_n = p_per_n > q_per_n ? p_per_n : q_per_n;
+  if (per_n >= (1L << 31)) return NNZ_EINVAL;
+  int chunk = (int)(((1L << 31) - 1) / per_n);
+  if (chunk > d.N) chunk = d.N;
   hipStream_t s = (hipStream_t)stream;
-  const bool z = pre_zeroed != 0;
   const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&
                    d.ext[1] == d.ext[2] && d.m_dims[0] > 1;
-  if (iso) {
-    const int ext = d.ext[0];
-    if (d.in_stride[0] == 1) {
-      if (ext == 0) return launch_wg_iso<4, 8, 8, 1, 0>(p, s, z);
-      if (ext == 1) return launch_wg_iso<4, 8, 8, 1, 1>(p, s, z);
-      return launch_wg_iso<4, 8, 8, 1, 2>(p, s, z);
-    }
-    if (ext <= 1) return launch_wg_iso<2, 4, 8, 2, 1>(p, s, z);
-    return launch_wg_iso<2, 4, 8, 2, 2>(p, s, z);
-  }
-  // per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) and anisotropic 3-D plans
   const bool strided = d.in_stride[0] == 2 || d.in_stride[1] == 2 || d.in_stride[2] == 2;
-  if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
-    if (strided) return launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, z);
-    return launch_wg<1, 32, 8, 6, WGeoDyn>(p, s, z);
+  for (int n0 = 0; n0 < d.N; n0 += chunk) {
+    WgradDev p;
+    p.p = (const f16*)boxed + (size_t)n0 * p_per_n;
+    p.q = (const f16*)plain + (size_t)n0 * q_per_n;
+    p.dw = dw;
+    p.d = d;
+    p.d.N = d.N - n0 < chunk ? d.N - n0 : chunk;
+    const bool z = pre_zeroed != 0 || n0 > 0;
+    int rc;
+    if (iso) {
+      const int ext = d.ext[0];
+      if (d.in_stride[0] == 1)
+        rc = ext == 0 ? launch_wg_iso<4, 8, 8, 1, 0>(p, s, z)
+                      : ext == 1 ? launch_wg_iso<4, 8, 8, 1, 1>(p, s, z) : launch_wg_iso<4, 8, 8, 1, 2>(p, s, z);
+      else
+        rc = ext <= 1 ? launch_wg_iso<2, 4, 8, 2, 1>(p, s, z) : launch_wg_iso<2, 4, 8, 2, 2>(p, s, z);
+    } else if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
+      // per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) ...
+      rc = strided ? launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, z) : launch_wg<1, 32, 8, 6, WGeoDyn>(p, s, z);
+    } else {
+      // ... and anisotropic 3-D plans
+      rc = strided ? launch_wg<2, 4, 8, 12, WGeoDyn>(p, s, z) : launch_wg<4, 8, 8, 10, WGeoDyn>(p, s, z);
+    }
+    if (rc != NNZ_OK) return rc;
   }
-  if (strided) return launch_wg<2, 4, 8, 12, WGeoDyn>(p, s, z);
-  return launch_wg<4, 8, 8, 10, WGeoDyn>(p, s, z);
+  return NNZ_OK;
 }

@@ -380,3 +380,42 @@ def test_batched_weight_pack_matches_single(hip_lib):
     torch.cuda.synchronize()
     for got, ref in expect:
         assert torch.equal(got, ref)
+
+
+def test_conv_batches_beyond_2g_elements(hip_lib):
+    """tensors with more than 2^31 elements (5 samples x 128^3 voxels x channel stride 256): the entry points split the
+    batch into sample chunks (32-bit voxel offsets inside the kernels); forward + statistics and weight gradient."""
+    g = torch.Generator().manual_seed(21)
+    N, dims, C, ld = 5, (128, 128, 128), 32, 256
+    V = int(np.prod(dims))
+    x1 = h(torch.randn(1, C, *dims, generator=g))
+    w = h(torch.randn(C, C, 3, 3, 3, generator=g) * 0.05)
+    ref = F.conv3d(x1, w, None, padding=1)
+    xin = torch.zeros((N, V, ld), dtype=torch.float16, device=DEV)
+    xin[:, :, 64:64 + C] = to_cl(x1)                      # every sample holds the same patch in channels 64..95
+    out = torch.zeros((N, V, ld), dtype=torch.float16, device=DEV)
+    pt = PreparedTable(cp.conv_forward(N, dims, C, C, ldi=ld, ldo=ld))
+    wp = ops.pack_weight(w.to(DEV), pt, C, C, 27, C * 27, 1)
+    stats = torch.zeros((N, C, 2), dtype=torch.float32, device=DEV)
+    ops.conv_tap_forward(pt, xin[:, :, 64:], wp, None, out[:, :, 128:], stats=stats)
+    torch.cuda.synchronize()
+    got0 = from_cl(out[0:1, :, 128:128 + C].contiguous(), dims)
+    close(got0, ref)
+    for n in range(1, N):
+        assert torch.equal(out[n], out[0]), n
+    assert out[:, :, :128].abs().max().item() == 0 and out[:, :, 128 + C:].abs().max().item() == 0
+    # (fp32 atomics: the per-sample sums agree to summation-order noise, absolute in the scale of the sum of squares)
+    assert torch.allclose(stats[1:], stats[:1].expand(N - 1, C, 2), rtol=1e-5, atol=1e-6 * stats.abs().max().item())
+    # weight gradient over the 5 chunks' samples = 5 x the single-sample gradient
+    dy1 = h(torch.randn(ref.shape, generator=g))
+    wz = torch.zeros(C, C, 3, 3, 3, requires_grad=True)
+    F.conv3d(x1, wz, None, padding=1).backward(dy1)
+    dyb = torch.zeros((N, V, ld), dtype=torch.float16, device=DEV)
+    dyb[:, :, :C] = to_cl(dy1)
+    ptw = PreparedTable(cp.conv_wgrad(N, dims, C, C, ldx=ld, lddy=ld))
+    dw = torch.empty((27, C, C), dtype=torch.float32, device=DEV)
+    ops.conv_tap_wgrad(ptw, xin[:, :, 64:], dyb, dw)
+    gw = torch.empty((C, C, 3, 3, 3), dtype=torch.float32, device=DEV)
+    ops.unpack_wgrad(dw, gw, C, C, 27, 27, C * 27, 1, ptw)
+    torch.cuda.synchronize()
+    close(gw.cpu(), N * wz.grad, rtol=2e-3, atol_frac=1e-3)
