@@ -45,6 +45,14 @@ int nnz_conv_tap_forward_stats(const void* in_f16, void* out_f16, const void* w_
                                const nnz_conv_desc* desc, float* stats, void* stream);
 int nnz_conv_tap_wgrad(const void* boxed_f16, const void* plain_f16, float* dw /* [T][A][B] */,
                        const nnz_conv_desc* desc, int dw_pre_zeroed, void* stream);
+/* two-stage form used by the training schedule: every workgroup stores its [T][32][32] partial block into `workspace`
+ * (nnz_conv_tap_wgrad_workspace_floats(desc) floats, no zero-fill, no atomics), then one reduction kernel sums the
+ * blocks in a fixed order straight into the torch-layout gradient
+ *   grad[a*sa + b*sb + ksel[t]*sk] (+)= dW[t][a][b]          (deterministic; replaces wgrad + unpack)           */
+long nnz_conv_tap_wgrad_workspace_floats(const nnz_conv_desc* desc);
+int nnz_conv_tap_wgrad_to_grad(const void* boxed_f16, const void* plain_f16, float* workspace, long ws_floats,
+                               float* grad, long sa, long sb, long sk, const int* ksel, int accumulate,
+                               const nnz_conv_desc* desc, void* stream);
 int nnz_pack_conv_weight(const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
                          const int* ksel, void* stream);
 /* batched packing: a device-resident table of nnz_pack_job_bytes()-sized records (filled on the host with

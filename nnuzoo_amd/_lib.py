@@ -64,6 +64,8 @@ SIGNATURES = {
     "nnz_conv_tap_forward": [_vp, _vp, _vp, _fp, _dp, _vp],
     "nnz_conv_tap_forward_stats": [_vp, _vp, _vp, _fp, _dp, _fp, _vp],
     "nnz_conv_tap_wgrad": [_vp, _vp, _fp, _dp, _i, _vp],
+    "nnz_conv_tap_wgrad_workspace_floats": [_dp],
+    "nnz_conv_tap_wgrad_to_grad": [_vp, _vp, _fp, _l, _fp, _l, _l, _l, _ip, _i, _dp, _vp],
     "nnz_pack_conv_weight": [_fp, _vp, _i, _i, _i, _l, _l, _l, _ip, _vp],
     "nnz_pack_job_bytes": [],
     "nnz_pack_job_fill": [_vp, _fp, _vp, _i, _i, _i, _l, _l, _l, _ip],
@@ -99,7 +101,7 @@ SIGNATURES = {
     "nnz_selective_scan_backward": [_fp] * 18 + [_i] * 6 + [_vp],
 }
 
-_LONG_RESULT = {"nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats"}
+_LONG_RESULT = {"nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats", "nnz_conv_tap_wgrad_workspace_floats"}
 _lib = None
 
 

@@ -22,7 +22,9 @@ namespace nnz {
 struct WgradDev {
   const f16* p;  // boxed operand
   const f16* q;  // plain operand
-  float* dw;     // [T][A][B] fp32, zeroed by the launcher
+  float* dw;     // [T][A][B] fp32, zeroed by the launcher (atomic mode)
+  float* part;   // [splits][T][A][B] fp32 partial blocks, plain stores (two-stage mode); null = atomic mode
+  long tab;      // T*A*B
   nnz_conv_desc d;  // Cin = A (boxed channels), Cout = B (plain channels), ldi/ldo their strides
   int tiles[3];
   int ntiles;   // per launch: N * tiles
@@ -252,18 +254,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     const int t = wave + 4 * i;
     if (i < ntw) {
       const int widx = p.d.taps[t].widx;
-      float* dst = p.dw + ((size_t)widx * A + a0) * B + b0 + (lane & 31);
+      if (p.part) {
+        // two-stage mode: every (pair, split) workgroup owns its 32x32 block of part[split]: plain 128-byte row
+        // stores, summed in fixed order by wgrad_reduce_kernel (deterministic, no zero-fill, no atomics)
+        float* dst = p.part + (size_t)split * p.tab + ((size_t)widx * A + a0) * B + b0 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        atomicAdd(dst + (size_t)row * B, acc[i][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          dst[(size_t)row * B] = acc[i][r];
+        }
+      } else {
+        float* dst = p.dw + ((size_t)widx * A + a0) * B + b0 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          atomicAdd(dst + (size_t)row * B, acc[i][r]);
+        }
       }
     }
   }
 }
 
+struct WgLaunchOpt {
+  bool pre_zeroed = false;
+  long max_wgs = 4096;     // two-stage mode: bounded by the partial workspace
+  int* splits_used = nullptr;
+};
+
 template <int TD, int TH, int TW, int LPT_BOX, int MAXT, class G>
-static int launch_wg_t(const WgradDev& base, hipStream_t stream, bool pre_zeroed) {
+static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchOpt& opt) {
+  const bool pre_zeroed = opt.pre_zeroed;
   using C = WgCfg<TD, TH, TW>;
   WgradDev p = base;
   const G geo(p.d);
@@ -283,8 +303,9 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, bool pre_zeroed
   int best = 1;
   double best_cost = 1e30;
   const double t_tile = 4.0 * (C::KB / 16.0) * (MAXT / 7.0);
-  const double t_flush = p.d.ntaps_total * 4096.0 / 1.1e6;
-  for (int s = 1; s <= p.ntiles && (long)s * pairs <= 4096; s *= 2) {
+  // (two-stage mode: the block is stored once and read once at ~5 TB/s instead of atomically added at 1.1 TB/s)
+  const double t_flush = p.part ? p.d.ntaps_total * 4096.0 * 2 / 5.0e6 : p.d.ntaps_total * 4096.0 / 1.1e6;
+  for (int s = 1; s <= p.ntiles && (long)s * pairs <= opt.max_wgs; s *= 2) {
     const long wgs = (long)s * pairs;
     const double rounds = (double)((wgs + 511) / 512);
     const double cost = rounds * ((p.ntiles + s - 1) / s) * t_tile + wgs * t_flush;
@@ -303,27 +324,81 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, bool pre_zeroed
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  if (!pre_zeroed) {
+  if (!p.part && !pre_zeroed) {
     hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.d.ntaps_total * p.d.Cin * p.d.Cout, stream);
     if (e != hipSuccess) return (int)e;
   }
+  if (opt.splits_used) *opt.splits_used = splits;
   hipLaunchKernelGGL(kern, dim3(pairs * splits), dim3(256), lds, stream, p);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
 
 template <int TD, int TH, int TW, int LPT_BOX, class G>
-static int launch_wg(const WgradDev& p, hipStream_t stream, bool pre_zeroed) {
+static int launch_wg(const WgradDev& p, hipStream_t stream, const WgLaunchOpt& opt) {
   const int per_wave = (p.d.ntaps_total + 3) / 4;
-  if (per_wave <= 2) return launch_wg_t<TD, TH, TW, LPT_BOX, 2, G>(p, stream, pre_zeroed);
-  return launch_wg_t<TD, TH, TW, LPT_BOX, 7, G>(p, stream, pre_zeroed);
+  if (per_wave <= 2) return launch_wg_t<TD, TH, TW, LPT_BOX, 2, G>(p, stream, opt);
+  return launch_wg_t<TD, TH, TW, LPT_BOX, 7, G>(p, stream, opt);
 }
 
 template <int TD, int TH, int TW, int IS, int EXT>
-static int launch_wg_iso(const WgradDev& p, hipStream_t stream, bool pre_zeroed) {
+static int launch_wg_iso(const WgradDev& p, hipStream_t stream, const WgLaunchOpt& opt) {
   constexpr int lpt =
       (((TD - 1) * IS + EXT + 1) * ((TH - 1) * IS + EXT + 1) * ((TW - 1) * IS + EXT + 1) * 4 + 255) / 256;
-  return launch_wg<TD, TH, TW, lpt, WGeoIso<IS, EXT>>(p, stream, pre_zeroed);
+  return launch_wg<TD, TH, TW, lpt, WGeoIso<IS, EXT>>(p, stream, opt);
+}
+
+// geometry dispatch shared by the atomic and the two-stage entry points
+static int launch_wgrad_any(const WgradDev& p, hipStream_t s, const WgLaunchOpt& o) {
+  const nnz_conv_desc& d = p.d;
+  const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&
+                   d.ext[1] == d.ext[2] && d.m_dims[0] > 1;
+  const bool strided = d.in_stride[0] == 2 || d.in_stride[1] == 2 || d.in_stride[2] == 2;
+  if (iso) {
+    const int ext = d.ext[0];
+    if (d.in_stride[0] == 1)
+      return ext == 0 ? launch_wg_iso<4, 8, 8, 1, 0>(p, s, o)
+                      : ext == 1 ? launch_wg_iso<4, 8, 8, 1, 1>(p, s, o) : launch_wg_iso<4, 8, 8, 1, 2>(p, s, o);
+    return ext <= 1 ? launch_wg_iso<2, 4, 8, 2, 1>(p, s, o) : launch_wg_iso<2, 4, 8, 2, 2>(p, s, o);
+  }
+  // per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) and anisotropic 3-D plans
+  if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1)
+    return strided ? launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, o) : launch_wg<1, 32, 8, 6, WGeoDyn>(p, s, o);
+  return strided ? launch_wg<2, 4, 8, 12, WGeoDyn>(p, s, o) : launch_wg<4, 8, 8, 10, WGeoDyn>(p, s, o);
+}
+
+struct WgKsel {
+  int k[32];
+};
+
+// grad[a*sa + b*sb + ksel[t]*sk] (+)= sum_s part[s][t][a][b], s in fixed order: thread = (element, split group of 4)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long tab,
+                                                           float* __restrict__ grad, int A, int B, long sa, long sb,
+                                                           long sk, WgKsel ks, int accumulate) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x;
+  const int el = tid & 63, sg = tid >> 6;
+  const long e = (long)blockIdx.x * 64 + el;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < tab) {
+    int s = sg;
+    for (; s + 4 < splits; s += 8) {  // two loads in flight
+      s0 += part[(size_t)s * tab + e];
+      s1 += part[(size_t)(s + 4) * tab + e];
+    }
+    if (s < splits) s0 += part[(size_t)s * tab + e];
+  }
+  red[sg][el] = s0 + s1;
+  __syncthreads();
+  if (sg == 0 && e < tab) {
+    const float v = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    const int b = (int)(e % B);
+    const long q = e / B;
+    const int a = (int)(q % A);
+    const int t = (int)(q / A);
+    float* g = grad + a * sa + b * sb + ks.k[t] * sk;
+    *g = accumulate ? *g + v : v;
+  }
 }
 
 }  // namespace nnz
@@ -348,33 +423,84 @@ extern "C" int nnz_conv_tap_wgrad(const void* boxed, const void* plain, float* d
   int chunk = (int)(((1L << 31) - 1) / per_n);
   if (chunk > d.N) chunk = d.N;
   hipStream_t s = (hipStream_t)stream;
-  const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&
-                   d.ext[1] == d.ext[2] && d.m_dims[0] > 1;
-  const bool strided = d.in_stride[0] == 2 || d.in_stride[1] == 2 || d.in_stride[2] == 2;
   for (int n0 = 0; n0 < d.N; n0 += chunk) {
-    WgradDev p;
+    WgradDev p = {};
     p.p = (const f16*)boxed + (size_t)n0 * p_per_n;
     p.q = (const f16*)plain + (size_t)n0 * q_per_n;
     p.dw = dw;
     p.d = d;
     p.d.N = d.N - n0 < chunk ? d.N - n0 : chunk;
-    const bool z = pre_zeroed != 0 || n0 > 0;
-    int rc;
-    if (iso) {
-      const int ext = d.ext[0];
-      if (d.in_stride[0] == 1)
-        rc = ext == 0 ? launch_wg_iso<4, 8, 8, 1, 0>(p, s, z)
-                      : ext == 1 ? launch_wg_iso<4, 8, 8, 1, 1>(p, s, z) : launch_wg_iso<4, 8, 8, 1, 2>(p, s, z);
-      else
-        rc = ext <= 1 ? launch_wg_iso<2, 4, 8, 2, 1>(p, s, z) : launch_wg_iso<2, 4, 8, 2, 2>(p, s, z);
-    } else if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
-      // per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) ...
-      rc = strided ? launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, z) : launch_wg<1, 32, 8, 6, WGeoDyn>(p, s, z);
-    } else {
-      // ... and anisotropic 3-D plans
-      rc = strided ? launch_wg<2, 4, 8, 12, WGeoDyn>(p, s, z) : launch_wg<4, 8, 8, 10, WGeoDyn>(p, s, z);
-    }
+    WgLaunchOpt o;
+    o.pre_zeroed = pre_zeroed != 0 || n0 > 0;
+    const int rc = launch_wgrad_any(p, s, o);
     if (rc != NNZ_OK) return rc;
   }
+  return NNZ_OK;
+}
+
+extern "C" long nnz_conv_tap_wgrad_workspace_floats(const nnz_conv_desc* desc) {
+  if (!desc) return 0;
+  // up to 1024 workgroups' [T][32][32] blocks (>= one full [T][A][B] image for every channel-pair count)
+  const long blk = (long)desc->ntaps_total * 1024;
+  const long pairs = (long)(desc->Cin / 32) * (desc->Cout / 32);
+  const long wgs = pairs > 1024 ? pairs : 1024;
+  return wgs * blk;
+}
+
+extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, float* workspace, long ws_floats,
+                                          float* grad, long sa, long sb, long sk, const int* ksel, int accumulate,
+                                          const nnz_conv_desc* desc, void* stream) {
+  using namespace nnz;
+  if (!boxed || !plain || !workspace || !grad || !ksel || !desc) return NNZ_EINVAL;
+  const nnz_conv_desc& d = *desc;
+  if (d.Cin % 32 || d.Cout % 32 || d.ngroups != 1 || d.ntaps_total > 28 || d.ntaps_total < 1 || d.ldi % 8 || d.ldo % 8)
+    return NNZ_EINVAL;
+  for (int a = 0; a < 3; ++a)
+    if ((d.in_stride[a] != 1 && d.in_stride[a] != 2) || (d.out_stride[a] != 1 && d.out_stride[a] != 2) ||
+        d.ext[a] < 0 || d.ext[a] > 2)
+      return NNZ_EINVAL;
+  const long tab = (long)d.ntaps_total * d.Cin * d.Cout;
+  const long pairs = (long)(d.Cin / 32) * (d.Cout / 32);
+  if (ws_floats < tab) return NNZ_EINVAL;
+  const long p_per_n = (long)d.in_dims[0] * d.in_dims[1] * d.in_dims[2] * d.ldi;
+  const long q_per_n = (long)d.out_dims[0] * d.out_dims[1] * d.out_dims[2] * d.ldo;
+  const long per_n = p_per_n > q_per_n ? p_per_n : q_per_n;
+  if (per_n >= (1L << 31)) return NNZ_EINVAL;
+  int chunk = (int)(((1L << 31) - 1) / per_n);
+  if (chunk > d.N) chunk = d.N;
+  hipStream_t s = (hipStream_t)stream;
+  WgKsel ks;
+  for (int i = 0; i < 32; ++i) ks.k[i] = i < d.ntaps_total ? ksel[i] : 0;
+  int splits = 1;
+  if (chunk >= d.N) {
+    // two-stage: partial blocks in the workspace, then the fixed-order reduction straight into the torch-layout grad
+    WgradDev p = {};
+    p.p = (const f16*)boxed; p.q = (const f16*)plain; p.part = workspace; p.tab = tab; p.d = d;
+    WgLaunchOpt o;
+    o.max_wgs = ws_floats / ((long)d.ntaps_total * 1024);  // workgroups whose blocks fit: splits * pairs <= this
+    if (o.max_wgs < pairs) return NNZ_EINVAL;
+    o.splits_used = &splits;
+    const int rc = launch_wgrad_any(p, s, o);
+    if (rc != NNZ_OK) return rc;
+  } else {
+    // batch beyond 2^31 elements: sample chunks accumulate atomically into one [T][A][B] image in the workspace
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * tab, s);
+    if (e != hipSuccess) return (int)e;
+    for (int n0 = 0; n0 < d.N; n0 += chunk) {
+      WgradDev p = {};
+      p.p = (const f16*)boxed + (size_t)n0 * p_per_n;
+      p.q = (const f16*)plain + (size_t)n0 * q_per_n;
+      p.dw = workspace; p.d = d;
+      p.d.N = d.N - n0 < chunk ? d.N - n0 : chunk;
+      WgLaunchOpt o;
+      o.pre_zeroed = true;
+      const int rc = launch_wgrad_any(p, s, o);
+      if (rc != NNZ_OK) return rc;
+    }
+  }
+  const long blocks = (tab + 63) / 64;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splits, tab,
+                     grad, d.Cin, d.Cout, sa, sb, sk, ks, accumulate);
+  NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -102,6 +102,20 @@ def conv_tap_wgrad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, 
                             stream_ptr()))
 
 
+def conv_tap_wgrad_workspace_floats(pt: PreparedTable) -> int:
+    return int(_lib.load().nnz_conv_tap_wgrad_workspace_floats(C.byref(pt.desc)))
+
+
+def conv_tap_wgrad_to_grad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, ws: torch.Tensor,
+                           grad: torch.Tensor, sa: int, sb: int, sk: int, accumulate: bool = False) -> None:
+    """weight gradient straight into the torch-layout `grad` (two-stage, deterministic): partial blocks in `ws`, then a
+    fixed-order reduction; grad[a*sa + b*sb + t*sk] with (a, b) = (boxed, plain) channels"""
+    _f16(boxed, "wgrad.boxed"); _f16(plain, "wgrad.plain"); _f32(ws, "wgrad.ws"); _f32(grad, "wgrad.grad")
+    TIMER.wrap("conv_wgrad_kernel", pt.flops,
+               lambda: call("nnz_conv_tap_wgrad_to_grad", ptr(boxed), ptr(plain), ptr(ws), ws.numel(), ptr(grad), sa, sb,
+                            sk, pt.ident_ksel, int(accumulate), C.byref(pt.desc), stream_ptr()))
+
+
 class PackJobTable:
     """Device-resident table of weight-pack jobs (one launch packs all of them)."""
 

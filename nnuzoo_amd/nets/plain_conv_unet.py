@@ -242,16 +242,15 @@ class _Plan:
                 if i > 0:
                     b.x_ld = self.enc_blocks[s][i - 1].y_ld
         self.all_blocks: List[_Block] = [b for blocks in self.enc_blocks + self.dec_blocks for b in blocks]
-        so = do = 0
+        so = 0
         for b in self.all_blocks:
             b.prepare()
             b.stats_off, so = so, so + N * b.cout * 2          # slice of the per-step statistics buffer
-            b.dw_off = do
-            if not b.stem:
-                do += b.nk * b.cin * b.cout                       # slice of the per-step dW buffer
-        for u in self.ups:
-            u.dw_off, do = do, do + u.nk * u.cout * u.cin
-        self.stats_floats, self.dw_floats = so, do
+        self.stats_floats = so
+        # partial-block workspace of the two-stage weight gradients (shared by all layers: they run one after another)
+        self.wgrad_ws_floats = max([ops.conv_tap_wgrad_workspace_floats(b.wgrad) for b in self.all_blocks if not b.stem]
+                                   + [ops.conv_tap_wgrad_workspace_floats(u.wgrad) for u in self.ups])
+        self.wgrad_ws = None
         self.pack_fwd = self.pack_bwd = None                      # built on first use (needs device pointers)
 
     def build_pack_tables(self, dev):
@@ -512,14 +511,13 @@ class PlainConvUNet(nn.Module):
             ops.stem_wgrad(x_in, draw, gw, (b.N, *b.in_dims), b.cout)
         else:
             nk = b.nk
-            dw = self._dw_all[b.dw_off:b.dw_off + nk * b.cin * b.cout].view(nk, b.cin, b.cout)
+            # dW[t][cin][cout] -> torch layout (cout, cin, *k): a = cin (stride nk), b = cout (stride cin*nk), t stride 1
             if b.padded:
-                ops.conv_tap_wgrad(b.wgrad, self._padded_input(b, x_in), draw, dw, pre_zeroed=True)
-                ops.unpack_wgrad(dw, b.gw_pad, b.cin, b.cout, nk, nk, b.cin * nk, 1, b.wgrad)
+                ops.conv_tap_wgrad_to_grad(b.wgrad, self._padded_input(b, x_in), draw, self._wgrad_ws, b.gw_pad, nk,
+                                           b.cin * nk, 1)
                 gw.copy_(b.gw_pad[:, :b.cin_w].reshape(gw.shape))
             else:
-                ops.conv_tap_wgrad(b.wgrad, x_in, draw, dw, pre_zeroed=True)
-                ops.unpack_wgrad(dw, gw, b.cin, b.cout, nk, nk, b.cin * nk, 1, b.wgrad)
+                ops.conv_tap_wgrad_to_grad(b.wgrad, x_in, draw, self._wgrad_ws, gw, nk, b.cin * nk, 1)
                 if b.zero_dx and not dx_acc:
                     dx_out.zero_()  # k1 s2 axes: odd input positions are outside every output's footprint
                 ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
@@ -559,7 +557,9 @@ class PlainConvUNet(nn.Module):
         self._arena_trace = []
         plan.pack_bwd.run()
         self._red_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
-        self._dw_all = torch.zeros(plan.dw_floats, dtype=torch.float32, device=dev)
+        if plan.wgrad_ws is None:
+            plan.wgrad_ws = torch.empty(plan.wgrad_ws_floats, dtype=torch.float32, device=dev)
+        self._wgrad_ws = plan.wgrad_ws
         gout_by_level = {lvl: g for lvl, g in zip(rec["out_levels"], gouts)}
         g_cur = None  # gradient wrt the current decoder stage output (act), contiguous [N, V, C]
         g_cats = [None] * (S - 1)
@@ -605,10 +605,9 @@ class PlainConvUNet(nn.Module):
             g_up = g_act  # channel slice [:C] of the cat gradient, ld = 2C
             Vb = int(np.prod(up.in_dims))
             nk = up.nk
-            dwt = self._dw_all[up.dw_off:up.dw_off + nk * up.cout * up.cin].view(nk, up.cout, up.cin)
-            ops.conv_tap_wgrad(up.wgrad, g_up, lres, dwt, pre_zeroed=True)
             gw = self._galloc(up.m.weight)
-            ops.unpack_wgrad(dwt, gw, up.cout, up.cin, nk, nk, up.cout * nk, 1, up.wgrad)
+            # dW[t][cout][cin] -> torch layout (cin, cout, *k): a = cout (stride nk), b = cin (stride cout*nk)
+            ops.conv_tap_wgrad_to_grad(up.wgrad, g_up, lres, self._wgrad_ws, gw, nk, up.cout * nk, 1)
             grads[up.m.weight] = gw
             if up.m.bias is not None:
                 st = torch.empty((N, up.cout, 2), dtype=torch.float32, device=dev)
@@ -652,7 +651,7 @@ class PlainConvUNet(nn.Module):
             self.grad_reducer.finish_arena(self._arena, self._arena_off)
         self._arena_layout = self._arena_trace
         self._last_arena = self._arena
-        self._red_all = self._dw_all = self._arena = self._arena_trace = None
+        self._red_all = self._wgrad_ws = self._arena = self._arena_trace = None
         return out
 
     # reference API (dynamic_network_architectures): used by the planner's VRAM estimate only

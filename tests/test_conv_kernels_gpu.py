@@ -419,3 +419,31 @@ def test_conv_batches_beyond_2g_elements(hip_lib):
     ops.unpack_wgrad(dw, gw, C, C, 27, 27, C * 27, 1, ptw)
     torch.cuda.synchronize()
     close(gw.cpu(), N * wz.grad, rtol=2e-3, atol_frac=1e-3)
+
+
+@pytest.mark.parametrize("N,dims,cin,cout,stride", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[4], (2, (32, 32, 32), 32, 32, 1)])
+def test_conv_wgrad_two_stage_deterministic(hip_lib, N, dims, cin, cout, stride):
+    """partial blocks + fixed-order reduction straight into the torch-layout gradient: equals the reference gradient,
+    is bit-identical run to run, and honours `accumulate`"""
+    g = torch.Generator().manual_seed(31)
+    x = h(torch.randn(N, cin, *dims, generator=g))
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    y = F.conv3d(x, w, None, stride=stride, padding=1)
+    dy = h(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    pt = PreparedTable(cp.conv_wgrad(N, dims, cin, cout, stride=stride))
+    ws = torch.empty(ops.conv_tap_wgrad_workspace_floats(pt), dtype=torch.float32, device=DEV)
+    xs, dys = to_cl(x), to_cl(dy)
+    outs = []
+    for rep in range(3):
+        ws.fill_(float("nan"))                      # nothing may depend on the workspace's previous content
+        gw = torch.full((cout, cin, 3, 3, 3), float("nan"), dtype=torch.float32, device=DEV)
+        ops.conv_tap_wgrad_to_grad(pt, xs, dys, ws, gw, 27, cin * 27, 1)
+        torch.cuda.synchronize()
+        outs.append(gw)
+    close(outs[0].cpu(), w.grad, rtol=2e-3, atol_frac=1e-3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    acc = torch.ones_like(outs[0])
+    ops.conv_tap_wgrad_to_grad(pt, xs, dys, ws, acc, 27, cin * 27, 1, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, outs[0] + 1.0, rtol=0, atol=1e-6 * outs[0].abs().max().item() + 1e-6)
