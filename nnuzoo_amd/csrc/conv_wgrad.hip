@@ -371,10 +371,10 @@ struct WgKsel {
   int k[32];
 };
 
-// grad[a*sa + b*sb + ksel[t]*sk] (+)= sum_s part[s][t][a][b], s in fixed order: thread = (element, split group of 4)
+// Stage 2a (many splits, few channels): tmp[e] = sum_s part[s][e], s in fixed order; thread = (element, split group of 4),
+// coalesced over the [t][a][b] element index.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long tab,
-                                                           float* __restrict__ grad, int A, int B, long sa, long sb,
-                                                           long sk, WgKsel ks, int accumulate) {
+                                                           float* __restrict__ tmp) {
   __shared__ float red[4][64];
   const int tid = threadIdx.x;
   const int el = tid & 63, sg = tid >> 6;
@@ -390,13 +390,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   red[sg][el] = s0 + s1;
   __syncthreads();
-  if (sg == 0 && e < tab) {
-    const float v = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-    const int b = (int)(e % B);
-    const long q = e / B;
-    const int a = (int)(q % A);
-    const int t = (int)(q / A);
-    float* g = grad + a * sa + b * sb + ks.k[t] * sk;
+  if (sg == 0 && e < tab) tmp[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+}
+
+// Stage 2b: grad[a*sa + b*sb + ksel[t]*sk] (+)= sum_s part[s][t][a][b] for one (a, 32 b) column block and all taps,
+// transposed through LDS: reads are 128-byte rows of the [t][a][b] image, writes are runs of T consecutive taps of the
+// torch layout (sk = 1), instead of one 4-byte write per 64-byte sector.
+__global__ __launch_bounds__(256) void wgrad_to_grad_kernel(const float* __restrict__ part, int splits, long tab,
+                                                            float* __restrict__ grad, int A, int B, int T, long sa,
+                                                            long sb, long sk, WgKsel ks, int accumulate) {
+  __shared__ float tile[32 * 33];
+  const int tid = threadIdx.x;
+  const int a = blockIdx.x % A;
+  const int b0 = (blockIdx.x / A) * 32;
+  const int n = T * 32;
+  for (int i = tid; i < n; i += 256) {
+    const int t = i >> 5, bb = i & 31;
+    const size_t e = ((size_t)t * A + a) * B + b0 + bb;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += part[(size_t)s * tab + e];
+    tile[t * 33 + bb] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int bb = i / T, t = i - bb * T;
+    float* g = grad + a * sa + (long)(b0 + bb) * sb + ks.k[t] * sk;
+    const float v = tile[t * 33 + bb];
     *g = accumulate ? *g + v : v;
   }
 }
@@ -444,7 +463,7 @@ extern "C" long nnz_conv_tap_wgrad_workspace_floats(const nnz_conv_desc* desc) {
   const long blk = (long)desc->ntaps_total * 1024;
   const long pairs = (long)(desc->Cin / 32) * (desc->Cout / 32);
   const long wgs = pairs > 1024 ? pairs : 1024;
-  return wgs * blk;
+  return wgs * blk + pairs * blk;  // partial blocks + one reduced [T][A][B] image
 }
 
 extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, float* workspace, long ws_floats,
@@ -461,7 +480,7 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
       return NNZ_EINVAL;
   const long tab = (long)d.ntaps_total * d.Cin * d.Cout;
   const long pairs = (long)(d.Cin / 32) * (d.Cout / 32);
-  if (ws_floats < tab) return NNZ_EINVAL;
+  if (ws_floats < 2 * tab) return NNZ_EINVAL;
   const long p_per_n = (long)d.in_dims[0] * d.in_dims[1] * d.in_dims[2] * d.ldi;
   const long q_per_n = (long)d.out_dims[0] * d.out_dims[1] * d.out_dims[2] * d.ldo;
   const long per_n = p_per_n > q_per_n ? p_per_n : q_per_n;
@@ -477,7 +496,7 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
     WgradDev p = {};
     p.p = (const f16*)boxed; p.q = (const f16*)plain; p.part = workspace; p.tab = tab; p.d = d;
     WgLaunchOpt o;
-    o.max_wgs = ws_floats / ((long)d.ntaps_total * 1024);  // workgroups whose blocks fit: splits * pairs <= this
+    o.max_wgs = (ws_floats - tab) / ((long)d.ntaps_total * 1024);  // workgroups whose blocks fit beside the temp image
     if (o.max_wgs < pairs) return NNZ_EINVAL;
     o.splits_used = &splits;
     const int rc = launch_wgrad_any(p, s, o);
@@ -498,9 +517,18 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
       if (rc != NNZ_OK) return rc;
     }
   }
-  const long blocks = (tab + 63) / 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splits, tab,
-                     grad, d.Cin, d.Cout, sa, sb, sk, ks, accumulate);
+  const float* src = workspace;
+  if (splits > 8) {
+    // many splits (small channel counts: tab is small): element-parallel pre-reduction into the temp image
+    float* tmp = workspace + (ws_floats - tab);
+    const long blocks = (tab + 63) / 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splits, tab,
+                       tmp);
+    src = tmp;
+    splits = 1;
+  }
+  hipLaunchKernelGGL(wgrad_to_grad_kernel, dim3((unsigned)(d.Cin * (d.Cout / 32))), dim3(256), 0, s, src, splits, tab,
+                     grad, d.Cin, d.Cout, d.ntaps_total, sa, sb, sk, ks, accumulate);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -61,7 +61,10 @@ def main():
         wd = ops.pack_weight(w, pd, cout, cin, cin * 27, 27, 1)
         tf = timeit(lambda: ops.conv_tap_forward(pf, x, wf, None, y), a.reps)
         td = timeit(lambda: ops.conv_tap_forward(pd, dy, wd, None, dx), a.reps)
-        tw = timeit(lambda: ops.conv_tap_wgrad(pw, x, dy, dw), a.reps)
+        # the schedule's weight-gradient path: partial blocks + fixed-order reduction into the torch-layout gradient
+        ws = torch.empty(ops.conv_tap_wgrad_workspace_floats(pw), device=dev, dtype=torch.float32)
+        gw = torch.empty_like(w)
+        tw = timeit(lambda: ops.conv_tap_wgrad_to_grad(pw, x, dy, ws, gw, 27, cin * 27, 1), a.reps)
         tot["fwd"] += tf; tot["dgrad"] += td; tot["wgrad"] += tw
         totf += flops
         print(f"{name:8s} {cin:4d}->{cout:4d} @{edge:3d} s{stride}  {flops/1e9:8.1f} GF | fwd {tf*1e3:8.3f} ms {flops/tf/1e12:7.1f} TF/s"
