@@ -25,21 +25,19 @@ struct StemArgs {
   int tiles[3];
 };
 
-__device__ __forceinline__ void stem_load_tile(const StemArgs& a, int n, int m0d, int m0h, int m0w, float* xt) {
-  for (int i = threadIdx.x; i < ST_BD * ST_BH * ST_BW; i += 256) {
-    const int bw = i % ST_BW, bh = (i / ST_BW) % ST_BH, bd = i / (ST_BW * ST_BH);
-    const int id = m0d + bd - 1, ih = m0h + bh - 1, iw = m0w + bw - 1;
-    float v = 0.f;
-    if ((unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-      v = (float)(f16)a.x[(((long)n * a.D + id) * a.H + ih) * a.W + iw];  // autocast rounding of the input
-    xt[i] = v;
-  }
-}
-
-__global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
-  __shared__ float xt[ST_BD * ST_BH * ST_BW];
-  __shared__ __attribute__((aligned(16))) float wt[27 * ST_CO];  // [t][co]
+// Stem forward on MFMA (a VALU version issued 864 v_fma + 216 broadcast LDS reads per voxel and ran 4x off the HBM
+// bound): D[row = cout][col = voxel] = W[cout][tap] * X[tap][voxel] with the 27 taps padded to K = 32
+// (two v_mfma_f32_32x32x16_f16 per 32 voxels).  A = the whole weight (32 x 32 fp16: two 16-byte registers per lane,
+// loaded once), B is gathered from the fp16 x tile in LDS: lane (voxel, hh) reads its 8 taps as 2-byte loads.  The
+// output tile goes through an LDS image so that stores are whole 16-byte pieces (full 64-byte voxel rows).
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemArgs a) {
+  constexpr int PW = 16;                                   // w pitch of the x tile (halves)
+  constexpr int ROWB = ST_CO * 2 + 16;                     // bytes per voxel row of the output image
+  __shared__ __attribute__((aligned(16))) f16 xt[ST_BD * ST_BH * PW];
+  __shared__ __attribute__((aligned(16))) char img[ST_TD * ST_TH * ST_TW * ROWB];
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
   int bx = blockIdx.x;
   const int tw_i = bx % a.tiles[2];
   bx /= a.tiles[2];
@@ -47,43 +45,63 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   const int td_i = bx / a.tiles[1];
   const int n = blockIdx.y;
   const int m0d = td_i * ST_TD, m0h = th_i * ST_TH, m0w = tw_i * ST_TW;
-  for (int i = tid; i < 27 * ST_CO; i += 256) {
-    const int t = i / ST_CO, co = i % ST_CO;
-    wt[i] = (float)(f16)a.w[co * 27 + t];
+  // x tile (autocast rounding of the input), zero outside the volume
+  for (int i = tid; i < ST_BD * ST_BH * ST_BW; i += 256) {
+    const int bw = i % ST_BW, bh = (i / ST_BW) % ST_BH, bd = i / (ST_BW * ST_BH);
+    const int id = m0d + bd - 1, ih = m0h + bh - 1, iw = m0w + bw - 1;
+    float v = 0.f;
+    if ((unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+      v = a.x[(((long)n * a.D + id) * a.H + ih) * a.W + iw];
+    xt[(bd * ST_BH + bh) * PW + bw] = (f16)v;
   }
-  stem_load_tile(a, n, m0d, m0h, m0w, xt);
-  __syncthreads();
-  const int tw = tid % ST_TW, th = (tid / ST_TW) % ST_TH, td = tid / (ST_TW * ST_TH);
-  float acc[ST_CO];
+  // A operand: row = cout (l31), k = 8*hh + j (+16 for the second MFMA); taps >= 27 are zero
+  f16x8 wa[2];
+  int toff[2][8];  // LDS element offset of tap k relative to the lane's voxel
 #pragma unroll
-  for (int c = 0; c < ST_CO; ++c) acc[c] = a.b ? a.b[c] : 0.f;
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-  for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const float xv = xt[((td + kd) * ST_BH + th + kh) * ST_BW + tw + kw];
-        const float* wr = wt + (kd * 9 + kh * 3 + kw) * ST_CO;
-#pragma unroll
-        for (int c4 = 0; c4 < ST_CO; c4 += 4) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c4);
-          acc[c4 + 0] += xv * w4[0];
-          acc[c4 + 1] += xv * w4[1];
-          acc[c4 + 2] += xv * w4[2];
-          acc[c4 + 3] += xv * w4[3];
-        }
-      }
-  const int od = m0d + td, oh = m0h + th, ow = m0w + tw;
-  if (od < a.D && oh < a.H && ow < a.W) {
-    f16* dst = a.y + ((((long)n * a.D + od) * a.H + oh) * a.W + ow) * a.ldy;
-#pragma unroll
-    for (int c8 = 0; c8 < ST_CO; c8 += 8) {
-      f16x8 h;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) h[i] = (f16)acc[c8 + i];
-      *reinterpret_cast<f16x8*>(dst + c8) = h;
+    for (int j = 0; j < 8; ++j) {
+      const int k = m * 16 + 8 * hh + j;
+      wa[m][j] = k < 27 ? (f16)a.w[l31 * 27 + k] : (f16)0.f;
+      const int kk = k < 27 ? k : 0;
+      toff[m][j] = ((kk / 9) * ST_BH + (kk / 3) % 3) * PW + kk % 3;
     }
+  float bias[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias[r] = a.b ? a.b[(r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+  __syncthreads();
+  // each wave: 2 groups of 32 voxels (the tile has 8)
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int v = (wave * 2 + gi) * 32 + l31;
+    const int tw = v % ST_TW, th = (v / ST_TW) % ST_TH, td = v / (ST_TW * ST_TH);
+    const int vbase = (td * ST_BH + th) * PW + tw;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f16x8 xb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] = xt[vbase + toff[m][j]];
+      acc = mfma32(wa[m], xb, acc);
+    }
+    // lane holds couts (r&3) + 8(r>>2) + 4hh of voxel v
+    char* row = img + v * ROWB + (4 * hh) * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f16x4 o = {(f16)acc[4 * q + 0], (f16)acc[4 * q + 1], (f16)acc[4 * q + 2], (f16)acc[4 * q + 3]};
+      *reinterpret_cast<f16x4*>(row + 16 * q) = o;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < ST_TD * ST_TH * ST_TW * 4; c += 256) {
+    const int v = c >> 2, part = c & 3;
+    const int tw = v % ST_TW, th = (v / ST_TW) % ST_TH, td = v / (ST_TW * ST_TH);
+    const int od = m0d + td, oh = m0h + th, ow = m0w + tw;
+    if (od < a.D && oh < a.H && ow < a.W)
+      *reinterpret_cast<f16x8*>(a.y + ((((long)n * a.D + od) * a.H + oh) * a.W + ow) * a.ldy + part * 8) =
+          *reinterpret_cast<const f16x8*>(img + v * ROWB + part * 16);
   }
 }
 
@@ -107,7 +125,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int tiles_per_n = a.tiles[0] * a.tiles[1] * a.tiles[2];
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // register prefetch of the next tile (x: 3 values, dy: 4 x 16 bytes per thread) under the current tile's MFMAs: the
+  // loop used to expose the full global-load latency for 4 MFMAs of work per wave
+  constexpr int XL = (ST_BD * ST_BH * ST_BW + 255) / 256;
+  float xreg[XL];
+  u32x4 dreg[4];
+  auto prefetch = [&](int tile) {
     const int n = tile / tiles_per_n;
     int r = tile % tiles_per_n;
     const int tw_i = r % a.tiles[2];
@@ -115,25 +138,45 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
     const int th_i = r % a.tiles[1];
     const int td_i = r / a.tiles[1];
     const int m0d = td_i * ST_TD, m0h = th_i * ST_TH, m0w = tw_i * ST_TW;
-    __syncthreads();
-    for (int i = tid; i < ST_BD * ST_BH * ST_BW; i += 256) {
+#pragma unroll
+    for (int k = 0; k < XL; ++k) {
+      const int i = tid + k * 256;
       const int bw = i % ST_BW, bh = (i / ST_BW) % ST_BH, bd = i / (ST_BW * ST_BH);
       const int id = m0d + bd - 1, ih = m0h + bh - 1, iw = m0w + bw - 1;
       float v = 0.f;
-      if ((unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+      if (i < ST_BD * ST_BH * ST_BW && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H &&
+          (unsigned)iw < (unsigned)a.W)
         v = a.x[(((long)n * a.D + id) * a.H + ih) * a.W + iw];
-      xt[i] = (f16)v;
+      xreg[k] = v;
     }
-    for (int i = tid; i < ST_TD * ST_TH * ST_TW * 4; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
       const int part = i & 3, v = i >> 2;
       const int tw = v % ST_TW, th = (v / ST_TW) % ST_TH, td = v / (ST_TW * ST_TH);
       const int od = m0d + td, oh = m0h + th, ow = m0w + tw;
       u32x4 val = {0u, 0u, 0u, 0u};
       if (od < a.D && oh < a.H && ow < a.W)
         val = *reinterpret_cast<const u32x4*>(a.dy + ((((long)n * a.D + od) * a.H + oh) * a.W + ow) * a.lddy + part * 8);
-      *reinterpret_cast<u32x4*>(dyt + v * ST_CO + part * 8) = val;
+      dreg[k] = val;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < XL; ++k) {
+      const int i = tid + k * 256;
+      if (i < ST_BD * ST_BH * ST_BW) xt[i] = (f16)xreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      *reinterpret_cast<u32x4*>(dyt + (i >> 2) * ST_CO + (i & 3) * 8) = dreg[k];
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
       const int kb = wave * 4 + kq;        // 16 k-blocks of 16 voxels, 4 per wave
@@ -424,7 +467,7 @@ extern "C" int nnz_stem_conv_forward(const float* x, const float* w, const float
   a.tiles[0] = (D + ST_TD - 1) / ST_TD;
   a.tiles[1] = (H + ST_TH - 1) / ST_TH;
   a.tiles[2] = (W + ST_TW - 1) / ST_TW;
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(a.tiles[0] * a.tiles[1] * a.tiles[2], N), dim3(256), 0,
+  hipLaunchKernelGGL(stem_fwd_mfma_kernel, dim3(a.tiles[0] * a.tiles[1] * a.tiles[2], N), dim3(256), 0,
                      (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
