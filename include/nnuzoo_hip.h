@@ -111,7 +111,7 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
  * get_tp_fp_fn_tn, training/loss/dice.py:122-180, label-map targets): argmax over classes (first maximum on ties)
  * against the int16 label map in one read; counts_u64[c] = {tp, fp, fn} exact (zeroed by the call). */
 int nnz_argmax_tp_fp_fn(const void* logits_nc, int logits_is_f16, const int16_t* target, void* counts_u64 /* [C][3] */,
-                        int B, int C, long V, void* stream);
+                        int B, int C, long V, int ignore_label /* -32768: none */, void* stream);
 
 /* ---- 1-D Mamba block pieces around the scan (nets/seg_mamba/mamba_simple.py:190-357, mamba_inner_ref in
  * nets/seg_mamba/selective_scan_interface.py:640-674): causal depthwise conv1d (width W <= 8, padding W-1, truncated to
@@ -142,11 +142,13 @@ int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, 
 /* ---- fused soft-Dice + cross-entropy statistics on NC(D)HW logits --------------------------------------------
  * replaces softmax + one-hot + reductions + CE of DC_and_CE_loss (nnunetv2/training/loss/compound_losses.py:31-56,
  * dice.py:72-119, robust_ce_loss.py:12-16).  sums[b] = {intersect[C], sum_pred[C], sum_gt[C], ce_sum};
- * coef[b] = {dL/dintersect[C], dL/dsum_pred[C], dL/dce_sum}.  target: int16 class ids [B][V]. */
+ * coef[b] = {dL/dintersect[C], dL/dsum_pred[C], dL/dce_sum}.  target: int16 class ids [B][V].
+ * ignore_label: voxels carrying this label are left out of every sum and get zero gradient (the loss_mask of the Dice
+ * terms and the CE's ignore_index, compound_losses.py:38-52); pass -32768 for none. */
 int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target, float* sums, int B, int C,
-                           long V, void* stream);
+                           long V, int ignore_label, void* stream);
 int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
-                            void* dlogits, int B, int C, long V, void* stream);
+                            void* dlogits, int B, int C, long V, int ignore_label, void* stream);
 
 /* ---- selective scan (Mamba S6), fp32, N = 16, B/C of shape (B, K, N, L), z = None ----------------------------
  * replaces mamba_ssm's selective_scan_cuda.fwd/bwd behind selective_scan_fn as called at

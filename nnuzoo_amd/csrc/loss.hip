@@ -24,6 +24,7 @@ struct LossArgs {
   int B, C;
   long V;
   int vpb;
+  int ignore;           // label value excluded from every sum and gradient (DC_and_CE_loss ignore_label), or -32768
 };
 
 template <typename T, int LS_MAXC>
@@ -65,9 +66,10 @@ __global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
 #pragma unroll
   for (int c = 0; c < LS_MAXC; ++c) inter[c] = sp[c] = sg[c] = 0.f;
   for (long v = v0 + tid; v < v1; v += 256) {
+    const int t = a.tgt[(long)b * a.V + v];
+    if (t == a.ignore) continue;  // loss_mask of the Dice sums and ignore_index of the CE (compound_losses.py:38-52)
     float p[LS_MAXC], lse;
     softmax_at<T, LS_MAXC>(a, base, v, p, lse);
-    const int t = a.tgt[(long)b * a.V + v];
 #pragma unroll
     for (int c = 0; c < LS_MAXC; ++c)
       if (c < a.C) {
@@ -111,9 +113,15 @@ __global__ __launch_bounds__(256) void dc_ce_bwd_kernel(LossArgs<T> a) {
   }
   const float gce = a.coef[(long)b * (2 * a.C + 1) + 2 * a.C];
   for (long v = v0 + tid; v < v1; v += 256) {
+    const int t = a.tgt[(long)b * a.V + v];
+    if (t == a.ignore) {
+#pragma unroll
+      for (int c = 0; c < LS_MAXC; ++c)
+        if (c < a.C) a.dlogits[base + (long)c * a.V + v] = (T)0.f;
+      continue;
+    }
     float p[LS_MAXC], lse;
     softmax_at<T, LS_MAXC>(a, base, v, p, lse);
-    const int t = a.tgt[(long)b * a.V + v];
     float S = 0.f;
     float ac[LS_MAXC];
 #pragma unroll
@@ -164,7 +172,7 @@ static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
 template <typename T, int LS_MAXC>
 __global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__ logits, const int16_t* __restrict__ tgt,
                                                            unsigned long long* __restrict__ counts, int C, long V,
-                                                           int vpb) {
+                                                           int vpb, int ignore) {
   __shared__ unsigned int lc[3 * LS_MAXC];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__
         }
       }
     const int t = tgt[(long)b * V + v];
+    if (t == ignore) continue;  // validation_step's mask (nnUNetTrainer.py:1209-1216): ignored voxels count nowhere
 #pragma unroll
     for (int c = 0; c < LS_MAXC; ++c) {
       tp[c] += (arg == c) & (t == c);
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__
 }  // namespace nnz
 
 extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const int16_t* target, void* counts_u64,
-                                   int B, int C, long V, void* stream) {
+                                   int B, int C, long V, int ignore_label, void* stream) {
   using namespace nnz;
   if (!logits || !target || !counts_u64 || C < 1 || C > LS_MAXC_BIG || B < 1 || V < 1) return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -226,7 +235,7 @@ extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const 
   const int gx = (int)((V + vpb - 1) / vpb);
 #define NNZ_ARGMAX(TT, MC)                                                                                       \
   hipLaunchKernelGGL((argmax_stats_kernel<TT, MC>), dim3(gx, B), dim3(256), 0, s, (const TT*)logits, target, \
-                     (unsigned long long*)counts_u64, C, V, (int)vpb)
+                     (unsigned long long*)counts_u64, C, V, (int)vpb, ignore_label)
   if (logits_is_f16) {
     if (C > 8) NNZ_ARGMAX(f16, LS_MAXC_BIG); else NNZ_ARGMAX(f16, 8);
   } else {
@@ -238,29 +247,29 @@ extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const 
 }
 
 extern "C" int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target, float* sums, int B,
-                                      int C, long V, void* stream) {
+                                      int C, long V, int ignore_label, void* stream) {
   using namespace nnz;
   if (!logits || !target || !sums) return NNZ_EINVAL;
   if (logits_is_f16) {
     LossArgs<f16> a = {};
-    a.logits = (const f16*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V;
+    a.logits = (const f16*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
     return launch_loss(a, false, (hipStream_t)stream);
   }
   LossArgs<float> a = {};
-  a.logits = (const float*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V;
+  a.logits = (const float*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
   return launch_loss(a, false, (hipStream_t)stream);
 }
 
 extern "C" int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
-                                       void* dlogits, int B, int C, long V, void* stream) {
+                                       void* dlogits, int B, int C, long V, int ignore_label, void* stream) {
   using namespace nnz;
   if (!logits || !target || !coef || !dlogits) return NNZ_EINVAL;
   if (logits_is_f16) {
     LossArgs<f16> a = {};
-    a.logits = (const f16*)logits; a.tgt = target; a.coef = coef; a.dlogits = (f16*)dlogits; a.B = B; a.C = C; a.V = V;
+    a.logits = (const f16*)logits; a.tgt = target; a.coef = coef; a.dlogits = (f16*)dlogits; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
     return launch_loss(a, true, (hipStream_t)stream);
   }
   LossArgs<float> a = {};
-  a.logits = (const float*)logits; a.tgt = target; a.coef = coef; a.dlogits = (float*)dlogits; a.B = B; a.C = C; a.V = V;
+  a.logits = (const float*)logits; a.tgt = target; a.coef = coef; a.dlogits = (float*)dlogits; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
   return launch_loss(a, true, (hipStream_t)stream);
 }

@@ -204,23 +204,26 @@ def _logits_kind(t: torch.Tensor) -> int:
     return 1 if t.dtype == torch.float16 else 0
 
 
-def dc_ce_forward(logits, target_i16, sums, B, Cc, V):
+NO_IGNORE = -32768
+
+
+def dc_ce_forward(logits, target_i16, sums, B, Cc, V, ignore_label: int = NO_IGNORE):
     if target_i16.dtype != torch.int16 or not target_i16.is_cuda:
         raise _lib.HipCallError("loss: target must be an int16 device tensor")
     _f32(sums, "loss.sums")
     call("nnz_dc_ce_loss_forward", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(sums), B, Cc, V,
-         stream_ptr())
+         int(ignore_label), stream_ptr())
 
 
-def dc_ce_backward(logits, target_i16, coef, dlogits, B, Cc, V):
+def dc_ce_backward(logits, target_i16, coef, dlogits, B, Cc, V, ignore_label: int = NO_IGNORE):
     _f32(coef, "loss.coef")
     if dlogits.dtype != logits.dtype:
         raise _lib.HipCallError("loss: dlogits dtype must equal logits dtype")
     call("nnz_dc_ce_loss_backward", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(coef), ptr(dlogits), B, Cc,
-         V, stream_ptr())
+         V, int(ignore_label), stream_ptr())
 
 
-def argmax_tp_fp_fn(logits: torch.Tensor, target_i16: torch.Tensor):
+def argmax_tp_fp_fn(logits: torch.Tensor, target_i16: torch.Tensor, ignore_label: int = -32768):
     """(B, C, *spatial) logits + (B, 1, *spatial) int16 labels -> exact int64 (tp, fp, fn) per class, one pass"""
     if target_i16.dtype != torch.int16 or not target_i16.is_cuda:
         raise _lib.HipCallError("argmax_tp_fp_fn: target must be an int16 device tensor")
@@ -229,5 +232,5 @@ def argmax_tp_fp_fn(logits: torch.Tensor, target_i16: torch.Tensor):
     V = logits[0, 0].numel()
     counts = torch.empty((Cc, 3), dtype=torch.int64, device=logits.device)
     call("nnz_argmax_tp_fp_fn", ptr(logits), _logits_kind(logits), ptr(target_i16.contiguous()), ptr(counts), B, Cc, V,
-         stream_ptr())
+         int(ignore_label), stream_ptr())
     return counts[:, 0], counts[:, 1], counts[:, 2]

@@ -62,18 +62,21 @@ class MemoryEfficientSoftDiceLoss(nn.Module):
         dc = (2 * intersect + self.smooth) / (torch.clip(sum_gt + sum_pred + self.smooth, 1e-8))
         return -dc.mean()
 
-    def forward(self, x, y, loss_mask=None):
+    def forward(self, x, y, loss_mask=None, ignore_label=None):
+        """loss_mask is supported in the form the reference produces it (DC_and_CE_loss: `target != ignore_label`):
+        pass `ignore_label` and the kernel leaves those voxels out; arbitrary mask tensors raise."""
         if loss_mask is not None:
-            raise NotImplementedError("loss_mask / ignore_label is outside the hot-path scope")
+            raise NotImplementedError("pass ignore_label (the mask DC_and_CE_loss derives); arbitrary loss_mask tensors "
+                                      "are not supported by the fused kernel")
         if self.apply_nonlin is not softmax_helper_dim1:
             raise NotImplementedError("the fused HIP Dice statistics assume apply_nonlin=softmax_helper_dim1")
-        intersect, sum_pred, sum_gt, _ = _fused_stats(x, y)
+        intersect, sum_pred, sum_gt, _ = _fused_stats(x, y, ignore_label)
         if not self.do_bg:
             intersect, sum_pred, sum_gt = intersect[:, 1:], sum_pred[:, 1:], sum_gt[:, 1:]
         return self.dice_from_sums(intersect, sum_pred, sum_gt.detach())
 
 
-def _fused_stats(net_output: torch.Tensor, target: torch.Tensor):
+def _fused_stats(net_output: torch.Tensor, target: torch.Tensor, ignore_label=None):
     if not net_output.is_cuda:
         raise RuntimeError("nnuzoo_amd losses run on MI355X through libnnuzoo_hip.so only (no CPU fallback); "
                            "the CPU restatement is oracle/losses.py (test-only)")
@@ -82,21 +85,23 @@ def _fused_stats(net_output: torch.Tensor, target: torch.Tensor):
     if target.ndim == net_output.ndim:
         assert target.shape[1] == 1, "target must be a label map (b, 1, ...)"
     tgt = target if target.dtype == torch.int16 else target.to(torch.int16)
-    return _FusedDiceCE.apply(net_output.contiguous(), tgt.contiguous())
+    from ..hip_ops import NO_IGNORE
+    return _FusedDiceCE.apply(net_output.contiguous(), tgt.contiguous(),
+                              NO_IGNORE if ignore_label is None else int(ignore_label))
 
 
 class _FusedDiceCE(torch.autograd.Function):
     """softmax + CE-sum + Dice sums in one pass over the logits; backward is one more pass (csrc/loss.hip)."""
 
     @staticmethod
-    def forward(ctx, logits: torch.Tensor, target: torch.Tensor):
+    def forward(ctx, logits: torch.Tensor, target: torch.Tensor, ignore: int):
         from .. import hip_ops as ops
         B, C = logits.shape[:2]
         V = logits[0, 0].numel()
         sums = torch.empty((B, 3 * C + 1), dtype=torch.float32, device=logits.device)
-        ops.dc_ce_forward(logits, target, sums, B, C, V)
+        ops.dc_ce_forward(logits, target, sums, B, C, V, ignore)
         ctx.save_for_backward(logits, target)
-        ctx.dims = (B, C, V)
+        ctx.dims = (B, C, V, ignore)
         intersect, sum_pred, sum_gt = (sums[:, :C].clone(), sums[:, C:2 * C].clone(), sums[:, 2 * C:3 * C].clone())
         ce_sum = sums[:, 3 * C].clone()
         ctx.mark_non_differentiable(sum_gt)
@@ -106,7 +111,7 @@ class _FusedDiceCE(torch.autograd.Function):
     def backward(ctx, g_int, g_pred, g_gt, g_ce):
         from .. import hip_ops as ops
         logits, target = ctx.saved_tensors
-        B, C, V = ctx.dims
+        B, C, V, ignore = ctx.dims
         dev = logits.device
         coef = torch.zeros((B, 2 * C + 1), dtype=torch.float32, device=dev)
         if g_int is not None:
@@ -116,8 +121,8 @@ class _FusedDiceCE(torch.autograd.Function):
         if g_ce is not None:
             coef[:, 2 * C] = g_ce
         dlogits = torch.empty_like(logits)
-        ops.dc_ce_backward(logits, target, coef, dlogits, B, C, V)
-        return dlogits, None
+        ops.dc_ce_backward(logits, target, coef, dlogits, B, C, V, ignore)
+        return dlogits, None, None
 
 
 class DC_and_CE_loss(nn.Module):
@@ -125,20 +130,30 @@ class DC_and_CE_loss(nn.Module):
                  dice_class=MemoryEfficientSoftDiceLoss):
         super().__init__()
         if ignore_label is not None:
-            raise NotImplementedError("ignore_label is outside the hot-path scope (SURVEY.md §8a a-11)")
+            ce_kwargs = dict(ce_kwargs)
+            ce_kwargs['ignore_index'] = ignore_label    # as the reference does (compound_losses.py:21-22)
         self.weight_dice, self.weight_ce, self.ignore_label = weight_dice, weight_ce, ignore_label
         self.ce = RobustCrossEntropyLoss(**ce_kwargs)
         self.dc = dice_class(apply_nonlin=softmax_helper_dim1, **soft_dice_kwargs)
-        self._plain_ce = not ce_kwargs
+        self._plain_ce = not [k for k in ce_kwargs if k != 'ignore_index']
 
     def forward(self, net_output: torch.Tensor, target: torch.Tensor):
         if not self._plain_ce or not isinstance(self.dc, MemoryEfficientSoftDiceLoss):
             raise NotImplementedError("fused HIP loss: ce_kwargs must be {} and dice_class MemoryEfficientSoftDiceLoss")
-        intersect, sum_pred, sum_gt, ce_sum = _fused_stats(net_output, target)
+        if self.ignore_label is not None:
+            assert target.shape[1] == 1, 'ignore label is not implemented for one hot encoded target variables ' \
+                                         '(DC_and_CE_loss)'
+        intersect, sum_pred, sum_gt_all, ce_sum = _fused_stats(net_output, target, self.ignore_label)
+        sum_gt = sum_gt_all
         if not self.dc.do_bg:
             intersect, sum_pred, sum_gt = intersect[:, 1:], sum_pred[:, 1:], sum_gt[:, 1:]
         dc_loss = self.dc.dice_from_sums(intersect, sum_pred, sum_gt.detach()) if self.weight_dice != 0 else 0
-        n_vox = net_output.shape[0] * net_output[0, 0].numel()
+        if self.ignore_label is None:
+            n_vox = net_output.shape[0] * net_output[0, 0].numel()
+        else:
+            # mean over the voxels that are not ignored (CrossEntropyLoss(ignore_index)); an all-ignored batch gives CE 0
+            # (compound_losses.py:51-52: `num_fg > 0`) - the sum is 0 then, the clamp only avoids 0/0
+            n_vox = sum_gt_all.detach().sum().clamp_min(1.0)
         ce_loss = ce_sum.sum() / n_vox if self.weight_ce != 0 else 0
         return self.weight_ce * ce_loss + self.weight_dice * dc_loss
 

@@ -72,9 +72,17 @@ def _num_segmentation_heads(dataset_json: dict) -> int:
     labels = dataset_json['labels']
     if any(isinstance(v, (list, tuple)) for v in labels.values()):
         raise NotImplementedError("region-based training is outside the hot-path scope")
-    if 'ignore' in labels:
-        raise NotImplementedError("ignore label is outside the hot-path scope")
-    return len(labels)
+    return len([k for k in labels if k != 'ignore'])     # LabelManager.num_segmentation_heads (label_handling.py:58-75)
+
+
+def _ignore_label(dataset_json: dict):
+    """LabelManager.ignore_label (label_handling.py:102-127): the integer under the key 'ignore' (must be the highest)"""
+    ig = dataset_json['labels'].get('ignore')
+    if ig is not None:
+        others = [v for k, v in dataset_json['labels'].items() if k != 'ignore']
+        assert isinstance(ig, int) and ig == max(others) + 1, \
+            'If you use the ignore label it must have the highest label value! It cannot be 0 or in between other labels.'
+    return ig
 
 
 def _num_input_channels(dataset_json: dict) -> int:
@@ -196,7 +204,8 @@ class nnUNetTrainer:
 
     def _build_loss(self):
         loss = DC_and_CE_loss({'batch_dice': self.configuration_manager.batch_dice, 'smooth': 1e-5, 'do_bg': False,
-                               'ddp': self.is_ddp}, {}, weight_ce=1, weight_dice=1, ignore_label=None,
+                               'ddp': self.is_ddp}, {}, weight_ce=1, weight_dice=1,
+                              ignore_label=_ignore_label(self.dataset_json),
                               dice_class=MemoryEfficientSoftDiceLoss)
         if self.enable_deep_supervision:
             scales = self._get_deep_supervision_scales()
@@ -275,7 +284,8 @@ class nnUNetTrainer:
         # argmax + TP/FP/FN in one HIP pass over logits and labels (reference: argmax -> one-hot scatter ->
         # get_tp_fp_fn_tn, nnUNetTrainer.py:1201-1221); float32 arrays like the reference's, background dropped
         tgt = target if target.dtype == torch.int16 else target.to(torch.int16)
-        tp, fp, fn = ops.argmax_tp_fp_fn(output, tgt)
+        ig = _ignore_label(self.dataset_json)
+        tp, fp, fn = ops.argmax_tp_fp_fn(output, tgt, -32768 if ig is None else ig)
         stats = torch.stack([tp, fp, fn]).to(torch.float32).cpu().numpy()
         return {'loss': l.detach().cpu().numpy(), 'tp_hard': stats[0][1:], 'fp_hard': stats[1][1:],
                 'fn_hard': stats[2][1:]}

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 
-def soft_dice(x_logits, y, batch_dice, do_bg=False, smooth=1e-5):
+def soft_dice(x_logits, y, batch_dice, do_bg=False, smooth=1e-5, loss_mask=None):
     x = torch.softmax(x_logits.float(), 1)
     axes = tuple(range(2, x.ndim))
     with torch.no_grad():
@@ -22,20 +22,31 @@ def soft_dice(x_logits, y, batch_dice, do_bg=False, smooth=1e-5):
         y_onehot.scatter_(1, y.long(), 1)
         if not do_bg:
             y_onehot = y_onehot[:, 1:]
-        sum_gt = y_onehot.sum(axes)
+        sum_gt = y_onehot.sum(axes) if loss_mask is None else (y_onehot * loss_mask).sum(axes)
     if not do_bg:
         x = x[:, 1:]
-    intersect = (x * y_onehot).sum(axes)
-    sum_pred = x.sum(axes)
+    if loss_mask is None:
+        intersect = (x * y_onehot).sum(axes)
+        sum_pred = x.sum(axes)
+    else:  # dice.py:98-103
+        intersect = (x * y_onehot * loss_mask).sum(axes)
+        sum_pred = (x * loss_mask).sum(axes)
     if batch_dice:
         intersect, sum_pred, sum_gt = intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)
     dc = (2 * intersect + smooth) / torch.clip(sum_gt + sum_pred + smooth, 1e-8)
     return -dc.mean()
 
 
-def dc_and_ce(x_logits, y, batch_dice, weight_ce=1.0, weight_dice=1.0):
-    ce = F.cross_entropy(x_logits.float(), y[:, 0].long())
-    return weight_ce * ce + weight_dice * soft_dice(x_logits, y, batch_dice)
+def dc_and_ce(x_logits, y, batch_dice, weight_ce=1.0, weight_dice=1.0, ignore_label=None):
+    if ignore_label is None:
+        ce = F.cross_entropy(x_logits.float(), y[:, 0].long())
+        return weight_ce * ce + weight_dice * soft_dice(x_logits, y, batch_dice)
+    # compound_losses.py:38-55: mask = target != ignore; Dice on the masked sums; CE with ignore_index (0 if all ignored)
+    mask = y != ignore_label
+    y_dice = torch.where(mask, y, torch.zeros_like(y))
+    dc = soft_dice(x_logits, y_dice, batch_dice, loss_mask=mask)
+    ce = F.cross_entropy(x_logits.float(), y[:, 0].long(), ignore_index=ignore_label) if mask.sum() > 0 else 0
+    return weight_ce * ce + weight_dice * dc
 
 
 def ds_weights(n_outputs, ddp_no_compile=False):

@@ -68,3 +68,41 @@ def test_argmax_tp_fp_fn_matches_reference_formula(hip_lib, shape, dtype):
     rtp, rfp, rfn = tp_fp_fn_hard(logits.float(), target)
     assert torch.equal(tp.cpu().float(), rtp) and torch.equal(fp.cpu().float(), rfp) and torch.equal(fn.cpu().float(), rfn)
     assert int((tp + fn).sum()) == target.numel()
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_ignore_label_matches_reference_golden(hip_lib, tag):
+    """fused kernel with ignore_label against the reference's DC_and_CE_loss(ignore_label=C) fixtures: loss, gradient
+    (zero on ignored voxels), the all-ignored batch, and the validation statistics with the same mask"""
+    import os
+    from nnuzoo_amd import hip_ops as ops
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g, gi = np.load(os.path.join(gold, f"loss_{tag}.npz")), np.load(os.path.join(gold, f"loss_ignore_{tag}.npz"))
+    ig, bd = int(gi["ignore_label"]), bool(g["batch_dice"])
+    loss = DC_and_CE_loss({'batch_dice': bd, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=ig, dice_class=MemoryEfficientSoftDiceLoss)
+    x = torch.from_numpy(g["logits"]).cuda().requires_grad_(True)
+    t = torch.from_numpy(gi["target"]).cuda()
+    l = loss(x, t)
+    l.backward()
+    assert abs(float(l) - float(gi["loss"])) < 2e-5
+    ref_g = torch.from_numpy(gi["dlogits"])
+    assert torch.allclose(x.grad.cpu(), ref_g, rtol=1e-4, atol=1e-4 * ref_g.abs().max().item())
+    assert x.grad.cpu()[(t.cpu() == ig).expand_as(x)].abs().max().item() == 0
+    l_all = loss(x.detach(), torch.full_like(t, ig))
+    assert abs(float(l_all) - float(gi["loss_all_ignored"])) < 1e-6
+    # validation statistics: ignored voxels count nowhere (nnUNetTrainer.validation_step's mask)
+    tp, fp, fn = ops.argmax_tp_fp_fn(x.detach(), t, ig)
+    keep = (t != ig)
+    tt = torch.where(keep, t, torch.zeros_like(t)).cpu()
+    rtp, rfp, rfn = O.tp_fp_fn_hard(x.detach().cpu(), tt)
+    # reference formula with the mask applied to every term
+    axes = [0] + list(range(2, x.ndim))
+    seg = x.detach().cpu().argmax(1)[:, None]
+    C = x.shape[1]
+    oh = torch.zeros(x.shape).scatter_(1, seg, 1)
+    yo = torch.zeros(x.shape, dtype=torch.bool).scatter_(1, tt.long(), 1)
+    m = keep.cpu().float()
+    assert torch.equal(tp.cpu().float(), (oh * yo * m).sum(axes))
+    assert torch.equal(fp.cpu().float(), (oh * (~yo) * m).sum(axes))
+    assert torch.equal(fn.cpu().float(), ((1 - oh) * yo * m).sum(axes))

@@ -66,3 +66,20 @@ def test_loss_oracle_vs_reference_golden(tag):
     lds = OL.deep_supervision_loss(outs, tgs, bool(z["batch_dice"]), z["ds_weights"])
     assert abs(float(lds) - float(z["ds_loss"])) < 1e-6
     assert np.allclose(OL.ds_weights(3), z["ds_weights"])
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_loss_oracle_ignore_label_vs_reference_golden(tag):
+    """DC_and_CE_loss(ignore_label=C): fixtures from the reference's own module (tools/make_golden.py gen_losses)"""
+    O = OL
+    g = np.load(os.path.join(G, f"loss_{tag}.npz"))
+    gi = np.load(os.path.join(G, f"loss_ignore_{tag}.npz"))
+    x = torch.from_numpy(g["logits"]).requires_grad_(True)
+    t = torch.from_numpy(gi["target"])
+    ig = int(gi["ignore_label"])
+    l = O.dc_and_ce(x, t, bool(g["batch_dice"]), ignore_label=ig)
+    (gr,) = torch.autograd.grad(l, x)
+    assert abs(float(l) - float(gi["loss"])) < 1e-6
+    assert np.allclose(gr.numpy(), gi["dlogits"], atol=1e-7)
+    l_all = O.dc_and_ce(x.detach(), torch.full_like(t, ig), bool(g["batch_dice"]), ignore_label=ig)
+    assert abs(float(l_all) - float(gi["loss_all_ignored"])) < 1e-6

@@ -93,6 +93,17 @@ def gen_losses():
         np.savez_compressed(os.path.join(OUT, f"loss_{tag}.npz"), logits=logits.detach().numpy(), target=target.numpy(),
                             loss=l.detach().numpy(), dlogits=gl.numpy(), ds_loss=lds.detach().numpy(), ds_weights=w,
                             batch_dice=np.array(batch_dice))
+        # ignore label (= C, the reference's convention: highest label + 1) on ~20 % of the voxels, and an all-ignored case
+        tgt_ig = target.clone()
+        tgt_ig[torch.rand(target.shape, generator=g) < 0.2] = C
+        loss_ig = DC_and_CE_loss({'batch_dice': batch_dice, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {},
+                                 weight_ce=1, weight_dice=1, ignore_label=C, dice_class=MemoryEfficientSoftDiceLoss)
+        logits2 = logits.detach().clone().requires_grad_(True)
+        l_ig = loss_ig(logits2, tgt_ig)
+        (g_ig,) = torch.autograd.grad(l_ig, logits2)
+        l_all = loss_ig(logits.detach(), torch.full_like(target, C))
+        np.savez_compressed(os.path.join(OUT, f"loss_ignore_{tag}.npz"), target=tgt_ig.numpy(), loss=l_ig.detach().numpy(),
+                            dlogits=g_ig.numpy(), loss_all_ignored=l_all.detach().numpy(), ignore_label=np.array(C))
 
 
 def gen_window_attention():
