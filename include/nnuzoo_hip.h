@@ -150,6 +150,18 @@ int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t*
 int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
                             void* dlogits, int B, int C, long V, int ignore_label, void* stream);
 
+/* region-based training (label_manager.has_regions): sigmoid soft-Dice (do_bg) + BCE-with-logits statistics of
+ * DC_and_BCE_loss (compound_losses.py:59-109) on one-hot region targets [B][Ct][V] (int16 0/1; Ct = C, or C+1 with the
+ * ignore mask in the last channel).  sums[b] = {intersect[C], sum_pred[C], sum_gt[C], bce_sum, mask_sum};
+ * coef[b] = {dL/dintersect[C], dL/dsum_pred[C], dL/dbce_sum}.  nnz_region_tp_fp_fn: validation statistics with the
+ * prediction sigmoid(z) > 0.5 (nnUNetTrainer.validation_step, nnUNetTrainer.py:1188-1216), counts_u64[c] = {tp, fp, fn}. */
+int nnz_dc_bce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target_regions, float* sums, int B,
+                            int C, int Ct, long V, void* stream);
+int nnz_dc_bce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target_regions, const float* coef,
+                             void* dlogits, int B, int C, int Ct, long V, void* stream);
+int nnz_region_tp_fp_fn(const void* logits, int logits_is_f16, const int16_t* target_regions, void* counts_u64, int B,
+                        int C, int Ct, long V, void* stream);
+
 /* ---- selective scan (Mamba S6), fp32, N = 16, B/C of shape (B, K, N, L), z = None ----------------------------
  * replaces mamba_ssm's selective_scan_cuda.fwd/bwd behind selective_scan_fn as called at
  * nnunetv2/nets/m2net.py:193-199 and ssnd2net.py:271-277 (definition: selective_scan_ref,

@@ -84,6 +84,9 @@ SIGNATURES = {
     "nnz_sgd_chunk_fill": [_vp, _vp, _vp, _l, _i],
     "nnz_grad_sumsq_nonfinite": [_fp, _l, _fp, _vp],
     "nnz_sgd_nesterov_fused": [_vp, _i, _fp, _fp, _fp, _f, _f, _f, _f, _i, _vp],
+    "nnz_dc_bce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _i, _l, _vp],
+    "nnz_dc_bce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _i, _l, _vp],
+    "nnz_region_tp_fp_fn": [_vp, _i, _vp, _vp, _i, _i, _i, _l, _vp],
     "nnz_argmax_tp_fp_fn": [_vp, _i, _vp, _vp, _i, _i, _l, _i, _vp],
     "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _i, _vp],
     "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _i, _vp],

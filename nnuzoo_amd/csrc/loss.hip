@@ -220,7 +220,222 @@ __global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__
   if (tid < 3 * C && lc[tid]) atomicAdd(counts + tid, (unsigned long long)lc[tid]);
 }
 
+// ---- region-based training: sigmoid Dice + BCE-with-logits over one-hot region targets ------------------------------
+// DC_and_BCE_loss.forward (/root/reference/nnunetv2/training/loss/compound_losses.py:59-109) with
+// MemoryEfficientSoftDiceLoss(apply_nonlin=torch.sigmoid, do_bg=True) (dice.py:72-119): per (b, region c)
+//   intersect = sum p*y*m, sum_pred = sum p*m, sum_gt = sum y*m, p = sigmoid(z), m = 1 - target[:, -1] (ignore channel)
+// and bce_sum = sum_{c,v} m * (max(z,0) - z*y + log(1 + exp(-|z|))), mask_sum = sum_v m.
+//   sums[b] = { intersect[C], sum_pred[C], sum_gt[C], bce_sum, mask_sum };   coef[b] = { dL/dintersect[C], dL/dsum_pred[C], dL/dbce_sum }
+template <typename T>
+struct RegionArgs {
+  const T* logits;        // [B][C][V]
+  const int16_t* tgt;     // [B][Ct][V], Ct = C (+1: last channel = ignore mask) values 0 / 1
+  float* sums;            // [B][3C+2]
+  const float* coef;      // [B][2C+1]
+  T* dlogits;
+  int B, C, Ct;
+  long V;
+  int vpb;
+};
+
+template <typename T, int LS_MAXC>
+__global__ __launch_bounds__(256) void dc_bce_fwd_kernel(RegionArgs<T> a) {
+  __shared__ float lred[3 * LS_MAXC + 2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  if (tid < 3 * LS_MAXC + 2) lred[tid] = 0.f;
+  __syncthreads();
+  const long v0 = (long)blockIdx.x * a.vpb;
+  long v1 = v0 + a.vpb;
+  if (v1 > a.V) v1 = a.V;
+  const long base = (long)b * a.C * a.V, tbase = (long)b * a.Ct * a.V;
+  float inter[LS_MAXC], sp[LS_MAXC], sg[LS_MAXC], bce = 0.f, ms = 0.f;
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c) inter[c] = sp[c] = sg[c] = 0.f;
+  for (long v = v0 + tid; v < v1; v += 256) {
+    const float m = a.Ct > a.C ? 1.f - (float)a.tgt[tbase + (long)a.C * a.V + v] : 1.f;
+    ms += m;
+#pragma unroll
+    for (int c = 0; c < LS_MAXC; ++c)
+      if (c < a.C) {
+        const float z = (float)a.logits[base + (long)c * a.V + v];
+        const float y = (float)a.tgt[tbase + (long)c * a.V + v];
+        const float e = __expf(-fabsf(z));
+        const float p = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        inter[c] += p * y * m;
+        sp[c] += p * m;
+        sg[c] += y * m;
+        bce += m * (fmaxf(z, 0.f) - z * y + __logf(1.f + e));
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c)
+    if (c < a.C) {
+      const float x0 = wave_sum(inter[c]), x1 = wave_sum(sp[c]), x2 = wave_sum(sg[c]);
+      if ((tid & 63) == 0) {
+        atomicAdd(&lred[c], x0);
+        atomicAdd(&lred[a.C + c], x1);
+        atomicAdd(&lred[2 * a.C + c], x2);
+      }
+    }
+  const float xb = wave_sum(bce), xm = wave_sum(ms);
+  if ((tid & 63) == 0) {
+    atomicAdd(&lred[3 * a.C], xb);
+    atomicAdd(&lred[3 * a.C + 1], xm);
+  }
+  __syncthreads();
+  if (tid < 3 * a.C + 2) atomicAdd(a.sums + (long)b * (3 * a.C + 2) + tid, lred[tid]);
+}
+
+template <typename T, int LS_MAXC>
+__global__ __launch_bounds__(256) void dc_bce_bwd_kernel(RegionArgs<T> a) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const long v0 = (long)blockIdx.x * a.vpb;
+  long v1 = v0 + a.vpb;
+  if (v1 > a.V) v1 = a.V;
+  const long base = (long)b * a.C * a.V, tbase = (long)b * a.Ct * a.V;
+  float gi[LS_MAXC], gp[LS_MAXC];
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c) {
+    gi[c] = c < a.C ? a.coef[(long)b * (2 * a.C + 1) + c] : 0.f;
+    gp[c] = c < a.C ? a.coef[(long)b * (2 * a.C + 1) + a.C + c] : 0.f;
+  }
+  const float gb = a.coef[(long)b * (2 * a.C + 1) + 2 * a.C];
+  for (long v = v0 + tid; v < v1; v += 256) {
+    const float m = a.Ct > a.C ? 1.f - (float)a.tgt[tbase + (long)a.C * a.V + v] : 1.f;
+#pragma unroll
+    for (int c = 0; c < LS_MAXC; ++c)
+      if (c < a.C) {
+        const float z = (float)a.logits[base + (long)c * a.V + v];
+        const float y = (float)a.tgt[tbase + (long)c * a.V + v];
+        const float e = __expf(-fabsf(z));
+        const float p = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        const float dp = p * (1.f - p);
+        a.dlogits[base + (long)c * a.V + v] = (T)(m * ((gi[c] * y + gp[c]) * dp + gb * (p - y)));
+      }
+  }
+}
+
+// validation statistics of region training: prediction = sigmoid(z) > 0.5 (z > 0) per region channel, masked
+template <typename T, int LS_MAXC>
+__global__ __launch_bounds__(256) void region_stats_kernel(const T* __restrict__ logits, const int16_t* __restrict__ tgt,
+                                                           unsigned long long* __restrict__ counts, int C, int Ct, long V,
+                                                           int vpb) {
+  __shared__ unsigned int lc[3 * LS_MAXC];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  if (tid < 3 * LS_MAXC) lc[tid] = 0u;
+  __syncthreads();
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
+  if (v1 > V) v1 = V;
+  unsigned int tp[LS_MAXC], fp[LS_MAXC], fn[LS_MAXC];
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c) tp[c] = fp[c] = fn[c] = 0u;
+  const long base = (long)b * C * V, tbase = (long)b * Ct * V;
+  for (long v = v0 + tid; v < v1; v += 256) {
+    if (Ct > C && tgt[tbase + (long)C * V + v] != 0) continue;
+#pragma unroll
+    for (int c = 0; c < LS_MAXC; ++c)
+      if (c < C) {
+        const bool pr = (float)logits[base + (long)c * V + v] > 0.f;
+        const bool y = tgt[tbase + (long)c * V + v] != 0;
+        tp[c] += pr & y;
+        fp[c] += pr & !y;
+        fn[c] += !pr & y;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < LS_MAXC; ++c)
+    if (c < C) {
+      const unsigned int a0 = wave_sum_u32(tp[c]), a1 = wave_sum_u32(fp[c]), a2 = wave_sum_u32(fn[c]);
+      if ((tid & 63) == 0) {
+        atomicAdd(&lc[c * 3 + 0], a0);
+        atomicAdd(&lc[c * 3 + 1], a1);
+        atomicAdd(&lc[c * 3 + 2], a2);
+      }
+    }
+  __syncthreads();
+  if (tid < 3 * C && lc[tid]) atomicAdd(counts + tid, (unsigned long long)lc[tid]);
+}
+
+template <typename T>
+static int launch_region(RegionArgs<T> a, int mode, void* counts, hipStream_t s) {
+  if (a.C < 1 || a.C > LS_MAXC_BIG || a.B < 1 || a.V < 1 || (a.Ct != a.C && a.Ct != a.C + 1)) return NNZ_EINVAL;
+  long vpb = (a.V * a.B + 2047) / 2048;
+  if (vpb < 1024) vpb = 1024;
+  if (vpb > a.V) vpb = a.V;
+  a.vpb = (int)vpb;
+  const int gx = (int)((a.V + vpb - 1) / vpb);
+  const bool big = a.C > 8;
+  if (mode == 0) {
+    hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(float) * a.B * (3 * a.C + 2), s);
+    if (e != hipSuccess) return (int)e;
+    if (big) hipLaunchKernelGGL((dc_bce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dc_bce_fwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
+  } else if (mode == 1) {
+    if (big) hipLaunchKernelGGL((dc_bce_bwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dc_bce_bwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
+  } else {
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 3 * a.C, s);
+    if (e != hipSuccess) return (int)e;
+    if (big)
+      hipLaunchKernelGGL((region_stats_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a.logits, a.tgt,
+                         (unsigned long long*)counts, a.C, a.Ct, a.V, (int)vpb);
+    else
+      hipLaunchKernelGGL((region_stats_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a.logits, a.tgt,
+                         (unsigned long long*)counts, a.C, a.Ct, a.V, (int)vpb);
+  }
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
 }  // namespace nnz
+
+extern "C" int nnz_dc_bce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target_regions, float* sums,
+                                       int B, int C, int Ct, long V, void* stream) {
+  using namespace nnz;
+  if (!logits || !target_regions || !sums) return NNZ_EINVAL;
+  if (logits_is_f16) {
+    RegionArgs<f16> a = {};
+    a.logits = (const f16*)logits; a.tgt = target_regions; a.sums = sums; a.B = B; a.C = C; a.Ct = Ct; a.V = V;
+    return launch_region(a, 0, nullptr, (hipStream_t)stream);
+  }
+  RegionArgs<float> a = {};
+  a.logits = (const float*)logits; a.tgt = target_regions; a.sums = sums; a.B = B; a.C = C; a.Ct = Ct; a.V = V;
+  return launch_region(a, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nnz_dc_bce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target_regions,
+                                        const float* coef, void* dlogits, int B, int C, int Ct, long V, void* stream) {
+  using namespace nnz;
+  if (!logits || !target_regions || !coef || !dlogits) return NNZ_EINVAL;
+  if (logits_is_f16) {
+    RegionArgs<f16> a = {};
+    a.logits = (const f16*)logits; a.tgt = target_regions; a.coef = coef; a.dlogits = (f16*)dlogits;
+    a.B = B; a.C = C; a.Ct = Ct; a.V = V;
+    return launch_region(a, 1, nullptr, (hipStream_t)stream);
+  }
+  RegionArgs<float> a = {};
+  a.logits = (const float*)logits; a.tgt = target_regions; a.coef = coef; a.dlogits = (float*)dlogits;
+  a.B = B; a.C = C; a.Ct = Ct; a.V = V;
+  return launch_region(a, 1, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nnz_region_tp_fp_fn(const void* logits, int logits_is_f16, const int16_t* target_regions, void* counts_u64,
+                                   int B, int C, int Ct, long V, void* stream) {
+  using namespace nnz;
+  if (!logits || !target_regions || !counts_u64) return NNZ_EINVAL;
+  if (logits_is_f16) {
+    RegionArgs<f16> a = {};
+    a.logits = (const f16*)logits; a.tgt = target_regions; a.B = B; a.C = C; a.Ct = Ct; a.V = V;
+    return launch_region(a, 2, counts_u64, (hipStream_t)stream);
+  }
+  RegionArgs<float> a = {};
+  a.logits = (const float*)logits; a.tgt = target_regions; a.B = B; a.C = C; a.Ct = Ct; a.V = V;
+  return launch_region(a, 2, counts_u64, (hipStream_t)stream);
+}
 
 extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const int16_t* target, void* counts_u64,
                                    int B, int C, long V, int ignore_label, void* stream) {

@@ -234,3 +234,34 @@ def argmax_tp_fp_fn(logits: torch.Tensor, target_i16: torch.Tensor, ignore_label
     call("nnz_argmax_tp_fp_fn", ptr(logits), _logits_kind(logits), ptr(target_i16.contiguous()), ptr(counts), B, Cc, V,
          int(ignore_label), stream_ptr())
     return counts[:, 0], counts[:, 1], counts[:, 2]
+
+
+def _regions_i16(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.HipCallError("region targets must be device tensors")
+    return (t if t.dtype == torch.int16 else t.to(torch.int16)).contiguous()
+
+
+def dc_bce_forward(logits, target_regions_i16, sums, B, Cc, Ct, V):
+    _f32(sums, "loss.sums")
+    call("nnz_dc_bce_loss_forward", ptr(logits), _logits_kind(logits), ptr(target_regions_i16), ptr(sums), B, Cc, Ct, V,
+         stream_ptr())
+
+
+def dc_bce_backward(logits, target_regions_i16, coef, dlogits, B, Cc, Ct, V):
+    _f32(coef, "loss.coef")
+    call("nnz_dc_bce_loss_backward", ptr(logits), _logits_kind(logits), ptr(target_regions_i16), ptr(coef), ptr(dlogits),
+         B, Cc, Ct, V, stream_ptr())
+
+
+def region_tp_fp_fn(logits: torch.Tensor, target_regions: torch.Tensor):
+    """(B, C, *spatial) logits + (B, C[+1], *spatial) 0/1 region targets (last channel = ignore mask if present) ->
+    exact int64 (tp, fp, fn) per region for the prediction sigmoid(z) > 0.5"""
+    logits = logits.contiguous()
+    tgt = _regions_i16(target_regions)
+    B, Cc = logits.shape[:2]
+    V = logits[0, 0].numel()
+    counts = torch.empty((Cc, 3), dtype=torch.int64, device=logits.device)
+    call("nnz_region_tp_fp_fn", ptr(logits), _logits_kind(logits), ptr(tgt), ptr(counts), B, Cc, int(tgt.shape[1]), V,
+         stream_ptr())
+    return counts[:, 0], counts[:, 1], counts[:, 2]

@@ -158,6 +158,78 @@ class DC_and_CE_loss(nn.Module):
         return self.weight_ce * ce_loss + self.weight_dice * dc_loss
 
 
+class _FusedDiceBCE(torch.autograd.Function):
+    """sigmoid + Dice sums + BCE-with-logits sum in one pass over the logits; backward one more pass (csrc/loss.hip)"""
+
+    @staticmethod
+    def forward(ctx, logits: torch.Tensor, target: torch.Tensor):
+        from .. import hip_ops as ops
+        B, C = logits.shape[:2]
+        Ct = target.shape[1]
+        V = logits[0, 0].numel()
+        sums = torch.empty((B, 3 * C + 2), dtype=torch.float32, device=logits.device)
+        ops.dc_bce_forward(logits, target, sums, B, C, Ct, V)
+        ctx.save_for_backward(logits, target)
+        ctx.dims = (B, C, Ct, V)
+        intersect, sum_pred, sum_gt = sums[:, :C].clone(), sums[:, C:2 * C].clone(), sums[:, 2 * C:3 * C].clone()
+        bce_sum, mask_sum = sums[:, 3 * C].clone(), sums[:, 3 * C + 1].clone()
+        ctx.mark_non_differentiable(sum_gt, mask_sum)
+        return intersect, sum_pred, sum_gt, bce_sum, mask_sum
+
+    @staticmethod
+    def backward(ctx, g_int, g_pred, g_gt, g_bce, g_mask):
+        from .. import hip_ops as ops
+        logits, target = ctx.saved_tensors
+        B, C, Ct, V = ctx.dims
+        coef = torch.zeros((B, 2 * C + 1), dtype=torch.float32, device=logits.device)
+        if g_int is not None:
+            coef[:, :C] = g_int
+        if g_pred is not None:
+            coef[:, C:2 * C] = g_pred
+        if g_bce is not None:
+            coef[:, 2 * C] = g_bce
+        dlogits = torch.empty_like(logits)
+        ops.dc_bce_backward(logits, target, coef, dlogits, B, C, Ct, V)
+        return dlogits, None
+
+
+class DC_and_BCE_loss(nn.Module):
+    """Region-based training loss (reference: training/loss/compound_losses.py:59-109): sigmoid soft Dice over the region
+    channels (all of them: do_bg=True is the trainer's setting) + BCE-with-logits, optional ignore mask in the target's
+    last channel.  One fused HIP pass; bce_kwargs must be {} (what nnUNetTrainer._build_loss passes)."""
+
+    def __init__(self, bce_kwargs, soft_dice_kwargs, weight_ce=1, weight_dice=1, use_ignore_label: bool = False,
+                 dice_class=MemoryEfficientSoftDiceLoss):
+        super().__init__()
+        if bce_kwargs:
+            raise NotImplementedError("fused HIP loss: bce_kwargs must be {}")
+        if dice_class is not MemoryEfficientSoftDiceLoss:
+            raise NotImplementedError("fused HIP loss: dice_class must be MemoryEfficientSoftDiceLoss")
+        self.weight_dice, self.weight_ce, self.use_ignore_label = weight_dice, weight_ce, use_ignore_label
+        self.dc = dice_class(apply_nonlin=torch.sigmoid, **soft_dice_kwargs)
+
+    def forward(self, net_output: torch.Tensor, target: torch.Tensor):
+        if not net_output.is_cuda:
+            raise RuntimeError("nnuzoo_amd losses run on MI355X through libnnuzoo_hip.so only (no CPU fallback); "
+                               "the CPU restatement is oracle/losses.py (test-only)")
+        C = net_output.shape[1]
+        if C > 32:
+            raise NotImplementedError("fused Dice+BCE kernel supports up to 32 regions")
+        want = C + 1 if self.use_ignore_label else C
+        assert target.shape[1] == want, f"target must hold {want} channels (regions{' + ignore mask' if self.use_ignore_label else ''})"
+        from ..hip_ops import _regions_i16
+        intersect, sum_pred, sum_gt, bce_sum, mask_sum = _FusedDiceBCE.apply(net_output.contiguous(), _regions_i16(target))
+        if not self.dc.do_bg:
+            intersect, sum_pred, sum_gt = intersect[:, 1:], sum_pred[:, 1:], sum_gt[:, 1:]
+        dc_loss = self.dc.dice_from_sums(intersect, sum_pred, sum_gt.detach())
+        if self.use_ignore_label:
+            # (bce * mask).sum() / clip(mask.sum(), 1e-8): summed over regions, averaged over the unmasked voxels
+            ce_loss = bce_sum.sum() / torch.clip(mask_sum.sum(), min=1e-8)
+        else:
+            ce_loss = bce_sum.sum() / (net_output.shape[0] * C * net_output[0, 0].numel())
+        return self.weight_ce * ce_loss + self.weight_dice * dc_loss
+
+
 class DeepSupervisionWrapper(nn.Module):
     def __init__(self, loss, weight_factors=None):
         super().__init__()

@@ -29,7 +29,7 @@ from .. import hip_ops as ops
 from ..ddp import attach_bucketed_allreduce
 from ..utilities.get_network_from_plans import get_network_from_plans
 from .fused_sgd import FusedSGD
-from .loss import DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
+from .loss import DC_and_BCE_loss, DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
 from .lr_scheduler import PolyLRScheduler
 
 
@@ -68,18 +68,35 @@ class ConfigurationView:
         return self.network_arch_init_kwargs['strides']
 
 
+def _has_regions(dataset_json: dict) -> bool:
+    """LabelManager.has_regions (label_handling.py:46-48): any label declared as a list / tuple of label values"""
+    return any(isinstance(v, (list, tuple)) and len(v) > 1 for v in dataset_json['labels'].values())
+
+
 def _num_segmentation_heads(dataset_json: dict) -> int:
+    """LabelManager.num_segmentation_heads (label_handling.py:58-100): one head per label, or per foreground region"""
     labels = dataset_json['labels']
-    if any(isinstance(v, (list, tuple)) for v in labels.values()):
-        raise NotImplementedError("region-based training is outside the hot-path scope")
-    return len([k for k in labels if k != 'ignore'])     # LabelManager.num_segmentation_heads (label_handling.py:58-75)
+    if _has_regions(dataset_json):
+        n = 0
+        for k, r in labels.items():
+            if k == 'ignore':
+                continue
+            vals = set(r) if isinstance(r, (list, tuple)) else {r}
+            if vals == {0}:
+                continue                      # regions that are background
+            n += 1
+        return n
+    return len([k for k in labels if k != 'ignore'])
 
 
 def _ignore_label(dataset_json: dict):
     """LabelManager.ignore_label (label_handling.py:102-127): the integer under the key 'ignore' (must be the highest)"""
     ig = dataset_json['labels'].get('ignore')
     if ig is not None:
-        others = [v for k, v in dataset_json['labels'].items() if k != 'ignore']
+        others = []
+        for k, v in dataset_json['labels'].items():
+            if k != 'ignore':
+                others += [int(i) for i in v] if isinstance(v, (list, tuple)) else [int(v)]
         assert isinstance(ig, int) and ig == max(others) + 1, \
             'If you use the ignore label it must have the highest label value! It cannot be 0 or in between other labels.'
     return ig
@@ -203,10 +220,15 @@ class nnUNetTrainer:
         return False  # the explicit HIP schedule replaces torch.compile (nnUNetTrainer.py:296-322)
 
     def _build_loss(self):
-        loss = DC_and_CE_loss({'batch_dice': self.configuration_manager.batch_dice, 'smooth': 1e-5, 'do_bg': False,
-                               'ddp': self.is_ddp}, {}, weight_ce=1, weight_dice=1,
-                              ignore_label=_ignore_label(self.dataset_json),
-                              dice_class=MemoryEfficientSoftDiceLoss)
+        ig = _ignore_label(self.dataset_json)
+        if _has_regions(self.dataset_json):
+            loss = DC_and_BCE_loss({}, {'batch_dice': self.configuration_manager.batch_dice, 'do_bg': True, 'smooth': 1e-5,
+                                        'ddp': self.is_ddp}, use_ignore_label=ig is not None,
+                                   dice_class=MemoryEfficientSoftDiceLoss)
+        else:
+            loss = DC_and_CE_loss({'batch_dice': self.configuration_manager.batch_dice, 'smooth': 1e-5, 'do_bg': False,
+                                   'ddp': self.is_ddp}, {}, weight_ce=1, weight_dice=1, ignore_label=ig,
+                                  dice_class=MemoryEfficientSoftDiceLoss)
         if self.enable_deep_supervision:
             scales = self._get_deep_supervision_scales()
             weights = np.array([1 / (2 ** i) for i in range(len(scales))])
@@ -281,14 +303,19 @@ class nnUNetTrainer:
             l = self.loss(output, target)
         if self.enable_deep_supervision:
             output, target = output[0], target[0]
-        # argmax + TP/FP/FN in one HIP pass over logits and labels (reference: argmax -> one-hot scatter ->
-        # get_tp_fp_fn_tn, nnUNetTrainer.py:1201-1221); float32 arrays like the reference's, background dropped
-        tgt = target if target.dtype == torch.int16 else target.to(torch.int16)
+        # online-Dice statistics in one HIP pass over logits and labels (reference: argmax / sigmoid -> one-hot ->
+        # get_tp_fp_fn_tn with the ignore mask, nnUNetTrainer.py:1188-1226); float32 arrays like the reference's
         ig = _ignore_label(self.dataset_json)
-        tp, fp, fn = ops.argmax_tp_fp_fn(output, tgt, -32768 if ig is None else ig)
+        if _has_regions(self.dataset_json):
+            tp, fp, fn = ops.region_tp_fp_fn(output, target)      # the ignore mask is the target's last channel
+            first = 0                                             # every head predicts some foreground region
+        else:
+            tgt = target if target.dtype == torch.int16 else target.to(torch.int16)
+            tp, fp, fn = ops.argmax_tp_fp_fn(output, tgt, -32768 if ig is None else ig)
+            first = 1                                             # drop the background class
         stats = torch.stack([tp, fp, fn]).to(torch.float32).cpu().numpy()
-        return {'loss': l.detach().cpu().numpy(), 'tp_hard': stats[0][1:], 'fp_hard': stats[1][1:],
-                'fn_hard': stats[2][1:]}
+        return {'loss': l.detach().cpu().numpy(), 'tp_hard': stats[0][first:], 'fp_hard': stats[1][first:],
+                'fn_hard': stats[2][first:]}
 
     @staticmethod
     def pseudo_dice(val_outputs: List[dict]) -> List[float]:

@@ -49,6 +49,46 @@ def dc_and_ce(x_logits, y, batch_dice, weight_ce=1.0, weight_dice=1.0, ignore_la
     return weight_ce * ce + weight_dice * dc
 
 
+def dc_and_bce(x_logits, y_regions, batch_dice, use_ignore_label=False, smooth=1e-5):
+    """DC_and_BCE_loss.forward (compound_losses.py:82-109) with MemoryEfficientSoftDiceLoss(sigmoid, do_bg=True)"""
+    if use_ignore_label:
+        mask = (1 - y_regions[:, -1:]).bool()
+        yr = y_regions[:, :-1]
+    else:
+        mask, yr = None, y_regions
+    x = torch.sigmoid(x_logits.float())
+    axes = tuple(range(2, x.ndim))
+    yf = yr.float()
+    if mask is None:
+        intersect, sum_pred, sum_gt = (x * yf).sum(axes), x.sum(axes), yf.sum(axes)
+    else:
+        intersect, sum_pred, sum_gt = (x * yf * mask).sum(axes), (x * mask).sum(axes), (yf * mask).sum(axes)
+    if batch_dice:
+        intersect, sum_pred, sum_gt = intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)
+    dc = -((2 * intersect + smooth) / torch.clip(sum_gt + sum_pred + smooth, 1e-8)).mean()
+    if mask is not None:
+        bce = (F.binary_cross_entropy_with_logits(x_logits.float(), yf, reduction='none') * mask).sum() / \
+            torch.clip(mask.sum(), min=1e-8)
+    else:
+        bce = F.binary_cross_entropy_with_logits(x_logits.float(), yf)
+    return bce + dc
+
+
+def region_tp_fp_fn(logits, target_regions, use_ignore_label=False):
+    """validation_step for regions (nnUNetTrainer.py:1188-1216): prediction sigmoid > 0.5, get_tp_fp_fn_tn with mask"""
+    axes = [0] + list(range(2, logits.ndim))
+    pred = (torch.sigmoid(logits.float()) > 0.5).float()
+    if use_ignore_label:
+        mask = (1 - target_regions[:, -1:]).float()
+        tgt = target_regions[:, :-1].float()
+    else:
+        mask, tgt = torch.ones_like(pred[:, :1]), target_regions.float()
+    tp = (pred * tgt * mask).sum(axes)
+    fp = (pred * (1 - tgt) * mask).sum(axes)
+    fn = ((1 - pred) * tgt * mask).sum(axes)
+    return tp, fp, fn
+
+
 def ds_weights(n_outputs, ddp_no_compile=False):
     w = np.array([1 / (2 ** i) for i in range(n_outputs)])
     w[-1] = 1e-6 if ddp_no_compile else 0

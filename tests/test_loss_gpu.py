@@ -106,3 +106,67 @@ def test_ignore_label_matches_reference_golden(hip_lib, tag):
     assert torch.equal(tp.cpu().float(), (oh * yo * m).sum(axes))
     assert torch.equal(fp.cpu().float(), (oh * (~yo) * m).sum(axes))
     assert torch.equal(fn.cpu().float(), ((1 - oh) * yo * m).sum(axes))
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_region_loss_matches_reference_golden(hip_lib, tag, dtype):
+    """fused sigmoid-Dice + BCE kernel (region-based training) against the reference's DC_and_BCE_loss fixtures, plain and
+    with the ignore-mask channel; validation statistics (sigmoid > 0.5) against the oracle formula, exact"""
+    import os
+    from nnuzoo_amd import hip_ops as ops
+    from nnuzoo_amd.training.loss import DC_and_BCE_loss
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"loss_regions_{tag}.npz"))
+    bd = bool(g["batch_dice"])
+    logits = torch.from_numpy(g["logits"]).to(dtype)
+    r, ig = torch.from_numpy(g["regions"]), torch.from_numpy(g["ignore"])
+    for name, use, t in (("plain", False, r), ("masked", True, torch.cat([r, ig], 1))):
+        loss = DC_and_BCE_loss({}, {'batch_dice': bd, 'do_bg': True, 'smooth': 1e-5, 'ddp': False}, use_ignore_label=use,
+                               dice_class=MemoryEfficientSoftDiceLoss)
+        x = logits.cuda().requires_grad_(True)
+        l = loss(x, t.cuda())
+        l.backward()
+        if dtype == torch.float32:
+            ref_l, ref_g = float(g[f"{name}_loss"]), torch.from_numpy(g[f"{name}_dlogits"])
+            ltol, gtol = 2e-5, 1e-4
+        else:   # fp16 logits: compare with the oracle on the rounded logits
+            xr = logits.float().requires_grad_(True)
+            lr_ = O.dc_and_bce(xr, t, bd, use)
+            (ref_g,) = torch.autograd.grad(lr_, xr)
+            ref_l, ltol, gtol = float(lr_.detach()), 2e-5, 2e-3
+        assert abs(float(l) - ref_l) <= ltol * max(1.0, abs(ref_l)), (float(l), ref_l)
+        got = x.grad.float().cpu()
+        assert torch.allclose(got, ref_g, rtol=gtol, atol=gtol * ref_g.abs().max().item())
+        tp, fp, fn = ops.region_tp_fp_fn(logits.cuda(), t.cuda())
+        rtp, rfp, rfn = O.region_tp_fp_fn(logits, t, use)
+        assert torch.equal(tp.cpu().float(), rtp) and torch.equal(fp.cpu().float(), rfp) and torch.equal(fn.cpu().float(), rfn)
+
+
+def test_region_trainer_step(hip_lib):
+    """nnUNetTrainer with a region-based dataset.json (+ ignore label): heads = foreground regions, DC_and_BCE_loss,
+    train and validation step run on one-hot region targets"""
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+    plans, cfg, dj = nnunet_plans(3, (32, 32, 32), batch_size=2)
+    dj = dict(dj)
+    dj["labels"] = {"background": 0, "whole": [1, 2, 3], "core": [2, 3], "enh": 3, "ignore": 4}
+    dj["regions_class_order"] = [1, 2, 3]
+    tr = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    assert tr.network.num_classes == 3
+    scales = tr._get_deep_supervision_scales()
+    base = synthetic_batch(2, (32, 32, 32), scales, seed=4)
+    g = torch.Generator().manual_seed(1)
+    tgt = []
+    for t in base["target"]:
+        lab = torch.randint(0, 5, t.shape, generator=g)                    # labels 0..3 and the ignore label 4
+        reg = torch.cat([((lab >= 1) & (lab <= 3)), ((lab >= 2) & (lab <= 3)), (lab == 3), (lab == 4)], 1).to(torch.int16)
+        tgt.append(reg)
+    batch = {"data": base["data"], "target": tgt}
+    l0 = float(tr.train_step(batch)["loss"])
+    l1 = float(tr.train_step(batch)["loss"])
+    assert np.isfinite(l0) and np.isfinite(l1)
+    v = tr.validation_step(batch)
+    assert v["tp_hard"].shape == (3,) and np.isfinite(v["loss"])
+    keep = int((tgt[0][:, 3] == 0).sum())
+    assert int(v["tp_hard"][0] + v["fn_hard"][0]) == int(((tgt[0][:, 0] == 1) & (tgt[0][:, 3] == 0)).sum()) <= keep

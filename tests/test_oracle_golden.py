@@ -83,3 +83,16 @@ def test_loss_oracle_ignore_label_vs_reference_golden(tag):
     assert np.allclose(gr.numpy(), gi["dlogits"], atol=1e-7)
     l_all = O.dc_and_ce(x.detach(), torch.full_like(t, ig), bool(g["batch_dice"]), ignore_label=ig)
     assert abs(float(l_all) - float(gi["loss_all_ignored"])) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_region_loss_oracle_vs_reference_golden(tag):
+    """DC_and_BCE_loss (region-based training), plain and with the ignore-mask channel (tools/make_golden.py)"""
+    g = np.load(os.path.join(G, f"loss_regions_{tag}.npz"))
+    x, r, ig = torch.from_numpy(g["logits"]), torch.from_numpy(g["regions"]), torch.from_numpy(g["ignore"])
+    for name, use, t in (("plain", False, r), ("masked", True, torch.cat([r, ig], 1))):
+        xx = x.clone().requires_grad_(True)
+        l = OL.dc_and_bce(xx, t, bool(g["batch_dice"]), use)
+        (gr,) = torch.autograd.grad(l, xx)
+        assert abs(float(l.detach()) - float(g[f"{name}_loss"])) < 1e-6
+        assert np.allclose(gr.numpy(), g[f"{name}_dlogits"], atol=1e-7)

@@ -106,6 +106,28 @@ def gen_losses():
                             dlogits=g_ig.numpy(), loss_all_ignored=l_all.detach().numpy(), ignore_label=np.array(C))
 
 
+def gen_region_losses():
+    """DC_and_BCE_loss (region-based training) from the reference's module: plain and with the ignore-mask channel"""
+    from nnunetv2.training.loss.compound_losses import DC_and_BCE_loss
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    for tag, (shape, C, batch_dice) in {"3d": ((2, 9, 10, 11), 3, False), "2d": ((3, 24, 20), 4, True)}.items():
+        g = torch.Generator().manual_seed(17)
+        B, sp = shape[0], shape[1:]
+        logits = (torch.randn(B, C, *sp, generator=g) * 2)
+        regions = (torch.rand(B, C, *sp, generator=g) < 0.35).to(torch.int16)
+        ign = (torch.rand(B, 1, *sp, generator=g) < 0.2).to(torch.int16)
+        out = dict(logits=logits.numpy(), regions=regions.numpy(), ignore=ign.numpy(), batch_dice=np.array(batch_dice))
+        for name, use_ig, tgt in (("plain", False, regions), ("masked", True, torch.cat([regions, ign], 1))):
+            loss = DC_and_BCE_loss({}, {'batch_dice': batch_dice, 'do_bg': True, 'smooth': 1e-5, 'ddp': False},
+                                   use_ignore_label=use_ig, dice_class=MemoryEfficientSoftDiceLoss)
+            x = logits.clone().requires_grad_(True)
+            l = loss(x, tgt)
+            (gr,) = torch.autograd.grad(l, x)
+            out[f"{name}_loss"] = l.detach().numpy()
+            out[f"{name}_dlogits"] = gr.numpy()
+        np.savez_compressed(os.path.join(OUT, f"loss_regions_{tag}.npz"), **out)
+
+
 def gen_window_attention():
     from nnunetv2.nets import swt2net
     for tag, (dim, heads, shift, HW) in {"s": (32, 2, True, 14), "n": (64, 4, False, 21)}.items():
@@ -350,6 +372,7 @@ if __name__ == "__main__":
         gen_selective_scan(ref)
     if "loss" in which:
         gen_losses()
+        gen_region_losses()
     if "attn" in which:
         gen_window_attention()
     if "ss2d" in which:
