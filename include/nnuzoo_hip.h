@@ -149,6 +149,19 @@ int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t*
                            long V, int ignore_label, void* stream);
 int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
                             void* dlogits, int B, int C, long V, int ignore_label, void* stream);
+/* value and gradient coefficients of DC_and_CE_loss from the sums, on the device (one launch per deep-supervision
+ * output instead of ~25 element-wise ones): dice = -mean((2I + smooth) / clip(G + P + smooth, 1e-8)) over (b, c) or,
+ * with batch_dice, over c of the batch sums (dice.py:105-119), classes 1.. only unless do_bg; ce = sum(ce_sum) / n with
+ * n = B*V, or the number of non-ignored voxels clamped to >= 1 when use_valid_count (compound_losses.py:44-52).
+ * loss_accum[0] += ds_weight * (weight_ce * ce + weight_dice * dice)   (deep_supervision.py:30: sum of weighted losses)
+ * coef[b] = ds_weight * {dL/dI[C], dL/dP[C], dL/dce_sum}.  _backward_scaled multiplies coef by the device scalar
+ * gmul_device[0] (the upstream gradient, i.e. the GradScaler's loss scale) when it is not NULL. */
+int nnz_dc_ce_loss_finalize(const float* sums, float* loss_accum, float* coef, int B, int C, long V, int batch_dice,
+                            int do_bg, float smooth, float weight_ce, float weight_dice, float ds_weight,
+                            int use_valid_count, void* stream);
+int nnz_dc_ce_loss_backward_scaled(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
+                                   const float* gmul_device, void* dlogits, int B, int C, long V, int ignore_label,
+                                   void* stream);
 
 /* region-based training (label_manager.has_regions): sigmoid soft-Dice (do_bg) + BCE-with-logits statistics of
  * DC_and_BCE_loss (compound_losses.py:59-109) on one-hot region targets [B][Ct][V] (int16 0/1; Ct = C, or C+1 with the

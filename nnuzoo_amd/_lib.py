@@ -90,6 +90,8 @@ SIGNATURES = {
     "nnz_argmax_tp_fp_fn": [_vp, _i, _vp, _vp, _i, _i, _l, _i, _vp],
     "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _i, _vp],
     "nnz_dc_ce_loss_backward": [_vp, _i, _vp, _fp, _vp, _i, _i, _l, _i, _vp],
+    "nnz_dc_ce_loss_finalize": [_fp, _fp, _fp, _i, _i, _l, _i, _i, _f, _f, _f, _f, _i, _vp],
+    "nnz_dc_ce_loss_backward_scaled": [_vp, _i, _vp, _fp, _fp, _vp, _i, _i, _l, _i, _vp],
     "nnz_sliding_window_accumulate": [_vp, _i, _ip, _vp, _vp, _vp, _i, _ip, _ip, _ip, _vp],
     "nnz_sliding_window_finalize": [_vp, _vp, _i, _l, _vp, _vp],
     "nnz_causal_conv1d_silu_forward": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],

@@ -20,6 +20,7 @@ struct LossArgs {
   const int16_t* tgt;   // [B][V]
   float* sums;          // [B][3C+1]
   const float* coef;    // [B][2C+1]
+  const float* gmul;    // optional device scalar multiplying every coefficient (upstream gradient of the loss)
   T* dlogits;           // [B][C][V]
   int B, C;
   long V;
@@ -106,12 +107,13 @@ __global__ __launch_bounds__(256) void dc_ce_bwd_kernel(LossArgs<T> a) {
   if (v1 > a.V) v1 = a.V;
   const long base = (long)b * a.C * a.V;
   float gi[LS_MAXC], gp[LS_MAXC];
+  const float gm = a.gmul ? a.gmul[0] : 1.f;
 #pragma unroll
   for (int c = 0; c < LS_MAXC; ++c) {
-    gi[c] = c < a.C ? a.coef[(long)b * (2 * a.C + 1) + c] : 0.f;
-    gp[c] = c < a.C ? a.coef[(long)b * (2 * a.C + 1) + a.C + c] : 0.f;
+    gi[c] = c < a.C ? gm * a.coef[(long)b * (2 * a.C + 1) + c] : 0.f;
+    gp[c] = c < a.C ? gm * a.coef[(long)b * (2 * a.C + 1) + a.C + c] : 0.f;
   }
-  const float gce = a.coef[(long)b * (2 * a.C + 1) + 2 * a.C];
+  const float gce = gm * a.coef[(long)b * (2 * a.C + 1) + 2 * a.C];
   for (long v = v0 + tid; v < v1; v += 256) {
     const int t = a.tgt[(long)b * a.V + v];
     if (t == a.ignore) {
@@ -218,6 +220,73 @@ __global__ __launch_bounds__(256) void argmax_stats_kernel(const T* __restrict__
     }
   __syncthreads();
   if (tid < 3 * C && lc[tid]) atomicAdd(counts + tid, (unsigned long long)lc[tid]);
+}
+
+// ---- loss value + gradient coefficients from the sums, one tiny launch per deep-supervision output ------------------
+// Replaces the ~25 element-wise torch launches per output that turn {intersect, sum_pred, sum_gt, ce_sum} into
+// DC_and_CE_loss's value (dice.py:105-119: dc = (2I + s) / clip(G + P + s, 1e-8), loss = -mean(dc); CE mean) and, through
+// autograd, into the coefficients the backward kernel needs.  loss_accum[0] += ds_weight * (w_ce * ce + w_dice * dice);
+// coef[b] = ds_weight * {dL/dI[C], dL/dP[C], dL/dce_sum} (classes excluded by do_bg = false get 0).
+struct FinalizeArgs {
+  const float* sums;  // [B][3C+1]
+  float* loss_accum;  // [1]
+  float* coef;        // [B][2C+1]
+  int B, C;
+  long V;
+  int batch_dice, do_bg, use_valid_count;
+  float smooth, w_ce, w_dice, ds_weight;
+};
+
+__global__ __launch_bounds__(64) void dc_ce_finalize_kernel(FinalizeArgs a) {
+  const int lane = threadIdx.x;
+  const int C = a.C, S = 3 * C + 1, c0 = a.do_bg ? 0 : 1, KC = C - c0;
+  float dice_sum = 0.f;
+  if (a.batch_dice) {
+    for (int c = c0 + lane; c < C; c += 64) {
+      float I = 0.f, P = 0.f, G = 0.f;
+      for (int b = 0; b < a.B; ++b) {
+        I += a.sums[b * S + c];
+        P += a.sums[b * S + C + c];
+        G += a.sums[b * S + 2 * C + c];
+      }
+      const float raw = G + P + a.smooth, den = fmaxf(raw, 1e-8f);
+      dice_sum += (2.f * I + a.smooth) / den;
+      const float k = a.ds_weight * a.w_dice / (float)KC;
+      const float dI = -2.f / den * k;
+      const float dP = raw > 1e-8f ? (2.f * I + a.smooth) / (den * den) * k : 0.f;
+      for (int b = 0; b < a.B; ++b) {
+        a.coef[b * (2 * C + 1) + c] = dI;
+        a.coef[b * (2 * C + 1) + C + c] = dP;
+      }
+    }
+  } else {
+    const int n = a.B * KC;
+    for (int i = lane; i < n; i += 64) {
+      const int b = i / KC, c = c0 + i % KC;
+      const float I = a.sums[b * S + c], P = a.sums[b * S + C + c], G = a.sums[b * S + 2 * C + c];
+      const float raw = G + P + a.smooth, den = fmaxf(raw, 1e-8f);
+      dice_sum += (2.f * I + a.smooth) / den;
+      const float k = a.ds_weight * a.w_dice / (float)n;
+      a.coef[b * (2 * C + 1) + c] = -2.f / den * k;
+      a.coef[b * (2 * C + 1) + C + c] = raw > 1e-8f ? (2.f * I + a.smooth) / (den * den) * k : 0.f;
+    }
+  }
+  if (!a.do_bg)
+    for (int b = lane; b < a.B; b += 64) a.coef[b * (2 * C + 1) + 0] = a.coef[b * (2 * C + 1) + C] = 0.f;
+  dice_sum = wave_sum(dice_sum);
+  float ce = 0.f, valid = 0.f;
+  for (int b = lane; b < a.B; b += 64) {
+    ce += a.sums[b * S + 3 * C];
+    for (int c = 0; c < C; ++c) valid += a.sums[b * S + 2 * C + c];
+  }
+  ce = wave_sum(ce);
+  valid = wave_sum(valid);
+  const float nvox = a.use_valid_count ? fmaxf(valid, 1.f) : (float)a.B * (float)a.V;
+  for (int b = lane; b < a.B; b += 64) a.coef[b * (2 * C + 1) + 2 * C] = a.ds_weight * a.w_ce / nvox;
+  if (lane == 0) {
+    const float dice = -dice_sum / (float)(a.batch_dice ? KC : a.B * KC);
+    atomicAdd(a.loss_accum, a.ds_weight * (a.w_ce * ce / nvox + a.w_dice * dice));
+  }
 }
 
 // ---- region-based training: sigmoid Dice + BCE-with-logits over one-hot region targets ------------------------------
@@ -475,16 +544,41 @@ extern "C" int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, con
   return launch_loss(a, false, (hipStream_t)stream);
 }
 
+extern "C" int nnz_dc_ce_loss_finalize(const float* sums, float* loss_accum, float* coef, int B, int C, long V,
+                                       int batch_dice, int do_bg, float smooth, float weight_ce, float weight_dice,
+                                       float ds_weight, int use_valid_count, void* stream) {
+  using namespace nnz;
+  if (!sums || !loss_accum || !coef || B < 1 || C < 1 || C > LS_MAXC_BIG || (!do_bg && C < 2)) return NNZ_EINVAL;
+  FinalizeArgs a = {};
+  a.sums = sums; a.loss_accum = loss_accum; a.coef = coef; a.B = B; a.C = C; a.V = V;
+  a.batch_dice = batch_dice; a.do_bg = do_bg; a.use_valid_count = use_valid_count;
+  a.smooth = smooth; a.w_ce = weight_ce; a.w_dice = weight_dice; a.ds_weight = ds_weight;
+  hipLaunchKernelGGL(dc_ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_dc_ce_loss_backward_scaled(const void* logits, int logits_is_f16, const int16_t* target,
+                                              const float* coef, const float* gmul_device, void* dlogits, int B, int C,
+                                              long V, int ignore_label, void* stream);
+
 extern "C" int nnz_dc_ce_loss_backward(const void* logits, int logits_is_f16, const int16_t* target, const float* coef,
                                        void* dlogits, int B, int C, long V, int ignore_label, void* stream) {
+  return nnz_dc_ce_loss_backward_scaled(logits, logits_is_f16, target, coef, nullptr, dlogits, B, C, V, ignore_label,
+                                        stream);
+}
+
+extern "C" int nnz_dc_ce_loss_backward_scaled(const void* logits, int logits_is_f16, const int16_t* target,
+                                              const float* coef, const float* gmul_device, void* dlogits, int B, int C,
+                                              long V, int ignore_label, void* stream) {
   using namespace nnz;
   if (!logits || !target || !coef || !dlogits) return NNZ_EINVAL;
   if (logits_is_f16) {
     LossArgs<f16> a = {};
-    a.logits = (const f16*)logits; a.tgt = target; a.coef = coef; a.dlogits = (f16*)dlogits; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
+    a.logits = (const f16*)logits; a.tgt = target; a.coef = coef; a.gmul = gmul_device; a.dlogits = (f16*)dlogits; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
     return launch_loss(a, true, (hipStream_t)stream);
   }
   LossArgs<float> a = {};
-  a.logits = (const float*)logits; a.tgt = target; a.coef = coef; a.dlogits = (float*)dlogits; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
+  a.logits = (const float*)logits; a.tgt = target; a.coef = coef; a.gmul = gmul_device; a.dlogits = (float*)dlogits; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
   return launch_loss(a, true, (hipStream_t)stream);
 }

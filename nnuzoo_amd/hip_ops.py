@@ -223,6 +223,21 @@ def dc_ce_backward(logits, target_i16, coef, dlogits, B, Cc, V, ignore_label: in
          V, int(ignore_label), stream_ptr())
 
 
+def dc_ce_finalize(sums, loss_accum, coef, B, Cc, V, batch_dice, do_bg, smooth, weight_ce, weight_dice, ds_weight,
+                   use_valid_count):
+    _f32(sums, "loss.sums"), _f32(loss_accum, "loss.loss_accum"), _f32(coef, "loss.coef")
+    call("nnz_dc_ce_loss_finalize", ptr(sums), ptr(loss_accum), ptr(coef), B, Cc, V, int(batch_dice), int(do_bg),
+         float(smooth), float(weight_ce), float(weight_dice), float(ds_weight), int(use_valid_count), stream_ptr())
+
+
+def dc_ce_backward_scaled(logits, target_i16, coef, gmul, dlogits, B, Cc, V, ignore_label: int = NO_IGNORE):
+    _f32(coef, "loss.coef"), _f32(gmul, "loss.gmul")
+    if dlogits.dtype != logits.dtype:
+        raise _lib.HipCallError("loss: dlogits dtype must equal logits dtype")
+    call("nnz_dc_ce_loss_backward_scaled", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(coef), ptr(gmul),
+         ptr(dlogits), B, Cc, V, int(ignore_label), stream_ptr())
+
+
 def argmax_tp_fp_fn(logits: torch.Tensor, target_i16: torch.Tensor, ignore_label: int = -32768):
     """(B, C, *spatial) logits + (B, 1, *spatial) int16 labels -> exact int64 (tp, fp, fn) per class, one pass"""
     if target_i16.dtype != torch.int16 or not target_i16.is_cuda:

@@ -125,6 +125,61 @@ class _FusedDiceCE(torch.autograd.Function):
         return dlogits, None, None
 
 
+def _prep_target(net_output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    if target.ndim == net_output.ndim:
+        assert target.shape[1] == 1, "target must be a label map (b, 1, ...)"
+    return (target if target.dtype == torch.int16 else target.to(torch.int16)).contiguous()
+
+
+class _FusedDSDiceCE(torch.autograd.Function):
+    """The whole (deep-supervision) DC_and_CE_loss on the device: per output one statistics pass over the logits and one
+    tiny launch that turns the sums into the weighted loss value and the gradient coefficients (csrc/loss.hip
+    dc_ce_finalize_kernel); backward is one pass per output, scaled by the upstream gradient read from device memory
+    (the GradScaler's loss scale), so nothing synchronises.  Sum over outputs as deep_supervision.py:30 does."""
+
+    @staticmethod
+    def forward(ctx, cfg, weights, targets, *logits):
+        from .. import hip_ops as ops
+        batch_dice, do_bg, smooth, w_ce, w_dice, ignore = cfg
+        dev = logits[0].device
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        saved, meta = [], []
+        for w, lg, tg in zip(weights, logits, targets):
+            if w == 0:
+                meta.append(None)
+                continue
+            B, C = lg.shape[:2]
+            V = lg[0, 0].numel()
+            lg = lg.contiguous()
+            sums = torch.empty((B, 3 * C + 1), dtype=torch.float32, device=dev)
+            coef = torch.empty((B, 2 * C + 1), dtype=torch.float32, device=dev)
+            ops.dc_ce_forward(lg, tg, sums, B, C, V, ignore)
+            ops.dc_ce_finalize(sums, loss, coef, B, C, V, batch_dice, do_bg, smooth, w_ce, w_dice, w,
+                               ignore != ops.NO_IGNORE)
+            meta.append((B, C, V, len(saved)))
+            saved += [lg, tg, coef]
+        ctx.save_for_backward(*saved)
+        ctx.meta, ctx.ignore = meta, ignore
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import hip_ops as ops
+        saved = ctx.saved_tensors
+        gmul = g.reshape(1).float().contiguous()
+        grads = []
+        for m in ctx.meta:
+            if m is None:
+                grads.append(None)
+                continue
+            B, C, V, i = m
+            lg, tg, coef = saved[i:i + 3]
+            dlogits = torch.empty_like(lg)
+            ops.dc_ce_backward_scaled(lg, tg, coef, gmul, dlogits, B, C, V, ctx.ignore)
+            grads.append(dlogits)
+        return (None, None, None, *grads)
+
+
 class DC_and_CE_loss(nn.Module):
     def __init__(self, soft_dice_kwargs, ce_kwargs, weight_ce=1, weight_dice=1, ignore_label=None,
                  dice_class=MemoryEfficientSoftDiceLoss):
@@ -137,12 +192,41 @@ class DC_and_CE_loss(nn.Module):
         self.dc = dice_class(apply_nonlin=softmax_helper_dim1, **soft_dice_kwargs)
         self._plain_ce = not [k for k in ce_kwargs if k != 'ignore_index']
 
+    def finalize_on_device(self) -> bool:
+        """batch Dice under DDP sums the statistics over ranks (AllGatherGrad, dice.py:96-103) between the two kernels, so
+        that one configuration keeps the element-wise torch arithmetic; everything else is finalised by one launch."""
+        if not self._plain_ce or type(self.dc) is not MemoryEfficientSoftDiceLoss:
+            return False
+        if self.dc.batch_dice and self.dc.ddp and torch.distributed.is_available() \
+                and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            return False
+        return True
+
+    def fused_sum(self, outputs, targets, weights) -> torch.Tensor:
+        """sum_i weights[i] * loss(outputs[i], targets[i]) - the deep-supervision sum - without leaving the device"""
+        from ..hip_ops import NO_IGNORE
+        for o in outputs:
+            if not o.is_cuda:
+                raise RuntimeError("nnuzoo_amd losses run on MI355X through libnnuzoo_hip.so only (no CPU fallback); "
+                                   "the CPU restatement is oracle/losses.py (test-only)")
+            if o.shape[1] > 32:
+                raise NotImplementedError("fused Dice+CE kernel supports up to 32 classes (register-resident softmax)")
+        if self.ignore_label is not None:
+            assert all(t.shape[1] == 1 for t in targets), 'ignore label is not implemented for one hot encoded ' \
+                                                          'target variables (DC_and_CE_loss)'
+        cfg = (bool(self.dc.batch_dice), bool(self.dc.do_bg), float(self.dc.smooth), float(self.weight_ce),
+               float(self.weight_dice), NO_IGNORE if self.ignore_label is None else int(self.ignore_label))
+        tg = tuple(_prep_target(o, t) for o, t in zip(outputs, targets))
+        return _FusedDSDiceCE.apply(cfg, tuple(float(w) for w in weights), tg, *outputs)
+
     def forward(self, net_output: torch.Tensor, target: torch.Tensor):
         if not self._plain_ce or not isinstance(self.dc, MemoryEfficientSoftDiceLoss):
             raise NotImplementedError("fused HIP loss: ce_kwargs must be {} and dice_class MemoryEfficientSoftDiceLoss")
         if self.ignore_label is not None:
             assert target.shape[1] == 1, 'ignore label is not implemented for one hot encoded target variables ' \
                                          '(DC_and_CE_loss)'
+        if self.finalize_on_device():
+            return self.fused_sum((net_output,), (target,), (1.0,))
         intersect, sum_pred, sum_gt_all, ce_sum = _fused_stats(net_output, target, self.ignore_label)
         sum_gt = sum_gt_all
         if not self.dc.do_bg:
@@ -241,4 +325,6 @@ class DeepSupervisionWrapper(nn.Module):
         assert all([isinstance(i, (tuple, list)) for i in args]), \
             f"all args must be either tuple or list, got {[type(i) for i in args]}"
         weights = (1,) * len(args[0]) if self.weight_factors is None else self.weight_factors
+        if isinstance(self.loss, DC_and_CE_loss) and len(args) == 2 and self.loss.finalize_on_device():
+            return self.loss.fused_sum(args[0], args[1], weights[:len(args[0])])
         return sum([weights[i] * self.loss(*inputs) for i, inputs in enumerate(zip(*args)) if weights[i] != 0.0])

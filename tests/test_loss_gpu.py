@@ -170,3 +170,35 @@ def test_region_trainer_step(hip_lib):
     assert v["tp_hard"].shape == (3,) and np.isfinite(v["loss"])
     keep = int((tgt[0][:, 3] == 0).sum())
     assert int(v["tp_hard"][0] + v["fn_hard"][0]) == int(((tgt[0][:, 0] == 1) & (tgt[0][:, 3] == 0)).sum()) <= keep
+
+
+@pytest.mark.parametrize("batch_dice,do_bg,ignore", [(False, False, None), (True, False, None), (False, True, None),
+                                                      (True, True, 3), (False, False, 3)])
+def test_device_finalize_equals_elementwise_path(hip_lib, monkeypatch, batch_dice, do_bg, ignore):
+    """the one-launch loss/coefficients kernel (used whenever batch Dice is not summed across DDP ranks) against the
+    element-wise torch arithmetic + autograd it replaces, through the deep-supervision sum and a loss scale"""
+    g = torch.Generator().manual_seed(11)
+    C, shapes = 3, [(2, 12, 20, 16), (2, 6, 10, 8), (2, 3, 5, 4)]
+    weights = [4 / 7, 2 / 7, 1 / 7]
+    outs = [(torch.randn(s[0], C, *s[1:], generator=g) * 2).half().cuda() for s in shapes]
+    tgs = [torch.randint(0, C + (1 if ignore is not None else 0), (s[0], 1, *s[1:]), generator=g).to(torch.int16).cuda()
+           for s in shapes]
+    loss = DC_and_CE_loss({'batch_dice': batch_dice, 'smooth': 1e-5, 'do_bg': do_bg, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1.5, ignore_label=ignore, dice_class=MemoryEfficientSoftDiceLoss)
+    w = DeepSupervisionWrapper(loss, weights)
+    scale = torch.tensor(1024.0, device="cuda")
+    res = []
+    for on_device in (True, False):
+        monkeypatch.setattr(DC_and_CE_loss, "finalize_on_device", lambda self, v=on_device: v)
+        xs = [o.clone().requires_grad_(True) for o in outs]
+        l = w(xs, tgs)
+        (l * scale).backward()
+        res.append((float(l.detach()), [x.grad.float().cpu() for x in xs]))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(1.0, abs(res[1][0])), (res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * b.abs().max().item()), (a - b).abs().max().item()
+    # a zero weight drops that output (no gradient), as the reference's `if weights[i] != 0.0`
+    monkeypatch.setattr(DC_and_CE_loss, "finalize_on_device", lambda self: True)
+    xs = [o.clone().requires_grad_(True) for o in outs]
+    DeepSupervisionWrapper(loss, [1.0, 0.0, 0.5])(xs, tgs).backward()
+    assert xs[1].grad is None and xs[0].grad is not None and xs[2].grad is not None
