@@ -139,6 +139,14 @@ int nnz_sliding_window_accumulate(const void* preds_f16, int M, const int* flip_
 int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, long V, int* inf_flag_device,
                                 void* stream);
 
+/* ---- LayerNorm over the last dimension of token-major tensors (nn.LayerNorm in the VSS / Swin blocks: m2net.py:101,521,
+ * ssnd2net.py, swt2net.py:630-660).  x: [rows][C] f16 or f32, C % 4 == 0, C <= 2048; y, dy: f32 (what autocast gives);
+ * dx has x's type; gamma / beta / dgamma / dbeta may be NULL (elementwise_affine = False).  mean / rstd: [rows] f32. */
+int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, float* y, float* mean,
+                           float* rstd, long rows, int C, float eps, void* stream);
+int nnz_layer_norm_backward(const void* x, int x_is_f16, const float* gamma, const float* mean, const float* rstd,
+                            const float* dy, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
+
 /* ---- fused soft-Dice + cross-entropy statistics on NC(D)HW logits --------------------------------------------
  * replaces softmax + one-hot + reductions + CE of DC_and_CE_loss (nnunetv2/training/loss/compound_losses.py:31-56,
  * dice.py:72-119, robust_ce_loss.py:12-16).  sums[b] = {intersect[C], sum_pred[C], sum_gt[C], ce_sum};

@@ -1,0 +1,234 @@
+// LayerNorm over the last (channel) dimension of token-major tensors, forward + backward, for the VSS / Swin blocks of
+// the zoo nets (reference: nn.LayerNorm at m2net.py:101,521; ssnd2net.py; swt2net.py:630-660 - `ln_1`, `out_norm`,
+// patch merge/expand norms).  C is small there (16 .. 1024) and the row count huge (512^2 tokens x batch), which the
+// generic kernels handle poorly (one workgroup per 16-float row); here a row lives on LPR = 4 .. 64 lanes of a wave
+// (16 bytes per lane per pass), several rows per wave, reductions by xor-shuffles inside the lane group - one HBM
+// pass forward, one backward, with dgamma / dbeta folded into the backward pass (per-lane partials over the rows the
+// lane group visits, one LDS fold per workgroup, one atomic per channel per workgroup).
+#include "common.hpp"
+
+namespace nnz {
+
+struct LnArgs {
+  const void* x;      // [R][C] f16 or f32
+  const float* gamma; // [C] or null
+  const float* beta;  // [C] or null
+  float* y;           // [R][C] f32                 (forward)
+  float* mean;        // [R]
+  float* rstd;        // [R]
+  const float* dy;    // [R][C] f32                 (backward)
+  void* dx;           // [R][C] same type as x
+  float* dgamma;      // [C] atomic, zeroed by the launcher; may be null
+  float* dbeta;
+  long R;
+  int C;
+  float eps;
+};
+
+template <class T>
+__device__ __forceinline__ f32x4 ld4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 ld4<f16>(const f16* p) {
+  const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(f16* p, f32x4 v) {
+  *reinterpret_cast<f16x4*>(p) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// a lane group of LPR lanes owns a row; lane q of the group holds the channels 4(q + LPR i) .. +3, i < IT
+template <class T, int LPR, int IT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
+  constexpr int GPW = 256 / LPR;  // lane groups (rows in flight) per workgroup
+  const int q = threadIdx.x % LPR, g = threadIdx.x / LPR;
+  const int C = a.C;
+  const float invC = 1.f / (float)C;
+  f32x4 gm[IT], bt[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = 4 * (q + LPR * i);
+    gm[i] = (a.gamma && c < C) ? ld4(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bt[i] = (a.beta && c < C) ? ld4(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long r = (long)blockIdx.x * GPW + g; r < a.R; r += (long)gridDim.x * GPW) {
+    const T* xr = (const T*)a.x + r * C;
+    f32x4 v[IT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = 4 * (q + LPR * i);
+      v[i] = c < C ? ld4(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mu = group_sum<LPR>(s) * invC;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = 4 * (q + LPR * i);
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[i][e] - mu;
+          ss += d * d;
+        }
+      }
+    }
+    const float rs = 1.f / sqrtf(group_sum<LPR>(ss) * invC + a.eps);
+    float* yr = a.y + r * C;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = 4 * (q + LPR * i);
+      if (c < C) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * gm[i][e] + bt[i][e];
+        st4(yr + c, o);
+      }
+    }
+    if (q == 0) {
+      a.mean[r] = mu;
+      a.rstd[r] = rs;
+    }
+  }
+}
+
+template <class T, int LPR, int IT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
+  constexpr int GPW = 256 / LPR;
+  __shared__ float fold[2][GPW][LPR * 4 * IT];
+  const int q = threadIdx.x % LPR, g = threadIdx.x / LPR;
+  const int C = a.C;
+  const float invC = 1.f / (float)C;
+  f32x4 gm[IT], dg[IT], db[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = 4 * (q + LPR * i);
+    gm[i] = (a.gamma && c < C) ? ld4(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long r = (long)blockIdx.x * GPW + g; r < a.R; r += (long)gridDim.x * GPW) {
+    const T* xr = (const T*)a.x + r * C;
+    const float* dyr = a.dy + r * C;
+    const float mu = a.mean[r], rs = a.rstd[r];
+    f32x4 xh[IT], gy[IT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = 4 * (q + LPR * i);
+      if (c < C) {
+        const f32x4 xv = ld4(xr + c), dv = ld4(dyr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          gy[i][e] = dv[e] * gm[i][e];
+          s1 += gy[i][e];
+          s2 += gy[i][e] * xh[i][e];
+          dg[i][e] += dv[e] * xh[i][e];
+          db[i][e] += dv[e];
+        }
+      } else {
+        xh[i] = gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float m1 = group_sum<LPR>(s1) * invC, m2 = group_sum<LPR>(s2) * invC;
+    T* dxr = (T*)a.dx + r * C;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = 4 * (q + LPR * i);
+      if (c < C) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
+        st4(dxr + c, o);
+      }
+    }
+  }
+  if (!a.dgamma && !a.dbeta) return;
+  // fold the lane groups' partials: fold[.][g][channel], then thread c sums over g
+#pragma unroll
+  for (int i = 0; i < IT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * (q + LPR * i) + e;
+      fold[0][g][c] = dg[i][e];
+      fold[1][g][c] = db[i][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sg = 0.f, sb = 0.f;
+    for (int gg = 0; gg < GPW; ++gg) {
+      sg += fold[0][gg][c];
+      sb += fold[1][gg][c];
+    }
+    if (a.dgamma) atomicAdd(a.dgamma + c, sg);
+    if (a.dbeta) atomicAdd(a.dbeta + c, sb);
+  }
+}
+
+template <class T, int LPR, int IT>
+static int ln_launch(const LnArgs& a, bool bwd, hipStream_t s) {
+  constexpr int GPW = 256 / LPR;
+  long want = (a.R + GPW - 1) / GPW;
+  // forward: enough workgroups to fill the chip several times; backward: fewer, so that the dgamma/dbeta atomics
+  // (one per channel per workgroup) stay a small fraction of the traffic
+  const long cap = bwd ? 1024 : 8192;
+  const unsigned grid = (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
+  if (bwd)
+    hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+template <class T>
+static int ln_dispatch(const LnArgs& a, bool bwd, hipStream_t s) {
+  const int C = a.C;
+  if (C <= 16) return ln_launch<T, 4, 1>(a, bwd, s);
+  if (C <= 32) return ln_launch<T, 8, 1>(a, bwd, s);
+  if (C <= 64) return ln_launch<T, 16, 1>(a, bwd, s);
+  if (C <= 128) return ln_launch<T, 32, 1>(a, bwd, s);
+  if (C <= 256) return ln_launch<T, 64, 1>(a, bwd, s);
+  if (C <= 512) return ln_launch<T, 64, 2>(a, bwd, s);
+  if (C <= 1024) return ln_launch<T, 64, 4>(a, bwd, s);
+  if (C <= 2048) return ln_launch<T, 64, 8>(a, bwd, s);
+  return NNZ_EINVAL;
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, float* y,
+                                      float* mean, float* rstd, long rows, int C, float eps, void* stream) {
+  using namespace nnz;
+  if (!x || !y || !mean || !rstd || rows < 0 || C < 4 || (C & 3) || C > 2048) return NNZ_EINVAL;
+  if (rows == 0) return NNZ_OK;
+  LnArgs a = {};
+  a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.R = rows; a.C = C; a.eps = eps;
+  return x_is_f16 ? ln_dispatch<f16>(a, false, (hipStream_t)stream) : ln_dispatch<float>(a, false, (hipStream_t)stream);
+}
+
+extern "C" int nnz_layer_norm_backward(const void* x, int x_is_f16, const float* gamma, const float* mean,
+                                       const float* rstd, const float* dy, void* dx, float* dgamma, float* dbeta,
+                                       long rows, int C, void* stream) {
+  using namespace nnz;
+  if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048) return NNZ_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dgamma) { hipError_t e = hipMemsetAsync(dgamma, 0, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
+  if (dbeta) { hipError_t e = hipMemsetAsync(dbeta, 0, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
+  if (rows == 0) return NNZ_OK;
+  LnArgs a = {};
+  a.x = x; a.gamma = gamma; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.dgamma = dgamma;
+  a.dbeta = dbeta; a.R = rows; a.C = C;
+  return x_is_f16 ? ln_dispatch<f16>(a, true, s) : ln_dispatch<float>(a, true, s);
+}

@@ -1,0 +1,64 @@
+"""`LayerNorm` with nn.LayerNorm's constructor, parameters and state_dict, running on the hand-written gfx950 kernels
+(csrc/layer_norm.hip) - the normalisation of the VSS / SSND / Swin blocks (reference: nn.LayerNorm at m2net.py:101,521,
+ssnd2net.py:266,532, swt2net.py:630-660).  Numerics follow torch under autocast: statistics and output in fp32 whatever
+the input type (layer_norm is on autocast's fp32 list), gradient of the input in the input's type.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from ._lib import call, ptr, stream_ptr
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        C = x.shape[-1]
+        xc = x.contiguous()
+        rows = xc.numel() // C
+        y = torch.empty(xc.shape, dtype=torch.float32, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call("nnz_layer_norm_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(y),
+             ptr(mean), ptr(rstd), rows, C, float(eps), stream_ptr())
+        ctx.save_for_backward(xc, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        ctx.out_dtype = out_dtype
+        return y if out_dtype == torch.float32 else y.to(out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight, mean, rstd = ctx.saved_tensors
+        C = xc.shape[-1]
+        rows = xc.numel() // C
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(xc)
+        dw = torch.empty_like(weight) if weight is not None and ctx.needs_input_grad[1] else None
+        db = torch.empty(C, dtype=torch.float32, device=xc.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        call("nnz_layer_norm_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
+             ptr(dy), ptr(dx), ptr(dw), ptr(db), rows, C, stream_ptr())
+        return dx, dw, db, None, None
+
+
+def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor:
+    """F.layer_norm(x, (C,), weight, bias, eps) over the last dimension on the HIP kernel (no CPU path)."""
+    if not x.is_cuda:
+        raise RuntimeError("nnuzoo_amd.layer_norm runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
+    C = x.shape[-1]
+    if C % 4 or C > 2048 or x.dtype not in (torch.float16, torch.float32) or \
+            (weight is not None and weight.dtype != torch.float32):
+        raise NotImplementedError(f"layer_norm kernel: C % 4 == 0, C <= 2048, fp16/fp32 input, fp32 affine "
+                                  f"(got C={C}, {x.dtype})")
+    # torch semantics: fp32 result under autocast (layer_norm is on the fp32 list), else the input's type
+    out_dtype = torch.float32 if (torch.is_autocast_enabled() or x.dtype == torch.float32) else x.dtype
+    return _LayerNormFn.apply(x, weight, bias, eps, out_dtype)
+
+
+class LayerNorm(nn.LayerNorm):
+    """drop-in for nn.LayerNorm (normalised shape = the last dimension)"""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if len(self.normalized_shape) != 1:
+            raise NotImplementedError("nnuzoo_amd.LayerNorm normalises the last dimension only")
+        return layer_norm(x, self.weight, self.bias, self.eps)

@@ -16,6 +16,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..layer_norm import LayerNorm
+
 
 class DropPath(nn.Module):
     def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
@@ -100,7 +102,7 @@ class RSU4F(nn.Module):
 class PatchMerging2D(nn.Module):
     """scale x scale space-to-depth -> LayerNorm -> Linear (token-major in/out; `permute` for NCHW callers)."""
 
-    def __init__(self, input_dim: int, scale: int, output_features: int = None, norm_layer=nn.LayerNorm):
+    def __init__(self, input_dim: int, scale: int, output_features: int = None, norm_layer=LayerNorm):
         super().__init__()
         self.input_feature_size = (scale ** 2) * input_dim
         self.output_features = output_features or input_dim * scale
@@ -129,7 +131,7 @@ class PatchExpand(nn.Module):
     """NCHW in -> token-major out.  output_dim None: Linear(dim -> scale*dim) then depth-to-space (dim/scale ch);
     output_dim given: depth-to-space first (dim/scale^2 ch) then Linear to output_dim.  LayerNorm last."""
 
-    def __init__(self, dim: int, scale, output_dim: int = None, norm_layer=nn.LayerNorm):
+    def __init__(self, dim: int, scale, output_dim: int = None, norm_layer=LayerNorm):
         super().__init__()
         self.dim, self.scale, self.output_dim = dim, scale, output_dim
         if output_dim is None:

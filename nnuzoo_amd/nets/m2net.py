@@ -21,6 +21,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..layer_norm import LayerNorm
+
 from ..selective_scan import selective_scan_fn
 from ..utilities.network_initialization import InitWeights_He
 from .common2d import DropPath, PatchExpand, PatchMerging2D, REBNCONV, RSU4F, _upsample_like
@@ -52,7 +54,7 @@ class SS2D(nn.Module):
         self.conv2d = nn.Conv2d(Di, Di, groups=Di, bias=conv_bias, kernel_size=d_conv, padding=(d_conv - 1) // 2, **fk)
         self.act = nn.SiLU()
         self.selective_scan = selective_scan_fn
-        self.out_norm = nn.LayerNorm(Di)
+        self.out_norm = LayerNorm(Di)
         self.out_proj = nn.Linear(Di, d_model, bias=bias, **fk)
         self.dropout = nn.Dropout(dropout) if dropout > 0. else None
 
@@ -135,7 +137,7 @@ class SS2D(nn.Module):
 
 
 class VSSBlock(nn.Module):
-    def __init__(self, hidden_dim: int = 0, drop_path: float = 0, norm_layer=nn.LayerNorm, attn_drop_rate: float = 0,
+    def __init__(self, hidden_dim: int = 0, drop_path: float = 0, norm_layer=LayerNorm, attn_drop_rate: float = 0,
                  d_state: int = 16, **kwargs):
         super().__init__()
         self.ln_1 = norm_layer(hidden_dim)
@@ -147,7 +149,7 @@ class VSSBlock(nn.Module):
 
 
 class VSSLayer(nn.Module):
-    def __init__(self, dim, depth, attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None,
+    def __init__(self, dim, depth, attn_drop=0., drop_path=0., norm_layer=LayerNorm, downsample=None,
                  use_checkpoint=False, d_state=16):
         super().__init__()
         self.dim, self.use_checkpoint = dim, use_checkpoint
@@ -190,7 +192,7 @@ def _vssm_init(m: nn.Module):
 
 class VSSMEncoder(nn.Module):
     def __init__(self, patch_size=4, in_chans=3, depths=[2, 2, 9, 2], dims=[96, 192, 384, 768], d_state=16,
-                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, patch_norm=True,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, norm_layer=LayerNorm, patch_norm=True,
                  use_checkpoint=False, skip_first_downsample: bool = False, skip_last_downsample: bool = False,
                  add_last: bool = False, out_ch: int = None):
         super().__init__()
@@ -255,13 +257,13 @@ class VSSMDecoder(nn.Module):
             if s == 1 and skip_first_expand:
                 expands.append(None)
             else:
-                expands.append(PatchExpand(dim=below, scale=2, output_dim=below, norm_layer=nn.LayerNorm))
+                expands.append(PatchExpand(dim=below, scale=2, output_dim=below, norm_layer=LayerNorm))
             stages.append(VSSLayer(dim=skip, depth=1, attn_drop=0., drop_path=dpr[sum(depths[:s - 1]):sum(depths[:s])],
                                    d_state=math.ceil(2 * skip / 6) if d_state is None else d_state,
-                                   norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False))
+                                   norm_layer=LayerNorm, downsample=None, use_checkpoint=False))
             segs.append(nn.Conv2d(skip, num_classes, 1, 1, 0, bias=True))
             fuse.append(nn.Linear(2 * skip, skip))
-        expands.append(PatchExpand(dim=chans[0], scale=patch_size, norm_layer=nn.LayerNorm))
+        expands.append(PatchExpand(dim=chans[0], scale=patch_size, norm_layer=LayerNorm))
         stages.append(nn.Identity())
         segs.append(nn.Conv2d(skip, num_classes, 1, 1, 0, bias=True))
         self.stages = nn.ModuleList(stages)
@@ -384,16 +386,16 @@ class M2Net(_U2Forward, nn.Module):
         self.pool56 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
         self.stage6 = RSU4F(512, 256, 512)
         self.stage5d = RSU4F(1024, 256, 512)
-        self.patch_expand4d = PatchExpand(dim=512, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand4d = PatchExpand(dim=512, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim4d = nn.Linear(512, 256)
         self.stage4d = mu(256, 128, 256, 4)
-        self.patch_expand3d = PatchExpand(dim=256, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand3d = PatchExpand(dim=256, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim3d = nn.Linear(256, 128)
         self.stage3d = mu(128, 64, 128, 5)
-        self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim2d = nn.Linear(128, 64)
         self.stage2d = mu(64, 32, 64, 6)
-        self.patch_expand1d = PatchExpand(dim=64, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand1d = PatchExpand(dim=64, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim1d = nn.Linear(64, 32)
         self.stage1d = mu(32, 16, 32, 7)
         for i, c in enumerate([32, 64, 128, 256, 512, 512], 1):
@@ -425,13 +427,13 @@ class M2NetP(_U2Forward, nn.Module):
         self.pool56 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
         self.stage6 = RSU4F(64, 16, 64)
         self.stage5d = RSU4F(128, 16, 128)
-        self.patch_expand4d = PatchExpand(dim=128, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand4d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
         self.stage4d = mu(128, 128, 4)
-        self.patch_expand3d = PatchExpand(dim=128, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand3d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
         self.stage3d = mu(128, 128, 5)
-        self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
         self.stage2d = mu(128, 128, 6)
-        self.patch_expand1d = PatchExpand(dim=128, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand1d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
         self.stage1d = mu(128, 128, 7)
         for i, c in enumerate([128, 128, 128, 128, 128, 64], 1):
             setattr(self, f"side{i}", nn.Conv2d(c, out_ch, 3, padding=1))

@@ -16,6 +16,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..layer_norm import LayerNorm
+
 from ..selective_scan import selective_scan_fn
 from .common2d import Convolution
 from .m2net import SS2D
@@ -48,7 +50,7 @@ class SSND(nn.Module):
                                   conv_only=True, dilation=dilation)
         self.act = nn.SiLU()
         self.selective_scan = selective_scan_fn
-        self.out_norm = nn.LayerNorm(Di)
+        self.out_norm = LayerNorm(Di)
         self.out_proj = nn.Linear(Di, d_model, bias=bias, **fk)
         self.dropout = nn.Dropout(dropout) if dropout > 0. else None
 

@@ -24,6 +24,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.init import trunc_normal_
 
+from ..layer_norm import LayerNorm
+
 from ..utilities.network_initialization import InitWeights_He
 from .common2d import Convolution, DropPath, get_dwconv_layer
 from .ssnd import SSND
@@ -92,7 +94,7 @@ def get_scales(spatial_dims, input_patch_size, n_layers, patch_size):
 class PatchMerging2D(nn.Module):
     """space-to-depth by `scale` per axis, LayerNorm, Linear to output_features (N-D despite the name)"""
 
-    def __init__(self, spatial_dims: int, input_dim: int, scale, output_features: int, norm_layer=nn.LayerNorm):
+    def __init__(self, spatial_dims: int, input_dim: int, scale, output_features: int, norm_layer=LayerNorm):
         super().__init__()
         self.spatial_dims = spatial_dims
         if spatial_dims == 2:
@@ -132,7 +134,7 @@ class PatchMerging2D(nn.Module):
 class PatchExpand(nn.Module):
     """depth-to-space by `scale` per axis around a Linear + LayerNorm (N-D)"""
 
-    def __init__(self, spatial_dims: int, dim: int, scale, output_dim: int = None, norm_layer=nn.LayerNorm):
+    def __init__(self, spatial_dims: int, dim: int, scale, output_dim: int = None, norm_layer=LayerNorm):
         super().__init__()
         self.spatial_dims, self.dim, self.output_dim = spatial_dims, dim, output_dim
         if isinstance(scale, int):
@@ -231,7 +233,7 @@ class GSC(nn.Module):
 
 class VSSBlock(nn.Module):
     def __init__(self, spatial_dims: int, factorization_type: str, hidden_dim: int = 0, drop_path: float = 0,
-                 norm_layer: Callable[..., torch.nn.Module] = partial(nn.LayerNorm, eps=1e-6), attn_drop_rate: float = 0,
+                 norm_layer: Callable[..., torch.nn.Module] = partial(LayerNorm, eps=1e-6), attn_drop_rate: float = 0,
                  d_state: int = 16, dilation: int = 1, **kwargs):
         super().__init__()
         self.spatial_dims = spatial_dims
@@ -248,7 +250,7 @@ class VSSBlock(nn.Module):
 
 class VSSLayer(nn.Module):
     def __init__(self, spatial_dims: int, factorization_type: str, dim, depth, attn_drop=0., drop_path=0.,
-                 norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False, d_state=16, dilation: int = 1):
+                 norm_layer=LayerNorm, downsample=None, use_checkpoint=False, d_state=16, dilation: int = 1):
         super().__init__()
         self.dim, self.use_checkpoint = dim, use_checkpoint
         self.blocks = nn.ModuleList([
@@ -284,7 +286,7 @@ def _vssm_init(m: nn.Module):
 class VSSMEncoder(nn.Module):
     def __init__(self, spatial_dims: int, factorization_type: str, patch_size=4, in_chans=3, depths=[2, 2, 9, 2],
                  dims=[96, 192, 384, 768], d_state=16, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1,
-                 norm_layer=nn.LayerNorm, patch_norm=True, use_checkpoint=False, add_last: bool = False,
+                 norm_layer=LayerNorm, patch_norm=True, use_checkpoint=False, add_last: bool = False,
                  out_ch: int = None, scales: List[Tuple[int, ...]] = None, dilations: list = None):
         super().__init__()
         self.scales, self.spatial_dims, self.num_layers, self.add_last = scales, spatial_dims, len(depths), add_last
@@ -345,19 +347,19 @@ class VSSMDecoder(nn.Module):
             below, skip = enc[-s], enc[-(s + 1)]
             if scales is not None and np.prod(scales[-s]) != 1:
                 expand_layers.append(PatchExpand(spatial_dims=spatial_dims, dim=below, scale=scales[-s], output_dim=below,
-                                                 norm_layer=nn.LayerNorm))
+                                                 norm_layer=LayerNorm))
             else:
                 expand_layers.append(None)
             stages.append(VSSLayer(spatial_dims=spatial_dims, factorization_type=factorization_type, dim=skip, depth=1,
                                    attn_drop=0., drop_path=dpr[sum(depths[:s - 1]):sum(depths[:s])],
                                    d_state=math.ceil(2 * skip / 6) if d_state is None else d_state,
-                                   norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                                   norm_layer=LayerNorm, downsample=None, use_checkpoint=False,
                                    dilation=dilations[s - 1]))
             seg_layers.append(Convolution(spatial_dims, skip, num_classes, 1, 1, padding=0, bias=True, conv_only=True))
             concat_back_dim.append(nn.Linear(2 * skip, skip))
         if patch_size != 1:
             expand_layers.append(PatchExpand(spatial_dims=spatial_dims, dim=enc[0], scale=patch_size,
-                                             norm_layer=nn.LayerNorm))
+                                             norm_layer=LayerNorm))
         else:
             expand_layers.append(None)
         stages.append(nn.Identity())
@@ -449,7 +451,7 @@ class _SSNDU2(nn.Module):
             lvl = 5 - j                                   # 5, 4, 3, 2, 1
             dim_below = enc[5][2] if j == 0 else cfg["dec"][j - 1][2]
             setattr(self, f"patch_expand{lvl}d", PatchExpand(spatial_dims=spatial_dims, dim=dim_below, scale=scales[-(j + 1)],
-                                                             norm_layer=nn.LayerNorm, output_dim=cfg["expand_out"][j]))
+                                                             norm_layer=LayerNorm, output_dim=cfg["expand_out"][j]))
             if j > 0:
                 a, b = cfg["concat_lin"][j - 1]
                 setattr(self, f"concat_back_dim{lvl}d", nn.Linear(a, b))

@@ -20,6 +20,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..layer_norm import LayerNorm
+
 from ..utilities.network_initialization import InitWeights_He
 from ..window_attention import window_attention_core
 from .common2d import Convolution, PatchExpand, PatchMerging2D, _upsample_like, get_dwconv_layer
@@ -75,7 +77,7 @@ class PatchEmbedding(nn.Module):
 
 
 class PatchMerging(nn.Module):
-    def __init__(self, dim: int, norm_layer=nn.LayerNorm):
+    def __init__(self, dim: int, norm_layer=LayerNorm):
         super().__init__()
         self.dim = dim
         self.norm = norm_layer(4 * dim)
@@ -96,7 +98,7 @@ def _depth_to_space(x, p):
 
 
 class PatchExpanding(nn.Module):
-    def __init__(self, dim: int, norm_layer=nn.LayerNorm):
+    def __init__(self, dim: int, norm_layer=LayerNorm):
         super().__init__()
         self.dim = dim
         self.expand = nn.Linear(dim, 2 * dim, bias=False)
@@ -107,7 +109,7 @@ class PatchExpanding(nn.Module):
 
 
 class FinalPatchExpanding(nn.Module):
-    def __init__(self, dim: int, norm_layer=nn.LayerNorm, patch_size: int = 4):
+    def __init__(self, dim: int, norm_layer=LayerNorm, patch_size: int = 4):
         super().__init__()
         self.dim = dim
         self.expand = nn.Linear(dim, (patch_size ** 2) * dim, bias=False)
@@ -174,7 +176,7 @@ class WindowAttention(nn.Module):
 
 class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, num_heads, window_size=7, shift=False, mlp_ratio=4., qkv_bias=True, drop=0., attn_drop=0.,
-                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+                 drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm):
         super().__init__()
         self.window_size = window_size
         self.norm1 = norm_layer(dim)
@@ -210,7 +212,7 @@ def _swin_blocks(dim, depth, num_head, window_size, mlp_ratio, qkv_bias, drop_ra
 class BasicBlock(nn.Module):
     def __init__(self, index: int, embed_dim: int = 96, window_size: int = 7, depths: tuple = (2, 2, 6, 2),
                  num_heads: tuple = (3, 6, 12, 24), mlp_ratio: float = 4., qkv_bias: bool = True, drop_rate: float = 0.,
-                 attn_drop_rate: float = 0., drop_path: float = 0.1, norm_layer=nn.LayerNorm,
+                 attn_drop_rate: float = 0., drop_path: float = 0.1, norm_layer=LayerNorm,
                  patch_merging: bool = True):
         super().__init__()
         dim = embed_dim * 2 ** index
@@ -228,7 +230,7 @@ class BasicBlockUp(nn.Module):
     def __init__(self, index: int, embed_dim: int = 96, window_size: int = 7, depths: tuple = (2, 2, 6, 2),
                  num_heads: tuple = (3, 6, 12, 24), mlp_ratio: float = 4., qkv_bias: bool = True, drop_rate: float = 0.,
                  attn_drop_rate: float = 0., drop_path: float = 0.1, patch_expanding: bool = True,
-                 norm_layer=nn.LayerNorm):
+                 norm_layer=LayerNorm):
         super().__init__()
         index = len(depths) - index - 2
         dim = embed_dim * 2 ** index
@@ -246,7 +248,7 @@ class SwinTransformerUnet(nn.Module):
     def __init__(self, patch_size: int = 4, in_ch: int = 3, out_ch: int = 1000, embed_dim: int = 96,
                  window_size: int = 7, depths: tuple = (2, 2, 6, 2), num_heads: tuple = (3, 6, 12, 24),
                  mlp_ratio: float = 4., qkv_bias: bool = True, drop_rate: float = 0., attn_drop_rate: float = 0.,
-                 drop_path_rate: float = 0.1, norm_layer=nn.LayerNorm, patch_norm: bool = True, add_last: bool = False):
+                 drop_path_rate: float = 0.1, norm_layer=LayerNorm, patch_norm: bool = True, add_last: bool = False):
         super().__init__()
         self.add_last, self.window_size, self.depths, self.num_heads = add_last, window_size, depths, num_heads
         self.num_layers, self.embed_dim = len(depths), embed_dim
@@ -302,7 +304,7 @@ class SwT2Net(_U2Forward, nn.Module):
         nn.Module.__init__(self)
         self.spatial_dims = 2
         self.deep_supervision = deep_supervision
-        ln = partial(nn.LayerNorm, eps=1e-6)
+        ln = partial(LayerNorm, eps=1e-6)
 
         def su(patch, i, o, embed, heads):
             return SwinTransformerUnet(patch_size=patch, in_ch=i, out_ch=o, depths=(2, 2, 4, 2), embed_dim=embed,
@@ -321,16 +323,16 @@ class SwT2Net(_U2Forward, nn.Module):
         self.pool56 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
         self.stage6 = RSU4F(512, 256, 512)
         self.stage5d = RSU4F(1024, 256, 512)
-        self.patch_expand4d = PatchExpand(dim=512, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand4d = PatchExpand(dim=512, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim4d = nn.Linear(512, 256)
         self.stage4d = su(1, 256, 256, 96, (3, 6, 12, 24))
-        self.patch_expand3d = PatchExpand(dim=256, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand3d = PatchExpand(dim=256, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim3d = nn.Linear(256, 128)
         self.stage3d = su(2, 128, 128, 96, (3, 6, 12, 24))
-        self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim2d = nn.Linear(128, 64)
         self.stage2d = su(4, 64, 64, 64, (2, 4, 8, 16))
-        self.patch_expand1d = PatchExpand(dim=64, scale=2, norm_layer=nn.LayerNorm)
+        self.patch_expand1d = PatchExpand(dim=64, scale=2, norm_layer=LayerNorm)
         self.concat_back_dim1d = nn.Linear(64, 32)
         self.stage1d = su(4, 32, 32, 32, (2, 2, 4, 8))
         for i, c in enumerate([32, 64, 128, 256, 512, 512], 1):

@@ -1,0 +1,58 @@
+"""HIP LayerNorm (csrc/layer_norm.hip, nnuzoo_amd.layer_norm.LayerNorm) against torch's F.layer_norm in fp32: forward
+rtol 1e-5, input gradient rtol 1e-4, dgamma / dbeta rtol 1e-4 (atomic fp32 sums over workgroups).  Shapes are the
+token-major activations of the VSS / Swin blocks (C = 16 .. 1024, non-power-of-two Swin widths)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16), (2, 33, 17, 32), (3, 50, 64), (1, 29, 31, 96), (2, 16, 16, 128),
+                                   (5, 7, 192), (4, 9, 256), (3, 11, 384), (2, 5, 512), (7, 1024), (3, 2048)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_layer_norm_matches_torch(hip_lib, shape, dtype):
+    from nnuzoo_amd.layer_norm import LayerNorm
+    g = torch.Generator().manual_seed(5)
+    C = shape[-1]
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(dtype).cuda()
+    ln = LayerNorm(C, eps=1e-5).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g) * 0.3 + 1)
+        ln.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    dy = torch.randn(shape, generator=g).cuda()
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16, enabled=dtype == torch.float16):
+        y = ln(xa)
+    assert y.dtype == torch.float32
+    y.backward(dy)
+    xr = x.float().clone().requires_grad_(True)
+    w, b = ln.weight.detach().clone().requires_grad_(True), ln.bias.detach().clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), w, b, 1e-5)
+    yr.backward(dy)
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-5), (y - yr).abs().max().item()
+    assert xa.grad.dtype == dtype
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    assert torch.allclose(xa.grad.float(), xr.grad, rtol=tol, atol=tol * xr.grad.abs().max().item())
+    assert torch.allclose(ln.weight.grad, w.grad, rtol=1e-4, atol=1e-4 * w.grad.abs().max().item())
+    assert torch.allclose(ln.bias.grad, b.grad, rtol=1e-4, atol=1e-4 * b.grad.abs().max().item())
+
+
+def test_layer_norm_large_rows_and_no_affine(hip_lib):
+    from nnuzoo_amd.layer_norm import LayerNorm, layer_norm
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 512, 512, 16, generator=g).cuda().requires_grad_(True)     # more rows than the grid covers
+    ln = LayerNorm(16).cuda()
+    y = ln(x)
+    y.sum().backward()
+    yr = F.layer_norm(x.detach(), (16,), ln.weight.detach(), ln.bias.detach())
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ln.bias.grad, torch.full((16,), 2.0 * 512 * 512, device="cuda"))
+    z = layer_norm(x.detach(), None, None, 1e-6)
+    assert torch.allclose(z, F.layer_norm(x.detach(), (16,), None, None, 1e-6), rtol=1e-5, atol=1e-5)
+
+
+def test_layer_norm_refuses_cpu():
+    from nnuzoo_amd.layer_norm import LayerNorm
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        LayerNorm(16)(torch.zeros(2, 16))
