@@ -139,6 +139,30 @@ int nnz_sliding_window_accumulate(const void* preds_f16, int M, const int* flip_
 int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, long V, int* inf_flag_device,
                                 void* stream);
 
+/* ---- SS2D cross-scan: the four scan directions of the SS2D block (m2net.py:170-206) over ONE input --------------------
+ * Direction k = s + 2j reads source s (0: row-major tokens, 1: column-major tokens = transposed image), reversed in time
+ * for j = 1, by index arithmetic inside the scan kernels - no stacked / flipped copies, no materialised delta.
+ *   x2  [2][B][Dg][L]      both sources of the block input (nnz_ss2d_prepare)
+ *   P   [2][B][2 Cp][L]    projections [W_s ; W_{s+2}] x_s, Cp = R + 32: rows j*Cp.. = R dt rows, 16 B rows, 16 C rows
+ *   Wdt [4 Dg][R]          dt_projs_weight; delta = softplus(Wdt . dt + delta_bias) formed in the kernel (R <= 8)
+ *   y, du [B][4 Dg][L]     per direction, in the source's token order (un-reversed)
+ *   dy2 [2][B][Dg][L]      gradient seen by both directions of a source (nnz_ss2d_split); dP like P; dWdt like Wdt
+ * chunk_state / grad_state / workspace: nnz_selective_scan_state_floats / _workspace_floats(B, 4 Dg, L).
+ * nnz_ss2d_merge: out (B, H, W, Dg) = y0 + y2 + (y1 + y3)^T;  nnz_ss2d_merge_dx: dx (B, Dg, H, W) = du0 + du2 + dx2[0]
+ * + (du1 + du3 + dx2[1])^T in x's type. */
+int nnz_ss2d_prepare(const void* x, int x_is_f16, float* x2, int Bt, int D, int H, int W, void* stream);
+int nnz_ss2d_merge(const float* y, float* out_tokens, int Bt, int D, int H, int W, void* stream);
+int nnz_ss2d_split(const float* dout_tokens, float* dy2, int Bt, int D, int H, int W, void* stream);
+int nnz_ss2d_merge_dx(const float* du, const float* dx2, void* dx, int dx_is_f16, int Bt, int D, int H, int W,
+                      void* stream);
+int nnz_ss2d_scan_forward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
+                          const float* delta_bias, float* y, float* chunk_state, float* workspace, int Bt, int Dg, int R,
+                          int L, int delta_softplus, void* stream);
+int nnz_ss2d_scan_backward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
+                           const float* delta_bias, const float* dy2, const float* chunk_state, float* grad_state,
+                           float* workspace, float* du, float* dP, float* dWdt, float* dA, float* dD, float* dbias,
+                           int Bt, int Dg, int R, int L, int delta_softplus, void* stream);
+
 /* ---- LayerNorm over the last dimension of token-major tensors (nn.LayerNorm in the VSS / Swin blocks: m2net.py:101,521,
  * ssnd2net.py, swt2net.py:630-660).  x: [rows][C] f16 or f32, C % 4 == 0, C <= 2048; y, dy: f32 (what autocast gives);
  * dx has x's type; gamma / beta / dgamma / dbeta may be NULL (elementwise_affine = False).  mean / rstd: [rows] f32. */

@@ -49,7 +49,20 @@ struct ScanArgs {
   int Bt, K, Dg, KD, L, nchunks;
   int rows_per_wg;     // multiple of SS_NW, divides Dg
   int softplus;
+  // ---- cross-scan mode (XS; the SS2D block, K = 4): the four directions read ONE input through index arithmetic
+  // instead of four materialised copies.  Direction k = s + 2j: source s (0: row-major tokens, 1: column-major
+  // tokens, i.e. the transposed image), reversed in time when j = 1.  u / dy: [2][B][Dg][L] by source; the projections
+  // P = [W_s ; W_{s+2}] x_s: [2][B][2 Cp][L], direction k's rows at j*Cp: R dt rows, N B rows, N C rows (Cp = R + 2N);
+  // delta is formed in the kernel from the R dt rows and Wdt[k][d][R] (no [B][KD][L] delta / ddelta tensors);
+  // y / du: [B][KD][L] per direction in the source's (un-reversed) token order; dP like P (accumulated).
+  const float* xs_P;
+  const float* xs_Wdt;  // [KD][R]
+  float* xs_dP;
+  int R, Cp;
 };
+
+constexpr int SS_RMAX = 8;          // largest dt_rank of the cross-scan mode
+constexpr int SS_DTP = SS_CL + 4;   // pitch of the staged dt tile: one column more than the chunk (dl of the next step)
 
 // ---- DPP helpers -----------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
@@ -120,6 +133,41 @@ __device__ __forceinline__ void store4(float* row, int t, int L, bool vec, const
   }
 }
 
+// time-reversed rows: logical step t lives at memory position L-1-t, so the 4 steps of a lane are 4 consecutive
+// elements read back to front (still one 16-byte access when L % 4 == 0)
+__device__ __forceinline__ void load4x(const float* row, int t, int L, bool vec, bool REV, float (&v)[SS_KI]) {
+  if (!REV) {
+    load4(row, t, L, vec, v);
+  } else if (vec && t + SS_KI <= L) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(row + (L - t - SS_KI));
+    v[0] = x[3]; v[1] = x[2]; v[2] = x[1]; v[3] = x[0];
+  } else {
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i) v[i] = (t + i < L) ? row[L - 1 - t - i] : 0.f;
+  }
+}
+__device__ __forceinline__ void store4x(float* row, int t, int L, bool vec, bool REV, const float (&v)[SS_KI]) {
+  if (!REV) {
+    store4(row, t, L, vec, v);
+  } else if (vec && t + SS_KI <= L) {
+    f32x4 x = {v[3], v[2], v[1], v[0]};
+    *reinterpret_cast<f32x4*>(row + (L - t - SS_KI)) = x;
+  } else {
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i)
+      if (t + i < L) row[L - 1 - t - i] = v[i];
+  }
+}
+// [rows][ncols] tile of rows with stride L starting at logical step t0, time-reversed or not, into dst[rows][pitch]
+__device__ __forceinline__ void stage_rows(const float* src, float* dst, int rows, int ncols, int pitch, int t0, int L,
+                                           bool REV) {
+  for (int i = threadIdx.x; i < rows * ncols; i += SS_NW * 64) {
+    const int n = i / ncols, tt = i % ncols;
+    const int t = t0 + tt;
+    dst[n * pitch + tt] = t < L ? src[(long)n * L + (REV ? L - 1 - t : t)] : 0.f;
+  }
+}
+
 // stage the [N][CL] tile of one (b, k) group for chunk c into LDS (zero beyond L)
 __device__ __forceinline__ void stage_tile(const float* src /* [N][L] */, float* dst /* [N][CL] */, int t0, int L) {
   for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
@@ -139,36 +187,61 @@ struct RowIn {
   float bias, Dv;
 };
 
-template <bool BWD, bool FINAL>
+template <bool BWD, bool FINAL, bool XS>
 __device__ __forceinline__ void load_row(const ScanArgs& a, int b, int k, int r, int c, int t, int lane, bool vec,
                                          RowIn& x) {
   const int kd = k * a.Dg + r;
   const long row = (long)b * a.KD + kd;
-  load4(a.delta + row * a.L, t, a.L, vec, x.dl);
-  if (!BWD || FINAL) load4(a.u + row * a.L, t, a.L, vec, x.u);
-  if (BWD) {
-    load4(a.dy + row * a.L, t, a.L, vec, x.dy);
-    const int tn = t + SS_KI;
-    x.dl_next = tn < a.L ? a.delta[row * a.L + tn] : 0.f;
+  if (!XS) {
+    load4(a.delta + row * a.L, t, a.L, vec, x.dl);
+    if (!BWD || FINAL) load4(a.u + row * a.L, t, a.L, vec, x.u);
+    if (BWD) {
+      load4(a.dy + row * a.L, t, a.L, vec, x.dy);
+      const int tn = t + SS_KI;
+      x.dl_next = tn < a.L ? a.delta[row * a.L + tn] : 0.f;
+    }
+  } else {
+    // shared input of the four directions: source k & 1, reversed for k >= 2; delta comes from the staged dt tile
+    const bool rev = k >= 2;
+    const long srow = ((long)(k & 1) * a.Bt + b) * a.Dg + r;
+    if (!BWD || FINAL) load4x(a.u + srow * a.L, t, a.L, vec, rev, x.u);
+    if (BWD) load4x(a.dy + srow * a.L, t, a.L, vec, rev, x.dy);
   }
   const int n = lane & 15;
   float v = 0.f;
   if (lane < 16) v = a.A[(long)kd * SS_N + n];
   else if (lane < 32) { if (FINAL) v = a.Hin[(row * a.nchunks + c) * SS_N + n]; }
   else if (lane < 48) { if (BWD && FINAL) v = a.Gin[(row * a.nchunks + c) * SS_N + n]; }
+  else if (XS && lane - 48 < a.R) v = a.xs_Wdt[(long)kd * a.R + (lane - 48)];
   x.aux = v;
   x.bias = a.bias ? a.bias[kd] : 0.f;
   x.Dv = a.D ? a.D[kd] : 0.f;
 }
 
+// cross-scan: raw delta of the lane's 4 steps (and of the step after them) = Wdt[k][d][:] . dt[:, t] from the LDS tile
+__device__ __forceinline__ void xs_delta(const float* sDt, const float* wrow /* LDS: Wdt[kd][0..R) */, int R, int lane,
+                                         float (&dl)[SS_KI], float& dl_next) {
+#pragma unroll
+  for (int i = 0; i < SS_KI; ++i) dl[i] = 0.f;
+  dl_next = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float w = wrow[r];
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(sDt + r * SS_DTP + lane * SS_KI);
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i) dl[i] += w * dv[i];
+    dl_next += w * sDt[r * SS_DTP + lane * SS_KI + SS_KI];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward: FINAL = false -> chunk summaries (P, S); FINAL = true -> y from the entry state Hin
 // ---------------------------------------------------------------------------------------------------------------
-template <bool FINAL>
+template <bool FINAL, bool XS>
 __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) float sB[SS_N * SS_CL];
   __shared__ __attribute__((aligned(16))) float sC[FINAL ? SS_N * SS_CL : 4];
-  __shared__ float sw[SS_NW][64];  // per wave: A row, entry state
+  __shared__ __attribute__((aligned(16))) float sDt[XS ? SS_RMAX * SS_DTP : 4];
+  __shared__ float sw[SS_NW][64];  // per wave: A row, entry state, (XS) Wdt row
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.x;                  // chunk
@@ -181,18 +254,31 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
   const bool vec = (a.L & 3) == 0;
   const int r_end = (sub + 1) * a.rows_per_wg;
 
+  const bool rev = XS && k >= 2;
+
   RowIn cur, nxt;
   int r = sub * a.rows_per_wg + wave;
-  load_row<false, FINAL>(a, b, k, r, c, t, lane, vec, cur);
-  stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
-  if (FINAL) stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
+  load_row<false, FINAL, XS>(a, b, k, r, c, t, lane, vec, cur);
+  if (!XS) {
+    stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
+    if (FINAL) stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
+  } else {
+    const float* Pk = a.xs_P + ((((long)(k & 1) * a.Bt + b) * 2 + (k >> 1)) * a.Cp) * a.L;
+    stage_rows(Pk, sDt, a.R, SS_CL + 1, SS_DTP, t0, a.L, rev);
+    stage_rows(Pk + (long)a.R * a.L, sB, SS_N, SS_CL, SS_CL, t0, a.L, rev);
+    if (FINAL) stage_rows(Pk + (long)(a.R + SS_N) * a.L, sC, SS_N, SS_CL, SS_CL, t0, a.L, rev);
+  }
   __syncthreads();
 
   for (; r < r_end; r += SS_NW) {
     const int kd = k * a.Dg + r;
     const long row = (long)b * a.KD + kd;
-    if (r + SS_NW < r_end) load_row<false, FINAL>(a, b, k, r + SS_NW, c, t, lane, vec, nxt);
+    if (r + SS_NW < r_end) load_row<false, FINAL, XS>(a, b, k, r + SS_NW, c, t, lane, vec, nxt);
     sw[wave][lane] = cur.aux;  // same-wave LDS: program order is enough
+    if (XS) {
+      float unused;
+      xs_delta(sDt, &sw[wave][48], a.R, lane, cur.dl, unused);
+    }
     float u[SS_KI], dl[SS_KI], yv[SS_KI];
 #pragma unroll
     for (int i = 0; i < SS_KI; ++i) {
@@ -239,7 +325,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
         }
       }
     }
-    if (FINAL) store4(a.y + row * a.L, t, a.L, vec, yv);
+    if (FINAL) store4x(a.y + row * a.L, t, a.L, vec, rev, yv);
     cur = nxt;
   }
 }
@@ -281,14 +367,16 @@ __global__ __launch_bounds__(256) void scan_carry_kernel(const float* __restrict
 // backward: FINAL = false -> reverse chunk summaries; FINAL = true -> all gradients
 // reverse recurrence  g_t = a_{t+1} g_{t+1} + C_t dy_t
 // ---------------------------------------------------------------------------------------------------------------
-template <bool FINAL>
+template <bool FINAL, bool XS>
 __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   float* sC = dyn_lds;                                   // [N][CL]
-  float* sw = sC + SS_N * SS_CL;                         // [NW][64] per wave: A row, Hin, Gin
+  float* sw = sC + SS_N * SS_CL;                         // [NW][64] per wave: A row, Hin, Gin, (XS) Wdt row
   float* sB = sw + SS_NW * 64;                           // FINAL only: [N][CL]
   float* sdB = sB + SS_N * SS_CL;                        // FINAL only
   float* sdC = sdB + SS_N * SS_CL;                       // FINAL only
+  float* sDt = FINAL ? sdC + SS_N * SS_CL : sB;          // XS only: [R][DTP] staged dt rows
+  float* sdDt = sDt + a.R * SS_DTP;                      // XS && FINAL only: [R][CL] gradient of the dt rows
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.x;
@@ -302,24 +390,37 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
   const int r_end = (sub + 1) * a.rows_per_wg;
   float* swv = sw + wave * 64;
 
+  const bool rev = XS && k >= 2;
+  const long pk_off = XS ? ((((long)(k & 1) * a.Bt + b) * 2 + (k >> 1)) * a.Cp) * a.L : 0;
+
   RowIn cur, nxt;
   int r = sub * a.rows_per_wg + wave;
-  load_row<true, FINAL>(a, b, k, r, c, t, lane, vec, cur);
-  stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
+  load_row<true, FINAL, XS>(a, b, k, r, c, t, lane, vec, cur);
+  if (!XS) {
+    stage_tile(a.Cm + (long)grp * SS_N * a.L, sC, t0, a.L);
+    if (FINAL) stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
+  } else {
+    const float* Pk = a.xs_P + pk_off;
+    stage_rows(Pk, sDt, a.R, SS_CL + 1, SS_DTP, t0, a.L, rev);
+    stage_rows(Pk + (long)(a.R + SS_N) * a.L, sC, SS_N, SS_CL, SS_CL, t0, a.L, rev);
+    if (FINAL) stage_rows(Pk + (long)a.R * a.L, sB, SS_N, SS_CL, SS_CL, t0, a.L, rev);
+  }
   if (FINAL) {
-    stage_tile(a.Bm + (long)grp * SS_N * a.L, sB, t0, a.L);
     for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
       sdB[i] = 0.f;
       sdC[i] = 0.f;
     }
+    if (XS)
+      for (int i = threadIdx.x; i < a.R * SS_CL; i += SS_NW * 64) sdDt[i] = 0.f;
   }
   __syncthreads();
 
   for (; r < r_end; r += SS_NW) {
     const int kd = k * a.Dg + r;
     const long row = (long)b * a.KD + kd;
-    if (r + SS_NW < r_end) load_row<true, FINAL>(a, b, k, r + SS_NW, c, t, lane, vec, nxt);
+    if (r + SS_NW < r_end) load_row<true, FINAL, XS>(a, b, k, r + SS_NW, c, t, lane, vec, nxt);
     swv[lane] = cur.aux;  // same-wave LDS: program order is enough
+    if (XS) xs_delta(sDt, swv + 48, a.R, lane, cur.dl, cur.dl_next);
     float u[SS_KI], draw[SS_KI], dl[SS_KI], dyv[SS_KI];
 #pragma unroll
     for (int i = 0; i < SS_KI; ++i) {
@@ -452,8 +553,27 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
         sdb += dd[i];
         sdD += dyv[i] * u[i];
       }
-      store4(a.du + row * a.L, t, a.L, vec, duv);
-      store4(a.ddelta + row * a.L, t, a.L, vec, dd);
+      store4x(a.du + row * a.L, t, a.L, vec, rev, duv);
+      if (!XS) {
+        store4(a.ddelta + row * a.L, t, a.L, vec, dd);
+      } else {
+        // delta = Wdt[kd][:] . dt[:, t]:  dWdt[kd][r] = sum_t dd_t dt[r][t] (per-(row, chunk) partial, summed by the
+        // finalize kernel);  d dt[r][t] += Wdt[kd][r] dd_t, reduced over the group's channels in LDS (the waves work
+        // on different rows at the same time: LDS atomics, 4 R per lane per row)
+        for (int rr = 0; rr < a.R; ++rr) {
+          const f32x4 dv = *reinterpret_cast<const f32x4*>(sDt + rr * SS_DTP + lane * SS_KI);
+          float sw_ = 0.f;
+          const float w = swv[48 + rr];
+#pragma unroll
+          for (int i = 0; i < SS_KI; ++i) {
+            sw_ += dd[i] * dv[i];
+            __hip_atomic_fetch_add(sdDt + rr * SS_CL + lane * SS_KI + i, w * dd[i], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          sw_ = wave_sum(sw_);
+          if (lane == 0) a.S[(row * SS_N + 2 + rr) * a.nchunks + c] = sw_;
+        }
+      }
       sdb = wave_sum(sdb);
       sdD = wave_sum(sdD);
       if (lane == 0) {
@@ -465,19 +585,31 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
   }
   if (FINAL) {
     __syncthreads();
-    float* gB = a.dB + (long)grp * SS_N * a.L;
-    float* gC = a.dC + (long)grp * SS_N * a.L;
+    float* gB = XS ? a.xs_dP + pk_off + (long)a.R * a.L : a.dB + (long)grp * SS_N * a.L;
+    float* gC = XS ? a.xs_dP + pk_off + (long)(a.R + SS_N) * a.L : a.dC + (long)grp * SS_N * a.L;
     const bool sole = wgs_per_group == 1;  // this workgroup is the only writer of the tile: plain stores
     for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
       const int n = i / SS_CL, tt = i % SS_CL;
       const int li = i;
       if (t0 + tt < a.L) {
+        const long m = (long)n * a.L + (rev ? a.L - 1 - (t0 + tt) : t0 + tt);
         if (sole) {
-          gB[(long)n * a.L + t0 + tt] = sdB[li];
-          gC[(long)n * a.L + t0 + tt] = sdC[li];
+          gB[m] = sdB[li];
+          gC[m] = sdC[li];
         } else {
-          atomicAdd(gB + (long)n * a.L + t0 + tt, sdB[li]);
-          atomicAdd(gC + (long)n * a.L + t0 + tt, sdC[li]);
+          atomicAdd(gB + m, sdB[li]);
+          atomicAdd(gC + m, sdC[li]);
+        }
+      }
+    }
+    if (XS) {
+      float* gT = a.xs_dP + pk_off;
+      for (int i = threadIdx.x; i < a.R * SS_CL; i += SS_NW * 64) {
+        const int rr = i / SS_CL, tt = i % SS_CL;
+        if (t0 + tt < a.L) {
+          const long m = (long)rr * a.L + (rev ? a.L - 1 - (t0 + tt) : t0 + tt);
+          if (sole) gT[m] = sdDt[i];
+          else atomicAdd(gT + m, sdDt[i]);
         }
       }
     }
@@ -487,7 +619,8 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
 // dA[kd][n] = sum_{b, c} P[(b*KD + kd)*N + n][c];  dbias / dD from rows 0 / 1 of S.  One wave per (kd, n).
 __global__ __launch_bounds__(256) void scan_bwd_finalize_kernel(const float* __restrict__ P, const float* __restrict__ S,
                                                                 float* __restrict__ dA, float* __restrict__ dbias,
-                                                                float* __restrict__ dD, int Bt, int KD, int nchunks) {
+                                                                float* __restrict__ dD, int Bt, int KD, int nchunks,
+                                                                float* __restrict__ dWdt, int R) {
   const int lane = threadIdx.x & 63;
   const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= (long)KD * SS_N) return;
@@ -497,7 +630,7 @@ __global__ __launch_bounds__(256) void scan_bwd_finalize_kernel(const float* __r
     const long base = (((long)b * KD + kd) * SS_N + n) * nchunks;
     for (int c = lane; c < nchunks; c += 64) {
       sa += P[base + c];
-      if (n < 2) s0 += S[base + c];
+      if (n < 2 + R) s0 += S[base + c];
     }
   }
   sa = wave_sum(sa);
@@ -506,6 +639,7 @@ __global__ __launch_bounds__(256) void scan_bwd_finalize_kernel(const float* __r
     dA[w] = sa;
     if (n == 0 && dbias) dbias[kd] = s0;
     if (n == 1 && dD) dD[kd] = s0;
+    if (n >= 2 && n < 2 + R && dWdt) dWdt[(long)kd * R + (n - 2)] = s0;   // cross-scan mode: rows 2 .. 2+R of S
   }
 }
 
@@ -535,26 +669,20 @@ extern "C" long nnz_selective_scan_state_floats(int Bt, int KD, int L) {
   return (long)Bt * KD * nnz::SS_N * nch;  // Hin (and Gin)
 }
 
-extern "C" int nnz_selective_scan_forward(const float* u, const float* delta, const float* A, const float* Bm,
-                                          const float* Cm, const float* D, const float* delta_bias, float* y,
-                                          float* chunk_state, float* workspace, int Bt, int K, int Dg, int N, int L,
-                                          int delta_softplus, void* stream) {
-  using namespace nnz;
-  if (!u || !delta || !A || !Bm || !Cm || !y || !chunk_state || !workspace || N != SS_N) return NNZ_EINVAL;
-  ScanArgs a = {};
-  a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.y = y;
-  a.Bt = Bt; a.K = K; a.Dg = Dg; a.KD = K * Dg; a.L = L; a.softplus = delta_softplus;
+namespace nnz {
+
+template <bool XS>
+static int scan_forward_impl(ScanArgs& a, float* chunk_state, float* workspace, hipStream_t s) {
   if (int rc = check(a)) return rc;
-  a.nchunks = (L + SS_CL - 1) / SS_CL;
-  const long rows = (long)Bt * a.KD;
+  a.nchunks = (a.L + SS_CL - 1) / SS_CL;
+  const long rows = (long)a.Bt * a.KD;
   a.P = workspace;
   a.S = workspace + rows * SS_N * a.nchunks;
   a.Hin = chunk_state;
-  a.rows_per_wg = pick_rows_per_wg(Dg, (long)Bt * K * a.nchunks);
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(a.nchunks, Bt * K * (Dg / a.rows_per_wg));
+  a.rows_per_wg = pick_rows_per_wg(a.Dg, (long)a.Bt * a.K * a.nchunks);
+  dim3 grid(a.nchunks, a.Bt * a.K * (a.Dg / a.rows_per_wg));
   if (a.nchunks > 1) {
-    hipLaunchKernelGGL(scan_fwd_kernel<false>, grid, dim3(SS_NW * 64), 0, s, a);
+    hipLaunchKernelGGL((scan_fwd_kernel<false, XS>), grid, dim3(SS_NW * 64), 0, s, a);
     NNZ_LAUNCH_CHECK();
     const long rows_n = rows * SS_N;
     hipLaunchKernelGGL(scan_carry_kernel<false>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Hin,
@@ -564,9 +692,71 @@ extern "C" int nnz_selective_scan_forward(const float* u, const float* delta, co
     hipError_t e = hipMemsetAsync(a.Hin, 0, sizeof(float) * rows * SS_N, s);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(scan_fwd_kernel<true>, grid, dim3(SS_NW * 64), 0, s, a);
+  hipLaunchKernelGGL((scan_fwd_kernel<true, XS>), grid, dim3(SS_NW * 64), 0, s, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+
+template <bool XS>
+static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad_state, float* workspace, float* dWdt,
+                              hipStream_t s) {
+  if (int rc = check(a)) return rc;
+  a.nchunks = (a.L + SS_CL - 1) / SS_CL;
+  const long rows = (long)a.Bt * a.KD;
+  a.P = workspace;
+  a.S = workspace + rows * SS_N * a.nchunks;
+  a.Hin = const_cast<float*>(chunk_state);
+  a.Gin = grad_state;
+  a.rows_per_wg = pick_rows_per_wg(a.Dg, (long)a.Bt * a.K * a.nchunks);
+  hipError_t e;
+  if (a.rows_per_wg != a.Dg) {  // several workgroups add into one dB/dC (dP) tile
+    if (XS) {
+      if ((e = hipMemsetAsync(a.xs_dP, 0, sizeof(float) * 2L * a.Bt * 2 * a.Cp * a.L, s)) != hipSuccess) return (int)e;
+    } else {
+      if ((e = hipMemsetAsync(a.dB, 0, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
+      if ((e = hipMemsetAsync(a.dC, 0, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
+    }
+  }
+  const int lds_summary = SS_BWD_LDS_SUMMARY + (XS ? a.R * SS_DTP * 4 : 0);
+  const int lds_final = SS_BWD_LDS_FINAL + (XS ? a.R * (SS_DTP + SS_CL) * 4 : 0);
+  dim3 grid(a.nchunks, a.Bt * a.K * (a.Dg / a.rows_per_wg));
+  if (a.nchunks > 1) {
+    hipLaunchKernelGGL((scan_bwd_kernel<false, XS>), grid, dim3(SS_NW * 64), lds_summary, s, a);
+    NNZ_LAUNCH_CHECK();
+    const long rows_n = rows * SS_N;
+    hipLaunchKernelGGL(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin,
+                       rows_n, a.nchunks);
+    NNZ_LAUNCH_CHECK();
+  } else {
+    if ((e = hipMemsetAsync(a.Gin, 0, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
+  }
+  static int attr_lds = 0;  // per instantiation (XS or not)
+  if (lds_final > attr_lds) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bwd_kernel<true, XS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_final);
+    if (e != hipSuccess) return (int)e;
+    attr_lds = lds_final;
+  }
+  hipLaunchKernelGGL((scan_bwd_kernel<true, XS>), grid, dim3(SS_NW * 64), lds_final, s, a);
+  NNZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA,
+                     a.dbias, a.dD, a.Bt, a.KD, a.nchunks, dWdt, XS ? a.R : 0);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_selective_scan_forward(const float* u, const float* delta, const float* A, const float* Bm,
+                                          const float* Cm, const float* D, const float* delta_bias, float* y,
+                                          float* chunk_state, float* workspace, int Bt, int K, int Dg, int N, int L,
+                                          int delta_softplus, void* stream) {
+  using namespace nnz;
+  if (!u || !delta || !A || !Bm || !Cm || !y || !chunk_state || !workspace || N != SS_N) return NNZ_EINVAL;
+  ScanArgs a = {};
+  a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.y = y;
+  a.Bt = Bt; a.K = K; a.Dg = Dg; a.KD = K * Dg; a.L = L; a.softplus = delta_softplus;
+  return scan_forward_impl<false>(a, chunk_state, workspace, (hipStream_t)stream);
 }
 
 extern "C" int nnz_selective_scan_backward(const float* u, const float* delta, const float* A, const float* Bm,
@@ -582,42 +772,35 @@ extern "C" int nnz_selective_scan_backward(const float* u, const float* delta, c
   a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.dy = dy;
   a.du = du; a.ddelta = ddelta; a.dA = dA; a.dB = dB; a.dC = dC; a.dD = dD; a.dbias = dbias;
   a.Bt = Bt; a.K = K; a.Dg = Dg; a.KD = K * Dg; a.L = L; a.softplus = delta_softplus;
-  if (int rc = check(a)) return rc;
-  a.nchunks = (L + SS_CL - 1) / SS_CL;
-  const long rows = (long)Bt * a.KD;
-  a.P = workspace;
-  a.S = workspace + rows * SS_N * a.nchunks;
-  a.Hin = const_cast<float*>(chunk_state);
-  a.Gin = grad_state;
-  a.rows_per_wg = pick_rows_per_wg(Dg, (long)Bt * K * a.nchunks);
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t e;
-  if (a.rows_per_wg != Dg) {  // several workgroups add into one dB/dC tile
-    if ((e = hipMemsetAsync(dB, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(dC, 0, sizeof(float) * (long)Bt * K * SS_N * L, s)) != hipSuccess) return (int)e;
-  }
-  dim3 grid(a.nchunks, Bt * K * (Dg / a.rows_per_wg));
-  if (a.nchunks > 1) {
-    hipLaunchKernelGGL(scan_bwd_kernel<false>, grid, dim3(SS_NW * 64), SS_BWD_LDS_SUMMARY, s, a);
-    NNZ_LAUNCH_CHECK();
-    const long rows_n = rows * SS_N;
-    hipLaunchKernelGGL(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin,
-                       rows_n, a.nchunks);
-    NNZ_LAUNCH_CHECK();
-  } else {
-    if ((e = hipMemsetAsync(a.Gin, 0, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bwd_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, SS_BWD_LDS_FINAL);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(scan_bwd_kernel<true>, grid, dim3(SS_NW * 64), SS_BWD_LDS_FINAL, s, a);
-  NNZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, dA,
-                     dbias, dD, Bt, a.KD, a.nchunks);
-  NNZ_LAUNCH_CHECK();
-  return NNZ_OK;
+  return scan_backward_impl<false>(a, chunk_state, grad_state, workspace, nullptr, (hipStream_t)stream);
+}
+
+// ---- cross-scan entry points (SS2D: 4 directions over one (B, Dg, H, W) input; see ScanArgs) -------------------------
+extern "C" int nnz_ss2d_scan_forward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
+                                     const float* delta_bias, float* y, float* chunk_state, float* workspace, int Bt,
+                                     int Dg, int R, int L, int delta_softplus, void* stream) {
+  using namespace nnz;
+  if (!x2 || !P || !Wdt || !A || !y || !chunk_state || !workspace || R < 1 || R > SS_RMAX) return NNZ_EINVAL;
+  ScanArgs a = {};
+  a.u = x2; a.xs_P = P; a.xs_Wdt = Wdt; a.A = A; a.D = D; a.bias = delta_bias; a.y = y;
+  a.R = R; a.Cp = R + 2 * SS_N;
+  a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus;
+  return scan_forward_impl<true>(a, chunk_state, workspace, (hipStream_t)stream);
+}
+
+extern "C" int nnz_ss2d_scan_backward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
+                                      const float* delta_bias, const float* dy2, const float* chunk_state,
+                                      float* grad_state, float* workspace, float* du, float* dP, float* dWdt, float* dA,
+                                      float* dD, float* dbias, int Bt, int Dg, int R, int L, int delta_softplus,
+                                      void* stream) {
+  using namespace nnz;
+  if (!x2 || !P || !Wdt || !A || !dy2 || !chunk_state || !grad_state || !workspace || !du || !dP || !dWdt || !dA ||
+      R < 1 || R > SS_RMAX)
+    return NNZ_EINVAL;
+  ScanArgs a = {};
+  a.u = x2; a.xs_P = P; a.xs_Wdt = Wdt; a.A = A; a.D = D; a.bias = delta_bias; a.dy = dy2;
+  a.du = du; a.xs_dP = dP; a.dA = dA; a.dD = dD; a.dbias = dbias;
+  a.R = R; a.Cp = R + 2 * SS_N;
+  a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus;
+  return scan_backward_impl<true>(a, chunk_state, grad_state, workspace, dWdt, (hipStream_t)stream);
 }

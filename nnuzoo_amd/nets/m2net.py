@@ -23,6 +23,7 @@ from torch import nn
 
 from ..layer_norm import LayerNorm
 
+from .. import ss2d_scan
 from ..selective_scan import selective_scan_fn
 from ..utilities.network_initialization import InitWeights_He
 from .common2d import DropPath, PatchExpand, PatchMerging2D, REBNCONV, RSU4F, _upsample_like
@@ -30,6 +31,7 @@ from .common2d import DropPath, PatchExpand, PatchMerging2D, REBNCONV, RSU4F, _u
 
 class SS2D(nn.Module):
     K = 4  # scan directions: row-major, column-major and their reversals
+    fused_cross_scan = True  # False: the reference's op-by-op formulation around selective_scan_fn (parity tests)
 
     def __init__(self, d_model, d_state=16, d_conv=3, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
                  dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, dropout=0., conv_bias=True, bias=False,
@@ -129,8 +131,13 @@ class SS2D(nn.Module):
         B, H, W, C = x.shape
         x, z = self.in_proj(x).chunk(2, dim=-1)
         x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
-        y1, y2, y3, y4 = self.forward_core(x)
-        y = (y1 + y2 + y3 + y4).transpose(1, 2).reshape(B, H, W, -1)
+        if self.fused_cross_scan and ss2d_scan.supported(x, self.dt_rank, self.d_state):
+            # directions by index arithmetic inside the scan kernels, one autograd node (nnuzoo_amd/ss2d_scan.py)
+            y = ss2d_scan.ss2d_cross_scan(x, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs,
+                                          self.Ds)
+        else:
+            y1, y2, y3, y4 = self.forward_core(x)
+            y = (y1 + y2 + y3 + y4).transpose(1, 2).reshape(B, H, W, -1)
         y = self.out_norm(y) * F.silu(z)
         out = self.out_proj(y)
         return self.dropout(out) if self.dropout is not None else out

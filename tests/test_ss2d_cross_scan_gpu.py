@@ -1,0 +1,95 @@
+"""The fused SS2D core (nnuzoo_amd/ss2d_scan.py: cross-scan mode of the chunk-scan kernels + layout kernels) against the
+op-by-op formulation of the reference's SS2D.forward_core around selective_scan_fn (SS2D.fused_cross_scan = False; that
+path is pinned to the reference by tests/golden via test_zoo_gpu.py / test_selective_scan_gpu.py).  fp32: outputs rtol
+1e-4, gradients rtol 2e-3 of the largest entry (atomic fp32 reductions in both formulations)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(block, x, dy, fused, autocast=False):
+    from nnuzoo_amd.nets.m2net import SS2D
+    block.zero_grad(set_to_none=True)
+    old = SS2D.fused_cross_scan
+    SS2D.fused_cross_scan = fused
+    try:
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+            y = block(xi)
+        y.float().backward(dy)
+    finally:
+        SS2D.fused_cross_scan = old
+    grads = {n: p.grad.clone() for n, p in block.named_parameters() if p.grad is not None}
+    return y.detach().float(), xi.grad.clone(), grads
+
+
+def _close(a, b, tol, what):
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, (what, err, scale)
+
+
+@pytest.mark.parametrize("d_model,B,H,W", [(16, 2, 24, 40), (16, 1, 13, 9), (32, 2, 16, 16), (64, 1, 20, 12),
+                                           (128, 2, 8, 8), (16, 1, 64, 48)])
+def test_fused_core_matches_composed_fp32(hip_lib, d_model, B, H, W):
+    from nnuzoo_amd.nets.m2net import SS2D
+    torch.manual_seed(d_model + H)
+    blk = SS2D(d_model=d_model).cuda()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, d_model, generator=g).cuda()
+    dy = torch.randn(B, H, W, d_model, generator=g).cuda()
+    y0, dx0, g0 = _run(blk, x, dy, fused=False)
+    y1, dx1, g1 = _run(blk, x, dy, fused=True)
+    _close(y1, y0, 1e-4, "y")
+    _close(dx1, dx0, 2e-3, "dx")
+    assert set(g0) == set(g1)
+    for n in g0:
+        _close(g1[n], g0[n], 2e-3, n)
+
+
+def test_fused_core_under_autocast(hip_lib):
+    """under autocast the op-by-op path rounds the x_proj / dt einsums to fp16 (as the reference does), the fused core
+    keeps them in fp32: agreement to fp16 rounding"""
+    from nnuzoo_amd.nets.m2net import SS2D
+    torch.manual_seed(3)
+    blk = SS2D(d_model=32).cuda()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 24, 24, 32, generator=g).cuda()
+    dy = torch.randn(2, 24, 24, 32, generator=g).cuda()
+    y0, dx0, g0 = _run(blk, x, dy, fused=False, autocast=True)
+    y1, dx1, g1 = _run(blk, x, dy, fused=True, autocast=True)
+    _close(y1, y0, 1e-2, "y")
+    _close(dx1, dx0, 3e-2, "dx")
+    for n in g0:
+        _close(g1[n], g0[n], 3e-2, n)
+
+
+def test_layout_kernels(hip_lib):
+    from nnuzoo_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(4)
+    B, D, H, W = 2, 20, 19, 37
+    L = H * W
+    x = torch.randn(B, D, H, W, generator=g).cuda()
+    for xx in (x, x.half()):
+        x2 = torch.empty(2, B, D, L, device="cuda")
+        call("nnz_ss2d_prepare", ptr(xx), int(xx.dtype == torch.float16), ptr(x2), B, D, H, W, stream_ptr())
+        assert torch.equal(x2[0], xx.float().reshape(B, D, L))
+        assert torch.equal(x2[1], xx.float().transpose(2, 3).reshape(B, D, L))
+    y = torch.randn(B, 4, D, L, generator=g).cuda()
+    out = torch.empty(B, H, W, D, device="cuda")
+    call("nnz_ss2d_merge", ptr(y), ptr(out), B, D, H, W, stream_ptr())
+    ref = (y[:, 0] + y[:, 2]).reshape(B, D, H, W) + (y[:, 1] + y[:, 3]).reshape(B, D, W, H).transpose(2, 3)
+    assert torch.allclose(out, ref.permute(0, 2, 3, 1), rtol=1e-6, atol=1e-6)
+    dout = torch.randn(B, H, W, D, generator=g).cuda()
+    dy2 = torch.empty(2, B, D, L, device="cuda")
+    call("nnz_ss2d_split", ptr(dout), ptr(dy2), B, D, H, W, stream_ptr())
+    assert torch.equal(dy2[0], dout.permute(0, 3, 1, 2).reshape(B, D, L))
+    assert torch.equal(dy2[1], dout.permute(0, 3, 2, 1).reshape(B, D, L))
+    du = torch.randn(B, 4, D, L, generator=g).cuda()
+    dx2 = torch.randn(2, B, D, L, generator=g).cuda()
+    dx = torch.empty(B, D, H, W, device="cuda")
+    call("nnz_ss2d_merge_dx", ptr(du), ptr(dx2), ptr(dx), 0, B, D, H, W, stream_ptr())
+    ref = (du[:, 0] + du[:, 2] + dx2[0]).reshape(B, D, H, W) + \
+        (du[:, 1] + du[:, 3] + dx2[1]).reshape(B, D, W, H).transpose(2, 3)
+    assert torch.allclose(dx, ref, rtol=1e-6, atol=1e-5)
