@@ -76,4 +76,39 @@ __device__ __forceinline__ T* pin_uniform(T* ptr) {
   return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
+// Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used anywhere in this library: captured into a hipGraph it
+// becomes a fill node whose pattern staging the runtime releases after capture - replays after later allocations then
+// fill with whatever landed there (measured on ROCm 7.2 / MI355X, tools/dbg/dbg_graph_memset2.py: NaNs in dbeta).
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void zero_fill_kernel(u32x4* __restrict__ p, size_t nvec, uint32_t* __restrict__ tail,
+                                                        int ntail) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+}
+// bytes must be a multiple of 4 (every caller zeroes float / 64-bit counters)
+inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  char* c = (char*)ptr;
+  size_t head = ((uintptr_t)c & 15) ? 16 - ((uintptr_t)c & 15) : 0;  // words up to the first 16-byte boundary
+  if (head > bytes) head = bytes;
+  if (head) {
+    hipLaunchKernelGGL(zero_fill_kernel<0>, dim3(1), dim3(256), 0, s, (u32x4*)nullptr, (size_t)0, (uint32_t*)c,
+                       (int)(head / 4));
+    c += head;
+    bytes -= head;
+  }
+  const size_t nvec = bytes / 16;
+  const int ntail = (int)((bytes - nvec * 16) / 4);
+  if (nvec || ntail) {
+    size_t wg = (nvec + 255) / 256;
+    if (wg > 4096) wg = 4096;
+    if (wg < 1) wg = 1;
+    hipLaunchKernelGGL(zero_fill_kernel<0>, dim3((unsigned)wg), dim3(256), 0, s, (u32x4*)c, nvec,
+                       (uint32_t*)(c + nvec * 16), ntail);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace nnz

@@ -484,7 +484,7 @@ extern "C" int nnz_stem_conv_wgrad(const float* x, const void* dy, float* dw, in
   a.tiles[1] = (H + ST_TH - 1) / ST_TH;
   a.tiles[2] = (W + ST_TW - 1) / ST_TW;
   const int ntiles = N * a.tiles[0] * a.tiles[1] * a.tiles[2];
-  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * ST_CO * 27, (hipStream_t)stream);
+  hipError_t e = nnz::zero_async(dw, sizeof(float) * ST_CO * 27, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   const int grid = ntiles < 512 ? ntiles : 512;  // persistent: 2 workgroups per CU, one atomic per element each
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ntiles);
@@ -583,9 +583,9 @@ extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw,
   a.x = (const f16*)x; a.dl = (const f16*)dlogits; a.dw = dw; a.db = db;
   a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * K * C, s);
+  hipError_t e = nnz::zero_async(dw, sizeof(float) * K * C, s);
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(db, 0, sizeof(float) * K, s);
+  e = nnz::zero_async(db, sizeof(float) * K, s);
   if (e != hipSuccess) return (int)e;
   long vpb = (V * N + 1023) / 1024;
   if (vpb < 256) vpb = 256;

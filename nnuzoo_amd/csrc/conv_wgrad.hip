@@ -325,7 +325,7 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchO
     attr_lds = lds;
   }
   if (!p.part && !pre_zeroed) {
-    hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.d.ntaps_total * p.d.Cin * p.d.Cout, stream);
+    hipError_t e = nnz::zero_async(p.dw, sizeof(float) * (size_t)p.d.ntaps_total * p.d.Cin * p.d.Cout, stream);
     if (e != hipSuccess) return (int)e;
   }
   if (opt.splits_used) *opt.splits_used = splits;
@@ -503,7 +503,7 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
     if (rc != NNZ_OK) return rc;
   } else {
     // batch beyond 2^31 elements: sample chunks accumulate atomically into one [T][A][B] image in the workspace
-    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * tab, s);
+    hipError_t e = nnz::zero_async(workspace, sizeof(float) * tab, s);
     if (e != hipSuccess) return (int)e;
     for (int n0 = 0; n0 < d.N; n0 += chunk) {
       WgradDev p = {};

@@ -224,8 +224,8 @@ extern "C" int nnz_layer_norm_backward(const void* x, int x_is_f16, const float*
   using namespace nnz;
   if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048) return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (dgamma) { hipError_t e = hipMemsetAsync(dgamma, 0, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
-  if (dbeta) { hipError_t e = hipMemsetAsync(dbeta, 0, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
+  if (dgamma) { hipError_t e = nnz::zero_async(dgamma, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
+  if (dbeta) { hipError_t e = nnz::zero_async(dbeta, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
   if (rows == 0) return NNZ_OK;
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.dgamma = dgamma;

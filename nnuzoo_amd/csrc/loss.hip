@@ -151,7 +151,7 @@ static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
   a.vpb = (int)vpb;
   const int gx = (int)((a.V + vpb - 1) / vpb);
   if (!bwd) {
-    hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(float) * a.B * (3 * a.C + 1), s);
+    hipError_t e = nnz::zero_async(a.sums, sizeof(float) * a.B * (3 * a.C + 1), s);
     if (e != hipSuccess) return (int)e;
     if (big)
       hipLaunchKernelGGL((dc_ce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
@@ -439,7 +439,7 @@ static int launch_region(RegionArgs<T> a, int mode, void* counts, hipStream_t s)
   const int gx = (int)((a.V + vpb - 1) / vpb);
   const bool big = a.C > 8;
   if (mode == 0) {
-    hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(float) * a.B * (3 * a.C + 2), s);
+    hipError_t e = nnz::zero_async(a.sums, sizeof(float) * a.B * (3 * a.C + 2), s);
     if (e != hipSuccess) return (int)e;
     if (big) hipLaunchKernelGGL((dc_bce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((dc_bce_fwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
@@ -447,7 +447,7 @@ static int launch_region(RegionArgs<T> a, int mode, void* counts, hipStream_t s)
     if (big) hipLaunchKernelGGL((dc_bce_bwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((dc_bce_bwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
   } else {
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 3 * a.C, s);
+    hipError_t e = nnz::zero_async(counts, sizeof(unsigned long long) * 3 * a.C, s);
     if (e != hipSuccess) return (int)e;
     if (big)
       hipLaunchKernelGGL((region_stats_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a.logits, a.tgt,
@@ -511,7 +511,7 @@ extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const 
   using namespace nnz;
   if (!logits || !target || !counts_u64 || C < 1 || C > LS_MAXC_BIG || B < 1 || V < 1) return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(counts_u64, 0, sizeof(unsigned long long) * 3 * C, s);
+  hipError_t e = nnz::zero_async(counts_u64, sizeof(unsigned long long) * 3 * C, s);
   if (e != hipSuccess) return (int)e;
   long vpb = (V * B + 2047) / 2048;
   if (vpb < 2048) vpb = 2048;

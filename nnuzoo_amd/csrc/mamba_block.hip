@@ -167,10 +167,10 @@ extern "C" int nnz_causal_conv1d_silu_backward(const float* x, const float* w, c
   using namespace nnz;
   if (!x || !w || !dy || !dx || !dw || B < 1 || D < 1 || L < 1 || W < 1 || W > CC_MAXW) return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * D * W, s);
+  hipError_t e = nnz::zero_async(dw, sizeof(float) * D * W, s);
   if (e != hipSuccess) return (int)e;
   if (dbias) {
-    e = hipMemsetAsync(dbias, 0, sizeof(float) * D, s);
+    e = nnz::zero_async(dbias, sizeof(float) * D, s);
     if (e != hipSuccess) return (int)e;
   }
   ConvArgs a = {};

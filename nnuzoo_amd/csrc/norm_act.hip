@@ -182,7 +182,7 @@ static int launch_norm(NormArgs a, hipStream_t s, bool pre_zeroed = false) {
   const int rows = 256 / (a.C >> 3);
   const size_t lds = (MODE == 0 || MODE == 2) ? sizeof(float) * rows * 2 * a.C : 0;
   if ((MODE == 0 || MODE == 2) && !pre_zeroed) {
-    hipError_t e = hipMemsetAsync(MODE == 0 ? a.stats : a.red, 0, sizeof(float) * 2 * a.N * a.C, s);
+    hipError_t e = nnz::zero_async(MODE == 0 ? a.stats : a.red, sizeof(float) * 2 * a.N * a.C, s);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(norm_kernel<MODE>, dim3(gx, a.N), dim3(256), lds, s, a);

@@ -689,7 +689,7 @@ static int scan_forward_impl(ScanArgs& a, float* chunk_state, float* workspace, 
                        rows_n, a.nchunks);
     NNZ_LAUNCH_CHECK();
   } else {
-    hipError_t e = hipMemsetAsync(a.Hin, 0, sizeof(float) * rows * SS_N, s);
+    hipError_t e = nnz::zero_async(a.Hin, sizeof(float) * rows * SS_N, s);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL((scan_fwd_kernel<true, XS>), grid, dim3(SS_NW * 64), 0, s, a);
@@ -711,10 +711,10 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
   hipError_t e;
   if (a.rows_per_wg != a.Dg) {  // several workgroups add into one dB/dC (dP) tile
     if (XS) {
-      if ((e = hipMemsetAsync(a.xs_dP, 0, sizeof(float) * 2L * a.Bt * 2 * a.Cp * a.L, s)) != hipSuccess) return (int)e;
+      if ((e = nnz::zero_async(a.xs_dP, sizeof(float) * 2L * a.Bt * 2 * a.Cp * a.L, s)) != hipSuccess) return (int)e;
     } else {
-      if ((e = hipMemsetAsync(a.dB, 0, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
-      if ((e = hipMemsetAsync(a.dC, 0, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
+      if ((e = nnz::zero_async(a.dB, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
+      if ((e = nnz::zero_async(a.dC, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
     }
   }
   const int lds_summary = SS_BWD_LDS_SUMMARY + (XS ? a.R * SS_DTP * 4 : 0);
@@ -728,7 +728,7 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
                        rows_n, a.nchunks);
     NNZ_LAUNCH_CHECK();
   } else {
-    if ((e = hipMemsetAsync(a.Gin, 0, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
+    if ((e = nnz::zero_async(a.Gin, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
   }
   static int attr_lds = 0;  // per instantiation (XS or not)
   if (lds_final > attr_lds) {

@@ -415,7 +415,7 @@ extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias
   a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.dout = dout; a.dqkv = dqkv; a.dbias = dbias_table;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
   if (int rc = check(a)) return rc;
-  hipError_t e = hipMemsetAsync(dbias_table, 0, sizeof(float) * heads * (2 * WA_WS - 1) * (2 * WA_WS - 1),
+  hipError_t e = nnz::zero_async(dbias_table, sizeof(float) * heads * (2 * WA_WS - 1) * (2 * WA_WS - 1),
                                 (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   const int nwin = B * (H / WA_WS) * (W / WA_WS);
