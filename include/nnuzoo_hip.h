@@ -147,6 +147,7 @@ int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, 
  *   Wdt [4 Dg][R]          dt_projs_weight; delta = softplus(Wdt . dt + delta_bias) formed in the kernel (R <= 8)
  *   y, du [B][4 Dg][L]     per direction, in the source's token order (un-reversed)
  *   dy2 [2][B][Dg][L]      gradient seen by both directions of a source (nnz_ss2d_split); dP like P; dWdt like Wdt
+ * a_is_log: A holds A_log [4 Dg][16]; the kernels use A = -exp(A_log) and return dA_log = dA * A (m2net.py:196).
  * chunk_state / grad_state / workspace: nnz_selective_scan_state_floats / _workspace_floats(B, 4 Dg, L).
  * nnz_ss2d_merge: out (B, H, W, Dg) = y0 + y2 + (y1 + y3)^T;  nnz_ss2d_merge_dx: dx (B, Dg, H, W) = du0 + du2 + dx2[0]
  * + (du1 + du3 + dx2[1])^T in x's type. */
@@ -157,11 +158,11 @@ int nnz_ss2d_merge_dx(const float* du, const float* dx2, void* dx, int dx_is_f16
                       void* stream);
 int nnz_ss2d_scan_forward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
                           const float* delta_bias, float* y, float* chunk_state, float* workspace, int Bt, int Dg, int R,
-                          int L, int delta_softplus, void* stream);
+                          int L, int delta_softplus, int a_is_log, void* stream);
 int nnz_ss2d_scan_backward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
                            const float* delta_bias, const float* dy2, const float* chunk_state, float* grad_state,
                            float* workspace, float* du, float* dP, float* dWdt, float* dA, float* dD, float* dbias,
-                           int Bt, int Dg, int R, int L, int delta_softplus, void* stream);
+                           int Bt, int Dg, int R, int L, int delta_softplus, int a_is_log, void* stream);
 
 /* ---- LayerNorm over the last dimension of token-major tensors (nn.LayerNorm in the VSS / Swin blocks: m2net.py:101,521,
  * ssnd2net.py, swt2net.py:630-660).  x: [rows][C] f16 or f32, C % 4 == 0, C <= 2048; y, dy: f32 (what autocast gives);
@@ -170,6 +171,14 @@ int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, cons
                            float* rstd, long rows, int C, float eps, void* stream);
 int nnz_layer_norm_backward(const void* x, int x_is_f16, const float* gamma, const float* mean, const float* rstd,
                             const float* dy, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
+/* y = LayerNorm(x) * silu(z): the gated output norm of the SS2D block (m2net.py:220 `self.out_norm(y) * F.silu(z)`).
+ * z: f16 or f32, rows z_row_stride elements apart (z is one half of the in_proj output); dz: [rows][C] in z's type. */
+int nnz_layer_norm_gate_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
+                                int z_is_f16, long z_row_stride, float* y, float* mean, float* rstd, long rows, int C,
+                                float eps, void* stream);
+int nnz_layer_norm_gate_backward(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
+                                 int z_is_f16, long z_row_stride, const float* mean, const float* rstd, const float* dy,
+                                 void* dx, void* dz, float* dgamma, float* dbeta, long rows, int C, void* stream);
 
 /* ---- fused soft-Dice + cross-entropy statistics on NC(D)HW logits --------------------------------------------
  * replaces softmax + one-hot + reductions + CE of DC_and_CE_loss (nnunetv2/training/loss/compound_losses.py:31-56,

@@ -23,7 +23,15 @@ struct LnArgs {
   long R;
   int C;
   float eps;
+  // optional gate (SS2D: out_norm(y) * silu(z), m2net.py:220): y_out = LN(x) * silu(z); z rows have their own stride (z is
+  // one half of the in_proj output), dz has z's type and is written densely [R][C]
+  const void* z;
+  void* dz;
+  long z_stride;
+  int z_is_f16;
 };
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 
 template <class T>
 __device__ __forceinline__ f32x4 ld4(const T* p);
@@ -39,6 +47,9 @@ __device__ __forceinline__ void st4(f16* p, f32x4 v) {
   *reinterpret_cast<f16x4*>(p) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
 }
 
+__device__ __forceinline__ f32x4 ldz(const LnArgs& a, long r, int c) {
+  return a.z_is_f16 ? ld4((const f16*)a.z + r * a.z_stride + c) : ld4((const float*)a.z + r * a.z_stride + c);
+}
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -92,6 +103,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * gm[i][e] + bt[i][e];
+        if (a.z) {
+          const f32x4 zv = ldz(a, r, c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= silu_f(zv[e]);
+        }
         st4(yr + c, o);
       }
     }
@@ -109,11 +125,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
   const int q = threadIdx.x % LPR, g = threadIdx.x / LPR;
   const int C = a.C;
   const float invC = 1.f / (float)C;
-  f32x4 gm[IT], dg[IT], db[IT];
+  f32x4 gm[IT], bt[IT], dg[IT], db[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int c = 4 * (q + LPR * i);
     gm[i] = (a.gamma && c < C) ? ld4(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bt[i] = (a.z && a.beta && c < C) ? ld4(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -127,7 +144,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
     for (int i = 0; i < IT; ++i) {
       const int c = 4 * (q + LPR * i);
       if (c < C) {
-        const f32x4 xv = ld4(xr + c), dv = ld4(dyr + c);
+        const f32x4 xv = ld4(xr + c);
+        f32x4 dv = ld4(dyr + c);
+        if (a.z) {
+          // out = n * silu(z), n = xhat * gamma + beta:  dn = dout * silu(z);  dz = dout * n * silu'(z)
+          const f32x4 zv = ldz(a, r, c);
+          f32x4 dzv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sg = 1.f / (1.f + __expf(-zv[e]));
+            const float n = (xv[e] - mu) * rs * gm[i][e] + bt[i][e];
+            dzv[e] = dv[e] * n * sg * (1.f + zv[e] * (1.f - sg));
+            dv[e] *= zv[e] * sg;
+          }
+          if (a.z_is_f16) st4((f16*)a.dz + r * C + c, dzv);
+          else st4((float*)a.dz + r * C + c, dzv);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[i][e] = (xv[e] - mu) * rs;
@@ -208,27 +240,64 @@ static int ln_dispatch(const LnArgs& a, bool bwd, hipStream_t s) {
 
 }  // namespace nnz
 
-extern "C" int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, float* y,
-                                      float* mean, float* rstd, long rows, int C, float eps, void* stream) {
+static int ln_forward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
+                           int z_is_f16, long z_stride, float* y, float* mean, float* rstd, long rows, int C, float eps,
+                           void* stream) {
   using namespace nnz;
-  if (!x || !y || !mean || !rstd || rows < 0 || C < 4 || (C & 3) || C > 2048) return NNZ_EINVAL;
+  if (!x || !y || !mean || !rstd || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (z_stride & 3))) return NNZ_EINVAL;
   if (rows == 0) return NNZ_OK;
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.R = rows; a.C = C; a.eps = eps;
+  a.z = z; a.z_is_f16 = z_is_f16; a.z_stride = z_stride;
   return x_is_f16 ? ln_dispatch<f16>(a, false, (hipStream_t)stream) : ln_dispatch<float>(a, false, (hipStream_t)stream);
+}
+
+static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
+                            int z_is_f16, long z_stride, const float* mean, const float* rstd, const float* dy, void* dx,
+                            void* dz, float* dgamma, float* dbeta, long rows, int C, void* stream) {
+  using namespace nnz;
+  if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (!dz || (z_stride & 3))))
+    return NNZ_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (dgamma && dbeta == dgamma + C) {  // one buffer [2][C]: one launch
+    if ((e = zero_async(dgamma, sizeof(float) * 2 * C, s)) != hipSuccess) return (int)e;
+  } else {
+    if (dgamma && (e = zero_async(dgamma, sizeof(float) * C, s)) != hipSuccess) return (int)e;
+    if (dbeta && (e = zero_async(dbeta, sizeof(float) * C, s)) != hipSuccess) return (int)e;
+  }
+  if (rows == 0) return NNZ_OK;
+  LnArgs a = {};
+  a.x = x; a.gamma = gamma; a.beta = beta; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.R = rows; a.C = C;
+  a.z = z; a.dz = dz; a.z_is_f16 = z_is_f16; a.z_stride = z_stride;
+  return x_is_f16 ? ln_dispatch<f16>(a, true, s) : ln_dispatch<float>(a, true, s);
+}
+
+extern "C" int nnz_layer_norm_gate_forward(const void* x, int x_is_f16, const float* gamma, const float* beta,
+                                           const void* z, int z_is_f16, long z_row_stride, float* y, float* mean,
+                                           float* rstd, long rows, int C, float eps, void* stream) {
+  if (!z) return NNZ_EINVAL;
+  return ln_forward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, y, mean, rstd, rows, C, eps, stream);
+}
+
+extern "C" int nnz_layer_norm_gate_backward(const void* x, int x_is_f16, const float* gamma, const float* beta,
+                                            const void* z, int z_is_f16, long z_row_stride, const float* mean,
+                                            const float* rstd, const float* dy, void* dx, void* dz, float* dgamma,
+                                            float* dbeta, long rows, int C, void* stream) {
+  if (!z) return NNZ_EINVAL;
+  return ln_backward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, mean, rstd, dy, dx, dz, dgamma, dbeta,
+                          rows, C, stream);
+}
+
+extern "C" int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, float* y,
+                                      float* mean, float* rstd, long rows, int C, float eps, void* stream) {
+  return ln_forward_impl(x, x_is_f16, gamma, beta, nullptr, 0, 0, y, mean, rstd, rows, C, eps, stream);
 }
 
 extern "C" int nnz_layer_norm_backward(const void* x, int x_is_f16, const float* gamma, const float* mean,
                                        const float* rstd, const float* dy, void* dx, float* dgamma, float* dbeta,
                                        long rows, int C, void* stream) {
-  using namespace nnz;
-  if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048) return NNZ_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  if (dgamma) { hipError_t e = nnz::zero_async(dgamma, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
-  if (dbeta) { hipError_t e = nnz::zero_async(dbeta, sizeof(float) * C, s); if (e != hipSuccess) return (int)e; }
-  if (rows == 0) return NNZ_OK;
-  LnArgs a = {};
-  a.x = x; a.gamma = gamma; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.dgamma = dgamma;
-  a.dbeta = dbeta; a.R = rows; a.C = C;
-  return x_is_f16 ? ln_dispatch<f16>(a, true, s) : ln_dispatch<float>(a, true, s);
+  return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dx, nullptr, dgamma, dbeta, rows, C,
+                          stream);
 }

@@ -57,6 +57,7 @@ struct ScanArgs {
   // y / du: [B][KD][L] per direction in the source's (un-reversed) token order; dP like P (accumulated).
   const float* xs_P;
   const float* xs_Wdt;  // [KD][R]
+  int a_is_log;         // A holds A_log: the kernels use -exp(A_log) and return dA_log = dA * A (m2net.py:196)
   float* xs_dP;
   int R, Cp;
 };
@@ -209,7 +210,10 @@ __device__ __forceinline__ void load_row(const ScanArgs& a, int b, int k, int r,
   }
   const int n = lane & 15;
   float v = 0.f;
-  if (lane < 16) v = a.A[(long)kd * SS_N + n];
+  if (lane < 16) {
+    v = a.A[(long)kd * SS_N + n];
+    if (XS && a.a_is_log) v = -__expf(v);
+  }
   else if (lane < 32) { if (FINAL) v = a.Hin[(row * a.nchunks + c) * SS_N + n]; }
   else if (lane < 48) { if (BWD && FINAL) v = a.Gin[(row * a.nchunks + c) * SS_N + n]; }
   else if (XS && lane - 48 < a.R) v = a.xs_Wdt[(long)kd * a.R + (lane - 48)];
@@ -620,7 +624,8 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
 __global__ __launch_bounds__(256) void scan_bwd_finalize_kernel(const float* __restrict__ P, const float* __restrict__ S,
                                                                 float* __restrict__ dA, float* __restrict__ dbias,
                                                                 float* __restrict__ dD, int Bt, int KD, int nchunks,
-                                                                float* __restrict__ dWdt, int R) {
+                                                                float* __restrict__ dWdt, int R,
+                                                                const float* __restrict__ Alog) {
   const int lane = threadIdx.x & 63;
   const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= (long)KD * SS_N) return;
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(256) void scan_bwd_finalize_kernel(const float* __r
   sa = wave_sum(sa);
   s0 = wave_sum(s0);
   if (lane == 0) {
-    dA[w] = sa;
+    dA[w] = Alog ? sa * -__expf(Alog[w]) : sa;
     if (n == 0 && dbias) dbias[kd] = s0;
     if (n == 1 && dD) dD[kd] = s0;
     if (n >= 2 && n < 2 + R && dWdt) dWdt[(long)kd * R + (n - 2)] = s0;   // cross-scan mode: rows 2 .. 2+R of S
@@ -740,7 +745,8 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
   hipLaunchKernelGGL((scan_bwd_kernel<true, XS>), grid, dim3(SS_NW * 64), lds_final, s, a);
   NNZ_LAUNCH_CHECK();
   hipLaunchKernelGGL(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA,
-                     a.dbias, a.dD, a.Bt, a.KD, a.nchunks, dWdt, XS ? a.R : 0);
+                     a.dbias, a.dD, a.Bt, a.KD, a.nchunks, dWdt, XS ? a.R : 0,
+                     (XS && a.a_is_log) ? a.A : (const float*)nullptr);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -778,13 +784,13 @@ extern "C" int nnz_selective_scan_backward(const float* u, const float* delta, c
 // ---- cross-scan entry points (SS2D: 4 directions over one (B, Dg, H, W) input; see ScanArgs) -------------------------
 extern "C" int nnz_ss2d_scan_forward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
                                      const float* delta_bias, float* y, float* chunk_state, float* workspace, int Bt,
-                                     int Dg, int R, int L, int delta_softplus, void* stream) {
+                                     int Dg, int R, int L, int delta_softplus, int a_is_log, void* stream) {
   using namespace nnz;
   if (!x2 || !P || !Wdt || !A || !y || !chunk_state || !workspace || R < 1 || R > SS_RMAX) return NNZ_EINVAL;
   ScanArgs a = {};
   a.u = x2; a.xs_P = P; a.xs_Wdt = Wdt; a.A = A; a.D = D; a.bias = delta_bias; a.y = y;
   a.R = R; a.Cp = R + 2 * SS_N;
-  a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus;
+  a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus; a.a_is_log = a_is_log;
   return scan_forward_impl<true>(a, chunk_state, workspace, (hipStream_t)stream);
 }
 
@@ -792,7 +798,7 @@ extern "C" int nnz_ss2d_scan_backward(const float* x2, const float* P, const flo
                                       const float* delta_bias, const float* dy2, const float* chunk_state,
                                       float* grad_state, float* workspace, float* du, float* dP, float* dWdt, float* dA,
                                       float* dD, float* dbias, int Bt, int Dg, int R, int L, int delta_softplus,
-                                      void* stream) {
+                                      int a_is_log, void* stream) {
   using namespace nnz;
   if (!x2 || !P || !Wdt || !A || !dy2 || !chunk_state || !grad_state || !workspace || !du || !dP || !dWdt || !dA ||
       R < 1 || R > SS_RMAX)
@@ -801,6 +807,6 @@ extern "C" int nnz_ss2d_scan_backward(const float* x2, const float* P, const flo
   a.u = x2; a.xs_P = P; a.xs_Wdt = Wdt; a.A = A; a.D = D; a.bias = delta_bias; a.dy = dy2;
   a.du = du; a.xs_dP = dP; a.dA = dA; a.dD = dD; a.dbias = dbias;
   a.R = R; a.Cp = R + 2 * SS_N;
-  a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus;
+  a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus; a.a_is_log = a_is_log;
   return scan_backward_impl<true>(a, chunk_state, grad_state, workspace, dWdt, (hipStream_t)stream);
 }

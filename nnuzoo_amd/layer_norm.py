@@ -34,11 +34,82 @@ class _LayerNormFn(torch.autograd.Function):
         rows = xc.numel() // C
         dy = dy.float().contiguous()
         dx = torch.empty_like(xc)
-        dw = torch.empty_like(weight) if weight is not None and ctx.needs_input_grad[1] else None
-        db = torch.empty(C, dtype=torch.float32, device=xc.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw, db = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, xc.device)
         call("nnz_layer_norm_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
              ptr(dy), ptr(dx), ptr(dw), ptr(db), rows, C, stream_ptr())
         return dx, dw, db, None, None
+
+
+def _affine_grads(weight, has_bias, need_w, need_b, C, device):
+    """dgamma / dbeta as the two rows of one buffer when both are needed: the kernel launcher zeroes them in one launch"""
+    need_w, need_b = need_w and weight is not None, need_b and has_bias
+    if need_w and need_b:
+        both = torch.empty((2, C), dtype=torch.float32, device=device)
+        return both[0], both[1]
+    return (torch.empty(C, dtype=torch.float32, device=device) if need_w else None,
+            torch.empty(C, dtype=torch.float32, device=device) if need_b else None)
+
+
+def _row_stride(z: torch.Tensor):
+    """element stride between consecutive rows of z viewed as [rows][C], or None when z is not such a view"""
+    C = z.shape[-1]
+    if z.stride(-1) != 1:
+        return None
+    rs = z.stride(-2) if z.dim() > 1 else C
+    expect = rs
+    for d in range(z.dim() - 2, -1, -1):
+        if z.shape[d] != 1 and z.stride(d) != expect:
+            return None
+        expect *= z.shape[d]
+    return rs
+
+
+class _LayerNormGateFn(torch.autograd.Function):
+    """LayerNorm(x) * silu(z) (SS2D's gated output norm) in one pass each way"""
+
+    @staticmethod
+    def forward(ctx, x, z, weight, bias, eps):
+        C = x.shape[-1]
+        xc = x.contiguous()
+        rows = xc.numel() // C
+        zs = _row_stride(z)
+        if zs is None or zs % 4 or z.data_ptr() % 8:
+            z = z.contiguous()
+            zs = C
+        y = torch.empty(xc.shape, dtype=torch.float32, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call("nnz_layer_norm_gate_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
+             int(z.dtype == torch.float16), zs, ptr(y), ptr(mean), ptr(rstd), rows, C, float(eps), stream_ptr())
+        ctx.save_for_backward(xc, z, weight, bias, mean, rstd)
+        ctx.zs = zs
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, z, weight, bias, mean, rstd = ctx.saved_tensors
+        C = xc.shape[-1]
+        rows = xc.numel() // C
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(xc)
+        dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+        dw, db = _affine_grads(weight, bias is not None, ctx.needs_input_grad[2], ctx.needs_input_grad[3], C, xc.device)
+        call("nnz_layer_norm_gate_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
+             int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), ptr(dx), ptr(dz), ptr(dw), ptr(db),
+             rows, C, stream_ptr())
+        return dx, dz, dw, db, None
+
+
+def layer_norm_gate(x: torch.Tensor, z: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor:
+    """F.layer_norm(x, (C,), weight, bias, eps) * F.silu(z) -> fp32, one kernel each way (no CPU path)"""
+    if not x.is_cuda:
+        raise RuntimeError("nnuzoo_amd.layer_norm runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
+    C = x.shape[-1]
+    if C % 4 or C > 2048 or x.dtype not in (torch.float16, torch.float32) or z.shape != x.shape or \
+            z.dtype not in (torch.float16, torch.float32) or (weight is not None and weight.dtype != torch.float32):
+        raise NotImplementedError(f"layer_norm_gate kernel: C % 4 == 0, C <= 2048, fp16/fp32 x and z of one shape "
+                                  f"(got C={C}, {x.dtype}, {z.dtype})")
+    return _LayerNormGateFn.apply(x, z, weight, bias, eps)
 
 
 def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor:

@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..layer_norm import LayerNorm
+from ..layer_norm import LayerNorm, layer_norm_gate
 
 from .. import ss2d_scan
 from ..selective_scan import selective_scan_fn
@@ -135,10 +135,11 @@ class SS2D(nn.Module):
             # directions by index arithmetic inside the scan kernels, one autograd node (nnuzoo_amd/ss2d_scan.py)
             y = ss2d_scan.ss2d_cross_scan(x, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs,
                                           self.Ds)
+            y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)   # LN(y) * silu(z)
         else:
             y1, y2, y3, y4 = self.forward_core(x)
             y = (y1 + y2 + y3 + y4).transpose(1, 2).reshape(B, H, W, -1)
-        y = self.out_norm(y) * F.silu(z)
+            y = self.out_norm(y) * F.silu(z)
         out = self.out_proj(y)
         return self.dropout(out) if self.dropout is not None else out
 

@@ -41,7 +41,7 @@ class _SS2DCrossScan(torch.autograd.Function):
             # direction k = s + 2j  ->  rows [j*Cp, (j+1)*Cp) of source s's stacked projection weight
             Wst = x_proj_weight.detach().float().view(2, 2, Cp, Di).transpose(0, 1).reshape(2, 1, 2 * Cp, Di)
             P = torch.matmul(Wst, x2)                                            # (2, B, 2Cp, L)
-            A = -torch.exp(A_logs.detach().float())                              # (4 Di, N)
+            A = A_logs.detach().float().contiguous()                             # A_log; the kernels use -exp(A_log)
             Wdt = dt_projs_weight.detach().float().reshape(K * Di, R).contiguous()
             bias = dt_projs_bias.detach().float().reshape(-1).contiguous()
             Dv = Ds.detach().float().contiguous()
@@ -49,7 +49,7 @@ class _SS2DCrossScan(torch.autograd.Function):
             state = torch.empty(lib.nnz_selective_scan_state_floats(B, K * Di, L), **f32)
             ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f32)
             call("nnz_ss2d_scan_forward", ptr(x2), ptr(P), ptr(Wdt), ptr(A), ptr(Dv), ptr(bias), ptr(y), ptr(state),
-                 ptr(ws), B, Di, R, L, 1, stream_ptr())
+                 ptr(ws), B, Di, R, L, 1, 1, stream_ptr())
             out = torch.empty((B, H, W, Di), **f32)
             call("nnz_ss2d_merge", ptr(y), ptr(out), B, Di, H, W, stream_ptr())
         ctx.save_for_backward(x2, P, Wst, A, Wdt, bias, Dv, state)
@@ -75,7 +75,7 @@ class _SS2DCrossScan(torch.autograd.Function):
             gstate = torch.empty_like(state)
             ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f32)
             call("nnz_ss2d_scan_backward", ptr(x2), ptr(P), ptr(Wdt), ptr(A), ptr(Dv), ptr(bias), ptr(dy2), ptr(state),
-                 ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B, Di, R, L, 1,
+                 ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B, Di, R, L, 1, 1,
                  stream_ptr())
             dx2 = torch.matmul(Wst.transpose(-1, -2), dP)                        # (2, B, Di, L)
             dWst = torch.einsum("sbcl,sbdl->scd", dP, x2)                        # (2, 2Cp, Di)
@@ -83,8 +83,7 @@ class _SS2DCrossScan(torch.autograd.Function):
             call("nnz_ss2d_merge_dx", ptr(du), ptr(dx2), ptr(dx), int(xdtype == torch.float16), B, Di, H, W,
                  stream_ptr())
             d_xproj = dWst.view(2, 2, Cp, Di).transpose(0, 1).reshape(K, Cp, Di)
-            d_alog = dA * A                                                      # A = -exp(A_log)
-        return dx, d_xproj, dWdt.view(K, Di, R), dbias.view(K, Di), d_alog, dD
+        return dx, d_xproj, dWdt.view(K, Di, R), dbias.view(K, Di), dA, dD    # dA is dA_log (a_is_log)
 
 
 def ss2d_cross_scan(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):

@@ -56,3 +56,29 @@ def test_layer_norm_refuses_cpu():
     from nnuzoo_amd.layer_norm import LayerNorm
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         LayerNorm(16)(torch.zeros(2, 16))
+
+
+@pytest.mark.parametrize("C,zdtype", [(32, torch.float16), (64, torch.float32), (256, torch.float16), (96, torch.float32)])
+def test_layer_norm_gate_matches_torch(hip_lib, C, zdtype):
+    """LN(y) * silu(z) with z a strided half of a wider tensor (the SS2D in_proj output), against torch ops in fp32"""
+    from nnuzoo_amd.layer_norm import layer_norm_gate
+    g = torch.Generator().manual_seed(C)
+    B, H, W = 2, 11, 13
+    y = torch.randn(B, H, W, C, generator=g).cuda().requires_grad_(True)
+    xz = torch.randn(B, H, W, 2 * C, generator=g).to(zdtype).cuda().requires_grad_(True)
+    w = (torch.randn(C, generator=g) * 0.3 + 1).cuda().requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.2).cuda().requires_grad_(True)
+    dout = torch.randn(B, H, W, C, generator=g).cuda()
+    z = xz.chunk(2, dim=-1)[1]
+    out = layer_norm_gate(y, z, w, b, 1e-5)
+    out.backward(dout)
+    got = [out.detach(), y.grad.clone(), xz.grad.float().clone(), w.grad.clone(), b.grad.clone()]
+    for t in (y, xz, w, b):
+        t.grad = None
+    z = xz.float().chunk(2, dim=-1)[1]
+    ref = F.layer_norm(y, (C,), w, b, 1e-5) * F.silu(z)
+    ref.backward(dout)
+    want = [ref.detach(), y.grad, xz.grad.float(), w.grad, b.grad]
+    tols = [1e-5, 1e-4, 1e-4 if zdtype == torch.float32 else 2e-3, 1e-4, 1e-4]
+    for a, r, tol in zip(got, want, tols):
+        assert torch.allclose(a, r, rtol=tol, atol=tol * r.abs().max().item()), (a - r).abs().max().item()
