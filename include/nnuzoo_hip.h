@@ -150,12 +150,20 @@ int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, 
  * a_is_log: A holds A_log [4 Dg][16]; the kernels use A = -exp(A_log) and return dA_log = dA * A (m2net.py:196).
  * chunk_state / grad_state / workspace: nnz_selective_scan_state_floats / _workspace_floats(B, 4 Dg, L).
  * nnz_ss2d_merge: out (B, H, W, Dg) = y0 + y2 + (y1 + y3)^T;  nnz_ss2d_merge_dx: dx (B, Dg, H, W) = du0 + du2 + dx2[0]
- * + (du1 + du3 + dx2[1])^T in x's type. */
+ * + (du1 + du3 + dx2[1])^T in x's type (du may be NULL). */
 int nnz_ss2d_prepare(const void* x, int x_is_f16, float* x2, int Bt, int D, int H, int W, void* stream);
 int nnz_ss2d_merge(const float* y, float* out_tokens, int Bt, int D, int H, int W, void* stream);
 int nnz_ss2d_split(const float* dout_tokens, float* dy2, int Bt, int D, int H, int W, void* stream);
 int nnz_ss2d_merge_dx(const float* du, const float* dx2, void* dx, int dx_is_f16, int Bt, int D, int H, int W,
                       void* stream);
+/* depthwise 3x3 conv (padding 1) + SiLU of the SS2D block (m2net.py:214) reading the token-major half of the in_proj
+ * output in place (rows x_row_stride elements apart, f16 or f32) and writing both scan sources x2 [2][B][D][L] (f32);
+ * backward from the gradient of x2: dx_tokens [B][H][W][D] dense in x's type, dweight [D][9], dbias [D] (may be NULL). */
+int nnz_ss2d_dwconv_silu_forward(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
+                                 const float* bias, float* x2, int Bt, int D, int H, int W, void* stream);
+int nnz_ss2d_dwconv_silu_backward(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
+                                  const float* bias, const float* dx2, void* dx_tokens, float* dweight, float* dbias,
+                                  int Bt, int D, int H, int W, void* stream);
 int nnz_ss2d_scan_forward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
                           const float* delta_bias, float* y, float* chunk_state, float* workspace, int Bt, int Dg, int R,
                           int L, int delta_softplus, int a_is_log, void* stream);

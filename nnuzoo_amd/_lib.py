@@ -92,6 +92,8 @@ SIGNATURES = {
     "nnz_ss2d_merge": [_fp, _fp, _i, _i, _i, _i, _vp],
     "nnz_ss2d_split": [_fp, _fp, _i, _i, _i, _i, _vp],
     "nnz_ss2d_merge_dx": [_fp, _fp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nnz_ss2d_dwconv_silu_forward": [_vp, _i, _l, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
+    "nnz_ss2d_dwconv_silu_backward": [_vp, _i, _l, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp],
     "nnz_ss2d_scan_forward": [_fp] * 9 + [_i, _i, _i, _i, _i, _i, _vp],
     "nnz_ss2d_scan_backward": [_fp] * 16 + [_i, _i, _i, _i, _i, _i, _vp],
     "nnz_layer_norm_gate_forward": [_vp, _i, _fp, _fp, _vp, _i, _l, _fp, _fp, _fp, _l, _i, _f, _vp],

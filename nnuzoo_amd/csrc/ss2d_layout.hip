@@ -5,7 +5,7 @@
 //   prepare  : x (B, D, H, W) f16|f32        -> x2 [2][B][D][L] f32   (row-major tokens | column-major tokens)
 //   merge    : y [B][4][D][L] (per direction, source order) -> out (B, H, W, D) f32 = y0 + y2 + (y1 + y3)^T
 //   split    : dout (B, H, W, D) f32         -> dy2 [2][B][D][L]      (the gradient every direction of a source sees)
-//   merge_dx : du [B][4][D][L] + dx2 [2][B][D][L] -> dx (B, D, H, W) in x's type
+//   merge_dx : du [B][4][D][L] (optional) + dx2 [2][B][D][L] -> dx (B, D, H, W) in x's type
 // All four are tiled transposes through LDS: every global access is a run of >= 16 consecutive floats.
 #include "common.hpp"
 
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void ss2d_merge_dx_kernel(const float* __restr
     float v = 0.f;
     if (h < H && w < W) {
       const long m = (long)w * H + h;
-      v = u1[m] + u3[m] + g1[m];
+      v = g1[m];
+      if (du) v += u1[m] + u3[m];
     }
     tile[tx][ty + i] = v;
   }
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(256) void ss2d_merge_dx_kernel(const float* __restr
     const int h = h0 + ty + i, w = w0 + tx;
     if (h < H && w < W) {
       const long m = (long)h * W + w;
-      dx[plane * L + m] = (T)(tile[ty + i][tx] + u0[m] + u2[m] + g0[m]);
+      float v = tile[ty + i][tx] + g0[m];
+      if (du) v += u0[m] + u2[m];
+      dx[plane * L + m] = (T)v;
     }
   }
 }
@@ -167,7 +170,7 @@ extern "C" int nnz_ss2d_prepare(const void* x, int x_is_f16, float* x2, int Bt, 
 extern "C" int nnz_ss2d_merge_dx(const float* du, const float* dx2, void* dx, int dx_is_f16, int Bt, int D, int H, int W,
                                  void* stream) {
   using namespace nnz;
-  if (!du || !dx2 || !dx || Bt < 1 || D < 1 || H < 1 || W < 1 || (long)Bt * D > 65535) return NNZ_EINVAL;
+  if (!dx2 || !dx || Bt < 1 || D < 1 || H < 1 || W < 1 || (long)Bt * D > 65535) return NNZ_EINVAL;
   const long planes = (long)Bt * D;
   dim3 grid(((H + XT - 1) / XT) * ((W + XT - 1) / XT), (unsigned)planes);
   if (dx_is_f16)

@@ -24,20 +24,96 @@ def supported(x: torch.Tensor, dt_rank: int, d_state: int) -> bool:
         and x.dtype in (torch.float16, torch.float32) and x.shape[0] * x.shape[1] <= 65535
 
 
+def _proj_weight_grad(dP: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """sum_{b,l} dP[s,b,c,l] x2[s,b,d,l].  For long sequences the library GEMM sees a 68 x 32 output with K = 10^5..10^6
+    and runs on ~10 workgroups (1 ms per call at 512^2); cutting L into chunks makes it a batched GEMM over strided
+    views (no copies) plus a small sum."""
+    S, B, C2, L = dP.shape
+    Di = x2.shape[2]
+    nc = 1
+    while nc < 64 and L % (nc * 2) == 0 and L // (nc * 2) >= 4096:
+        nc *= 2
+    if nc == 1:
+        return torch.einsum("sbcl,sbdl->scd", dP, x2)
+    lc = L // nc
+    out = torch.zeros((S, C2, Di), dtype=dP.dtype, device=dP.device)
+    for s_ in range(S):
+        acc = None
+        for b in range(B):
+            a = dP[s_, b].view(C2, nc, lc).transpose(0, 1)                       # (nc, C2, lc), rows L apart
+            x = x2[s_, b].view(Di, nc, lc).permute(1, 2, 0)                      # (nc, lc, Di)
+            part = torch.bmm(a, x)                                              # (nc, C2, Di)
+            acc = part if acc is None else acc + part
+        out[s_] = acc.sum(0)
+    return out
+
+
+class _PrepareFn(torch.autograd.Function):
+    """(B, Di, H, W) f16|f32 -> x2 [2][B][Di][L] f32: row-major and column-major token order (one transposing copy)"""
+
+    @staticmethod
+    def forward(ctx, xc):
+        B, Di, H, W = xc.shape
+        xc = xc.contiguous()
+        x2 = torch.empty((2, B, Di, H * W), dtype=torch.float32, device=xc.device)
+        call("nnz_ss2d_prepare", ptr(xc), int(xc.dtype == torch.float16), ptr(x2), B, Di, H, W, stream_ptr())
+        ctx.meta = (B, Di, H, W, xc.dtype)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        B, Di, H, W, dt = ctx.meta
+        dx2 = dx2.float().contiguous()
+        dx = torch.empty((B, Di, H, W), dtype=dt, device=dx2.device)
+        call("nnz_ss2d_merge_dx", 0, ptr(dx2), ptr(dx), int(dt == torch.float16), B, Di, H, W, stream_ptr())
+        return dx
+
+
+class _DwConvSiluPrepareFn(torch.autograd.Function):
+    """depthwise 3x3 conv + SiLU on the token-major x half of the in_proj output, written straight as x2 (m2net.py:214
+    `self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))` + the layout change of forward_core); csrc/ss2d_dwconv.hip"""
+
+    @staticmethod
+    def forward(ctx, x_tok, weight, bias):
+        from .layer_norm import _row_stride
+        B, H, W, Di = x_tok.shape
+        xs = _row_stride(x_tok)
+        if xs is None or x_tok.data_ptr() % 4:
+            x_tok = x_tok.contiguous()
+            xs = Di
+        w9 = weight.detach().float().reshape(Di, 9)
+        bv = None if bias is None else bias.detach().float()
+        x2 = torch.empty((2, B, Di, H * W), dtype=torch.float32, device=x_tok.device)
+        call("nnz_ss2d_dwconv_silu_forward", ptr(x_tok), int(x_tok.dtype == torch.float16), xs, ptr(w9), ptr(bv), ptr(x2),
+             B, Di, H, W, stream_ptr())
+        ctx.save_for_backward(x_tok, w9, bv)
+        ctx.meta = (B, Di, H, W, xs, weight.shape)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x_tok, w9, bv = ctx.saved_tensors
+        B, Di, H, W, xs, wshape = ctx.meta
+        dx2 = dx2.float().contiguous()
+        dx = torch.empty((B, H, W, Di), dtype=x_tok.dtype, device=dx2.device)
+        dwb = torch.empty(Di * 10, dtype=torch.float32, device=dx2.device)      # [Di][9] weights, then [Di] bias
+        dw, db = dwb[:Di * 9], dwb[Di * 9:]
+        call("nnz_ss2d_dwconv_silu_backward", ptr(x_tok), int(x_tok.dtype == torch.float16), xs, ptr(w9), ptr(bv),
+             ptr(dx2), ptr(dx), ptr(dw), ptr(db), B, Di, H, W, stream_ptr())
+        return dx, dw.view(wshape), (db if bv is not None else None)
+
+
 class _SS2DCrossScan(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+    def forward(ctx, x2, hw, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
         lib = load()
-        B, Di, H, W = xc.shape
-        L, K = H * W, 4
+        H, W = hw
+        _, B, Di, L = x2.shape
+        K = 4
         R = dt_projs_weight.shape[2]
         Cp = R + 2 * N_STATE
-        dev = xc.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        xc = xc.contiguous()
+        f32 = dict(dtype=torch.float32, device=x2.device)
         with torch.autocast("cuda", enabled=False):
-            x2 = torch.empty((2, B, Di, L), **f32)
-            call("nnz_ss2d_prepare", ptr(xc), int(xc.dtype == torch.float16), ptr(x2), B, Di, H, W, stream_ptr())
             # direction k = s + 2j  ->  rows [j*Cp, (j+1)*Cp) of source s's stacked projection weight
             Wst = x_proj_weight.detach().float().view(2, 2, Cp, Di).transpose(0, 1).reshape(2, 1, 2 * Cp, Di)
             P = torch.matmul(Wst, x2)                                            # (2, B, 2Cp, L)
@@ -53,14 +129,14 @@ class _SS2DCrossScan(torch.autograd.Function):
             out = torch.empty((B, H, W, Di), **f32)
             call("nnz_ss2d_merge", ptr(y), ptr(out), B, Di, H, W, stream_ptr())
         ctx.save_for_backward(x2, P, Wst, A, Wdt, bias, Dv, state)
-        ctx.meta = (B, Di, H, W, R, xc.dtype)
+        ctx.meta = (B, Di, H, W, R)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = load()
         x2, P, Wst, A, Wdt, bias, Dv, state = ctx.saved_tensors
-        B, Di, H, W, R, xdtype = ctx.meta
+        B, Di, H, W, R = ctx.meta
         L, K = H * W, 4
         Cp = R + 2 * N_STATE
         f32 = dict(dtype=torch.float32, device=dout.device)
@@ -78,12 +154,11 @@ class _SS2DCrossScan(torch.autograd.Function):
                  ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B, Di, R, L, 1, 1,
                  stream_ptr())
             dx2 = torch.matmul(Wst.transpose(-1, -2), dP)                        # (2, B, Di, L)
-            dWst = torch.einsum("sbcl,sbdl->scd", dP, x2)                        # (2, 2Cp, Di)
-            dx = torch.empty((B, Di, H, W), dtype=xdtype, device=dout.device)
-            call("nnz_ss2d_merge_dx", ptr(du), ptr(dx2), ptr(dx), int(xdtype == torch.float16), B, Di, H, W,
-                 stream_ptr())
+            # + the scans' own input gradients: direction k = 2j + s belongs to source s
+            dx2 += du.view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
+            dWst = _proj_weight_grad(dP, x2)                                     # (2, 2Cp, Di)
             d_xproj = dWst.view(2, 2, Cp, Di).transpose(0, 1).reshape(K, Cp, Di)
-        return dx, d_xproj, dWdt.view(K, Di, R), dbias.view(K, Di), dA, dD    # dA is dA_log (a_is_log)
+        return dx2, None, d_xproj, dWdt.view(K, Di, R), dbias.view(K, Di), dA, dD    # dA is dA_log (a_is_log)
 
 
 def ss2d_cross_scan(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
@@ -91,4 +166,20 @@ def ss2d_cross_scan(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, D
     in token-major layout (what SS2D.forward feeds to out_norm)."""
     if not xc.is_cuda:
         raise RuntimeError("ss2d_cross_scan runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
-    return _SS2DCrossScan.apply(xc, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+    H, W = xc.shape[2:]
+    return _SS2DCrossScan.apply(_PrepareFn.apply(xc), (H, W), x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+
+
+def dwconv_supported(conv: torch.nn.Conv2d) -> bool:
+    return conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1) and conv.dilation == (1, 1) \
+        and conv.groups == conv.in_channels == conv.out_channels and conv.padding_mode == "zeros"
+
+
+def ss2d_conv_cross_scan(x_tok, conv, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+    """x_tok: (B, H, W, Di) token-major x half of the in_proj output (a strided view is read in place); applies the block's
+    depthwise 3x3 conv + SiLU and the four-direction scan -> (B, H, W, Di) fp32."""
+    if not x_tok.is_cuda:
+        raise RuntimeError("ss2d_conv_cross_scan runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
+    H, W = x_tok.shape[1:3]
+    x2 = _DwConvSiluPrepareFn.apply(x_tok, conv.weight, conv.bias)
+    return _SS2DCrossScan.apply(x2, (H, W), x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)

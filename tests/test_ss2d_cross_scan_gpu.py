@@ -8,18 +8,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(block, x, dy, fused, autocast=False):
+def _run(block, x, dy, fused, autocast=False, dwconv=True):
     from nnuzoo_amd.nets.m2net import SS2D
     block.zero_grad(set_to_none=True)
-    old = SS2D.fused_cross_scan
-    SS2D.fused_cross_scan = fused
+    old, old_dw = SS2D.fused_cross_scan, SS2D.fused_dwconv
+    SS2D.fused_cross_scan, SS2D.fused_dwconv = fused, dwconv
     try:
         xi = x.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
             y = block(xi)
         y.float().backward(dy)
     finally:
-        SS2D.fused_cross_scan = old
+        SS2D.fused_cross_scan, SS2D.fused_dwconv = old, old_dw
     grads = {n: p.grad.clone() for n, p in block.named_parameters() if p.grad is not None}
     return y.detach().float(), xi.grad.clone(), grads
 
@@ -31,7 +31,7 @@ def _close(a, b, tol, what):
 
 
 @pytest.mark.parametrize("d_model,B,H,W", [(16, 2, 24, 40), (16, 1, 13, 9), (32, 2, 16, 16), (64, 1, 20, 12),
-                                           (128, 2, 8, 8), (16, 1, 64, 48)])
+                                           (128, 2, 8, 8), (16, 1, 64, 48), (16, 2, 128, 64)])
 def test_fused_core_matches_composed_fp32(hip_lib, d_model, B, H, W):
     from nnuzoo_amd.nets.m2net import SS2D
     torch.manual_seed(d_model + H)
@@ -40,12 +40,13 @@ def test_fused_core_matches_composed_fp32(hip_lib, d_model, B, H, W):
     x = torch.randn(B, H, W, d_model, generator=g).cuda()
     dy = torch.randn(B, H, W, d_model, generator=g).cuda()
     y0, dx0, g0 = _run(blk, x, dy, fused=False)
-    y1, dx1, g1 = _run(blk, x, dy, fused=True)
-    _close(y1, y0, 1e-4, "y")
-    _close(dx1, dx0, 2e-3, "dx")
-    assert set(g0) == set(g1)
-    for n in g0:
-        _close(g1[n], g0[n], 2e-3, n)
+    for dwconv in (False, True):       # library conv + fused scan | conv + SiLU + layouts fused too
+        y1, dx1, g1 = _run(blk, x, dy, fused=True, dwconv=dwconv)
+        _close(y1, y0, 1e-4, "y")
+        _close(dx1, dx0, 2e-3, "dx")
+        assert set(g0) == set(g1)
+        for n in g0:
+            _close(g1[n], g0[n], 2e-3, n)
 
 
 def test_fused_core_under_autocast(hip_lib):
