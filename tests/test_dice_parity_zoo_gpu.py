@@ -1,0 +1,20 @@
+"""Dice within +-0.01 for the SS2D^2Net path (BASELINE.json north_star): M2NetP trained twice on the GPU from the same
+seeded weights on the same synthetic batches - fused SS2D block + HIP LayerNorm (product path) vs the reference's op-by-op
+formulation of the block (pinned to the reference by tests/golden) - compared by foreground Dice on held-out patches."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_m2netp_dice_within_one_percent(hip_lib):
+    from dice_parity_zoo import run
+    r = run("M2NetP", size=128, steps=80, heldout=16)
+    print(r)
+    assert r["dice_reference_formulation"] > 0.5, "the synthetic task must be learnt for the comparison to mean anything"
+    assert r["abs_delta"] <= 0.01
+    assert r["mask_agreement"] >= 0.95
