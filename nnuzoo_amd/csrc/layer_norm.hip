@@ -13,10 +13,10 @@ struct LnArgs {
   const void* x;      // [R][C] f16 or f32
   const float* gamma; // [C] or null
   const float* beta;  // [C] or null
-  float* y;           // [R][C] f32                 (forward)
+  void* y;            // [R][C] f32, or f16 when y_is_f16 (the consumer is an autocast Linear: same rounding, no cast pass)
   float* mean;        // [R]
   float* rstd;        // [R]
-  const float* dy;    // [R][C] f32                 (backward)
+  const void* dy;     // [R][C] f32 or f16 (dy_is_f16)
   void* dx;           // [R][C] same type as x
   float* dgamma;      // [C] atomic, zeroed by the launcher; may be null
   float* dbeta;
@@ -29,6 +29,7 @@ struct LnArgs {
   void* dz;
   long z_stride;
   int z_is_f16;
+  int y_is_f16, dy_is_f16;
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
       }
     }
     const float rs = 1.f / sqrtf(group_sum<LPR>(ss) * invC + a.eps);
-    float* yr = a.y + r * C;
+    const long yo = r * C;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = 4 * (q + LPR * i);
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] *= silu_f(zv[e]);
         }
-        st4(yr + c, o);
+        if (a.y_is_f16) st4((f16*)a.y + yo + c, o);
+        else st4((float*)a.y + yo + c, o);
       }
     }
     if (q == 0) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
   }
   for (long r = (long)blockIdx.x * GPW + g; r < a.R; r += (long)gridDim.x * GPW) {
     const T* xr = (const T*)a.x + r * C;
-    const float* dyr = a.dy + r * C;
+    const long dyo = r * C;
     const float mu = a.mean[r], rs = a.rstd[r];
     f32x4 xh[IT], gy[IT];
     float s1 = 0.f, s2 = 0.f;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
       const int c = 4 * (q + LPR * i);
       if (c < C) {
         const f32x4 xv = ld4(xr + c);
-        f32x4 dv = ld4(dyr + c);
+        f32x4 dv = a.dy_is_f16 ? ld4((const f16*)a.dy + dyo + c) : ld4((const float*)a.dy + dyo + c);
         if (a.z) {
           // out = n * silu(z), n = xhat * gamma + beta:  dn = dout * silu(z);  dz = dout * n * silu'(z)
           const f32x4 zv = ldz(a, r, c);
@@ -241,20 +243,21 @@ static int ln_dispatch(const LnArgs& a, bool bwd, hipStream_t s) {
 }  // namespace nnz
 
 static int ln_forward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
-                           int z_is_f16, long z_stride, float* y, float* mean, float* rstd, long rows, int C, float eps,
-                           void* stream) {
+                           int z_is_f16, long z_stride, void* y, int y_is_f16, float* mean, float* rstd, long rows, int C,
+                           float eps, void* stream) {
   using namespace nnz;
   if (!x || !y || !mean || !rstd || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (z_stride & 3))) return NNZ_EINVAL;
   if (rows == 0) return NNZ_OK;
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.R = rows; a.C = C; a.eps = eps;
-  a.z = z; a.z_is_f16 = z_is_f16; a.z_stride = z_stride;
+  a.z = z; a.z_is_f16 = z_is_f16; a.z_stride = z_stride; a.y_is_f16 = y_is_f16;
   return x_is_f16 ? ln_dispatch<f16>(a, false, (hipStream_t)stream) : ln_dispatch<float>(a, false, (hipStream_t)stream);
 }
 
 static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
-                            int z_is_f16, long z_stride, const float* mean, const float* rstd, const float* dy, void* dx,
-                            void* dz, float* dgamma, float* dbeta, long rows, int C, void* stream) {
+                            int z_is_f16, long z_stride, const float* mean, const float* rstd, const void* dy,
+                            int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, long rows, int C,
+                            void* stream) {
   using namespace nnz;
   if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (!dz || (z_stride & 3))))
     return NNZ_EINVAL;
@@ -270,34 +273,36 @@ static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, con
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx;
   a.dgamma = dgamma; a.dbeta = dbeta; a.R = rows; a.C = C;
-  a.z = z; a.dz = dz; a.z_is_f16 = z_is_f16; a.z_stride = z_stride;
+  a.z = z; a.dz = dz; a.z_is_f16 = z_is_f16; a.z_stride = z_stride; a.dy_is_f16 = dy_is_f16;
   return x_is_f16 ? ln_dispatch<f16>(a, true, s) : ln_dispatch<float>(a, true, s);
 }
 
 extern "C" int nnz_layer_norm_gate_forward(const void* x, int x_is_f16, const float* gamma, const float* beta,
-                                           const void* z, int z_is_f16, long z_row_stride, float* y, float* mean,
-                                           float* rstd, long rows, int C, float eps, void* stream) {
+                                           const void* z, int z_is_f16, long z_row_stride, void* y, int y_is_f16,
+                                           float* mean, float* rstd, long rows, int C, float eps, void* stream) {
   if (!z) return NNZ_EINVAL;
-  return ln_forward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, y, mean, rstd, rows, C, eps, stream);
+  return ln_forward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, y, y_is_f16, mean, rstd, rows, C, eps,
+                         stream);
 }
 
 extern "C" int nnz_layer_norm_gate_backward(const void* x, int x_is_f16, const float* gamma, const float* beta,
                                             const void* z, int z_is_f16, long z_row_stride, const float* mean,
-                                            const float* rstd, const float* dy, void* dx, void* dz, float* dgamma,
-                                            float* dbeta, long rows, int C, void* stream) {
+                                            const float* rstd, const void* dy, int dy_is_f16, void* dx, void* dz,
+                                            float* dgamma, float* dbeta, long rows, int C, void* stream) {
   if (!z) return NNZ_EINVAL;
-  return ln_backward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, mean, rstd, dy, dx, dz, dgamma, dbeta,
-                          rows, C, stream);
+  return ln_backward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, mean, rstd, dy, dy_is_f16, dx, dz, dgamma,
+                          dbeta, rows, C, stream);
 }
 
-extern "C" int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, float* y,
-                                      float* mean, float* rstd, long rows, int C, float eps, void* stream) {
-  return ln_forward_impl(x, x_is_f16, gamma, beta, nullptr, 0, 0, y, mean, rstd, rows, C, eps, stream);
+extern "C" int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, void* y,
+                                      int y_is_f16, float* mean, float* rstd, long rows, int C, float eps,
+                                      void* stream) {
+  return ln_forward_impl(x, x_is_f16, gamma, beta, nullptr, 0, 0, y, y_is_f16, mean, rstd, rows, C, eps, stream);
 }
 
 extern "C" int nnz_layer_norm_backward(const void* x, int x_is_f16, const float* gamma, const float* mean,
-                                       const float* rstd, const float* dy, void* dx, float* dgamma, float* dbeta,
-                                       long rows, int C, void* stream) {
-  return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dx, nullptr, dgamma, dbeta, rows, C,
-                          stream);
+                                       const float* rstd, const void* dy, int dy_is_f16, void* dx, float* dgamma,
+                                       float* dbeta, long rows, int C, void* stream) {
+  return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dy_is_f16, dx, nullptr, dgamma,
+                          dbeta, rows, C, stream);
 }

@@ -11,32 +11,37 @@ from torch import nn
 from ._lib import call, ptr, stream_ptr
 
 
+def _dy(dy: torch.Tensor) -> torch.Tensor:
+    """the kernels read f32 or f16 gradients in place"""
+    return (dy if dy.dtype in (torch.float16, torch.float32) else dy.float()).contiguous()
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, out_dtype):
         C = x.shape[-1]
         xc = x.contiguous()
         rows = xc.numel() // C
-        y = torch.empty(xc.shape, dtype=torch.float32, device=x.device)
+        half = out_dtype == torch.float16
+        y = torch.empty(xc.shape, dtype=torch.float16 if half else torch.float32, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        call("nnz_layer_norm_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(y),
+        call("nnz_layer_norm_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(y), int(half),
              ptr(mean), ptr(rstd), rows, C, float(eps), stream_ptr())
         ctx.save_for_backward(xc, weight, mean, rstd)
         ctx.has_bias = bias is not None
-        ctx.out_dtype = out_dtype
-        return y if out_dtype == torch.float32 else y.to(out_dtype)
+        return y if out_dtype in (torch.float32, torch.float16) else y.to(out_dtype)
 
     @staticmethod
     def backward(ctx, dy):
         xc, weight, mean, rstd = ctx.saved_tensors
         C = xc.shape[-1]
         rows = xc.numel() // C
-        dy = dy.float().contiguous()
+        dy = _dy(dy)
         dx = torch.empty_like(xc)
         dw, db = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, xc.device)
         call("nnz_layer_norm_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
-             ptr(dy), ptr(dx), ptr(dw), ptr(db), rows, C, stream_ptr())
+             ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), rows, C, stream_ptr())
         return dx, dw, db, None, None
 
 
@@ -68,7 +73,7 @@ class _LayerNormGateFn(torch.autograd.Function):
     """LayerNorm(x) * silu(z) (SS2D's gated output norm) in one pass each way"""
 
     @staticmethod
-    def forward(ctx, x, z, weight, bias, eps):
+    def forward(ctx, x, z, weight, bias, eps, half_out):
         C = x.shape[-1]
         xc = x.contiguous()
         rows = xc.numel() // C
@@ -76,11 +81,12 @@ class _LayerNormGateFn(torch.autograd.Function):
         if zs is None or zs % 4 or z.data_ptr() % 8:
             z = z.contiguous()
             zs = C
-        y = torch.empty(xc.shape, dtype=torch.float32, device=x.device)
+        y = torch.empty(xc.shape, dtype=torch.float16 if half_out else torch.float32, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         call("nnz_layer_norm_gate_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
-             int(z.dtype == torch.float16), zs, ptr(y), ptr(mean), ptr(rstd), rows, C, float(eps), stream_ptr())
+             int(z.dtype == torch.float16), zs, ptr(y), int(half_out), ptr(mean), ptr(rstd), rows, C, float(eps),
+             stream_ptr())
         ctx.save_for_backward(xc, z, weight, bias, mean, rstd)
         ctx.zs = zs
         return y
@@ -90,18 +96,26 @@ class _LayerNormGateFn(torch.autograd.Function):
         xc, z, weight, bias, mean, rstd = ctx.saved_tensors
         C = xc.shape[-1]
         rows = xc.numel() // C
-        dy = dy.float().contiguous()
+        dy = _dy(dy)
         dx = torch.empty_like(xc)
         dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
         dw, db = _affine_grads(weight, bias is not None, ctx.needs_input_grad[2], ctx.needs_input_grad[3], C, xc.device)
         call("nnz_layer_norm_gate_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
-             int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), ptr(dx), ptr(dz), ptr(dw), ptr(db),
-             rows, C, stream_ptr())
-        return dx, dz, dw, db, None
+             int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), int(dy.dtype == torch.float16),
+             ptr(dx), ptr(dz), ptr(dw), ptr(db), rows, C, stream_ptr())
+        return dx, dz, dw, db, None, None
 
 
-def layer_norm_gate(x: torch.Tensor, z: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor:
-    """F.layer_norm(x, (C,), weight, bias, eps) * F.silu(z) -> fp32, one kernel each way (no CPU path)"""
+def _half_for_linear(flag: bool) -> bool:
+    """write fp16 when the only consumer is a Linear under fp16 autocast: that Linear would round the same fp32 value to
+    fp16 itself, so the numbers are identical and a cast pass (and its backward) disappears"""
+    return bool(flag) and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16
+
+
+def layer_norm_gate(x: torch.Tensor, z: torch.Tensor, weight, bias, eps: float = 1e-5,
+                    feeds_linear: bool = False) -> torch.Tensor:
+    """F.layer_norm(x, (C,), weight, bias, eps) * F.silu(z) -> fp32 (fp16 under autocast when `feeds_linear`), one kernel
+    each way (no CPU path)"""
     if not x.is_cuda:
         raise RuntimeError("nnuzoo_amd.layer_norm runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
     C = x.shape[-1]
@@ -109,10 +123,10 @@ def layer_norm_gate(x: torch.Tensor, z: torch.Tensor, weight, bias, eps: float =
             z.dtype not in (torch.float16, torch.float32) or (weight is not None and weight.dtype != torch.float32):
         raise NotImplementedError(f"layer_norm_gate kernel: C % 4 == 0, C <= 2048, fp16/fp32 x and z of one shape "
                                   f"(got C={C}, {x.dtype}, {z.dtype})")
-    return _LayerNormGateFn.apply(x, z, weight, bias, eps)
+    return _LayerNormGateFn.apply(x, z, weight, bias, eps, _half_for_linear(feeds_linear))
 
 
-def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor:
+def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5, feeds_linear: bool = False) -> torch.Tensor:
     """F.layer_norm(x, (C,), weight, bias, eps) over the last dimension on the HIP kernel (no CPU path)."""
     if not x.is_cuda:
         raise RuntimeError("nnuzoo_amd.layer_norm runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
@@ -123,13 +137,17 @@ def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5) -> torch.Tensor
                                   f"(got C={C}, {x.dtype})")
     # torch semantics: fp32 result under autocast (layer_norm is on the fp32 list), else the input's type
     out_dtype = torch.float32 if (torch.is_autocast_enabled() or x.dtype == torch.float32) else x.dtype
+    if _half_for_linear(feeds_linear):
+        out_dtype = torch.float16
     return _LayerNormFn.apply(x, weight, bias, eps, out_dtype)
 
 
 class LayerNorm(nn.LayerNorm):
-    """drop-in for nn.LayerNorm (normalised shape = the last dimension)"""
+    """drop-in for nn.LayerNorm (normalised shape = the last dimension).  `feeds_linear` (set by the owning block when the
+    output goes into an nn.Linear and nowhere else) lets the kernel write fp16 under fp16 autocast."""
+    feeds_linear = False
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if len(self.normalized_shape) != 1:
             raise NotImplementedError("nnuzoo_amd.LayerNorm normalises the last dimension only")
-        return layer_norm(x, self.weight, self.bias, self.eps)
+        return layer_norm(x, self.weight, self.bias, self.eps, self.feeds_linear)

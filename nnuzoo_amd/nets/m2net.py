@@ -138,13 +138,15 @@ class SS2D(nn.Module):
             # gated output norm in one kernel (nnuzoo_amd/ss2d_scan.py, layer_norm.py)
             y = ss2d_scan.ss2d_conv_cross_scan(x, self.conv2d, self.x_proj_weight, self.dt_projs_weight,
                                                self.dt_projs_bias, self.A_logs, self.Ds)
-            y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)   # LN(y) * silu(z)
+            y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps,
+                                feeds_linear=True)                      # LN(y) * silu(z) -> out_proj
         else:
             x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
             if fused:
                 y = ss2d_scan.ss2d_cross_scan(x, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                                               self.A_logs, self.Ds)
-                y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+                y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps,
+                                    feeds_linear=True)
             else:
                 y1, y2, y3, y4 = self.forward_core(x)
                 y = (y1 + y2 + y3 + y4).transpose(1, 2).reshape(B, H, W, -1)
@@ -158,6 +160,8 @@ class VSSBlock(nn.Module):
                  d_state: int = 16, **kwargs):
         super().__init__()
         self.ln_1 = norm_layer(hidden_dim)
+        if isinstance(self.ln_1, LayerNorm):
+            self.ln_1.feeds_linear = True     # its only consumer is SS2D.in_proj
         self.self_attention = SS2D(d_model=hidden_dim, dropout=attn_drop_rate, d_state=d_state, **kwargs)
         self.drop_path = DropPath(drop_path)
 

@@ -102,7 +102,8 @@ class SSND(nn.Module):
                 y = ss2d_scan.ss2d_conv_cross_scan(x, conv, *args)
             else:                                                   # dilated depthwise conv: library conv in front
                 y = ss2d_scan.ss2d_cross_scan(self.act(self.convnd(x.permute(0, 3, 1, 2).contiguous())), *args)
-            y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+            y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps,
+                                feeds_linear=True)
             out = self.out_proj(y)
             return self.dropout(out) if self.dropout is not None else out
         perm = (0, 3, 1, 2) if self.spatial_dims == 2 else (0, 4, 1, 2, 3)

@@ -238,6 +238,8 @@ class VSSBlock(nn.Module):
         super().__init__()
         self.spatial_dims = spatial_dims
         self.ln_1 = norm_layer(hidden_dim)
+        if isinstance(self.ln_1, LayerNorm):
+            self.ln_1.feeds_linear = True     # its only consumer is SSND.in_proj
         self.gsc = GSC(spatial_dims=spatial_dims, in_channels=hidden_dim)
         self.self_attention = SSND(spatial_dims=spatial_dims, factorization_type=factorization_type, d_model=hidden_dim,
                                    dropout=attn_drop_rate, d_state=d_state, dilation=dilation, **kwargs)

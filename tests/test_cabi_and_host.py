@@ -98,3 +98,29 @@ def test_product_paths_refuse_cpu_tensors():
                           weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         loss(torch.zeros(1, 2, 4, 4), torch.zeros(1, 1, 4, 4, dtype=torch.int16))
+
+
+def test_row_stride_of_token_major_views():
+    """host logic of the in-place readers (gated LayerNorm's z, the fused depthwise conv's x): both halves of the SS2D
+    in_proj output are row-strided views; anything that is not such a view is reported so the caller copies"""
+    import torch
+    from nnuzoo_amd.layer_norm import _row_stride
+    xz = torch.zeros(2, 5, 7, 24)
+    x, z = xz.chunk(2, dim=-1)
+    assert _row_stride(x) == 24 and _row_stride(z) == 24 and _row_stride(xz) == 24
+    assert _row_stride(torch.zeros(3, 8)) == 8
+    assert _row_stride(xz.permute(0, 2, 1, 3)) is None          # rows no longer uniformly spaced
+    assert _row_stride(xz.transpose(-1, -2)) is None            # last dimension strided
+    assert _row_stride(xz[:, :, ::2]) is None
+
+
+def test_projection_weight_gradient_chunking_matches_einsum():
+    """the chunked batched-GEMM form used for long sequences (nnuzoo_amd/ss2d_scan.py) is the same contraction"""
+    import torch
+    from nnuzoo_amd.ss2d_scan import _proj_weight_grad
+    g = torch.Generator().manual_seed(0)
+    for L in (8192 * 2, 4096, 8192 * 8):
+        dP = torch.randn(2, 2, 5, L, generator=g, dtype=torch.float64)
+        x2 = torch.randn(2, 2, 3, L, generator=g, dtype=torch.float64)
+        ref = torch.einsum("sbcl,sbdl->scd", dP, x2)
+        assert torch.allclose(_proj_weight_grad(dP, x2), ref, rtol=1e-10, atol=1e-9)

@@ -82,3 +82,39 @@ def test_layer_norm_gate_matches_torch(hip_lib, C, zdtype):
     tols = [1e-5, 1e-4, 1e-4 if zdtype == torch.float32 else 2e-3, 1e-4, 1e-4]
     for a, r, tol in zip(got, want, tols):
         assert torch.allclose(a, r, rtol=tol, atol=tol * r.abs().max().item()), (a - r).abs().max().item()
+
+
+def test_layer_norm_half_output_for_linear_consumers(hip_lib):
+    """feeds_linear: under fp16 autocast the kernel writes fp16 (what the consuming Linear's own cast would produce) and
+    reads the fp16 gradient that Linear returns; outside autocast nothing changes"""
+    from nnuzoo_amd.layer_norm import LayerNorm, layer_norm_gate
+    g = torch.Generator().manual_seed(9)
+    C = 64
+    x = torch.randn(2, 9, 7, C, generator=g).cuda()
+    ln = LayerNorm(C).cuda()
+    ln.feeds_linear = True
+    lin = torch.nn.Linear(C, 24).cuda()
+    assert ln(x).dtype == torch.float32
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = ln(xa)
+        out = lin(y)
+    assert y.dtype == torch.float16
+    out.float().sum().backward()
+    xr = x.clone().requires_grad_(True)
+    w, b = ln.weight.detach().clone().requires_grad_(True), ln.bias.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        yr = F.layer_norm(xr, (C,), w, b, 1e-5)
+        outr = lin(yr)
+    outr.float().sum().backward()
+    assert torch.allclose(y.float(), yr.half().float(), rtol=2e-3, atol=2e-3)
+    assert torch.allclose(out.float(), outr.float(), rtol=1e-2, atol=1e-2)
+    assert torch.allclose(xa.grad, xr.grad, rtol=1e-2, atol=1e-2 * xr.grad.abs().max().item())
+    assert torch.allclose(ln.weight.grad, w.grad, rtol=1e-2, atol=1e-2 * w.grad.abs().max().item())
+    # gated variant
+    z = torch.randn(2, 9, 7, C, generator=g).cuda().half()
+    with torch.autocast("cuda", dtype=torch.float16):
+        yg = layer_norm_gate(x, z, ln.weight, ln.bias, 1e-5, feeds_linear=True)
+    assert yg.dtype == torch.float16
+    ref = F.layer_norm(x, (C,), ln.weight, ln.bias, 1e-5) * F.silu(z.float())
+    assert torch.allclose(yg.float(), ref, rtol=2e-3, atol=2e-3)
