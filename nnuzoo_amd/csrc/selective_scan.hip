@@ -90,19 +90,52 @@ __device__ __forceinline__ void wave_scan_affine(float& a, float& b) {
 #undef NNZ_STEP
 }
 
-// inclusive SUFFIX scan (higher lanes applied first): lane l gets F_l o F_{l+1} o ... o F_63
+// inclusive SUFFIX scan (higher lanes applied first): lane l gets F_l o F_{l+1} o ... o F_63.
+// DPP only (the first version used 12 ds_bpermute shuffles per call, whose LDS round trips were the dependent chain of the
+// backward's state loop): row_shl 1/2/4/8 inside the 16-lane rows, then the rows' totals (lanes 16, 32, 48) are read
+// with v_readlane and composed as wave-uniform values - there is no downward row broadcast in DPP.
 __device__ __forceinline__ void wave_rscan_affine(float& a, float& b, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    float pa = __shfl_down(a, off, 64);
-    float pb = __shfl_down(b, off, 64);
-    if (lane + off >= 64) {
-      pa = 1.f;
-      pb = 0.f;
-    }
-    b = a * pb + b;
-    a = a * pa;
+#define NNZ_RSTEP(CTRL)                            \
+  {                                                \
+    const float pa = dpp<CTRL, 0xF>(1.f, a);       \
+    const float pb = dpp<CTRL, 0xF>(0.f, b);       \
+    b = a * pb + b;                                \
+    a = a * pa;                                    \
   }
+  NNZ_RSTEP(0x101)  // row_shl:1
+  NNZ_RSTEP(0x102)  // row_shl:2
+  NNZ_RSTEP(0x104)  // row_shl:4
+  NNZ_RSTEP(0x108)  // row_shl:8
+#undef NNZ_RSTEP
+  const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 16));
+  const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 16));
+  const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 32));
+  const float b2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 32));
+  const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 48));
+  const float b3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 48));
+  // what follows each row: U2 = T3, U1 = T2 o T3, U0 = T1 o T2 o T3 (T_r = total of row r)
+  const float u1a = a2 * a3, u1b = a2 * b3 + b2;
+  const float u0a = a1 * u1a, u0b = a1 * u1b + b1;
+  const int row = lane >> 4;
+  const float ua = row == 0 ? u0a : row == 1 ? u1a : row == 2 ? a3 : 1.f;
+  const float ub = row == 0 ? u0b : row == 1 ? u1b : row == 2 ? b3 : 0.f;
+  b = a * ub + b;
+  a = a * ua;
+}
+
+// value of the previous / next lane (wave_shr:1 / wave_shl:1); lane 0 / lane 63 receive `edge`
+__device__ __forceinline__ float lane_prev(float v, float edge) { return dpp<0x138, 0xF>(edge, v); }
+__device__ __forceinline__ float lane_next(float v, float edge) { return dpp<0x130, 0xF>(edge, v); }
+
+// wave-wide sum by DPP (row_shr 1/2/4/8 + row_bcast15/31): the total arrives in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp<0x111, 0xF>(0.f, v);
+  v += dpp<0x112, 0xF>(0.f, v);
+  v += dpp<0x114, 0xF>(0.f, v);
+  v += dpp<0x118, 0xF>(0.f, v);
+  v += dpp<0x142, 0xA>(0.f, v);
+  v += dpp<0x143, 0xC>(0.f, v);
+  return v;
 }
 
 // softplus(x) = max(x, 0) + log1p(exp(-|x|)); log1p by its series for tiny arguments (keeps relative accuracy
@@ -315,11 +348,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_fwd_kernel(ScanArgs a) {
           a.S[(row * SS_N + n) * a.nchunks + c] = pb;
         }
       } else {
-        float ea = __shfl_up(pa, 1, 64), eb = __shfl_up(pb, 1, 64);
-        if (lane == 0) {
-          ea = 1.f;
-          eb = 0.f;
-        }
+        const float ea = lane_prev(pa, 1.f), eb = lane_prev(pb, 0.f);  // lane 0: identity
         float h = ea * sw[wave][16 + n] + eb;
         const f32x4 Cv = *reinterpret_cast<const f32x4*>(sC + n * SS_CL + lane * SS_KI);
 #pragma unroll
@@ -495,11 +524,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
         pa *= ai[i];
       }
       wave_scan_affine(pa, pb);
-      float ea = __shfl_up(pa, 1, 64), eb = __shfl_up(pb, 1, 64);
-      if (lane == 0) {
-        ea = 1.f;
-        eb = 0.f;
-      }
+      const float ea = lane_prev(pa, 1.f), eb = lane_prev(pb, 0.f);  // lane 0: identity
       float hprev[SS_KI], hcur[SS_KI];
       float h = ea * hin[n] + eb;
 #pragma unroll
@@ -510,11 +535,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
       }
       // ---- reverse scan of g -------------------------------------------------------------------------------
       wave_rscan_affine(ra, rb, lane);
-      float xa = __shfl_down(ra, 1, 64), xb = __shfl_down(rb, 1, 64);
-      if (lane == 63) {
-        xa = 1.f;
-        xb = 0.f;
-      }
+      const float xa = lane_next(ra, 1.f), xb = lane_next(rb, 0.f);  // lane 63: identity
       float g = xa * gin[n] + xb;  // g of the first item of lane+1 (or of the next chunk)
       float dAn = 0.f;
       float dBv[SS_KI], dCv[SS_KI];
@@ -542,8 +563,8 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
       }
       // per-(row, chunk) partial of dA goes to the (now free) summary workspace with a plain store; a finalize
       // kernel sums over chunks and batch: no contended atomic (and no vector-memory wait) inside this loop
-      dAn = wave_sum(dAn);
-      if (lane == 0) a.P[(row * SS_N + n) * a.nchunks + c] = dAn;
+      dAn = wave_sum_to_lane63(dAn);
+      if (lane == 63) a.P[(row * SS_N + n) * a.nchunks + c] = dAn;
       __syncthreads();  // keeps the waves' skewed n-order disjoint (all waves run the same trip counts)
     }
     if (FINAL) {

@@ -41,3 +41,39 @@ for B, KD, L in SHAPES:
     fb = 4 * (3 * B * KD * L + 2 * B * K * N * L)
     bb = 4 * (5 * B * KD * L + 4 * B * K * N * L)
     print(f"({B},{KD},{L}): fwd {tf:8.3f} ms {fb/tf/1e6:8.1f} GB/s | bwd {tb:8.3f} ms {bb/tb/1e6:8.1f} GB/s", flush=True)
+
+# ---- cross-scan mode (the fused SS2D core): the C-ABI scan alone on M2Net's (B, Di, H, W) shapes -------------------------
+# algorithmic bytes: fwd reads x2 once per source (2 B D L) and P (2 B 2Cp L), writes y (B 4D L); bwd reads x2, P, dy2,
+# writes du (B 4D L) and dP.  state-updates = B * 4 D * 16 * L per pass.
+from nnuzoo_amd._lib import call, load, ptr, stream_ptr
+
+print("# cross-scan mode (nnz_ss2d_scan_forward / _backward), B=2: ms, algorithmic GB/s, G state-updates/s")
+lib = load()
+for Di, H in [(32, 512), (64, 256), (32, 256), (128, 128), (256, 64), (256, 32), (32, 16)]:
+    B, W, R, N = 2, H, max(1, Di // 32), 16
+    L, Cp, K = H * W, R + 32, 4
+    f = dict(device="cuda", dtype=torch.float32)
+    x2 = torch.randn(2, B, Di, L, **f)
+    P = torch.randn(2, B, 2 * Cp, L, **f) * 0.5
+    Wdt = torch.randn(K * Di, R, **f) * 0.3
+    Alog = torch.randn(K * Di, N, **f) * 0.3
+    Dv, bias = torch.randn(K * Di, **f), torch.randn(K * Di, **f)
+    y, du = torch.empty(B, K * Di, L, **f), torch.empty(B, K * Di, L, **f)
+    dy2 = torch.randn(2, B, Di, L, **f)
+    dP = torch.empty_like(P)
+    dWdt, dA, dD, dbias = torch.empty_like(Wdt), torch.empty_like(Alog), torch.empty_like(Dv), torch.empty_like(bias)
+    state = torch.empty(lib.nnz_selective_scan_state_floats(B, K * Di, L), **f)
+    gstate = torch.empty_like(state)
+    ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f)
+    fwd = lambda: call("nnz_ss2d_scan_forward", ptr(x2), ptr(P), ptr(Wdt), ptr(Alog), ptr(Dv), ptr(bias), ptr(y),
+                       ptr(state), ptr(ws), B, Di, R, L, 1, 1, stream_ptr())
+    bwd = lambda: call("nnz_ss2d_scan_backward", ptr(x2), ptr(P), ptr(Wdt), ptr(Alog), ptr(Dv), ptr(bias), ptr(dy2),
+                       ptr(state), ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B,
+                       Di, R, L, 1, 1, stream_ptr())
+    tf = t(fwd)
+    tb = t(bwd)
+    fb = 4 * B * L * (2 * Di + 2 * 2 * Cp + 4 * Di)
+    bb = 4 * B * L * (2 * Di + 2 * 2 * Cp + 2 * Di + 4 * Di + 2 * 2 * Cp)
+    su = B * K * Di * N * L
+    print(f"Di={Di:4d} {H}x{W}: fwd {tf:7.3f} ms {fb/tf/1e6:7.1f} GB/s {su/tf/1e6:7.1f} Gsu/s | "
+          f"bwd {tb:7.3f} ms {bb/tb/1e6:7.1f} GB/s {su/tb/1e6:7.1f} Gsu/s", flush=True)
