@@ -54,7 +54,12 @@ def cpu_baseline(edge: int = 64):
         opt.step()
         return float(l)
 
-    step(64)  # thread-pool / allocator warm-up (64^3 is the smallest cube the 6-stage net accepts in training)
+    # thread-pool / allocator warm-up on a few small convolutions: a full warm-up step would double the ~100 s this
+    # sample takes (64^3 is the smallest cube the 6-stage net accepts in training); primitive set-up is < 2 % of the step
+    with torch.no_grad():
+        w = torch.randn(32, 32, 3, 3, 3)
+        for _ in range(3):
+            torch.nn.functional.conv3d(torch.randn(1, 32, 32, 32, 32), w, padding=1)
     t0 = time.perf_counter()
     step(edge)
     dt = time.perf_counter() - t0

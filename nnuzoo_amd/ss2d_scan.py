@@ -19,11 +19,6 @@ N_STATE = 16
 MAX_DT_RANK = 8
 
 
-def supported(x: torch.Tensor, dt_rank: int, d_state: int) -> bool:
-    return x.is_cuda and x.dim() == 4 and d_state == N_STATE and 1 <= dt_rank <= MAX_DT_RANK and x.shape[1] % 4 == 0 \
-        and x.dtype in (torch.float16, torch.float32) and x.shape[0] * x.shape[1] <= 65535
-
-
 def _proj_weight_grad(dP: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """sum_{b,l} dP[s,b,c,l] x2[s,b,d,l].  For long sequences the library GEMM sees a 68 x 32 output with K = 10^5..10^6
     and runs on ~10 workgroups (1 ms per call at 512^2); cutting L into chunks makes it a batched GEMM over strided
