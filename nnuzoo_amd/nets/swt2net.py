@@ -73,7 +73,12 @@ class PatchEmbedding(nn.Module):
         p = self.patch_size
         if H % p or W % p:
             x = F.pad(x, (0, p - W % p, 0, p - H % p, 0, 0))  # right/bottom, full extra patch when one side divides
-        return self.norm(self.proj(x).permute(0, 2, 3, 1))
+        # the non-overlapping conv (kernel = stride = p) as space-to-depth + one GEMM on the conv's own parameters: same
+        # arithmetic, lands token-major directly, and avoids the library's strided-conv weight gradient (23 ms per call
+        # at 512^2 in fp32: `profiles/r01_swt2net_step_kernels.txt`)
+        B, C, H, W = x.shape
+        x = x.view(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
+        return self.norm(F.linear(x, self.proj.weight.view(self.proj.out_channels, -1), self.proj.bias))
 
 
 class PatchMerging(nn.Module):
