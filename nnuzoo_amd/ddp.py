@@ -103,3 +103,51 @@ def attach_bucketed_allreduce(network, process_group=None, bucket_bytes: int = 1
     red = BucketedAllReduce(params, process_group, bucket_bytes)
     network.grad_reducer = red
     return red
+
+
+def allreduce_gradients(params, process_group=None, bucket_bytes: int = 64 << 20) -> int:
+    """Gradient averaging for the autograd-graph networks (the X^2-Net zoo), called once after backward: the existing
+    gradients are flattened into buckets, all-reduced (SUM) asynchronously, and written back divided by the world size.
+    Parameters without a gradient are skipped: every rank runs the same graph, so the same parameters are without one
+    everywhere (the zoo's inner `seg_layers` never receive gradients - the reference needs torch DDP's
+    find_unused_parameters for these nets).  Their steps are launch-bound (7-10 thousand small kernels), so the exchange
+    (160 MB for M2Net = ~1.5 ms over xGMI) is not overlapped with backward.  Returns the number of gradients reduced."""
+    from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+    world = dist.get_world_size(process_group)
+    grads = [p.grad for p in params if p.grad is not None]
+    if world == 1 or not grads:
+        return len(grads)
+    buckets, cur, cur_bytes = [], [], 0
+    by_type = {}
+    for g in grads:                                  # one dtype / device per flat buffer
+        by_type.setdefault((g.dtype, g.device), []).append(g)
+    for gs in by_type.values():
+        for g in gs:
+            cur.append(g)
+            cur_bytes += g.numel() * g.element_size()
+            if cur_bytes >= bucket_bytes:
+                buckets.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+    inflight = []
+    for gs in buckets:
+        flat = _flatten_dense_tensors(gs)
+        inflight.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group, async_op=True), flat, gs))
+    inv = 1.0 / world
+    for handle, flat, gs in inflight:
+        handle.wait()
+        flat.mul_(inv)
+        torch._foreach_copy_(gs, list(_unflatten_dense_tensors(flat, gs)))
+    return len(grads)
+
+
+def prepare_autograd_network_for_ddp(network: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """What the reference's initialize() does before wrapping in torch DDP (nnUNetTrainer.py:275-280): BatchNorm ->
+    SyncBatchNorm (RSU4F / REBNCONV stages of the zoo), and every rank starts from rank 0's parameters and buffers."""
+    network = torch.nn.SyncBatchNorm.convert_sync_batchnorm(network, process_group)
+    with torch.no_grad():
+        for t in list(network.parameters()) + list(network.buffers()):
+            dist.broadcast(t.data, src=0, group=process_group)
+    return network

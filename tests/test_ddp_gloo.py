@@ -78,6 +78,23 @@ def _worker(rank, world, port, q):
         # gradient, which the 1/world of the parameter-gradient averaging cancels (reference semantics)
         assert torch.allclose(a.grad, world * ra.grad[sl], atol=1e-6)
         assert torch.allclose(b.grad, world * rb.grad[sl], atol=1e-6)
+        # autograd-graph networks (the zoo): average whatever gradients exist; a parameter without gradient is skipped
+        from nnuzoo_amd.ddp import allreduce_gradients, prepare_autograd_network_for_ddp
+        torch.manual_seed(200 + rank)
+        zoo = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.BatchNorm1d(4), torch.nn.Linear(4, 3))
+        unused = torch.nn.Parameter(torch.ones(5))                  # like the zoo's inner seg_layers
+        zoo = prepare_autograd_network_for_ddp(zoo)
+        assert isinstance(zoo[1], torch.nn.SyncBatchNorm)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [p.tolist() for p in zoo.parameters()])
+        assert gathered[0] == gathered[1]
+        ps = list(zoo.parameters()) + [unused]
+        for i, p in enumerate(ps[:-1]):
+            p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+        assert allreduce_gradients(ps, bucket_bytes=32) == len(ps) - 1
+        for i, p in enumerate(ps[:-1]):
+            assert torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))), (i, p.grad.flatten()[:3])
+        assert unused.grad is None
         # trainer batch split: global 5 over 2 ranks -> 3 + 2
         from nnuzoo_amd.synthetic import nnunet_plans
         from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
