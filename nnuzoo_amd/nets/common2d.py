@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..token_linear import TokenLinear
 from ..layer_norm import LayerNorm
 
 
@@ -107,7 +108,7 @@ class PatchMerging2D(nn.Module):
         self.input_feature_size = (scale ** 2) * input_dim
         self.output_features = output_features or input_dim * scale
         self.scale = scale
-        self.reduction = nn.Linear(self.input_feature_size, self.output_features, bias=False)
+        self.reduction = TokenLinear(self.input_feature_size, self.output_features, bias=False)
         self.norm = norm_layer(self.input_feature_size)
 
     def forward(self, x, permute=False):
@@ -135,10 +136,10 @@ class PatchExpand(nn.Module):
         super().__init__()
         self.dim, self.scale, self.output_dim = dim, scale, output_dim
         if output_dim is None:
-            self.expand = nn.Linear(dim, scale * dim, bias=False)
+            self.expand = TokenLinear(dim, scale * dim, bias=False)
             self.norm = norm_layer(dim // scale)
         else:
-            self.expand = nn.Linear(dim // (scale ** 2), output_dim, bias=False)
+            self.expand = TokenLinear(dim // (scale ** 2), output_dim, bias=False)
             self.norm = norm_layer(output_dim)
 
     def _d2s(self, x):

@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..token_linear import TokenLinear
 from ..layer_norm import LayerNorm, layer_norm_gate
 
 from .. import ss2d_scan
@@ -53,12 +54,12 @@ class SS2D(nn.Module):
         self.A_logs = self.A_log_init(N, Di, copies=K, merge=True)                     # (K * Di, N)
         self.Ds = self.D_init(Di, copies=K, merge=True)                                # (K * Di)
 
-        self.in_proj = nn.Linear(d_model, Di * 2, bias=bias, **fk)
+        self.in_proj = TokenLinear(d_model, Di * 2, bias=bias, **fk)
         self.conv2d = nn.Conv2d(Di, Di, groups=Di, bias=conv_bias, kernel_size=d_conv, padding=(d_conv - 1) // 2, **fk)
         self.act = nn.SiLU()
         self.selective_scan = selective_scan_fn
         self.out_norm = LayerNorm(Di)
-        self.out_proj = nn.Linear(Di, d_model, bias=bias, **fk)
+        self.out_proj = TokenLinear(Di, d_model, bias=bias, **fk)
         self.dropout = nn.Dropout(dropout) if dropout > 0. else None
 
     # ---- initialisers (same distributions as the reference, :113-168) --------------------------------------------

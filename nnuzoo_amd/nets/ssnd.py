@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..token_linear import TokenLinear
 from ..layer_norm import LayerNorm
 
 from .. import ss2d_scan
@@ -46,14 +47,14 @@ class SSND(nn.Module):
         self.dt_projs_bias = nn.Parameter(torch.stack([t.bias for t in dts], dim=0))
         self.A_logs = SS2D.A_log_init(N, Di, copies=K, merge=True)
         self.Ds = SS2D.D_init(Di, copies=K, merge=True)
-        self.in_proj = nn.Linear(d_model, Di * 2, bias=bias, **fk)
+        self.in_proj = TokenLinear(d_model, Di * 2, bias=bias, **fk)
         self.convnd = Convolution(spatial_dims, Di, Di, groups=Di, bias=conv_bias, kernel_size=d_conv,
                                   padding=(d_conv - 1) // 2 * dilation if dilation != 1 else (d_conv - 1) // 2,
                                   conv_only=True, dilation=dilation)
         self.act = nn.SiLU()
         self.selective_scan = selective_scan_fn
         self.out_norm = LayerNorm(Di)
-        self.out_proj = nn.Linear(Di, d_model, bias=bias, **fk)
+        self.out_proj = TokenLinear(Di, d_model, bias=bias, **fk)
         self.dropout = nn.Dropout(dropout) if dropout > 0. else None
 
     def forward_core(self, x: torch.Tensor):

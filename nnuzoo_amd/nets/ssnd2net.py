@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.init import trunc_normal_
 
+from ..token_linear import TokenLinear
 from ..layer_norm import LayerNorm
 
 from ..utilities.network_initialization import InitWeights_He
@@ -104,7 +105,7 @@ class PatchMerging2D(nn.Module):
             self.zs, self.hs, self.ws = (scale, scale, scale) if isinstance(scale, int) else scale
         self.input_feature_size = (self.zs * self.ws * self.hs) * input_dim
         self.output_features = output_features
-        self.reduction = nn.Linear(self.input_feature_size, self.output_features, bias=False)
+        self.reduction = TokenLinear(self.input_feature_size, self.output_features, bias=False)
         self.norm = norm_layer(self.input_feature_size)
 
     def forward(self, x, permute_=False):
@@ -155,10 +156,10 @@ class PatchExpand(nn.Module):
             if self.output_dim is not None and self.cs is not None:
                 raise ValueError("output_dim and cs cannot be not None at the same time!")
         if self.output_dim is None:
-            self.expand = nn.Linear(dim, self.zs * self.hs * self.ws // self.cs, bias=False)
+            self.expand = TokenLinear(dim, self.zs * self.hs * self.ws // self.cs, bias=False)
             self.norm = norm_layer(dim // self.cs)
         else:
-            self.expand = nn.Linear(dim // (self.zs * self.hs * self.ws), self.output_dim, bias=False)
+            self.expand = TokenLinear(dim // (self.zs * self.hs * self.ws), self.output_dim, bias=False)
             self.norm = norm_layer(self.output_dim)
 
     def _d2s(self, x):

@@ -124,3 +124,16 @@ def test_projection_weight_gradient_chunking_matches_einsum():
         x2 = torch.randn(2, 2, 3, L, generator=g, dtype=torch.float64)
         ref = torch.einsum("sbcl,sbdl->scd", dP, x2)
         assert torch.allclose(_proj_weight_grad(dP, x2), ref, rtol=1e-10, atol=1e-9)
+
+
+def test_token_linear_chunking_and_cpu_path():
+    """host logic: chunk counts are powers of two that divide the token count and keep >= 4096 tokens per chunk; on CPU
+    tensors (e.g. state-dict tooling) the layer is a plain Linear"""
+    import torch
+    from nnuzoo_amd.token_linear import TokenLinear, _chunks
+    assert _chunks(4096) == 1 and _chunks(8192) == 2 and _chunks(524288) == 128 and _chunks(3 * 8192) == 4
+    assert _chunks(8191) == 1
+    lin = TokenLinear(4, 3)
+    x = torch.randn(5, 4)
+    assert torch.equal(lin(x), torch.nn.functional.linear(x, lin.weight, lin.bias))
+    assert list(lin.state_dict()) == ["weight", "bias"]
