@@ -1,0 +1,84 @@
+"""hipGraph safety of the C-ABI launchers (hipGraph): a captured launch sequence must replay correctly
+after the process has made further allocations.  Regression test for the round-1 finding that a captured hipMemsetAsync
+node replays with a corrupted fill pattern (tools/dbg/dbg_graph_memset2.py): every zeroing in the library is a kernel."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _junk():
+    j = [torch.full((1 + 37 * i,), float("nan"), device="cuda") for i in range(2000)]
+    torch.cuda.synchronize()
+    del j
+
+
+def _capture(fn):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        fn()
+    return g
+
+
+def test_layer_norm_backward_replays_after_allocations(hip_lib):
+    from nnuzoo_amd._lib import call, ptr, stream_ptr
+    torch.manual_seed(0)
+    R, C = 1152, 32
+    x, dy, w = torch.randn(R, C, device="cuda"), torch.randn(R, C, device="cuda"), torch.ones(C, device="cuda")
+    mean, rstd = x.mean(1).contiguous(), (x.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dx, dwb = torch.empty_like(x), torch.empty(2, C, device="cuda")
+
+    def run():
+        call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), ptr(dwb[0]),
+             ptr(dwb[1]), R, C, stream_ptr())
+
+    run()
+    torch.cuda.synchronize()
+    ref_dx, ref_dwb = dx.clone(), dwb.clone()
+    assert torch.allclose(ref_dwb[1], dy.sum(0), rtol=1e-4, atol=1e-3)
+    g = _capture(run)
+    for _ in range(3):
+        dx.fill_(777.0)
+        dwb.fill_(777.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dx, ref_dx)
+        assert torch.allclose(dwb, ref_dwb, rtol=1e-4, atol=1e-3), (dwb - ref_dwb).abs().max().item()
+        _junk()
+
+
+def test_ss2d_block_forward_backward_replays_after_allocations(hip_lib):
+    """the fused SS2D block (dwconv, cross-scan, merge, gated norm: memset-free accumulators everywhere) under capture"""
+    from nnuzoo_amd.nets.m2net import VSSBlock
+    torch.manual_seed(1)
+    blk = VSSBlock(hidden_dim=16, drop_path=0.0).cuda()
+    x = torch.randn(2, 24, 40, 16, device="cuda", requires_grad=True)
+    dy = torch.randn(2, 24, 40, 16, device="cuda")
+    params = list(blk.parameters())
+    state = {}
+
+    def run():
+        for p in params:
+            p.grad = None
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            state["y"] = blk(x)
+        state["y"].float().backward(dy)
+
+    g = _capture(run)
+    g.replay()
+    torch.cuda.synchronize()
+    ref = [state["y"].detach().float().clone(), x.grad.clone()] + [p.grad.clone() for p in params]
+    assert all(bool(torch.isfinite(t).all()) for t in ref)
+    for _ in range(2):
+        _junk()
+        g.replay()
+        torch.cuda.synchronize()
+        now = [state["y"].detach().float(), x.grad] + [p.grad for p in params]
+        for a, b in zip(now, ref):
+            assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * b.abs().max().item() + 1e-7), (a - b).abs().max().item()
