@@ -131,6 +131,10 @@ def load() -> C.CDLL:
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m nnuzoo_amd.build` (hipcc --offload-arch=gfx950). "
             "nnuzoo_amd has no CPU fallback.")
+    # torch first: PyTorch-ROCm ships its own libamdhip64; our library's NEEDED entry must resolve to that already-loaded
+    # runtime.  Loaded the other way round the process holds two HIP runtimes and every launch from here fails with
+    # hipErrorNoDevice (seen when a test touched the library before anything imported torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design

@@ -18,6 +18,15 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define NNZ_OK 0
 #define NNZ_EINVAL (-22)
 
+// hipGetLastError() reports the last error of ANY runtime call of the thread, including benign failures inside other
+// libraries (torch / MIOpen probing calls) that happened before we were entered: clear that state in front of every
+// launch, so that NNZ_LAUNCH_CHECK attributes only our own launch's failure to us.
+#define NNZ_LAUNCH(...)              \
+  do {                               \
+    (void)hipGetLastError();         \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define NNZ_LAUNCH_CHECK()                         \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \
@@ -94,8 +103,7 @@ inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
   size_t head = ((uintptr_t)c & 15) ? 16 - ((uintptr_t)c & 15) : 0;  // words up to the first 16-byte boundary
   if (head > bytes) head = bytes;
   if (head) {
-    hipLaunchKernelGGL(zero_fill_kernel<0>, dim3(1), dim3(256), 0, s, (u32x4*)nullptr, (size_t)0, (uint32_t*)c,
-                       (int)(head / 4));
+    NNZ_LAUNCH(zero_fill_kernel<0>, dim3(1), dim3(256), 0, s, (u32x4*)nullptr, (size_t)0, (uint32_t*)c, (int)(head / 4));
     c += head;
     bytes -= head;
   }
@@ -105,8 +113,8 @@ inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
     size_t wg = (nvec + 255) / 256;
     if (wg > 4096) wg = 4096;
     if (wg < 1) wg = 1;
-    hipLaunchKernelGGL(zero_fill_kernel<0>, dim3((unsigned)wg), dim3(256), 0, s, (u32x4*)c, nvec,
-                       (uint32_t*)(c + nvec * 16), ntail);
+    NNZ_LAUNCH(zero_fill_kernel<0>, dim3((unsigned)wg), dim3(256), 0, s, (u32x4*)c, nvec, (uint32_t*)(c + nvec * 16),
+               ntail);
   }
   return hipGetLastError();
 }

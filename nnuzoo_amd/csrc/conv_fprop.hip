@@ -400,7 +400,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
     attr_lds = lds;
   }
   const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, p);
+  NNZ_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, p);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

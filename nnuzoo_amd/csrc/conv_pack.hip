@@ -112,7 +112,7 @@ extern "C" int nnz_pack_job_fill(void* out, const float* src, void* dst_f16, int
 extern "C" int nnz_pack_conv_weights_batched(const void* jobs_device, int njobs, void* stream) {
   using namespace nnz;
   if (!jobs_device || njobs < 1) return NNZ_EINVAL;
-  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(128, njobs), dim3(256), 0, (hipStream_t)stream,
+  NNZ_LAUNCH(pack_weight_batched_kernel, dim3(128, njobs), dim3(256), 0, (hipStream_t)stream,
                      (const PackJob*)jobs_device);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -127,7 +127,7 @@ extern "C" int nnz_pack_conv_weight(const float* src, void* dst_f16, int R, int 
   const long total = (long)R * C * T;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (f16*)dst_f16, R, C, T,
+  NNZ_LAUNCH(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (f16*)dst_f16, R, C, T,
                      sr, sc, sk, tab);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -142,7 +142,7 @@ extern "C" int nnz_unpack_conv_wgrad(const float* dw, float* grad, int A, int B,
   const long total = (long)A * B * T;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dw, grad, A, B, T, sa, sb,
+  NNZ_LAUNCH(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dw, grad, A, B, T, sa, sb,
                      sk, tab, accumulate);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;

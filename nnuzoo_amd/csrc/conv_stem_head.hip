@@ -467,7 +467,7 @@ extern "C" int nnz_stem_conv_forward(const float* x, const float* w, const float
   a.tiles[0] = (D + ST_TD - 1) / ST_TD;
   a.tiles[1] = (H + ST_TH - 1) / ST_TH;
   a.tiles[2] = (W + ST_TW - 1) / ST_TW;
-  hipLaunchKernelGGL(stem_fwd_mfma_kernel, dim3(a.tiles[0] * a.tiles[1] * a.tiles[2], N), dim3(256), 0,
+  NNZ_LAUNCH(stem_fwd_mfma_kernel, dim3(a.tiles[0] * a.tiles[1] * a.tiles[2], N), dim3(256), 0,
                      (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -487,7 +487,7 @@ extern "C" int nnz_stem_conv_wgrad(const float* x, const void* dy, float* dw, in
   hipError_t e = nnz::zero_async(dw, sizeof(float) * ST_CO * 27, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   const int grid = ntiles < 512 ? ntiles : 512;  // persistent: 2 workgroups per CU, one atomic per element each
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ntiles);
+  NNZ_LAUNCH(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ntiles);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -502,14 +502,14 @@ static void launch_head_fwd_cg(const HeadArgs& a, hipStream_t s) {
   const int cgs = a.C >> 3, rows = 256 / cgs;
   long blocks = ((long)a.N * a.V + rows * HD_UNR - 1) / (rows * HD_UNR);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(head_fwd_cg_kernel<K>, dim3((int)blocks), dim3(256), 0, s, a, cgs);
+  NNZ_LAUNCH(head_fwd_cg_kernel<K>, dim3((int)blocks), dim3(256), 0, s, a, cgs);
 }
 template <int K>
 static void launch_head_dgrad_cg(const HeadArgs& a, int accumulate, hipStream_t s) {
   const int cgs = a.C >> 3, rows = 256 / cgs;
   long blocks = ((long)a.N * a.V + rows * HD_UNR - 1) / (rows * HD_UNR);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(head_dgrad_cg_kernel<K>, dim3((int)blocks), dim3(256), 0, s, a, cgs, accumulate);
+  NNZ_LAUNCH(head_dgrad_cg_kernel<K>, dim3((int)blocks), dim3(256), 0, s, a, cgs, accumulate);
 }
 #define NNZ_HEAD_K_SWITCH(K, CALL) \
   switch (K) {                      \
@@ -541,9 +541,9 @@ extern "C" int nnz_seg_head_forward(const void* x, const float* w, const float* 
   long blocks = (N * V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (K <= 8)
-    hipLaunchKernelGGL(head_fwd_kernel<8>, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a);
+    NNZ_LAUNCH(head_fwd_kernel<8>, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(head_fwd_kernel<HD_MAXK>, dim3((int)blocks), dim3(256), sizeof(float) * K * C,
+    NNZ_LAUNCH(head_fwd_kernel<HD_MAXK>, dim3((int)blocks), dim3(256), sizeof(float) * K * C,
                        (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -566,10 +566,10 @@ extern "C" int nnz_seg_head_dgrad(const void* dlogits, const float* w, void* dx,
   long blocks = (N * V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (K <= 8)
-    hipLaunchKernelGGL(head_dgrad_kernel<8>, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream,
+    NNZ_LAUNCH(head_dgrad_kernel<8>, dim3((int)blocks), dim3(256), sizeof(float) * K * C, (hipStream_t)stream,
                        a, accumulate);
   else
-    hipLaunchKernelGGL(head_dgrad_kernel<HD_MAXK>, dim3((int)blocks), dim3(256), sizeof(float) * K * C,
+    NNZ_LAUNCH(head_dgrad_kernel<HD_MAXK>, dim3((int)blocks), dim3(256), sizeof(float) * K * C,
                        (hipStream_t)stream, a, accumulate);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -601,7 +601,7 @@ extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw,
     a.K = kg; a.Ktot = K; a.k0 = k0;
     const size_t lds = sizeof(float) * rows * (kg * C + kg);
     if (lds > 64 * 1024) return NNZ_EINVAL;  // K*C beyond the slab: not a segmentation head
-#define NNZ_CALL(KK) hipLaunchKernelGGL(head_wgrad_kernel<KK>, dim3(gx, N), dim3(256), lds, s, a, (int)vpb)
+#define NNZ_CALL(KK) NNZ_LAUNCH(head_wgrad_kernel<KK>, dim3(gx, N), dim3(256), lds, s, a, (int)vpb)
     NNZ_HEAD_K_SWITCH(kg, NNZ_CALL)
 #undef NNZ_CALL
   }

@@ -329,7 +329,7 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchO
     if (e != hipSuccess) return (int)e;
   }
   if (opt.splits_used) *opt.splits_used = splits;
-  hipLaunchKernelGGL(kern, dim3(pairs * splits), dim3(256), lds, stream, p);
+  NNZ_LAUNCH(kern, dim3(pairs * splits), dim3(256), lds, stream, p);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -522,12 +522,12 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
     // many splits (small channel counts: tab is small): element-parallel pre-reduction into the temp image
     float* tmp = workspace + (ws_floats - tab);
     const long blocks = (tab + 63) / 64;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splits, tab,
+    NNZ_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splits, tab,
                        tmp);
     src = tmp;
     splits = 1;
   }
-  hipLaunchKernelGGL(wgrad_to_grad_kernel, dim3((unsigned)(d.Cin * (d.Cout / 32))), dim3(256), 0, s, src, splits, tab,
+  NNZ_LAUNCH(wgrad_to_grad_kernel, dim3((unsigned)(d.Cin * (d.Cout / 32))), dim3(256), 0, s, src, splits, tab,
                      grad, d.Cin, d.Cout, d.ntaps_total, sa, sb, sk, ks, accumulate);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;

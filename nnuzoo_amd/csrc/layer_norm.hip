@@ -219,9 +219,9 @@ static int ln_launch(const LnArgs& a, bool bwd, hipStream_t s) {
   const long cap = bwd ? 1024 : 8192;
   const unsigned grid = (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
   if (bwd)
-    hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);
+    NNZ_LAUNCH((ln_bwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((ln_fwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);
+    NNZ_LAUNCH((ln_fwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -154,14 +154,14 @@ static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
     hipError_t e = nnz::zero_async(a.sums, sizeof(float) * a.B * (3 * a.C + 1), s);
     if (e != hipSuccess) return (int)e;
     if (big)
-      hipLaunchKernelGGL((dc_ce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+      NNZ_LAUNCH((dc_ce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((dc_ce_fwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
+      NNZ_LAUNCH((dc_ce_fwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
   } else {
     if (big)
-      hipLaunchKernelGGL((dc_ce_bwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+      NNZ_LAUNCH((dc_ce_bwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((dc_ce_bwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
+      NNZ_LAUNCH((dc_ce_bwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
   }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -441,19 +441,19 @@ static int launch_region(RegionArgs<T> a, int mode, void* counts, hipStream_t s)
   if (mode == 0) {
     hipError_t e = nnz::zero_async(a.sums, sizeof(float) * a.B * (3 * a.C + 2), s);
     if (e != hipSuccess) return (int)e;
-    if (big) hipLaunchKernelGGL((dc_bce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dc_bce_fwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
+    if (big) NNZ_LAUNCH((dc_bce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+    else NNZ_LAUNCH((dc_bce_fwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
   } else if (mode == 1) {
-    if (big) hipLaunchKernelGGL((dc_bce_bwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dc_bce_bwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
+    if (big) NNZ_LAUNCH((dc_bce_bwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
+    else NNZ_LAUNCH((dc_bce_bwd_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a);
   } else {
     hipError_t e = nnz::zero_async(counts, sizeof(unsigned long long) * 3 * a.C, s);
     if (e != hipSuccess) return (int)e;
     if (big)
-      hipLaunchKernelGGL((region_stats_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a.logits, a.tgt,
+      NNZ_LAUNCH((region_stats_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a.logits, a.tgt,
                          (unsigned long long*)counts, a.C, a.Ct, a.V, (int)vpb);
     else
-      hipLaunchKernelGGL((region_stats_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a.logits, a.tgt,
+      NNZ_LAUNCH((region_stats_kernel<T, 8>), dim3(gx, a.B), dim3(256), 0, s, a.logits, a.tgt,
                          (unsigned long long*)counts, a.C, a.Ct, a.V, (int)vpb);
   }
   NNZ_LAUNCH_CHECK();
@@ -518,7 +518,7 @@ extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const 
   if (vpb > V) vpb = V;
   const int gx = (int)((V + vpb - 1) / vpb);
 #define NNZ_ARGMAX(TT, MC)                                                                                       \
-  hipLaunchKernelGGL((argmax_stats_kernel<TT, MC>), dim3(gx, B), dim3(256), 0, s, (const TT*)logits, target, \
+  NNZ_LAUNCH((argmax_stats_kernel<TT, MC>), dim3(gx, B), dim3(256), 0, s, (const TT*)logits, target, \
                      (unsigned long long*)counts_u64, C, V, (int)vpb, ignore_label)
   if (logits_is_f16) {
     if (C > 8) NNZ_ARGMAX(f16, LS_MAXC_BIG); else NNZ_ARGMAX(f16, 8);
@@ -553,7 +553,7 @@ extern "C" int nnz_dc_ce_loss_finalize(const float* sums, float* loss_accum, flo
   a.sums = sums; a.loss_accum = loss_accum; a.coef = coef; a.B = B; a.C = C; a.V = V;
   a.batch_dice = batch_dice; a.do_bg = do_bg; a.use_valid_count = use_valid_count;
   a.smooth = smooth; a.w_ce = weight_ce; a.w_dice = weight_dice; a.ds_weight = ds_weight;
-  hipLaunchKernelGGL(dc_ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(dc_ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

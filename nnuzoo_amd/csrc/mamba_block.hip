@@ -156,7 +156,7 @@ extern "C" int nnz_causal_conv1d_silu_forward(const float* x, const float* w, co
   ConvArgs a = {};
   a.x = x; a.w = w; a.b = bias; a.y = y; a.B = B; a.D = D; a.L = L; a.W = W;
   const int gx = (L + 256 * CC_LPT - 1) / (256 * CC_LPT);
-  hipLaunchKernelGGL(causal_conv1d_silu_fwd_kernel, dim3(gx, B * D), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(causal_conv1d_silu_fwd_kernel, dim3(gx, B * D), dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -176,7 +176,7 @@ extern "C" int nnz_causal_conv1d_silu_backward(const float* x, const float* w, c
   ConvArgs a = {};
   a.x = x; a.w = w; a.b = bias; a.dy = dy; a.dx = dx; a.dw = dw; a.db = dbias; a.B = B; a.D = D; a.L = L; a.W = W;
   const int gx = (L + 256 * CC_LPT - 1) / (256 * CC_LPT);
-  hipLaunchKernelGGL(causal_conv1d_silu_bwd_kernel, dim3(gx, B * D), dim3(256), 0, s, a);
+  NNZ_LAUNCH(causal_conv1d_silu_bwd_kernel, dim3(gx, B * D), dim3(256), 0, s, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -186,7 +186,7 @@ extern "C" int nnz_silu_gate_forward(const float* y, const float* z, float* out,
   if (!y || !z || !out || n < 1) return NNZ_EINVAL;
   long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(silu_gate_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, y, z, out, n);
+  NNZ_LAUNCH(silu_gate_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, y, z, out, n);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -197,7 +197,7 @@ extern "C" int nnz_silu_gate_backward(const float* dout, const float* y, const f
   if (!dout || !y || !z || !dy || !dz || n < 1) return NNZ_EINVAL;
   long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(silu_gate_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dout, y, z, dy, dz, n);
+  NNZ_LAUNCH(silu_gate_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dout, y, z, dy, dz, n);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -185,7 +185,7 @@ static int launch_norm(NormArgs a, hipStream_t s, bool pre_zeroed = false) {
     hipError_t e = nnz::zero_async(MODE == 0 ? a.stats : a.red, sizeof(float) * 2 * a.N * a.C, s);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(norm_kernel<MODE>, dim3(gx, a.N), dim3(256), lds, s, a);
+  NNZ_LAUNCH(norm_kernel<MODE>, dim3(gx, a.N), dim3(256), lds, s, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

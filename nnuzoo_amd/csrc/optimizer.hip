@@ -98,7 +98,7 @@ extern "C" int nnz_grad_sumsq_nonfinite(const float* grads, long n, float* out2_
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(grad_sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grads, n, out2_zeroed);
+  NNZ_LAUNCH(grad_sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grads, n, out2_zeroed);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -108,7 +108,7 @@ extern "C" int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, co
                                       float weight_decay, int first_step, void* stream) {
   using namespace nnz;
   if (!chunks_device || nchunks < 1 || !arena || !stats2) return NNZ_EINVAL;
-  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+  NNZ_LAUNCH(sgd_nesterov_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
                      (const SgdChunk*)chunks_device, arena, stats2, inv_scale_device, max_norm, lr, momentum, weight_decay,
                      first_step);
   NNZ_LAUNCH_CHECK();

@@ -708,17 +708,17 @@ static int scan_forward_impl(ScanArgs& a, float* chunk_state, float* workspace, 
   a.rows_per_wg = pick_rows_per_wg(a.Dg, (long)a.Bt * a.K * a.nchunks);
   dim3 grid(a.nchunks, a.Bt * a.K * (a.Dg / a.rows_per_wg));
   if (a.nchunks > 1) {
-    hipLaunchKernelGGL((scan_fwd_kernel<false, XS>), grid, dim3(SS_NW * 64), 0, s, a);
+    NNZ_LAUNCH((scan_fwd_kernel<false, XS>), grid, dim3(SS_NW * 64), 0, s, a);
     NNZ_LAUNCH_CHECK();
     const long rows_n = rows * SS_N;
-    hipLaunchKernelGGL(scan_carry_kernel<false>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Hin,
+    NNZ_LAUNCH(scan_carry_kernel<false>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Hin,
                        rows_n, a.nchunks);
     NNZ_LAUNCH_CHECK();
   } else {
     hipError_t e = nnz::zero_async(a.Hin, sizeof(float) * rows * SS_N, s);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((scan_fwd_kernel<true, XS>), grid, dim3(SS_NW * 64), 0, s, a);
+  NNZ_LAUNCH((scan_fwd_kernel<true, XS>), grid, dim3(SS_NW * 64), 0, s, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -747,10 +747,10 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
   const int lds_final = SS_BWD_LDS_FINAL + (XS ? a.R * (SS_DTP + SS_CL) * 4 : 0);
   dim3 grid(a.nchunks, a.Bt * a.K * (a.Dg / a.rows_per_wg));
   if (a.nchunks > 1) {
-    hipLaunchKernelGGL((scan_bwd_kernel<false, XS>), grid, dim3(SS_NW * 64), lds_summary, s, a);
+    NNZ_LAUNCH((scan_bwd_kernel<false, XS>), grid, dim3(SS_NW * 64), lds_summary, s, a);
     NNZ_LAUNCH_CHECK();
     const long rows_n = rows * SS_N;
-    hipLaunchKernelGGL(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin,
+    NNZ_LAUNCH(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin,
                        rows_n, a.nchunks);
     NNZ_LAUNCH_CHECK();
   } else {
@@ -763,9 +763,9 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
     if (e != hipSuccess) return (int)e;
     attr_lds = lds_final;
   }
-  hipLaunchKernelGGL((scan_bwd_kernel<true, XS>), grid, dim3(SS_NW * 64), lds_final, s, a);
+  NNZ_LAUNCH((scan_bwd_kernel<true, XS>), grid, dim3(SS_NW * 64), lds_final, s, a);
   NNZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA,
+  NNZ_LAUNCH(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA,
                      a.dbias, a.dD, a.Bt, a.KD, a.nchunks, dWdt, XS ? a.R : 0,
                      (XS && a.a_is_log) ? a.A : (const float*)nullptr);
   NNZ_LAUNCH_CHECK();

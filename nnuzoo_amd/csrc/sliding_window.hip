@@ -89,7 +89,7 @@ extern "C" int nnz_sliding_window_accumulate(const void* preds_f16, int M, const
   const long tv = (long)a.t[0] * a.t[1] * a.t[2];
   long blocks = (tv + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(sw_accumulate_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(sw_accumulate_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -100,7 +100,7 @@ extern "C" int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f
   if (!logits_f16 || !npred_f16 || !inf_flag || K < 1 || V < 1) return NNZ_EINVAL;
   long blocks = ((long)K * V + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(sw_finalize_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (f16*)logits_f16,
+  NNZ_LAUNCH(sw_finalize_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (f16*)logits_f16,
                      (const f16*)npred_f16, K, V, inf_flag);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;

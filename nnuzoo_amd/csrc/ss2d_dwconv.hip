@@ -183,7 +183,7 @@ extern "C" int nnz_ss2d_dwconv_silu_forward(const void* x_tokens, int x_is_f16, 
   a.x = x_tokens; a.x_is_f16 = x_is_f16; a.x_stride = x_row_stride; a.w = weight; a.bias = bias; a.x2 = x2;
   a.B = Bt; a.D = D; a.H = H; a.W = W;
   dim3 grid(((H + DT - 1) / DT) * ((W + DT - 1) / DT), (D + DC - 1) / DC, Bt);
-  hipLaunchKernelGGL(dwconv_silu_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(dwconv_silu_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -208,7 +208,7 @@ extern "C" int nnz_ss2d_dwconv_silu_backward(const void* x_tokens, int x_is_f16,
   a.dx = dx_tokens; a.dw = dweight; a.dbias = dbias;
   a.B = Bt; a.D = D; a.H = H; a.W = W;
   dim3 grid(((H + DT - 1) / DT) * ((W + DT - 1) / DT), (D + DC - 1) / DC, Bt);
-  hipLaunchKernelGGL(dwconv_silu_bwd_kernel, grid, dim3(256), 0, s, a);
+  NNZ_LAUNCH(dwconv_silu_bwd_kernel, grid, dim3(256), 0, s, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -159,9 +159,9 @@ extern "C" int nnz_ss2d_prepare(const void* x, int x_is_f16, float* x2, int Bt, 
   const long planes = (long)Bt * D;
   dim3 grid(((H + XT - 1) / XT) * ((W + XT - 1) / XT), (unsigned)planes);
   if (x_is_f16)
-    hipLaunchKernelGGL(ss2d_prepare_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x2, H, W, planes);
+    NNZ_LAUNCH(ss2d_prepare_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x2, H, W, planes);
   else
-    hipLaunchKernelGGL(ss2d_prepare_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, x2, H, W,
+    NNZ_LAUNCH(ss2d_prepare_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, x2, H, W,
                        planes);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -174,10 +174,10 @@ extern "C" int nnz_ss2d_merge_dx(const float* du, const float* dx2, void* dx, in
   const long planes = (long)Bt * D;
   dim3 grid(((H + XT - 1) / XT) * ((W + XT - 1) / XT), (unsigned)planes);
   if (dx_is_f16)
-    hipLaunchKernelGGL(ss2d_merge_dx_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, du, dx2, (f16*)dx, D, H, W,
+    NNZ_LAUNCH(ss2d_merge_dx_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, du, dx2, (f16*)dx, D, H, W,
                        planes);
   else
-    hipLaunchKernelGGL(ss2d_merge_dx_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, du, dx2, (float*)dx, D, H, W,
+    NNZ_LAUNCH(ss2d_merge_dx_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, du, dx2, (float*)dx, D, H, W,
                        planes);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -188,7 +188,7 @@ extern "C" int nnz_ss2d_merge(const float* y, float* out_tokens, int Bt, int D, 
   if (!y || !out_tokens || Bt < 1 || D < 1 || H < 1 || W < 1 || Bt > 65535 || (D + MT - 1) / MT > 65535)
     return NNZ_EINVAL;
   dim3 grid(((H + MT - 1) / MT) * ((W + MT - 1) / MT), (D + MT - 1) / MT, Bt);
-  hipLaunchKernelGGL(ss2d_merge_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, out_tokens, (float*)nullptr,
+  NNZ_LAUNCH(ss2d_merge_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, out_tokens, (float*)nullptr,
                      Bt, D, H, W);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -199,7 +199,7 @@ extern "C" int nnz_ss2d_split(const float* dout_tokens, float* dy2, int Bt, int 
   if (!dout_tokens || !dy2 || Bt < 1 || D < 1 || H < 1 || W < 1 || Bt > 65535 || (D + MT - 1) / MT > 65535)
     return NNZ_EINVAL;
   dim3 grid(((H + MT - 1) / MT) * ((W + MT - 1) / MT), (D + MT - 1) / MT, Bt);
-  hipLaunchKernelGGL(ss2d_merge_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+  NNZ_LAUNCH(ss2d_merge_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
                      const_cast<float*>(dout_tokens), dy2, Bt, D, H, W);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;

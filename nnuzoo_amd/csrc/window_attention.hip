@@ -410,7 +410,7 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
   if (int rc = check(a)) return rc;
   const int nwin = B * (H / WA_WS) * (W / WA_WS);
-  hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(win_attn_fwd_kernel, dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -428,7 +428,7 @@ extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias
                                 (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   const int nwin = B * (H / WA_WS) * (W / WA_WS);
-  hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(win_attn_bwd_kernel, dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
