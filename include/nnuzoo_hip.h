@@ -176,21 +176,23 @@ int nnz_ss2d_scan_backward(const float* x2, const float* P, const float* Wdt, co
  * ssnd2net.py, swt2net.py:630-660).  x: [rows][C] f16 or f32, C % 4 == 0, C <= 2048; y, dy: f32 (what autocast gives);
  * dx has x's type; gamma / beta / dgamma / dbeta may be NULL (elementwise_affine = False).  mean / rstd: [rows] f32. */
 int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, void* y, int y_is_f16,
-                           float* mean, float* rstd, long rows, int C, float eps, void* stream);
+                           float* mean, float* rstd, float* zero_2c, long rows, int C, float eps, void* stream);
 int nnz_layer_norm_backward(const void* x, int x_is_f16, const float* gamma, const float* mean, const float* rstd,
-                            const void* dy, int dy_is_f16, void* dx, float* dgamma, float* dbeta, long rows, int C,
-                            void* stream);
+                            const void* dy, int dy_is_f16, void* dx, float* dgamma, float* dbeta, int pre_zeroed,
+                            long rows, int C, void* stream);
 /* y = LayerNorm(x) * silu(z): the gated output norm of the SS2D block (m2net.py:220 `self.out_norm(y) * F.silu(z)`).
  * z: f16 or f32, rows z_row_stride elements apart (z is one half of the in_proj output); dz: [rows][C] in z's type.
  * y_is_f16 (all four): write y as f16 when its only consumer is an autocast Linear (the cast that consumer would apply
- * rounds the same fp32 value once - identical numbers, one pass and one launch less); dy then arrives as f16. */
+ * rounds the same fp32 value once - identical numbers, one pass and one launch less); dy then arrives as f16.
+ * zero_2c (forward, may be NULL): the [2][C] buffer the matching backward accumulates dgamma / dbeta into; the forward
+ * launch zeroes it so that the backward (pre_zeroed = 1) needs no zeroing launch. */
 int nnz_layer_norm_gate_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
                                 int z_is_f16, long z_row_stride, void* y, int y_is_f16, float* mean, float* rstd,
-                                long rows, int C, float eps, void* stream);
+                                float* zero_2c, long rows, int C, float eps, void* stream);
 int nnz_layer_norm_gate_backward(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
                                  int z_is_f16, long z_row_stride, const float* mean, const float* rstd, const void* dy,
-                                 int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, long rows, int C,
-                                 void* stream);
+                                 int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, int pre_zeroed,
+                                 long rows, int C, void* stream);
 
 /* ---- fused soft-Dice + cross-entropy statistics on NC(D)HW logits --------------------------------------------
  * replaces softmax + one-hot + reductions + CE of DC_and_CE_loss (nnunetv2/training/loss/compound_losses.py:31-56,

@@ -30,6 +30,8 @@ struct LnArgs {
   long z_stride;
   int z_is_f16;
   int y_is_f16, dy_is_f16;
+  float* zero_buf;  // forward: [2][C] buffer the matching backward will accumulate dgamma / dbeta into - zeroed here, so the
+                    // backward needs no zeroing launch of its own (may be null)
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
@@ -72,6 +74,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     gm[i] = (a.gamma && c < C) ? ld4(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
     bt[i] = (a.beta && c < C) ? ld4(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  if (a.zero_buf && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < 2 * C; c += 256) a.zero_buf[c] = 0.f;
   for (long r = (long)blockIdx.x * GPW + g; r < a.R; r += (long)gridDim.x * GPW) {
     const T* xr = (const T*)a.x + r * C;
     f32x4 v[IT];
@@ -243,27 +247,28 @@ static int ln_dispatch(const LnArgs& a, bool bwd, hipStream_t s) {
 }  // namespace nnz
 
 static int ln_forward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
-                           int z_is_f16, long z_stride, void* y, int y_is_f16, float* mean, float* rstd, long rows, int C,
-                           float eps, void* stream) {
+                           int z_is_f16, long z_stride, void* y, int y_is_f16, float* mean, float* rstd, float* zero_2c,
+                           long rows, int C, float eps, void* stream) {
   using namespace nnz;
   if (!x || !y || !mean || !rstd || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (z_stride & 3))) return NNZ_EINVAL;
   if (rows == 0) return NNZ_OK;
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.R = rows; a.C = C; a.eps = eps;
-  a.z = z; a.z_is_f16 = z_is_f16; a.z_stride = z_stride; a.y_is_f16 = y_is_f16;
+  a.z = z; a.z_is_f16 = z_is_f16; a.z_stride = z_stride; a.y_is_f16 = y_is_f16; a.zero_buf = zero_2c;
   return x_is_f16 ? ln_dispatch<f16>(a, false, (hipStream_t)stream) : ln_dispatch<float>(a, false, (hipStream_t)stream);
 }
 
 static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
                             int z_is_f16, long z_stride, const float* mean, const float* rstd, const void* dy,
-                            int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, long rows, int C,
-                            void* stream) {
+                            int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, int pre_zeroed, long rows,
+                            int C, void* stream) {
   using namespace nnz;
   if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (!dz || (z_stride & 3))))
     return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
-  if (dgamma && dbeta == dgamma + C) {  // one buffer [2][C]: one launch
+  if (pre_zeroed) {  // the forward launch zeroed the [2][C] buffer
+  } else if (dgamma && dbeta == dgamma + C) {  // one buffer [2][C]: one launch
     if ((e = zero_async(dgamma, sizeof(float) * 2 * C, s)) != hipSuccess) return (int)e;
   } else {
     if (dgamma && (e = zero_async(dgamma, sizeof(float) * C, s)) != hipSuccess) return (int)e;
@@ -279,30 +284,32 @@ static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, con
 
 extern "C" int nnz_layer_norm_gate_forward(const void* x, int x_is_f16, const float* gamma, const float* beta,
                                            const void* z, int z_is_f16, long z_row_stride, void* y, int y_is_f16,
-                                           float* mean, float* rstd, long rows, int C, float eps, void* stream) {
+                                           float* mean, float* rstd, float* zero_2c, long rows, int C, float eps,
+                                           void* stream) {
   if (!z) return NNZ_EINVAL;
-  return ln_forward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, y, y_is_f16, mean, rstd, rows, C, eps,
-                         stream);
+  return ln_forward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, y, y_is_f16, mean, rstd, zero_2c, rows, C,
+                         eps, stream);
 }
 
 extern "C" int nnz_layer_norm_gate_backward(const void* x, int x_is_f16, const float* gamma, const float* beta,
                                             const void* z, int z_is_f16, long z_row_stride, const float* mean,
                                             const float* rstd, const void* dy, int dy_is_f16, void* dx, void* dz,
-                                            float* dgamma, float* dbeta, long rows, int C, void* stream) {
+                                            float* dgamma, float* dbeta, int pre_zeroed, long rows, int C,
+                                            void* stream) {
   if (!z) return NNZ_EINVAL;
   return ln_backward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, mean, rstd, dy, dy_is_f16, dx, dz, dgamma,
-                          dbeta, rows, C, stream);
+                          dbeta, pre_zeroed, rows, C, stream);
 }
 
 extern "C" int nnz_layer_norm_forward(const void* x, int x_is_f16, const float* gamma, const float* beta, void* y,
-                                      int y_is_f16, float* mean, float* rstd, long rows, int C, float eps,
-                                      void* stream) {
-  return ln_forward_impl(x, x_is_f16, gamma, beta, nullptr, 0, 0, y, y_is_f16, mean, rstd, rows, C, eps, stream);
+                                      int y_is_f16, float* mean, float* rstd, float* zero_2c, long rows, int C,
+                                      float eps, void* stream) {
+  return ln_forward_impl(x, x_is_f16, gamma, beta, nullptr, 0, 0, y, y_is_f16, mean, rstd, zero_2c, rows, C, eps, stream);
 }
 
 extern "C" int nnz_layer_norm_backward(const void* x, int x_is_f16, const float* gamma, const float* mean,
                                        const float* rstd, const void* dy, int dy_is_f16, void* dx, float* dgamma,
-                                       float* dbeta, long rows, int C, void* stream) {
+                                       float* dbeta, int pre_zeroed, long rows, int C, void* stream) {
   return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dy_is_f16, dx, nullptr, dgamma,
-                          dbeta, rows, C, stream);
+                          dbeta, pre_zeroed, rows, C, stream);
 }

@@ -26,9 +26,13 @@ class _LayerNormFn(torch.autograd.Function):
         y = torch.empty(xc.shape, dtype=torch.float16 if half else torch.float32, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        # dgamma / dbeta accumulator of the backward, zeroed by the forward launch (no zeroing launch later)
+        gwb = torch.empty((2, C), dtype=torch.float32, device=x.device) \
+            if weight is not None and bias is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] else None
         call("nnz_layer_norm_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(y), int(half),
-             ptr(mean), ptr(rstd), rows, C, float(eps), stream_ptr())
+             ptr(mean), ptr(rstd), ptr(gwb), rows, C, float(eps), stream_ptr())
         ctx.save_for_backward(xc, weight, mean, rstd)
+        ctx.gwb = gwb
         ctx.has_bias = bias is not None
         return y if out_dtype in (torch.float32, torch.float16) else y.to(out_dtype)
 
@@ -39,20 +43,25 @@ class _LayerNormFn(torch.autograd.Function):
         rows = xc.numel() // C
         dy = _dy(dy)
         dx = torch.empty_like(xc)
-        dw, db = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, xc.device)
+        dw, db, pre = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, xc.device,
+                                    ctx.gwb)
+        ctx.gwb = None      # single use: a second backward through the same node zeroes in its own launch
         call("nnz_layer_norm_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
-             ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), rows, C, stream_ptr())
+             ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), pre, rows, C, stream_ptr())
         return dx, dw, db, None, None
 
 
-def _affine_grads(weight, has_bias, need_w, need_b, C, device):
-    """dgamma / dbeta as the two rows of one buffer when both are needed: the kernel launcher zeroes them in one launch"""
+def _affine_grads(weight, has_bias, need_w, need_b, C, device, prezeroed=None):
+    """dgamma / dbeta as the two rows of one buffer when both are needed (zeroed by the forward launch when `prezeroed`
+    is that buffer, else by one launch of the backward).  Returns (dgamma, dbeta, pre_zeroed flag)."""
     need_w, need_b = need_w and weight is not None, need_b and has_bias
     if need_w and need_b:
+        if prezeroed is not None:
+            return prezeroed[0], prezeroed[1], 1
         both = torch.empty((2, C), dtype=torch.float32, device=device)
-        return both[0], both[1]
+        return both[0], both[1], 0
     return (torch.empty(C, dtype=torch.float32, device=device) if need_w else None,
-            torch.empty(C, dtype=torch.float32, device=device) if need_b else None)
+            torch.empty(C, dtype=torch.float32, device=device) if need_b else None, 0)
 
 
 def _row_stride(z: torch.Tensor):
@@ -84,11 +93,13 @@ class _LayerNormGateFn(torch.autograd.Function):
         y = torch.empty(xc.shape, dtype=torch.float16 if half_out else torch.float32, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        gwb = torch.empty((2, C), dtype=torch.float32, device=x.device) \
+            if weight is not None and bias is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3] else None
         call("nnz_layer_norm_gate_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
-             int(z.dtype == torch.float16), zs, ptr(y), int(half_out), ptr(mean), ptr(rstd), rows, C, float(eps),
-             stream_ptr())
+             int(z.dtype == torch.float16), zs, ptr(y), int(half_out), ptr(mean), ptr(rstd), ptr(gwb), rows, C,
+             float(eps), stream_ptr())
         ctx.save_for_backward(xc, z, weight, bias, mean, rstd)
-        ctx.zs = zs
+        ctx.zs, ctx.gwb = zs, gwb
         return y
 
     @staticmethod
@@ -99,10 +110,12 @@ class _LayerNormGateFn(torch.autograd.Function):
         dy = _dy(dy)
         dx = torch.empty_like(xc)
         dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
-        dw, db = _affine_grads(weight, bias is not None, ctx.needs_input_grad[2], ctx.needs_input_grad[3], C, xc.device)
+        dw, db, pre = _affine_grads(weight, bias is not None, ctx.needs_input_grad[2], ctx.needs_input_grad[3], C,
+                                    xc.device, ctx.gwb)
+        ctx.gwb = None
         call("nnz_layer_norm_gate_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
              int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), int(dy.dtype == torch.float16),
-             ptr(dx), ptr(dz), ptr(dw), ptr(db), rows, C, stream_ptr())
+             ptr(dx), ptr(dz), ptr(dw), ptr(db), pre, rows, C, stream_ptr())
         return dx, dz, dw, db, None, None
 
 

@@ -35,7 +35,7 @@ def test_layer_norm_backward_replays_after_allocations(hip_lib):
 
     def run():
         call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), ptr(dwb[0]),
-             ptr(dwb[1]), R, C, stream_ptr())
+             ptr(dwb[1]), 0, R, C, stream_ptr())
 
     run()
     torch.cuda.synchronize()

@@ -20,7 +20,7 @@ dx, dw, db = torch.empty_like(x), torch.empty(C, device="cuda"), torch.empty(C, 
 
 
 def run():
-    call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), ptr(dw), ptr(db), R, C,
+    call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), ptr(dw), ptr(db), 0, R, C,
          stream_ptr())
 
 

@@ -20,7 +20,7 @@ z = torch.empty(4096, device="cuda")
 
 
 def kernel_only():
-    call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), 0, 0, R, C, stream_ptr())
+    call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), 0, 0, 0, R, C, stream_ptr())
 
 
 def memset_only():
@@ -28,7 +28,7 @@ def memset_only():
 
 
 def both():
-    call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), ptr(dw), ptr(db), R, C,
+    call("nnz_layer_norm_backward", ptr(x), 0, ptr(w), ptr(mean), ptr(rstd), ptr(dy), 0, ptr(dx), ptr(dw), ptr(db), 0, R, C,
          stream_ptr())
 
 
