@@ -8,9 +8,13 @@ sub-module / parameter names and shapes as /root/reference/nnunetv2/nets/m2net.p
   M2Net             :805-971,   M2NetP :1011-1184
   get_m2net_from_plans / get_m2netp_from_plans :1187-1232
 
-The selective scan runs on the hand-written gfx950 chunk-scan kernel (nnuzoo_amd.selective_scan.selective_scan_fn,
-csrc/selective_scan.hip) in fp32 exactly as the reference forces it (`.float()` at :185-191); Linear / LayerNorm /
-conv layers are library ops.  There is no eager fallback for the scan: CPU tensors raise.
+The SS2D block body runs on hand-written gfx950 kernels (nnuzoo_amd/ss2d_scan.py): depthwise conv + SiLU + scan layouts
+(csrc/ss2d_dwconv.hip), the chunk scan in cross-scan mode - four directions by index arithmetic, delta and A formed in
+the kernel, fp32 as the reference forces it (`.float()` at :185-191) - (csrc/selective_scan.hip), direction merge
+(csrc/ss2d_layout.hip) and the gated output norm (csrc/layer_norm.hip); every LayerNorm is nnuzoo_amd.layer_norm.LayerNorm
+and the tall token Linears are nnuzoo_amd.token_linear.TokenLinear.  `SS2D.fused_cross_scan = False` selects the
+reference's op-by-op formulation around `selective_scan_fn` (parity tests).  The remaining Linear / RSU4F conv layers are
+library ops.  There is no eager fallback for the scan: CPU tensors raise.
 """
 from __future__ import annotations
 
