@@ -172,6 +172,15 @@ int nnz_ss2d_scan_backward(const float* x2, const float* P, const float* Wdt, co
                            float* workspace, float* du, float* dP, float* dWdt, float* dA, float* dD, float* dbias,
                            int Bt, int Dg, int R, int L, int delta_softplus, int a_is_log, void* stream);
 
+/* ---- residual add with stochastic depth: out = input + x * mask[b] * scale  (VSSBlock.forward, m2net.py:530, with timm's
+ * DropPath: mask drawn per sample by the caller, scale = 1 / keep_prob).  input / x / out: [B][per_sample] f16 or f32
+ * (per_sample % 4 == 0), mask [B] f16 or f32 or NULL.  Backward: dx = dout * mask[b] * scale (d input = dout). */
+int nnz_residual_droppath_forward(const void* input, int input_is_f16, const void* x, int x_is_f16, const void* mask,
+                                  int mask_is_f16, float scale, void* out, int out_is_f16, int B, long per_sample,
+                                  void* stream);
+int nnz_residual_droppath_backward(const void* dout, int dout_is_f16, const void* mask, int mask_is_f16, float scale,
+                                   void* dx, int dx_is_f16, int B, long per_sample, void* stream);
+
 /* ---- LayerNorm over the last dimension of token-major tensors (nn.LayerNorm in the VSS / Swin blocks: m2net.py:101,521,
  * ssnd2net.py, swt2net.py:630-660).  x: [rows][C] f16 or f32, C % 4 == 0, C <= 2048; y, dy: f32 (what autocast gives);
  * dx has x's type; gamma / beta / dgamma / dbeta may be NULL (elementwise_affine = False).  mean / rstd: [rows] f32. */

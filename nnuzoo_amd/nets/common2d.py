@@ -35,6 +35,53 @@ class DropPath(nn.Module):
         return x * mask
 
 
+class _ResidualDropPathFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, x, mask, scale):
+        from .._lib import call, ptr, stream_ptr
+        inp, x = inp.contiguous(), x.contiguous()
+        B = x.shape[0]
+        P = x.numel() // B
+        out_dtype = torch.float16 if (inp.dtype == torch.float16 and x.dtype == torch.float16) else torch.float32
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        h = torch.float16
+        call("nnz_residual_droppath_forward", ptr(inp), int(inp.dtype == h), ptr(x), int(x.dtype == h), ptr(mask),
+             int(mask is not None and mask.dtype == h), float(scale), ptr(out), int(out_dtype == h), B, P, stream_ptr())
+        ctx.save_for_backward(mask)
+        ctx.meta = (scale, x.dtype, inp.dtype, B, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .._lib import call, ptr, stream_ptr
+        (mask,) = ctx.saved_tensors
+        scale, xdt, idt, B, P = ctx.meta
+        dout = dout.contiguous()
+        h = torch.float16
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty(dout.shape, dtype=xdt, device=dout.device)
+            call("nnz_residual_droppath_backward", ptr(dout), int(dout.dtype == h), ptr(mask),
+                 int(mask is not None and mask.dtype == h), float(scale), ptr(dx), int(xdt == h), B, P, stream_ptr())
+        dinp = (dout if dout.dtype == idt else dout.to(idt)) if ctx.needs_input_grad[0] else None
+        return dinp, dx, None, None
+
+
+def residual_drop_path(inp: torch.Tensor, x: torch.Tensor, drop_path: "DropPath") -> torch.Tensor:
+    """`inp + drop_path(x)` (the residual of the VSS / SSND blocks) in one pass each way.  The per-sample mask is drawn
+    with the same call as timm's DropPath (same RNG stream); mask scaling, multiply and add are one kernel."""
+    ok = x.is_cuda and inp.shape == x.shape and x.dtype in (torch.float16, torch.float32) \
+        and inp.dtype in (torch.float16, torch.float32) and x.shape[0] <= 65535 and (x.numel() // x.shape[0]) % 4 == 0
+    if not ok:
+        return inp + drop_path(x)
+    if drop_path.drop_prob == 0. or not drop_path.training:
+        return _ResidualDropPathFn.apply(inp, x, None, 1.0)
+    keep = 1 - drop_path.drop_prob
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+    scale = 1.0 / keep if (keep > 0.0 and drop_path.scale_by_keep) else 1.0
+    return _ResidualDropPathFn.apply(inp, x, mask, scale)
+
+
 class Convolution(nn.Sequential):
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, strides=1, kernel_size=3, bias=True,
                  conv_only: bool = True, groups: int = 1, dilation: int = 1, padding=None):

@@ -31,7 +31,7 @@ from ..layer_norm import LayerNorm, layer_norm_gate
 from .. import ss2d_scan
 from ..selective_scan import selective_scan_fn
 from ..utilities.network_initialization import InitWeights_He
-from .common2d import DropPath, PatchExpand, PatchMerging2D, REBNCONV, RSU4F, _upsample_like
+from .common2d import DropPath, PatchExpand, PatchMerging2D, REBNCONV, RSU4F, _upsample_like, residual_drop_path
 
 
 class SS2D(nn.Module):
@@ -171,7 +171,7 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, input: torch.Tensor):
-        return input + self.drop_path(self.self_attention(self.ln_1(input)))
+        return residual_drop_path(input, self.self_attention(self.ln_1(input)), self.drop_path)
 
 
 class VSSLayer(nn.Module):

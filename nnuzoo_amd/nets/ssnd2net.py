@@ -28,7 +28,7 @@ from ..token_linear import TokenLinear
 from ..layer_norm import LayerNorm
 
 from ..utilities.network_initialization import InitWeights_He
-from .common2d import Convolution, DropPath, get_dwconv_layer
+from .common2d import Convolution, DropPath, get_dwconv_layer, residual_drop_path
 from .ssnd import SSND
 
 
@@ -248,7 +248,7 @@ class VSSBlock(nn.Module):
 
     def forward(self, input: torch.Tensor):
         input = permute(self.gsc(permute(input, self.spatial_dims, reverse=True)), self.spatial_dims)
-        return input + self.drop_path(self.self_attention(self.ln_1(input)))
+        return residual_drop_path(input, self.self_attention(self.ln_1(input)), self.drop_path)
 
 
 class VSSLayer(nn.Module):

@@ -132,3 +132,27 @@ def test_whole_net_training_step(hip_lib, name):
     # seg_layers are never used and get no gradient (the X^2Net plugins therefore cannot use plain torch DDP)
     unused = [n for n, p in net.named_parameters() if p.grad is None]
     assert all("vssm_decoder.seg_layers" in n for n in unused), unused[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,in_dtype,x_dtype", [(0.0, torch.float32, torch.float32), (0.3, torch.float32, torch.float16),
+                                                 (0.3, torch.float16, torch.float16), (0.5, torch.float32, torch.float32)])
+def test_residual_drop_path_matches_torch_ops(hip_lib, p, in_dtype, x_dtype):
+    """fused `input + drop_path(x)` (csrc/residual.hip) against the op-by-op form with the same RNG state"""
+    from nnuzoo_amd.nets.common2d import DropPath, residual_drop_path
+    g = torch.Generator().manual_seed(3)
+    inp = torch.randn(6, 5, 7, 16, generator=g).to(in_dtype).cuda()
+    x = torch.randn(6, 5, 7, 16, generator=g).to(x_dtype).cuda()
+    dout = torch.randn(6, 5, 7, 16, generator=g).cuda()
+    dp = DropPath(p).train()
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        a, b = inp.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        out = residual_drop_path(a, b, dp) if fused else a + dp(b)
+        out.backward(dout.to(out.dtype))
+        res.append((out.detach().float(), a.grad.float(), b.grad.float(), out.dtype))
+    assert res[0][3] == res[1][3]
+    tol = 1e-6 if x_dtype == torch.float32 else 4e-3
+    for u, v in zip(res[0][:3], res[1][:3]):
+        assert torch.allclose(u, v, rtol=tol, atol=tol * max(1.0, v.abs().max().item())), (u - v).abs().max().item()
