@@ -443,10 +443,15 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
       sdB[i] = 0.f;
       sdC[i] = 0.f;
     }
-    if (XS)
-      for (int i = threadIdx.x; i < a.R * SS_CL; i += SS_NW * 64) sdDt[i] = 0.f;
   }
   __syncthreads();
+  // cross-scan: d dt[r][t] = sum_d Wdt[kd][r] dd_d[t] summed over the wave's channels in registers (R <= 8 rows x 4 steps),
+  // folded over the four waves once per workgroup (ds_add_f32 per row and lane was the slow part of this mode)
+  float accDt[XS && FINAL ? SS_RMAX : 1][SS_KI];
+#pragma unroll
+  for (int rr = 0; rr < (XS && FINAL ? SS_RMAX : 1); ++rr)
+#pragma unroll
+    for (int i = 0; i < SS_KI; ++i) accDt[rr][i] = 0.f;
 
   for (; r < r_end; r += SS_NW) {
     const int kd = k * a.Dg + r;
@@ -583,20 +588,21 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
         store4(a.ddelta + row * a.L, t, a.L, vec, dd);
       } else {
         // delta = Wdt[kd][:] . dt[:, t]:  dWdt[kd][r] = sum_t dd_t dt[r][t] (per-(row, chunk) partial, summed by the
-        // finalize kernel);  d dt[r][t] += Wdt[kd][r] dd_t, reduced over the group's channels in LDS (the waves work
-        // on different rows at the same time: LDS atomics, 4 R per lane per row)
-        for (int rr = 0; rr < a.R; ++rr) {
-          const f32x4 dv = *reinterpret_cast<const f32x4*>(sDt + rr * SS_DTP + lane * SS_KI);
-          float sw_ = 0.f;
-          const float w = swv[48 + rr];
+        // finalize kernel);  d dt[r][t] += Wdt[kd][r] dd_t, summed over this wave's channels in registers
 #pragma unroll
-          for (int i = 0; i < SS_KI; ++i) {
-            sw_ += dd[i] * dv[i];
-            __hip_atomic_fetch_add(sdDt + rr * SS_CL + lane * SS_KI + i, w * dd[i], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int rr = 0; rr < SS_RMAX; ++rr) {
+          if (rr < a.R) {  // wave-uniform
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(sDt + rr * SS_DTP + lane * SS_KI);
+            float sw_ = 0.f;
+            const float w = swv[48 + rr];
+#pragma unroll
+            for (int i = 0; i < SS_KI; ++i) {
+              sw_ += dd[i] * dv[i];
+              accDt[rr][i] += w * dd[i];
+            }
+            sw_ = wave_sum_to_lane63(sw_);
+            if (lane == 63) a.S[(row * SS_N + 2 + rr) * a.nchunks + c] = sw_;
           }
-          sw_ = wave_sum(sw_);
-          if (lane == 0) a.S[(row * SS_N + 2 + rr) * a.nchunks + c] = sw_;
         }
       }
       sdb = wave_sum(sdb);
@@ -628,6 +634,21 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
       }
     }
     if (XS) {
+      // fold the four waves' register sums into the LDS tile: wave 0 stores, waves 1..3 add in turn
+      for (int w = 0; w < SS_NW; ++w) {
+        if (wave == w) {
+#pragma unroll
+          for (int rr = 0; rr < SS_RMAX; ++rr) {
+            if (rr < a.R) {
+              f32x4* pT = reinterpret_cast<f32x4*>(sdDt + rr * SS_CL + lane * SS_KI);
+              f32x4 v = {accDt[rr][0], accDt[rr][1], accDt[rr][2], accDt[rr][3]};
+              if (w > 0) v += *pT;
+              *pT = v;
+            }
+          }
+        }
+        __syncthreads();
+      }
       float* gT = a.xs_dP + pk_off;
       for (int i = threadIdx.x; i < a.R * SS_CL; i += SS_NW * 64) {
         const int rr = i / SS_CL, tt = i % SS_CL;
