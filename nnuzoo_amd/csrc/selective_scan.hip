@@ -485,7 +485,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
     const float* hin = swv + 16;
     const float* gin = swv + 32;
     // The 4 waves of the workgroup walk the states in a skewed order (wave w starts at n = 4w) and meet at a
-    // barrier after every state: at any moment they update DIFFERENT rows of the dB/dC accumulation tiles, so the
+    // barrier after every 4th state: at any moment they update DIFFERENT rows of the dB/dC accumulation tiles, so the
     // cross-channel reduction is a plain LDS read-modify-write (ds_add_f32 atomics measured ~4x slower in total).
     for (int j = 0; j < SS_N; ++j) {
       const int n = FINAL ? ((j + 4 * wave) & (SS_N - 1)) : j;
@@ -570,7 +570,9 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
       // kernel sums over chunks and batch: no contended atomic (and no vector-memory wait) inside this loop
       dAn = wave_sum_to_lane63(dAn);
       if (lane == 63) a.P[(row * SS_N + n) * a.nchunks + c] = dAn;
-      __syncthreads();  // keeps the waves' skewed n-order disjoint (all waves run the same trip counts)
+      // keeps the waves' skewed n-order disjoint (all waves run the same trip counts).  A barrier every 4th state is
+      // enough: between two barriers wave w touches rows 4(k + w) .. 4(k + w) + 3 (mod 16), disjoint for the four waves
+      if ((j & 3) == 3) __syncthreads();
     }
     if (FINAL) {
       float sdb = 0.f, sdD = 0.f;
