@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Sequence, Tuple
 
 from ._lib import ConvDesc, NNZ_MAX_GROUPS, NNZ_MAX_TAPS

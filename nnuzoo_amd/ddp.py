@@ -16,7 +16,7 @@ per-collective latency (~20-30 us) negligible while still giving 6-8 collectives
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 import torch.distributed as dist

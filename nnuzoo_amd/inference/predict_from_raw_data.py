@@ -18,13 +18,12 @@ MI355X-first differences (results are bit-identical to the reference loop given 
 from __future__ import annotations
 
 import itertools
-from typing import List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 from torch import nn
 
-from .. import _lib
 from .._lib import call, ptr, stream_ptr
 from .sliding_window_prediction import compute_gaussian, compute_steps_for_sliding_window, pad_to_tile
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..mamba_block import mamba_inner_fn, mamba_inner_fn_no_out_proj
+from ..mamba_block import mamba_inner_fn_no_out_proj
 
 
 def _s4d_real_log(d_inner, d_state, device):

@@ -16,7 +16,7 @@ from __future__ import annotations
 import itertools
 import math
 from functools import partial
-from typing import Callable, List, Tuple, Union
+from typing import Callable, List, Tuple
 
 import numpy as np
 import torch

@@ -24,7 +24,7 @@ from ..layer_norm import LayerNorm
 
 from ..utilities.network_initialization import InitWeights_He
 from ..window_attention import window_attention_core
-from .common2d import Convolution, PatchExpand, PatchMerging2D, _upsample_like, get_dwconv_layer
+from .common2d import Convolution, PatchExpand, PatchMerging2D, get_dwconv_layer
 from .common2d import RSU4F as _RSU4F
 from .m2net import _U2Forward, _heads
 

@@ -11,7 +11,6 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
 from ._lib import call, load, ptr, stream_ptr
 
 

@@ -12,7 +12,7 @@ tensors raise (the CPU restatement of the reference formulas is oracle/losses.py
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Optional, Tuple
+from typing import Any, Callable, Tuple
 
 import torch
 from torch import nn

@@ -19,7 +19,7 @@ xGMI, overlapped with the explicit backward schedule) instead of torch DDP's aut
 from __future__ import annotations
 
 import inspect
-from typing import List, Optional, Tuple, Union
+from typing import List, Union
 
 import numpy as np
 import torch
