@@ -137,3 +137,67 @@ def test_token_linear_chunking_and_cpu_path():
     x = torch.randn(5, 4)
     assert torch.equal(lin(x), torch.nn.functional.linear(x, lin.weight, lin.bias))
     assert list(lin.state_dict()) == ["weight", "bias"]
+
+
+def test_ctypes_signatures_match_the_header_declarations():
+    """every ctypes signature has the arity and the per-position kind (pointer / int / long / float) of its
+    declaration in include/nnuzoo_hip.h - a drifted table would corrupt arguments silently"""
+    from nnuzoo_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "nnuzoo_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    decls = re.findall(r"\b(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\((.*?)\)\s*;", txt, flags=re.S)
+    assert len(decls) == len(_lib.SIGNATURES)
+
+    def kind_of_decl(p):
+        p = " ".join(p.split())
+        if "*" in p:
+            return "ptr"
+        if re.search(r"\bfloat\b", p):
+            return "float"
+        if re.search(r"\blong\b", p):
+            return "long"
+        assert re.search(r"\bint\b", p), p
+        return "int"
+
+    def kind_of_ctype(t):
+        return {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int: "int", ctypes.c_long: "long", ctypes.c_float: "float"}.get(
+            t, "ptr" if isinstance(t, type) and issubclass(t, ctypes._Pointer) else str(t))
+
+    for name, params in decls:
+        plist = [p for p in params.split(",") if p.strip() and p.strip() != "void"]
+        sig = _lib.SIGNATURES[name]
+        assert len(plist) == len(sig), (name, len(plist), len(sig))
+        for i, (p, t) in enumerate(zip(plist, sig)):
+            assert kind_of_decl(p) == kind_of_ctype(t), (name, i, p.strip(), t)
+
+
+def test_header_matches_the_extern_c_definitions():
+    """include/nnuzoo_hip.h against the `extern "C"` definitions in nnuzoo_amd/csrc/*.hip: same functions, same arity,
+    same per-position kind"""
+    def strip(txt):
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        return re.sub(r"//[^\n]*", "", txt)
+
+    def kinds(params):
+        out = []
+        for p in params.split(","):
+            p = " ".join(p.split())
+            if not p or p == "void":
+                continue
+            out.append("ptr" if "*" in p else "float" if re.search(r"\bfloat\b", p) else
+                       "long" if re.search(r"\blong\b", p) else "int")
+        return out
+
+    hdr = strip(open(os.path.join(ROOT, "include", "nnuzoo_hip.h")).read())
+    declared = {n: kinds(p) for n, p in re.findall(r"\b(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\((.*?)\)\s*;", hdr, flags=re.S)}
+    defined = {}
+    csrc = os.path.join(ROOT, "nnuzoo_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            src = strip(open(os.path.join(csrc, f)).read())
+            for n, p in re.findall(r'extern\s+"C"\s+(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*\{', src, flags=re.S):
+                defined[n] = kinds(p)
+    assert sorted(declared) == sorted(defined), set(declared) ^ set(defined)
+    for n in declared:
+        assert declared[n] == defined[n], (n, declared[n], defined[n])
