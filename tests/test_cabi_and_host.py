@@ -201,3 +201,29 @@ def test_header_matches_the_extern_c_definitions():
     assert sorted(declared) == sorted(defined), set(declared) ^ set(defined)
     for n in declared:
         assert declared[n] == defined[n], (n, declared[n], defined[n])
+
+
+def test_python_call_sites_pass_the_declared_number_of_arguments():
+    """static check of every `call("nnz_...", ...)` in the package and the tools: the positional argument count equals
+    the ctypes signature's (a missing / extra argument would shift every later one)"""
+    import ast
+    from nnuzoo_amd import _lib
+    checked = 0
+    for base in ("nnuzoo_amd", "tools", "tests"):
+        for root, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if not f.endswith(".py"):
+                    continue
+                tree = ast.parse(open(os.path.join(root, f)).read())
+                for node in ast.walk(tree):
+                    if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "call" \
+                            and node.args and isinstance(node.args[0], ast.Constant) \
+                            and isinstance(node.args[0].value, str) and node.args[0].value.startswith("nnz_"):
+                        if any(isinstance(a, ast.Starred) for a in node.args):
+                            continue
+                        name = node.args[0].value
+                        assert name in _lib.SIGNATURES, (f, name)
+                        assert len(node.args) - 1 == len(_lib.SIGNATURES[name]), \
+                            (os.path.join(root, f), node.lineno, name, len(node.args) - 1, len(_lib.SIGNATURES[name]))
+                        checked += 1
+    assert checked >= 40
