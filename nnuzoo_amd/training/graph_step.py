@@ -1,10 +1,13 @@
 """hipGraph capture of the forward + loss + backward part of a training step.
 
-The zoo models issue ~15 000 small kernels per step (profiles/r01_m2net_step_window.txt): eager launch overhead, not
-GPU time, sets the step time.  MI355X-first answer (task brief: "capture launch-bound inner loops in hipGraphs"):
+The zoo models issue 7 000 - 10 000 small kernels per step (profiles/r01_m2net_step_kernels_v6.txt): eager launch
+overhead, not GPU time, sets the step time.  MI355X-first answer (task brief: "capture launch-bound inner loops in hipGraphs"):
 record the step once on a side stream and replay it as ONE graph launch.  torch.cuda.CUDAGraph is hipGraph on ROCm;
-our C-ABI launchers are capture-safe by construction (stream-ordered, allocation-free, no host sync;
-include/nnuzoo_hip.h conventions).
+our C-ABI launchers are capture-safe by construction (stream-ordered, allocation-free, no host sync, and no
+hipMemsetAsync: a captured memset node replays with a corrupted fill pattern on this stack once the process has made
+further allocations - every zeroing is a kernel, csrc/common.hpp zero_async; tests/test_graph_replay_gpu.py).
+Still opt-in: library ops inside the captured region (ATen's multi-block reductions, MIOpen's fp32 convs) use that
+memset themselves.
 
 What is captured: zero-grad-free forward, loss, (scaled) backward into static .grad buffers.  What stays eager: the
 GradScaler unscale / inf check, clip_grad_norm_, optimizer step and the loss read-back - the reference's train_step
