@@ -99,11 +99,12 @@ int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const flo
  * nnz_sgd_chunk_fill: parameter and momentum pointers of <= 16384 elements + their gradient offset in the arena):
  *   g = grad * inv_scale * min(1, max_norm / (sqrt(sumsq) * inv_scale + 1e-6)) + weight_decay * p
  *   buf = momentum * buf + g;  p -= lr * (g + momentum * buf)        (buf starts at 0 == torch's first-step rule)
- * nothing is written when stats2[1] > 0 or the sum of squares is not finite.  inv_scale_device may be NULL (1). */
+ * nothing is written when stats2[1] > 0 or the sum of squares is not finite; in the latter case stats2[1] is set to 1
+ * so that the caller's found_inf flag reports the skip.  inv_scale_device may be NULL (1). */
 int nnz_sgd_chunk_bytes(void);
 int nnz_sgd_chunk_fill(void* out_host, float* param, float* momentum, long arena_offset, int n);
 int nnz_grad_sumsq_nonfinite(const float* grads, long n, float* out2_zeroed, void* stream);
-int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* arena, const float* stats2,
+int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* arena, float* stats2,
                            const float* inv_scale_device, float max_norm, float lr, float momentum, float weight_decay,
                            int first_step, void* stream);
 

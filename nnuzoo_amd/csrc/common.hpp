@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -87,7 +89,7 @@ __device__ __forceinline__ T* pin_uniform(T* ptr) {
 
 // Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used anywhere in this library: captured into a hipGraph it
 // becomes a fill node whose pattern staging the runtime releases after capture - replays after later allocations then
-// fill with whatever landed there (measured on ROCm 7.2 / MI355X, tools/dbg/dbg_graph_memset2.py: NaNs in dbeta).
+// fill with whatever landed there (measured on ROCm 7.2 / MI355X, tools/probes/graph_memset_repro.py: NaNs in dbeta).
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void zero_fill_kernel(u32x4* __restrict__ p, size_t nvec, uint32_t* __restrict__ tail,
                                                         int ntail) {
@@ -117,6 +119,27 @@ inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
                ntail);
   }
   return hipGetLastError();
+}
+
+// Dynamic-LDS opt-in above 64 KB (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE function attribute.  One
+// cache per kernel instantiation remembers the largest size registered on each device; atomics make concurrent host
+// threads safe (the worst case is a redundant, idempotent hipFuncSetAttribute call).
+struct DynLdsCache {
+  static constexpr int MAX_DEV = 32;
+  std::atomic<int> granted[MAX_DEV];
+};
+inline hipError_t ensure_dyn_lds(const void* kern, int lds_bytes, DynLdsCache& cache) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const bool cached = dev >= 0 && dev < DynLdsCache::MAX_DEV;
+  if (cached && lds_bytes <= cache.granted[dev].load(std::memory_order_acquire)) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess || !cached) return e;
+  int seen = cache.granted[dev].load(std::memory_order_relaxed);
+  while (seen < lds_bytes && !cache.granted[dev].compare_exchange_weak(seen, lds_bytes, std::memory_order_release)) {
+  }
+  return hipSuccess;
 }
 
 }  // namespace nnz

@@ -392,12 +392,10 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   p.gy = p.d.Cout / (32 * NB);
   p.gz = p.d.N * p.d.ngroups;
   auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G>;
-  static int attr_lds = 0;  // per instantiation: largest dynamic LDS size registered so far
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static DynLdsCache lds_cache;  // per instantiation, per device
+  {
+    hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_cache);
     if (e != hipSuccess) return (int)e;
-    attr_lds = lds;
   }
   const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
   NNZ_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, p);

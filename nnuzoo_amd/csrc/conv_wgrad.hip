@@ -317,12 +317,10 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchO
   p.splits = best;
   const int splits = best;
   auto kern = conv_wgrad_kernel<TD, TH, TW, LPT_BOX, MAXT, G>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static DynLdsCache lds_cache;  // per instantiation, per device
+  {
+    hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_cache);
     if (e != hipSuccess) return (int)e;
-    attr_lds = lds;
   }
   if (!p.part && !pre_zeroed) {
     hipError_t e = nnz::zero_async(p.dw, sizeof(float) * (size_t)p.d.ntaps_total * p.d.Cin * p.d.Cout, stream);

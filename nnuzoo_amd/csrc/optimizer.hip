@@ -56,12 +56,18 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void sgd_nesterov_kernel(const SgdChunk* __restrict__ chunks,
                                                            const float* __restrict__ arena,
-                                                           const float* __restrict__ stats2,
+                                                           float* __restrict__ stats2,
                                                            const float* __restrict__ inv_scale_dev, float max_norm,
                                                            float lr, float momentum, float wd, int first_step) {
   // sum of squares of the scaled gradients; a non-finite sum also marks the step as skipped (overflowed squares)
   const float ss = stats2[0];
-  if (stats2[1] > 0.f || !(ss == ss) || __builtin_isinf(ss)) return;  // GradScaler semantics: leave params and momentum
+  const bool overflow = !(ss == ss) || __builtin_isinf(ss);
+  if (stats2[1] > 0.f || overflow) {  // GradScaler semantics: leave params and momentum
+    // finite gradients whose squares overflowed: the caller's found_inf flag (stats2[1]) must say "skipped" too, so
+    // that the loss scale backs off exactly when this kernel skipped (every workgroup takes this branch: no race)
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) stats2[1] = 1.f;
+    return;
+  }
   const float inv_scale = inv_scale_dev ? inv_scale_dev[0] : 1.f;
   const float total_norm = sqrtf(ss) * inv_scale;
   float clip = max_norm / (total_norm + 1e-6f);
@@ -103,7 +109,7 @@ extern "C" int nnz_grad_sumsq_nonfinite(const float* grads, long n, float* out2_
   return NNZ_OK;
 }
 
-extern "C" int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* arena, const float* stats2,
+extern "C" int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* arena, float* stats2,
                                       const float* inv_scale_device, float max_norm, float lr, float momentum,
                                       float weight_decay, int first_step, void* stream) {
   using namespace nnz;

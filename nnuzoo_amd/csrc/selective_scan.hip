@@ -779,13 +779,9 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
   } else {
     if ((e = nnz::zero_async(a.Gin, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
   }
-  static int attr_lds = 0;  // per instantiation (XS or not)
-  if (lds_final > attr_lds) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bwd_kernel<true, XS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_final);
-    if (e != hipSuccess) return (int)e;
-    attr_lds = lds_final;
-  }
+  static DynLdsCache lds_cache;  // per instantiation (XS or not), per device
+  e = ensure_dyn_lds(reinterpret_cast<const void*>(scan_bwd_kernel<true, XS>), lds_final, lds_cache);
+  if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH((scan_bwd_kernel<true, XS>), grid, dim3(SS_NW * 64), lds_final, s, a);
   NNZ_LAUNCH_CHECK();
   NNZ_LAUNCH(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA,

@@ -132,7 +132,13 @@ class nnUNetPredictor(object):
         return combos
 
     def _forward_logits(self, x: torch.Tensor) -> torch.Tensor:
-        out = self.network(x)
+        if hasattr(self.network, "grad_arena") or not x.is_cuda:
+            out = self.network(x)  # native HIP schedule: autocast numerics are built in
+        else:
+            # any other network class named in plans.json runs under torch.autocast exactly as in the reference
+            # (predict_from_raw_data.py:586 wraps the whole loop in `torch.autocast(device.type, enabled=True)`)
+            with torch.autocast("cuda", enabled=True):
+                out = self.network(x)
         if isinstance(out, (list, tuple)):
             out = out[0]
         if out.dtype != torch.float16:

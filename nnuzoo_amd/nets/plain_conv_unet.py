@@ -523,14 +523,20 @@ class PlainConvUNet(nn.Module):
                 ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
         grads[h.conv.weight] = gw
 
-    def _galloc(self, like: torch.Tensor) -> torch.Tensor:
+    def _galloc(self, like: torch.Tensor, unused: bool = False) -> torch.Tensor:
         """Gradient storage comes from ONE flat fp32 arena, filled in backward-completion order: the data-parallel
         reducer all-reduces contiguous slices of it in place (no flatten / unflatten copies) and the fused optimizer
-        (training/fused_sgd.py) reads it directly."""
+        (training/fused_sgd.py) reads it directly.  unused=True marks a parameter that took no part in the loss (the
+        seg head of a deep-supervision output with weight 0, deep_supervision.py:30): its slice stays zero so that the
+        arena layout and the reducer's slices are the same on every rank, but autograd receives None for it and the
+        fused optimizer skips it - like torch, which leaves a parameter without .grad untouched (no weight decay,
+        no momentum update)."""
         n = like.numel()
         off = self._arena_off
         self._arena_off = off + n
         self._arena_trace.append((like, off))
+        if unused:
+            self._arena_unused.add(id(like))
         return self._arena[off:off + n].view(like.shape)
 
     # ---- gradient arena of the most recent backward (fused optimizer) ---------------------------------------------
@@ -540,6 +546,10 @@ class PlainConvUNet(nn.Module):
     def grad_arena_layout(self):
         """[(parameter, element offset)] in arena order; fixed by the schedule (identical every step)"""
         return list(self._arena_layout)
+
+    def grad_arena_unused(self):
+        """ids of the parameters whose arena slice carries no gradient in the most recent backward"""
+        return frozenset(getattr(self, "_last_unused", ()))
 
     def release_grad_arena(self):
         self._last_arena = None
@@ -555,6 +565,7 @@ class PlainConvUNet(nn.Module):
         self._arena = torch.zeros(sum(p.numel() for p in self._params()), dtype=torch.float32, device=dev)
         self._arena_off = 0
         self._arena_trace = []
+        self._arena_unused = set()
         plan.pack_bwd.run()
         self._red_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
         if plan.wgrad_ws is None:
@@ -589,8 +600,8 @@ class PlainConvUNet(nn.Module):
                 if not have:
                     g_cur.zero_()
                 if self.decoder.deep_supervision or j == S - 2:
-                    grads[seg.weight] = self._galloc(seg.weight)
-                    grads[seg.bias] = self._galloc(seg.bias)
+                    grads[seg.weight] = self._galloc(seg.weight, unused=True)
+                    grads[seg.bias] = self._galloc(seg.bias, unused=True)
             # conv blocks of the stage, last to first
             blocks = plan.dec_blocks[j]
             g_act, g_ld = g_cur, C_
@@ -646,12 +657,15 @@ class PlainConvUNet(nn.Module):
         out = []
         for p in self._params():
             gp = grads.get(p)
-            out.append(gp if gp is not None else self._galloc(p))
+            if gp is None:
+                gp = self._galloc(p, unused=True)  # e.g. seg heads that were not evaluated (deep supervision off)
+            out.append(None if id(p) in self._arena_unused else gp)
         if self.grad_reducer is not None:
             self.grad_reducer.finish_arena(self._arena, self._arena_off)
         self._arena_layout = self._arena_trace
         self._last_arena = self._arena
-        self._red_all = self._wgrad_ws = self._arena = self._arena_trace = None
+        self._last_unused = self._arena_unused
+        self._red_all = self._wgrad_ws = self._arena = self._arena_trace = self._arena_unused = None
         return out
 
     # reference API (dynamic_network_architectures): used by the planner's VRAM estimate only

@@ -35,16 +35,20 @@ class FusedSGD(torch.optim.SGD):
         self._nchunks = 0
         self._links: List[Tuple[torch.nn.Parameter, int, int, int]] = []  # (param, offset, param ptr, momentum ptr)
         self._total = 0
+        self._unused = frozenset()
 
     # ---- availability --------------------------------------------------------------------------------------------
     def fused_available(self) -> bool:
         return getattr(self._net, "grad_arena", None) is not None and self._net.grad_arena() is not None
 
     # ---- flat momentum + chunk table (rebuilt when storage moved: first step, load_state_dict, .to()) ------------
-    def _build(self, layout: List[Tuple[torch.nn.Parameter, int]], device):
+    def _build(self, layout: List[Tuple[torch.nn.Parameter, int]], device, unused=frozenset()):
         lib = _lib.load()
         self._total = sum(p.numel() for p, _ in layout)
         flat = torch.zeros(self._total, dtype=torch.float32, device=device)
+        # parameters without a gradient in this schedule (unused deep-supervision heads): no momentum state, no update -
+        # what torch.optim.SGD does for a parameter whose .grad is None
+        layout = [(p, off) for p, off in layout if id(p) not in unused]
         for p, off in layout:
             st = self.state[p]
             old = st.get('momentum_buffer')
@@ -68,15 +72,20 @@ class FusedSGD(torch.optim.SGD):
         self._nchunks = len(recs)
         self._flat_mom = flat
         self._links = [(p, off, p.data_ptr(), self.state[p]['momentum_buffer'].data_ptr()) for p, off in layout]
+        self._unused = unused
 
     def _linked(self) -> bool:
-        if self._flat_mom is None:
+        if self._flat_mom is None or self._unused != self._net_unused():
             return False
         for p, _, pptr, mptr in self._links:
             mb = self.state[p].get('momentum_buffer')
             if mb is None or mb.data_ptr() != mptr or p.data_ptr() != pptr:
                 return False
         return True
+
+    def _net_unused(self):
+        f = getattr(self._net, "grad_arena_unused", None)
+        return f() if f is not None else frozenset()
 
     # ---- the fused tail ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -87,7 +96,7 @@ class FusedSGD(torch.optim.SGD):
         if arena is None:
             raise _lib.HipCallError("FusedSGD.fused_step: the network has no gradient arena (run backward first)")
         if not self._linked():
-            self._build(self._net.grad_arena_layout(), arena.device)
+            self._build(self._net.grad_arena_layout(), arena.device, self._net_unused())
         g = self.param_groups[0]
         stats = torch.zeros(2, dtype=torch.float32, device=arena.device)
         call("nnz_grad_sumsq_nonfinite", ptr(arena), self._total, ptr(stats), stream_ptr())

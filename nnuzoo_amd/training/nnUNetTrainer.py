@@ -18,6 +18,7 @@ xGMI, overlapped with the explicit backward schedule) instead of torch DDP's aut
 """
 from __future__ import annotations
 
+import contextlib
 import inspect
 from typing import List, Union
 
@@ -254,6 +255,15 @@ class nnUNetTrainer:
         self.network.decoder.deep_supervision = enabled
 
     # ---- the hot loop ------------------------------------------------------------------------------------------
+    def _autocast_context(self):
+        """The native HIP schedule (a network with a gradient arena) already has the numerics of the reference's autocast
+        region - fp16 operands, fp32 accumulate - so nothing is wrapped around it.  Any other class resolved from
+        plans.json (get_network_from_plans locates arbitrary names) gets `torch.autocast` on cuda exactly as
+        nnUNetTrainer.py:1128 / :1178 do, instead of silently training in fp32 under an active GradScaler."""
+        if self.device.type != 'cuda' or hasattr(self.network, "grad_arena"):
+            return contextlib.nullcontext()
+        return torch.autocast('cuda', enabled=True)
+
     def train_step(self, batch: dict) -> dict:
         data = batch['data'].to(self.device, non_blocking=True)
         target = batch['target']
@@ -262,10 +272,9 @@ class nnUNetTrainer:
         else:
             target = target.to(self.device, non_blocking=True)
         self.optimizer.zero_grad(set_to_none=True)
-        # the HIP schedule has the numerics of the reference's autocast region (fp16 operands, fp32 accumulate),
-        # so no torch.autocast context is needed around it
-        output = self.network(data)
-        l = self.loss(output, target)
+        with self._autocast_context():
+            output = self.network(data)
+            l = self.loss(output, target)
         fused = isinstance(self.optimizer, FusedSGD) and self.use_fused_optimizer
         if self.grad_scaler is not None:
             self.grad_scaler.scale(l).backward()
@@ -298,7 +307,7 @@ class nnUNetTrainer:
             target = [i.to(self.device, non_blocking=True) for i in target]
         else:
             target = target.to(self.device, non_blocking=True)
-        with torch.no_grad():
+        with torch.no_grad(), self._autocast_context():
             output = self.network(data)
             l = self.loss(output, target)
         if self.enable_deep_supervision:

@@ -101,16 +101,23 @@ def deep_supervision_loss(outputs, targets, batch_dice, weights=None):
     return sum(w * dc_and_ce(o, t, batch_dice) for w, o, t in zip(weights, outputs, targets) if w != 0)
 
 
-def tp_fp_fn_hard(logits: torch.Tensor, target: torch.Tensor):
-    """Online-Dice statistics of validation_step (nnUNetTrainer.py:1201-1221: argmax -> one-hot scatter ->
-    get_tp_fp_fn_tn, dice.py:122-180, label-map target, no mask): float32 tp / fp / fn per class."""
+def tp_fp_fn_hard(logits: torch.Tensor, target: torch.Tensor, ignore_label=None):
+    """Online-Dice statistics of validation_step (nnUNetTrainer.py:1188-1221: argmax -> one-hot scatter ->
+    get_tp_fp_fn_tn, dice.py:122-180, label-map target; with an ignore label the mask `target != ignore` multiplies
+    every term and ignored voxels are relabelled 0 first, :1199-1203): float32 tp / fp / fn per class.
+    Pinned by tests/golden/tp_fp_fn.npz (outputs of the reference's own get_tp_fp_fn_tn)."""
     axes = [0] + list(range(2, logits.ndim))
     seg = logits.argmax(1)[:, None]
     onehot = torch.zeros(logits.shape, dtype=torch.float32)
     onehot.scatter_(1, seg, 1)
+    target = target.clone()
+    mask = torch.ones(target.shape, dtype=torch.float32)
+    if ignore_label is not None:
+        mask = (target != ignore_label).float()
+        target[target == ignore_label] = 0
     y = torch.zeros(logits.shape, dtype=torch.bool)
     y.scatter_(1, target.long(), 1)
-    tp = (onehot * y).sum(axes)
-    fp = (onehot * (~y)).sum(axes)
-    fn = ((1 - onehot) * y).sum(axes)
+    tp = (onehot * y * mask).sum(axes)
+    fp = (onehot * (~y) * mask).sum(axes)
+    fn = ((1 - onehot) * y * mask).sum(axes)
     return tp, fp, fn

@@ -1,6 +1,6 @@
 """hipGraph safety of the C-ABI launchers (hipGraph): a captured launch sequence must replay correctly
 after the process has made further allocations.  Regression test for the round-1 finding that a captured hipMemsetAsync
-node replays with a corrupted fill pattern (tools/dbg/dbg_graph_memset2.py): every zeroing in the library is a kernel."""
+node replays with a corrupted fill pattern (tools/probes/graph_memset_repro.py): every zeroing in the library is a kernel."""
 import pytest
 import torch
 

@@ -71,6 +71,28 @@ def test_argmax_tp_fp_fn_matches_reference_formula(hip_lib, shape, dtype):
 
 
 @pytest.mark.parametrize("tag", ["2d", "3d"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_validation_statistics_match_reference_golden(hip_lib, tag, dtype):
+    """nnz_argmax_tp_fp_fn / nnz_region_tp_fp_fn against tests/golden/tp_fp_fn.npz: the outputs of the reference's own
+    get_tp_fp_fn_tn (dice.py:122-180) driven as validation_step drives it (nnUNetTrainer.py:1188-1216) - label maps
+    with exact ties, ignore label, regions with and without the ignore channel.  Exact counts (the golden logits are
+    multiples of 0.5, so the fp16 copy is the same number)."""
+    import os
+    from nnuzoo_amd import hip_ops as ops
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tp_fp_fn.npz"))
+    logits = torch.from_numpy(z[f"{tag}_logits"]).to(dtype).cuda()
+    def stack(t):
+        return torch.stack([v.cpu().float() for v in t]).numpy()
+    assert np.array_equal(stack(ops.argmax_tp_fp_fn(logits, torch.from_numpy(z[f"{tag}_target"]).cuda())),
+                          z[f"{tag}_plain"])
+    assert np.array_equal(stack(ops.argmax_tp_fp_fn(logits, torch.from_numpy(z[f"{tag}_target_ignore"]).cuda(),
+                                                    int(z[f"{tag}_ignore_label"]))), z[f"{tag}_ignore"])
+    r, ig = torch.from_numpy(z[f"{tag}_regions"]), torch.from_numpy(z[f"{tag}_regions_ignore_channel"])
+    assert np.array_equal(stack(ops.region_tp_fp_fn(logits, r.cuda())), z[f"{tag}_regions_plain"])
+    assert np.array_equal(stack(ops.region_tp_fp_fn(logits, torch.cat([r, ig], 1).cuda())), z[f"{tag}_regions_masked"])
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
 def test_ignore_label_matches_reference_golden(hip_lib, tag):
     """fused kernel with ignore_label against the reference's DC_and_CE_loss(ignore_label=C) fixtures: loss, gradient
     (zero on ignored voxels), the all-ignored batch, and the validation statistics with the same mask"""

@@ -96,3 +96,21 @@ def test_region_loss_oracle_vs_reference_golden(tag):
         (gr,) = torch.autograd.grad(l, xx)
         assert abs(float(l.detach()) - float(g[f"{name}_loss"])) < 1e-6
         assert np.allclose(gr.numpy(), g[f"{name}_dlogits"], atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_tp_fp_fn_oracle_vs_reference_golden(tag):
+    """oracle.losses.tp_fp_fn_hard / region_tp_fp_fn against the outputs of the reference's own get_tp_fp_fn_tn driven
+    as validation_step drives it (tests/golden/tp_fp_fn.npz, tools/make_golden.py:gen_tp_fp_fn); exact counts"""
+    z = np.load(os.path.join(G, "tp_fp_fn.npz"))
+    logits = torch.from_numpy(z[f"{tag}_logits"])
+    got = torch.stack(OL.tp_fp_fn_hard(logits, torch.from_numpy(z[f"{tag}_target"]))).numpy()
+    assert np.array_equal(got, z[f"{tag}_plain"])
+    assert got[0].sum() + got[2].sum() == z[f"{tag}_target"].size          # every voxel is a TP or an FN of its class
+    got = torch.stack(OL.tp_fp_fn_hard(logits, torch.from_numpy(z[f"{tag}_target_ignore"]),
+                                       int(z[f"{tag}_ignore_label"]))).numpy()
+    assert np.array_equal(got, z[f"{tag}_ignore"])
+    r, ig = torch.from_numpy(z[f"{tag}_regions"]), torch.from_numpy(z[f"{tag}_regions_ignore_channel"])
+    assert np.array_equal(torch.stack(OL.region_tp_fp_fn(logits, r, False)).numpy(), z[f"{tag}_regions_plain"])
+    assert np.array_equal(torch.stack(OL.region_tp_fp_fn(logits, torch.cat([r, ig], 1), True)).numpy(),
+                          z[f"{tag}_regions_masked"])

@@ -106,6 +106,52 @@ def gen_losses():
                             dlogits=g_ig.numpy(), loss_all_ignored=l_all.detach().numpy(), ignore_label=np.array(C))
 
 
+def gen_tp_fp_fn():
+    """Online-Dice statistics of validation_step: the reference's own get_tp_fp_fn_tn (training/loss/dice.py:122-180,
+    imported as-is) driven exactly as nnUNetTrainer.validation_step does (nnUNetTrainer.py:1188-1216): argmax -> one-hot
+    scatter (label maps, optional ignore label -> mask, target[ignore] = 0) or sigmoid > 0.5 (regions, optional ignore
+    channel), axes = [0] + spatial.  Logits contain exact ties (argmax takes the first maximum)."""
+    from nnunetv2.training.loss.dice import get_tp_fp_fn_tn
+    out = {}
+    for tag, (shape, C) in {"3d": ((2, 7, 9, 10), 3), "2d": ((3, 17, 23), 5)}.items():
+        g = torch.Generator().manual_seed(23)
+        B, sp = shape[0], shape[1:]
+        logits = torch.round(torch.randn(B, C, *sp, generator=g) * 2) / 2          # coarse values: many exact ties
+        target = torch.randint(0, C, (B, 1, *sp), generator=g).to(torch.int16)
+        axes = [0] + list(range(2, logits.ndim))
+
+        def label_stats(tgt, ignore_label):
+            output_seg = logits.argmax(1)[:, None]
+            onehot = torch.zeros(logits.shape, dtype=torch.float32)
+            onehot.scatter_(1, output_seg, 1)
+            tgt = tgt.clone()
+            mask = None
+            if ignore_label is not None:
+                mask = (tgt != ignore_label).float()
+                tgt[tgt == ignore_label] = 0
+            tp, fp, fn, _ = get_tp_fp_fn_tn(onehot, tgt, axes=axes, mask=mask)
+            return np.stack([tp.numpy(), fp.numpy(), fn.numpy()])
+
+        out[f"{tag}_logits"], out[f"{tag}_target"] = logits.numpy(), target.numpy()
+        out[f"{tag}_plain"] = label_stats(target, None)
+        tgt_ig = target.clone()
+        tgt_ig[torch.rand(target.shape, generator=g) < 0.25] = C
+        out[f"{tag}_target_ignore"], out[f"{tag}_ignore_label"] = tgt_ig.numpy(), np.array(C)
+        out[f"{tag}_ignore"] = label_stats(tgt_ig, C)
+        # regions
+        regions = (torch.rand(B, C, *sp, generator=g) < 0.4).to(torch.int16)
+        ign = (torch.rand(B, 1, *sp, generator=g) < 0.2).to(torch.int16)
+        pred = (torch.sigmoid(logits) > 0.5).long()
+        tp, fp, fn, _ = get_tp_fp_fn_tn(pred, regions.bool(), axes=axes, mask=None)
+        out[f"{tag}_regions"], out[f"{tag}_regions_ignore_channel"] = regions.numpy(), ign.numpy()
+        out[f"{tag}_regions_plain"] = np.stack([tp.numpy(), fp.numpy(), fn.numpy()])
+        tgt = torch.cat([regions, ign], 1)
+        mask = 1 - tgt[:, -1:]
+        tp, fp, fn, _ = get_tp_fp_fn_tn(pred, tgt[:, :-1].bool(), axes=axes, mask=mask)
+        out[f"{tag}_regions_masked"] = np.stack([tp.numpy(), fp.numpy(), fn.numpy()])
+    np.savez_compressed(os.path.join(OUT, "tp_fp_fn.npz"), **out)
+
+
 def gen_region_losses():
     """DC_and_BCE_loss (region-based training) from the reference's module: plain and with the ignore-mask channel"""
     from nnunetv2.training.loss.compound_losses import DC_and_BCE_loss
@@ -373,6 +419,7 @@ if __name__ == "__main__":
     if "loss" in which:
         gen_losses()
         gen_region_losses()
+        gen_tp_fp_fn()
     if "attn" in which:
         gen_window_attention()
     if "ss2d" in which:
