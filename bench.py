@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py - training patches/s of the nnU-Net hot path on MI355X (BASELINE.json metric, config[1]).
+"""bench.py - training patches/s of the nnU-Net hot path on MI355X (BASELINE.json metric: "training patches/sec/GPU +
+Dice vs ref, 3D nnUNet 128^3 & SS2D2Net 512^2").
 
-One "step" = nnUNetTrainer.train_step on one batch of synthetic 1x128^3 patches (batch 2 per GPU): forward of the
-3d_fullres PlainConvUNet, deep-supervision Dice+CE loss, backward, GradScaler unscale, clip_grad_norm_(12), SGD
-step, loss read-back - the step of /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1112-1144.
-Inputs are resident in HBM when the timed region starts.
+Primary leg (the contract's `value`, BASELINE configs[1]): one "step" = nnUNetTrainer.train_step on one batch of
+synthetic 1x128^3 patches (batch 2 per GPU): forward of the 3d_fullres PlainConvUNet, deep-supervision Dice+CE loss,
+backward, GradScaler unscale, clip_grad_norm_(12), SGD step, loss read-back - the step of
+/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1112-1144.  Inputs are resident in HBM when the timed
+region starts.
+
+Secondary leg (`secondary`, BASELINE configs[2], N = 1 only): nnUNetTrainerM2Net.train_step (M2Net = SS2D^2Net,
+/root/reference/nnunetv2/nets/m2net.py:805-971, trainer nnUNetTrainerM2Net.py) on synthetic 1x512^2 patches, batch 2,
+eager, with the roofline of its dominant kernel family (the cross-scan backward, HBM-bound by SURVEY.md 8d).
 
     python bench.py --gpus N --steps K --warmup W
 (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; weak scaling: 2 patches per GPU.)
-Prints ONE JSON line on rank 0 (contract in the task description) carrying `roofline` (dominant kernel =
-conv_box_kernel, MFMA-bound; algorithmic FLOPs / HIP-event time of its launches inside the timed region) and
-`cpu_baseline` (the CPU oracle timed on this host's cores, bounded sample).
+Prints ONE JSON line on rank 0 carrying `roofline` (dominant kernel conv_box_kernel, MFMA-bound; algorithmic FLOPs /
+HIP-event time of its launches inside the timed region), `cpu_baseline` (the CPU oracle, warmed, timed on this host's
+cores on a bounded sample), `secondary` and `dice` (protocol results of record).
 """
 import argparse
 import json
@@ -26,26 +32,37 @@ import torch
 import torch.distributed as dist
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0                # same guide: HBM3E ~8 TB/s
 
 
-def cpu_baseline(edge: int = 64):
-    """One full training step of the CPU oracle (reference-equivalent torch-CPU path: fp32, no autocast, all host
-    threads as run_training.py:256-260 does for -device cpu) on ONE patch of edge^3, scaled to 128^3 by voxels."""
-    import multiprocessing
+def host_threads():
+    """threads for the CPU legs: the physical cores this process may use (SMT siblings only oversubscribe the fp32 conv
+    kernels - round 1 timed a cold, 256-thread step and understated the CPU path tenfold)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        smt = open("/sys/devices/system/cpu/smt/active").read().strip() == "1"
+    except OSError:
+        smt = False
+    return max(1, n // 2 if smt else n), n
+
+
+def cpu_baseline(edge: int = 64, timed_steps: int = 2):
+    """Full training steps of the CPU oracle (reference-equivalent torch-CPU path: fp32, no autocast) on ONE
+    patch of edge^3: one untimed warm-up step, then `timed_steps` timed ones; scaled to 128^3 by voxel count."""
     from oracle.plain_conv_unet import OraclePlainConvUNet, planner_arch_kwargs
     from oracle.losses import deep_supervision_loss
     from nnuzoo_amd.synthetic import synthetic_batch
     from nnuzoo_amd.utilities.network_initialization import InitWeights_He
-    cores = multiprocessing.cpu_count()
-    torch.set_num_threads(cores)
+    threads, logical = host_threads()
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     net = OraclePlainConvUNet(1, num_classes=2, **planner_arch_kwargs(3, 6, [32, 64, 128, 256, 320, 320]))
     net.apply(InitWeights_He(1e-2))
     opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
     scales = [[1 / 2 ** i] * 3 for i in range(5)]
+    b = synthetic_batch(1, (edge, edge, edge), scales, seed=7)
 
-    def step(e):
-        b = synthetic_batch(1, (e, e, e), scales, seed=7)
+    def step():
         opt.zero_grad(set_to_none=True)
         out = net(b['data'])
         l = deep_supervision_loss(out, b['target'], batch_dice=False)
@@ -54,29 +71,121 @@ def cpu_baseline(edge: int = 64):
         opt.step()
         return float(l)
 
-    # thread-pool / allocator warm-up on a few small convolutions: a full warm-up step would double the ~100 s this
-    # sample takes (64^3 is the smallest cube the 6-stage net accepts in training); primitive set-up is < 2 % of the step
-    with torch.no_grad():
-        w = torch.randn(32, 32, 3, 3, 3)
-        for _ in range(3):
-            torch.nn.functional.conv3d(torch.randn(1, 32, 32, 32, 32), w, padding=1)
     t0 = time.perf_counter()
-    step(edge)
+    step()
+    warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(timed_steps):
+        step()
+    dt = (time.perf_counter() - t0) / timed_steps
+    return {"value": (1.0 / dt) * (edge / 128.0) ** 3, "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"CPU oracle, full fp32 train step (fwd+loss+bwd+clip+SGD) on one {edge}^3 patch: 1 warm-up step "
+                      f"({warm:.1f} s) + {timed_steps} timed steps ({dt:.2f} s each), scaled to 128^3 by voxel count; torch "
+                      f"{torch.__version__} CPU, {threads} threads ({logical} logical CPUs visible)"}
+
+
+def cpu_scan_baseline(L: int = 8192):
+    """SS2D^2Net has no CPU implementation in the reference (its scan is a CUDA extension): the comparator
+    is the semantics of selective_scan_ref - a time loop over L - timed forward-only on one call shape and extrapolated
+    linearly in state updates to M2Net's 80 calls per forward (5.4 G (b, d, n, t) updates per sample).  An upper bound
+    for any CPU step: the rest of the network and the backward are not in it."""
+    from oracle.selective_scan import selective_scan_torch
+    threads, _ = host_threads()
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    Bt, K, D, N = 2, 4, 32, 16
+    u = torch.randn(Bt, K * D, L, generator=g)
+    delta = torch.randn(Bt, K * D, L, generator=g) * 0.5
+    A = -torch.rand(K * D, N, generator=g) - 0.1
+    Bm, Cm = torch.randn(Bt, K, N, L, generator=g), torch.randn(Bt, K, N, L, generator=g)
+    with torch.no_grad():
+        selective_scan_torch(u[..., :256], delta[..., :256], A, Bm[..., :256], Cm[..., :256], None, None, True)
+        t0 = time.perf_counter()
+        selective_scan_torch(u, delta, A, Bm, Cm, torch.ones(K * D), torch.zeros(K * D), True)
+        dt = time.perf_counter() - t0
+    updates = Bt * K * D * N * L
+    rate = updates / dt
+    per_sample_fwd = 5.4e9 / rate
+    return {"value": 1.0 / per_sample_fwd, "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"oracle selective scan (selective_scan_ref semantics), forward only, (2, 128, 16, {L}) in {dt:.2f} s = "
+                      f"{rate / 1e6:.1f} M state-updates/s; extrapolated to the 5.4 G updates of one M2Net 512^2 forward "
+                      f"sample - scan forward ONLY, an upper bound on any CPU step rate"}
+
+
+def _profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def run_secondary(steps: int, warmup: int):
+    """BASELINE configs[2]: M2Net (SS2D^2Net) 1x512^2, batch 2, nnUNetTrainerM2Net.train_step (autocast step, AdamW)"""
+    from nnuzoo_amd import hip_ops
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerM2Net
+    size, batch = 512, 2
+    plans, cfg, dj = nnunet_plans(2, (size, size), batch_size=batch)
+    torch.manual_seed(0)
+    tr = nnUNetTrainerM2Net(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    b = synthetic_batch(batch, (size, size), tr._get_deep_supervision_scales(), seed=3)
+    b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+    losses = []
+    for _ in range(warmup):
+        losses.append(float(tr.train_step(b)["loss"]))
+    hip_ops.TIMER.enabled = True
+    hip_ops.TIMER.records = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(float(tr.train_step(b)["loss"]))
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    patches_per_s = (1.0 / dt) * (edge / 128.0) ** 3
-    return {"value": patches_per_s, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"1 full fp32 train step (fwd+loss+bwd+clip+SGD) of the CPU oracle on one {edge}^3 patch "
-                      f"({dt:.1f} s), scaled to 128^3 by voxel count; torch {torch.__version__} CPU, {cores} threads"}
+    hip_ops.TIMER.enabled = False
+    summ = hip_ops.TIMER.summary()
+    hip_ops.TIMER.records = []
+    if not all(np.isfinite(losses)):
+        raise SystemExit(f"non-finite loss in the secondary bench: {losses}")
+    roof = None
+    if "ss2d_scan_bwd" in summ:
+        n, by, sec = summ["ss2d_scan_bwd"]
+        ach = by / sec / 1e9
+        roof = {"bound": "hbm", "kernel": "ss2d cross-scan backward (scan_bwd_kernel passes + carry + finalize per call)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "launches_per_step": n // steps, "avg_launch_us": round(sec / n * 1e6, 2),
+                "bytes_per_launch": by / n, "ms_per_step": round(sec / steps * 1e3, 3)}
+        if "ss2d_scan_fwd" in summ:
+            n2, by2, sec2 = summ["ss2d_scan_fwd"]
+            roof["fwd_achieved"] = round(by2 / sec2 / 1e9, 1)
+            roof["fwd_ms_per_step"] = round(sec2 / steps * 1e3, 3)
+    out = {"metric": "training patches/sec, SS2D2Net (M2Net) 1x512^2 patches", "value": round(batch * steps / dt, 3),
+           "unit": "patches/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+           "dtype": "f32 scan / f16 autocast elsewhere (GradScaler)",
+           "config": {"workload": "M2Net (SS2D^2Net) 2d, synthetic 1x512^2 patches, batch 2, deep supervision, full "
+                                  "nnUNetTrainerM2Net.train_step (AdamW), eager"},
+           "final_loss": round(losses[-1], 5), "roofline": roof,
+           "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    dz = _profile_json("r02_dice_parity_m2netp_128.json") or _profile_json("r01_dice_parity_m2netp_128.json")
+    if dz:
+        out["dice"] = {"hip": round(dz["dice_fused"], 5), "ref_formulation": round(dz["dice_reference_formulation"], 5),
+                       "abs_delta": round(dz["abs_delta"], 5),
+                       "source": "profiles/*dice_parity_m2netp_128.json (tools/dice_parity_zoo.py: M2NetP 128^2, 80 "
+                                 "identical steps; protocol result of record, not re-run here)"}
+    del tr
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)     # SURVEY.md 8d: >= 100 timed, >= 20 warm-up iterations
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timer", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--secondary-steps", type=int, default=20)
+    ap.add_argument("--secondary-warmup", type=int, default=5)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,6 +194,7 @@ def main():
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} "
                          f"(WORLD_SIZE={world})")
+    backend = os.environ.get("NNZ_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local_rank)
     force_ddp = os.environ.get("NNZ_BENCH_FORCE_DDP") == "1"  # exercise the RCCL reducer path even at world size 1
     if world > 1 or force_ddp:
@@ -92,7 +202,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
 
     from nnuzoo_amd import hip_ops
     from nnuzoo_amd.synthetic import conv_flops_forward, nnunet_plans, synthetic_batch
@@ -126,6 +236,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     hip_ops.TIMER.enabled = False
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
+    reducer = getattr(trainer.network, "grad_reducer", None)
+    buckets_per_step = getattr(reducer, "buckets_last_step", None)
     if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -138,22 +251,25 @@ def main():
         arch = plans["configurations"][cfg]["architecture"]["arch_kwargs"]
         fwd_flops = sum(conv_flops_forward(arch, patch).values())
         summ = hip_ops.TIMER.summary()
+        hip_ops.TIMER.records = []
         roof = None
         if "conv_box_kernel" in summ:
             n, fl, sec = summ["conv_box_kernel"]
             ach = fl / sec / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "conv_box_kernel_hbm_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic, tsrc = None, None
+            tj = _profile_json("conv_box_kernel_hbm_traffic.json")
+            if tj:
+                traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/conv_box_kernel_hbm_traffic.json (separate " \
+                    "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, tools/pmc_traffic.py)"
             roof = {"bound": "mfma", "kernel": "conv_box_kernel (fprop + dgrad launches of the step)",
                     "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "launches_per_step": n // a.steps, "avg_launch_us": round(sec / n * 1e6, 2),
-                    "flops_per_launch": fl / n}
+                    "flops_per_launch": fl / n, "ms_per_step": round(sec / a.steps * 1e3, 3)}
             if "conv_wgrad_kernel" in summ:
                 n2, fl2, sec2 = summ["conv_wgrad_kernel"]
                 roof["wgrad_kernel_achieved"] = round(fl2 / sec2 / 1e12, 2)
+                roof["wgrad_ms_per_step"] = round(sec2 / a.steps * 1e3, 3)
         line = {
             "metric": "training patches/sec, 3D nnUNet (PlainConvUNet 3d_fullres) 1x128^3 patches",
             "value": round(patches / dt, 3), "unit": "patches/s", "n_gpus": world, "steps": a.steps,
@@ -166,12 +282,28 @@ def main():
                        "conv_gflop_per_sample_fwd": round(fwd_flops / 1e9, 1)},
             "patches_per_s_per_gpu": round(patches / dt / world, 3),
             "final_loss": round(losses[-1], 5),
+            "rccl_ranks": rccl_ranks, "allreduce_buckets_per_step": buckets_per_step,
             "roofline": roof,
         }
+        dz = _profile_json("r02_dice_parity_64cubed.json") or _profile_json("r01_dice_parity_64cubed.json")
+        if dz:
+            line["dice"] = {"hip": round(dz["dice_hip"], 5), "oracle": round(dz["dice_oracle"], 5),
+                            "abs_delta": round(dz["abs_delta"], 6), "mask_agreement": round(dz["mask_agreement"], 5),
+                            "source": "profiles/*dice_parity_64cubed.json (tools/dice_parity.py: 100 identical steps at "
+                                      "64^3 on HIP and on the CPU oracle, 16 held-out patches; protocol result of "
+                                      "record, not re-run here - the CPU side takes ~10 min)"}
+    del trainer, batch
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not a.no_secondary:
+            line["secondary"] = run_secondary(a.secondary_steps, a.secondary_warmup)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            if "secondary" in line:
+                line["secondary"]["cpu_baseline"] = cpu_scan_baseline()
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -31,6 +31,10 @@ class BucketedAllReduce:
         self._pending: List[torch.Tensor] = []
         self._pending_bytes = 0
         self._inflight = []
+        self._arena_lo = 0
+        self._slices = []              # (lo, hi) element ranges of the arena collectives launched in the current step
+        self.slices_last_step = []     # ... of the most recent finished step (bench.py / tests read these)
+        self.buckets_last_step = 0
 
     def _launch(self):
         if not self._pending:
@@ -55,22 +59,26 @@ class BucketedAllReduce:
     def stage_done_arena(self, arena: torch.Tensor, filled: int):
         """Everything in arena[:filled] is final.  Launch an in-place all-reduce for the not-yet-reduced part once it
         is at least one bucket long."""
-        lo = getattr(self, "_arena_lo", 0)
+        lo = self._arena_lo
         if (filled - lo) * arena.element_size() >= self.bucket_bytes:
             h = dist.all_reduce(arena[lo:filled], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._inflight.append((h, None, None))
+            self._slices.append((lo, filled))
             self._arena_lo = filled
 
     def finish_arena(self, arena: torch.Tensor, filled: int):
-        lo = getattr(self, "_arena_lo", 0)
+        lo = self._arena_lo
         if filled > lo:
             h = dist.all_reduce(arena[lo:filled], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._inflight.append((h, None, None))
+            self._slices.append((lo, filled))
         for h, _, _ in self._inflight:
             h.wait()
         arena[:filled].mul_(1.0 / self.world)
         self._inflight = []
         self._arena_lo = 0
+        self.slices_last_step, self._slices = self._slices, []
+        self.buckets_last_step = len(self.slices_last_step)
 
     def finish(self, all_grads: List[torch.Tensor]):
         """Flush, wait for every collective and write the averaged gradients back in place."""
@@ -92,7 +100,7 @@ class BucketedAllReduce:
         self._seen = set()
 
 
-def attach_bucketed_allreduce(network, process_group=None, bucket_bytes: int = 16 << 20) -> BucketedAllReduce:
+def attach_bucketed_allreduce(network, process_group=None, bucket_bytes: int = 12 << 20) -> BucketedAllReduce:
     """DDP for nnuzoo_amd networks: broadcast rank-0 parameters, then reduce gradients inside backward."""
     params = list(network.parameters())
     with torch.no_grad():

@@ -44,11 +44,12 @@ class PreparedTable:
 
 
 class LaunchTimer:
-    """HIP-event timing of the MFMA conv launches on the stream they run on (bench.py's roofline leg)."""
+    """HIP-event timing of the dominant kernels' launches on the stream they run on (bench.py's roofline legs).  `work`
+    is the algorithmic work of the launch: FLOPs for the MFMA-bound conv kernels, HBM bytes for the scan kernels."""
 
     def __init__(self):
         self.enabled = False
-        self.records = []  # (kind, flops, start, end)
+        self.records = []  # (kind, work, start, end)
 
     def wrap(self, kind: str, flops: float, fn):
         if not self.enabled:

@@ -522,6 +522,9 @@ class PlainConvUNet(nn.Module):
                     dx_out.zero_()  # k1 s2 axes: odd input positions are outside every output's footprint
                 ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
         grads[h.conv.weight] = gw
+        if self.grad_reducer is not None:
+            # hand-over point per conv block (finer than per stage: the 320-channel decoder stage alone is 37 MB)
+            self.grad_reducer.stage_done_arena(self._arena, self._arena_off)
 
     def _galloc(self, like: torch.Tensor, unused: bool = False) -> torch.Tensor:
         """Gradient storage comes from ONE flat fp32 arena, filled in backward-completion order: the data-parallel

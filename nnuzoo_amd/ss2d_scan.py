@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 
 from ._lib import call, load, ptr, stream_ptr
+from .hip_ops import TIMER
 
 N_STATE = 16
 MAX_DT_RANK = 8
@@ -119,8 +120,11 @@ class _SS2DCrossScan(torch.autograd.Function):
             y = torch.empty((B, K, Di, L), **f32)
             state = torch.empty(lib.nnz_selective_scan_state_floats(B, K * Di, L), **f32)
             ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f32)
-            call("nnz_ss2d_scan_forward", ptr(x2), ptr(P), ptr(Wdt), ptr(A), ptr(Dv), ptr(bias), ptr(y), ptr(state),
-                 ptr(ws), B, Di, R, L, 1, 1, stream_ptr())
+            # algorithmic HBM bytes of the cross-scan forward: both sources of u once, the dt / B / C
+            # rows of the four directions, y of the four directions
+            TIMER.wrap("ss2d_scan_fwd", 4.0 * B * L * (2 * Di + 4 * Cp + 4 * Di), lambda: call(
+                "nnz_ss2d_scan_forward", ptr(x2), ptr(P), ptr(Wdt), ptr(A), ptr(Dv), ptr(bias), ptr(y), ptr(state),
+                ptr(ws), B, Di, R, L, 1, 1, stream_ptr()))
             out = torch.empty((B, H, W, Di), **f32)
             call("nnz_ss2d_merge", ptr(y), ptr(out), B, Di, H, W, stream_ptr())
         ctx.save_for_backward(x2, P, Wst, A, Wdt, bias, Dv, state)
@@ -145,9 +149,12 @@ class _SS2DCrossScan(torch.autograd.Function):
             dD, dbias = torch.empty_like(Dv), torch.empty_like(bias)
             gstate = torch.empty_like(state)
             ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f32)
-            call("nnz_ss2d_scan_backward", ptr(x2), ptr(P), ptr(Wdt), ptr(A), ptr(Dv), ptr(bias), ptr(dy2), ptr(state),
-                 ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B, Di, R, L, 1, 1,
-                 stream_ptr())
+            # algorithmic bytes of the backward: reads u (2 sources), projections (4 dirs), dy (2 token orders); writes
+            # du (4 dirs) and the projection gradient (4 dirs)
+            TIMER.wrap("ss2d_scan_bwd", 4.0 * B * L * (2 * Di + 4 * Cp + 2 * Di + 4 * Di + 4 * Cp), lambda: call(
+                "nnz_ss2d_scan_backward", ptr(x2), ptr(P), ptr(Wdt), ptr(A), ptr(Dv), ptr(bias), ptr(dy2), ptr(state),
+                ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B, Di, R, L, 1, 1,
+                stream_ptr()))
             dx2 = torch.matmul(Wst.transpose(-1, -2), dP)                        # (2, B, Di, L)
             # + the scans' own input gradients: direction k = 2j + s belongs to source s
             dx2 += du.view(B, 2, 2, Di, L).sum(1).transpose(0, 1)

@@ -42,8 +42,10 @@ class FusedSGD(torch.optim.SGD):
         return getattr(self._net, "grad_arena", None) is not None and self._net.grad_arena() is not None
 
     # ---- flat momentum + chunk table (rebuilt when storage moved: first step, load_state_dict, .to()) ------------
-    def _build(self, layout: List[Tuple[torch.nn.Parameter, int]], device, unused=frozenset()):
+    def _build(self, layout: List[Tuple[torch.nn.Parameter, int]], device, unused=None):
         lib = _lib.load()
+        if unused is None:
+            unused = self._net_unused()
         self._total = sum(p.numel() for p, _ in layout)
         flat = torch.zeros(self._total, dtype=torch.float32, device=device)
         # parameters without a gradient in this schedule (unused deep-supervision heads): no momentum state, no update -

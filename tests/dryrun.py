@@ -1,0 +1,65 @@
+"""Test helper: run the PlainConvUNet forward / backward SCHEDULE on CPU tensors with every kernel launch replaced by a
+host stand-in.  Nothing is computed - the stand-ins only fill the parameter-gradient buffers they are handed with a
+constant - so that schedule-level properties (gradient arena layout, reducer hand-over points, which parameters receive
+a gradient) can be tested without a GPU.  Product code never imports this."""
+import contextlib
+
+import torch
+
+from nnuzoo_amd.nets import plain_conv_unet as pcu
+
+
+class _NoPack:
+    def __init__(self, device):
+        self.jobs = []
+
+    def add(self, *a, **k):
+        self.jobs.append(a)
+
+    def run(self):
+        pass
+
+
+@contextlib.contextmanager
+def stub_kernel_launches(fill: float = 1.0):
+    ops = pcu.ops
+    saved = {}
+
+    def put(name, fn):
+        saved[name] = getattr(ops, name)
+        setattr(ops, name, fn)
+
+    def nop(*a, **k):
+        return None
+
+    def wgrad_to_grad(pt, boxed, plain, ws, grad, *a, **k):
+        grad.fill_(fill)
+
+    def stem_wgrad(x, dy, dw, *a, **k):
+        dw.fill_(fill)
+
+    def head_wgrad(x, g, gw, gb, *a, **k):
+        gw.fill_(fill)
+        gb.fill_(fill)
+
+    def norm_bwd(x, g, stats, gamma, beta, red, dx, *a, dgamma=None, dbeta=None, **k):
+        dgamma.fill_(fill)
+        dbeta.fill_(fill)
+
+    def stats(x, st, N, V, Cc, ldx, pre_zeroed=False):
+        st.zero_()
+        st[:, :, 0] = fill / N   # the transposed conv's bias gradient is the sum over samples of this column
+
+    try:
+        for n in ("stem_forward", "conv_tap_forward", "instnorm_lrelu_apply", "head_forward", "head_dgrad"):
+            put(n, nop)
+        put("instnorm_stats", stats)
+        put("conv_tap_wgrad_to_grad", wgrad_to_grad)
+        put("stem_wgrad", stem_wgrad)
+        put("head_wgrad", head_wgrad)
+        put("instnorm_lrelu_bwd", norm_bwd)
+        put("PackJobTable", _NoPack)
+        yield
+    finally:
+        for n, fn in saved.items():
+            setattr(ops, n, fn)
