@@ -95,9 +95,15 @@ struct ConvCfg {
 };
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
-template <int TD, int TH, int TW, int NB, int LPT_BOX, class G>
+// DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
+// One voxel fragment of INPUT plane d0 + p then feeds the MFMAs of the three depth taps (output planes p, p - 1, p - 2)
+// instead of being re-read from LDS for each: 6 voxel + 3 weight fragments per (kh, kw) for 12 MFMAs = 0.75 KB of LDS
+// reads per MFMA against 1.25 KB in the tap-by-tap loop.  With Cout = 32 there is only one N block, so this is the only
+// reuse a voxel fragment can get; it takes the LDS array from ~75 % to ~50 % busy on the full-resolution layers.
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false>
 __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   using C = ConvCfg<TD, TH, TW, NB>;
+  static_assert(!DRE || (TD == 8 && TH == 8 && TW == 8 && NB == 1), "depth-reuse loop: 8x8x8 tile, one cout block");
   const G geo(p.d);
   const BoxGeom<TD, TH, TW, G> bg(geo);
   const int ISD = geo.is(0), ISH = geo.is(1), ISW = geo.is(2);
@@ -168,9 +174,15 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   const int wn = wave / C::WAVES_M;
   int vox_off[C::WM];  // LDS byte offset of the lane's voxel row for a tap of even h offset (odd: ^ 16)
   int out_vox[C::WM];  // element offset of the lane's output voxel, -1 if masked
+  // tile-linear voxel index of fragment i of this wave.  Default: fragments are consecutive runs of 32 voxels.  DRE:
+  // fragment i = depth plane 4 (wm >> 1) + i, h rows 4 (wm & 1) .. + 3.
+  auto frag_voxel = [&](int i) -> int {
+    if constexpr (DRE) return ((4 * (wm >> 1) + i) * TH + 4 * (wm & 1) + (l31 >> 3)) * TW + (l31 & 7);
+    return (wm * C::WM + i) * 32 + l31;
+  };
 #pragma unroll
   for (int i = 0; i < C::WM; ++i) {
-    const int v = (wm * C::WM + i) * 32 + l31;
+    const int v = frag_voxel(i);
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
     const int base = (((td * ISD) * bg.BH + th * ISH) * bg.PW + tw) * 32;  // column tw of the (de-interleaved) image
     const int f = th & 1;
@@ -264,6 +276,47 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       for (int j = 0; j < C::WM; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
   };
 
+  // depth-reuse loop: per (kh, kw) row r the box offset without its depth part (lane r of rtab)
+  int rtab = 0;
+  if constexpr (DRE) {
+    for (int r = 0; r < 9; ++r) {
+      const nnz_conv_tap tp = p.d.taps[tb + r];
+      const int o1 = tp.off[1] - p.d.lo[1], o2 = tp.off[2] - p.d.lo[2];
+      const int enc = ((o1 * bg.PW + o2) * 32) | ((o1 & 1) << 4);
+      rtab = lane == r ? enc : rtab;
+    }
+  }
+  const int plane_bytes = bg.BH * bg.PW * 32;
+  // addresses: flip only toggles bit 4 of the lane's base (every other term is a multiple of 32), so the six planes and
+  // the three depth taps of a row are immediate offsets from ONE voxel base and ONE weight base per row
+  const int vb_even = vox_off[0], vb_odd = vox_off[0] ^ 16;
+  // a row (kh, kw) is processed in two halves so that only three voxel fragments per register set are live:
+  //   half A: weights of the three depth taps + input planes 0..2  -> 6 MFMAs;   half B: input planes 3..5 -> 6 MFMAs
+  auto load_a = [&](int r, f16x8 (&a)[3], f16x8 (&x)[3]) {
+    const int enc = __builtin_amdgcn_readlane(rtab, r);
+    const char* wrow = wl + w_lane + (r << 10);
+    const char* xrow = box + ((enc & 16) ? vb_odd : vb_even) + (enc & ~16);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const f16x8*>(wrow + (DFLIP ? 2 - q : q) * 9 * 1024);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const f16x8*>(xrow + pl * plane_bytes);
+  };
+  auto load_b = [&](int r, f16x8 (&x)[3]) {
+    const int enc = __builtin_amdgcn_readlane(rtab, r);
+    const char* xrow = box + ((enc & 16) ? vb_odd : vb_even) + (enc & ~16);
+#pragma unroll
+    for (int pl = 3; pl < 6; ++pl) x[pl - 3] = *reinterpret_cast<const f16x8*>(xrow + pl * plane_bytes);
+  };
+  auto mfma_half = [&](const f16x8 (&a)[3], const f16x8 (&x)[3], int pl0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int j = pl0 + i - q;  // output plane of (input plane pl0 + i, depth offset q)
+        if (j >= 0 && j < 4) acc[0][j] = mfma32(a[q], x[i], acc[0][j]);
+      }
+  };
+
   issue_loads(0);
   for (int kc = 0; kc < nkc; ++kc) {
     __syncthreads();  // all waves finished reading the previous slice
@@ -271,17 +324,49 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
     __syncthreads();
     if (kc + 1 < nkc) issue_loads(kc + 1);
 
-    // software pipeline over the taps: the LDS reads of tap t+1 are in flight while tap t's MFMAs issue
-    f16x8 a0[C::WN], b0[C::WM], a1[C::WN], b1[C::WM];
-    load_frags(0, a0, b0);
-    int t = 0;
-    for (; t + 2 <= nt; t += 2) {
-      load_frags(t + 1, a1, b1);
-      mfma_all(a0, b0);
-      if (t + 2 < nt) load_frags(t + 2, a0, b0);
-      mfma_all(a1, b1);
+    if constexpr (DRE) {
+      // Software pipeline by half rows: the reads of the NEXT half are issued as a group before the six MFMAs of the
+      // current one, so every MFMA's operands were requested ~200 cycles earlier.  The scheduling barriers keep the
+      // compiler from sinking the reads next to their uses (it does, to save registers, and then every MFMA waits on
+      // lgkmcnt(0) for a read issued just before it).
+      f16x8 a0[3], a1[3], xa[3], xb[3];
+      load_a(0, a0, xa);
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        load_b(r, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a0, xa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(r + 1, a1, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a0, xb, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(r + 1, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a1, xa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(r + 2, a0, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a1, xb, 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      load_b(8, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(a0, xa, 0);
+      mfma_half(a0, xb, 3);
+    } else {
+      // software pipeline over the taps: the LDS reads of tap t+1 are in flight while tap t's MFMAs issue
+      f16x8 a0[C::WN], b0[C::WM], a1[C::WN], b1[C::WM];
+      load_frags(0, a0, b0);
+      int t = 0;
+      for (; t + 2 <= nt; t += 2) {
+        load_frags(t + 1, a1, b1);
+        mfma_all(a0, b0);
+        if (t + 2 < nt) load_frags(t + 2, a0, b0);
+        mfma_all(a1, b1);
+      }
+      if (t < nt) mfma_all(a0, b0);
     }
-    if (t < nt) mfma_all(a0, b0);
   }
 
   // ---- epilogue: D[row = cout][col = voxel]; lane holds couts (r&3) + 8(r>>2) + 4hh of its voxel -----
@@ -296,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
     const int nbl = wn * C::WN + i;
 #pragma unroll
     for (int j = 0; j < C::WM; ++j) {
-      const int v = (wm * C::WM + j) * 32 + l31;
+      const int v = frag_voxel(j);
       char* row = smem + v * ROWB + (nbl * 32 + 4 * hh) * 2;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -369,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   }
 }
 
-template <int TD, int TH, int TW, int NB, int LPT_BOX, class G>
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false>
 static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   using C = ConvCfg<TD, TH, TW, NB>;
   ConvDev p = base;
@@ -391,7 +476,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   p.gx = p.tiles[0] * p.tiles[1] * p.tiles[2];
   p.gy = p.d.Cout / (32 * NB);
   p.gz = p.d.N * p.d.ngroups;
-  auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G>;
+  auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G, DRE, DFLIP>;
   static DynLdsCache lds_cache;  // per instantiation, per device
   {
     hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_cache);
@@ -412,6 +497,32 @@ static int launch_iso(const ConvDev& p, hipStream_t stream) {
   return launch_cfg<TD, TH, TW, NB, iso_lpt<TD, TH, TW, IS, EXT>(), GeoIso<IS, EXT>>(p, stream);
 }
 
+// Tuning knobs (diagnostics / per-layer experiments; defaults are the measured best).  nnz_conv_tuning(knob, value):
+//   0  depth-reuse loop for k3 s1 layers with Cout % 64 != 0 on >= 64^3 grids          (default 1)
+//   1  depth-reuse loop (one 32-cout block per workgroup) also for Cout % 64 == 0      (default 1)
+//      (only with >= 4 reduction slices, Cin >= 64: a 2-slice layer pays the doubled box staging of two workgroups
+//      per tile more than it gains - measured on dec0.0's data gradient, 32 -> 64 channels: 760 -> 680 TFLOP/s)
+//   2  smallest m-grid edge (cube root of the voxel count) that takes the depth-reuse loop (default 32)
+static int g_tuning[8] = {1, 1, 32, 0, 0, 0, 0, 0};
+
+// k3 s1 table in depth-major tap order whose three depth taps of every (kh, kw) row share their in-plane offset and sit
+// on box planes (0, 1, 2) [forward] or (2, 1, 0) [data gradient]: what the depth-reuse loop assumes.  Returns -1 if not.
+static int depth_reuse_flip(const nnz_conv_desc& d) {
+  if (d.ngroups != 1 || d.groups[0].ntaps != 27 || d.groups[0].tap_begin != 0) return -1;
+  for (int a = 0; a < 3; ++a)
+    if (d.in_stride[a] != 1 || d.out_stride[a] != 1 || d.ext[a] != 2) return -1;
+  const int first = d.taps[0].off[0] - d.lo[0];
+  if (first != 0 && first != 2) return -1;
+  const int flip = first == 2;
+  for (int r = 0; r < 9; ++r)
+    for (int q = 0; q < 3; ++q) {
+      const nnz_conv_tap& t = d.taps[q * 9 + r];
+      if (t.off[1] != d.taps[r].off[1] || t.off[2] != d.taps[r].off[2]) return -1;
+      if (t.off[0] - d.lo[0] != (flip ? 2 - q : q)) return -1;
+    }
+  return flip;
+}
+
 // isotropic 3-D plans (the tuned path: every box dimension is a compile-time constant)
 template <int IS, int EXT>
 static int launch_tile(const ConvDev& p, hipStream_t stream) {
@@ -419,6 +530,14 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
   const bool nb2 = (p.d.Cout % 64) == 0;
   if constexpr (IS == 1) {
     // big tile for the 32-channel full-resolution layers (more weight reuse per wave), otherwise 4x8x8
+    if constexpr (EXT == 2) {
+      const int flip = depth_reuse_flip(p.d);
+      const long edge = g_tuning[2];
+      if (flip >= 0 && mvox >= edge * edge * edge && ((!nb2 && g_tuning[0]) || (nb2 && g_tuning[1] && p.d.Cin >= 64))) {
+        if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true>(p, stream);
+        return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false>(p, stream);
+      }
+    }
     if (!nb2) {
       if (mvox >= 64 * 64 * 64) return launch_iso<8, 8, 8, 1, IS, EXT>(p, stream);
       return launch_iso<4, 8, 8, 1, IS, EXT>(p, stream);
@@ -468,6 +587,12 @@ static int launch_dyn(const ConvDev& p, hipStream_t stream) {
 
 extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void* w_packed, const float* bias,
                                           const nnz_conv_desc* desc, float* stats, void* stream);
+
+extern "C" int nnz_conv_tuning(int knob, int value) {
+  if (knob < 0 || knob >= 8) return NNZ_EINVAL;
+  nnz::g_tuning[knob] = value;
+  return NNZ_OK;
+}
 
 extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_packed, const float* bias,
                                     const nnz_conv_desc* desc, void* stream) {

@@ -36,7 +36,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--tuning", type=str, default="", help="comma list knob=value for nnz_conv_tuning (include/nnuzoo_hip.h)")
     a = ap.parse_args()
+    if a.tuning:
+        from nnuzoo_amd import _lib
+        for kv in a.tuning.split(","):
+            k, v = kv.split("=")
+            _lib.call("nnz_conv_tuning", int(k), int(v))
+        print("tuning:", a.tuning)
     N = 2
     dev = "cuda"
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
