@@ -114,6 +114,20 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
                            const float* inv_scale_device, float max_norm, float lr, float momentum, float weight_decay,
                            int first_step, void* stream);
 
+/* ---- token-major Linear layers with many tokens and few features (VSS / SSND in_proj, out_proj, patch merge / expand:
+ * /root/reference/nnunetv2/nets/m2net.py:97,103,258,300) under the autocast step: fp16 activations, fp32 master weight
+ * (converted while it is staged into LDS), fp32 accumulate, fp16 result.
+ * nnz_token_linear_forward: out[T][Mo] = in[T][Kr] A^T + bias with A = W[Mo][Kr] (transposed = 0: the forward) or
+ * A = W^T, W[Kr][Mo] (transposed = 1: the input gradient dX = dY W).  Kr in {16, 32, 64, 128, 256}; Mo % 8 == 0, <= 256;
+ * nnz_token_linear_supported(Kr, Mo) tells whether a shape is served (else -22 here; callers use the library GEMM).
+ * nnz_token_linear_wgrad: dW[N][K] += sum_t dy[t][n] x[t][k], db[n] += sum_t dy[t][n] (fp32, caller zeroes; db may be
+ * NULL); N, K multiples of 8 with (N/8)(K/8) <= 256. */
+int nnz_token_linear_forward(const void* in_f16, const float* W, const float* bias, void* out_f16, long T, int Kr, int Mo,
+                             int transposed, void* stream);
+int nnz_token_linear_supported(int Kr, int Mo);
+int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, float* dW, float* db, long T, int N, int K,
+                           void* stream);
+
 /* online-Dice statistics of the validation step (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 +
  * get_tp_fp_fn_tn, training/loss/dice.py:122-180, label-map targets): argmax over classes (first maximum on ties)
  * against the int16 label map in one read; counts_u64[c] = {tp, fp, fn} exact (zeroed by the call). */

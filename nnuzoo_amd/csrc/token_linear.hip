@@ -1,0 +1,298 @@
+// Token-major Linear layers with very many tokens and few features (gfx950): y[T][N] = x[T][K] W[N][K]^T + b.
+// These are the in_proj / out_proj / patch-merge `reduction` / patch `expand` Linears of the VSS / SSND blocks
+// (/root/reference/nnunetv2/nets/m2net.py:97,103,258,300; ssnd2net.py: same layers) under the autocast step of
+// nnUNetTrainerM2Net / SSND2Net (fp16 operands, fp32 accumulate, fp16 result): 16..256 features, up to 5 x 10^5 tokens.
+// A GEMM library sees M = tokens, N <= 256, K <= 256 and answers with a 64x64 or 16x16 macro tile and a K loop: 0.2-1 ms
+// per call where the data is 20-90 MB (15-60 us at HBM speed); the M2Net step made 480 such calls (30 ms of 144).
+//
+// Design (memory-bound, so: one pass over x, one over y, weights never re-read from HBM):
+//   * forward and input gradient are ONE kernel: out[T][Mo] = in[T][Kr] A[Mo][Kr]^T with A = W (forward) or A = W^T
+//     (input gradient).  A is tiny: it is staged once per workgroup into LDS as fp16 MFMA fragments straight from the fp32
+//     master parameter (no separate cast launch, no fp16 weight copy in HBM).
+//   * v_mfma_f32_32x32x16_f16 with A as the A operand (rows = output features) and TOKENS on the lanes (B operand): a
+//     lane's B fragment is 8 consecutive fp16 of its token's row = one 16-byte global load, no LDS staging for activations;
+//     waves are persistent over 32-token tiles and prefetch the next tile's rows under the current tile's MFMAs.
+//   * D comes out feature-major per lane (4 consecutive features of one token per accumulator quad); the tile is
+//     transposed through a per-wave LDS image so that global stores are whole 16-byte pieces in token-major order.
+//   * weight gradient dW[N][K] = sum_t dy[t][n] x[t][k] (+ bias gradient): 2 T N K <= ~1 GFLOP per call - plain fp32 FMAs
+//     on register tiles (8 x 8 per thread), token ranges split over workgroups, one fp32 atomic per entry and workgroup.
+#include "common.hpp"
+
+namespace nnz {
+
+struct TlArgs {
+  const f16* in;      // [T][Kr]
+  const float* W;     // fp32 master parameter [N][K] (torch layout)
+  const float* bias;  // [Mo] or null
+  f16* out;           // [T][Mo_real]
+  long T;
+  int Kr, Mo_real;    // reduction length, real number of output features (Mo_real <= 32 * MB)
+  int transposed;     // 0: A[m][kk] = W[m][kk] (ld = Kr); 1: A[m][kk] = W[kk][m] (ld = Mo_real)
+  int ntiles;
+};
+
+template <int MB, int KS>
+__global__ __launch_bounds__(256) void tl_fwd_kernel(TlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Mo = MB * 32, Kr = KS * 16;
+  constexpr int ROWB = Mo * 2 + 16;  // per-wave output image: bytes per token row (+16 spreads the b64 writes over banks)
+  char* sA = smem;                            // [MB][KS][32 rows][32 B], 16-byte halves swizzled by (row >> 4) & 1
+  char* sO = smem + MB * KS * 1024;           // [4 waves][32 tokens][ROWB]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  // ---- stage A (fp32 master -> fp16 fragments) -------------------------------------------------------------------
+  for (int e = tid; e < Mo * Kr; e += 256) {
+    int m, kk;
+    float v = 0.f;
+    if (!a.transposed) {
+      m = e / Kr; kk = e % Kr;                       // W[m][kk], kk contiguous
+      if (m < a.Mo_real) v = a.W[(long)m * Kr + kk];
+    } else {
+      kk = e / Mo; m = e % Mo;                       // W[kk][m], m contiguous
+      if (m < a.Mo_real) v = a.W[(long)kk * a.Mo_real + m];
+    }
+    const int mb = m >> 5, row = m & 31, ks = kk >> 4, k16 = kk & 15;
+    const int half = (k16 >> 3) ^ ((row >> 4) & 1);
+    *reinterpret_cast<f16*>(sA + ((mb * KS + ks) * 32 + row) * 32 + half * 16 + (k16 & 7) * 2) = (f16)v;
+  }
+  __syncthreads();
+  const int a_lane = l31 * 32 + ((hh ^ ((l31 >> 4) & 1)) << 4);
+  char* sOw = sO + wave * 32 * ROWB;
+
+  const int nwaves = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  auto load_tile = [&](int tl, f16x8 (&b)[KS]) {
+    const long t = (long)tl * 32 + l31;
+    const bool ok = tl < a.ntiles && t < a.T;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) v = *reinterpret_cast<const f16x8*>(a.in + t * Kr + ks * 16 + hh * 8);
+      b[ks] = v;
+    }
+  };
+  f16x8 bcur[KS], bnxt[KS];
+  load_tile(tile, bcur);
+  for (; tile < a.ntiles; tile += nwaves) {
+    load_tile(tile + nwaves, bnxt);
+    f32x16 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f16x8 af = *reinterpret_cast<const f16x8*>(sA + (mb * KS + ks) * 1024 + a_lane);
+        acc[mb] = mfma32(af, bcur[ks], acc[mb]);
+      }
+    }
+    // ---- epilogue: D[row = feature][col = token]; lane holds features (r&3) + 8(r>>2) + 4hh of token l31 ----------
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        const int f0 = mb * 32 + 8 * q + 4 * hh;
+        if (a.bias && f0 + 3 < a.Mo_real) bv = *reinterpret_cast<const f32x4*>(a.bias + f0);
+        f16x4 o = {(f16)(acc[mb][4 * q + 0] + bv[0]), (f16)(acc[mb][4 * q + 1] + bv[1]),
+                   (f16)(acc[mb][4 * q + 2] + bv[2]), (f16)(acc[mb][4 * q + 3] + bv[3])};
+        *reinterpret_cast<f16x4*>(sOw + l31 * ROWB + f0 * 2) = o;
+      }
+    // same-wave LDS: program order is enough (no barrier; the image is private to the wave)
+    const int ppr = a.Mo_real >> 3;  // 16-byte pieces per token row
+    const long tbase = (long)tile * 32;
+    for (int p = lane; p < 32 * ppr; p += 64) {
+      const int tk = p / ppr, c8 = p % ppr;
+      if (tbase + tk < a.T)
+        *reinterpret_cast<f16x8*>(a.out + (tbase + tk) * a.Mo_real + c8 * 8) =
+            *reinterpret_cast<const f16x8*>(sOw + tk * ROWB + c8 * 16);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnxt[ks];
+  }
+}
+
+template <int MB, int KS>
+static int launch_tl(const TlArgs& a, hipStream_t s) {
+  const int lds = MB * KS * 1024 + 4 * 32 * (MB * 64 + 16);
+  auto kern = tl_fwd_kernel<MB, KS>;
+  static DynLdsCache cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, cache);
+  if (e != hipSuccess) return (int)e;
+  int wgs = (a.ntiles + 3) / 4;
+  const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;
+  if (wgs > 256 * per_cu) wgs = 256 * per_cu;  // persistent waves: a few workgroups per CU
+  NNZ_LAUNCH(kern, dim3(wgs), dim3(256), lds, s, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+template <int MB>
+static int dispatch_ks(const TlArgs& a, int ks, hipStream_t s) {
+  switch (ks) {
+    case 1: return launch_tl<MB, 1>(a, s);
+    case 2: return launch_tl<MB, 2>(a, s);
+    case 4: return launch_tl<MB, 4>(a, s);
+    case 8: return launch_tl<MB, 8>(a, s);
+    case 16: return launch_tl<MB, 16>(a, s);
+  }
+  return NNZ_EINVAL;
+}
+
+// ---- weight (+ bias) gradient ------------------------------------------------------------------------------------
+struct TlWgArgs {
+  const f16* dy;  // [T][N]
+  const f16* x;   // [T][K]
+  float* dW;      // [N][K] fp32, pre-zeroed (atomic accumulation over workgroups)
+  float* db;      // [N] or null, pre-zeroed
+  long T;
+  int N, K;
+  long tokens_per_wg;
+};
+
+// thread = (token slice ts, 8x8 block of dW); TSL token slices of the workgroup run in parallel over its token range and
+// are folded through LDS at the end.  Rows of dy / x are broadcast LDS reads (16 bytes = 8 fp16 per operand and token).
+constexpr int TLW_TOK = 64;  // tokens staged per round
+
+__global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.N, K = a.K;
+  const int nbk = (N >> 3) * (K >> 3);         // 8x8 blocks of dW
+  const int TSL = 256 / nbk > 0 ? 256 / nbk : 1;  // token slices (>= 1); nbk <= 256 is checked by the launcher
+  f16* sdy = reinterpret_cast<f16*>(smem);                      // [TLW_TOK][N]
+  f16* sx = sdy + TLW_TOK * N;                                  // [TLW_TOK][K]
+  float* sred = reinterpret_cast<float*>(sx + TLW_TOK * K);     // [TSL][N*K] fold buffer (+ [TSL][N] bias)
+  const int tid = threadIdx.x;
+  const int blk = tid % nbk, ts = tid / nbk;
+  const bool active = ts < TSL;
+  const int n0 = (blk / (K >> 3)) * 8, k0 = (blk % (K >> 3)) * 8;
+  float acc[8][8];
+  float accb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    accb[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  }
+  const long t_begin = (long)blockIdx.x * a.tokens_per_wg;
+  long t_end = t_begin + a.tokens_per_wg;
+  if (t_end > a.T) t_end = a.T;
+  const int pn = N >> 3, pk = K >> 3;  // 16-byte pieces per row
+  for (long tb = t_begin; tb < t_end; tb += TLW_TOK) {
+    __syncthreads();
+    const int nt = (int)((t_end - tb) < TLW_TOK ? (t_end - tb) : TLW_TOK);
+    for (int p = tid; p < nt * pn; p += 256)
+      reinterpret_cast<f16x8*>(sdy)[p] = *reinterpret_cast<const f16x8*>(a.dy + tb * N + (long)p * 8);
+    for (int p = tid; p < nt * pk; p += 256)
+      reinterpret_cast<f16x8*>(sx)[p] = *reinterpret_cast<const f16x8*>(a.x + tb * K + (long)p * 8);
+    __syncthreads();
+    if (active) {
+      for (int tt = ts; tt < nt; tt += TSL) {
+        const f16x8 d8 = *reinterpret_cast<const f16x8*>(sdy + tt * N + n0);
+        const f16x8 x8 = *reinterpret_cast<const f16x8*>(sx + tt * K + k0);
+        float df[8], xf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          df[i] = (float)d8[i];
+          xf[i] = (float)x8[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (k0 == 0) accb[i] += df[i];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[i][j] += df[i] * xf[j];
+        }
+      }
+    }
+  }
+  // ---- fold the token slices, one atomic per entry -----------------------------------------------------------------
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sred[(long)ts * N * K + (n0 + i) * K + k0 + j] = acc[i][j];
+    if (k0 == 0)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sred[(long)TSL * N * K + ts * N + n0 + i] = accb[i];
+  }
+  __syncthreads();
+  for (int e = tid; e < N * K; e += 256) {
+    float v = 0.f;
+    for (int s_ = 0; s_ < TSL; ++s_) v += sred[(long)s_ * N * K + e];
+    atomicAdd(a.dW + e, v);
+  }
+  if (a.db)
+    for (int e = tid; e < N; e += 256) {
+      float v = 0.f;
+      for (int s_ = 0; s_ < TSL; ++s_) v += sred[(long)TSL * N * K + s_ * N + e];
+      atomicAdd(a.db + e, v);
+    }
+}
+
+}  // namespace nnz
+
+// out[T][Mo] (f16) = in[T][Kr] (f16) A^T + bias, A = W (transposed = 0: W is [Mo][Kr]) or W^T (transposed = 1: W is
+// [Kr][Mo]); W fp32.  Kr in {16, 32, 64, 128, 256}; Mo % 8 == 0, Mo <= 256, Mo padded to {32, 64, 128, 256} internally.
+extern "C" int nnz_token_linear_forward(const void* in_f16, const float* W, const float* bias, void* out_f16, long T,
+                                        int Kr, int Mo, int transposed, void* stream) {
+  using namespace nnz;
+  if (!in_f16 || !W || !out_f16 || T < 1 || Mo < 8 || Mo > 256 || (Mo & 7) || T > (1L << 36)) return NNZ_EINVAL;
+  if (Kr != 16 && Kr != 32 && Kr != 64 && Kr != 128 && Kr != 256) return NNZ_EINVAL;
+  const int mb = Mo <= 32 ? 1 : Mo <= 64 ? 2 : Mo <= 128 ? 4 : 8;
+  if (mb * 32 * Kr > 65536) return NNZ_EINVAL;  // A fragments in LDS: at most 128 KB of fp16 incl. the output images
+  // register budget: MB accumulators (16 VGPRs each) + two sets of KS token fragments (4 VGPRs each)
+  if (mb * 16 + 2 * (Kr / 16) * 4 > 208) return NNZ_EINVAL;
+  TlArgs a = {};
+  a.in = (const f16*)in_f16; a.W = W; a.bias = bias; a.out = (f16*)out_f16;
+  a.T = T; a.Kr = Kr; a.Mo_real = Mo; a.transposed = transposed;
+  a.ntiles = (int)((T + 31) / 32);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mb) {
+    case 1: return dispatch_ks<1>(a, Kr / 16, s);
+    case 2: return dispatch_ks<2>(a, Kr / 16, s);
+    case 4: return dispatch_ks<4>(a, Kr / 16, s);
+    case 8: return dispatch_ks<8>(a, Kr / 16, s);
+  }
+  return NNZ_EINVAL;
+}
+
+// 1 if nnz_token_linear_forward supports (Kr, Mo), else 0 (the host falls back to the library GEMM)
+extern "C" int nnz_token_linear_supported(int Kr, int Mo) {
+  if (Kr != 16 && Kr != 32 && Kr != 64 && Kr != 128 && Kr != 256) return 0;
+  if (Mo < 8 || Mo > 256 || (Mo & 7)) return 0;
+  const int mb = Mo <= 32 ? 1 : Mo <= 64 ? 2 : Mo <= 128 ? 4 : 8;
+  if (mb * 32 * Kr > 65536) return 0;
+  if (mb * 16 + 2 * (Kr / 16) * 4 > 208) return 0;
+  return 1;
+}
+
+// dW[N][K] += sum_t dy[t][n] x[t][k];  db[n] += sum_t dy[t][n]  (dW / db pre-zeroed fp32; N, K multiples of 8,
+// (N/8)(K/8) <= 256)
+extern "C" int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, float* dW, float* db, long T, int N, int K,
+                                      void* stream) {
+  using namespace nnz;
+  if (!dy_f16 || !x_f16 || !dW || T < 1 || (N & 7) || (K & 7) || N < 8 || K < 8) return NNZ_EINVAL;
+  const int nbk = (N >> 3) * (K >> 3);
+  if (nbk > 256) return NNZ_EINVAL;
+  const int TSL = 256 / nbk;
+  TlWgArgs a = {};
+  a.dy = (const f16*)dy_f16; a.x = (const f16*)x_f16; a.dW = dW; a.db = db;
+  a.T = T; a.N = N; a.K = K;
+  long wgs = (T + 2047) / 2048;           // >= 2048 tokens per workgroup keeps the atomics per entry below T / 2048
+  if (wgs > 1024) wgs = 1024;
+  if (wgs < 1) wgs = 1;
+  a.tokens_per_wg = ((T + wgs - 1) / wgs + TLW_TOK - 1) / TLW_TOK * TLW_TOK;
+  wgs = (T + a.tokens_per_wg - 1) / a.tokens_per_wg;
+  const size_t lds = (size_t)TLW_TOK * (N + K) * 2 + (size_t)TSL * (N * K + N) * 4;
+  if (lds > 160 * 1024) return NNZ_EINVAL;
+  static DynLdsCache cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(tl_wgrad_kernel), (int)lds, cache);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH(tl_wgrad_kernel, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

@@ -1,16 +1,24 @@
 """`TokenLinear`: nn.Linear (same parameters, state_dict, autocast numerics) for token-major activations with very many
 tokens and few features - the in_proj / out_proj / patch merge / expand layers of the VSS blocks at 512^2 (524 288 tokens
-x 16..128 features).  Forward and input gradient are the library GEMMs; the WEIGHT gradient dW = dY^T X is a (out x in)
-matrix of a few thousand entries contracted over 10^5..10^6 tokens, for which the library picks a 16x16 macro-tile
-without split-K and runs on a handful of workgroups (1 ms per call on MI355X; 10 such calls per M2Net step).  Here the
-token axis is cut into chunks: one batched GEMM over strided views (no copies) plus a small sum."""
+x 16..256 features; reference: nets/m2net.py:97,103,258,300).
+
+Under the fp16 autocast step the three products run on the hand-written kernels of csrc/token_linear.hip (one pass over
+the activations, weights staged once per workgroup from the fp32 master parameter - no weight cast launch): forward and
+input gradient are one MFMA kernel, the weight / bias gradient an fp32 register-tile kernel.  Shapes those kernels do not
+serve (features beyond 256, fp32 steps) keep the library GEMMs; there the WEIGHT gradient dW = dY^T X - a few thousand
+entries contracted over 10^5..10^6 tokens, for which the library picks a 16x16 macro-tile without split-K - is cut along
+the token axis into one batched GEMM over strided views plus a small sum."""
 from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
 MIN_TOKENS = 65536
+HIP_MIN_TOKENS = 1024   # below this the call is launch-bound either way
 MAX_FEATURES = 256
 
 
@@ -19,6 +27,57 @@ def _chunks(T: int) -> int:
     while nc < 128 and T % (nc * 2) == 0 and T // (nc * 2) >= 4096:
         nc *= 2
     return nc
+
+
+def _hip_ok(kr: int, mo: int) -> bool:
+    return bool(_lib.load().nnz_token_linear_supported(int(kr), int(mo)))
+
+
+class _HipTokenLinearFn(torch.autograd.Function):
+    """fp16 autocast path on csrc/token_linear.hip.  x: (..., K) fp16 contiguous device tensor; weight / bias fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, K = weight.shape
+        T = x.numel() // K
+        y = torch.empty((*x.shape[:-1], N), dtype=torch.float16, device=x.device)
+        call("nnz_token_linear_forward", ptr(x), ptr(weight), ptr(bias), ptr(y), T, K, N, 0, stream_ptr())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape
+        T = x.numel() // K
+        dy = dy if dy.dtype == torch.float16 else dy.to(torch.float16)
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if _hip_ok(N, K):
+                dx = torch.empty_like(x)
+                call("nnz_token_linear_forward", ptr(dy), ptr(weight), None, ptr(dx), T, N, K, 1, stream_ptr())
+            else:
+                dx = (dy.reshape(-1, N) @ weight.to(torch.float16)).view(x.shape)
+        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            if (N // 8) * (K // 8) <= 256:
+                buf = torch.zeros(N * K + N, dtype=torch.float32, device=x.device)
+                dw, dbv = buf[:N * K].view(N, K), buf[N * K:]
+                call("nnz_token_linear_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(dbv) if need_b else None, T, N, K,
+                     stream_ptr())
+                db = dbv if need_b else None
+            else:
+                dy2, x2 = dy.reshape(-1, N), x.reshape(-1, K)
+                nc = _chunks(T)
+                if nc > 1:
+                    dw = torch.bmm(dy2.view(nc, T // nc, N).transpose(1, 2), x2.view(nc, T // nc, K)).sum(
+                        0, dtype=torch.float32)
+                else:
+                    dw = (dy2.t() @ x2).float()
+                db = dy2.sum(0, dtype=torch.float32) if need_b else None
+        return dx, dw, db
 
 
 class _TallLinearFn(torch.autograd.Function):
@@ -62,6 +121,12 @@ class _TallLinearFn(torch.autograd.Function):
 class TokenLinear(nn.Linear):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         tokens = x.numel() // max(1, x.shape[-1])
+        if x.is_cuda and tokens >= HIP_MIN_TOKENS and x.is_contiguous() and self.weight.dtype == torch.float32 \
+                and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16 \
+                and x.dtype in (torch.float16, torch.float32) and self.in_features % 8 == 0 \
+                and _hip_ok(self.in_features, self.out_features):
+            xh = x if x.dtype == torch.float16 else x.to(torch.float16)
+            return _HipTokenLinearFn.apply(xh, self.weight, self.bias)
         if x.is_cuda and tokens >= MIN_TOKENS and self.in_features <= MAX_FEATURES and self.out_features <= MAX_FEATURES \
                 and x.is_contiguous() and x.dtype in (torch.float16, torch.float32):
             return _TallLinearFn.apply(x, self.weight, self.bias)
