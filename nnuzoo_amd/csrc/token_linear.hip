@@ -282,11 +282,13 @@ extern "C" int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, flo
   TlWgArgs a = {};
   a.dy = (const f16*)dy_f16; a.x = (const f16*)x_f16; a.dW = dW; a.db = db;
   a.T = T; a.N = N; a.K = K;
-  long wgs = (T + 2047) / 2048;           // >= 2048 tokens per workgroup keeps the atomics per entry below T / 2048
-  if (wgs > 1024) wgs = 1024;
-  if (wgs < 1) wgs = 1;
-  a.tokens_per_wg = ((T + wgs - 1) / wgs + TLW_TOK - 1) / TLW_TOK * TLW_TOK;
-  wgs = (T + a.tokens_per_wg - 1) / a.tokens_per_wg;
+  // ~512 workgroups (two per CU) whatever T is: the low-resolution levels have few tokens but large N x K, and a
+  // workgroup's serial loop is tokens x 64 FMAs per thread (the first version fixed 2048 tokens per workgroup: 16
+  // workgroups and 280 us for T = 32 768, N K = 16 384).  One fp32 atomic per entry and workgroup: <= 8 M per call.
+  long tpw = (T + 511) / 512;
+  tpw = (tpw + TLW_TOK - 1) / TLW_TOK * TLW_TOK;
+  a.tokens_per_wg = tpw;
+  long wgs = (T + tpw - 1) / tpw;
   const size_t lds = (size_t)TLW_TOK * (N + K) * 2 + (size_t)TSL * (N * K + N) * 4;
   if (lds > 160 * 1024) return NNZ_EINVAL;
   static DynLdsCache cache;

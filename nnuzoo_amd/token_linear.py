@@ -10,6 +10,8 @@ entries contracted over 10^5..10^6 tokens, for which the library picks a 16x16 m
 the token axis into one batched GEMM over strided views plus a small sum."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -19,6 +21,7 @@ from ._lib import call, ptr, stream_ptr
 
 MIN_TOKENS = 65536
 HIP_MIN_TOKENS = 1024   # below this the call is launch-bound either way
+USE_HIP_KERNELS = os.environ.get("NNZ_TOKEN_LINEAR", "1") != "0"   # A/B switch for measurements
 MAX_FEATURES = 256
 
 
@@ -121,7 +124,7 @@ class _TallLinearFn(torch.autograd.Function):
 class TokenLinear(nn.Linear):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         tokens = x.numel() // max(1, x.shape[-1])
-        if x.is_cuda and tokens >= HIP_MIN_TOKENS and x.is_contiguous() and self.weight.dtype == torch.float32 \
+        if USE_HIP_KERNELS and x.is_cuda and tokens >= HIP_MIN_TOKENS and x.is_contiguous() and self.weight.dtype == torch.float32 \
                 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16 \
                 and x.dtype in (torch.float16, torch.float32) and self.in_features % 8 == 0 \
                 and _hip_ok(self.in_features, self.out_features):
