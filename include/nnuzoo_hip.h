@@ -114,6 +114,17 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
                            const float* inv_scale_device, float max_norm, float lr, float momentum, float weight_decay,
                            int first_step, void* stream);
 
+/* ---- x_proj of the cross-scan SS2D block on channel-major fp32 activations (the einsum of SS2D.forward_core,
+ * /root/reference/nnunetv2/nets/m2net.py:179-184, in the two-source formulation of nnz_ss2d_scan_*):
+ *   forward     P[s][b][c][l]   = sum_d W[s][c][d] x2[s][b][d][l]                       c < C2 <= 80, Di % 32 == 0
+ *   backward_x  dx2[s][b][d][l] = sum_c W[s][c][d] dP[s][b][c][l] + du[b][s][d][l] + du[b][s+2][d][l]
+ *   backward_w  dW[s][c][d]    += sum_{b,l} dP[s][b][c][l] x2[s][b][d][l]     (fp32, caller zeroes; L % 64 == 0 and
+ *                                                                              ceil8(C2)/8 * Di/8 <= 256, else -22) */
+int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P, int B, int Di, int C2, long L, void* stream);
+int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const float* du, float* dx2, int B, int Di, int C2,
+                              long L, void* stream);
+int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L, void* stream);
+
 /* ---- token-major Linear layers with many tokens and few features (VSS / SSND in_proj, out_proj, patch merge / expand:
  * /root/reference/nnunetv2/nets/m2net.py:97,103,258,300) under the autocast step: fp16 activations, fp32 master weight
  * (converted while it is staged into LDS), fp32 accumulate, fp16 result.

@@ -1,0 +1,243 @@
+// x_proj of the SS2D / cross-scan block on channel-major fp32 activations (gfx950).
+// Reference: the two einsums of SS2D.forward_core, /root/reference/nnunetv2/nets/m2net.py:179-184
+//   x_dbl = einsum("b k d l, k c d -> b k c l", xs, x_proj_weight)   (dt, B, C rows of each direction)
+// In the cross-scan formulation (nnuzoo_amd/ss2d_scan.py) directions k = s + 2j share source s (row- / column-major
+// tokens), so the projection is  P[s][b][c][l] = sum_d Wst[s][c][d] x2[s][b][d][l],  c < C2 = 2 (R + 2N) <= 80 rows,
+// Di = 32..256 input channels, L up to 262 144 tokens.  As GEMMs these are (C2 x Di) x (Di x L): a library call with
+// M = 66..80 runs a 16x16 macro tile at ~1 ms (10 calls per M2Net step at 512^2) where the data is 0.1-0.4 GB
+// (25-70 us at HBM speed), and each call costs ~28 us of host dispatch (660 mm / bmm calls per step).
+//
+// Layout-native design: the token axis is contiguous, so LANES = TOKENS and every global access is a coalesced 256-byte
+// run per wave; the small weight matrix is staged (32 input channels at a time) into LDS and read as wave-uniform
+// broadcasts; a thread keeps all C2 outputs of its token in registers.  fp32 FMAs throughout (the scan is fp32 in the
+// reference: `.float()` at m2net.py:185-191).
+//   xproj_fwd  : P   = W x2
+//   xproj_bwd_x: dx2 = W^T dP + du[k = s] + du[k = s + 2]            (the scans' own input gradients folded in)
+//   xproj_bwd_w: dW  = sum_{b, l} dP x2^T                             (register tiles, token ranges over workgroups)
+#include "common.hpp"
+
+namespace nnz {
+
+constexpr int XP_CMAX = 80;  // 2 (R + 32), R <= 8
+constexpr int XP_DC = 32;    // input channels per staged weight chunk
+
+struct XpArgs {
+  const float* x2;   // [2][B][Di][L]
+  const float* W;    // [2][C2][Di]
+  float* P;          // [2][B][C2][L]
+  const float* dP;   // [2][B][C2][L]
+  const float* du;   // [B][4][Di][L]
+  float* dx2;        // [2][B][Di][L]
+  float* dW;         // [2][C2][Di] (atomic, pre-zeroed)
+  int B, Di, C2;
+  long L;
+  long tokens_per_wg;
+};
+
+__global__ __launch_bounds__(256) void xproj_fwd_kernel(XpArgs a) {
+  __shared__ __attribute__((aligned(16))) float sW[XP_CMAX * XP_DC];  // [c][32 d] of the current chunk
+  const int sb = blockIdx.y;                 // s * B + b
+  const int s = sb / a.B;
+  const long l = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = l < a.L;
+  const float* x = a.x2 + (long)sb * a.Di * a.L + (ok ? l : 0);
+  const float* W = a.W + (long)s * a.C2 * a.Di;
+  float acc[XP_CMAX];
+#pragma unroll
+  for (int c = 0; c < XP_CMAX; ++c) acc[c] = 0.f;
+  for (int d0 = 0; d0 < a.Di; d0 += XP_DC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < XP_CMAX * XP_DC; e += 256) {
+      const int c = e / XP_DC, d = e % XP_DC;
+      sW[e] = c < a.C2 ? W[(long)c * a.Di + d0 + d] : 0.f;
+    }
+    float xv[XP_DC];
+#pragma unroll
+    for (int d = 0; d < XP_DC; ++d) xv[d] = ok ? x[(long)(d0 + d) * a.L] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < XP_CMAX; ++c) {
+#pragma unroll
+      for (int d4 = 0; d4 < XP_DC; d4 += 4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW + c * XP_DC + d4);  // wave-uniform address: broadcast
+        acc[c] += w[0] * xv[d4] + w[1] * xv[d4 + 1] + w[2] * xv[d4 + 2] + w[3] * xv[d4 + 3];
+      }
+    }
+  }
+  if (ok) {
+    float* P = a.P + (long)sb * a.C2 * a.L + l;
+#pragma unroll
+    for (int c = 0; c < XP_CMAX; ++c)
+      if (c < a.C2) P[(long)c * a.L] = acc[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void xproj_bwd_x_kernel(XpArgs a) {
+  __shared__ __attribute__((aligned(16))) float sWt[XP_DC * XP_CMAX];  // [32 d][c] of the current chunk (transposed)
+  const int sb = blockIdx.y;
+  const int s = sb / a.B, b = sb % a.B;
+  const long l = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = l < a.L;
+  const float* dP = a.dP + (long)sb * a.C2 * a.L + (ok ? l : 0);
+  const float* W = a.W + (long)s * a.C2 * a.Di;
+  float g[XP_CMAX];
+#pragma unroll
+  for (int c = 0; c < XP_CMAX; ++c) g[c] = (ok && c < a.C2) ? dP[(long)c * a.L] : 0.f;
+  // du of the two directions of this source: k = s and k = s + 2 in [B][4][Di][L]
+  const float* du0 = a.du + (((long)b * 4 + s) * a.Di) * a.L + (ok ? l : 0);
+  const float* du1 = a.du + (((long)b * 4 + s + 2) * a.Di) * a.L + (ok ? l : 0);
+  float* dx = a.dx2 + (long)sb * a.Di * a.L + l;
+  for (int d0 = 0; d0 < a.Di; d0 += XP_DC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < XP_DC * XP_CMAX; e += 256) {
+      const int c = e / XP_DC, d = e % XP_DC;     // read W[c][d0 + d] with d fastest (coalesced), store transposed
+      sWt[d * XP_CMAX + c] = c < a.C2 ? W[(long)c * a.Di + d0 + d] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int d = 0; d < XP_DC; ++d) {
+      float v = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < XP_CMAX; c4 += 4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sWt + d * XP_CMAX + c4);
+        v += w[0] * g[c4] + w[1] * g[c4 + 1] + w[2] * g[c4 + 2] + w[3] * g[c4 + 3];
+      }
+      if (ok) {
+        const long o = (long)(d0 + d) * a.L;
+        dx[o] = v + du0[o] + du1[o];
+      }
+    }
+  }
+}
+
+// dW[s][c][d] = sum over (b, l) of dP[c][l] x2[d][l].  Workgroup = one source s and a token range; thread = (token slice,
+// 8 x 8 block of dW); rows are staged as [row][64 tokens] tiles and read 4 tokens (16 bytes) at a time.
+constexpr int XPW_TOK = 64;
+
+__global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int C2p = (a.C2 + 7) & ~7;
+  const int nbk = (C2p >> 3) * (a.Di >> 3);
+  const int TSL = 256 / nbk;  // >= 1 (launcher checks nbk <= 256)
+  float* sP = smem_f;                         // [C2p][64]
+  float* sX = sP + C2p * XPW_TOK;             // [Di][64]
+  float* sred = sX + a.Di * XPW_TOK;          // [TSL][C2p * Di]
+  const int tid = threadIdx.x;
+  const int s = blockIdx.y;
+  const int blk = tid % nbk, ts = tid / nbk;
+  const bool active = ts < TSL;
+  const int c0 = (blk / (a.Di >> 3)) * 8, d0 = (blk % (a.Di >> 3)) * 8;
+  float acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  const long T = (long)a.B * a.L;             // tokens of this source, (b, l) flattened: rows are [b][row][l]
+  const long t_begin = (long)blockIdx.x * a.tokens_per_wg;
+  long t_end = t_begin + a.tokens_per_wg;
+  if (t_end > T) t_end = T;
+  for (long tb = t_begin; tb < t_end; tb += XPW_TOK) {
+    // a 64-token round never straddles two samples: tokens_per_wg and L are multiples of 64 (launcher)
+    const int b = (int)(tb / a.L);
+    const long l0 = tb - (long)b * a.L;
+    const float* dPb = a.dP + ((long)(s * a.B + b) * a.C2) * a.L + l0;
+    const float* xb = a.x2 + ((long)(s * a.B + b) * a.Di) * a.L + l0;
+    __syncthreads();
+    for (int e = tid; e < C2p * (XPW_TOK / 4); e += 256) {
+      const int c = e / (XPW_TOK / 4), q = e % (XPW_TOK / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < a.C2) v = *reinterpret_cast<const f32x4*>(dPb + (long)c * a.L + q * 4);
+      *reinterpret_cast<f32x4*>(sP + c * XPW_TOK + q * 4) = v;
+    }
+    for (int e = tid; e < a.Di * (XPW_TOK / 4); e += 256) {
+      const int d = e / (XPW_TOK / 4), q = e % (XPW_TOK / 4);
+      *reinterpret_cast<f32x4*>(sX + d * XPW_TOK + q * 4) =
+          *reinterpret_cast<const f32x4*>(xb + (long)d * a.L + q * 4);
+    }
+    __syncthreads();
+    if (active) {
+      for (int q = ts; q < XPW_TOK / 4; q += TSL) {
+        f32x4 pv[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          pv[i] = *reinterpret_cast<const f32x4*>(sP + (c0 + i) * XPW_TOK + q * 4);
+          xv[i] = *reinterpret_cast<const f32x4*>(sX + (d0 + i) * XPW_TOK + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[i][j] += pv[i][0] * xv[j][0] + pv[i][1] * xv[j][1] + pv[i][2] * xv[j][2] + pv[i][3] * xv[j][3];
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sred[(long)ts * C2p * a.Di + (c0 + i) * a.Di + d0 + j] = acc[i][j];
+  }
+  __syncthreads();
+  float* dW = a.dW + (long)s * a.C2 * a.Di;
+  for (int e = tid; e < a.C2 * a.Di; e += 256) {
+    float v = 0.f;
+    for (int q = 0; q < TSL; ++q) v += sred[(long)q * C2p * a.Di + e];
+    atomicAdd(dW + e, v);
+  }
+}
+
+static bool xp_shape_ok(int B, int Di, int C2, long L) {
+  return B >= 1 && Di >= XP_DC && Di % XP_DC == 0 && Di <= 1024 && C2 >= 8 && C2 <= XP_CMAX && L >= 1;
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P, int B, int Di, int C2, long L,
+                                      void* stream) {
+  using namespace nnz;
+  if (!x2 || !W || !P || !xp_shape_ok(B, Di, C2, L)) return NNZ_EINVAL;
+  XpArgs a = {};
+  a.x2 = x2; a.W = W; a.P = P; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
+  NNZ_LAUNCH(xproj_fwd_kernel, dim3((unsigned)((L + 255) / 256), 2 * B), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const float* du, float* dx2, int B, int Di,
+                                         int C2, long L, void* stream) {
+  using namespace nnz;
+  if (!dP || !W || !du || !dx2 || !xp_shape_ok(B, Di, C2, L)) return NNZ_EINVAL;
+  XpArgs a = {};
+  a.dP = dP; a.W = W; a.du = du; a.dx2 = dx2; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
+  NNZ_LAUNCH(xproj_bwd_x_kernel, dim3((unsigned)((L + 255) / 256), 2 * B), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// dW[2][C2][Di] (pre-zeroed, fp32) += per-source token contraction.  Needs L % 64 == 0 and (ceil8(C2)/8)(Di/8) <= 256;
+// returns -22 otherwise (the caller keeps the library path for those shapes).
+extern "C" int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L,
+                                         void* stream) {
+  using namespace nnz;
+  if (!dP || !x2 || !dW || !xp_shape_ok(B, Di, C2, L) || (L % XPW_TOK)) return NNZ_EINVAL;
+  const int C2p = (C2 + 7) & ~7;
+  const int nbk = (C2p >> 3) * (Di >> 3);
+  if (nbk > 256) return NNZ_EINVAL;
+  const int TSL = 256 / nbk;
+  XpArgs a = {};
+  a.dP = dP; a.x2 = x2; a.dW = dW; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
+  const long T = (long)B * L;
+  long tpw = (T + 255) / 256;                              // ~256 workgroups per source (512 in all)
+  tpw = (tpw + XPW_TOK - 1) / XPW_TOK * XPW_TOK;
+  a.tokens_per_wg = tpw;
+  const long wgs = (T + tpw - 1) / tpw;
+  const size_t lds = sizeof(float) * ((size_t)(C2p + Di) * XPW_TOK + (size_t)TSL * C2p * Di);
+  if (lds > 160 * 1024) return NNZ_EINVAL;
+  static DynLdsCache cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(xproj_bwd_w_kernel), (int)lds, cache);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH(xproj_bwd_w_kernel, dim3((unsigned)wgs, 2), dim3(256), lds, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

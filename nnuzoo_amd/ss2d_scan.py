@@ -11,6 +11,8 @@ fp32 throughout, as the reference forces for the scan (`.float()` at m2net.py:18
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import call, load, ptr, stream_ptr
@@ -18,6 +20,14 @@ from .hip_ops import TIMER
 
 N_STATE = 16
 MAX_DT_RANK = 8
+
+
+_USE_XPROJ = os.environ.get("NNZ_XPROJ", "1") != "0"   # A/B switch for measurements
+
+
+def _xproj_ok(Di: int, C2: int) -> bool:
+    """shapes served by csrc/ss2d_xproj.hip (32-channel weight chunks, at most 80 projection rows)"""
+    return _USE_XPROJ and Di % 32 == 0 and 32 <= Di <= 1024 and 8 <= C2 <= 80
 
 
 def _proj_weight_grad(dP: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
@@ -112,7 +122,11 @@ class _SS2DCrossScan(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             # direction k = s + 2j  ->  rows [j*Cp, (j+1)*Cp) of source s's stacked projection weight
             Wst = x_proj_weight.detach().float().view(2, 2, Cp, Di).transpose(0, 1).reshape(2, 1, 2 * Cp, Di)
-            P = torch.matmul(Wst, x2)                                            # (2, B, 2Cp, L)
+            if _xproj_ok(Di, 2 * Cp):
+                P = torch.empty((2, B, 2 * Cp, L), **f32)                        # csrc/ss2d_xproj.hip: lanes = tokens
+                call("nnz_ss2d_xproj_forward", ptr(x2), ptr(Wst), ptr(P), B, Di, 2 * Cp, L, stream_ptr())
+            else:
+                P = torch.matmul(Wst, x2)                                        # (2, B, 2Cp, L)
             A = A_logs.detach().float().contiguous()                             # A_log; the kernels use -exp(A_log)
             Wdt = dt_projs_weight.detach().float().reshape(K * Di, R).contiguous()
             bias = dt_projs_bias.detach().float().reshape(-1).contiguous()
@@ -155,10 +169,19 @@ class _SS2DCrossScan(torch.autograd.Function):
                 "nnz_ss2d_scan_backward", ptr(x2), ptr(P), ptr(Wdt), ptr(A), ptr(Dv), ptr(bias), ptr(dy2), ptr(state),
                 ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B, Di, R, L, 1, 1,
                 stream_ptr()))
-            dx2 = torch.matmul(Wst.transpose(-1, -2), dP)                        # (2, B, Di, L)
-            # + the scans' own input gradients: direction k = 2j + s belongs to source s
-            dx2 += du.view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
-            dWst = _proj_weight_grad(dP, x2)                                     # (2, 2Cp, Di)
+            if _xproj_ok(Di, 2 * Cp):
+                # W^T dP + the scans' own input gradients of the source's two directions, one pass (ss2d_xproj.hip)
+                dx2 = torch.empty((2, B, Di, L), **f32)
+                call("nnz_ss2d_xproj_backward_x", ptr(dP), ptr(Wst), ptr(du), ptr(dx2), B, Di, 2 * Cp, L, stream_ptr())
+            else:
+                dx2 = torch.matmul(Wst.transpose(-1, -2), dP)                    # (2, B, Di, L)
+                # + the scans' own input gradients: direction k = 2j + s belongs to source s
+                dx2 += du.view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
+            if _xproj_ok(Di, 2 * Cp) and L % 64 == 0 and ((2 * Cp + 7) // 8) * (Di // 8) <= 256:
+                dWst = torch.zeros((2, 2 * Cp, Di), **f32)
+                call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(dWst), B, Di, 2 * Cp, L, stream_ptr())
+            else:
+                dWst = _proj_weight_grad(dP, x2)                                 # (2, 2Cp, Di)
             d_xproj = dWst.view(2, 2, Cp, Di).transpose(0, 1).reshape(K, Cp, Di)
         return dx2, None, d_xproj, dWdt.view(K, Di, R), dbias.view(K, Di), dA, dD    # dA is dA_log (a_is_log)
 

@@ -94,3 +94,29 @@ def test_layout_kernels(hip_lib):
     ref = (du[:, 0] + du[:, 2] + dx2[0]).reshape(B, D, H, W) + \
         (du[:, 1] + du[:, 3] + dx2[1]).reshape(B, D, W, H).transpose(2, 3)
     assert torch.allclose(dx, ref, rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Di,R,L", [(2, 32, 1, 4096), (1, 64, 2, 1000), (2, 128, 4, 640), (1, 256, 8, 192)])
+def test_xproj_kernels_vs_einsum(hip_lib, B, Di, R, L):
+    """csrc/ss2d_xproj.hip against the einsums they replace (fp32): projection, its input gradient with the scans' own
+    input gradients folded in, and the weight gradient (token contraction); ragged L for the lane-per-token kernels"""
+    from nnuzoo_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(B * Di + L)
+    C2 = 2 * (R + 32)
+    x2 = torch.randn(2, B, Di, L, generator=g).cuda()
+    W = (torch.randn(2, C2, Di, generator=g) / Di ** 0.5).cuda()
+    dP = torch.randn(2, B, C2, L, generator=g).cuda()
+    du = torch.randn(B, 4, Di, L, generator=g).cuda()
+    P = torch.empty(2, B, C2, L, device="cuda")
+    call("nnz_ss2d_xproj_forward", ptr(x2), ptr(W), ptr(P), B, Di, C2, L, stream_ptr())
+    ref = torch.einsum("scd,sbdl->sbcl", W.double(), x2.double())
+    assert torch.allclose(P.double(), ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())
+    dx = torch.empty_like(x2)
+    call("nnz_ss2d_xproj_backward_x", ptr(dP), ptr(W), ptr(du), ptr(dx), B, Di, C2, L, stream_ptr())
+    rdx = torch.einsum("scd,sbcl->sbdl", W.double(), dP.double()) + du.double().view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
+    assert torch.allclose(dx.double(), rdx, rtol=1e-5, atol=1e-5 * rdx.abs().max().item())
+    if L % 64 == 0 and ((C2 + 7) // 8) * (Di // 8) <= 256:
+        dW = torch.zeros(2, C2, Di, device="cuda")
+        call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(dW), B, Di, C2, L, stream_ptr())
+        rdw = torch.einsum("sbcl,sbdl->scd", dP.double(), x2.double())
+        assert torch.allclose(dW.double(), rdw, rtol=1e-4, atol=1e-5 * rdw.abs().max().item())
