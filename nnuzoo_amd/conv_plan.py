@@ -94,20 +94,23 @@ def conv_out_dims(in_dims, ks, stride):
     return tuple((in_dims[a] + 2 * (ks[a] // 2) - ks[a]) // stride[a] + 1 for a in range(3))
 
 
-def conv_forward(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldi=None, ldo=None) -> TapTable:
-    """Y[o] = sum_k X[s*o + k - pad] W[k]; packed slice widx == flat kernel index.  ks in {1,3}, stride in {1,2},
-    both per axis (a 2-D layer is the D = 1 case with ks[0] = stride[0] = 1)."""
-    ks, stride = _triple(ks), _triple(stride)
+def conv_forward(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldi=None, ldo=None, dilation=1) -> TapTable:
+    """Y[o] = sum_k X[s*o + (k - ks//2) * dil] W[k] ("same" padding = dil * (ks//2)); packed slice widx == flat kernel
+    index.  ks in {1,3}, stride in {1,2}, both per axis (a 2-D layer is the D = 1 case with ks[0] = stride[0] = 1);
+    dilation per axis (stride 1 only) - the dilated 3x3 convolutions of REBNCONV, m2net.py:18-30."""
+    ks, stride, dil = _triple(ks), _triple(stride), _triple(dilation)
+    assert all(d == 1 or st == 1 for d, st in zip(dil, stride)), "dilation is supported for stride-1 axes"
     out_dims = conv_out_dims(in_dims, ks, stride)
     taps = []
     for k in itertools.product(range(ks[0]), range(ks[1]), range(ks[2])):
-        off = tuple(k[a] - ks[a] // 2 for a in range(3))
+        off = tuple((k[a] - ks[a] // 2) * dil[a] for a in range(3))
         taps.append((off, _flat(k, ks)))
     return TapTable(N, tuple(in_dims), out_dims, out_dims, Cin, Cout, ldi or Cin, ldo or Cout, stride, (1, 1, 1),
                     [((0, 0, 0), taps)])
 
 
-def conv_dgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldi=None, ldo=None, accumulate=False) -> TapTable:
+def conv_dgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldi=None, ldo=None, accumulate=False,
+               dilation=1) -> TapTable:
     """dX of the convolution above.  `in` of the table is dY (Cout channels), `out` is dX (Cin channels).
 
     per axis, stride 1: dX[i] = sum_k dY[i - k + pad] W[k]
@@ -116,12 +119,13 @@ def conv_dgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldi=None, ldo=None
     Output-parity groups are the product over the stride-2 axes (1, 2, 4 or 8 groups).
     ldi / ldo here are the channel strides of dY / dX.
     """
-    ks, stride = _triple(ks), _triple(stride)
+    ks, stride, dil = _triple(ks), _triple(stride), _triple(dilation)
+    assert all(d == 1 or st == 1 for d, st in zip(dil, stride)), "dilation is supported for stride-1 axes"
     y_dims = conv_out_dims(in_dims, ks, stride)
     per_axis = []  # parity -> [(off, k)]
     for a in range(3):
         if stride[a] == 1:
-            per_axis.append({0: [(ks[a] // 2 - k, k) for k in range(ks[a])]})
+            per_axis.append({0: [((ks[a] // 2 - k) * dil[a], k) for k in range(ks[a])]})
         elif stride[a] == 2:
             if ks[a] == 3:
                 per_axis.append({0: [(0, 1)], 1: [(1, 0), (0, 2)]})
@@ -152,9 +156,9 @@ def dgrad_uncovered(ks, stride) -> bool:
     return any(stride[a] == 2 and ks[a] == 1 for a in range(3))
 
 
-def conv_wgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldx=None, lddy=None) -> TapTable:
-    """dW[k][ci][co] = sum_o X[s*o + k - pad][ci] dY[o][co]: boxed = X, plain = dY."""
-    t = conv_forward(N, in_dims, Cin, Cout, ks, stride, ldi=ldx or Cin, ldo=lddy or Cout)
+def conv_wgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldx=None, lddy=None, dilation=1) -> TapTable:
+    """dW[k][ci][co] = sum_o X[s*o + (k - ks//2) * dil][ci] dY[o][co]: boxed = X, plain = dY."""
+    t = conv_forward(N, in_dims, Cin, Cout, ks, stride, ldi=ldx or Cin, ldo=lddy or Cout, dilation=dilation)
     return t
 
 

@@ -561,6 +561,12 @@ static int launch_dyn(const ConvDev& p, hipStream_t stream) {
   const bool nb2 = (d.Cout % 64) == 0;
   const bool strided = d.in_stride[0] == 2 || d.in_stride[1] == 2 || d.in_stride[2] == 2;
   if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
+    // dilated 3x3 (REBNCONV, dilation 2 / 4 / 8: tap offsets up to +-8, box = tile + 2 * dilation): the 1x8x8 tile with
+    // room for a 24 x 24 box in the staging registers (the maps are 32^2 / 16^2: one wave of workgroups either way)
+    if (d.ext[1] > 2 || d.ext[2] > 2) {
+      if (strided) return NNZ_EINVAL;
+      return nb2 ? launch_cfg<1, 8, 8, 2, 5, GeoDyn>(p, stream) : launch_cfg<1, 16, 8, 1, 6, GeoDyn>(p, stream);
+    }
     // flat tiles: 1x32x8 voxels (stride 1), 1x16x8 (stride 2: the box is (2*TH+1) x 17), 1x8x8 for small maps
     const long wgs = (long)d.N * d.ngroups * (d.Cout / (nb2 ? 64 : 32)) * ((d.m_dims[1] + 31) / 32) *
                      ((d.m_dims[2] + 7) / 8);
@@ -610,9 +616,11 @@ extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void*
   if (d.Cin % 32 || d.Cout % 32 || d.ngroups < 1 || d.ngroups > NNZ_MAX_GROUPS || d.ntaps_total > NNZ_MAX_TAPS ||
       d.ldi % 8 || d.ldo % 8)
     return NNZ_EINVAL;
+  // tap extent per axis: 0..2 for the k1 / k3 layers; up to 16 (dilation 8) on the H / W axes of 2-D layers
+  const bool flat = d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1;
   for (int a = 0; a < 3; ++a)
     if ((d.in_stride[a] != 1 && d.in_stride[a] != 2) || (d.out_stride[a] != 1 && d.out_stride[a] != 2) ||
-        d.ext[a] < 0 || d.ext[a] > 2)
+        d.ext[a] < 0 || d.ext[a] > ((flat && a > 0) ? 16 : 2))
       return NNZ_EINVAL;
   for (int g = 0; g < d.ngroups; ++g)
     if (d.groups[g].ntaps > 27 || d.groups[g].ntaps < 1) return NNZ_EINVAL;

@@ -360,8 +360,11 @@ static int launch_wgrad_any(const WgradDev& p, hipStream_t s, const WgLaunchOpt&
     return ext <= 1 ? launch_wg_iso<2, 4, 8, 2, 1>(p, s, o) : launch_wg_iso<2, 4, 8, 2, 2>(p, s, o);
   }
   // per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) and anisotropic 3-D plans
-  if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1)
+  if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
+    // dilated 3x3 (tap offsets up to +-8): the 1x16x8 tile's staging registers hold its (16 + 16) x (8 + 16) box
+    if (d.ext[1] > 2 || d.ext[2] > 2) return strided ? NNZ_EINVAL : launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, o);
     return strided ? launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, o) : launch_wg<1, 32, 8, 6, WGeoDyn>(p, s, o);
+  }
   return strided ? launch_wg<2, 4, 8, 12, WGeoDyn>(p, s, o) : launch_wg<4, 8, 8, 10, WGeoDyn>(p, s, o);
 }
 
@@ -429,7 +432,7 @@ extern "C" int nnz_conv_tap_wgrad(const void* boxed, const void* plain, float* d
     return NNZ_EINVAL;
   for (int a = 0; a < 3; ++a)
     if ((d.in_stride[a] != 1 && d.in_stride[a] != 2) || (d.out_stride[a] != 1 && d.out_stride[a] != 2) ||
-        d.ext[a] < 0 || d.ext[a] > 2)
+        d.ext[a] < 0 || d.ext[a] > ((d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1 && a > 0) ? 16 : 2))
       return NNZ_EINVAL;
   // 32-bit voxel offsets inside the kernel: batches beyond 2^31 elements per tensor run as sample chunks that
   // accumulate into the same dW (zeroed once)
@@ -474,7 +477,7 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
     return NNZ_EINVAL;
   for (int a = 0; a < 3; ++a)
     if ((d.in_stride[a] != 1 && d.in_stride[a] != 2) || (d.out_stride[a] != 1 && d.out_stride[a] != 2) ||
-        d.ext[a] < 0 || d.ext[a] > 2)
+        d.ext[a] < 0 || d.ext[a] > ((d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1 && a > 0) ? 16 : 2))
       return NNZ_EINVAL;
   const long tab = (long)d.ntaps_total * d.Cin * d.Cout;
   const long pairs = (long)(d.Cin / 32) * (d.Cout / 32);

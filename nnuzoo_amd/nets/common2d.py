@@ -136,6 +136,10 @@ class RSU4F(nn.Module):
         self.rebnconv1d = B(mid_ch * 2, out_ch, dirate=1)
 
     def forward(self, x):
+        from .. import rebnconv
+        if rebnconv.USE_HIP and rebnconv.hip_path_ok(self, x):
+            # dilated conv + batch-stat norm + ReLU units on the tap-table conv kernels, channels-last inside the block
+            return rebnconv.rsu4f_forward(self, x)
         xin = self.rebnconvin(x)
         e1 = self.rebnconv1(xin)
         e2 = self.rebnconv2(e1)

@@ -1,0 +1,148 @@
+"""REBNCONV / RSU4F on the hand-written conv kernels (reference: /root/reference/nnunetv2/nets/m2net.py:18-30 `REBNCONV` =
+Conv2d 3x3 with dilation 1/2/4/8 -> BatchNorm2d -> ReLU, and `RSU4F` :769-801, the residual U of eight of those; the same
+classes in nets/u2net.py).  In M2Net they are stage5 / stage6 / stage5d: 512 -> 512 channels at 32^2 and 16^2.
+
+The unit is the conv block of the 3-D nnU-Net schedule with three differences, all of which the kernels already
+parameterise: dilated taps (a tap table with offsets +-dilation: `conv_plan.conv_forward(..., dilation=)`, box = tile +
+2 x dilation), batch statistics instead of per-instance ones (the conv epilogue's per-sample sums are added over the
+batch and the norm kernels run on the batch as ONE instance of N x H x W voxels), and slope 0 (ReLU).  Activations stay
+channels-last fp16 between the units of an RSU4F, so its `torch.cat` calls are last-dimension concatenations and the
+NCHW <-> channels-last conversion happens once per RSU4F, not per conv.
+
+Numerics = the reference's autocast step: fp16 operands, fp32 accumulate, fp32 statistics / affine.  Used when the
+module runs under fp16 autocast on the GPU in training mode or in eval mode for inference (no backward through eval-mode
+statistics); otherwise the module keeps its torch path (e.g. SyncBatchNorm under DDP).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+import torch
+
+from . import conv_plan as cp
+from . import hip_ops as ops
+from .hip_ops import PreparedTable
+
+USE_HIP = os.environ.get("NNZ_REBNCONV", "1") != "0"   # A/B switch for measurements
+_TABLES: Dict[Tuple, Tuple[PreparedTable, PreparedTable, PreparedTable]] = {}
+
+
+def _tables(N: int, H: int, W: int, cin: int, cout: int, dil: int):
+    key = (N, H, W, cin, cout, dil)
+    t = _TABLES.get(key)
+    if t is None:
+        dims, ks, d3 = (1, H, W), (1, 3, 3), (1, dil, dil)
+        t = (PreparedTable(cp.conv_forward(N, dims, cin, cout, ks=ks, stride=1, dilation=d3)),
+             PreparedTable(cp.conv_dgrad(N, dims, cin, cout, ks=ks, stride=1, dilation=d3)),
+             PreparedTable(cp.conv_wgrad(N, dims, cin, cout, ks=ks, stride=1, dilation=d3)))
+        _TABLES[key] = t
+    return t
+
+
+def supported(conv: torch.nn.Conv2d, bn: torch.nn.Module) -> bool:
+    return type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats and bn.momentum is not None \
+        and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 \
+        and conv.dilation[0] == conv.dilation[1] and conv.dilation[0] in (1, 2, 4, 8) \
+        and conv.padding == conv.dilation and conv.padding_mode == "zeros" \
+        and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.bias is not None
+
+
+class _RebnConvFn(torch.autograd.Function):
+    """x: (N, H, W, Cin) fp16 channels-last -> relu(bn(conv(x))): (N, H, W, Cout) fp16"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, dil, eps, momentum, training):
+        N, H, W, cin = x.shape
+        cout = weight.shape[0]
+        V = H * W
+        dev = x.device
+        fwd, dgrad, wgrad = _tables(N, H, W, cin, cout, dil)
+        wp = ops.pack_weight(weight.detach(), fwd, cin, cout, 9, cin * 9, 1)
+        raw = torch.empty((N, V, cout), dtype=torch.float16, device=dev)
+        stats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
+        ops.conv_tap_forward(fwd, x.view(N, V, cin), wp, bias.detach(), raw, stats=stats if training else None)
+        n = N * V
+        if training:
+            bstats = stats.sum(0, keepdim=True)                      # batch statistics: one instance of N * V voxels
+            with torch.no_grad():                                     # running estimates (F.batch_norm's update rule)
+                mean = bstats[0, :, 0] / n
+                var = (bstats[0, :, 1] / n - mean * mean).clamp_min_(0)
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        else:
+            rm, rv = running_mean.float(), running_var.float()
+            bstats = torch.stack([rm * n, (rv + rm * rm) * n], dim=1).unsqueeze(0).contiguous()
+        y = torch.empty((N, H, W, cout), dtype=torch.float16, device=dev)
+        ops.instnorm_lrelu_apply(raw, bstats, gamma.detach(), beta.detach(), y, 1, n, cout, cout, cout, float(eps), 0.0)
+        ctx.save_for_backward(x, weight, raw, bstats, gamma, beta)
+        ctx.cfg = (dil, float(eps), bool(training))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, raw, bstats, gamma, beta = ctx.saved_tensors
+        dil, eps, training = ctx.cfg
+        if not training:
+            raise RuntimeError("nnuzoo_amd REBNCONV: backward through eval-mode BatchNorm statistics is not supported")
+        N, H, W, cin = x.shape
+        cout = weight.shape[0]
+        V, n = H * W, N * H * W
+        dev = x.device
+        fwd, dgrad, wgrad = _tables(N, H, W, cin, cout, dil)
+        gy = gy.contiguous()
+        if gy.dtype != torch.float16:
+            gy = gy.to(torch.float16)
+        red = torch.zeros((1, cout, 2), dtype=torch.float32, device=dev)
+        draw = torch.empty((N, V, cout), dtype=torch.float16, device=dev)
+        dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        ops.instnorm_lrelu_bwd(raw, gy.view(N, V, cout), bstats, gamma.detach(), beta.detach(), red, draw, 1, n, cout,
+                               cout, cout, cout, eps, 0.0, pre_zeroed=True, dgamma=dgb[0], dbeta=dgb[1])
+        gw = torch.empty_like(weight, dtype=torch.float32)
+        ws = torch.empty(ops.conv_tap_wgrad_workspace_floats(wgrad), dtype=torch.float32, device=dev)
+        ops.conv_tap_wgrad_to_grad(wgrad, x.view(N, V, cin), draw, ws, gw, 9, cin * 9, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpd = ops.pack_weight(weight.detach(), dgrad, cout, cin, cin * 9, 9, 1)
+            dx = torch.empty((N, H, W, cin), dtype=torch.float16, device=dev)
+            ops.conv_tap_forward(dgrad, draw, wpd, None, dx.view(N, V, cin))
+        # a conv bias in front of batch statistics has an identically zero gradient (mean removal)
+        gb = torch.zeros(cout, dtype=torch.float32, device=dev)
+        return dx, gw, gb, dgb[0], dgb[1], None, None, None, None, None, None
+
+
+def rebnconv_cl(mod, x_cl: torch.Tensor) -> torch.Tensor:
+    """one REBNCONV unit (module with conv_s1 / bn_s1) on a channels-last fp16 tensor"""
+    conv, bn = mod.conv_s1, mod.bn_s1
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _RebnConvFn.apply(x_cl, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                             conv.dilation[0], bn.eps, bn.momentum, bn.training)
+
+
+def hip_path_ok(rsu, x: torch.Tensor) -> bool:
+    if not (x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.float16):
+        return False
+    units = [rsu.rebnconvin, rsu.rebnconv1, rsu.rebnconv2, rsu.rebnconv3, rsu.rebnconv4, rsu.rebnconv3d, rsu.rebnconv2d,
+             rsu.rebnconv1d]
+    if not all(hasattr(u, "conv_s1") and isinstance(u.conv_s1, torch.nn.Conv2d) and supported(u.conv_s1, u.bn_s1)
+               for u in units):
+        return False
+    if not units[0].bn_s1.training and torch.is_grad_enabled() and x.requires_grad:
+        return False                                             # eval-mode statistics with autograd: torch path
+    return True
+
+
+def rsu4f_forward(rsu, x: torch.Tensor) -> torch.Tensor:
+    """RSU4F.forward (m2net.py:789-801) on channels-last fp16 activations; input / output NCHW like the module"""
+    xc = x.permute(0, 2, 3, 1).to(torch.float16).contiguous()
+    xin = rebnconv_cl(rsu.rebnconvin, xc)
+    e1 = rebnconv_cl(rsu.rebnconv1, xin)
+    e2 = rebnconv_cl(rsu.rebnconv2, e1)
+    e3 = rebnconv_cl(rsu.rebnconv3, e2)
+    e4 = rebnconv_cl(rsu.rebnconv4, e3)
+    d3 = rebnconv_cl(rsu.rebnconv3d, torch.cat((e4, e3), -1))
+    d2 = rebnconv_cl(rsu.rebnconv2d, torch.cat((d3, e2), -1))
+    d1 = rebnconv_cl(rsu.rebnconv1d, torch.cat((d2, e1), -1))
+    return (d1 + xin).permute(0, 3, 1, 2)

@@ -24,6 +24,28 @@ def main():
     print(f"kernels {len(rows)}  busy {tot / 1e6:.2f} ms  span {span / 1e6:.2f} ms")
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print(f"{t / 1e6:9.3f} ms {n:6d} calls {t / n / 1e3:9.2f} us  {name[:110]}")
+    # idle gaps between consecutive kernels (host-bound stretches): histogram + the kernels that follow the largest gaps
+    gaps = []
+    end = int(rows[0]["End_Timestamp"])
+    for prev, r in zip(rows, rows[1:]):
+        st = int(r["Start_Timestamp"])
+        if st > end:
+            gaps.append((st - end, prev["Kernel_Name"], r["Kernel_Name"]))
+        end = max(end, int(r["End_Timestamp"]))
+    tot_gap = sum(g[0] for g in gaps)
+    print(f"idle gaps: {len(gaps)} totalling {tot_gap / 1e6:.2f} ms; "
+          f">100us: {sum(g[0] for g in gaps if g[0] > 1e5) / 1e6:.2f} ms in {sum(1 for g in gaps if g[0] > 1e5)}; "
+          f"10-100us: {sum(g[0] for g in gaps if 1e4 < g[0] <= 1e5) / 1e6:.2f} ms in {sum(1 for g in gaps if 1e4 < g[0] <= 1e5)}; "
+          f"<10us: {sum(g[0] for g in gaps if g[0] <= 1e4) / 1e6:.2f} ms")
+    after = defaultdict(lambda: [0, 0])
+    for g, pn, nn in gaps:
+        after[nn[:70]][0] += 1
+        after[nn[:70]][1] += g
+    print("gap time by FOLLOWING kernel:")
+    for name, (n, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"{t / 1e6:9.3f} ms {n:6d} gaps {t / n / 1e3:8.1f} us  -> {name}")
+    for g, pn, nn in sorted(gaps, reverse=True)[:8]:
+        print(f"  gap {g / 1e3:9.1f} us  after {pn[:50]}  before {nn[:50]}")
 
 
 if __name__ == "__main__":
