@@ -361,8 +361,8 @@ static int launch_wgrad_any(const WgradDev& p, hipStream_t s, const WgLaunchOpt&
   }
   // per-axis geometry: 2-D plans (depth-1 volumes -> flat tiles) and anisotropic 3-D plans
   if (d.m_dims[0] == 1 && d.in_dims[0] == 1 && d.out_dims[0] == 1) {
-    // dilated 3x3 (tap offsets up to +-8): the 1x16x8 tile's staging registers hold its (16 + 16) x (8 + 16) box
-    if (d.ext[1] > 2 || d.ext[2] > 2) return strided ? NNZ_EINVAL : launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, o);
+    // dilated 3x3 (tap offsets up to +-8): the 1x16x8 tile with 12 staging pieces per thread holds its (16 + 16) x (8 + 16) box
+    if (d.ext[1] > 2 || d.ext[2] > 2) return strided ? NNZ_EINVAL : launch_wg<1, 16, 8, 12, WGeoDyn>(p, s, o);
     return strided ? launch_wg<1, 16, 8, 9, WGeoDyn>(p, s, o) : launch_wg<1, 32, 8, 6, WGeoDyn>(p, s, o);
   }
   return strided ? launch_wg<2, 4, 8, 12, WGeoDyn>(p, s, o) : launch_wg<4, 8, 8, 10, WGeoDyn>(p, s, o);
