@@ -114,6 +114,14 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
                            const float* inv_scale_device, float max_norm, float lr, float momentum, float weight_decay,
                            int first_step, void* stream);
 
+/* ---- hipGraph rewriting pass (csrc/graph_tools.hip): replaces every memset node of a captured, not yet instantiated
+ * hipGraph_t by a fill-kernel node with the same dependencies / dependents and the same bytes (a captured hipMemsetAsync
+ * node replays with a corrupted pattern on ROCm 7.2 once the process has allocated since capture; ATen's multi-block
+ * reductions and some library paths emit such nodes).  *n_replaced = nodes rewritten.  nnz_graph_node_census counts the
+ * nodes per hipGraphNodeType (diagnostics). */
+int nnz_graph_replace_memsets(void* hip_graph, int* n_replaced);
+int nnz_graph_node_census(void* hip_graph, int* counts, int ncounts);
+
 /* ---- x_proj of the cross-scan SS2D block on channel-major fp32 activations (the einsum of SS2D.forward_core,
  * /root/reference/nnunetv2/nets/m2net.py:179-184, in the two-source formulation of nnz_ss2d_scan_*):
  *   forward     P[s][b][c][l]   = sum_d W[s][c][d] x2[s][b][d][l]                       c < C2 <= 80, Di % 32 == 0

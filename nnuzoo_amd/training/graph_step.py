@@ -6,8 +6,10 @@ record the step once on a side stream and replay it as ONE graph launch.  torch.
 our C-ABI launchers are capture-safe by construction (stream-ordered, allocation-free, no host sync, and no
 hipMemsetAsync: a captured memset node replays with a corrupted fill pattern on this stack once the process has made
 further allocations - every zeroing is a kernel, csrc/common.hpp zero_async; tests/test_graph_replay_gpu.py).
-Still opt-in: library ops inside the captured region (ATen's multi-block reductions, MIOpen's fp32 convs) use that
-memset themselves.
+Library ops captured alongside (ATen's multi-block reductions zero their semaphores with hipMemsetAsync, some MIOpen /
+hipBLASLt paths too) are handled by a graph REWRITING pass: the captured hipGraph_t is kept (`keep_graph=True`), every
+memset node is replaced by a fill-kernel node with the same edges (csrc/graph_tools.hip: nnz_graph_replace_memsets), and
+only then the graph is instantiated - the replayed graph consists of kernel nodes only.
 
 What is captured: zero-grad-free forward, loss, (scaled) backward into static .grad buffers.  What stays eager: the
 GradScaler unscale / inf check, clip_grad_norm_, optimizer step and the loss read-back - the reference's train_step
@@ -15,19 +17,44 @@ semantics (/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1128
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional
 
 import torch
 
 
+def capture_memset_free(fn: Callable, stream: torch.cuda.Stream):
+    """Captures fn() on `stream` into a hipGraph, rewrites its memset nodes into kernel nodes and instantiates it.
+    Returns (torch.cuda.CUDAGraph, number of memset nodes rewritten).  Capture on the SAME side stream the warm-up ran
+    on: library handles (MIOpen / rocBLAS keep one per stream) are then already initialised; a fresh capture stream made
+    their lazy set-up run inside the capture (segfault)."""
+    import ctypes as C
+    from .._lib import call
+    if os.environ.get("NNZ_GRAPH_KEEP", "1") == "0":      # diagnostics: plain capture, no rewriting
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            fn()
+        return graph, 0
+    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(graph, stream=stream):
+        fn()
+    raw = graph.raw_cuda_graph()
+    n = C.c_int(0)
+    if os.environ.get("NNZ_GRAPH_REWRITE", "1") != "0":   # diagnostics switch
+        call("nnz_graph_replace_memsets", C.c_void_p(int(raw)), C.byref(n))
+    graph.instantiate()
+    return graph, int(n.value)
+
+
 class GraphedForwardBackward:
-    def __init__(self, network: torch.nn.Module, loss_fn: Callable, grad_scaler, autocast: bool, warmup_iters: int = 3):
+    def __init__(self, network: torch.nn.Module, loss_fn: Callable, grad_scaler, autocast: bool, warmup_iters: int = 2):
         self.network, self.loss_fn, self.scaler, self.autocast = network, loss_fn, grad_scaler, autocast
         self.warmup_iters = warmup_iters
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_data = None
         self.static_target: List[torch.Tensor] = []
         self.static_loss = None
+        self.memset_nodes_replaced = 0
         self._key = None
 
     def _fwd_bwd(self, data, target):
@@ -45,6 +72,9 @@ class GraphedForwardBackward:
         self.static_data = data.clone()
         self.static_target = [t.clone() for t in target]
         params = [p for p in self.network.parameters()]
+        # the eager warm-up passes must leave no trace in the module state: BatchNorm running estimates / counters are
+        # restored afterwards (the captured pass itself is only recorded, not executed)
+        buffers = [(b, b.detach().clone()) for b in self.network.buffers()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -55,11 +85,11 @@ class GraphedForwardBackward:
         torch.cuda.current_stream().wait_stream(side)
         for p in params:
             p.grad = None
-        self.graph = torch.cuda.CUDAGraph()
-        # capture on the SAME side stream the warm-up ran on: library handles (MIOpen / rocBLAS keep one per stream)
-        # are then already initialised; a fresh capture stream made their lazy set-up run inside the capture (segfault)
-        with torch.cuda.graph(self.graph, stream=side):
-            self.static_loss = self._fwd_bwd(self.static_data, self.static_target)
+        self.graph, self.memset_nodes_replaced = capture_memset_free(
+            lambda: setattr(self, "static_loss", self._fwd_bwd(self.static_data, self.static_target)), side)
+        with torch.no_grad():
+            for b, saved in buffers:
+                b.copy_(saved)
         self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
 
     def __call__(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:

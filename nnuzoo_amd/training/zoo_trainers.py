@@ -50,7 +50,11 @@ class _X2Trainer(nnUNetTrainer):
         self.early_stop_epoch = 25
         if self._fp32_step:
             self.grad_scaler = None
-        self.use_hip_graph = False  # opt-in: replay forward+loss+backward as one hipGraph (training/graph_step.py)
+        # forward + loss + backward replayed as ONE hipGraph (training/graph_step.py): the zoo steps issue 5 000 - 10 000
+        # small kernels and are host-bound in eager mode.  Captured memset nodes (ATen reductions, library paths) are
+        # rewritten into kernel nodes before instantiation (csrc/graph_tools.hip), which is what made replay exact on
+        # this stack.  NNZ_HIP_GRAPH=0 (or `use_hip_graph = False`) selects the eager step.
+        self.use_hip_graph = self.device.type == 'cuda' and os.environ.get("NNZ_HIP_GRAPH", "1") != "0"
         self._graphed = None
 
     def initialize(self):

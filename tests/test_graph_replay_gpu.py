@@ -82,3 +82,44 @@ def test_ss2d_block_forward_backward_replays_after_allocations(hip_lib):
         now = [state["y"].detach().float(), x.grad] + [p.grad for p in params]
         for a, b in zip(now, ref):
             assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * b.abs().max().item() + 1e-7), (a - b).abs().max().item()
+
+
+def test_memset_nodes_are_rewritten_and_replay_after_allocations(hip_lib):
+    """ATen ops that zero through hipMemsetAsync (Tensor.zero_ on a contiguous tensor, the semaphores of a multi-block
+    sum) captured next to our kernels: the rewriting pass (csrc/graph_tools.hip) replaces their memset nodes by fill-kernel
+    nodes; the replayed graph has no memset node and reproduces the eager results after the process allocated more."""
+    import ctypes as C
+    from nnuzoo_amd._lib import call
+    from nnuzoo_amd.training.graph_step import capture_memset_free
+    torch.manual_seed(0)
+    z = torch.empty(4099, device="cuda")
+    zb = torch.empty(1000, dtype=torch.uint8, device="cuda")
+    big = torch.randn(64, 1 << 16, device="cuda")            # column sums: a multi-block (global) reduction
+    out = torch.empty(64, device="cuda")
+    tot = torch.empty((), device="cuda")
+
+    def run():
+        z.zero_()
+        zb.zero_()
+        torch.sum(big, dim=1, out=out)
+        torch.sum(big, dim=(0, 1), out=tot)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref_out, ref_tot = out.clone(), tot.clone()
+    g, replaced = capture_memset_free(run, side)
+    assert replaced >= 1, "expected ATen to emit at least one memset node for these ops"
+    counts = (C.c_int * 16)()
+    call("nnz_graph_node_census", C.c_void_p(int(g.raw_cuda_graph())), counts, 16)
+    assert counts[2] == 0 and counts[0] >= replaced            # hipGraphNodeTypeMemset = 2, Kernel = 0
+    for _ in range(3):
+        z.fill_(7.0); zb.fill_(9); out.fill_(float("nan")); tot.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert float(z.abs().max()) == 0.0 and int(zb.max()) == 0
+        assert torch.allclose(out, ref_out, rtol=1e-5, atol=1e-3) and torch.allclose(tot, ref_tot, rtol=1e-5, atol=1e-2)
+        _junk()

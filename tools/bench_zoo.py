@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--graph", type=int, default=0)  # hipGraph replay is experimental: opt in with --graph 1
+    ap.add_argument("--graph", type=int, default=1)  # 1: hipGraph replay of fwd+loss+bwd (the trainers' default), 0: eager
     a = ap.parse_args()
     for name in a.models.split(","):
         cls = getattr(Z, "nnUNetTrainer" + name)

@@ -31,6 +31,29 @@ with torch.autocast("cuda", enabled=AC):
 l.backward()
 eager = {n: p.grad.clone() for n, p in tr.network.named_parameters() if p.grad is not None}
 print("eager loss", l.item(), flush=True)
+# yardstick: a SECOND eager pass on the same batch (fp32 atomics / reduction order make two runs differ)
+for p in tr.network.parameters():
+    p.grad = None
+with torch.autocast("cuda", enabled=AC):
+    out = tr.network(data)
+    l = tr.loss(list(out), target)
+l.backward()
+nb, worst = 0, 0.0
+gn = sum((eager[n].float() ** 2).sum() for n in eager).sqrt().item()
+dn = 0.0
+for n, p in tr.network.named_parameters():
+    if p.grad is None or n not in eager:
+        continue
+    d = (p.grad - eager[n]).abs().max().item()
+    s_ = eager[n].abs().max().item()
+    dn += ((p.grad - eager[n]).float() ** 2).sum().item()
+    if not (d <= 3e-2 * max(s_, 1e-6)):
+        nb += 1
+        worst = max(worst, d / max(s_, 1e-12))
+print("eager vs eager: params off by > 3e-2:", nb, "worst", worst, "global rel L2", dn ** 0.5 / gn, flush=True)
+del l, out   # the eager autograd graph (AccumulateGrad nodes bound to the default stream) must not outlive into the capture
+for p in tr.network.parameters():
+    p.grad = None
 g = GraphedForwardBackward(tr.network, tr.loss, None, autocast=AC)
 for it in range(3):
     lg = g(data, target)
@@ -44,4 +67,10 @@ for it in range(3):
         if not (d <= 3e-2 * max(s, 1e-6)):
             bad.append((d / max(s, 1e-12), n))
     bad.sort(reverse=True)
-    print("replay", it, "loss", lg.item(), "params off by > 3e-2:", len(bad), bad[:5], flush=True)
+    dn = sum(((p.grad - eager[n]).float() ** 2).sum().item() for n, p in tr.network.named_parameters()
+             if p.grad is not None and n in eager)
+    print("replay", it, "global rel L2 vs eager", dn ** 0.5 / gn, "loss", lg.item(), "memset nodes rewritten", g.memset_nodes_replaced,
+          "params off by > 3e-2:", len(bad), bad[:5], flush=True)
+    junk = [torch.full((1 + 37 * i,), float("nan"), device="cuda") for i in range(1500)]   # allocations between replays
+    torch.cuda.synchronize()
+    del junk
