@@ -10,7 +10,8 @@ region starts.
 
 Secondary leg (`secondary`, BASELINE configs[2], N = 1 only): nnUNetTrainerM2Net.train_step (M2Net = SS2D^2Net,
 /root/reference/nnunetv2/nets/m2net.py:805-971, trainer nnUNetTrainerM2Net.py) on synthetic 1x512^2 patches, batch 2,
-eager, with the roofline of its dominant kernel family (the cross-scan backward, HBM-bound by SURVEY.md 8d).
+forward+loss+backward replayed as one hipGraph (the trainer's default; optimizer tail eager), with the roofline of its
+dominant kernel family (the cross-scan backward, HBM-bound by SURVEY.md 8d) timed over eager steps.
 
     python bench.py --gpus N --steps K --warmup W
 (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; weak scaling: 2 patches per GPU.)
