@@ -45,6 +45,7 @@ struct ConvDev {
   nnz_conv_desc d;
   int tiles[3];
   int gx, gy, gz;
+  int cout_fastest;  // workgroup order: cout block index fastest (1) or m-tile index fastest (0)
 };
 
 // Box geometry policies.  GeoIso: input stride and tap extent are compile-time and equal on the three axes (the
@@ -94,6 +95,16 @@ struct ConvCfg {
   static constexpr int OUT_BYTES = TD * TH * TW * (NB * 64 + 16);  // epilogue staging image
 };
 
+// Tuning knobs (diagnostics / per-layer experiments; defaults are the measured best).  nnz_conv_tuning(knob, value):
+//   0  depth-reuse loop for k3 s1 layers with Cout % 64 != 0 on >= 64^3 grids          (default 1)
+//   1  depth-reuse loop (one 32-cout block per workgroup) also for Cout % 64 == 0      (default 1)
+//      (only with >= 4 reduction slices, Cin >= 64: a 2-slice layer pays the doubled box staging of two workgroups
+//      per tile more than it gains - measured on dec0.0's data gradient, 32 -> 64 channels: 760 -> 680 TFLOP/s)
+//   2  smallest m-grid edge (cube root of the voxel count) that takes the depth-reuse loop (default 32)
+//   3  workgroup order: cout block fastest (1) / m-tile fastest (0)                        (default 1)
+//   4  smallest Cin for knob 1                                                          (default 64)
+static int g_tuning[8] = {1, 1, 32, 1, 64, 0, 0, 0};
+
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
 // One voxel fragment of INPUT plane d0 + p then feeds the MFMAs of the three depth taps (output planes p, p - 1, p - 2)
@@ -120,10 +131,21 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   // ---- workgroup -> (tile, cout block, sample, group) ---------------------------------------------
   const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
   unsigned lin = xcd_remap(blockIdx.x, nwg);
-  const int bx = lin % p.gx;
-  lin /= p.gx;
-  const int by = lin % p.gy;
-  const int bz = lin / p.gy;
+  int bx, by;
+  if (p.cout_fastest) {
+    // the cout blocks of one m-tile are neighbours in launch order (same XCD, same time): the second .. gy-th of them
+    // find the tile's input box in L2 instead of HBM
+    by = lin % p.gy;
+    lin /= p.gy;
+    bx = lin % p.gx;
+    lin /= p.gx;
+  } else {
+    bx = lin % p.gx;
+    lin /= p.gx;
+    by = lin % p.gy;
+    lin /= p.gy;
+  }
+  const int bz = lin;
   const int g = bz % p.d.ngroups;
   const int n = bz / p.d.ngroups;
   const int tw_i = bx % p.tiles[2];
@@ -476,6 +498,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   p.gx = p.tiles[0] * p.tiles[1] * p.tiles[2];
   p.gy = p.d.Cout / (32 * NB);
   p.gz = p.d.N * p.d.ngroups;
+  p.cout_fastest = g_tuning[3] && p.gy > 1;
   auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G, DRE, DFLIP>;
   static DynLdsCache lds_cache;  // per instantiation, per device
   {
@@ -496,14 +519,6 @@ template <int TD, int TH, int TW, int NB, int IS, int EXT>
 static int launch_iso(const ConvDev& p, hipStream_t stream) {
   return launch_cfg<TD, TH, TW, NB, iso_lpt<TD, TH, TW, IS, EXT>(), GeoIso<IS, EXT>>(p, stream);
 }
-
-// Tuning knobs (diagnostics / per-layer experiments; defaults are the measured best).  nnz_conv_tuning(knob, value):
-//   0  depth-reuse loop for k3 s1 layers with Cout % 64 != 0 on >= 64^3 grids          (default 1)
-//   1  depth-reuse loop (one 32-cout block per workgroup) also for Cout % 64 == 0      (default 1)
-//      (only with >= 4 reduction slices, Cin >= 64: a 2-slice layer pays the doubled box staging of two workgroups
-//      per tile more than it gains - measured on dec0.0's data gradient, 32 -> 64 channels: 760 -> 680 TFLOP/s)
-//   2  smallest m-grid edge (cube root of the voxel count) that takes the depth-reuse loop (default 32)
-static int g_tuning[8] = {1, 1, 32, 0, 0, 0, 0, 0};
 
 // k3 s1 table in depth-major tap order whose three depth taps of every (kh, kw) row share their in-plane offset and sit
 // on box planes (0, 1, 2) [forward] or (2, 1, 0) [data gradient]: what the depth-reuse loop assumes.  Returns -1 if not.
@@ -533,7 +548,7 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
     if constexpr (EXT == 2) {
       const int flip = depth_reuse_flip(p.d);
       const long edge = g_tuning[2];
-      if (flip >= 0 && mvox >= edge * edge * edge && ((!nb2 && g_tuning[0]) || (nb2 && g_tuning[1] && p.d.Cin >= 64))) {
+      if (flip >= 0 && mvox >= edge * edge * edge && ((!nb2 && g_tuning[0]) || (nb2 && g_tuning[1] && p.d.Cin >= g_tuning[4]))) {
         if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true>(p, stream);
         return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false>(p, stream);
       }

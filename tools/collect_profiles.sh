@@ -1,0 +1,32 @@
+#!/bin/bash
+# Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh r02
+# Writes under gpurun_out/ (copy what is to be judged into profiles/).
+set -u
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary"
+# 1. kernel trace + stats of the primary bench command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $BENCH > $OUT/${TAG}_bench_profiled.json 2>/dev/null
+cp $(ls $OUT/prof_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_n1_kernel_stats.csv
+# 2. HBM traffic counters, separate passes (MI355X_MICROARCH.md, HBM / rocprofv3 section)
+BENCH2="python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-launch-timer"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_f -- $BENCH2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_w -- $BENCH2 > /dev/null 2>&1
+cp $(ls $OUT/prof_f/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_fetch_size.csv
+cp $(ls $OUT/prof_w/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_write_size.csv
+# 3. scan / attention kernels: stats of the zoo steps (eager so that every launch is attributed) + one SQ counter pass
+ZOO="python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models M2Net --steps 2 --warmup 2 --graph 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_zoo -- $ZOO > /dev/null 2>&1
+cp $(ls $OUT/prof_zoo/*/*kernel_stats.csv | head -1) $OUT/${TAG}_m2net_kernel_stats.csv
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/prof_zoo_pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_scan.py > /dev/null 2>&1
+cp $(ls $OUT/prof_zoo_pmc/*/*counter_collection.csv | head -1) $OUT/${TAG}_scan_pmc_sq.csv
+SW="python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models SwT2Net --steps 2 --warmup 2 --graph 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sw -- $SW > /dev/null 2>&1
+cp $(ls $OUT/prof_sw/*/*kernel_stats.csv | head -1) $OUT/${TAG}_swt2net_kernel_stats.csv
+rm -rf $OUT/prof_stats $OUT/prof_f $OUT/prof_w $OUT/prof_zoo $OUT/prof_zoo_pmc $OUT/prof_sw
+cd $GRAFT_REPO_ROOT
+python3 tools/bench_scan.py > $OUT/${TAG}_scan_bench.txt 2>&1
+python3 tools/bench_conv_layers.py > $OUT/${TAG}_conv_layers.txt 2>&1
+ls -la $OUT | tail -20

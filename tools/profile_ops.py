@@ -23,6 +23,7 @@ def main():
     torch.manual_seed(0)
     tr = cls(plans, cfg, 0, dj, device=torch.device("cuda"))
     tr.initialize()
+    tr.use_hip_graph = False   # the census is about the eager op stream
     b = synthetic_batch(2, (a.size, a.size), tr._get_deep_supervision_scales(), seed=3)
     b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
     for _ in range(3):
