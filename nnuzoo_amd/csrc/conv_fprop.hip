@@ -98,12 +98,13 @@ struct ConvCfg {
 // Tuning knobs (diagnostics / per-layer experiments; defaults are the measured best).  nnz_conv_tuning(knob, value):
 //   0  depth-reuse loop for k3 s1 layers with Cout % 64 != 0 on >= 64^3 grids          (default 1)
 //   1  depth-reuse loop (one 32-cout block per workgroup) also for Cout % 64 == 0      (default 1)
-//      (only with >= 4 reduction slices, Cin >= 64: a 2-slice layer pays the doubled box staging of two workgroups
-//      per tile more than it gains - measured on dec0.0's data gradient, 32 -> 64 channels: 760 -> 680 TFLOP/s)
+//      (with the m-tile-fastest order a 2-slice layer paid the doubled box fetch of two workgroups per tile more than
+//      it gained - dec0.0's data gradient, 32 -> 64 channels: 760 -> 680 TFLOP/s; with the cout-fastest order of knob 3
+//      the second workgroup finds the box in L2 and the same layer gains: 628 -> 720 on one box)
 //   2  smallest m-grid edge (cube root of the voxel count) that takes the depth-reuse loop (default 32)
 //   3  workgroup order: cout block fastest (1) / m-tile fastest (0)                        (default 1)
-//   4  smallest Cin for knob 1                                                          (default 64)
-static int g_tuning[8] = {1, 1, 32, 1, 64, 0, 0, 0};
+//   4  smallest Cin for knob 1                                                          (default 32)
+static int g_tuning[8] = {1, 1, 32, 1, 32, 0, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
