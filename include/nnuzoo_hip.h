@@ -46,7 +46,7 @@ int nnz_conv_tap_forward_stats(const void* in_f16, void* out_f16, const void* w_
 /* Tuning / diagnostics knob of the conv kernels' tile dispatch (per-layer experiments; defaults are the measured best):
  * knob 0 = depth-reuse tap loop for k3 s1 layers with one 32-wide cout block on >= 64^3 grids (default 1),
  * knob 1 = the same loop, one cout block per workgroup, for Cout % 64 == 0 layers (default 1),
- * knob 2 = smallest m-grid edge (cube root of the voxel count) that takes that loop (default 32),
+ * knob 2 = smallest m-grid edge (cube root of the voxel count) that takes that loop (default 16),
  * knob 3 = workgroup order: cout block fastest (1, default) or m-tile fastest (0),
  * knob 4 = smallest Cin for knob 1 (default 32).  Process-wide. */
 int nnz_conv_tuning(int knob, int value);

@@ -101,10 +101,10 @@ struct ConvCfg {
 //      (with the m-tile-fastest order a 2-slice layer paid the doubled box fetch of two workgroups per tile more than
 //      it gained - dec0.0's data gradient, 32 -> 64 channels: 760 -> 680 TFLOP/s; with the cout-fastest order of knob 3
 //      the second workgroup finds the box in L2 and the same layer gains: 628 -> 720 on one box)
-//   2  smallest m-grid edge (cube root of the voxel count) that takes the depth-reuse loop (default 32)
+//   2  smallest m-grid edge (cube root of the voxel count) that takes the depth-reuse loop (default 16)
 //   3  workgroup order: cout block fastest (1) / m-tile fastest (0)                        (default 1)
 //   4  smallest Cin for knob 1                                                          (default 32)
-static int g_tuning[8] = {1, 1, 32, 1, 32, 0, 0, 0};
+static int g_tuning[8] = {1, 1, 16, 1, 32, 0, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.

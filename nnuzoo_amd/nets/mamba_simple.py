@@ -25,7 +25,7 @@ def _s4d_real_log(d_inner, d_state, device):
 class Mamba(nn.Module):
     def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
                  dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False, use_fast_path=True,
-                 layer_idx=None, device=None, dtype=None, bimamba_type="none", nslices=5):
+                 layer_idx=None, device=None, dtype=None, bimamba_type="none", nslices=5, _single_direction_params=False):
         fk = {"device": device, "dtype": dtype}
         super().__init__()
         self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
@@ -64,6 +64,12 @@ class Mamba(nn.Module):
         self.A_log._no_weight_decay = True
         self.D = nn.Parameter(torch.ones(self.d_inner, device=device))
         self.D._no_weight_decay = True
+        if _single_direction_params:
+            # parameter set of `mamba_ssm.Mamba` (class MambaSSM below): no backward / slice direction tensors
+            if bimamba_type != "none":
+                raise ValueError("the single-direction parameter set has no bimamba variants")
+            self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **fk)
+            return
         # backward direction
         self.A_b_log = nn.Parameter(_s4d_real_log(self.d_inner, self.d_state, device))
         self.A_b_log._no_weight_decay = True
@@ -114,3 +120,18 @@ class Mamba(nn.Module):
         raise NotImplementedError("nnuzoo_amd.Mamba: step-wise decoding is outside the segmentation hot path")
 
     allocate_inference_cache = step
+
+
+class MambaSSM(Mamba):
+    """`mamba_ssm.Mamba` as the reference binds it (`from mamba_ssm import Mamba`: nets/mamba_nd2net.py:26, lm2net.py:14,
+    LightMUNet.py:6): the same block with the one-direction parameter set - state_dict keys in_proj.weight, conv1d.weight,
+    conv1d.bias, x_proj.weight, dt_proj.weight, dt_proj.bias, A_log, D, out_proj.weight (same construction / RNG order as
+    the vendored class above minus its `_b` / `_s` tensors).  mamba_ssm is not installed here and its version is not
+    pinned by the reference: key names restated from the published 1.x / 2.x module."""
+
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False, use_fast_path=True,
+                 layer_idx=None, device=None, dtype=None):
+        super().__init__(d_model, d_state, d_conv, expand, dt_rank, dt_min, dt_max, dt_init, dt_scale, dt_init_floor,
+                         conv_bias, bias, use_fast_path, layer_idx, device, dtype, bimamba_type="none",
+                         _single_direction_params=True)

@@ -174,3 +174,23 @@ class nnUNetTrainerSSND2NetP(nnUNetTrainerSSND2Net):
     def build_network_architecture(*args, **kwargs):
         from ..nets.ssnd2net import get_ssnd2net_from_plans
         return _legacy_or_live(lambda *a, **k: get_ssnd2net_from_plans(*a, small_mode=True, **k), args, kwargs)
+
+
+class nnUNetTrainerMambaND2Net(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerMambaND2Net.py:15-131 (N-D; fp32 step without autocast / GradScaler
+    :111-131; AdamW 1e-4 / wd 5e-2, cosine; the 7-entry deep-supervision scale list per axis)"""
+    _fp32_step = True
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.mamba_nd2net import get_mamband2net_from_plans
+        return _legacy_or_live(lambda *a, **k: get_mamband2net_from_plans(*a, small_mode=False, **k), args, kwargs)
+
+
+class nnUNetTrainerMambaND2NetP(nnUNetTrainerMambaND2Net):
+    """reference :134-156: small_mode=True, for which the reference's factory raises NotImplementedError (:1926)"""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.mamba_nd2net import get_mamband2net_from_plans
+        return _legacy_or_live(lambda *a, **k: get_mamband2net_from_plans(*a, small_mode=True, **k), args, kwargs)

@@ -1,0 +1,95 @@
+"""MambaND2Net (nnuzoo_amd/nets/mamba_nd2net.py; reference nets/mamba_nd2net.py).  Pinned part: `MambaNDCore` - the
+patch embedding + ordered / reversed Mamba block stack, all in-tree reference code - against tests/golden/mambandcore.npz
+(the reference class run on CPU with `mamba_ssm.Mamba` bound to the reference's vendored block, tools/make_golden.py):
+parameter names, forward (final and an intermediate layer), input and parameter gradients, 2-D and 3-D.  The UNETR
+encoder / decoder blocks around it come from monai (absent): PARITY UNPINNED, covered by shape / finiteness checks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden", "mambandcore.npz")
+
+
+def _core(z, tag):
+    from nnuzoo_amd.nets.mamba_nd2net import MambaNDCore
+    cfg = [int(v) for v in z[f"{tag}_cfg"]]
+    sd, cin, E, nl = cfg[:4]
+    img, patch = tuple(cfg[4:4 + sd]), tuple(cfg[4 + sd:4 + 2 * sd])
+    core = MambaNDCore(sd, img, patch, cin, E, nl)
+    return core, (sd, cin, E, nl, img, patch)
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_core_parameter_names_match_reference(tag):
+    z = np.load(G)
+    core, _ = _core(z, tag)
+    want = sorted(k[len(tag) + 3:] for k in z.files if k.startswith(f"{tag}_p_"))
+    assert sorted(n for n, _ in core.named_parameters()) == want
+    for n, p in core.named_parameters():
+        assert tuple(p.shape) == z[f"{tag}_p_{n}"].shape, n
+
+
+def test_whole_net_structure_cpu():
+    from nnuzoo_amd.nets.mamba_nd2net import MambaND2Net, get_mamband2net_from_plans
+    net = MambaND2Net(2, 1, 2, True, [512, 512])
+    assert round(sum(p.numel() for p in net.parameters()) / 1e6, 2) == 41.39
+    keys = list(net.state_dict())
+    assert "stage1.mamba.patch_embed.projection.0.conv.weight" in keys and "stage3d.decoder5.transp_conv.conv.weight" in keys
+    assert "stage5.encoder2.transp_conv_init.conv.weight" in keys and "side6.conv.weight" in keys and "outconv.conv.bias" in keys
+    assert net.stage1.out_indices == [2, 4, 6] and net.stage5.out_indices == [2, 2, 3]      # linspace(2, L - 1, 3)
+    assert [l.reverse for l in net.stage1.mamba.layers] == [False, True] * 3 + [False]
+    with pytest.raises(NotImplementedError):
+        class CM:
+            patch_size = [64, 64]
+        get_mamband2net_from_plans(None, {"labels": {"a": 0, "b": 1}}, CM(), 1, small_mode=True)
+    MambaND2Net(3, 1, 3, False, [64, 64, 64])                                               # 3-D constructs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_core_forward_backward_vs_reference_golden(hip_lib, tag):
+    z = np.load(G)
+    core, _ = _core(z, tag)
+    with torch.no_grad():
+        for n, p in core.named_parameters():
+            p.copy_(torch.from_numpy(z[f"{tag}_p_{n}"]))
+    core = core.cuda().train()
+    x = torch.from_numpy(z[f"{tag}_x"]).cuda().requires_grad_(True)
+    y, outs = core(x)
+    (y * torch.from_numpy(z[f"{tag}_G"]).cuda()).sum().backward()
+
+    def close(a, b, tol=3e-4):
+        b = torch.from_numpy(b)
+        return torch.allclose(a.detach().float().cpu(), b, rtol=tol, atol=tol * max(1e-6, b.abs().max().item()))
+
+    assert close(y, z[f"{tag}_y"]) and close(outs[2], z[f"{tag}_mid"])
+    assert close(x.grad, z[f"{tag}_dx"], 1e-3)
+    for n, p in core.named_parameters():
+        k = f"{tag}_g_{n}"
+        if k in z.files:
+            assert close(p.grad, z[k], 2e-3), n
+
+
+@pytest.mark.gpu
+def test_whole_net_forward_backward_and_trainer_step(hip_lib):
+    from nnuzoo_amd.nets.mamba_nd2net import MambaND2Net
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerMambaND2Net
+    torch.manual_seed(0)
+    net = MambaND2Net(2, 1, 2, True, [64, 64]).cuda()
+    outs = net(torch.randn(2, 1, 64, 64, device="cuda"))
+    assert [tuple(o.shape[2:]) for o in outs] == [(64, 64), (64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (4, 4)]
+    sum(o.float().pow(2).mean() for o in outs).backward()
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    plans, cfg, dj = nnunet_plans(2, (64, 64), batch_size=2)
+    tr = nnUNetTrainerMambaND2Net(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    scales = tr._get_deep_supervision_scales()
+    # the reference's scale list ends 1/16, 1/32 although stages 5 and 6 share a resolution (patch_merging5 has scale 1):
+    # the last target does not match the last output, which is harmless because its deep-supervision weight is 0
+    b = synthetic_batch(2, (64, 64), scales, seed=1)
+    assert b["target"][-1].shape[-1] == 2 and b["target"][-2].shape[-1] == 4
+    losses = [float(tr.train_step({"data": b["data"], "target": b["target"]})["loss"]) for _ in range(3)]
+    assert all(np.isfinite(losses))

@@ -405,13 +405,54 @@ def gen_mamba(ref):
     np.savez_compressed(os.path.join(OUT, "mamba_block.npz"), **out)
 
 
+def gen_mambandcore(ref):
+    """MambaNDCore (nets/mamba_nd2net.py:725-1001: patch embedding + ordered / reversed Mamba blocks) of the reference,
+    run on CPU with `mamba_ssm.Mamba` bound to the reference's own vendored block (nets/seg_mamba/mamba_simple.py, slow
+    path on selective_scan_ref - same mathematics as mamba_ssm's block, bimamba "none"), 2-D and 3-D."""
+    from nnunetv2.nets.seg_mamba import mamba_simple as ms
+    ms.causal_conv1d_fn = None
+    ms.selective_scan_fn = ref
+    import nnunetv2.nets.mamba_nd2net as R
+    R.Mamba = lambda dim, layer_idx=None, **kw: ms.Mamba(dim, bimamba_type="none", use_fast_path=False,
+                                                         layer_idx=layer_idx, **kw)
+    out = {}
+    for tag, sd, img, patch, cin, E, nl in [("2d", 2, (32, 48), (4, 4), 3, 32, 5), ("3d", 3, (16, 16, 16), (4, 4, 4), 2, 48, 7)]:
+        torch.manual_seed(0)
+        core = R.MambaNDCore(spatial_dims=sd, in_channels=cin, img_size=img, patch_size=patch, embed_dims=E,
+                             drop_path_rate=0.0, final_norm=False, fused_add_norm=False, drop_rate=0.0, d_state=16,
+                             force_a2=False, pretrained=None, num_layers=nl).train()
+        det_fill(core, skip=())
+        with torch.no_grad():
+            for n, p in core.named_parameters():
+                if n.endswith("A_log") or "A_b_log" in n or "A_s_log" in n:
+                    p.copy_(torch.log(1.0 + torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) % 16) * 0.9 + 0.05 * p)
+        i = torch.arange(2 * cin * int(np.prod(img)), dtype=torch.float64)
+        x = torch.cos(0.37 * i + 0.5).float().reshape(2, cin, *img).requires_grad_(True)
+        y, outs = core(x)
+        G = torch.sin(0.11 * torch.arange(y.numel(), dtype=torch.float64) + 1.0).float().reshape(y.shape)
+        (y * G).sum().backward()
+        out[f"{tag}_cfg"] = np.array([sd, cin, E, nl, *img, *patch])
+        out[f"{tag}_x"], out[f"{tag}_G"], out[f"{tag}_y"] = x.detach().numpy(), G.numpy(), y.detach().numpy()
+        out[f"{tag}_mid"] = outs[2].detach().numpy()
+        out[f"{tag}_dx"] = x.grad.numpy()
+        for n, p in core.named_parameters():
+            if any(t in n for t in ("_b.", "_s.", "_b_log", "_s_log", ".D_b", ".D_s")):
+                continue                       # tensors of the vendored class that mamba_ssm.Mamba does not have
+            out[f"{tag}_p_{n}"] = p.detach().numpy()
+            if p.grad is not None:
+                out[f"{tag}_g_{n}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "mambandcore.npz"), **out)
+
+
 if __name__ == "__main__":
     ref = ref_shim.install()
-    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba", "ssnd2net"]
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba", "ssnd2net", "mambandcore"]
     if "sw" in which:
         gen_sliding_window()
     if "mamba" in which:
         gen_mamba(ref)
+    if "mambandcore" in which:
+        gen_mambandcore(ref)
     if "ssnd2net" in which:
         gen_ssnd2net()
     if "scan" in which:
