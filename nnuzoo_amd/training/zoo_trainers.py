@@ -181,6 +181,15 @@ class nnUNetTrainerMambaND2Net(_X2Trainer):
     :111-131; AdamW 1e-4 / wd 5e-2, cosine; the 7-entry deep-supervision scale list per axis)"""
     _fp32_step = True
 
+    def initialize(self):
+        # The UNETR-style blocks of this net are fp32 convolutions with 4..128 channels (1x1, 3x3, k = s transposed).
+        # On this stack (ROCm 7.2 MIOpen through PyTorch's immediate mode) their backward faults with an out-of-bounds
+        # access inside the full network (each block alone passes; MIOpen logs "workspace required ... provided ..." for
+        # the solver it then runs anyway) - tools/probes/mambaND_stage_probe.py.  ATen's native convolution path is
+        # exact and, at these channel counts, not slower, so the library path is switched off for this trainer's process.
+        torch.backends.cudnn.enabled = False
+        super().initialize()
+
     @staticmethod
     def build_network_architecture(*args, **kwargs):
         from ..nets.mamba_nd2net import get_mamband2net_from_plans

@@ -78,6 +78,20 @@ def test_whole_net_forward_backward_and_trainer_step(hip_lib):
     from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
     from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerMambaND2Net
     torch.manual_seed(0)
+    # fp32 small-channel convolutions of the UNETR blocks: ATen's native path (the trainer does the same, see its
+    # initialize(): MIOpen's immediate-mode backward faults inside the full network on this stack)
+    prev = torch.backends.cudnn.enabled
+    torch.backends.cudnn.enabled = False
+    try:
+        _whole_net_checks()
+    finally:
+        torch.backends.cudnn.enabled = prev
+
+
+def _whole_net_checks():
+    from nnuzoo_amd.nets.mamba_nd2net import MambaND2Net
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerMambaND2Net
     net = MambaND2Net(2, 1, 2, True, [64, 64]).cuda()
     outs = net(torch.randn(2, 1, 64, 64, device="cuda"))
     assert [tuple(o.shape[2:]) for o in outs] == [(64, 64), (64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (4, 4)]
