@@ -250,9 +250,11 @@ class PatchExpand(_PatchExpandND):
                          tuple(scale[:spatial_dims]), output_dim=output_dim, norm_layer=norm_layer)
 
 
-class MambaND2Net(nn.Module):
-    def __init__(self, spatial_dims: int, in_ch: int, out_ch: int, deep_supervision: bool, input_patch_size):
-        super().__init__()
+class _UnetrStageX2(nn.Module):
+    """outer U^2 wiring shared by MambaND2Net and UNETR2Net (the two reference constructors are identical up to the
+    inner stage class: nets/mamba_nd2net.py:1598-1809, nets/unetr2net.py:1026-1240)"""
+
+    def _build(self, stage_cls, spatial_dims: int, in_ch: int, out_ch: int, deep_supervision: bool, input_patch_size):
         sd = self.spatial_dims = spatial_dims
         self.deep_supervision, self.input_patch_size = deep_supervision, input_patch_size
         self.scales = scales = get_scales(sd, input_patch_size, n_layers=5, patch_size=None)
@@ -260,7 +262,7 @@ class MambaND2Net(nn.Module):
         def ips(k):
             return input_patch_size if k == 0 else get_scale_value(sd, input_patch_size, scales[:k])
 
-        mnd = partial(MambaND, spatial_dims=sd)
+        mnd = partial(stage_cls, spatial_dims=sd)
         deep = dict(encoder_layers=(0, 0, 0), decoder_scale=(2, 1, 1, 1))
         self.stage1 = mnd(in_channels=in_ch, out_channels=32, feature_size=4, hidden_size=96, num_layers=7,
                           patch_size=(16, 16, 16), img_size=ips(0))
@@ -337,6 +339,12 @@ class MambaND2Net(nn.Module):
         for g in self._encoder_groups():
             for p in g.parameters():
                 p.requires_grad = True
+
+
+class MambaND2Net(_UnetrStageX2):
+    def __init__(self, spatial_dims: int, in_ch: int, out_ch: int, deep_supervision: bool, input_patch_size):
+        super().__init__()
+        self._build(MambaND, spatial_dims, in_ch, out_ch, deep_supervision, input_patch_size)
 
 
 def get_mamband2net_from_plans(plans_manager, dataset_json: dict, configuration_manager, num_input_channels: int,

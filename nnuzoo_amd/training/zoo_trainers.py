@@ -203,3 +203,21 @@ class nnUNetTrainerMambaND2NetP(nnUNetTrainerMambaND2Net):
     def build_network_architecture(*args, **kwargs):
         from ..nets.mamba_nd2net import get_mamband2net_from_plans
         return _legacy_or_live(lambda *a, **k: get_mamband2net_from_plans(*a, small_mode=True, **k), args, kwargs)
+
+
+class nnUNetTrainerUNETR2Net(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerUNETR2Net.py:15-118 (inherits the base autocast train_step;
+    num_epochs 1000; AdamW 1e-4 / wd 5e-2, cosine; the 7-entry deep-supervision scale list per axis)"""
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 1000):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+
+    def initialize(self):
+        torch.backends.cudnn.enabled = False   # same small-channel UNETR conv blocks as MambaND2Net (see there)
+        super().initialize()
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.unetr2net import get_unetr2net_from_plans
+        return _legacy_or_live(lambda *a, **k: get_unetr2net_from_plans(*a, small_mode=False, **k), args, kwargs)

@@ -45,6 +45,9 @@ TRAINERS = {
     "nnUNetTrainerSSND2NetP": ("nnUNetTrainerSSND2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerSSND2NetP"),
     "nnUNetTrainerMambaND2Net": ("nnUNetTrainerMambaND2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerMambaND2Net"),
     "nnUNetTrainerMambaND2NetP": ("nnUNetTrainerMambaND2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerMambaND2NetP"),
+    "nnUNetTrainerUNETR2Net": ("nnUNetTrainerUNETR2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerUNETR2Net"),
+    "nnUNetTrainerLightMamba2Net": ("nnUNetTrainerLightMamba2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerLightMamba2Net"),
+    "nnUNetTrainerLightMamba2NetP": ("nnUNetTrainerLightMamba2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerLightMamba2NetP"),
 }
 TRAINERS = {k: v for k, v in TRAINERS.items()
             if os.path.exists(os.path.join(TRAINER_FOLDER, v[0] + ".py"))}  # families not built yet have no module
