@@ -75,7 +75,9 @@ def get_scale_value(spatial_dims: int, input_patch_size, scales):
     return tuple(v)
 
 
-def get_scales(spatial_dims, input_patch_size, n_layers, patch_size):
+def get_scales(spatial_dims, input_patch_size, n_layers, patch_size=None, min_size: int = 1):
+    """per level and axis: halve unless the size is odd or (light_mamba2net.py:562-600) the half would fall below
+    `min_size`; min_size=1 is ssnd2net.py's / mamba_nd2net.py's form"""
     if input_patch_size is None:
         return None
     v = list(input_patch_size)
@@ -86,7 +88,11 @@ def get_scales(spatial_dims, input_patch_size, n_layers, patch_size):
     for _ in range(n_layers):
         step = []
         for a in range(spatial_dims):
-            f, v[a] = get_scale(v[a])
+            f, half = get_scale(v[a])
+            if half >= min_size:
+                v[a] = half
+            else:
+                f = 1
             step.append(f)
         scales.append(tuple(step))
     return scales

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
+
 import torch
 from torch.optim import AdamW
 from torch.optim.lr_scheduler import CosineAnnealingLR
@@ -221,3 +223,48 @@ class nnUNetTrainerUNETR2Net(_X2Trainer):
     def build_network_architecture(*args, **kwargs):
         from ..nets.unetr2net import get_unetr2net_from_plans
         return _legacy_or_live(lambda *a, **k: get_unetr2net_from_plans(*a, small_mode=False, **k), args, kwargs)
+
+
+class nnUNetTrainerLightMamba2Net(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerLightMamba2Net.py:18-131 (N-D; fp32 step without autocast /
+    GradScaler :30-48; AdamW 1e-4 / wd 5e-2, cosine; deep-supervision scales from get_scales(min_size=8) :70-94)"""
+    _fp32_step = True
+    _small_model = False
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.early_stop_epoch = 350
+
+    def initialize(self):
+        # fp32 convolutions with 16..256 channels, depthwise 3x3 and 1x1: ATen's native path (see MambaND2Net above)
+        torch.backends.cudnn.enabled = False
+        super().initialize()
+
+    def _get_deep_supervision_scales(self):
+        if not self.enable_deep_supervision:
+            return None
+        from ..nets.ssnd2net import get_scales
+        ps = self.configuration_manager.patch_size
+        cum, out = np.ones(len(ps)), [[1.0] * len(ps), [1.0] * len(ps)]
+        for s in get_scales(len(ps), ps, n_layers=5, patch_size=None, min_size=8):
+            cum = cum / np.array(s)
+            out.append([float(v) for v in cum])
+        return out
+
+    @classmethod
+    def _build(cls, args, kwargs, small):
+        from ..nets.light_mamba2net import get_light_mamba2net_from_plans
+        return _legacy_or_live(lambda *a, **k: get_light_mamba2net_from_plans(*a, small_model=small, **k), args, kwargs)
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        return nnUNetTrainerLightMamba2Net._build(args, kwargs, False)
+
+
+class nnUNetTrainerLightMamba2NetP(nnUNetTrainerLightMamba2Net):
+    """reference :134-156: the small model (LightMamba2NetP)"""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        return nnUNetTrainerLightMamba2Net._build(args, kwargs, True)
