@@ -95,10 +95,10 @@ def test_ssnd_golden(hip_lib, tag, sd):
         close(g, z["g_" + n], "g_" + n, rtol=3e-4)
 
 
-@pytest.mark.parametrize("name", ["M2NetP", "SwT2Net"])
+@pytest.mark.parametrize("name", ["M2NetP", "M2Net", "SwT2Net"])
 def test_whole_net_forward_golden(hip_lib, name):
     from nnuzoo_amd.nets import m2net, swt2net
-    cls = {"M2NetP": m2net.M2NetP, "SwT2Net": swt2net.SwT2Net}[name]
+    cls = {"M2NetP": m2net.M2NetP, "M2Net": m2net.M2Net, "SwT2Net": swt2net.SwT2Net}[name]
     z = np.load(os.path.join(G, f"net_{name}_64.npz"))
     torch.manual_seed(0)
     net = cls(1, 2, True)
@@ -114,6 +114,45 @@ def test_whole_net_forward_golden(hip_lib, name):
     margin = (ref0[:, 1] - ref0[:, 0]).abs()
     agree = (ref0.argmax(1) == outs[0].cpu().argmax(1)) | (margin < 1e-4 * ref0.abs().max())
     assert agree.all()
+
+
+@pytest.mark.parametrize("name", ["M2NetP", "SwT2Net"])
+def test_whole_net_backward_golden(hip_lib, name):
+    """whole-net BACKWARD against the reference's own autograd (tools/make_golden.py gen_nets: eval mode, loss =
+    sum_i <out_i, G_i> / voxels with formula-made G_i): dx in full; of every parameter gradient the reference's <= 256
+    evenly strided samples and its L2 norm.  Tolerances are relative to each gradient's own scale and were set from the
+    measured worst case x ~4 (hundreds of fp32 layers, different but equally valid reduction orders)."""
+    from nnuzoo_amd.nets import m2net, swt2net
+    cls = {"M2NetP": m2net.M2NetP, "SwT2Net": swt2net.SwT2Net}[name]
+    z = np.load(os.path.join(G, f"netgrad_{name}_64.npz"))
+    x0 = np.load(os.path.join(G, f"net_{name}_64.npz"))["x"]
+    torch.manual_seed(0)
+    net = cls(1, 2, True)
+    det_fill(net)
+    net = net.cuda().eval()
+    x = torch.tensor(x0).cuda().requires_grad_(True)
+    outs = net(x)
+    loss = 0
+    for i, o in enumerate(outs):
+        j = torch.arange(o.numel(), dtype=torch.float64)
+        loss = loss + (o * torch.sin(0.37 * j + i).float().view_as(o).cuda()).sum() / o[0, 0].numel()
+    loss.backward()
+    close(x.grad, z["dx"], "dx", rtol=2e-3)
+    names = [str(n) for n in z["names"]]
+    with_grad = [n for n, p in net.named_parameters() if p.grad is not None]
+    assert with_grad == names                                   # the same parameters are reached by the backward
+    worst = (0.0, "")
+    for k, (n, p) in enumerate(net.named_parameters()):
+        if p.grad is None:
+            continue
+        g = p.grad.reshape(-1)
+        ref = torch.tensor(z[f"g{k}"])
+        got = g[::max(1, g.numel() // 256)][:256].float().cpu()
+        scale = float(z[f"n{k}"]) / g.numel() ** 0.5 + 1e-12    # rms of the reference gradient
+        err = ((got - ref).abs().max() / max(scale, ref.abs().max().item())).item()
+        worst = max(worst, (err, n))
+        assert abs(g.double().norm().item() - float(z[f"n{k}"])) <= 5e-3 * float(z[f"n{k}"]) + 1e-9, n
+    assert worst[0] < 5e-3, worst
 
 
 @pytest.mark.parametrize("name", ["M2NetP", "SwT2Net"])

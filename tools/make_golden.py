@@ -253,6 +253,34 @@ def gen_nets():
         np.savez_compressed(os.path.join(OUT, f"net_{name}_{size}.npz"), x=x.numpy(),
                             **{f"out{i}": o.numpy() for i, o in enumerate(outs)})
         man[name] = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        # whole-net BACKWARD (eval mode: running BatchNorm statistics, no DropPath): loss = sum_i <out_i, G_i> with
+        # formula-made G_i; dx in full, of every parameter gradient <= 256 evenly strided samples + its L2 norm
+        xg = x.clone().requires_grad_(True)
+        outs = net(xg)
+        loss = 0
+        for i, o in enumerate(outs):
+            j = torch.arange(o.numel(), dtype=torch.float64)
+            loss = loss + (o * torch.sin(0.37 * j + i).float().view_as(o)).sum() / o[0, 0].numel()
+        loss.backward()
+        gd = {"dx": xg.grad.numpy()}
+        names = []
+        for k, (n, p) in enumerate(net.named_parameters()):
+            if p.grad is None:
+                continue
+            g = p.grad.reshape(-1)
+            names.append(n)
+            gd[f"g{k}"] = g[::max(1, g.numel() // 256)][:256].numpy()
+            gd[f"n{k}"] = np.array(float(g.double().norm()))
+        np.savez_compressed(os.path.join(OUT, f"netgrad_{name}_{size}.npz"), names=np.array(names), **gd)
+    # the benchmark model itself (M2Net, not the small variant): forward fixture
+    torch.manual_seed(0)
+    net = m2net.M2Net(1, 2, True)
+    det_fill(net)
+    net.eval()
+    x = torch.randn(1, 1, 64, 64, generator=torch.Generator().manual_seed(22))
+    with torch.no_grad():
+        outs = net(x)
+    np.savez_compressed(os.path.join(OUT, "net_M2Net_64.npz"), x=x.numpy(), **{f"out{i}": o.numpy() for i, o in enumerate(outs)})
     torch.manual_seed(0)
     man["M2Net"] = [(k, tuple(v.shape)) for k, v in m2net.M2Net(1, 2, True).state_dict().items()]
     import json
