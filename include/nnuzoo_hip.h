@@ -190,7 +190,11 @@ int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, 
  *   y, du [B][4 Dg][L]     per direction, in the source's token order (un-reversed)
  *   dy2 [2][B][Dg][L]      gradient seen by both directions of a source (nnz_ss2d_split); dP like P; dWdt like Wdt
  * a_is_log: A holds A_log [4 Dg][16]; the kernels use A = -exp(A_log) and return dA_log = dA * A (m2net.py:196).
- * chunk_state / grad_state / workspace: nnz_selective_scan_state_floats / _workspace_floats(B, 4 Dg, L).
+ * chunk_state / grad_state / workspace: nnz_ss2d_scan_state_floats / _grad_state_floats / _workspace_floats(B, Dg, L)
+ * floats.  chunk_state holds the forward's checkpoints (state entering every chunk and, for the channels-on-lanes
+ * kernels of csrc/ss2d_scan_rl.hpp, every 16-step sub-block) and must reach the backward unchanged.
+ * nnz_scan_tuning(knob, value): 0 = channels-on-lanes kernels on/off (default on; they need L % 16 == 0 and Dg = 32 or a
+ * multiple of 64, other shapes take the time-on-lanes kernels), 1 = forced chunk length in 16-step sub-blocks (4/8/16).
  * nnz_ss2d_merge: out (B, H, W, Dg) = y0 + y2 + (y1 + y3)^T;  nnz_ss2d_merge_dx: dx (B, Dg, H, W) = du0 + du2 + dx2[0]
  * + (du1 + du3 + dx2[1])^T in x's type (du may be NULL). */
 int nnz_ss2d_prepare(const void* x, int x_is_f16, float* x2, int Bt, int D, int H, int W, void* stream);
@@ -206,6 +210,10 @@ int nnz_ss2d_dwconv_silu_forward(const void* x_tokens, int x_is_f16, long x_row_
 int nnz_ss2d_dwconv_silu_backward(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
                                   const float* bias, const float* dx2, void* dx_tokens, float* dweight, float* dbias,
                                   int Bt, int D, int H, int W, void* stream);
+long nnz_ss2d_scan_state_floats(int Bt, int Dg, int L);
+long nnz_ss2d_scan_grad_state_floats(int Bt, int Dg, int L);
+long nnz_ss2d_scan_workspace_floats(int Bt, int Dg, int L);
+int nnz_scan_tuning(int knob, int value);
 int nnz_ss2d_scan_forward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
                           const float* delta_bias, float* y, float* chunk_state, float* workspace, int Bt, int Dg, int R,
                           int L, int delta_softplus, int a_is_log, void* stream);

@@ -103,6 +103,10 @@ SIGNATURES = {
     "nnz_ss2d_merge_dx": [_fp, _fp, _vp, _i, _i, _i, _i, _i, _vp],
     "nnz_ss2d_dwconv_silu_forward": [_vp, _i, _l, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
     "nnz_ss2d_dwconv_silu_backward": [_vp, _i, _l, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp],
+    "nnz_ss2d_scan_state_floats": [_i, _i, _i],
+    "nnz_ss2d_scan_grad_state_floats": [_i, _i, _i],
+    "nnz_ss2d_scan_workspace_floats": [_i, _i, _i],
+    "nnz_scan_tuning": [_i, _i],
     "nnz_ss2d_scan_forward": [_fp] * 9 + [_i, _i, _i, _i, _i, _i, _vp],
     "nnz_ss2d_scan_backward": [_fp] * 16 + [_i, _i, _i, _i, _i, _i, _vp],
     "nnz_residual_droppath_forward": [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _l, _vp],
@@ -130,7 +134,8 @@ SIGNATURES = {
     "nnz_selective_scan_backward": [_fp] * 18 + [_i] * 6 + [_vp],
 }
 
-_LONG_RESULT = {"nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats", "nnz_conv_tap_wgrad_workspace_floats"}
+_LONG_RESULT = {"nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats", "nnz_ss2d_scan_workspace_floats",
+                "nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats", "nnz_conv_tap_wgrad_workspace_floats"}
 _lib = None
 
 

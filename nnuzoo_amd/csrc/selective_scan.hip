@@ -709,6 +709,124 @@ static int check(const ScanArgs& a) {
 
 }  // namespace nnz
 
+#include "ss2d_scan_rl.hpp"
+
+namespace nnz {
+
+// Tuning knobs of the cross-scan (diagnostics / A-B runs; nnz_scan_tuning(knob, value)):
+//   0  channels-on-lanes kernels (ss2d_scan_rl.hpp) for the cross-scan forward AND backward   (default 1)
+//   1  forced sub-blocks per chunk (4 / 8 / .. / 64 = chunks of 64 .. 1024 steps), 0 = by size   (default 0)
+//   2  smallest problem (batch x 4 Dg x L row-steps) that takes the channels-on-lanes kernels   (default 4 M)
+static int g_scan_tuning[4] = {1, 0, 4 << 20, 0};
+
+constexpr int RL_MIN_CLB = 4;   // shortest chunk: 64 steps (sizes of the state / workspace buffers assume it)
+
+// sub-blocks per chunk: the longest chunk (<= 1024 steps) that divides L and still gives every SIMD of the chip (1024)
+// two waves; 0 = shape not supported by the channels-on-lanes kernels
+static int rl_pick_clb(const ScanArgs& a) {
+  if (a.L % (RL_MIN_CLB * RL_T) != 0 || !(a.Dg == 32 || a.Dg % 64 == 0) || a.R > SS_RMAX) return 0;
+  // small problems (fewer than ~4 M row-steps: 32x32 tokens at 256 channels and below) leave most SIMDs without a wave in
+  // this mapping; the time-on-lanes kernels split them finer (tools/bench_scan.py: break-even between 2 M and 8 M)
+  if ((long)a.Bt * a.KD * a.L < (long)g_scan_tuning[2]) return 0;
+  const int forced = g_scan_tuning[1];
+  if (forced >= RL_MIN_CLB && (forced & (forced - 1)) == 0 && a.L % (forced * RL_T) == 0) return forced;
+  const long lanes = (long)a.Bt * a.KD;
+  int best = RL_MIN_CLB;
+  for (int clb = RL_MIN_CLB; clb <= 64; clb *= 2) {
+    if (a.L % (clb * RL_T) != 0) break;
+    if (clb > RL_MIN_CLB && lanes * (a.L / (clb * RL_T)) / 64 < 2048) break;
+    best = clb;
+  }
+  return best;
+}
+static bool rl_ok(const ScanArgs& a) { return g_scan_tuning[0] != 0 && rl_pick_clb(a) != 0; }
+static long rl_nch_max(int L) { return (L + RL_MIN_CLB * RL_T - 1) / (RL_MIN_CLB * RL_T); }
+
+static void rl_setup(ScanArgs& a, int& clb, dim3& grid, float* chunk_state, float* workspace, float*& Hck) {
+  clb = rl_pick_clb(a);
+  a.nchunks = (a.L + clb * RL_T - 1) / (clb * RL_T);
+  const long rows = (long)a.Bt * a.KD;
+  a.P = workspace;
+  a.S = workspace + rows * SS_N * a.nchunks;
+  a.Hin = chunk_state;
+  Hck = chunk_state + rows * SS_N * rl_nch_max(a.L);
+  const int Dl = a.Dg < 64 ? a.Dg : 64;
+  const int slots = 64 / Dl;
+  grid = dim3((a.nchunks + slots - 1) / slots, a.Bt * 4 * (a.Dg / Dl));
+}
+
+static int rl_forward(ScanArgs& a, float* chunk_state, float* workspace, hipStream_t s) {
+  int clb;
+  dim3 grid;
+  float* Hck;
+  rl_setup(a, clb, grid, chunk_state, workspace, Hck);
+  const long rows = (long)a.Bt * a.KD;
+  if (a.nchunks > 1) {
+    NNZ_LAUNCH(xs_rl_fwd_summary_kernel, grid, dim3(64), 0, s, a, clb);
+    NNZ_LAUNCH_CHECK();
+    const long rows_n = rows * SS_N;
+    NNZ_LAUNCH(scan_carry_kernel<false>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Hin, rows_n,
+               a.nchunks);
+    NNZ_LAUNCH_CHECK();
+  } else {
+    hipError_t e = nnz::zero_async(a.Hin, sizeof(float) * rows * SS_N, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  NNZ_LAUNCH(xs_rl_fwd_final_kernel, grid, dim3(64), 0, s, a, clb, Hck);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state, float* workspace, float* dWdt,
+                       hipStream_t s) {
+  int clb;
+  dim3 grid;
+  float* Hck;
+  rl_setup(a, clb, grid, const_cast<float*>(chunk_state), workspace, Hck);
+  a.Gin = grad_state;
+  const long rows = (long)a.Bt * a.KD;
+  const int atomic_dp = a.Dg > 64;      // several waves (channel groups of 64) add into one dP tile
+  hipError_t e;
+  if (atomic_dp && (e = nnz::zero_async(a.xs_dP, sizeof(float) * 2L * a.Bt * 2 * a.Cp * a.L, s)) != hipSuccess)
+    return (int)e;
+  if (a.nchunks > 1) {
+    NNZ_LAUNCH(xs_rl_bwd_summary_kernel, grid, dim3(64), 0, s, a, clb);
+    NNZ_LAUNCH_CHECK();
+    const long rows_n = rows * SS_N;
+    NNZ_LAUNCH(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin, rows_n,
+               a.nchunks);
+    NNZ_LAUNCH_CHECK();
+  } else {
+    if ((e = nnz::zero_async(a.Gin, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
+  }
+  NNZ_LAUNCH(xs_rl_bwd_kernel, grid, dim3(64), 0, s, a, clb, Hck, atomic_dp);
+  NNZ_LAUNCH_CHECK();
+  NNZ_LAUNCH(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA, a.dbias,
+             a.dD, a.Bt, a.KD, a.nchunks, dWdt, a.R, a.a_is_log ? a.A : (const float*)nullptr);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+}  // namespace nnz
+
+extern "C" int nnz_scan_tuning(int knob, int value) {
+  if (knob < 0 || knob >= 4) return NNZ_EINVAL;
+  nnz::g_scan_tuning[knob] = value;
+  return NNZ_OK;
+}
+
+// buffer sizes of the cross-scan entry points (cover both kernel generations)
+extern "C" long nnz_ss2d_scan_state_floats(int Bt, int Dg, int L) {
+  const long rows = (long)Bt * 4 * Dg;
+  return rows * nnz::SS_N * nnz::rl_nch_max(L) + rows * (((long)L + nnz::RL_T - 1) / nnz::RL_T) * nnz::SS_N;
+}
+extern "C" long nnz_ss2d_scan_grad_state_floats(int Bt, int Dg, int L) {
+  return (long)Bt * 4 * Dg * nnz::SS_N * nnz::rl_nch_max(L);
+}
+extern "C" long nnz_ss2d_scan_workspace_floats(int Bt, int Dg, int L) {
+  return 2L * Bt * 4 * Dg * nnz::SS_N * nnz::rl_nch_max(L);
+}
+
 extern "C" long nnz_selective_scan_workspace_floats(int Bt, int KD, int L) {
   const long nch = (L + nnz::SS_CL - 1) / nnz::SS_CL;
   return 2L * Bt * KD * nnz::SS_N * nch;  // P and S
@@ -831,6 +949,7 @@ extern "C" int nnz_ss2d_scan_forward(const float* x2, const float* P, const floa
   a.u = x2; a.xs_P = P; a.xs_Wdt = Wdt; a.A = A; a.D = D; a.bias = delta_bias; a.y = y;
   a.R = R; a.Cp = R + 2 * SS_N;
   a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus; a.a_is_log = a_is_log;
+  if (rl_ok(a)) return rl_forward(a, chunk_state, workspace, (hipStream_t)stream);
   return scan_forward_impl<true>(a, chunk_state, workspace, (hipStream_t)stream);
 }
 
@@ -848,5 +967,6 @@ extern "C" int nnz_ss2d_scan_backward(const float* x2, const float* P, const flo
   a.du = du; a.xs_dP = dP; a.dA = dA; a.dD = dD; a.dbias = dbias;
   a.R = R; a.Cp = R + 2 * SS_N;
   a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus; a.a_is_log = a_is_log;
+  if (rl_ok(a)) return rl_backward(a, chunk_state, grad_state, workspace, dWdt, (hipStream_t)stream);
   return scan_backward_impl<true>(a, chunk_state, grad_state, workspace, dWdt, (hipStream_t)stream);
 }

@@ -1,0 +1,641 @@
+// Cross-scan (SS2D) selective scan, second generation: CHANNELS ON THE LANES.  Included by selective_scan.hip.
+//
+// Why: the time-on-lanes kernels of selective_scan.hip are VALU-issue bound (profiles/r02_scan_pmc_sq_summary.json: VALU
+// busy 78-90 %, HBM at ~10 %): every state update pays a 6-step DPP scan of affine pairs in two passes, ~0.5 issue slots
+// per (row, step, state).  With a lane per channel the recurrence is what it is on paper -
+//     a = exp2(dl * A2[n]);  h[n] = a h[n] + (dl u) B_t[n];  y += C_t[n] h[n]            (4 VALU ops + 1 transcendental)
+// - no cross-lane traffic at all in the forward, the 16 states of a channel live in 16 registers, B_t / C_t / dt_t are
+// wave-uniform LDS broadcasts, and the 16 independent state chains hide each other's latency.
+//
+// Mapping: one wave = 64 lanes = `slots` chunk slots x Dl channels of one (batch, direction) group (Dl = min(Dg, 64);
+// Dg = 32 puts two consecutive chunks of the same 32 channels on the two halves of the wave).  All global traffic is
+// coalesced through LDS: the wave's 64 rows of u / dy move as [64 rows][W steps] tiles (W = 32: whole 128-byte lines
+// per row; first version: 16 bytes per lane straight from its row - every access instruction touched 64 cache lines and the
+// forward spent half its time there, tools/probes/scan_rl_probe.py), each lane then reads its own row of the tile
+// (pitch W + 4 floats: conflict-free 16-byte reads) and writes y / du back in place.  The group's B / C / dt rows are
+// staged as [step][state] (forward) or [state][step] (backward).
+// Chunks run in parallel exactly like before: pass 1 = chunk summaries (P = exp(A sum dl), S = state from zero), the
+// carry kernel of selective_scan.hip, pass 2 = replay from the true entry state.  Pass 2 also writes the state entering
+// every 16-step sub-block (Hck [b][block][state][channel]: coalesced over the lanes; as large as u): the backward needs
+// h_{t-1} for every step and state and gets it by replaying 16 steps from that checkpoint instead of a whole chunk.
+//
+// Backward (per sub-block, states in the OUTER loop so that only 16 steps x 1 state of h are live): forward replay of
+// h over the 16 steps, reverse sweep of G_t = a_{t+1} g_{t+1}, g_t = G_t + C_t dy_t.  The sums over the group's
+// channels (dB_t[n], dC_t[n], d dt_t[r]) are column sums of a [64 lanes][32] LDS tile (conflict-free transposed reads:
+// ~3 issue slots per value against 12 for a DPP wave reduction).
+//
+// Shapes: L a multiple of the chunk length (a power of two times 16 steps, >= 64), Dg = 32 or a multiple of 64; the
+// launcher sends everything else to the time-on-lanes kernels.
+#pragma once
+
+namespace nnz {
+
+constexpr int RL_T = 16;                 // steps per sub-block
+constexpr float RL_LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ float rl_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Workgroup = ONE wave: LDS instructions of a wave execute in issue order, so ordering the wave's own LDS writes before its
+// later reads only needs the compiler not to move them across this point.  (__syncthreads() here would also drain
+// vmcnt - the prefetched global loads of the next stage - at every tile hand-over.)
+__device__ __forceinline__ void rl_sync() { __builtin_amdgcn_wave_barrier(); }
+
+// 4 logical steps t .. t+3 of a row (time-reversed rows: logical step t lives at memory position L-1-t); selects, no
+// divergent code paths
+// rl_ld4 returns the RAW 16 bytes (memory order); rl_swz puts them in logical order.  The two are separate so that a
+// prefetch does not touch its data: a select right after the load made the compiler wait for the load on the spot.
+__device__ __forceinline__ f32x4 rl_ld4(const float* row, int t, int L, bool rev) {
+  return *reinterpret_cast<const f32x4*>(row + (rev ? L - t - 4 : t));
+}
+__device__ __forceinline__ f32x4 rl_swz(f32x4 x, bool rev) {
+  return f32x4{rev ? x[3] : x[0], rev ? x[2] : x[1], rev ? x[1] : x[2], rev ? x[0] : x[3]};
+}
+__device__ __forceinline__ void rl_st4(float* row, int t, int L, bool rev, f32x4 v) {
+  *reinterpret_cast<f32x4*>(row + (rev ? L - t - 4 : t)) =
+      f32x4{rev ? v[3] : v[0], rev ? v[2] : v[1], rev ? v[1] : v[2], rev ? v[0] : v[3]};
+}
+__device__ __forceinline__ void rl_add4(float* row, int t, int L, bool rev, f32x4 v, bool atomic) {
+  if (!atomic) { rl_st4(row, t, L, rev, v); return; }
+  float* p = row + (rev ? L - t - 4 : t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unsafeAtomicAdd(p + i, rev ? v[3 - i] : v[i]);
+}
+
+// derivative of softplus from the activated value: sigmoid(x) = 1 - exp(-softplus(x))
+__device__ __forceinline__ float rl_softplus_grad(float dl) { return 1.f - __expf(-dl); }
+
+// what a wave shares (k, b, channel group) and what a lane owns (channel, chunk)
+struct RlWave {
+  int Dl, slots, b, k, rg, cw, CL;
+  bool rev;
+  long pk_off;
+};
+struct RlLane {
+  int slot, lis, d, kd, c, t_begin;
+  long row;      // b * KD + kd: row of y / du / the per-row workspaces
+  long srow;     // row of the two-source inputs u / dy
+  bool live;
+};
+
+__device__ __forceinline__ RlWave rl_wave(const ScanArgs& a, int clb) {
+  RlWave w;
+  w.Dl = a.Dg < 64 ? a.Dg : 64;
+  w.slots = 64 / w.Dl;
+  const int rgs = a.Dg / w.Dl;
+  int yb = blockIdx.y;
+  w.rg = yb % rgs;
+  yb /= rgs;
+  w.k = yb % 4;
+  w.b = yb / 4;
+  w.cw = blockIdx.x;
+  w.CL = clb * RL_T;
+  w.rev = w.k >= 2;
+  w.pk_off = ((((long)(w.k & 1) * a.Bt + w.b) * 2 + (w.k >> 1)) * a.Cp) * a.L;
+  return w;
+}
+// geometry of tile row r (r = the lane that owns it)
+__device__ __forceinline__ RlLane rl_row(const ScanArgs& a, const RlWave& w, int r) {
+  RlLane g;
+  g.slot = r / w.Dl;
+  g.lis = r % w.Dl;
+  const int c = w.cw * w.slots + g.slot;
+  g.live = c < a.nchunks;
+  g.c = g.live ? c : a.nchunks - 1;      // an idle slot shadows the last chunk (loads stay in range, stores are masked)
+  g.d = w.rg * w.Dl + g.lis;
+  g.kd = w.k * a.Dg + g.d;
+  g.row = (long)w.b * a.KD + g.kd;
+  g.srow = ((long)(w.k & 1) * a.Bt + w.b) * a.Dg + g.d;
+  g.t_begin = g.c * w.CL;
+  return g;
+}
+
+// ---- [64 rows][W steps] tiles of the wave's rows (pitch W + 4): W / 4 pieces of 4 steps per lane -----------------------
+template <int W>
+__device__ __forceinline__ void rl_rows_fetch(const ScanArgs& a, const RlWave& w, const float* src, int toff,
+                                              f32x4 (&v)[W / 4]) {
+  constexpr int PPR = W / 4;   // pieces per row
+#pragma unroll
+  for (int p = 0; p < PPR; ++p) {
+    const int i = (int)threadIdx.x + 64 * p;
+    const RlLane o = rl_row(a, w, i / PPR);
+    v[p] = rl_ld4(src + o.srow * a.L, o.t_begin + toff + 4 * (i % PPR), a.L, w.rev);
+  }
+}
+template <int W>
+__device__ __forceinline__ void rl_rows_commit(float* tile, const f32x4 (&v)[W / 4], bool rev) {
+  constexpr int PPR = W / 4;
+#pragma unroll
+  for (int p = 0; p < PPR; ++p) {
+    const int i = (int)threadIdx.x + 64 * p;
+    *reinterpret_cast<f32x4*>(tile + (i / PPR) * (W + 4) + 4 * (i % PPR)) = rl_swz(v[p], rev);
+  }
+}
+// tile -> rows of dst [B][KD][L] (y / du)
+template <int W>
+__device__ __forceinline__ void rl_rows_store(const ScanArgs& a, const RlWave& w, const float* tile, float* dst, int toff) {
+  constexpr int PPR = W / 4;
+#pragma unroll
+  for (int p = 0; p < PPR; ++p) {
+    const int i = (int)threadIdx.x + 64 * p;
+    const RlLane o = rl_row(a, w, i / PPR);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (i / PPR) * (W + 4) + 4 * (i % PPR));
+    if (o.live) rl_st4(dst + o.row * a.L, o.t_begin + toff + 4 * (i % PPR), a.L, w.rev, v);
+  }
+}
+
+// ---- the group's B / C / dt rows for W steps: per slot 16 x W / 4 pieces (B, C), R x W / 4 pieces (dt) -----------------
+template <int W>
+struct RlTiles {
+  f32x4 tB[W / 8], tC[W / 8], tDt[W / 16];   // pieces per lane at Dl = 32 (half of them are used at Dl = 64)
+};
+template <int W, bool NEED_B, bool NEED_C>
+__device__ __forceinline__ void rl_tiles_fetch(const ScanArgs& a, const RlWave& w, const RlLane& g, int toff, RlTiles<W>& s) {
+  constexpr int PPR = W / 4;
+  const float* Pk = a.xs_P + w.pk_off;
+  const int t = g.t_begin + toff;
+#pragma unroll
+  for (int p = 0; p < W / 8; ++p) {
+    const int i = g.lis + p * w.Dl;
+    if (i < SS_N * PPR) {
+      if (NEED_B) s.tB[p] = rl_ld4(Pk + (long)(a.R + i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
+      if (NEED_C) s.tC[p] = rl_ld4(Pk + (long)(a.R + SS_N + i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < W / 16; ++p) {
+    const int i = g.lis + p * w.Dl;
+    if (i < a.R * PPR) s.tDt[p] = rl_ld4(Pk + (long)(i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
+  }
+}
+// STEP_MAJOR: sB / sC [W steps][16 states] (forward: one step's 16 states are 4 vector reads); else [16 states][W steps]
+// (backward: one state's steps are vector reads).  sDt [R][W].
+template <int W, bool NEED_B, bool NEED_C, bool STEP_MAJOR>
+__device__ __forceinline__ void rl_tiles_commit(const ScanArgs& a, const RlWave& w, const RlLane& g, const RlTiles<W>& s,
+                                                float* sB, float* sC, float* sDt) {
+  constexpr int PPR = W / 4;
+#pragma unroll
+  for (int p = 0; p < W / 8; ++p) {
+    const int i = g.lis + p * w.Dl;
+    if (i < SS_N * PPR) {
+      const int n = i / PPR, t4 = 4 * (i % PPR);
+      f32x4 vb, vc;
+      if (NEED_B) vb = rl_swz(s.tB[p], w.rev);
+      if (NEED_C) vc = rl_swz(s.tC[p], w.rev);
+      if (STEP_MAJOR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (NEED_B) sB[(t4 + j) * SS_N + n] = vb[j];
+          if (NEED_C) sC[(t4 + j) * SS_N + n] = vc[j];
+        }
+      } else {
+        if (NEED_B) *reinterpret_cast<f32x4*>(sB + n * W + t4) = vb;
+        if (NEED_C) *reinterpret_cast<f32x4*>(sC + n * W + t4) = vc;
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < W / 16; ++p) {
+    const int i = g.lis + p * w.Dl;
+    if (i < a.R * PPR) *reinterpret_cast<f32x4*>(sDt + (i / PPR) * W + 4 * (i % PPR)) = rl_swz(s.tDt[p], w.rev);
+  }
+}
+
+__device__ __forceinline__ void rl_lane_consts(const ScanArgs& a, const RlLane& g, float (&A2)[SS_N], float (&wdt)[SS_RMAX],
+                                               float& bias, float& Dv) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + (long)g.kd * SS_N + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A2[4 * q + i] = (a.a_is_log ? -__expf(v[i]) : v[i]) * RL_LOG2E;
+  }
+#pragma unroll
+  for (int r = 0; r < SS_RMAX; ++r) wdt[r] = r < a.R ? a.xs_Wdt[(long)g.kd * a.R + r] : 0.f;
+  bias = a.bias ? a.bias[g.kd] : 0.f;
+  Dv = a.D ? a.D[g.kd] : 0.f;
+}
+
+// checkpoint layout [b][block of 16 steps][state][KD channel]: a store / load per state is coalesced over the lanes
+__device__ __forceinline__ long rl_ck_index(const ScanArgs& a, const RlWave& w, const RlLane& g, long blk, int n) {
+  return ((((long)w.b * (a.L / RL_T) + blk) * SS_N + n) * a.KD) + g.kd;
+}
+
+constexpr int RL_FW = 32;            // steps per staged tile in the forward / summary kernels
+constexpr int RL_FP = RL_FW + 4;
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward.  FINAL = false: chunk summaries P, S.  FINAL = true: y, and the state entering every sub-block (Hck)
+// ---------------------------------------------------------------------------------------------------------------
+template <bool FINAL>
+__device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float* __restrict__ Hck) {
+  __shared__ __attribute__((aligned(16))) float sU[64 * RL_FP];                  // u in, y out (in place)
+  __shared__ __attribute__((aligned(16))) float sB[2][RL_FW * SS_N];
+  __shared__ __attribute__((aligned(16))) float sC[2][FINAL ? RL_FW * SS_N : 4];
+  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * RL_FW];
+  const int lane = threadIdx.x;
+  const RlWave w = rl_wave(a, clb);
+  const RlLane g = rl_row(a, w, lane);
+  float A2[SS_N], wdt[SS_RMAX], bias, Dv;
+  rl_lane_consts(a, g, A2, wdt, bias, Dv);
+  float h[SS_N];
+  if (FINAL) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.Hin + (g.row * a.nchunks + g.c) * SS_N + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h[4 * q + i] = v[i];
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < SS_N; ++n) h[n] = 0.f;
+  }
+  float sumdl = 0.f;
+  float* myB = sB[g.slot];
+  float* myC = sC[g.slot];
+  float* myDt = sDt[g.slot];
+  float* myU = sU + lane * RL_FP;
+
+  f32x4 ru[RL_FW / 4];
+  RlTiles<RL_FW> rt;
+  rl_rows_fetch<RL_FW>(a, w, a.u, 0, ru);
+  rl_tiles_fetch<RL_FW, true, FINAL>(a, w, g, 0, rt);
+  rl_rows_commit<RL_FW>(sU, ru, w.rev);
+  rl_tiles_commit<RL_FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
+  rl_sync();
+  const int nst = w.CL / RL_FW;
+  for (int st = 0; st < nst; ++st) {
+    const int toff = st * RL_FW;
+    if (st + 1 < nst) {   // next stage's global loads fly under this stage's math
+      rl_rows_fetch<RL_FW>(a, w, a.u, toff + RL_FW, ru);
+      rl_tiles_fetch<RL_FW, true, FINAL>(a, w, g, toff + RL_FW, rt);
+    }
+#pragma unroll 1
+    for (int j = 0; j < RL_FW / 4; ++j) {     // 4 steps at a time: small live set
+      if (FINAL && (j & 3) == 0 && g.live) {  // state entering a 16-step sub-block
+        const long blk = (g.t_begin + toff) / RL_T + (j >> 2);
+#pragma unroll
+        for (int n = 0; n < SS_N; ++n) Hck[rl_ck_index(a, w, g, blk, n)] = h[n];
+      }
+      const f32x4 u4 = *reinterpret_cast<const f32x4*>(myU + 4 * j);
+      f32x4 dr = {bias, bias, bias, bias};
+#pragma unroll
+      for (int r = 0; r < SS_RMAX; ++r)
+        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_FW + 4 * j);
+      f32x4 yv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dl = a.softplus ? softplus_f(dr[i]) : dr[i];
+        const float ut = u4[i];
+        const float dlu = dl * ut;
+        sumdl += dl;
+        float acc = Dv * ut;
+        const float* bt = myB + (4 * j + i) * SS_N;
+        const float* ct = myC + (4 * j + i) * SS_N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 Bv = *reinterpret_cast<const f32x4*>(bt + 4 * q);
+          f32x4 Cv;
+          if (FINAL) Cv = *reinterpret_cast<const f32x4*>(ct + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = 4 * q + e;
+            const float an = rl_exp2(dl * A2[n]);
+            h[n] = an * h[n] + dlu * Bv[e];
+            if (FINAL) acc += Cv[e] * h[n];
+          }
+        }
+        yv[i] = acc;
+        __builtin_amdgcn_sched_barrier(0);   // one step's 32 B / C values live at a time (the scheduler hoists all four steps' reads otherwise)
+      }
+      if (FINAL) *reinterpret_cast<f32x4*>(myU + 4 * j) = yv;
+    }
+    rl_sync();
+    if (FINAL) rl_rows_store<RL_FW>(a, w, sU, a.y, toff);
+    rl_sync();
+    if (st + 1 < nst) {
+      rl_rows_commit<RL_FW>(sU, ru, w.rev);
+      rl_tiles_commit<RL_FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
+    }
+    rl_sync();
+  }
+  if (!FINAL && g.live) {
+#pragma unroll
+    for (int n = 0; n < SS_N; ++n) {
+      a.P[(g.row * SS_N + n) * a.nchunks + g.c] = rl_exp2(A2[n] * sumdl);
+      a.S[(g.row * SS_N + n) * a.nchunks + g.c] = h[n];
+    }
+  }
+}
+
+// the summary pass fits two waves per SIMD (register cap 256); the final pass (C tile, y tile stores, checkpoints) does
+// not without spilling and runs one wave per SIMD on the 16 interleaved state chains
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void xs_rl_fwd_summary_kernel(ScanArgs a, int clb) {
+  xs_rl_fwd_body<false>(a, clb, nullptr);
+}
+__global__ __launch_bounds__(64) void xs_rl_fwd_final_kernel(ScanArgs a, int clb, float* __restrict__ Hck) {
+  xs_rl_fwd_body<true>(a, clb, Hck);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward pass 1: reverse chunk summaries.  G_{t-1} = a_t (G_t + C_t dy_t) walked from the chunk's last step to its first:
+// X_left = P X_right + S with P = prod a_t = exp(A sum dl), S = the walk from zero.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void xs_rl_bwd_summary_kernel(ScanArgs a, int clb) {
+  __shared__ __attribute__((aligned(16))) float sY[64 * RL_FP];
+  __shared__ __attribute__((aligned(16))) float sC[2][RL_FW * SS_N];
+  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * RL_FW];
+  const int lane = threadIdx.x;
+  const RlWave w = rl_wave(a, clb);
+  const RlLane g = rl_row(a, w, lane);
+  float A2[SS_N], wdt[SS_RMAX], bias, Dv;
+  rl_lane_consts(a, g, A2, wdt, bias, Dv);
+  float G[SS_N];
+#pragma unroll
+  for (int n = 0; n < SS_N; ++n) G[n] = 0.f;
+  float sumdl = 0.f;
+  float* myC = sC[g.slot];
+  float* myDt = sDt[g.slot];
+  const float* myY = sY + lane * RL_FP;
+  f32x4 ry[RL_FW / 4];
+  RlTiles<RL_FW> rt;
+  const int nst = w.CL / RL_FW;
+  rl_rows_fetch<RL_FW>(a, w, a.dy, (nst - 1) * RL_FW, ry);
+  rl_tiles_fetch<RL_FW, false, true>(a, w, g, (nst - 1) * RL_FW, rt);
+  rl_rows_commit<RL_FW>(sY, ry, w.rev);
+  rl_tiles_commit<RL_FW, false, true, true>(a, w, g, rt, nullptr, myC, myDt);
+  rl_sync();
+  for (int st = nst - 1; st >= 0; --st) {
+    if (st > 0) {
+      rl_rows_fetch<RL_FW>(a, w, a.dy, (st - 1) * RL_FW, ry);
+      rl_tiles_fetch<RL_FW, false, true>(a, w, g, (st - 1) * RL_FW, rt);
+    }
+#pragma unroll 1
+    for (int j = RL_FW / 4 - 1; j >= 0; --j) {
+      const f32x4 dy4 = *reinterpret_cast<const f32x4*>(myY + 4 * j);
+      f32x4 dr = {bias, bias, bias, bias};
+#pragma unroll
+      for (int r = 0; r < SS_RMAX; ++r)
+        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_FW + 4 * j);
+#pragma unroll
+      for (int i = 3; i >= 0; --i) {
+        const float dl = a.softplus ? softplus_f(dr[i]) : dr[i];
+        const float dyt = dy4[i];
+        sumdl += dl;
+        const float* ct = myC + (4 * j + i) * SS_N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 Cv = *reinterpret_cast<const f32x4*>(ct + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = 4 * q + e;
+            G[n] = rl_exp2(dl * A2[n]) * (G[n] + Cv[e] * dyt);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    rl_sync();
+    if (st > 0) {
+      rl_rows_commit<RL_FW>(sY, ry, w.rev);
+      rl_tiles_commit<RL_FW, false, true, true>(a, w, g, rt, nullptr, myC, myDt);
+    }
+    rl_sync();
+  }
+  if (g.live) {
+#pragma unroll
+    for (int n = 0; n < SS_N; ++n) {
+      a.P[(g.row * SS_N + n) * a.nchunks + g.c] = rl_exp2(A2[n] * sumdl);
+      a.S[(g.row * SS_N + n) * a.nchunks + g.c] = G[n];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward pass 2: all gradients.  Gin[c] = G at the right edge of chunk c (from the reverse carry).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RL_CP = 33;            // pitch of the column-sum tile (32 columns + 1: conflict-free row and column access)
+constexpr int RL_BP = RL_T + 4;      // pitch of the backward's 16-step row tiles
+
+__global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, const float* __restrict__ Hck, int atomic_dp) {
+  __shared__ __attribute__((aligned(16))) float sU[64 * RL_BP];                  // u rows
+  __shared__ __attribute__((aligned(16))) float sY[64 * RL_BP];                  // dy rows in, du out (in place)
+  __shared__ __attribute__((aligned(16))) float sB[2][RL_T * SS_N];              // [state][step]
+  __shared__ __attribute__((aligned(16))) float sC[2][RL_T * SS_N];
+  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * RL_T];
+  __shared__ float sG[SS_N][64], sdA[SS_N][64], sA2[SS_N][64];                   // per-state values of every lane
+  __shared__ float sT[64 * RL_CP];                                               // column-sum tile [lane][32]
+  __shared__ __attribute__((aligned(16))) float sOut[2][2 * SS_N * RL_T];        // per slot: dB [n][t], then dC [n][t]
+  __shared__ __attribute__((aligned(16))) float sOutDt[2][SS_RMAX * RL_T];       // per slot: d dt [r][t]
+  const int lane = threadIdx.x;
+  const RlWave w = rl_wave(a, clb);
+  const RlLane g = rl_row(a, w, lane);
+  float wdt[SS_RMAX], bias, Dv;
+  {
+    float A2[SS_N];
+    rl_lane_consts(a, g, A2, wdt, bias, Dv);
+#pragma unroll
+    for (int n = 0; n < SS_N; ++n) {
+      sA2[n][lane] = A2[n];
+      sdA[n][lane] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.Gin + (g.row * a.nchunks + g.c) * SS_N + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sG[4 * q + i][lane] = v[i];
+    }
+  }
+  float* myB = sB[g.slot];
+  float* myC = sC[g.slot];
+  float* myDt = sDt[g.slot];
+  float* myOut = sOut[g.slot];
+  float* myOutDt = sOutDt[g.slot];
+  float dWacc[SS_RMAX];
+#pragma unroll
+  for (int r = 0; r < SS_RMAX; ++r) dWacc[r] = 0.f;
+  float dbias_acc = 0.f, dD_acc = 0.f;
+  const bool one_slot = w.Dl == 64;
+  // column-sum geometry: 32 columns (16 dB + 16 dC, or two dt rows); lanes of a slot sum their slot's rows
+  const int col = lane & 31;
+  const int half = lane >> 5;
+
+  f32x4 ru[RL_T / 4], ry[RL_T / 4];
+  RlTiles<RL_T> rt;
+  rl_rows_fetch<RL_T>(a, w, a.u, (clb - 1) * RL_T, ru);
+  rl_rows_fetch<RL_T>(a, w, a.dy, (clb - 1) * RL_T, ry);
+  rl_tiles_fetch<RL_T, true, true>(a, w, g, (clb - 1) * RL_T, rt);
+  rl_rows_commit<RL_T>(sU, ru, w.rev);
+  rl_rows_commit<RL_T>(sY, ry, w.rev);
+  rl_tiles_commit<RL_T, true, true, false>(a, w, g, rt, myB, myC, myDt);
+  rl_sync();
+  for (int sb = clb - 1; sb >= 0; --sb) {
+    const int toff = sb * RL_T;
+    const int tb = g.t_begin + toff;
+    if (sb > 0) {
+      rl_rows_fetch<RL_T>(a, w, a.u, toff - RL_T, ru);
+      rl_rows_fetch<RL_T>(a, w, a.dy, toff - RL_T, ry);
+      rl_tiles_fetch<RL_T, true, true>(a, w, g, toff - RL_T, rt);
+    }
+    const long blk = tb / RL_T;
+    float dl[RL_T], u[RL_T], dy[RL_T], dlu[RL_T], du[RL_T], ddl[RL_T];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 uv = *reinterpret_cast<const f32x4*>(sU + lane * RL_BP + 4 * j);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(sY + lane * RL_BP + 4 * j);
+      f32x4 dr = {bias, bias, bias, bias};
+#pragma unroll
+      for (int r = 0; r < SS_RMAX; ++r)
+        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_T + 4 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = 4 * j + i;
+        dl[t] = a.softplus ? softplus_f(dr[i]) : dr[i];
+        u[t] = uv[i];
+        dy[t] = yv[i];
+        dlu[t] = dl[t] * u[t];
+        du[t] = Dv * dy[t];
+        ddl[t] = 0.f;
+        dD_acc += dy[t] * u[t];
+      }
+    }
+    float hin_next = Hck[rl_ck_index(a, w, g, blk, 0)];
+    for (int n = 0; n < SS_N; ++n) {
+      const float A2n = sA2[n][lane];
+      const float An = A2n * (1.f / RL_LOG2E);        // a_t = exp(dl_t A_n): d a_t / d dl_t = a_t A_n
+      const float hin = hin_next;                     // state n entering this sub-block (forward checkpoint)
+      if (n + 1 < SS_N) hin_next = Hck[rl_ck_index(a, w, g, blk, n + 1)];
+      float an[RL_T], hc[RL_T], Bn[RL_T], Cn[RL_T];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(myB + n * RL_T + 4 * j);
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(myC + n * RL_T + 4 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Bn[4 * j + i] = bv[i];
+          Cn[4 * j + i] = cv[i];
+        }
+      }
+      {   // forward replay of state n over the sub-block
+        float h = hin;
+#pragma unroll
+        for (int t = 0; t < RL_T; ++t) {
+          an[t] = rl_exp2(dl[t] * A2n);
+          h = an[t] * h + dlu[t] * Bn[t];
+          hc[t] = h;
+        }
+      }
+      float G = sG[n][lane];
+      float dAn = 0.f;
+#pragma unroll
+      for (int t = RL_T - 1; t >= 0; --t) {
+        const float gt = G + Cn[t] * dy[t];
+        const float wv = gt * Bn[t];
+        du[t] += wv * dl[t];
+        ddl[t] += wv * u[t];
+        const float hprev = t > 0 ? hc[t - 1] : hin;
+        const float qa = gt * an[t] * hprev;          // d loss / d a_t
+        dAn += qa * dl[t];
+        ddl[t] += qa * An;
+        sT[lane * RL_CP + t] = gt * dlu[t];           // dB_t[n] contribution of this channel
+        sT[lane * RL_CP + RL_T + t] = dy[t] * hc[t];  // dC_t[n]
+        G = an[t] * gt;
+      }
+      sG[n][lane] = G;
+      sdA[n][lane] += dAn;
+      rl_sync();
+      {   // column sums over the slot's channels
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s4[i & 3] += sT[(half * 32 + i) * RL_CP + col];
+        float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        if (one_slot) s += __shfl_xor(s, 32, 64);
+        // lanes of slot `half` (two slots) or lanes 0..31 (one slot) hold column `col`: dB for col < 16, dC after
+        if (!one_slot || half == 0) {
+          float* o = one_slot ? myOut : sOut[half];
+          o[(col >> 4) * (SS_N * RL_T) + n * RL_T + (col & 15)] = s;
+        }
+      }
+      rl_sync();
+    }
+    // delta gradient through the softplus
+    float dd[RL_T];
+#pragma unroll
+    for (int t = 0; t < RL_T; ++t) {
+      const float gsp = a.softplus ? rl_softplus_grad(dl[t]) : 1.f;
+      dd[t] = ddl[t] * gsp;
+      dbias_acc += dd[t];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(sY + lane * RL_BP + 4 * j) = f32x4{du[4 * j], du[4 * j + 1], du[4 * j + 2], du[4 * j + 3]};
+    // d dt[r][t] = sum_channels Wdt[kd][r] dd_t;  dWdt[kd][r] += sum_t dd_t dt[r][t]
+#pragma unroll
+    for (int r = 0; r < SS_RMAX; ++r) {
+      if (r < a.R) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 dv = *reinterpret_cast<const f32x4*>(myDt + r * RL_T + 4 * j);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dWacc[r] += dd[4 * j + i] * dv[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < SS_RMAX; r0 += 2) {
+      if (r0 >= a.R) break;                      // wave-uniform
+#pragma unroll
+      for (int t = 0; t < RL_T; ++t) {
+        sT[lane * RL_CP + t] = wdt[r0] * dd[t];
+        sT[lane * RL_CP + RL_T + t] = wdt[r0 + 1] * dd[t];      // wdt[r] = 0 for r >= R
+      }
+      rl_sync();
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 32; ++i) s4[i & 3] += sT[(half * 32 + i) * RL_CP + col];
+      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      if (one_slot) s += __shfl_xor(s, 32, 64);
+      if ((!one_slot || half == 0) && r0 + (col >> 4) < a.R) {
+        float* o = one_slot ? myOutDt : sOutDt[half];
+        o[(r0 + (col >> 4)) * RL_T + (col & 15)] = s;
+      }
+      rl_sync();
+    }
+    rl_sync();
+    rl_rows_store<RL_T>(a, w, sY, a.du, toff);
+    // the sub-block's dB / dC / d dt tiles (rows of dP)
+    if (g.live) {
+      float* gP = a.xs_dP + w.pk_off;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int i = g.lis + p * w.Dl;          // 128 pieces of 4 steps: 32 rows (16 dB, 16 dC) x 4
+        if (i < 128) {
+          const int rowi = i >> 2, t4 = (i & 3) * 4;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(myOut + rowi * RL_T + t4);
+          rl_add4(gP + (long)(a.R + rowi) * a.L, tb + t4, a.L, w.rev, v, atomic_dp != 0);
+        }
+      }
+      if (g.lis < a.R * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(myOutDt + (g.lis >> 2) * RL_T + (g.lis & 3) * 4);
+        rl_add4(gP + (long)(g.lis >> 2) * a.L, tb + (g.lis & 3) * 4, a.L, w.rev, v, atomic_dp != 0);
+      }
+    }
+    rl_sync();
+    if (sb > 0) {
+      rl_rows_commit<RL_T>(sU, ru, w.rev);
+      rl_rows_commit<RL_T>(sY, ry, w.rev);
+      rl_tiles_commit<RL_T, true, true, false>(a, w, g, rt, myB, myC, myDt);
+    }
+    rl_sync();
+  }
+  if (g.live) {
+    // per-(row, chunk) partials for the finalize kernel of selective_scan.hip: P rows = dA, S rows 0 / 1 / 2.. = dbias / dD / dWdt
+#pragma unroll
+    for (int n = 0; n < SS_N; ++n) a.P[(g.row * SS_N + n) * a.nchunks + g.c] = sdA[n][lane];
+    a.S[(g.row * SS_N + 0) * a.nchunks + g.c] = dbias_acc;
+    a.S[(g.row * SS_N + 1) * a.nchunks + g.c] = dD_acc;
+#pragma unroll
+    for (int r = 0; r < SS_RMAX; ++r)
+      if (r < a.R) a.S[(g.row * SS_N + 2 + r) * a.nchunks + g.c] = dWacc[r];
+  }
+}
+
+}  // namespace nnz

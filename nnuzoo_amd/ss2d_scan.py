@@ -132,8 +132,8 @@ class _SS2DCrossScan(torch.autograd.Function):
             bias = dt_projs_bias.detach().float().reshape(-1).contiguous()
             Dv = Ds.detach().float().contiguous()
             y = torch.empty((B, K, Di, L), **f32)
-            state = torch.empty(lib.nnz_selective_scan_state_floats(B, K * Di, L), **f32)
-            ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f32)
+            state = torch.empty(lib.nnz_ss2d_scan_state_floats(B, Di, L), **f32)
+            ws = torch.empty(lib.nnz_ss2d_scan_workspace_floats(B, Di, L), **f32)
             # algorithmic HBM bytes of the cross-scan forward: both sources of u once, the dt / B / C
             # rows of the four directions, y of the four directions
             TIMER.wrap("ss2d_scan_fwd", 4.0 * B * L * (2 * Di + 4 * Cp + 4 * Di), lambda: call(
@@ -161,8 +161,8 @@ class _SS2DCrossScan(torch.autograd.Function):
             dP = torch.empty_like(P)
             dWdt, dA = torch.empty_like(Wdt), torch.empty_like(A)
             dD, dbias = torch.empty_like(Dv), torch.empty_like(bias)
-            gstate = torch.empty_like(state)
-            ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f32)
+            gstate = torch.empty(lib.nnz_ss2d_scan_grad_state_floats(B, Di, L), **f32)
+            ws = torch.empty(lib.nnz_ss2d_scan_workspace_floats(B, Di, L), **f32)
             # algorithmic bytes of the backward: reads u (2 sources), projections (4 dirs), dy (2 token orders); writes
             # du (4 dirs) and the projection gradient (4 dirs)
             TIMER.wrap("ss2d_scan_bwd", 4.0 * B * L * (2 * Di + 4 * Cp + 2 * Di + 4 * Di + 4 * Cp), lambda: call(

@@ -24,7 +24,7 @@ def t(fn, reps=5):
     return s.elapsed_time(e) / reps
 
 
-for B, KD, L in SHAPES:
+for B, KD, L in ([] if "--xs-only" in sys.argv else SHAPES):
     K, N = 4, 16
     u = torch.randn(B, KD, L, device="cuda", requires_grad=True)
     dl = (torch.randn(B, KD, L, device="cuda") * 0.5).requires_grad_(True)
@@ -62,18 +62,26 @@ for Di, H in [(32, 512), (64, 256), (32, 256), (128, 128), (256, 64), (256, 32),
     dy2 = torch.randn(2, B, Di, L, **f)
     dP = torch.empty_like(P)
     dWdt, dA, dD, dbias = torch.empty_like(Wdt), torch.empty_like(Alog), torch.empty_like(Dv), torch.empty_like(bias)
-    state = torch.empty(lib.nnz_selective_scan_state_floats(B, K * Di, L), **f)
-    gstate = torch.empty_like(state)
-    ws = torch.empty(lib.nnz_selective_scan_workspace_floats(B, K * Di, L), **f)
+    state = torch.empty(lib.nnz_ss2d_scan_state_floats(B, Di, L), **f)
+    gstate = torch.empty(lib.nnz_ss2d_scan_grad_state_floats(B, Di, L), **f)
+    ws = torch.empty(lib.nnz_ss2d_scan_workspace_floats(B, Di, L), **f)
     fwd = lambda: call("nnz_ss2d_scan_forward", ptr(x2), ptr(P), ptr(Wdt), ptr(Alog), ptr(Dv), ptr(bias), ptr(y),
                        ptr(state), ptr(ws), B, Di, R, L, 1, 1, stream_ptr())
     bwd = lambda: call("nnz_ss2d_scan_backward", ptr(x2), ptr(P), ptr(Wdt), ptr(Alog), ptr(Dv), ptr(bias), ptr(dy2),
                        ptr(state), ptr(gstate), ptr(ws), ptr(du), ptr(dP), ptr(dWdt), ptr(dA), ptr(dD), ptr(dbias), B,
                        Di, R, L, 1, 1, stream_ptr())
-    tf = t(fwd)
-    tb = t(bwd)
     fb = 4 * B * L * (2 * Di + 2 * 2 * Cp + 4 * Di)
     bb = 4 * B * L * (2 * Di + 2 * 2 * Cp + 2 * Di + 4 * Di + 2 * 2 * Cp)
     su = B * K * Di * N * L
-    print(f"Di={Di:4d} {H}x{W}: fwd {tf:7.3f} ms {fb/tf/1e6:7.1f} GB/s {su/tf/1e6:7.1f} Gsu/s | "
-          f"bwd {tb:7.3f} ms {bb/tb/1e6:7.1f} GB/s {su/tb/1e6:7.1f} Gsu/s", flush=True)
+    outs = {}
+    for gen in (0, 1):          # 0: time-on-lanes kernels (selective_scan.hip), 1: channels-on-lanes (ss2d_scan_rl.hpp)
+        call("nnz_scan_tuning", 0, gen)
+        tf = t(fwd)
+        tb = t(bwd)
+        torch.cuda.synchronize()
+        outs[gen] = [v.clone() for v in (y, du, dP, dWdt, dA, dD, dbias)]
+        print(f"Di={Di:4d} {H}x{W} gen{gen}: fwd {tf:7.3f} ms {fb/tf/1e6:7.1f} GB/s {su/tf/1e6:7.1f} Gsu/s | "
+              f"bwd {tb:7.3f} ms {bb/tb/1e6:7.1f} GB/s {su/tb/1e6:7.1f} Gsu/s", flush=True)
+    rel = [((p - q).abs().max() / q.abs().max().clamp_min(1e-20)).item() for p, q in zip(outs[1], outs[0])]
+    print("      gen1 vs gen0 max|diff|/max|ref|: " + " ".join(f"{n}={v:.1e}" for n, v in
+                                                                 zip(("y", "du", "dP", "dWdt", "dA", "dD", "dbias"), rel)), flush=True)
