@@ -214,6 +214,7 @@ long nnz_ss2d_scan_state_floats(int Bt, int Dg, int L);
 long nnz_ss2d_scan_grad_state_floats(int Bt, int Dg, int L);
 long nnz_ss2d_scan_workspace_floats(int Bt, int Dg, int L);
 int nnz_scan_tuning(int knob, int value);
+int nnz_scan_tuning_get(int knob);   /* knob 3: number of channels-on-lanes launches so far */
 int nnz_ss2d_scan_forward(const float* x2, const float* P, const float* Wdt, const float* A, const float* D,
                           const float* delta_bias, float* y, float* chunk_state, float* workspace, int Bt, int Dg, int R,
                           int L, int delta_softplus, int a_is_log, void* stream);

@@ -717,6 +717,7 @@ namespace nnz {
 //   0  channels-on-lanes kernels (ss2d_scan_rl.hpp) for the cross-scan forward AND backward   (default 1)
 //   1  forced sub-blocks per chunk (4 / 8 / .. / 64 = chunks of 64 .. 1024 steps), 0 = by size   (default 0)
 //   2  smallest problem (batch x 4 Dg x L row-steps) that takes the channels-on-lanes kernels   (default 4 M)
+//   3  (read-only use) number of channels-on-lanes launches so far: lets a test assert which generation ran
 static int g_scan_tuning[4] = {1, 0, 4 << 20, 0};
 
 constexpr int RL_MIN_CLB = 4;   // shortest chunk: 64 steps (sizes of the state / workspace buffers assume it)
@@ -756,6 +757,7 @@ static void rl_setup(ScanArgs& a, int& clb, dim3& grid, float* chunk_state, floa
 }
 
 static int rl_forward(ScanArgs& a, float* chunk_state, float* workspace, hipStream_t s) {
+  ++g_scan_tuning[3];
   int clb;
   dim3 grid;
   float* Hck;
@@ -779,6 +781,7 @@ static int rl_forward(ScanArgs& a, float* chunk_state, float* workspace, hipStre
 
 static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state, float* workspace, float* dWdt,
                        hipStream_t s) {
+  ++g_scan_tuning[3];
   int clb;
   dim3 grid;
   float* Hck;
@@ -814,6 +817,7 @@ extern "C" int nnz_scan_tuning(int knob, int value) {
   nnz::g_scan_tuning[knob] = value;
   return NNZ_OK;
 }
+extern "C" int nnz_scan_tuning_get(int knob) { return (knob < 0 || knob >= 4) ? -1 : nnz::g_scan_tuning[knob]; }
 
 // buffer sizes of the cross-scan entry points (cover both kernel generations)
 extern "C" long nnz_ss2d_scan_state_floats(int Bt, int Dg, int L) {

@@ -225,12 +225,12 @@ constexpr int RL_FP = RL_FW + 4;
 // ---------------------------------------------------------------------------------------------------------------
 // forward.  FINAL = false: chunk summaries P, S.  FINAL = true: y, and the state entering every sub-block (Hck)
 // ---------------------------------------------------------------------------------------------------------------
-template <bool FINAL>
+template <bool FINAL, int FW>
 __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float* __restrict__ Hck) {
-  __shared__ __attribute__((aligned(16))) float sU[64 * RL_FP];                  // u in, y out (in place)
-  __shared__ __attribute__((aligned(16))) float sB[2][RL_FW * SS_N];
-  __shared__ __attribute__((aligned(16))) float sC[2][FINAL ? RL_FW * SS_N : 4];
-  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * RL_FW];
+  __shared__ __attribute__((aligned(16))) float sU[64 * (FW + 4)];                  // u in, y out (in place)
+  __shared__ __attribute__((aligned(16))) float sB[2][FW * SS_N];
+  __shared__ __attribute__((aligned(16))) float sC[2][FINAL ? FW * SS_N : 4];
+  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * FW];
   const int lane = threadIdx.x;
   const RlWave w = rl_wave(a, clb);
   const RlLane g = rl_row(a, w, lane);
@@ -252,34 +252,38 @@ __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float
   float* myB = sB[g.slot];
   float* myC = sC[g.slot];
   float* myDt = sDt[g.slot];
-  float* myU = sU + lane * RL_FP;
+  float* myU = sU + lane * (FW + 4);
 
-  f32x4 ru[RL_FW / 4];
-  RlTiles<RL_FW> rt;
-  rl_rows_fetch<RL_FW>(a, w, a.u, 0, ru);
-  rl_tiles_fetch<RL_FW, true, FINAL>(a, w, g, 0, rt);
-  rl_rows_commit<RL_FW>(sU, ru, w.rev);
-  rl_tiles_commit<RL_FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
+  f32x4 ru[FW / 4];
+  RlTiles<FW> rt;
+  rl_rows_fetch<FW>(a, w, a.u, 0, ru);
+  rl_tiles_fetch<FW, true, FINAL>(a, w, g, 0, rt);
+  rl_rows_commit<FW>(sU, ru, w.rev);
+  rl_tiles_commit<FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
   rl_sync();
-  const int nst = w.CL / RL_FW;
+  const int nst = w.CL / FW;
   for (int st = 0; st < nst; ++st) {
-    const int toff = st * RL_FW;
+    const int toff = st * FW;
     if (st + 1 < nst) {   // next stage's global loads fly under this stage's math
-      rl_rows_fetch<RL_FW>(a, w, a.u, toff + RL_FW, ru);
-      rl_tiles_fetch<RL_FW, true, FINAL>(a, w, g, toff + RL_FW, rt);
+      rl_rows_fetch<FW>(a, w, a.u, toff + FW, ru);
+      rl_tiles_fetch<FW, true, FINAL>(a, w, g, toff + FW, rt);
     }
 #pragma unroll 1
-    for (int j = 0; j < RL_FW / 4; ++j) {     // 4 steps at a time: small live set
+    for (int j = 0; j < FW / 4; ++j) {     // 4 steps at a time: small live set
       if (FINAL && (j & 3) == 0 && g.live) {  // state entering a 16-step sub-block
         const long blk = (g.t_begin + toff) / RL_T + (j >> 2);
+        float* ck = Hck + rl_ck_index(a, w, g, blk, 0);      // one running pointer (16 separate addresses cost 32 VGPRs)
 #pragma unroll
-        for (int n = 0; n < SS_N; ++n) Hck[rl_ck_index(a, w, g, blk, n)] = h[n];
+        for (int n = 0; n < SS_N; ++n) {
+          *ck = h[n];
+          ck += a.KD;
+        }
       }
       const f32x4 u4 = *reinterpret_cast<const f32x4*>(myU + 4 * j);
       f32x4 dr = {bias, bias, bias, bias};
 #pragma unroll
       for (int r = 0; r < SS_RMAX; ++r)
-        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_FW + 4 * j);
+        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * FW + 4 * j);
       f32x4 yv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -309,11 +313,11 @@ __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float
       if (FINAL) *reinterpret_cast<f32x4*>(myU + 4 * j) = yv;
     }
     rl_sync();
-    if (FINAL) rl_rows_store<RL_FW>(a, w, sU, a.y, toff);
+    if (FINAL) rl_rows_store<FW>(a, w, sU, a.y, toff);
     rl_sync();
     if (st + 1 < nst) {
-      rl_rows_commit<RL_FW>(sU, ru, w.rev);
-      rl_tiles_commit<RL_FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
+      rl_rows_commit<FW>(sU, ru, w.rev);
+      rl_tiles_commit<FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
     }
     rl_sync();
   }
@@ -327,12 +331,13 @@ __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float
 }
 
 // the summary pass fits two waves per SIMD (register cap 256); the final pass (C tile, y tile stores, checkpoints) does
-// not without spilling and runs one wave per SIMD on the 16 interleaved state chains
+// not without spilling and runs one wave per SIMD on the 16 interleaved state chains (measured: capped to two waves with
+// 16-step tiles it spills outside the step loop only, yet the 512^2 forward goes from 0.65 to 0.87 ms)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void xs_rl_fwd_summary_kernel(ScanArgs a, int clb) {
-  xs_rl_fwd_body<false>(a, clb, nullptr);
+  xs_rl_fwd_body<false, RL_FW>(a, clb, nullptr);
 }
 __global__ __launch_bounds__(64) void xs_rl_fwd_final_kernel(ScanArgs a, int clb, float* __restrict__ Hck) {
-  xs_rl_fwd_body<true>(a, clb, Hck);
+  xs_rl_fwd_body<true, RL_FW>(a, clb, Hck);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
   __shared__ __attribute__((aligned(16))) float sB[2][RL_T * SS_N];              // [state][step]
   __shared__ __attribute__((aligned(16))) float sC[2][RL_T * SS_N];
   __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * RL_T];
-  __shared__ float sG[SS_N][64], sdA[SS_N][64], sA2[SS_N][64];                   // per-state values of every lane
+  __shared__ float sG[SS_N][64], sdA[SS_N][64];                                  // per-state values of every lane
   __shared__ float sT[64 * RL_CP];                                               // column-sum tile [lane][32]
   __shared__ __attribute__((aligned(16))) float sOut[2][2 * SS_N * RL_T];        // per slot: dB [n][t], then dC [n][t]
   __shared__ __attribute__((aligned(16))) float sOutDt[2][SS_RMAX * RL_T];       // per slot: d dt [r][t]
@@ -430,13 +435,13 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
   const RlLane g = rl_row(a, w, lane);
   float wdt[SS_RMAX], bias, Dv;
   {
-    float A2[SS_N];
-    rl_lane_consts(a, g, A2, wdt, bias, Dv);
+    // (A is re-read per state inside the loop: a 16 x 64 table of it in LDS put the kernel over 40 KB = 3 waves per CU)
 #pragma unroll
-    for (int n = 0; n < SS_N; ++n) {
-      sA2[n][lane] = A2[n];
-      sdA[n][lane] = 0.f;
-    }
+    for (int r = 0; r < SS_RMAX; ++r) wdt[r] = r < a.R ? a.xs_Wdt[(long)g.kd * a.R + r] : 0.f;
+    bias = a.bias ? a.bias[g.kd] : 0.f;
+    Dv = a.D ? a.D[g.kd] : 0.f;
+#pragma unroll
+    for (int n = 0; n < SS_N; ++n) sdA[n][lane] = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(a.Gin + (g.row * a.nchunks + g.c) * SS_N + 4 * q);
@@ -498,11 +503,15 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
       }
     }
     float hin_next = Hck[rl_ck_index(a, w, g, blk, 0)];
+    float araw_next = a.A[(long)g.kd * SS_N];
     for (int n = 0; n < SS_N; ++n) {
-      const float A2n = sA2[n][lane];
-      const float An = A2n * (1.f / RL_LOG2E);        // a_t = exp(dl_t A_n): d a_t / d dl_t = a_t A_n
+      const float An = a.a_is_log ? -__expf(araw_next) : araw_next;   // a_t = exp(dl_t A_n): d a_t / d dl_t = a_t A_n
+      const float A2n = An * RL_LOG2E;
       const float hin = hin_next;                     // state n entering this sub-block (forward checkpoint)
-      if (n + 1 < SS_N) hin_next = Hck[rl_ck_index(a, w, g, blk, n + 1)];
+      if (n + 1 < SS_N) {                             // next state's operands fly under this state's math
+        hin_next = Hck[rl_ck_index(a, w, g, blk, n + 1)];
+        araw_next = a.A[(long)g.kd * SS_N + n + 1];
+      }
       float an[RL_T], hc[RL_T], Bn[RL_T], Cn[RL_T];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

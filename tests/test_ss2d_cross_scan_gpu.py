@@ -49,6 +49,41 @@ def test_fused_core_matches_composed_fp32(hip_lib, d_model, B, H, W):
             _close(g1[n], g0[n], 2e-3, n)
 
 
+@pytest.mark.parametrize("d_model,B,H,W,clb", [(16, 2, 16, 16, 0), (16, 1, 8, 24, 4), (16, 2, 64, 64, 16), (16, 1, 64, 64, 64),
+                                               (32, 2, 16, 32, 0), (64, 1, 16, 16, 4), (64, 2, 32, 32, 8),
+                                               (128, 1, 8, 16, 0)])
+def test_fused_core_channels_on_lanes_kernels(hip_lib, d_model, B, H, W, clb):
+    """the second-generation cross-scan kernels (csrc/ss2d_scan_rl.hpp; by default only for >= 4 M row-steps) forced on
+    for small shapes: two chunk slots per wave (Dg = 32, incl. an odd chunk count = idle slot), one slot (Dg = 64), several
+    channel groups adding into one dP tile (Dg = 128, 256), dt ranks 1..8, chunk lengths 64..1024 steps - against the
+    op-by-op formulation that is pinned to the reference"""
+    from nnuzoo_amd._lib import call, load
+    from nnuzoo_amd.nets.m2net import SS2D
+    lib = load()
+    torch.manual_seed(d_model + H)
+    blk = SS2D(d_model=d_model).cuda()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, d_model, generator=g).cuda()
+    dy = torch.randn(B, H, W, d_model, generator=g).cuda()
+    y0, dx0, g0 = _run(blk, x, dy, fused=False)
+    saved = [lib.nnz_scan_tuning_get(k) for k in range(3)]
+    try:
+        call("nnz_scan_tuning", 0, 1)
+        call("nnz_scan_tuning", 1, clb)
+        call("nnz_scan_tuning", 2, 0)
+        before = lib.nnz_scan_tuning_get(3)
+        y1, dx1, g1 = _run(blk, x, dy, fused=True)
+        assert lib.nnz_scan_tuning_get(3) == before + 2          # forward and backward both took the new kernels
+    finally:
+        for k, v in enumerate(saved):
+            call("nnz_scan_tuning", k, v)
+    _close(y1, y0, 1e-4, "y")
+    _close(dx1, dx0, 2e-3, "dx")
+    assert set(g0) == set(g1)
+    for n in g0:
+        _close(g1[n], g0[n], 2e-3, n)
+
+
 def test_fused_core_under_autocast(hip_lib):
     """under autocast the op-by-op path rounds the x_proj / dt einsums to fp16 (as the reference does), the fused core
     keeps them in fp32: agreement to fp16 rounding"""
