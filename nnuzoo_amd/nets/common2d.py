@@ -12,6 +12,8 @@ kernels of the zoo path are the selective scan and the window-attention core.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -82,13 +84,50 @@ def residual_drop_path(inp: torch.Tensor, x: torch.Tensor, drop_path: "DropPath"
     return _ResidualDropPathFn.apply(inp, x, mask, scale)
 
 
+class _DepthwiseNativeFn(torch.autograd.Function):
+    """fp32 depthwise convolution through ATen's native depthwise kernels instead of the library path.  Measured on the
+    SwT2Net step (tools/probes/swt_slow_conv_probe.py): MIOpen runs the weight gradient of the three fp32 depthwise 3x3
+    convolutions (32 ch @ 512^2, 64 @ 256^2, 128 @ 128^2) as a batched xdlops GEMM - 72 + 19 + 5 ms of a 206 ms step;
+    ATen's direct kernels take < 3 ms for the same three.  The backend is picked again inside convolution_backward, so the
+    switch has to wrap the backward call too - hence an autograd Function rather than a context manager in forward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation, groups):
+        with torch.backends.cudnn.flags(enabled=False):
+            y = F.conv2d(x, w, b, stride, padding, dilation, groups)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, dilation, groups, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, groups, has_b = ctx.cfg
+        with torch.backends.cudnn.flags(enabled=False):
+            dx, dw, db = torch.ops.aten.convolution_backward(
+                dy.contiguous(), x, w, [w.shape[0]] if has_b else None, list(stride), list(padding), list(dilation), False,
+                [0, 0], groups, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]])
+        return dx, dw, db, None, None, None, None
+
+
+class _Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict) that sends fp32 depthwise calls on the GPU to _DepthwiseNativeFn"""
+
+    def forward(self, x):
+        if (self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda
+                and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.padding_mode == "zeros"
+                and os.environ.get("NNZ_DW_NATIVE", "1") != "0"):
+            return _DepthwiseNativeFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return super().forward(x)
+
+
 class Convolution(nn.Sequential):
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, strides=1, kernel_size=3, bias=True,
                  conv_only: bool = True, groups: int = 1, dilation: int = 1, padding=None):
         super().__init__()
         if not conv_only:
             raise NotImplementedError("only the conv_only form is used by the zoo")
-        conv = {2: nn.Conv2d, 3: nn.Conv3d}[spatial_dims]
+        conv = {2: _Conv2d, 3: nn.Conv3d}[spatial_dims]
         k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
         pad = (k - 1) // 2 * dilation if padding is None else padding
         self.add_module("conv", conv(in_channels, out_channels, kernel_size, strides, pad, dilation, groups, bias))

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary"
 # 1. kernel trace + stats of the primary bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $BENCH > $OUT/${TAG}_bench_profiled.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $BENCH > $OUT/${TAG}_bench_n1_profiled_run.json 2>/dev/null
 cp $(ls $OUT/prof_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_n1_kernel_stats.csv
 # 2. HBM traffic counters, separate passes (MI355X_MICROARCH.md, HBM / rocprofv3 section)
 BENCH2="python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-launch-timer"
@@ -16,17 +16,20 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_f -- $BENCH2 > /dev/
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_w -- $BENCH2 > /dev/null 2>&1
 cp $(ls $OUT/prof_f/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_fetch_size.csv
 cp $(ls $OUT/prof_w/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_write_size.csv
-# 3. scan / attention kernels: stats of the zoo steps (eager so that every launch is attributed) + one SQ counter pass
-ZOO="python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models M2Net --steps 2 --warmup 2 --graph 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_zoo -- $ZOO > /dev/null 2>&1
-cp $(ls $OUT/prof_zoo/*/*kernel_stats.csv | head -1) $OUT/${TAG}_m2net_kernel_stats.csv
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/prof_zoo_pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_scan.py > /dev/null 2>&1
+# 3. the zoo steps as they run (hipGraph replay): kernel trace, second half of the run aggregated by kernel
+for M in M2Net SwT2Net; do
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_zoo -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models $M --steps 3 --warmup 3 > /dev/null 2>&1
+  python3 $GRAFT_REPO_ROOT/tools/kernel_summary.py $(ls $OUT/prof_zoo/*/*kernel_trace.csv | head -1) 45 0.75 > $OUT/${TAG}_${M,,}_graph_kernels.txt 2>&1
+  rm -rf $OUT/prof_zoo
+done
+# 4. one SQ counter pass over the scan kernels (both generations)
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/prof_zoo_pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_scan.py --xs-only > /dev/null 2>&1
 cp $(ls $OUT/prof_zoo_pmc/*/*counter_collection.csv | head -1) $OUT/${TAG}_scan_pmc_sq.csv
-SW="python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models SwT2Net --steps 2 --warmup 2 --graph 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sw -- $SW > /dev/null 2>&1
-cp $(ls $OUT/prof_sw/*/*kernel_stats.csv | head -1) $OUT/${TAG}_swt2net_kernel_stats.csv
-rm -rf $OUT/prof_stats $OUT/prof_f $OUT/prof_w $OUT/prof_zoo $OUT/prof_zoo_pmc $OUT/prof_sw
+rm -rf $OUT/prof_stats $OUT/prof_f $OUT/prof_w $OUT/prof_zoo_pmc
 cd $GRAFT_REPO_ROOT
 python3 tools/bench_scan.py > $OUT/${TAG}_scan_bench.txt 2>&1
 python3 tools/bench_conv_layers.py > $OUT/${TAG}_conv_layers.txt 2>&1
+python3 tools/bench_zoo.py --models M2NetP,M2Net,SwT2Net,SSND2Net,MambaND2Net,UNETR2Net,LightMamba2Net,LightMamba2NetP --steps 5 --warmup 3 2>&1 | grep '"model"' > $OUT/${TAG}_zoo_bench.txt
+# 5. the bench line of record (defaults: both legs, cpu_baseline)
+python3 bench.py > $OUT/${TAG}_bench_n1.json 2>$OUT/${TAG}_bench_n1.err
 ls -la $OUT | tail -20
