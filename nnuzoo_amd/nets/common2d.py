@@ -88,7 +88,8 @@ class _DepthwiseNativeFn(torch.autograd.Function):
     """fp32 depthwise convolution through ATen's native depthwise kernels instead of the library path.  Measured on the
     SwT2Net step (tools/probes/swt_slow_conv_probe.py): MIOpen runs the weight gradient of the three fp32 depthwise 3x3
     convolutions (32 ch @ 512^2, 64 @ 256^2, 128 @ 128^2) as a batched xdlops GEMM - 72 + 19 + 5 ms of a 206 ms step;
-    ATen's direct kernels take < 3 ms for the same three.  The backend is picked again inside convolution_backward, so the
+    ATen's direct kernels take < 3 ms for the same three.  Under fp16 autocast (SSND2Net) the library picks a 24 ms grouped-conv
+    weight-gradient kernel for the same layers: 379 -> 277 ms per step with the direct kernels.  The backend is picked again inside convolution_backward, so the
     switch has to wrap the backward call too - hence an autograd Function rather than a context manager in forward."""
 
     @staticmethod
@@ -111,13 +112,21 @@ class _DepthwiseNativeFn(torch.autograd.Function):
 
 
 class _Conv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters / state_dict) that sends fp32 depthwise calls on the GPU to _DepthwiseNativeFn"""
+    """nn.Conv2d (same parameters / state_dict) that sends depthwise calls on the GPU to _DepthwiseNativeFn"""
 
     def forward(self, x):
+        mode = os.environ.get("NNZ_DW_NATIVE", "2")     # 0: library path, 1: fp32 calls only, 2: fp16 autocast calls too
         if (self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda
-                and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.padding_mode == "zeros"
-                and os.environ.get("NNZ_DW_NATIVE", "1") != "0"):
-            return _DepthwiseNativeFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+                and self.padding_mode == "zeros" and mode != "0"):
+            w, b = self.weight, self.bias
+            if torch.is_autocast_enabled():
+                if mode != "2":
+                    return super().forward(x)
+                dt = torch.get_autocast_dtype("cuda")   # what autocast would have cast the convolution's operands to
+                x, w, b = x.to(dt), w.to(dt), (b.to(dt) if b is not None else None)
+            elif x.dtype != torch.float32:
+                return super().forward(x)
+            return _DepthwiseNativeFn.apply(x, w, b, self.stride, self.padding, self.dilation, self.groups)
         return super().forward(x)
 
 

@@ -199,7 +199,8 @@ def test_residual_drop_path_matches_torch_ops(hip_lib, p, in_dtype, x_dtype):
 
 def test_fp32_depthwise_conv_native_path_matches_library(hip_lib):
     """common2d._Conv2d sends fp32 depthwise convolutions to ATen's direct kernels (the library's weight gradient for them
-    is a 70 ms batched GEMM at 512^2): same values and gradients as the plain nn.Conv2d call, same state_dict keys"""
+    is a 70 ms batched GEMM at 512^2; under fp16 autocast a 24 ms grouped-conv kernel, SSND2Net): same values and gradients
+    as the plain nn.Conv2d call, same state_dict keys"""
     from nnuzoo_amd.nets.common2d import Convolution, _DepthwiseNativeFn
     torch.manual_seed(0)
     m = Convolution(2, 32, 32, kernel_size=3, groups=32, bias=True).cuda()
@@ -215,5 +216,9 @@ def test_fp32_depthwise_conv_native_path_matches_library(hip_lib):
     close(gx, rx.float().cpu(), "dx", rtol=1e-5)
     close(gw, rw.float().cpu(), "dw", rtol=1e-4)
     close(gb, rb.float().cpu(), "db", rtol=1e-4)
-    with torch.autocast("cuda"):                                  # fp16 autocast calls stay on the library path
-        assert not type(m(x).grad_fn).__name__.startswith("_DepthwiseNativeFn")
+    with torch.autocast("cuda"):                                  # autocast calls: operands cast to fp16, same kernels
+        yh = m(x)
+    assert yh.dtype == torch.float16
+    (gxh,) = torch.autograd.grad(yh, [x], dy.half())
+    close(yh, ref.float().cpu(), "y fp16", rtol=2e-3)
+    close(gxh, rx.float().cpu(), "dx fp16", rtol=5e-3)
