@@ -124,6 +124,22 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
 int nnz_graph_replace_memsets(void* hip_graph, int* n_replaced);
 int nnz_graph_node_census(void* hip_graph, int* counts, int ncounts);
 
+/* ---- GPU-side input pipeline ----------------------------------------------------------------------------
+ * Replaces the voxel-moving part of nnUNetDataLoader.generate_train_batch
+ * (/root/reference/nnunetv2/training/dataloading/data_loader.py:180-259): data_all[j] = crop_and_pad_nd(data, bbox, 0),
+ * seg_all[j] = crop_and_pad_nd(seg, bbox, -1) (:207-218), plus of the transform chain the MirrorTransform
+ * (nnUNetTrainer.py:917-920) and DownsampleSegForDSTransform (:971) - for cases that are RESIDENT in HBM.
+ * src: B host-side entries, each a DEVICE pointer to a case volume [C][sd][sh][sw]; shapes, lbs: B x 3 host ints (case
+ * extent, lower bbox corner in case coordinates - may be negative or reach beyond the case: padded); flips: B host ints
+ * (bit a = mirror the patch along axis a: 0 depth, 1 height, 2 width) or NULL; dst: device [B][C][pd][ph][pw].
+ * 2-D data: pd = 1.  nnz_downsample_nearest_i16: torch's interpolate(mode='nearest-exact') index rule, bit-exact. */
+int nnz_crop_pad_f32(const void* const* src, const int* shapes, const int* lbs, const int* flips, float* dst, int B, int C,
+                     int pd, int ph, int pw, float pad_value, void* stream);
+int nnz_crop_pad_i16(const void* const* src, const int* shapes, const int* lbs, const int* flips, short* dst, int B, int C,
+                     int pd, int ph, int pw, int pad_value, void* stream);
+int nnz_downsample_nearest_i16(const short* src, short* dst, long nc, int id, int ih, int iw, int od, int oh, int ow,
+                               void* stream);
+
 /* ---- x_proj of the cross-scan SS2D block on channel-major fp32 activations (the einsum of SS2D.forward_core,
  * /root/reference/nnunetv2/nets/m2net.py:179-184, in the two-source formulation of nnz_ss2d_scan_*):
  *   forward     P[s][b][c][l]   = sum_d W[s][c][d] x2[s][b][d][l]                       c < C2 <= 80, Di % 32 == 0

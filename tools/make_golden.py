@@ -472,9 +472,76 @@ def gen_mambandcore(ref):
     np.savez_compressed(os.path.join(OUT, "mambandcore.npz"), **out)
 
 
+def gen_dataloader_bbox():
+    """tests/golden/dataloader_bbox.json: outputs of the reference's OWN nnUNetDataLoader.get_bbox
+    (training/dataloading/data_loader.py:102-178).  The class cannot be imported (its base class lives in batchgenerators,
+    absent), so the method's source is taken from the file by ast and executed unchanged against a plain namespace that
+    carries the four attributes it reads (need_to_pad, patch_size, has_ignore, annotated_classes_key).  Scenarios are
+    regenerated by the test from the stored parameters; the numpy seed makes the RNG stream part of the fixture."""
+    import ast
+    import json
+    import types
+    import warnings
+    path = os.path.join(ref_shim.REF, "nnunetv2/training/dataloading/data_loader.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "nnUNetDataLoader"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "get_bbox"][0]
+    mod = ast.Module(body=[fn], type_ignores=[])
+    import typing
+    ns = {"np": np, "warnings": warnings, "Union": typing.Union, "Tuple": typing.Tuple}
+    exec(compile(mod, path, "exec"), ns)
+    get_bbox = ns["get_bbox"]
+    out = []
+    for sc in _bbox_scenarios():
+        self_ = types.SimpleNamespace(need_to_pad=np.array(sc["need_to_pad"]), patch_size=tuple(sc["patch_size"]),
+                                      has_ignore=sc["has_ignore"], annotated_classes_key=tuple(sc["annotated_classes_key"]))
+        np.random.seed(sc["seed"])
+        cl = _bbox_class_locations(sc)
+        res = []
+        for i in range(8):
+            lbs, ubs = get_bbox(self_, np.array(sc["data_shape"]), sc["force_fg"][i % len(sc["force_fg"])], cl)
+            res.append([[int(v) for v in lbs], [int(v) for v in ubs]])
+        out.append(dict(sc, boxes=res))
+    with open(os.path.join(OUT, "dataloader_bbox.json"), "w") as f:
+        json.dump(out, f)
+
+
+def _bbox_scenarios():
+    return [
+        dict(seed=1, data_shape=[40, 56, 48], patch_size=[32, 32, 32], need_to_pad=[8, 8, 8], has_ignore=False,
+             annotated_classes_key=[-1, 0, 1, 2], force_fg=[False], classes="none"),
+        dict(seed=2, data_shape=[40, 56, 48], patch_size=[32, 32, 32], need_to_pad=[8, 8, 8], has_ignore=False,
+             annotated_classes_key=[-1, 0, 1, 2], force_fg=[False, True], classes="two"),
+        dict(seed=3, data_shape=[20, 30, 64], patch_size=[32, 32, 32], need_to_pad=[0, 4, 9], has_ignore=False,
+             annotated_classes_key=[-1, 0, 1], force_fg=[True], classes="two"),          # case smaller than the patch
+        dict(seed=4, data_shape=[1, 50, 40], patch_size=[1, 32, 32], need_to_pad=[0, 6, 6], has_ignore=True,
+             annotated_classes_key=[-1, 0, 1, 2], force_fg=[False, True], classes="ignore"),   # pseudo 3-D, ignore label
+        dict(seed=5, data_shape=[48, 48, 48], patch_size=[32, 32, 32], need_to_pad=[8, 8, 8], has_ignore=False,
+             annotated_classes_key=[-1, 0, 1, 2], force_fg=[True], classes="empty"),     # no foreground at all
+    ]
+
+
+def _bbox_class_locations(sc):
+    """class_locations as the preprocessing stores them: per class an (n, 4) integer array (channel, z, y, x)"""
+    if sc["classes"] == "none":
+        return None
+    rs = np.random.RandomState(100 + sc["seed"])
+    sh = sc["data_shape"]
+
+    def locs(n):
+        return np.stack([np.zeros(n, dtype=np.int64)] + [rs.randint(0, s, n) for s in sh], 1)
+
+    if sc["classes"] == "two":
+        return {1: locs(40), 2: locs(7), 3: np.zeros((0, 4), dtype=np.int64)}
+    if sc["classes"] == "ignore":
+        return {1: locs(30), 2: np.zeros((0, 4), dtype=np.int64), tuple(sc["annotated_classes_key"]): locs(60)}
+    return {1: np.zeros((0, 4), dtype=np.int64), 2: np.zeros((0, 4), dtype=np.int64)}
+
+
 if __name__ == "__main__":
     ref = ref_shim.install()
-    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba", "ssnd2net", "mambandcore"]
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba", "ssnd2net", "mambandcore", "bbox"]
     if "sw" in which:
         gen_sliding_window()
     if "mamba" in which:
@@ -497,4 +564,6 @@ if __name__ == "__main__":
         gen_ssnd()
     if "nets" in which:
         gen_nets()
+    if "bbox" in which:
+        gen_dataloader_bbox()
     print(sorted(os.listdir(OUT)))
