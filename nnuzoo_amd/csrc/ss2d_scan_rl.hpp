@@ -30,6 +30,8 @@
 
 namespace nnz {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int RL_T = 16;                 // steps per sub-block
 constexpr float RL_LOG2E = 1.4426950408889634f;
 
@@ -481,7 +483,10 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
       rl_tiles_fetch<RL_T, true, true>(a, w, g, toff - RL_T, rt);
     }
     const long blk = tb / RL_T;
-    float dl[RL_T], u[RL_T], dy[RL_T], dlu[RL_T], du[RL_T], ddl[RL_T];
+    // per-step values as explicit PAIRS of consecutive steps (f32x2 = one 64-bit register pair): the element-wise part of
+    // the state loop then compiles to v_pk_* instructions on operands that already sit in aligned pairs.  With scalar
+    // arrays the SLP vectoriser found the same packed ops but paid 118 v_mov per state to build the pairs.
+    f32x2 dl2[RL_T / 2], u2[RL_T / 2], dy2[RL_T / 2], dlu2[RL_T / 2], du2[RL_T / 2], ddl2[RL_T / 2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 uv = *reinterpret_cast<const f32x4*>(sU + lane * RL_BP + 4 * j);
@@ -491,15 +496,18 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
       for (int r = 0; r < SS_RMAX; ++r)
         if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_T + 4 * j);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int t = 4 * j + i;
-        dl[t] = a.softplus ? softplus_f(dr[i]) : dr[i];
-        u[t] = uv[i];
-        dy[t] = yv[i];
-        dlu[t] = dl[t] * u[t];
-        du[t] = Dv * dy[t];
-        ddl[t] = 0.f;
-        dD_acc += dy[t] * u[t];
+      for (int i = 0; i < 4; ++i) dr[i] = a.softplus ? softplus_f(dr[i]) : dr[i];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = 2 * j + q;
+        dl2[k] = f32x2{dr[2 * q], dr[2 * q + 1]};
+        u2[k] = f32x2{uv[2 * q], uv[2 * q + 1]};
+        dy2[k] = f32x2{yv[2 * q], yv[2 * q + 1]};
+        dlu2[k] = dl2[k] * u2[k];
+        du2[k] = Dv * dy2[k];
+        ddl2[k] = f32x2{0.f, 0.f};
+        const f32x2 yu = dy2[k] * u2[k];
+        dD_acc += yu[0] + yu[1];
       }
     }
     float hin_next = Hck[rl_ck_index(a, w, g, blk, 0)];
@@ -512,44 +520,57 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
         hin_next = Hck[rl_ck_index(a, w, g, blk, n + 1)];
         araw_next = a.A[(long)g.kd * SS_N + n + 1];
       }
-      float an[RL_T], hc[RL_T], Bn[RL_T], Cn[RL_T];
+      f32x2 an2[RL_T / 2], hc2[RL_T / 2], hp2[RL_T / 2], Bn2[RL_T / 2], Cn2[RL_T / 2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(myB + n * RL_T + 4 * j);
         const f32x4 cv = *reinterpret_cast<const f32x4*>(myC + n * RL_T + 4 * j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          Bn[4 * j + i] = bv[i];
-          Cn[4 * j + i] = cv[i];
-        }
+        Bn2[2 * j] = f32x2{bv[0], bv[1]};
+        Bn2[2 * j + 1] = f32x2{bv[2], bv[3]};
+        Cn2[2 * j] = f32x2{cv[0], cv[1]};
+        Cn2[2 * j + 1] = f32x2{cv[2], cv[3]};
       }
-      {   // forward replay of state n over the sub-block
+      {   // forward replay of state n over the sub-block: hc = h_t, hp = h_{t-1}, written straight into the pair halves
         float h = hin;
 #pragma unroll
-        for (int t = 0; t < RL_T; ++t) {
-          an[t] = rl_exp2(dl[t] * A2n);
-          h = an[t] * h + dlu[t] * Bn[t];
-          hc[t] = h;
+        for (int k = 0; k < RL_T / 2; ++k) {
+          const f32x2 e = dl2[k] * A2n;
+          const f32x2 b = dlu2[k] * Bn2[k];
+          an2[k][0] = rl_exp2(e[0]);
+          an2[k][1] = rl_exp2(e[1]);
+          hp2[k][0] = h;
+          h = an2[k][0] * h + b[0];
+          hc2[k][0] = h;
+          hp2[k][1] = h;
+          h = an2[k][1] * h + b[1];
+          hc2[k][1] = h;
         }
       }
       float G = sG[n][lane];
-      float dAn = 0.f;
+      f32x2 dA2 = {0.f, 0.f};
 #pragma unroll
-      for (int t = RL_T - 1; t >= 0; --t) {
-        const float gt = G + Cn[t] * dy[t];
-        const float wv = gt * Bn[t];
-        du[t] += wv * dl[t];
-        ddl[t] += wv * u[t];
-        const float hprev = t > 0 ? hc[t - 1] : hin;
-        const float qa = gt * an[t] * hprev;          // d loss / d a_t
-        dAn += qa * dl[t];
-        ddl[t] += qa * An;
-        sT[lane * RL_CP + t] = gt * dlu[t];           // dB_t[n] contribution of this channel
-        sT[lane * RL_CP + RL_T + t] = dy[t] * hc[t];  // dC_t[n]
-        G = an[t] * gt;
+      for (int k = RL_T / 2 - 1; k >= 0; --k) {
+        const f32x2 cdy = Cn2[k] * dy2[k];
+        f32x2 gt;
+        gt[1] = G + cdy[1];
+        G = an2[k][1] * gt[1];
+        gt[0] = G + cdy[0];
+        G = an2[k][0] * gt[0];
+        const f32x2 wv = gt * Bn2[k];
+        du2[k] += wv * dl2[k];
+        ddl2[k] += wv * u2[k];
+        const f32x2 qa = gt * an2[k] * hp2[k];        // d loss / d a_t
+        dA2 += qa * dl2[k];
+        ddl2[k] += qa * An;
+        const f32x2 dBv = gt * dlu2[k];               // dB_t[n] contribution of this channel
+        const f32x2 dCv = dy2[k] * hc2[k];            // dC_t[n]
+        sT[lane * RL_CP + 2 * k] = dBv[0];
+        sT[lane * RL_CP + 2 * k + 1] = dBv[1];
+        sT[lane * RL_CP + RL_T + 2 * k] = dCv[0];
+        sT[lane * RL_CP + RL_T + 2 * k + 1] = dCv[1];
       }
       sG[n][lane] = G;
-      sdA[n][lane] += dAn;
+      sdA[n][lane] += dA2[0] + dA2[1];
       rl_sync();
       {   // column sums over the slot's channels
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -568,14 +589,17 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
     // delta gradient through the softplus
     float dd[RL_T];
 #pragma unroll
-    for (int t = 0; t < RL_T; ++t) {
-      const float gsp = a.softplus ? rl_softplus_grad(dl[t]) : 1.f;
-      dd[t] = ddl[t] * gsp;
-      dbias_acc += dd[t];
+    for (int k = 0; k < RL_T / 2; ++k) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float gsp = a.softplus ? rl_softplus_grad(dl2[k][q]) : 1.f;
+        dd[2 * k + q] = ddl2[k][q] * gsp;
+        dbias_acc += dd[2 * k + q];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(sY + lane * RL_BP + 4 * j) = f32x4{du[4 * j], du[4 * j + 1], du[4 * j + 2], du[4 * j + 3]};
+      *reinterpret_cast<f32x4*>(sY + lane * RL_BP + 4 * j) = f32x4{du2[2 * j][0], du2[2 * j][1], du2[2 * j + 1][0], du2[2 * j + 1][1]};
     // d dt[r][t] = sum_channels Wdt[kd][r] dd_t;  dWdt[kd][r] += sum_t dd_t dt[r][t]
 #pragma unroll
     for (int r = 0; r < SS_RMAX; ++r) {
