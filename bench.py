@@ -159,7 +159,7 @@ def run_secondary(steps: int, warmup: int):
     if "ss2d_scan_bwd" in summ:
         n, by, sec = summ["ss2d_scan_bwd"]
         ach = by / sec / 1e9
-        roof = {"bound": "hbm", "kernel": "ss2d cross-scan backward (summary + carry + final + finalize kernels per call: xs_rl_bwd_* for >= 4 M row-steps, scan_bwd_kernel below)",
+        roof = {"bound": "hbm", "kernel": "ss2d cross-scan backward (summary + carry + final + finalize kernels per call: xs_rl_bwd_* for >= 2 M row-steps, scan_bwd_kernel below)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "launches_per_step": n // roof_steps, "avg_launch_us": round(sec / n * 1e6, 2),
                 "bytes_per_launch": by / n, "ms_per_step": round(sec / roof_steps * 1e3, 3),

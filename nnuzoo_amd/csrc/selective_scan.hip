@@ -716,9 +716,9 @@ namespace nnz {
 // Tuning knobs of the cross-scan (diagnostics / A-B runs; nnz_scan_tuning(knob, value)):
 //   0  channels-on-lanes kernels (ss2d_scan_rl.hpp) for the cross-scan forward AND backward   (default 1)
 //   1  forced sub-blocks per chunk (4 / 8 / .. / 64 = chunks of 64 .. 1024 steps), 0 = by size   (default 0)
-//   2  smallest problem (batch x 4 Dg x L row-steps) that takes the channels-on-lanes kernels   (default 4 M)
+//   2  smallest problem (batch x 4 Dg x L row-steps) that takes the channels-on-lanes kernels   (default 2 M)
 //   3  (read-only use) number of channels-on-lanes launches so far: lets a test assert which generation ran
-static int g_scan_tuning[4] = {1, 0, 4 << 20, 0};
+static int g_scan_tuning[4] = {1, 0, 2 << 20, 0};
 
 constexpr int RL_MIN_CLB = 4;   // shortest chunk: 64 steps (sizes of the state / workspace buffers assume it)
 
@@ -726,8 +726,8 @@ constexpr int RL_MIN_CLB = 4;   // shortest chunk: 64 steps (sizes of the state 
 // two waves; 0 = shape not supported by the channels-on-lanes kernels
 static int rl_pick_clb(const ScanArgs& a) {
   if (a.L % (RL_MIN_CLB * RL_T) != 0 || !(a.Dg == 32 || a.Dg % 64 == 0) || a.R > SS_RMAX) return 0;
-  // small problems (fewer than ~4 M row-steps: 32x32 tokens at 256 channels and below) leave most SIMDs without a wave in
-  // this mapping; the time-on-lanes kernels split them finer (tools/bench_scan.py: break-even between 2 M and 8 M)
+  // small problems (fewer than ~2 M row-steps: 32x32 tokens at 128 channels and below) leave most SIMDs without a wave in
+  // this mapping; the time-on-lanes kernels split them finer (tools/probes/scan_threshold_probe.py: break-even between 1 M and 2 M)
   if ((long)a.Bt * a.KD * a.L < (long)g_scan_tuning[2]) return 0;
   const int forced = g_scan_tuning[1];
   if (forced >= RL_MIN_CLB && (forced & (forced - 1)) == 0 && a.L % (forced * RL_T) == 0) return forced;

@@ -53,7 +53,7 @@ def test_fused_core_matches_composed_fp32(hip_lib, d_model, B, H, W):
                                                (32, 2, 16, 32, 0), (64, 1, 16, 16, 4), (64, 2, 32, 32, 8),
                                                (128, 1, 8, 16, 0)])
 def test_fused_core_channels_on_lanes_kernels(hip_lib, d_model, B, H, W, clb):
-    """the second-generation cross-scan kernels (csrc/ss2d_scan_rl.hpp; by default only for >= 4 M row-steps) forced on
+    """the second-generation cross-scan kernels (csrc/ss2d_scan_rl.hpp; by default only for >= 2 M row-steps) forced on
     for small shapes: two chunk slots per wave (Dg = 32, incl. an odd chunk count = idle slot), one slot (Dg = 64), several
     channel groups adding into one dP tile (Dg = 128, 256), dt ranks 1..8, chunk lengths 64..1024 steps - against the
     op-by-op formulation that is pinned to the reference"""
