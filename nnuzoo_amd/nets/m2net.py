@@ -49,7 +49,11 @@ class SS2D(nn.Module):
         self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
         K, R, N, Di = self.K, self.dt_rank, d_state, self.d_inner
 
-        # bare parameters first (registration order fixes named_parameters()/state_dict order)
+        # creation order = the reference's (m2net.py:70-110): the RNG stream of a seeded construction is then the same
+        # (named_parameters() lists a module's bare parameters before its children whatever the order of creation)
+        self.in_proj = TokenLinear(d_model, Di * 2, bias=bias, **fk)
+        self.conv2d = nn.Conv2d(Di, Di, groups=Di, bias=conv_bias, kernel_size=d_conv, padding=(d_conv - 1) // 2, **fk)
+        self.act = nn.SiLU()
         xp = [nn.Linear(Di, R + 2 * N, bias=False, **fk).weight for _ in range(K)]
         self.x_proj_weight = nn.Parameter(torch.stack(xp, dim=0))                      # (K, R + 2N, Di)
         dts = [self.dt_init(R, Di, dt_scale, dt_init, dt_min, dt_max, dt_init_floor, **fk) for _ in range(K)]
@@ -58,9 +62,6 @@ class SS2D(nn.Module):
         self.A_logs = self.A_log_init(N, Di, copies=K, merge=True)                     # (K * Di, N)
         self.Ds = self.D_init(Di, copies=K, merge=True)                                # (K * Di)
 
-        self.in_proj = TokenLinear(d_model, Di * 2, bias=bias, **fk)
-        self.conv2d = nn.Conv2d(Di, Di, groups=Di, bias=conv_bias, kernel_size=d_conv, padding=(d_conv - 1) // 2, **fk)
-        self.act = nn.SiLU()
         self.selective_scan = selective_scan_fn
         self.out_norm = LayerNorm(Di)
         self.out_proj = TokenLinear(Di, d_model, bias=bias, **fk)
@@ -182,8 +183,16 @@ class VSSLayer(nn.Module):
         self.blocks = nn.ModuleList([
             VSSBlock(hidden_dim=dim, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
                      norm_layer=norm_layer, attn_drop_rate=attn_drop, d_state=d_state) for i in range(depth)])
-        # the reference runs a no-op re-init here that only advances the RNG (m2net.py:571-578); seeded-init parity
-        # is therefore statistical, not bitwise
+        # the reference runs a no-op re-init here that only advances the RNG (m2net.py:571-578):
+        # kaiming_uniform_ on a detached CLONE of every `out_proj.weight`, visited in nn.Module.apply order.  Replayed so
+        # that a seeded construction draws the same stream as the reference's (bitwise equal parameters, see
+        # tests/test_state_dict_manifest.py::test_seeded_construction_checksums)
+        def _advance_rng(module: nn.Module):
+            for name, p in module.named_parameters():
+                if name in ["out_proj.weight"]:
+                    nn.init.kaiming_uniform_(p.clone().detach_(), a=math.sqrt(5))
+
+        self.apply(_advance_rng)
         self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
     def forward(self, x):

@@ -40,6 +40,12 @@ class SSND(nn.Module):
         self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
         self.k = K = 2 * spatial_dims
         R, N, Di = self.dt_rank, d_state, self.d_inner
+        # creation order = the reference's (ssnd2net.py:108-160): same RNG stream for a seeded construction
+        self.in_proj = TokenLinear(d_model, Di * 2, bias=bias, **fk)
+        self.convnd = Convolution(spatial_dims, Di, Di, groups=Di, bias=conv_bias, kernel_size=d_conv,
+                                  padding=(d_conv - 1) // 2 * dilation if dilation != 1 else (d_conv - 1) // 2,
+                                  conv_only=True, dilation=dilation)
+        self.act = nn.SiLU()
         xp = [nn.Linear(Di, R + 2 * N, bias=False, **fk).weight for _ in range(K)]
         self.x_proj_weight = nn.Parameter(torch.stack(xp, dim=0))
         dts = [SS2D.dt_init(R, Di, dt_scale, dt_init, dt_min, dt_max, dt_init_floor, **fk) for _ in range(K)]
@@ -47,11 +53,6 @@ class SSND(nn.Module):
         self.dt_projs_bias = nn.Parameter(torch.stack([t.bias for t in dts], dim=0))
         self.A_logs = SS2D.A_log_init(N, Di, copies=K, merge=True)
         self.Ds = SS2D.D_init(Di, copies=K, merge=True)
-        self.in_proj = TokenLinear(d_model, Di * 2, bias=bias, **fk)
-        self.convnd = Convolution(spatial_dims, Di, Di, groups=Di, bias=conv_bias, kernel_size=d_conv,
-                                  padding=(d_conv - 1) // 2 * dilation if dilation != 1 else (d_conv - 1) // 2,
-                                  conv_only=True, dilation=dilation)
-        self.act = nn.SiLU()
         self.selective_scan = selective_scan_fn
         self.out_norm = LayerNorm(Di)
         self.out_proj = TokenLinear(Di, d_model, bias=bias, **fk)

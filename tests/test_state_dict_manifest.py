@@ -33,3 +33,39 @@ def test_plain_conv_unet_keys_follow_dna_layout():
         assert k in keys, k
     assert net.state_dict()["decoder.transpconvs.0.weight"].shape == (128, 64, 2, 2, 2)
     assert net.state_dict()["decoder.stages.0.convs.0.conv.weight"].shape == (64, 128, 3, 3, 3)
+
+
+def _state_digest(sd):
+    """restated from tools/make_golden.py: sha256 over every tensor's bytes in state_dict order + crc32 of every 40th"""
+    import hashlib
+    import zlib
+    h = hashlib.sha256()
+    crc = {}
+    for i, (k, v) in enumerate(sd.items()):
+        b = v.detach().cpu().contiguous().numpy().tobytes()
+        h.update(b)
+        if i % 40 == 0:
+            crc[k] = zlib.crc32(b)
+    return {"sha256": h.hexdigest(), "n_tensors": len(sd), "crc32": crc}
+
+
+@pytest.mark.parametrize("name", ["SS2D_16", "M2NetP", "M2Net", "SwT2Net", "SSND2NetP_2d", "SSND2Net_3d"])
+def test_seeded_construction_checksums(name):
+    """torch.manual_seed(0) + constructor = the reference's parameters BIT FOR BIT (tests/golden/seeded_init.json: digests
+    of the reference's own networks, tools/make_golden.py gen_seeded_init): same creation order inside SS2D / SSND, the
+    RNG-advancing fake init of VSSLayer (m2net.py:571-578) replayed, same initialisers"""
+    import json
+    import torch
+    from nnuzoo_amd.nets import m2net, ssnd2net, swt2net
+    kw2 = dict(spatial_dims=2, factorization_type="cross-scan", in_ch=1, out_ch=2, deep_supervision=True, input_patch_size=[96, 96])
+    kw3 = dict(spatial_dims=3, factorization_type="cross-scan", in_ch=1, out_ch=2, deep_supervision=True, input_patch_size=[24, 24, 24])
+    ctor = {"SS2D_16": lambda: m2net.SS2D(d_model=16), "M2NetP": lambda: m2net.M2NetP(1, 2, True),
+            "M2Net": lambda: m2net.M2Net(1, 2, True), "SwT2Net": lambda: swt2net.SwT2Net(1, 2, True),
+            "SSND2NetP_2d": lambda: ssnd2net.SSND2NetP(**kw2), "SSND2Net_3d": lambda: ssnd2net.SSND2Net(**kw3)}[name]
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "seeded_init.json")))[name]
+    torch.manual_seed(0)
+    got = _state_digest(ctor().state_dict())
+    assert got["n_tensors"] == want["n_tensors"]
+    bad = [k for k in want["crc32"] if got["crc32"].get(k) != want["crc32"][k]]
+    assert not bad, bad[:5]
+    assert got["sha256"] == want["sha256"]

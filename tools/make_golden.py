@@ -472,6 +472,41 @@ def gen_mambandcore(ref):
     np.savez_compressed(os.path.join(OUT, "mambandcore.npz"), **out)
 
 
+def state_digest(sd):
+    """sha256 over every tensor's bytes in state_dict order + crc32 of every 40th tensor (restated in the test)"""
+    import hashlib
+    import zlib
+    h = hashlib.sha256()
+    crc = {}
+    for i, (k, v) in enumerate(sd.items()):
+        b = v.detach().cpu().contiguous().numpy().tobytes()
+        h.update(b)
+        if i % 40 == 0:
+            crc[k] = zlib.crc32(b)
+    return {"sha256": h.hexdigest(), "n_tensors": len(sd), "crc32": crc}
+
+
+def gen_seeded_init():
+    """tests/golden/seeded_init.json: digests of the reference's networks constructed under torch.manual_seed(0) - the
+    product's constructors must draw the same RNG stream (creation order, the RNG-advancing fake init of VSSLayer)."""
+    import json
+    from nnunetv2.nets import m2net, ssnd2net, swt2net
+    out = {}
+    for name, ctor in _seeded_models(m2net, swt2net, ssnd2net).items():
+        torch.manual_seed(0)
+        out[name] = state_digest(ctor().state_dict())
+    with open(os.path.join(OUT, "seeded_init.json"), "w") as f:
+        json.dump(out, f)
+
+
+def _seeded_models(m2net, swt2net, ssnd2net):
+    kw2 = dict(spatial_dims=2, factorization_type="cross-scan", in_ch=1, out_ch=2, deep_supervision=True, input_patch_size=[96, 96])
+    kw3 = dict(spatial_dims=3, factorization_type="cross-scan", in_ch=1, out_ch=2, deep_supervision=True, input_patch_size=[24, 24, 24])
+    return {"SS2D_16": lambda: m2net.SS2D(d_model=16), "M2NetP": lambda: m2net.M2NetP(1, 2, True),
+            "M2Net": lambda: m2net.M2Net(1, 2, True), "SwT2Net": lambda: swt2net.SwT2Net(1, 2, True),
+            "SSND2NetP_2d": lambda: ssnd2net.SSND2NetP(**kw2), "SSND2Net_3d": lambda: ssnd2net.SSND2Net(**kw3)}
+
+
 def gen_dataloader_bbox():
     """tests/golden/dataloader_bbox.json: outputs of the reference's OWN nnUNetDataLoader.get_bbox
     (training/dataloading/data_loader.py:102-178).  The class cannot be imported (its base class lives in batchgenerators,
@@ -541,7 +576,7 @@ def _bbox_class_locations(sc):
 
 if __name__ == "__main__":
     ref = ref_shim.install()
-    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba", "ssnd2net", "mambandcore", "bbox"]
+    which = sys.argv[1:] or ["scan", "loss", "attn", "ss2d", "ssnd", "nets", "sw", "mamba", "ssnd2net", "mambandcore", "bbox", "seeded"]
     if "sw" in which:
         gen_sliding_window()
     if "mamba" in which:
@@ -566,4 +601,6 @@ if __name__ == "__main__":
         gen_nets()
     if "bbox" in which:
         gen_dataloader_bbox()
+    if "seeded" in which:
+        gen_seeded_init()
     print(sorted(os.listdir(OUT)))
