@@ -21,20 +21,21 @@ sys.path.insert(0, os.path.dirname(HERE))
 import ref_shim  # noqa: E402
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="M2NetP", choices=["M2NetP", "SwT2Net"])
 ap.add_argument("--size", type=int, default=64)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--heldout", type=int, default=16)
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 ref_shim.install()
-from nnunetv2.nets import m2net as R  # noqa: E402
+from nnunetv2.nets import m2net, swt2net  # noqa: E402
 from nnunetv2.training.loss.compound_losses import DC_and_CE_loss  # noqa: E402
 from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper  # noqa: E402
 from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss  # noqa: E402
 from nnuzoo_amd.synthetic import synthetic_batch  # noqa: E402  (the batch generator is shared: same seeds, same voxels)
 
 torch.manual_seed(0)
-net = R.M2NetP(1, 2, True)
+net = {"M2NetP": m2net.M2NetP, "SwT2Net": swt2net.SwT2Net}[a.model](1, 2, True)
 for m in net.modules():
     if hasattr(m, "drop_prob"):
         m.drop_prob = 0.0
@@ -78,9 +79,9 @@ with torch.no_grad():
         masks.append(pm.to(torch.uint8))
         for k in range(2):
             dice.append(dice_of(pm[k], gt[k]))
-res = {"model": "M2NetP (reference classes, CPU fp32, selective_scan_ref)", "size": a.size, "steps": a.steps,
+res = {"model": a.model + " (reference classes, CPU fp32)", "size": a.size, "steps": a.steps,
        "heldout": a.heldout, "dice": float(np.mean(dice)), "losses": losses, "seconds": time.time() - t0,
-       "masks_packed": np.packbits(torch.cat(masks).numpy().reshape(-1)).tolist() if a.size <= 64 else None}
+       "masks_packed": np.packbits(torch.cat(masks).numpy().reshape(-1)).tolist() if a.size <= 128 else None}
 if a.out:
     json.dump(res, open(a.out, "w"))
 print(json.dumps({k: v for k, v in res.items() if k != "masks_packed"}))
