@@ -63,8 +63,10 @@ def test_fp32_training_trajectory_matches_the_reference_cpu_run(hip_lib):
     assert abs(got[0] - want[0]) < 2e-5 * max(1.0, abs(want[0])), (got, want)
     # later steps include 1..5 optimiser updates computed from our backward; fp32 reduction orders differ and AdamW's
     # g / (sqrt(v) + eps) turns tiny gradient differences of near-zero entries into O(lr) parameter differences early on
-    # (measured |d loss| 3.3e-3, 4.1e-3, 1.2e-2, 1.4e-2, 5.7e-4 while the loss itself falls 0.53 -> 0.22)
-    assert np.all(np.abs(got - want) < 2.5e-2), (got, want)
+    # (measured |d loss| 3.3e-3, 4.1e-3 at steps 1-2 - the same in every run - then 1.0e-2 .. 1.8e-2 over five runs once the
+    # fp32-atomic run-to-run noise has been amplified, while the loss itself falls 0.53 -> 0.22)
+    assert np.all(np.abs(got[:3] - want[:3]) < 1e-2), (got, want)
+    assert np.all(np.abs(got - want) < 4e-2), (got, want)
     assert got[-1] < 0.6 * got[0]
 
 
