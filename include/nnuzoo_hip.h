@@ -124,6 +124,18 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
 int nnz_graph_replace_memsets(void* hip_graph, int* n_replaced);
 int nnz_graph_node_census(void* hip_graph, int* counts, int ncounts);
 
+/* ---- ConvTranspose with kernel = stride (UNetDecoder.transpconvs of PlainConvUNet; csrc/conv_transpose.hip) -----------------
+ * out[n][s m + p][:Cout] = bias + in[n][m][:Cin] W[:, :, p]  and its data gradient, channels-last fp16 activations with row
+ * strides ldi / ldo (elements, multiples of 8: a tensor may be a channel slice of a wider buffer), W = the fp32 parameter in
+ * torch's ConvTranspose layout (Cin, Cout, kd, kh, kw), strides 1 or 2 per axis (2-D: sd = 1, Di = 1).
+ * nnz_convT_supported: 1 when the P x Cin x Cout weights fit LDS as MFMA fragments (the full-resolution stages); other
+ * shapes return -22 and the caller keeps the tap-table path (nnz_conv_tap_forward with a transposed-conv table). */
+int nnz_convT_supported(int Cin, int Cout, int sd, int sh, int sw, int dgrad);
+int nnz_convT_forward(const void* in, const float* W, const float* bias, void* out, int N, int Di, int Hi, int Wi, int Cin,
+                      int Cout, int sd, int sh, int sw, int ldi, int ldo, void* stream);
+int nnz_convT_dgrad(const void* dout, const float* W, void* din, int N, int Di, int Hi, int Wi, int Cin, int Cout, int sd,
+                    int sh, int sw, int ldi, int ldo, void* stream);
+
 /* ---- GPU-side input pipeline ----------------------------------------------------------------------------
  * Replaces the voxel-moving part of nnUNetDataLoader.generate_train_batch
  * (/root/reference/nnunetv2/training/dataloading/data_loader.py:180-259): data_all[j] = crop_and_pad_nd(data, bbox, 0),

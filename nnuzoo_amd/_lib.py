@@ -83,6 +83,9 @@ SIGNATURES = {
     "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _fp, _fp, _vp],
     "nnz_graph_replace_memsets": [_vp, _ip],
     "nnz_graph_node_census": [_vp, _ip, _i],
+    "nnz_convT_supported": [_i] * 6,
+    "nnz_convT_forward": [_fp, _fp, _fp, _fp] + [_i] * 11 + [_vp],
+    "nnz_convT_dgrad": [_fp, _fp, _fp] + [_i] * 11 + [_vp],
     "nnz_crop_pad_f32": [_vp, _ip, _ip, _ip, _fp, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_crop_pad_i16": [_vp, _ip, _ip, _ip, _fp, _i, _i, _i, _i, _i, _i, _vp],
     "nnz_downsample_nearest_i16": [_fp, _fp, _l, _i, _i, _i, _i, _i, _i, _vp],

@@ -95,6 +95,29 @@ def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor,
                             C.byref(pt.desc), ptr(stats), stream_ptr()))
 
 
+def convT_supported(cin: int, cout: int, stride, dgrad: bool) -> bool:
+    return bool(_lib.load().nnz_convT_supported(cin, cout, int(stride[0]), int(stride[1]), int(stride[2]), int(dgrad)))
+
+
+def convT_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, N: int, in_dims,
+                  cin: int, cout: int, stride, ldi: int, ldo: int) -> None:
+    """kernel = stride ConvTranspose on its own HBM-bound kernel (csrc/conv_transpose.hip); weight = the fp32 parameter"""
+    _f16(x, "convT.in"); _f16(out, "convT.out"); _f32(weight, "convT.w"); _f32(bias, "convT.bias")
+    flops = 2.0 * N * in_dims[0] * in_dims[1] * in_dims[2] * cin * cout * stride[0] * stride[1] * stride[2]
+    TIMER.wrap("convT_kernel", flops, lambda: call(
+        "nnz_convT_forward", ptr(x), ptr(weight), ptr(bias), ptr(out), N, int(in_dims[0]), int(in_dims[1]), int(in_dims[2]),
+        cin, cout, int(stride[0]), int(stride[1]), int(stride[2]), ldi, ldo, stream_ptr()))
+
+
+def convT_dgrad(dout: torch.Tensor, weight: torch.Tensor, din: torch.Tensor, N: int, in_dims, cin: int, cout: int, stride,
+                ldi: int, ldo: int) -> None:
+    _f16(dout, "convT.dout"); _f16(din, "convT.din"); _f32(weight, "convT.w")
+    flops = 2.0 * N * in_dims[0] * in_dims[1] * in_dims[2] * cin * cout * stride[0] * stride[1] * stride[2]
+    TIMER.wrap("convT_kernel", flops, lambda: call(
+        "nnz_convT_dgrad", ptr(dout), ptr(weight), ptr(din), N, int(in_dims[0]), int(in_dims[1]), int(in_dims[2]), cin, cout,
+        int(stride[0]), int(stride[1]), int(stride[2]), ldi, ldo, stream_ptr()))
+
+
 def conv_tap_wgrad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, dw: torch.Tensor,
                    pre_zeroed: bool = False) -> None:
     _f16(boxed, "wgrad.boxed"); _f16(plain, "wgrad.plain"); _f32(dw, "wgrad.dw")

@@ -20,6 +20,7 @@ Data layout in HBM (per resolution level s, C_s features):
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple, Type, Union
 
 import numpy as np
@@ -192,6 +193,10 @@ class _Up:
         self.dgrad = PreparedTable(cp.convT_dgrad(N, in_dims, cin, cout, ldi=ldo, ldo=cin, stride=st))
         self.wgrad = PreparedTable(cp.convT_wgrad(N, in_dims, cin, cout, lddout=ldo, ldin=cin, stride=st))
         self.ldo = ldo
+        # full-resolution stages: the dedicated HBM-bound kernel (weights resident in LDS); deeper stages: tap-table path
+        w_ok = tconv.weight.dtype == torch.float32 and tconv.weight.is_contiguous() and os.environ.get("NNZ_CONVT", "1") != "0"
+        self.native_fwd = w_ok and ops.convT_supported(cin, cout, st, False)
+        self.native_dgrad = w_ok and ops.convT_supported(cin, cout, st, True)
 
 
 class _Plan:
@@ -472,7 +477,11 @@ class PlainConvUNet(nn.Module):
         for j in range(S - 1):
             lvl = S - 2 - j
             up = plan.ups[j]
-            ops.conv_tap_forward(up.fwd, lres, up.wp_fwd, up.m.bias, cats[lvl])
+            if up.native_fwd:
+                ops.convT_forward(lres, up.m.weight, up.m.bias, cats[lvl], up.N, up.in_dims, up.cin, up.cout, up.stride,
+                                  up.cin, up.ldo)
+            else:
+                ops.conv_tap_forward(up.fwd, lres, up.wp_fwd, up.m.bias, cats[lvl])
             cur = cats[lvl]
             stage_rec = []
             for b in plan.dec_blocks[j]:
@@ -630,7 +639,10 @@ class PlainConvUNet(nn.Module):
                 gub.copy_(st[:, :, 0].sum(0))
                 grads[up.m.bias] = gub
             g_below = torch.empty((N, Vb, up.cin), dtype=f16, device=dev)
-            ops.conv_tap_forward(up.dgrad, g_up, up.wp_dgrad, None, g_below)
+            if up.native_dgrad:
+                ops.convT_dgrad(g_up, up.m.weight, g_below, up.N, up.in_dims, up.cin, up.cout, up.stride, up.ldo, up.cin)
+            else:
+                ops.conv_tap_forward(up.dgrad, g_up, up.wp_dgrad, None, g_below)
             g_cur = g_below
             if self.grad_reducer is not None:
                 self.grad_reducer.stage_done_arena(self._arena, self._arena_off)

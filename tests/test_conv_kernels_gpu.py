@@ -447,3 +447,41 @@ def test_conv_wgrad_two_stage_deterministic(hip_lib, N, dims, cin, cout, stride)
     ops.conv_tap_wgrad_to_grad(pt, xs, dys, ws, acc, 27, cin * 27, 1, accumulate=True)
     torch.cuda.synchronize()
     assert torch.allclose(acc, outs[0] + 1.0, rtol=0, atol=1e-6 * outs[0].abs().max().item() + 1e-6)
+
+
+@pytest.mark.parametrize("N,dims,cin,cout,stride,ld_out_mult", [
+    (2, (8, 8, 8), 64, 32, (2, 2, 2), 2),        # the full-resolution stage's shape family; output = channel slice of a cat buffer
+    (1, (5, 6, 7), 128, 64, (2, 2, 2), 2),       # voxel count not a multiple of the 32-voxel tile
+    (2, (4, 9, 8), 64, 32, (1, 2, 2), 1),        # anisotropic stride
+    (3, (1, 12, 10), 64, 32, (1, 2, 2), 2),      # 2-D plan (depth-1 volume)
+    (1, (3, 4, 5), 32, 96, (2, 2, 2), 1)])
+def test_conv_transpose_kernel_matches_torch(hip_lib, N, dims, cin, cout, stride, ld_out_mult):
+    """csrc/conv_transpose.hip (kernel = stride ConvTranspose, forward + data gradient) against torch's ConvTranspose3d in
+    fp32 on the fp16-rounded operands"""
+    from nnuzoo_amd import hip_ops as ops
+    torch.manual_seed(0)
+    assert ops.convT_supported(cin, cout, stride, False)
+    m = torch.nn.ConvTranspose3d(cin, cout, stride, stride, bias=True).cuda()
+    V = dims[0] * dims[1] * dims[2]
+    od = tuple(d * s for d, s in zip(dims, stride))
+    Vo = od[0] * od[1] * od[2]
+    x = torch.randn(N, V, cin, device="cuda").half()
+    ldo = cout * ld_out_mult
+    out = torch.full((N, Vo, ldo), 7.0, device="cuda", dtype=torch.float16)
+    ops.convT_forward(x, m.weight.detach(), m.bias.detach(), out, N, dims, cin, cout, stride, cin, ldo)
+    w16 = m.weight.detach().half().float()
+    xr = x.float().transpose(1, 2).reshape(N, cin, *dims)
+    ref = torch.nn.functional.conv_transpose3d(xr, w16, m.bias.detach(), stride=stride)
+    ref_cl = ref.reshape(N, cout, Vo).transpose(1, 2)
+    got = out[..., :cout].float()
+    assert torch.allclose(got, ref_cl, rtol=2e-3, atol=2e-3 * ref_cl.abs().max().item())
+    if ld_out_mult > 1:
+        assert bool((out[..., cout:] == 7.0).all())          # the other half of the wider buffer is untouched
+    if ops.convT_supported(cin, cout, stride, True):
+        dy = torch.randn(N, Vo, ldo, device="cuda").half()
+        din = torch.empty(N, V, cin, device="cuda", dtype=torch.float16)
+        ops.convT_dgrad(dy, m.weight.detach(), din, N, dims, cin, cout, stride, ldo, cin)
+        dyr = dy[..., :cout].float().transpose(1, 2).reshape(N, cout, *od)
+        ref_d = torch.nn.functional.conv3d(dyr, w16, stride=stride)          # adjoint of the transposed conv
+        ref_d = ref_d.reshape(N, cin, V).transpose(1, 2)
+        assert torch.allclose(din.float(), ref_d, rtol=2e-3, atol=2e-3 * ref_d.abs().max().item())
