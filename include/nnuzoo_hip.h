@@ -87,6 +87,7 @@ int nnz_seg_head_wgrad(const void* x_f16, const void* dlogits_f16_nc, float* dw,
 /* ---- InstanceNorm(affine, eps) + LeakyReLU(slope) ---------------------------------------------------------
  * replaces nn.InstanceNorm3d + nn.LeakyReLU of every conv block (arch kwargs at
  * nnunetv2/experiment_planning/experiment_planners/default_experiment_planner.py:285-305). */
+int nnz_norm_tuning(int knob, int value);   /* knob 0: target workgroups per norm launch (default 2048; A/B runs) */
 int nnz_instnorm_stats(const void* x_f16, float* stats /* [N][C][2] sum,sumsq */, int N, long V, int C, int ldx,
                        int stats_pre_zeroed, void* stream);
 int nnz_instnorm_lrelu_apply(const void* x_f16, const float* stats, const float* gamma, const float* beta, void* y_f16,

@@ -113,6 +113,7 @@ SIGNATURES = {
     "nnz_ss2d_scan_grad_state_floats": [_i, _i, _i],
     "nnz_ss2d_scan_workspace_floats": [_i, _i, _i],
     "nnz_scan_tuning": [_i, _i],
+    "nnz_norm_tuning": [_i, _i],
     "nnz_scan_tuning_get": [_i],
     "nnz_ss2d_scan_forward": [_fp] * 9 + [_i, _i, _i, _i, _i, _i, _vp],
     "nnz_ss2d_scan_backward": [_fp] * 16 + [_i, _i, _i, _i, _i, _i, _vp],
