@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "nnuzoo_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(nnz_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -146,7 +146,7 @@ def test_ctypes_signatures_match_the_header_declarations():
     txt = open(os.path.join(ROOT, "include", "nnuzoo_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"//[^\n]*", "", txt)
-    decls = re.findall(r"\b(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\((.*?)\)\s*;", txt, flags=re.S)
+    decls = re.findall(r"\b(?:int|long)\s+(nnz_[A-Za-z0-9_]+)\s*\((.*?)\)\s*;", txt, flags=re.S)
     assert len(decls) == len(_lib.SIGNATURES)
 
     def kind_of_decl(p):
@@ -190,13 +190,13 @@ def test_header_matches_the_extern_c_definitions():
         return out
 
     hdr = strip(open(os.path.join(ROOT, "include", "nnuzoo_hip.h")).read())
-    declared = {n: kinds(p) for n, p in re.findall(r"\b(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\((.*?)\)\s*;", hdr, flags=re.S)}
+    declared = {n: kinds(p) for n, p in re.findall(r"\b(?:int|long)\s+(nnz_[A-Za-z0-9_]+)\s*\((.*?)\)\s*;", hdr, flags=re.S)}
     defined = {}
     csrc = os.path.join(ROOT, "nnuzoo_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
         if f.endswith(".hip"):
             src = strip(open(os.path.join(csrc, f)).read())
-            for n, p in re.findall(r'extern\s+"C"\s+(?:int|long)\s+(nnz_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*\{', src, flags=re.S):
+            for n, p in re.findall(r'extern\s+"C"\s+(?:int|long)\s+(nnz_[A-Za-z0-9_]+)\s*\(([^;{}]*?)\)\s*\{', src, flags=re.S):
                 defined[n] = kinds(p)
     assert sorted(declared) == sorted(defined), set(declared) ^ set(defined)
     for n in declared:
