@@ -51,7 +51,8 @@ def stub_kernel_launches(fill: float = 1.0):
         st[:, :, 0] = fill / N   # the transposed conv's bias gradient is the sum over samples of this column
 
     try:
-        for n in ("stem_forward", "conv_tap_forward", "instnorm_lrelu_apply", "head_forward", "head_dgrad"):
+        for n in ("stem_forward", "conv_tap_forward", "convT_forward", "convT_dgrad", "instnorm_lrelu_apply", "head_forward",
+                  "head_dgrad"):
             put(n, nop)
         put("instnorm_stats", stats)
         put("conv_tap_wgrad_to_grad", wgrad_to_grad)
