@@ -29,6 +29,7 @@ from ..layer_norm import LayerNorm
 
 from ..utilities.network_initialization import InitWeights_He
 from .common2d import Convolution, DropPath, get_dwconv_layer, residual_drop_path
+from .common2d import _upsample_like as _upsample_like_2d
 from .ssnd import SSND
 
 
@@ -58,8 +59,9 @@ def shape(x, spatial_dims, channel_first=True):
 
 def _upsample_like(src, tar, upsample_mode="nontrainable"):
     """monai UpSample(nontrainable, InterpolateMode.LINEAR, align_corners=False) to tar's spatial size"""
-    mode = "bilinear" if src.dim() == 4 else "trilinear"
-    return F.interpolate(src, size=tar.shape[2:], mode=mode, align_corners=False)
+    if src.dim() == 4:
+        return _upsample_like_2d(src, tar.shape[2:])        # torch's forward, matmul-adjoint backward (common2d)
+    return F.interpolate(src, size=tar.shape[2:], mode="trilinear", align_corners=False)
 
 
 def get_scale(scale_value, scale_factor=2):

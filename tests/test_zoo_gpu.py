@@ -222,3 +222,21 @@ def test_fp32_depthwise_conv_native_path_matches_library(hip_lib):
     (gxh,) = torch.autograd.grad(yh, [x], dy.half())
     close(yh, ref.float().cpu(), "y fp16", rtol=2e-3)
     close(gxh, rx.float().cpu(), "dx fp16", rtol=5e-3)
+
+
+@pytest.mark.parametrize("shape,size", [((2, 2, 16, 16), (512, 512)), ((1, 3, 7, 12), (40, 31)), ((2, 5, 64, 64), (128, 128)),
+                                        ((1, 2, 33, 20), (33, 20))])
+def test_upsample_like_adjoint_backward_equals_autograd(hip_lib, shape, size):
+    """common2d._upsample_like: forward = F.interpolate itself (bit-identical), backward = Wy^T g Wx; compared with autograd's
+    own backward of F.interpolate"""
+    from nnuzoo_amd.nets.common2d import _upsample_like
+    torch.manual_seed(1)
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    g = torch.randn(*shape[:2], *size, device="cuda")
+    y = _upsample_like(x, size)
+    assert type(y.grad_fn).__name__.startswith("_BilinearUpFn")
+    ref = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    assert torch.equal(y, ref)
+    (gx,) = torch.autograd.grad(y, x, g)
+    (gr,) = torch.autograd.grad(ref, x, g)
+    close(gx, gr.cpu(), "dx", rtol=2e-5)
