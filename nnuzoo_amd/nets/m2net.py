@@ -297,7 +297,7 @@ class VSSMDecoder(nn.Module):
                                    d_state=math.ceil(2 * skip / 6) if d_state is None else d_state,
                                    norm_layer=LayerNorm, downsample=None, use_checkpoint=False))
             segs.append(nn.Conv2d(skip, num_classes, 1, 1, 0, bias=True))
-            fuse.append(nn.Linear(2 * skip, skip))
+            fuse.append(TokenLinear(2 * skip, skip))      # nn.Linear subclass: MFMA token kernels under fp16 autocast
         expands.append(PatchExpand(dim=chans[0], scale=patch_size, norm_layer=LayerNorm))
         stages.append(nn.Identity())
         segs.append(nn.Conv2d(skip, num_classes, 1, 1, 0, bias=True))
@@ -422,16 +422,16 @@ class M2Net(_U2Forward, nn.Module):
         self.stage6 = RSU4F(512, 256, 512)
         self.stage5d = RSU4F(1024, 256, 512)
         self.patch_expand4d = PatchExpand(dim=512, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim4d = nn.Linear(512, 256)
+        self.concat_back_dim4d = TokenLinear(512, 256)
         self.stage4d = mu(256, 128, 256, 4)
         self.patch_expand3d = PatchExpand(dim=256, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim3d = nn.Linear(256, 128)
+        self.concat_back_dim3d = TokenLinear(256, 128)
         self.stage3d = mu(128, 64, 128, 5)
         self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim2d = nn.Linear(128, 64)
+        self.concat_back_dim2d = TokenLinear(128, 64)
         self.stage2d = mu(64, 32, 64, 6)
         self.patch_expand1d = PatchExpand(dim=64, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim1d = nn.Linear(64, 32)
+        self.concat_back_dim1d = TokenLinear(64, 32)
         self.stage1d = mu(32, 16, 32, 7)
         for i, c in enumerate([32, 64, 128, 256, 512, 512], 1):
             setattr(self, f"side{i}", nn.Conv2d(c, out_ch, 3, padding=1))

@@ -367,7 +367,7 @@ class VSSMDecoder(nn.Module):
                                    norm_layer=LayerNorm, downsample=None, use_checkpoint=False,
                                    dilation=dilations[s - 1]))
             seg_layers.append(Convolution(spatial_dims, skip, num_classes, 1, 1, padding=0, bias=True, conv_only=True))
-            concat_back_dim.append(nn.Linear(2 * skip, skip))
+            concat_back_dim.append(TokenLinear(2 * skip, skip))
         if patch_size != 1:
             expand_layers.append(PatchExpand(spatial_dims=spatial_dims, dim=enc[0], scale=patch_size,
                                              norm_layer=LayerNorm))
@@ -465,7 +465,7 @@ class _SSNDU2(nn.Module):
                                                              norm_layer=LayerNorm, output_dim=cfg["expand_out"][j]))
             if j > 0:
                 a, b = cfg["concat_lin"][j - 1]
-                setattr(self, f"concat_back_dim{lvl}d", nn.Linear(a, b))
+                setattr(self, f"concat_back_dim{lvl}d", TokenLinear(a, b))
             extra = dict(input_patch_size=ips(lvl - 1)) if lvl <= 4 else {}
             setattr(self, f"stage{lvl}d", mu(in_ch=ci, mid_ch=cm, out_ch=co, n_layers=nl, **extra))
         for i, c in enumerate(cfg["side_in"]):
