@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..layer_norm import LayerNorm
+from ..token_linear import TokenLinear
 
 from ..utilities.network_initialization import InitWeights_He
 from ..window_attention import window_attention_core
@@ -86,7 +87,7 @@ class PatchMerging(nn.Module):
         super().__init__()
         self.dim = dim
         self.norm = norm_layer(4 * dim)
-        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.reduction = TokenLinear(4 * dim, 2 * dim, bias=False)
 
     def forward(self, x):
         _, H, W, _ = x.shape
@@ -106,7 +107,7 @@ class PatchExpanding(nn.Module):
     def __init__(self, dim: int, norm_layer=LayerNorm):
         super().__init__()
         self.dim = dim
-        self.expand = nn.Linear(dim, 2 * dim, bias=False)
+        self.expand = TokenLinear(dim, 2 * dim, bias=False)
         self.norm = norm_layer(dim // 2)
 
     def forward(self, x):
@@ -117,7 +118,7 @@ class FinalPatchExpanding(nn.Module):
     def __init__(self, dim: int, norm_layer=LayerNorm, patch_size: int = 4):
         super().__init__()
         self.dim = dim
-        self.expand = nn.Linear(dim, (patch_size ** 2) * dim, bias=False)
+        self.expand = TokenLinear(dim, (patch_size ** 2) * dim, bias=False)
         self.norm = norm_layer(dim)
         self.patch_size = patch_size
 
@@ -131,10 +132,10 @@ class Mlp(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc1 = TokenLinear(in_features, hidden_features)
         self.act = act_layer()
         self.drop1 = nn.Dropout(drop)
-        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.fc2 = TokenLinear(hidden_features, out_features)
         self.drop2 = nn.Dropout(drop)
 
     def forward(self, x):
@@ -158,9 +159,9 @@ class WindowAttention(nn.Module):
         coords = torch.stack(torch.meshgrid([ar, ar], indexing="ij")).flatten(1)       # (2, 49)
         rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + (window_size - 1)
         self.register_buffer("relative_position_index", rel[:, :, 0] * (2 * window_size - 1) + rel[:, :, 1])
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = TokenLinear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = TokenLinear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.softmax = nn.Softmax(dim=-1)
 
@@ -271,7 +272,7 @@ class SwinTransformerUnet(nn.Module):
         self.layers_up = nn.ModuleList([BasicBlockUp(index=i, patch_expanding=i < n - 2, **common)
                                         for i in range(n - 1)])
         self.skip_connection_layers = nn.ModuleList([
-            nn.Linear(embed_dim * 2 ** (n - 2 - i) * 2, embed_dim * 2 ** (n - 2 - i)) for i in range(n - 1)])
+            TokenLinear(embed_dim * 2 ** (n - 2 - i) * 2, embed_dim * 2 ** (n - 2 - i)) for i in range(n - 1)])
         self.norm_up = norm_layer(embed_dim)
         self.final_patch_expanding = FinalPatchExpanding(dim=embed_dim, norm_layer=norm_layer, patch_size=patch_size)
         self.head = nn.Conv2d(embed_dim, out_ch, kernel_size=(1, 1), bias=False)
@@ -329,16 +330,16 @@ class SwT2Net(_U2Forward, nn.Module):
         self.stage6 = RSU4F(512, 256, 512)
         self.stage5d = RSU4F(1024, 256, 512)
         self.patch_expand4d = PatchExpand(dim=512, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim4d = nn.Linear(512, 256)
+        self.concat_back_dim4d = TokenLinear(512, 256)
         self.stage4d = su(1, 256, 256, 96, (3, 6, 12, 24))
         self.patch_expand3d = PatchExpand(dim=256, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim3d = nn.Linear(256, 128)
+        self.concat_back_dim3d = TokenLinear(256, 128)
         self.stage3d = su(2, 128, 128, 96, (3, 6, 12, 24))
         self.patch_expand2d = PatchExpand(dim=128, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim2d = nn.Linear(128, 64)
+        self.concat_back_dim2d = TokenLinear(128, 64)
         self.stage2d = su(4, 64, 64, 64, (2, 4, 8, 16))
         self.patch_expand1d = PatchExpand(dim=64, scale=2, norm_layer=LayerNorm)
-        self.concat_back_dim1d = nn.Linear(64, 32)
+        self.concat_back_dim1d = TokenLinear(64, 32)
         self.stage1d = su(4, 32, 32, 32, (2, 2, 4, 8))
         for i, c in enumerate([32, 64, 128, 256, 512, 512], 1):
             setattr(self, f"side{i}", Convolution(2, c, out_ch, kernel_size=1, padding=0, conv_only=True))

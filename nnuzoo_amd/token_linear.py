@@ -32,6 +32,22 @@ def _chunks(T: int) -> int:
     return nc
 
 
+def _wgrad_chunks(T: int, fin: int, fout: int) -> int:
+    """how many token chunks the weight-gradient GEMM dW[fout, fin] = dY^T X is cut into (a batched GEMM + a sum over the
+    chunks).  Two regimes make one library GEMM slow: very many tokens (`_chunks`), and a SMALL result - a 256 x 256 dW is one
+    256 x 256 macro tile = one workgroup walking all T tokens (SwT2Net: 20 such calls at 205 us and 8 at 225 us per step,
+    tools/probes/swt_slow_conv_probe.py); cutting T gives the chip something to do."""
+    nc = _chunks(T)
+    wgs = -(-fout // 256) * -(-fin // 256)
+    if wgs < 32 and T >= 256:
+        want = min(64 // wgs, T // 64)
+        for c in range(want, 1, -1):
+            if T % c == 0:
+                nc = max(nc, c)
+                break
+    return nc
+
+
 def _hip_ok(kr: int, mo: int) -> bool:
     return bool(_lib.load().nnz_token_linear_supported(int(kr), int(mo)))
 
@@ -110,7 +126,7 @@ class _TallLinearFn(torch.autograd.Function):
                 dx = (dy2 @ wc).view(xc.shape).to(xdt)
             if ctx.needs_input_grad[1]:
                 T = x2.shape[0]
-                nc = _chunks(T)
+                nc = _wgrad_chunks(T, fin, fout)
                 if nc > 1:
                     part = torch.bmm(dy2.view(nc, T // nc, fout).transpose(1, 2), x2.view(nc, T // nc, fin))
                     dw = part.sum(0, dtype=torch.float32).to(wdt)
@@ -130,7 +146,7 @@ class TokenLinear(nn.Linear):
                 and _hip_ok(self.in_features, self.out_features):
             xh = x if x.dtype == torch.float16 else x.to(torch.float16)
             return _HipTokenLinearFn.apply(xh, self.weight, self.bias)
-        if x.is_cuda and tokens >= MIN_TOKENS and self.in_features <= MAX_FEATURES and self.out_features <= MAX_FEATURES \
-                and x.is_contiguous() and x.dtype in (torch.float16, torch.float32):
+        if x.is_cuda and x.is_contiguous() and x.dtype in (torch.float16, torch.float32) \
+                and _wgrad_chunks(tokens, self.in_features, self.out_features) > 1:
             return _TallLinearFn.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
