@@ -227,3 +227,30 @@ def test_python_call_sites_pass_the_declared_number_of_arguments():
                             (os.path.join(root, f), node.lineno, name, len(node.args) - 1, len(_lib.SIGNATURES[name]))
                         checked += 1
     assert checked >= 40
+
+
+def test_interpolation_matrix_equals_torch_bilinear_on_cpu():
+    """common2d._interp_matrix (the separable form behind _upsample_like's backward): Wy x Wx^T reproduces
+    F.interpolate(bilinear, align_corners=False) and its transpose is autograd's backward"""
+    import torch
+    import torch.nn.functional as F
+    from nnuzoo_amd.nets.common2d import _interp_matrix
+    torch.manual_seed(0)
+    for (h, w), (H, W) in (((16, 16), (512, 512)), ((7, 12), (40, 31)), ((33, 20), (33, 20)), ((5, 9), (10, 9))):
+        x = torch.randn(2, 3, h, w, requires_grad=True)
+        Wy, Wx = _interp_matrix(h, H, "cpu"), _interp_matrix(w, W, "cpu")
+        ref = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False)
+        assert torch.allclose(Wy @ x.detach() @ Wx.t(), ref.detach(), atol=1e-5)
+        g = torch.randn_like(ref)
+        (gr,) = torch.autograd.grad(ref, x, g)
+        assert torch.allclose(Wy.t() @ g @ Wx, gr, atol=1e-4)
+
+
+def test_wgrad_chunk_policy():
+    from nnuzoo_amd.token_linear import _wgrad_chunks
+    assert _wgrad_chunks(882, 256, 256) == 9            # one 256 x 256 macro tile: cut the 882 tokens (98 per chunk)
+    assert 882 % _wgrad_chunks(882, 256, 256) == 0
+    assert _wgrad_chunks(35378, 32, 32) >= 32           # tiny result, many tokens
+    assert _wgrad_chunks(200, 256, 256) == 1            # too few tokens to cut
+    assert _wgrad_chunks(2450, 3072, 3072) == 1         # 144 macro tiles already fill the chip
+    assert _wgrad_chunks(524288, 64, 32) == 128         # the tall case of the VSS blocks (unchanged rule)
