@@ -323,10 +323,13 @@ int nnz_region_tp_fp_fn(const void* logits, int logits_is_f16, const int16_t* ta
  * replaces mamba_ssm's selective_scan_cuda.fwd/bwd behind selective_scan_fn as called at
  * nnunetv2/nets/m2net.py:193-199 and ssnd2net.py:271-277 (definition: selective_scan_ref,
  * nnunetv2/nets/seg_mamba/selective_scan_interface.py:86-152).  u, delta, y: (B, K*Dg, L); A: (K*Dg, N).
- * chunk_state (forward checkpoints, kept for backward) and grad_state: nnz_selective_scan_state_floats floats;
- * workspace: nnz_selective_scan_workspace_floats floats. */
+ * chunk_state (forward checkpoints, kept for backward): nnz_selective_scan_state_floats floats; grad_state:
+ * nnz_selective_scan_grad_state_floats floats; workspace: nnz_selective_scan_workspace_floats floats.  Large calls
+ * (L % 64 == 0, Dg = 32 or a multiple of 64, at least nnz_scan_tuning knob 2 row-steps) run on the channels-on-lanes
+ * kernels of csrc/ss2d_scan_rl.hpp like the cross-scan below; the rest on the time-on-lanes kernels. */
 long nnz_selective_scan_workspace_floats(int Bt, int KD, int L);
 long nnz_selective_scan_state_floats(int Bt, int KD, int L);
+long nnz_selective_scan_grad_state_floats(int Bt, int KD, int L);
 int nnz_selective_scan_forward(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
                                const float* D, const float* delta_bias, float* y, float* chunk_state,
                                float* workspace, int Bt, int K, int Dg, int N, int L, int delta_softplus,

@@ -138,12 +138,14 @@ SIGNATURES = {
     "nnz_window_attention_backward": [_fp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_selective_scan_workspace_floats": [_i, _i, _i],
     "nnz_selective_scan_state_floats": [_i, _i, _i],
+    "nnz_selective_scan_grad_state_floats": [_i, _i, _i],
     "nnz_selective_scan_forward": [_fp] * 10 + [_i] * 6 + [_vp],
     "nnz_selective_scan_backward": [_fp] * 18 + [_i] * 6 + [_vp],
 }
 
 _LONG_RESULT = {"nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats", "nnz_ss2d_scan_workspace_floats",
-                "nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats", "nnz_conv_tap_wgrad_workspace_floats"}
+                "nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats",
+                "nnz_selective_scan_grad_state_floats", "nnz_conv_tap_wgrad_workspace_floats"}
 _lib = None
 
 

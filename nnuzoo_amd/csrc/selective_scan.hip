@@ -740,7 +740,7 @@ static int rl_pick_clb(const ScanArgs& a) {
   }
   return best;
 }
-static bool rl_ok(const ScanArgs& a) { return g_scan_tuning[0] != 0 && rl_pick_clb(a) != 0; }
+static bool rl_ok(const ScanArgs& a) { return g_scan_tuning[0] != 0 && check(a) == NNZ_OK && rl_pick_clb(a) != 0; }
 static long rl_nch_max(int L) { return (L + RL_MIN_CLB * RL_T - 1) / (RL_MIN_CLB * RL_T); }
 
 static void rl_setup(ScanArgs& a, int& clb, dim3& grid, float* chunk_state, float* workspace, float*& Hck) {
@@ -753,9 +753,10 @@ static void rl_setup(ScanArgs& a, int& clb, dim3& grid, float* chunk_state, floa
   Hck = chunk_state + rows * SS_N * rl_nch_max(a.L);
   const int Dl = a.Dg < 64 ? a.Dg : 64;
   const int slots = 64 / Dl;
-  grid = dim3((a.nchunks + slots - 1) / slots, a.Bt * 4 * (a.Dg / Dl));
+  grid = dim3((a.nchunks + slots - 1) / slots, a.Bt * a.K * (a.Dg / Dl));
 }
 
+template <bool XS>
 static int rl_forward(ScanArgs& a, float* chunk_state, float* workspace, hipStream_t s) {
   ++g_scan_tuning[3];
   int clb;
@@ -764,7 +765,7 @@ static int rl_forward(ScanArgs& a, float* chunk_state, float* workspace, hipStre
   rl_setup(a, clb, grid, chunk_state, workspace, Hck);
   const long rows = (long)a.Bt * a.KD;
   if (a.nchunks > 1) {
-    NNZ_LAUNCH(xs_rl_fwd_summary_kernel, grid, dim3(64), 0, s, a, clb);
+    NNZ_LAUNCH(xs_rl_fwd_summary_kernel<XS>, grid, dim3(64), 0, s, a, clb);
     NNZ_LAUNCH_CHECK();
     const long rows_n = rows * SS_N;
     NNZ_LAUNCH(scan_carry_kernel<false>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Hin, rows_n,
@@ -774,11 +775,12 @@ static int rl_forward(ScanArgs& a, float* chunk_state, float* workspace, hipStre
     hipError_t e = nnz::zero_async(a.Hin, sizeof(float) * rows * SS_N, s);
     if (e != hipSuccess) return (int)e;
   }
-  NNZ_LAUNCH(xs_rl_fwd_final_kernel, grid, dim3(64), 0, s, a, clb, Hck);
+  NNZ_LAUNCH(xs_rl_fwd_final_kernel<XS>, grid, dim3(64), 0, s, a, clb, Hck);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
 
+template <bool XS>
 static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state, float* workspace, float* dWdt,
                        hipStream_t s) {
   ++g_scan_tuning[3];
@@ -790,10 +792,16 @@ static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state,
   const long rows = (long)a.Bt * a.KD;
   const int atomic_dp = a.Dg > 64;      // several waves (channel groups of 64) add into one dP tile
   hipError_t e;
-  if (atomic_dp && (e = nnz::zero_async(a.xs_dP, sizeof(float) * 2L * a.Bt * 2 * a.Cp * a.L, s)) != hipSuccess)
-    return (int)e;
+  if (atomic_dp) {
+    if (XS) {
+      if ((e = nnz::zero_async(a.xs_dP, sizeof(float) * 2L * a.Bt * 2 * a.Cp * a.L, s)) != hipSuccess) return (int)e;
+    } else {
+      if ((e = nnz::zero_async(a.dB, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
+      if ((e = nnz::zero_async(a.dC, sizeof(float) * (long)a.Bt * a.K * SS_N * a.L, s)) != hipSuccess) return (int)e;
+    }
+  }
   if (a.nchunks > 1) {
-    NNZ_LAUNCH(xs_rl_bwd_summary_kernel, grid, dim3(64), 0, s, a, clb);
+    NNZ_LAUNCH(xs_rl_bwd_summary_kernel<XS>, grid, dim3(64), 0, s, a, clb);
     NNZ_LAUNCH_CHECK();
     const long rows_n = rows * SS_N;
     NNZ_LAUNCH(scan_carry_kernel<true>, dim3((unsigned)((rows_n + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.Gin, rows_n,
@@ -802,7 +810,7 @@ static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state,
   } else {
     if ((e = nnz::zero_async(a.Gin, sizeof(float) * rows * SS_N, s)) != hipSuccess) return (int)e;
   }
-  NNZ_LAUNCH(xs_rl_bwd_kernel, grid, dim3(64), 0, s, a, clb, Hck, atomic_dp);
+  NNZ_LAUNCH(xs_rl_bwd_kernel<XS>, grid, dim3(64), 0, s, a, clb, Hck, atomic_dp);
   NNZ_LAUNCH_CHECK();
   NNZ_LAUNCH(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA, a.dbias,
              a.dD, a.Bt, a.KD, a.nchunks, dWdt, a.R, a.a_is_log ? a.A : (const float*)nullptr);
@@ -831,13 +839,17 @@ extern "C" long nnz_ss2d_scan_workspace_floats(int Bt, int Dg, int L) {
   return 2L * Bt * 4 * Dg * nnz::SS_N * nnz::rl_nch_max(L);
 }
 
+// buffer sizes of the plain entry points (cover both kernel generations: chunks as short as 64 steps, and the forward's
+// 16-step checkpoints behind the chunk-entry states)
 extern "C" long nnz_selective_scan_workspace_floats(int Bt, int KD, int L) {
-  const long nch = (L + nnz::SS_CL - 1) / nnz::SS_CL;
-  return 2L * Bt * KD * nnz::SS_N * nch;  // P and S
+  return 2L * Bt * KD * nnz::SS_N * nnz::rl_nch_max(L);  // P and S
 }
 extern "C" long nnz_selective_scan_state_floats(int Bt, int KD, int L) {
-  const long nch = (L + nnz::SS_CL - 1) / nnz::SS_CL;
-  return (long)Bt * KD * nnz::SS_N * nch;  // Hin (and Gin)
+  const long rows = (long)Bt * KD;
+  return rows * nnz::SS_N * nnz::rl_nch_max(L) + rows * (((long)L + nnz::RL_T - 1) / nnz::RL_T) * nnz::SS_N;  // Hin, Hck
+}
+extern "C" long nnz_selective_scan_grad_state_floats(int Bt, int KD, int L) {
+  return (long)Bt * KD * nnz::SS_N * nnz::rl_nch_max(L);  // Gin
 }
 
 namespace nnz {
@@ -924,6 +936,7 @@ extern "C" int nnz_selective_scan_forward(const float* u, const float* delta, co
   ScanArgs a = {};
   a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.y = y;
   a.Bt = Bt; a.K = K; a.Dg = Dg; a.KD = K * Dg; a.L = L; a.softplus = delta_softplus;
+  if (rl_ok(a)) return rl_forward<false>(a, chunk_state, workspace, (hipStream_t)stream);
   return scan_forward_impl<false>(a, chunk_state, workspace, (hipStream_t)stream);
 }
 
@@ -940,6 +953,7 @@ extern "C" int nnz_selective_scan_backward(const float* u, const float* delta, c
   a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.dy = dy;
   a.du = du; a.ddelta = ddelta; a.dA = dA; a.dB = dB; a.dC = dC; a.dD = dD; a.dbias = dbias;
   a.Bt = Bt; a.K = K; a.Dg = Dg; a.KD = K * Dg; a.L = L; a.softplus = delta_softplus;
+  if (rl_ok(a)) return rl_backward<false>(a, chunk_state, grad_state, workspace, nullptr, (hipStream_t)stream);
   return scan_backward_impl<false>(a, chunk_state, grad_state, workspace, nullptr, (hipStream_t)stream);
 }
 
@@ -953,7 +967,7 @@ extern "C" int nnz_ss2d_scan_forward(const float* x2, const float* P, const floa
   a.u = x2; a.xs_P = P; a.xs_Wdt = Wdt; a.A = A; a.D = D; a.bias = delta_bias; a.y = y;
   a.R = R; a.Cp = R + 2 * SS_N;
   a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus; a.a_is_log = a_is_log;
-  if (rl_ok(a)) return rl_forward(a, chunk_state, workspace, (hipStream_t)stream);
+  if (rl_ok(a)) return rl_forward<true>(a, chunk_state, workspace, (hipStream_t)stream);
   return scan_forward_impl<true>(a, chunk_state, workspace, (hipStream_t)stream);
 }
 
@@ -971,6 +985,6 @@ extern "C" int nnz_ss2d_scan_backward(const float* x2, const float* P, const flo
   a.du = du; a.xs_dP = dP; a.dA = dA; a.dD = dD; a.dbias = dbias;
   a.R = R; a.Cp = R + 2 * SS_N;
   a.Bt = Bt; a.K = 4; a.Dg = Dg; a.KD = 4 * Dg; a.L = L; a.softplus = delta_softplus; a.a_is_log = a_is_log;
-  if (rl_ok(a)) return rl_backward(a, chunk_state, grad_state, workspace, dWdt, (hipStream_t)stream);
+  if (rl_ok(a)) return rl_backward<true>(a, chunk_state, grad_state, workspace, dWdt, (hipStream_t)stream);
   return scan_backward_impl<true>(a, chunk_state, grad_state, workspace, dWdt, (hipStream_t)stream);
 }

@@ -69,8 +69,8 @@ __device__ __forceinline__ float rl_softplus_grad(float dl) { return 1.f - __exp
 // what a wave shares (k, b, channel group) and what a lane owns (channel, chunk)
 struct RlWave {
   int Dl, slots, b, k, rg, cw, CL;
-  bool rev;
-  long pk_off;
+  bool rev, xs;
+  long pk_off;   // cross-scan: direction k's rows of the projections P / dP; plain: group (b, k)'s rows of B / C / dB / dC
 };
 struct RlLane {
   int slot, lis, d, kd, c, t_begin;
@@ -87,12 +87,14 @@ __device__ __forceinline__ RlWave rl_wave(const ScanArgs& a, int clb) {
   int yb = blockIdx.y;
   w.rg = yb % rgs;
   yb /= rgs;
-  w.k = yb % 4;
-  w.b = yb / 4;
+  w.k = yb % a.K;
+  w.b = yb / a.K;
   w.cw = blockIdx.x;
   w.CL = clb * RL_T;
-  w.rev = w.k >= 2;
-  w.pk_off = ((((long)(w.k & 1) * a.Bt + w.b) * 2 + (w.k >> 1)) * a.Cp) * a.L;
+  w.xs = a.xs_P != nullptr;
+  w.rev = w.xs && w.k >= 2;
+  w.pk_off = w.xs ? ((((long)(w.k & 1) * a.Bt + w.b) * 2 + (w.k >> 1)) * a.Cp) * a.L
+                  : ((long)w.b * a.K + w.k) * SS_N * a.L;
   return w;
 }
 // geometry of tile row r (r = the lane that owns it)
@@ -106,7 +108,7 @@ __device__ __forceinline__ RlLane rl_row(const ScanArgs& a, const RlWave& w, int
   g.d = w.rg * w.Dl + g.lis;
   g.kd = w.k * a.Dg + g.d;
   g.row = (long)w.b * a.KD + g.kd;
-  g.srow = ((long)(w.k & 1) * a.Bt + w.b) * a.Dg + g.d;
+  g.srow = w.xs ? ((long)(w.k & 1) * a.Bt + w.b) * a.Dg + g.d : g.row;
   g.t_begin = g.c * w.CL;
   return g;
 }
@@ -150,28 +152,32 @@ template <int W>
 struct RlTiles {
   f32x4 tB[W / 8], tC[W / 8], tDt[W / 16];   // pieces per lane at Dl = 32 (half of them are used at Dl = 64)
 };
-template <int W, bool NEED_B, bool NEED_C>
+template <bool XS, int W, bool NEED_B, bool NEED_C>
 __device__ __forceinline__ void rl_tiles_fetch(const ScanArgs& a, const RlWave& w, const RlLane& g, int toff, RlTiles<W>& s) {
   constexpr int PPR = W / 4;
-  const float* Pk = a.xs_P + w.pk_off;
+  const float* Pk = XS ? a.xs_P + w.pk_off : nullptr;
+  const float* Bk = XS ? Pk + (long)a.R * a.L : a.Bm + w.pk_off;              // 16 rows of B, then (XS) 16 rows of C
+  const float* Ck = XS ? Pk + (long)(a.R + SS_N) * a.L : a.Cm + w.pk_off;
   const int t = g.t_begin + toff;
 #pragma unroll
   for (int p = 0; p < W / 8; ++p) {
     const int i = g.lis + p * w.Dl;
     if (i < SS_N * PPR) {
-      if (NEED_B) s.tB[p] = rl_ld4(Pk + (long)(a.R + i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
-      if (NEED_C) s.tC[p] = rl_ld4(Pk + (long)(a.R + SS_N + i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
+      if (NEED_B) s.tB[p] = rl_ld4(Bk + (long)(i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
+      if (NEED_C) s.tC[p] = rl_ld4(Ck + (long)(i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
     }
   }
+  if (XS) {
 #pragma unroll
-  for (int p = 0; p < W / 16; ++p) {
-    const int i = g.lis + p * w.Dl;
-    if (i < a.R * PPR) s.tDt[p] = rl_ld4(Pk + (long)(i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
+    for (int p = 0; p < W / 16; ++p) {
+      const int i = g.lis + p * w.Dl;
+      if (i < a.R * PPR) s.tDt[p] = rl_ld4(Pk + (long)(i / PPR) * a.L, t + 4 * (i % PPR), a.L, w.rev);
+    }
   }
 }
 // STEP_MAJOR: sB / sC [W steps][16 states] (forward: one step's 16 states are 4 vector reads); else [16 states][W steps]
 // (backward: one state's steps are vector reads).  sDt [R][W].
-template <int W, bool NEED_B, bool NEED_C, bool STEP_MAJOR>
+template <bool XS, int W, bool NEED_B, bool NEED_C, bool STEP_MAJOR>
 __device__ __forceinline__ void rl_tiles_commit(const ScanArgs& a, const RlWave& w, const RlLane& g, const RlTiles<W>& s,
                                                 float* sB, float* sC, float* sDt) {
   constexpr int PPR = W / 4;
@@ -195,10 +201,12 @@ __device__ __forceinline__ void rl_tiles_commit(const ScanArgs& a, const RlWave&
       }
     }
   }
+  if (XS) {
 #pragma unroll
-  for (int p = 0; p < W / 16; ++p) {
-    const int i = g.lis + p * w.Dl;
-    if (i < a.R * PPR) *reinterpret_cast<f32x4*>(sDt + (i / PPR) * W + 4 * (i % PPR)) = rl_swz(s.tDt[p], w.rev);
+    for (int p = 0; p < W / 16; ++p) {
+      const int i = g.lis + p * w.Dl;
+      if (i < a.R * PPR) *reinterpret_cast<f32x4*>(sDt + (i / PPR) * W + 4 * (i % PPR)) = rl_swz(s.tDt[p], w.rev);
+    }
   }
 }
 
@@ -211,7 +219,7 @@ __device__ __forceinline__ void rl_lane_consts(const ScanArgs& a, const RlLane& 
     for (int i = 0; i < 4; ++i) A2[4 * q + i] = (a.a_is_log ? -__expf(v[i]) : v[i]) * RL_LOG2E;
   }
 #pragma unroll
-  for (int r = 0; r < SS_RMAX; ++r) wdt[r] = r < a.R ? a.xs_Wdt[(long)g.kd * a.R + r] : 0.f;
+  for (int r = 0; r < SS_RMAX; ++r) wdt[r] = r < a.R ? a.xs_Wdt[(long)g.kd * a.R + r] : 0.f;   // R = 0 in plain mode
   bias = a.bias ? a.bias[g.kd] : 0.f;
   Dv = a.D ? a.D[g.kd] : 0.f;
 }
@@ -227,12 +235,13 @@ constexpr int RL_FP = RL_FW + 4;
 // ---------------------------------------------------------------------------------------------------------------
 // forward.  FINAL = false: chunk summaries P, S.  FINAL = true: y, and the state entering every sub-block (Hck)
 // ---------------------------------------------------------------------------------------------------------------
-template <bool FINAL, int FW>
+template <bool XS, bool FINAL, int FW>
 __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float* __restrict__ Hck) {
   __shared__ __attribute__((aligned(16))) float sU[64 * (FW + 4)];                  // u in, y out (in place)
   __shared__ __attribute__((aligned(16))) float sB[2][FW * SS_N];
   __shared__ __attribute__((aligned(16))) float sC[2][FINAL ? FW * SS_N : 4];
-  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * FW];
+  __shared__ __attribute__((aligned(16))) float sDt[2][XS ? SS_RMAX * FW : 4];
+  __shared__ __attribute__((aligned(16))) float sDl[XS ? 4 : 64 * (FW + 4)];      // plain mode: the rows of delta
   const int lane = threadIdx.x;
   const RlWave w = rl_wave(a, clb);
   const RlLane g = rl_row(a, w, lane);
@@ -255,20 +264,24 @@ __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float
   float* myC = sC[g.slot];
   float* myDt = sDt[g.slot];
   float* myU = sU + lane * (FW + 4);
+  const float* myDl = sDl + (XS ? 0 : lane * (FW + 4));
 
-  f32x4 ru[FW / 4];
+  f32x4 ru[FW / 4], rd[XS ? 1 : FW / 4];
   RlTiles<FW> rt;
   rl_rows_fetch<FW>(a, w, a.u, 0, ru);
-  rl_tiles_fetch<FW, true, FINAL>(a, w, g, 0, rt);
+  if constexpr (!XS) rl_rows_fetch<FW>(a, w, a.delta, 0, rd);
+  rl_tiles_fetch<XS, FW, true, FINAL>(a, w, g, 0, rt);
   rl_rows_commit<FW>(sU, ru, w.rev);
-  rl_tiles_commit<FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
+  if constexpr (!XS) rl_rows_commit<FW>(sDl, rd, false);
+  rl_tiles_commit<XS, FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
   rl_sync();
   const int nst = w.CL / FW;
   for (int st = 0; st < nst; ++st) {
     const int toff = st * FW;
     if (st + 1 < nst) {   // next stage's global loads fly under this stage's math
       rl_rows_fetch<FW>(a, w, a.u, toff + FW, ru);
-      rl_tiles_fetch<FW, true, FINAL>(a, w, g, toff + FW, rt);
+      if constexpr (!XS) rl_rows_fetch<FW>(a, w, a.delta, toff + FW, rd);
+      rl_tiles_fetch<XS, FW, true, FINAL>(a, w, g, toff + FW, rt);
     }
 #pragma unroll 1
     for (int j = 0; j < FW / 4; ++j) {     // 4 steps at a time: small live set
@@ -283,9 +296,13 @@ __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float
       }
       const f32x4 u4 = *reinterpret_cast<const f32x4*>(myU + 4 * j);
       f32x4 dr = {bias, bias, bias, bias};
+      if constexpr (XS) {
 #pragma unroll
-      for (int r = 0; r < SS_RMAX; ++r)
-        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * FW + 4 * j);
+        for (int r = 0; r < SS_RMAX; ++r)
+          if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * FW + 4 * j);
+      } else {
+        dr += *reinterpret_cast<const f32x4*>(myDl + 4 * j);
+      }
       f32x4 yv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -319,7 +336,8 @@ __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float
     rl_sync();
     if (st + 1 < nst) {
       rl_rows_commit<FW>(sU, ru, w.rev);
-      rl_tiles_commit<FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
+      if constexpr (!XS) rl_rows_commit<FW>(sDl, rd, false);
+      rl_tiles_commit<XS, FW, true, FINAL, true>(a, w, g, rt, myB, myC, myDt);
     }
     rl_sync();
   }
@@ -335,21 +353,25 @@ __device__ __forceinline__ void xs_rl_fwd_body(const ScanArgs& a, int clb, float
 // the summary pass fits two waves per SIMD (register cap 256); the final pass (C tile, y tile stores, checkpoints) does
 // not without spilling and runs one wave per SIMD on the 16 interleaved state chains (measured: capped to two waves with
 // 16-step tiles it spills outside the step loop only, yet the 512^2 forward goes from 0.65 to 0.87 ms)
+template <bool XS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void xs_rl_fwd_summary_kernel(ScanArgs a, int clb) {
-  xs_rl_fwd_body<false, RL_FW>(a, clb, nullptr);
+  xs_rl_fwd_body<XS, false, RL_FW>(a, clb, nullptr);
 }
+template <bool XS>
 __global__ __launch_bounds__(64) void xs_rl_fwd_final_kernel(ScanArgs a, int clb, float* __restrict__ Hck) {
-  xs_rl_fwd_body<true, RL_FW>(a, clb, Hck);
+  xs_rl_fwd_body<XS, true, RL_FW>(a, clb, Hck);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward pass 1: reverse chunk summaries.  G_{t-1} = a_t (G_t + C_t dy_t) walked from the chunk's last step to its first:
 // X_left = P X_right + S with P = prod a_t = exp(A sum dl), S = the walk from zero.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool XS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void xs_rl_bwd_summary_kernel(ScanArgs a, int clb) {
   __shared__ __attribute__((aligned(16))) float sY[64 * RL_FP];
   __shared__ __attribute__((aligned(16))) float sC[2][RL_FW * SS_N];
-  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * RL_FW];
+  __shared__ __attribute__((aligned(16))) float sDt[2][XS ? SS_RMAX * RL_FW : 4];
+  __shared__ __attribute__((aligned(16))) float sDl[XS ? 4 : 64 * RL_FP];
   const int lane = threadIdx.x;
   const RlWave w = rl_wave(a, clb);
   const RlLane g = rl_row(a, w, lane);
@@ -362,26 +384,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float* myC = sC[g.slot];
   float* myDt = sDt[g.slot];
   const float* myY = sY + lane * RL_FP;
-  f32x4 ry[RL_FW / 4];
+  const float* myDl = sDl + (XS ? 0 : lane * RL_FP);
+  f32x4 ry[RL_FW / 4], rd[XS ? 1 : RL_FW / 4];
   RlTiles<RL_FW> rt;
   const int nst = w.CL / RL_FW;
   rl_rows_fetch<RL_FW>(a, w, a.dy, (nst - 1) * RL_FW, ry);
-  rl_tiles_fetch<RL_FW, false, true>(a, w, g, (nst - 1) * RL_FW, rt);
+  if constexpr (!XS) rl_rows_fetch<RL_FW>(a, w, a.delta, (nst - 1) * RL_FW, rd);
+  rl_tiles_fetch<XS, RL_FW, false, true>(a, w, g, (nst - 1) * RL_FW, rt);
   rl_rows_commit<RL_FW>(sY, ry, w.rev);
-  rl_tiles_commit<RL_FW, false, true, true>(a, w, g, rt, nullptr, myC, myDt);
+  if constexpr (!XS) rl_rows_commit<RL_FW>(sDl, rd, false);
+  rl_tiles_commit<XS, RL_FW, false, true, true>(a, w, g, rt, nullptr, myC, myDt);
   rl_sync();
   for (int st = nst - 1; st >= 0; --st) {
     if (st > 0) {
       rl_rows_fetch<RL_FW>(a, w, a.dy, (st - 1) * RL_FW, ry);
-      rl_tiles_fetch<RL_FW, false, true>(a, w, g, (st - 1) * RL_FW, rt);
+      if constexpr (!XS) rl_rows_fetch<RL_FW>(a, w, a.delta, (st - 1) * RL_FW, rd);
+      rl_tiles_fetch<XS, RL_FW, false, true>(a, w, g, (st - 1) * RL_FW, rt);
     }
 #pragma unroll 1
     for (int j = RL_FW / 4 - 1; j >= 0; --j) {
       const f32x4 dy4 = *reinterpret_cast<const f32x4*>(myY + 4 * j);
       f32x4 dr = {bias, bias, bias, bias};
+      if constexpr (XS) {
 #pragma unroll
-      for (int r = 0; r < SS_RMAX; ++r)
-        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_FW + 4 * j);
+        for (int r = 0; r < SS_RMAX; ++r)
+          if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_FW + 4 * j);
+      } else {
+        dr += *reinterpret_cast<const f32x4*>(myDl + 4 * j);
+      }
 #pragma unroll
       for (int i = 3; i >= 0; --i) {
         const float dl = a.softplus ? softplus_f(dr[i]) : dr[i];
@@ -403,7 +433,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     rl_sync();
     if (st > 0) {
       rl_rows_commit<RL_FW>(sY, ry, w.rev);
-      rl_tiles_commit<RL_FW, false, true, true>(a, w, g, rt, nullptr, myC, myDt);
+      if constexpr (!XS) rl_rows_commit<RL_FW>(sDl, rd, false);
+      rl_tiles_commit<XS, RL_FW, false, true, true>(a, w, g, rt, nullptr, myC, myDt);
     }
     rl_sync();
   }
@@ -422,16 +453,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 constexpr int RL_CP = 33;            // pitch of the column-sum tile (32 columns + 1: conflict-free row and column access)
 constexpr int RL_BP = RL_T + 4;      // pitch of the backward's 16-step row tiles
 
+template <bool XS>
 __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, const float* __restrict__ Hck, int atomic_dp) {
   __shared__ __attribute__((aligned(16))) float sU[64 * RL_BP];                  // u rows
   __shared__ __attribute__((aligned(16))) float sY[64 * RL_BP];                  // dy rows in, du out (in place)
   __shared__ __attribute__((aligned(16))) float sB[2][RL_T * SS_N];              // [state][step]
   __shared__ __attribute__((aligned(16))) float sC[2][RL_T * SS_N];
-  __shared__ __attribute__((aligned(16))) float sDt[2][SS_RMAX * RL_T];
+  __shared__ __attribute__((aligned(16))) float sDt[2][XS ? SS_RMAX * RL_T : 4];
+  __shared__ __attribute__((aligned(16))) float sDl[XS ? 4 : 64 * RL_BP];        // plain mode: delta rows in, d delta out
   __shared__ float sG[SS_N][64], sdA[SS_N][64];                                  // per-state values of every lane
   __shared__ float sT[64 * RL_CP];                                               // column-sum tile [lane][32]
   __shared__ __attribute__((aligned(16))) float sOut[2][2 * SS_N * RL_T];        // per slot: dB [n][t], then dC [n][t]
-  __shared__ __attribute__((aligned(16))) float sOutDt[2][SS_RMAX * RL_T];       // per slot: d dt [r][t]
+  __shared__ __attribute__((aligned(16))) float sOutDt[2][XS ? SS_RMAX * RL_T : 4];   // per slot: d dt [r][t]
   const int lane = threadIdx.x;
   const RlWave w = rl_wave(a, clb);
   const RlLane g = rl_row(a, w, lane);
@@ -439,7 +472,7 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
   {
     // (A is re-read per state inside the loop: a 16 x 64 table of it in LDS put the kernel over 40 KB = 3 waves per CU)
 #pragma unroll
-    for (int r = 0; r < SS_RMAX; ++r) wdt[r] = r < a.R ? a.xs_Wdt[(long)g.kd * a.R + r] : 0.f;
+    for (int r = 0; r < SS_RMAX; ++r) wdt[r] = (XS && r < a.R) ? a.xs_Wdt[(long)g.kd * a.R + r] : 0.f;
     bias = a.bias ? a.bias[g.kd] : 0.f;
     Dv = a.D ? a.D[g.kd] : 0.f;
 #pragma unroll
@@ -465,14 +498,16 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
   const int col = lane & 31;
   const int half = lane >> 5;
 
-  f32x4 ru[RL_T / 4], ry[RL_T / 4];
+  f32x4 ru[RL_T / 4], ry[RL_T / 4], rd[XS ? 1 : RL_T / 4];
   RlTiles<RL_T> rt;
   rl_rows_fetch<RL_T>(a, w, a.u, (clb - 1) * RL_T, ru);
   rl_rows_fetch<RL_T>(a, w, a.dy, (clb - 1) * RL_T, ry);
-  rl_tiles_fetch<RL_T, true, true>(a, w, g, (clb - 1) * RL_T, rt);
+  if constexpr (!XS) rl_rows_fetch<RL_T>(a, w, a.delta, (clb - 1) * RL_T, rd);
+  rl_tiles_fetch<XS, RL_T, true, true>(a, w, g, (clb - 1) * RL_T, rt);
   rl_rows_commit<RL_T>(sU, ru, w.rev);
   rl_rows_commit<RL_T>(sY, ry, w.rev);
-  rl_tiles_commit<RL_T, true, true, false>(a, w, g, rt, myB, myC, myDt);
+  if constexpr (!XS) rl_rows_commit<RL_T>(sDl, rd, false);
+  rl_tiles_commit<XS, RL_T, true, true, false>(a, w, g, rt, myB, myC, myDt);
   rl_sync();
   for (int sb = clb - 1; sb >= 0; --sb) {
     const int toff = sb * RL_T;
@@ -480,7 +515,8 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
     if (sb > 0) {
       rl_rows_fetch<RL_T>(a, w, a.u, toff - RL_T, ru);
       rl_rows_fetch<RL_T>(a, w, a.dy, toff - RL_T, ry);
-      rl_tiles_fetch<RL_T, true, true>(a, w, g, toff - RL_T, rt);
+      if constexpr (!XS) rl_rows_fetch<RL_T>(a, w, a.delta, toff - RL_T, rd);
+      rl_tiles_fetch<XS, RL_T, true, true>(a, w, g, toff - RL_T, rt);
     }
     const long blk = tb / RL_T;
     // per-step values as explicit PAIRS of consecutive steps (f32x2 = one 64-bit register pair): the element-wise part of
@@ -492,9 +528,13 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
       const f32x4 uv = *reinterpret_cast<const f32x4*>(sU + lane * RL_BP + 4 * j);
       const f32x4 yv = *reinterpret_cast<const f32x4*>(sY + lane * RL_BP + 4 * j);
       f32x4 dr = {bias, bias, bias, bias};
+      if constexpr (XS) {
 #pragma unroll
-      for (int r = 0; r < SS_RMAX; ++r)
-        if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_T + 4 * j);
+        for (int r = 0; r < SS_RMAX; ++r)
+          if (r < a.R) dr += wdt[r] * *reinterpret_cast<const f32x4*>(myDt + r * RL_T + 4 * j);
+      } else {
+        dr += *reinterpret_cast<const f32x4*>(sDl + lane * RL_BP + 4 * j);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) dr[i] = a.softplus ? softplus_f(dr[i]) : dr[i];
 #pragma unroll
@@ -600,10 +640,15 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<f32x4*>(sY + lane * RL_BP + 4 * j) = f32x4{du2[2 * j][0], du2[2 * j][1], du2[2 * j + 1][0], du2[2 * j + 1][1]};
+    if constexpr (!XS) {   // plain mode: delta is an input of its own, its gradient a row tile like du
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(sDl + lane * RL_BP + 4 * j) = f32x4{dd[4 * j], dd[4 * j + 1], dd[4 * j + 2], dd[4 * j + 3]};
+    }
     // d dt[r][t] = sum_channels Wdt[kd][r] dd_t;  dWdt[kd][r] += sum_t dd_t dt[r][t]
 #pragma unroll
     for (int r = 0; r < SS_RMAX; ++r) {
-      if (r < a.R) {
+      if (XS && r < a.R) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 dv = *reinterpret_cast<const f32x4*>(myDt + r * RL_T + 4 * j);
@@ -614,7 +659,7 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
     }
 #pragma unroll
     for (int r0 = 0; r0 < SS_RMAX; r0 += 2) {
-      if (r0 >= a.R) break;                      // wave-uniform
+      if (!XS || r0 >= a.R) break;               // wave-uniform
 #pragma unroll
       for (int t = 0; t < RL_T; ++t) {
         sT[lane * RL_CP + t] = wdt[r0] * dd[t];
@@ -634,19 +679,22 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
     }
     rl_sync();
     rl_rows_store<RL_T>(a, w, sY, a.du, toff);
-    // the sub-block's dB / dC / d dt tiles (rows of dP)
+    if constexpr (!XS) rl_rows_store<RL_T>(a, w, sDl, a.ddelta, toff);
+    // the sub-block's dB / dC / d dt tiles (rows of dP; plain mode: rows of dB and dC)
     if (g.live) {
-      float* gP = a.xs_dP + w.pk_off;
+      float* gP = XS ? a.xs_dP + w.pk_off : nullptr;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int i = g.lis + p * w.Dl;          // 128 pieces of 4 steps: 32 rows (16 dB, 16 dC) x 4
         if (i < 128) {
           const int rowi = i >> 2, t4 = (i & 3) * 4;
           const f32x4 v = *reinterpret_cast<const f32x4*>(myOut + rowi * RL_T + t4);
-          rl_add4(gP + (long)(a.R + rowi) * a.L, tb + t4, a.L, w.rev, v, atomic_dp != 0);
+          float* orow = XS ? gP + (long)(a.R + rowi) * a.L
+                           : (rowi < SS_N ? a.dB : a.dC) + w.pk_off + (long)(rowi & (SS_N - 1)) * a.L;
+          rl_add4(orow, tb + t4, a.L, w.rev, v, atomic_dp != 0);
         }
       }
-      if (g.lis < a.R * 4) {
+      if (XS && g.lis < a.R * 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(myOutDt + (g.lis >> 2) * RL_T + (g.lis & 3) * 4);
         rl_add4(gP + (long)(g.lis >> 2) * a.L, tb + (g.lis & 3) * 4, a.L, w.rev, v, atomic_dp != 0);
       }
@@ -655,7 +703,8 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
     if (sb > 0) {
       rl_rows_commit<RL_T>(sU, ru, w.rev);
       rl_rows_commit<RL_T>(sY, ry, w.rev);
-      rl_tiles_commit<RL_T, true, true, false>(a, w, g, rt, myB, myC, myDt);
+      if constexpr (!XS) rl_rows_commit<RL_T>(sDl, rd, false);
+      rl_tiles_commit<XS, RL_T, true, true, false>(a, w, g, rt, myB, myC, myDt);
     }
     rl_sync();
   }
@@ -667,7 +716,7 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
     a.S[(g.row * SS_N + 1) * a.nchunks + g.c] = dD_acc;
 #pragma unroll
     for (int r = 0; r < SS_RMAX; ++r)
-      if (r < a.R) a.S[(g.row * SS_N + 2 + r) * a.nchunks + g.c] = dWacc[r];
+      if (XS && r < a.R) a.S[(g.row * SS_N + 2 + r) * a.nchunks + g.c] = dWacc[r];
   }
 }
 

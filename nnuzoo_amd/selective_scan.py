@@ -70,7 +70,7 @@ class SelectiveScanFn(torch.autograd.Function):
         dB, dC = torch.empty_like(B), torch.empty_like(C)
         dD = torch.empty_like(D) if D is not None else None
         dbias = torch.empty_like(delta_bias) if delta_bias is not None else None
-        gstate = torch.empty_like(state)
+        gstate = torch.empty(lib.nnz_selective_scan_grad_state_floats(Bt, KD, L), dtype=torch.float32, device=dev)
         ws = torch.empty(lib.nnz_selective_scan_workspace_floats(Bt, KD, L), dtype=torch.float32, device=dev)
         call("nnz_selective_scan_backward", ptr(u), ptr(delta), ptr(A), ptr(B), ptr(C), ptr(D), ptr(delta_bias),
              ptr(dy), ptr(state), ptr(gstate), ptr(ws), ptr(du), ptr(ddelta), ptr(dA), ptr(dB), ptr(dC), ptr(dD),

@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/nnuzoo_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, set(_lib.SIGNATURES) ^ set(syms)
     assert lib.nnz_version() == 100
-    assert lib.nnz_selective_scan_state_floats(2, 128, 1000) == 2 * 128 * 16 * 4
+    # chunk-entry states for chunks as short as 64 steps + one state per 16-step sub-block (both kernel generations)
+    assert lib.nnz_selective_scan_state_floats(2, 128, 1000) == 2 * 128 * 16 * 16 + 2 * 128 * 63 * 16
+    assert lib.nnz_selective_scan_grad_state_floats(2, 128, 1000) == 2 * 128 * 16 * 16
 
 
 def test_invalid_arguments_are_rejected_without_gpu():

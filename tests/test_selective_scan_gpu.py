@@ -66,6 +66,49 @@ def test_against_oracle(hip_lib, b, K, Dg, L):
         close(a, r, "d" + n, rtol=3e-4)
 
 
+@pytest.mark.parametrize("b,K,Dg,L,clb,opt", [(2, 4, 32, 1024, 0, True), (1, 4, 32, 192, 4, True), (1, 1, 64, 2048, 16, True),
+                                              (2, 6, 64, 256, 4, False), (1, 2, 128, 512, 8, True),
+                                              (1, 1, 192, 1024, 64, False)])
+def test_against_oracle_channels_on_lanes(hip_lib, b, K, Dg, L, clb, opt):
+    """the second-generation kernels (csrc/ss2d_scan_rl.hpp, plain-API instantiation; by default only for >= 2 M row-steps)
+    forced on for small shapes: two chunk slots per wave (Dg = 32, incl. an odd chunk count = idle slot), one slot
+    (Dg = 64), several channel groups adding into one dB / dC tile (Dg = 128, 192), chunk lengths 64..1024 steps, with
+    and without D / delta_bias / softplus - against the float64 oracle"""
+    from nnuzoo_amd._lib import call, load
+    lib = load()
+    g = torch.Generator().manual_seed(L + Dg)
+    KD, N = K * Dg, 16
+    inp = dict(u=torch.randn(b, KD, L, generator=g), delta=torch.randn(b, KD, L, generator=g) * 0.5,
+               A=-torch.exp(torch.randn(KD, N, generator=g) * 0.5), B=torch.randn(b, K, N, L, generator=g),
+               C=torch.randn(b, K, N, L, generator=g), D=torch.randn(KD, generator=g),
+               delta_bias=torch.randn(KD, generator=g) * 0.5 - 1)
+    if not opt:
+        inp["delta"] = inp["delta"].abs() * 0.2 + 0.01
+    names = NAMES if opt else NAMES[:5]
+    ref_in = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    args = lambda d: [d[k] for k in NAMES[:5]] + ([d["D"], None, d["delta_bias"], True] if opt else [None, None, None, False])
+    yr = selective_scan_torch(*[ref_in[k] for k in NAMES[:5]],
+                              *([ref_in["D"], ref_in["delta_bias"], True] if opt else [None, None, False]))
+    dy = torch.randn(yr.shape, generator=g)
+    gr = torch.autograd.grad(yr, [ref_in[k] for k in names], dy)
+    t = {k: v.cuda().requires_grad_(True) for k, v in inp.items()}
+    saved = [lib.nnz_scan_tuning_get(k) for k in range(3)]
+    try:
+        call("nnz_scan_tuning", 0, 1)
+        call("nnz_scan_tuning", 1, clb)
+        call("nnz_scan_tuning", 2, 0)
+        before = lib.nnz_scan_tuning_get(3)
+        y = selective_scan_fn(*args(t))
+        gg = torch.autograd.grad(y, [t[k] for k in names], dy.cuda())
+        assert lib.nnz_scan_tuning_get(3) == before + 2          # forward and backward both took the new kernels
+    finally:
+        for k, v in enumerate(saved):
+            call("nnz_scan_tuning", k, v)
+    close(y.detach(), yr.detach(), "y")
+    for n, a, r in zip(names, gg, gr):
+        close(a, r, "d" + n, rtol=3e-4)
+
+
 def test_full_length_properties(hip_lib):
     """L = 512*512 as in the first SS2D block of M2Net at 512^2 (u: (1, 128, 262144))."""
     g = torch.Generator().manual_seed(0)

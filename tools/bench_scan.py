@@ -34,13 +34,22 @@ for B, KD, L in ([] if "--xs-only" in sys.argv else SHAPES):
     D = torch.randn(KD, device="cuda", requires_grad=True)
     bias = torch.randn(KD, device="cuda", requires_grad=True)
     dy = torch.randn(B, KD, L, device="cuda")
-    with torch.no_grad():
-        tf = t(lambda: selective_scan_fn(u, dl, A, Bm, Cm, D, None, bias, True))
-    y = selective_scan_fn(u, dl, A, Bm, Cm, D, None, bias, True)
-    tb = t(lambda: torch.autograd.grad(y, [u, dl, A, Bm, Cm, D, bias], dy, retain_graph=True))
+    from nnuzoo_amd._lib import call as _call, load as _load
     fb = 4 * (3 * B * KD * L + 2 * B * K * N * L)
     bb = 4 * (5 * B * KD * L + 4 * B * K * N * L)
-    print(f"({B},{KD},{L}): fwd {tf:8.3f} ms {fb/tf/1e6:8.1f} GB/s | bwd {tb:8.3f} ms {bb/tb/1e6:8.1f} GB/s", flush=True)
+    for gen in (0, 1):     # 0: time-on-lanes kernels only; 1: channels-on-lanes kernels where the launcher picks them
+        _call("nnz_scan_tuning", 0, gen)
+        n0 = _load().nnz_scan_tuning_get(3)
+        with torch.no_grad():
+            tf = t(lambda: selective_scan_fn(u, dl, A, Bm, Cm, D, None, bias, True))
+        y = selective_scan_fn(u, dl, A, Bm, Cm, D, None, bias, True)
+        tb = t(lambda: torch.autograd.grad(y, [u, dl, A, Bm, Cm, D, bias], dy, retain_graph=True))
+        took = "channels-on-lanes" if _load().nnz_scan_tuning_get(3) > n0 else "time-on-lanes"
+        print(f"({B},{KD},{L}) gen{gen} [{took}]: fwd {tf:8.3f} ms {fb/tf/1e6:8.1f} GB/s | bwd {tb:8.3f} ms "
+              f"{bb/tb/1e6:8.1f} GB/s", flush=True)
+        if took == "time-on-lanes" and gen == 1:
+            break
+    _call("nnz_scan_tuning", 0, 1)
 
 # ---- cross-scan mode (the fused SS2D core): the C-ABI scan alone on M2Net's (B, Di, H, W) shapes -------------------------
 # algorithmic bytes: fwd reads x2 once per source (2 B D L) and P (2 B 2Cp L), writes y (B 4D L); bwd reads x2, P, dy2,
