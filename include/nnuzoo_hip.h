@@ -125,6 +125,15 @@ int nnz_sgd_nesterov_fused(const void* chunks_device, int nchunks, const float* 
 int nnz_graph_replace_memsets(void* hip_graph, int* n_replaced);
 int nnz_graph_node_census(void* hip_graph, int* counts, int ncounts);
 
+/* ---- depthwise 3x3 weight / bias gradient (csrc/depthwise_wgrad.hip), stride 1, padding = dilation ------------------------
+ * the depthwise nn.Conv2d layers of the 2-D zoo nets (nnunetv2/nets/ssnd2net.py: GSC and the SSND `convnd`;
+ * nets/light_mamba2net.py: get_dwconv_layer), reached through torch's convolution_backward in the reference.
+ * in, dy: [B][C][H][W] contiguous, fp16 (is_f16 = 1) or fp32; dw [C][3][3] and db [C] (or NULL) fp32; workspace:
+ * nnz_dwconv2d_wgrad_workspace_floats floats.  Deterministic (two-stage sum, no atomics). */
+long nnz_dwconv2d_wgrad_workspace_floats(int B, int C, int H, int W);
+int nnz_dwconv2d_wgrad(const void* in, const void* dy, int is_f16, float* workspace, float* dw, float* db, int B, int C,
+                       int H, int W, int dilation, void* stream);
+
 /* ---- ConvTranspose with kernel = stride (UNetDecoder.transpconvs of PlainConvUNet; csrc/conv_transpose.hip) -----------------
  * out[n][s m + p][:Cout] = bias + in[n][m][:Cin] W[:, :, p]  and its data gradient, channels-last fp16 activations with row
  * strides ldi / ldo (elements, multiples of 8: a tensor may be a channel slice of a wider buffer), W = the fp32 parameter in

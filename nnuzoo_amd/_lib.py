@@ -84,6 +84,8 @@ SIGNATURES = {
     "nnz_graph_replace_memsets": [_vp, _ip],
     "nnz_graph_node_census": [_vp, _ip, _i],
     "nnz_convT_supported": [_i] * 6,
+    "nnz_dwconv2d_wgrad_workspace_floats": [_i] * 4,
+    "nnz_dwconv2d_wgrad": [_fp, _fp, _i, _fp, _fp, _fp] + [_i] * 5 + [_vp],
     "nnz_convT_forward": [_fp, _fp, _fp, _fp] + [_i] * 11 + [_vp],
     "nnz_convT_dgrad": [_fp, _fp, _fp] + [_i] * 11 + [_vp],
     "nnz_crop_pad_f32": [_vp, _ip, _ip, _ip, _fp, _i, _i, _i, _i, _i, _f, _vp],
@@ -145,7 +147,7 @@ SIGNATURES = {
 
 _LONG_RESULT = {"nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats", "nnz_ss2d_scan_workspace_floats",
                 "nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats",
-                "nnz_selective_scan_grad_state_floats", "nnz_conv_tap_wgrad_workspace_floats"}
+                "nnz_selective_scan_grad_state_floats", "nnz_dwconv2d_wgrad_workspace_floats", "nnz_conv_tap_wgrad_workspace_floats"}
 _lib = None
 
 

@@ -104,11 +104,36 @@ class _DepthwiseNativeFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         stride, padding, dilation, groups, has_b = ctx.cfg
-        with torch.backends.cudnn.flags(enabled=False):
-            dx, dw, db = torch.ops.aten.convolution_backward(
-                dy.contiguous(), x, w, [w.shape[0]] if has_b else None, list(stride), list(padding), list(dilation), False,
-                [0, 0], groups, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]])
-        return dx, dw, db, None, None, None, None
+        dy = dy.contiguous()
+        need_w, need_b = ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
+        dw = db = None
+        if (need_w or need_b) and _dw_wgrad_ok(x, dy, w, stride, padding, dilation):
+            # weight / bias gradient on csrc/depthwise_wgrad.hip (ATen's kernel gives each (channel, tap) one workgroup
+            # over the whole batch: 110-126 us per call in the SSND2Net / LightMamba2Net steps)
+            from .._lib import call, load, ptr, stream_ptr
+            B, C, H, W = x.shape
+            buf = torch.empty(load().nnz_dwconv2d_wgrad_workspace_floats(B, C, H, W) + C * 10, dtype=torch.float32,
+                              device=x.device)
+            dw32, db32, ws = buf[:C * 9], buf[C * 9:C * 10], buf[C * 10:]
+            call("nnz_dwconv2d_wgrad", ptr(x), ptr(dy), int(x.dtype == torch.float16), ptr(ws), ptr(dw32),
+                 ptr(db32) if need_b else None, B, C, H, W, int(dilation[0]), stream_ptr())
+            dw = dw32.view(w.shape).to(w.dtype) if need_w else None
+            db = db32.to(w.dtype) if need_b else None
+            need_w = need_b = False
+        dx = dw2 = db2 = None
+        if ctx.needs_input_grad[0] or need_w or need_b:
+            with torch.backends.cudnn.flags(enabled=False):
+                dx, dw2, db2 = torch.ops.aten.convolution_backward(
+                    dy, x, w, [w.shape[0]] if has_b else None, list(stride), list(padding), list(dilation), False,
+                    [0, 0], groups, [ctx.needs_input_grad[0], need_w, need_b])
+        return dx, (dw if dw is not None else dw2), (db if db is not None else db2), None, None, None, None
+
+
+def _dw_wgrad_ok(x, dy, w, stride, padding, dilation) -> bool:
+    return (os.environ.get("NNZ_DW_WGRAD", "1") != "0" and x.dim() == 4 and tuple(w.shape[1:]) == (1, 3, 3)
+            and tuple(stride) == (1, 1) and dilation[0] == dilation[1] and tuple(padding) == tuple(dilation)
+            and x.dtype == dy.dtype and x.dtype in (torch.float16, torch.float32) and x.is_contiguous()
+            and dy.shape == x.shape and x.shape[1] <= 65535)
 
 
 class _Conv2d(nn.Conv2d):
