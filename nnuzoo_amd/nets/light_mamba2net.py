@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from ..layer_norm import LayerNorm
+from ..token_linear import TokenLinear
 from ..utilities.network_initialization import InitWeights_He
 from .common2d import Convolution, get_dwconv_layer
 from .mamba2 import Mamba2
@@ -69,7 +70,7 @@ class MambaLayer(nn.Module):
         self.norm = LayerNorm(input_dim)
         self.mamba = Mamba2(d_model=input_dim, d_state=d_state, d_conv=d_conv, expand=expand,
                             headdim=self.get_nheaddim(input_dim, expand))
-        self.proj = nn.Linear(input_dim, output_dim)
+        self.proj = TokenLinear(input_dim, output_dim)
         self.skip_scale = nn.Parameter(torch.ones(1))
 
     def forward(self, x):
@@ -286,7 +287,7 @@ class _LightX2(_UnetrStageX2):
                                                                     norm_layer=LayerNorm, output_dim=half))
                 nxt = dec[j + 1]["in_ch"]
                 setattr(self, f"concat_back_dim{lvl - 1}d",
-                        nn.Identity() if (concat_identity_ok and 2 * half == nxt) else nn.Linear(2 * half, nxt))
+                        nn.Identity() if (concat_identity_ok and 2 * half == nxt) else TokenLinear(2 * half, nxt))
         for i, c in enumerate(side_in):
             setattr(self, f"side{i + 1}", Convolution(sd, c, out_ch, kernel_size=side_kernel,
                                                       padding=(side_kernel - 1) // 2, conv_only=True))

@@ -32,6 +32,7 @@ from torch import nn
 
 from ..mamba_block import causal_conv1d_fn, silu_gate
 from ..selective_scan import selective_scan_fn
+from ..token_linear import TokenLinear
 
 
 class RMSNormGated(nn.Module):
@@ -62,7 +63,7 @@ class Mamba2(nn.Module):
             raise ValueError("d_inner must be a multiple of headdim")
         self.nheads = self.d_ssm // headdim
         # registration and RNG order as mamba_ssm's, so that equal seeds give equal parameters
-        self.in_proj = nn.Linear(d_model, 2 * self.d_inner + 2 * ngroups * d_state + self.nheads, bias=bias)
+        self.in_proj = TokenLinear(d_model, 2 * self.d_inner + 2 * ngroups * d_state + self.nheads, bias=bias)
         conv_dim = self.d_ssm + 2 * ngroups * d_state
         self.conv1d = nn.Conv1d(conv_dim, conv_dim, bias=conv_bias, kernel_size=d_conv, groups=conv_dim, padding=d_conv - 1)
         if conv_init is not None:
@@ -77,7 +78,7 @@ class Mamba2(nn.Module):
         self.D = nn.Parameter(torch.ones(self.nheads))
         self.D._no_weight_decay = True
         self.norm = RMSNormGated(self.d_ssm, eps=1e-5)
-        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
+        self.out_proj = TokenLinear(self.d_inner, d_model, bias=bias)
 
     def _per_channel(self, per_head: torch.Tensor) -> torch.Tensor:
         return per_head.float().repeat_interleave(self.headdim)

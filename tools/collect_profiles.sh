@@ -17,7 +17,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_w -- $BENCH2 > /dev/
 cp $(ls $OUT/prof_f/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_fetch_size.csv
 cp $(ls $OUT/prof_w/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_write_size.csv
 # 3. the zoo steps as they run (hipGraph replay): kernel trace, second half of the run aggregated by kernel
-for M in M2Net SwT2Net; do
+for M in M2Net SwT2Net SSND2Net LightMamba2Net; do
   rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_zoo -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models $M --steps 3 --warmup 3 > /dev/null 2>&1
   python3 $GRAFT_REPO_ROOT/tools/kernel_summary.py $(ls $OUT/prof_zoo/*/*kernel_trace.csv | head -1) 45 0.75 > $OUT/${TAG}_${M,,}_graph_kernels.txt 2>&1
   rm -rf $OUT/prof_zoo
