@@ -117,7 +117,9 @@ class _DepthwiseNativeFn(torch.autograd.Function):
             dw32, db32, ws = buf[:C * 9], buf[C * 9:C * 10], buf[C * 10:]
             call("nnz_dwconv2d_wgrad", ptr(x), ptr(dy), int(x.dtype == torch.float16), ptr(ws), ptr(dw32),
                  ptr(db32) if need_b else None, B, C, H, W, int(dilation[0]), stream_ptr())
-            dw = dw32.view(w.shape).to(w.dtype) if need_w else None
+            if w.shape[-1] == 1:       # 1x1 depthwise (a per-channel scale): the centre tap of the 3x3 sums
+                dw32 = dw32.view(C, 9)[:, 4]
+            dw = dw32.reshape(w.shape).to(w.dtype) if need_w else None
             db = db32.to(w.dtype) if need_b else None
             need_w = need_b = False
         dx = dw2 = db2 = None
@@ -130,8 +132,9 @@ class _DepthwiseNativeFn(torch.autograd.Function):
 
 
 def _dw_wgrad_ok(x, dy, w, stride, padding, dilation) -> bool:
-    return (os.environ.get("NNZ_DW_WGRAD", "1") != "0" and x.dim() == 4 and tuple(w.shape[1:]) == (1, 3, 3)
-            and tuple(stride) == (1, 1) and dilation[0] == dilation[1] and tuple(padding) == tuple(dilation)
+    k3 = tuple(w.shape[1:]) == (1, 3, 3) and dilation[0] == dilation[1] and tuple(padding) == tuple(dilation)
+    k1 = tuple(w.shape[1:]) == (1, 1, 1) and tuple(padding) == (0, 0) and tuple(dilation) == (1, 1)
+    return (os.environ.get("NNZ_DW_WGRAD", "1") != "0" and x.dim() == 4 and (k3 or k1) and tuple(stride) == (1, 1)
             and x.dtype == dy.dtype and x.dtype in (torch.float16, torch.float32) and x.is_contiguous()
             and dy.shape == x.shape and x.shape[1] <= 65535)
 

@@ -228,7 +228,8 @@ def test_fp32_depthwise_conv_native_path_matches_library(hip_lib):
 
 @pytest.mark.parametrize("B,C,H,W,dil,half,bias", [(2, 32, 64, 64, 1, False, True), (1, 16, 33, 47, 2, False, False),
                                                    (2, 64, 16, 16, 1, True, True), (1, 8, 128, 128, 3, True, False),
-                                                   (2, 512, 8, 8, 1, False, True), (1, 4, 300, 20, 1, True, True)])
+                                                   (2, 512, 8, 8, 1, False, True), (1, 4, 300, 20, 1, True, True),
+                                                   (2, 8, 64, 48, 0, False, True)])
 def test_depthwise_wgrad_kernel_matches_float64(hip_lib, B, C, H, W, dil, half, bias):
     """csrc/depthwise_wgrad.hip behind common2d._DepthwiseNativeFn.backward: weight / bias gradient of the depthwise 3x3
     convolution (stride 1, padding = dilation) against float64 autograd on the same (fp16-rounded where applicable)
@@ -238,15 +239,19 @@ def test_depthwise_wgrad_kernel_matches_float64(hip_lib, B, C, H, W, dil, half, 
     torch.manual_seed(C + H)
     dt = torch.float16 if half else torch.float32
     x = torch.randn(B, C, H, W, device="cuda").to(dt).requires_grad_(True)
-    w = (torch.randn(C, 1, 3, 3, device="cuda") * 0.3).to(dt).requires_grad_(True)
+    k = 3 if dil else 1                    # dil = 0 stands for the 1x1 depthwise layer (padding 0)
+    w = (torch.randn(C, 1, k, k, device="cuda") * 0.3).to(dt).requires_grad_(True)
     b = torch.randn(C, device="cuda").to(dt).requires_grad_(True) if bias else None
     dy = torch.randn(B, C, H, W, device="cuda").to(dt)
     prm = [x, w] + ([b] if bias else [])
     lib = load()
-    y = _DepthwiseNativeFn.apply(x, w, b, (1, 1), (dil, dil), (dil, dil), C)
+    y = _DepthwiseNativeFn.apply(x, w, b, (1, 1), (dil, dil), (max(dil, 1), max(dil, 1)), C)
+    from nnuzoo_amd.nets.common2d import _dw_wgrad_ok
+    assert _dw_wgrad_ok(x, dy, w, (1, 1), (dil, dil), (max(dil, 1), max(dil, 1)))      # the HIP kernel is what runs below
     g1 = torch.autograd.grad(y, prm, dy, retain_graph=True)
     g2 = torch.autograd.grad(y, prm, dy)
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double() if bias else None, padding=dil, dilation=dil, groups=C)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double() if bias else None, padding=dil, dilation=max(dil, 1),
+                                     groups=C)
     gr = torch.autograd.grad(ref, prm, dy.double())
     tol = 2e-3 if half else 1e-4            # fp16: the result itself is rounded to fp16 (relative 5e-4)
     for n, a, a2, r in zip(["dx", "dw", "db"], g1, g2, gr):
