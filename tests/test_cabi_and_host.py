@@ -256,3 +256,25 @@ def test_wgrad_chunk_policy():
     assert _wgrad_chunks(200, 256, 256) == 1            # too few tokens to cut
     assert _wgrad_chunks(2450, 3072, 3072) == 1         # 144 macro tiles already fill the chip
     assert _wgrad_chunks(524288, 64, 32) == 128         # the tall case of the VSS blocks (unchanged rule)
+
+
+def test_depthwise_wgrad_routing_and_workspace():
+    """host side of csrc/depthwise_wgrad.hip: which depthwise calls common2d sends to it, and its workspace size function
+    (one 10-float partial per (channel, batch, band); bands only while a band keeps >= 2048 pixels)"""
+    import torch
+    from nnuzoo_amd import _lib
+    from nnuzoo_amd.nets.common2d import _dw_wgrad_ok
+    lib = _lib.load()
+    assert lib.nnz_dwconv2d_wgrad_workspace_floats(2, 512, 16, 16) == 512 * 2 * 10            # plenty of planes: one band each
+    assert lib.nnz_dwconv2d_wgrad_workspace_floats(2, 32, 512, 512) == 32 * 2 * 32 * 10       # 64 planes: 32 bands of 16 rows
+    assert lib.nnz_dwconv2d_wgrad_workspace_floats(1, 1, 8, 8) == 10
+    assert lib.nnz_dwconv2d_wgrad_workspace_floats(0, 4, 8, 8) == 0
+    assert lib.nnz_dwconv2d_wgrad(None, None, 0, None, None, None, 1, 1, 8, 8, 1, None) == -22
+    x, w3, w1, w5 = torch.zeros(1, 4, 8, 8), torch.zeros(4, 1, 3, 3), torch.zeros(4, 1, 1, 1), torch.zeros(4, 1, 5, 5)
+    assert _dw_wgrad_ok(x, x, w3, (1, 1), (1, 1), (1, 1))
+    assert _dw_wgrad_ok(x, x, w3, (1, 1), (2, 2), (2, 2))            # dilated, padding = dilation
+    assert _dw_wgrad_ok(x, x, w1, (1, 1), (0, 0), (1, 1))            # 1x1 depthwise: centre tap
+    assert not _dw_wgrad_ok(x, x, w3, (2, 2), (1, 1), (1, 1))        # strided: ATen
+    assert not _dw_wgrad_ok(x, x, w3, (1, 1), (0, 0), (1, 1))        # 'valid' padding: output smaller than input
+    assert not _dw_wgrad_ok(x, x, w5, (1, 1), (2, 2), (1, 1))        # other kernel sizes
+    assert not _dw_wgrad_ok(x.double(), x.double(), w3.double(), (1, 1), (1, 1), (1, 1))
