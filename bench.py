@@ -14,7 +14,13 @@ forward+loss+backward replayed as one hipGraph (the trainer's default; optimizer
 dominant kernel family (the cross-scan backward, HBM-bound by SURVEY.md 8d) timed over eager steps.
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; weak scaling: 2 patches per GPU.)
+N > 1, weak scaling (2 patches per GPU), one process per GPU over RCCL.  Either an outer launcher started the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: WORLD_SIZE == N in the environment) or -
+typed as above - this process starts them itself: BEFORE anything touches the GPU it runs that very launcher as a child
+process, relays rank 0's JSON line and exits with the children's status (the reference starts its ranks with mp.spawn,
+/root/reference/nnunetv2/run/run_training.py:218-232; a process that has initialised HIP is never re-exec'ed).
+NNZ_BENCH_DRYRUN=1 (CPU, gloo, kernel launches stubbed by tests/dryrun.py) exercises launch + process group + the
+gradient reducer on the real backward schedule without a GPU; its line says "dryrun": true and carries no throughput.
 Prints ONE JSON line on rank 0 carrying `roofline` (dominant kernel conv_box_kernel, MFMA-bound; algorithmic FLOPs /
 HIP-event time of its launches inside the timed region), `cpu_baseline` (the CPU oracle, warmed, timed on this host's
 cores on a bounded sample), `secondary` and `dice` (protocol results of record).
@@ -189,6 +195,72 @@ def run_secondary(steps: int, warmup: int):
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILD processes through
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port), pass their output through and return their status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for ln in p.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return p.wait()
+
+
+def dryrun(a, world: int, rank: int) -> None:
+    """Plumbing check without a GPU (tests/test_bench_launch.py): the real forward / backward SCHEDULE of the 3d_fullres
+    network with every kernel launch replaced by a host stand-in (tests/dryrun.py), under a gloo process group - the same
+    launcher, environment handling, trainer set-up (batch split, parameter broadcast, reducer attachment), bucketed
+    in-place all-reduce of the gradient arena and JSON line as the GPU run.  Measures nothing."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dryrun import stub_kernel_launches
+    from nnuzoo_amd.synthetic import nnunet_plans
+    from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+    if os.environ.get("NNZ_BENCH_DRYRUN_FAIL") == "1" and rank == world - 1:
+        raise SystemExit(3)                    # test hook: a failing rank must become the parent's exit status
+    if world > 1:
+        dist.init_process_group("gloo")
+    plans, cfg, dataset_json = nnunet_plans(3, (128,) * 3, batch_size=2 * world)
+    torch.manual_seed(1234 + rank)             # different per rank: attach_bucketed_allreduce must broadcast rank 0's
+    tr = nnUNetTrainer(plans, cfg, 0, dataset_json, device=torch.device("cpu"))
+    tr.initialize()
+    assert tr.batch_size == 2
+    net = tr.network
+    x = torch.zeros(tr.batch_size, 1, 32, 32, 32)
+    for _ in range(a.warmup + a.steps):
+        with stub_kernel_launches(float(rank + 1)):
+            outs, rec = net._run_forward(x, save=True)
+            gouts = [torch.zeros_like(o) for o in outs]
+            gouts[-1] = None                   # the deep-supervision output of weight 0
+            net._run_backward(rec, gouts)
+    arena, red = net.grad_arena(), net.grad_reducer
+    mean = sum(r + 1 for r in range(world)) / world
+    ok = bool(((arena == mean) | (arena == 0)).all())   # every reduced gradient is the mean over ranks
+    if world > 1:
+        t = torch.tensor([float(ok)])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training patches/sec, 3D nnUNet (PlainConvUNet 3d_fullres) 1x128^3 patches",
+                          "dryrun": True, "value": None, "unit": "patches/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "scaling": "weak", "rccl_ranks": dist.get_world_size() if world > 1 else 0,
+                          "backend": "gloo", "allreduce_buckets_per_step": getattr(red, "buckets_last_step", None),
+                          "arena_floats": int(arena.numel()), "gradients_are_rank_mean": ok,
+                          "config": {"global_batch": 2 * world, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,10 +277,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} "
-                         f"(WORLD_SIZE={world})")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))          # nothing has touched the GPU yet
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     backend = os.environ.get("NNZ_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+    if os.environ.get("NNZ_BENCH_DRYRUN") == "1":
+        return dryrun(a, world, rank)
+    # NNZ_BENCH_SHARE_GPU=1: several ranks on one device (gloo only - RCCL refuses duplicate devices); used by the
+    # 1-GPU box test that runs the real two-rank step
+    share = os.environ.get("NNZ_BENCH_SHARE_GPU") == "1"
+    local_rank = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(local_rank)
     force_ddp = os.environ.get("NNZ_BENCH_FORCE_DDP") == "1"  # exercise the RCCL reducer path even at world size 1
     if world > 1 or force_ddp:
@@ -216,7 +295,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from nnuzoo_amd import hip_ops
     from nnuzoo_amd.synthetic import conv_flops_forward, nnunet_plans, synthetic_batch

@@ -56,6 +56,7 @@ class GraphedForwardBackward:
         self.static_loss = None
         self.memset_nodes_replaced = 0
         self._key = None
+        self._static_grads = []        # [(parameter, the .grad tensor the captured backward writes)]
 
     def _fwd_bwd(self, data, target):
         if self.autocast:
@@ -90,6 +91,10 @@ class GraphedForwardBackward:
         with torch.no_grad():
             for b, saved in buffers:
                 b.copy_(saved)
+        # the captured backward WRITES (p.grad was None at capture: assignment, not accumulation) into these tensors on
+        # every replay; whatever happens to p.grad between replays (optimizer.zero_grad(set_to_none=True), an eager step
+        # in between, user hooks), __call__ re-attaches them so that clip / optimizer never see None or a stale buffer
+        self._static_grads = [(p, p.grad) for p in params if p.grad is not None]
         self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
 
     def __call__(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
@@ -101,4 +106,7 @@ class GraphedForwardBackward:
         for s, t in zip(self.static_target, target):
             s.copy_(t, non_blocking=True)
         self.graph.replay()
+        for p, g in self._static_grads:
+            if p.grad is not g:
+                p.grad = g
         return self.static_loss

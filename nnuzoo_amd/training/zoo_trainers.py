@@ -8,6 +8,7 @@ GradScaler (nnUNetTrainerSwT2Net.py:112-130).  The M2Net plugins inherit the aut
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import numpy as np
@@ -42,6 +43,16 @@ def _legacy_or_live(factory, args, kwargs):
 class _X2Trainer(nnUNetTrainer):
     _factory = None
     _fp32_step = False
+    # True for the nets whose small-channel fp32 conv blocks fault inside MIOpen's immediate-mode backward on this stack
+    # (see nnUNetTrainerMambaND2Net): their steps run with the library path disabled for the DURATION of the step only
+    # (`torch.backends.cudnn.flags`), never as a process-wide switch - other networks, predictors and tests in the same
+    # process keep MIOpen.
+    _no_miopen = False
+
+    def _library_scope(self):
+        if self._no_miopen and self.device.type == 'cuda':
+            return torch.backends.cudnn.flags(enabled=False)
+        return contextlib.nullcontext()
 
     def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
                  device: torch.device = torch.device('cuda'), num_epochs: int = 250):
@@ -96,6 +107,14 @@ class _X2Trainer(nnUNetTrainer):
         self.network.deep_supervision = enabled
 
     def train_step(self, batch: dict) -> dict:
+        with self._library_scope():
+            return self._train_step(batch)
+
+    def validation_step(self, batch: dict) -> dict:
+        with self._library_scope():
+            return super().validation_step(batch)
+
+    def _train_step(self, batch: dict) -> dict:
         data = batch['data'].to(self.device, non_blocking=True)
         target = [i.to(self.device, non_blocking=True) for i in batch['target']] \
             if isinstance(batch['target'], list) else batch['target'].to(self.device, non_blocking=True)
@@ -182,15 +201,12 @@ class nnUNetTrainerMambaND2Net(_X2Trainer):
     """reference: training/nnUNetTrainer/nnUNetTrainerMambaND2Net.py:15-131 (N-D; fp32 step without autocast / GradScaler
     :111-131; AdamW 1e-4 / wd 5e-2, cosine; the 7-entry deep-supervision scale list per axis)"""
     _fp32_step = True
-
-    def initialize(self):
-        # The UNETR-style blocks of this net are fp32 convolutions with 4..128 channels (1x1, 3x3, k = s transposed).
-        # On this stack (ROCm 7.2 MIOpen through PyTorch's immediate mode) their backward faults with an out-of-bounds
-        # access inside the full network (each block alone passes; MIOpen logs "workspace required ... provided ..." for
-        # the solver it then runs anyway) - tools/probes/mambaND_stage_probe.py.  ATen's native convolution path is
-        # exact and, at these channel counts, not slower, so the library path is switched off for this trainer's process.
-        torch.backends.cudnn.enabled = False
-        super().initialize()
+    # The UNETR-style blocks of this net are fp32 convolutions with 4..128 channels (1x1, 3x3, k = s transposed).
+    # On this stack (ROCm 7.2 MIOpen through PyTorch's immediate mode) their backward faults with an out-of-bounds
+    # access inside the full network (each block alone passes; MIOpen logs "workspace required ... provided ..." for
+    # the solver it then runs anyway) - tools/probes/mambaND_stage_probe.py.  ATen's native convolution path is
+    # exact and, at these channel counts, not slower, so the library path is off INSIDE this trainer's steps.
+    _no_miopen = True
 
     @staticmethod
     def build_network_architecture(*args, **kwargs):
@@ -215,9 +231,7 @@ class nnUNetTrainerUNETR2Net(_X2Trainer):
                  device: torch.device = torch.device('cuda'), num_epochs: int = 1000):
         super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
 
-    def initialize(self):
-        torch.backends.cudnn.enabled = False   # same small-channel UNETR conv blocks as MambaND2Net (see there)
-        super().initialize()
+    _no_miopen = True                          # same small-channel UNETR conv blocks as MambaND2Net (see there)
 
     @staticmethod
     def build_network_architecture(*args, **kwargs):
@@ -236,10 +250,7 @@ class nnUNetTrainerLightMamba2Net(_X2Trainer):
         super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
         self.early_stop_epoch = 350
 
-    def initialize(self):
-        # fp32 convolutions with 16..256 channels, depthwise 3x3 and 1x1: ATen's native path (see MambaND2Net above)
-        torch.backends.cudnn.enabled = False
-        super().initialize()
+    _no_miopen = True   # fp32 convolutions with 16..256 channels, depthwise 3x3 and 1x1 (see MambaND2Net above)
 
     def _get_deep_supervision_scales(self):
         if not self.enable_deep_supervision:

@@ -123,3 +123,52 @@ def test_memset_nodes_are_rewritten_and_replay_after_allocations(hip_lib):
         assert float(z.abs().max()) == 0.0 and int(zb.max()) == 0
         assert torch.allclose(out, ref_out, rtol=1e-5, atol=1e-3) and torch.allclose(tot, ref_tot, rtol=1e-5, atol=1e-2)
         _junk()
+
+
+def test_graph_and_eager_steps_alternate(hip_lib):
+    """the captured backward writes into the .grad tensors that existed at capture time.  An eager step in
+    between (optimizer.zero_grad(set_to_none=True) + fresh gradients) must not leave later replays writing into orphaned
+    buffers: after every graph step p.grad IS the static tensor and holds this step's gradient, and training moves."""
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerM2NetP
+    plans, cfg, dj = nnunet_plans(2, (64, 64), batch_size=2)
+    torch.manual_seed(0)
+    tr = nnUNetTrainerM2NetP(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    assert tr.use_hip_graph
+    b = synthetic_batch(2, (64, 64), tr._get_deep_supervision_scales(), seed=5)
+    b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+    losses = [float(tr.train_step(b)["loss"]) for _ in range(2)]             # graph (captures on the first call)
+    static = dict((id(p), g) for p, g in tr._graphed._static_grads)
+    assert len(static) > 100
+    for rnd in range(3):
+        tr.use_hip_graph = False
+        losses.append(float(tr.train_step(b)["loss"]))                       # eager: zero_grad(set_to_none) + new grads
+        moved = [p for p in tr.network.parameters() if p.grad is not None and p.grad is not static.get(id(p))]
+        assert len(moved) > 100                                              # the eager step really swapped the tensors
+        tr.use_hip_graph = True
+        tr.optimizer.zero_grad(set_to_none=True)                             # and a user-side zero_grad on top
+        for p, g in tr._graphed._static_grads:
+            g.fill_(float("nan"))                                            # a replay that did not write would show
+        before = [p.detach().clone() for p in tr.network.parameters()]
+        losses.append(float(tr.train_step(b)["loss"]))
+        for p in tr.network.parameters():
+            if id(p) in static:
+                assert p.grad is static[id(p)] and bool(torch.isfinite(p.grad).all())
+        changed = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, tr.network.parameters()))
+        assert changed > 100                                                 # the optimizer saw the replayed gradients
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
+    assert torch.backends.cudnn.enabled                                      # no trainer leaves the library switched off
+
+
+def test_no_miopen_scope_is_restored(hip_lib):
+    """MambaND2Net / UNETR2Net / LightMamba2Net disable the MIOpen path INSIDE their steps only"""
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerMambaND2Net, nnUNetTrainerM2Net
+    from nnuzoo_amd.synthetic import nnunet_plans
+    plans, cfg, dj = nnunet_plans(2, (64, 64), batch_size=2)
+    tr = nnUNetTrainerMambaND2Net(plans, cfg, 0, dj, device=torch.device("cuda"))
+    assert tr._no_miopen and not nnUNetTrainerM2Net._no_miopen
+    assert torch.backends.cudnn.enabled
+    with tr._library_scope():
+        assert not torch.backends.cudnn.enabled
+    assert torch.backends.cudnn.enabled
