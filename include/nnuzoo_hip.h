@@ -101,6 +101,38 @@ int nnz_instnorm_lrelu_bwd_apply(const void* x_f16, const void* g_f16, const flo
                                  float* dgamma /* [C] = sum_n red[n][c][1], may be NULL */,
                                  float* dbeta /* [C] = sum_n red[n][c][0], NULL iff dgamma is */, void* stream);
 
+/* Deterministic variants (round 3).  fp32 atomicAdd makes the statistics depend on the order the workgroups finish in;
+ * these entry points fold their partials in a fixed order per workgroup, add them across workgroups as FIXED-POINT 64-bit
+ * integers (integer adds commute: bit-identical results run to run) and let the launch's last workgroup write the float
+ * tables - no zero-fill launches, no sumsq/V - mean^2 cancellation in fp32 (moments are taken about a pilot value and
+ * re-centred in double).  `acc`: N * C * 2 records of nnz_fxacc_bytes() bytes; `counter`: one 32-bit word; both zero
+ * before their first use and left zero by every launch.
+ *   nstat[N][C][4] = {mean, rstd, rstd * gamma, beta - mean * rstd * gamma}     (InstanceNorm table of a conv output)
+ *   nred [N][C][2] = {mean of g', mean of g' * xhat},  g' = g * lrelu'(y)        (backward reduction) */
+int nnz_fxacc_bytes(void);
+int nnz_conv_tap_forward_norm(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
+                              const nnz_conv_desc* desc, void* acc, void* counter, const float* gamma,
+                              const float* beta, float eps, float* nstat, void* stream);
+int nnz_stem_conv_wgrad_det(const float* x, const void* dy_f16, float* dw, int N, int D, int H, int W, int Cout, int lddy,
+                            void* acc /* >= 864 records */, void* counter, void* stream);
+int nnz_seg_head_wgrad_det(const void* x_f16, const void* dlogits_f16, float* dw, float* db, int N, long V, int C, int K,
+                           int ldx, void* acc /* >= 8 * (C + 1) records */, void* counter, void* stream);
+int nnz_dc_ce_loss_forward_det(const void* logits, int logits_is_f16, const int16_t* target, float* sums /* written */,
+                               int B, int C, long V, int ignore_label, void* acc /* B * (3C + 1) records */,
+                               void* counter, void* stream);
+int nnz_grad_sumsq_nonfinite_det(const float* grads, long n, float* out2 /* written */, void* acc /* 2 records */,
+                                 void* counter, void* stream);
+int nnz_instnorm_stats_det(const void* x_f16, int N, long V, int C, int ldx, void* acc, void* counter,
+                           const float* gamma /* NULL iff nstat is */, const float* beta, float eps,
+                           float* nstat /* may be NULL */, float* sums /* [N][C][2] {sum, sumsq}, may be NULL */,
+                           void* stream);
+int nnz_instnorm_lrelu_apply_tab(const void* x_f16, const float* nstat, void* y_f16, int N, long V, int C, int ldx,
+                                 int ldy, float slope, void* stream);
+int nnz_instnorm_lrelu_bwd_tab(const void* x_f16, const void* g_f16, const float* nstat, void* acc, void* counter,
+                               float* nred, void* dx_f16, int N, long V, int C, int ldx, int ldg, int lddx, float slope,
+                               float* dgamma /* [C], may be NULL */, float* dbeta /* NULL iff dgamma is */,
+                               void* stream);
+
 /* ---- fused optimizer tail of train_step (nnUNetTrainer.py:1131-1139: grad_scaler.unscale_ -> clip_grad_norm_(12) ->
  * SGD(momentum, nesterov, weight decay) step, skipped when a gradient is not finite) over a flat fp32 gradient arena.
  * nnz_grad_sumsq_nonfinite adds {sum of squares, count of non-finite elements} of grads[0..n) to out2 (caller zeroes).

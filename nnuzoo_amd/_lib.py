@@ -81,6 +81,15 @@ SIGNATURES = {
     "nnz_instnorm_lrelu_apply": [_vp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _f, _f, _vp],
     "nnz_instnorm_lrelu_bwd_reduce": [_vp, _vp, _fp, _fp, _fp, _fp, _i, _l, _i, _i, _i, _f, _f, _i, _vp],
     "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _fp, _fp, _vp],
+    "nnz_fxacc_bytes": [],
+    "nnz_conv_tap_forward_norm": [_vp, _vp, _vp, _fp, _dp, _vp, _vp, _fp, _fp, _f, _fp, _vp],
+    "nnz_stem_conv_wgrad_det": [_fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "nnz_seg_head_wgrad_det": [_vp, _vp, _fp, _fp, _i, _l, _i, _i, _i, _vp, _vp, _vp],
+    "nnz_dc_ce_loss_forward_det": [_vp, _i, _vp, _fp, _i, _i, _l, _i, _vp, _vp, _vp],
+    "nnz_grad_sumsq_nonfinite_det": [_fp, _l, _fp, _vp, _vp, _vp],
+    "nnz_instnorm_stats_det": [_vp, _i, _l, _i, _i, _vp, _vp, _fp, _fp, _f, _fp, _fp, _vp],
+    "nnz_instnorm_lrelu_apply_tab": [_vp, _fp, _vp, _i, _l, _i, _i, _i, _f, _vp],
+    "nnz_instnorm_lrelu_bwd_tab": [_vp, _vp, _fp, _vp, _vp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _fp, _fp, _vp],
     "nnz_graph_replace_memsets": [_vp, _ip],
     "nnz_graph_node_census": [_vp, _ip, _i],
     "nnz_convT_supported": [_i] * 6,

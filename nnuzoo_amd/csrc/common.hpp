@@ -87,6 +87,56 @@ __device__ __forceinline__ T* pin_uniform(T* ptr) {
   return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
+// ---- deterministic cross-workgroup sums ------------------------------------------------------------------------------
+// fp32 atomicAdd makes a sum depend on the order the workgroups happen to finish in: two runs of the same step differ in
+// the last bits, and LeakyReLU / softmax amplify that into visibly different gradients.  Integer addition commutes, so a
+// sum kept as a FIXED-POINT integer is bit-identical however the adds interleave.  A partial (a double a workgroup has
+// formed in a fixed order) is split into a coarse word in units of 2^-10 and a fine word in units of 2^-58: range
+// |total| < 2^53, resolution 3.5e-18 absolute, up to 65 536 partials per accumulator before the fine word could wrap -
+// i.e. double precision for every magnitude an fp16 tensor's moments or a loss-scaled gradient sum can take.  Non-finite
+// partials are counted in a third word and make the total NaN (GradScaler's inf check must still see them).
+struct FxAcc {
+  long long w[4];  // coarse (2^-10), fine (2^-58), non-finite partials, unused (32-byte records)
+};
+__device__ __forceinline__ void fx_add(FxAcc* a, double v) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(a->w);
+  if (!(fabs(v) < 0x1p52)) {  // inf, NaN or beyond the range: poison the accumulator
+    atomicAdd(w + 2, 1ull);
+    return;
+  }
+  const double h = rint(v * 1024.0);
+  const double rem = v - h * (1.0 / 1024.0);  // exact: |rem| <= 2^-11
+  atomicAdd(w + 0, (unsigned long long)(long long)h);
+  atomicAdd(w + 1, (unsigned long long)(long long)rint(rem * 0x1p58));
+}
+// read AND reset (the workgroup that finalises leaves the accumulator ready for the next launch: no zero-fill kernels)
+__device__ __forceinline__ double fx_take(FxAcc* a) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(a->w);
+  const long long hi = (long long)atomicExch(w + 0, 0ull);
+  const long long lo = (long long)atomicExch(w + 1, 0ull);
+  const unsigned long long bad = atomicExch(w + 2, 0ull);
+  const double v = (double)hi * (1.0 / 1024.0) + (double)lo * 0x1p-58;
+  return bad ? __builtin_nan("") : v;
+}
+// "Was this the last workgroup of the launch to get here?"  Every thread of every workgroup calls it after its fx_add
+// calls (uniformly: it contains barriers).  The fence orders this workgroup's atomics before its ticket; the workgroup
+// that draws the last ticket therefore sees every other workgroup's contributions (it reads them with L2 atomics), and
+// re-arms the counter.  `counter` is a zero-initialised word owned by this launch sequence.
+__device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned nwg) {
+  __shared__ unsigned s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(counter, 1u);
+    s_last = (t == nwg - 1u);
+    if (t == nwg - 1u) atomicExch(counter, 0u);
+  }
+  __syncthreads();
+  const bool last = s_last != 0;
+  if (last) __threadfence();
+  return last;
+}
+
 // Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used anywhere in this library: captured into a hipGraph it
 // becomes a fill node whose pattern staging the runtime releases after capture - replays after later allocations then
 // fill with whatever landed there (measured on ROCm 7.2 / MI355X, tools/probes/graph_memset_repro.py: NaNs in dbeta).

@@ -42,6 +42,14 @@ struct ConvDev {
   const f16* w;
   const float* bias;
   float* stats;  // optional [N][Cout][2] {sum, sumsq} of the fp16 outputs (InstanceNorm statistics), pre-zeroed
+  // deterministic statistics (nnz_conv_tap_forward_norm): fixed-point accumulators [N][Cout][2] {sum, sumsq}, zero
+  // between launches; the last workgroup turns them into nstat[N][Cout][4] = {mean, rstd, rstd*gamma, beta - mean*rstd*gamma}
+  FxAcc* acc;
+  float* nstat;
+  unsigned* counter;
+  const float* gamma;
+  const float* beta;
+  float eps;
   nnz_conv_desc d;
   int tiles[3];
   int gx, gy, gz;
@@ -453,6 +461,57 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       for (int q = 0; q < PARTS; ++q) t += slab[q * (2 * NC) + tid];
       atomicAdd(p.stats + ((size_t)n * Cout + cb0 * 32) * 2 + tid, t);
     }
+  } else if (p.acc) {
+    // Deterministic and cancellation-free variant: moments about a PILOT value per channel (the tile's first voxel), folded
+    // in a fixed order inside the workgroup, re-centred in double and added to the sample's fixed-point accumulators (integer
+    // adds commute: the result does not depend on which workgroup finishes first).  sum x^2 is exact to ~1e-16 relative, so
+    // var = E[x^2] - mean^2 formed in double by the finalising workgroup stays good for |mean| / std up to ~1e4.
+    constexpr int NC = NB * 32, NVOX = TD * TH * TW;
+    constexpr int PARTS = 256 / PPV;
+    float* slab = reinterpret_cast<float*>(smem + NVOX * ROWB);
+    const int part = tid / PPV, c8 = tid % PPV;
+    float K[8], s1[8], s2[8];
+    {
+      const f16x8 k0 = *reinterpret_cast<const f16x8*>(smem + c8 * 16);  // voxel (0, 0, 0) of the tile: always valid
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        K[e] = (float)k0[e];
+        s1[e] = s2[e] = 0.f;
+      }
+    }
+    for (int v = part; v < NVOX; v += PARTS) {
+      const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+      if (m0d + td < p.d.m_dims[0] && m0h + th < p.d.m_dims[1] && m0w + tw < p.d.m_dims[2]) {
+        const f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + c8 * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (float)val[e] - K[e];
+          s1[e] += x;
+          s2[e] += x * x;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      slab[part * (2 * NC) + (c8 * 8 + e) * 2 + 0] = s1[e];
+      slab[part * (2 * NC) + (c8 * 8 + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    if (tid < NC) {
+      float S1 = 0.f, S2 = 0.f;
+      for (int q = 0; q < PARTS; ++q) {
+        S1 += slab[q * (2 * NC) + tid * 2 + 0];
+        S2 += slab[q * (2 * NC) + tid * 2 + 1];
+      }
+      const int cd = p.d.m_dims[0] - m0d < TD ? p.d.m_dims[0] - m0d : TD;
+      const int ch = p.d.m_dims[1] - m0h < TH ? p.d.m_dims[1] - m0h : TH;
+      const int cw = p.d.m_dims[2] - m0w < TW ? p.d.m_dims[2] - m0w : TW;
+      const double cnt = (double)(cd * ch * cw);
+      const double k = (double)(float)*reinterpret_cast<const f16*>(smem + tid * 2);
+      FxAcc* a = p.acc + ((size_t)n * Cout + cb0 * 32 + tid) * 2;
+      fx_add(a, (double)S1 + cnt * k);
+      fx_add(a + 1, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
+    }
   }
 #pragma unroll 2
   for (int c = tid; c < NPIECE; c += 256) {
@@ -475,6 +534,23 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
     }
     *reinterpret_cast<f16x8*>(dst) = val;
   }
+  if (p.acc) {
+    if (last_workgroup(p.counter, nwg)) {
+      const double V = (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
+      for (int i = tid; i < p.d.N * Cout; i += 256) {
+        FxAcc* a = p.acc + (size_t)i * 2;
+        const double sx = fx_take(a), sq = fx_take(a + 1);
+        const double mean = sx / V;
+        double var = sq / V - mean * mean;
+        var = var < 0.0 ? 0.0 : var;  // (NaN stays NaN)
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const int c = i % Cout;
+        const float sc = rstd * p.gamma[c];
+        const f32x4 o = {(float)mean, rstd, sc, p.beta[c] - (float)mean * sc};
+        *reinterpret_cast<f32x4*>(p.nstat + (size_t)i * 4) = o;
+      }
+    }
+  }
 }
 
 template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false>
@@ -488,7 +564,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   for (int g = 0; g < p.d.ngroups; ++g) maxnt = p.d.groups[g].ntaps > maxnt ? p.d.groups[g].ntaps : maxnt;
   const int wbytes = NB * maxnt * 1024;
   int lds = bg.BOX_BYTES + wbytes > C::OUT_BYTES ? bg.BOX_BYTES + wbytes : C::OUT_BYTES;
-  if (p.stats) {  // statistics slab [256 / (4 NB)][2 * 32 NB] floats behind the output image
+  if (p.stats || p.acc) {  // statistics slab [256 / (4 NB)][2 * 32 NB] floats behind the output image
     const int need = C::OUT_BYTES + (256 / (NB * 4)) * (2 * NB * 32) * 4;
     lds = lds > need ? lds : need;
   }
@@ -609,6 +685,9 @@ static int launch_dyn(const ConvDev& p, hipStream_t stream) {
 
 extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void* w_packed, const float* bias,
                                           const nnz_conv_desc* desc, float* stats, void* stream);
+static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
+                                 const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
+                                 const float* gamma, const float* beta, float eps, float* nstat, void* stream);
 
 extern "C" int nnz_conv_tuning(int knob, int value) {
   if (knob < 0 || knob >= 8) return NNZ_EINVAL;
@@ -623,11 +702,30 @@ extern "C" int nnz_conv_tap_forward(const void* in, void* out, const void* w_pac
 
 extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void* w_packed, const float* bias,
                                           const nnz_conv_desc* desc, float* stats, void* stream) {
+  return conv_tap_forward_impl(in, out, w_packed, bias, desc, stats, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, stream);
+}
+
+// Forward convolution whose epilogue also produces the InstanceNorm table of its own output - deterministic (fixed-point
+// accumulators, see common.hpp) and free of the sumsq/V - mean^2 cancellation in fp32: nstat[N][Cout][4] = {mean, rstd,
+// rstd * gamma, beta - mean * rstd * gamma}, written by the launch's last workgroup.  `acc`: N * Cout * 2 records of
+// nnz_fxacc_bytes() bytes, `counter`: one 32-bit word; both zero before the first launch and left zero by every launch.
+extern "C" int nnz_conv_tap_forward_norm(const void* in, void* out, const void* w_packed, const float* bias,
+                                         const nnz_conv_desc* desc, void* acc, void* counter, const float* gamma,
+                                         const float* beta, float eps, float* nstat, void* stream) {
+  if (!acc || !counter || !gamma || !beta || !nstat) return NNZ_EINVAL;
+  return conv_tap_forward_impl(in, out, w_packed, bias, desc, nullptr, acc, (unsigned*)counter, gamma, beta, eps, nstat, stream);
+}
+
+extern "C" int nnz_fxacc_bytes(void) { return (int)sizeof(nnz::FxAcc); }
+
+static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
+                                 const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
+                                 const float* gamma, const float* beta, float eps, float* nstat, void* stream) {
   using namespace nnz;
   if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
   // fused statistics: plain forward convolutions only (one group, output written once, unit output stride)
-  if (stats && (d.ngroups != 1 || d.accumulate || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1))
+  if ((stats || acc) && (d.ngroups != 1 || d.accumulate || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1))
     return NNZ_EINVAL;
   if (d.Cin % 32 || d.Cout % 32 || d.ngroups < 1 || d.ngroups > NNZ_MAX_GROUPS || d.ntaps_total > NNZ_MAX_TAPS ||
       d.ldi % 8 || d.ldo % 8)
@@ -658,6 +756,12 @@ extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void*
     p.w = (const f16*)w_packed;
     p.bias = bias;
     p.stats = stats ? stats + (size_t)n0 * d.Cout * 2 : nullptr;
+    p.acc = acc ? (FxAcc*)acc + (size_t)n0 * d.Cout * 2 : nullptr;
+    p.nstat = nstat ? nstat + (size_t)n0 * d.Cout * 4 : nullptr;
+    p.counter = counter;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.eps = eps;
     p.d = d;
     p.d.N = d.N - n0 < chunk ? d.N - n0 : chunk;
     int rc;

@@ -23,6 +23,8 @@ struct StemArgs {
   float* dw;        // [32][27] fp32  (wgrad, zeroed by launcher)
   int N, D, H, W, ldy, lddy;
   int tiles[3];
+  FxAcc* acc;        // deterministic weight gradient: 27 * 32 fixed-point accumulators (common.hpp) + launch counter
+  unsigned* counter;
 };
 
 // Stem forward on MFMA (a VALU version issued 864 v_fma + 216 broadcast LDS reads per voxel and ran 4x off the HBM
@@ -209,8 +211,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
     const int tt = i / 32, c = i % 32;
     const float s = red[(0 * 32 + tt) * 32 + c] + red[(1 * 32 + tt) * 32 + c] + red[(2 * 32 + tt) * 32 + c] +
                     red[(3 * 32 + tt) * 32 + c];
-    atomicAdd(a.dw + c * 27 + tt, s);
+    if (a.acc)
+      fx_add(a.acc + c * 27 + tt, (double)s);
+    else
+      atomicAdd(a.dw + c * 27 + tt, s);
   }
+  if (a.acc && last_workgroup(a.counter, gridDim.x))
+    for (int i = tid; i < 27 * 32; i += 256) a.dw[i] = (float)fx_take(a.acc + i);
 }
 
 // ------------------------------------------------------------------------------------------------ head
@@ -229,6 +236,8 @@ struct HeadArgs {
   int N, C, K, ldx, lddx;
   long V;
   int Ktot, k0;      // weight-gradient launches cover classes k0 .. k0 + K - 1 of Ktot
+  FxAcc* acc;        // deterministic weight gradient: K * C + K fixed-point accumulators (common.hpp) + launch counter
+  unsigned* counter;
 };
 
 template <int MAXK>
@@ -448,11 +457,21 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
   for (int i = tid; i < KC; i += 256) {
     float t = 0.f;
     for (int rr = 0; rr < rows; ++rr) t += lred[rr * KC + i];
-    if (i < K * a.C)
+    if (a.acc)
+      fx_add(a.acc + i, (double)t);
+    else if (i < K * a.C)
       atomicAdd(a.dw + (long)a.k0 * a.C + i, t);
     else
       atomicAdd(a.db + a.k0 + (i - K * a.C), t);
   }
+  if (a.acc && last_workgroup(a.counter, gridDim.x * gridDim.y))
+    for (int i = tid; i < KC; i += 256) {
+      const float t = (float)fx_take(a.acc + i);
+      if (i < K * a.C)
+        a.dw[(long)a.k0 * a.C + i] = t;
+      else
+        a.db[a.k0 + (i - K * a.C)] = t;
+    }
 }
 
 }  // namespace nnz
@@ -473,19 +492,31 @@ extern "C" int nnz_stem_conv_forward(const float* x, const float* w, const float
   return NNZ_OK;
 }
 
+extern "C" int nnz_stem_conv_wgrad_det(const float* x, const void* dy, float* dw, int N, int D, int H, int W, int Cout,
+                                       int lddy, void* acc, void* counter, void* stream);
 extern "C" int nnz_stem_conv_wgrad(const float* x, const void* dy, float* dw, int N, int D, int H, int W, int Cout,
                                    int lddy, void* stream) {
+  return nnz_stem_conv_wgrad_det(x, dy, dw, N, D, H, W, Cout, lddy, nullptr, nullptr, stream);
+}
+
+// acc / counter (both or neither): >= 864 zeroed fixed-point records (nnz_fxacc_bytes() each) + one zeroed 32-bit word,
+// left zero; with them the gradient is bit-identical run to run (no float atomics) and dw needs no zero fill
+extern "C" int nnz_stem_conv_wgrad_det(const float* x, const void* dy, float* dw, int N, int D, int H, int W, int Cout,
+                                       int lddy, void* acc, void* counter, void* stream) {
   using namespace nnz;
-  if (!x || !dy || !dw || Cout != ST_CO || lddy % 8) return NNZ_EINVAL;
+  if (!x || !dy || !dw || Cout != ST_CO || lddy % 8 || (!acc != !counter)) return NNZ_EINVAL;
   StemArgs a = {};
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.x = x; a.dy = (const f16*)dy; a.dw = dw;
   a.N = N; a.D = D; a.H = H; a.W = W; a.lddy = lddy;
   a.tiles[0] = (D + ST_TD - 1) / ST_TD;
   a.tiles[1] = (H + ST_TH - 1) / ST_TH;
   a.tiles[2] = (W + ST_TW - 1) / ST_TW;
   const int ntiles = N * a.tiles[0] * a.tiles[1] * a.tiles[2];
-  hipError_t e = nnz::zero_async(dw, sizeof(float) * ST_CO * 27, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
+  if (!acc) {
+    hipError_t e = nnz::zero_async(dw, sizeof(float) * ST_CO * 27, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
   const int grid = ntiles < 512 ? ntiles : 512;  // persistent: 2 workgroups per CU, one atomic per element each
   NNZ_LAUNCH(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ntiles);
   NNZ_LAUNCH_CHECK();
@@ -575,18 +606,31 @@ extern "C" int nnz_seg_head_dgrad(const void* dlogits, const float* w, void* dx,
   return NNZ_OK;
 }
 
+extern "C" int nnz_seg_head_wgrad_det(const void* x, const void* dlogits, float* dw, float* db, int N, long V, int C,
+                                      int K, int ldx, void* acc, void* counter, void* stream);
 extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw, float* db, int N, long V, int C, int K,
                                   int ldx, void* stream) {
+  return nnz_seg_head_wgrad_det(x, dlogits, dw, db, N, V, C, K, ldx, nullptr, nullptr, stream);
+}
+
+// acc / counter (both or neither): >= 8 * (C + 1) zeroed fixed-point records + one zeroed 32-bit word, left zero; with
+// them dw / db are bit-identical run to run (no float atomics) and need no zero fill
+extern "C" int nnz_seg_head_wgrad_det(const void* x, const void* dlogits, float* dw, float* db, int N, long V, int C,
+                                      int K, int ldx, void* acc, void* counter, void* stream) {
   using namespace nnz;
-  if (!x || !dlogits || !dw || !db || K < 1 || K > HD_MAXK || C % 8 || C > 640 || ldx % 8) return NNZ_EINVAL;
+  if (!x || !dlogits || !dw || !db || K < 1 || K > HD_MAXK || C % 8 || C > 640 || ldx % 8 || (!acc != !counter))
+    return NNZ_EINVAL;
   HeadArgs a = {};
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.x = (const f16*)x; a.dl = (const f16*)dlogits; a.dw = dw; a.db = db;
   a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = nnz::zero_async(dw, sizeof(float) * K * C, s);
-  if (e != hipSuccess) return (int)e;
-  e = nnz::zero_async(db, sizeof(float) * K, s);
-  if (e != hipSuccess) return (int)e;
+  if (!acc) {
+    hipError_t e = nnz::zero_async(dw, sizeof(float) * K * C, s);
+    if (e != hipSuccess) return (int)e;
+    e = nnz::zero_async(db, sizeof(float) * K, s);
+    if (e != hipSuccess) return (int)e;
+  }
   long vpb = (V * N + 1023) / 1024;
   if (vpb < 256) vpb = 256;
   if (vpb > V) vpb = V;

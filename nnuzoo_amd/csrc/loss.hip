@@ -26,6 +26,8 @@ struct LossArgs {
   long V;
   int vpb;
   int ignore;           // label value excluded from every sum and gradient (DC_and_CE_loss ignore_label), or -32768
+  FxAcc* acc;           // optional [B][3C+1] fixed-point accumulators + launch counter (common.hpp): deterministic sums
+  unsigned* counter;
 };
 
 template <typename T, int LS_MAXC>
@@ -55,6 +57,7 @@ __device__ __forceinline__ void softmax_at(const LossArgs<T>& a, long base, long
 template <typename T, int LS_MAXC>
 __global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
   __shared__ float lred[3 * LS_MAXC + 1];
+  __shared__ float lwave[4][3 * LS_MAXC + 1];  // deterministic mode: one slot per wave, folded in wave order
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   if (tid < 3 * LS_MAXC + 1) lred[tid] = 0.f;
@@ -87,15 +90,34 @@ __global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
     if (c < a.C) {
       const float x0 = wave_sum(inter[c]), x1 = wave_sum(sp[c]), x2 = wave_sum(sg[c]);
       if ((tid & 63) == 0) {
-        atomicAdd(&lred[c], x0);
-        atomicAdd(&lred[a.C + c], x1);
-        atomicAdd(&lred[2 * a.C + c], x2);
+        if (a.acc) {
+          lwave[tid >> 6][c] = x0;
+          lwave[tid >> 6][a.C + c] = x1;
+          lwave[tid >> 6][2 * a.C + c] = x2;
+        } else {
+          atomicAdd(&lred[c], x0);
+          atomicAdd(&lred[a.C + c], x1);
+          atomicAdd(&lred[2 * a.C + c], x2);
+        }
       }
     }
   const float xc = wave_sum(ce);
-  if ((tid & 63) == 0) atomicAdd(&lred[3 * a.C], xc);
+  if ((tid & 63) == 0) {
+    if (a.acc)
+      lwave[tid >> 6][3 * a.C] = xc;
+    else
+      atomicAdd(&lred[3 * a.C], xc);
+  }
   __syncthreads();
-  if (tid < 3 * a.C + 1) atomicAdd(a.sums + (long)b * (3 * a.C + 1) + tid, lred[tid]);
+  const int S = 3 * a.C + 1;
+  if (a.acc) {
+    if (tid < S)
+      fx_add(a.acc + (long)b * S + tid, (double)((lwave[0][tid] + lwave[1][tid]) + (lwave[2][tid] + lwave[3][tid])));
+    if (last_workgroup(a.counter, gridDim.x * gridDim.y))
+      for (int i = tid; i < a.B * S; i += 256) a.sums[i] = (float)fx_take(a.acc + i);
+    return;
+  }
+  if (tid < S) atomicAdd(a.sums + (long)b * S + tid, lred[tid]);
 }
 
 template <typename T, int LS_MAXC>
@@ -151,8 +173,10 @@ static int launch_loss(LossArgs<T> a, bool bwd, hipStream_t s) {
   a.vpb = (int)vpb;
   const int gx = (int)((a.V + vpb - 1) / vpb);
   if (!bwd) {
-    hipError_t e = nnz::zero_async(a.sums, sizeof(float) * a.B * (3 * a.C + 1), s);
-    if (e != hipSuccess) return (int)e;
+    if (!a.acc) {
+      hipError_t e = nnz::zero_async(a.sums, sizeof(float) * a.B * (3 * a.C + 1), s);
+      if (e != hipSuccess) return (int)e;
+    }
     if (big)
       NNZ_LAUNCH((dc_ce_fwd_kernel<T, LS_MAXC_BIG>), dim3(gx, a.B), dim3(256), 0, s, a);
     else
@@ -530,16 +554,29 @@ extern "C" int nnz_argmax_tp_fp_fn(const void* logits, int logits_is_f16, const 
   return NNZ_OK;
 }
 
+extern "C" int nnz_dc_ce_loss_forward_det(const void* logits, int logits_is_f16, const int16_t* target, float* sums,
+                                          int B, int C, long V, int ignore_label, void* acc, void* counter,
+                                          void* stream);
 extern "C" int nnz_dc_ce_loss_forward(const void* logits, int logits_is_f16, const int16_t* target, float* sums, int B,
                                       int C, long V, int ignore_label, void* stream) {
+  return nnz_dc_ce_loss_forward_det(logits, logits_is_f16, target, sums, B, C, V, ignore_label, nullptr, nullptr, stream);
+}
+
+// acc / counter (both or neither): B * (3C + 1) zeroed fixed-point records (nnz_fxacc_bytes() each) + one zeroed 32-bit
+// word, left zero by the launch: the sums are then bit-identical run to run (no float atomics, common.hpp)
+extern "C" int nnz_dc_ce_loss_forward_det(const void* logits, int logits_is_f16, const int16_t* target, float* sums,
+                                          int B, int C, long V, int ignore_label, void* acc, void* counter,
+                                          void* stream) {
   using namespace nnz;
-  if (!logits || !target || !sums) return NNZ_EINVAL;
+  if (!logits || !target || !sums || (!acc != !counter)) return NNZ_EINVAL;
   if (logits_is_f16) {
     LossArgs<f16> a = {};
+    a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
     a.logits = (const f16*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
     return launch_loss(a, false, (hipStream_t)stream);
   }
   LossArgs<float> a = {};
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.logits = (const float*)logits; a.tgt = target; a.sums = sums; a.B = B; a.C = C; a.V = V; a.ignore = ignore_label;
   return launch_loss(a, false, (hipStream_t)stream);
 }

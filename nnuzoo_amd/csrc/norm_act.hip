@@ -27,6 +27,15 @@ struct NormArgs {
   long V;
   int vpb;           // voxels per block
   float eps, slope;
+  // deterministic variants (fixed-point accumulators, common.hpp): `nstat` [N][C][4] = {mean, rstd, rstd*gamma, beta -
+  // mean*rstd*gamma} replaces stats + gamma + beta as the INPUT of modes 1-3 and is the OUTPUT of mode 0; `nred` [N][C][2]
+  // = {mean g', mean g' xhat} is the output of mode 2 (with dgamma / dbeta) and the input of mode 3; `sums` [N][C][2] =
+  // {sum, sumsq} is an alternative mode-0 output (plain moments, e.g. a bias gradient)
+  FxAcc* acc;        // [N][C][2], zero between launches
+  unsigned* counter;
+  float* nstat;
+  float* nred;
+  float* sums;
 };
 
 __device__ __forceinline__ void load8(const f16* p, float (&v)[8]) {
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
   if (v1 > a.V) v1 = a.V;
   const bool active = r < rows;
 
-  if (MODE == 3 && a.dgamma && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (MODE == 3 && a.dgamma && !a.nred && blockIdx.x == 0 && blockIdx.y == 0) {
     // parameter gradients of the affine: one workgroup folds the per-sample reductions (saves a torch reduction and
     // two copies per conv block)
     for (int c = tid; c < a.C; c += 256) {
@@ -77,7 +86,21 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
   }
 
   float scale[8], shift[8], mean[8], rstd[8], m1[8], m2[8];
-  if (MODE != 0 && active) {
+  if (MODE != 0 && active && a.nstat) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cg * 8 + i;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(a.nstat + ((long)n * a.C + c) * 4);
+      mean[i] = t[0];
+      rstd[i] = t[1];
+      scale[i] = t[2];
+      shift[i] = t[3];
+      if (MODE == 3) {
+        m1[i] = a.nred[((long)n * a.C + c) * 2 + 0];
+        m2[i] = a.nred[((long)n * a.C + c) * 2 + 1];
+      }
+    }
+  } else if (MODE != 0 && active) {
     const float invV = 1.f / (float)a.V;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -98,9 +121,16 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
     }
   }
 
-  float acc0[8], acc1[8];
+  float acc0[8], acc1[8], pilot[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc0[i] = acc1[i] = 0.f;
+  for (int i = 0; i < 8; ++i) acc0[i] = acc1[i] = pilot[i] = 0.f;
+  if (MODE == 0 && a.acc && active) {
+    // moments about a pilot value (the block's first voxel) instead of about 0: no cancellation when |mean| >> std
+    float t[8];
+    load8(a.x + ((long)n * a.V + v0) * a.ldx + cg * 8, t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pilot[i] = t[i];
+  }
 
   if (active) {
     const long base = (long)n * a.V;
@@ -121,7 +151,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
         if (MODE == 0) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float x = (float)xh[k][i];
+            const float x = (float)xh[k][i] - pilot[i];
             acc0[i] += x;
             acc1[i] += x * x;
           }
@@ -161,6 +191,67 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
       }
     }
     __syncthreads();
+    if (a.acc) {
+      // deterministic: fixed-order fold inside the workgroup, fixed-point adds across workgroups, the last workgroup of
+      // the launch turns the totals into the float tables
+      for (int c = tid; c < a.C; c += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int rr = 0; rr < rows; ++rr) {
+          s0 += lred[rr * C2 + c * 2 + 0];
+          s1 += lred[rr * C2 + c * 2 + 1];
+        }
+        FxAcc* acc = a.acc + ((long)n * a.C + c) * 2;
+        if (MODE == 0) {
+          const double cnt = (double)(v1 - v0);
+          const double k = (double)(float)a.x[((long)n * a.V + v0) * a.ldx + c];
+          fx_add(acc, (double)s0 + cnt * k);
+          fx_add(acc + 1, (double)s1 + 2.0 * k * (double)s0 + cnt * k * k);
+        } else {
+          fx_add(acc, (double)s0);
+          fx_add(acc + 1, (double)s1);
+        }
+      }
+      if (last_workgroup(a.counter, gridDim.x * gridDim.y)) {
+        const double V = (double)a.V;
+        if (MODE == 0) {
+          for (int i = tid; i < a.N * a.C; i += 256) {
+            const double sx = fx_take(a.acc + (long)i * 2), sq = fx_take(a.acc + (long)i * 2 + 1);
+            if (a.sums) {
+              a.sums[(long)i * 2 + 0] = (float)sx;
+              a.sums[(long)i * 2 + 1] = (float)sq;
+            }
+            if (a.nstat) {
+              const double mean = sx / V;
+              double var = sq / V - mean * mean;
+              var = var < 0.0 ? 0.0 : var;
+              const float rs = (float)(1.0 / sqrt(var + (double)a.eps));
+              const int c = i % a.C;
+              const float sc = rs * a.gamma[c];
+              const f32x4 o = {(float)mean, rs, sc, a.beta[c] - (float)mean * sc};
+              *reinterpret_cast<f32x4*>(a.nstat + (long)i * 4) = o;
+            }
+          }
+        } else {
+          // per sample the two means the apply pass needs; over the batch (fixed order) the affine's gradients
+          for (int c = tid; c < a.C; c += 256) {
+            double sg = 0.0, sb = 0.0;
+            for (int nn = 0; nn < a.N; ++nn) {
+              const long i = (long)nn * a.C + c;
+              const double r0 = fx_take(a.acc + i * 2), r1 = fx_take(a.acc + i * 2 + 1);
+              a.nred[i * 2 + 0] = (float)(r0 / V);
+              a.nred[i * 2 + 1] = (float)(r1 / V);
+              sb += r0;
+              sg += r1;
+            }
+            if (a.dgamma) {
+              a.dgamma[c] = (float)sg;
+              a.dbeta[c] = (float)sb;
+            }
+          }
+        }
+      }
+      return;
+    }
     float* dst = (MODE == 0 ? a.stats : a.red) + (long)n * C2;
     for (int i = tid; i < C2; i += 256) {
       float s = 0.f;
@@ -187,7 +278,7 @@ static int launch_norm(NormArgs a, hipStream_t s, bool pre_zeroed = false) {
   const int gx = (int)((a.V + vpb - 1) / vpb);
   const int rows = 256 / (a.C >> 3);
   const size_t lds = (MODE == 0 || MODE == 2) ? sizeof(float) * rows * 2 * a.C : 0;
-  if ((MODE == 0 || MODE == 2) && !pre_zeroed) {
+  if ((MODE == 0 || MODE == 2) && !pre_zeroed && !a.acc) {
     hipError_t e = nnz::zero_async(MODE == 0 ? a.stats : a.red, sizeof(float) * 2 * a.N * a.C, s);
     if (e != hipSuccess) return (int)e;
   }
@@ -260,5 +351,58 @@ extern "C" int nnz_instnorm_lrelu_bwd_apply(const void* x, const void* g, const 
   a.dgamma = dgamma; a.dbeta = dbeta;
   a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldg = ldg; a.ldy = lddx;
   a.eps = eps; a.slope = slope;
+  return launch_norm<3>(a, (hipStream_t)stream);
+}
+
+
+// ---- deterministic entry points (fixed-point accumulators; see common.hpp and NormArgs) ----------------------------------
+// `acc`: N * C * 2 records of nnz_fxacc_bytes() bytes, `counter`: one 32-bit word; zero before the first launch, left zero.
+
+// statistics of x: nstat[N][C][4] (needs gamma, beta, eps) and / or plain moments sums[N][C][2] = {sum, sumsq}
+extern "C" int nnz_instnorm_stats_det(const void* x, int N, long V, int C, int ldx, void* acc, void* counter,
+                                      const float* gamma, const float* beta, float eps, float* nstat, float* sums,
+                                      void* stream) {
+  using namespace nnz;
+  if (!x || !acc || !counter || (!nstat && !sums) || (nstat && (!gamma || !beta))) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx;
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
+  a.gamma = gamma; a.beta = beta; a.eps = eps; a.nstat = nstat; a.sums = sums;
+  return launch_norm<0>(a, (hipStream_t)stream, true);
+}
+
+// y = lrelu(x * nstat.scale + nstat.shift)
+extern "C" int nnz_instnorm_lrelu_apply_tab(const void* x, const float* nstat, void* y, int N, long V, int C, int ldx,
+                                            int ldy, float slope, void* stream) {
+  using namespace nnz;
+  if (!x || !nstat || !y) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x;
+  a.nstat = const_cast<float*>(nstat);
+  a.y = (f16*)y;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldy = ldy;
+  a.slope = slope;
+  return launch_norm<1>(a, (hipStream_t)stream);
+}
+
+// backward of InstanceNorm(affine) + LeakyReLU in two launches: the reduction (nred, dgamma, dbeta) and the apply pass
+extern "C" int nnz_instnorm_lrelu_bwd_tab(const void* x, const void* g, const float* nstat, void* acc, void* counter,
+                                          float* nred, void* dx, int N, long V, int C, int ldx, int ldg, int lddx,
+                                          float slope, float* dgamma, float* dbeta, void* stream) {
+  using namespace nnz;
+  if (!x || !g || !nstat || !acc || !counter || !nred || !dx || (!dgamma != !dbeta)) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x; a.g = (const f16*)g;
+  a.nstat = const_cast<float*>(nstat);
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
+  a.nred = nred;
+  a.y = (f16*)dx;
+  a.dgamma = dgamma; a.dbeta = dbeta;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldg = ldg; a.ldy = lddx;
+  a.slope = slope;
+  const int rc = launch_norm<2>(a, (hipStream_t)stream, true);
+  if (rc != NNZ_OK) return rc;
+  a.acc = nullptr;
   return launch_norm<3>(a, (hipStream_t)stream);
 }

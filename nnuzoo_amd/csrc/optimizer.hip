@@ -20,7 +20,8 @@ struct SgdChunk {
   int pad;
 };
 
-__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out2) {
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out2,
+                                                         FxAcc* acc, unsigned* counter) {
   __shared__ float red[4][2];
   float s = 0.f, bad = 0.f;
   const long n4 = n >> 2;
@@ -47,6 +48,20 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
     red[wave][1] = bad;
   }
   __syncthreads();
+  if (acc) {
+    // deterministic: fixed-point sum across workgroups (common.hpp), the last one writes the two floats.  A non-finite
+    // gradient makes the block's partial non-finite, which poisons the accumulator: the total reads back NaN and the
+    // count of bad entries below stays the inf-skip flag.
+    if (threadIdx.x == 0) {
+      fx_add(acc, (double)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])));
+      fx_add(acc + 1, (double)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
+    }
+    if (last_workgroup(counter, gridDim.x) && threadIdx.x == 0) {
+      out2[0] = (float)fx_take(acc);
+      out2[1] = (float)fx_take(acc + 1);
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     atomicAdd(out2 + 0, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
     const float b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
@@ -104,7 +119,23 @@ extern "C" int nnz_grad_sumsq_nonfinite(const float* grads, long n, float* out2_
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  NNZ_LAUNCH(grad_sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grads, n, out2_zeroed);
+  NNZ_LAUNCH(grad_sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grads, n, out2_zeroed,
+             (FxAcc*)nullptr, (unsigned*)nullptr);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// deterministic variant: `acc` = 2 zeroed fixed-point records (nnz_fxacc_bytes() each), `counter` = one zeroed 32-bit word,
+// both left zero; out2 = {sum of squares, number of non-finite entries} is WRITTEN (needs no zero fill)
+extern "C" int nnz_grad_sumsq_nonfinite_det(const float* grads, long n, float* out2, void* acc, void* counter,
+                                            void* stream) {
+  using namespace nnz;
+  if (!grads || !out2 || !acc || !counter || n < 1 || ((size_t)grads & 15)) return NNZ_EINVAL;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  NNZ_LAUNCH(grad_sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grads, n, out2, (FxAcc*)acc,
+             (unsigned*)counter);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -95,6 +95,48 @@ def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor,
                             C.byref(pt.desc), ptr(stats), stream_ptr()))
 
 
+class NormScratch:
+    """Per-device scratch of the deterministic statistics (csrc/common.hpp FxAcc): fixed-point accumulators for the
+    widest (N, C) in use and the launch counter.  Zero-initialised ONCE; every launch leaves them zero again, so the same
+    scratch serves all conv blocks of a network one after the other (stream order)."""
+
+    def __init__(self, device, n_times_c: int):
+        nb = int(_lib.load().nnz_fxacc_bytes())
+        n_times_c = max(int(n_times_c), 2816)   # also the stem (864) and seg-head (8 * 641) weight-gradient sums
+        self.acc = torch.zeros(n_times_c * 2 * nb // 8, dtype=torch.int64, device=device)
+        self.counter = torch.zeros(2, dtype=torch.int32, device=device)
+        self.capacity = n_times_c
+        self.records = 2 * n_times_c
+
+
+_SCRATCH = {}
+
+
+def det_scratch(device, records: int = 0) -> NormScratch:
+    """the device's shared scratch of the deterministic reductions (loss sums, gradient norm, ...): launches on one stream
+    use it one after the other and each leaves it zeroed; grows on demand"""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    sc = _SCRATCH.get(key)
+    if sc is None or sc.capacity * 2 < records:
+        sc = NormScratch(device, max((records + 1) // 2, 4096))
+        _SCRATCH[key] = sc
+    return sc
+
+
+def conv_tap_forward_norm(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                          out: torch.Tensor, scratch: NormScratch, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                          nstat: torch.Tensor) -> None:
+    """forward convolution + the InstanceNorm table of its output: nstat [N, Cout, 4] = {mean, rstd, scale, shift}
+    (deterministic fixed-point statistics, written by the launch's last workgroup)"""
+    _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
+    _f32(gamma, "conv.gamma"); _f32(beta, "conv.beta"); _f32(nstat, "conv.nstat")
+    assert pt.table.N * pt.table.Cout <= scratch.capacity
+    TIMER.wrap("conv_box_kernel", pt.flops,
+               lambda: call("nnz_conv_tap_forward_norm", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
+                            ptr(scratch.acc), ptr(scratch.counter), ptr(gamma), ptr(beta), float(eps), ptr(nstat),
+                            stream_ptr()))
+
+
 def convT_supported(cin: int, cout: int, stride, dgrad: bool) -> bool:
     return bool(_lib.load().nnz_convT_supported(cin, cout, int(stride[0]), int(stride[1]), int(stride[2]), int(dgrad)))
 
@@ -180,10 +222,16 @@ def stem_forward(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], y:
     call("nnz_stem_conv_forward", ptr(x), ptr(w), ptr(b), ptr(y), N, D, H, W, w.shape[0], ldy, stream_ptr())
 
 
-def stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dims, lddy: int):
+def stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dims, lddy: int, scratch: "NormScratch" = None):
+    """scratch: deterministic (fixed-point) cross-workgroup sum instead of float atomics"""
     _f32(x, "stem.x"); _f16(dy, "stem.dy"); _f32(dw, "stem.dw")
     N, D, H, W = dims
-    call("nnz_stem_conv_wgrad", ptr(x), ptr(dy), ptr(dw), N, D, H, W, dw.shape[0], lddy, stream_ptr())
+    if scratch is None:
+        call("nnz_stem_conv_wgrad", ptr(x), ptr(dy), ptr(dw), N, D, H, W, dw.shape[0], lddy, stream_ptr())
+    else:
+        assert scratch.capacity * 2 >= 864
+        call("nnz_stem_conv_wgrad_det", ptr(x), ptr(dy), ptr(dw), N, D, H, W, dw.shape[0], lddy, ptr(scratch.acc),
+             ptr(scratch.counter), stream_ptr())
 
 
 def head_forward(x, w, b, logits, N, V, Cc, K, ldx):
@@ -196,9 +244,14 @@ def head_dgrad(dlogits, w, dx, N, V, Cc, K, lddx, accumulate):
     call("nnz_seg_head_dgrad", ptr(dlogits), ptr(w), ptr(dx), N, V, Cc, K, lddx, int(accumulate), stream_ptr())
 
 
-def head_wgrad(x, dlogits, dw, db, N, V, Cc, K, ldx):
+def head_wgrad(x, dlogits, dw, db, N, V, Cc, K, ldx, scratch: "NormScratch" = None):
     _f16(x, "head.x"); _f16(dlogits, "head.dlogits"); _f32(dw, "head.dw"); _f32(db, "head.db")
-    call("nnz_seg_head_wgrad", ptr(x), ptr(dlogits), ptr(dw), ptr(db), N, V, Cc, K, ldx, stream_ptr())
+    if scratch is None:
+        call("nnz_seg_head_wgrad", ptr(x), ptr(dlogits), ptr(dw), ptr(db), N, V, Cc, K, ldx, stream_ptr())
+    else:
+        assert scratch.capacity * 2 >= 8 * (Cc + 1)
+        call("nnz_seg_head_wgrad_det", ptr(x), ptr(dlogits), ptr(dw), ptr(db), N, V, Cc, K, ldx, ptr(scratch.acc),
+             ptr(scratch.counter), stream_ptr())
 
 
 def instnorm_stats(x, stats, N, V, Cc, ldx, pre_zeroed: bool = False):
@@ -222,6 +275,29 @@ def instnorm_lrelu_bwd(x, g, stats, gamma, beta, red, dx, N, V, Cc, ldx, ldg, ld
          Cc, ldx, ldg, lddx, eps, slope, ptr(dgamma), ptr(dbeta), stream_ptr())
 
 
+def instnorm_stats_det(x, N, V, Cc, ldx, scratch: NormScratch, gamma=None, beta=None, eps: float = 0.0, nstat=None,
+                       sums=None):
+    """deterministic statistics pass: nstat [N, C, 4] (needs gamma, beta, eps) and / or sums [N, C, 2] = {sum, sumsq}"""
+    _f16(x, "in.x"); _f32(nstat, "in.nstat"); _f32(sums, "in.sums"); _f32(gamma, "in.gamma"); _f32(beta, "in.beta")
+    assert N * Cc <= scratch.capacity
+    call("nnz_instnorm_stats_det", ptr(x), N, V, Cc, ldx, ptr(scratch.acc), ptr(scratch.counter), ptr(gamma), ptr(beta),
+         float(eps), ptr(nstat), ptr(sums), stream_ptr())
+
+
+def instnorm_lrelu_apply_tab(x, nstat, y, N, V, Cc, ldx, ldy, slope):
+    _f16(x, "in.x"); _f16(y, "in.y"); _f32(nstat, "in.nstat")
+    call("nnz_instnorm_lrelu_apply_tab", ptr(x), ptr(nstat), ptr(y), N, V, Cc, ldx, ldy, float(slope), stream_ptr())
+
+
+def instnorm_lrelu_bwd_tab(x, g, nstat, scratch: NormScratch, nred, dx, N, V, Cc, ldx, ldg, lddx, slope, dgamma=None,
+                           dbeta=None):
+    _f16(x, "in.x"); _f16(g, "in.g"); _f16(dx, "in.dx"); _f32(nstat, "in.nstat"); _f32(nred, "in.nred")
+    _f32(dgamma, "in.dgamma"); _f32(dbeta, "in.dbeta")
+    assert N * Cc <= scratch.capacity
+    call("nnz_instnorm_lrelu_bwd_tab", ptr(x), ptr(g), ptr(nstat), ptr(scratch.acc), ptr(scratch.counter), ptr(nred),
+         ptr(dx), N, V, Cc, ldx, ldg, lddx, float(slope), ptr(dgamma), ptr(dbeta), stream_ptr())
+
+
 def _logits_kind(t: torch.Tensor) -> int:
     if not t.is_cuda or t.dtype not in (torch.float16, torch.float32):
         raise _lib.HipCallError(f"loss: logits must be fp16/fp32 device tensors, got {t.dtype} on {t.device}")
@@ -232,11 +308,13 @@ NO_IGNORE = -32768
 
 
 def dc_ce_forward(logits, target_i16, sums, B, Cc, V, ignore_label: int = NO_IGNORE):
+    """sums are formed deterministically (fixed-point cross-workgroup adds, csrc/common.hpp): bit-identical run to run"""
     if target_i16.dtype != torch.int16 or not target_i16.is_cuda:
         raise _lib.HipCallError("loss: target must be an int16 device tensor")
     _f32(sums, "loss.sums")
-    call("nnz_dc_ce_loss_forward", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(sums), B, Cc, V,
-         int(ignore_label), stream_ptr())
+    sc = det_scratch(logits.device, B * (3 * Cc + 1))
+    call("nnz_dc_ce_loss_forward_det", ptr(logits), _logits_kind(logits), ptr(target_i16), ptr(sums), B, Cc, V,
+         int(ignore_label), ptr(sc.acc), ptr(sc.counter), stream_ptr())
 
 
 def dc_ce_backward(logits, target_i16, coef, dlogits, B, Cc, V, ignore_label: int = NO_IGNORE):

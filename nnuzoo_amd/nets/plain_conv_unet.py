@@ -250,8 +250,10 @@ class _Plan:
         so = 0
         for b in self.all_blocks:
             b.prepare()
-            b.stats_off, so = so, so + N * b.cout * 2          # slice of the per-step statistics buffer
+            b.stats_off, so = so, so + N * b.cout * 4          # slice of the per-step InstanceNorm tables (nstat)
         self.stats_floats = so
+        self.norm_scratch = None                                  # fixed-point accumulators + counter (first use)
+        self.norm_capacity = N * max([b.cout for b in self.all_blocks] + [u.cout for u in self.ups])
         # partial-block workspace of the two-stage weight gradients (shared by all layers: they run one after another)
         self.wgrad_ws_floats = max([ops.conv_tap_wgrad_workspace_floats(b.wgrad) for b in self.all_blocks if not b.stem]
                                    + [ops.conv_tap_wgrad_workspace_floats(u.wgrad) for u in self.ups])
@@ -420,16 +422,18 @@ class PlainConvUNet(nn.Module):
     def _conv_block_fwd(self, b: _Block, x_act: torch.Tensor, act_out: torch.Tensor, dev, stats_all):
         h = b.h
         raw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
-        stats = stats_all[b.stats_off:b.stats_off + b.N * b.cout * 2].view(b.N, b.cout, 2)  # zeroed once per step
+        # the block's InstanceNorm table {mean, rstd, scale, shift} per (sample, channel): written by the last workgroup
+        # of the launch that produces the statistics (deterministic fixed-point sums, csrc/common.hpp)
+        stats = stats_all[b.stats_off:b.stats_off + b.N * b.cout * 4].view(b.N, b.cout, 4)
+        scratch = self._scratch
         if b.stem:
             ops.stem_forward(x_act, h.conv.weight, h.conv.bias, raw, (b.N, *b.in_dims), b.cout)
-            ops.instnorm_stats(raw, stats, b.N, b.V, b.cout, b.cout, pre_zeroed=True)
+            ops.instnorm_stats_det(raw, b.N, b.V, b.cout, b.cout, scratch, h.norm.weight, h.norm.bias, b.eps, nstat=stats)
         else:
             # the convolution's epilogue accumulates the InstanceNorm statistics of the tile it just produced
-            ops.conv_tap_forward(b.fwd, self._padded_input(b, x_act) if b.padded else x_act, b.wp_fwd, h.conv.bias,
-                                 raw, stats=stats)
-        ops.instnorm_lrelu_apply(raw, stats, h.norm.weight, h.norm.bias, act_out, b.N, b.V, b.cout, b.cout, b.y_ld,
-                                 b.eps, b.slope)
+            ops.conv_tap_forward_norm(b.fwd, self._padded_input(b, x_act) if b.padded else x_act, b.wp_fwd, h.conv.bias,
+                                      raw, scratch, h.norm.weight, h.norm.bias, b.eps, stats)
+        ops.instnorm_lrelu_apply_tab(raw, stats, act_out, b.N, b.V, b.cout, b.cout, b.y_ld, b.slope)
         return raw, stats
 
     @staticmethod
@@ -455,7 +459,10 @@ class PlainConvUNet(nn.Module):
         if b0.padded:
             b0.w_pad[:, :b0.cin_w].copy_(b0.h.conv.weight.detach().reshape(b0.cout, b0.cin_w, *b0.ks))
         plan.pack_fwd.run()
-        stats_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
+        if plan.norm_scratch is None:
+            plan.norm_scratch = ops.NormScratch(dev, plan.norm_capacity)
+        self._scratch = plan.norm_scratch
+        stats_all = torch.empty(plan.stats_floats, dtype=torch.float32, device=dev)
         cats = [torch.empty((N, int(np.prod(plan.level_dims[s])), 2 * feats[s]), dtype=f16, device=dev)
                 for s in range(S - 1)]
         rec = {"x": x, "plan": plan, "cats": cats, "enc": [], "dec": [], "heads": []}
@@ -507,17 +514,17 @@ class PlainConvUNet(nn.Module):
         block input into dx_out (None for the stem) and the parameter gradients into `grads`."""
         x_in, raw, stats, _ = recd
         h = b.h
-        red = self._red_all[b.stats_off:b.stats_off + b.N * b.cout * 2].view(b.N, b.cout, 2)  # zeroed once per step
+        red = self._red_all[b.stats_off // 2:b.stats_off // 2 + b.N * b.cout * 2].view(b.N, b.cout, 2)
         draw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
         gnw, gnb = self._galloc(h.norm.weight), self._galloc(h.norm.bias)
-        ops.instnorm_lrelu_bwd(raw, g_act, stats, h.norm.weight, h.norm.bias, red, draw, b.N, b.V, b.cout, b.cout, g_ld,
-                               b.cout, b.eps, b.slope, pre_zeroed=True, dgamma=gnw, dbeta=gnb)
+        ops.instnorm_lrelu_bwd_tab(raw, g_act, stats, self._scratch, red, draw, b.N, b.V, b.cout, b.cout, g_ld, b.cout,
+                                   b.slope, dgamma=gnw, dbeta=gnb)
         grads[h.norm.weight], grads[h.norm.bias] = gnw, gnb
         # the bias of a conv followed by InstanceNorm has an identically zero gradient (mean removal)
         grads[h.conv.bias] = self._galloc(h.conv.bias)  # arena is zero-initialised
         gw = self._galloc(h.conv.weight)
         if b.stem:
-            ops.stem_wgrad(x_in, draw, gw, (b.N, *b.in_dims), b.cout)
+            ops.stem_wgrad(x_in, draw, gw, (b.N, *b.in_dims), b.cout, scratch=self._scratch)
         else:
             nk = b.nk
             # dW[t][cin][cout] -> torch layout (cout, cin, *k): a = cin (stride nk), b = cout (stride cin*nk), t stride 1
@@ -579,7 +586,8 @@ class PlainConvUNet(nn.Module):
         self._arena_trace = []
         self._arena_unused = set()
         plan.pack_bwd.run()
-        self._red_all = torch.zeros(plan.stats_floats, dtype=torch.float32, device=dev)
+        self._red_all = torch.empty(plan.stats_floats // 2, dtype=torch.float32, device=dev)
+        self._scratch = plan.norm_scratch
         if plan.wgrad_ws is None:
             plan.wgrad_ws = torch.empty(plan.wgrad_ws_floats, dtype=torch.float32, device=dev)
         self._wgrad_ws = plan.wgrad_ws
@@ -605,7 +613,7 @@ class PlainConvUNet(nn.Module):
                     g = g.to(f16)
                 gw = self._galloc(seg.weight)
                 gb = self._galloc(seg.bias)
-                ops.head_wgrad(out_act, g, gw, gb, N, V, C_, K, C_)
+                ops.head_wgrad(out_act, g, gw, gb, N, V, C_, K, C_, scratch=self._scratch)
                 ops.head_dgrad(g, seg.weight, g_cur, N, V, C_, K, C_, accumulate=have)
                 grads[seg.weight], grads[seg.bias] = gw, gb
             else:
@@ -634,7 +642,7 @@ class PlainConvUNet(nn.Module):
             grads[up.m.weight] = gw
             if up.m.bias is not None:
                 st = torch.empty((N, up.cout, 2), dtype=torch.float32, device=dev)
-                ops.instnorm_stats(g_up, st, N, V, up.cout, 2 * up.cout)
+                ops.instnorm_stats_det(g_up, N, V, up.cout, 2 * up.cout, self._scratch, sums=st)
                 gub = self._galloc(up.m.bias)
                 gub.copy_(st[:, :, 0].sum(0))
                 grads[up.m.bias] = gub
@@ -680,7 +688,7 @@ class PlainConvUNet(nn.Module):
         self._arena_layout = self._arena_trace
         self._last_arena = self._arena
         self._last_unused = self._arena_unused
-        self._red_all = self._wgrad_ws = self._arena = self._arena_trace = self._arena_unused = None
+        self._red_all = self._wgrad_ws = self._arena = self._arena_trace = self._arena_unused = self._scratch = None
         return out
 
     # reference API (dynamic_network_architectures): used by the planner's VRAM estimate only

@@ -19,6 +19,7 @@ import torch
 
 from .. import _lib
 from .._lib import call, ptr, stream_ptr
+from ..hip_ops import det_scratch
 
 CHUNK = 16384  # elements per workgroup of the update kernel
 
@@ -100,8 +101,9 @@ class FusedSGD(torch.optim.SGD):
         if not self._linked():
             self._build(self._net.grad_arena_layout(), arena.device, self._net_unused())
         g = self.param_groups[0]
-        stats = torch.zeros(2, dtype=torch.float32, device=arena.device)
-        call("nnz_grad_sumsq_nonfinite", ptr(arena), self._total, ptr(stats), stream_ptr())
+        stats = torch.empty(2, dtype=torch.float32, device=arena.device)
+        sc = det_scratch(arena.device, 2)      # fixed-point cross-workgroup sum: the clip factor is reproducible run to run
+        call("nnz_grad_sumsq_nonfinite_det", ptr(arena), self._total, ptr(stats), ptr(sc.acc), ptr(sc.counter), stream_ptr())
         call("nnz_sgd_nesterov_fused", ptr(self._chunks), self._nchunks, ptr(arena), ptr(stats), ptr(inv_scale),
              float(max_norm), float(g['lr']), float(g['momentum']), float(g['weight_decay']), 0, stream_ptr())
         return stats[1:2]
@@ -109,7 +111,9 @@ class FusedSGD(torch.optim.SGD):
     def total_grad_norm(self, inv_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
         """unscaled global gradient norm of the current arena (diagnostics / tests)"""
         arena = self._net.grad_arena()
-        stats = torch.zeros(2, dtype=torch.float32, device=arena.device)
-        call("nnz_grad_sumsq_nonfinite", ptr(arena), arena.numel(), ptr(stats), stream_ptr())
+        stats = torch.empty(2, dtype=torch.float32, device=arena.device)
+        sc = det_scratch(arena.device, 2)
+        call("nnz_grad_sumsq_nonfinite_det", ptr(arena), arena.numel(), ptr(stats), ptr(sc.acc), ptr(sc.counter),
+             stream_ptr())
         n = stats[0].sqrt()
         return n * inv_scale[0] if inv_scale is not None else n

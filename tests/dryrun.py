@@ -42,23 +42,29 @@ def stub_kernel_launches(fill: float = 1.0):
         gw.fill_(fill)
         gb.fill_(fill)
 
-    def norm_bwd(x, g, stats, gamma, beta, red, dx, *a, dgamma=None, dbeta=None, **k):
+    def norm_bwd(x, g, nstat, scratch, nred, dx, *a, dgamma=None, dbeta=None, **k):
         dgamma.fill_(fill)
         dbeta.fill_(fill)
 
-    def stats(x, st, N, V, Cc, ldx, pre_zeroed=False):
-        st.zero_()
-        st[:, :, 0] = fill / N   # the transposed conv's bias gradient is the sum over samples of this column
+    def stats(x, N, V, Cc, ldx, scratch, gamma=None, beta=None, eps=0.0, nstat=None, sums=None):
+        if sums is not None:
+            sums.zero_()
+            sums[:, :, 0] = fill / N   # the transposed conv's bias gradient is the sum over samples of this column
+
+    class _Scratch:
+        def __init__(self, device, n_times_c):
+            self.capacity = n_times_c
 
     try:
-        for n in ("stem_forward", "conv_tap_forward", "convT_forward", "convT_dgrad", "instnorm_lrelu_apply", "head_forward",
-                  "head_dgrad"):
+        for n in ("stem_forward", "conv_tap_forward", "conv_tap_forward_norm", "convT_forward", "convT_dgrad",
+                  "instnorm_lrelu_apply_tab", "head_forward", "head_dgrad"):
             put(n, nop)
-        put("instnorm_stats", stats)
+        put("instnorm_stats_det", stats)
+        put("NormScratch", _Scratch)
         put("conv_tap_wgrad_to_grad", wgrad_to_grad)
         put("stem_wgrad", stem_wgrad)
         put("head_wgrad", head_wgrad)
-        put("instnorm_lrelu_bwd", norm_bwd)
+        put("instnorm_lrelu_bwd_tab", norm_bwd)
         put("PackJobTable", _NoPack)
         yield
     finally:

@@ -60,7 +60,11 @@ def test_swin_block_padding_quirk(hip_lib):
     close(blk(torch.tensor(z["x"]).cuda()), z["y"], "swin block 19x19")
 
 
-def test_ss2d_golden(hip_lib):
+@pytest.mark.parametrize("gen2_clb", [None, 0, 4])
+def test_ss2d_golden(hip_lib, force_scan_gen2, gen2_clb):
+    """gen2_clb None: the default kernel choice (generation 1 at this size); 0 / 4: the generation-2 cross-scan kernels
+    - the ones the 512^2 bench runs on - forced on (launcher-chosen / 64-step chunks) against the REFERENCE's golden"""
+    import contextlib
     from nnuzoo_amd.nets.m2net import SS2D
     z = np.load(os.path.join(G, "ss2d.npz"))
     m = SS2D(d_model=16).cuda().eval()
@@ -68,10 +72,12 @@ def test_ss2d_golden(hip_lib):
     names = [n for n, _ in m.named_parameters()]
     assert names == [str(n) for n in z["names"]]
     x = torch.tensor(z["x"]).cuda().requires_grad_(True)
-    y = m(x)
-    close(y, z["y"], "y")
     params = list(m.named_parameters())
-    grads = torch.autograd.grad(y, [x] + [p for _, p in params], torch.tensor(z["dy"]).cuda())
+    with (force_scan_gen2(gen2_clb) if gen2_clb is not None else contextlib.nullcontext(lambda: 2)) as taken:
+        y = m(x)
+        grads = torch.autograd.grad(y, [x] + [p for _, p in params], torch.tensor(z["dy"]).cuda())
+        assert taken() == 2                                      # forward and backward of the one cross-scan
+    close(y, z["y"], "y")
     close(grads[0], z["dx"], "dx", rtol=3e-4)
     for (n, _), g in zip(params, grads[1:]):
         close(g, z["g_" + n], "g_" + n, rtol=3e-4)
@@ -95,17 +101,21 @@ def test_ssnd_golden(hip_lib, tag, sd):
         close(g, z["g_" + n], "g_" + n, rtol=3e-4)
 
 
-@pytest.mark.parametrize("name", ["M2NetP", "M2Net", "SwT2Net"])
-def test_whole_net_forward_golden(hip_lib, name):
+@pytest.mark.parametrize("name", ["M2NetP", "M2Net", "SwT2Net", "M2Net-gen2", "M2NetP-gen2"])
+def test_whole_net_forward_golden(hip_lib, force_scan_gen2, name):
+    """`-gen2`: every cross-scan that generation 2 can take (L % 64 == 0, >= 32 channels per group) forced onto it"""
+    import contextlib
     from nnuzoo_amd.nets import m2net, swt2net
+    name, gen2 = name.split("-")[0], name.endswith("-gen2")
     cls = {"M2NetP": m2net.M2NetP, "M2Net": m2net.M2Net, "SwT2Net": swt2net.SwT2Net}[name]
     z = np.load(os.path.join(G, f"net_{name}_64.npz"))
     torch.manual_seed(0)
     net = cls(1, 2, True)
     det_fill(net)
     net = net.cuda().eval()
-    with torch.no_grad():
+    with torch.no_grad(), (force_scan_gen2(0) if gen2 else contextlib.nullcontext(lambda: 99)) as taken:
         outs = net(torch.tensor(z["x"]).cuda())
+        assert taken() >= 8, taken()                             # the 64^2 ... 16^2 levels qualify
     assert len(outs) == 7
     for i, o in enumerate(outs):
         close(o, z[f"out{i}"], f"{name} out{i}", rtol=3e-4)
@@ -116,13 +126,15 @@ def test_whole_net_forward_golden(hip_lib, name):
     assert agree.all()
 
 
-@pytest.mark.parametrize("name", ["M2NetP", "SwT2Net"])
-def test_whole_net_backward_golden(hip_lib, name):
+@pytest.mark.parametrize("name", ["M2NetP", "SwT2Net", "M2NetP-gen2"])
+def test_whole_net_backward_golden(hip_lib, force_scan_gen2, name):
     """whole-net BACKWARD against the reference's own autograd (tools/make_golden.py gen_nets: eval mode, loss =
     sum_i <out_i, G_i> / voxels with formula-made G_i): dx in full; of every parameter gradient the reference's <= 256
     evenly strided samples and its L2 norm.  Tolerances are relative to each gradient's own scale and were set from the
     measured worst case x ~4 (hundreds of fp32 layers, different but equally valid reduction orders)."""
+    import contextlib
     from nnuzoo_amd.nets import m2net, swt2net
+    name, gen2 = name.split("-")[0], name.endswith("-gen2")
     cls = {"M2NetP": m2net.M2NetP, "SwT2Net": swt2net.SwT2Net}[name]
     z = np.load(os.path.join(G, f"netgrad_{name}_64.npz"))
     x0 = np.load(os.path.join(G, f"net_{name}_64.npz"))["x"]
@@ -131,12 +143,14 @@ def test_whole_net_backward_golden(hip_lib, name):
     det_fill(net)
     net = net.cuda().eval()
     x = torch.tensor(x0).cuda().requires_grad_(True)
-    outs = net(x)
-    loss = 0
-    for i, o in enumerate(outs):
-        j = torch.arange(o.numel(), dtype=torch.float64)
-        loss = loss + (o * torch.sin(0.37 * j + i).float().view_as(o).cuda()).sum() / o[0, 0].numel()
-    loss.backward()
+    with (force_scan_gen2(0) if gen2 else contextlib.nullcontext(lambda: 99)) as taken:
+        outs = net(x)
+        loss = 0
+        for i, o in enumerate(outs):
+            j = torch.arange(o.numel(), dtype=torch.float64)
+            loss = loss + (o * torch.sin(0.37 * j + i).float().view_as(o).cuda()).sum() / o[0, 0].numel()
+        loss.backward()
+        assert taken() >= 16, taken()                            # forward + backward calls on generation 2
     close(x.grad, z["dx"], "dx", rtol=2e-3)
     names = [str(n) for n in z["names"]]
     with_grad = [n for n, p in net.named_parameters() if p.grad is not None]
