@@ -69,6 +69,14 @@ int nnz_pack_job_bytes(void);
 int nnz_pack_job_fill(void* out_host, const float* src, void* dst_f16, int R, int C, int T, long sr, long sc, long sk,
                       const int* ksel);
 int nnz_pack_conv_weights_batched(const void* jobs_device, int njobs, void* stream);
+/* Both packed forms of every layer from ONE read of the fp32 parameters (round 3): forward Wf[X/16][Y/32][T][32][16] and
+ * data-gradient Wb[Y/16][X/32][T][32][16] (X = the forward convolution's input channels, Y = its output channels; taps
+ * contiguous in the parameter; x_inner = 1 for Conv weights (Y, X, k...), 0 for ConvTranspose weights (X, Y, k...)).
+ * One workgroup per 32 x 32 channel block; jobs carry the prefix sum of their block counts. */
+int nnz_pack_dual_job_bytes(void);
+int nnz_pack_dual_job_fill(void* out, const float* src, void* dst_fwd_f16, void* dst_dgrad_f16, int X, int Y, int nk,
+                           int x_inner, int first_block, const int* ksel_fwd, const int* ksel_dgrad);
+int nnz_pack_dual_batched(const void* jobs_device, int njobs, int total_blocks, int max_nk, void* stream);
 int nnz_unpack_conv_wgrad(const float* dw, float* grad, int A, int B, int T, long sa, long sb, long sk,
                           const int* ksel, int accumulate, void* stream);
 

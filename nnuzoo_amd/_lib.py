@@ -71,6 +71,9 @@ SIGNATURES = {
     "nnz_pack_job_bytes": [],
     "nnz_pack_job_fill": [_vp, _fp, _vp, _i, _i, _i, _l, _l, _l, _ip],
     "nnz_pack_conv_weights_batched": [_vp, _i, _vp],
+    "nnz_pack_dual_job_bytes": [],
+    "nnz_pack_dual_job_fill": [_vp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _ip],
+    "nnz_pack_dual_batched": [_vp, _i, _i, _i, _vp],
     "nnz_unpack_conv_wgrad": [_fp, _fp, _i, _i, _i, _l, _l, _l, _ip, _i, _vp],
     "nnz_stem_conv_forward": [_fp, _fp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "nnz_stem_conv_wgrad": [_fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp],

@@ -93,7 +93,129 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const PackJob*
   }
 }
 
+// ---- both packed forms of every layer from ONE read of the parameters (round 3) ------------------------------------------
+// The forward convolution wants Wf[X/16][Y/32][T][32 y][16 x] (X = input channels = its reduction), the data gradient
+// Wb[Y/16][X/32][T][32 x][16 y] with its own tap order.  Rounds 1-2 packed them in two launches (start of forward / of
+// backward), each re-reading all 125 MB of fp32 parameters with 4-byte loads: 0.39 ms per step at ~1 TB/s.  Here a
+// workgroup owns one 32 x 32 channel block of one layer for ALL kernel positions: it streams the block in with 16-byte
+// loads along the parameter's contiguous runs (32 inner channels x nk taps = one run per outer channel), converts to fp16
+// into one LDS image [k][x][y] and streams both packed blocks out as whole 16-byte pieces.
+struct DualPackJob {
+  const float* src;
+  f16* dst_f;
+  f16* dst_b;
+  int X, Y, nk, x_inner;  // x_inner: the X axis has stride nk (conv weights (Y, X, k)); else the Y axis has (convT (X, Y, k))
+  int first_block;        // prefix sum of (X/32) * (Y/32) over the jobs before this one
+  int pad;
+  int ksel_f[32];
+  int ksel_b[32];
+};
+
+constexpr int DP_PITCH = 40;  // f16 per x row of the LDS image: 80 bytes keeps the 8-y pieces 16-byte aligned
+
+__global__ __launch_bounds__(256) void pack_dual_kernel(const DualPackJob* __restrict__ jobs, int njobs) {
+  extern __shared__ __attribute__((aligned(16))) f16 img[];  // [nk][32 x][DP_PITCH]
+  __shared__ int s_job;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].first_block <= (int)blockIdx.x) ++j;
+    s_job = j;
+  }
+  __syncthreads();
+  const DualPackJob& J = jobs[s_job];
+  const int nk = J.nk, X = J.X, Y = J.Y;
+  const int blk = blockIdx.x - J.first_block;
+  const int nyb = Y >> 5;
+  const int xb = blk / nyb, yb = blk % nyb;
+  const int inner_n = J.x_inner ? X : Y;                 // channels along the contiguous axis
+  const int ib = J.x_inner ? xb : yb, ob = J.x_inner ? yb : xb;
+  const int row_f4 = 8 * nk;                             // float4 per outer row of the block (32 * nk floats)
+  const int total = 32 * row_f4;
+  const float* base = J.src + ((size_t)(ob * 32) * inner_n + ib * 32) * nk;
+  for (int p0 = tid; p0 < total; p0 += 4 * 256) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 256;
+      if (p < total) {
+        const int row = p / row_f4, q = p - row * row_f4;
+        v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)row * inner_n * nk + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 256;
+      if (p < total) {
+        const int row = p / row_f4, q = p - row * row_f4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int f = 4 * q + e;
+          const int inner = f / nk, kk = f - inner * nk;
+          const int x = J.x_inner ? inner : row, y = J.x_inner ? row : inner;
+          img[(kk * 32 + x) * DP_PITCH + y] = (f16)v[u][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int npiece = nk * 128;  // 16-byte pieces per packed form: 2 halves x nk x 32 x 2
+  // forward form: unit (xb * 2 + xh, yb), piece = [t][y][xo] holding x = xh * 16 + xo * 8 .. + 7 (stride DP_PITCH in LDS)
+  for (int p = tid; p < npiece; p += 256) {
+    const int xo = p & 1, y = (p >> 1) & 31, r = p >> 6;
+    const int t = r % nk, xh = r / nk;
+    const f16* s0 = img + (J.ksel_f[t] * 32 + xh * 16 + xo * 8) * DP_PITCH + y;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = s0[j * DP_PITCH];
+    f16* d = J.dst_f + ((size_t)((xb * 2 + xh) * nyb + yb) * nk + t) * 512 + y * 16 + xo * 8;
+    *reinterpret_cast<f16x8*>(d) = o;
+  }
+  // data-gradient form: unit (yb * 2 + yh, xb), piece = [t][x][yo] holding y = yh * 16 + yo * 8 .. + 7 (contiguous in LDS)
+  const int nxb = X >> 5;
+  for (int p = tid; p < npiece; p += 256) {
+    const int yo = p & 1, x = (p >> 1) & 31, r = p >> 6;
+    const int t = r % nk, yh = r / nk;
+    const f16x8 o = *reinterpret_cast<const f16x8*>(img + (J.ksel_b[t] * 32 + x) * DP_PITCH + yh * 16 + yo * 8);
+    f16* d = J.dst_b + ((size_t)((yb * 2 + yh) * nxb + xb) * nk + t) * 512 + x * 16 + yo * 8;
+    *reinterpret_cast<f16x8*>(d) = o;
+  }
+}
+
 }  // namespace nnz
+
+extern "C" int nnz_pack_dual_job_bytes(void) { return (int)sizeof(nnz::DualPackJob); }
+
+// host helper: serialise one job (first_block = number of 32 x 32 blocks of all earlier jobs)
+extern "C" int nnz_pack_dual_job_fill(void* out, const float* src, void* dst_fwd_f16, void* dst_dgrad_f16, int X, int Y,
+                                      int nk, int x_inner, int first_block, const int* ksel_fwd, const int* ksel_dgrad) {
+  using namespace nnz;
+  if (!out || !src || !dst_fwd_f16 || !dst_dgrad_f16 || !ksel_fwd || !ksel_dgrad || X % 32 || Y % 32 || nk < 1 || nk > 27)
+    return NNZ_EINVAL;
+  DualPackJob j = {};
+  j.src = src; j.dst_f = (f16*)dst_fwd_f16; j.dst_b = (f16*)dst_dgrad_f16;
+  j.X = X; j.Y = Y; j.nk = nk; j.x_inner = x_inner; j.first_block = first_block;
+  for (int i = 0; i < 32; ++i) {
+    j.ksel_f[i] = i < nk ? ksel_fwd[i] : 0;
+    j.ksel_b[i] = i < nk ? ksel_dgrad[i] : 0;
+    if (j.ksel_f[i] < 0 || j.ksel_f[i] >= nk || j.ksel_b[i] < 0 || j.ksel_b[i] >= nk) return NNZ_EINVAL;
+  }
+  memcpy(out, &j, sizeof(j));
+  return NNZ_OK;
+}
+
+extern "C" int nnz_pack_dual_batched(const void* jobs_device, int njobs, int total_blocks, int max_nk, void* stream) {
+  using namespace nnz;
+  if (!jobs_device || njobs < 1 || total_blocks < 1 || max_nk < 1 || max_nk > 27) return NNZ_EINVAL;
+  const int lds = max_nk * 32 * DP_PITCH * 2;  // <= 69 120 bytes
+  static DynLdsCache lds_cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(pack_dual_kernel), lds, lds_cache);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH(pack_dual_kernel, dim3(total_blocks), dim3(256), lds, (hipStream_t)stream,
+             (const DualPackJob*)jobs_device, njobs);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
 
 extern "C" int nnz_pack_job_bytes(void) { return (int)sizeof(nnz::PackJob); }
 

@@ -209,6 +209,42 @@ class PackJobTable:
         call("nnz_pack_conv_weights_batched", ptr(self.table), len(self.jobs), stream_ptr())
 
 
+class DualPackTable:
+    """Device-resident job table of the dual weight pack (csrc/conv_pack.hip pack_dual_kernel): one launch per step reads
+    every parameter once and writes the forward AND the data-gradient packed form."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+        self.table = None
+
+    def add(self, param: torch.Tensor, dst_fwd: torch.Tensor, dst_dgrad: torch.Tensor, X: int, Y: int, nk: int,
+            x_inner: bool, fwd: PreparedTable, dgrad: PreparedTable):
+        assert param.is_contiguous() and param.dtype == torch.float32
+        self.jobs.append((param, dst_fwd, dst_dgrad, X, Y, nk, int(x_inner), fwd, dgrad))
+        self.table = None
+
+    def run(self):
+        if not self.jobs:
+            return
+        lib = _lib.load()
+        if self.table is None:
+            nb = lib.nnz_pack_dual_job_bytes()
+            host = (C.c_char * (nb * len(self.jobs)))()
+            blocks = 0
+            for i, (param, df, db, X, Y, nk, xin, fwd, dgrad) in enumerate(self.jobs):
+                _lib.check(lib.nnz_pack_dual_job_fill(C.byref(host, i * nb), ptr(param), ptr(df), ptr(db), X, Y, nk, xin,
+                                                      blocks, fwd.pack_ksel, dgrad.pack_ksel), "nnz_pack_dual_job_fill")
+                blocks += (X // 32) * (Y // 32)
+            self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+            self.blocks, self.max_nk = blocks, max(j[5] for j in self.jobs)
+            self._ptrs = [(j[0].data_ptr(), j[1].data_ptr(), j[2].data_ptr()) for j in self.jobs]
+        else:
+            assert self._ptrs == [(j[0].data_ptr(), j[1].data_ptr(), j[2].data_ptr()) for j in self.jobs], \
+                "parameter storage moved"
+        call("nnz_pack_dual_batched", ptr(self.table), len(self.jobs), self.blocks, self.max_nk, stream_ptr())
+
+
 def unpack_wgrad(dw: torch.Tensor, grad: torch.Tensor, A: int, B: int, T: int, sa: int, sb: int, sk: int,
                  pt: PreparedTable, accumulate: bool = False) -> None:
     _f32(dw, "unpack.dw"); _f32(grad, "unpack.grad")

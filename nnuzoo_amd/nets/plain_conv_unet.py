@@ -258,12 +258,13 @@ class _Plan:
         self.wgrad_ws_floats = max([ops.conv_tap_wgrad_workspace_floats(b.wgrad) for b in self.all_blocks if not b.stem]
                                    + [ops.conv_tap_wgrad_workspace_floats(u.wgrad) for u in self.ups])
         self.wgrad_ws = None
-        self.pack_fwd = self.pack_bwd = None                      # built on first use (needs device pointers)
+        self.pack_fwd = self.pack_dual = None                     # built on first use (needs device pointers)
 
     def build_pack_tables(self, dev):
         """persistent packed-weight buffers + device job tables: ONE pack launch per forward and per backward"""
         f16 = torch.float16
-        self.pack_fwd, self.pack_bwd = ops.PackJobTable(dev), ops.PackJobTable(dev)
+        # pack_fwd: only what the dual pack does not cover (a zero-padded first conv: forward form only)
+        self.pack_fwd, self.pack_dual = ops.PackJobTable(dev), ops.DualPackTable(dev)
         for b in self.all_blocks:
             if b.stem:
                 continue
@@ -278,15 +279,13 @@ class _Plan:
                 self.pack_fwd.add(b.w_pad, b.wp_fwd, b.fwd, b.cin, b.cout, nk, b.cin * nk, 1)
                 continue
             b.wp_dgrad = torch.empty(b.cin * b.cout * nk, dtype=f16, device=dev)
-            self.pack_fwd.add(w, b.wp_fwd, b.fwd, b.cin, b.cout, nk, b.cin * nk, 1)
-            self.pack_bwd.add(w, b.wp_dgrad, b.dgrad, b.cout, b.cin, b.cin * nk, nk, 1)
+            self.pack_dual.add(w, b.wp_fwd, b.wp_dgrad, b.cin, b.cout, nk, True, b.fwd, b.dgrad)
         for u in self.ups:
             w = u.m.weight
             nk = u.nk
             u.wp_fwd = torch.empty(u.cin * u.cout * nk, dtype=f16, device=dev)
             u.wp_dgrad = torch.empty(u.cin * u.cout * nk, dtype=f16, device=dev)
-            self.pack_fwd.add(w, u.wp_fwd, u.fwd, u.cin, u.cout, u.cout * nk, nk, 1)
-            self.pack_bwd.add(w, u.wp_dgrad, u.dgrad, u.cout, u.cin, nk, u.cout * nk, 1)
+            self.pack_dual.add(w, u.wp_fwd, u.wp_dgrad, u.cin, u.cout, nk, False, u.fwd, u.dgrad)
 
 
 def _check_supported(net: "PlainConvUNet"):
@@ -458,7 +457,9 @@ class PlainConvUNet(nn.Module):
         b0 = plan.enc_blocks[0][0]
         if b0.padded:
             b0.w_pad[:, :b0.cin_w].copy_(b0.h.conv.weight.detach().reshape(b0.cout, b0.cin_w, *b0.ks))
-        plan.pack_fwd.run()
+        if plan.pack_fwd.jobs:
+            plan.pack_fwd.run()
+        plan.pack_dual.run()     # forward AND data-gradient forms from one read of the parameters (one launch per step)
         if plan.norm_scratch is None:
             plan.norm_scratch = ops.NormScratch(dev, plan.norm_capacity)
         self._scratch = plan.norm_scratch
@@ -585,7 +586,6 @@ class PlainConvUNet(nn.Module):
         self._arena_off = 0
         self._arena_trace = []
         self._arena_unused = set()
-        plan.pack_bwd.run()
         self._red_all = torch.empty(plan.stats_floats // 2, dtype=torch.float32, device=dev)
         self._scratch = plan.norm_scratch
         if plan.wgrad_ws is None:

@@ -66,6 +66,7 @@ def stub_kernel_launches(fill: float = 1.0):
         put("head_wgrad", head_wgrad)
         put("instnorm_lrelu_bwd_tab", norm_bwd)
         put("PackJobTable", _NoPack)
+        put("DualPackTable", _NoPack)
         yield
     finally:
         for n, fn in saved.items():

@@ -382,6 +382,41 @@ def test_batched_weight_pack_matches_single(hip_lib):
         assert torch.equal(got, ref)
 
 
+def test_dual_weight_pack_matches_single(hip_lib):
+    """round 3: ONE launch reading every parameter once and writing the forward and the data-gradient packed forms
+    (csrc/conv_pack.hip pack_dual_kernel) == the two per-layer packs, bit-exact; conv (3-D k3, stride 2, thick-slice k(1,3,3),
+    2-D) and transposed-conv parameter layouts, several 32 x 32 blocks per layer"""
+    g = torch.Generator().manual_seed(17)
+    dual = ops.DualPackTable(torch.device(DEV))
+    expect = []
+    for cin, cout, ks, st in [(32, 64, (3, 3, 3), 1), (96, 32, (1, 3, 3), 1), (64, 320, (3, 3, 3), 2), (32, 32, (3, 3, 3), 1),
+                              (640, 320, (3, 3, 3), 1)]:
+        nk = ks[0] * ks[1] * ks[2]
+        w = torch.randn(cout, cin, *ks, generator=g).to(DEV)
+        st3 = (1, st, st) if ks[0] == 1 else (st,) * 3
+        fwd = PreparedTable(cp.conv_forward(1, (4, 8, 8), cin, cout, ks=ks, stride=st3))
+        dgr = PreparedTable(cp.conv_dgrad(1, (4, 8, 8), cin, cout, ks=ks, stride=st3))
+        df = torch.zeros(cin * cout * nk, dtype=torch.float16, device=DEV)
+        db = torch.zeros(cin * cout * nk, dtype=torch.float16, device=DEV)
+        dual.add(w, df, db, cin, cout, nk, True, fwd, dgr)
+        expect.append((df, ops.pack_weight(w, fwd, cin, cout, nk, cin * nk, 1)))
+        expect.append((db, ops.pack_weight(w, dgr, cout, cin, cin * nk, nk, 1)))
+    for cin, cout, st in [(128, 64, (2, 2, 2)), (64, 32, (1, 2, 2))]:
+        nk = st[0] * st[1] * st[2]
+        wt = torch.randn(cin, cout, *st, generator=g).to(DEV)
+        fwd = PreparedTable(cp.convT_forward(1, (4, 4, 4), cin, cout, stride=st))
+        dgr = PreparedTable(cp.convT_dgrad(1, (4, 4, 4), cin, cout, stride=st))
+        df = torch.zeros(cin * cout * nk, dtype=torch.float16, device=DEV)
+        db = torch.zeros(cin * cout * nk, dtype=torch.float16, device=DEV)
+        dual.add(wt, df, db, cin, cout, nk, False, fwd, dgr)
+        expect.append((df, ops.pack_weight(wt, fwd, cin, cout, cout * nk, nk, 1)))
+        expect.append((db, ops.pack_weight(wt, dgr, cout, cin, nk, cout * nk, 1)))
+    dual.run()
+    torch.cuda.synchronize()
+    for i, (got, ref) in enumerate(expect):
+        assert torch.equal(got, ref), i
+
+
 def test_conv_batches_beyond_2g_elements(hip_lib):
     """tensors with more than 2^31 elements (5 samples x 128^3 voxels x channel stride 256): the entry points split the
     batch into sample chunks (32-bit voxel offsets inside the kernels); forward + statistics and weight gradient."""
