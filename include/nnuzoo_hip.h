@@ -227,6 +227,20 @@ int nnz_token_linear_supported(int Kr, int Mo);
 int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, float* dW, float* db, long T, int N, int K,
                            void* stream);
 
+/* ---- fp32 token-major Linear layers on v_mfma_f32_32x32x2_f32 (csrc/dense32.hip, round 3) -----------------------------
+ * The Swin / ViT trainers run without autocast (nnunetv2/training/nnUNetTrainer/nnUNetTrainerSwT2Net.py:112-130): qkv /
+ * proj (nets/swt2net.py:584-619), Mlp (:496-515), patch merging / expanding, skip fusions (:843-868) are exact fp32
+ * F.linear calls there.  x [T][K], W [N][K] (torch layout), y [T][N]; K, N multiples of 4.
+ *   forward: y = x W^T + bias;  gelu != 0: y keeps the pre-activation and y_act = GELU(y) (erf form, nn.GELU default)
+ *   dgrad:   dx = dy W  (times GELU'(h) when h [T][K] is given)
+ *   wgrad:   dW = dy^T x, db = column sums of dy (db may be NULL); token splits fold in a fixed order (deterministic) */
+int nnz_dense32_forward(const float* x, const float* W, const float* bias, float* y, float* y_act, long T, int K, int N,
+                        int gelu, void* stream);
+int nnz_dense32_dgrad(const float* dy, const float* W, const float* h, float* dx, long T, int K, int N, void* stream);
+long nnz_dense32_wgrad_workspace_floats(long T, int K, int N);
+int nnz_dense32_wgrad(const float* dy, const float* x, float* dW, float* db, float* workspace, long T, int K, int N,
+                      void* stream);
+
 /* online-Dice statistics of the validation step (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 +
  * get_tp_fp_fn_tn, training/loss/dice.py:122-180, label-map targets): argmax over classes (first maximum on ties)
  * against the int16 label map in one read; counts_u64[c] = {tp, fp, fn} exact (zeroed by the call). */
@@ -397,9 +411,12 @@ int nnz_selective_scan_backward(const float* u, const float* delta, const float*
  * H, W multiples of 7; shift = 0 or 3. */
 int nnz_window_attention_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out, int B,
                                  int H, int W, int C, int heads, int shift, float scale, void* stream);
+/* backward: dbias_table is WRITTEN (deterministic: fixed-order sums per table entry, fixed-point adds across workgroups);
+ * acc = heads * 169 zeroed records of nnz_fxacc_bytes() bytes, counter = one zeroed 32-bit word, both left zero.
+ * bias_index must have the reference's displacement layout index[i][j] = (yi - yj + 6) * 13 + (xi - xj + 6). */
 int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index, const float* dout,
-                                  float* dqkv, float* dbias_table, int B, int H, int W, int C, int heads, int shift,
-                                  float scale, void* stream);
+                                  float* dqkv, float* dbias_table, void* acc, void* counter, int B, int H, int W, int C,
+                                  int heads, int shift, float scale, void* stream);
 
 #ifdef __cplusplus
 }

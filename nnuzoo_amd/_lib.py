@@ -108,6 +108,10 @@ SIGNATURES = {
     "nnz_ss2d_xproj_backward_w": [_fp, _fp, _fp, _i, _i, _i, _l, _vp],
     "nnz_token_linear_forward": [_vp, _fp, _fp, _vp, _l, _i, _i, _i, _vp],
     "nnz_token_linear_supported": [_i, _i],
+    "nnz_dense32_forward": [_fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp],
+    "nnz_dense32_dgrad": [_fp, _fp, _fp, _fp, _l, _i, _i, _vp],
+    "nnz_dense32_wgrad_workspace_floats": [_l, _i, _i],
+    "nnz_dense32_wgrad": [_fp, _fp, _fp, _fp, _fp, _l, _i, _i, _vp],
     "nnz_token_linear_wgrad": [_vp, _vp, _fp, _fp, _l, _i, _i, _vp],
     "nnz_sgd_chunk_bytes": [],
     "nnz_sgd_chunk_fill": [_vp, _vp, _vp, _l, _i],
@@ -149,7 +153,7 @@ SIGNATURES = {
     "nnz_silu_gate_forward": [_fp, _fp, _fp, _l, _vp],
     "nnz_silu_gate_backward": [_fp, _fp, _fp, _fp, _fp, _l, _vp],
     "nnz_window_attention_forward": [_fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
-    "nnz_window_attention_backward": [_fp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "nnz_window_attention_backward": [_fp, _fp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_selective_scan_workspace_floats": [_i, _i, _i],
     "nnz_selective_scan_state_floats": [_i, _i, _i],
     "nnz_selective_scan_grad_state_floats": [_i, _i, _i],
@@ -159,7 +163,8 @@ SIGNATURES = {
 
 _LONG_RESULT = {"nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats", "nnz_ss2d_scan_workspace_floats",
                 "nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats",
-                "nnz_selective_scan_grad_state_floats", "nnz_dwconv2d_wgrad_workspace_floats", "nnz_conv_tap_wgrad_workspace_floats"}
+                "nnz_selective_scan_grad_state_floats", "nnz_dwconv2d_wgrad_workspace_floats", "nnz_conv_tap_wgrad_workspace_floats",
+                "nnz_dense32_wgrad_workspace_floats"}
 _lib = None
 
 

@@ -92,14 +92,19 @@ __device__ __forceinline__ T* pin_uniform(T* ptr) {
 // the last bits, and LeakyReLU / softmax amplify that into visibly different gradients.  Integer addition commutes, so a
 // sum kept as a FIXED-POINT integer is bit-identical however the adds interleave.  A partial (a double a workgroup has
 // formed in a fixed order) is split into a coarse word in units of 2^-10 and a fine word in units of 2^-58: range
-// |total| < 2^53, resolution 3.5e-18 absolute, up to 65 536 partials per accumulator before the fine word could wrap -
+// |total| < 2^53, resolution 3.5e-18 absolute, up to 65 536 partials per accumulator (and replica) before the fine word could wrap -
 // i.e. double precision for every magnitude an fp16 tensor's moments or a loss-scaled gradient sum can take.  Non-finite
 // partials are counted in a third word and make the total NaN (GradScaler's inf check must still see them).
 struct FxAcc {
   long long w[4];  // coarse (2^-10), fine (2^-58), non-finite partials, unused (32-byte records)
 };
-__device__ __forceinline__ void fx_add(FxAcc* a, double v) {
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(a->w);
+// Every logical accumulator exists in FX_REP replicas (replica r of record i of a bank of n records: acc[r * n + i]); a
+// workgroup adds to replica (its index mod FX_REP).  Atomics to ONE address serialise at ~23 ns each on this part (4096 conv
+// workgroups adding to the same 128 words cost 28 us per launch, measured); eight replicas make that 4 us, and since the
+// words are integers the replicas can be summed in any order without changing a bit.
+constexpr int FX_REP = 8;
+__device__ __forceinline__ void fx_add(FxAcc* bank, long i, long n, unsigned rep, double v) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)(rep & (FX_REP - 1)) * n + i].w);
   if (!(fabs(v) < 0x1p52)) {  // inf, NaN or beyond the range: poison the accumulator
     atomicAdd(w + 2, 1ull);
     return;
@@ -109,22 +114,40 @@ __device__ __forceinline__ void fx_add(FxAcc* a, double v) {
   atomicAdd(w + 0, (unsigned long long)(long long)h);
   atomicAdd(w + 1, (unsigned long long)(long long)rint(rem * 0x1p58));
 }
-// read AND reset (the workgroup that finalises leaves the accumulator ready for the next launch: no zero-fill kernels)
-__device__ __forceinline__ double fx_take(FxAcc* a) {
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(a->w);
-  const long long hi = (long long)atomicExch(w + 0, 0ull);
-  const long long lo = (long long)atomicExch(w + 1, 0ull);
-  const unsigned long long bad = atomicExch(w + 2, 0ull);
+// read AND reset all replicas of record i (the workgroup that finalises leaves the bank ready for the next launch: no
+// zero-fill kernels).  Agent-scope atomic loads / stores: they bypass the non-coherent caches like the adds did, but -
+// unlike read-modify-write atomics - pipeline, so a thread's 3 * FX_REP reads are one round trip.
+__device__ __forceinline__ double fx_take(FxAcc* bank, long i, long n) {
+  long long hi = 0, lo = 0;
+  unsigned long long bad = 0;
+#pragma unroll
+  for (int r = 0; r < FX_REP; ++r) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)r * n + i].w);
+    hi += (long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lo += (long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bad += __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int r = 0; r < FX_REP; ++r) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)r * n + i].w);
+    __hip_atomic_store(w + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const double v = (double)hi * (1.0 / 1024.0) + (double)lo * 0x1p-58;
   return bad ? __builtin_nan("") : v;
 }
 // "Was this the last workgroup of the launch to get here?"  Every thread of every workgroup calls it after its fx_add
-// calls (uniformly: it contains barriers).  The fence orders this workgroup's atomics before its ticket; the workgroup
-// that draws the last ticket therefore sees every other workgroup's contributions (it reads them with L2 atomics), and
-// re-arms the counter.  `counter` is a zero-initialised word owned by this launch sequence.
+// calls (uniformly: it contains barriers).  Everything the workgroups exchange travels in device-scope ATOMICS (the
+// accumulators, the ticket), so all that is needed is that a workgroup's adds have been performed before its ticket is
+// drawn: each thread waits for its own outstanding memory operations (a workgroup-scope release = s_waitcnt vmcnt(0)),
+// the barrier joins them, one thread draws the ticket.  NOT __threadfence(): at agent scope that is an L2 write-back +
+// invalidate on this multi-XCD part - in the epilogue of every conv workgroup it doubled the convolution's time (measured:
+// conv_box 6.0 -> 12.1 ms per step).  The workgroup that draws the last ticket reads the totals with atomics (performed
+// at the coherence point, never cached) and re-arms the counter.  `counter`: a zero-initialised word.
 __device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned nwg) {
   __shared__ unsigned s_last;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(counter, 1u);
@@ -132,9 +155,7 @@ __device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned nwg) 
     if (t == nwg - 1u) atomicExch(counter, 0u);
   }
   __syncthreads();
-  const bool last = s_last != 0;
-  if (last) __threadfence();
-  return last;
+  return s_last != 0;
 }
 
 // Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used anywhere in this library: captured into a hipGraph it

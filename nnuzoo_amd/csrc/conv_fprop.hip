@@ -508,9 +508,9 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       const int cw = p.d.m_dims[2] - m0w < TW ? p.d.m_dims[2] - m0w : TW;
       const double cnt = (double)(cd * ch * cw);
       const double k = (double)(float)*reinterpret_cast<const f16*>(smem + tid * 2);
-      FxAcc* a = p.acc + ((size_t)n * Cout + cb0 * 32 + tid) * 2;
-      fx_add(a, (double)S1 + cnt * k);
-      fx_add(a + 1, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
+      const long rec = ((long)n * Cout + cb0 * 32 + tid) * 2, nrec = (long)p.d.N * Cout * 2;
+      fx_add(p.acc, rec, nrec, blockIdx.x, (double)S1 + cnt * k);
+      fx_add(p.acc, rec + 1, nrec, blockIdx.x, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
     }
   }
 #pragma unroll 2
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
     if (last_workgroup(p.counter, nwg)) {
       const double V = (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
       for (int i = tid; i < p.d.N * Cout; i += 256) {
-        FxAcc* a = p.acc + (size_t)i * 2;
-        const double sx = fx_take(a), sq = fx_take(a + 1);
+        const long nrec = (long)p.d.N * Cout * 2;
+        const double sx = fx_take(p.acc, (long)i * 2, nrec), sq = fx_take(p.acc, (long)i * 2 + 1, nrec);
         const double mean = sx / V;
         double var = sq / V - mean * mean;
         var = var < 0.0 ? 0.0 : var;  // (NaN stays NaN)
@@ -716,7 +716,8 @@ extern "C" int nnz_conv_tap_forward_norm(const void* in, void* out, const void* 
   return conv_tap_forward_impl(in, out, w_packed, bias, desc, nullptr, acc, (unsigned*)counter, gamma, beta, eps, nstat, stream);
 }
 
-extern "C" int nnz_fxacc_bytes(void) { return (int)sizeof(nnz::FxAcc); }
+// bytes of ONE logical accumulator record as the *_det / *_norm entry points count them (all its replicas)
+extern "C" int nnz_fxacc_bytes(void) { return (int)sizeof(nnz::FxAcc) * nnz::FX_REP; }
 
 static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
                                  const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
@@ -756,7 +757,7 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
     p.w = (const f16*)w_packed;
     p.bias = bias;
     p.stats = stats ? stats + (size_t)n0 * d.Cout * 2 : nullptr;
-    p.acc = acc ? (FxAcc*)acc + (size_t)n0 * d.Cout * 2 : nullptr;
+    p.acc = (FxAcc*)acc;  // every sample chunk is a launch of its own: the bank is indexed from 0 again
     p.nstat = nstat ? nstat + (size_t)n0 * d.Cout * 4 : nullptr;
     p.counter = counter;
     p.gamma = gamma;

@@ -212,12 +212,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a, int ntiles)
     const float s = red[(0 * 32 + tt) * 32 + c] + red[(1 * 32 + tt) * 32 + c] + red[(2 * 32 + tt) * 32 + c] +
                     red[(3 * 32 + tt) * 32 + c];
     if (a.acc)
-      fx_add(a.acc + c * 27 + tt, (double)s);
+      fx_add(a.acc, c * 27 + tt, 27 * 32, blockIdx.x, (double)s);
     else
       atomicAdd(a.dw + c * 27 + tt, s);
   }
   if (a.acc && last_workgroup(a.counter, gridDim.x))
-    for (int i = tid; i < 27 * 32; i += 256) a.dw[i] = (float)fx_take(a.acc + i);
+    for (int i = tid; i < 27 * 32; i += 256) a.dw[i] = (float)fx_take(a.acc, i, 27 * 32);
 }
 
 // ------------------------------------------------------------------------------------------------ head
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
     float t = 0.f;
     for (int rr = 0; rr < rows; ++rr) t += lred[rr * KC + i];
     if (a.acc)
-      fx_add(a.acc + i, (double)t);
+      fx_add(a.acc, i, KC, blockIdx.x, (double)t);
     else if (i < K * a.C)
       atomicAdd(a.dw + (long)a.k0 * a.C + i, t);
     else
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
   }
   if (a.acc && last_workgroup(a.counter, gridDim.x * gridDim.y))
     for (int i = tid; i < KC; i += 256) {
-      const float t = (float)fx_take(a.acc + i);
+      const float t = (float)fx_take(a.acc, i, KC);
       if (i < K * a.C)
         a.dw[(long)a.k0 * a.C + i] = t;
       else

@@ -1,0 +1,306 @@
+// fp32 token-major Linear layers on the fp32 matrix cores (gfx950, v_mfma_f32_32x32x2_f32): forward (+ bias, + GELU),
+// input gradient (+ GELU'), weight + bias gradient.  The Swin / ViT trainers of the reference run WITHOUT autocast
+// (/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainerSwT2Net.py:112-130), so the Linear layers that hold 80 %
+// of SwT2Net's FLOPs - qkv / proj (/root/reference/nnunetv2/nets/swt2net.py:584-619), the Mlp (:496-515), patch merging /
+// expanding and the skip fusions (:843-868) - are exact fp32 contractions.  Rounds 1-2 sent them to the GEMM library:
+// per Linear and step one forward GEMM, one input-gradient GEMM, a chunked batched GEMM + sum for the weight gradient, a
+// reduce launch for the bias gradient, plus element-wise launches for bias / GELU / GELU' - ~9 000 small kernels per step.
+//
+// One kernel template serves the three products; what differs is only how an operand tile reaches LDS:
+//   forward   y[t][n]  = sum_k x[t][k]  W[n][k]   rows = tokens (x, k contiguous)   cols = features (W, k contiguous)
+//   dgrad     dx[t][k] = sum_n dy[t][n] W[n][k]   rows = tokens (dy, n contiguous)  cols = k (W read transposed)
+//   wgrad     dW[n][k] = sum_t dy[t][n] x[t][k]   rows = n (dy read transposed)     cols = k (x read transposed)
+// LDS tiles are [row][contraction] with the contraction index contiguous, so a lane fetches FOUR consecutive contraction
+// steps of its row with one ds_read_b128: lane half hh takes steps 4hh .. 4hh+3 of every 8 - any assignment of steps to
+// MFMA issues is valid as long as both operands use the same one.  Rows (tokens) are the MFMA A operand and features sit
+// on the lanes, so an accumulator register is 32 consecutive features of one token: stores are 128-byte runs without a
+// transpose.  4 waves per workgroup in a 2 x 2 grid, each wave WM x WN MFMA tiles (up to 64 x 64 outputs = 64 accumulator
+// registers); the next contraction block is prefetched into registers under the MFMAs of the current one.
+// The weight gradient splits the token axis over workgroups; partials go to a workspace and a second kernel folds them in
+// a fixed order (deterministic: no float atomics), the bias gradient rides along as the column sums of the dy tile.
+#include "common.hpp"
+
+namespace nnz {
+
+constexpr int D32_BK = 16;          // contraction steps per LDS block
+constexpr int D32_PITCH = 20;       // floats per LDS row: 80 bytes (16-byte aligned rows, 2-way conflicts at worst)
+
+__device__ __forceinline__ f32x16 mfma_f32x(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// tanh-free exact GELU (torch.nn.GELU default, approximate='none'): 0.5 x (1 + erf(x / sqrt 2))
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+struct D32Args {
+  const float* A;       // row operand source
+  const float* B;       // column operand source
+  float* out;           // [rows][ldo]
+  float* out2;          // forward + GELU: the activated copy (out keeps the pre-activation for the backward)
+  const float* bias;    // per column, or null
+  const float* aux;     // dgrad + GELU': pre-activation h[rows][cols] (same layout as out)
+  float* part_db;       // wgrad: [splits][rows] column sums of dy (null: none)
+  long a_rs, a_cs;      // element (row r, contraction c) of A at A[r * a_rs + c * a_cs]   (one of the two strides is 1)
+  long b_rs, b_cs;      // element (col j, contraction c) of B at B[j * b_rs + c * b_cs]
+  long ldo;
+  int rows, cols, kc;   // problem size: rows x cols outputs, contraction length kc (per split for wgrad)
+  int kc_total;         // wgrad: full contraction length (tokens); splits cut it into kc-sized ranges
+  long split_stride;    // wgrad: out + split * split_stride
+  int epi;              // 0 none / bias, 1 GELU (dual output), 2 multiply by GELU'(aux)
+};
+
+// stage a [NR rows][16 contraction steps] tile into LDS.  CONTIG: contraction index contiguous in memory (16-byte loads along
+// it), else the ROW index is contiguous (16-byte loads along 4 rows, scattered into the transposed image).
+template <int NR, bool CONTIG>
+struct D32Stage {
+  static constexpr int NV = NR * D32_BK / 4;           // 16-byte pieces per tile
+  static constexpr int LPT = (NV + 255) / 256;
+  f32x4 reg[LPT];
+  __device__ __forceinline__ void load(const float* src, long rs, long cs, int r0, int nrows, int c0, int nc, int tid) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int p = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < NV) {
+        if (CONTIG) {
+          const int r = p >> 2, c4 = (p & 3) * 4;     // 4 pieces of 4 steps per row
+          if (r0 + r < nrows && c0 + c4 < nc) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * rs + (c0 + c4));
+        } else {
+          // 4 consecutive rows at one contraction step; consecutive lanes walk the contraction index so that the
+          // transposed LDS writes of a wave land on 64 different banks (rows 4 apart are 16 banks apart at this pitch)
+          const int c = p & (D32_BK - 1), r4 = (p / D32_BK) * 4;
+          if (c0 + c < nc) {
+            const float* s = src + (long)(c0 + c) * cs + (r0 + r4);
+            if (r0 + r4 + 3 < nrows) {
+              v = *reinterpret_cast<const f32x4*>(s);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (r0 + r4 + e < nrows) v[e] = s[e];
+            }
+          }
+        }
+      }
+      reg[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int p = tid + i * 256;
+      if (p < NV) {
+        if (CONTIG) {
+          const int r = p >> 2, c4 = (p & 3) * 4;
+          *reinterpret_cast<f32x4*>(tile + r * D32_PITCH + c4) = reg[i];
+        } else {
+          const int c = p & (D32_BK - 1), r4 = (p / D32_BK) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tile[(r4 + e) * D32_PITCH + c] = reg[i][e];
+        }
+      }
+    }
+  }
+};
+
+// WM x WN MFMA tiles per wave; workgroup tile = (64 WM) rows x (64 WN) cols
+template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD>
+__global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  __shared__ __attribute__((aligned(16))) float sA[BM * D32_PITCH];
+  __shared__ __attribute__((aligned(16))) float sB[BN * D32_PITCH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;           // wave grid 2 x 2
+  const int ntc = (a.cols + BN - 1) / BN;
+  const int tile = blockIdx.x;
+  const int r0 = (tile / ntc) * BM, c0 = (tile % ntc) * BN;
+  const int split = blockIdx.y;
+  int k_begin = 0, k_end = a.kc;
+  if (WGRAD) {
+    k_begin = split * a.kc;
+    k_end = k_begin + a.kc < a.kc_total ? k_begin + a.kc : a.kc_total;
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float dbsum = 0.f;  // wgrad: this thread's row of the dy tile (tid < BM), summed over the contraction
+
+  D32Stage<BM, A_CONTIG> stA;
+  D32Stage<BN, B_CONTIG> stB;
+  stA.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k_begin, k_end, tid);
+  stB.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid);
+  for (int k0 = k_begin; k0 < k_end; k0 += D32_BK) {
+    __syncthreads();
+    stA.store(sA, tid);
+    stB.store(sB, tid);
+    __syncthreads();
+    if (k0 + D32_BK < k_end) {
+      stA.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0 + D32_BK, k_end, tid);
+      stB.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + D32_BK, k_end, tid);
+    }
+    if (WGRAD && a.part_db && c0 == 0 && tid < BM) {
+      const float* row = sA + tid * D32_PITCH;
+#pragma unroll
+      for (int q = 0; q < D32_BK; ++q) dbsum += row[q];
+    }
+#pragma unroll
+    for (int kb = 0; kb < D32_BK / 8; ++kb) {
+      f32x4 fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(sA + ((wr * WM + i) * 32 + l31) * D32_PITCH + kb * 8 + hh * 4);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        fb[j] = *reinterpret_cast<const f32x4*>(sB + ((wc * WN + j) * 32 + l31) * D32_PITCH + kb * 8 + hh * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = mfma_f32x(fa[i][s], fb[j][s], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: acc[i][j][r] = output (row = r0 + (wr WM + i) 32 + (r&3) + 8 (r>>2) + 4 hh, col = c0 + (wc WN + j) 32 + l31)
+  float* out = a.out + (WGRAD ? (long)split * a.split_stride : 0);
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = c0 + (wc * WN + j) * 32 + l31;
+    if (col >= a.cols) continue;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + (wr * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row >= a.rows) continue;
+        float v = acc[i][j][r] + bv;
+        const long o = (long)row * a.ldo + col;
+        if (a.epi == 2) v *= gelu_grad_f(a.aux[o]);
+        out[o] = v;
+        if (a.epi == 1) a.out2[o] = gelu_f(v);
+      }
+  }
+  if (WGRAD && a.part_db && c0 == 0 && tid < BM && r0 + tid < a.rows) a.part_db[(long)split * a.rows + r0 + tid] = dbsum;
+}
+
+// fold the weight-gradient partials in split order: dW[e] = sum_s part[s][e], db[n] = sum_s part_db[s][n]
+__global__ __launch_bounds__(256) void dense32_fold_kernel(const float* __restrict__ part, int splits, long n,
+                                                           float* __restrict__ dst, const float* __restrict__ part_db,
+                                                           int nb, float* __restrict__ db) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    float s = 0.f;
+    for (int q = 0; q < splits; ++q) s += part[(long)q * n + i];
+    dst[i] = s;
+  } else if (db && i - n < nb) {
+    const long j = i - n;
+    float s = 0.f;
+    for (int q = 0; q < splits; ++q) s += part_db[(long)q * nb + j];
+    db[j] = s;
+  }
+}
+
+template <bool AC, bool BC, bool WG>
+static int d32_launch(const D32Args& a, int splits, hipStream_t s) {
+  // tile choice: the largest tile that still gives the chip ~2 workgroups per CU
+  auto wgs = [&](int bm, int bn) { return (long)((a.rows + bm - 1) / bm) * ((a.cols + bn - 1) / bn) * splits; };
+  if (a.cols > 64 && a.rows > 64 && wgs(128, 128) >= 384) {
+    NNZ_LAUNCH((dense32_kernel<2, 2, AC, BC, WG>), dim3((unsigned)wgs(128, 128) / splits, splits), dim3(256), 0, s, a);
+  } else if (a.cols > 64 && wgs(64, 128) >= 256) {
+    NNZ_LAUNCH((dense32_kernel<1, 2, AC, BC, WG>), dim3((unsigned)wgs(64, 128) / splits, splits), dim3(256), 0, s, a);
+  } else {
+    NNZ_LAUNCH((dense32_kernel<1, 1, AC, BC, WG>), dim3((unsigned)wgs(64, 64) / splits, splits), dim3(256), 0, s, a);
+  }
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+}  // namespace nnz
+
+// y[T][N] = x[T][K] W[N][K]^T + bias;  gelu != 0: y keeps the pre-activation, y_act = GELU(y) (exact erf form)
+extern "C" int nnz_dense32_forward(const float* x, const float* W, const float* bias, float* y, float* y_act, long T, int K,
+                                   int N, int gelu, void* stream) {
+  using namespace nnz;
+  if (!x || !W || !y || T < 1 || T > (1L << 30) || K < 4 || N < 1 || (K & 3) || (gelu && !y_act)) return NNZ_EINVAL;
+  D32Args a = {};
+  a.A = x; a.a_rs = K; a.a_cs = 1;
+  a.B = W; a.b_rs = K; a.b_cs = 1;
+  a.out = y; a.out2 = y_act; a.bias = bias; a.ldo = N;
+  a.rows = (int)T; a.cols = N; a.kc = K; a.epi = gelu ? 1 : 0;
+  return d32_launch<true, true, false>(a, 1, (hipStream_t)stream);
+}
+
+// dx[T][K] = dy[T][N] W[N][K]  (* GELU'(h[T][K]) when h is given: the gradient w.r.t. the pre-activation of the layer below)
+extern "C" int nnz_dense32_dgrad(const float* dy, const float* W, const float* h, float* dx, long T, int K, int N,
+                                 void* stream) {
+  using namespace nnz;
+  if (!dy || !W || !dx || T < 1 || T > (1L << 30) || K < 1 || N < 4 || (N & 3) || (K & 3)) return NNZ_EINVAL;
+  D32Args a = {};
+  a.A = dy; a.a_rs = N; a.a_cs = 1;
+  a.B = W; a.b_rs = 1; a.b_cs = K;      // column j = input feature k: W[n][k], contraction n strided by K, rows contiguous
+  a.out = dx; a.aux = h; a.ldo = K;
+  a.rows = (int)T; a.cols = K; a.kc = N; a.epi = h ? 2 : 0;
+  return d32_launch<true, false, false>(a, 1, (hipStream_t)stream);
+}
+
+// token splits of the weight gradient: enough workgroups to fill the chip (~1536 with the 64 x 64 tile), at least 64
+// tokens each, at most 64 splits; `per` = tokens per split (a multiple of the contraction block)
+static long d32_wgrad_splits(long T, int K, int N, long* per_out) {
+  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  long splits = (1536 + tiles - 1) / tiles;
+  const long max_by_tokens = (T + 63) / 64;
+  if (splits > max_by_tokens) splits = max_by_tokens;
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  long per = (T + splits - 1) / splits;
+  per = (per + nnz::D32_BK - 1) / nnz::D32_BK * nnz::D32_BK;
+  if (per_out) *per_out = per;
+  return (T + per - 1) / per;
+}
+
+extern "C" long nnz_dense32_wgrad_workspace_floats(long T, int K, int N) {
+  if (T < 1 || K < 1 || N < 1) return 0;
+  const long splits = d32_wgrad_splits(T, K, N, nullptr);
+  return splits > 1 ? splits * ((long)N * K + N) : 1;
+}
+
+// dW[N][K] = sum_t dy[t][n] x[t][k];  db[n] = sum_t dy[t][n] (db may be null).  Deterministic: token splits write partials
+// into `workspace` (nnz_dense32_wgrad_workspace_floats), folded in split order.
+extern "C" int nnz_dense32_wgrad(const float* dy, const float* x, float* dW, float* db, float* workspace, long T, int K,
+                                 int N, void* stream) {
+  using namespace nnz;
+  if (!dy || !x || !dW || !workspace || T < 1 || T > (1L << 30) || (K & 3) || (N & 3) || K < 4 || N < 4) return NNZ_EINVAL;
+  long per = 0;
+  const long splits = d32_wgrad_splits(T, K, N, &per);
+  D32Args a = {};
+  a.A = dy; a.a_rs = 1; a.a_cs = N;     // row = n, contraction = token t (stride N)
+  a.B = x; a.b_rs = 1; a.b_cs = K;      // col = k, contraction = token t (stride K)
+  a.ldo = K; a.rows = N; a.cols = K; a.kc = (int)per; a.kc_total = (int)T;
+  hipStream_t s = (hipStream_t)stream;
+  if (splits == 1) {
+    a.out = dW; a.split_stride = 0; a.part_db = db;
+    return d32_launch<false, false, true>(a, 1, s);
+  }
+  a.out = workspace; a.split_stride = (long)N * K;
+  a.part_db = db ? workspace + splits * (long)N * K : nullptr;
+  const int rc = d32_launch<false, false, true>(a, (int)splits, s);
+  if (rc != NNZ_OK) return rc;
+  const long n = (long)N * K;
+  const long total = n + (db ? N : 0);
+  NNZ_LAUNCH(dense32_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
+             (int)splits, n, dW, (const float*)a.part_db, N, db);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

@@ -112,9 +112,10 @@ __global__ __launch_bounds__(256) void dc_ce_fwd_kernel(LossArgs<T> a) {
   const int S = 3 * a.C + 1;
   if (a.acc) {
     if (tid < S)
-      fx_add(a.acc + (long)b * S + tid, (double)((lwave[0][tid] + lwave[1][tid]) + (lwave[2][tid] + lwave[3][tid])));
+      fx_add(a.acc, (long)b * S + tid, (long)a.B * S, blockIdx.x,
+             (double)((lwave[0][tid] + lwave[1][tid]) + (lwave[2][tid] + lwave[3][tid])));
     if (last_workgroup(a.counter, gridDim.x * gridDim.y))
-      for (int i = tid; i < a.B * S; i += 256) a.sums[i] = (float)fx_take(a.acc + i);
+      for (int i = tid; i < a.B * S; i += 256) a.sums[i] = (float)fx_take(a.acc, i, (long)a.B * S);
     return;
   }
   if (tid < S) atomicAdd(a.sums + (long)b * S + tid, lred[tid]);

@@ -200,22 +200,23 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
           s0 += lred[rr * C2 + c * 2 + 0];
           s1 += lred[rr * C2 + c * 2 + 1];
         }
-        FxAcc* acc = a.acc + ((long)n * a.C + c) * 2;
+        const long rec = ((long)n * a.C + c) * 2, nrec = (long)a.N * a.C * 2;
         if (MODE == 0) {
           const double cnt = (double)(v1 - v0);
           const double k = (double)(float)a.x[((long)n * a.V + v0) * a.ldx + c];
-          fx_add(acc, (double)s0 + cnt * k);
-          fx_add(acc + 1, (double)s1 + 2.0 * k * (double)s0 + cnt * k * k);
+          fx_add(a.acc, rec, nrec, blockIdx.x, (double)s0 + cnt * k);
+          fx_add(a.acc, rec + 1, nrec, blockIdx.x, (double)s1 + 2.0 * k * (double)s0 + cnt * k * k);
         } else {
-          fx_add(acc, (double)s0);
-          fx_add(acc + 1, (double)s1);
+          fx_add(a.acc, rec, nrec, blockIdx.x, (double)s0);
+          fx_add(a.acc, rec + 1, nrec, blockIdx.x, (double)s1);
         }
       }
       if (last_workgroup(a.counter, gridDim.x * gridDim.y)) {
         const double V = (double)a.V;
+        const long nrec = (long)a.N * a.C * 2;
         if (MODE == 0) {
           for (int i = tid; i < a.N * a.C; i += 256) {
-            const double sx = fx_take(a.acc + (long)i * 2), sq = fx_take(a.acc + (long)i * 2 + 1);
+            const double sx = fx_take(a.acc, (long)i * 2, nrec), sq = fx_take(a.acc, (long)i * 2 + 1, nrec);
             if (a.sums) {
               a.sums[(long)i * 2 + 0] = (float)sx;
               a.sums[(long)i * 2 + 1] = (float)sq;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
             double sg = 0.0, sb = 0.0;
             for (int nn = 0; nn < a.N; ++nn) {
               const long i = (long)nn * a.C + c;
-              const double r0 = fx_take(a.acc + i * 2), r1 = fx_take(a.acc + i * 2 + 1);
+              const double r0 = fx_take(a.acc, i * 2, nrec), r1 = fx_take(a.acc, i * 2 + 1, nrec);
               a.nred[i * 2 + 0] = (float)(r0 / V);
               a.nred[i * 2 + 1] = (float)(r1 / V);
               sb += r0;

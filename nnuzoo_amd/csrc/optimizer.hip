@@ -53,12 +53,12 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
     // gradient makes the block's partial non-finite, which poisons the accumulator: the total reads back NaN and the
     // count of bad entries below stays the inf-skip flag.
     if (threadIdx.x == 0) {
-      fx_add(acc, (double)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])));
-      fx_add(acc + 1, (double)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
+      fx_add(acc, 0, 2, blockIdx.x, (double)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])));
+      fx_add(acc, 1, 2, blockIdx.x, (double)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
     }
     if (last_workgroup(counter, gridDim.x) && threadIdx.x == 0) {
-      out2[0] = (float)fx_take(acc);
-      out2[1] = (float)fx_take(acc + 1);
+      out2[0] = (float)fx_take(acc, 0, 2);
+      out2[1] = (float)fx_take(acc, 1, 2);
     }
     return;
   }

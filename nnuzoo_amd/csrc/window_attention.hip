@@ -8,18 +8,35 @@
 // merged-head result to the (B, H, W, C) position it came from: the four rearrange/roll copies of the reference
 // (each a full read + write of the activation) never exist.  The shift mask is computed from region ids on the fly.
 //
-// One wave per (window, head).  v_mfma_f32_32x32x2_f32 (exact fp32, matching the reference's fp32 trainer
-// nnUNetTrainerSwT2Net.train_step, no autocast).  The score tile is computed TRANSPOSED (keys on rows, queries on
-// lanes): a query's 64 (49 + pad) scores then live in two lanes' registers, so softmax needs one lane exchange
-// instead of a 32-lane reduction, and P^T feeds the PV MFMA as its B operand with no data movement
-// (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand", T12).
+// v_mfma_f32_32x32x2_f32 (exact fp32, matching the reference's fp32 trainer nnUNetTrainerSwT2Net.train_step, no autocast).
+// The score tile is computed TRANSPOSED (keys on rows, queries on lanes): a query's 64 (49 + pad) scores then live in two
+// lanes' registers, so softmax needs one lane exchange instead of a 32-lane reduction, and P^T feeds the PV MFMA as its B
+// operand with no data movement (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand", T12).
+//
+// Round 3 (the round-2 kernels ran one wave per workgroup, staged q / k / v through 25-34 KB of LDS per wave - one wave
+// per SIMD - and fetched the relative-position bias with two dependent GLOBAL loads per score: 26 us forward / 75 us
+// backward per call at ~0.02 of the fp32 MFMA rate):
+//   * a workgroup = 4 waves = one HEAD and a run of windows: the head's 49 x 49 bias matrix is gathered ONCE into LDS
+//     (transposed, so that the lanes of a score register read consecutive words) and serves every window of the run;
+//   * the contraction over channels may visit the channels in any order as long as both operands agree, so lane half hh
+//     simply owns channels [hh hd/2, (hh+1) hd/2) of its token's row: Q / K / V / dO "row" operands are 16-byte GLOBAL
+//     loads straight into the MFMA operand registers - no LDS, no transposition;
+//   * operands needed with the TOKEN index in the contraction (V in the forward; K, Q, dO in the backward) are read per
+//     MFMA step as one coalesced row segment (lane = channel), also straight from global memory (the rows were just read
+//     as row operands: L2 hits) - no operand is staged in LDS at all, 15 KB (forward) / 47 KB (backward) per workgroup;
+//   * the bias-table gradient is DETERMINISTIC: dS goes through LDS once per key tile, each of the 169 table entries
+//     (entry = displacement (yi - yj, xi - xj), the layout of the reference's relative_position_index, swt2net.py:545)
+//     sums its (7 - |dy|)(7 - |dx|) members in a fixed order, waves are folded in wave order and workgroups add
+//     fixed-point integers (common.hpp FxAcc) - no float atomics anywhere.
 #include "common.hpp"
 
 namespace nnz {
 
 constexpr int WA_L = 49;   // tokens per window
 constexpr int WA_WS = 7;
-constexpr int WA_LD = 33;  // LDS row stride (floats): head_dim <= 32, +1 pad -> conflict-free column reads
+constexpr int WA_LD = 33;  // LDS row stride (floats) of a [token][channel] image: head_dim <= 32, +1 pad
+constexpr int WA_NBIAS = (2 * WA_WS - 1) * (2 * WA_WS - 1);
+constexpr int WA_BP = 64;  // pitch of the transposed bias matrix sbT[key][query]
 
 struct AttnArgs {
   const float* qkv;    // [B][H][W][3C]
@@ -28,8 +45,11 @@ struct AttnArgs {
   float* out;          // [B][H][W][C]
   const float* dout;   // [B][H][W][C]
   float* dqkv;         // [B][H][W][3C]
-  float* dbias;        // gradient of the table [169][heads] (atomic, zeroed by launcher)
+  float* dbias;        // gradient of the table [169][heads] (written by the launch's last workgroup)
+  FxAcc* acc;          // [heads][169] fixed-point accumulators + launch counter (backward)
+  unsigned* counter;
   int B, H, W, C, heads, hd, shift;
+  int nwin, wpb;       // windows in total, windows per workgroup
   float scale;
 };
 
@@ -38,12 +58,8 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-struct TokenMap {
-  long base;   // element offset of the token's (b, y, x) position, in units of "C" (multiply by row length)
-  int region;  // shift-mask region id (0 when not shifted)
-};
-
-__device__ __forceinline__ TokenMap token_map(const AttnArgs& a, int win, int l) {
+// token l of window `win`: element offset of its (b, y, x) position in units of one token row, and its shift-mask region
+__device__ __forceinline__ void token_map(const AttnArgs& a, int win, int l, int& base, int& region) {
   const int nww = a.W / WA_WS, nwh = a.H / WA_WS;
   const int b = win / (nwh * nww);
   const int wi = (win / nww) % nwh, wj = win % nww;
@@ -51,35 +67,36 @@ __device__ __forceinline__ TokenMap token_map(const AttnArgs& a, int win, int l)
   int y = r + a.shift, x = c + a.shift;
   if (y >= a.H) y -= a.H;
   if (x >= a.W) x -= a.W;
-  TokenMap m;
-  m.base = ((long)b * a.H + y) * a.W + x;
-  m.region = 0;
+  base = (b * a.H + y) * a.W + x;
+  region = 0;
   if (a.shift > 0) {
     const int hid = r < a.H - WA_WS ? 0 : (r < a.H - a.shift ? 1 : 2);
     const int wid = c < a.W - WA_WS ? 0 : (c < a.W - a.shift ? 1 : 2);
-    m.region = 3 * hid + wid;
+    region = 3 * hid + wid;
   }
-  return m;
 }
 
-// stage one [49][hd] operand (rows >= 49 and columns >= hd zero-filled) into an LDS image [64][WA_LD]
-__device__ __forceinline__ void stage(const AttnArgs& a, const float* src, int row_len, int ch0, int win, float mul,
-                                      float* dst, int lane) {
-  for (int i = lane; i < 64 * WA_LD; i += 64) dst[i] = 0.f;
-  __syncthreads();
-  if ((a.hd & 3) == 0) {
-    const int q4 = a.hd >> 2;
-    for (int i = lane; i < WA_L * q4; i += 64) {
-      const int l = i / q4, c4 = (i % q4) * 4;
-      const TokenMap m = token_map(a, win, l);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + m.base * row_len + ch0 + c4);
-      float* d = dst + l * WA_LD + c4;
-      d[0] = v[0] * mul; d[1] = v[1] * mul; d[2] = v[2] * mul; d[3] = v[3] * mul;
-    }
-  } else {  // head_dim not a multiple of 4: scalar staging
-    for (int i = lane; i < WA_L * a.hd; i += 64) {
-      const int l = i / a.hd, c = i % a.hd;
-      dst[l * WA_LD + c] = src[token_map(a, win, l).base * row_len + ch0 + c] * mul;
+// "row" operand of one 32-token tile: lane (token l31, half hh) gets channels hh*hd/2 + s, s = 0 .. hd/2 - 1, of its
+// token's row (zeros for tokens >= 49): the contraction over channels visits them in this order for BOTH operands.
+__device__ __forceinline__ void load_rows(const float* src, long row_len, int ch0, int hd, const int* stok, int tile,
+                                          int l31, int hh, float mul, float (&v)[16]) {
+  const int l = tile * 32 + l31;
+  const int half = hd >> 1;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) v[s] = 0.f;
+  if (l < WA_L) {
+    const float* p = src + (long)stok[l] * row_len + ch0 + hh * half;
+    if ((hd & 7) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * q < half) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+          v[4 * q] = t[0] * mul; v[4 * q + 1] = t[1] * mul; v[4 * q + 2] = t[2] * mul; v[4 * q + 3] = t[3] * mul;
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (s < half) v[s] = p[s] * mul;
     }
   }
 }
@@ -102,252 +119,269 @@ __device__ __forceinline__ void store_cols(float* dst, const f32x16& o, int hh, 
   }
 }
 
-// region id of every token of the window (0 when not shifted), computed once per workgroup
-__device__ __forceinline__ void stage_regions(const AttnArgs& a, int win, int* sreg, int lane) {
-  sreg[lane] = (a.shift > 0 && lane < WA_L) ? token_map(a, win, lane).region : 0;
+// the head's bias matrix, transposed: sbT[key j][query i] = table[index[i][j]][head]   (one gather per workgroup)
+__device__ __forceinline__ void stage_bias(const AttnArgs& a, int head, float* sbT, int tid, int nthreads) {
+  for (int e = tid; e < WA_L * WA_L; e += nthreads) {
+    const int i = e / WA_L, j = e - i * WA_L;
+    sbT[j * WA_BP + i] = a.bias[a.bidx[e] * a.heads + head];
+  }
 }
 
-// S^T = K Q^T (+ bias^T + mask), softmax over keys per query.  On return p[tk][tq][r] = P[query][key] for
-// query = tq*32 + (lane&31), key = tk*32 + crow(r, lane>>5); also returns nothing else (m/l are folded in).
-__device__ __forceinline__ void scores_T(const AttnArgs& a, const float* sq, const float* sk, const int* sreg,
-                                         int head, int lane, f32x16 (&p)[2][2]) {
-  const int l31 = lane & 31, hh = lane >> 5;
+// wave-private LDS hand-over (one wave writes, the same wave's other lanes read): LDS instructions of a wave execute in
+// order; the fence keeps the compiler from moving accesses across
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// S^T tiles of one query tile tq: s[tk] (keys tk*32 + crow(r, hh) on rows, query tq*32 + l31 on the lane) from the row
+// operands, + bias + mask, softmax over the keys.  Returns P^T in s; m / inv are the query's row max and 1 / sum.
+__device__ __forceinline__ void scores_T(const float (&kv)[2][16], const float (&qv)[16], int steps, const float* sbT,
+                                         const int* sreg, int shift, int tq, int l31, int hh, f32x16 (&s)[2], float& m_out,
+                                         float& inv_out) {
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
+    for (int r = 0; r < 16; ++r) s[x][r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) p[x][y][r] = 0.f;
-  for (int kk = 0; kk < a.hd / 2; ++kk) {
-    const int c = 2 * kk + hh;
-    const float k0 = sk[l31 * WA_LD + c], k1 = sk[(32 + l31) * WA_LD + c];
-    const float q0 = sq[l31 * WA_LD + c], q1 = sq[(32 + l31) * WA_LD + c];
-    p[0][0] = mfma_f32(k0, q0, p[0][0]);
-    p[0][1] = mfma_f32(k0, q1, p[0][1]);
-    p[1][0] = mfma_f32(k1, q0, p[1][0]);
-    p[1][1] = mfma_f32(k1, q1, p[1][1]);
-  }
-  const float* bias = a.bias + head;
+  for (int st = 0; st < 16; ++st)
+    if (st < steps) {
+      s[0] = mfma_f32(kv[0][st], qv[st], s[0]);
+      s[1] = mfma_f32(kv[1][st], qv[st], s[1]);
+    }
+  const int i = tq * 32 + l31;
+  const int ic = i < WA_L ? i : WA_L - 1;
+  const int reg_i = shift ? sreg[ic] : 0;
+  float m = -3.0e38f;
 #pragma unroll
-  for (int tq = 0; tq < 2; ++tq) {
-    const int i = tq * 32 + l31;
-    const int ic = i < WA_L ? i : WA_L - 1;
-    const int reg_i = sreg[ic];
-    float m = -3.0e38f;
+  for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = tk * 32 + crow(r, hh);
+      float x = -3.0e38f;
+      if (j < WA_L) {
+        x = s[tk][r] + sbT[j * WA_BP + ic];
+        if (shift && sreg[j] != reg_i) x += -100.f;
+      }
+      s[tk][r] = x;
+      m = fmaxf(m, x);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = tk * 32 + crow(r, hh);
+      const float e = j < WA_L ? __expf(s[tk][r] - m) : 0.f;
+      s[tk][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[tk][r] *= inv;
+  m_out = m;
+  inv_out = inv;
+}
+
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
+  __shared__ float sbT[WA_L * WA_BP];
+  __shared__ int stok_all[4][64], sreg_all[4][64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y;
+  const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
+  int* stok = stok_all[wave];
+  int* sreg = sreg_all[wave];
+  stage_bias(a, head, sbT, tid, 256);
+  __syncthreads();
+  const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
+  for (int win = blockIdx.x * a.wpb + wave; win < w_end; win += 4) {
+    wave_sync();  // the previous window's readers are done with stok / sreg
+    {
+      int base = 0, region = 0;
+      if (lane < WA_L) token_map(a, win, lane, base, region);
+      stok[lane] = base;
+      sreg[lane] = region;
+    }
+    wave_sync();
+    float kv[2][16];
+    load_rows(a.qkv, C3, a.C + head * hd, hd, stok, 0, l31, hh, 1.f, kv[0]);
+    load_rows(a.qkv, C3, a.C + head * hd, hd, stok, 1, l31, hh, 1.f, kv[1]);
+    // V with the KEY in the contraction: step r of key tile tk needs V[key tk*32 + crow(r, hh)][channel l31] - one
+    // coalesced row segment per lane half
+    float vc[2][16];
 #pragma unroll
     for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = tk * 32 + crow(r, hh);
-        float s = -3.0e38f;
-        if (j < WA_L) {
-          s = p[tk][tq][r] + bias[a.bidx[ic * WA_L + j] * a.heads];
-          if (sreg[j] != reg_i) s += -100.f;
-        }
-        p[tk][tq][r] = s;
-        m = fmaxf(m, s);
+        vc[tk][r] = (j < WA_L && l31 < hd) ? a.qkv[(long)stok[j] * C3 + 2 * a.C + head * hd + l31] : 0.f;
       }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = tk * 32 + crow(r, hh);
-        const float e = j < WA_L ? __expf(p[tk][tq][r] - m) : 0.f;
-        p[tk][tq][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[tk][tq][r] *= inv;
-  }
-}
-
-__global__ __launch_bounds__(64) void win_attn_fwd_kernel(AttnArgs a) {
-  __shared__ float sq[64 * WA_LD], sk[64 * WA_LD], sv[64 * WA_LD];
-  __shared__ int sreg[64];
-  const int lane = threadIdx.x;
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int win = blockIdx.x, head = blockIdx.y;
-  const int C3 = 3 * a.C;
-  stage_regions(a, win, sreg, lane);
-  stage(a, a.qkv, C3, head * a.hd, win, a.scale, sq, lane);
-  stage(a, a.qkv, C3, a.C + head * a.hd, win, 1.f, sk, lane);
-  stage(a, a.qkv, C3, 2 * a.C + head * a.hd, win, 1.f, sv, lane);
-  __syncthreads();
-  f32x16 p[2][2];
-  scores_T(a, sq, sk, sreg, head, lane, p);
-  // O^T[p][query] = sum_key V[key][p] * P^T[key][query]
-#pragma unroll
-  for (int tq = 0; tq < 2; ++tq) {
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o = mfma_f32(sv[(tk * 32 + crow(r, hh)) * WA_LD + l31], p[tk][tq][r], o);
-    const int i = tq * 32 + l31;
-    if (i < WA_L) {
-      store_cols(a.out + token_map(a, win, i).base * a.C + head * a.hd, o, hh, a.hd, 1.f);
-    }
-  }
-}
-
-// backward.  Pass A (transposed orientation, queries on lanes): P^T, dP^T, delta, dS^T -> dQ.
-//            Pass B (queries on rows): P, dP, dS -> dV, dK, dbias.  Row statistics cross from A to B through LDS.
-__global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
-  __shared__ float sq[64 * WA_LD], sk[64 * WA_LD], sv[64 * WA_LD], sdo[64 * WA_LD];
-  __shared__ float srow[3][64];  // per query: row max m, 1/sum, delta
-  __shared__ int sreg[64];
-  // gradient of the relative-position bias table: summed per (window, head) in LDS first (for a fixed query the 49 keys
-  // hit 49 different table entries, so the LDS atomics of a step do not collide), then ONE global atomic per table entry.
-  // The first version issued all 2401 atomics per (window, head) straight at the (169, heads) table: ~10 000 colliding
-  // atomics per address made the backward 16x slower than the forward.
-  constexpr int NBIAS = (2 * WA_WS - 1) * (2 * WA_WS - 1);
-  __shared__ float sdb[NBIAS];
-  const int lane = threadIdx.x;
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int win = blockIdx.x, head = blockIdx.y;
-  const int C3 = 3 * a.C;
-  for (int i = lane; i < NBIAS; i += 64) sdb[i] = 0.f;
-  stage_regions(a, win, sreg, lane);
-  stage(a, a.qkv, C3, head * a.hd, win, a.scale, sq, lane);
-  stage(a, a.qkv, C3, a.C + head * a.hd, win, 1.f, sk, lane);
-  stage(a, a.qkv, C3, 2 * a.C + head * a.hd, win, 1.f, sv, lane);
-  stage(a, a.dout, a.C, head * a.hd, win, 1.f, sdo, lane);
-  __syncthreads();
-  const float* bias = a.bias + head;
-
-  // ---------------- pass A ------------------------------------------------------------------------------------
-  {
-    f32x16 s[2][2], dp[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s[x][y][r] = 0.f;
-          dp[x][y][r] = 0.f;
-        }
-    for (int kk = 0; kk < a.hd / 2; ++kk) {
-      const int c = 2 * kk + hh;
-      const float k0 = sk[l31 * WA_LD + c], k1 = sk[(32 + l31) * WA_LD + c];
-      const float q0 = sq[l31 * WA_LD + c], q1 = sq[(32 + l31) * WA_LD + c];
-      const float v0 = sv[l31 * WA_LD + c], v1 = sv[(32 + l31) * WA_LD + c];
-      const float g0 = sdo[l31 * WA_LD + c], g1 = sdo[(32 + l31) * WA_LD + c];
-      s[0][0] = mfma_f32(k0, q0, s[0][0]);
-      s[0][1] = mfma_f32(k0, q1, s[0][1]);
-      s[1][0] = mfma_f32(k1, q0, s[1][0]);
-      s[1][1] = mfma_f32(k1, q1, s[1][1]);
-      dp[0][0] = mfma_f32(v0, g0, dp[0][0]);  // dP^T[key][query] = sum_c V[key][c] dO[query][c]
-      dp[0][1] = mfma_f32(v0, g1, dp[0][1]);
-      dp[1][0] = mfma_f32(v1, g0, dp[1][0]);
-      dp[1][1] = mfma_f32(v1, g1, dp[1][1]);
-    }
-#pragma unroll
+#pragma unroll 1
     for (int tq = 0; tq < 2; ++tq) {
-      const int i = tq * 32 + l31;
-      const int ic = i < WA_L ? i : WA_L - 1;
-      const int reg_i = sreg[ic];
-      float m = -3.0e38f;
-#pragma unroll
-      for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = tk * 32 + crow(r, hh);
-          float x = -3.0e38f;
-          if (j < WA_L) {
-            x = s[tk][tq][r] + bias[a.bidx[ic * WA_L + j] * a.heads];
-            if (sreg[j] != reg_i) x += -100.f;
-          }
-          s[tk][tq][r] = x;
-          m = fmaxf(m, x);
-        }
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = tk * 32 + crow(r, hh);
-          const float e = j < WA_L ? __expf(s[tk][tq][r] - m) : 0.f;
-          s[tk][tq][r] = e;
-          sum += e;
-        }
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.f / sum;
-      float delta = 0.f;
-#pragma unroll
-      for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s[tk][tq][r] *= inv;  // P^T
-          delta += s[tk][tq][r] * dp[tk][tq][r];
-        }
-      delta += __shfl_xor(delta, 32, 64);
-      if (hh == 0) {
-        srow[0][i] = m;
-        srow[1][i] = inv;
-        srow[2][i] = delta;
-      }
-#pragma unroll
-      for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[tk][tq][r] *= (dp[tk][tq][r] - delta);  // dS^T
-      // dQ^T[c][query] = scale * sum_key K[key][c] dS^T[key][query]
+      float qv[16];
+      load_rows(a.qkv, C3, head * hd, hd, stok, tq, l31, hh, a.scale, qv);
+      f32x16 p[2];
+      float m, inv;
+      scores_T(kv, qv, steps, sbT, sreg, a.shift, tq, l31, hh, p, m, inv);
+      // O^T[channel][query] = sum_key V[key][channel] P^T[key][query]
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
       for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o = mfma_f32(sk[(tk * 32 + crow(r, hh)) * WA_LD + l31], s[tk][tq][r], o);
-      if (i < WA_L) {
-        store_cols(a.dqkv + token_map(a, win, i).base * C3 + head * a.hd, o, hh, a.hd, a.scale);
-      }
+        for (int r = 0; r < 16; ++r) o = mfma_f32(vc[tk][r], p[tk][r], o);
+      const int i = tq * 32 + l31;
+      if (i < WA_L) store_cols(a.out + (long)stok[i] * a.C + head * hd, o, hh, hd, 1.f);
     }
   }
-  __syncthreads();
+}
 
-  // ---------------- pass B: queries on rows, keys on lanes ------------------------------------------------------
-  {
-    f32x16 s[2][2], dp[2][2];  // [tq][tk]: row = query tq*32 + crow(r, hh), col = key tk*32 + l31
+// "column" operand: step r of a 32-token tile needs X[token tile*32 + crow(r, hh)][channel l31] - the token index is the
+// contraction index of the MFMA, the lane is the channel: one coalesced row segment per lane half and step, straight from
+// global memory (the rows were just read as row operands: L2 hits)
+__device__ __forceinline__ void load_cols(const float* src, long row_len, int ch0, int hd, const int* stok, int tile,
+                                          int l31, int hh, float mul, float (&v)[16]) {
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s[x][y][r] = 0.f;
-          dp[x][y][r] = 0.f;
-        }
-    for (int kk = 0; kk < a.hd / 2; ++kk) {
-      const int c = 2 * kk + hh;
-      const float k0 = sk[l31 * WA_LD + c], k1 = sk[(32 + l31) * WA_LD + c];
-      const float q0 = sq[l31 * WA_LD + c], q1 = sq[(32 + l31) * WA_LD + c];
-      const float v0 = sv[l31 * WA_LD + c], v1 = sv[(32 + l31) * WA_LD + c];
-      const float g0 = sdo[l31 * WA_LD + c], g1 = sdo[(32 + l31) * WA_LD + c];
-      s[0][0] = mfma_f32(q0, k0, s[0][0]);
-      s[0][1] = mfma_f32(q0, k1, s[0][1]);
-      s[1][0] = mfma_f32(q1, k0, s[1][0]);
-      s[1][1] = mfma_f32(q1, k1, s[1][1]);
-      dp[0][0] = mfma_f32(g0, v0, dp[0][0]);  // dP[query][key] = sum_c dO[query][c] V[key][c]
-      dp[0][1] = mfma_f32(g0, v1, dp[0][1]);
-      dp[1][0] = mfma_f32(g1, v0, dp[1][0]);
-      dp[1][1] = mfma_f32(g1, v1, dp[1][1]);
+  for (int r = 0; r < 16; ++r) {
+    const int j = tile * 32 + crow(r, hh);
+    v[r] = (j < WA_L && l31 < hd) ? src[(long)stok[j] * row_len + ch0 + l31] * mul : 0.f;
+  }
+}
+
+// backward.  Pass A (transposed orientation, queries on lanes): P^T, dP^T, delta, dS^T -> dQ.
+//            Pass B (queries on rows, keys on lanes): P, dP, dS -> dV, dK, and dS -> the bias-table gradient.
+// Row statistics cross from A to B through LDS.  No operand is staged: LDS holds the head's bias matrix (per workgroup)
+// and per wave the row statistics, the token map and one [49][33] dS tile for the bias-gradient sums: 47 KB per workgroup,
+// three workgroups per CU.
+constexpr int WA_DSP = 33;                                    // pitch of the per-key-tile dS image [query][key - 32 tk]
+constexpr int WA_WAVE_FLOATS = WA_L * WA_DSP + 3 * 64 + 2 * 64;  // sds | srow[3][64] | stok, sreg
+
+__global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sbT = smem;                                   // [49][64]
+  float* sdb_all = smem + WA_L * WA_BP;                // [4 waves][176]
+  float* wbase = sdb_all + 4 * 176;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y;
+  const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
+  float* sds = wbase + wave * WA_WAVE_FLOATS;          // dS[query][key - 32 tk] of the current key tile
+  float* srow = sds + WA_L * WA_DSP;                   // [3][64]: row max, 1 / sum, delta per query
+  int* stok = reinterpret_cast<int*>(srow + 3 * 64);
+  int* sreg = stok + 64;
+  float* sdb = sdb_all + wave * 176;
+  const int qo = head * hd, ko = a.C + head * hd, vo = 2 * a.C + head * hd;
+  stage_bias(a, head, sbT, tid, 256);
+  // the wave's share of the bias-table gradient: lane owns table entries lane, lane + 64, lane + 128
+  float db_acc[3] = {0.f, 0.f, 0.f};
+  __syncthreads();
+  const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
+  for (int win = blockIdx.x * a.wpb + wave; win < w_end; win += 4) {
+    wave_sync();
+    {
+      int base = 0, region = 0;
+      if (lane < WA_L) token_map(a, win, lane, base, region);
+      stok[lane] = base;
+      sreg[lane] = region;
     }
-    float* dbias = a.dbias + head;
+    wave_sync();
+
+    // ---------------- pass A: keys on rows, queries on lanes --------------------------------------------------------
+#pragma unroll 1
+    for (int tq = 0; tq < 2; ++tq) {
+      float qv[16], gv[16];
+      load_rows(a.qkv, C3, qo, hd, stok, tq, l31, hh, a.scale, qv);
+      load_rows(a.dout, a.C, qo, hd, stok, tq, l31, hh, 1.f, gv);
+      f32x16 s[2], dp[2];
+      float m, inv;
+      {
+        float kv[2][16];
+        load_rows(a.qkv, C3, ko, hd, stok, 0, l31, hh, 1.f, kv[0]);
+        load_rows(a.qkv, C3, ko, hd, stok, 1, l31, hh, 1.f, kv[1]);
+        scores_T(kv, qv, steps, sbT, sreg, a.shift, tq, l31, hh, s, m, inv);  // s = P^T
+      }
 #pragma unroll
+      for (int tk = 0; tk < 2; ++tk) {
+        float vv[16];
+        load_rows(a.qkv, C3, vo, hd, stok, tk, l31, hh, 1.f, vv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[tk][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+          if (st < steps) dp[tk] = mfma_f32(vv[st], gv[st], dp[tk]);  // dP^T[key][query] = sum_c V[key][c] dO[query][c]
+      }
+      float delta = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) delta += s[tk][r] * dp[tk][r];
+      delta += __shfl_xor(delta, 32, 64);
+      const int i = tq * 32 + l31;
+      if (hh == 0) {
+        srow[i] = m;
+        srow[64 + i] = inv;
+        srow[128 + i] = delta;
+      }
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[tk][r] *= (dp[tk][r] - delta);  // dS^T
+      // dQ^T[c][query] = scale * sum_key K[key][c] dS^T[key][query]
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk) {
+        float kc[16];
+        load_cols(a.qkv, C3, ko, hd, stok, tk, l31, hh, 1.f, kc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = mfma_f32(kc[r], s[tk][r], o);
+      }
+      if (i < WA_L) store_cols(a.dqkv + (long)stok[i] * C3 + qo, o, hh, hd, a.scale);
+    }
+    wave_sync();  // srow is complete
+
+    // ---------------- pass B: queries on rows, keys on lanes ---------------------------------------------------------
+    // the row operands with roles swapped: A = Q (rows = queries), B = K (cols = keys); dP: A = dO, B = V
+#pragma unroll 1
     for (int tk = 0; tk < 2; ++tk) {
+      f32x16 s[2], dp[2];  // [tq]
+      {
+        float kv[16], vv[16];
+        load_rows(a.qkv, C3, ko, hd, stok, tk, l31, hh, 1.f, kv);
+        load_rows(a.qkv, C3, vo, hd, stok, tk, l31, hh, 1.f, vv);
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+          float qr[16], gr[16];
+          load_rows(a.qkv, C3, qo, hd, stok, tq, l31, hh, a.scale, qr);
+          load_rows(a.dout, a.C, qo, hd, stok, tq, l31, hh, 1.f, gr);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            s[tq][r] = 0.f;
+            dp[tq][r] = 0.f;
+          }
+#pragma unroll
+          for (int st = 0; st < 16; ++st)
+            if (st < steps) {
+              s[tq] = mfma_f32(qr[st], kv[st], s[tq]);
+              dp[tq] = mfma_f32(gr[st], vv[st], dp[tq]);
+            }
+        }
+      }
       const int j = tk * 32 + l31;
       const int jc = j < WA_L ? j : WA_L - 1;
-      const int reg_j = sreg[jc];
+      const int reg_j = a.shift ? sreg[jc] : 0;
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
@@ -355,15 +389,14 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
           const int i = tq * 32 + crow(r, hh);
           float pv = 0.f, ds = 0.f;
           if (i < WA_L && j < WA_L) {
-            const int bx = a.bidx[i * WA_L + j];
-            float x = s[tq][tk][r] + bias[bx * a.heads];
-            if (sreg[i] != reg_j) x += -100.f;
-            pv = __expf(x - srow[0][i]) * srow[1][i];
-            ds = pv * (dp[tq][tk][r] - srow[2][i]);
-            __hip_atomic_fetch_add(sdb + bx, ds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            float x = s[tq][r] + sbT[j * WA_BP + i];
+            if (a.shift && sreg[i] != reg_j) x += -100.f;
+            pv = __expf(x - srow[i]) * srow[64 + i];
+            ds = pv * (dp[tq][r] - srow[128 + i]);
           }
-          s[tq][tk][r] = pv;   // P[query][key]
-          dp[tq][tk][r] = ds;  // dS[query][key]
+          s[tq][r] = pv;    // P[query][key]
+          dp[tq][r] = ds;   // dS[query][key]
+          if (i < WA_L) sds[i * WA_DSP + l31] = ds;
         }
       // dV^T[c][key] = sum_query dO[query][c] P[query][key];  dK^T[c][key] = sum_query Qs[query][c] dS[query][key]
       f32x16 ov, ok;
@@ -373,29 +406,71 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(AttnArgs a) {
         ok[r] = 0.f;
       }
 #pragma unroll
-      for (int tq = 0; tq < 2; ++tq)
+      for (int tq = 0; tq < 2; ++tq) {
+        float gc[16], qc[16];
+        load_cols(a.dout, a.C, qo, hd, stok, tq, l31, hh, 1.f, gc);
+        load_cols(a.qkv, C3, qo, hd, stok, tq, l31, hh, a.scale, qc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int i = tq * 32 + crow(r, hh);
-          ov = mfma_f32(sdo[i * WA_LD + l31], s[tq][tk][r], ov);
-          ok = mfma_f32(sq[i * WA_LD + l31], dp[tq][tk][r], ok);
+          ov = mfma_f32(gc[r], s[tq][r], ov);
+          ok = mfma_f32(qc[r], dp[tq][r], ok);
         }
-      if (j < WA_L) {
-        float* dst = a.dqkv + token_map(a, win, j).base * C3 + head * a.hd;
-        store_cols(dst + a.C, ok, hh, a.hd, 1.f);
-        store_cols(dst + 2 * a.C, ov, hh, a.hd, 1.f);
       }
+      if (j < WA_L) {
+        float* dst = a.dqkv + (long)stok[j] * C3;
+        store_cols(dst + ko, ok, hh, hd, 1.f);
+        store_cols(dst + vo, ov, hh, hd, 1.f);
+      }
+      // bias-table gradient, this key tile's share: every table entry sums its members (i, j) in raster order of i
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int bx = lane + 64 * e;
+        if (bx < WA_NBIAS) {
+          // entry bx = (yi - yj + 6) * 13 + (xi - xj + 6): all (i, j) with that displacement
+          const int dy = bx / 13 - 6, dx = bx % 13 - 6;
+          const int y0 = dy > 0 ? dy : 0, y1 = dy < 0 ? WA_WS + dy : WA_WS;
+          const int x0 = dx > 0 ? dx : 0, x1 = dx < 0 ? WA_WS + dx : WA_WS;
+          float t = 0.f;
+          for (int yi = y0; yi < y1; ++yi)
+            for (int xi = x0; xi < x1; ++xi) {
+              const int i = yi * WA_WS + xi, jj = (yi - dy) * WA_WS + (xi - dx) - 32 * tk;
+              if (jj >= 0 && jj < 32) t += sds[i * WA_DSP + jj];
+            }
+          db_acc[e] += t;
+        }
+      }
+      wave_sync();  // the next key tile overwrites sds
     }
-    __syncthreads();
-    for (int i = lane; i < NBIAS; i += 64) atomicAdd(dbias + i * a.heads, sdb[i]);
   }
+  // ---- fold the four waves in wave order, one fixed-point add per table entry and workgroup, last workgroup writes ------
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (lane + 64 * e < WA_NBIAS) sdb[lane + 64 * e] = db_acc[e];
+  __syncthreads();
+  if (tid < WA_NBIAS) {
+    const float t = (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
+    fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
+  }
+  if (last_workgroup(a.counter, gridDim.x * gridDim.y))
+    for (int e = tid; e < WA_NBIAS * a.heads; e += 256) {
+      const int h = e / WA_NBIAS, bx = e - h * WA_NBIAS;
+      a.dbias[bx * a.heads + h] = (float)fx_take(a.acc, e, (long)a.heads * WA_NBIAS);
+    }
 }
 
 static int check(const AttnArgs& a) {
   if (a.B < 1 || a.H % WA_WS || a.W % WA_WS || a.heads < 1 || a.C != a.heads * a.hd || a.hd % 2 || a.hd > 32 ||
-      a.hd < 2 || (a.shift != 0 && a.shift != WA_WS / 2))
+      a.hd < 2 || (a.shift != 0 && a.shift != WA_WS / 2) || (long)a.B * a.H * a.W * 3 * a.C >= (1L << 31) * 3)
     return NNZ_EINVAL;
   return NNZ_OK;
+}
+
+// windows per workgroup: a multiple of 4 (one per wave and round) that still leaves >= ~768 workgroups, at most 16
+static int windows_per_wg(int nwin, int heads) {
+  int wpb = 4;
+  while (wpb < 16 && (long)((nwin + 2 * wpb - 1) / (2 * wpb)) * heads >= 768) wpb *= 2;
+  return wpb;
 }
 
 }  // namespace nnz
@@ -409,26 +484,32 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
   a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.out = out;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
   if (int rc = check(a)) return rc;
-  const int nwin = B * (H / WA_WS) * (W / WA_WS);
-  NNZ_LAUNCH(win_attn_fwd_kernel, dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, a);
+  a.nwin = B * (H / WA_WS) * (W / WA_WS);
+  a.wpb = windows_per_wg(a.nwin, heads);
+  NNZ_LAUNCH(win_attn_fwd_kernel, dim3((a.nwin + a.wpb - 1) / a.wpb, heads), dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
 
+// acc: heads * 169 zeroed fixed-point records (nnz_fxacc_bytes() each), counter: one zeroed 32-bit word; both left zero.
+// dbias_table is WRITTEN (no zero fill needed) and bit-identical run to run.
 extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index,
-                                             const float* dout, float* dqkv, float* dbias_table, int B, int H, int W,
-                                             int C, int heads, int shift, float scale, void* stream) {
+                                             const float* dout, float* dqkv, float* dbias_table, void* acc, void* counter,
+                                             int B, int H, int W, int C, int heads, int shift, float scale, void* stream) {
   using namespace nnz;
-  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table) return NNZ_EINVAL;
+  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table || !acc || !counter) return NNZ_EINVAL;
   AttnArgs a = {};
   a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.dout = dout; a.dqkv = dqkv; a.dbias = dbias_table;
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
   if (int rc = check(a)) return rc;
-  hipError_t e = nnz::zero_async(dbias_table, sizeof(float) * heads * (2 * WA_WS - 1) * (2 * WA_WS - 1),
-                                (hipStream_t)stream);
+  a.nwin = B * (H / WA_WS) * (W / WA_WS);
+  a.wpb = windows_per_wg(a.nwin, heads);
+  const int lds = (WA_L * WA_BP + 4 * 176 + 4 * WA_WAVE_FLOATS) * (int)sizeof(float);
+  static DynLdsCache cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_bwd_kernel), lds, cache);
   if (e != hipSuccess) return (int)e;
-  const int nwin = B * (H / WA_WS) * (W / WA_WS);
-  NNZ_LAUNCH(win_attn_bwd_kernel, dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(win_attn_bwd_kernel, dim3((a.nwin + a.wpb - 1) / a.wpb, heads), dim3(256), lds, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..layer_norm import LayerNorm
-from ..token_linear import TokenLinear
+from ..token_linear import TokenLinear, mlp_gelu
 
 from ..utilities.network_initialization import InitWeights_He
 from ..window_attention import window_attention_core
@@ -139,6 +139,8 @@ class Mlp(nn.Module):
         self.drop2 = nn.Dropout(drop)
 
     def forward(self, x):
+        if isinstance(self.act, nn.GELU) and self.act.approximate == "none" and self.drop1.p == 0:
+            return self.drop2(mlp_gelu(x, self.fc1, self.fc2))     # fp32 step: one fused chain on csrc/dense32.hip
         return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
 
 

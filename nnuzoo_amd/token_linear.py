@@ -137,15 +137,139 @@ class _TallLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+USE_DENSE32 = os.environ.get("NNZ_DENSE32", "1") != "0"   # A/B switch: fp32 MFMA kernels (csrc/dense32.hip) vs GEMM library
+DENSE32_MIN_TOKENS = 64
+_WS = {}
+
+
+def _d32_workspace(device, floats: int) -> torch.Tensor:
+    """per-device partial-sum workspace of the fp32 weight gradients (calls on one stream use it one after the other)"""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def dense32_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """fp32 step (no autocast), device tensors, features multiples of 4: the hand-written fp32 MFMA path"""
+    if not (USE_DENSE32 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    N, K = weight.shape
+    return K % 4 == 0 and N % 4 == 0 and x.numel() // K >= DENSE32_MIN_TOKENS
+
+
+def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None):
+    """the three products of a Linear's backward on csrc/dense32.hip: dx (optionally times GELU'(h)), dW, db"""
+    N, K = weight.shape
+    T = x2.shape[0]
+    dx = dw = db = None
+    if need_x:
+        dx = torch.empty((T, K), dtype=torch.float32, device=dy2.device)
+        call("nnz_dense32_dgrad", ptr(dy2), ptr(weight), ptr(h), ptr(dx), T, K, N, stream_ptr())
+    if need_w or need_b:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+        db = torch.empty(N, dtype=torch.float32, device=dy2.device) if need_b else None
+        ws = _d32_workspace(dy2.device, int(_lib.load().nnz_dense32_wgrad_workspace_floats(T, K, N)))
+        call("nnz_dense32_wgrad", ptr(dy2), ptr(x2), ptr(dw), ptr(db), ptr(ws), T, K, N, stream_ptr())
+    return dx, dw, db
+
+
+class _Dense32LinearFn(torch.autograd.Function):
+    """y = x W^T + b in fp32 on v_mfma_f32_32x32x2_f32 (csrc/dense32.hip): bias in the epilogue; backward = one input
+    gradient launch + one weight/bias gradient launch (+ a fixed-order fold of its token splits) - no library GEMM, no
+    reduce / fill / copy launches.  Reference numerics: torch fp32 F.linear (nnUNetTrainerSwT2Net.py:112-130, no autocast)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, K = weight.shape
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        y = torch.empty((T, N), dtype=torch.float32, device=x.device)
+        call("nnz_dense32_forward", ptr(x2), ptr(weight), ptr(bias), ptr(y), None, T, K, N, 0, stream_ptr())
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = dy.reshape(-1, N)
+        if not dy2.is_contiguous() or dy2.dtype != torch.float32:
+            dy2 = dy2.float().contiguous()
+        dx, dw, db = _d32_backward_products(dy2, x2, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                            ctx.has_bias and ctx.needs_input_grad[2])
+        return (None if dx is None else dx.view(ctx.xshape)), (dw if ctx.needs_input_grad[1] else None), db
+
+
+class _Dense32MlpFn(torch.autograd.Function):
+    """fc2(GELU(fc1(x))) - the Mlp of the Swin / ViT blocks (swt2net.py:496-515, dropout 0) as four launches forward and
+    backward each: GELU is applied in fc1's epilogue (which stores the pre-activation too), GELU' in the epilogue of fc2's
+    input gradient; no element-wise launch touches the (tokens x 4C) hidden tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        Hd, K = w1.shape
+        N = w2.shape[0]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        dev = x.device
+        h = torch.empty((T, Hd), dtype=torch.float32, device=dev)
+        a = torch.empty((T, Hd), dtype=torch.float32, device=dev)
+        call("nnz_dense32_forward", ptr(x2), ptr(w1), ptr(b1), ptr(h), ptr(a), T, K, Hd, 1, stream_ptr())
+        y = torch.empty((T, N), dtype=torch.float32, device=dev)
+        call("nnz_dense32_forward", ptr(a), ptr(w2), ptr(b2), ptr(y), None, T, Hd, N, 0, stream_ptr())
+        ctx.save_for_backward(x2, w1, w2, h, a)
+        ctx.bias = (b1 is not None, b2 is not None)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, a = ctx.saved_tensors
+        N = w2.shape[0]
+        dy2 = dy.reshape(-1, N)
+        if not dy2.is_contiguous() or dy2.dtype != torch.float32:
+            dy2 = dy2.float().contiguous()
+        ni = ctx.needs_input_grad
+        dh, dw2, db2 = _d32_backward_products(dy2, a, w2, True, ni[3], ctx.bias[1] and ni[4], h=h)   # dh = (dy W2) * GELU'(h)
+        dx, dw1, db1 = _d32_backward_products(dh, x2, w1, ni[0], ni[1], ctx.bias[0] and ni[2])
+        return (None if dx is None else dx.view(ctx.xshape)), (dw1 if ni[1] else None), db1, (dw2 if ni[3] else None), db2
+
+
+def mlp_gelu(x: torch.Tensor, fc1: nn.Linear, fc2: nn.Linear) -> torch.Tensor:
+    """fc2(GELU(fc1(x))); the fused fp32 path when it applies, the module-by-module form otherwise"""
+    if dense32_ok(x, fc1.weight) and dense32_ok(x, fc2.weight) and fc2.weight.shape[1] == fc1.weight.shape[0]:
+        return _Dense32MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+    return fc2(F.gelu(fc1(x)))
+
+
 class TokenLinear(nn.Linear):
+    #: which implementation the most recent forward took ("hip-f16" / "hip-f32" / "library"); tests and the bench read it
+    backend = "unset"
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         tokens = x.numel() // max(1, x.shape[-1])
+        if dense32_ok(x, self.weight):
+            self.backend = "hip-f32"
+            return _Dense32LinearFn.apply(x, self.weight, self.bias)
         if USE_HIP_KERNELS and x.is_cuda and tokens >= HIP_MIN_TOKENS and x.is_contiguous() and self.weight.dtype == torch.float32 \
                 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16 \
                 and x.dtype in (torch.float16, torch.float32) and self.in_features % 8 == 0 \
                 and _hip_ok(self.in_features, self.out_features):
             xh = x if x.dtype == torch.float16 else x.to(torch.float16)
+            self.backend = "hip-f16"
             return _HipTokenLinearFn.apply(xh, self.weight, self.bias)
+        self.backend = "library"
         if x.is_cuda and x.is_contiguous() and x.dtype in (torch.float16, torch.float32) \
                 and _wgrad_chunks(tokens, self.in_features, self.out_features) > 1:
             return _TallLinearFn.apply(x, self.weight, self.bias)

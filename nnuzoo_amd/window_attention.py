@@ -13,6 +13,24 @@ import torch
 
 from ._lib import call, ptr, stream_ptr
 
+_CHECKED_INDEX = set()
+
+
+def _check_index_layout(bias_index: torch.Tensor) -> None:
+    """the backward kernel sums the bias-table gradient by displacement, index[i][j] = (yi - yj + 6) * 13 + (xi - xj + 6) -
+    the layout the reference registers (swt2net.py:545).  Verified once per buffer; any other content is refused loudly."""
+    key = (bias_index.data_ptr(), bias_index._version)
+    if key in _CHECKED_INDEX:
+        return
+    ar = torch.arange(7)
+    yy, xx = torch.meshgrid(ar, ar, indexing="ij")
+    y, x = yy.flatten(), xx.flatten()
+    expect = (y[:, None] - y[None, :] + 6) * 13 + (x[:, None] - x[None, :] + 6)
+    if bias_index.shape != (49, 49) or not torch.equal(bias_index.cpu().long(), expect):
+        raise NotImplementedError("window_attention_core: relative_position_index does not have the reference's "
+                                  "displacement layout (swt2net.py:545)")
+    _CHECKED_INDEX.add(key)
+
 
 class WindowAttentionCore(torch.autograd.Function):
     @staticmethod
@@ -22,6 +40,7 @@ class WindowAttentionCore(torch.autograd.Function):
             raise RuntimeError("window_attention_core runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
         if bias_index.dtype != torch.int32 or not bias_index.is_contiguous():
             raise ValueError("bias_index must be a contiguous int32 tensor")
+        _check_index_layout(bias_index)
         qkv = qkv.float().contiguous()
         table = bias_table.float().contiguous()
         B, H, W, C3 = qkv.shape
@@ -40,8 +59,10 @@ class WindowAttentionCore(torch.autograd.Function):
         dout = dout.float().contiguous()
         dqkv = torch.empty_like(qkv)
         dtable = torch.empty_like(table)
+        from .hip_ops import det_scratch
+        sc = det_scratch(qkv.device, 169 * heads)     # fixed-point sums of the bias-table gradient (deterministic)
         call("nnz_window_attention_backward", ptr(qkv), ptr(table), ptr(bias_index), ptr(dout), ptr(dqkv), ptr(dtable),
-             B, H, W, C, heads, shift, scale, stream_ptr())
+             ptr(sc.acc), ptr(sc.counter), B, H, W, C, heads, shift, scale, stream_ptr())
         return dqkv, dtable, None, None, None, None
 
 

@@ -87,7 +87,7 @@ def test_stats_kernel_large_mean(hip_lib, ratio, N, V, C):
                                                    ((1, 64, 48), 32, 32, 1), ((12, 20, 28), 32, 64, 1)])
 def test_conv_epilogue_table_large_mean(hip_lib, dims, cin, cout, stride):
     """the forward convolution's own statistics (all tile shapes incl. ragged edges and the depth-reuse loop) with a bias
-    that puts |mean| at ~200 std: table vs float64 on the stored fp16 outputs; outputs identical to the plain launch"""
+    that puts |mean| at 20 ... 200 std: table vs float64 on the stored fp16 outputs; outputs identical to the plain launch"""
     N = 2
     g = torch.Generator().manual_seed(sum(dims) + cout)
     x = torch.randn(N, int(np.prod(dims)), cin, generator=g).to(torch.float16).to(DEV)
@@ -95,7 +95,7 @@ def test_conv_epilogue_table_large_mean(hip_lib, dims, cin, cout, stride):
     ks = (1, 3, 3) if dims[0] == 1 else (3, 3, 3)
     if dims[0] == 1:
         w = w[:, :, 1:2].contiguous()
-    b = (4.0 + torch.randn(cout, generator=g)).to(DEV)
+    b = (6.0 + 0.5 * torch.randn(cout, generator=g)).to(DEV)
     st = (1, stride, stride) if dims[0] == 1 else stride
     pt = PreparedTable(cp.conv_forward(N, dims, cin, cout, ks=ks, stride=st))
     nk = int(np.prod(ks))
@@ -114,7 +114,7 @@ def test_conv_epilogue_table_large_mean(hip_lib, dims, cin, cout, stride):
         torch.cuda.synchronize()
         assert torch.equal(out, out0)
         ratio = (out.double().mean(1).abs() / out.double().std(1)).min().item()
-        assert ratio > 30, ratio
+        assert ratio > 20, ratio
         _check_table(nstat, _ref_table(out, gamma, beta, 1e-5), f"conv epilogue rep {rep}")
         assert int(sc.acc.abs().max()) == 0 and int(sc.counter.abs().max()) == 0
 

@@ -136,6 +136,7 @@ def test_graph_and_eager_steps_alternate(hip_lib):
     tr = nnUNetTrainerM2NetP(plans, cfg, 0, dj, device=torch.device("cuda"))
     tr.initialize()
     assert tr.use_hip_graph
+    tr.grad_scaler = torch.amp.GradScaler("cuda", init_scale=256.0)   # no fp16 overflow / skipped steps in this short run
     b = synthetic_batch(2, (64, 64), tr._get_deep_supervision_scales(), seed=5)
     b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
     losses = [float(tr.train_step(b)["loss"]) for _ in range(2)]             # graph (captures on the first call)
@@ -149,12 +150,13 @@ def test_graph_and_eager_steps_alternate(hip_lib):
         tr.use_hip_graph = True
         tr.optimizer.zero_grad(set_to_none=True)                             # and a user-side zero_grad on top
         for p, g in tr._graphed._static_grads:
-            g.fill_(float("nan"))                                            # a replay that did not write would show
+            g.fill_(7777.0)                                                  # a replay that did not write would show
         before = [p.detach().clone() for p in tr.network.parameters()]
         losses.append(float(tr.train_step(b)["loss"]))
         for p in tr.network.parameters():
             if id(p) in static:
                 assert p.grad is static[id(p)] and bool(torch.isfinite(p.grad).all())
+                assert not bool((p.grad == 7777.0).all())
         changed = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, tr.network.parameters()))
         assert changed > 100                                                 # the optimizer saw the replayed gradients
     assert all(l == l for l in losses) and losses[-1] < losses[0]
