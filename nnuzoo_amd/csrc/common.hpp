@@ -99,10 +99,13 @@ struct FxAcc {
   long long w[4];  // coarse (2^-10), fine (2^-58), non-finite partials, unused (32-byte records)
 };
 // Every logical accumulator exists in FX_REP replicas (replica r of record i of a bank of n records: acc[r * n + i]); a
-// workgroup adds to replica (its index mod FX_REP).  Atomics to ONE address serialise at ~23 ns each on this part (4096 conv
-// workgroups adding to the same 128 words cost 28 us per launch, measured); eight replicas make that 4 us, and since the
-// words are integers the replicas can be summed in any order without changing a bit.
-constexpr int FX_REP = 8;
+// workgroup adds to replica (its index mod FX_REP); since the words are integers the replicas can be summed in any order
+// without changing a bit.  Measured (tools/probes/probe_atomic_rt.hip): atomics to ONE address serialise at ~43 ns each
+// (64-bit integer; fp32 adds: 69 ns), which a launch whose workgroups arrive spread over its run time absorbs; what costs
+// is the FINALISING workgroup's uncached reads and resets - with 8 replicas x 3 words x (load + store) per record the lone
+// last workgroup spent ~20 us per launch (+1 ms per training step) on thousands of 8-byte sc1 transactions.  Two replicas
+// keep the per-address queue short enough and the tail at a few microseconds.
+constexpr int FX_REP = 2;
 __device__ __forceinline__ void fx_add(FxAcc* bank, long i, long n, unsigned rep, double v) {
   unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)(rep & (FX_REP - 1)) * n + i].w);
   if (!(fabs(v) < 0x1p52)) {  // inf, NaN or beyond the range: poison the accumulator
@@ -114,40 +117,64 @@ __device__ __forceinline__ void fx_add(FxAcc* bank, long i, long n, unsigned rep
   atomicAdd(w + 0, (unsigned long long)(long long)h);
   atomicAdd(w + 1, (unsigned long long)(long long)rint(rem * 0x1p58));
 }
-// read AND reset all replicas of record i (the workgroup that finalises leaves the bank ready for the next launch: no
-// zero-fill kernels).  Agent-scope atomic loads / stores: they bypass the non-coherent caches like the adds did, but -
-// unlike read-modify-write atomics - pipeline, so a thread's 3 * FX_REP reads are one round trip.
+// read AND reset all replicas of NR consecutive records i .. i + NR - 1 (the workgroup that finalises leaves the bank ready
+// for the next launch: no zero-fill kernels).  Agent-scope atomic loads / stores: they bypass the non-coherent caches like
+// the adds did, but - unlike read-modify-write atomics - pipeline: ALL loads of the NR records are issued before the first
+// store, so a call costs one memory round trip (~3 us in the tail of a launch, where nothing else hides it) however many
+// records it takes.  Callers therefore take a thread's records in one call.
+template <int NR>
+__device__ __forceinline__ void fx_take_n(FxAcc* bank, long i, long n, double (&out)[NR]) {
+  long long hi[NR], lo[NR];
+  unsigned long long bad[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    hi[q] = 0;
+    lo[q] = 0;
+    bad[q] = 0;
+  }
+#pragma unroll
+  for (int r = 0; r < FX_REP; ++r)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)r * n + i + q].w);
+      hi[q] += (long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lo[q] += (long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bad[q] += __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+  for (int r = 0; r < FX_REP; ++r)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)r * n + i + q].w);
+      __hip_atomic_store(w + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(w + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(w + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    const double v = (double)hi[q] * (1.0 / 1024.0) + (double)lo[q] * 0x1p-58;
+    out[q] = bad[q] ? __builtin_nan("") : v;
+  }
+}
 __device__ __forceinline__ double fx_take(FxAcc* bank, long i, long n) {
-  long long hi = 0, lo = 0;
-  unsigned long long bad = 0;
-#pragma unroll
-  for (int r = 0; r < FX_REP; ++r) {
-    unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)r * n + i].w);
-    hi += (long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    lo += (long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bad += __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#pragma unroll
-  for (int r = 0; r < FX_REP; ++r) {
-    unsigned long long* w = reinterpret_cast<unsigned long long*>(bank[(long)r * n + i].w);
-    __hip_atomic_store(w + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(w + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(w + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const double v = (double)hi * (1.0 / 1024.0) + (double)lo * 0x1p-58;
-  return bad ? __builtin_nan("") : v;
+  double v[1];
+  fx_take_n<1>(bank, i, n, v);
+  return v[0];
 }
 // "Was this the last workgroup of the launch to get here?"  Every thread of every workgroup calls it after its fx_add
 // calls (uniformly: it contains barriers).  Everything the workgroups exchange travels in device-scope ATOMICS (the
 // accumulators, the ticket), so all that is needed is that a workgroup's adds have been performed before its ticket is
-// drawn: each thread waits for its own outstanding memory operations (a workgroup-scope release = s_waitcnt vmcnt(0)),
-// the barrier joins them, one thread draws the ticket.  NOT __threadfence(): at agent scope that is an L2 write-back +
-// invalidate on this multi-XCD part - in the epilogue of every conv workgroup it doubled the convolution's time (measured:
-// conv_box 6.0 -> 12.1 ms per step).  The workgroup that draws the last ticket reads the totals with atomics (performed
-// at the coherence point, never cached) and re-arms the counter.  `counter`: a zero-initialised word.
+// drawn: each thread waits until its own outstanding vector-memory operations have been acknowledged (s_waitcnt
+// vmcnt(0): on gfx9 the counter also covers atomics without return and drops when L2 has performed them), the barrier
+// joins the threads, one thread draws the ticket.  Two things that do NOT work here: __threadfence() - at agent scope an L2
+// write-back + invalidate on this multi-XCD part; in the epilogue of every conv workgroup it doubled the convolution's
+// time (measured: conv_box 6.0 -> 12.1 ms per step) - and a workgroup-scope release fence, which compiles to nothing for
+// global memory in this mode (checked in the ISA: the adds were still in flight at the barrier, a late add then landed
+// after the finalising workgroup had read and reset the accumulator).  The workgroup that draws the last ticket reads the
+// totals with agent-scope atomic loads (never cached) and re-arms the counter.  `counter`: a zero-initialised word.
 __device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned nwg) {
   __shared__ unsigned s_last;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(counter, 1u);

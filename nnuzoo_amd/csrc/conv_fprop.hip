@@ -513,6 +513,28 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       fx_add(p.acc, rec + 1, nrec, blockIdx.x, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
     }
   }
+  // The finalising protocol runs BEFORE the output stores: its s_waitcnt then covers only the statistics atomics (one
+  // short round trip) and the workgroup leaves right after issuing its stores, instead of holding its CU slot until the
+  // whole output tile has drained to memory.
+  if (p.acc) {
+    if (last_workgroup(p.counter, nwg)) {
+      const double V = (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
+      for (int i = tid; i < p.d.N * Cout; i += 256) {
+        const long nrec = (long)p.d.N * Cout * 2;
+        double mom[2];
+        fx_take_n<2>(p.acc, (long)i * 2, nrec, mom);
+        const double sx = mom[0], sq = mom[1];
+        const double mean = sx / V;
+        double var = sq / V - mean * mean;
+        var = var < 0.0 ? 0.0 : var;  // (NaN stays NaN)
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const int c = i % Cout;
+        const float sc = rstd * p.gamma[c];
+        const f32x4 o = {(float)mean, rstd, sc, p.beta[c] - (float)mean * sc};
+        *reinterpret_cast<f32x4*>(p.nstat + (size_t)i * 4) = o;
+      }
+    }
+  }
 #pragma unroll 2
   for (int c = tid; c < NPIECE; c += 256) {
     const int v = c / PPV, part = c % PPV;
@@ -533,23 +555,6 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       for (int e = 0; e < 8; ++e) val[e] = (f16)((float)val[e] + (float)old[e]);
     }
     *reinterpret_cast<f16x8*>(dst) = val;
-  }
-  if (p.acc) {
-    if (last_workgroup(p.counter, nwg)) {
-      const double V = (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
-      for (int i = tid; i < p.d.N * Cout; i += 256) {
-        const long nrec = (long)p.d.N * Cout * 2;
-        const double sx = fx_take(p.acc, (long)i * 2, nrec), sq = fx_take(p.acc, (long)i * 2 + 1, nrec);
-        const double mean = sx / V;
-        double var = sq / V - mean * mean;
-        var = var < 0.0 ? 0.0 : var;  // (NaN stays NaN)
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-        const int c = i % Cout;
-        const float sc = rstd * p.gamma[c];
-        const f32x4 o = {(float)mean, rstd, sc, p.beta[c] - (float)mean * sc};
-        *reinterpret_cast<f32x4*>(p.nstat + (size_t)i * 4) = o;
-      }
-    }
   }
 }
 

@@ -216,7 +216,9 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
         const long nrec = (long)a.N * a.C * 2;
         if (MODE == 0) {
           for (int i = tid; i < a.N * a.C; i += 256) {
-            const double sx = fx_take(a.acc, (long)i * 2, nrec), sq = fx_take(a.acc, (long)i * 2 + 1, nrec);
+            double mom[2];
+            fx_take_n<2>(a.acc, (long)i * 2, nrec, mom);
+            const double sx = mom[0], sq = mom[1];
             if (a.sums) {
               a.sums[(long)i * 2 + 0] = (float)sx;
               a.sums[(long)i * 2 + 1] = (float)sq;
@@ -233,20 +235,48 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
             }
           }
         } else {
-          // per sample the two means the apply pass needs; over the batch (fixed order) the affine's gradients
-          for (int c = tid; c < a.C; c += 256) {
-            double sg = 0.0, sb = 0.0;
-            for (int nn = 0; nn < a.N; ++nn) {
-              const long i = (long)nn * a.C + c;
-              const double r0 = fx_take(a.acc, i * 2, nrec), r1 = fx_take(a.acc, i * 2 + 1, nrec);
-              a.nred[i * 2 + 0] = (float)(r0 / V);
-              a.nred[i * 2 + 1] = (float)(r1 / V);
-              sb += r0;
-              sg += r1;
+          // per sample the two means the apply pass needs; over the batch (fixed order) the affine's gradients.  One
+          // thread per (sample, channel) takes both sums in ONE round trip; the sums over the batch go through LDS
+          // (the reduction slab is free now) when they fit, else through a per-channel loop.
+          double* sred = reinterpret_cast<double*>(lred);
+          const bool via_lds = (size_t)a.N * a.C * 2 * sizeof(double) <= sizeof(float) * (size_t)rows * C2;
+          __syncthreads();
+          if (via_lds) {
+            for (int i = tid; i < a.N * a.C; i += 256) {
+              double r[2];
+              fx_take_n<2>(a.acc, (long)i * 2, nrec, r);
+              a.nred[(long)i * 2 + 0] = (float)(r[0] / V);
+              a.nred[(long)i * 2 + 1] = (float)(r[1] / V);
+              sred[(long)i * 2 + 0] = r[0];
+              sred[(long)i * 2 + 1] = r[1];
             }
-            if (a.dgamma) {
-              a.dgamma[c] = (float)sg;
-              a.dbeta[c] = (float)sb;
+            __syncthreads();
+            if (a.dgamma)
+              for (int c = tid; c < a.C; c += 256) {
+                double sg = 0.0, sb = 0.0;
+                for (int nn = 0; nn < a.N; ++nn) {
+                  sb += sred[((long)nn * a.C + c) * 2 + 0];
+                  sg += sred[((long)nn * a.C + c) * 2 + 1];
+                }
+                a.dgamma[c] = (float)sg;
+                a.dbeta[c] = (float)sb;
+              }
+          } else {
+            for (int c = tid; c < a.C; c += 256) {
+              double sg = 0.0, sb = 0.0;
+              for (int nn = 0; nn < a.N; ++nn) {
+                const long i = (long)nn * a.C + c;
+                double r[2];
+                fx_take_n<2>(a.acc, i * 2, nrec, r);
+                a.nred[i * 2 + 0] = (float)(r[0] / V);
+                a.nred[i * 2 + 1] = (float)(r[1] / V);
+                sb += r[0];
+                sg += r[1];
+              }
+              if (a.dgamma) {
+                a.dgamma[c] = (float)sg;
+                a.dbeta[c] = (float)sb;
+              }
             }
           }
         }

@@ -86,9 +86,10 @@ def test_token_linear_fp32_module_matches_torch(hip_lib):
     _close(gx, rx, 288, "dx")
     _close(gw, rw, 3430, "dW")
     _close(gb, rb, 3430, "db")
+    m2 = TokenLinear(64, 128).to(DEV)
     with torch.autocast("cuda", dtype=torch.float16):          # autocast steps keep their fp16 kernels
-        m(x)
-    assert m.backend == "hip-f16"
+        m2(torch.randn(2, 35, 49, 64, device=DEV))
+    assert m2.backend == "hip-f16"
 
 
 def test_fused_mlp_matches_torch(hip_lib):
