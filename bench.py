@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--secondary-steps", type=int, default=20)
     ap.add_argument("--secondary-warmup", type=int, default=5)
+    ap.add_argument("--tune", default="", help="A/B knobs, e.g. norm1=1024,conv3=0 (nnz_norm_tuning / nnz_conv_tuning)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -301,6 +302,11 @@ def main():
             dist.init_process_group(backend)
 
     from nnuzoo_amd import hip_ops
+    from nnuzoo_amd._lib import call as _call
+    for kv in [t for t in a.tune.split(",") if t]:
+        name, val = kv.split("=")
+        fam, knob = ("nnz_norm_tuning", name[4:]) if name.startswith("norm") else ("nnz_conv_tuning", name[4:])
+        _call(fam, int(knob), int(val))
     from nnuzoo_amd.synthetic import conv_flops_forward, nnunet_plans, synthetic_batch
     from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
 

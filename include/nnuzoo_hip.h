@@ -121,6 +121,14 @@ int nnz_fxacc_bytes(void);
 int nnz_conv_tap_forward_norm(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
                               const nnz_conv_desc* desc, void* acc, void* counter, const float* gamma,
                               const float* beta, float eps, float* nstat, void* stream);
+/* ... and with a caller-provided fp32 workspace: few-tile / long-reduction layers (the <= 8^3 levels) split the reduction
+ * over workgroups (split-K), partials in the workspace, folded in split order (deterministic) */
+int nnz_conv_tap_forward_ws(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
+                            const nnz_conv_desc* desc, float* workspace, long ws_floats, void* stream);
+int nnz_conv_tap_forward_norm_ws(const void* in_f16, void* out_f16, const void* w_packed_f16, const float* bias,
+                                 const nnz_conv_desc* desc, void* acc, void* counter, const float* gamma,
+                                 const float* beta, float eps, float* nstat, float* workspace, long ws_floats,
+                                 void* stream);
 int nnz_stem_conv_wgrad_det(const float* x, const void* dy_f16, float* dw, int N, int D, int H, int W, int Cout, int lddy,
                             void* acc /* >= 864 records */, void* counter, void* stream);
 int nnz_seg_head_wgrad_det(const void* x_f16, const void* dlogits_f16, float* dw, float* db, int N, long V, int C, int K,

@@ -86,6 +86,8 @@ SIGNATURES = {
     "nnz_instnorm_lrelu_bwd_apply": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _f, _fp, _fp, _vp],
     "nnz_fxacc_bytes": [],
     "nnz_conv_tap_forward_norm": [_vp, _vp, _vp, _fp, _dp, _vp, _vp, _fp, _fp, _f, _fp, _vp],
+    "nnz_conv_tap_forward_ws": [_vp, _vp, _vp, _fp, _dp, _fp, _l, _vp],
+    "nnz_conv_tap_forward_norm_ws": [_vp, _vp, _vp, _fp, _dp, _vp, _vp, _fp, _fp, _f, _fp, _fp, _l, _vp],
     "nnz_stem_conv_wgrad_det": [_fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "nnz_seg_head_wgrad_det": [_vp, _vp, _fp, _fp, _i, _l, _i, _i, _i, _vp, _vp, _vp],
     "nnz_dc_ce_loss_forward_det": [_vp, _i, _vp, _fp, _i, _i, _l, _i, _vp, _vp, _vp],

@@ -50,6 +50,12 @@ struct ConvDev {
   const float* gamma;
   const float* beta;
   float eps;
+  // split-K over the 16-channel slices of the reduction (the <= 8^3 levels: 10-40 workgroups each walking 20-40 slices of
+  // 55 KB of weights were 55 us of pure latency per launch): workgroup (.., split) covers slices [split * kper, ...) and
+  // stores its fp32 accumulators to part[split][n][voxel][cout]; conv_splitk_finish_kernel folds the splits in order
+  float* part;
+  long ws_floats;
+  int nsplit, kper;
   nnz_conv_desc d;
   int tiles[3];
   int gx, gy, gz;
@@ -112,6 +118,7 @@ struct ConvCfg {
 //   2  smallest m-grid edge (cube root of the voxel count) that takes the depth-reuse loop (default 16)
 //   3  workgroup order: cout block fastest (1) / m-tile fastest (0)                        (default 1)
 //   4  smallest Cin for knob 1                                                          (default 32)
+//   5  1 disables split-K over the reduction slices (the <= 8^3 levels; needs the *_ws entry points)  (default 0)
 static int g_tuning[8] = {1, 1, 16, 1, 32, 0, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
@@ -154,7 +161,12 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
     by = lin % p.gy;
     lin /= p.gy;
   }
-  const int bz = lin;
+  int bz = lin;
+  int split = 0;
+  if (p.nsplit > 1) {
+    split = bz % p.nsplit;
+    bz /= p.nsplit;
+  }
   const int g = bz % p.d.ngroups;
   const int n = bz / p.d.ngroups;
   const int tw_i = bx % p.tiles[2];
@@ -348,12 +360,14 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       }
   };
 
-  issue_loads(0);
-  for (int kc = 0; kc < nkc; ++kc) {
+  const int kc0 = p.nsplit > 1 ? split * p.kper : 0;
+  const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
+  issue_loads(kc0);
+  for (int kc = kc0; kc < kc1; ++kc) {
     __syncthreads();  // all waves finished reading the previous slice
     write_lds();
     __syncthreads();
-    if (kc + 1 < nkc) issue_loads(kc + 1);
+    if (kc + 1 < kc1) issue_loads(kc + 1);
 
     if constexpr (DRE) {
       // Software pipeline by half rows: the reads of the NEXT half are issued as a group before the six MFMAs of the
@@ -400,6 +414,34 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
     }
   }
 
+  if (p.part) {
+    // split-K: the lane's accumulator quads are 4 consecutive couts of one voxel -> 16-byte fp32 stores, no transposition
+    const long vox_per_n = (long)p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2];
+#pragma unroll
+    for (int j = 0; j < C::WM; ++j) {
+      const int v = frag_voxel(j);
+      const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+      const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
+      const int od = md * p.d.out_stride[0] + grp.ooff[0];
+      const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
+      const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
+      if (!(md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] && od < p.d.out_dims[0] &&
+            oh < p.d.out_dims[1] && ow < p.d.out_dims[2]))
+        continue;
+      const long vox = ((long)od * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow;
+      float* dst = p.part + (((long)split * p.d.N + n) * vox_per_n + vox) * Cout;
+#pragma unroll
+      for (int i = 0; i < C::WN; ++i) {
+        const int nbl = wn * C::WN + i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(dst + (cb0 + nbl) * 32 + 4 * hh + 8 * q) = o;
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: D[row = cout][col = voxel]; lane holds couts (r&3) + 8(r>>2) + 4hh of its voxel -----
   // The tile is transposed through LDS (the box/weight region is free now) so that global stores are whole
   // 16-byte pieces in voxel-major order: a wave writes full 128-byte lines.  (Direct 8-byte stores from the
@@ -558,6 +600,100 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   }
 }
 
+// Split-K epilogue: out[n][v][c] (+)= bias[c] + sum_s part[s][n][v][c] in split order, rounded once to fp16; a workgroup
+// owns ALL voxels of one (sample, 32-channel block), so the InstanceNorm table of these small layers needs no cross-
+// workgroup sum at all: per-thread (count, mean, M2) triples are merged pairwise in a fixed tree (Chan), in double.
+struct SplitKFinish {
+  const float* part;
+  const float* bias;
+  f16* out;
+  float* nstat;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int nsplit, N, Cout, ldo, accumulate;
+  long V;
+};
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(SplitKFinish a) {
+  __shared__ double sm[32][32], sq[32][32];
+  __shared__ float scnt[32][32];
+  const int tid = threadIdx.x;
+  const int c4 = (tid & 7) * 4, vl = tid >> 3;   // 8 threads cover the block's 32 channels; 32 voxel lanes
+  const int cb = blockIdx.x, n = blockIdx.y;
+  const int c0 = cb * 32 + c4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + c0);
+  float cnt = 0.f, mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+  const long slab = (long)a.N * a.V * a.Cout;
+  for (long v = vl; v < a.V; v += 32) {
+    const float* src = a.part + ((long)n * a.V + v) * a.Cout + c0;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < a.nsplit; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + q * slab);
+      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    f16* dst = a.out + ((long)n * a.V + v) * a.ldo + c0;
+    f16x4 o = {(f16)(s[0] + bv[0]), (f16)(s[1] + bv[1]), (f16)(s[2] + bv[2]), (f16)(s[3] + bv[3])};
+    if (a.accumulate) {
+      const f16x4 old = *reinterpret_cast<const f16x4*>(dst);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)((float)o[e] + (float)old[e]);
+    }
+    *reinterpret_cast<f16x4*>(dst) = o;
+    if (a.nstat) {  // Welford on the stored fp16 values
+      cnt += 1.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = (float)o[e], d = x - mean[e];
+        mean[e] += d / cnt;
+        m2[e] += d * (x - mean[e]);
+      }
+    }
+  }
+  if (!a.nstat) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sm[vl][c4 + e] = (double)mean[e];
+    sq[vl][c4 + e] = (double)m2[e];
+  }
+  scnt[vl][c4] = cnt;
+  __syncthreads();
+  if (tid < 32) {
+    const int c = tid;
+    double M = 0.0, Q = 0.0, Nn = 0.0;
+    for (int l = 0; l < 32; ++l) {   // fixed order
+      const double nb = (double)scnt[l][c & ~3];
+      if (nb == 0.0) continue;
+      const double d = sm[l][c] - M, tot = Nn + nb;
+      M += d * nb / tot;
+      Q += sq[l][c] + d * d * Nn * nb / tot;
+      Nn = tot;
+    }
+    const double var = Nn > 0.0 ? Q / Nn : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const int cg = cb * 32 + c;
+    const float sc = rstd * a.gamma[cg];
+    const f32x4 o = {(float)M, rstd, sc, a.beta[cg] - (float)M * sc};
+    *reinterpret_cast<f32x4*>(a.nstat + ((long)n * a.Cout + cg) * 4) = o;
+  }
+}
+
+// split-K decision: few workgroups, many slices, one tap group with unit output stride, and a workspace that holds the partials
+static int splitk_plan(const ConvDev& p, long ws_floats, int wgs_base, int* kper) {
+  const nnz_conv_desc& d = p.d;
+  const int nkc = d.Cin / 16;
+  if (g_tuning[5] || !p.part || d.ngroups != 1 || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1 ||
+      nkc < 8 || wgs_base >= 128 || p.stats)
+    return 1;
+  int splits = (384 + wgs_base - 1) / wgs_base;
+  if (splits > nkc / 2) splits = nkc / 2;          // at least two slices per workgroup
+  const long per_split = (long)d.N * d.out_dims[0] * d.out_dims[1] * d.out_dims[2] * d.Cout;
+  if ((long)splits * per_split > ws_floats) splits = (int)(ws_floats / per_split);
+  if (splits < 2) return 1;
+  *kper = (nkc + splits - 1) / splits;
+  return (nkc + *kper - 1) / *kper;
+}
+
 template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false>
 static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   using C = ConvCfg<TD, TH, TW, NB>;
@@ -579,7 +715,10 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   p.tiles[2] = (p.d.m_dims[2] + TW - 1) / TW;
   p.gx = p.tiles[0] * p.tiles[1] * p.tiles[2];
   p.gy = p.d.Cout / (32 * NB);
-  p.gz = p.d.N * p.d.ngroups;
+  p.kper = 0;
+  p.nsplit = splitk_plan(p, p.ws_floats, p.gx * p.gy * p.d.N * p.d.ngroups, &p.kper);
+  if (p.nsplit <= 1) p.part = nullptr;
+  p.gz = p.d.N * p.d.ngroups * (p.nsplit > 1 ? p.nsplit : 1);
   p.cout_fastest = g_tuning[3] && p.gy > 1;
   auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G, DRE, DFLIP>;
   static DynLdsCache lds_cache;  // per instantiation, per device
@@ -589,6 +728,14 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   }
   const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
   NNZ_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, p);
+  if (p.nsplit > 1) {
+    SplitKFinish f = {};
+    f.part = p.part; f.bias = p.bias; f.out = p.out; f.nstat = p.acc ? p.nstat : nullptr;
+    f.gamma = p.gamma; f.beta = p.beta; f.eps = p.eps;
+    f.nsplit = p.nsplit; f.N = p.d.N; f.Cout = p.d.Cout; f.ldo = p.d.ldo; f.accumulate = p.d.accumulate;
+    f.V = (long)p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2];
+    NNZ_LAUNCH(conv_splitk_finish_kernel, dim3(p.d.Cout / 32, p.d.N), dim3(256), 0, stream, f);
+  }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -692,7 +839,8 @@ extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void*
                                           const nnz_conv_desc* desc, float* stats, void* stream);
 static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
                                  const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
-                                 const float* gamma, const float* beta, float eps, float* nstat, void* stream);
+                                 const float* gamma, const float* beta, float eps, float* nstat, void* stream,
+                                 float* workspace = nullptr, long ws_floats = 0);
 
 extern "C" int nnz_conv_tuning(int knob, int value) {
   if (knob < 0 || knob >= 8) return NNZ_EINVAL;
@@ -722,11 +870,30 @@ extern "C" int nnz_conv_tap_forward_norm(const void* in, void* out, const void* 
 }
 
 // bytes of ONE logical accumulator record as the *_det / *_norm entry points count them (all its replicas)
+// The same two entry points with a caller-provided fp32 workspace: layers with few output tiles and a long reduction (the
+// <= 8^3 levels of the 3-D nets) then split the reduction over workgroups (split-K over 16-channel slices), partials in the
+// workspace, folded in split order by a finishing kernel that also writes the InstanceNorm table (norm variant).  Results are
+// deterministic; without a workspace (or for layers that do not qualify) the call is the plain one.
+extern "C" int nnz_conv_tap_forward_ws(const void* in, void* out, const void* w_packed, const float* bias,
+                                       const nnz_conv_desc* desc, float* workspace, long ws_floats, void* stream) {
+  return conv_tap_forward_impl(in, out, w_packed, bias, desc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, stream,
+                               workspace, ws_floats);
+}
+extern "C" int nnz_conv_tap_forward_norm_ws(const void* in, void* out, const void* w_packed, const float* bias,
+                                            const nnz_conv_desc* desc, void* acc, void* counter, const float* gamma,
+                                            const float* beta, float eps, float* nstat, float* workspace, long ws_floats,
+                                            void* stream) {
+  if (!acc || !counter || !gamma || !beta || !nstat) return NNZ_EINVAL;
+  return conv_tap_forward_impl(in, out, w_packed, bias, desc, nullptr, acc, (unsigned*)counter, gamma, beta, eps, nstat, stream,
+                               workspace, ws_floats);
+}
+
 extern "C" int nnz_fxacc_bytes(void) { return (int)sizeof(nnz::FxAcc) * nnz::FX_REP; }
 
 static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
                                  const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
-                                 const float* gamma, const float* beta, float eps, float* nstat, void* stream) {
+                                 const float* gamma, const float* beta, float eps, float* nstat, void* stream,
+                                 float* workspace, long ws_floats) {
   using namespace nnz;
   if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
@@ -768,6 +935,10 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
     p.gamma = gamma;
     p.beta = beta;
     p.eps = eps;
+    p.part = workspace;
+    p.ws_floats = workspace ? ws_floats : 0;
+    p.nsplit = 1;
+    p.kper = 0;
     p.d = d;
     p.d.N = d.N - n0 < chunk ? d.N - n0 : chunk;
     int rc;

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
 }
 
 static int g_norm_blocks = 2048;   // nnz_norm_tuning(0, blocks): target number of workgroups per launch (A/B runs)
+static int g_norm_blocks_red = 512;   // nnz_norm_tuning(1, blocks): the same for the reducing kernels (statistics, backward reduce)
 
 template <int MODE>
 static int launch_norm(NormArgs a, hipStream_t s, bool pre_zeroed = false) {
@@ -301,7 +302,7 @@ static int launch_norm(NormArgs a, hipStream_t s, bool pre_zeroed = false) {
   // (tools/probes/norm_bw_probe.py on the 268 MB full-resolution tensor: the apply kernels gain 6-10 % from 4x more, smaller
   // workgroups - 5.05 -> 5.6 TB/s, torch's device copy does 5.2-5.4 - the reducing kernels lose 40 %: their per-block
   // LDS slab + atomics are a fixed cost)
-  const long nblk = (MODE == 0 || MODE == 2) ? g_norm_blocks : 4L * g_norm_blocks;
+  const long nblk = (MODE == 0 || MODE == 2) ? g_norm_blocks_red : 4L * g_norm_blocks;
   long vpb = (a.V * a.N + nblk - 1) / nblk;
   if (vpb < 512) vpb = 512;
   if (vpb > a.V) vpb = a.V;
@@ -321,8 +322,8 @@ static int launch_norm(NormArgs a, hipStream_t s, bool pre_zeroed = false) {
 }  // namespace nnz
 
 extern "C" int nnz_norm_tuning(int knob, int value) {
-  if (knob != 0 || value < 64) return NNZ_EINVAL;
-  nnz::g_norm_blocks = value;
+  if ((knob != 0 && knob != 1) || value < 64) return NNZ_EINVAL;
+  (knob == 0 ? nnz::g_norm_blocks : nnz::g_norm_blocks_red) = value;
   return NNZ_OK;
 }
 

@@ -85,11 +85,16 @@ def pack_weight(param: torch.Tensor, pt: PreparedTable, R: int, Cc: int, sr: int
 
 
 def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
-                     out: torch.Tensor, stats: Optional[torch.Tensor] = None) -> None:
+                     out: torch.Tensor, stats: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> None:
     """stats: optional pre-zeroed fp32 [N, Cout, 2]; the kernel adds {sum, sumsq} of its fp16 outputs (fused
-    InstanceNorm statistics)"""
+    InstanceNorm statistics).  workspace: fp32 scratch that lets few-tile / long-reduction layers run split-K"""
     _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
-    _f32(stats, "conv.stats")
+    _f32(stats, "conv.stats"); _f32(workspace, "conv.workspace")
+    if workspace is not None and stats is None:
+        TIMER.wrap("conv_box_kernel", pt.flops,
+                   lambda: call("nnz_conv_tap_forward_ws", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
+                                ptr(workspace), workspace.numel(), stream_ptr()))
+        return
     TIMER.wrap("conv_box_kernel", pt.flops,
                lambda: call("nnz_conv_tap_forward_stats", ptr(x), ptr(out), ptr(w_packed), ptr(bias),
                             C.byref(pt.desc), ptr(stats), stream_ptr()))
@@ -125,16 +130,17 @@ def det_scratch(device, records: int = 0) -> NormScratch:
 
 def conv_tap_forward_norm(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
                           out: torch.Tensor, scratch: NormScratch, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-                          nstat: torch.Tensor) -> None:
+                          nstat: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> None:
     """forward convolution + the InstanceNorm table of its output: nstat [N, Cout, 4] = {mean, rstd, scale, shift}
     (deterministic fixed-point statistics, written by the launch's last workgroup)"""
     _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
     _f32(gamma, "conv.gamma"); _f32(beta, "conv.beta"); _f32(nstat, "conv.nstat")
     assert pt.table.N * pt.table.Cout <= scratch.capacity
+    _f32(workspace, "conv.workspace")
     TIMER.wrap("conv_box_kernel", pt.flops,
-               lambda: call("nnz_conv_tap_forward_norm", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
+               lambda: call("nnz_conv_tap_forward_norm_ws", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
                             ptr(scratch.acc), ptr(scratch.counter), ptr(gamma), ptr(beta), float(eps), ptr(nstat),
-                            stream_ptr()))
+                            ptr(workspace), 0 if workspace is None else workspace.numel(), stream_ptr()))
 
 
 def convT_supported(cin: int, cout: int, stride, dgrad: bool) -> bool:

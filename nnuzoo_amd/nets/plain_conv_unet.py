@@ -431,7 +431,7 @@ class PlainConvUNet(nn.Module):
         else:
             # the convolution's epilogue accumulates the InstanceNorm statistics of the tile it just produced
             ops.conv_tap_forward_norm(b.fwd, self._padded_input(b, x_act) if b.padded else x_act, b.wp_fwd, h.conv.bias,
-                                      raw, scratch, h.norm.weight, h.norm.bias, b.eps, stats)
+                                      raw, scratch, h.norm.weight, h.norm.bias, b.eps, stats, workspace=self._ws)
         ops.instnorm_lrelu_apply_tab(raw, stats, act_out, b.N, b.V, b.cout, b.cout, b.y_ld, b.slope)
         return raw, stats
 
@@ -463,6 +463,9 @@ class PlainConvUNet(nn.Module):
         if plan.norm_scratch is None:
             plan.norm_scratch = ops.NormScratch(dev, plan.norm_capacity)
         self._scratch = plan.norm_scratch
+        if plan.wgrad_ws is None:   # fp32 workspace shared by the weight gradients and the split-K layers (stream order)
+            plan.wgrad_ws = torch.empty(plan.wgrad_ws_floats, dtype=torch.float32, device=dev)
+        self._ws = plan.wgrad_ws
         stats_all = torch.empty(plan.stats_floats, dtype=torch.float32, device=dev)
         cats = [torch.empty((N, int(np.prod(plan.level_dims[s])), 2 * feats[s]), dtype=f16, device=dev)
                 for s in range(S - 1)]
@@ -537,7 +540,7 @@ class PlainConvUNet(nn.Module):
                 ops.conv_tap_wgrad_to_grad(b.wgrad, x_in, draw, self._wgrad_ws, gw, nk, b.cin * nk, 1)
                 if b.zero_dx and not dx_acc:
                     dx_out.zero_()  # k1 s2 axes: odd input positions are outside every output's footprint
-                ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out)
+                ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out, workspace=self._wgrad_ws)
         grads[h.conv.weight] = gw
         if self.grad_reducer is not None:
             # hand-over point per conv block (finer than per stage: the 320-channel decoder stage alone is 37 MB)

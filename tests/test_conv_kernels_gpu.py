@@ -382,6 +382,71 @@ def test_batched_weight_pack_matches_single(hip_lib):
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("N,dims,cin,cout,stride", [(2, (4, 4, 4), 320, 320, 1), (2, (8, 8, 8), 640, 320, 1),
+                                                    (1, (8, 8, 8), 256, 320, 2), (2, (6, 5, 7), 128, 64, 1),
+                                                    (2, (16, 16, 16), 256, 256, 1)])
+def test_conv_splitk_small_levels(hip_lib, N, dims, cin, cout, stride):
+    """round 3: the <= 8^3 levels split the reduction over workgroups when a workspace is handed in (split-K over
+    16-channel slices + a finishing kernel): forward with the fused InstanceNorm table, data gradient plain and
+    accumulating - against torch fp32 on the same fp16-rounded operands and against the unsplit launch; run twice:
+    bit-identical (fixed split order)"""
+    from nnuzoo_amd._lib import call, load
+    g = torch.Generator().manual_seed(cin + dims[0])
+    x = h(torch.randn(N, cin, *dims, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv3d(x, w, b, stride=stride, padding=1)
+    odims = tuple(ref.shape[2:])
+    V = int(np.prod(odims))
+    pt = PreparedTable(cp.conv_forward(N, dims, cin, cout, stride=stride))
+    wp = ops.pack_weight(w.to(DEV), pt, cin, cout, 27, cin * 27, 1)
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    xc = to_cl(x)
+    plain = torch.empty((N, V, cout), dtype=torch.float16, device=DEV)
+    ops.conv_tap_forward(pt, xc, wp, b.to(DEV), plain)
+    gamma, beta = (1 + 0.1 * torch.randn(cout, generator=g)).to(DEV), (0.1 * torch.randn(cout, generator=g)).to(DEV)
+    sc = ops.NormScratch(torch.device(DEV), N * cout)
+    outs = []
+    for _ in range(2):
+        out = torch.full((N, V, cout), float("nan"), dtype=torch.float16, device=DEV)
+        nstat = torch.full((N, cout, 4), float("nan"), device=DEV)
+        ops.conv_tap_forward_norm(pt, xc, wp, b.to(DEV), out, sc, gamma, beta, 1e-5, nstat, workspace=ws)
+        outs.append((out, nstat))
+    torch.cuda.synchronize()
+    close(from_cl(outs[0][0], odims), ref)
+    assert (outs[0][0].float() - plain.float()).abs().max().item() <= 2e-3 * plain.float().abs().max().item()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    o64 = outs[0][0].double()
+    mean, var = o64.mean(1), o64.var(1, unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    tab = outs[0][1].double()
+    assert torch.allclose(tab[..., 0], mean, rtol=1e-5, atol=1e-6) and torch.allclose(tab[..., 1], rstd, rtol=1e-5)
+    assert torch.allclose(tab[..., 2], rstd * gamma.double(), rtol=1e-5)
+    assert torch.allclose(tab[..., 3], beta.double() - mean * rstd * gamma.double(), rtol=1e-4, atol=1e-5)
+    # data gradient (one tap group at stride 1): plain and accumulating
+    if stride == 1:
+        dy = h(torch.randn(N, cout, *odims, generator=g))
+        xr = x.clone().requires_grad_(True)
+        (rdx,) = torch.autograd.grad(F.conv3d(xr, w, None, stride=1, padding=1), xr, dy)
+        ptd = PreparedTable(cp.conv_dgrad(N, dims, cin, cout, stride=1))
+        wpd = ops.pack_weight(w.to(DEV), ptd, cout, cin, cin * 27, 27, 1)
+        dx = torch.full((N, int(np.prod(dims)), cin), float("nan"), dtype=torch.float16, device=DEV)
+        ops.conv_tap_forward(ptd, to_cl(dy), wpd, None, dx, workspace=ws)
+        close(from_cl(dx, dims), rdx)
+        base = h(torch.randn(N, cin, *dims, generator=g))
+        acc = to_cl(base).clone()
+        ops.conv_tap_forward(ptd.with_accumulate(True), to_cl(dy), wpd, None, acc, workspace=ws)
+        close(from_cl(acc, dims), rdx + base)
+    lib = load()
+    call("nnz_conv_tuning", 5, 1)                   # the A/B switch: split-K off -> the unsplit kernel, same interface
+    try:
+        out = torch.empty_like(plain)
+        ops.conv_tap_forward(pt, xc, wp, b.to(DEV), out, workspace=ws)
+        assert torch.equal(out, plain)
+    finally:
+        call("nnz_conv_tuning", 5, 0)
+
+
 def test_dual_weight_pack_matches_single(hip_lib):
     """round 3: ONE launch reading every parameter once and writing the forward and the data-gradient packed forms
     (csrc/conv_pack.hip pack_dual_kernel) == the two per-layer packs, bit-exact; conv (3-D k3, stride 2, thick-slice k(1,3,3),
