@@ -10,9 +10,10 @@
 //   forward   y[t][n]  = sum_k x[t][k]  W[n][k]   rows = tokens (x, k contiguous)   cols = features (W, k contiguous)
 //   dgrad     dx[t][k] = sum_n dy[t][n] W[n][k]   rows = tokens (dy, n contiguous)  cols = k (W read transposed)
 //   wgrad     dW[n][k] = sum_t dy[t][n] x[t][k]   rows = n (dy read transposed)     cols = k (x read transposed)
-// LDS tiles are [row][contraction] with the contraction index contiguous, so a lane fetches FOUR consecutive contraction
-// steps of its row with one ds_read_b128: lane half hh takes steps 4hh .. 4hh+3 of every 8 - any assignment of steps to
-// MFMA issues is valid as long as both operands use the same one.  Rows (tokens) are the MFMA A operand and features sit
+// Lane half hh takes contraction steps 4hh .. 4hh+3 of every 8 - any assignment of steps to MFMA issues is valid as long as
+// both operands use the same one - so an operand whose contraction index is contiguous in memory is fetched from its
+// [row][step] LDS image with one ds_read_b128 per four MFMAs; an operand whose ROW index is contiguous keeps that layout in
+// LDS ([step][row]: 16-byte staging writes, no scattered transposition) and is fetched with four conflict-free ds_read_b32.  Rows (tokens) are the MFMA A operand and features sit
 // on the lanes, so an accumulator register is 32 consecutive features of one token: stores are 128-byte runs without a
 // transpose.  4 waves per workgroup in a 2 x 2 grid, each wave WM x WN MFMA tiles (up to 64 x 64 outputs = 64 accumulator
 // registers); the next contraction block is prefetched into registers under the MFMAs of the current one.
@@ -22,8 +23,7 @@
 
 namespace nnz {
 
-constexpr int D32_BK = 16;          // contraction steps per LDS block
-constexpr int D32_PITCH = 20;       // floats per LDS row: 80 bytes (16-byte aligned rows, 2-way conflicts at worst)
+constexpr int D32_BK = 32;          // contraction steps per LDS block of the large tiles (64 for the 64 x 64 tile)
 
 __device__ __forceinline__ f32x16 mfma_f32x(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -53,11 +53,19 @@ struct D32Args {
   int epi;              // 0 none / bias, 1 GELU (dual output), 2 multiply by GELU'(aux)
 };
 
-// stage a [NR rows][16 contraction steps] tile into LDS.  CONTIG: contraction index contiguous in memory (16-byte loads along
-// it), else the ROW index is contiguous (16-byte loads along 4 rows, scattered into the transposed image).
-template <int NR, bool CONTIG>
-struct D32Stage {
-  static constexpr int NV = NR * D32_BK / 4;           // 16-byte pieces per tile
+// An operand tile of NR rows x D32_BK contraction steps.  Global loads are always 16 bytes along the axis that is
+// contiguous in MEMORY, and the LDS image keeps that axis contiguous too (16-byte LDS writes, no scattered transposition):
+//   CONTIG  (contraction contiguous: x / dy rows, W in the forward)   image [row][step], pitch 36: a lane's four steps of
+//           its row are one ds_read_b128;
+//   !CONTIG (row index contiguous: W in the input gradient, dy / x in the weight gradient)   image [step][row], pitch
+//           NR + 4: a lane's four steps are four ds_read_b32 whose 32 lanes read consecutive words (conflict-free).
+template <int NR, bool CONTIG, int BK>
+struct D32Tile {
+  static constexpr int D32_BK = BK;
+  static constexpr int D32_PITCH = BK + 4;                             // floats per row of the [row][step] image (16-byte aligned)
+  static constexpr int TP = NR + 4;                                    // pitch of the [step][row] image
+  static constexpr int FLOATS = CONTIG ? NR * D32_PITCH : D32_BK * TP;
+  static constexpr int NV = NR * D32_BK / 4;                           // 16-byte pieces per tile
   static constexpr int LPT = (NV + 255) / 256;
   f32x4 reg[LPT];
   __device__ __forceinline__ void load(const float* src, long rs, long cs, int r0, int nrows, int c0, int nc, int tid) {
@@ -67,12 +75,10 @@ struct D32Stage {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (p < NV) {
         if (CONTIG) {
-          const int r = p >> 2, c4 = (p & 3) * 4;     // 4 pieces of 4 steps per row
+          const int r = p / (D32_BK / 4), c4 = (p % (D32_BK / 4)) * 4;
           if (r0 + r < nrows && c0 + c4 < nc) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * rs + (c0 + c4));
         } else {
-          // 4 consecutive rows at one contraction step; consecutive lanes walk the contraction index so that the
-          // transposed LDS writes of a wave land on 64 different banks (rows 4 apart are 16 banks apart at this pitch)
-          const int c = p & (D32_BK - 1), r4 = (p / D32_BK) * 4;
+          const int c = p / (NR / 4), r4 = (p % (NR / 4)) * 4;         // consecutive lanes: consecutive rows of one step
           if (c0 + c < nc) {
             const float* s = src + (long)(c0 + c) * cs + (r0 + r4);
             if (r0 + r4 + 3 < nrows) {
@@ -94,24 +100,36 @@ struct D32Stage {
       const int p = tid + i * 256;
       if (p < NV) {
         if (CONTIG) {
-          const int r = p >> 2, c4 = (p & 3) * 4;
+          const int r = p / (D32_BK / 4), c4 = (p % (D32_BK / 4)) * 4;
           *reinterpret_cast<f32x4*>(tile + r * D32_PITCH + c4) = reg[i];
         } else {
-          const int c = p & (D32_BK - 1), r4 = (p / D32_BK) * 4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tile[(r4 + e) * D32_PITCH + c] = reg[i][e];
+          const int c = p / (NR / 4), r4 = (p % (NR / 4)) * 4;
+          *reinterpret_cast<f32x4*>(tile + c * TP + r4) = reg[i];
         }
       }
     }
   }
+  // the lane's four contraction steps kb * 8 + hh * 4 + {0..3} of row `row`
+  static __device__ __forceinline__ f32x4 frag(const float* tile, int row, int kb, int hh) {
+    if (CONTIG) return *reinterpret_cast<const f32x4*>(tile + row * D32_PITCH + kb * 8 + hh * 4);
+    const float* p = tile + (kb * 8 + hh * 4) * TP + row;
+    f32x4 v = {p[0], p[TP], p[2 * TP], p[3 * TP]};
+    return v;
+  }
 };
 
-// WM x WN MFMA tiles per wave; workgroup tile = (64 WM) rows x (64 WN) cols
+// WM x WN MFMA tiles per wave; workgroup tile = (64 WM) rows x (64 WN) cols.  The contraction runs in blocks of BK steps
+// with a prefetch distance of TWO blocks (two register sets, the loop unrolled by two): most calls of the Swin / ViT nets
+// are small (a few hundred workgroups, 12-96 blocks each), so a block's global-load latency must hide behind the LDS
+// hand-over and the MFMAs of two neighbouring blocks, not one.
 template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD>
 __global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
-  __shared__ __attribute__((aligned(16))) float sA[BM * D32_PITCH];
-  __shared__ __attribute__((aligned(16))) float sB[BN * D32_PITCH];
+  constexpr int D32_BK = (WM == 1 && WN == 1) ? 64 : 32;
+  using TA = D32Tile<BM, A_CONTIG, D32_BK>;
+  using TB = D32Tile<BN, B_CONTIG, D32_BK>;
+  __shared__ __attribute__((aligned(16))) float sA[TA::FLOATS];
+  __shared__ __attribute__((aligned(16))) float sB[TB::FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,39 +154,54 @@ __global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float dbsum = 0.f;  // wgrad: this thread's row of the dy tile (tid < BM), summed over the contraction
 
-  D32Stage<BM, A_CONTIG> stA;
-  D32Stage<BN, B_CONTIG> stB;
-  stA.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k_begin, k_end, tid);
-  stB.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid);
-  for (int k0 = k_begin; k0 < k_end; k0 += D32_BK) {
-    __syncthreads();
-    stA.store(sA, tid);
-    stB.store(sB, tid);
-    __syncthreads();
-    if (k0 + D32_BK < k_end) {
-      stA.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0 + D32_BK, k_end, tid);
-      stB.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + D32_BK, k_end, tid);
-    }
+  TA stA0, stA1;
+  TB stB0, stB1;
+  auto compute = [&]() {
     if (WGRAD && a.part_db && c0 == 0 && tid < BM) {
-      const float* row = sA + tid * D32_PITCH;
 #pragma unroll
-      for (int q = 0; q < D32_BK; ++q) dbsum += row[q];
+      for (int q = 0; q < D32_BK; ++q) dbsum += A_CONTIG ? sA[tid * TA::D32_PITCH + q] : sA[q * TA::TP + tid];
     }
 #pragma unroll
     for (int kb = 0; kb < D32_BK / 8; ++kb) {
       f32x4 fa[WM], fb[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
-        fa[i] = *reinterpret_cast<const f32x4*>(sA + ((wr * WM + i) * 32 + l31) * D32_PITCH + kb * 8 + hh * 4);
+      for (int i = 0; i < WM; ++i) fa[i] = TA::frag(sA, (wr * WM + i) * 32 + l31, kb, hh);
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
-        fb[j] = *reinterpret_cast<const f32x4*>(sB + ((wc * WN + j) * 32 + l31) * D32_PITCH + kb * 8 + hh * 4);
+      for (int j = 0; j < WN; ++j) fb[j] = TB::frag(sB, (wc * WN + j) * 32 + l31, kb, hh);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j) acc[i][j] = mfma_f32x(fa[i][s], fb[j][s], acc[i][j]);
+    }
+  };
+  stA0.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k_begin, k_end, tid);
+  stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid);
+  if (k_begin + D32_BK < k_end) {
+    stA1.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k_begin + D32_BK, k_end, tid);
+    stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin + D32_BK, k_end, tid);
+  }
+  for (int k0 = k_begin; k0 < k_end; k0 += 2 * D32_BK) {
+    __syncthreads();
+    stA0.store(sA, tid);
+    stB0.store(sB, tid);
+    __syncthreads();
+    if (k0 + 2 * D32_BK < k_end) {
+      stA0.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0 + 2 * D32_BK, k_end, tid);
+      stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 2 * D32_BK, k_end, tid);
+    }
+    compute();
+    if (k0 + D32_BK < k_end) {
+      __syncthreads();
+      stA1.store(sA, tid);
+      stB1.store(sB, tid);
+      __syncthreads();
+      if (k0 + 3 * D32_BK < k_end) {
+        stA1.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0 + 3 * D32_BK, k_end, tid);
+        stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 3 * D32_BK, k_end, tid);
+      }
+      compute();
     }
   }
 
@@ -216,9 +249,9 @@ template <bool AC, bool BC, bool WG>
 static int d32_launch(const D32Args& a, int splits, hipStream_t s) {
   // tile choice: the largest tile that still gives the chip ~2 workgroups per CU
   auto wgs = [&](int bm, int bn) { return (long)((a.rows + bm - 1) / bm) * ((a.cols + bn - 1) / bn) * splits; };
-  if (a.cols > 64 && a.rows > 64 && wgs(128, 128) >= 384) {
+  if (a.cols > 64 && a.rows > 64 && wgs(128, 128) >= 256) {
     NNZ_LAUNCH((dense32_kernel<2, 2, AC, BC, WG>), dim3((unsigned)wgs(128, 128) / splits, splits), dim3(256), 0, s, a);
-  } else if (a.cols > 64 && wgs(64, 128) >= 256) {
+  } else if (a.cols > 64 && wgs(64, 128) >= 192) {
     NNZ_LAUNCH((dense32_kernel<1, 2, AC, BC, WG>), dim3((unsigned)wgs(64, 128) / splits, splits), dim3(256), 0, s, a);
   } else {
     NNZ_LAUNCH((dense32_kernel<1, 1, AC, BC, WG>), dim3((unsigned)wgs(64, 64) / splits, splits), dim3(256), 0, s, a);
@@ -255,17 +288,17 @@ extern "C" int nnz_dense32_dgrad(const float* dy, const float* W, const float* h
   return d32_launch<true, false, false>(a, 1, (hipStream_t)stream);
 }
 
-// token splits of the weight gradient: enough workgroups to fill the chip (~1536 with the 64 x 64 tile), at least 64
-// tokens each, at most 64 splits; `per` = tokens per split (a multiple of the contraction block)
+// token splits of the weight gradient: none when the weight matrix alone gives >= 256 tiles of 64 x 64, otherwise enough
+// to reach ~768 workgroups, at least 64 tokens each, at most 64 splits; `per` = tokens per split (a multiple of the contraction block)
 static long d32_wgrad_splits(long T, int K, int N, long* per_out) {
   const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
-  long splits = (1536 + tiles - 1) / tiles;
+  long splits = tiles >= 256 ? 1 : (768 + tiles - 1) / tiles;
   const long max_by_tokens = (T + 63) / 64;
   if (splits > max_by_tokens) splits = max_by_tokens;
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
   long per = (T + splits - 1) / splits;
-  per = (per + nnz::D32_BK - 1) / nnz::D32_BK * nnz::D32_BK;
+  per = (per + 63) / 64 * 64;   // a multiple of every tile's contraction block
   if (per_out) *per_out = per;
   return (T + per - 1) / per;
 }

@@ -18,12 +18,12 @@
 // backward per call at ~0.02 of the fp32 MFMA rate):
 //   * a workgroup = 4 waves = one HEAD and a run of windows: the head's 49 x 49 bias matrix is gathered ONCE into LDS
 //     (transposed, so that the lanes of a score register read consecutive words) and serves every window of the run;
-//   * the contraction over channels may visit the channels in any order as long as both operands agree, so lane half hh
-//     simply owns channels [hh hd/2, (hh+1) hd/2) of its token's row: Q / K / V / dO "row" operands are 16-byte GLOBAL
-//     loads straight into the MFMA operand registers - no LDS, no transposition;
+//   * every operand of a (window, head) is fetched from global memory ONCE, as 16-byte row loads into wave-private
+//     49-row LDS images (a first attempt without any staging made ~36 dependent L2 round trips per window and was slower
+//     than round 2); the contraction over channels may visit the channels in any order as long as both operands agree, so
+//     lane half hh simply owns channels [hh hd/2, (hh+1) hd/2) of its token's image row: no transposed copies;
 //   * operands needed with the TOKEN index in the contraction (V in the forward; K, Q, dO in the backward) are read per
-//     MFMA step as one coalesced row segment (lane = channel), also straight from global memory (the rows were just read
-//     as row operands: L2 hits) - no operand is staged in LDS at all, 15 KB (forward) / 47 KB (backward) per workgroup;
+//     MFMA step as one row segment of the image (lane = channel: conflict-free);
 //   * the bias-table gradient is DETERMINISTIC: dS goes through LDS once per key tile, each of the 169 table entries
 //     (entry = displacement (yi - yj, xi - xj), the layout of the reference's relative_position_index, swt2net.py:545)
 //     sums its (7 - |dy|)(7 - |dx|) members in a fixed order, waves are folded in wave order and workgroups add
@@ -76,10 +76,42 @@ __device__ __forceinline__ void token_map(const AttnArgs& a, int win, int l, int
   }
 }
 
-// "row" operand of one 32-token tile: lane (token l31, half hh) gets channels hh*hd/2 + s, s = 0 .. hd/2 - 1, of its
-// token's row (zeros for tokens >= 49): the contraction over channels visits them in this order for BOTH operands.
-__device__ __forceinline__ void load_rows(const float* src, long row_len, int ch0, int hd, const int* stok, int tile,
-                                          int l31, int hh, float mul, float (&v)[16]) {
+// One [49][hd] operand of the window -> a wave-private LDS image [49][WA_LD] (16-byte global loads along the token's row).
+// Every operand is fetched from global memory exactly once per (window, head): the round-3 first attempt read row and
+// column operands straight from global memory step by step and spent its time in ~36 dependent L2 round trips per window.
+__device__ __forceinline__ void stage_image(const float* src, long row_len, int ch0, int hd, const int* stok, float mul,
+                                            float* dst, int lane) {
+  if ((hd & 3) == 0) {
+    const int q4 = hd >> 2;
+    for (int i = lane; i < WA_L * q4; i += 64) {
+      const int l = i / q4, c4 = (i - l * q4) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)stok[l] * row_len + ch0 + c4);
+      float* d = dst + l * WA_LD + c4;
+      d[0] = v[0] * mul; d[1] = v[1] * mul; d[2] = v[2] * mul; d[3] = v[3] * mul;
+    }
+  } else {
+    for (int i = lane; i < WA_L * hd; i += 64) {
+      const int l = i / hd, c = i - l * hd;
+      dst[l * WA_LD + c] = src[(long)stok[l] * row_len + ch0 + c] * mul;
+    }
+  }
+}
+
+// "row" operand of one 32-token tile from an image: lane (token l31, half hh) gets channels hh*hd/2 + s, s = 0 .. hd/2 - 1
+// of its token's row (zeros for tokens >= 49): the contraction over channels visits them in this order for BOTH operands.
+// Pitch 33 makes the 32 tokens of a lane half hit 32 different banks.
+__device__ __forceinline__ void load_rows(const float* img, int hd, int tile, int l31, int hh, float (&v)[16]) {
+  const int l = tile * 32 + l31;
+  const int half = hd >> 1;
+  const float* p = img + (l < WA_L ? l : 0) * WA_LD + hh * half;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) v[s] = (l < WA_L && s < half) ? p[s] : 0.f;
+}
+
+// the same row operand straight from global memory (forward: Q is used once per window, so it skips the image and the
+// forward's LDS drops to two images per wave = two workgroups per CU)
+__device__ __forceinline__ void load_rows_global(const float* src, long row_len, int ch0, int hd, const int* stok, int tile,
+                                                 int l31, int hh, float mul, float (&v)[16]) {
   const int l = tile * 32 + l31;
   const int half = hd >> 1;
 #pragma unroll
@@ -98,6 +130,16 @@ __device__ __forceinline__ void load_rows(const float* src, long row_len, int ch
       for (int s = 0; s < 16; ++s)
         if (s < half) v[s] = p[s] * mul;
     }
+  }
+}
+
+// "column" operand: step r of a 32-token tile needs X[token tile*32 + crow(r, hh)][channel l31] - the token index is the
+// contraction index of the MFMA, the lane is the channel (consecutive words of one image row: conflict-free)
+__device__ __forceinline__ void load_cols(const float* img, int hd, int tile, int l31, int hh, float (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = tile * 32 + crow(r, hh);
+    v[r] = (j < WA_L && l31 < hd) ? img[j * WA_LD + l31] : 0.f;
   }
 }
 
@@ -188,22 +230,27 @@ __device__ __forceinline__ void scores_T(const float (&kv)[2][16], const float (
   inv_out = inv;
 }
 
+constexpr int WA_IMG = WA_L * WA_LD;  // floats of one [49][33] image
+
 __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
-  __shared__ float sbT[WA_L * WA_BP];
-  __shared__ int stok_all[4][64], sreg_all[4][64];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sbT = smem;                                      // [49][64]
+  float* wbase = smem + WA_L * WA_BP;                     // per wave: sk, sv images | stok, sreg
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
   const int head = blockIdx.y;
   const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
-  int* stok = stok_all[wave];
-  int* sreg = sreg_all[wave];
+  float* sk = wbase + wave * (2 * WA_IMG + 128);
+  float* sv = sk + WA_IMG;
+  int* stok = reinterpret_cast<int*>(sv + WA_IMG);
+  int* sreg = stok + 64;
   stage_bias(a, head, sbT, tid, 256);
   __syncthreads();
   const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
   for (int win = blockIdx.x * a.wpb + wave; win < w_end; win += 4) {
-    wave_sync();  // the previous window's readers are done with stok / sreg
+    wave_sync();  // the previous window's readers are done with the images / stok / sreg
     {
       int base = 0, region = 0;
       if (lane < WA_L) token_map(a, win, lane, base, region);
@@ -211,61 +258,45 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
       sreg[lane] = region;
     }
     wave_sync();
+    float qv[2][16];
+    load_rows_global(a.qkv, C3, head * hd, hd, stok, 0, l31, hh, a.scale, qv[0]);
+    load_rows_global(a.qkv, C3, head * hd, hd, stok, 1, l31, hh, a.scale, qv[1]);
+    stage_image(a.qkv, C3, a.C + head * hd, hd, stok, 1.f, sk, lane);
+    stage_image(a.qkv, C3, 2 * a.C + head * hd, hd, stok, 1.f, sv, lane);
+    wave_sync();
     float kv[2][16];
-    load_rows(a.qkv, C3, a.C + head * hd, hd, stok, 0, l31, hh, 1.f, kv[0]);
-    load_rows(a.qkv, C3, a.C + head * hd, hd, stok, 1, l31, hh, 1.f, kv[1]);
-    // V with the KEY in the contraction: step r of key tile tk needs V[key tk*32 + crow(r, hh)][channel l31] - one
-    // coalesced row segment per lane half
-    float vc[2][16];
+    load_rows(sk, hd, 0, l31, hh, kv[0]);
+    load_rows(sk, hd, 1, l31, hh, kv[1]);
 #pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = tk * 32 + crow(r, hh);
-        vc[tk][r] = (j < WA_L && l31 < hd) ? a.qkv[(long)stok[j] * C3 + 2 * a.C + head * hd + l31] : 0.f;
-      }
-#pragma unroll 1
     for (int tq = 0; tq < 2; ++tq) {
-      float qv[16];
-      load_rows(a.qkv, C3, head * hd, hd, stok, tq, l31, hh, a.scale, qv);
       f32x16 p[2];
       float m, inv;
-      scores_T(kv, qv, steps, sbT, sreg, a.shift, tq, l31, hh, p, m, inv);
+      scores_T(kv, qv[tq], steps, sbT, sreg, a.shift, tq, l31, hh, p, m, inv);
       // O^T[channel][query] = sum_key V[key][channel] P^T[key][query]
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
-      for (int tk = 0; tk < 2; ++tk)
+      for (int tk = 0; tk < 2; ++tk) {
+        float vc[16];
+        load_cols(sv, hd, tk, l31, hh, vc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o = mfma_f32(vc[tk][r], p[tk][r], o);
+        for (int r = 0; r < 16; ++r) o = mfma_f32(vc[r], p[tk][r], o);
+      }
       const int i = tq * 32 + l31;
       if (i < WA_L) store_cols(a.out + (long)stok[i] * a.C + head * hd, o, hh, hd, 1.f);
     }
   }
 }
 
-// "column" operand: step r of a 32-token tile needs X[token tile*32 + crow(r, hh)][channel l31] - the token index is the
-// contraction index of the MFMA, the lane is the channel: one coalesced row segment per lane half and step, straight from
-// global memory (the rows were just read as row operands: L2 hits)
-__device__ __forceinline__ void load_cols(const float* src, long row_len, int ch0, int hd, const int* stok, int tile,
-                                          int l31, int hh, float mul, float (&v)[16]) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int j = tile * 32 + crow(r, hh);
-    v[r] = (j < WA_L && l31 < hd) ? src[(long)stok[j] * row_len + ch0 + l31] * mul : 0.f;
-  }
-}
-
 // backward.  Pass A (transposed orientation, queries on lanes): P^T, dP^T, delta, dS^T -> dQ.
 //            Pass B (queries on rows, keys on lanes): P, dP, dS -> dV, dK, and dS -> the bias-table gradient.
-// Row statistics cross from A to B through LDS.  No operand is staged: LDS holds the head's bias matrix (per workgroup)
-// and per wave the row statistics, the token map and one [49][33] dS tile for the bias-gradient sums: 47 KB per workgroup,
-// three workgroups per CU.
+// Row statistics cross from A to B through LDS.  LDS per workgroup: the head's bias matrix and per wave four operand images,
+// one [49][33] dS tile for the bias-gradient sums, the row statistics and the token map (~150 KB: one workgroup per CU).
 constexpr int WA_DSP = 33;                                    // pitch of the per-key-tile dS image [query][key - 32 tk]
-constexpr int WA_WAVE_FLOATS = WA_L * WA_DSP + 3 * 64 + 2 * 64;  // sds | srow[3][64] | stok, sreg
+constexpr int WA_WAVE_FLOATS = 4 * WA_IMG + WA_L * WA_DSP + 3 * 64 + 2 * 64;  // sq sk sv sdo | sds | srow[3][64] | stok, sreg
 
-__global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sbT = smem;                                   // [49][64]
   float* sdb_all = smem + WA_L * WA_BP;                // [4 waves][176]
@@ -276,7 +307,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(AttnArgs a) {
   const int l31 = lane & 31, hh = lane >> 5;
   const int head = blockIdx.y;
   const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
-  float* sds = wbase + wave * WA_WAVE_FLOATS;          // dS[query][key - 32 tk] of the current key tile
+  float* sq = wbase + wave * WA_WAVE_FLOATS;           // Q * scale, K, V, dO images [49][33]
+  float* sk = sq + WA_IMG;
+  float* sv = sk + WA_IMG;
+  float* sdo = sv + WA_IMG;
+  float* sds = sdo + WA_IMG;                           // dS[query][key - 32 tk] of the current key tile
   float* srow = sds + WA_L * WA_DSP;                   // [3][64]: row max, 1 / sum, delta per query
   int* stok = reinterpret_cast<int*>(srow + 3 * 64);
   int* sreg = stok + 64;
@@ -296,25 +331,30 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(AttnArgs a) {
       sreg[lane] = region;
     }
     wave_sync();
+    stage_image(a.qkv, C3, qo, hd, stok, a.scale, sq, lane);
+    stage_image(a.qkv, C3, ko, hd, stok, 1.f, sk, lane);
+    stage_image(a.qkv, C3, vo, hd, stok, 1.f, sv, lane);
+    stage_image(a.dout, a.C, qo, hd, stok, 1.f, sdo, lane);
+    wave_sync();
 
     // ---------------- pass A: keys on rows, queries on lanes --------------------------------------------------------
 #pragma unroll 1
     for (int tq = 0; tq < 2; ++tq) {
       float qv[16], gv[16];
-      load_rows(a.qkv, C3, qo, hd, stok, tq, l31, hh, a.scale, qv);
-      load_rows(a.dout, a.C, qo, hd, stok, tq, l31, hh, 1.f, gv);
+      load_rows(sq, hd, tq, l31, hh, qv);
+      load_rows(sdo, hd, tq, l31, hh, gv);
       f32x16 s[2], dp[2];
       float m, inv;
       {
         float kv[2][16];
-        load_rows(a.qkv, C3, ko, hd, stok, 0, l31, hh, 1.f, kv[0]);
-        load_rows(a.qkv, C3, ko, hd, stok, 1, l31, hh, 1.f, kv[1]);
+        load_rows(sk, hd, 0, l31, hh, kv[0]);
+        load_rows(sk, hd, 1, l31, hh, kv[1]);
         scores_T(kv, qv, steps, sbT, sreg, a.shift, tq, l31, hh, s, m, inv);  // s = P^T
       }
 #pragma unroll
       for (int tk = 0; tk < 2; ++tk) {
         float vv[16];
-        load_rows(a.qkv, C3, vo, hd, stok, tk, l31, hh, 1.f, vv);
+        load_rows(sv, hd, tk, l31, hh, vv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[tk][r] = 0.f;
 #pragma unroll
@@ -344,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int tk = 0; tk < 2; ++tk) {
         float kc[16];
-        load_cols(a.qkv, C3, ko, hd, stok, tk, l31, hh, 1.f, kc);
+        load_cols(sk, hd, tk, l31, hh, kc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) o = mfma_f32(kc[r], s[tk][r], o);
       }
@@ -359,13 +399,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(AttnArgs a) {
       f32x16 s[2], dp[2];  // [tq]
       {
         float kv[16], vv[16];
-        load_rows(a.qkv, C3, ko, hd, stok, tk, l31, hh, 1.f, kv);
-        load_rows(a.qkv, C3, vo, hd, stok, tk, l31, hh, 1.f, vv);
+        load_rows(sk, hd, tk, l31, hh, kv);
+        load_rows(sv, hd, tk, l31, hh, vv);
 #pragma unroll
         for (int tq = 0; tq < 2; ++tq) {
           float qr[16], gr[16];
-          load_rows(a.qkv, C3, qo, hd, stok, tq, l31, hh, a.scale, qr);
-          load_rows(a.dout, a.C, qo, hd, stok, tq, l31, hh, 1.f, gr);
+          load_rows(sq, hd, tq, l31, hh, qr);
+          load_rows(sdo, hd, tq, l31, hh, gr);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             s[tq][r] = 0.f;
@@ -408,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq) {
         float gc[16], qc[16];
-        load_cols(a.dout, a.C, qo, hd, stok, tq, l31, hh, 1.f, gc);
-        load_cols(a.qkv, C3, qo, hd, stok, tq, l31, hh, a.scale, qc);
+        load_cols(sdo, hd, tq, l31, hh, gc);
+        load_cols(sq, hd, tq, l31, hh, qc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           ov = mfma_f32(gc[r], s[tq][r], ov);
@@ -486,7 +526,11 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
   if (int rc = check(a)) return rc;
   a.nwin = B * (H / WA_WS) * (W / WA_WS);
   a.wpb = windows_per_wg(a.nwin, heads);
-  NNZ_LAUNCH(win_attn_fwd_kernel, dim3((a.nwin + a.wpb - 1) / a.wpb, heads), dim3(256), 0, (hipStream_t)stream, a);
+  const int lds = (WA_L * WA_BP + 4 * (2 * WA_IMG + 128)) * (int)sizeof(float);
+  static DynLdsCache cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_fwd_kernel), lds, cache);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH(win_attn_fwd_kernel, dim3((a.nwin + a.wpb - 1) / a.wpb, heads), dim3(256), lds, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
