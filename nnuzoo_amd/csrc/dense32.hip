@@ -19,6 +19,8 @@
 // registers); the next contraction block is prefetched into registers under the MFMAs of the current one.
 // The weight gradient splits the token axis over workgroups; partials go to a workspace and a second kernel folds them in
 // a fixed order (deterministic: no float atomics), the bias gradient rides along as the column sums of the dy tile.
+// (Folding inside the same launch - the split that finishes last re-reads its tile's partials - was tried: the partials
+// then have to travel through agent-scope 4-byte stores and loads, which made the SwT2Net step 40 % slower.)
 #include "common.hpp"
 
 namespace nnz {
@@ -289,13 +291,13 @@ extern "C" int nnz_dense32_dgrad(const float* dy, const float* W, const float* h
 }
 
 // token splits of the weight gradient: none when the weight matrix alone gives >= 256 tiles of 64 x 64, otherwise enough
-// to reach ~768 workgroups, at least 64 tokens each, at most 64 splits; `per` = tokens per split (a multiple of the contraction block)
+// to reach ~768 workgroups, at least 64 tokens each, at most 16 splits; `per` = tokens per split (a multiple of the contraction block)
 static long d32_wgrad_splits(long T, int K, int N, long* per_out) {
   const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
   long splits = tiles >= 256 ? 1 : (768 + tiles - 1) / tiles;
   const long max_by_tokens = (T + 63) / 64;
   if (splits > max_by_tokens) splits = max_by_tokens;
-  if (splits > 64) splits = 64;
+  if (splits > 16) splits = 16;
   if (splits < 1) splits = 1;
   long per = (T + splits - 1) / splits;
   per = (per + 63) / 64 * 64;   // a multiple of every tile's contraction block

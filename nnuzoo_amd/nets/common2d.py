@@ -61,7 +61,9 @@ class _ResidualDropPathFn(torch.autograd.Function):
         dout = dout.contiguous()
         h = torch.float16
         dx = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and mask is None and scale == 1.0 and dout.dtype == xdt:
+            dx = dout                                   # plain residual: both branches receive the same gradient tensor
+        elif ctx.needs_input_grad[1]:
             dx = torch.empty(dout.shape, dtype=xdt, device=dout.device)
             call("nnz_residual_droppath_backward", ptr(dout), int(dout.dtype == h), ptr(mask),
                  int(mask is not None and mask.dtype == h), float(scale), ptr(dx), int(xdt == h), B, P, stream_ptr())

@@ -25,7 +25,7 @@ from ..token_linear import TokenLinear, mlp_gelu
 
 from ..utilities.network_initialization import InitWeights_He
 from ..window_attention import window_attention_core
-from .common2d import Convolution, PatchExpand, PatchMerging2D, get_dwconv_layer
+from .common2d import Convolution, PatchExpand, PatchMerging2D, _ResidualDropPathFn, get_dwconv_layer
 from .common2d import RSU4F as _RSU4F
 from .m2net import _U2Forward, _heads
 
@@ -194,14 +194,28 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
+    def _residual(self, inp, y):
+        """inp + drop_path(y) (swt2net.py:379-388) as ONE kernel each way (csrc/residual.hip) instead of div, mul and add;
+        the per-sample mask is drawn exactly like the reference's DropPath (torch.rand of shape (B, 1, 1, 1), floor)"""
+        dp = self.drop_path
+        ok = y.is_cuda and inp.shape == y.shape and y.dtype == torch.float32 and inp.dtype == torch.float32 \
+            and y.is_contiguous() and inp.is_contiguous() and (y.numel() // y.shape[0]) % 4 == 0
+        if not ok:
+            return inp + dp(y)
+        if isinstance(dp, DropPath) and dp.drop_prob > 0. and dp.training:
+            keep = 1 - dp.drop_prob
+            mask = (keep + torch.rand((y.shape[0],) + (1,) * (y.ndim - 1), dtype=y.dtype, device=y.device)).floor_()
+            return _ResidualDropPathFn.apply(inp, y, mask, 1.0 / keep)
+        return _ResidualDropPathFn.apply(inp, y, None, 1.0)
+
     def forward(self, x):
         _, H, W, _ = x.shape
         ws = self.window_size
         pad = H % ws != 0 or W % ws != 0
         if pad:  # top/left padding, a full extra window on an axis that already divides (reference quirk, :643-645)
             x = F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0))
-        x = x + self.drop_path(self.attn(self.norm1(x)))
-        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        x = self._residual(x, self.attn(self.norm1(x)))
+        x = self._residual(x, self.mlp(self.norm2(x)))
         return x[:, -H:, -W:, :] if pad else x
 
 
