@@ -426,6 +426,15 @@ int nnz_window_attention_backward(const float* qkv, const float* bias_table, con
                                   float* dqkv, float* dbias_table, void* acc, void* counter, int B, int H, int W, int C,
                                   int heads, int shift, float scale, void* stream);
 
+/* ---- global (ViT) multi-head self-attention core, fp32 MFMA, flash-style (csrc/global_attention.hip, round 3) -----------
+ * replaces monai's SABlock einsum / softmax / einsum between its qkv and out_proj Linears (bound by the reference at
+ * nnunetv2/nets/unetr2net.py:10,1414-1428).  qkv [B][L][3][H][D], out [B][L][H*D], lse [B][H][L]; D even, <= 32.
+ * The backward writes all of dqkv and uses no atomics (keys-side pass: dK, dV; queries-side pass: dQ). */
+int nnz_global_attention_forward(const float* qkv, float* out, float* lse, int B, int L, int H, int D, float scale,
+                                 void* stream);
+int nnz_global_attention_backward(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
+                                  int B, int L, int H, int D, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

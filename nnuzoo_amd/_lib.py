@@ -154,6 +154,8 @@ SIGNATURES = {
     "nnz_causal_conv1d_silu_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
     "nnz_silu_gate_forward": [_fp, _fp, _fp, _l, _vp],
     "nnz_silu_gate_backward": [_fp, _fp, _fp, _fp, _fp, _l, _vp],
+    "nnz_global_attention_forward": [_fp, _fp, _fp, _i, _i, _i, _i, _f, _vp],
+    "nnz_global_attention_backward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _vp],
     "nnz_window_attention_forward": [_fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_window_attention_backward": [_fp, _fp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_selective_scan_workspace_floats": [_i, _i, _i],

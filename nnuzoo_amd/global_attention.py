@@ -2,18 +2,45 @@
 /root/reference/nnunetv2/nets/unetr2net.py:10,1414-1428): softmax(q k^T * scale) v over all L <= 1024 patch tokens, head_dim
 8 / 16 / 32, from the packed qkv projection (B, L, 3, heads, head_dim) to the merged-head output (B, L, heads * head_dim).
 
-The score matrix is never written to HBM: the contraction runs through the fused scaled-dot-product kernels of the ROCm
-stack (`torch.nn.functional.scaled_dot_product_attention`, flash / memory-efficient back ends), reading q, k, v as strided
-views of the qkv tensor.  (A hand-written kernel for this shape class is the same problem as csrc/window_attention.hip
-with 1024 keys instead of 49 - listed as next in DESIGN.md.)"""
+Hand-written flash-style kernels (csrc/global_attention.hip, fp32 MFMA; round 2 forwarded to torch's SDPA): the score
+matrix is never written to HBM, the backward is two atomic-free passes (keys side: dK / dV, queries side: dQ) that
+recompute P from the saved log-sum-exp.  fp16 inputs (autocast steps) are widened to fp32 operands: products of fp16
+values are exact in fp32 and the accumulation is fp32 either way, so the result is at least as accurate as the
+reference's autocast einsum / softmax / einsum chain; the output takes the input's dtype.  CPU tensors raise."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
+
+from ._lib import call, ptr, stream_ptr
+
+
+class _GlobalAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv: torch.Tensor, scale: float):
+        if not qkv.is_cuda:
+            raise RuntimeError("global_attention runs on MI355X through libnnuzoo_hip.so only (no CPU fallback)")
+        B, L, three, H, D = qkv.shape
+        if three != 3 or D % 2 or D > 32:
+            raise NotImplementedError(f"global_attention: head_dim must be even and <= 32, got {D}")
+        q32 = qkv.float().contiguous()
+        out = torch.empty((B, L, H * D), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+        call("nnz_global_attention_forward", ptr(q32), ptr(out), ptr(lse), B, L, H, D, float(scale), stream_ptr())
+        ctx.save_for_backward(q32, out, lse)
+        ctx.cfg = (B, L, H, D, float(scale), qkv.dtype)
+        return out if qkv.dtype == torch.float32 else out.to(qkv.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q32, out, lse = ctx.saved_tensors
+        B, L, H, D, scale, dt = ctx.cfg
+        dout = dout.float().contiguous()
+        dqkv = torch.empty_like(q32)
+        call("nnz_global_attention_backward", ptr(q32), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), B, L, H, D, scale,
+             stream_ptr())
+        return (dqkv if dt == torch.float32 else dqkv.to(dt)), None
 
 
 def global_attention(qkv: torch.Tensor, scale: float) -> torch.Tensor:
-    B, L, three, H, D = qkv.shape
-    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # (B, H, L, D) views
-    o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=scale)
-    return o.transpose(1, 2).reshape(B, L, H * D)
+    """qkv: (B, L, 3, heads, head_dim) -> (B, L, heads * head_dim)"""
+    return _GlobalAttentionFn.apply(qkv, scale)

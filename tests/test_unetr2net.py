@@ -22,8 +22,12 @@ def test_structure_cpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,L,H,D", [(2, 1024, 12, 8), (1, 256, 12, 16), (2, 64, 12, 32), (3, 4, 12, 32)])
+@pytest.mark.parametrize("B,L,H,D", [(2, 1024, 12, 8), (1, 256, 12, 16), (2, 64, 12, 32), (3, 4, 12, 32), (1, 777, 3, 24),
+                                     (2, 130, 5, 2), (1, 1024, 12, 32)])
 def test_global_attention_vs_explicit_formula(hip_lib, B, L, H, D):
+    """csrc/global_attention.hip (hand-written flash-style kernels, round 3) against the explicit float64 formula of monai's
+    SABlock; ragged L (not a multiple of the 64-token blocks / 128-token workgroups), all head_dims of the zoo and odd ones;
+    the backward has no atomics: two runs are bit-identical"""
     from nnuzoo_amd.global_attention import global_attention
     g = torch.Generator().manual_seed(L + D)
     qkv = torch.randn(B, L, 3, H, D, generator=g).cuda().requires_grad_(True)
@@ -38,6 +42,13 @@ def test_global_attention_vs_explicit_formula(hip_lib, B, L, H, D):
     ref.backward(go.double())
     assert torch.allclose(o.double(), ref, rtol=2e-4, atol=2e-5)
     assert torch.allclose(qkv.grad.double(), ref_in.grad, rtol=2e-3, atol=2e-5)
+    g1 = qkv.grad.clone()
+    qkv.grad = None
+    global_attention(qkv, scale).backward(go)
+    assert torch.equal(qkv.grad, g1)
+    with torch.autocast("cuda", dtype=torch.float16):                       # autocast steps hand over fp16 qkv
+        oh = global_attention(qkv.detach().half(), scale)
+    assert oh.dtype == torch.float16 and torch.allclose(oh.double(), ref.detach(), rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.gpu
