@@ -58,14 +58,17 @@ class GraphedForwardBackward:
         self._key = None
         self._static_grads = []        # [(parameter, the .grad tensor the captured backward writes)]
 
+    def _loss(self, out, target):
+        if isinstance(out, (tuple, list)):
+            return self.loss_fn(list(out), target)
+        return self.loss_fn(out, target[0] if isinstance(target, (tuple, list)) else target)   # single-output network
+
     def _fwd_bwd(self, data, target):
         if self.autocast:
             with torch.autocast('cuda'):
-                out = self.network(data)
-                loss = self.loss_fn(list(out) if isinstance(out, (tuple, list)) else out, target)
+                loss = self._loss(self.network(data), target)
         else:
-            out = self.network(data)
-            loss = self.loss_fn(list(out) if isinstance(out, (tuple, list)) else out, target)
+            loss = self._loss(self.network(data), target)
         (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
         return loss
 

@@ -139,7 +139,7 @@ class _X2Trainer(nnUNetTrainer):
         self.optimizer.zero_grad(set_to_none=True)
         if self._fp32_step:
             output = self.network(data)
-            l = self.loss(list(output), target)
+            l = self.loss(list(output) if isinstance(output, (tuple, list)) else output, target)
             l.backward()
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())
@@ -148,7 +148,7 @@ class _X2Trainer(nnUNetTrainer):
         else:
             with torch.autocast('cuda'):
                 output = self.network(data)
-                l = self.loss(list(output), target)
+                l = self.loss(list(output) if isinstance(output, (tuple, list)) else output, target)
             self.grad_scaler.scale(l).backward()
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())    # scaled gradients, like torch DDP under AMP
@@ -279,3 +279,72 @@ class nnUNetTrainerLightMamba2NetP(nnUNetTrainerLightMamba2Net):
     @staticmethod
     def build_network_architecture(*args, **kwargs):
         return nnUNetTrainerLightMamba2Net._build(args, kwargs, True)
+
+
+def _live_num_in_out(args, kwargs):
+    """(num_input_channels, num_output_channels, deep_supervision) from the live calling convention
+    (architecture_class_name, arch_init_kwargs, req_import, num_input_channels, num_output_channels, ds) or, for callers
+    that still use the legacy one, from (plans_manager, dataset_json, configuration_manager, num_input_channels, ds)"""
+    if args and isinstance(args[0], str):
+        ds = args[5] if len(args) > 5 else kwargs.get("enable_deep_supervision", True)
+        return args[3], args[4], ds
+    names = ["plans_manager", "dataset_json", "configuration_manager", "num_input_channels", "enable_deep_supervision"]
+    a = dict(zip(names, args))
+    a.update(kwargs)
+    from .nnUNetTrainer import _num_segmentation_heads
+    return a["num_input_channels"], _num_segmentation_heads(a["dataset_json"]), a.get("enable_deep_supervision", True)
+
+
+class nnUNetTrainerU2Net(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerU2Net.py:14-99 (U2NET; the base trainer's autocast train_step; AdamW
+    1e-4 / wd 5e-2 / eps 1e-5, cosine to 1e-6; seven deep-supervision outputs, ALL at full resolution: scales [[1, 1]] * 7)"""
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250, **kwargs):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.early_stop_epoch = 10
+
+    def _get_deep_supervision_scales(self):
+        return [[1.0, 1.0]] * 7 if self.enable_deep_supervision else None
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.u2net import get_u2net_from_plans
+        num_in, num_out, ds = _live_num_in_out(args, kwargs)
+        return get_u2net_from_plans(num_out, num_in, deep_supervision=ds, use_pretrain=False)
+
+
+class nnUNetTrainerU2NetP(nnUNetTrainerU2Net):
+    """reference :102-124 (U2NETP)"""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.u2net import get_u2netp_from_plans
+        num_in, num_out, ds = _live_num_in_out(args, kwargs)
+        return get_u2netp_from_plans(num_out, num_in, deep_supervision=ds, use_pretrain=False)
+
+
+class nnUNetTrainerSwinTransformerUnet(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerSwinTransformerUnet.py:17-108 (the single Swin U-net of nets/swt.py; deep
+    supervision OFF - one output -, AdamW 1e-4 / wd 5e-2, cosine; the base trainer's autocast train_step).  The reference's
+    build_network_architecture passes (plans_manager, dataset_json, configuration_manager, ...) to a factory that takes
+    (num_segmentation_heads, num_input_channels, ...) - it cannot run as written (:36-43 vs swt.py:505-510); here the factory
+    receives the counts it is declared with."""
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.enable_deep_supervision = False
+        self.early_stop_epoch = 10
+
+    def _get_deep_supervision_scales(self):
+        return [[1.0, 1.0]] * 7 if self.enable_deep_supervision else None
+
+    def set_deep_supervision_enabled(self, enabled: bool):
+        pass                                   # single-output network
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.swt import get_swin_transformer_unet
+        num_in, num_out, ds = _live_num_in_out(args, kwargs)
+        return get_swin_transformer_unet(num_out, num_in, deep_supervision=ds, use_pretrain=False)

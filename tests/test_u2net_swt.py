@@ -1,0 +1,146 @@
+"""U^2-Net / U^2-Net-P (nnuzoo_amd/nets/u2net.py) and the single Swin U-net (nnuzoo_amd/nets/swt.py) against fixtures produced
+by the REFERENCE's own classes (tools/make_golden_r3.py under tools/ref_shim.py: nets/u2net.py U2NET / U2NETP through their
+factories, nets/swt.py get_swin_transformer_unet):
+  CPU  state_dict names / shapes / ORDER; torch.manual_seed(0) + factory = the reference's parameters bit for bit; U2NET(P)
+       forward + backward in fp32 on the CPU (these classes are torch modules there; the HIP dispatch needs the GPU)
+  GPU  whole-net forward (all outputs) and backward (dx, every parameter gradient: 256 strided samples + L2 norm) - fp32
+       (library convs for U^2-Net, the native attention / Linear / LayerNorm kernels for the Swin net) and, for U2NET, the fp16
+       autocast step in train mode where its REBNCONV units run on the tap-table MFMA conv kernels (backend asserted)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import det_fill
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+MAN = json.load(open(os.path.join(G, "r3_manifest.json")))
+
+
+def _factory(name):
+    from nnuzoo_amd.nets import swt, u2net
+    return {"U2NET": u2net.get_u2net_from_plans, "U2NETP": u2net.get_u2netp_from_plans,
+            "SwinTransformerUnet": swt.get_swin_transformer_unet}[name]
+
+
+def _digest(sd):
+    import hashlib
+    import zlib
+    h = hashlib.sha256()
+    crc = {}
+    for i, (k, v) in enumerate(sd.items()):
+        b = v.detach().cpu().contiguous().numpy().tobytes()
+        h.update(b)
+        if i % 40 == 0:
+            crc[k] = zlib.crc32(b)
+    return {"sha256": h.hexdigest(), "n_tensors": len(sd), "crc32": crc}
+
+
+@pytest.mark.parametrize("name", ["U2NET", "U2NETP", "SwinTransformerUnet"])
+def test_state_dict_and_seeded_construction(name):
+    torch.manual_seed(0)
+    net = _factory(name)(2, 1, True, False)
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == MAN[name]["state_dict"]
+    got, want = _digest(net.state_dict()), MAN[name]["seeded"]
+    assert got["n_tensors"] == want["n_tensors"]
+    assert [k for k in want["crc32"] if got["crc32"].get(k) != want["crc32"][k]] == []
+    assert got["sha256"] == want["sha256"]
+
+
+def _close(got, ref, what, rtol):
+    ref = torch.as_tensor(ref)
+    got = got.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * max(ref.abs().max().item(), 1e-6), (what, err, ref.abs().max().item())
+
+
+def _fwd_bwd_check(name, dev, rtol_out, rtol_grad, autocast=False, train=False):
+    z = np.load(os.path.join(G, f"net_{name}_64.npz"))
+    zg = np.load(os.path.join(G, f"netgrad_{name}_64.npz"))
+    torch.manual_seed(0)
+    net = _factory(name)(2, 1, True, False)
+    det_fill(net)
+    net = net.to(dev)
+    net.train(train)
+    x = torch.tensor(z["x"]).to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+        outs = net(x)
+    outs = list(outs) if isinstance(outs, (tuple, list)) else [outs]
+    assert len(outs) == len([k for k in z.files if k.startswith("out")])
+    if not train:
+        for i, o in enumerate(outs):
+            _close(o, z[f"out{i}"], f"{name} out{i}", rtol_out)
+    loss = 0
+    for i, o in enumerate(outs):
+        j = torch.arange(o.numel(), dtype=torch.float64)
+        loss = loss + (o.float() * torch.sin(0.37 * j + i).float().view_as(o).to(dev)).sum() / o[0, 0].numel()
+    loss.backward()
+    if train:
+        assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+        return net
+    _close(x.grad, zg["dx"], "dx", rtol_grad)
+    names = [str(n) for n in zg["names"]]
+    assert [n for n, p in net.named_parameters() if p.grad is not None] == names
+    worst = (0.0, "")
+    for k, (n, p) in enumerate(net.named_parameters()):
+        if p.grad is None:
+            continue
+        g = p.grad.reshape(-1)
+        ref = torch.tensor(zg[f"g{k}"])
+        got = g[::max(1, g.numel() // 256)][:256].float().cpu()
+        scale = float(zg[f"n{k}"]) / g.numel() ** 0.5 + 1e-12
+        worst = max(worst, (((got - ref).abs().max() / max(scale, ref.abs().max().item())).item(), n))
+        assert abs(g.double().norm().item() - float(zg[f"n{k}"])) <= 5 * rtol_grad * float(zg[f"n{k}"]) + 1e-9, n
+    assert worst[0] < 5 * rtol_grad, worst
+    return net
+
+
+@pytest.mark.parametrize("name", ["U2NET", "U2NETP"])
+def test_u2net_cpu_forward_backward_golden(name):
+    _fwd_bwd_check(name, "cpu", 2e-5, 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["U2NET", "U2NETP", "SwinTransformerUnet"])
+def test_gpu_forward_backward_golden(hip_lib, name):
+    _fwd_bwd_check(name, "cuda", 3e-4, 2e-3)
+
+
+@pytest.mark.gpu
+def test_u2net_autocast_units_run_on_hip(hip_lib):
+    """eval-mode forward under fp16 autocast against the fp32 golden (fp16 tolerance), then a train-mode step: the REBNCONV
+    units with channel counts in multiples of 32 report the HIP backend, the others (1-channel input, 16-channel mid) torch"""
+    from nnuzoo_amd.nets.u2net import REBNCONV
+    z = np.load(os.path.join(G, "net_U2NET_64.npz"))
+    torch.manual_seed(0)
+    net = _factory("U2NET")(2, 1, True, False)
+    det_fill(net)
+    net = net.cuda().eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        outs = net(torch.tensor(z["x"]).cuda())
+    for i, o in enumerate(outs):
+        _close(o, z[f"out{i}"], f"autocast out{i}", 3e-2)
+    units = [m for m in net.modules() if isinstance(m, REBNCONV)]
+    assert sum(m.backend == "hip" for m in units) >= 60 and net.stage1.rebnconvin.backend == "library"
+    net = _fwd_bwd_check("U2NET", "cuda", 0, 0, autocast=True, train=True)
+    assert sum(m.backend == "hip" for m in net.modules() if isinstance(m, REBNCONV)) >= 60
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trainer", ["nnUNetTrainerU2NetP", "nnUNetTrainerSwinTransformerUnet"])
+def test_trainer_steps(hip_lib, trainer):
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training import zoo_trainers as Z
+    plans, cfg, dj = nnunet_plans(2, (64, 64), batch_size=2)
+    torch.manual_seed(0)
+    tr = getattr(Z, trainer)(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    scales = tr._get_deep_supervision_scales()
+    b = synthetic_batch(2, (64, 64), scales if scales else [[1.0, 1.0]], seed=5)
+    tgt = [t.cuda() for t in b["target"]] if scales else b["target"][0].cuda()
+    b = {"data": b["data"].cuda(), "target": tgt}
+    losses = [float(tr.train_step(b)["loss"]) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
