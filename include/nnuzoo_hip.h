@@ -426,6 +426,16 @@ int nnz_window_attention_backward(const float* qkv, const float* bias_table, con
                                   float* dqkv, float* dbias_table, void* acc, void* counter, int B, int H, int W, int C,
                                   int heads, int shift, float scale, void* stream);
 
+/* LayerNorm backward with deterministic dgamma / dbeta (fixed-point cross-workgroup sums, csrc/common.hpp): acc = 2 * C
+ * zeroed records of nnz_fxacc_bytes() bytes, counter = one zeroed 32-bit word, both left zero; dgamma / dbeta are written */
+int nnz_layer_norm_backward_det(const void* x, int x_is_f16, const float* gamma, const float* mean, const float* rstd,
+                                const void* dy, int dy_is_f16, void* dx, float* dgamma, float* dbeta, void* acc,
+                                void* counter, long rows, int C, void* stream);
+int nnz_layer_norm_gate_backward_det(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
+                                     int z_is_f16, long z_row_stride, const float* mean, const float* rstd,
+                                     const void* dy, int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta,
+                                     void* acc, void* counter, long rows, int C, void* stream);
+
 /* ---- global (ViT) multi-head self-attention core, fp32 MFMA, flash-style (csrc/global_attention.hip, round 3) -----------
  * replaces monai's SABlock einsum / softmax / einsum between its qkv and out_proj Linears (bound by the reference at
  * nnunetv2/nets/unetr2net.py:10,1414-1428).  qkv [B][L][3][H][D], out [B][L][H*D], lse [B][H][L]; D even, <= 32.

@@ -30,6 +30,8 @@ struct LnArgs {
   long z_stride;
   int z_is_f16;
   int y_is_f16, dy_is_f16;
+  FxAcc* acc;       // backward, deterministic: [2][C] fixed-point accumulators (common.hpp) + launch counter; dgamma / dbeta are
+  unsigned* counter;  // then WRITTEN by the launch's last workgroup (no zero fill, no float atomics)
   float* zero_buf;  // forward: [2][C] buffer the matching backward will accumulate dgamma / dbeta into - zeroed here, so the
                     // backward needs no zeroing launch of its own (may be null)
 };
@@ -209,9 +211,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
       sg += fold[0][gg][c];
       sb += fold[1][gg][c];
     }
-    if (a.dgamma) atomicAdd(a.dgamma + c, sg);
-    if (a.dbeta) atomicAdd(a.dbeta + c, sb);
+    if (a.acc) {
+      fx_add(a.acc, c, 2L * C, blockIdx.x, (double)sg);
+      fx_add(a.acc, (long)C + c, 2L * C, blockIdx.x, (double)sb);
+    } else {
+      if (a.dgamma) atomicAdd(a.dgamma + c, sg);
+      if (a.dbeta) atomicAdd(a.dbeta + c, sb);
+    }
   }
+  if (a.acc && last_workgroup(a.counter, gridDim.x))
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const double g = fx_take(a.acc, c, 2L * C), b = fx_take(a.acc, (long)C + c, 2L * C);
+      if (a.dgamma) a.dgamma[c] = (float)g;
+      if (a.dbeta) a.dbeta[c] = (float)b;
+    }
 }
 
 template <class T, int LPR, int IT>
@@ -261,8 +274,9 @@ static int ln_forward_impl(const void* x, int x_is_f16, const float* gamma, cons
 static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
                             int z_is_f16, long z_stride, const float* mean, const float* rstd, const void* dy,
                             int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, int pre_zeroed, long rows,
-                            int C, void* stream) {
+                            int C, void* stream, void* acc = nullptr, void* counter = nullptr) {
   using namespace nnz;
+  if (acc) pre_zeroed = 1;   // dgamma / dbeta are written, not accumulated
   if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (!dz || (z_stride & 3))))
     return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -278,6 +292,7 @@ static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, con
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx;
   a.dgamma = dgamma; a.dbeta = dbeta; a.R = rows; a.C = C;
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.z = z; a.dz = dz; a.z_is_f16 = z_is_f16; a.z_stride = z_stride; a.dy_is_f16 = dy_is_f16;
   return x_is_f16 ? ln_dispatch<f16>(a, true, s) : ln_dispatch<float>(a, true, s);
 }
@@ -312,4 +327,23 @@ extern "C" int nnz_layer_norm_backward(const void* x, int x_is_f16, const float*
                                        float* dbeta, int pre_zeroed, long rows, int C, void* stream) {
   return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dy_is_f16, dx, nullptr, dgamma,
                           dbeta, pre_zeroed, rows, C, stream);
+}
+
+// deterministic variants: acc = 2 * C zeroed records of nnz_fxacc_bytes() bytes, counter = one zeroed 32-bit word (both left
+// zero); dgamma / dbeta are written by the launch's last workgroup - bit-identical run to run, no zero fill needed
+extern "C" int nnz_layer_norm_backward_det(const void* x, int x_is_f16, const float* gamma, const float* mean,
+                                           const float* rstd, const void* dy, int dy_is_f16, void* dx, float* dgamma,
+                                           float* dbeta, void* acc, void* counter, long rows, int C, void* stream) {
+  if (!acc || !counter) return NNZ_EINVAL;
+  return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dy_is_f16, dx, nullptr, dgamma,
+                          dbeta, 1, rows, C, stream, acc, counter);
+}
+extern "C" int nnz_layer_norm_gate_backward_det(const void* x, int x_is_f16, const float* gamma, const float* beta,
+                                                const void* z, int z_is_f16, long z_row_stride, const float* mean,
+                                                const float* rstd, const void* dy, int dy_is_f16, void* dx, void* dz,
+                                                float* dgamma, float* dbeta, void* acc, void* counter, long rows, int C,
+                                                void* stream) {
+  if (!z || !acc || !counter) return NNZ_EINVAL;
+  return ln_backward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, mean, rstd, dy, dy_is_f16, dx, dz, dgamma,
+                          dbeta, 1, rows, C, stream, acc, counter);
 }

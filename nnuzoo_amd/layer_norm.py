@@ -27,8 +27,7 @@ class _LayerNormFn(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         # dgamma / dbeta accumulator of the backward, zeroed by the forward launch (no zeroing launch later)
-        gwb = torch.empty((2, C), dtype=torch.float32, device=x.device) \
-            if weight is not None and bias is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] else None
+        gwb = None     # round 3: the deterministic backward WRITES dgamma / dbeta, nothing to pre-zero
         call("nnz_layer_norm_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(y), int(half),
              ptr(mean), ptr(rstd), ptr(gwb), rows, C, float(eps), stream_ptr())
         ctx.save_for_backward(xc, weight, mean, rstd)
@@ -46,8 +45,11 @@ class _LayerNormFn(torch.autograd.Function):
         dw, db, pre = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, xc.device,
                                     ctx.gwb)
         ctx.gwb = None      # single use: a second backward through the same node zeroes in its own launch
-        call("nnz_layer_norm_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
-             ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), pre, rows, C, stream_ptr())
+        from .hip_ops import det_scratch
+        sc = det_scratch(xc.device, 2 * C)     # fixed-point cross-workgroup sums: dgamma / dbeta bit-identical run to run
+        call("nnz_layer_norm_backward_det", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
+             ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C,
+             stream_ptr())
         return dx, dw, db, None, None
 
 
@@ -93,8 +95,7 @@ class _LayerNormGateFn(torch.autograd.Function):
         y = torch.empty(xc.shape, dtype=torch.float16 if half_out else torch.float32, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        gwb = torch.empty((2, C), dtype=torch.float32, device=x.device) \
-            if weight is not None and bias is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3] else None
+        gwb = None
         call("nnz_layer_norm_gate_forward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
              int(z.dtype == torch.float16), zs, ptr(y), int(half_out), ptr(mean), ptr(rstd), ptr(gwb), rows, C,
              float(eps), stream_ptr())
@@ -113,9 +114,11 @@ class _LayerNormGateFn(torch.autograd.Function):
         dw, db, pre = _affine_grads(weight, bias is not None, ctx.needs_input_grad[2], ctx.needs_input_grad[3], C,
                                     xc.device, ctx.gwb)
         ctx.gwb = None
-        call("nnz_layer_norm_gate_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
+        from .hip_ops import det_scratch
+        sc = det_scratch(xc.device, 2 * C)
+        call("nnz_layer_norm_gate_backward_det", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
              int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), int(dy.dtype == torch.float16),
-             ptr(dx), ptr(dz), ptr(dw), ptr(db), pre, rows, C, stream_ptr())
+             ptr(dx), ptr(dz), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C, stream_ptr())
         return dx, dz, dw, db, None, None
 
 

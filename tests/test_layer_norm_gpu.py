@@ -118,3 +118,27 @@ def test_layer_norm_half_output_for_linear_consumers(hip_lib):
     assert yg.dtype == torch.float16
     ref = F.layer_norm(x, (C,), ln.weight, ln.bias, 1e-5) * F.silu(z.float())
     assert torch.allclose(yg.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_affine_gradients_are_bit_identical_run_to_run(hip_lib):
+    """round 3: dgamma / dbeta are fixed-point cross-workgroup sums (csrc/common.hpp FxAcc) written by the launch's last
+    workgroup - no float atomics: two backward passes give the same bits, and the shared scratch is left zero"""
+    import torch
+    from nnuzoo_amd.hip_ops import det_scratch
+    from nnuzoo_amd.layer_norm import LayerNorm
+    torch.manual_seed(0)
+    for C, rows in [(96, 35378), (768, 882), (16, 262144)]:
+        ln = LayerNorm(C).cuda()
+        x = torch.randn(rows, C, device="cuda", requires_grad=True)
+        dy = torch.randn(rows, C, device="cuda")
+        outs = []
+        for _ in range(2):
+            gx, gw, gb = torch.autograd.grad(ln(x), [x, ln.weight, ln.bias], dy)
+            outs.append((gw.clone(), gb.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        xr = x.detach().double()
+        xh = (xr - xr.mean(1, keepdim=True)) / torch.sqrt(xr.var(1, unbiased=False, keepdim=True) + ln.eps)
+        assert torch.allclose(outs[0][0].double(), (dy.double() * xh).sum(0), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(outs[0][1].double(), dy.double().sum(0), rtol=1e-4, atol=1e-3)
+    sc = det_scratch(torch.device("cuda", 0), 0)
+    assert int(sc.acc.abs().max()) == 0 and int(sc.counter.abs().max()) == 0
