@@ -185,6 +185,27 @@ __device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned nwg) 
   return s_last != 0;
 }
 
+// LDS hand-over inside one wave (its LDS instructions execute in order; the fences keep the compiler from moving accesses)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The same protocol run by ONE wave (the only wave of the workgroup that issued fx_add calls): no workgroup barrier, the
+// other waves go on with their stores / leave.  Wave-uniform result.  Used where the statistics are a side job of a
+// kernel whose workgroups would otherwise all stall ~2 us on the ticket's round trip (conv epilogue, norm reductions).
+__device__ __forceinline__ bool last_workgroup_wave(unsigned* counter, unsigned nwg) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned last = 0;
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned t = atomicAdd(counter, 1u);
+    last = t == nwg - 1u;
+    if (last) atomicExch(counter, 0u);
+  }
+  return __builtin_amdgcn_readfirstlane((int)last) != 0;
+}
+
 // Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used anywhere in this library: captured into a hipGraph it
 // becomes a fill node whose pattern staging the runtime releases after capture - replays after later allocations then
 // fill with whatever landed there (measured on ROCm 7.2 / MI355X, tools/probes/graph_memset_repro.py: NaNs in dbeta).

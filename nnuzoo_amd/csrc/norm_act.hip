@@ -193,14 +193,17 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
     __syncthreads();
     if (a.acc) {
       // deterministic: fixed-order fold inside the workgroup, fixed-point adds across workgroups, the last workgroup of
-      // the launch turns the totals into the float tables
-      for (int c = tid; c < a.C; c += 256) {
+      // the launch turns the totals into the float tables.  Wave 0 does all of it - the other waves leave: no workgroup
+      // waits on the ticket's round trip.
+      if (tid >= 64) return;
+      const long nrec = (long)a.N * a.C * 2;
+      for (int c = tid; c < a.C; c += 64) {
         float s0 = 0.f, s1 = 0.f;
         for (int rr = 0; rr < rows; ++rr) {
           s0 += lred[rr * C2 + c * 2 + 0];
           s1 += lred[rr * C2 + c * 2 + 1];
         }
-        const long rec = ((long)n * a.C + c) * 2, nrec = (long)a.N * a.C * 2;
+        const long rec = ((long)n * a.C + c) * 2;
         if (MODE == 0) {
           const double cnt = (double)(v1 - v0);
           const double k = (double)(float)a.x[((long)n * a.V + v0) * a.ldx + c];
@@ -211,72 +214,70 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
           fx_add(a.acc, rec + 1, nrec, blockIdx.x, (double)s1);
         }
       }
-      if (last_workgroup(a.counter, gridDim.x * gridDim.y)) {
-        const double V = (double)a.V;
-        const long nrec = (long)a.N * a.C * 2;
-        if (MODE == 0) {
-          for (int i = tid; i < a.N * a.C; i += 256) {
-            double mom[2];
-            fx_take_n<2>(a.acc, (long)i * 2, nrec, mom);
-            const double sx = mom[0], sq = mom[1];
-            if (a.sums) {
-              a.sums[(long)i * 2 + 0] = (float)sx;
-              a.sums[(long)i * 2 + 1] = (float)sq;
-            }
-            if (a.nstat) {
-              const double mean = sx / V;
-              double var = sq / V - mean * mean;
-              var = var < 0.0 ? 0.0 : var;
-              const float rs = (float)(1.0 / sqrt(var + (double)a.eps));
-              const int c = i % a.C;
-              const float sc = rs * a.gamma[c];
-              const f32x4 o = {(float)mean, rs, sc, a.beta[c] - (float)mean * sc};
-              *reinterpret_cast<f32x4*>(a.nstat + (long)i * 4) = o;
-            }
+      if (!last_workgroup_wave(a.counter, gridDim.x * gridDim.y)) return;
+      const double V = (double)a.V;
+      if (MODE == 0) {
+        for (int i = tid; i < a.N * a.C; i += 64) {
+          double mom[2];
+          fx_take_n<2>(a.acc, (long)i * 2, nrec, mom);
+          const double sx = mom[0], sq = mom[1];
+          if (a.sums) {
+            a.sums[(long)i * 2 + 0] = (float)sx;
+            a.sums[(long)i * 2 + 1] = (float)sq;
           }
-        } else {
-          // per sample the two means the apply pass needs; over the batch (fixed order) the affine's gradients.  One
-          // thread per (sample, channel) takes both sums in ONE round trip; the sums over the batch go through LDS
-          // (the reduction slab is free now) when they fit, else through a per-channel loop.
-          double* sred = reinterpret_cast<double*>(lred);
-          const bool via_lds = (size_t)a.N * a.C * 2 * sizeof(double) <= sizeof(float) * (size_t)rows * C2;
-          __syncthreads();
-          if (via_lds) {
-            for (int i = tid; i < a.N * a.C; i += 256) {
-              double r[2];
-              fx_take_n<2>(a.acc, (long)i * 2, nrec, r);
-              a.nred[(long)i * 2 + 0] = (float)(r[0] / V);
-              a.nred[(long)i * 2 + 1] = (float)(r[1] / V);
-              sred[(long)i * 2 + 0] = r[0];
-              sred[(long)i * 2 + 1] = r[1];
-            }
-            __syncthreads();
-            if (a.dgamma)
-              for (int c = tid; c < a.C; c += 256) {
-                double sg = 0.0, sb = 0.0;
-                for (int nn = 0; nn < a.N; ++nn) {
-                  sb += sred[((long)nn * a.C + c) * 2 + 0];
-                  sg += sred[((long)nn * a.C + c) * 2 + 1];
-                }
-                a.dgamma[c] = (float)sg;
-                a.dbeta[c] = (float)sb;
-              }
-          } else {
-            for (int c = tid; c < a.C; c += 256) {
+          if (a.nstat) {
+            const double mean = sx / V;
+            double var = sq / V - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const float rs = (float)(1.0 / sqrt(var + (double)a.eps));
+            const int c = i % a.C;
+            const float sc = rs * a.gamma[c];
+            const f32x4 o = {(float)mean, rs, sc, a.beta[c] - (float)mean * sc};
+            *reinterpret_cast<f32x4*>(a.nstat + (long)i * 4) = o;
+          }
+        }
+      } else {
+        // per sample the two means the apply pass needs; over the batch (fixed order) the affine's gradients.  One lane
+        // per (sample, channel) takes both sums in ONE round trip; the sums over the batch go through LDS (the reduction
+        // slab is free now) when they fit, else through a per-channel loop.
+        double* sred = reinterpret_cast<double*>(lred);
+        const bool via_lds = (size_t)a.N * a.C * 2 * sizeof(double) <= sizeof(float) * (size_t)rows * C2;
+        wave_lds_sync();
+        if (via_lds) {
+          for (int i = tid; i < a.N * a.C; i += 64) {
+            double r[2];
+            fx_take_n<2>(a.acc, (long)i * 2, nrec, r);
+            a.nred[(long)i * 2 + 0] = (float)(r[0] / V);
+            a.nred[(long)i * 2 + 1] = (float)(r[1] / V);
+            sred[(long)i * 2 + 0] = r[0];
+            sred[(long)i * 2 + 1] = r[1];
+          }
+          wave_lds_sync();
+          if (a.dgamma)
+            for (int c = tid; c < a.C; c += 64) {
               double sg = 0.0, sb = 0.0;
               for (int nn = 0; nn < a.N; ++nn) {
-                const long i = (long)nn * a.C + c;
-                double r[2];
-                fx_take_n<2>(a.acc, i * 2, nrec, r);
-                a.nred[i * 2 + 0] = (float)(r[0] / V);
-                a.nred[i * 2 + 1] = (float)(r[1] / V);
-                sb += r[0];
-                sg += r[1];
+                sb += sred[((long)nn * a.C + c) * 2 + 0];
+                sg += sred[((long)nn * a.C + c) * 2 + 1];
               }
-              if (a.dgamma) {
-                a.dgamma[c] = (float)sg;
-                a.dbeta[c] = (float)sb;
-              }
+              a.dgamma[c] = (float)sg;
+              a.dbeta[c] = (float)sb;
+            }
+        } else {
+          for (int c = tid; c < a.C; c += 64) {
+            double sg = 0.0, sb = 0.0;
+            for (int nn = 0; nn < a.N; ++nn) {
+              const long i = (long)nn * a.C + c;
+              double r[2];
+              fx_take_n<2>(a.acc, i * 2, nrec, r);
+              a.nred[i * 2 + 0] = (float)(r[0] / V);
+              a.nred[i * 2 + 1] = (float)(r[1] / V);
+              sb += r[0];
+              sg += r[1];
+            }
+            if (a.dgamma) {
+              a.dgamma[c] = (float)sg;
+              a.dbeta[c] = (float)sb;
             }
           }
         }
