@@ -38,6 +38,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+MFMA_F32_DENSE_PEAK_TFLOPS = 157.0   # same guide: fp32 matrix cores (v_mfma_f32_32x32x2_f32)
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0                # same guide: HBM3E ~8 TB/s
 
@@ -261,6 +262,71 @@ def dryrun(a, world: int, rank: int) -> None:
         dist.destroy_process_group()
 
 
+def run_swt2net(steps: int, warmup: int):
+    """BASELINE configs[3]: SwT2Net 1x512^2, batch 2, nnUNetTrainerSwT2Net.train_step (fp32 step: no autocast, no GradScaler,
+    /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainerSwT2Net.py:112-130).  roofline = the window-attention core
+    (the op BASELINE.json's north_star names as the dense contraction) against the fp32 MFMA peak."""
+    from nnuzoo_amd import hip_ops
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerSwT2Net
+    size, batch = 512, 2
+    plans, cfg, dj = nnunet_plans(2, (size, size), batch_size=batch)
+    torch.manual_seed(0)
+    tr = nnUNetTrainerSwT2Net(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    b = synthetic_batch(batch, (size, size), tr._get_deep_supervision_scales(), seed=3)
+    b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+    graph = bool(getattr(tr, "use_hip_graph", False))
+    losses = [float(tr.train_step(b)["loss"]) for _ in range(warmup)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(float(tr.train_step(b)["loss"]))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof_steps = min(3, steps)
+    tr.use_hip_graph = False
+    tr.train_step(b)
+    hip_ops.TIMER.enabled = True
+    hip_ops.TIMER.records = []
+    for _ in range(roof_steps):
+        losses.append(float(tr.train_step(b)["loss"]))
+    torch.cuda.synchronize()
+    hip_ops.TIMER.enabled = False
+    summ = hip_ops.TIMER.summary()
+    hip_ops.TIMER.records = []
+    if not all(np.isfinite(losses)):
+        raise SystemExit(f"non-finite loss in the SwT2Net bench: {losses}")
+    roof = None
+    if "win_attn_fwd" in summ and "win_attn_bwd" in summ:
+        nf, ff, sf = summ["win_attn_fwd"]
+        nb, fb, sb = summ["win_attn_bwd"]
+        ach = (ff + fb) / (sf + sb) / 1e12
+        roof = {"bound": "mfma", "kernel": "win_attn_fwd_kernel + win_attn_bwd_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                "achieved": round(ach, 2), "peak": MFMA_F32_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": (nf + nb) // roof_steps, "fwd_avg_launch_us": round(sf / nf * 1e6, 2),
+                "bwd_avg_launch_us": round(sb / nb * 1e6, 2), "ms_per_step": round((sf + sb) / roof_steps * 1e3, 3),
+                "fwd_achieved": round(ff / sf / 1e12, 2), "bwd_achieved": round(fb / sb / 1e12, 2),
+                "timed_over": f"{roof_steps} eager steps after the timed region"}
+    from nnuzoo_amd.token_linear import TokenLinear
+    backends = {}
+    for m in tr.network.modules():
+        if isinstance(m, TokenLinear):
+            backends[m.backend] = backends.get(m.backend, 0) + 1
+    out = {"metric": "training patches/sec, SwT2Net 1x512^2 patches", "value": round(batch * steps / dt, 3),
+           "unit": "patches/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+           "dtype": "f32 (no autocast, like the reference trainer)",
+           "config": {"workload": "SwT2Net 2d, synthetic 1x512^2 patches, batch 2, deep supervision, full "
+                                  "nnUNetTrainerSwT2Net.train_step (fused AdamW); forward+loss+backward "
+                                  + ("replayed as one hipGraph" if graph else "eager")},
+           "hip_graph": graph, "final_loss": round(losses[-1], 5), "roofline": roof,
+           "linear_backends": backends, "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +338,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--secondary-steps", type=int, default=20)
     ap.add_argument("--secondary-warmup", type=int, default=5)
+    ap.add_argument("--no-swt2net", action="store_true")
     ap.add_argument("--tune", default="", help="A/B knobs, e.g. norm1=1024,conv3=0 (nnz_norm_tuning / nnz_conv_tuning)")
     a = ap.parse_args()
 
@@ -399,6 +466,8 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_secondary:
             line["secondary"] = run_secondary(a.secondary_steps, a.secondary_warmup)
+            if not a.no_swt2net:
+                line["swt2net"] = run_swt2net(max(4, a.secondary_steps // 2), max(2, a.secondary_warmup // 2))
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             if "secondary" in line:

@@ -183,7 +183,29 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
 
   if (MODE == 0 || MODE == 2) {
     const int C2 = 2 * a.C;
-    if (active) {
+    // When the channel groups divide the wave (CG = 4 .. 64, a power of two - every layer but the 320-channel ones) the
+    // rows a wave holds are folded with lane exchanges first and the slab has one row per WAVE: the lone finishing wave then
+    // adds 4 values per channel instead of walking up to 64 dependent LDS reads per channel (3 us per workgroup, measured as
+    // the tail of every reducing launch).  Fixed exchange order: deterministic.
+    const bool fold = a.acc && CG <= 64 && (CG & (CG - 1)) == 0;
+    int nrows = rows;
+    if (fold) {
+      for (int off = CG; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc0[i] += __shfl_xor(acc0[i], off, 64);
+          acc1[i] += __shfl_xor(acc1[i], off, 64);
+        }
+      nrows = 4;
+      if ((tid & 63) < CG) {
+        const int w = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          lred[w * C2 + (cg * 8 + i) * 2 + 0] = acc0[i];
+          lred[w * C2 + (cg * 8 + i) * 2 + 1] = acc1[i];
+        }
+      }
+    } else if (active) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         lred[r * C2 + (cg * 8 + i) * 2 + 0] = acc0[i];
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
       const long nrec = (long)a.N * a.C * 2;
       for (int c = tid; c < a.C; c += 64) {
         float s0 = 0.f, s1 = 0.f;
-        for (int rr = 0; rr < rows; ++rr) {
+        for (int rr = 0; rr < nrows; ++rr) {
           s0 += lred[rr * C2 + c * 2 + 0];
           s1 += lred[rr * C2 + c * 2 + 1];
         }

@@ -46,8 +46,12 @@ class WindowAttentionCore(torch.autograd.Function):
         B, H, W, C3 = qkv.shape
         C = C3 // 3
         out = torch.empty((B, H, W, C), dtype=torch.float32, device=qkv.device)
-        call("nnz_window_attention_forward", ptr(qkv), ptr(table), ptr(bias_index), ptr(out), B, H, W, C, num_heads,
-             shift, float(scale), stream_ptr())
+        from .hip_ops import TIMER
+        # algorithmic FLOPs: 4 L^2 hd per (window, head) = q k^T and p v, L = 49
+        flops = 4.0 * 49 * 49 * (C // num_heads) * num_heads * B * (H // 7) * (W // 7)
+        TIMER.wrap("win_attn_fwd", flops, lambda: call(
+            "nnz_window_attention_forward", ptr(qkv), ptr(table), ptr(bias_index), ptr(out), B, H, W, C, num_heads,
+            shift, float(scale), stream_ptr()))
         ctx.save_for_backward(qkv, table, bias_index)
         ctx.cfg = (B, H, W, C, num_heads, shift, float(scale))
         return out
@@ -61,8 +65,12 @@ class WindowAttentionCore(torch.autograd.Function):
         dtable = torch.empty_like(table)
         from .hip_ops import det_scratch
         sc = det_scratch(qkv.device, 169 * heads)     # fixed-point sums of the bias-table gradient (deterministic)
-        call("nnz_window_attention_backward", ptr(qkv), ptr(table), ptr(bias_index), ptr(dout), ptr(dqkv), ptr(dtable),
-             ptr(sc.acc), ptr(sc.counter), B, H, W, C, heads, shift, scale, stream_ptr())
+        from .hip_ops import TIMER
+        # backward: dQ, dK, dV and dP = dO v^T are four more L^2 hd products (the recomputed q k^T is not counted)
+        flops = 8.0 * 49 * 49 * (C // heads) * heads * B * (H // 7) * (W // 7)
+        TIMER.wrap("win_attn_bwd", flops, lambda: call(
+            "nnz_window_attention_backward", ptr(qkv), ptr(table), ptr(bias_index), ptr(dout), ptr(dqkv), ptr(dtable),
+            ptr(sc.acc), ptr(sc.counter), B, H, W, C, heads, shift, scale, stream_ptr()))
         return dqkv, dtable, None, None, None, None
 
 
