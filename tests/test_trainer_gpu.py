@@ -161,3 +161,34 @@ def test_fused_optimizer_skips_on_inf_and_relinks_after_load(hip_lib, tmp_path):
     assert opt._linked()
     for p, off, _, _ in opt._links:
         assert opt.state[p]["momentum_buffer"].data_ptr() == opt._flat_mom.data_ptr() + 4 * off
+
+
+def test_graph_replayed_steps_equal_eager_steps_bit_for_bit(hip_lib):
+    """round 3: nnUNetTrainer.train_step replays forward + loss + backward as one hipGraph by default.  All kernels of the
+    path are deterministic, so graph and eager training must agree to the last bit: losses of 4 steps, every parameter
+    and the momentum buffers afterwards - with junk allocations between the steps (the captured graph owns its memory)"""
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+
+    def run(graph):
+        plans, cfg, dj = nnunet_plans(3, (64, 64, 64), batch_size=2)
+        torch.manual_seed(0)
+        tr = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+        tr.use_hip_graph = graph
+        tr.initialize()
+        losses = []
+        for i in range(4):
+            b = synthetic_batch(2, (64, 64, 64), tr._get_deep_supervision_scales(), seed=10 + i)      # a NEW batch each step
+            b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+            losses.append(float(tr.train_step(b)["loss"]))
+            junk = [torch.full((1 + 997 * k,), float("nan"), device="cuda") for k in range(50)]
+            del junk
+        mom = [tr.optimizer.state[p]["momentum_buffer"].clone() for p in tr.network.parameters() if p in tr.optimizer.state]
+        return losses, [p.detach().clone() for p in tr.network.parameters()], mom, tr
+
+    le, pe, me, _ = run(False)
+    lg, pg, mg, tr = run(True)
+    assert tr._graphed is not None and tr._graphed.graph is not None          # the graph path really ran
+    assert le == lg, (le, lg)
+    assert all(torch.equal(a, b) for a, b in zip(pe, pg))
+    assert len(me) == len(mg) and all(torch.equal(a, b) for a, b in zip(me, mg))
