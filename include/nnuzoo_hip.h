@@ -129,6 +129,19 @@ int nnz_conv_tap_forward_norm_ws(const void* in_f16, void* out_f16, const void* 
                                  const nnz_conv_desc* desc, void* acc, void* counter, const float* gamma,
                                  const float* beta, float eps, float* nstat, float* workspace, long ws_floats,
                                  void* stream);
+/* Data-gradient launch (any dgrad table) whose epilogue also closes the reductions of the InstanceNorm(affine) + LeakyReLU
+ * backward of the layer BELOW (the layer whose activation gradient this launch writes): x_raw = that layer's fp16 conv
+ * output [N][out voxels][ld_x], nstat = its table.  Writes nred[N][Cout][2] = {mean g', mean g' xhat} and dgamma / dbeta
+ * [Cout] (may both be NULL); the caller then runs nnz_instnorm_lrelu_bwd_apply_tab only.  Replaces the reducing launch of
+ * nnz_instnorm_lrelu_bwd_tab (two full reads of x and g) - reference op: the autograd backward of
+ * nn.InstanceNorm3d + nn.LeakyReLU inside ConvDropoutNormReLU (dynamic_network_architectures, instantiated at
+ * nnunetv2/utilities/get_network_from_plans.py:10-42). */
+int nnz_conv_tap_dgrad_normred(const void* in_f16, void* out_f16, const void* w_packed_f16, const nnz_conv_desc* desc,
+                               const void* x_raw_f16, int ld_x, const float* nstat, float slope, void* acc, void* counter,
+                               float* nred, float* dgamma, float* dbeta, void* stream);
+int nnz_instnorm_lrelu_bwd_apply_tab(const void* x_f16, const void* g_f16, const float* nstat, const float* nred,
+                                     void* dx_f16, int N, long V, int C, int ldx, int ldg, int lddx, float slope,
+                                     void* stream);
 int nnz_stem_conv_wgrad_det(const float* x, const void* dy_f16, float* dw, int N, int D, int H, int W, int Cout, int lddy,
                             void* acc /* >= 864 records */, void* counter, void* stream);
 int nnz_seg_head_wgrad_det(const void* x_f16, const void* dlogits_f16, float* dw, float* db, int N, long V, int C, int K,

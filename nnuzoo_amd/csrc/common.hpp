@@ -192,6 +192,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic ONLY: waits for this wave's LDS instructions (lgkmcnt) and meets the other
+// waves.  __syncthreads() also drains vmcnt - every global load in flight - which is exactly what a prefetch issued before
+// the barrier must not pay.  Use only where no global store -> load hand-over between the waves crosses the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // The same protocol run by ONE wave (the only wave of the workgroup that issued fx_add calls): no workgroup barrier, the
 // other waves go on with their stores / leave.  Wave-uniform result.  Used where the statistics are a side job of a
 // kernel whose workgroups would otherwise all stall ~2 us on the ticket's round trip (conv epilogue, norm reductions).

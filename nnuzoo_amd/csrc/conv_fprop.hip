@@ -50,6 +50,20 @@ struct ConvDev {
   const float* gamma;
   const float* beta;
   float eps;
+  // Data-gradient launches (nnz_conv_tap_dgrad_normred): the tile this launch writes is g = dL/d(activation) of the layer
+  // BELOW, i.e. the input of that layer's InstanceNorm + LeakyReLU backward.  With `bx` (that layer's fp16 conv output
+  // [N][out voxels][ldbx]) and `bstat` (its table [N][Cout][4]) the epilogue also forms the two per-(sample, channel)
+  // reductions of that backward - sum g' and sum g' xhat, g' = g * lrelu'(pre) - on the tile it holds, adds them to the
+  // fixed-point accumulators and the launch's last workgroup writes nred[N][Cout][2] = {mean g', mean g' xhat} and the
+  // affine's gradients: the separate reducing pass over (x, g) of norm_act.hip MODE 2 (two full reads) disappears.
+  const f16* bx;
+  const float* bstat;
+  float* nred;
+  float* dgamma;
+  float* dbeta;
+  float slope;
+  int ldbx;
+  int dbg;  // nnz_conv_tuning(6, bits): epilogue experiments (tools/probes/normred_epilogue_probe.py); 0 in production
   // split-K over the 16-channel slices of the reduction (the <= 8^3 levels: 10-40 workgroups each walking 20-40 slices of
   // 55 KB of weights were 55 us of pure latency per launch): workgroup (.., split) covers slices [split * kper, ...) and
   // stores its fp32 accumulators to part[split][n][voxel][cout]; conv_splitk_finish_kernel folds the splits in order
@@ -119,6 +133,7 @@ struct ConvCfg {
 //   3  workgroup order: cout block fastest (1) / m-tile fastest (0)                        (default 1)
 //   4  smallest Cin for knob 1                                                          (default 32)
 //   5  1 disables split-K over the reduction slices (the <= 8^3 levels; needs the *_ws entry points)  (default 0)
+//   6  epilogue experiments of the fused norm-backward launches (ConvDev::dbg)         (default 0)
 static int g_tuning[8] = {1, 1, 16, 1, 32, 0, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
@@ -360,6 +375,39 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       }
   };
 
+  constexpr int PPV = NB * 4;  // 16-byte pieces per voxel
+  // fused norm-backward reductions (ConvDev::bx): the loads of the layer-below tile are issued at the start of the epilogue,
+  // before the accumulators go through LDS, INTO the staging registers of the main loop (free now).  The epilogue's barriers
+  // are lds_barrier(): __syncthreads() would drain these loads.  (Tried and dropped, tools/probes/normred_epilogue_probe.py:
+  // issuing them inside the last reduction slice - no gain, and separate destination arrays made the allocator spill 550
+  // registers; a one-workgroup finishing kernel instead of the ticket protocol - no gain; 16 accumulator replicas - the
+  // finishing reads cost more than the contention they remove.)
+  constexpr int BX_PARTS = 256 / PPV;
+  constexpr int BX_NIT = (TD * TH * TW + BX_PARTS - 1) / BX_PARTS;
+  static_assert(BX_NIT <= LPT_BOX + C::LPT_W, "layer-below tile must fit the staging registers");
+  const bool bxmode = p.acc && p.bx;
+  auto bx_index = [&](int k) -> long {   // row index of item k of this thread in the output / layer-below tensors, -1: none
+    const int v = tid / PPV + k * BX_PARTS;
+    const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+    const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
+    const int od = md * p.d.out_stride[0] + grp.ooff[0];
+    const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
+    const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
+    const bool ok = v < TD * TH * TW && md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] &&
+                    od < p.d.out_dims[0] && oh < p.d.out_dims[1] && ow < p.d.out_dims[2];
+    return ok ? ((long)((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) : -1;
+  };
+  auto issue_bx = [&]() {
+    const int co = cb0 * 32 + (tid % PPV) * 8;
+#pragma unroll
+    for (int k = 0; k < BX_NIT; ++k) {
+      const long idx = bx_index(k);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx >= 0 && !(p.dbg & 1)) v = *reinterpret_cast<const u32x4*>(p.bx + idx * p.ldbx + co);
+      if (k < LPT_BOX) breg[k < LPT_BOX ? k : 0] = v;
+      else wreg[k >= LPT_BOX ? k - LPT_BOX : 0] = v;
+    }
+  };
   const int kc0 = p.nsplit > 1 ? split * p.kper : 0;
   const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
   issue_loads(kc0);
@@ -448,7 +496,25 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   // accumulator layout measured WRITE_SIZE = 1.5x the output bytes: partial-line writes.)
   constexpr int ROWB = NB * 64 + 16;  // LDS bytes per voxel row (+16: spreads the b64 writes over the banks)
   static_assert(TD * TH * TW * ROWB <= C::OUT_BYTES, "output image must fit the staging LDS");
-  __syncthreads();  // every wave is done reading box / weights
+  // the old gradient (accumulating launches), the layer-below table and the row indices: requested before the staging where
+  // the accumulators leave room for them (one cout block per workgroup), after it otherwise (the two-block tiles sit at 256
+  // registers: asking earlier spilled 22 of them)
+  f16x8 bold[BX_NIT];
+  f32x4 btab[8];
+  long boidx[BX_NIT];
+  auto bx_side_loads = [&]() {
+    const int co = cb0 * 32 + (tid % PPV) * 8;
+#pragma unroll
+    for (int k = 0; k < BX_NIT; ++k) {
+      boidx[k] = bx_index(k);
+      if (p.d.accumulate && boidx[k] >= 0) bold[k] = *reinterpret_cast<const f16x8*>(p.out + boidx[k] * p.d.ldo + co);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) btab[e] = *reinterpret_cast<const f32x4*>(p.bstat + ((size_t)n * Cout + co + e) * 4);
+  };
+  if (bxmode) issue_bx();
+  if (NB == 1 && bxmode) bx_side_loads();
+  lds_barrier();  // every wave is done reading box / weights (LDS-only barrier: global loads stay in flight)
 #pragma unroll
   for (int i = 0; i < C::WN; ++i) {
     const int nbl = wn * C::WN + i;
@@ -466,8 +532,8 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       }
     }
   }
-  __syncthreads();
-  constexpr int PPV = NB * 4;  // 16-byte pieces per voxel
+  lds_barrier();
+  if (NB != 1 && bxmode) bx_side_loads();
   constexpr int NPIECE = TD * TH * TW * PPV;
   if (p.stats) {
     // InstanceNorm statistics of this tile from the fp16 image (what the normalisation will read): a thread sums 8
@@ -503,6 +569,95 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       for (int q = 0; q < PARTS; ++q) t += slab[q * (2 * NC) + tid];
       atomicAdd(p.stats + ((size_t)n * Cout + cb0 * 32) * 2 + tid, t);
     }
+  } else if (bxmode) {
+    // InstanceNorm + LeakyReLU backward reductions of the layer below on this tile (see ConvDev::bx).  Thread = (voxel share,
+    // 8-channel group): the same (voxel, piece) items it would store in the loop at the end, so the final fp16 values
+    // (after the optional accumulate) are formed once, used for the sums and stored from here.  Packed fp32 arithmetic
+    // (two channels per instruction): the sums are ~10 VALU operations per element on 16 elements x 8 voxels per lane.
+    constexpr int NC = NB * 32, NVOX = TD * TH * TW;
+    float* slab = reinterpret_cast<float*>(smem + NVOX * ROWB);
+    const int part = tid / PPV, c8 = tid % PPV;
+    const int co = cb0 * 32 + c8 * 8;
+    f32x2 mean2[4], scale2[4], shift2[4], s1[4], s2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x4 t0 = btab[2 * e], t1 = btab[2 * e + 1];
+      mean2[e] = f32x2{t0[0], t1[0]};
+      scale2[e] = f32x2{t0[2], t1[2]};
+      shift2[e] = f32x2{t0[3], t1[3]};
+      s1[e] = s2[e] = f32x2{0.f, 0.f};
+    }
+    const f32x2 slope2 = {p.slope, p.slope};
+#pragma unroll
+    for (int k = 0; k < BX_NIT; ++k) {
+      if (boidx[k] < 0) continue;
+      const int v = part + k * BX_PARTS;
+      f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + c8 * 16);
+      if (p.d.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] = (f16)((float)val[e] + (float)bold[k][e]);
+      }
+      *reinterpret_cast<f16x8*>(p.out + boidx[k] * p.d.ldo + co) = val;
+      if (p.dbg & 2) continue;
+      const u32x4 xraw = k < LPT_BOX ? breg[k < LPT_BOX ? k : 0] : wreg[k >= LPT_BOX ? k - LPT_BOX : 0];
+      const f16x8 xk = __builtin_bit_cast(f16x8, xraw);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 x = {(float)xk[2 * e], (float)xk[2 * e + 1]};
+        const f32x2 g = {(float)val[2 * e], (float)val[2 * e + 1]};
+        const f32x2 pre = x * scale2[e] + shift2[e];
+        const f32x2 gs = g * slope2;
+        const f32x2 gp = {pre[0] > 0.f ? g[0] : gs[0], pre[1] > 0.f ? g[1] : gs[1]};
+        s1[e] += gp;
+        s2[e] += gp * (x - mean2[e]);   // times rstd once per channel, below
+      }
+    }
+#pragma unroll
+    for (int off = PPV; off < 64; off <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[e][0] += __shfl_xor(s1[e][0], off, 64);
+        s1[e][1] += __shfl_xor(s1[e][1], off, 64);
+        s2[e][0] += __shfl_xor(s2[e][0], off, 64);
+        s2[e][1] += __shfl_xor(s2[e][1], off, 64);
+      }
+    if (lane < PPV) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *reinterpret_cast<f32x4*>(slab + wave * (2 * NC) + (lane * 8 + 2 * e) * 2) =
+            f32x4{s1[e][0], s2[e][0] * btab[2 * e][1], s1[e][1], s2[e][1] * btab[2 * e + 1][1]};   // s2 *= rstd
+      }
+    }
+    __syncthreads();
+    if (wave != 0 || (p.dbg & 4)) return;
+    const long nrec = (long)p.d.N * Cout * 2;
+    for (int c = lane; c < NC; c += 64) {
+      const float S1 = (slab[c * 2] + slab[2 * NC + c * 2]) + (slab[4 * NC + c * 2] + slab[6 * NC + c * 2]);
+      const float S2 = (slab[c * 2 + 1] + slab[2 * NC + c * 2 + 1]) + (slab[4 * NC + c * 2 + 1] + slab[6 * NC + c * 2 + 1]);
+      const long ch = (long)n * Cout + cb0 * 32 + c;
+      fx_add(p.acc, ch * 2, nrec, blockIdx.x, (double)S1);
+      fx_add(p.acc, ch * 2 + 1, nrec, blockIdx.x, (double)S2);
+    }
+    if (last_workgroup_wave(p.counter, nwg)) {
+      const double V = (double)p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2];
+      for (int c = lane; c < Cout; c += 64) {
+        double sg = 0.0, sb = 0.0;
+        for (int nn = 0; nn < p.d.N; ++nn) {
+          const long i = (long)nn * Cout + c;
+          double r[2];
+          fx_take_n<2>(p.acc, i * 2, nrec, r);
+          p.nred[i * 2 + 0] = (float)(r[0] / V);
+          p.nred[i * 2 + 1] = (float)(r[1] / V);
+          sb += r[0];
+          sg += r[1];
+        }
+        if (p.dgamma) {
+          p.dgamma[c] = (float)sg;
+          p.dbeta[c] = (float)sb;
+        }
+      }
+    }
+    return;
   } else if (p.acc) {
     // Deterministic and cancellation-free variant: moments about a PILOT value per channel (the tile's first voxel), folded
     // in a fixed order inside the workgroup, re-centred in double and added to the sample's fixed-point accumulators (integer
@@ -691,7 +846,7 @@ static int splitk_plan(const ConvDev& p, long ws_floats, int wgs_base, int* kper
   const nnz_conv_desc& d = p.d;
   const int nkc = d.Cin / 16;
   if (g_tuning[5] || !p.part || d.ngroups != 1 || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1 ||
-      nkc < 8 || wgs_base >= 128 || p.stats)
+      nkc < 8 || wgs_base >= 128 || p.stats || p.bx)
     return 1;
   int splits = (384 + wgs_base - 1) / wgs_base;
   if (splits > nkc / 2) splits = nkc / 2;          // at least two slices per workgroup
@@ -845,10 +1000,19 @@ static int launch_dyn(const ConvDev& p, hipStream_t stream) {
 
 extern "C" int nnz_conv_tap_forward_stats(const void* in, void* out, const void* w_packed, const float* bias,
                                           const nnz_conv_desc* desc, float* stats, void* stream);
+struct NormRedArgs {  // see ConvDev::bx
+  const void* bx;
+  const float* bstat;
+  float* nred;
+  float* dgamma;
+  float* dbeta;
+  float slope;
+  int ldbx;
+};
 static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
                                  const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
                                  const float* gamma, const float* beta, float eps, float* nstat, void* stream,
-                                 float* workspace = nullptr, long ws_floats = 0);
+                                 float* workspace = nullptr, long ws_floats = 0, const NormRedArgs* nr = nullptr);
 
 extern "C" int nnz_conv_tuning(int knob, int value) {
   if (knob < 0 || knob >= 8) return NNZ_EINVAL;
@@ -896,17 +1060,36 @@ extern "C" int nnz_conv_tap_forward_norm_ws(const void* in, void* out, const voi
                                workspace, ws_floats);
 }
 
+// Data-gradient launch (any dgrad table: stride-1, the phase groups of a stride-2 layer, accumulating or not) that also
+// closes the reductions of the InstanceNorm(affine) + LeakyReLU backward of the layer BELOW: `out` is dL/d(activation) of
+// that layer, `x_raw` its fp16 conv output [N][out voxels][ld_x], `nstat` its table [N][Cout][4] (Cout = desc->Cout).
+// Writes nred[N][Cout][2] = {mean g', mean g' xhat} and, if given, dgamma / dbeta [Cout] - what
+// nnz_instnorm_lrelu_bwd_tab's reducing launch would produce; the caller then runs only its apply launch
+// (nnz_instnorm_lrelu_bwd_apply_tab).  Deterministic (fixed-point sums).  `acc`: N * Cout * 2 records of nnz_fxacc_bytes(),
+// `counter`: one word; zero before, left zero.  The whole batch must fit one launch (< 2^31 elements per tensor).
+extern "C" int nnz_conv_tap_dgrad_normred(const void* in, void* out, const void* w_packed, const nnz_conv_desc* desc,
+                                          const void* x_raw, int ld_x, const float* nstat, float slope, void* acc,
+                                          void* counter, float* nred, float* dgamma, float* dbeta, void* stream) {
+  NormRedArgs nr = {x_raw, nstat, nred, dgamma, dbeta, slope, ld_x};
+  return conv_tap_forward_impl(in, out, w_packed, nullptr, desc, nullptr, acc, (unsigned*)counter, nullptr, nullptr, 0.f,
+                               nullptr, stream, nullptr, 0, &nr);
+}
+
 extern "C" int nnz_fxacc_bytes(void) { return (int)sizeof(nnz::FxAcc) * nnz::FX_REP; }
 
 static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
                                  const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
                                  const float* gamma, const float* beta, float eps, float* nstat, void* stream,
-                                 float* workspace, long ws_floats) {
+                                 float* workspace, long ws_floats, const NormRedArgs* nr) {
   using namespace nnz;
   if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
   // fused statistics: plain forward convolutions only (one group, output written once, unit output stride)
-  if ((stats || acc) && (d.ngroups != 1 || d.accumulate || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1))
+  if ((stats || acc) && !nr &&
+      (d.ngroups != 1 || d.accumulate || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1))
+    return NNZ_EINVAL;
+  if (nr && (!acc || !counter || !nr->bx || !nr->bstat || !nr->nred || nr->ldbx % 8 || nr->ldbx < d.Cout ||
+             (nr->dgamma == nullptr) != (nr->dbeta == nullptr)))
     return NNZ_EINVAL;
   if (d.Cin % 32 || d.Cout % 32 || d.ngroups < 1 || d.ngroups > NNZ_MAX_GROUPS || d.ntaps_total > NNZ_MAX_TAPS ||
       d.ldi % 8 || d.ldo % 8)
@@ -927,6 +1110,7 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
   if (per_n >= (1L << 31)) return NNZ_EINVAL;
   int chunk = (int)(((1L << 31) - 1) / per_n);
   if (chunk > d.N) chunk = d.N;
+  if (nr && chunk < d.N) return NNZ_EINVAL;  // the fused reductions close over the whole batch in one launch
   hipStream_t s = (hipStream_t)stream;
   const bool iso = d.in_stride[0] == d.in_stride[1] && d.in_stride[1] == d.in_stride[2] && d.ext[0] == d.ext[1] &&
                    d.ext[1] == d.ext[2] && d.m_dims[0] > 1;
@@ -943,6 +1127,14 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
     p.gamma = gamma;
     p.beta = beta;
     p.eps = eps;
+    p.bx = nr ? (const f16*)nr->bx : nullptr;
+    p.bstat = nr ? nr->bstat : nullptr;
+    p.nred = nr ? nr->nred : nullptr;
+    p.dgamma = nr ? nr->dgamma : nullptr;
+    p.dbeta = nr ? nr->dbeta : nullptr;
+    p.slope = nr ? nr->slope : 0.f;
+    p.ldbx = nr ? nr->ldbx : 0;
+    p.dbg = g_tuning[6];
     p.part = workspace;
     p.ws_floats = workspace ? ws_floats : 0;
     p.nsplit = 1;

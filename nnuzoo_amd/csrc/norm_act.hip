@@ -461,3 +461,20 @@ extern "C" int nnz_instnorm_lrelu_bwd_tab(const void* x, const void* g, const fl
   a.acc = nullptr;
   return launch_norm<3>(a, (hipStream_t)stream);
 }
+
+// the apply launch alone: nred[N][C][2] already holds {mean g', mean g' xhat} (nnz_conv_tap_dgrad_normred wrote it from the
+// epilogue of the convolution that produced g)
+extern "C" int nnz_instnorm_lrelu_bwd_apply_tab(const void* x, const void* g, const float* nstat, const float* nred, void* dx,
+                                                int N, long V, int C, int ldx, int ldg, int lddx, float slope,
+                                                void* stream) {
+  using namespace nnz;
+  if (!x || !g || !nstat || !nred || !dx) return NNZ_EINVAL;
+  NormArgs a = {};
+  a.x = (const f16*)x; a.g = (const f16*)g;
+  a.nstat = const_cast<float*>(nstat);
+  a.nred = const_cast<float*>(nred);
+  a.y = (f16*)dx;
+  a.N = N; a.V = V; a.C = C; a.ldx = ldx; a.ldg = ldg; a.ldy = lddx;
+  a.slope = slope;
+  return launch_norm<3>(a, (hipStream_t)stream);
+}

@@ -26,7 +26,22 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
   float s = 0.f, bad = 0.f;
   const long n4 = n >> 2;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+  // four independent 16-byte loads in flight per lane (the loop is latency-bound otherwise)
+  const long stride = (long)gridDim.x * 256;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = g4[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s += v[k][e] * v[k][e];
+        bad += (__builtin_isnan(v[k][e]) || __builtin_isinf(v[k][e])) ? 1.f : 0.f;
+      }
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = g4[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -35,8 +50,8 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
     }
   }
   if (blockIdx.x == 0)
-    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
-      const float v = g[i];
+    for (long j = (n4 << 2) + threadIdx.x; j < n; j += 256) {
+      const float v = g[j];
       s += v * v;
       bad += (__builtin_isnan(v) || __builtin_isinf(v)) ? 1.f : 0.f;
     }
@@ -51,12 +66,13 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
   if (acc) {
     // deterministic: fixed-point sum across workgroups (common.hpp), the last one writes the two floats.  A non-finite
     // gradient makes the block's partial non-finite, which poisons the accumulator: the total reads back NaN and the
-    // count of bad entries below stays the inf-skip flag.
+    // count of bad entries below stays the inf-skip flag.  Wave 0 alone runs the protocol (the others leave).
+    if (threadIdx.x >= 64) return;
     if (threadIdx.x == 0) {
       fx_add(acc, 0, 2, blockIdx.x, (double)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])));
       fx_add(acc, 1, 2, blockIdx.x, (double)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
     }
-    if (last_workgroup(counter, gridDim.x) && threadIdx.x == 0) {
+    if (last_workgroup_wave(counter, gridDim.x) && threadIdx.x == 0) {
       out2[0] = (float)fx_take(acc, 0, 2);
       out2[1] = (float)fx_take(acc, 1, 2);
     }
@@ -131,8 +147,10 @@ extern "C" int nnz_grad_sumsq_nonfinite_det(const float* grads, long n, float* o
                                             void* stream) {
   using namespace nnz;
   if (!grads || !out2 || !acc || !counter || n < 1 || ((size_t)grads & 15)) return NNZ_EINVAL;
-  long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  // every workgroup ends in two fixed-point adds on the SAME two records (~43 ns each, serialised per address, FX_REP
+  // replicas): 2048 workgroups spent 86 us there for a 125 MB read.  512 workgroups x 4 loads in flight per lane.
+  long blocks = (n / 16 + 255) / 256;
+  if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   NNZ_LAUNCH(grad_sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grads, n, out2, (FxAcc*)acc,
              (unsigned*)counter);

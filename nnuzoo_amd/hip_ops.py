@@ -340,6 +340,27 @@ def instnorm_lrelu_bwd_tab(x, g, nstat, scratch: NormScratch, nred, dx, N, V, Cc
          ptr(dx), N, V, Cc, ldx, ldg, lddx, float(slope), ptr(dgamma), ptr(dbeta), stream_ptr())
 
 
+def instnorm_lrelu_bwd_apply_tab(x, g, nstat, nred, dx, N, V, Cc, ldx, ldg, lddx, slope):
+    """the apply launch of the InstanceNorm + LeakyReLU backward alone: nred came from conv_tap_dgrad_normred"""
+    _f16(x, "in.x"); _f16(g, "in.g"); _f16(dx, "in.dx"); _f32(nstat, "in.nstat"); _f32(nred, "in.nred")
+    call("nnz_instnorm_lrelu_bwd_apply_tab", ptr(x), ptr(g), ptr(nstat), ptr(nred), ptr(dx), N, V, Cc, ldx, ldg, lddx,
+         float(slope), stream_ptr())
+
+
+def conv_tap_dgrad_normred(pt: PreparedTable, dy: torch.Tensor, w_packed: torch.Tensor, dx: torch.Tensor,
+                           x_raw: torch.Tensor, ld_x: int, nstat: torch.Tensor, slope: float, scratch: NormScratch,
+                           nred: torch.Tensor, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor]) -> None:
+    """data-gradient convolution whose epilogue also forms the norm-backward reductions of the layer below (the layer whose
+    activation gradient `dx` is): nred [N, C, 2], dgamma / dbeta [C]"""
+    _f16(dy, "conv.in"); _f16(dx, "conv.out"); _f16(w_packed, "conv.w"); _f16(x_raw, "conv.x_raw")
+    _f32(nstat, "conv.nstat"); _f32(nred, "conv.nred"); _f32(dgamma, "conv.dgamma"); _f32(dbeta, "conv.dbeta")
+    assert pt.table.N * pt.table.Cout <= scratch.capacity
+    TIMER.wrap("conv_box_kernel", pt.flops,
+               lambda: call("nnz_conv_tap_dgrad_normred", ptr(dy), ptr(dx), ptr(w_packed), C.byref(pt.desc), ptr(x_raw),
+                            int(ld_x), ptr(nstat), float(slope), ptr(scratch.acc), ptr(scratch.counter), ptr(nred),
+                            ptr(dgamma), ptr(dbeta), stream_ptr()))
+
+
 def _logits_kind(t: torch.Tensor) -> int:
     if not t.is_cuda or t.dtype not in (torch.float16, torch.float32):
         raise _lib.HipCallError(f"loss: logits must be fp16/fp32 device tensors, got {t.dtype} on {t.device}")

@@ -381,6 +381,9 @@ class PlainConvUNet(nn.Module):
         self._plans = {}
         self._param_list: Optional[List[nn.Parameter]] = None
         self.grad_reducer = None  # set by nnuzoo_amd.ddp.attach_bucketed_allreduce
+        # data-gradient launches also close the InstanceNorm-backward reductions of the layer below (see _conv_block_bwd);
+        # NNZ_FUSE_NORM_REDUCE=0 keeps the separate reducing launches (A/B runs, tests)
+        self.fuse_norm_reduce = os.environ.get("NNZ_FUSE_NORM_REDUCE", "1") != "0"
 
     # reference API: `network.apply(network.initialize)` (get_network_from_plans.py:59-60)
     @staticmethod
@@ -513,16 +516,27 @@ class PlainConvUNet(nn.Module):
         return out_list, (rec if save else None)
 
     # ---- backward schedule ---------------------------------------------------------------------------------------
-    def _conv_block_bwd(self, b: _Block, recd, g_act: torch.Tensor, g_ld: int, grads: dict, dx_out, dx_acc: bool, dev):
+    def _conv_block_bwd(self, b: _Block, recd, g_act: torch.Tensor, g_ld: int, grads: dict, dx_out, dx_acc: bool, dev,
+                        below=None):
         """g_act: gradient wrt the block's activated output (channel stride g_ld).  Writes the gradient wrt the
-        block input into dx_out (None for the stem) and the parameter gradients into `grads`."""
+        block input into dx_out (None for the stem) and the parameter gradients into `grads`.
+
+        below = (block, record) of the conv block whose ACTIVATION dx_out is the gradient of (None: a tensor without a
+        norm below it, or a gradient that other launches still add to).  The data-gradient launch then also closes that
+        block's InstanceNorm-backward reductions in its epilogue (csrc/conv_fprop.hip, ConvDev::bx) and the block's own
+        call of this method runs the apply launch only."""
         x_in, raw, stats, _ = recd
         h = b.h
         red = self._red_all[b.stats_off // 2:b.stats_off // 2 + b.N * b.cout * 2].view(b.N, b.cout, 2)
         draw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
-        gnw, gnb = self._galloc(h.norm.weight), self._galloc(h.norm.bias)
-        ops.instnorm_lrelu_bwd_tab(raw, g_act, stats, self._scratch, red, draw, b.N, b.V, b.cout, b.cout, g_ld, b.cout,
-                                   b.slope, dgamma=gnw, dbeta=gnb)
+        pre = self._prereduced.pop(id(b), None)
+        if pre is not None:
+            gnw, gnb = pre
+            ops.instnorm_lrelu_bwd_apply_tab(raw, g_act, stats, red, draw, b.N, b.V, b.cout, b.cout, g_ld, b.cout, b.slope)
+        else:
+            gnw, gnb = self._galloc(h.norm.weight), self._galloc(h.norm.bias)
+            ops.instnorm_lrelu_bwd_tab(raw, g_act, stats, self._scratch, red, draw, b.N, b.V, b.cout, b.cout, g_ld, b.cout,
+                                       b.slope, dgamma=gnw, dbeta=gnb)
         grads[h.norm.weight], grads[h.norm.bias] = gnw, gnb
         # the bias of a conv followed by InstanceNorm has an identically zero gradient (mean removal)
         grads[h.conv.bias] = self._galloc(h.conv.bias)  # arena is zero-initialised
@@ -540,7 +554,19 @@ class PlainConvUNet(nn.Module):
                 ops.conv_tap_wgrad_to_grad(b.wgrad, x_in, draw, self._wgrad_ws, gw, nk, b.cin * nk, 1)
                 if b.zero_dx and not dx_acc:
                     dx_out.zero_()  # k1 s2 axes: odd input positions are outside every output's footprint
-                ops.conv_tap_forward(b.dgrad_acc if dx_acc else b.dgrad, draw, b.wp_dgrad, None, dx_out, workspace=self._wgrad_ws)
+                pt = b.dgrad_acc if dx_acc else b.dgrad
+                # (not on the <= 8^3 levels: there the data gradient runs split-K, which has no fused epilogue, and the
+                # separate reducing launch over a few hundred voxels costs nothing)
+                if below is not None and self.fuse_norm_reduce and not b.zero_dx and below[0].cout == b.cin \
+                        and below[0].V >= 4096 and b.N * max(b.V * b.cout, below[0].V * pt.desc.ldo) < 2 ** 31:
+                    pb, prec = below
+                    pred = self._red_all[pb.stats_off // 2:pb.stats_off // 2 + pb.N * pb.cout * 2].view(pb.N, pb.cout, 2)
+                    pgw, pgb = self._galloc(pb.h.norm.weight), self._galloc(pb.h.norm.bias)
+                    ops.conv_tap_dgrad_normred(pt, draw, b.wp_dgrad, dx_out, prec[1], pb.cout, prec[2], pb.slope,
+                                               self._scratch, pred, pgw, pgb)
+                    self._prereduced[id(pb)] = (pgw, pgb)
+                else:
+                    ops.conv_tap_forward(pt, draw, b.wp_dgrad, None, dx_out, workspace=self._wgrad_ws)
         grads[h.conv.weight] = gw
         if self.grad_reducer is not None:
             # hand-over point per conv block (finer than per stage: the 320-channel decoder stage alone is 37 MB)
@@ -590,6 +616,7 @@ class PlainConvUNet(nn.Module):
         self._arena_trace = []
         self._arena_unused = set()
         self._red_all = torch.empty(plan.stats_floats // 2, dtype=torch.float32, device=dev)
+        self._prereduced = {}
         self._scratch = plan.norm_scratch
         if plan.wgrad_ws is None:
             plan.wgrad_ws = torch.empty(plan.wgrad_ws_floats, dtype=torch.float32, device=dev)
@@ -631,7 +658,8 @@ class PlainConvUNet(nn.Module):
             for i in range(len(blocks) - 1, -1, -1):
                 b = blocks[i]
                 dx = torch.empty((N, V, b.cin), dtype=f16, device=dev)
-                self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, False, dev)
+                self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, False, dev,
+                                     below=(blocks[i - 1], stage_rec[i - 1]) if i > 0 else None)
                 g_act, g_ld = dx, b.cin
             g_cats[lvl] = g_act  # [N, V, 2C]: [..., :C] -> transposed conv, [..., C:] -> encoder skip
             # transposed conv backward
@@ -672,11 +700,14 @@ class PlainConvUNet(nn.Module):
                     # input is the skip of level s-1 living in cat_{s-1}[..., C:]: accumulate into its gradient
                     Cp = feats[s - 1]
                     dx = g_cats[s - 1][:, :, Cp:]
-                    self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, True, dev)
+                    # this launch completes the gradient of the previous stage's output (skip + downsampling path)
+                    self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, True, dev,
+                                         below=(plan.enc_blocks[s - 1][-1], rec["enc"][s - 1][-1]))
                     g_act, g_ld = dx, 2 * Cp
                 else:
                     dx = torch.empty((N, b.V, b.cin), dtype=f16, device=dev)
-                    self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, False, dev)
+                    self._conv_block_bwd(b, stage_rec[i], g_act, g_ld, grads, dx, False, dev,
+                                         below=(blocks[i - 1], stage_rec[i - 1]))
                     g_act, g_ld = dx, b.cin
             if self.grad_reducer is not None:
                 self.grad_reducer.stage_done_arena(self._arena, self._arena_off)
@@ -691,6 +722,7 @@ class PlainConvUNet(nn.Module):
         self._arena_layout = self._arena_trace
         self._last_arena = self._arena
         self._last_unused = self._arena_unused
+        assert not self._prereduced, "a fused norm reduction was produced for a block whose backward never ran"
         self._red_all = self._wgrad_ws = self._arena = self._arena_trace = self._arena_unused = self._scratch = None
         return out
 

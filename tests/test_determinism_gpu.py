@@ -149,3 +149,72 @@ def test_training_steps_are_bit_identical_run_to_run(hip_lib):
     assert all(torch.equal(p, q) for p, q in zip(a[2], b[2]))               # parameters after three SGD steps
     assert all(torch.equal(p, q) for p, q in zip(a[3], b[3]))               # logits of the trained network
     assert float(a[1].abs().max()) > 0 and all(np.isfinite(a[0]))
+
+
+@pytest.mark.parametrize("dims,cin,cout,stride,acc", [((16, 16, 16), 32, 32, 1, False), ((32, 32, 32), 32, 64, 1, False),
+                                                       ((64, 64, 64), 32, 32, 1, False), ((16, 16, 16), 32, 64, 2, True),
+                                                       ((24, 16, 8), 64, 128, 2, True), ((12, 20, 28), 64, 64, 1, False),
+                                                       ((8, 8, 8), 256, 320, 2, True), ((8, 8, 8), 320, 320, 1, False),
+                                                       ((1, 32, 48), 32, 32, 1, False), ((1, 32, 48), 32, 64, 2, True)])
+def test_dgrad_epilogue_closes_norm_backward_reductions(hip_lib, dims, cin, cout, stride, acc):
+    """nnz_conv_tap_dgrad_normred: the data-gradient launch of conv(cin -> cout) also forms {mean g', mean g' xhat}, dgamma,
+    dbeta of the InstanceNorm + LeakyReLU below it (cin channels) - against the separate reducing launch on the same g and
+    against float64; g itself is bit-identical to the plain launch (stride-2 phase groups, accumulate into a 2C-strided
+    skip slice, ragged tiles, the 2-D tables, the split-K-sized 8^3 levels)."""
+    N = 2
+    g = torch.Generator().manual_seed(sum(dims) + cout + stride)
+    flat = dims[0] == 1
+    ks = (1, 3, 3) if flat else (3, 3, 3)
+    st = ((1, stride, stride) if flat else (stride,) * 3)
+    ldo = 2 * cin if acc else cin
+    pt = PreparedTable(cp.conv_dgrad(N, dims, cin, cout, ks=ks, stride=st, ldi=cout, ldo=ldo, accumulate=acc))
+    nk = int(np.prod(ks))
+    w = (torch.randn(cout, cin, *ks, generator=g) * 0.05).to(DEV)
+    wp = ops.pack_weight(w, pt, cout, cin, 1, cin * nk, nk)         # any packing serves both launches alike
+    ydims = cp.conv_out_dims(dims, ks, st)
+    dy = torch.randn(N, int(np.prod(ydims)), cout, generator=g).to(torch.float16).to(DEV)
+    V = int(np.prod(dims))
+    base = (torch.randn(N, V, ldo, generator=g) * 0.5).to(torch.float16).to(DEV)
+    x_raw = (0.3 + torch.randn(N, V, cin, generator=g)).to(torch.float16).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(cin, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(cin, generator=g)).to(DEV)
+    sc = ops.NormScratch(torch.device(DEV), N * max(cin, cout))
+    nstat = torch.empty((N, cin, 4), device=DEV)
+    ops.instnorm_stats_det(x_raw, N, V, cin, cin, sc, gamma, beta, 1e-5, nstat=nstat)
+    # separate launches
+    out0 = base.clone()
+    view0 = out0[:, :, ldo - cin:]
+    ops.conv_tap_forward(pt, dy, wp, None, view0)
+    nred0 = torch.empty((N, cin, 2), device=DEV)
+    dg0, db0 = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
+    dx0 = torch.empty((N, V, cin), dtype=torch.float16, device=DEV)
+    ops.instnorm_lrelu_bwd_tab(x_raw, view0, nstat, sc, nred0, dx0, N, V, cin, cin, ldo, cin, 0.01, dgamma=dg0, dbeta=db0)
+    res = []
+    for _ in range(2):
+        out1 = base.clone()
+        view1 = out1[:, :, ldo - cin:]
+        nred1 = torch.full((N, cin, 2), float("nan"), device=DEV)
+        dg1, db1 = torch.full((cin,), float("nan"), device=DEV), torch.full((cin,), float("nan"), device=DEV)
+        ops.conv_tap_dgrad_normred(pt, dy, wp, view1, x_raw, cin, nstat, 0.01, sc, nred1, dg1, db1)
+        dx1 = torch.empty((N, V, cin), dtype=torch.float16, device=DEV)
+        ops.instnorm_lrelu_bwd_apply_tab(x_raw, view1, nstat, nred1, dx1, N, V, cin, cin, ldo, cin, 0.01)
+        torch.cuda.synchronize()
+        assert int(sc.acc.abs().max()) == 0 and int(sc.counter.abs().max()) == 0
+        assert torch.equal(out1, out0)                 # g (and the untouched half of a skip buffer) bit for bit
+        res.append((nred1, dg1, db1, dx1))
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    # float64 on the stored fp16 g
+    gg = view0.double().cpu()
+    xx = x_raw.double().cpu()
+    t = nstat.double().cpu()
+    pre = xx * t[:, None, :, 2] + t[:, None, :, 3]
+    gp = torch.where(pre > 0, gg, gg * 0.01)
+    xn = (xx - t[:, None, :, 0]) * t[:, None, :, 1]
+    ref = torch.stack([gp.mean(1), (gp * xn).mean(1)], -1)
+    for name, got, sep, r in [("nred", res[0][0], nred0, ref), ("dgamma", res[0][1], dg0, (gp * xn).sum((0, 1))),
+                              ("dbeta", res[0][2], db0, gp.sum((0, 1)))]:
+        scale = r.abs().max().item()
+        noise = (gp.abs().mean().item() * (V ** -0.5 if name == "nred" else (N * V) ** 0.5)) * 2e-6 + 1e-6 * scale
+        assert (got.double().cpu() - r).abs().max().item() <= noise + 2e-6 * scale, name
+        assert (sep.double().cpu() - r).abs().max().item() <= noise + 2e-6 * scale, name + " (separate launch)"
+    assert (res[0][3].float() - dx0.float()).abs().max().item() <= 2e-3 * dx0.float().abs().max().item()
