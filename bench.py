@@ -185,7 +185,7 @@ def run_secondary(steps: int, warmup: int):
            "hip_graph": graph,
            "final_loss": round(losses[-1], 5), "roofline": roof,
            "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
-    dz = _profile_json("r02_dice_parity_m2netp_128.json") or _profile_json("r01_dice_parity_m2netp_128.json")
+    dz = _profile_json("r03_dice_parity_m2netp_128.json") or _profile_json("r02_dice_parity_m2netp_128.json") or _profile_json("r01_dice_parity_m2netp_128.json")
     if dz:
         out["dice"] = {"hip": round(dz["dice_fused"], 5), "ref_formulation": round(dz["dice_reference_formulation"], 5),
                        "abs_delta": round(dz["abs_delta"], 5),
@@ -480,7 +480,7 @@ def main():
             "hip_graph": graph, "rccl_ranks": rccl_ranks, "allreduce_buckets_per_step": buckets_per_step,
             "roofline": roof,
         }
-        dz = _profile_json("r02_dice_parity_64cubed.json") or _profile_json("r01_dice_parity_64cubed.json")
+        dz = _profile_json("r03_dice_parity_64cubed.json") or _profile_json("r02_dice_parity_64cubed.json") or _profile_json("r01_dice_parity_64cubed.json")
         if dz:
             line["dice"] = {"hip": round(dz["dice_hip"], 5), "oracle": round(dz["dice_oracle"], 5),
                             "abs_delta": round(dz["abs_delta"], 6), "mask_agreement": round(dz["mask_agreement"], 5),

@@ -1,23 +1,26 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03
 # Writes under gpurun_out/ (copy what is to be judged into profiles/).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-swt2net"
 # 1. kernel trace + stats of the primary bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $BENCH > $OUT/${TAG}_bench_n1_profiled_run.json 2>/dev/null
 cp $(ls $OUT/prof_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_n1_kernel_stats.csv
 # 2. HBM traffic counters, separate passes (MI355X_MICROARCH.md, HBM / rocprofv3 section)
-BENCH2="python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-launch-timer"
+# (eager steps for the counter passes: NNZ_UNET_GRAPH=0 - the same kernels, dispatched one by one)
+BENCH2="python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-swt2net --no-launch-timer"
+export NNZ_UNET_GRAPH=0
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_f -- $BENCH2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_w -- $BENCH2 > /dev/null 2>&1
 cp $(ls $OUT/prof_f/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_fetch_size.csv
 cp $(ls $OUT/prof_w/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_write_size.csv
+unset NNZ_UNET_GRAPH
 # 3. the zoo steps as they run (hipGraph replay): kernel trace, second half of the run aggregated by kernel
-for M in M2Net SwT2Net SSND2Net LightMamba2Net; do
+for M in M2Net SwT2Net SSND2Net LightMamba2Net UNETR2Net; do
   rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_zoo -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models $M --steps 3 --warmup 3 > /dev/null 2>&1
   python3 $GRAFT_REPO_ROOT/tools/kernel_summary.py $(ls $OUT/prof_zoo/*/*kernel_trace.csv | head -1) 45 0.75 > $OUT/${TAG}_${M,,}_graph_kernels.txt 2>&1
   rm -rf $OUT/prof_zoo
@@ -30,6 +33,10 @@ cd $GRAFT_REPO_ROOT
 python3 tools/bench_scan.py > $OUT/${TAG}_scan_bench.txt 2>&1
 python3 tools/bench_conv_layers.py > $OUT/${TAG}_conv_layers.txt 2>&1
 python3 tools/bench_zoo.py --models M2NetP,M2Net,SwT2Net,SSND2Net,MambaND2Net,UNETR2Net,LightMamba2Net,LightMamba2NetP --steps 5 --warmup 3 2>&1 | grep '"model"' > $OUT/${TAG}_zoo_bench.txt
+# 4b. the window-attention kernels: SQ counters over one SwT2Net run (eager: one dispatch per kernel)
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $OUT/prof_wa_pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models SwT2Net --steps 1 --warmup 1 --graph 0 > /dev/null 2>&1
+python3 $GRAFT_REPO_ROOT/tools/pmc_kernel_sums.py $(ls $OUT/prof_wa_pmc/*/*counter_collection.csv | head -1) win_attn dense32 > $OUT/${TAG}_swt2net_pmc_sq_summary.json 2>&1
+rm -rf $OUT/prof_wa_pmc
 # 5. the bench line of record (defaults: both legs, cpu_baseline)
 python3 bench.py > $OUT/${TAG}_bench_n1.json 2>$OUT/${TAG}_bench_n1.err
 ls -la $OUT | tail -20
