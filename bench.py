@@ -127,6 +127,7 @@ def _profile_json(name):
 
 def run_secondary(steps: int, warmup: int):
     """BASELINE configs[2]: M2Net (SS2D^2Net) 1x512^2, batch 2, nnUNetTrainerM2Net.train_step (autocast step, AdamW)"""
+    from nnuzoo_amd import backends as _bk
     from nnuzoo_amd import hip_ops
     from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
     from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerM2Net
@@ -183,7 +184,7 @@ def run_secondary(steps: int, warmup: int):
                                   "nnUNetTrainerM2Net.train_step (fused AdamW); forward+loss+backward "
                                   + ("replayed as one hipGraph" if graph else "eager")},
            "hip_graph": graph,
-           "final_loss": round(losses[-1], 5), "roofline": roof,
+           "final_loss": round(losses[-1], 5), "roofline": roof, "backends": _bk.report(tr.network),
            "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     dz = _profile_json("r03_dice_parity_m2netp_128.json") or _profile_json("r02_dice_parity_m2netp_128.json") or _profile_json("r01_dice_parity_m2netp_128.json")
     if dz:
@@ -309,11 +310,8 @@ def run_swt2net(steps: int, warmup: int):
                 "bwd_avg_launch_us": round(sb / nb * 1e6, 2), "ms_per_step": round((sf + sb) / roof_steps * 1e3, 3),
                 "fwd_achieved": round(ff / sf / 1e12, 2), "bwd_achieved": round(fb / sb / 1e12, 2),
                 "timed_over": f"{roof_steps} eager steps after the timed region"}
-    from nnuzoo_amd.token_linear import TokenLinear
-    backends = {}
-    for m in tr.network.modules():
-        if isinstance(m, TokenLinear):
-            backends[m.backend] = backends.get(m.backend, 0) + 1
+    from nnuzoo_amd import backends as _bk
+    backends = _bk.report(tr.network)      # which kernel family every dispatching module took (nnuzoo_amd/backends.py)
     out = {"metric": "training patches/sec, SwT2Net 1x512^2 patches", "value": round(batch * steps / dt, 3),
            "unit": "patches/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
            "dtype": "f32 (no autocast, like the reference trainer)",
@@ -321,7 +319,7 @@ def run_swt2net(steps: int, warmup: int):
                                   "nnUNetTrainerSwT2Net.train_step (fused AdamW); forward+loss+backward "
                                   + ("replayed as one hipGraph" if graph else "eager")},
            "hip_graph": graph, "final_loss": round(losses[-1], 5), "roofline": roof,
-           "linear_backends": backends, "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+           "backends": backends, "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     del tr
     torch.cuda.empty_cache()
     return out

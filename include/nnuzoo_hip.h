@@ -261,6 +261,20 @@ int nnz_dense32_dgrad(const float* dy, const float* W, const float* h, float* dx
 long nnz_dense32_wgrad_workspace_floats(long T, int K, int N);
 int nnz_dense32_wgrad(const float* dy, const float* x, float* dW, float* db, float* workspace, long T, int K, int N,
                       void* stream);
+/* ALL weight gradients of a backward pass in one launch (+ one fold launch): the ~670 Linear layers of a Swin / ViT step are
+ * 18-30 us problems each; they do not sit on the data-gradient chain, so the caller queues them and runs them together.
+ * Same split rule and arithmetic as nnz_dense32_wgrad (bit-identical results).  Protocol: nnz_dense32_group_plan per
+ * problem -> its workgroups, fold blocks (0: written directly) and workspace floats; jobs are laid out back to back
+ * (wg_begin / blk_begin = running sums); nnz_dense32_group_fill writes one record per job into HOST tables
+ * (nnz_dense32_group_record_bytes(0) bytes per weight-gradient record, (1) per fold record; fold records only for jobs with
+ * fold blocks, numbered in job order); the caller builds the int32 maps workgroup -> job and fold block -> fold job, copies
+ * the four arrays to the device and calls nnz_dense32_group_launch. */
+int nnz_dense32_group_record_bytes(int which);
+int nnz_dense32_group_plan(long T, int K, int N, int* wgs, int* fold_blocks, long* ws_floats);
+int nnz_dense32_group_fill(void* job_host, void* fold_host, const float* dy, const float* x, float* dW, float* db,
+                           float* workspace, long T, int K, int N, int wg_begin, int blk_begin);
+int nnz_dense32_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs, const void* fold_dev,
+                             const int* blk_job_dev, int total_blks, void* stream);
 
 /* online-Dice statistics of the validation step (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 +
  * get_tp_fp_fn_tn, training/loss/dice.py:122-180, label-map targets): argmax over classes (first maximum on ties)

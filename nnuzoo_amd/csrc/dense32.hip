@@ -125,7 +125,7 @@ struct D32Tile {
 // are small (a few hundred workgroups, 12-96 blocks each), so a block's global-load latency must hide behind the LDS
 // hand-over and the MFMAs of two neighbouring blocks, not one.
 template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD>
-__global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
+__device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, const int split) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int D32_BK = (WM == 1 && WN == 1) ? 64 : 32;
   using TA = D32Tile<BM, A_CONTIG, D32_BK>;
@@ -138,9 +138,7 @@ __global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
   const int l31 = lane & 31, hh = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;           // wave grid 2 x 2
   const int ntc = (a.cols + BN - 1) / BN;
-  const int tile = blockIdx.x;
   const int r0 = (tile / ntc) * BM, c0 = (tile % ntc) * BN;
-  const int split = blockIdx.y;
   int k_begin = 0, k_end = a.kc;
   if (WGRAD) {
     k_begin = split * a.kc;
@@ -228,6 +226,58 @@ __global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
       }
   }
   if (WGRAD && a.part_db && c0 == 0 && tid < BM && r0 + tid < a.rows) a.part_db[(long)split * a.rows + r0 + tid] = dbsum;
+}
+
+template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD>
+__global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
+  dense32_body<WM, WN, A_CONTIG, B_CONTIG, WGRAD>(a, blockIdx.x, blockIdx.y);
+}
+
+// ---- grouped weight gradients: ALL weight gradients of a backward pass in one launch ------------------------------------
+// The Swin / ViT steps hold ~670 Linear layers whose weight gradients (T = 882 ... 35 378 tokens, K, N = 96 ... 3072) are
+// 18-30 us launches of a few hundred workgroups each plus a fold launch: 21 ms of a 104 ms SwT2Net step, latency not MFMA
+// rate.  They do not sit on the data-gradient chain, so the autograd nodes only queue (dy, x, dW, db) and the end of the
+// backward pass runs every queued problem in ONE launch of 64 x 64 tiles (job table + workgroup -> job map in device
+// memory) and ONE fold launch.  Same arithmetic and split rule as nnz_dense32_wgrad: bit-identical results.
+struct D32Job {
+  D32Args a;
+  int wg_begin;   // first workgroup of this job in the grouped launch
+  int ntiles;     // 64 x 64 tiles of the weight matrix; workgroup (wg - wg_begin) = split * ntiles + tile
+};
+struct D32FoldJob {
+  const float* part;
+  float* dst;
+  const float* part_db;
+  float* db;
+  long n;
+  int splits, nb;
+  int blk_begin;  // first 256-thread block of this job in the grouped fold launch
+  int pad;
+};
+__global__ __launch_bounds__(256, 2) void dense32_group_wgrad_kernel(const D32Job* __restrict__ jobs,
+                                                                     const int* __restrict__ wg_job) {
+  const int j = __builtin_amdgcn_readfirstlane(wg_job[blockIdx.x]);
+  const D32Job* jp = jobs + j;
+  const D32Args a = jp->a;
+  const int local = (int)blockIdx.x - jp->wg_begin;
+  const int nt = jp->ntiles;
+  dense32_body<1, 1, false, false, true>(a, local % nt, local / nt);
+}
+__global__ __launch_bounds__(256) void dense32_group_fold_kernel(const D32FoldJob* __restrict__ jobs,
+                                                                 const int* __restrict__ blk_job) {
+  const int j = __builtin_amdgcn_readfirstlane(blk_job[blockIdx.x]);
+  const D32FoldJob f = jobs[j];
+  const long i = (long)((int)blockIdx.x - f.blk_begin) * 256 + threadIdx.x;
+  if (i < f.n) {
+    float s = 0.f;
+    for (int q = 0; q < f.splits; ++q) s += f.part[(long)q * f.n + i];
+    f.dst[i] = s;
+  } else if (f.db && i - f.n < f.nb) {
+    const long jj = i - f.n;
+    float s = 0.f;
+    for (int q = 0; q < f.splits; ++q) s += f.part_db[(long)q * f.nb + jj];
+    f.db[jj] = s;
+  }
 }
 
 // fold the weight-gradient partials in split order: dW[e] = sum_s part[s][e], db[n] = sum_s part_db[s][n]
@@ -336,6 +386,65 @@ extern "C" int nnz_dense32_wgrad(const float* dy, const float* x, float* dW, flo
   const long total = n + (db ? N : 0);
   NNZ_LAUNCH(dense32_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
              (int)splits, n, dW, (const float*)a.part_db, N, db);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// ---- grouped weight gradients (see dense32_group_wgrad_kernel) -------------------------------------------------------------
+// Host protocol: for every queued problem nnz_dense32_group_plan gives its workgroups, fold blocks (0: written directly) and
+// workspace floats; the caller lays the jobs out back to back (wg_begin / blk_begin = running sums), fills one record per job
+// with nnz_dense32_group_fill into HOST tables of nnz_dense32_group_record_bytes(0 / 1) bytes per record, builds the two
+// int32 maps (workgroup -> job, fold block -> fold job), copies the four arrays to the device and calls
+// nnz_dense32_group_launch.
+extern "C" int nnz_dense32_group_record_bytes(int which) {
+  return which == 0 ? (int)sizeof(nnz::D32Job) : (int)sizeof(nnz::D32FoldJob);
+}
+extern "C" int nnz_dense32_group_plan(long T, int K, int N, int* wgs, int* fold_blocks, long* ws_floats) {
+  if (T < 1 || T > (1L << 30) || (K & 3) || (N & 3) || K < 4 || N < 4 || !wgs || !fold_blocks || !ws_floats) return NNZ_EINVAL;
+  const long splits = d32_wgrad_splits(T, K, N, nullptr);
+  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  *wgs = (int)(tiles * splits);
+  *fold_blocks = splits > 1 ? (int)(((long)N * K + N + 255) / 256) : 0;
+  *ws_floats = splits > 1 ? splits * ((long)N * K + N) : 0;
+  return NNZ_OK;
+}
+extern "C" int nnz_dense32_group_fill(void* job_host, void* fold_host, const float* dy, const float* x, float* dW, float* db,
+                                      float* workspace, long T, int K, int N, int wg_begin, int blk_begin) {
+  using namespace nnz;
+  if (!job_host || !dy || !x || !dW || T < 1 || T > (1L << 30) || (K & 3) || (N & 3) || K < 4 || N < 4) return NNZ_EINVAL;
+  long per = 0;
+  const long splits = d32_wgrad_splits(T, K, N, &per);
+  if (splits > 1 && (!workspace || !fold_host)) return NNZ_EINVAL;
+  D32Job j = {};
+  D32Args& a = j.a;
+  a.A = dy; a.a_rs = 1; a.a_cs = N;
+  a.B = x; a.b_rs = 1; a.b_cs = K;
+  a.ldo = K; a.rows = N; a.cols = K; a.kc = (int)per; a.kc_total = (int)T;
+  j.wg_begin = wg_begin;
+  j.ntiles = ((N + 63) / 64) * ((K + 63) / 64);
+  if (splits == 1) {
+    a.out = dW; a.split_stride = 0; a.part_db = db;
+  } else {
+    a.out = workspace; a.split_stride = (long)N * K;
+    a.part_db = db ? workspace + splits * (long)N * K : nullptr;
+    D32FoldJob f = {};
+    f.part = workspace; f.dst = dW; f.part_db = a.part_db; f.db = db;
+    f.n = (long)N * K; f.splits = (int)splits; f.nb = N; f.blk_begin = blk_begin;
+    *reinterpret_cast<D32FoldJob*>(fold_host) = f;
+  }
+  *reinterpret_cast<D32Job*>(job_host) = j;
+  return NNZ_OK;
+}
+extern "C" int nnz_dense32_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs, const void* fold_dev,
+                                        const int* blk_job_dev, int total_blks, void* stream) {
+  using namespace nnz;
+  if (!jobs_dev || !wg_job_dev || total_wgs < 1 || total_blks < 0 || (total_blks > 0 && (!fold_dev || !blk_job_dev)))
+    return NNZ_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  NNZ_LAUNCH(dense32_group_wgrad_kernel, dim3((unsigned)total_wgs), dim3(256), 0, s, (const D32Job*)jobs_dev, wg_job_dev);
+  if (total_blks > 0)
+    NNZ_LAUNCH(dense32_group_fold_kernel, dim3((unsigned)total_blks), dim3(256), 0, s, (const D32FoldJob*)fold_dev,
+               blk_job_dev);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

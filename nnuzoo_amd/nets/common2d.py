@@ -15,6 +15,8 @@ from __future__ import annotations
 import os
 
 import torch
+
+from .. import backends as _backends
 import torch.nn.functional as F
 from torch import nn
 
@@ -151,12 +153,21 @@ class _Conv2d(nn.Conv2d):
             w, b = self.weight, self.bias
             if torch.is_autocast_enabled():
                 if mode != "2":
+                    _backends.note(self, "library", why="NNZ_DW_NATIVE=1 under autocast")
                     return super().forward(x)
                 dt = torch.get_autocast_dtype("cuda")   # what autocast would have cast the convolution's operands to
                 x, w, b = x.to(dt), w.to(dt), (b.to(dt) if b is not None else None)
             elif x.dtype != torch.float32:
+                _backends.note(self, "library", why=f"depthwise input {x.dtype} outside autocast")
                 return super().forward(x)
+            # forward / input gradient: ATen's direct depthwise kernels (chosen over MIOpen's batched-GEMM path); weight
+            # gradient: csrc/depthwise_wgrad.hip where _dw_wgrad_ok
+            _backends.note(self, "aten")
+            _backends.note(self, "hip" if _dw_wgrad_ok(x, x, w, self.stride, self.padding, self.dilation) else "aten",
+                           site="wgrad")
             return _DepthwiseNativeFn.apply(x, w, b, self.stride, self.padding, self.dilation, self.groups)
+        if self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda:
+            _backends.note(self, "library", why="depthwise with NNZ_DW_NATIVE=0 or non-zero padding mode")
         return super().forward(x)
 
 
@@ -258,6 +269,8 @@ class RSU4F(nn.Module):
 
     def forward(self, x):
         from .. import rebnconv
+        _backends.note(self, "hip" if rebnconv.USE_HIP and rebnconv.hip_path_ok(self, x) else "library",
+                       why="RSU4F outside fp16 autocast / unsupported channels / eval with autograd")
         if rebnconv.USE_HIP and rebnconv.hip_path_ok(self, x):
             # dilated conv + batch-stat norm + ReLU units on the tap-table conv kernels, channels-last inside the block
             return rebnconv.rsu4f_forward(self, x)

@@ -22,6 +22,8 @@ import math
 from typing import List, Tuple, Union
 
 import torch
+
+from .. import backends as _backends
 import torch.nn.functional as F
 from torch import nn
 
@@ -140,6 +142,7 @@ class SS2D(nn.Module):
         fused = self.fused_cross_scan and x.is_cuda and self.d_state == 16 and 1 <= self.dt_rank <= 8 \
             and self.d_inner % 4 == 0 and B * self.d_inner <= 65535 and x.dtype in (torch.float16, torch.float32)
         if fused and self.fused_dwconv and ss2d_scan.dwconv_supported(self.conv2d):
+            _backends.note(self, "hip")
             # conv + SiLU + both scan layouts in one kernel, directions by index arithmetic inside the scan kernels,
             # gated output norm in one kernel (nnuzoo_amd/ss2d_scan.py, layer_norm.py)
             y = ss2d_scan.ss2d_conv_cross_scan(x, self.conv2d, self.x_proj_weight, self.dt_projs_weight,
@@ -147,6 +150,8 @@ class SS2D(nn.Module):
             y = layer_norm_gate(y, z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps,
                                 feeds_linear=True)                      # LN(y) * silu(z) -> out_proj
         else:
+            _backends.note(self, "hip-opbyop" if x.is_cuda else "library",
+                           why="op-by-op formulation around selective_scan_fn (fused_cross_scan off or unsupported shape)")
             x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
             if fused:
                 y = ss2d_scan.ss2d_cross_scan(x, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,

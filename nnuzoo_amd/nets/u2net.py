@@ -12,6 +12,8 @@ in the reference's order)."""
 from __future__ import annotations
 
 import torch
+
+from .. import backends as _backends
 import torch.nn.functional as F
 from torch import nn
 
@@ -41,12 +43,12 @@ class REBNCONV(nn.Module):
 
     def forward(self, x):
         if self._hip_ok(x):
-            self.backend = "hip"
+            _backends.note(self, "hip")
             xc = x.permute(0, 2, 3, 1)        # free when x is already channels-last in memory
             if xc.dtype != torch.float16 or not xc.is_contiguous():
                 xc = xc.to(torch.float16).contiguous()
             return _rb.rebnconv_cl(self, xc).permute(0, 3, 1, 2)
-        self.backend = "library"
+        _backends.note(self, "library", why="outside fp16 autocast / unsupported channels / eval with autograd")
         return self.relu_s1(self.bn_s1(self.conv_s1(x)))
 
 

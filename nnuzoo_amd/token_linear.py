@@ -12,7 +12,11 @@ from __future__ import annotations
 
 import os
 
+import ctypes as C
+
 import torch
+
+from . import backends as _backends
 import torch.nn.functional as F
 from torch import nn
 
@@ -162,8 +166,112 @@ def dense32_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return K % 4 == 0 and N % 4 == 0 and x.numel() // K >= DENSE32_MIN_TOKENS
 
 
-def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None):
-    """the three products of a Linear's backward on csrc/dense32.hip: dx (optionally times GELU'(h)), dW, db"""
+# ---- deferred, grouped weight gradients ------------------------------------------------------------------------------------
+# Inside `with deferred_wgrads():` (the trainers wrap loss.backward() in it) the fp32 Linear nodes do NOT launch their
+# weight-gradient kernels: they queue (dy, x, parameter) and return None for the parameter gradients; leaving the context
+# runs every queued problem in ONE grouped launch (+ one fold launch, csrc/dense32.hip dense32_group_*) and assigns /
+# accumulates `.grad` itself.  A Swin step holds ~670 such problems of 18-30 us each (21 ms of a 104 ms SwT2Net step); they
+# do not sit on the data-gradient chain.  Results are bit-identical to the per-layer launches (same split rule, same
+# arithmetic, fixed fold order).  Outside the context (torch.autograd.grad, parity tests) nothing changes.
+GROUP_WGRAD = os.environ.get("NNZ_DENSE32_GROUP", "1") != "0"
+_DEFER = {"on": False, "jobs": []}
+_GROUP_KEEP = []          # host tables captured into a hipGraph must outlive it
+_HOST_CACHE, _HOST_EVENTS = {}, {}
+
+
+class deferred_wgrads:
+    def __enter__(self):
+        self._outer = _DEFER["on"]
+        _DEFER["on"] = GROUP_WGRAD or self._outer
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if not self._outer:
+            _DEFER["on"] = False
+            jobs, _DEFER["jobs"] = _DEFER["jobs"], []
+            if et is None and jobs:
+                _flush_group(jobs)
+        return False
+
+
+def _flush_group(jobs) -> None:
+    import numpy as np
+    lib = _lib.load()
+    dev = jobs[0][0].device
+    rb_job, rb_fold = int(lib.nnz_dense32_group_record_bytes(0)), int(lib.nnz_dense32_group_record_bytes(1))
+    plans = []
+    wgs, blks, ws_f = C.c_int(0), C.c_int(0), C.c_long(0)
+    for dy2, x2, w, b in jobs:
+        N, K = w.shape
+        call("nnz_dense32_group_plan", x2.shape[0], K, N, C.addressof(wgs), C.addressof(blks), C.addressof(ws_f))
+        plans.append((wgs.value, blks.value, ws_f.value))
+    nfold = sum(1 for p in plans if p[1] > 0)
+    total_wgs, total_blks = sum(p[0] for p in plans), sum(p[1] for p in plans)
+    ws = torch.empty(max(1, sum(p[2] for p in plans)), dtype=torch.float32, device=dev)
+    # one pinned host buffer: [job records | fold records | workgroup -> job | fold block -> fold job]
+    o_fold = (len(jobs) * rb_job + 15) // 16 * 16
+    o_wg = (o_fold + nfold * rb_fold + 15) // 16 * 16
+    o_blk = o_wg + total_wgs * 4
+    # Pinned memory cannot be allocated while a stream is capturing (it invalidates the capture): the eager warm-up passes
+    # that precede every capture leave their buffer in _HOST_CACHE under the pass's shape signature; a capturing flush TAKES
+    # it (the captured copy node re-reads it at every replay, so no later flush may write to it).
+    nbytes = o_blk + max(1, total_blks) * 4
+    key = tuple((x2.shape[0],) + tuple(w.shape) + (b is not None,) for _, x2, w, b in jobs)
+    capturing = torch.cuda.is_current_stream_capturing()
+    host = _HOST_CACHE.pop(key, None)
+    ev = _HOST_EVENTS.pop(key, None)
+    if host is not None and ev is not None and not capturing:
+        ev.synchronize()                  # the previous copy out of this buffer has run
+    if host is None or host.numel() != nbytes:
+        if capturing:
+            raise RuntimeError("grouped weight gradients: no pinned table from a warm-up pass for this capture - run one "
+                               "eager pass with the same shapes before capturing")
+        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    hp = host.data_ptr()
+    hn = host.numpy()
+    wg_job = hn[o_wg:o_wg + total_wgs * 4].view(np.int32)
+    blk_job = hn[o_blk:o_blk + total_blks * 4].view(np.int32)
+    wg0 = blk0 = fi = 0
+    ws_off = 0
+    outs = []
+    for j, ((dy2, x2, w, b), (nw, nb, nf)) in enumerate(zip(jobs, plans)):
+        N, K = w.shape
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        db = torch.empty(N, dtype=torch.float32, device=dev) if b is not None else None
+        call("nnz_dense32_group_fill", hp + j * rb_job, (hp + o_fold + fi * rb_fold) if nb else None, ptr(dy2), ptr(x2),
+             ptr(dw), ptr(db), (ws.data_ptr() + 4 * ws_off) if nf else None, x2.shape[0], K, N, wg0, blk0)
+        wg_job[wg0:wg0 + nw] = j
+        if nb:
+            blk_job[blk0:blk0 + nb] = fi
+            fi += 1
+        wg0, blk0, ws_off = wg0 + nw, blk0 + nb, ws_off + nf
+        outs.append((w, dw, b, db))
+    tab = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
+    tab.copy_(host, non_blocking=True)
+    if capturing:
+        _GROUP_KEEP.append(host)          # the captured copy node reads this buffer at every replay
+    else:
+        # the copy above is stream-ordered; the next flush with this signature rewrites the buffer only after synchronising
+        # with it (same stream: its own copy is ordered behind this one; the host writes are guarded by the event below)
+        ev = torch.cuda.Event()
+        ev.record()
+        _HOST_CACHE[key] = host
+        _HOST_EVENTS[key] = ev
+    base = tab.data_ptr()
+    call("nnz_dense32_group_launch", base, base + o_wg, total_wgs, base + o_fold, base + o_blk, total_blks, stream_ptr())
+    for w, dw, b, db in outs:
+        for p, g in ((w, dw), (b, db)):
+            if g is None:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+
+
+def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None, bias=None):
+    """the three products of a Linear's backward on csrc/dense32.hip: dx (optionally times GELU'(h)), dW, db.  Inside
+    deferred_wgrads() the weight / bias gradients are queued for the grouped launch and returned as None"""
     N, K = weight.shape
     T = x2.shape[0]
     dx = dw = db = None
@@ -171,6 +279,9 @@ def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None):
         dx = torch.empty((T, K), dtype=torch.float32, device=dy2.device)
         call("nnz_dense32_dgrad", ptr(dy2), ptr(weight), ptr(h), ptr(dx), T, K, N, stream_ptr())
     if need_w or need_b:
+        if _DEFER["on"] and need_w and weight.is_leaf and (bias is None or bias.is_leaf):
+            _DEFER["jobs"].append((dy2, x2, weight, bias if need_b else None))
+            return dx, None, None
         dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
         db = torch.empty(N, dtype=torch.float32, device=dy2.device) if need_b else None
         ws = _d32_workspace(dy2.device, int(_lib.load().nnz_dense32_wgrad_workspace_floats(T, K, N)))
@@ -194,6 +305,7 @@ class _Dense32LinearFn(torch.autograd.Function):
         call("nnz_dense32_forward", ptr(x2), ptr(weight), ptr(bias), ptr(y), None, T, K, N, 0, stream_ptr())
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)             # the parameter objects themselves (leaves): the deferred path sets their .grad
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], N)
 
@@ -204,8 +316,8 @@ class _Dense32LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, N)
         if not dy2.is_contiguous() or dy2.dtype != torch.float32:
             dy2 = dy2.float().contiguous()
-        dx, dw, db = _d32_backward_products(dy2, x2, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                            ctx.has_bias and ctx.needs_input_grad[2])
+        dx, dw, db = _d32_backward_products(dy2, x2, ctx.params[0], ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                            ctx.has_bias and ctx.needs_input_grad[2], bias=ctx.params[1])
         return (None if dx is None else dx.view(ctx.xshape)), (dw if ctx.needs_input_grad[1] else None), db
 
 
@@ -229,6 +341,7 @@ class _Dense32MlpFn(torch.autograd.Function):
         y = torch.empty((T, N), dtype=torch.float32, device=dev)
         call("nnz_dense32_forward", ptr(a), ptr(w2), ptr(b2), ptr(y), None, T, Hd, N, 0, stream_ptr())
         ctx.save_for_backward(x2, w1, w2, h, a)
+        ctx.params = (w1, b1, w2, b2)
         ctx.bias = (b1 is not None, b2 is not None)
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], N)
@@ -241,35 +354,37 @@ class _Dense32MlpFn(torch.autograd.Function):
         if not dy2.is_contiguous() or dy2.dtype != torch.float32:
             dy2 = dy2.float().contiguous()
         ni = ctx.needs_input_grad
-        dh, dw2, db2 = _d32_backward_products(dy2, a, w2, True, ni[3], ctx.bias[1] and ni[4], h=h)   # dh = (dy W2) * GELU'(h)
-        dx, dw1, db1 = _d32_backward_products(dh, x2, w1, ni[0], ni[1], ctx.bias[0] and ni[2])
+        p = ctx.params
+        dh, dw2, db2 = _d32_backward_products(dy2, a, p[2], True, ni[3], ctx.bias[1] and ni[4], h=h, bias=p[3])   # dh = (dy W2) * GELU'(h)
+        dx, dw1, db1 = _d32_backward_products(dh, x2, p[0], ni[0], ni[1], ctx.bias[0] and ni[2], bias=p[1])
         return (None if dx is None else dx.view(ctx.xshape)), (dw1 if ni[1] else None), db1, (dw2 if ni[3] else None), db2
 
 
 def mlp_gelu(x: torch.Tensor, fc1: nn.Linear, fc2: nn.Linear) -> torch.Tensor:
     """fc2(GELU(fc1(x))); the fused fp32 path when it applies, the module-by-module form otherwise"""
     if dense32_ok(x, fc1.weight) and dense32_ok(x, fc2.weight) and fc2.weight.shape[1] == fc1.weight.shape[0]:
+        _backends.note(fc1, "hip-f32")
+        _backends.note(fc2, "hip-f32")
         return _Dense32MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
     return fc2(F.gelu(fc1(x)))
 
 
 class TokenLinear(nn.Linear):
-    #: which implementation the most recent forward took ("hip-f16" / "hip-f32" / "library"); tests and the bench read it
-    backend = "unset"
-
+    #: `self.backend` (set by the first call, nnuzoo_amd/backends.py): which implementation the most recent forward took -
+    #: "hip-f16" / "hip-f32" / "library"; tests and the bench read it
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         tokens = x.numel() // max(1, x.shape[-1])
         if dense32_ok(x, self.weight):
-            self.backend = "hip-f32"
+            _backends.note(self, "hip-f32")
             return _Dense32LinearFn.apply(x, self.weight, self.bias)
         if USE_HIP_KERNELS and x.is_cuda and tokens >= HIP_MIN_TOKENS and x.is_contiguous() and self.weight.dtype == torch.float32 \
                 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16 \
                 and x.dtype in (torch.float16, torch.float32) and self.in_features % 8 == 0 \
                 and _hip_ok(self.in_features, self.out_features):
             xh = x if x.dtype == torch.float16 else x.to(torch.float16)
-            self.backend = "hip-f16"
+            _backends.note(self, "hip-f16")
             return _HipTokenLinearFn.apply(xh, self.weight, self.bias)
-        self.backend = "library"
+        _backends.note(self, "library", why=f"{tuple(x.shape)} {x.dtype}, autocast {torch.is_autocast_enabled()}")
         if x.is_cuda and x.is_contiguous() and x.dtype in (torch.float16, torch.float32) \
                 and _wgrad_chunks(tokens, self.in_features, self.out_features) > 1:
             return _TallLinearFn.apply(x, self.weight, self.bias)

@@ -69,7 +69,9 @@ class GraphedForwardBackward:
                 loss = self._loss(self.network(data), target)
         else:
             loss = self._loss(self.network(data), target)
-        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
+        from ..token_linear import deferred_wgrads
+        with deferred_wgrads():      # fp32 Linear weight gradients of the pass run as ONE grouped launch at the end
+            (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
         return loss
 
     def _capture(self, data, target):

@@ -14,6 +14,8 @@ import os
 import numpy as np
 
 import torch
+
+from ..token_linear import deferred_wgrads
 from torch.optim import AdamW
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
@@ -140,7 +142,8 @@ class _X2Trainer(nnUNetTrainer):
         if self._fp32_step:
             output = self.network(data)
             l = self.loss(list(output) if isinstance(output, (tuple, list)) else output, target)
-            l.backward()
+            with deferred_wgrads():  # fp32 Linear weight gradients of the pass: one grouped launch (token_linear.py)
+                l.backward()
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())
             torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)

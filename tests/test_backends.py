@@ -1,0 +1,60 @@
+"""the dispatch sites of the zoo record which kernel family they took
+(nnuzoo_amd/backends.py) instead of deciding behind a silent predicate, and the bench configurations run on the HIP
+kernels everywhere except the documented ATen choices."""
+import pytest
+import torch
+
+from nnuzoo_amd import backends as bk
+
+
+def test_note_report_assert_cpu():
+    bk.reset()
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.ReLU())
+    bk.note(net[0], "hip-f32")
+    bk.note(net[1], "library", why="test")
+    bk.note(net[1], "hip", site="wgrad")
+    assert net[0].backend == "hip-f32" and net[1].backend == "library" and net[1].backend_sites == {"wgrad": "hip"}
+    rep = bk.report(net)
+    assert rep == {"Linear": {"hip-f32": 1, "library": 1}, "Linear.wgrad": {"hip": 1}}
+    with pytest.raises(AssertionError, match="library"):
+        bk.assert_hip(net)
+    net[1].backend = "hip-f16"
+    assert bk.assert_hip(net) == {"Linear": {"hip-f32": 1, "hip-f16": 1}, "Linear.wgrad": {"hip": 1}}
+    assert bk.COUNTS[("Linear", "forward", "library")] == 1
+    assert "backend" not in net.state_dict() and len(net.state_dict()) == 4      # plain attributes: state_dict untouched
+
+
+def _step(trainer_cls, size=128):
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    plans, cfg, dj = nnunet_plans(2, (size, size), batch_size=2)
+    torch.manual_seed(0)
+    tr = trainer_cls(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    b = synthetic_batch(2, (size, size), tr._get_deep_supervision_scales(), seed=3)
+    b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+    tr.train_step(b)
+    torch.cuda.synchronize()
+    return tr
+
+
+@pytest.mark.gpu
+def test_m2net_bench_configuration_runs_on_hip(hip_lib):
+    """bench.py's secondary leg (nnUNetTrainerM2Net, fp16 autocast): SS2D blocks fused, RSU4F on conv_box, every Linear on
+    the token-major MFMA kernel"""
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerM2Net
+    tr = _step(nnUNetTrainerM2Net)
+    rep = bk.assert_hip(tr.network)
+    assert rep["SS2D"] == {"hip": sum(type(m).__name__ == "SS2D" for m in tr.network.modules())}
+    assert set(rep["TokenLinear"]) <= {"hip-f16"} and rep["RSU4F"].get("hip", 0) >= 1
+
+
+@pytest.mark.gpu
+def test_swt2net_bench_configuration_runs_on_hip(hip_lib):
+    """bench.py's SwT2Net leg (fp32 step): every Linear incl. the Mlp pairs on the fp32 MFMA kernels; the depthwise
+    convolutions are the one documented non-HIP choice - ATen's direct kernels forward / input gradient (over MIOpen's
+    batched-GEMM path), weight gradient on csrc/depthwise_wgrad.hip"""
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerSwT2Net
+    tr = _step(nnUNetTrainerSwT2Net)
+    rep = bk.assert_hip(tr.network, allow=("_Conv2d",))
+    assert rep["TokenLinear"] == {"hip-f32": sum(type(m).__name__ == "TokenLinear" for m in tr.network.modules())}
+    assert set(rep.get("_Conv2d", {})) <= {"aten"} and set(rep.get("_Conv2d.wgrad", {})) <= {"hip"}

@@ -109,3 +109,43 @@ def test_fused_mlp_matches_torch(hip_lib):
     _close(y, yr.detach(), 768, "y")
     for name, a, r in zip(["dx", "dW1", "db1", "dW2", "db2"], grads, ref):
         _close(a, r, 9800, name)
+
+
+def test_grouped_deferred_weight_gradients_equal_per_layer_launches(hip_lib):
+    """inside deferred_wgrads() the Linear / Mlp nodes queue their weight gradients and ONE grouped launch (+ one fold)
+    produces them: bit-identical to the per-layer launches, .grad assigned (and accumulated on a second pass)"""
+    from nnuzoo_amd.nets.swt2net import Mlp
+    from nnuzoo_amd.token_linear import TokenLinear, deferred_wgrads
+    torch.manual_seed(2)
+    layers = [TokenLinear(96, 288), Mlp(192, 768), TokenLinear(768, 3072, bias=False), TokenLinear(100, 36),
+              TokenLinear(3072, 768), Mlp(96, 384)]
+    toks = [35378, 9800, 882, 70, 882, 333]
+    net = torch.nn.ModuleList(layers).to(DEV)
+    xs = [torch.randn(t, (m.in_features if isinstance(m, TokenLinear) else m.fc1.in_features), device=DEV) for m, t in
+          zip(net, toks)]
+
+    def run(deferred: bool):
+        for p in net.parameters():
+            p.grad = None
+        loss = sum((m(x) * (1 + i)).square().mean() for i, (m, x) in enumerate(zip(net, xs)))
+        if deferred:
+            with deferred_wgrads():
+                loss.backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net.parameters()]
+
+    ref = run(False)
+    got = run(True)
+    assert len(ref) == len(got) == len(list(net.parameters()))
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    # accumulation into existing .grad
+    loss = sum(m(x).mean() for m, x in zip(net, xs))
+    with deferred_wgrads():
+        loss.backward()
+    extra = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    sum(m(x).mean() for m, x in zip(net, xs)).backward()
+    assert all(torch.allclose(e, g + p.grad, rtol=1e-6, atol=1e-7) for e, g, p in zip(extra, got, net.parameters()))

@@ -65,7 +65,10 @@ def test_fp32_training_trajectory_matches_the_reference_cpu_run(hip_lib):
     # g / (sqrt(v) + eps) turns tiny gradient differences of near-zero entries into O(lr) parameter differences early on
     # (measured |d loss| 3.3e-3, 4.1e-3 at steps 1-2 - the same in every run - then 1.0e-2 .. 1.8e-2 over five runs once the
     # fp32-atomic run-to-run noise has been amplified, while the loss itself falls 0.53 -> 0.22)
-    assert np.all(np.abs(got[:3] - want[:3]) < 1e-2), (got, want)
+    # round 3: the fp32 Linear layers of this step run on the hand-written fp32 MFMA kernels (csrc/dense32.hip) instead of
+    # hipBLASLt - a different (equally valid) summation order; step 2 then measured 0.8e-2 ... 1.35e-2 over four runs (with
+    # NNZ_DENSE32=0: < 1e-2 in every run), so its bound is 2e-2; steps 0-1 keep theirs
+    assert np.all(np.abs(got[:2] - want[:2]) < 1e-2) and abs(got[2] - want[2]) < 2e-2, (got, want)
     assert np.all(np.abs(got - want) < 4e-2), (got, want)
     assert got[-1] < 0.6 * got[0]
 
