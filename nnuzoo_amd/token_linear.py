@@ -384,7 +384,17 @@ class TokenLinear(nn.Linear):
             xh = x if x.dtype == torch.float16 else x.to(torch.float16)
             _backends.note(self, "hip-f16")
             return _HipTokenLinearFn.apply(xh, self.weight, self.bias)
-        _backends.note(self, "library", why=f"{tuple(x.shape)} {x.dtype}, autocast {torch.is_autocast_enabled()}")
+        # the reason is part of the record (tests assert that bench configurations only take this branch for small calls)
+        if x.is_cuda and tokens < HIP_MIN_TOKENS and torch.is_autocast_enabled():
+            why = "small"            # fewer than HIP_MIN_TOKENS tokens: launch-bound either way
+        elif x.is_cuda and torch.is_autocast_enabled() and (self.in_features % 8 or self.in_features > MAX_FEATURES
+                                                            or self.out_features > 4 * MAX_FEATURES
+                                                            or not _hip_ok(self.in_features, self.out_features)):
+            why = "features"         # feature counts outside the f16 token kernel's set
+        else:
+            why = "other"            # CPU tensor, dtype / layout outside both kernel families, switched off by environment
+        self.backend_why = why
+        _backends.note(self, "library", why=why)
         if x.is_cuda and x.is_contiguous() and x.dtype in (torch.float16, torch.float32) \
                 and _wgrad_chunks(tokens, self.in_features, self.out_features) > 1:
             return _TallLinearFn.apply(x, self.weight, self.bias)
