@@ -64,12 +64,19 @@ class MambaLayer(nn.Module):
                 nheaddim = i
         return nheaddim
 
+    #: the sequence mixer: Mamba2 here; nets/lm2net.py (the 1-D Mamba variant of the same file family) overrides it
+    mixer = "mamba2"
+
     def __init__(self, input_dim, output_dim, d_state=16, d_conv=4, expand=2):
         super().__init__()
         self.input_dim, self.output_dim = input_dim, output_dim
         self.norm = LayerNorm(input_dim)
-        self.mamba = Mamba2(d_model=input_dim, d_state=d_state, d_conv=d_conv, expand=expand,
-                            headdim=self.get_nheaddim(input_dim, expand))
+        if self.mixer == "mamba2":
+            self.mamba = Mamba2(d_model=input_dim, d_state=d_state, d_conv=d_conv, expand=expand,
+                                headdim=self.get_nheaddim(input_dim, expand))
+        else:
+            from .mamba_simple import Mamba
+            self.mamba = Mamba(d_model=input_dim, d_state=d_state, d_conv=d_conv, expand=expand)
         self.proj = TokenLinear(input_dim, output_dim)
         self.skip_scale = nn.Parameter(torch.ones(1))
 
@@ -147,6 +154,8 @@ _AXES = {2: "hw", 3: "dhw"}
 
 
 class ResMambaBlock(nn.Module):
+    layer_cls = MambaLayer
+
     def __init__(self, spatial_dims: int, in_channels: int, norm, kernel_size: int = 3, act=_RELU, order: str = "d h w"):
         super().__init__()
         if kernel_size % 2 != 1:
@@ -156,8 +165,8 @@ class ResMambaBlock(nn.Module):
         self.norm1 = get_norm_layer(norm, spatial_dims, in_channels)
         self.norm2 = get_norm_layer(norm, spatial_dims, in_channels)
         self.act = get_act_layer(act)
-        self.mamba1 = MambaLayer(input_dim=in_channels, output_dim=in_channels)
-        self.mamba2 = MambaLayer(input_dim=in_channels, output_dim=in_channels)
+        self.mamba1 = self.layer_cls(input_dim=in_channels, output_dim=in_channels)
+        self.mamba2 = self.layer_cls(input_dim=in_channels, output_dim=in_channels)
 
     def nd_mamba_order(self, order: str, x: torch.Tensor, mamba_module: nn.Module):
         """runs the layer with the spatial axes permuted to `order` (the token sequence walks the LAST named axis
@@ -178,6 +187,11 @@ class ResMambaBlock(nn.Module):
 
 
 class LightMUNet(nn.Module):
+    block_cls = ResMambaBlock
+    #: lm2net.py's LightMUNet (:223-402) differs in two points: `add_last` is honoured - a depthwise-separable conv of the
+    #: input, created FIRST, is added to the output - and every encoder level has ONE ResMambaBlock (here: 1, 2, 2, ...)
+    lm_variant = False
+
     def __init__(self, spatial_dims: int = 3, mid_ch: int = 32, in_ch: int = 1, out_ch: int = 2, dropout_prob=None,
                  act=_RELU, norm=_GROUP8, norm_name: str = "", num_groups: int = 8, use_conv_final: bool = True,
                  n_layers: int = 7, add_last: bool = False, upsample_mode="nontrainable", min_size: int = 4,
@@ -186,9 +200,11 @@ class LightMUNet(nn.Module):
         if spatial_dims not in (2, 3):
             raise ValueError("`spatial_dims` can only be 2 or 3.")
         self.input_path_size, self.add_last, self.spatial_dims = input_patch_size, add_last, spatial_dims
+        if self.lm_variant and add_last:
+            self.rebnconvin = get_dwconv_layer(2, in_ch, out_ch)
         self.init_filters, self.in_channels, self.n_layers = mid_ch, in_ch, n_layers
         self.layer_in_channels = [mid_ch] * n_layers
-        self.blocks_down = [1] + [2] * (n_layers - 1)
+        self.blocks_down = [1] + [1 if self.lm_variant else 2] * (n_layers - 1)
         self.blocks_up = [1] * (n_layers - 1)
         self.dropout_prob, self.act = dropout_prob, act
         self.act_mod = get_act_layer(act)
@@ -213,8 +229,8 @@ class LightMUNet(nn.Module):
             ch = self.layer_in_channels[i]
             down = MaxPool(self.spatial_dims, kernel_size=self.scales[i], stride=self.scales[i]) \
                 if np.prod(self.scales[i]) != 1 else nn.Identity()
-            down_layers.append(nn.Sequential(down, *[ResMambaBlock(self.spatial_dims, ch, norm=self.norm, act=self.act,
-                                                                   order=orders[i % len(orders)]) for _ in range(item)]))
+            down_layers.append(nn.Sequential(down, *[self.block_cls(self.spatial_dims, ch, norm=self.norm, act=self.act,
+                                                                    order=orders[i % len(orders)]) for _ in range(item)]))
         return down_layers
 
     def _make_up_layers(self):
@@ -251,9 +267,11 @@ class LightMUNet(nn.Module):
         return self.conv_final(x) if self.use_conv_final else x
 
     def forward(self, x):
+        last_add = self.rebnconvin(x) if (self.lm_variant and self.add_last) else None
         x, down_x = self.encode(x)
         down_x.reverse()
-        return self.decode(x, down_x)
+        x = self.decode(x, down_x)
+        return x if last_add is None else x + last_add
 
 
 class _LightX2(_UnetrStageX2):

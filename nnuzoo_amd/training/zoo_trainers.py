@@ -284,6 +284,35 @@ class nnUNetTrainerLightMamba2NetP(nnUNetTrainerLightMamba2Net):
         return nnUNetTrainerLightMamba2Net._build(args, kwargs, True)
 
 
+class nnUNetTrainerLM2Net(nnUNetTrainerLightMamba2Net):
+    """reference: training/nnUNetTrainer/nnUNetTrainerLM2Net.py:16-133 (LM2Net, 2-D; the base trainer's fp16-autocast
+    train_step - the class does not override it; AdamW 1e-4 / wd 5e-2 / eps 1e-5, cosine to 1e-6; deep-supervision scales
+    from get_scales(n_layers=5, min_size=8) :53-74, the same rule as LightMamba2Net's)"""
+    _fp32_step = False
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.early_stop_epoch = 25
+
+    @classmethod
+    def _build(cls, args, kwargs, small):
+        from ..nets.lm2net import get_lm2net_from_plans
+        return _legacy_or_live(lambda *a, **k: get_lm2net_from_plans(*a, small=small, **k), args, kwargs)
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        return nnUNetTrainerLM2Net._build(args, kwargs, False)
+
+
+class nnUNetTrainerLM2NetP(nnUNetTrainerLM2Net):
+    """reference :136-158: the small model (LM2NetP)"""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        return nnUNetTrainerLM2Net._build(args, kwargs, True)
+
+
 def _live_num_in_out(args, kwargs):
     """(num_input_channels, num_output_channels, deep_supervision) from the live calling convention
     (architecture_class_name, arch_init_kwargs, req_import, num_input_channels, num_output_channels, ds) or, for callers
