@@ -46,6 +46,12 @@ def stub_kernel_launches(fill: float = 1.0):
         dgamma.fill_(fill)
         dbeta.fill_(fill)
 
+    def dgrad_normred(pt, dy, w_packed, dx, x_raw, ld_x, nstat, slope, scratch, nred, dgamma, dbeta, *a, **k):
+        # the fused data-gradient launch also writes the affine gradients of the layer below
+        if dgamma is not None:
+            dgamma.fill_(fill)
+            dbeta.fill_(fill)
+
     def stats(x, N, V, Cc, ldx, scratch, gamma=None, beta=None, eps=0.0, nstat=None, sums=None):
         if sums is not None:
             sums.zero_()
@@ -57,7 +63,7 @@ def stub_kernel_launches(fill: float = 1.0):
 
     try:
         for n in ("stem_forward", "conv_tap_forward", "conv_tap_forward_norm", "convT_forward", "convT_dgrad",
-                  "instnorm_lrelu_apply_tab", "head_forward", "head_dgrad"):
+                  "instnorm_lrelu_apply_tab", "instnorm_lrelu_bwd_apply_tab", "head_forward", "head_dgrad"):
             put(n, nop)
         put("instnorm_stats_det", stats)
         put("NormScratch", _Scratch)
@@ -65,6 +71,7 @@ def stub_kernel_launches(fill: float = 1.0):
         put("stem_wgrad", stem_wgrad)
         put("head_wgrad", head_wgrad)
         put("instnorm_lrelu_bwd_tab", norm_bwd)
+        put("conv_tap_dgrad_normred", dgrad_normred)
         put("PackJobTable", _NoPack)
         put("DualPackTable", _NoPack)
         yield

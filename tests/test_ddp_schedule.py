@@ -146,5 +146,7 @@ def test_recording_reducer_single_process():
     total = sum(p.numel() for p in net.parameters())
     # one mark per conv block (22) + one per decoder / encoder stage (5 + 6)
     assert len(rec.marks) == 22 + 5 + 6 and rec.marks == sorted(rec.marks) and rec.finished == total
-    # backward starts at the full-resolution decoder stage: its second conv block (32 -> 32, + norm + seg head) comes first
-    assert rec.marks[0] == 32 * 32 * 27 + 3 * 32 + 2 * 32 + 2
+    # backward starts at the full-resolution decoder stage: its second conv block (32 -> 32, + norm + seg head) comes first;
+    # round 3: its data-gradient launch also produces the affine gradients (2 x 32) of the block below (fused norm-backward
+    # reductions), which therefore sit in front of the first hand-over mark
+    assert rec.marks[0] == 32 * 32 * 27 + 3 * 32 + 2 * 32 + 2 + 2 * 32
