@@ -11,3 +11,4 @@ This package provides those module paths - one module per reference file name, h
 every one of them re-exports the native implementation; no arithmetic lives here.  Modules of the reference that are
 outside the hot path (planning, preprocessing, data loading, evaluation, image IO, CLI) are deliberately absent.
 """
+__path__ = __import__("pkgutil").extend_path(__path__, __name__)  # a pip-installed distribution of the same name supplies every module this namespace does not define (ADVICE r2)

@@ -129,8 +129,9 @@ def hip_path_ok(rsu, x: torch.Tensor) -> bool:
     if not all(hasattr(u, "conv_s1") and isinstance(u.conv_s1, torch.nn.Conv2d) and supported(u.conv_s1, u.bn_s1)
                for u in units):
         return False
-    if not units[0].bn_s1.training and torch.is_grad_enabled() and x.requires_grad:
-        return False                                             # eval-mode statistics with autograd: torch path
+    if not units[0].bn_s1.training and torch.is_grad_enabled() and \
+            (x.requires_grad or any(p.requires_grad for p in rsu.parameters())):
+        return False      # eval-mode statistics with autograd (frozen-BN fine-tuning, raw-input first block): torch path
     return True
 
 

@@ -143,5 +143,32 @@ def test_namespace_modules_are_import_only():
             for node in tree.body:
                 ok = isinstance(node, (ast.Import, ast.ImportFrom)) or \
                     (isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant)) or \
-                    (isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "__all__")
+                    (isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") in ("__all__", "__path__"))
                 assert ok, (f, ast.dump(node)[:80])
+
+
+def test_namespace_defers_to_an_installed_distribution_for_other_modules(tmp_path):
+    """modules this namespace does not define resolve from a distribution of the same name further down sys.path
+    (pkgutil.extend_path) instead of failing with ModuleNotFoundError; the native classes keep precedence"""
+    import subprocess
+    import sys
+    site = tmp_path / "site"
+    for pkg, sub, mod, body in [("nnunetv2", "", "paths", "nnUNet_raw = 'from-the-installed-package'\n"),
+                                ("nnunetv2", "nets", "only_upstream", "X = 7\n"),
+                                ("dynamic_network_architectures", "building_blocks", "helper", "Y = 9\n")]:
+        d = site / pkg / sub
+        d.mkdir(parents=True, exist_ok=True)
+        for q in (site / pkg, d):
+            (q / "__init__.py").touch()
+        (d / f"{mod}.py").write_text(body)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.append(%r)\n"
+            "import nnunetv2.paths, nnunetv2.nets.only_upstream, dynamic_network_architectures.building_blocks.helper as h\n"
+            "from nnunetv2.nets.m2net import M2Net\n"
+            "import pydoc\n"
+            "cls = pydoc.locate('dynamic_network_architectures.architectures.unet.PlainConvUNet')\n"
+            "print(nnunetv2.paths.nnUNet_raw, nnunetv2.nets.only_upstream.X, h.Y, M2Net.__module__, cls.__module__)\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(site)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["from-the-installed-package", "7", "9", "nnuzoo_amd.nets.m2net",
+                                  "nnuzoo_amd.nets.plain_conv_unet"], out.stdout

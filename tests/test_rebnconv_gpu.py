@@ -102,3 +102,22 @@ def test_rsu4f_hip_vs_torch(hip_lib):
             ye = hip(x)
         yr = ref32(x)
     assert rel(ye.float(), yr) < 1e-2
+
+
+def test_eval_mode_with_trainable_weights_takes_the_torch_path(hip_lib):
+    """eval-mode statistics with autograd ON and an input that does not require grad while the weights do (frozen-BN
+    fine-tuning, the first RSU4F on raw input) must not take the HIP path (its backward supports batch statistics only):
+    forward + backward run through torch and the recorded backend says so"""
+    from nnuzoo_amd import rebnconv
+    from nnuzoo_amd.nets.common2d import RSU4F
+    torch.manual_seed(0)
+    m = RSU4F(32, 16, 32).cuda().eval()
+    x = torch.randn(2, 32, 32, 32, device="cuda")                       # requires_grad False
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert not rebnconv.hip_path_ok(m, x)
+        y = m(x)
+    assert m.backend == "library"
+    y.float().square().mean().backward()                                 # raised RuntimeError inside _RebnConvFn before
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert rebnconv.hip_path_ok(m, x)                                # pure inference keeps the HIP path
