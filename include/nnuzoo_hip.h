@@ -447,7 +447,8 @@ int nnz_selective_scan_backward(const float* u, const float* delta, const float*
 int nnz_window_attention_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out, int B,
                                  int H, int W, int C, int heads, int shift, float scale, void* stream);
 /* backward: dbias_table is WRITTEN (deterministic: fixed-order sums per table entry, fixed-point adds across workgroups);
- * acc = heads * 169 zeroed records of nnz_fxacc_bytes() bytes, counter = one zeroed 32-bit word, both left zero.
+ * acc = heads * 170 zeroed records of nnz_fxacc_bytes() bytes (169 table entries + one ticket record per head), left zero;
+ * counter is unused (may be NULL).
  * bias_index must have the reference's displacement layout index[i][j] = (yi - yj + 6) * 13 + (xi - xj + 6). */
 int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index, const float* dout,
                                   float* dqkv, float* dbias_table, void* acc, void* counter, int B, int H, int W, int C,

@@ -492,11 +492,14 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
     const float t = (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
     fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
   }
-  if (last_workgroup(a.counter, gridDim.x * gridDim.y))
-    for (int e = tid; e < WA_NBIAS * a.heads; e += 256) {
-      const int h = e / WA_NBIAS, bx = e - h * WA_NBIAS;
-      a.dbias[bx * a.heads + h] = (float)fx_take(a.acc, e, (long)a.heads * WA_NBIAS);
-    }
+  // One ticket per HEAD (its counter lives behind the accumulator bank): the head's last workgroup reads its 169 entries -
+  // one take per thread, a single memory round trip.  (One ticket per launch made the last workgroup take all 169 * heads
+  // entries, 16 dependent round trips per thread at 24 heads: a fixed 65 us per launch - tools/bench_window_attention.py
+  // measured 86 us for 48 (window, head) problems as for 600.)
+  const long nrec = (long)a.heads * WA_NBIAS;
+  unsigned* ticket = reinterpret_cast<unsigned*>(a.acc[(long)FX_REP * nrec + head].w);
+  if (last_workgroup(ticket, gridDim.x) && tid < WA_NBIAS)
+    a.dbias[tid * a.heads + head] = (float)fx_take(a.acc, (long)head * WA_NBIAS + tid, nrec);
 }
 
 static int check(const AttnArgs& a) {
@@ -535,13 +538,14 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
   return NNZ_OK;
 }
 
-// acc: heads * 169 zeroed fixed-point records (nnz_fxacc_bytes() each), counter: one zeroed 32-bit word; both left zero.
+// acc: heads * 169 zeroed fixed-point records (nnz_fxacc_bytes() each) followed by `heads` zeroed 32-byte ticket records
+// (i.e. at least heads * 170 records of nnz_fxacc_bytes()); all left zero.  `counter` is unused (kept in the signature).
 // dbias_table is WRITTEN (no zero fill needed) and bit-identical run to run.
 extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index,
                                              const float* dout, float* dqkv, float* dbias_table, void* acc, void* counter,
                                              int B, int H, int W, int C, int heads, int shift, float scale, void* stream) {
   using namespace nnz;
-  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table || !acc || !counter) return NNZ_EINVAL;
+  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table || !acc) return NNZ_EINVAL;
   AttnArgs a = {};
   a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.dout = dout; a.dqkv = dqkv; a.dbias = dbias_table;
   a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;

@@ -64,7 +64,8 @@ class WindowAttentionCore(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dtable = torch.empty_like(table)
         from .hip_ops import det_scratch
-        sc = det_scratch(qkv.device, 169 * heads)     # fixed-point sums of the bias-table gradient (deterministic)
+        # fixed-point sums of the bias-table gradient (deterministic) + one ticket record per head behind them
+        sc = det_scratch(qkv.device, 170 * heads)
         from .hip_ops import TIMER
         # backward: dQ, dK, dV and dP = dO v^T are four more L^2 hd products (the recomputed q k^T is not counted)
         flops = 8.0 * 49 * 49 * (C // heads) * heads * B * (H // 7) * (W // 7)

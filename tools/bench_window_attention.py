@@ -8,7 +8,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nnuzoo_amd.window_attention import window_attention_core
+from nnuzoo_amd._lib import call, ptr, stream_ptr
+from nnuzoo_amd.hip_ops import det_scratch
 
 
 def timeit(fn, reps=20):
@@ -32,13 +33,18 @@ def main():
         B, hd = 2, 32
         C = heads * hd
         nwin = B * (H // 7) ** 2
-        qkv = torch.randn(B, H, H, 3 * C, device="cuda", requires_grad=True)
-        table = (torch.randn(169, heads, device="cuda") * 0.5).requires_grad_(True)
+        qkv = torch.randn(B, H, H, 3 * C, device="cuda")
+        table = torch.randn(169, heads, device="cuda") * 0.5
         dout = torch.randn(B, H, H, C, device="cuda")
+        out, dqkv, dtable = torch.empty_like(dout), torch.empty_like(qkv), torch.empty_like(table)
+        sc = det_scratch(qkv.device, 170 * heads)
         for shift in (0, 3):
-            tf = timeit(lambda: window_attention_core(qkv.detach(), table.detach(), idx, heads, shift, hd ** -0.5))
-            yv = window_attention_core(qkv, table, idx, heads, shift, hd ** -0.5)
-            tb = timeit(lambda: torch.autograd.grad(yv, [qkv, table], dout, retain_graph=True))
+            # the C-ABI entry points directly, 20 launches back to back (through autograd the small shapes are host-bound)
+            tf = timeit(lambda: call("nnz_window_attention_forward", ptr(qkv), ptr(table), ptr(idx), ptr(out), B, H, H, C,
+                                     heads, shift, hd ** -0.5, stream_ptr()))
+            tb = timeit(lambda: call("nnz_window_attention_backward", ptr(qkv), ptr(table), ptr(idx), ptr(dout), ptr(dqkv),
+                                     ptr(dtable), ptr(sc.acc), ptr(sc.counter), B, H, H, C, heads, shift, hd ** -0.5,
+                                     stream_ptr()))
             fl = 4.0 * 49 * 49 * hd * nwin * heads
             by_f = 4.0 * B * H * H * (3 * C + C)
             by_b = 4.0 * B * H * H * (3 * C + C + 3 * C)
