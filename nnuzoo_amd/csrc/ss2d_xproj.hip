@@ -34,29 +34,36 @@ struct XpArgs {
   long tokens_per_wg;
 };
 
+// CPT = outputs per thread: a thread's work is CPT * Di FMAs whatever L is, so the deep levels (Di = 256 ... 512, L = 256 ...
+// 4 096 tokens: 4-64 workgroups) ran ~55 us on pure loop latency (r03_m2net_kernel_histogram: median launch 16 workgroups,
+// 55 us); there the outputs are split into 80 / CPT groups over blockIdx.z - more, shorter threads (x2 is re-read per group
+// from L2).
+template <int CPT>
 __global__ __launch_bounds__(256) void xproj_fwd_kernel(XpArgs a) {
-  __shared__ __attribute__((aligned(16))) float sW[XP_CMAX * XP_DC];  // [c][32 d] of the current chunk
+  __shared__ __attribute__((aligned(16))) float sW[CPT * XP_DC];  // [c][32 d] of the current chunk
   const int sb = blockIdx.y;                 // s * B + b
   const int s = sb / a.B;
+  const int cbase = blockIdx.z * CPT;
+  if (cbase >= a.C2) return;
   const long l = (long)blockIdx.x * 256 + threadIdx.x;
   const bool ok = l < a.L;
   const float* x = a.x2 + (long)sb * a.Di * a.L + (ok ? l : 0);
   const float* W = a.W + (long)s * a.C2 * a.Di;
-  float acc[XP_CMAX];
+  float acc[CPT];
 #pragma unroll
-  for (int c = 0; c < XP_CMAX; ++c) acc[c] = 0.f;
+  for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
   for (int d0 = 0; d0 < a.Di; d0 += XP_DC) {
     __syncthreads();
-    for (int e = threadIdx.x; e < XP_CMAX * XP_DC; e += 256) {
+    for (int e = threadIdx.x; e < CPT * XP_DC; e += 256) {
       const int c = e / XP_DC, d = e % XP_DC;
-      sW[e] = c < a.C2 ? W[(long)c * a.Di + d0 + d] : 0.f;
+      sW[e] = cbase + c < a.C2 ? W[(long)(cbase + c) * a.Di + d0 + d] : 0.f;
     }
     float xv[XP_DC];
 #pragma unroll
     for (int d = 0; d < XP_DC; ++d) xv[d] = ok ? x[(long)(d0 + d) * a.L] : 0.f;
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < XP_CMAX; ++c) {
+    for (int c = 0; c < CPT; ++c) {
 #pragma unroll
       for (int d4 = 0; d4 < XP_DC; d4 += 4) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(sW + c * XP_DC + d4);  // wave-uniform address: broadcast
@@ -67,8 +74,8 @@ __global__ __launch_bounds__(256) void xproj_fwd_kernel(XpArgs a) {
   if (ok) {
     float* P = a.P + (long)sb * a.C2 * a.L + l;
 #pragma unroll
-    for (int c = 0; c < XP_CMAX; ++c)
-      if (c < a.C2) P[(long)c * a.L] = acc[c];
+    for (int c = 0; c < CPT; ++c)
+      if (cbase + c < a.C2) P[(long)(cbase + c) * a.L] = acc[c];
   }
 }
 
@@ -87,7 +94,9 @@ __global__ __launch_bounds__(256) void xproj_bwd_x_kernel(XpArgs a) {
   const float* du0 = a.du + (((long)b * 4 + s) * a.Di) * a.L + (ok ? l : 0);
   const float* du1 = a.du + (((long)b * 4 + s + 2) * a.Di) * a.L + (ok ? l : 0);
   float* dx = a.dx2 + (long)sb * a.Di * a.L + l;
-  for (int d0 = 0; d0 < a.Di; d0 += XP_DC) {
+  // blockIdx.z = a slice of the Di output channels (the deep levels: few tokens, many channels - see xproj_fwd_kernel)
+  const int dper = a.Di / gridDim.z;
+  for (int d0 = blockIdx.z * dper; d0 < (blockIdx.z + 1) * dper; d0 += XP_DC) {
     __syncthreads();
     for (int e = threadIdx.x; e < XP_DC * XP_CMAX; e += 256) {
       const int c = e / XP_DC, d = e % XP_DC;     // read W[c][d0 + d] with d fastest (coalesced), store transposed
@@ -199,7 +208,18 @@ extern "C" int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P,
   if (!x2 || !W || !P || !xp_shape_ok(B, Di, C2, L)) return NNZ_EINVAL;
   XpArgs a = {};
   a.x2 = x2; a.W = W; a.P = P; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
-  NNZ_LAUNCH(xproj_fwd_kernel, dim3((unsigned)((L + 255) / 256), 2 * B), dim3(256), 0, (hipStream_t)stream, a);
+  // output groups until the launch has ~256 workgroups
+  const long base_wgs = ((L + 255) / 256) * 2 * B;
+  const dim3 g1((unsigned)((L + 255) / 256), 2 * B, 1);
+  if (base_wgs >= 128) {
+    NNZ_LAUNCH(xproj_fwd_kernel<XP_CMAX>, g1, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (base_wgs >= 64) {
+    NNZ_LAUNCH(xproj_fwd_kernel<40>, dim3(g1.x, g1.y, (C2 + 39) / 40), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (base_wgs >= 32) {
+    NNZ_LAUNCH(xproj_fwd_kernel<20>, dim3(g1.x, g1.y, (C2 + 19) / 20), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    NNZ_LAUNCH(xproj_fwd_kernel<10>, dim3(g1.x, g1.y, (C2 + 9) / 10), dim3(256), 0, (hipStream_t)stream, a);
+  }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -210,7 +230,11 @@ extern "C" int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const 
   if (!dP || !W || !du || !dx2 || !xp_shape_ok(B, Di, C2, L)) return NNZ_EINVAL;
   XpArgs a = {};
   a.dP = dP; a.W = W; a.du = du; a.dx2 = dx2; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
-  NNZ_LAUNCH(xproj_bwd_x_kernel, dim3((unsigned)((L + 255) / 256), 2 * B), dim3(256), 0, (hipStream_t)stream, a);
+  // channel slices (multiples of the 32-channel chunk) until the launch has ~256 workgroups
+  const long base_wgs = ((L + 255) / 256) * 2 * B;
+  int slices = 1;
+  while (slices < 16 && base_wgs * slices < 256 && (Di / XP_DC) % (slices * 2) == 0) slices *= 2;
+  NNZ_LAUNCH(xproj_bwd_x_kernel, dim3((unsigned)((L + 255) / 256), 2 * B, slices), dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -131,7 +131,10 @@ def test_layout_kernels(hip_lib):
     assert torch.allclose(dx, ref, rtol=1e-6, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,Di,R,L", [(2, 32, 1, 4096), (1, 64, 2, 1000), (2, 128, 4, 640), (1, 256, 8, 192)])
+@pytest.mark.parametrize("B,Di,R,L", [(2, 32, 1, 4096), (1, 64, 2, 1000), (2, 128, 4, 640), (1, 256, 8, 192),
+                                      # round 3: every output-group / channel-slice variant of the small-token launches
+                                      (2, 32, 1, 2048), (2, 32, 1, 16384), (2, 512, 8, 256), (2, 256, 8, 1024),
+                                      (2, 96, 3, 64)])
 def test_xproj_kernels_vs_einsum(hip_lib, B, Di, R, L):
     """csrc/ss2d_xproj.hip against the einsums they replace (fp32): projection, its input gradient with the scans' own
     input gradients folded in, and the weight gradient (token contraction); ragged L for the lane-per-token kernels"""
