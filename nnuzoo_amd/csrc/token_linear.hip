@@ -44,19 +44,37 @@ __global__ __launch_bounds__(256) void tl_fwd_kernel(TlArgs a) {
   const int l31 = lane & 31, hh = lane >> 5;
 
   // ---- stage A (fp32 master -> fp16 fragments) -------------------------------------------------------------------
-  for (int e = tid; e < Mo * Kr; e += 256) {
-    int m, kk;
-    float v = 0.f;
-    if (!a.transposed) {
-      m = e / Kr; kk = e % Kr;                       // W[m][kk], kk contiguous
-      if (m < a.Mo_real) v = a.W[(long)m * Kr + kk];
-    } else {
-      kk = e / Mo; m = e % Mo;                       // W[kk][m], m contiguous
-      if (m < a.Mo_real) v = a.W[(long)kk * a.Mo_real + m];
-    }
+  // 16-byte global loads (four consecutive elements of the contiguous axis) - the element-by-element version made this
+  // prologue 59 us for the 256 x 128 / 128 x 256 weights of the deep levels, whatever the token count
+  // (profiles/r03_m2net_kernel_histogram.txt: tl_fwd_kernel<8, 8> / <4, 16> flat at 57-68 us for 16-256 workgroups)
+  auto put = [&](int m, int kk, float v) {
     const int mb = m >> 5, row = m & 31, ks = kk >> 4, k16 = kk & 15;
     const int half = (k16 >> 3) ^ ((row >> 4) & 1);
     *reinterpret_cast<f16*>(sA + ((mb * KS + ks) * 32 + row) * 32 + half * 16 + (k16 & 7) * 2) = (f16)v;
+  };
+  if (!a.transposed) {
+    for (int e4 = tid; e4 < Mo * Kr / 4; e4 += 256) {
+      const int m = e4 / (Kr / 4), kk = (e4 % (Kr / 4)) * 4;     // W[m][kk .. kk + 3], kk contiguous
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.Mo_real) v = *reinterpret_cast<const f32x4*>(a.W + (long)m * Kr + kk);
+      const int mb = m >> 5, row = m & 31, ks = kk >> 4, k16 = kk & 15;
+      const int half = (k16 >> 3) ^ ((row >> 4) & 1);
+      const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+      *reinterpret_cast<f16x4*>(sA + ((mb * KS + ks) * 32 + row) * 32 + half * 16 + (k16 & 7) * 2) = h;
+    }
+  } else if ((a.Mo_real & 3) == 0) {
+    for (int e4 = tid; e4 < Mo * Kr / 4; e4 += 256) {
+      const int kk = e4 / (Mo / 4), m = (e4 % (Mo / 4)) * 4;     // W[kk][m .. m + 3], m contiguous
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.Mo_real) v = *reinterpret_cast<const f32x4*>(a.W + (long)kk * a.Mo_real + m);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) put(m + q, kk, v[q]);
+    }
+  } else {
+    for (int e = tid; e < Mo * Kr; e += 256) {
+      const int kk = e / Mo, m = e % Mo;
+      put(m, kk, m < a.Mo_real ? a.W[(long)kk * a.Mo_real + m] : 0.f);
+    }
   }
   __syncthreads();
   const int a_lane = l31 * 32 + ((hh ^ ((l31 >> 4) & 1)) << 4);
