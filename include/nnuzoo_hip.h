@@ -229,10 +229,13 @@ int nnz_downsample_nearest_i16(const short* src, short* dst, long nc, int id, in
  *   backward_x  dx2[s][b][d][l] = sum_c W[s][c][d] dP[s][b][c][l] + du[b][s][d][l] + du[b][s+2][d][l]
  *   backward_w  dW[s][c][d]    += sum_{b,l} dP[s][b][c][l] x2[s][b][d][l]     (fp32, caller zeroes; L % 64 == 0 and
  *                                                                              ceil8(C2)/8 * Di/8 <= 256, else -22) */
-int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P, int B, int Di, int C2, long L, void* stream);
+/* cp: 0 = W (dW) is [2][C2][Di]; > 0 = W (dW) is the module's own x_proj_weight layout [4][cp][Di], C2 = 2 cp (direction
+ * k = s + 2 j holds rows [j cp, (j + 1) cp) of source s) - no stacked copy of the weight / un-stacking copy of its gradient */
+int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P, int B, int Di, int C2, long L, int cp, void* stream);
 int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const float* du, float* dx2, int B, int Di, int C2,
-                              long L, void* stream);
-int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L, void* stream);
+                              long L, int cp, void* stream);
+int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L, int cp,
+                              void* stream);
 
 /* ---- token-major Linear layers with many tokens and few features (VSS / SSND in_proj, out_proj, patch merge / expand:
  * /root/reference/nnunetv2/nets/m2net.py:97,103,258,300) under the autocast step: fp16 activations, fp32 master weight

@@ -107,9 +107,9 @@ SIGNATURES = {
     "nnz_crop_pad_f32": [_vp, _ip, _ip, _ip, _fp, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_crop_pad_i16": [_vp, _ip, _ip, _ip, _fp, _i, _i, _i, _i, _i, _i, _vp],
     "nnz_downsample_nearest_i16": [_fp, _fp, _l, _i, _i, _i, _i, _i, _i, _vp],
-    "nnz_ss2d_xproj_forward": [_fp, _fp, _fp, _i, _i, _i, _l, _vp],
-    "nnz_ss2d_xproj_backward_x": [_fp, _fp, _fp, _fp, _i, _i, _i, _l, _vp],
-    "nnz_ss2d_xproj_backward_w": [_fp, _fp, _fp, _i, _i, _i, _l, _vp],
+    "nnz_ss2d_xproj_forward": [_fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
+    "nnz_ss2d_xproj_backward_x": [_fp, _fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
+    "nnz_ss2d_xproj_backward_w": [_fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
     "nnz_token_linear_forward": [_vp, _fp, _fp, _vp, _l, _i, _i, _i, _vp],
     "nnz_token_linear_supported": [_i, _i],
     "nnz_dense32_forward": [_fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp],

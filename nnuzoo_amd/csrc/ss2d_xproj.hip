@@ -32,7 +32,17 @@ struct XpArgs {
   int B, Di, C2;
   long L;
   long tokens_per_wg;
+  // Cp > 0: W / dW are the module's own x_proj_weight layout [K = 4][Cp][Di] (direction k = s + 2 j holds rows
+  // [j Cp, (j + 1) Cp) of source s's stacked matrix, C2 = 2 Cp) - no stacked copy of the weight per call, no un-stacking
+  // copy of its gradient; Cp == 0: W / dW are [2][C2][Di]
+  int Cp;
 };
+
+// row c2 of source s's projection matrix
+__device__ __forceinline__ long xp_row(const XpArgs& a, int s, int c2) {
+  if (a.Cp > 0) return ((long)(s + 2 * (c2 / a.Cp)) * a.Cp + c2 % a.Cp) * a.Di;
+  return ((long)s * a.C2 + c2) * a.Di;
+}
 
 // CPT = outputs per thread: a thread's work is CPT * Di FMAs whatever L is, so the deep levels (Di = 256 ... 512, L = 256 ...
 // 4 096 tokens: 4-64 workgroups) ran ~55 us on pure loop latency (r03_m2net_kernel_histogram: median launch 16 workgroups,
@@ -48,7 +58,6 @@ __global__ __launch_bounds__(256) void xproj_fwd_kernel(XpArgs a) {
   const long l = (long)blockIdx.x * 256 + threadIdx.x;
   const bool ok = l < a.L;
   const float* x = a.x2 + (long)sb * a.Di * a.L + (ok ? l : 0);
-  const float* W = a.W + (long)s * a.C2 * a.Di;
   float acc[CPT];
 #pragma unroll
   for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256) void xproj_fwd_kernel(XpArgs a) {
     __syncthreads();
     for (int e = threadIdx.x; e < CPT * XP_DC; e += 256) {
       const int c = e / XP_DC, d = e % XP_DC;
-      sW[e] = cbase + c < a.C2 ? W[(long)(cbase + c) * a.Di + d0 + d] : 0.f;
+      sW[e] = cbase + c < a.C2 ? a.W[xp_row(a, s, cbase + c) + d0 + d] : 0.f;
     }
     float xv[XP_DC];
 #pragma unroll
@@ -86,7 +95,6 @@ __global__ __launch_bounds__(256) void xproj_bwd_x_kernel(XpArgs a) {
   const long l = (long)blockIdx.x * 256 + threadIdx.x;
   const bool ok = l < a.L;
   const float* dP = a.dP + (long)sb * a.C2 * a.L + (ok ? l : 0);
-  const float* W = a.W + (long)s * a.C2 * a.Di;
   float g[XP_CMAX];
 #pragma unroll
   for (int c = 0; c < XP_CMAX; ++c) g[c] = (ok && c < a.C2) ? dP[(long)c * a.L] : 0.f;
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256) void xproj_bwd_x_kernel(XpArgs a) {
     __syncthreads();
     for (int e = threadIdx.x; e < XP_DC * XP_CMAX; e += 256) {
       const int c = e / XP_DC, d = e % XP_DC;     // read W[c][d0 + d] with d fastest (coalesced), store transposed
-      sWt[d * XP_CMAX + c] = c < a.C2 ? W[(long)c * a.Di + d0 + d] : 0.f;
+      sWt[d * XP_CMAX + c] = c < a.C2 ? a.W[xp_row(a, s, c) + d0 + d] : 0.f;
     }
     __syncthreads();
 #pragma unroll 4
@@ -188,11 +196,10 @@ __global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) {
       for (int j = 0; j < 8; ++j) sred[(long)ts * C2p * a.Di + (c0 + i) * a.Di + d0 + j] = acc[i][j];
   }
   __syncthreads();
-  float* dW = a.dW + (long)s * a.C2 * a.Di;
   for (int e = tid; e < a.C2 * a.Di; e += 256) {
     float v = 0.f;
     for (int q = 0; q < TSL; ++q) v += sred[(long)q * C2p * a.Di + e];
-    atomicAdd(dW + e, v);
+    atomicAdd(a.dW + xp_row(a, s, e / a.Di) + e % a.Di, v);
   }
 }
 
@@ -202,12 +209,13 @@ static bool xp_shape_ok(int B, int Di, int C2, long L) {
 
 }  // namespace nnz
 
-extern "C" int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P, int B, int Di, int C2, long L,
+// cp: 0 = W is [2][C2][Di]; > 0 = W is the module's [4][cp][Di] x_proj_weight (C2 must be 2 * cp), see XpArgs::Cp
+extern "C" int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P, int B, int Di, int C2, long L, int cp,
                                       void* stream) {
   using namespace nnz;
-  if (!x2 || !W || !P || !xp_shape_ok(B, Di, C2, L)) return NNZ_EINVAL;
+  if (!x2 || !W || !P || !xp_shape_ok(B, Di, C2, L) || cp < 0 || (cp > 0 && 2 * cp != C2)) return NNZ_EINVAL;
   XpArgs a = {};
-  a.x2 = x2; a.W = W; a.P = P; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
+  a.x2 = x2; a.W = W; a.P = P; a.B = B; a.Di = Di; a.C2 = C2; a.L = L; a.Cp = cp;
   // output groups until the launch has ~256 workgroups
   const long base_wgs = ((L + 255) / 256) * 2 * B;
   const dim3 g1((unsigned)((L + 255) / 256), 2 * B, 1);
@@ -225,11 +233,11 @@ extern "C" int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P,
 }
 
 extern "C" int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const float* du, float* dx2, int B, int Di,
-                                         int C2, long L, void* stream) {
+                                         int C2, long L, int cp, void* stream) {
   using namespace nnz;
-  if (!dP || !W || !du || !dx2 || !xp_shape_ok(B, Di, C2, L)) return NNZ_EINVAL;
+  if (!dP || !W || !du || !dx2 || !xp_shape_ok(B, Di, C2, L) || cp < 0 || (cp > 0 && 2 * cp != C2)) return NNZ_EINVAL;
   XpArgs a = {};
-  a.dP = dP; a.W = W; a.du = du; a.dx2 = dx2; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
+  a.dP = dP; a.W = W; a.du = du; a.dx2 = dx2; a.B = B; a.Di = Di; a.C2 = C2; a.L = L; a.Cp = cp;
   // channel slices (multiples of the 32-channel chunk) until the launch has ~256 workgroups
   const long base_wgs = ((L + 255) / 256) * 2 * B;
   int slices = 1;
@@ -242,15 +250,16 @@ extern "C" int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const 
 // dW[2][C2][Di] (pre-zeroed, fp32) += per-source token contraction.  Needs L % 64 == 0 and (ceil8(C2)/8)(Di/8) <= 256;
 // returns -22 otherwise (the caller keeps the library path for those shapes).
 extern "C" int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L,
-                                         void* stream) {
+                                         int cp, void* stream) {
   using namespace nnz;
-  if (!dP || !x2 || !dW || !xp_shape_ok(B, Di, C2, L) || (L % XPW_TOK)) return NNZ_EINVAL;
+  if (!dP || !x2 || !dW || !xp_shape_ok(B, Di, C2, L) || (L % XPW_TOK) || cp < 0 || (cp > 0 && 2 * cp != C2))
+    return NNZ_EINVAL;
   const int C2p = (C2 + 7) & ~7;
   const int nbk = (C2p >> 3) * (Di >> 3);
   if (nbk > 256) return NNZ_EINVAL;
   const int TSL = 256 / nbk;
   XpArgs a = {};
-  a.dP = dP; a.x2 = x2; a.dW = dW; a.B = B; a.Di = Di; a.C2 = C2; a.L = L;
+  a.dP = dP; a.x2 = x2; a.dW = dW; a.B = B; a.Di = Di; a.C2 = C2; a.L = L; a.Cp = cp;
   const long T = (long)B * L;
   long tpw = (T + 255) / 256;                              // ~256 workgroups per source (512 in all)
   tpw = (tpw + XPW_TOK - 1) / XPW_TOK * XPW_TOK;

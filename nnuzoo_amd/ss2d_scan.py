@@ -121,11 +121,14 @@ class _SS2DCrossScan(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=x2.device)
         with torch.autocast("cuda", enabled=False):
             # direction k = s + 2j  ->  rows [j*Cp, (j+1)*Cp) of source s's stacked projection weight
-            Wst = x_proj_weight.detach().float().view(2, 2, Cp, Di).transpose(0, 1).reshape(2, 1, 2 * Cp, Di)
             if _xproj_ok(Di, 2 * Cp):
-                P = torch.empty((2, B, 2 * Cp, L), **f32)                        # csrc/ss2d_xproj.hip: lanes = tokens
-                call("nnz_ss2d_xproj_forward", ptr(x2), ptr(Wst), ptr(P), B, Di, 2 * Cp, L, stream_ptr())
+                # csrc/ss2d_xproj.hip: lanes = tokens; the kernels address the module's [4][Cp][Di] weight themselves (cp
+                # argument) - no stacked copy per call, no un-stacking copy of its gradient
+                Wst = x_proj_weight.detach().float().contiguous()
+                P = torch.empty((2, B, 2 * Cp, L), **f32)
+                call("nnz_ss2d_xproj_forward", ptr(x2), ptr(Wst), ptr(P), B, Di, 2 * Cp, L, Cp, stream_ptr())
             else:
+                Wst = x_proj_weight.detach().float().view(2, 2, Cp, Di).transpose(0, 1).reshape(2, 1, 2 * Cp, Di)
                 P = torch.matmul(Wst, x2)                                        # (2, B, 2Cp, L)
             A = A_logs.detach().float().contiguous()                             # A_log; the kernels use -exp(A_log)
             Wdt = dt_projs_weight.detach().float().reshape(K * Di, R).contiguous()
@@ -172,17 +175,17 @@ class _SS2DCrossScan(torch.autograd.Function):
             if _xproj_ok(Di, 2 * Cp):
                 # W^T dP + the scans' own input gradients of the source's two directions, one pass (ss2d_xproj.hip)
                 dx2 = torch.empty((2, B, Di, L), **f32)
-                call("nnz_ss2d_xproj_backward_x", ptr(dP), ptr(Wst), ptr(du), ptr(dx2), B, Di, 2 * Cp, L, stream_ptr())
+                call("nnz_ss2d_xproj_backward_x", ptr(dP), ptr(Wst), ptr(du), ptr(dx2), B, Di, 2 * Cp, L, Cp, stream_ptr())
             else:
                 dx2 = torch.matmul(Wst.transpose(-1, -2), dP)                    # (2, B, Di, L)
                 # + the scans' own input gradients: direction k = 2j + s belongs to source s
                 dx2 += du.view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
             if _xproj_ok(Di, 2 * Cp) and L % 64 == 0 and ((2 * Cp + 7) // 8) * (Di // 8) <= 256:
-                dWst = torch.zeros((2, 2 * Cp, Di), **f32)
-                call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(dWst), B, Di, 2 * Cp, L, stream_ptr())
+                d_xproj = torch.zeros((K, Cp, Di), **f32)                        # written in the module's layout
+                call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(d_xproj), B, Di, 2 * Cp, L, Cp, stream_ptr())
             else:
                 dWst = _proj_weight_grad(dP, x2)                                 # (2, 2Cp, Di)
-            d_xproj = dWst.view(2, 2, Cp, Di).transpose(0, 1).reshape(K, Cp, Di)
+                d_xproj = dWst.view(2, 2, Cp, Di).transpose(0, 1).reshape(K, Cp, Di)
         return dx2, None, d_xproj, dWdt.view(K, Di, R), dbias.view(K, Di), dA, dD    # dA is dA_log (a_is_log)
 
 

@@ -24,7 +24,7 @@ from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 MIN_TOKENS = 65536
-HIP_MIN_TOKENS = 1024   # below this the call is launch-bound either way
+HIP_MIN_TOKENS = int(os.environ.get("NNZ_TL_MIN_TOKENS", "1024"))   # below this the call is launch-bound either way (A/B: env)
 USE_HIP_KERNELS = os.environ.get("NNZ_TOKEN_LINEAR", "1") != "0"   # A/B switch for measurements
 MAX_FEATURES = 256
 

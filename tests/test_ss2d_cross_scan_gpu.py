@@ -137,24 +137,30 @@ def test_layout_kernels(hip_lib):
                                       (2, 96, 3, 64)])
 def test_xproj_kernels_vs_einsum(hip_lib, B, Di, R, L):
     """csrc/ss2d_xproj.hip against the einsums they replace (fp32): projection, its input gradient with the scans' own
-    input gradients folded in, and the weight gradient (token contraction); ragged L for the lane-per-token kernels"""
+    input gradients folded in, and the weight gradient (token contraction); ragged L for the lane-per-token kernels; both
+    weight layouts: the stacked [2][C2][Di] matrix (cp = 0) and the module's own [4][Cp][Di] parameter (cp = Cp), where
+    direction k = s + 2 j holds rows [j Cp, (j + 1) Cp) of source s"""
     from nnuzoo_amd._lib import call, ptr, stream_ptr
     g = torch.Generator().manual_seed(B * Di + L)
-    C2 = 2 * (R + 32)
+    Cp = R + 32
+    C2 = 2 * Cp
     x2 = torch.randn(2, B, Di, L, generator=g).cuda()
     W = (torch.randn(2, C2, Di, generator=g) / Di ** 0.5).cuda()
+    Wk = W.view(2, 2, Cp, Di).transpose(0, 1).reshape(4, Cp, Di).contiguous()      # module layout of the same matrix
     dP = torch.randn(2, B, C2, L, generator=g).cuda()
     du = torch.randn(B, 4, Di, L, generator=g).cuda()
-    P = torch.empty(2, B, C2, L, device="cuda")
-    call("nnz_ss2d_xproj_forward", ptr(x2), ptr(W), ptr(P), B, Di, C2, L, stream_ptr())
     ref = torch.einsum("scd,sbdl->sbcl", W.double(), x2.double())
-    assert torch.allclose(P.double(), ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())
-    dx = torch.empty_like(x2)
-    call("nnz_ss2d_xproj_backward_x", ptr(dP), ptr(W), ptr(du), ptr(dx), B, Di, C2, L, stream_ptr())
     rdx = torch.einsum("scd,sbcl->sbdl", W.double(), dP.double()) + du.double().view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
-    assert torch.allclose(dx.double(), rdx, rtol=1e-5, atol=1e-5 * rdx.abs().max().item())
-    if L % 64 == 0 and ((C2 + 7) // 8) * (Di // 8) <= 256:
-        dW = torch.zeros(2, C2, Di, device="cuda")
-        call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(dW), B, Di, C2, L, stream_ptr())
-        rdw = torch.einsum("sbcl,sbdl->scd", dP.double(), x2.double())
-        assert torch.allclose(dW.double(), rdw, rtol=1e-4, atol=1e-5 * rdw.abs().max().item())
+    rdw = torch.einsum("sbcl,sbdl->scd", dP.double(), x2.double())
+    for cp, Wt in ((0, W), (Cp, Wk)):
+        P = torch.full((2, B, C2, L), float("nan"), device="cuda")
+        call("nnz_ss2d_xproj_forward", ptr(x2), ptr(Wt), ptr(P), B, Di, C2, L, cp, stream_ptr())
+        assert torch.allclose(P.double(), ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())
+        dx = torch.full_like(x2, float("nan"))
+        call("nnz_ss2d_xproj_backward_x", ptr(dP), ptr(Wt), ptr(du), ptr(dx), B, Di, C2, L, cp, stream_ptr())
+        assert torch.allclose(dx.double(), rdx, rtol=1e-5, atol=1e-5 * rdx.abs().max().item())
+        if L % 64 == 0 and ((C2 + 7) // 8) * (Di // 8) <= 256:
+            dW = torch.zeros_like(Wt)
+            call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(dW), B, Di, C2, L, cp, stream_ptr())
+            got = dW if cp == 0 else dW.view(2, 2, Cp, Di).transpose(0, 1).reshape(2, C2, Di)
+            assert torch.allclose(got.double(), rdw, rtol=1e-4, atol=1e-5 * rdw.abs().max().item())
