@@ -111,8 +111,8 @@ def test_eval_mode_with_trainable_weights_takes_the_torch_path(hip_lib):
     from nnuzoo_amd import rebnconv
     from nnuzoo_amd.nets.common2d import RSU4F
     torch.manual_seed(0)
-    m = RSU4F(32, 16, 32).cuda().eval()
-    x = torch.randn(2, 32, 32, 32, device="cuda")                       # requires_grad False
+    m = RSU4F(64, 32, 64).cuda().eval()                                 # channel counts the conv_box path takes
+    x = torch.randn(2, 64, 32, 32, device="cuda")                       # requires_grad False
     with torch.autocast("cuda", dtype=torch.float16):
         assert not rebnconv.hip_path_ok(m, x)
         y = m(x)
