@@ -502,6 +502,227 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
     a.dbias[tid * a.heads + head] = (float)fx_take(a.acc, (long)head * WA_NBIAS + tid, nrec);
 }
 
+// The same backward with TWO waves per window (launches of fewer (window, head) problems than SIMDs: 120 of the 144 launches of
+// a SwT2Net pass sit on the latency of one window's chain - tools/bench_window_attention.py: 62-68 us for 48 ... 600
+// problems).  Wave pair p = wave >> 1 owns a window; role = wave & 1 stages half of the images (Q, K / V, dO), takes query
+// tile `role` in pass A and key tile `role` in pass B (each with its own dS tile).  The pair meets at workgroup barriers
+// (both pairs run the same number of iterations; a pair without a window idles through them).
+constexpr int WA_PAIR_FLOATS = 4 * WA_IMG + 2 * WA_L * WA_DSP + 3 * 64 + 2 * 64;  // sq sk sv sdo | sds[2] | srow[3][64] | stok, sreg
+
+__global__ __launch_bounds__(256) void win_attn_bwd_pair_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sbT = smem;                                   // [49][64]
+  float* sdb_all = smem + WA_L * WA_BP;                // [4 waves][176]
+  float* wbase = sdb_all + 4 * 176;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y;
+  const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
+  const int pair = wave >> 1, role = wave & 1;
+  float* sq = wbase + pair * WA_PAIR_FLOATS;           // Q * scale, K, V, dO images [49][33], shared by the pair
+  float* sk = sq + WA_IMG;
+  float* sv = sk + WA_IMG;
+  float* sdo = sv + WA_IMG;
+  float* sds = sdo + WA_IMG + role * WA_L * WA_DSP;    // dS[query][key - 32 role]: this wave's key tile
+  float* srow = sdo + WA_IMG + 2 * WA_L * WA_DSP;      // [3][64]: row max, 1 / sum, delta per query
+  int* stok = reinterpret_cast<int*>(srow + 3 * 64);
+  int* sreg = stok + 64;
+  float* sdb = sdb_all + wave * 176;
+  const int qo = head * hd, ko = a.C + head * hd, vo = 2 * a.C + head * hd;
+  stage_bias(a, head, sbT, tid, 256);
+  // the wave's share of the bias-table gradient: lane owns table entries lane, lane + 64, lane + 128
+  float db_acc[3] = {0.f, 0.f, 0.f};
+  __syncthreads();
+  const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
+  const int iters = (a.wpb + 1) / 2;
+  for (int it = 0; it < iters; ++it) {
+    const int win = blockIdx.x * a.wpb + pair + 2 * it;
+    const bool live = win < w_end;
+    lds_barrier();   // the previous window's readers are done with the images / stok / sreg
+    if (live && role == 0) {
+      int base = 0, region = 0;
+      if (lane < WA_L) token_map(a, win, lane, base, region);
+      stok[lane] = base;
+      sreg[lane] = region;
+    }
+    lds_barrier();
+    if (live) {
+      if (role == 0) {
+        stage_image(a.qkv, C3, qo, hd, stok, a.scale, sq, lane);
+        stage_image(a.qkv, C3, ko, hd, stok, 1.f, sk, lane);
+      } else {
+        stage_image(a.qkv, C3, vo, hd, stok, 1.f, sv, lane);
+        stage_image(a.dout, a.C, qo, hd, stok, 1.f, sdo, lane);
+      }
+    }
+    lds_barrier();
+
+    // ---------------- pass A: keys on rows, queries on lanes --------------------------------------------------------
+    if (live) {
+      const int tq = role;
+      float qv[16], gv[16];
+      load_rows(sq, hd, tq, l31, hh, qv);
+      load_rows(sdo, hd, tq, l31, hh, gv);
+      f32x16 s[2], dp[2];
+      float m, inv;
+      {
+        float kv[2][16];
+        load_rows(sk, hd, 0, l31, hh, kv[0]);
+        load_rows(sk, hd, 1, l31, hh, kv[1]);
+        scores_T(kv, qv, steps, sbT, sreg, a.shift, tq, l31, hh, s, m, inv);  // s = P^T
+      }
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk) {
+        float vv[16];
+        load_rows(sv, hd, tk, l31, hh, vv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[tk][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+          if (st < steps) dp[tk] = mfma_f32(vv[st], gv[st], dp[tk]);  // dP^T[key][query] = sum_c V[key][c] dO[query][c]
+      }
+      float delta = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) delta += s[tk][r] * dp[tk][r];
+      delta += __shfl_xor(delta, 32, 64);
+      const int i = tq * 32 + l31;
+      if (hh == 0) {
+        srow[i] = m;
+        srow[64 + i] = inv;
+        srow[128 + i] = delta;
+      }
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[tk][r] *= (dp[tk][r] - delta);  // dS^T
+      // dQ^T[c][query] = scale * sum_key K[key][c] dS^T[key][query]
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk) {
+        float kc[16];
+        load_cols(sk, hd, tk, l31, hh, kc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = mfma_f32(kc[r], s[tk][r], o);
+      }
+      if (i < WA_L) store_cols(a.dqkv + (long)stok[i] * C3 + qo, o, hh, hd, a.scale);
+    }
+    lds_barrier();  // srow is complete (both query tiles)
+
+    // ---------------- pass B: queries on rows, keys on lanes ---------------------------------------------------------
+    // the row operands with roles swapped: A = Q (rows = queries), B = K (cols = keys); dP: A = dO, B = V
+    if (live) {
+      const int tk = role;
+      f32x16 s[2], dp[2];  // [tq]
+      {
+        float kv[16], vv[16];
+        load_rows(sk, hd, tk, l31, hh, kv);
+        load_rows(sv, hd, tk, l31, hh, vv);
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+          float qr[16], gr[16];
+          load_rows(sq, hd, tq, l31, hh, qr);
+          load_rows(sdo, hd, tq, l31, hh, gr);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            s[tq][r] = 0.f;
+            dp[tq][r] = 0.f;
+          }
+#pragma unroll
+          for (int st = 0; st < 16; ++st)
+            if (st < steps) {
+              s[tq] = mfma_f32(qr[st], kv[st], s[tq]);
+              dp[tq] = mfma_f32(gr[st], vv[st], dp[tq]);
+            }
+        }
+      }
+      const int j = tk * 32 + l31;
+      const int jc = j < WA_L ? j : WA_L - 1;
+      const int reg_j = a.shift ? sreg[jc] : 0;
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = tq * 32 + crow(r, hh);
+          float pv = 0.f, ds = 0.f;
+          if (i < WA_L && j < WA_L) {
+            float x = s[tq][r] + sbT[j * WA_BP + i];
+            if (a.shift && sreg[i] != reg_j) x += -100.f;
+            pv = __expf(x - srow[i]) * srow[64 + i];
+            ds = pv * (dp[tq][r] - srow[128 + i]);
+          }
+          s[tq][r] = pv;    // P[query][key]
+          dp[tq][r] = ds;   // dS[query][key]
+          if (i < WA_L) sds[i * WA_DSP + l31] = ds;
+        }
+      // dV^T[c][key] = sum_query dO[query][c] P[query][key];  dK^T[c][key] = sum_query Qs[query][c] dS[query][key]
+      f32x16 ov, ok;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ov[r] = 0.f;
+        ok[r] = 0.f;
+      }
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq) {
+        float gc[16], qc[16];
+        load_cols(sdo, hd, tq, l31, hh, gc);
+        load_cols(sq, hd, tq, l31, hh, qc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ov = mfma_f32(gc[r], s[tq][r], ov);
+          ok = mfma_f32(qc[r], dp[tq][r], ok);
+        }
+      }
+      if (j < WA_L) {
+        float* dst = a.dqkv + (long)stok[j] * C3;
+        store_cols(dst + ko, ok, hh, hd, 1.f);
+        store_cols(dst + vo, ov, hh, hd, 1.f);
+      }
+      // bias-table gradient, this key tile's share: every table entry sums its members (i, j) in raster order of i
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int bx = lane + 64 * e;
+        if (bx < WA_NBIAS) {
+          // entry bx = (yi - yj + 6) * 13 + (xi - xj + 6): all (i, j) with that displacement
+          const int dy = bx / 13 - 6, dx = bx % 13 - 6;
+          const int y0 = dy > 0 ? dy : 0, y1 = dy < 0 ? WA_WS + dy : WA_WS;
+          const int x0 = dx > 0 ? dx : 0, x1 = dx < 0 ? WA_WS + dx : WA_WS;
+          float t = 0.f;
+          for (int yi = y0; yi < y1; ++yi)
+            for (int xi = x0; xi < x1; ++xi) {
+              const int i = yi * WA_WS + xi, jj = (yi - dy) * WA_WS + (xi - dx) - 32 * tk;
+              if (jj >= 0 && jj < 32) t += sds[i * WA_DSP + jj];
+            }
+          db_acc[e] += t;
+        }
+      }
+    }
+  }
+  // ---- fold the four waves in wave order, one fixed-point add per table entry and workgroup, last workgroup writes ------
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (lane + 64 * e < WA_NBIAS) sdb[lane + 64 * e] = db_acc[e];
+  __syncthreads();
+  if (tid < WA_NBIAS) {
+    const float t = (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
+    fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
+  }
+  // One ticket per HEAD (its counter lives behind the accumulator bank): the head's last workgroup reads its 169 entries -
+  // one take per thread, a single memory round trip.  (One ticket per launch made the last workgroup take all 169 * heads
+  // entries, 16 dependent round trips per thread at 24 heads: a fixed 65 us per launch - tools/bench_window_attention.py
+  // measured 86 us for 48 (window, head) problems as for 600.)
+  const long nrec = (long)a.heads * WA_NBIAS;
+  unsigned* ticket = reinterpret_cast<unsigned*>(a.acc[(long)FX_REP * nrec + head].w);
+  if (last_workgroup(ticket, gridDim.x) && tid < WA_NBIAS)
+    a.dbias[tid * a.heads + head] = (float)fx_take(a.acc, (long)head * WA_NBIAS + tid, nrec);
+}
+
 static int check(const AttnArgs& a) {
   if (a.B < 1 || a.H % WA_WS || a.W % WA_WS || a.heads < 1 || a.C != a.heads * a.hd || a.hd % 2 || a.hd > 32 ||
       a.hd < 2 || (a.shift != 0 && a.shift != WA_WS / 2) || (long)a.B * a.H * a.W * 3 * a.C >= (1L << 31) * 3)
@@ -553,6 +774,22 @@ extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias
   if (int rc = check(a)) return rc;
   a.nwin = B * (H / WA_WS) * (W / WA_WS);
   a.wpb = windows_per_wg(a.nwin, heads);
+  // fewer (window, head) problems than ~2 per SIMD: two waves per window (win_attn_bwd_pair_kernel)
+  static const int pair_mode = [] { const char* v = getenv("NNZ_WA_PAIR"); return v ? atoi(v) : 1; }();
+  // one pair per window halves the chain (65 -> 39 us measured) but a CU then holds 2 windows instead of 4: take the pairs
+  // when ceil(P / 512) rounds of 39 us beat ceil(P / 1024) rounds of 65 us (P <= 512, or 1025 ... 1536 problems)
+  const long nprob = (long)a.nwin * heads;
+  if (pair_mode && nprob <= 2048 && 3 * ((nprob + 511) / 512) < 5 * ((nprob + 1023) / 1024)) {
+    a.wpb = a.nwin < 2 ? 1 : 2;
+    while (a.wpb < 8 && (long)((a.nwin + 2 * a.wpb - 1) / (2 * a.wpb)) * heads >= 512) a.wpb *= 2;
+    const int ldsp = (WA_L * WA_BP + 4 * 176 + 2 * WA_PAIR_FLOATS) * (int)sizeof(float);
+    static DynLdsCache cachep;
+    hipError_t ep = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_bwd_pair_kernel), ldsp, cachep);
+    if (ep != hipSuccess) return (int)ep;
+    NNZ_LAUNCH(win_attn_bwd_pair_kernel, dim3((a.nwin + a.wpb - 1) / a.wpb, heads), dim3(256), ldsp, (hipStream_t)stream, a);
+    NNZ_LAUNCH_CHECK();
+    return NNZ_OK;
+  }
   const int lds = (WA_L * WA_BP + 4 * 176 + 4 * WA_WAVE_FLOATS) * (int)sizeof(float);
   static DynLdsCache cache;
   hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_bwd_kernel), lds, cache);
