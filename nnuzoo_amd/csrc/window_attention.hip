@@ -507,9 +507,10 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
 // problems).  Wave pair p = wave >> 1 owns a window; role = wave & 1 stages half of the images (Q, K / V, dO), takes query
 // tile `role` in pass A and key tile `role` in pass B (each with its own dS tile).  The pair meets at workgroup barriers
 // (both pairs run the same number of iterations; a pair without a window idles through them).
-constexpr int WA_PAIR_FLOATS = 4 * WA_IMG + 2 * WA_L * WA_DSP + 3 * 64 + 2 * 64;  // sq sk sv sdo | sds[2] | srow[3][64] | stok, sreg
+static_assert(WA_L * WA_DSP <= WA_IMG, "a dS tile must fit the image it replaces");
+constexpr int WA_PAIR_FLOATS = 4 * WA_IMG + 3 * 64 + 2 * 64;  // sq sk sv sdo (sk / sv double as the dS tiles) | srow[3][64] | stok, sreg
 
-__global__ __launch_bounds__(256) void win_attn_bwd_pair_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sbT = smem;                                   // [49][64]
   float* sdb_all = smem + WA_L * WA_BP;                // [4 waves][176]
@@ -525,8 +526,10 @@ __global__ __launch_bounds__(256) void win_attn_bwd_pair_kernel(AttnArgs a) {
   float* sk = sq + WA_IMG;
   float* sv = sk + WA_IMG;
   float* sdo = sv + WA_IMG;
-  float* sds = sdo + WA_IMG + role * WA_L * WA_DSP;    // dS[query][key - 32 role]: this wave's key tile
-  float* srow = sdo + WA_IMG + 2 * WA_L * WA_DSP;      // [3][64]: row max, 1 / sum, delta per query
+  // dS[query][key - 32 role] of this wave's key tile lives ON the K (role 0) / V (role 1) image: both are dead once the pair
+  // has taken its K / V row operands of pass B (barrier below) - 27 KB per pair instead of 40, two workgroups per CU
+  float* sds = role == 0 ? sk : sv;
+  float* srow = sdo + WA_IMG;                          // [3][64]: row max, 1 / sum, delta per query
   int* stok = reinterpret_cast<int*>(srow + 3 * 64);
   int* sreg = stok + 64;
   float* sdb = sdb_all + wave * 176;
@@ -616,13 +619,18 @@ __global__ __launch_bounds__(256) void win_attn_bwd_pair_kernel(AttnArgs a) {
 
     // ---------------- pass B: queries on rows, keys on lanes ---------------------------------------------------------
     // the row operands with roles swapped: A = Q (rows = queries), B = K (cols = keys); dP: A = dO, B = V
+    float kvB[16], vvB[16];
+    if (live) {
+      load_rows(sk, hd, role, l31, hh, kvB);
+      load_rows(sv, hd, role, l31, hh, vvB);
+    }
+    lds_barrier();  // both waves hold their K / V rows: the two images become the dS tiles
     if (live) {
       const int tk = role;
       f32x16 s[2], dp[2];  // [tq]
       {
-        float kv[16], vv[16];
-        load_rows(sk, hd, tk, l31, hh, kv);
-        load_rows(sv, hd, tk, l31, hh, vv);
+        float (&kv)[16] = kvB;
+        float (&vv)[16] = vvB;
 #pragma unroll
         for (int tq = 0; tq < 2; ++tq) {
           float qr[16], gr[16];
@@ -774,14 +782,14 @@ extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias
   if (int rc = check(a)) return rc;
   a.nwin = B * (H / WA_WS) * (W / WA_WS);
   a.wpb = windows_per_wg(a.nwin, heads);
-  // fewer (window, head) problems than ~2 per SIMD: two waves per window (win_attn_bwd_pair_kernel)
+  // two waves per window (win_attn_bwd_pair_kernel) at every size: with the dS tiles on the K / V images a pair needs 27 KB
+  // of LDS, two workgroups = four windows = eight waves fit a CU, and a window's chain is 36-39 us instead of 62-68
+  // (tools/bench_window_attention.py, NNZ_WA_PAIR=0 selects the one-wave kernel: 2 166 problems 207 -> 142 us, 1 200: 137 ->
+  // 96, 600: 67 -> 48, <= 432: 65 -> 37)
   static const int pair_mode = [] { const char* v = getenv("NNZ_WA_PAIR"); return v ? atoi(v) : 1; }();
-  // one pair per window halves the chain (65 -> 39 us measured) but a CU then holds 2 windows instead of 4: take the pairs
-  // when ceil(P / 512) rounds of 39 us beat ceil(P / 1024) rounds of 65 us (P <= 512, or 1025 ... 1536 problems)
-  const long nprob = (long)a.nwin * heads;
-  if (pair_mode && nprob <= 2048 && 3 * ((nprob + 511) / 512) < 5 * ((nprob + 1023) / 1024)) {
+  if (pair_mode) {
     a.wpb = a.nwin < 2 ? 1 : 2;
-    while (a.wpb < 8 && (long)((a.nwin + 2 * a.wpb - 1) / (2 * a.wpb)) * heads >= 512) a.wpb *= 2;
+    while (a.wpb < 8 && (long)((a.nwin + 2 * a.wpb - 1) / (2 * a.wpb)) * heads >= 1024) a.wpb *= 2;
     const int ldsp = (WA_L * WA_BP + 4 * 176 + 2 * WA_PAIR_FLOATS) * (int)sizeof(float);
     static DynLdsCache cachep;
     hipError_t ep = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_bwd_pair_kernel), ldsp, cachep);
