@@ -289,6 +289,71 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// forward with TWO waves per window (see win_attn_bwd_pair_kernel): role 0 stages K, role 1 stages V, each takes one query
+// tile.  Two pairs per workgroup, 14 KB of images per pair.
+__global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sbT = smem;                                      // [49][64]
+  float* wbase = smem + WA_L * WA_BP;                     // per wave: sk, sv images | stok, sreg
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y;
+  const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
+  const int pair = wave >> 1, role = wave & 1;
+  float* sk = wbase + pair * (2 * WA_IMG + 128);
+  float* sv = sk + WA_IMG;
+  int* stok = reinterpret_cast<int*>(sv + WA_IMG);
+  int* sreg = stok + 64;
+  stage_bias(a, head, sbT, tid, 256);
+  __syncthreads();
+  const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
+  const int iters = (a.wpb + 1) / 2;
+  for (int it = 0; it < iters; ++it) {
+    const int win = blockIdx.x * a.wpb + pair + 2 * it;
+    const bool live = win < w_end;
+    lds_barrier();  // the previous window's readers are done with the images / stok / sreg
+    if (live && role == 0) {
+      int base = 0, region = 0;
+      if (lane < WA_L) token_map(a, win, lane, base, region);
+      stok[lane] = base;
+      sreg[lane] = region;
+    }
+    lds_barrier();
+    float qv[16];
+    if (live) {
+      load_rows_global(a.qkv, C3, head * hd, hd, stok, role, l31, hh, a.scale, qv);
+      if (role == 0) stage_image(a.qkv, C3, a.C + head * hd, hd, stok, 1.f, sk, lane);
+      else stage_image(a.qkv, C3, 2 * a.C + head * hd, hd, stok, 1.f, sv, lane);
+    }
+    lds_barrier();
+    if (!live) continue;
+    float kv[2][16];
+    load_rows(sk, hd, 0, l31, hh, kv[0]);
+    load_rows(sk, hd, 1, l31, hh, kv[1]);
+    {
+      const int tq = role;
+      f32x16 p[2];
+      float m, inv;
+      scores_T(kv, qv, steps, sbT, sreg, a.shift, tq, l31, hh, p, m, inv);
+      // O^T[channel][query] = sum_key V[key][channel] P^T[key][query]
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk) {
+        float vc[16];
+        load_cols(sv, hd, tk, l31, hh, vc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = mfma_f32(vc[r], p[tk][r], o);
+      }
+      const int i = tq * 32 + l31;
+      if (i < WA_L) store_cols(a.out + (long)stok[i] * a.C + head * hd, o, hh, hd, 1.f);
+    }
+  }
+}
+
 // backward.  Pass A (transposed orientation, queries on lanes): P^T, dP^T, delta, dS^T -> dQ.
 //            Pass B (queries on rows, keys on lanes): P, dP, dS -> dV, dK, and dS -> the bias-table gradient.
 // Row statistics cross from A to B through LDS.  LDS per workgroup: the head's bias matrix and per wave four operand images,
@@ -757,6 +822,18 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
   if (int rc = check(a)) return rc;
   a.nwin = B * (H / WA_WS) * (W / WA_WS);
+  static const int pair_mode = [] { const char* v = getenv("NNZ_WA_PAIR"); return v ? atoi(v) : 1; }();
+  if (pair_mode) {
+    a.wpb = a.nwin < 2 ? 1 : 2;
+    while (a.wpb < 8 && (long)((a.nwin + 2 * a.wpb - 1) / (2 * a.wpb)) * heads >= 2048) a.wpb *= 2;
+    const int ldsp = (WA_L * WA_BP + 2 * (2 * WA_IMG + 128)) * (int)sizeof(float);
+    static DynLdsCache cachep;
+    hipError_t ep = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_fwd_pair_kernel), ldsp, cachep);
+    if (ep != hipSuccess) return (int)ep;
+    NNZ_LAUNCH(win_attn_fwd_pair_kernel, dim3((a.nwin + a.wpb - 1) / a.wpb, heads), dim3(256), ldsp, (hipStream_t)stream, a);
+    NNZ_LAUNCH_CHECK();
+    return NNZ_OK;
+  }
   a.wpb = windows_per_wg(a.nwin, heads);
   const int lds = (WA_L * WA_BP + 4 * (2 * WA_IMG + 128)) * (int)sizeof(float);
   static DynLdsCache cache;
