@@ -313,6 +313,46 @@ class nnUNetTrainerLM2NetP(nnUNetTrainerLM2Net):
         return nnUNetTrainerLM2Net._build(args, kwargs, True)
 
 
+class nnUNetTrainerLightMUNet(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerLightMUNet.py:14-129 (stand-alone LightMUNet, 2-D or 3-D; fp32 step
+    without autocast / GradScaler :45-63; ONE output, deep supervision off :29, :127-128; Adam lr 1e-4 / wd 1e-5 / eps 1e-5,
+    PolyLR exponent 0.9 :120-124; gradient clipping 12)"""
+    _fp32_step = True
+    _no_miopen = True   # small-channel fp32 convolutions, depthwise 3x3 / 1x1 (see MambaND2Net above)
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.grad_scaler = None
+        self.initial_lr = 1e-4
+        self.weight_decay = 1e-5
+        self.enable_deep_supervision = False
+
+    def _get_deep_supervision_scales(self):
+        return None
+
+    def set_deep_supervision_enabled(self, enabled: bool):
+        pass
+
+    def configure_optimizers(self):
+        from torch.optim import Adam
+        from .lr_scheduler import PolyLRScheduler
+        fused = self.device.type == 'cuda' and os.environ.get("NNZ_FUSED_ADAMW", "1") != "0"
+        optimizer = Adam(self.network.parameters(), lr=self.initial_lr, weight_decay=self.weight_decay, eps=1e-5, fused=fused)
+        return optimizer, PolyLRScheduler(optimizer, self.initial_lr, self.num_epochs, exponent=0.9)
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.lightmunet import LightMUNet
+        num_in, num_out, _ = _live_num_in_out(args, kwargs)
+        cm = next((a for a in list(args) + list(kwargs.values()) if hasattr(a, "patch_size")), None)
+        if cm is None:
+            raise ValueError("nnUNetTrainerLightMUNet.build_network_architecture needs the configuration manager (patch size "
+                             "-> spatial dims)")
+        return LightMUNet(spatial_dims=len(cm.patch_size), init_filters=32, in_channels=num_in, out_channels=num_out,
+                          blocks_down=[1, 2, 2, 4], blocks_up=[1, 1, 1])
+
+
 def _live_num_in_out(args, kwargs):
     """(num_input_channels, num_output_channels, deep_supervision) from the live calling convention
     (architecture_class_name, arch_init_kwargs, req_import, num_input_channels, num_output_channels, ds) or, for callers

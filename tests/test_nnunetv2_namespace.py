@@ -48,6 +48,7 @@ TRAINERS = {
     "nnUNetTrainerUNETR2Net": ("nnUNetTrainerUNETR2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerUNETR2Net"),
     "nnUNetTrainerLightMamba2Net": ("nnUNetTrainerLightMamba2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerLightMamba2Net"),
     "nnUNetTrainerLightMamba2NetP": ("nnUNetTrainerLightMamba2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerLightMamba2NetP"),
+    "nnUNetTrainerLightMUNet": ("nnUNetTrainerLightMUNet", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerLightMUNet"),
     "nnUNetTrainerLM2Net": ("nnUNetTrainerLM2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerLM2Net"),
     "nnUNetTrainerLM2NetP": ("nnUNetTrainerLM2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerLM2NetP"),
     "nnUNetTrainerU2Net": ("nnUNetTrainerU2Net", "nnuzoo_amd.training.zoo_trainers.nnUNetTrainerU2Net"),

@@ -140,7 +140,50 @@ def main():
               "finite", all(bool(torch.isfinite(o).all()) for o in outs), flush=True)
     with open(os.path.join(OUT, "lm2net_manifest.json"), "w") as f:
         json.dump(man, f)
+    light_munet()
+
+
+def light_munet():
+    """nets/LightMUNet.py LightMUNet (the stand-alone net of nnUNetTrainerLightMUNet), 2-D and 3-D, the trainer's
+    configuration (init_filters 32, blocks (1, 2, 2, 4) / (1, 1, 1)): forward + backward (dx, 256 strided samples + L2 norm
+    of every parameter gradient), state_dict manifest"""
+    import nnunetv2.nets.LightMUNet as R
+    man = {}
+    for tag, sd, shape in (("2d", 2, (1, 1, 64, 64)), ("3d", 3, (1, 2, 16, 16, 16))):
+        torch.manual_seed(0)
+        net = R.LightMUNet(spatial_dims=sd, init_filters=32, in_channels=shape[1], out_channels=3,
+                           blocks_down=[1, 2, 2, 4], blocks_up=[1, 1, 1])
+        man[tag] = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+        det_fill(net)
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                if n.endswith("A_log"):
+                    p.copy_(torch.log(1.0 + torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) % 16) * 0.9 + 0.05 * p)
+        net.train()
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(7))
+        xg = x.clone().requires_grad_(True)
+        y = net(xg)
+        j = torch.arange(y.numel(), dtype=torch.float64)
+        ((y * torch.sin(0.37 * j).float().view_as(y)).sum() / y[0, 0].numel()).backward()
+        gd = {"x": x.numpy(), "y": y.detach().numpy(), "dx": xg.grad.numpy()}
+        names = []
+        for k, (n, p) in enumerate(net.named_parameters()):
+            if p.grad is None:
+                continue
+            g = p.grad.reshape(-1)
+            names.append(n)
+            gd[f"g{k}"] = g[::max(1, g.numel() // 256)][:256].numpy()
+            gd[f"n{k}"] = np.array(float(g.double().norm()))
+        np.savez_compressed(os.path.join(OUT, f"net_LightMUNet_{tag}.npz"), names=np.array(names), **gd)
+        print("LightMUNet", tag, "params", sum(p.numel() for p in net.parameters()), "out", tuple(y.shape),
+              "finite", bool(torch.isfinite(y).all()), flush=True)
+    with open(os.path.join(OUT, "lightmunet_manifest.json"), "w") as f:
+        json.dump(man, f)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "lightmunet":
+        bind()
+        light_munet()
+    else:
+        main()
