@@ -145,8 +145,7 @@ def main():
 
 def light_munet():
     """nets/LightMUNet.py LightMUNet (the stand-alone net of nnUNetTrainerLightMUNet), 2-D and 3-D, the trainer's
-    configuration (init_filters 32, blocks (1, 2, 2, 4) / (1, 1, 1)): forward + backward (dx, 256 strided samples + L2 norm
-    of every parameter gradient), state_dict manifest"""
+    configuration (init_filters 32, blocks (1, 2, 2, 4) / (1, 1, 1)): forward, dx, the names of the parameters that receive a gradient, state_dict manifest"""
     import nnunetv2.nets.LightMUNet as R
     man = {}
     for tag, sd, shape in (("2d", 2, (1, 1, 64, 64)), ("3d", 3, (1, 2, 16, 16, 16))):
@@ -165,15 +164,9 @@ def light_munet():
         y = net(xg)
         j = torch.arange(y.numel(), dtype=torch.float64)
         ((y * torch.sin(0.37 * j).float().view_as(y)).sum() / y[0, 0].numel()).backward()
+        # gradient VALUES are not stored beyond dx (used for its norm): tools/probes/lightmunet_reference_conditioning.py
         gd = {"x": x.numpy(), "y": y.detach().numpy(), "dx": xg.grad.numpy()}
-        names = []
-        for k, (n, p) in enumerate(net.named_parameters()):
-            if p.grad is None:
-                continue
-            g = p.grad.reshape(-1)
-            names.append(n)
-            gd[f"g{k}"] = g[::max(1, g.numel() // 256)][:256].numpy()
-            gd[f"n{k}"] = np.array(float(g.double().norm()))
+        names = [n for n, p in net.named_parameters() if p.grad is not None]
         np.savez_compressed(os.path.join(OUT, f"net_LightMUNet_{tag}.npz"), names=np.array(names), **gd)
         print("LightMUNet", tag, "params", sum(p.numel() for p in net.parameters()), "out", tuple(y.shape),
               "finite", bool(torch.isfinite(y).all()), flush=True)
