@@ -273,11 +273,12 @@ int nnz_dense32_wgrad(const float* dy, const float* x, float* dW, float* db, flo
  * fold blocks, numbered in job order); the caller builds the int32 maps workgroup -> job and fold block -> fold job, copies
  * the four arrays to the device and calls nnz_dense32_group_launch. */
 int nnz_dense32_group_record_bytes(int which);
+int nnz_dense32_group_class(long T, int K, int N);   /* 0: 64 x 64 tiles, 1: 128 x 128; one launch per class */
 int nnz_dense32_group_plan(long T, int K, int N, int* wgs, int* fold_blocks, long* ws_floats);
 int nnz_dense32_group_fill(void* job_host, void* fold_host, const float* dy, const float* x, float* dW, float* db,
                            float* workspace, long T, int K, int N, int wg_begin, int blk_begin);
 int nnz_dense32_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs, const void* fold_dev,
-                             const int* blk_job_dev, int total_blks, void* stream);
+                             const int* blk_job_dev, int total_blks, int tile_class, void* stream);
 
 /* online-Dice statistics of the validation step (nnUNetTrainer.validation_step, nnUNetTrainer.py:1185-1226 +
  * get_tp_fp_fn_tn, training/loss/dice.py:122-180, label-map targets): argmax over classes (first maximum on ties)

@@ -119,7 +119,8 @@ SIGNATURES = {
     "nnz_dense32_group_record_bytes": [_i],
     "nnz_dense32_group_plan": [_l, _i, _i, _vp, _vp, _vp],
     "nnz_dense32_group_fill": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _i],
-    "nnz_dense32_group_launch": [_vp, _vp, _i, _vp, _vp, _i, _vp],
+    "nnz_dense32_group_class": [_l, _i, _i],
+    "nnz_dense32_group_launch": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp],
     "nnz_token_linear_wgrad": [_vp, _vp, _fp, _fp, _l, _i, _i, _vp],
     "nnz_sgd_chunk_bytes": [],
     "nnz_sgd_chunk_fill": [_vp, _vp, _vp, _l, _i],

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
 struct D32Job {
   D32Args a;
   int wg_begin;   // first workgroup of this job in the grouped launch
-  int ntiles;     // 64 x 64 tiles of the weight matrix; workgroup (wg - wg_begin) = split * ntiles + tile
+  int ntiles;     // tiles of the weight matrix (64 x 64 or 128 x 128 by launch class); workgroup (wg - wg_begin) = split * ntiles + tile
 };
 struct D32FoldJob {
   const float* part;
@@ -254,6 +254,7 @@ struct D32FoldJob {
   int blk_begin;  // first 256-thread block of this job in the grouped fold launch
   int pad;
 };
+template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void dense32_group_wgrad_kernel(const D32Job* __restrict__ jobs,
                                                                      const int* __restrict__ wg_job) {
   const int j = __builtin_amdgcn_readfirstlane(wg_job[blockIdx.x]);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void dense32_group_wgrad_kernel(const D32Jo
   const D32Args a = jp->a;
   const int local = (int)blockIdx.x - jp->wg_begin;
   const int nt = jp->ntiles;
-  dense32_body<1, 1, false, false, true>(a, local % nt, local / nt);
+  dense32_body<WM, WN, false, false, true>(a, local % nt, local / nt);
 }
 __global__ __launch_bounds__(256) void dense32_group_fold_kernel(const D32FoldJob* __restrict__ jobs,
                                                                  const int* __restrict__ blk_job) {
@@ -399,10 +400,21 @@ extern "C" int nnz_dense32_wgrad(const float* dy, const float* x, float* dW, flo
 extern "C" int nnz_dense32_group_record_bytes(int which) {
   return which == 0 ? (int)sizeof(nnz::D32Job) : (int)sizeof(nnz::D32FoldJob);
 }
+// launch class of a job: 1 = 128 x 128 tiles (weight matrices that still give >= 256 workgroups with them), 0 = 64 x 64; the
+// token splits do not depend on it, so the results are bit-identical either way
+static int d32_group_class(long T, int K, int N) {
+  const long splits = d32_wgrad_splits(T, K, N, nullptr);
+  return (N > 64 && K > 64 && (long)((N + 127) / 128) * ((K + 127) / 128) * splits >= 256) ? 1 : 0;
+}
+extern "C" int nnz_dense32_group_class(long T, int K, int N) {
+  if (T < 1 || K < 4 || N < 4) return NNZ_EINVAL;
+  return d32_group_class(T, K, N);
+}
 extern "C" int nnz_dense32_group_plan(long T, int K, int N, int* wgs, int* fold_blocks, long* ws_floats) {
   if (T < 1 || T > (1L << 30) || (K & 3) || (N & 3) || K < 4 || N < 4 || !wgs || !fold_blocks || !ws_floats) return NNZ_EINVAL;
   const long splits = d32_wgrad_splits(T, K, N, nullptr);
-  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  const int tsz = d32_group_class(T, K, N) ? 128 : 64;
+  const long tiles = (long)((N + tsz - 1) / tsz) * ((K + tsz - 1) / tsz);
   *wgs = (int)(tiles * splits);
   *fold_blocks = splits > 1 ? (int)(((long)N * K + N + 255) / 256) : 0;
   *ws_floats = splits > 1 ? splits * ((long)N * K + N) : 0;
@@ -421,7 +433,8 @@ extern "C" int nnz_dense32_group_fill(void* job_host, void* fold_host, const flo
   a.B = x; a.b_rs = 1; a.b_cs = K;
   a.ldo = K; a.rows = N; a.cols = K; a.kc = (int)per; a.kc_total = (int)T;
   j.wg_begin = wg_begin;
-  j.ntiles = ((N + 63) / 64) * ((K + 63) / 64);
+  const int tsz = d32_group_class(T, K, N) ? 128 : 64;
+  j.ntiles = ((N + tsz - 1) / tsz) * ((K + tsz - 1) / tsz);
   if (splits == 1) {
     a.out = dW; a.split_stride = 0; a.part_db = db;
   } else {
@@ -435,13 +448,20 @@ extern "C" int nnz_dense32_group_fill(void* job_host, void* fold_host, const flo
   *reinterpret_cast<D32Job*>(job_host) = j;
   return NNZ_OK;
 }
+// all jobs of one launch must be of the same class (nnz_dense32_group_class)
 extern "C" int nnz_dense32_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs, const void* fold_dev,
-                                        const int* blk_job_dev, int total_blks, void* stream) {
+                                        const int* blk_job_dev, int total_blks, int tile_class, void* stream) {
   using namespace nnz;
   if (!jobs_dev || !wg_job_dev || total_wgs < 1 || total_blks < 0 || (total_blks > 0 && (!fold_dev || !blk_job_dev)))
     return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  NNZ_LAUNCH(dense32_group_wgrad_kernel, dim3((unsigned)total_wgs), dim3(256), 0, s, (const D32Job*)jobs_dev, wg_job_dev);
+  if (tile_class == 1) {
+    NNZ_LAUNCH((dense32_group_wgrad_kernel<2, 2>), dim3((unsigned)total_wgs), dim3(256), 0, s, (const D32Job*)jobs_dev,
+               wg_job_dev);
+  } else {
+    NNZ_LAUNCH((dense32_group_wgrad_kernel<1, 1>), dim3((unsigned)total_wgs), dim3(256), 0, s, (const D32Job*)jobs_dev,
+               wg_job_dev);
+  }
   if (total_blks > 0)
     NNZ_LAUNCH(dense32_group_fold_kernel, dim3((unsigned)total_blks), dim3(256), 0, s, (const D32FoldJob*)fold_dev,
                blk_job_dev);

@@ -190,11 +190,16 @@ class deferred_wgrads:
             _DEFER["on"] = False
             jobs, _DEFER["jobs"] = _DEFER["jobs"], []
             if et is None and jobs:
-                _flush_group(jobs)
+                # one grouped launch per tile class (64 x 64 / 128 x 128 tiles; csrc/dense32.hip d32_group_class)
+                lib = _lib.load()
+                for cls in (0, 1):
+                    sub = [j for j in jobs if int(lib.nnz_dense32_group_class(j[1].shape[0], j[2].shape[1], j[2].shape[0])) == cls]
+                    if sub:
+                        _flush_group(sub, cls)
         return False
 
 
-def _flush_group(jobs) -> None:
+def _flush_group(jobs, tile_class: int = 0) -> None:
     import numpy as np
     lib = _lib.load()
     dev = jobs[0][0].device
@@ -216,7 +221,7 @@ def _flush_group(jobs) -> None:
     # that precede every capture leave their buffer in _HOST_CACHE under the pass's shape signature; a capturing flush TAKES
     # it (the captured copy node re-reads it at every replay, so no later flush may write to it).
     nbytes = o_blk + max(1, total_blks) * 4
-    key = tuple((x2.shape[0],) + tuple(w.shape) + (b is not None,) for _, x2, w, b in jobs)
+    key = (tile_class,) + tuple((x2.shape[0],) + tuple(w.shape) + (b is not None,) for _, x2, w, b in jobs)
     capturing = torch.cuda.is_current_stream_capturing()
     host = _HOST_CACHE.pop(key, None)
     ev = _HOST_EVENTS.pop(key, None)
@@ -258,7 +263,8 @@ def _flush_group(jobs) -> None:
         _HOST_CACHE[key] = host
         _HOST_EVENTS[key] = ev
     base = tab.data_ptr()
-    call("nnz_dense32_group_launch", base, base + o_wg, total_wgs, base + o_fold, base + o_blk, total_blks, stream_ptr())
+    call("nnz_dense32_group_launch", base, base + o_wg, total_wgs, base + o_fold, base + o_blk, total_blks, int(tile_class),
+         stream_ptr())
     for w, dw, b, db in outs:
         for p, g in ((w, dw), (b, db)):
             if g is None:
