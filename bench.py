@@ -414,14 +414,18 @@ def main():
     dt = time.perf_counter() - t0
     hip_ops.TIMER.enabled = False
     roof_note = f"HIP events around every launch on every 4th step of the timed region ({timed_steps_with_events} steps)"
+    eager_ms = None
     if graph and not a.no_launch_timer:
         trainer.use_hip_graph = False
         trainer.train_step(batch)
         timed_steps_with_events = min(8, a.steps)
         hip_ops.TIMER.enabled = True
+        torch.cuda.synchronize()
+        te = time.perf_counter()
         for _ in range(timed_steps_with_events):
             losses.append(float(trainer.train_step(batch)["loss"]))
         torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - te) / timed_steps_with_events * 1e3   # incl. the event pairs around every launch
         hip_ops.TIMER.enabled = False
         trainer.use_hip_graph = True
         roof_note = (f"HIP events around every launch over {timed_steps_with_events} EAGER steps right after the timed region "
@@ -458,6 +462,9 @@ def main():
                     "launches_per_step": n // max(1, timed_steps_with_events), "avg_launch_us": round(sec / n * 1e6, 2),
                     "flops_per_launch": fl / n, "ms_per_step": round(sec / max(1, timed_steps_with_events) * 1e3, 3),
                     "timed_over": roof_note}
+            if eager_ms is not None:
+                # the same step launched eagerly with an event pair around every launch (what the roofline was timed in)
+                roof["eager_instrumented_ms_per_step"] = round(eager_ms, 3)
             if "conv_wgrad_kernel" in summ:
                 n2, fl2, sec2 = summ["conv_wgrad_kernel"]
                 roof["wgrad_kernel_achieved"] = round(fl2 / sec2 / 1e12, 2)
