@@ -139,6 +139,11 @@ int nnz_conv_tap_forward_norm_ws(const void* in_f16, void* out_f16, const void* 
 int nnz_conv_tap_dgrad_normred(const void* in_f16, void* out_f16, const void* w_packed_f16, const nnz_conv_desc* desc,
                                const void* x_raw_f16, int ld_x, const float* nstat, float slope, void* acc, void* counter,
                                float* nred, float* dgamma, float* dbeta, void* stream);
+/* BatchNorm2d in training mode (REBNCONV): stats[N][C][2] per-sample {sum, sumsq} of the conv epilogue -> bstats[C][2] batch
+ * sums (what the apply kernel reads with N = 1) and F.batch_norm's running-estimate update (unbiased variance n / (n - 1),
+ * momentum-weighted; running_mean / running_var may both be NULL) in one launch; n = number of values per channel */
+int nnz_bn_batch_stats_finish(const float* stats, int N, int C, float n, float momentum, float* bstats, float* running_mean,
+                              float* running_var, void* stream);
 int nnz_instnorm_lrelu_bwd_apply_tab(const void* x_f16, const void* g_f16, const float* nstat, const float* nred,
                                      void* dx_f16, int N, long V, int C, int ldx, int ldg, int lddx, float slope,
                                      void* stream);

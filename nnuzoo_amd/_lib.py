@@ -95,6 +95,7 @@ SIGNATURES = {
     "nnz_instnorm_stats_det": [_vp, _i, _l, _i, _i, _vp, _vp, _fp, _fp, _f, _fp, _fp, _vp],
     "nnz_instnorm_lrelu_apply_tab": [_vp, _fp, _vp, _i, _l, _i, _i, _i, _f, _vp],
     "nnz_conv_tap_dgrad_normred": [_vp, _vp, _vp, _dp, _vp, _i, _fp, _f, _vp, _vp, _fp, _fp, _fp, _vp],
+    "nnz_bn_batch_stats_finish": [_fp, _i, _i, _f, _f, _fp, _fp, _fp, _vp],
     "nnz_instnorm_lrelu_bwd_apply_tab": [_vp, _vp, _fp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _vp],
     "nnz_instnorm_lrelu_bwd_tab": [_vp, _vp, _fp, _vp, _vp, _fp, _vp, _i, _l, _i, _i, _i, _i, _f, _fp, _fp, _vp],
     "nnz_graph_replace_memsets": [_vp, _ip],

@@ -478,3 +478,42 @@ extern "C" int nnz_instnorm_lrelu_bwd_apply_tab(const void* x, const void* g, co
   a.slope = slope;
   return launch_norm<3>(a, (hipStream_t)stream);
 }
+
+// BatchNorm (REBNCONV, nnuzoo_amd/rebnconv.py) in training mode: the per-sample sums of the conv epilogue -> the batch sums
+// the apply kernel reads, and torch's running-estimate update (F.batch_norm: biased variance for the normalisation, unbiased
+// n / (n - 1) for running_var, momentum-weighted) - ONE launch instead of ten element-wise ones per REBNCONV unit.
+namespace nnz {
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ stats, int N, int C, float n,
+                                                              float momentum, float* __restrict__ bstats,
+                                                              float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < N; ++i) {
+    s += stats[((long)i * C + c) * 2 + 0];
+    q += stats[((long)i * C + c) * 2 + 1];
+  }
+  bstats[c * 2 + 0] = s;
+  bstats[c * 2 + 1] = q;
+  if (running_mean && running_var) {
+    const float mean = s / n;
+    float var = q / n - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float unb = n > 1.f ? n / (n - 1.f) : 1.f;
+    running_mean[c] = running_mean[c] * (1.f - momentum) + mean * momentum;
+    running_var[c] = running_var[c] * (1.f - momentum) + var * unb * momentum;
+  }
+}
+}  // namespace nnz
+
+extern "C" int nnz_bn_batch_stats_finish(const float* stats, int N, int C, float n, float momentum, float* bstats,
+                                         float* running_mean, float* running_var, void* stream) {
+  using namespace nnz;
+  if (!stats || !bstats || N < 1 || C < 1 || !(n >= 1.f) || (running_mean == nullptr) != (running_var == nullptr))
+    return NNZ_EINVAL;
+  NNZ_LAUNCH(bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, N, C, n, momentum,
+             bstats, running_mean, running_var);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

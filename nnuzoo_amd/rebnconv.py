@@ -20,6 +20,8 @@ from typing import Dict, Tuple
 
 import torch
 
+from ._lib import call as _call, ptr as _ptr, stream_ptr as _stream_ptr
+
 from . import conv_plan as cp
 from . import hip_ops as ops
 from .hip_ops import PreparedTable
@@ -64,12 +66,20 @@ class _RebnConvFn(torch.autograd.Function):
         ops.conv_tap_forward(fwd, x.view(N, V, cin), wp, bias.detach(), raw, stats=stats if training else None)
         n = N * V
         if training:
-            bstats = stats.sum(0, keepdim=True)                      # batch statistics: one instance of N * V voxels
-            with torch.no_grad():                                     # running estimates (F.batch_norm's update rule)
-                mean = bstats[0, :, 0] / n
-                var = (bstats[0, :, 1] / n - mean * mean).clamp_min_(0)
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+            # batch statistics (one instance of N * V voxels) + the running estimates (F.batch_norm's update rule) in ONE
+            # launch (csrc/norm_act.hip bn_stats_finish_kernel; ten element-wise launches per unit before: 24 units in M2Net)
+            bstats = torch.empty((1, cout, 2), dtype=torch.float32, device=dev)
+            if running_mean.dtype == torch.float32 and running_var.dtype == torch.float32 \
+                    and running_mean.is_contiguous() and running_var.is_contiguous():
+                _call("nnz_bn_batch_stats_finish", _ptr(stats), N, cout, float(n), float(momentum), _ptr(bstats),
+                      _ptr(running_mean), _ptr(running_var), _stream_ptr())
+            else:
+                bstats = stats.sum(0, keepdim=True)
+                with torch.no_grad():
+                    mean = bstats[0, :, 0] / n
+                    var = (bstats[0, :, 1] / n - mean * mean).clamp_min_(0)
+                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
         else:
             rm, rv = running_mean.float(), running_var.float()
             bstats = torch.stack([rm * n, (rv + rm * rm) * n], dim=1).unsqueeze(0).contiguous()
