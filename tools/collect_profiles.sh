@@ -37,6 +37,11 @@ python3 tools/bench_zoo.py --models M2NetP,M2Net,SwT2Net,SSND2Net,MambaND2Net,UN
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $OUT/prof_wa_pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models SwT2Net --steps 1 --warmup 1 --graph 0 > /dev/null 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_kernel_sums.py $(ls $OUT/prof_wa_pmc/*/*counter_collection.csv | head -1) win_attn dense32 > $OUT/${TAG}_swt2net_pmc_sq_summary.json 2>&1
 rm -rf $OUT/prof_wa_pmc
+# 4c. window attention per stage shape; per-kernel duration distributions of the M2Net step
+python3 $GRAFT_REPO_ROOT/tools/bench_window_attention.py > $OUT/${TAG}_window_attention_bench.txt 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_zoo -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models M2Net --steps 3 --warmup 3 > /dev/null 2>&1
+python3 $GRAFT_REPO_ROOT/tools/kernel_histogram.py $(ls $OUT/prof_zoo/*/*kernel_trace.csv | head -1) 0.4 22 > $OUT/${TAG}_m2net_kernel_histogram.txt 2>&1
+rm -rf $OUT/prof_zoo
 # 5. the bench line of record (defaults: both legs, cpu_baseline)
 python3 bench.py > $OUT/${TAG}_bench_n1.json 2>$OUT/${TAG}_bench_n1.err
 ls -la $OUT | tail -20
