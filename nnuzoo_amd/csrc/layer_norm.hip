@@ -231,9 +231,12 @@ template <class T, int LPR, int IT>
 static int ln_launch(const LnArgs& a, bool bwd, hipStream_t s) {
   constexpr int GPW = 256 / LPR;
   long want = (a.R + GPW - 1) / GPW;
-  // forward: enough workgroups to fill the chip several times; backward: fewer, so that the dgamma/dbeta atomics
-  // (one per channel per workgroup) stay a small fraction of the traffic
-  const long cap = bwd ? 1024 : 8192;
+  // forward: enough workgroups to fill the chip several times; backward: one workgroup per CU, grid-striding over the rows -
+  // every workgroup ends with 2 C fixed-point adds and the last one waits for all of them, so the tail grows with the grid
+  // (SwT2Net step at 1024 / 512 / 256 / 128 / 64 workgroups: 84.1 / 82.6 / 81.6 / 81.3 / 82.5 ms, M2Net 87.8 / 86.9 / 86.8 /
+  // 88.4 / 91.5 ms; NNZ_LN_BWD_CAP overrides)
+  static const long bwd_cap = [] { const char* e = getenv("NNZ_LN_BWD_CAP"); return e && atol(e) > 0 ? atol(e) : 256L; }();
+  const long cap = bwd ? bwd_cap : 8192;
   const unsigned grid = (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
   if (bwd)
     NNZ_LAUNCH((ln_bwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);

@@ -5,6 +5,8 @@ the input type (layer_norm is on autocast's fp32 list), gradient of the input in
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -14,6 +16,10 @@ from ._lib import call, ptr, stream_ptr
 def _dy(dy: torch.Tensor) -> torch.Tensor:
     """the kernels read f32 or f16 gradients in place"""
     return (dy if dy.dtype in (torch.float16, torch.float32) else dy.float()).contiguous()
+
+
+# NNZ_LN_DET=0: dgamma / dbeta through fp32 atomics (rounds 1-2) instead of the fixed-point sums + last-workgroup finalisation
+_LN_DET = os.environ.get("NNZ_LN_DET", "1") != "0"
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -45,11 +51,15 @@ class _LayerNormFn(torch.autograd.Function):
         dw, db, pre = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, xc.device,
                                     ctx.gwb)
         ctx.gwb = None      # single use: a second backward through the same node zeroes in its own launch
-        from .hip_ops import det_scratch
-        sc = det_scratch(xc.device, 2 * C)     # fixed-point cross-workgroup sums: dgamma / dbeta bit-identical run to run
-        call("nnz_layer_norm_backward_det", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
-             ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C,
-             stream_ptr())
+        if _LN_DET:
+            from .hip_ops import det_scratch
+            sc = det_scratch(xc.device, 2 * C)     # fixed-point cross-workgroup sums: dgamma / dbeta bit-identical run to run
+            call("nnz_layer_norm_backward_det", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
+                 ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C,
+                 stream_ptr())
+        else:
+            call("nnz_layer_norm_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd),
+                 ptr(dy), int(dy.dtype == torch.float16), ptr(dx), ptr(dw), ptr(db), int(pre), rows, C, stream_ptr())
         return dx, dw, db, None, None
 
 
@@ -114,11 +124,16 @@ class _LayerNormGateFn(torch.autograd.Function):
         dw, db, pre = _affine_grads(weight, bias is not None, ctx.needs_input_grad[2], ctx.needs_input_grad[3], C,
                                     xc.device, ctx.gwb)
         ctx.gwb = None
-        from .hip_ops import det_scratch
-        sc = det_scratch(xc.device, 2 * C)
-        call("nnz_layer_norm_gate_backward_det", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
-             int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), int(dy.dtype == torch.float16),
-             ptr(dx), ptr(dz), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C, stream_ptr())
+        if _LN_DET:
+            from .hip_ops import det_scratch
+            sc = det_scratch(xc.device, 2 * C)
+            call("nnz_layer_norm_gate_backward_det", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
+                 int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), int(dy.dtype == torch.float16),
+                 ptr(dx), ptr(dz), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C, stream_ptr())
+        else:
+            call("nnz_layer_norm_gate_backward", ptr(xc), int(xc.dtype == torch.float16), ptr(weight), ptr(bias), ptr(z),
+                 int(z.dtype == torch.float16), ctx.zs, ptr(mean), ptr(rstd), ptr(dy), int(dy.dtype == torch.float16),
+                 ptr(dx), ptr(dz), ptr(dw), ptr(db), int(pre), rows, C, stream_ptr())
         return dx, dz, dw, db, None, None
 
 
