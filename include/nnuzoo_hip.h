@@ -367,6 +367,14 @@ int nnz_residual_droppath_forward(const void* input, int input_is_f16, const voi
                                   void* stream);
 int nnz_residual_droppath_backward(const void* dout, int dout_is_f16, const void* mask, int mask_is_f16, float scale,
                                    void* dx, int dx_is_f16, int B, long per_sample, void* stream);
+/* the same pair with the mask made inside: rand = B fp32 uniform draws, mask[b] = floor(rand[b] + keep) - the reference's
+ * Swin DropPath (swt2net.py:379-388: keep_prob + torch.rand(..), floor_(), x.div(keep_prob) * mask) without its add and
+ * floor launches; keep > 0 */
+int nnz_residual_droppath_rand_forward(const void* input, int input_is_f16, const void* x, int x_is_f16, const float* rand,
+                                       float keep, float scale, void* out, int out_is_f16, int B, long per_sample,
+                                       void* stream);
+int nnz_residual_droppath_rand_backward(const void* dout, int dout_is_f16, const float* rand, float keep, float scale,
+                                        void* dx, int dx_is_f16, int B, long per_sample, void* stream);
 
 /* ---- LayerNorm over the last dimension of token-major tensors (nn.LayerNorm in the VSS / Swin blocks: m2net.py:101,521,
  * ssnd2net.py, swt2net.py:630-660).  x: [rows][C] f16 or f32, C % 4 == 0, C <= 2048; y, dy: f32 (what autocast gives);

@@ -16,6 +16,7 @@ struct ResArgs {
   int B;
   int in_f16, x_f16, mask_f16, out_f16;
   float scale;
+  float mask_add;     // != 0: mask holds uniform draws r[b] and the 0 / 1 mask is floor(r[b] + mask_add) (timm-style DropPath)
 };
 
 __device__ __forceinline__ f32x4 ld4any(const void* p, long i, int is_f16) {
@@ -35,7 +36,11 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void residual_droppath_kernel(ResArgs a) {
   const int b = blockIdx.y;
   float m = a.scale;
-  if (a.mask) m *= a.mask_f16 ? (float)((const f16*)a.mask)[b] : ((const float*)a.mask)[b];
+  if (a.mask) {
+    float mv = a.mask_f16 ? (float)((const f16*)a.mask)[b] : ((const float*)a.mask)[b];
+    if (a.mask_add != 0.f) mv = floorf(mv + a.mask_add);
+    m *= mv;
+  }
   const long base = (long)b * a.P;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.P; i += (long)gridDim.x * 1024) {
     const f32x4 r = ld4any(a.input, base + i, a.in_f16);
@@ -81,5 +86,29 @@ extern "C" int nnz_residual_droppath_backward(const void* dout, int dout_is_f16,
   ResArgs a = {};
   a.input = dout; a.mask = mask; a.out = dx; a.P = per_sample; a.B = B;
   a.in_f16 = dout_is_f16; a.mask_f16 = mask_is_f16; a.out_f16 = dx_is_f16; a.scale = scale;
+  return res_launch(a, true, (hipStream_t)stream);
+}
+
+// the same pair with the mask still to be made: `rand` = B fp32 uniform draws, mask[b] = floor(rand[b] + keep) - what the
+// reference's DropPath computes with an add and a floor_ launch of its own (swt2net.py:379-388)
+extern "C" int nnz_residual_droppath_rand_forward(const void* input, int input_is_f16, const void* x, int x_is_f16,
+                                                  const float* rand, float keep, float scale, void* out,
+                                                  int out_is_f16, int B, long per_sample, void* stream) {
+  using namespace nnz;
+  if (!x || !rand || !(keep > 0.f)) return NNZ_EINVAL;
+  ResArgs a = {};
+  a.input = input; a.x = x; a.mask = rand; a.out = out; a.P = per_sample; a.B = B; a.mask_add = keep;
+  a.in_f16 = input_is_f16; a.x_f16 = x_is_f16; a.out_f16 = out_is_f16; a.scale = scale;
+  return res_launch(a, false, (hipStream_t)stream);
+}
+
+extern "C" int nnz_residual_droppath_rand_backward(const void* dout, int dout_is_f16, const float* rand, float keep,
+                                                   float scale, void* dx, int dx_is_f16, int B, long per_sample,
+                                                   void* stream) {
+  using namespace nnz;
+  if (!rand || !(keep > 0.f)) return NNZ_EINVAL;
+  ResArgs a = {};
+  a.input = dout; a.mask = rand; a.out = dx; a.P = per_sample; a.B = B; a.mask_add = keep;
+  a.in_f16 = dout_is_f16; a.out_f16 = dx_is_f16; a.scale = scale;
   return res_launch(a, true, (hipStream_t)stream);
 }

@@ -41,7 +41,8 @@ class DropPath(nn.Module):
 
 class _ResidualDropPathFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inp, x, mask, scale):
+    def forward(ctx, inp, x, mask, scale, rand_keep=0.0):
+        """rand_keep > 0: `mask` holds fp32 uniform draws and the 0 / 1 mask is floor(mask + rand_keep), made in the kernel"""
         from .._lib import call, ptr, stream_ptr
         inp, x = inp.contiguous(), x.contiguous()
         B = x.shape[0]
@@ -49,10 +50,17 @@ class _ResidualDropPathFn(torch.autograd.Function):
         out_dtype = torch.float16 if (inp.dtype == torch.float16 and x.dtype == torch.float16) else torch.float32
         out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
         h = torch.float16
-        call("nnz_residual_droppath_forward", ptr(inp), int(inp.dtype == h), ptr(x), int(x.dtype == h), ptr(mask),
-             int(mask is not None and mask.dtype == h), float(scale), ptr(out), int(out_dtype == h), B, P, stream_ptr())
+        if rand_keep > 0.0:
+            assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B
+            call("nnz_residual_droppath_rand_forward", ptr(inp), int(inp.dtype == h), ptr(x), int(x.dtype == h), ptr(mask),
+                 float(rand_keep), float(scale), ptr(out), int(out_dtype == h), B, P, stream_ptr())
+        else:
+            call("nnz_residual_droppath_forward", ptr(inp), int(inp.dtype == h), ptr(x), int(x.dtype == h), ptr(mask),
+                 int(mask is not None and mask.dtype == h), float(scale), ptr(out), int(out_dtype == h), B, P,
+                 stream_ptr())
         ctx.save_for_backward(mask)
         ctx.meta = (scale, x.dtype, inp.dtype, B, P)
+        ctx.rand_keep = float(rand_keep)
         return out
 
     @staticmethod
@@ -67,10 +75,14 @@ class _ResidualDropPathFn(torch.autograd.Function):
             dx = dout                                   # plain residual: both branches receive the same gradient tensor
         elif ctx.needs_input_grad[1]:
             dx = torch.empty(dout.shape, dtype=xdt, device=dout.device)
-            call("nnz_residual_droppath_backward", ptr(dout), int(dout.dtype == h), ptr(mask),
-                 int(mask is not None and mask.dtype == h), float(scale), ptr(dx), int(xdt == h), B, P, stream_ptr())
+            if ctx.rand_keep > 0.0:
+                call("nnz_residual_droppath_rand_backward", ptr(dout), int(dout.dtype == h), ptr(mask), ctx.rand_keep,
+                     float(scale), ptr(dx), int(xdt == h), B, P, stream_ptr())
+            else:
+                call("nnz_residual_droppath_backward", ptr(dout), int(dout.dtype == h), ptr(mask),
+                     int(mask is not None and mask.dtype == h), float(scale), ptr(dx), int(xdt == h), B, P, stream_ptr())
         dinp = (dout if dout.dtype == idt else dout.to(idt)) if ctx.needs_input_grad[0] else None
-        return dinp, dx, None, None
+        return dinp, dx, None, None, None
 
 
 def residual_drop_path(inp: torch.Tensor, x: torch.Tensor, drop_path: "DropPath") -> torch.Tensor:

@@ -150,9 +150,17 @@ def test_trainer_steps(hip_lib, trainer):
     tgt = [t.cuda() for t in b["target"]] if scales else b["target"][0].cuda()
     b = {"data": b["data"].cuda(), "target": tgt}
     before = [p.detach().clone() for p in tr.network.parameters()]
+    scaler = getattr(tr, "grad_scaler", None)
+    scale0 = scaler.get_scale() if scaler is not None else None
     losses = [float(tr.train_step(b)["loss"]) for _ in range(6)]
-    assert all(np.isfinite(losses)), losses
+    if scaler is not None and scaler.get_scale() < scale0:
+        # fp16 overflow in the scaled gradients: GradScaler skipped optimizer steps and backed off (legitimate, and with the
+        # library's atomically accumulated weight gradients not the same on every run) - give it steps at the lower scale
+        losses += [float(tr.train_step(b)["loss"]) for _ in range(10)]
+    scale1 = scaler.get_scale() if scaler is not None else None
+    assert all(np.isfinite(losses)), (losses, scale0, scale1)
     moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, tr.network.parameters()))
-    assert moved > 0.9 * len(before), (moved, len(before))          # AdamW at lr 1e-4: every reached parameter moves
+    # AdamW at lr 1e-4: every reached parameter moves
+    assert moved > 0.9 * len(before), (moved, len(before), losses, scale0, scale1)
     if "Swin" in trainer:
         assert losses[-1] < losses[0], losses

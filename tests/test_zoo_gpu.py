@@ -215,6 +215,35 @@ def test_residual_drop_path_matches_torch_ops(hip_lib, p, in_dtype, x_dtype):
         assert torch.allclose(u, v, rtol=tol, atol=tol * max(1.0, v.abs().max().item())), (u - v).abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [0.1, 0.5, 0.9])
+def test_swin_block_residual_makes_the_mask_in_kernel(hip_lib, p):
+    """SwinTransformerBlock._residual hands the raw uniform draws to the residual kernel, which forms floor(keep + r) itself
+    (csrc/residual.hip, nnz_residual_droppath_rand_*): bit-identical to the reference's DropPath op by op (swt2net.py:379-388:
+    keep + torch.rand, floor_, x.div(keep) * mask) up to the div-vs-reciprocal rounding, same RNG consumption"""
+    from nnuzoo_amd.nets.swt2net import SwinTransformerBlock, DropPath
+    blk = SwinTransformerBlock(dim=32, num_heads=2, window_size=7, shift=False, drop_path=p).cuda().train()
+    g = torch.Generator().manual_seed(5)
+    inp = torch.randn(64, 7, 7, 32, generator=g).cuda()
+    y = torch.randn(64, 7, 7, 32, generator=g).cuda()
+    dout = torch.randn(64, 7, 7, 32, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(23)
+        a, b = inp.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        out = blk._residual(a, b) if fused else a + DropPath(p).train()(b)
+        out.backward(dout)
+        after = torch.rand(4, device="cuda")          # same generator offset afterwards
+        res.append((out.detach(), a.grad, b.grad, after))
+    kept = (res[1][2].flatten(1).abs().sum(1) > 0)
+    assert 0 < int(kept.sum()) < 64                   # both outcomes present
+    assert torch.equal((res[0][2].flatten(1).abs().sum(1) > 0), kept)          # the very same samples dropped
+    assert torch.equal(res[0][3], res[1][3])
+    assert torch.equal(res[0][1], res[1][1])
+    for u, v in zip(res[0][:3:2], res[1][:3:2]):
+        assert torch.allclose(u, v, rtol=1e-6, atol=1e-6), (u - v).abs().max().item()
+
+
 def test_fp32_depthwise_conv_native_path_matches_library(hip_lib):
     """common2d._Conv2d sends fp32 depthwise convolutions to ATen's direct kernels (the library's weight gradient for them
     is a 70 ms batched GEMM at 512^2; under fp16 autocast a 24 ms grouped-conv kernel, SSND2Net): same values and gradients
