@@ -376,6 +376,12 @@ int nnz_residual_droppath_rand_forward(const void* input, int input_is_f16, cons
 int nnz_residual_droppath_rand_backward(const void* dout, int dout_is_f16, const float* rand, float keep, float scale,
                                         void* dx, int dx_is_f16, int B, long per_sample, void* stream);
 
+/* ---- top / left zero padding of a channels-last fp32 map to the window multiple and the crop back (SwinTransformerBlock.forward,
+ * swt2net.py:643-645 F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0)) and :660 x[:, -H:, -W:, :]; each is the other's
+ * backward).  small [B][H][W][C], big [B][H + py][W + px][C], C % 4 == 0, B * (H + py) <= 65535; one launch each. */
+int nnz_pad_top_left(const float* small, float* big, int B, int H, int W, int C, int py, int px, void* stream);
+int nnz_crop_top_left(const float* big, float* small, int B, int H, int W, int C, int py, int px, void* stream);
+
 /* ---- LayerNorm over the last dimension of token-major tensors (nn.LayerNorm in the VSS / Swin blocks: m2net.py:101,521,
  * ssnd2net.py, swt2net.py:630-660).  x: [rows][C] f16 or f32, C % 4 == 0, C <= 2048; y, dy: f32 (what autocast gives);
  * dx has x's type; gamma / beta / dgamma / dbeta may be NULL (elementwise_affine = False).  mean / rstd: [rows] f32. */

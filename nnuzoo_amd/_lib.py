@@ -149,6 +149,8 @@ SIGNATURES = {
     "nnz_residual_droppath_backward": [_vp, _i, _vp, _i, _f, _vp, _i, _i, _l, _vp],
     "nnz_residual_droppath_rand_forward": [_vp, _i, _vp, _i, _fp, _f, _f, _vp, _i, _i, _l, _vp],
     "nnz_residual_droppath_rand_backward": [_vp, _i, _fp, _f, _f, _vp, _i, _i, _l, _vp],
+    "nnz_pad_top_left": [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp],
+    "nnz_crop_top_left": [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp],
     "nnz_layer_norm_gate_forward": [_vp, _i, _fp, _fp, _vp, _i, _l, _vp, _i, _fp, _fp, _fp, _l, _i, _f, _vp],
     "nnz_layer_norm_gate_backward": [_vp, _i, _fp, _fp, _vp, _i, _l, _fp, _fp, _vp, _i, _vp, _vp, _fp, _fp, _i, _l, _i,
                                      _vp],

@@ -112,3 +112,64 @@ extern "C" int nnz_residual_droppath_rand_backward(const void* dout, int dout_is
   a.in_f16 = dout_is_f16; a.out_f16 = dx_is_f16; a.scale = scale;
   return res_launch(a, true, (hipStream_t)stream);
 }
+
+// ---- top / left zero padding of a channels-last map and its inverse crop (SwinTransformerBlock.forward pads every block's
+// input to a multiple of the 7-token window and crops the result: F.pad is a fill + a copy, the crop's backward another
+// fill + copy - here each is one launch).  small: [B][H][W][C], big: [B][H + py][W + px][C], fp32, C % 4 == 0.
+namespace nnz {
+struct PadArgs {
+  const float* src;
+  float* dst;
+  long rowC;      // W * C of the SMALL map
+  long big_rowC;  // (W + px) * C
+  long pxC;       // px * C
+  int H, py, B;
+};
+
+// PAD: dst = big, every element written (zeros in the first py rows / first px columns); else dst = small = src[.., py:, px:, :]
+template <bool PAD>
+__global__ __launch_bounds__(256) void pad_crop_kernel(PadArgs a) {
+  const int rows = PAD ? a.H + a.py : a.H;                  // rows of dst
+  const long dst_rowC = PAD ? a.big_rowC : a.rowC;
+  const long row = blockIdx.y;                              // b * rows + y
+  const int b = (int)(row / rows), y = (int)(row % rows);
+  float* d = a.dst + row * dst_rowC;
+  if (PAD) {
+    const bool live = y >= a.py;
+    const float* sp = a.src + ((long)b * a.H + (y - a.py)) * a.rowC - a.pxC;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < dst_rowC; i += (long)gridDim.x * 1024) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (live && i >= a.pxC) v = *reinterpret_cast<const f32x4*>(sp + i);
+      *reinterpret_cast<f32x4*>(d + i) = v;
+    }
+  } else {
+    const float* sp = a.src + ((long)b * (a.H + a.py) + (y + a.py)) * a.big_rowC + a.pxC;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < dst_rowC; i += (long)gridDim.x * 1024)
+      *reinterpret_cast<f32x4*>(d + i) = *reinterpret_cast<const f32x4*>(sp + i);
+  }
+}
+}  // namespace nnz
+
+static int pad_crop_launch(const float* src, float* dst, int B, int H, int W, int C, int py, int px, bool pad, void* stream) {
+  using namespace nnz;
+  if (!src || !dst || B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || py < 0 || px < 0) return NNZ_EINVAL;
+  PadArgs a = {};
+  a.src = src; a.dst = dst; a.rowC = (long)W * C; a.big_rowC = (long)(W + px) * C; a.pxC = (long)px * C;
+  a.H = H; a.py = py; a.B = B;
+  const long rows = (long)B * (pad ? H + py : H);
+  if (rows > 65535) return NNZ_EINVAL;
+  const long rc = pad ? a.big_rowC : a.rowC;
+  long gx = (rc / 4 + 255) / 256;
+  if (gx > 64) gx = 64;
+  if (pad) NNZ_LAUNCH(pad_crop_kernel<true>, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+  else NNZ_LAUNCH(pad_crop_kernel<false>, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+extern "C" int nnz_pad_top_left(const float* small, float* big, int B, int H, int W, int C, int py, int px, void* stream) {
+  return pad_crop_launch(small, big, B, H, W, C, py, px, true, stream);
+}
+extern "C" int nnz_crop_top_left(const float* big, float* small, int B, int H, int W, int C, int py, int px, void* stream) {
+  return pad_crop_launch(big, small, B, H, W, C, py, px, false, stream);
+}

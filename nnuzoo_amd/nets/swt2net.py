@@ -62,6 +62,35 @@ class DropPath(nn.Module):
         return x.div(keep) * mask
 
 
+class _PadCropFn(torch.autograd.Function):
+    """pad=True: zero rows / columns in FRONT of a (B, H, W, C) fp32 map (F.pad(x, (0, 0, px, 0, py, 0))); pad=False: the
+    crop x[:, py:, px:, :] as a contiguous tensor.  Each is the other's backward, one launch either way (csrc/residual.hip
+    pad_crop_kernel) - ATen runs the pad and the crop's backward as a fill plus a copy."""
+
+    @staticmethod
+    def forward(ctx, x, py, px, pad):
+        from .._lib import call, ptr, stream_ptr
+        B, H, W, C = x.shape
+        ctx.cfg = (py, px, pad)
+        if pad:
+            out = torch.empty((B, H + py, W + px, C), dtype=torch.float32, device=x.device)
+            call("nnz_pad_top_left", ptr(x), ptr(out), B, H, W, C, py, px, stream_ptr())
+        else:
+            out = torch.empty((B, H - py, W - px, C), dtype=torch.float32, device=x.device)
+            call("nnz_crop_top_left", ptr(x), ptr(out), B, H - py, W - px, C, py, px, stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        py, px, pad = ctx.cfg
+        return _PadCropFn.apply(g.contiguous(), py, px, not pad), None, None, None
+
+
+def _pad_crop_ok(x, rows):
+    return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0 \
+        and x.shape[0] * rows <= 65535
+
+
 class PatchEmbedding(nn.Module):
     def __init__(self, patch_size: int = 4, in_c: int = 3, embed_dim: int = 96, norm_layer=None):
         super().__init__()
@@ -214,11 +243,15 @@ class SwinTransformerBlock(nn.Module):
         _, H, W, _ = x.shape
         ws = self.window_size
         pad = H % ws != 0 or W % ws != 0
+        py, px = ws - H % ws, ws - W % ws
+        fused = pad and _pad_crop_ok(x, H + py)
         if pad:  # top/left padding, a full extra window on an axis that already divides (reference quirk, :643-645)
-            x = F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0))
+            x = _PadCropFn.apply(x, py, px, True) if fused else F.pad(x, (0, 0, px, 0, py, 0))
         x = self._residual(x, self.attn(self.norm1(x)))
         x = self._residual(x, self.mlp(self.norm2(x)))
-        return x[:, -H:, -W:, :] if pad else x
+        if not pad:
+            return x
+        return _PadCropFn.apply(x, py, px, False) if fused and x.is_contiguous() else x[:, -H:, -W:, :]
 
 
 def _stage_drop_path(depths, drop_path, index):

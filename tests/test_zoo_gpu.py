@@ -244,6 +244,30 @@ def test_swin_block_residual_makes_the_mask_in_kernel(hip_lib, p):
         assert torch.allclose(u, v, rtol=1e-6, atol=1e-6), (u - v).abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,py,px", [((2, 9, 11, 8), 5, 3), ((3, 128, 128, 32), 5, 5), ((1, 7, 7, 4), 7, 7),
+                                         ((2, 4, 6, 256), 3, 1)])
+def test_window_pad_and_crop_kernels_match_torch(hip_lib, shape, py, px):
+    """csrc/residual.hip pad_crop_kernel (the Swin block's F.pad to the window multiple and the crop back, one launch each,
+    each the other's backward) against F.pad / slicing, values and gradients, bit for bit"""
+    import torch.nn.functional as F
+    from nnuzoo_amd.nets.swt2net import _PadCropFn
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=g).cuda().requires_grad_(True)
+    big = _PadCropFn.apply(x, py, px, True)
+    ref = F.pad(x.detach(), (0, 0, px, 0, py, 0))
+    assert torch.equal(big, ref)
+    dbig = torch.randn(*ref.shape, generator=g).cuda()
+    (dx,) = torch.autograd.grad(big, x, dbig)
+    assert torch.equal(dx, dbig[:, py:, px:, :])
+    y = big.detach().clone().requires_grad_(True)
+    small = _PadCropFn.apply(y, py, px, False)
+    assert small.is_contiguous() and torch.equal(small, y.detach()[:, py:, px:, :])
+    dsmall = torch.randn(*small.shape, generator=g).cuda()
+    (dy,) = torch.autograd.grad(small, y, dsmall)
+    assert torch.equal(dy, F.pad(dsmall, (0, 0, px, 0, py, 0)))
+
+
 def test_fp32_depthwise_conv_native_path_matches_library(hip_lib):
     """common2d._Conv2d sends fp32 depthwise convolutions to ATen's direct kernels (the library's weight gradient for them
     is a 70 ms batched GEMM at 512^2; under fp16 autocast a 24 ms grouped-conv kernel, SSND2Net): same values and gradients
