@@ -157,6 +157,7 @@ SIGNATURES = {
     "nnz_layer_norm_forward": [_vp, _i, _fp, _fp, _vp, _i, _fp, _fp, _fp, _l, _i, _f, _vp],
     "nnz_layer_norm_backward": [_vp, _i, _fp, _fp, _fp, _vp, _i, _vp, _fp, _fp, _i, _l, _i, _vp],
     "nnz_layer_norm_backward_det": [_vp, _i, _fp, _fp, _fp, _vp, _i, _vp, _fp, _fp, _vp, _vp, _l, _i, _vp],
+    "nnz_layer_norm_backward_det_res": [_vp, _i, _fp, _fp, _fp, _vp, _i, _fp, _vp, _fp, _fp, _vp, _vp, _l, _i, _vp],
     "nnz_layer_norm_gate_backward_det": [_vp, _i, _fp, _fp, _vp, _i, _l, _fp, _fp, _vp, _i, _vp, _vp, _fp, _fp, _vp, _vp, _l,
                                          _i, _vp],
     "nnz_dc_ce_loss_forward": [_vp, _i, _vp, _fp, _i, _i, _l, _i, _vp],

@@ -18,6 +18,8 @@ struct LnArgs {
   float* rstd;        // [R]
   const void* dy;     // [R][C] f32 or f16 (dy_is_f16)
   void* dx;           // [R][C] same type as x
+  const float* dres;  // backward, optional: [R][C] f32 gradient of the residual stream the normalised tensor was taken from -
+                      // dx = dres + (LayerNorm backward), the sum autograd would make with an add launch of its own
   float* dgamma;      // [C] atomic, zeroed by the launcher; may be null
   float* dbeta;
   long R;
@@ -190,6 +192,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
+        if (a.dres) {
+          const f32x4 sk = ld4(a.dres + r * C + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = sk[e] + o[e];
+        }
         st4(dxr + c, o);
       }
     }
@@ -277,7 +284,8 @@ static int ln_forward_impl(const void* x, int x_is_f16, const float* gamma, cons
 static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, const float* beta, const void* z,
                             int z_is_f16, long z_stride, const float* mean, const float* rstd, const void* dy,
                             int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, int pre_zeroed, long rows,
-                            int C, void* stream, void* acc = nullptr, void* counter = nullptr) {
+                            int C, void* stream, void* acc = nullptr, void* counter = nullptr,
+                            const float* dres = nullptr) {
   using namespace nnz;
   if (acc) pre_zeroed = 1;   // dgamma / dbeta are written, not accumulated
   if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (!dz || (z_stride & 3))))
@@ -295,7 +303,7 @@ static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, con
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx;
   a.dgamma = dgamma; a.dbeta = dbeta; a.R = rows; a.C = C;
-  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
+  a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter; a.dres = dres;
   a.z = z; a.dz = dz; a.z_is_f16 = z_is_f16; a.z_stride = z_stride; a.dy_is_f16 = dy_is_f16;
   return x_is_f16 ? ln_dispatch<f16>(a, true, s) : ln_dispatch<float>(a, true, s);
 }
@@ -349,4 +357,16 @@ extern "C" int nnz_layer_norm_gate_backward_det(const void* x, int x_is_f16, con
   if (!z || !acc || !counter) return NNZ_EINVAL;
   return ln_backward_impl(x, x_is_f16, gamma, beta, z, z_is_f16, z_row_stride, mean, rstd, dy, dy_is_f16, dx, dz, dgamma,
                           dbeta, 1, rows, C, stream, acc, counter);
+}
+
+// nnz_layer_norm_backward_det with the residual stream's gradient added into dx (dres: [rows][C] f32, may alias nothing
+// else; null = the plain backward): x -> (LayerNorm(x), x) is how every Swin / VSS block uses its norm, and the two
+// gradients of x meet here instead of in an add launch
+extern "C" int nnz_layer_norm_backward_det_res(const void* x, int x_is_f16, const float* gamma, const float* mean,
+                                               const float* rstd, const void* dy, int dy_is_f16, const float* dres,
+                                               void* dx, float* dgamma, float* dbeta, void* acc, void* counter,
+                                               long rows, int C, void* stream) {
+  if (!acc || !counter) return NNZ_EINVAL;
+  return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dy_is_f16, dx, nullptr, dgamma,
+                          dbeta, 1, rows, C, stream, acc, counter, dres);
 }

@@ -63,6 +63,58 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _LayerNormSkipFn(torch.autograd.Function):
+    """x -> (LayerNorm(x), x) for the pre-norm residual blocks (x + f(norm(x)): swt2net.py:646-659).  The second output is x
+    itself; taking the residual stream from it instead of from the caller's x brings both gradients of x into ONE backward
+    call, where the kernel adds them (nnz_layer_norm_backward_det_res) - autograd's accumulation is an add launch per norm,
+    288 per SwT2Net step.  fp32 contiguous device tensors only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call("nnz_layer_norm_forward", ptr(x), 0, ptr(weight), ptr(bias), ptr(y), 0, ptr(mean), ptr(rstd), None, rows, C,
+             float(eps), stream_ptr())
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)
+        return y, x
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        if dy is None:
+            return dskip, None, None, None
+        x, weight, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dy = _dy(dy)
+        if dskip is not None and (dskip.dtype != torch.float32 or not dskip.is_contiguous()):
+            dskip = dskip.float().contiguous()
+        dx = torch.empty_like(x)
+        dw, db, _ = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, x.device)
+        from .hip_ops import det_scratch
+        sc = det_scratch(x.device, 2 * C)
+        call("nnz_layer_norm_backward_det_res", ptr(x), 0, ptr(weight), ptr(mean), ptr(rstd), ptr(dy),
+             int(dy.dtype == torch.float16), ptr(dskip), ptr(dx), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C,
+             stream_ptr())
+        return dx, dw, db, None
+
+
+def layer_norm_skip(norm: "nn.LayerNorm", x: torch.Tensor):
+    """(norm(x), x) with the two gradients of x summed inside the LayerNorm backward kernel; falls back to (norm(x), x) when
+    the tensor is not an fp32 contiguous device tensor the kernel takes"""
+    C = x.shape[-1]
+    ok = x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and len(norm.normalized_shape) == 1 \
+        and C % 4 == 0 and C <= 2048 and not torch.is_autocast_enabled() and torch.is_grad_enabled() and x.requires_grad \
+        and (norm.weight is None or norm.weight.dtype == torch.float32)
+    if not ok:
+        return norm(x), x
+    return _LayerNormSkipFn.apply(x, norm.weight, norm.bias, norm.eps)
+
+
 def _affine_grads(weight, has_bias, need_w, need_b, C, device, prezeroed=None):
     """dgamma / dbeta as the two rows of one buffer when both are needed (zeroed by the forward launch when `prezeroed`
     is that buffer, else by one launch of the backward).  Returns (dgamma, dbeta, pre_zeroed flag)."""

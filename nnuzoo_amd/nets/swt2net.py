@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..layer_norm import LayerNorm
+from ..layer_norm import LayerNorm, layer_norm_skip
 from ..token_linear import TokenLinear, mlp_gelu
 
 from ..utilities.network_initialization import InitWeights_He
@@ -122,7 +122,12 @@ class PatchMerging(nn.Module):
         _, H, W, _ = x.shape
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
-        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        # torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1) of the reference (swt2net.py:452-456)
+        # as one permuted copy: channel block k = 2 * (column parity) + (row parity).  Same values; the backward is one
+        # strided copy instead of four zero fills, four slice copies and three adds
+        B, H2, W2, C = x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]
+        x = x.view(B, H2, 2, W2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, H2, W2, 4 * C) if x.is_contiguous() else \
+            torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
         return self.reduction(self.norm(x))
 
 
@@ -247,8 +252,10 @@ class SwinTransformerBlock(nn.Module):
         fused = pad and _pad_crop_ok(x, H + py)
         if pad:  # top/left padding, a full extra window on an axis that already divides (reference quirk, :643-645)
             x = _PadCropFn.apply(x, py, px, True) if fused else F.pad(x, (0, 0, px, 0, py, 0))
-        x = self._residual(x, self.attn(self.norm1(x)))
-        x = self._residual(x, self.mlp(self.norm2(x)))
+        n, x = layer_norm_skip(self.norm1, x)       # (norm(x), x): both gradients of x meet inside the norm's backward
+        x = self._residual(x, self.attn(n))
+        n, x = layer_norm_skip(self.norm2, x)
+        x = self._residual(x, self.mlp(n))
         if not pad:
             return x
         return _PadCropFn.apply(x, py, px, False) if fused and x.is_contiguous() else x[:, -H:, -W:, :]

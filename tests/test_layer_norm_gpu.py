@@ -142,3 +142,43 @@ def test_affine_gradients_are_bit_identical_run_to_run(hip_lib):
         assert torch.allclose(outs[0][1].double(), dy.double().sum(0), rtol=1e-4, atol=1e-3)
     sc = det_scratch(torch.device("cuda", 0), 0)
     assert int(sc.acc.abs().max()) == 0 and int(sc.counter.abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 14, 14, 32), (3, 35, 35, 96), (1, 7, 7, 768), (5, 9, 64)])
+def test_layer_norm_skip_sums_both_gradients_in_the_kernel(hip_lib, shape):
+    """layer_norm_skip: (norm(x), x) whose backward adds the residual stream's gradient inside ln_bwd_kernel
+    (nnz_layer_norm_backward_det_res) - against x + f(norm(x)) written with the plain module and autograd's own add;
+    1e-6: the in-kernel sum may contract into an fma.  Also: only one of the two outputs used."""
+    from nnuzoo_amd.layer_norm import LayerNorm, layer_norm_skip
+    torch.manual_seed(0)
+    C = shape[-1]
+    norm = LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x0 = torch.randn(*shape, device="cuda")
+    w = torch.randn(C, C, device="cuda") / C ** 0.5
+    dout = torch.randn(*shape, device="cuda")
+    res = []
+    for fused in (True, False):
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.0                                    # a non-leaf, like the block input
+        n, s = layer_norm_skip(norm, h) if fused else (norm(h), h)
+        if fused:
+            assert type(n.grad_fn).__name__.startswith("_LayerNormSkipFn")
+        out = s + torch.tanh(n @ w)
+        gx, gw, gb = torch.autograd.grad(out, [x, norm.weight, norm.bias], dout)
+        res.append((out.detach(), gx, gw, gb))
+    assert torch.equal(res[0][0], res[1][0])
+    for u, v, name in zip(res[0][1:], res[1][1:], ("dx", "dgamma", "dbeta")):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-6 * max(1.0, v.abs().max().item())), (name, (u - v).abs().max().item())
+    # one output only: the skip alone passes the gradient through, the norm alone is the plain backward
+    x = x0.clone().requires_grad_(True)
+    n, s = layer_norm_skip(norm, x * 1.0)
+    (g1,) = torch.autograd.grad(s, x, dout, retain_graph=True)
+    assert torch.equal(g1, dout)
+    (g2,) = torch.autograd.grad(n, x, dout)
+    x2 = x0.clone().requires_grad_(True)
+    (g3,) = torch.autograd.grad(norm(x2 * 1.0), x2, dout)
+    assert torch.equal(g2, g3)
