@@ -317,8 +317,10 @@ class PatchMerging2D(nn.Module):
         if s != 2:
             raise NotImplementedError("the zoo only merges 2x2 patches")
         # channel order of the reference: (0,0), (1,0), (0,1), (1,1)  (m2net.py:254-267)
-        parts = [x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]]
-        x = torch.cat([p[:, :Hs, :Ws] for p in parts], -1)
+        # = torch.cat of the four strided slices, as ONE permuted copy: channel block k = 2 * (column parity) + (row parity);
+        # the backward is one strided copy instead of four zero fills, four slice copies and three adds
+        x = x[:, :2 * Hs, :2 * Ws].unflatten(2, (Ws, 2)).unflatten(1, (Hs, 2)).permute(0, 1, 3, 4, 2, 5) \
+            .reshape(B, Hs, Ws, 4 * C)
         x = self.reduction(self.norm(x))
         if permute:
             x = x.permute(0, 3, 1, 2).contiguous()
