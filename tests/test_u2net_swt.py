@@ -164,3 +164,52 @@ def test_trainer_steps(hip_lib, trainer):
     assert moved > 0.9 * len(before), (moved, len(before), losses, scale0, scale1)
     if "Swin" in trainer:
         assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 8, 8), (1, 7, 9, 4), (3, 5, 5, 12), (2, 2, 2, 4)])
+def test_patch_merging_gather_is_the_reference_concatenation(shape):
+    """PatchMerging / PatchMerging2D gather the 2x2 neighbourhoods with one permuted copy; the reference concatenates four
+    strided slices (swt2net.py:452-456, m2net.py:254-267: (0,0), (1,0), (0,1), (1,1); odd sizes are padded by the Swin
+    module and truncated by the VSS one).  Same values and same input gradient, including odd sizes and NCHW-permuted input."""
+    import torch.nn.functional as F
+    from nnuzoo_amd.nets.swt2net import PatchMerging
+    from nnuzoo_amd.nets.common2d import PatchMerging2D
+
+    class Probe(torch.nn.Module):          # stands in for norm and reduction: returns what the gather produced
+        def forward(self, x):
+            return x
+
+    g = torch.Generator().manual_seed(4)
+    B, H, W, C = shape
+    x0 = torch.randn(*shape, generator=g)
+
+    def swin_ref(x):
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        return torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1)
+
+    def vss_ref(x):
+        Hs, Ws = H // 2, W // 2
+        return torch.cat([x[:, 0::2, 0::2][:, :Hs, :Ws], x[:, 1::2, 0::2][:, :Hs, :Ws], x[:, 0::2, 1::2][:, :Hs, :Ws],
+                          x[:, 1::2, 1::2][:, :Hs, :Ws]], -1)
+
+    swin = PatchMerging(C)
+    swin.norm, swin.reduction = Probe(), Probe()
+    vss = PatchMerging2D(C, scale=2)
+    vss.norm, vss.reduction = Probe(), Probe()
+    cases = [(swin, swin_ref, False)]
+    if H >= 2 and W >= 2:
+        cases += [(vss, vss_ref, False), (vss, vss_ref, True)]
+    for mod, ref, nchw in cases:
+        a = x0.clone().requires_grad_(True)
+        b = x0.clone().requires_grad_(True)
+        if nchw:       # the module permutes an NCHW tensor itself (non-contiguous token-major view inside)
+            out = mod(a.permute(0, 3, 1, 2).contiguous().requires_grad_(True), permute=True).permute(0, 2, 3, 1)
+            want = ref(b)
+            assert torch.equal(out, want)
+            continue
+        out, want = mod(a), ref(b)
+        assert out.shape == want.shape and torch.equal(out, want)
+        dy = torch.randn(*want.shape, generator=g)
+        (ga,), (gb,) = torch.autograd.grad(out, a, dy), torch.autograd.grad(want, b, dy)
+        assert torch.equal(ga, gb)
