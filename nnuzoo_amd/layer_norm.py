@@ -107,7 +107,8 @@ def layer_norm_skip(norm: "nn.LayerNorm", x: torch.Tensor):
     """(norm(x), x) with the two gradients of x summed inside the LayerNorm backward kernel; falls back to (norm(x), x) when
     the tensor is not an fp32 contiguous device tensor the kernel takes"""
     C = x.shape[-1]
-    ok = x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and len(norm.normalized_shape) == 1 \
+    ok = isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and x.is_cuda and x.dtype == torch.float32 \
+        and x.is_contiguous() and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == C \
         and C % 4 == 0 and C <= 2048 and not torch.is_autocast_enabled() and torch.is_grad_enabled() and x.requires_grad \
         and (norm.weight is None or norm.weight.dtype == torch.float32)
     if not ok:
