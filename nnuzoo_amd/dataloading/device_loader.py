@@ -62,6 +62,46 @@ class DeviceCaseStore:
         return sum(t.numel() * t.element_size() for t in list(self.data.values()) + list(self.seg.values()))
 
 
+def _bbox_bounds(data_shape, patch_size, need_to_pad):
+    """Inclusive range of admissible lower patch corners per axis.  A case smaller than the patch is padded on both sides
+    (the extra voxel of an odd amount goes to the upper side); `need_to_pad` widens the range symmetrically."""
+    shape = np.asarray(data_shape, dtype=np.int64)
+    patch = np.asarray(patch_size, dtype=np.int64)
+    pad = np.maximum(np.asarray(need_to_pad, dtype=np.int64), patch - shape)
+    lo = np.floor_divide(-pad, 2)
+    hi = shape + pad // 2 + pad % 2 - patch
+    return [int(v) for v in lo], [int(v) for v in hi]
+
+
+def _class_to_centre_on(annotated_key, force_fg: bool, class_locations, overwrite_class, verbose: bool):
+    """Which entry of `class_locations` the patch centre is drawn from; None = plain random crop.  Draws from the numpy RNG
+    only when a foreground class has to be chosen among several candidates."""
+    if not force_fg:
+        # only reached with an ignore label: centre on any annotated voxel so that the patch is not all-ignore
+        if len(class_locations[annotated_key]) == 0:
+            warnings.warn('Warning! No annotated pixels in image!')
+            return None
+        return annotated_key
+    assert class_locations is not None, 'if force_fg is set class_locations cannot be None'
+    if overwrite_class is not None:
+        assert overwrite_class in class_locations.keys(), \
+            'desired class ("overwrite_class") does not have class_locations (missing key)'
+    candidates = [k for k, locs in class_locations.items() if len(locs) > 0]
+
+    # the "all annotated voxels" region is a candidate only when nothing else is (keys may be ints or tuples)
+    def is_region_key(k):
+        return isinstance(k, tuple) and k == annotated_key
+    if len(candidates) > 1 and any(is_region_key(k) for k in candidates):
+        candidates = [k for k in candidates if not is_region_key(k)]
+    if not candidates:
+        if verbose:
+            print('case does not contain any foreground classes')
+        return None
+    if overwrite_class is not None and overwrite_class in candidates:
+        return overwrite_class
+    return candidates[np.random.choice(len(candidates))]
+
+
 class nnUNetDataLoader:
     def __init__(self, data: DeviceCaseStore, batch_size: int, initial_patch_size, final_patch_size, label_manager,
                  oversample_foreground_percent: float = 0.0, sampling_probabilities=None, pad_sides=None,
@@ -118,47 +158,21 @@ class nnUNetDataLoader:
         return np.random.choice(self.indices, self.batch_size, replace=True, p=self.sampling_probabilities)
 
     def get_bbox(self, data_shape, force_fg: bool, class_locations, overwrite_class=None, verbose: bool = False):
-        """data_loader.py:102-178, same statements in the same order (the numpy RNG stream is part of the contract)"""
-        need_to_pad = self.need_to_pad.copy()
-        dim = len(data_shape)
-        for d in range(dim):
-            if need_to_pad[d] + data_shape[d] < self.patch_size[d]:
-                need_to_pad[d] = self.patch_size[d] - data_shape[d]
-        lbs = [- need_to_pad[i] // 2 for i in range(dim)]
-        ubs = [data_shape[i] + need_to_pad[i] // 2 + need_to_pad[i] % 2 - self.patch_size[i] for i in range(dim)]
-        if not force_fg and not self.has_ignore:
-            bbox_lbs = [np.random.randint(lbs[i], ubs[i] + 1) for i in range(dim)]
+        """Patch corner rule of data_loader.py:102-178 (bounds, class selection, voxel draw).  The order of the numpy RNG
+        draws is part of the contract - class choice, then voxel choice, or one randint per axis - and is pinned against the
+        reference's own method by tests/golden/dataloader_bbox.json."""
+        lo, hi = _bbox_bounds(data_shape, self.patch_size, self.need_to_pad)
+        axes = range(len(data_shape))
+        centre_class = None
+        if force_fg or self.has_ignore:
+            centre_class = _class_to_centre_on(self.annotated_classes_key, force_fg, class_locations, overwrite_class, verbose)
+        if centre_class is None:
+            corner = [np.random.randint(lo[a], hi[a] + 1) for a in axes]
         else:
-            if not force_fg and self.has_ignore:
-                selected_class = self.annotated_classes_key
-                if len(class_locations[selected_class]) == 0:
-                    warnings.warn('Warning! No annotated pixels in image!')
-                    selected_class = None
-            elif force_fg:
-                assert class_locations is not None, 'if force_fg is set class_locations cannot be None'
-                if overwrite_class is not None:
-                    assert overwrite_class in class_locations.keys(), \
-                        'desired class ("overwrite_class") does not have class_locations (missing key)'
-                eligible = [i for i in class_locations.keys() if len(class_locations[i]) > 0]
-                tmp = [i == self.annotated_classes_key if isinstance(i, tuple) else False for i in eligible]
-                if any(tmp):
-                    if len(eligible) > 1:
-                        eligible.pop(np.where(tmp)[0][0])
-                if len(eligible) == 0:
-                    selected_class = None
-                else:
-                    selected_class = eligible[np.random.choice(len(eligible))] if \
-                        (overwrite_class is None or (overwrite_class not in eligible)) else overwrite_class
-            else:
-                raise RuntimeError('lol what!?')
-            if selected_class is not None:
-                voxels = class_locations[selected_class]
-                selected_voxel = voxels[np.random.choice(len(voxels))]
-                bbox_lbs = [max(lbs[i], selected_voxel[i + 1] - self.patch_size[i] // 2) for i in range(dim)]
-            else:
-                bbox_lbs = [np.random.randint(lbs[i], ubs[i] + 1) for i in range(dim)]
-        bbox_ubs = [bbox_lbs[i] + self.patch_size[i] for i in range(dim)]
-        return bbox_lbs, bbox_ubs
+            locs = class_locations[centre_class]
+            voxel = locs[np.random.choice(len(locs))]          # (channel, *spatial): spatial index a sits at a + 1
+            corner = [max(lo[a], voxel[a + 1] - self.patch_size[a] // 2) for a in axes]
+        return corner, [corner[a] + self.patch_size[a] for a in axes]
 
     # ---- the batch ----------------------------------------------------------------------------------------------------------
     def _draw_flips(self) -> List[int]:
