@@ -115,14 +115,23 @@ class NormScratch:
 
 
 _SCRATCH = {}
+_SCRATCH_RETIRED = []   # outgrown scratches stay alive: captured hipGraphs have their `acc` / `counter` pointers baked in
 
 
 def det_scratch(device, records: int = 0) -> NormScratch:
-    """the device's shared scratch of the deterministic reductions (loss sums, gradient norm, ...): launches on one stream
-    use it one after the other and each leaves it zeroed; grows on demand"""
+    """The device's shared scratch of the deterministic reductions (loss sums, gradient norm, ...).  Single-stream contract:
+    launches on ONE stream use it one after the other and each leaves it zeroed (the last-workgroup ticket and the records are
+    shared, so two streams using it concurrently would corrupt each other's sums).  Grows on demand; an outgrown scratch is
+    never freed (a captured graph may still write to it) and growing while a stream is capturing is refused - the capture
+    would record pointers of a buffer whose zero-initialisation is not part of the graph."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     sc = _SCRATCH.get(key)
     if sc is None or sc.capacity * 2 < records:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"det_scratch: {records} records requested during hipGraph capture but the device scratch "
+                               f"holds {0 if sc is None else sc.capacity * 2}; run one eager warm-up pass first")
+        if sc is not None:
+            _SCRATCH_RETIRED.append(sc)
         sc = NormScratch(device, max((records + 1) // 2, 4096))
         _SCRATCH[key] = sc
     return sc

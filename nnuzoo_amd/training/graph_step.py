@@ -57,6 +57,7 @@ class GraphedForwardBackward:
         self.memset_nodes_replaced = 0
         self._key = None
         self._static_grads = []        # [(parameter, the .grad tensor the captured backward writes)]
+        self._static_arena = None      # explicit-schedule networks: (arena, layout, unused ids) the captured backward fills
 
     def _loss(self, out, target):
         if isinstance(out, (tuple, list)):
@@ -100,6 +101,13 @@ class GraphedForwardBackward:
         # every replay; whatever happens to p.grad between replays (optimizer.zero_grad(set_to_none=True), an eager step
         # in between, user hooks), __call__ re-attaches them so that clip / optimizer never see None or a stale buffer
         self._static_grads = [(p, p.grad) for p in params if p.grad is not None]
+        # Networks with an explicit backward schedule (PlainConvUNet) publish their gradients through a flat arena that the
+        # Python side of `_run_backward` registers on the module (`_last_arena` & co).  A replay runs no Python, so after an
+        # EAGER step in between (use_hip_graph toggled, a validation pass with gradients, ...) the module would still point
+        # at that eager pass's arena while the replay fills the captured one - FusedSGD would then apply stale gradients.
+        # The captured arena is therefore remembered here and re-registered after every replay.
+        if hasattr(self.network, "grad_arena") and self.network.grad_arena() is not None:
+            self._static_arena = (self.network._last_arena, self.network._arena_layout, self.network._last_unused)
         self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
 
     def __call__(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
@@ -114,4 +122,7 @@ class GraphedForwardBackward:
         for p, g in self._static_grads:
             if p.grad is not g:
                 p.grad = g
+        if self._static_arena is not None:
+            net = self.network
+            net._last_arena, net._arena_layout, net._last_unused = self._static_arena
         return self.static_loss

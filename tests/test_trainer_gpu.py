@@ -192,3 +192,33 @@ def test_graph_replayed_steps_equal_eager_steps_bit_for_bit(hip_lib):
     assert le == lg, (le, lg)
     assert all(torch.equal(a, b) for a, b in zip(pe, pg))
     assert len(me) == len(mg) and all(torch.equal(a, b) for a, b in zip(me, mg))
+
+
+def test_graph_and_eager_steps_alternate_with_fused_sgd(hip_lib):
+    """FusedSGD reads the gradients from `network.grad_arena()`.  A graph replay runs no Python, so after an eager
+    step in between the module still pointed at the EAGER pass's arena while the replay filled the captured one - the update
+    was then computed from stale gradients.  GraphedForwardBackward re-registers the captured arena after every replay: steps
+    alternating graph / eager / graph / ... must equal an all-eager run bit for bit (all kernels are deterministic)."""
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+    from nnuzoo_amd.training.fused_sgd import FusedSGD
+
+    def run(pattern):
+        plans, cfg, dj = nnunet_plans(3, (32, 32, 32), batch_size=2)
+        torch.manual_seed(0)
+        tr = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+        tr.initialize()
+        assert isinstance(tr.optimizer, FusedSGD)
+        losses = []
+        for i, g in enumerate(pattern):
+            tr.use_hip_graph = g
+            b = synthetic_batch(2, (32, 32, 32), tr._get_deep_supervision_scales(), seed=20 + i)
+            b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+            losses.append(float(tr.train_step(b)["loss"]))
+        return losses, [p.detach().clone() for p in tr.network.parameters()], tr
+
+    le, pe, _ = run([False] * 6)
+    lg, pg, tr = run([True, True, False, True, False, True])
+    assert tr._graphed is not None and tr._graphed.graph is not None
+    assert le == lg, (le, lg)
+    assert all(torch.equal(a, b) for a, b in zip(pe, pg))
