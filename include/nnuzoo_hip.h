@@ -501,6 +501,37 @@ int nnz_global_attention_forward(const float* qkv, float* out, float* lse, int B
 int nnz_global_attention_backward(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
                                   int B, int L, int H, int D, float scale, void* stream);
 
+/* ---- consumer-side InstanceNorm + LeakyReLU (round 4): "conv + norm + act fused" --------------------------------------------
+ * The reference op sequence of every PlainConvUNet block is Conv -> InstanceNorm(affine) -> LeakyReLU
+ * (nnunetv2/experiment_planning/experiment_planners/default_experiment_planner.py:285-305).  The statistics need the whole
+ * volume, so the producer cannot normalise its own tiles; instead every CONSUMER of a block's activation takes the block's RAW
+ * fp16 conv output plus its table nstat[N][C][4] = {mean, rstd, scale, shift} (written by the producer launch's last workgroup,
+ * nnz_conv_tap_forward_norm*) and applies y = lrelu(x * scale + shift) while it stages its operand - fp32 FMA, LeakyReLU, ONE
+ * rounding to fp16: bit for bit what nnz_instnorm_lrelu_apply_tab would have written.  The activated tensor never exists in HBM
+ * (one write and one read of every activation less per forward pass, the `act` buffers gone).  Zero padding stays zero.
+ *   tab == NULL selects the plain behaviour where the comment says so.  c0: channels [0, c0) of the operand are used as they are
+ *   (a cat buffer's transposed-conv half); tab then holds C - c0 channels per sample. */
+int nnz_conv_tap_forward_innorm(const void* in_raw_f16, void* out_f16, const void* w_packed_f16, const float* bias,
+                                const nnz_conv_desc* desc, const float* in_tab, int in_c0 /* % 16 == 0 */, float in_slope,
+                                void* acc, void* counter, const float* gamma, const float* beta, float eps,
+                                float* nstat /* acc .. nstat: all NULL = no statistics of the output */,
+                                float* workspace /* may be NULL */, long ws_floats, void* stream);
+/* weight gradient with raw operands: boxed = the layer input of a convolution, plain = the lower-resolution activation of a
+ * transposed convolution; either table may be NULL (operand used as is); c0 % 32 == 0; N <= 64 */
+int nnz_conv_tap_wgrad_to_grad_innorm(const void* boxed_f16, const void* plain_f16, float* workspace, long ws_floats, float* grad,
+                                      long sa, long sb, long sk, const int* ksel, int accumulate, const nnz_conv_desc* desc,
+                                      const float* boxed_tab, int boxed_c0, float boxed_slope, const float* plain_tab,
+                                      int plain_c0, float plain_slope, void* stream);
+/* 1x1 segmentation head and its weight gradient on the raw output of the stage's last block (in_tab NULL = plain entry points) */
+int nnz_seg_head_forward_innorm(const void* x_raw_f16, const float* in_tab, float in_slope, const float* w, const float* bias,
+                                void* logits_f16_nc, int N, long V, int C, int K, int ldx, void* stream);
+int nnz_seg_head_wgrad_innorm(const void* x_raw_f16, const float* in_tab, float in_slope, const void* dlogits_f16, float* dw,
+                              float* db, int N, long V, int C, int K, int ldx, void* acc, void* counter, void* stream);
+/* kernel = stride transposed convolution (full-resolution stages) on the raw output of the block below */
+int nnz_convT_forward_innorm(const void* in_raw_f16, const float* in_tab, float in_slope, const float* W, const float* bias,
+                             void* out, int N, int Di, int Hi, int Wi, int Cin, int Cout, int sd, int sh, int sw, int ldi, int ldo,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,6 +162,19 @@ def conv_wgrad(N, in_dims, Cin, Cout, ks=(3, 3, 3), stride=1, ldx=None, lddy=Non
     return t
 
 
+def conv_wgrad_flipped(N, in_dims, Cin, Cout, ks=(3, 3, 3), ldx=None, lddy=None, dilation=1) -> TapTable:
+    """The same weight gradient of a STRIDE-1 convolution with the operand roles exchanged:
+        dW[k][ci][co] = sum_i X[i][ci] dY[i - (k - ks//2) * dil][co]        boxed = dY (A = Cout), plain = X (B = Cin)
+    (substitute i = o + off; out-of-range dY positions contribute nothing, exactly like the zero padding of X in the
+    direct form).  The result block is dW[widx][co][ci].  Used when X is a RAW conv output that the kernel normalises while
+    staging (round 4): the plain operand has no halo, so every voxel of X is normalised once per tile instead of 2.3 times."""
+    ks = _triple(ks)
+    t = conv_forward(N, in_dims, Cout, Cin, ks, 1, ldi=lddy or Cout, ldo=ldx or Cin, dilation=dilation)
+    (ooff, taps), = t.groups
+    t.groups = [(ooff, [(tuple(-o for o in off), widx) for off, widx in taps])]
+    return t
+
+
 def convT_forward(N, in_dims, Cin, Cout, ldi=None, ldo=None, stride=2) -> TapTable:
     """ConvTranspose(kernel = stride, per axis 1 or 2): out[s*m + p] = bias + sum_ci in[m] W[ci][co][p];
     prod(stride) one-tap groups."""

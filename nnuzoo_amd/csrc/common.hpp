@@ -66,6 +66,44 @@ __device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v) {
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// InstanceNorm(affine) + LeakyReLU of 8 fp16 channels (one 16-byte piece) with torch-autocast rounding points: the
+// normalisation y = x * scale + shift is one fp32 FMA rounded ONCE to fp16 (what nn.InstanceNorm3d hands on under autocast),
+// LeakyReLU then acts on the fp16 value, max(y, y * slope) in packed fp16 (slope in [0, 1]).  16 VALU operations per piece:
+// v_fma_mixlo/hi_f16 take the fp16 element and the fp32 {scale, shift} pair directly (no conversions), then v_pk_mul_f16 +
+// v_pk_max_f16 on channel pairs.  EVERY place that applies the norm - the apply pass of norm_act.hip and the consumers that
+// normalise raw conv outputs while staging them (conv_fprop / conv_wgrad / conv_stem_head / conv_transpose) - goes through
+// this function, so they all produce the same bits.  (The first consumer-side version converted to fp32, used a select
+// for LeakyReLU and converted back: 36 operations per piece in the staging path cost more than the apply pass it removed.)
+typedef _Float16 nnz_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned norm_lrelu_pair(unsigned x, float s0, float t0, float s1, float t1, nnz_h2 slope2) {
+  unsigned y;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(y) : "v"(x), "v"(s0), "v"(t0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(y) : "v"(x), "v"(s1), "v"(t1));
+  const nnz_h2 h = __builtin_bit_cast(nnz_h2, y);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, h * slope2));
+}
+// sc / sh: the piece's 8 {scale, shift} values; slope2 = {slope, slope} as fp16
+template <class V4>
+__device__ __forceinline__ V4 norm_lrelu8(V4 r, const float (&sc)[8], const float (&sh)[8], nnz_h2 slope2) {
+  V4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = norm_lrelu_pair(r[q], sc[2 * q], sh[2 * q], sc[2 * q + 1], sh[2 * q + 1], slope2);
+  return o;
+}
+// the same with the pairs as they lie in a [c]{scale, shift} fp32 table: 16 consecutive floats at `tp` (16-byte aligned)
+template <class V4>
+__device__ __forceinline__ V4 norm_lrelu8_tab(V4 r, const float* tp, nnz_h2 slope2) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  V4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f4 t = *reinterpret_cast<const f4*>(tp + 4 * q);
+    o[q] = norm_lrelu_pair(r[q], t[0], t[1], t[2], t[3], slope2);
+  }
+  return o;
+}
+__device__ __forceinline__ nnz_h2 slope_pair(float slope) { return nnz_h2{(_Float16)slope, (_Float16)slope}; }
+
 // XCD-aware bijective remap of a linear workgroup id: blocks that are neighbours in the remapped
 // order share an XCD (and its L2).  cdna_hip_programming.md §5.5 T1 (bijective variant).
 __device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {

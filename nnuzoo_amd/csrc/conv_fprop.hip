@@ -74,6 +74,17 @@ struct ConvDev {
   int tiles[3];
   int gx, gy, gz;
   int cout_fastest;  // workgroup order: cout block index fastest (1) or m-tile index fastest (0)
+  // Consumer-side InstanceNorm + LeakyReLU (nnz_conv_tap_forward_innorm): `in` is the RAW conv output of the producer block(s)
+  // and is normalised while the box is staged, y = lrelu(x * scale + shift) with {scale, shift} = in_tab[n][c - in_c0][2..3]
+  // (the producer's table, written by its own launch's last workgroup); channels [0, in_c0) - the transposed-conv half of a
+  // cat buffer - pass unchanged.  The separate apply pass (norm_act.hip MODE 1: one read + one write of every activation)
+  // and the activated tensor itself disappear; the arithmetic is that pass's (common.hpp norm_lrelu8: fp32 FMA rounded to
+  // fp16, LeakyReLU in fp16), so the box holds the same bits the materialised activation would.  Padding voxels stay zero (the reference pads the
+  // ACTIVATION with zeros).
+  const float* in_tab;
+  int in_c0;
+  float in_slope;
+  int intab_off;   // byte offset of the LDS table (launcher)
 };
 
 // Box geometry policies.  GeoIso: input stride and tap extent are compile-time and equal on the three axes (the
@@ -281,7 +292,22 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   u32x4 breg[LPT_BOX];
   u32x4 wreg[C::LPT_W];
   const int nkc = Cin >> 4;
-
+  // consumer-side norm: {scale, shift} of a slice's 16 channels live in a two-slot LDS table behind box + weights.  Threads
+  // 0..15 fetch slice kc + 1's pairs one slice ahead (tabreg) and drop them into slot (kc + 1) & 1 while everybody stages
+  // slice kc from slot kc & 1 - two barriers separate every write of a slot from its reads, no extra barrier needed.
+  float* intab = reinterpret_cast<float*>(smem + p.intab_off);
+  f32x2 tabreg = {1.f, 0.f};
+  auto load_tab = [&](int kc) {
+    if (p.in_tab && tid < 16) {
+      const int c = kc * 16 + tid;
+      tabreg = f32x2{1.f, 0.f};
+      if (c >= p.in_c0)
+        tabreg = *reinterpret_cast<const f32x2*>(p.in_tab + ((size_t)n * (Cin - p.in_c0) + (c - p.in_c0)) * 4 + 2);
+    }
+  };
+  auto store_tab = [&](int kc) {
+    if (p.in_tab && tid < 16) *reinterpret_cast<f32x2*>(intab + (kc & 1) * 32 + 2 * tid) = tabreg;
+  };
   auto issue_loads = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i) {
@@ -302,7 +328,38 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
       wreg[i] = v;
     }
   };
-  auto write_lds = [&]() {
+  // Consumer-side norm of the staged pieces between the slice's two barriers, CHANNEL PAIR by channel pair (every piece of a
+  // thread holds the same 8 channels of the slice: c = tid + 256 i -> half = tid & 1; dword q of every piece = channels 2q,
+  // 2q + 1 of that half): one 16-byte table read per pair, then 4 VALU operations per piece (common.hpp norm_lrelu_pair).
+  // Padding pieces are normalised like the others and zeroed again when the box is not interior.
+  // Measured alternatives (tools/bench_conv_layers.py --innorm, 32 -> 32 @128^3 forward, 0.291 ms without the norm): fp32
+  // convert / select / convert arithmetic between the barriers 0.34 ms; this form +8 %; the same work moved INSIDE the MFMA
+  // loop of the previous slice - piece by piece (+15 %) or as a software pipeline over the loop's last steps with the table
+  // read one step ahead (+13 %) - is slower than between the barriers: the loop is issue-bound per wave (two waves per SIMD,
+  // LDS fragment reads + MFMAs back to back), so every extra instruction costs its issue slot wherever it sits, and inside
+  // the loop it also lengthens the read -> MFMA dependency chains.
+  auto norm_pair = [&](int kc, int q) {
+    const f32x4 tq = *reinterpret_cast<const f32x4*>(intab + (kc & 1) * 32 + (tid & 1) * 16 + 4 * q);
+    const nnz_h2 sl = slope_pair(kc * 16 < p.in_c0 ? 1.f : p.in_slope);
+#pragma unroll
+    for (int i = 0; i < LPT_BOX; ++i) breg[i][q] = norm_lrelu_pair(breg[i][q], tq[0], tq[1], tq[2], tq[3], sl);
+  };
+  bool padded_box;   // some piece of this thread's box lies outside the volume (uniform over the workgroup's tile)
+  {
+    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = m0w * ISW + p.d.lo[2];
+    padded_box = lod < 0 || loh < 0 || low < 0 || lod + bg.BD > Di || loh + bg.BH > Hi || low + bg.BW > Wi;
+  }
+  auto write_lds = [&](int kc) {
+    if (p.in_tab) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) norm_pair(kc, q);
+      if (padded_box) {
+#pragma unroll
+        for (int i = 0; i < LPT_BOX; ++i)
+          if (box_goff[i] < 0) breg[i] = u32x4{0u, 0u, 0u, 0u};
+      }
+      store_tab(kc + 1);
+    }
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i)
       if (box_loff[i] >= 0) *reinterpret_cast<u32x4*>(box + box_loff[i]) = breg[i];
@@ -411,11 +468,15 @@ __global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
   const int kc0 = p.nsplit > 1 ? split * p.kper : 0;
   const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
   issue_loads(kc0);
+  load_tab(kc0);
+  store_tab(kc0);
+  if (kc0 + 1 < kc1) load_tab(kc0 + 1);
   for (int kc = kc0; kc < kc1; ++kc) {
     __syncthreads();  // all waves finished reading the previous slice
-    write_lds();
+    write_lds(kc);
     __syncthreads();
     if (kc + 1 < kc1) issue_loads(kc + 1);
+    if (kc + 2 < kc1) load_tab(kc + 2);
 
     if constexpr (DRE) {
       // Software pipeline by half rows: the reads of the NEXT half are issued as a group before the six MFMAs of the
@@ -872,6 +933,11 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
     const int need = C::OUT_BYTES + (256 / (NB * 4)) * (2 * NB * 32) * 4;
     lds = lds > need ? lds : need;
   }
+  p.intab_off = (bg.BOX_BYTES + wbytes + 15) & ~15;
+  if (p.in_tab) {
+    const int need = p.intab_off + 2 * 16 * 8;
+    lds = lds > need ? lds : need;
+  }
   if (lds > 160 * 1024) return NNZ_EINVAL;
   p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
   p.tiles[1] = (p.d.m_dims[1] + TH - 1) / TH;
@@ -1009,10 +1075,16 @@ struct NormRedArgs {  // see ConvDev::bx
   float slope;
   int ldbx;
 };
+struct InNormArgs {  // see ConvDev::in_tab
+  const float* tab;
+  int c0;
+  float slope;
+};
 static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
                                  const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
                                  const float* gamma, const float* beta, float eps, float* nstat, void* stream,
-                                 float* workspace = nullptr, long ws_floats = 0, const NormRedArgs* nr = nullptr);
+                                 float* workspace = nullptr, long ws_floats = 0, const NormRedArgs* nr = nullptr,
+                                 const InNormArgs* inn = nullptr);
 
 extern "C" int nnz_conv_tuning(int knob, int value) {
   if (knob < 0 || knob >= 8) return NNZ_EINVAL;
@@ -1075,14 +1147,36 @@ extern "C" int nnz_conv_tap_dgrad_normred(const void* in, void* out, const void*
                                nullptr, stream, nullptr, 0, &nr);
 }
 
+// Forward convolution whose INPUT is the raw (pre-norm) conv output of the producer block: InstanceNorm(affine) + LeakyReLU
+// are applied while the input box is staged (ConvDev::in_tab), so the activated tensor never exists in HBM - the consumer
+// side of the "conv + norm + act" fusion (reference op sequence Conv -> InstanceNorm -> LeakyReLU,
+// /root/reference/nnunetv2/experiment_planning/experiment_planners/default_experiment_planner.py:285-305).
+//   in_tab   [N][Cin - in_c0][4]   the producer's table {mean, rstd, scale, shift} (nnz_conv_tap_forward_norm* output)
+//   in_c0    channels [0, in_c0) of `in` are used as they are (cat buffer: transposed-conv half), multiple of 16
+//   in_slope LeakyReLU slope of the producer block
+// acc / counter / gamma / beta / nstat as in nnz_conv_tap_forward_norm_ws (all NULL: no statistics of the output, e.g. the
+// one-tap groups of a transposed convolution); workspace as in nnz_conv_tap_forward_ws.
+extern "C" int nnz_conv_tap_forward_innorm(const void* in, void* out, const void* w_packed, const float* bias,
+                                           const nnz_conv_desc* desc, const float* in_tab, int in_c0, float in_slope,
+                                           void* acc, void* counter, const float* gamma, const float* beta, float eps,
+                                           float* nstat, float* workspace, long ws_floats, void* stream) {
+  if (!in_tab) return NNZ_EINVAL;
+  const bool any = acc || counter || gamma || beta || nstat;
+  if (any && (!acc || !counter || !gamma || !beta || !nstat)) return NNZ_EINVAL;
+  InNormArgs inn = {in_tab, in_c0, in_slope};
+  return conv_tap_forward_impl(in, out, w_packed, bias, desc, nullptr, acc, (unsigned*)counter, gamma, beta, eps, nstat, stream,
+                               workspace, ws_floats, nullptr, &inn);
+}
+
 extern "C" int nnz_fxacc_bytes(void) { return (int)sizeof(nnz::FxAcc) * nnz::FX_REP; }
 
 static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed, const float* bias,
                                  const nnz_conv_desc* desc, float* stats, void* acc, unsigned* counter,
                                  const float* gamma, const float* beta, float eps, float* nstat, void* stream,
-                                 float* workspace, long ws_floats, const NormRedArgs* nr) {
+                                 float* workspace, long ws_floats, const NormRedArgs* nr, const InNormArgs* inn) {
   using namespace nnz;
   if (!in || !out || !w_packed || !desc) return NNZ_EINVAL;
+  if (inn && inn->tab && (inn->c0 < 0 || inn->c0 % 16 || inn->c0 >= desc->Cin)) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
   // fused statistics: plain forward convolutions only (one group, output written once, unit output stride)
   if ((stats || acc) && !nr &&
@@ -1135,6 +1229,10 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
     p.slope = nr ? nr->slope : 0.f;
     p.ldbx = nr ? nr->ldbx : 0;
     p.dbg = g_tuning[6];
+    p.in_tab = inn && inn->tab ? inn->tab + (size_t)n0 * (d.Cin - inn->c0) * 4 : nullptr;
+    p.in_c0 = inn ? inn->c0 : 0;
+    p.in_slope = inn ? inn->slope : 0.f;
+    p.intab_off = 0;
     p.part = workspace;
     p.ws_floats = workspace ? ws_floats : 0;
     p.nsplit = 1;

@@ -238,7 +238,26 @@ struct HeadArgs {
   int Ktot, k0;      // weight-gradient launches cover classes k0 .. k0 + K - 1 of Ktot
   FxAcc* acc;        // deterministic weight gradient: K * C + K fixed-point accumulators (common.hpp) + launch counter
   unsigned* counter;
+  // consumer-side InstanceNorm + LeakyReLU (nnz_seg_head_forward_innorm / nnz_seg_head_wgrad_innorm): x is the RAW conv
+  // output of the decoder stage's last block; every 16-byte piece is normalised right after its load with the block's table
+  // in_tab[N][C][4] = {mean, rstd, scale, shift} - y = lrelu(x * scale + shift), rounded once to fp16 like the apply pass of
+  // norm_act.hip - so the activated tensor is never written.  The forward launches then take one sample per grid row.
+  const float* in_tab;
+  float in_slope;
 };
+
+// the thread's 8 channels of sample n: scale / shift registers
+__device__ __forceinline__ void head_tab8(const HeadArgs& a, long n, int c0, float (&sc)[8], float (&sh)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x2 t = *reinterpret_cast<const f32x2*>(a.in_tab + ((size_t)n * a.C + c0 + i) * 4 + 2);
+    sc[i] = t[0];
+    sh[i] = t[1];
+  }
+}
+__device__ __forceinline__ f16x8 head_norm8(f16x8 h, const float (&sc)[8], const float (&sh)[8], float slope) {
+  return __builtin_bit_cast(f16x8, norm_lrelu8(__builtin_bit_cast(u32x4, h), sc, sh, slope_pair(slope)));
+}
 
 template <int MAXK>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
@@ -253,7 +272,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
     for (int k = 0; k < MAXK; ++k) acc[k] = (k < a.K && a.b) ? a.b[k] : 0.f;
     const f16* xp = a.x + row * a.ldx;
     for (int c8 = 0; c8 < a.C; c8 += 8) {
-      const f16x8 h = *reinterpret_cast<const f16x8*>(xp + c8);
+      f16x8 h = *reinterpret_cast<const f16x8*>(xp + c8);
+      if (a.in_tab) {   // (this kernel serves the C = 320 levels: a few hundred rows)
+        float sc[8], sh[8];
+        head_tab8(a, n, c8, sc, sh);
+        h = head_norm8(h, sc, sh, a.in_slope);
+      }
 #pragma unroll
       for (int k = 0; k < MAXK; ++k)
         if (k < a.K) {
@@ -321,13 +345,21 @@ __global__ __launch_bounds__(256) void head_fwd_cg_kernel(HeadArgs a, int cgs) {
   float bias[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) bias[k] = a.b ? a.b[k] : 0.f;
-  const long total = (long)a.N * a.V;
-  for (long row0 = (long)blockIdx.x * rows * HD_UNR; row0 < total; row0 += (long)gridDim.x * rows * HD_UNR) {
+  // consumer-side norm: grid row = sample, the thread's {scale, shift} pairs stay in registers
+  float sc[8], sh[8];
+  if (a.in_tab) head_tab8(a, blockIdx.y, cg * 8, sc, sh);
+  const long base = a.in_tab ? (long)blockIdx.y * a.V : 0;
+  const long total = a.in_tab ? base + a.V : (long)a.N * a.V;
+  for (long row0 = base + (long)blockIdx.x * rows * HD_UNR; row0 < total; row0 += (long)gridDim.x * rows * HD_UNR) {
     f16x8 h[HD_UNR];
 #pragma unroll
     for (int u = 0; u < HD_UNR; ++u) {
       const long row = row0 + u * rows + r;
       if (row < total) h[u] = *reinterpret_cast<const f16x8*>(a.x + row * a.ldx + cg * 8);
+    }
+    if (a.in_tab) {
+#pragma unroll
+      for (int u = 0; u < HD_UNR; ++u) h[u] = head_norm8(h[u], sc, sh, a.in_slope);
     }
 #pragma unroll
     for (int u = 0; u < HD_UNR; ++u) {
@@ -417,6 +449,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
   if (r < rows) {
     const f16* xp = a.x + (long)n * a.V * a.ldx + cg * 8;
     const f16* gp = a.dl + ((long)n * a.Ktot + a.k0) * a.V;
+    float sc[8], sh[8];
+    if (a.in_tab) head_tab8(a, n, cg * 8, sc, sh);
     for (long v = v0 + r; v < v1; v += (long)rows * HD_UNR) {
       // HD_UNR rows in flight per thread (one 16-byte load + K 2-byte loads each): the loop was latency-bound
       f16x8 h[HD_UNR];
@@ -429,6 +463,10 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int vpb) {
 #pragma unroll
           for (int k = 0; k < K; ++k) gk[u][k] = (float)gp[(long)k * a.V + vv];
         }
+      }
+      if (a.in_tab) {
+#pragma unroll
+        for (int u = 0; u < HD_UNR; ++u) h[u] = head_norm8(h[u], sc, sh, a.in_slope);
       }
 #pragma unroll
       for (int u = 0; u < HD_UNR; ++u) {
@@ -531,9 +569,10 @@ static inline bool head_cg_ok(int C) {
 template <int K>
 static void launch_head_fwd_cg(const HeadArgs& a, hipStream_t s) {
   const int cgs = a.C >> 3, rows = 256 / cgs;
-  long blocks = ((long)a.N * a.V + rows * HD_UNR - 1) / (rows * HD_UNR);
+  const long nrows = a.in_tab ? a.V : (long)a.N * a.V;   // consumer-side norm: one sample per grid row
+  long blocks = (nrows + rows * HD_UNR - 1) / (rows * HD_UNR);
   if (blocks > 8192) blocks = 8192;
-  NNZ_LAUNCH(head_fwd_cg_kernel<K>, dim3((int)blocks), dim3(256), 0, s, a, cgs);
+  NNZ_LAUNCH(head_fwd_cg_kernel<K>, dim3((int)blocks, a.in_tab ? a.N : 1), dim3(256), 0, s, a, cgs);
 }
 template <int K>
 static void launch_head_dgrad_cg(const HeadArgs& a, int accumulate, hipStream_t s) {
@@ -555,11 +594,23 @@ static void launch_head_dgrad_cg(const HeadArgs& a, int accumulate, hipStream_t 
   }
 }  // namespace nnz
 
+extern "C" int nnz_seg_head_forward_innorm(const void* x_raw, const float* in_tab, float in_slope, const float* w,
+                                           const float* bias, void* logits, int N, long V, int C, int K, int ldx,
+                                           void* stream);
 extern "C" int nnz_seg_head_forward(const void* x, const float* w, const float* bias, void* logits, int N, long V,
                                     int C, int K, int ldx, void* stream) {
+  return nnz_seg_head_forward_innorm(x, nullptr, 0.f, w, bias, logits, N, V, C, K, ldx, stream);
+}
+
+// 1x1 segmentation head on the RAW conv output of the decoder stage's last block: InstanceNorm + LeakyReLU are applied to
+// every piece as it is loaded (HeadArgs::in_tab); in_tab == NULL is nnz_seg_head_forward.
+extern "C" int nnz_seg_head_forward_innorm(const void* x, const float* in_tab, float in_slope, const float* w,
+                                           const float* bias, void* logits, int N, long V, int C, int K, int ldx,
+                                           void* stream) {
   using namespace nnz;
   if (!x || !w || !logits || K < 1 || K > HD_MAXK || C % 8 || ldx % 8) return NNZ_EINVAL;
   HeadArgs a = {};
+  a.in_tab = in_tab; a.in_slope = in_slope;
   a.x = (const f16*)x; a.w = w; a.b = bias; a.logits = (f16*)logits;
   a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;
   if (head_cg_ok(C) && K <= 8) {
@@ -608,6 +659,9 @@ extern "C" int nnz_seg_head_dgrad(const void* dlogits, const float* w, void* dx,
 
 extern "C" int nnz_seg_head_wgrad_det(const void* x, const void* dlogits, float* dw, float* db, int N, long V, int C,
                                       int K, int ldx, void* acc, void* counter, void* stream);
+extern "C" int nnz_seg_head_wgrad_innorm(const void* x_raw, const float* in_tab, float in_slope, const void* dlogits,
+                                         float* dw, float* db, int N, long V, int C, int K, int ldx, void* acc,
+                                         void* counter, void* stream);
 extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw, float* db, int N, long V, int C, int K,
                                   int ldx, void* stream) {
   return nnz_seg_head_wgrad_det(x, dlogits, dw, db, N, V, C, K, ldx, nullptr, nullptr, stream);
@@ -617,10 +671,18 @@ extern "C" int nnz_seg_head_wgrad(const void* x, const void* dlogits, float* dw,
 // them dw / db are bit-identical run to run (no float atomics) and need no zero fill
 extern "C" int nnz_seg_head_wgrad_det(const void* x, const void* dlogits, float* dw, float* db, int N, long V, int C,
                                       int K, int ldx, void* acc, void* counter, void* stream) {
+  return nnz_seg_head_wgrad_innorm(x, nullptr, 0.f, dlogits, dw, db, N, V, C, K, ldx, acc, counter, stream);
+}
+
+// ... with x the RAW conv output of the stage's last block (HeadArgs::in_tab); in_tab == NULL is nnz_seg_head_wgrad_det
+extern "C" int nnz_seg_head_wgrad_innorm(const void* x, const float* in_tab, float in_slope, const void* dlogits, float* dw,
+                                         float* db, int N, long V, int C, int K, int ldx, void* acc, void* counter,
+                                         void* stream) {
   using namespace nnz;
   if (!x || !dlogits || !dw || !db || K < 1 || K > HD_MAXK || C % 8 || C > 640 || ldx % 8 || (!acc != !counter))
     return NNZ_EINVAL;
   HeadArgs a = {};
+  a.in_tab = in_tab; a.in_slope = in_slope;
   a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.x = (const f16*)x; a.dl = (const f16*)dlogits; a.dw = dw; a.db = db;
   a.N = N; a.V = V; a.C = C; a.K = K; a.ldx = ldx;

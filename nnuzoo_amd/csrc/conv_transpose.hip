@@ -24,6 +24,12 @@ struct ConvTArgs {
   f16* out;           // fwd: [N][Vout][ldo] (Cout ch);  dgrad: dIn [N][Vin][ldo] (Cin ch)
   int N, Di, Hi, Wi, Cin, Cout, sd, sh, sw, ldi, ldo;
   long ntiles;        // ceil(N * Vin / 32)
+  // forward only - consumer-side InstanceNorm + LeakyReLU (nnz_convT_forward_innorm): `in` is the RAW conv output of the
+  // block below; its table in_tab[N][Cin][4] = {mean, rstd, scale, shift} is staged as [N][Cin] {scale, shift} pairs in LDS
+  // and every B fragment is normalised in registers (fp32 FMA, LeakyReLU, one rounding to fp16 - the bits the apply pass of
+  // norm_act.hip would have written)
+  const float* in_tab;
+  float in_slope;
 };
 
 constexpr int CT_PAD = 8;   // f16 of padding per staged output row
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTArgs a) {
   f16* sOut = reinterpret_cast<f16*>(ct_lds + (size_t)nfrag * 16);           // [4 waves][32][pitch]
   long* sOv = reinterpret_cast<long*>(sOut + 4 * 32 * pitch);               // [4 waves][32] output voxel of each column
   float* sBias = reinterpret_cast<float*>(sOv + 4 * 32);                     // [Cout] (fwd)
+  float* sTab = sBias + a.Cout;                                              // [N][Cin][2] (fwd, consumer-side norm)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hh = lane >> 5;
 
@@ -89,6 +96,9 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTArgs a) {
   }
   if (!DGRAD)
     for (int c = tid; c < a.Cout; c += 256) sBias[c] = a.bias ? a.bias[c] : 0.f;
+  if (!DGRAD && a.in_tab)
+    for (int i = tid; i < a.N * a.Cin; i += 256)
+      *reinterpret_cast<f32x2*>(sTab + 2 * i) = *reinterpret_cast<const f32x2*>(a.in_tab + (size_t)i * 4 + 2);
   __syncthreads();
 
   const long Vin = (long)a.Di * a.Hi * a.Wi;
@@ -113,6 +123,15 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 20; ++ks)
         if (ks < KS) bf[ks] = *reinterpret_cast<const f16x8*>(a.in + vv * a.ldi + ks * 16 + 8 * hh);
+      if (a.in_tab) {
+        const float* tn = sTab + ((long)n * a.Cin + 8 * hh) * 2;
+#pragma unroll
+        for (int ks = 0; ks < 20; ++ks)
+          if (ks < KS) {
+            bf[ks] = __builtin_bit_cast(f16x8, norm_lrelu8_tab(__builtin_bit_cast(u32x4, bf[ks]), tn + ks * 32,
+                                                               slope_pair(a.in_slope)));
+          }
+      }
       for (int p = 0; p < P; ++p) {
         const int px = p % a.sw, py = (p / a.sw) % a.sh, pz = p / (a.sw * a.sh);
         const long ov = (((long)n * Do + a.sd * z + pz) * Ho + a.sh * y + py) * Wo + a.sw * x + px;
@@ -167,9 +186,10 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTArgs a) {
   }
 }
 
-static size_t ct_lds_bytes(int Cin, int Cout, int P, bool dgrad) {
+static size_t ct_lds_bytes(int Cin, int Cout, int P, bool dgrad, int tabN = 0) {
   const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-  return (size_t)P * (M / 32) * (K / 16) * 64 * 16 + (size_t)4 * 32 * (M + CT_PAD) * 2 + 4 * 32 * 8 + (size_t)Cout * 4;
+  return (size_t)P * (M / 32) * (K / 16) * 64 * 16 + (size_t)4 * 32 * (M + CT_PAD) * 2 + 4 * 32 * 8 + (size_t)Cout * 4 +
+         (size_t)tabN * Cin * 8;
 }
 
 static bool ct_supported(int Cin, int Cout, int sd, int sh, int sw, bool dgrad) {
@@ -189,7 +209,9 @@ static int ct_launch(ConvTArgs a, hipStream_t s) {
   if (a.ldi % 8 || a.ldo % 8) return NNZ_EINVAL;
   const long total = (long)a.N * a.Di * a.Hi * a.Wi;
   a.ntiles = (total + 31) / 32;
-  const size_t lds = ct_lds_bytes(a.Cin, a.Cout, a.sd * a.sh * a.sw, DGRAD);
+  if (a.in_tab && (DGRAD || a.Cout % 4)) return NNZ_EINVAL;
+  const size_t lds = ct_lds_bytes(a.Cin, a.Cout, a.sd * a.sh * a.sw, DGRAD, a.in_tab ? a.N : 0);
+  if (lds > 160 * 1024) return NNZ_EINVAL;
   static DynLdsCache cache;
   hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(convT_kernel<DGRAD>), (int)lds, cache);
   if (e != hipSuccess) return (int)e;
@@ -216,6 +238,18 @@ extern "C" int nnz_convT_forward(const void* in, const float* W, const float* bi
                                  int Cin, int Cout, int sd, int sh, int sw, int ldi, int ldo, void* stream) {
   nnz::ConvTArgs a = {};
   a.in = (const f16*)in; a.W = W; a.bias = bias; a.out = (f16*)out;
+  a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.sd = sd; a.sh = sh; a.sw = sw; a.ldi = ldi; a.ldo = ldo;
+  return nnz::ct_launch<false>(a, (hipStream_t)stream);
+}
+
+// ... with `in` the RAW conv output of the block below, normalised on the fly (ConvTArgs::in_tab); reference ops:
+// InstanceNorm3d + LeakyReLU feeding nn.ConvTranspose3d in the decoder (default_experiment_planner.py:285-305)
+extern "C" int nnz_convT_forward_innorm(const void* in, const float* in_tab, float in_slope, const float* W, const float* bias,
+                                        void* out, int N, int Di, int Hi, int Wi, int Cin, int Cout, int sd, int sh, int sw,
+                                        int ldi, int ldo, void* stream) {
+  if (!in_tab) return NNZ_EINVAL;
+  nnz::ConvTArgs a = {};
+  a.in = (const f16*)in; a.W = W; a.bias = bias; a.out = (f16*)out; a.in_tab = in_tab; a.in_slope = in_slope;
   a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.sd = sd; a.sh = sh; a.sw = sw; a.ldi = ldi; a.ldo = ldo;
   return nnz::ct_launch<false>(a, (hipStream_t)stream);
 }

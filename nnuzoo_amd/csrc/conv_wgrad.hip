@@ -30,6 +30,15 @@ struct WgradDev {
   int ntiles;   // per launch: N * tiles
   int splits;
   int pairs_b;  // B/32
+  // Consumer-side InstanceNorm + LeakyReLU (nnz_conv_tap_wgrad_to_grad_innorm): an operand that is the RAW conv output of
+  // its producer block is normalised while its tile is staged, y = lrelu(x * scale + shift), {scale, shift} =
+  // tab[n][c - c0][2..3]; channels below c0 (the transposed-conv half of a cat buffer) pass unchanged; padding stays zero.
+  // Same arithmetic and single fp16 rounding as the apply pass of norm_act.hip: the LDS images hold the bits the
+  // materialised activation would.  Tables of this workgroup's 32 + 32 channels for all N samples sit behind the tiles.
+  const float* p_tab;
+  const float* q_tab;
+  int p_c0, q_c0;
+  float p_slope, q_slope;
 };
 
 // Box geometry policies (same split as conv_fprop.hip): compile-time isotropic stride/extent for the 3-D plans the
@@ -118,6 +127,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   const f16* Qp = pin_uniform(p.q) + b0;
   const int ntiles = pin_uniform(p.ntiles), splits = pin_uniform(p.splits);
 
+  // consumer-side norm tables: [N][32] {scale, shift} per operand, behind the Q tile; visible after the loop's first barrier
+  float* ptab = reinterpret_cast<float*>(smem + gBOX_BYTES + C::Q_BYTES);
+  float* qtab = ptab + p.d.N * 64;
+  const bool pnorm = p.p_tab && a0 >= p.p_c0, qnorm = p.q_tab && b0 >= p.q_c0;
+  if (pnorm)
+    for (int i = tid; i < p.d.N * 32; i += 256)
+      *reinterpret_cast<f32x2*>(ptab + 2 * i) = *reinterpret_cast<const f32x2*>(
+          p.p_tab + ((size_t)(i >> 5) * (p.d.Cin - p.p_c0) + (a0 - p.p_c0) + (i & 31)) * 4 + 2);
+  if (qnorm)
+    for (int i = tid; i < p.d.N * 32; i += 256)
+      *reinterpret_cast<f32x2*>(qtab + 2 * i) = *reinterpret_cast<const f32x2*>(
+          p.q_tab + ((size_t)(i >> 5) * (p.d.Cout - p.q_c0) + (b0 - p.q_c0) + (i & 31)) * 4 + 2);
+
   // taps of this wave: wave, wave+4, ...  (MAXT = 7 for 27 taps, 2 for the 8 taps of the k2s2 transpose)
   int tap_off[MAXT];
   int ntw = 0;
@@ -149,8 +171,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
 
   u32x4 breg[LPT_BOX];
   u32x4 qreg[C::LPT_Q];
+  unsigned bmask = 0, qmask = 0;   // pieces of the prefetched tile that came from memory (the others are zero padding)
+  bool ppad = false, qpad = false;  // the prefetched box / tile has pieces outside the volume (uniform over the workgroup)
 
   auto issue_loads = [&](int tile) {
+    bmask = qmask = 0;
     const int n = tile / tiles_per_n;
     int r = tile - n * tiles_per_n;
     const int tw_i = r % tiles2;
@@ -159,6 +184,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     const int td_i = r / tiles1;
     const int m0d = td_i * TD, m0h = th_i * TH, m0w = tw_i * TW;
     const int lod = m0d * ISD + lo0, loh = m0h * ISH + lo1, low = m0w * ISW + lo2;
+    ppad = lod < 0 || loh < 0 || low < 0 || lod + gBD > Di || loh + gBH > Hi || low + gBW > Wi;
+    qpad = m0d + TD > Dm || m0h + TH > Hm || m0w + TW > Wm || (m0d + TD - 1) * os0 + oo0 >= Do ||
+           (m0h + TH - 1) * os1 + oo1 >= Ho || (m0w + TW - 1) * os2 + oo2 >= Wo;
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
@@ -172,8 +200,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         const int hw = (gBW + 1) >> 1;
         const int bw = ISW == 2 ? (bwl < hw ? 2 * bwl : 2 * (bwl - hw) + 1) : bwl;
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
-        if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
+        if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi) {
           v = *reinterpret_cast<const u32x4*>(Pp + ((size_t)((n * Di + id) * Hi + ih) * Wi + iw) * ldi + part * 8);
+          bmask |= 1u << i;
+        }
       }
       breg[i] = v;
     }
@@ -189,13 +219,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         const int od = md * os0 + oo0;
         const int oh = mh * os1 + oo1;
         const int ow = mw * os2 + oo2;
-        if (md < Dm && mh < Hm && mw < Wm && od < Do && oh < Ho && ow < Wo)
+        if (md < Dm && mh < Hm && mw < Wm && od < Do && oh < Ho && ow < Wo) {
           v = *reinterpret_cast<const u32x4*>(Qp + ((size_t)((n * Do + od) * Ho + oh) * Wo + ow) * ldo + part * 8);
+          qmask |= 1u << i;
+        }
       }
       qreg[i] = v;
     }
   };
-  auto write_lds = [&]() {
+  // Consumer-side norm of the staged tile between the two barriers, CHANNEL PAIR by channel pair (every piece of a thread holds
+  // the same 8 channels: c = tid + 256 i -> part = tid & 3; dword q of a piece = channels 2q, 2q + 1 of that part): one 16-byte
+  // table read per pair, then 4 VALU operations per piece (common.hpp norm_lrelu_pair).  Padding pieces are normalised like
+  // the others and zeroed again when the tile has any (ppad / qpad).  The caller makes the normalised operand the PLAIN one
+  // where it can (conv_plan.conv_wgrad_flipped): 4 halo-free pieces per tile instead of 10 boxed ones.
+  // (Measured and dropped: the same work inside the MFMA loop of the previous tile, piece by piece or as a software pipeline
+  //  over the last k-blocks - +12 % on the kernel either way against +7 % here; the loop is issue-bound per wave, and the extra
+  //  live state pushed the 4 x 8 x 8 instantiation into scratch.)
+  auto norm_regs = [&](const float* tp, float slope, auto& regs, int npieces) {
+    const nnz_h2 sl = slope_pair(slope);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(tp + 4 * q);
+#pragma unroll
+      for (int i = 0; i < LPT_BOX + C::LPT_Q; ++i)
+        if (i < npieces) regs[i < npieces ? i : 0][q] = norm_lrelu_pair(regs[i < npieces ? i : 0][q], t[0], t[1], t[2], t[3], sl);
+    }
+  };
+  auto zero_padding = [&]() {
+    if (pnorm && ppad) {
+#pragma unroll
+      for (int i = 0; i < LPT_BOX; ++i)
+        if (!((bmask >> i) & 1u)) breg[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    if (qnorm && qpad) {
+#pragma unroll
+      for (int i = 0; i < C::LPT_Q; ++i)
+        if (!((qmask >> i) & 1u)) qreg[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto write_lds = [&](int tile) {
+    if (pnorm || qnorm) {
+      const int n = tile / tiles_per_n;
+      if (pnorm) norm_regs(ptab + n * 64 + (tid & 3) * 16, p.p_slope, breg, LPT_BOX);
+      if (qnorm) norm_regs(qtab + n * 64 + (tid & 3) * 16, p.q_slope, qreg, C::LPT_Q);
+      zero_padding();
+    }
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
@@ -212,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   if (tile < ntiles) issue_loads(tile);
   for (; tile < ntiles; tile += splits) {
     __syncthreads();
-    write_lds();
+    write_lds(tile);
     __syncthreads();
     if (tile + splits < ntiles) issue_loads(tile + splits);
 
@@ -289,7 +357,8 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchO
   const G geo(p.d);
   const WBoxGeom<TD, TH, TW, G> bg(geo);
   if (bg.NBOXLOAD > LPT_BOX * 256) return NNZ_EINVAL;  // register staging cannot hold this box
-  const int lds = bg.BOX_BYTES + C::Q_BYTES;
+  const int lds = bg.BOX_BYTES + C::Q_BYTES + ((p.p_tab || p.q_tab) ? p.d.N * 512 : 0);
+  if (lds > 160 * 1024) return NNZ_EINVAL;
   p.tiles[0] = (p.d.m_dims[0] + TD - 1) / TD;
   p.tiles[1] = (p.d.m_dims[1] + TH - 1) / TH;
   p.tiles[2] = (p.d.m_dims[2] + TW - 1) / TW;
@@ -467,9 +536,44 @@ extern "C" long nnz_conv_tap_wgrad_workspace_floats(const nnz_conv_desc* desc) {
   return wgs * blk + pairs * blk;  // partial blocks + one reduced [T][A][B] image
 }
 
+struct WgNormArgs {
+  const float* p_tab;
+  int p_c0;
+  float p_slope;
+  const float* q_tab;
+  int q_c0;
+  float q_slope;
+};
+static int wgrad_to_grad_impl(const void* boxed, const void* plain, float* workspace, long ws_floats, float* grad, long sa,
+                              long sb, long sk, const int* ksel, int accumulate, const nnz_conv_desc* desc,
+                              const WgNormArgs* nm, void* stream);
+
 extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, float* workspace, long ws_floats,
                                           float* grad, long sa, long sb, long sk, const int* ksel, int accumulate,
                                           const nnz_conv_desc* desc, void* stream) {
+  return wgrad_to_grad_impl(boxed, plain, workspace, ws_floats, grad, sa, sb, sk, ksel, accumulate, desc, nullptr, stream);
+}
+
+// ... with operands that are RAW conv outputs of their producer blocks (WgradDev::p_tab): the layer input of a convolution
+// (boxed operand), the lower-resolution activation of a transposed convolution (plain operand).  tab == NULL: the operand
+// is used as it is.  c0 multiples of 32.  Reference ops: the bwd-weight kernels of nn.Conv3d / nn.ConvTranspose3d fed by
+// InstanceNorm + LeakyReLU outputs (default_experiment_planner.py:285-305).
+extern "C" int nnz_conv_tap_wgrad_to_grad_innorm(const void* boxed, const void* plain, float* workspace, long ws_floats,
+                                                 float* grad, long sa, long sb, long sk, const int* ksel, int accumulate,
+                                                 const nnz_conv_desc* desc, const float* boxed_tab, int boxed_c0,
+                                                 float boxed_slope, const float* plain_tab, int plain_c0,
+                                                 float plain_slope, void* stream) {
+  if (!desc || (!boxed_tab && !plain_tab)) return NNZ_EINVAL;
+  if ((boxed_tab && (boxed_c0 < 0 || boxed_c0 % 32 || boxed_c0 >= desc->Cin)) ||
+      (plain_tab && (plain_c0 < 0 || plain_c0 % 32 || plain_c0 >= desc->Cout)) || desc->N > 64)
+    return NNZ_EINVAL;
+  WgNormArgs nm = {boxed_tab, boxed_c0, boxed_slope, plain_tab, plain_c0, plain_slope};
+  return wgrad_to_grad_impl(boxed, plain, workspace, ws_floats, grad, sa, sb, sk, ksel, accumulate, desc, &nm, stream);
+}
+
+static int wgrad_to_grad_impl(const void* boxed, const void* plain, float* workspace, long ws_floats, float* grad, long sa,
+                              long sb, long sk, const int* ksel, int accumulate, const nnz_conv_desc* desc,
+                              const WgNormArgs* nm, void* stream) {
   using namespace nnz;
   if (!boxed || !plain || !workspace || !grad || !ksel || !desc) return NNZ_EINVAL;
   const nnz_conv_desc& d = *desc;
@@ -496,6 +600,10 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
     // two-stage: partial blocks in the workspace, then the fixed-order reduction straight into the torch-layout grad
     WgradDev p = {};
     p.p = (const f16*)boxed; p.q = (const f16*)plain; p.part = workspace; p.tab = tab; p.d = d;
+    if (nm) {
+      p.p_tab = nm->p_tab; p.p_c0 = nm->p_c0; p.p_slope = nm->p_slope;
+      p.q_tab = nm->q_tab; p.q_c0 = nm->q_c0; p.q_slope = nm->q_slope;
+    }
     WgLaunchOpt o;
     o.max_wgs = (ws_floats - tab) / ((long)d.ntaps_total * 1024);  // workgroups whose blocks fit beside the temp image
     if (o.max_wgs < pairs) return NNZ_EINVAL;
@@ -503,6 +611,7 @@ extern "C" int nnz_conv_tap_wgrad_to_grad(const void* boxed, const void* plain, 
     const int rc = launch_wgrad_any(p, s, o);
     if (rc != NNZ_OK) return rc;
   } else {
+    if (nm) return NNZ_EINVAL;   // (the chunked path keeps materialised operands)
     // batch beyond 2^31 elements: sample chunks accumulate atomically into one [T][A][B] image in the workspace
     hipError_t e = nnz::zero_async(workspace, sizeof(float) * tab, s);
     if (e != hipSuccess) return (int)e;

@@ -156,9 +156,8 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
             acc1[i] += x * x;
           }
         } else if (MODE == 1) {
-          f16x8 o;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (f16)leaky((float)xh[k][i] * scale[i] + shift[i], a.slope);
+          // (common.hpp norm_lrelu8: the rounding points of torch's autocast op sequence; shared with the consumer-side norm)
+          const f16x8 o = __builtin_bit_cast(f16x8, norm_lrelu8(__builtin_bit_cast(u32x4, xh[k]), scale, shift, slope_pair(a.slope)));
           *reinterpret_cast<f16x8*>(a.y + (base + vv) * a.ldy + cg * 8) = o;
         } else {
           f16x8 o;

@@ -85,11 +85,20 @@ def pack_weight(param: torch.Tensor, pt: PreparedTable, R: int, Cc: int, sr: int
 
 
 def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
-                     out: torch.Tensor, stats: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> None:
+                     out: torch.Tensor, stats: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                     innorm: Optional["InNorm"] = None) -> None:
     """stats: optional pre-zeroed fp32 [N, Cout, 2]; the kernel adds {sum, sumsq} of its fp16 outputs (fused
-    InstanceNorm statistics).  workspace: fp32 scratch that lets few-tile / long-reduction layers run split-K"""
+    InstanceNorm statistics).  workspace: fp32 scratch that lets few-tile / long-reduction layers run split-K.
+    innorm: x is a raw conv output, normalised + activated while it is staged"""
     _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
     _f32(stats, "conv.stats"); _f32(workspace, "conv.workspace")
+    if innorm is not None:
+        assert stats is None
+        TIMER.wrap("conv_box_kernel", pt.flops,
+                   lambda: call("nnz_conv_tap_forward_innorm", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
+                                ptr(innorm.tab), innorm.c0, innorm.slope, None, None, None, None, 0.0, None,
+                                ptr(workspace), 0 if workspace is None else workspace.numel(), stream_ptr()))
+        return
     if workspace is not None and stats is None:
         TIMER.wrap("conv_box_kernel", pt.flops,
                    lambda: call("nnz_conv_tap_forward_ws", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
@@ -98,6 +107,16 @@ def conv_tap_forward(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor,
     TIMER.wrap("conv_box_kernel", pt.flops,
                lambda: call("nnz_conv_tap_forward_stats", ptr(x), ptr(out), ptr(w_packed), ptr(bias),
                             C.byref(pt.desc), ptr(stats), stream_ptr()))
+
+
+class InNorm:
+    """Consumer-side InstanceNorm + LeakyReLU of an operand (include/nnuzoo_hip.h, round 4): the operand is the RAW conv output
+    of its producer block; `tab` is that block's table [N, C - c0, 4] = {mean, rstd, scale, shift}; channels [0, c0) pass
+    unchanged (the transposed-conv half of a cat buffer)."""
+    __slots__ = ("tab", "c0", "slope")
+
+    def __init__(self, tab: torch.Tensor, slope: float, c0: int = 0):
+        self.tab, self.c0, self.slope = tab, int(c0), float(slope)     # (validated by the launch wrappers: ptr() needs HIP memory)
 
 
 class NormScratch:
@@ -139,13 +158,22 @@ def det_scratch(device, records: int = 0) -> NormScratch:
 
 def conv_tap_forward_norm(pt: PreparedTable, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
                           out: torch.Tensor, scratch: NormScratch, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-                          nstat: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> None:
+                          nstat: torch.Tensor, workspace: Optional[torch.Tensor] = None,
+                          innorm: Optional["InNorm"] = None) -> None:
     """forward convolution + the InstanceNorm table of its output: nstat [N, Cout, 4] = {mean, rstd, scale, shift}
-    (deterministic fixed-point statistics, written by the launch's last workgroup)"""
+    (deterministic fixed-point statistics, written by the launch's last workgroup).  innorm: x is the RAW output of the
+    producer block(s), normalised + activated while the input box is staged (consumer side of conv + norm + act)"""
     _f16(x, "conv.in"); _f16(out, "conv.out"); _f16(w_packed, "conv.w"); _f32(bias, "conv.bias")
     _f32(gamma, "conv.gamma"); _f32(beta, "conv.beta"); _f32(nstat, "conv.nstat")
     assert pt.table.N * pt.table.Cout <= scratch.capacity
     _f32(workspace, "conv.workspace")
+    if innorm is not None:
+        TIMER.wrap("conv_box_kernel", pt.flops,
+                   lambda: call("nnz_conv_tap_forward_innorm", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
+                                ptr(innorm.tab), innorm.c0, innorm.slope, ptr(scratch.acc), ptr(scratch.counter), ptr(gamma),
+                                ptr(beta), float(eps), ptr(nstat), ptr(workspace),
+                                0 if workspace is None else workspace.numel(), stream_ptr()))
+        return
     TIMER.wrap("conv_box_kernel", pt.flops,
                lambda: call("nnz_conv_tap_forward_norm_ws", ptr(x), ptr(out), ptr(w_packed), ptr(bias), C.byref(pt.desc),
                             ptr(scratch.acc), ptr(scratch.counter), ptr(gamma), ptr(beta), float(eps), ptr(nstat),
@@ -157,10 +185,17 @@ def convT_supported(cin: int, cout: int, stride, dgrad: bool) -> bool:
 
 
 def convT_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, N: int, in_dims,
-                  cin: int, cout: int, stride, ldi: int, ldo: int) -> None:
+                  cin: int, cout: int, stride, ldi: int, ldo: int, innorm: Optional["InNorm"] = None) -> None:
     """kernel = stride ConvTranspose on its own HBM-bound kernel (csrc/conv_transpose.hip); weight = the fp32 parameter"""
     _f16(x, "convT.in"); _f16(out, "convT.out"); _f32(weight, "convT.w"); _f32(bias, "convT.bias")
     flops = 2.0 * N * in_dims[0] * in_dims[1] * in_dims[2] * cin * cout * stride[0] * stride[1] * stride[2]
+    if innorm is not None:
+        assert innorm.c0 == 0
+        TIMER.wrap("convT_kernel", flops, lambda: call(
+            "nnz_convT_forward_innorm", ptr(x), ptr(innorm.tab), innorm.slope, ptr(weight), ptr(bias), ptr(out), N,
+            int(in_dims[0]), int(in_dims[1]), int(in_dims[2]), cin, cout, int(stride[0]), int(stride[1]), int(stride[2]), ldi,
+            ldo, stream_ptr()))
+        return
     TIMER.wrap("convT_kernel", flops, lambda: call(
         "nnz_convT_forward", ptr(x), ptr(weight), ptr(bias), ptr(out), N, int(in_dims[0]), int(in_dims[1]), int(in_dims[2]),
         cin, cout, int(stride[0]), int(stride[1]), int(stride[2]), ldi, ldo, stream_ptr()))
@@ -188,10 +223,20 @@ def conv_tap_wgrad_workspace_floats(pt: PreparedTable) -> int:
 
 
 def conv_tap_wgrad_to_grad(pt: PreparedTable, boxed: torch.Tensor, plain: torch.Tensor, ws: torch.Tensor,
-                           grad: torch.Tensor, sa: int, sb: int, sk: int, accumulate: bool = False) -> None:
+                           grad: torch.Tensor, sa: int, sb: int, sk: int, accumulate: bool = False,
+                           boxed_norm: Optional["InNorm"] = None, plain_norm: Optional["InNorm"] = None) -> None:
     """weight gradient straight into the torch-layout `grad` (two-stage, deterministic): partial blocks in `ws`, then a
-    fixed-order reduction; grad[a*sa + b*sb + t*sk] with (a, b) = (boxed, plain) channels"""
+    fixed-order reduction; grad[a*sa + b*sb + t*sk] with (a, b) = (boxed, plain) channels.  boxed_norm / plain_norm: that
+    operand is a raw conv output, normalised + activated while its tile is staged"""
     _f16(boxed, "wgrad.boxed"); _f16(plain, "wgrad.plain"); _f32(ws, "wgrad.ws"); _f32(grad, "wgrad.grad")
+    if boxed_norm is not None or plain_norm is not None:
+        bn, pn = boxed_norm, plain_norm
+        TIMER.wrap("conv_wgrad_kernel", pt.flops,
+                   lambda: call("nnz_conv_tap_wgrad_to_grad_innorm", ptr(boxed), ptr(plain), ptr(ws), ws.numel(), ptr(grad), sa,
+                                sb, sk, pt.ident_ksel, int(accumulate), C.byref(pt.desc),
+                                ptr(bn.tab) if bn else None, bn.c0 if bn else 0, bn.slope if bn else 0.0,
+                                ptr(pn.tab) if pn else None, pn.c0 if pn else 0, pn.slope if pn else 0.0, stream_ptr()))
+        return
     TIMER.wrap("conv_wgrad_kernel", pt.flops,
                lambda: call("nnz_conv_tap_wgrad_to_grad", ptr(boxed), ptr(plain), ptr(ws), ws.numel(), ptr(grad), sa, sb,
                             sk, pt.ident_ksel, int(accumulate), C.byref(pt.desc), stream_ptr()))
@@ -285,8 +330,13 @@ def stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dims, lddy: 
              ptr(scratch.counter), stream_ptr())
 
 
-def head_forward(x, w, b, logits, N, V, Cc, K, ldx):
+def head_forward(x, w, b, logits, N, V, Cc, K, ldx, innorm: Optional["InNorm"] = None):
     _f16(x, "head.x"); _f32(w, "head.w"); _f32(b, "head.b"); _f16(logits, "head.logits")
+    if innorm is not None:
+        assert innorm.c0 == 0
+        call("nnz_seg_head_forward_innorm", ptr(x), ptr(innorm.tab), innorm.slope, ptr(w), ptr(b), ptr(logits), N, V, Cc, K,
+             ldx, stream_ptr())
+        return
     call("nnz_seg_head_forward", ptr(x), ptr(w), ptr(b), ptr(logits), N, V, Cc, K, ldx, stream_ptr())
 
 
@@ -295,8 +345,13 @@ def head_dgrad(dlogits, w, dx, N, V, Cc, K, lddx, accumulate):
     call("nnz_seg_head_dgrad", ptr(dlogits), ptr(w), ptr(dx), N, V, Cc, K, lddx, int(accumulate), stream_ptr())
 
 
-def head_wgrad(x, dlogits, dw, db, N, V, Cc, K, ldx, scratch: "NormScratch" = None):
+def head_wgrad(x, dlogits, dw, db, N, V, Cc, K, ldx, scratch: "NormScratch" = None, innorm: Optional["InNorm"] = None):
     _f16(x, "head.x"); _f16(dlogits, "head.dlogits"); _f32(dw, "head.dw"); _f32(db, "head.db")
+    if innorm is not None:
+        assert innorm.c0 == 0 and scratch is not None and scratch.capacity * 2 >= 8 * (Cc + 1)
+        call("nnz_seg_head_wgrad_innorm", ptr(x), ptr(innorm.tab), innorm.slope, ptr(dlogits), ptr(dw), ptr(db), N, V, Cc, K,
+             ldx, ptr(scratch.acc), ptr(scratch.counter), stream_ptr())
+        return
     if scratch is None:
         call("nnz_seg_head_wgrad", ptr(x), ptr(dlogits), ptr(dw), ptr(db), N, V, Cc, K, ldx, stream_ptr())
     else:

@@ -12,11 +12,16 @@ autograd.Function whose backward is an explicit reverse schedule.  CPU tensors r
 
 Data layout in HBM (per resolution level s, C_s features):
   raw_b   [N, V_s, C_s]  fp16  conv output before norm, one per conv block (saved for backward)
-  stats_b [N, C_s, 2]    fp32  per-instance sum / sum of squares
+  nstat_b [N, C_s, 4]    fp32  the block's InstanceNorm table {mean, rstd, scale, shift}
   cat_s   [N, V_s, 2C_s] fp16  decoder input: [..., :C_s] = transposed-conv output, [..., C_s:] = encoder skip
-                               (the last encoder block of the level writes its activation straight into the
-                               second half: torch.cat is never materialised)
-  act_b   [N, V_s, C_s]  fp16  activated output of the other blocks
+                               (the last encoder block of the level writes straight into the second half: torch.cat is
+                               never materialised)
+Round 4 - consumer-side norm + activation ("conv + norm + act fused"): the ACTIVATED tensors do not exist.  Every consumer
+of a block (the next convolution, the stride-2 convolution of the next stage, the transposed convolution, the segmentation
+head, and in the backward the weight-gradient kernels) reads raw_b and applies lrelu(x * scale + shift) from nstat_b while
+it stages its operand (hip_ops.InNorm; csrc/conv_fprop.hip ConvDev::in_tab).  The skip half of cat_s therefore holds the RAW
+output of the level's last encoder block.  NNZ_CONSUMER_NORM=0 keeps the separate apply pass and the `act` tensors (A/B
+runs; both forms give the same bits, tests/test_plain_unet_gpu.py).
 """
 from __future__ import annotations
 
@@ -167,13 +172,26 @@ class _Block:
         self.y_ld = self.cout     # channel stride of the output activation (2C when written into a cat buffer)
         self.fwd = self.dgrad = self.wgrad = None
         self.zero_dx = cp.dgrad_uncovered(self.ks, self.stride)
+        self.raw_ld = self.cout   # channel stride of the block's raw conv output (y_ld when consumers normalise on the fly)
+        self.wgrad_flipped = False
 
-    def prepare(self):
+    def prepare(self, consumer_norm: bool):
+        # consumer-side norm: the raw output IS what later kernels read, so a skip block's convolution writes into the cat buffer
+        self.raw_ld = self.y_ld if consumer_norm else self.cout
         if not self.stem:
             self.fwd = PreparedTable(cp.conv_forward(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
-                                                     stride=self.stride, ldi=self.x_ld, ldo=self.cout))
-            self.wgrad = PreparedTable(cp.conv_wgrad(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
-                                                     stride=self.stride, ldx=self.x_ld, lddy=self.cout))
+                                                     stride=self.stride, ldi=self.x_ld, ldo=self.raw_ld))
+            # stride 1: operand roles exchanged (conv_plan.conv_wgrad_flipped) so that the layer input is the halo-free plain
+            # operand of the weight-gradient kernel - with consumer-side norm every voxel of the RAW input is then
+            # normalised once per tile instead of 2.3 times.  Both modes use the same form (same summation order: the two
+            # schedules stay bit-identical).
+            self.wgrad_flipped = self.stride == (1, 1, 1) and not self.padded
+            if self.wgrad_flipped:
+                self.wgrad = PreparedTable(cp.conv_wgrad_flipped(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
+                                                                 ldx=self.x_ld, lddy=self.cout))
+            else:
+                self.wgrad = PreparedTable(cp.conv_wgrad(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
+                                                         stride=self.stride, ldx=self.x_ld, lddy=self.cout))
         if not self.stem and not self.padded:
             # dgrad: in = d(raw) [ld cout] -> out = d(input activation) [ld x_ld]
             self.dgrad = PreparedTable(cp.conv_dgrad(self.N, self.in_dims, self.cin, self.cout, ks=self.ks,
@@ -203,6 +221,7 @@ class _Plan:
     def __init__(self, net: "PlainConvUNet", N: int, dims: Tuple[int, int, int]):
         enc, dec = net.encoder, net.decoder
         self.N, self.dims = N, tuple(dims)
+        self.consumer_norm = bool(net.consumer_norm)
         S = len(enc.stages)
         self.S = S
         feats = enc.output_channels
@@ -249,7 +268,10 @@ class _Plan:
         self.all_blocks: List[_Block] = [b for blocks in self.enc_blocks + self.dec_blocks for b in blocks]
         so = 0
         for b in self.all_blocks:
-            b.prepare()
+            if self.consumer_norm and b.stem and b.y_ld != b.cout:
+                raise NotImplementedError("nnuzoo_amd.PlainConvUNet: a one-conv first stage (the stem kernel writing into a "
+                                          "cat buffer) needs NNZ_CONSUMER_NORM=0")
+            b.prepare(self.consumer_norm)
             b.stats_off, so = so, so + N * b.cout * 4          # slice of the per-step InstanceNorm tables (nstat)
         self.stats_floats = so
         self.norm_scratch = None                                  # fixed-point accumulators + counter (first use)
@@ -384,6 +406,8 @@ class PlainConvUNet(nn.Module):
         # data-gradient launches also close the InstanceNorm-backward reductions of the layer below (see _conv_block_bwd);
         # NNZ_FUSE_NORM_REDUCE=0 keeps the separate reducing launches (A/B runs, tests)
         self.fuse_norm_reduce = os.environ.get("NNZ_FUSE_NORM_REDUCE", "1") != "0"
+        # consumers normalise + activate raw conv outputs while staging them; no apply pass, no activated tensors (module doc)
+        self.consumer_norm = os.environ.get("NNZ_CONSUMER_NORM", "1") != "0"
 
     # reference API: `network.apply(network.initialize)` (get_network_from_plans.py:59-60)
     @staticmethod
@@ -421,22 +445,30 @@ class PlainConvUNet(nn.Module):
         return outs[0]
 
     # ---- forward schedule ----------------------------------------------------------------------------------------
-    def _conv_block_fwd(self, b: _Block, x_act: torch.Tensor, act_out: torch.Tensor, dev, stats_all):
+    def _conv_block_fwd(self, b: _Block, x_in: torch.Tensor, x_norm, out_buf: torch.Tensor, dev, stats_all):
+        """One block.  x_in / x_norm: the input operand and its hip_ops.InNorm (None: x_in is used as it is).  out_buf: where
+        consumers will read the block from (a cat-buffer slice for skip blocks).  Returns (raw, stats, out, out_norm): the raw
+        conv output with its table, and the operand + InNorm later kernels take - (raw, table) with consumer-side norm, the
+        materialised activation otherwise."""
         h = b.h
-        raw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
+        cn = self._plan_cn
+        raw = out_buf if cn else torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
         # the block's InstanceNorm table {mean, rstd, scale, shift} per (sample, channel): written by the last workgroup
         # of the launch that produces the statistics (deterministic fixed-point sums, csrc/common.hpp)
         stats = stats_all[b.stats_off:b.stats_off + b.N * b.cout * 4].view(b.N, b.cout, 4)
         scratch = self._scratch
         if b.stem:
-            ops.stem_forward(x_act, h.conv.weight, h.conv.bias, raw, (b.N, *b.in_dims), b.cout)
+            ops.stem_forward(x_in, h.conv.weight, h.conv.bias, raw, (b.N, *b.in_dims), b.cout)
             ops.instnorm_stats_det(raw, b.N, b.V, b.cout, b.cout, scratch, h.norm.weight, h.norm.bias, b.eps, nstat=stats)
         else:
             # the convolution's epilogue accumulates the InstanceNorm statistics of the tile it just produced
-            ops.conv_tap_forward_norm(b.fwd, self._padded_input(b, x_act) if b.padded else x_act, b.wp_fwd, h.conv.bias,
-                                      raw, scratch, h.norm.weight, h.norm.bias, b.eps, stats, workspace=self._ws)
-        ops.instnorm_lrelu_apply_tab(raw, stats, act_out, b.N, b.V, b.cout, b.cout, b.y_ld, b.slope)
-        return raw, stats
+            ops.conv_tap_forward_norm(b.fwd, self._padded_input(b, x_in) if b.padded else x_in, b.wp_fwd, h.conv.bias,
+                                      raw, scratch, h.norm.weight, h.norm.bias, b.eps, stats, workspace=self._ws,
+                                      innorm=x_norm)
+        if cn:
+            return raw, stats, raw, ops.InNorm(stats, b.slope)
+        ops.instnorm_lrelu_apply_tab(raw, stats, out_buf, b.N, b.V, b.cout, b.cout, b.y_ld, b.slope)
+        return raw, stats, out_buf, None
 
     @staticmethod
     def _padded_input(b: _Block, x: torch.Tensor) -> torch.Tensor:
@@ -473,44 +505,50 @@ class PlainConvUNet(nn.Module):
         cats = [torch.empty((N, int(np.prod(plan.level_dims[s])), 2 * feats[s]), dtype=f16, device=dev)
                 for s in range(S - 1)]
         rec = {"x": x, "plan": plan, "cats": cats, "enc": [], "dec": [], "heads": []}
-        cur = x
+        self._plan_cn = plan.consumer_norm
+        # cur / cur_norm: the operand the next kernel reads and its consumer-side norm (None: used as it is)
+        cur, cur_norm = x, None
         for s in range(S):
             stage_rec = []
             for i, b in enumerate(plan.enc_blocks[s]):
                 last = i == len(plan.enc_blocks[s]) - 1
                 if last and s < S - 1:
-                    act = cats[s][:, :, feats[s]:]
+                    buf = cats[s][:, :, feats[s]:]
                 else:
-                    act = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
-                raw, stats = self._conv_block_fwd(b, cur, act, dev, stats_all)
-                stage_rec.append((cur, raw, stats, act))
-                cur = act
+                    buf = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
+                raw, stats, out, out_norm = self._conv_block_fwd(b, cur, cur_norm, buf, dev, stats_all)
+                stage_rec.append((cur, raw, stats, out, cur_norm, out_norm))
+                cur, cur_norm = out, out_norm
             rec["enc"].append(stage_rec)
         outs = [None] * (S - 1)
-        lres = cur
+        lres, lres_norm = cur, cur_norm
         for j in range(S - 1):
             lvl = S - 2 - j
             up = plan.ups[j]
             if up.native_fwd:
                 ops.convT_forward(lres, up.m.weight, up.m.bias, cats[lvl], up.N, up.in_dims, up.cin, up.cout, up.stride,
-                                  up.cin, up.ldo)
+                                  up.cin, up.ldo, innorm=lres_norm)
             else:
-                ops.conv_tap_forward(up.fwd, lres, up.wp_fwd, up.m.bias, cats[lvl])
+                ops.conv_tap_forward(up.fwd, lres, up.wp_fwd, up.m.bias, cats[lvl], innorm=lres_norm)
+            # decoder input = [transposed conv | skip]: with consumer-side norm the skip half is the raw output of the level's
+            # last encoder block, normalised by the reader (channels below C pass unchanged)
+            skip_norm = rec["enc"][lvl][-1][5]
             cur = cats[lvl]
+            cur_norm = ops.InNorm(skip_norm.tab, skip_norm.slope, c0=feats[lvl]) if skip_norm is not None else None
             stage_rec = []
             for b in plan.dec_blocks[j]:
-                act = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
-                raw, stats = self._conv_block_fwd(b, cur, act, dev, stats_all)
-                stage_rec.append((cur, raw, stats, act))
-                cur = act
-            rec["dec"].append((lres, stage_rec))
+                buf = torch.empty((N, b.V, b.cout), dtype=f16, device=dev)
+                raw, stats, out, out_norm = self._conv_block_fwd(b, cur, cur_norm, buf, dev, stats_all)
+                stage_rec.append((cur, raw, stats, out, cur_norm, out_norm))
+                cur, cur_norm = out, out_norm
+            rec["dec"].append((lres, stage_rec, lres_norm))
             if self.decoder.deep_supervision or j == S - 2:
                 seg = self.decoder.seg_layers[j]
                 V = int(np.prod(plan.level_dims[lvl]))
                 logits = torch.empty((N, K, *plan.level_dims[lvl][3 - self._nd:]), dtype=f16, device=dev)
-                ops.head_forward(cur, seg.weight, seg.bias, logits, N, V, feats[lvl], K, feats[lvl])
+                ops.head_forward(cur, seg.weight, seg.bias, logits, N, V, feats[lvl], K, feats[lvl], innorm=cur_norm)
                 outs[lvl] = logits
-            lres = cur
+            lres, lres_norm = cur, cur_norm
         out_list = [o for o in outs if o is not None]  # highest resolution first
         rec["out_levels"] = [lvl for lvl, o in enumerate(outs) if o is not None]
         return out_list, (rec if save else None)
@@ -525,17 +563,17 @@ class PlainConvUNet(nn.Module):
         norm below it, or a gradient that other launches still add to).  The data-gradient launch then also closes that
         block's InstanceNorm-backward reductions in its epilogue (csrc/conv_fprop.hip, ConvDev::bx) and the block's own
         call of this method runs the apply launch only."""
-        x_in, raw, stats, _ = recd
+        x_in, raw, stats, _, x_norm, _ = recd
         h = b.h
         red = self._red_all[b.stats_off // 2:b.stats_off // 2 + b.N * b.cout * 2].view(b.N, b.cout, 2)
         draw = torch.empty((b.N, b.V, b.cout), dtype=torch.float16, device=dev)
         pre = self._prereduced.pop(id(b), None)
         if pre is not None:
             gnw, gnb = pre
-            ops.instnorm_lrelu_bwd_apply_tab(raw, g_act, stats, red, draw, b.N, b.V, b.cout, b.cout, g_ld, b.cout, b.slope)
+            ops.instnorm_lrelu_bwd_apply_tab(raw, g_act, stats, red, draw, b.N, b.V, b.cout, b.raw_ld, g_ld, b.cout, b.slope)
         else:
             gnw, gnb = self._galloc(h.norm.weight), self._galloc(h.norm.bias)
-            ops.instnorm_lrelu_bwd_tab(raw, g_act, stats, self._scratch, red, draw, b.N, b.V, b.cout, b.cout, g_ld, b.cout,
+            ops.instnorm_lrelu_bwd_tab(raw, g_act, stats, self._scratch, red, draw, b.N, b.V, b.cout, b.raw_ld, g_ld, b.cout,
                                        b.slope, dgamma=gnw, dbeta=gnb)
         grads[h.norm.weight], grads[h.norm.bias] = gnw, gnb
         # the bias of a conv followed by InstanceNorm has an identically zero gradient (mean removal)
@@ -551,7 +589,10 @@ class PlainConvUNet(nn.Module):
                                            b.cin * nk, 1)
                 gw.copy_(b.gw_pad[:, :b.cin_w].reshape(gw.shape))
             else:
-                ops.conv_tap_wgrad_to_grad(b.wgrad, x_in, draw, self._wgrad_ws, gw, nk, b.cin * nk, 1)
+                if b.wgrad_flipped:   # dW[t][cout][cin]: a = cout (stride cin*nk), b = cin (stride nk)
+                    ops.conv_tap_wgrad_to_grad(b.wgrad, draw, x_in, self._wgrad_ws, gw, b.cin * nk, nk, 1, plain_norm=x_norm)
+                else:
+                    ops.conv_tap_wgrad_to_grad(b.wgrad, x_in, draw, self._wgrad_ws, gw, nk, b.cin * nk, 1, boxed_norm=x_norm)
                 if b.zero_dx and not dx_acc:
                     dx_out.zero_()  # k1 s2 axes: odd input positions are outside every output's footprint
                 pt = b.dgrad_acc if dx_acc else b.dgrad
@@ -562,7 +603,7 @@ class PlainConvUNet(nn.Module):
                     pb, prec = below
                     pred = self._red_all[pb.stats_off // 2:pb.stats_off // 2 + pb.N * pb.cout * 2].view(pb.N, pb.cout, 2)
                     pgw, pgb = self._galloc(pb.h.norm.weight), self._galloc(pb.h.norm.bias)
-                    ops.conv_tap_dgrad_normred(pt, draw, b.wp_dgrad, dx_out, prec[1], pb.cout, prec[2], pb.slope,
+                    ops.conv_tap_dgrad_normred(pt, draw, b.wp_dgrad, dx_out, prec[1], pb.raw_ld, prec[2], pb.slope,
                                                self._scratch, pred, pgw, pgb)
                     self._prereduced[id(pb)] = (pgw, pgb)
                 else:
@@ -628,8 +669,8 @@ class PlainConvUNet(nn.Module):
             lvl = S - 2 - j
             C_ = feats[lvl]
             V = int(np.prod(plan.level_dims[lvl]))
-            lres, stage_rec = rec["dec"][j]
-            out_act = stage_rec[-1][3]
+            lres, stage_rec, lres_norm = rec["dec"][j]
+            out_act, out_norm = stage_rec[-1][3], stage_rec[-1][5]
             seg = self.decoder.seg_layers[j]
             g = gout_by_level.get(lvl)
             if g_cur is None:
@@ -643,7 +684,7 @@ class PlainConvUNet(nn.Module):
                     g = g.to(f16)
                 gw = self._galloc(seg.weight)
                 gb = self._galloc(seg.bias)
-                ops.head_wgrad(out_act, g, gw, gb, N, V, C_, K, C_, scratch=self._scratch)
+                ops.head_wgrad(out_act, g, gw, gb, N, V, C_, K, C_, scratch=self._scratch, innorm=out_norm)
                 ops.head_dgrad(g, seg.weight, g_cur, N, V, C_, K, C_, accumulate=have)
                 grads[seg.weight], grads[seg.bias] = gw, gb
             else:
@@ -669,7 +710,7 @@ class PlainConvUNet(nn.Module):
             nk = up.nk
             gw = self._galloc(up.m.weight)
             # dW[t][cout][cin] -> torch layout (cin, cout, *k): a = cout (stride nk), b = cin (stride cout*nk)
-            ops.conv_tap_wgrad_to_grad(up.wgrad, g_up, lres, self._wgrad_ws, gw, nk, up.cout * nk, 1)
+            ops.conv_tap_wgrad_to_grad(up.wgrad, g_up, lres, self._wgrad_ws, gw, nk, up.cout * nk, 1, plain_norm=lres_norm)
             grads[up.m.weight] = gw
             if up.m.bias is not None:
                 st = torch.empty((N, up.cout, 2), dtype=torch.float32, device=dev)

@@ -111,6 +111,12 @@ def test_conv_tables(dims, ks, stride):
     t = cp.conv_wgrad(N, dims, cin, cout, ks=ks, stride=stride)
     dw = interp_wgrad(t, cl(x.detach()), cl(dy))  # [nk][cin][cout]
     assert torch.allclose(dw.permute(2, 1, 0).reshape(cout, cin, *ks3), w.grad, atol=1e-10)
+    if st3 == (1, 1, 1):
+        # round 4: the same gradient with the operand roles exchanged (boxed = dY, plain = X; block [nk][cout][cin])
+        t = cp.conv_wgrad_flipped(N, dims, cin, cout, ks=ks)
+        assert (t.Cin, t.Cout) == (cout, cin)
+        dwf = interp_wgrad(t, cl(dy), cl(x.detach()))
+        assert torch.allclose(dwf.permute(1, 2, 0).reshape(cout, cin, *ks3), w.grad, atol=1e-10)
 
 
 @pytest.mark.parametrize("dims,stride", [((2, 3, 4), 2), ((1, 1, 1), 2), ((2, 3, 4), (1, 2, 2)), ((1, 5, 4), (1, 2, 2)),

@@ -214,3 +214,40 @@ def test_many_classes(hip_lib, num_classes, dim, patch):
             gr = refp[n].grad
             rel = (p.grad.cpu() - gr).norm().item() / (gr.norm().item() + 1e-12)
             assert rel < 5e-2, (n, rel)
+
+
+@pytest.mark.parametrize("n_stages,feats,patch,geom", [
+    (3, [32, 64, 128], (16, 16, 16), ISO),
+    (4, [32, 64, 128, 256], (32, 16, 24), ISO),
+    (6, [32, 64, 128, 256, 320, 320], (64, 64, 64), ISO),            # every tile family of the 3d_fullres plan incl. split-K
+    (4, [32, 64, 128, 256], (64, 48), PLAN_2D),
+    (3, [32, 64, 128], (32, 40), PLAN_2D_RGB),
+    (3, [32, 64, 128], (6, 32, 24), PLAN_THICK),
+    (3, [32, 64, 128], (16, 16, 12), PLAN_STOP),
+])
+def test_consumer_side_norm_equals_the_materialised_activation_bit_for_bit(hip_lib, n_stages, feats, patch, geom):
+    """Round 4: the consumers of a block (next conv, stride-2 conv, transposed conv, head, weight-gradient kernels) apply
+    InstanceNorm + LeakyReLU to the RAW conv output while they stage it; the apply pass and the activated tensors are gone.
+    The on-the-fly arithmetic is the apply pass's (fp32 FMA, LeakyReLU, one rounding to fp16), so logits and EVERY parameter
+    gradient must equal the materialised schedule (NNZ_CONSUMER_NORM=0) to the last bit - all kernels are deterministic."""
+    dim, cin, kernel_sizes, strides = geom
+    _, net = build_pair(n_stages, feats, dim=dim, cin=cin, kernel_sizes=kernel_sizes, strides=strides)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, cin, *patch, generator=g).cuda()
+    res = {}
+    for mode in (False, True):
+        net.consumer_norm = mode
+        net._plans.clear()
+        net.zero_grad(set_to_none=True)
+        outs = net(x)
+        gs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(3 + i)).to(torch.float16).cuda()
+              for i, o in enumerate(outs)]
+        loss = sum((o.float() * G.float()).sum() * w for o, G, w in zip(outs[:-1], gs, (1.0, 0.5, 0.25, 0.125, 0.0625)))
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = ([o.detach().clone() for o in outs], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+    assert res[False][1].keys() == res[True][1].keys()
+    for n in res[False][1]:
+        assert torch.equal(res[False][1][n], res[True][1][n]), (n, (res[False][1][n] - res[True][1][n]).abs().max().item())

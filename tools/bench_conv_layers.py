@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--tuning", type=str, default="", help="comma list knob=value for nnz_conv_tuning (include/nnuzoo_hip.h)")
+    ap.add_argument("--innorm", type=int, default=0, help="1: x is a raw conv output normalised by the consumers (round 4): "
+                    "forward with an input table, weight gradient in the flipped form with a plain-operand table")
     a = ap.parse_args()
     if a.tuning:
         from nnuzoo_amd import _lib
@@ -66,12 +68,23 @@ def main():
         pw = PreparedTable(cp.conv_wgrad(N, dims, cin, cout, stride=stride))
         wf = ops.pack_weight(w, pf, cin, cout, 27, cin * 27, 1)
         wd = ops.pack_weight(w, pd, cout, cin, cin * 27, 27, 1)
-        tf = timeit(lambda: ops.conv_tap_forward(pf, x, wf, None, y), a.reps)
+        inn = None
+        if a.innorm:
+            tab = torch.randn(N, cin, 4, device=dev)
+            tab[:, :, 2] = 1.0 + 0.1 * tab[:, :, 2]
+            inn = ops.InNorm(tab, 0.01)
+        tf = timeit(lambda: ops.conv_tap_forward(pf, x, wf, None, y, innorm=inn), a.reps)
         td = timeit(lambda: ops.conv_tap_forward(pd, dy, wd, None, dx), a.reps)
         # the schedule's weight-gradient path: partial blocks + fixed-order reduction into the torch-layout gradient
         ws = torch.empty(ops.conv_tap_wgrad_workspace_floats(pw), device=dev, dtype=torch.float32)
         gw = torch.empty_like(w)
-        tw = timeit(lambda: ops.conv_tap_wgrad_to_grad(pw, x, dy, ws, gw, 27, cin * 27, 1), a.reps)
+        if a.innorm and stride == 1:
+            pwf = PreparedTable(cp.conv_wgrad_flipped(N, dims, cin, cout))
+            tw = timeit(lambda: ops.conv_tap_wgrad_to_grad(pwf, dy, x, ws, gw, cin * 27, 27, 1, plain_norm=inn), a.reps)
+        elif a.innorm:
+            tw = timeit(lambda: ops.conv_tap_wgrad_to_grad(pw, x, dy, ws, gw, 27, cin * 27, 1, boxed_norm=inn), a.reps)
+        else:
+            tw = timeit(lambda: ops.conv_tap_wgrad_to_grad(pw, x, dy, ws, gw, 27, cin * 27, 1), a.reps)
         tot["fwd"] += tf; tot["dgrad"] += td; tot["wgrad"] += tw
         totf += flops
         print(f"{name:8s} {cin:4d}->{cout:4d} @{edge:3d} s{stride}  {flops/1e9:8.1f} GF | fwd {tf*1e3:8.3f} ms {flops/tf/1e12:7.1f} TF/s"
