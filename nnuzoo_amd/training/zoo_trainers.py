@@ -367,6 +367,29 @@ def _live_num_in_out(args, kwargs):
     return a["num_input_channels"], _num_segmentation_heads(a["dataset_json"]), a.get("enable_deep_supervision", True)
 
 
+class nnUNetTrainerSegMamba(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerSegMamba.py:15-110 (SegMamba, 2-D or 3-D; the base trainer's fp16-autocast
+    train_step - the class does not override it; deep supervision OFF - one output; AdamW 1e-4 / wd 5e-2 / eps 1e-5, cosine to
+    1e-6; `small_mode` of the factory raises there as well)"""
+    _no_miopen = True   # small-channel convolutions around the Mamba layers (see MambaND2Net above)
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.enable_deep_supervision = False
+
+    def _get_deep_supervision_scales(self):
+        if not self.enable_deep_supervision:
+            return None
+        return super()._get_deep_supervision_scales()
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.segmamba import get_seg_mamba_from_plans
+        return _legacy_or_live(lambda *a, **k: get_seg_mamba_from_plans(*a, use_pretrain=False, small_mode=False, **k),
+                               args, kwargs)
+
+
 class nnUNetTrainerU2Net(_X2Trainer):
     """reference: training/nnUNetTrainer/nnUNetTrainerU2Net.py:14-99 (U2NET; the base trainer's autocast train_step; AdamW
     1e-4 / wd 5e-2 / eps 1e-5, cosine to 1e-6; seven deep-supervision outputs, ALL at full resolution: scales [[1, 1]] * 7)"""
