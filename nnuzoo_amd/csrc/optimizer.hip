@@ -116,7 +116,125 @@ __global__ __launch_bounds__(256) void sgd_nesterov_kernel(const SgdChunk* __res
   }
 }
 
+// ---- fused AdamW tail of the zoo trainers (round 4) ------------------------------------------------------------------------------
+// The X^2-Net plugins step AdamW(lr 1e-4, wd 5e-2, eps 1e-5) behind GradScaler.unscale_ + clip_grad_norm_(12)
+// (/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainerM2Net.py:58-65, nnUNetTrainer.py:1131-1139).  With 1 500 - 4 100
+// parameter tensors torch's multi-tensor path issues ~260 launches per step, each behind 60-100 us of host-side list handling:
+// 8-17 ms of GPU idle time per step in the M2Net / SwT2Net / SSND2Net traces (profiles/r03_*_graph_kernels.txt).  Here the
+// gradients stay where autograd (or the replayed hipGraph) leaves them and a DEVICE TABLE of chunks {param, grad, exp_avg,
+// exp_avg_sq, n} - built once, the addresses are static under graph replay - drives two launches:
+//   pass 1  sum of squares + non-finite count of all (still scaled) gradients, fixed-point across workgroups (deterministic);
+//           its last workgroup also advances the per-parameter step counters when the step is going to be applied
+//   pass 2  g = grad * inv_scale * clip;  p *= 1 - lr wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+//           p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)          (torch.optim.AdamW, amsgrad off)
+// No host synchronisation: the inf / overflow skip is decided on the device like in the SGD tail above.
+struct AdamChunk {
+  float* param;
+  const float* grad;
+  float* m;
+  float* v;
+  int n;
+  int pad;
+};
+
+__global__ __launch_bounds__(256) void adam_sumsq_kernel(const AdamChunk* __restrict__ chunks, int nchunks,
+                                                         float* __restrict__ out2, FxAcc* acc, unsigned* counter,
+                                                         float* __restrict__ steps, int nsteps) {
+  __shared__ float red[4][2];
+  float s = 0.f, bad = 0.f;
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const AdamChunk ch = chunks[c];
+    const bool vec = (((size_t)ch.grad) & 15) == 0;
+    const int n4 = vec ? ch.n >> 2 : 0;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(ch.grad);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const f32x4 v = g4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s += v[e] * v[e];
+        bad += (__builtin_isnan(v[e]) || __builtin_isinf(v[e])) ? 1.f : 0.f;
+      }
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < ch.n; i += 256) {
+      const float v = ch.grad[i];
+      s += v * v;
+      bad += (__builtin_isnan(v) || __builtin_isinf(v)) ? 1.f : 0.f;
+    }
+  }
+  s = wave_sum(s);
+  bad = wave_sum(bad);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave][0] = s;
+    red[wave][1] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  if (threadIdx.x == 0) {
+    fx_add(acc, 0, 2, blockIdx.x, (double)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])));
+    fx_add(acc, 1, 2, blockIdx.x, (double)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
+  }
+  if (last_workgroup_wave(counter, gridDim.x)) {
+    float ss = 0.f, nb = 0.f;
+    if (threadIdx.x == 0) {
+      ss = (float)fx_take(acc, 0, 2);
+      nb = (float)fx_take(acc, 1, 2);
+      const bool overflow = !(ss == ss) || __builtin_isinf(ss);
+      if (overflow) nb = nb > 0.f ? nb : 1.f;   // finite gradients whose squares overflowed: skipped as well
+      out2[0] = ss;
+      out2[1] = nb;
+    }
+    nb = __shfl(nb, 0, 64);
+    if (!(nb > 0.f))
+      for (int i = threadIdx.x; i < nsteps; i += 64) steps[i] += 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, const float* __restrict__ stats2,
+                                                    const float* __restrict__ inv_scale_dev, float max_norm, float lr,
+                                                    float b1, float b2, float eps, float wd,
+                                                    const float* __restrict__ steps) {
+  if (stats2[1] > 0.f) return;   // GradScaler semantics: parameters and moments untouched
+  const float inv_scale = inv_scale_dev ? inv_scale_dev[0] : 1.f;
+  const float total_norm = sqrtf(stats2[0]) * inv_scale;
+  float clip = max_norm > 0.f ? max_norm / (total_norm + 1e-6f) : 1.f;
+  clip = clip > 1.f ? 1.f : clip;
+  const float mult = inv_scale * clip;
+  const float t = steps[0];                       // already advanced by pass 1
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1, decay = 1.f - lr * wd;
+  const AdamChunk c = chunks[blockIdx.x];
+  for (int i = threadIdx.x; i < c.n; i += 256) {
+    const float g = c.grad[i] * mult;
+    const float p = c.param[i] * decay;
+    const float m = b1 * c.m[i] + (1.f - b1) * g;
+    const float v = b2 * c.v[i] + (1.f - b2) * g * g;
+    c.m[i] = m;
+    c.v[i] = v;
+    c.param[i] = p - step_size * (m / (sqrtf(v) / bc2s + eps));
+  }
+}
+
 }  // namespace nnz
+
+extern "C" int nnz_adam_chunk_bytes(void) { return (int)sizeof(nnz::AdamChunk); }
+
+// stats2 (2 floats) is written: {sum of squares of the scaled gradients, > 0 if the step is skipped}; acc / counter: 2 zeroed
+// fixed-point records + one zeroed word (left zero); steps: the parameters' step counters (fp32, one per parameter, advanced
+// here when the step is applied); inv_scale_device: 1 / loss scale (1 float on the device) or NULL; max_norm <= 0: no clipping
+extern "C" int nnz_adamw_fused(const void* chunks_device, int nchunks, float* stats2, void* acc, void* counter,
+                               const float* inv_scale_device, float max_norm, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float* steps, int nsteps, void* stream) {
+  using namespace nnz;
+  if (!chunks_device || nchunks < 1 || !stats2 || !acc || !counter || !steps || nsteps < 1) return NNZ_EINVAL;
+  const int blocks = nchunks < 512 ? nchunks : 512;
+  NNZ_LAUNCH(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks_device, nchunks,
+             stats2, (FxAcc*)acc, (unsigned*)counter, steps, nsteps);
+  NNZ_LAUNCH(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks_device,
+             (const float*)stats2, inv_scale_device, max_norm, lr, beta1, beta2, eps, weight_decay, (const float*)steps);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
 
 extern "C" int nnz_sgd_chunk_bytes(void) { return (int)sizeof(nnz::SgdChunk); }
 

@@ -41,6 +41,24 @@ class _GlobalAttentionFn(torch.autograd.Function):
         return (dqkv if dt == torch.float32 else dqkv.to(dt)), None
 
 
-def global_attention(qkv: torch.Tensor, scale: float) -> torch.Tensor:
-    """qkv: (B, L, 3, heads, head_dim) -> (B, L, heads * head_dim)"""
-    return _GlobalAttentionFn.apply(qkv, scale)
+def hip_supported(qkv: torch.Tensor) -> bool:
+    """what csrc/global_attention.hip takes: a device tensor with an even head_dim <= 32 (the zoo's ViT stages: 8 / 16 / 32)"""
+    return qkv.is_cuda and qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.shape[4] % 2 == 0 and qkv.shape[4] <= 32
+
+
+def global_attention(qkv: torch.Tensor, scale: float, module: torch.nn.Module = None) -> torch.Tensor:
+    """qkv: (B, L, 3, heads, head_dim) -> (B, L, heads * head_dim).  Shapes outside the kernel's set (monai's UNETR / ViT
+    defaults hidden 768 / 12 heads = head_dim 64) and CPU tensors (structure checks, the planner) run on torch's
+    scaled_dot_product_attention; the choice is recorded on `module` (nnuzoo_amd/backends.py) - never silent."""
+    if hip_supported(qkv):
+        if module is not None:
+            from . import backends
+            backends.note(module, "hip-f32", "attention")
+        return _GlobalAttentionFn.apply(qkv, scale)
+    if module is not None:
+        from . import backends
+        backends.note(module, "library", "attention", why=f"head_dim {qkv.shape[-1]} on {qkv.device.type}")
+    B, L, _, H, D = qkv.shape
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))           # (B, H, L, D)
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v, scale=scale)
+    return o.transpose(1, 2).reshape(B, L, H * D)

@@ -60,7 +60,7 @@ class SABlock(nn.Module):
         qkv = self.qkv(x).view(B, L, 3, self.num_heads, self.head_dim)
         if self.dropout_rate > 0 and self.training:
             raise NotImplementedError("attention dropout > 0 is not used by the zoo (dropout_rate 0.0)")
-        o = global_attention(qkv, self.scale)                       # (B, L, heads * head_dim)
+        o = global_attention(qkv, self.scale, self)                 # (B, L, heads * head_dim)
         return self.drop_output(self.out_proj(o))
 
 

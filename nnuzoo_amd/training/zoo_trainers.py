@@ -101,9 +101,40 @@ class _X2Trainer(nnUNetTrainer):
         # instead of the foreach path, whose ~3 000 host-side `.item()` / dispatch calls per step for 1 526 parameter
         # tensors cost more host time than the whole backward (tools/profile_ops.py)
         fused = self.device.type == 'cuda' and os.environ.get("NNZ_FUSED_ADAMW", "1") != "0"
-        optimizer = AdamW(self.network.parameters(), lr=self.initial_lr, weight_decay=self.weight_decay, eps=1e-5,
-                          betas=(0.9, 0.999), fused=fused)
+        if fused and os.environ.get("NNZ_HIP_ADAMW", "1") != "0":
+            # round 4: an AdamW (same class hierarchy, state under torch's names) whose unscale + clip + step tail is two HIP
+            # launches over a device chunk table instead of ~260 multi-tensor launches (training/fused_adamw.py)
+            from .fused_adamw import FusedAdamW
+            optimizer = FusedAdamW(self.network.parameters(), lr=self.initial_lr, weight_decay=self.weight_decay, eps=1e-5,
+                                   betas=(0.9, 0.999))
+        else:
+            optimizer = AdamW(self.network.parameters(), lr=self.initial_lr, weight_decay=self.weight_decay, eps=1e-5,
+                              betas=(0.9, 0.999), fused=fused)
         return optimizer, CosineAnnealingLR(optimizer, T_max=self.num_epochs, eta_min=1e-6)
+
+    def _optimizer_tail(self):
+        """unscale_ -> clip_grad_norm_(12) -> step -> scaler update (nnUNetTrainer.py:1131-1139); the fused HIP tail when the
+        optimizer offers it, torch's sequence otherwise"""
+        from .nnUNetTrainer import _scaler_internals_ok
+        opt, sc = self.optimizer, self.grad_scaler
+        hip = hasattr(opt, "fused_step") and opt.fused_available() and (sc is None or _scaler_internals_ok(sc))
+        if hip:
+            if sc is not None:
+                inv_scale = sc._scale.double().reciprocal().float()
+                found_inf = opt.fused_step(inv_scale, 12)
+                torch._amp_update_scale_(sc._scale, sc._growth_tracker, found_inf, sc._growth_factor, sc._backoff_factor,
+                                         sc._growth_interval)
+            else:
+                opt.fused_step(None, 12)
+            return
+        if sc is not None:
+            sc.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+            sc.step(opt)
+            sc.update()
+        else:
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+            opt.step()
 
     def set_deep_supervision_enabled(self, enabled: bool):
         self.network.deep_supervision = enabled
@@ -129,14 +160,7 @@ class _X2Trainer(nnUNetTrainer):
             l = self._graphed(data, tl)
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())
-            if self.grad_scaler is not None:
-                self.grad_scaler.unscale_(self.optimizer)
-                torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
-                self.grad_scaler.step(self.optimizer)
-                self.grad_scaler.update()
-            else:
-                torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
-                self.optimizer.step()
+            self._optimizer_tail()
             return {'loss': l.detach().cpu().numpy()}
         self.optimizer.zero_grad(set_to_none=True)
         if self._fp32_step:
@@ -146,8 +170,7 @@ class _X2Trainer(nnUNetTrainer):
                 l.backward()
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())
-            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
-            self.optimizer.step()
+            self._optimizer_tail()
         else:
             with torch.autocast('cuda'):
                 output = self.network(data)
@@ -155,10 +178,7 @@ class _X2Trainer(nnUNetTrainer):
             self.grad_scaler.scale(l).backward()
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())    # scaled gradients, like torch DDP under AMP
-            self.grad_scaler.unscale_(self.optimizer)
-            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
-            self.grad_scaler.step(self.optimizer)
-            self.grad_scaler.update()
+            self._optimizer_tail()
         return {'loss': l.detach().cpu().numpy()}
 
 

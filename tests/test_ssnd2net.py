@@ -90,3 +90,114 @@ def test_ssnd2net_trainer_step_3d(hip_lib):
     assert np.isfinite(l0) and np.isfinite(l1)
     # (the first steps of a GradScaler run may carry inf gradients and be skipped; the graph must reach stage 1)
     assert sum(p.grad is not None for p in tr.network.stage1.parameters()) > 100
+
+
+# ---- round 4: every top-level module of the network against the reference's own module (stage-wise fixtures) -------------------
+def _stage_fixtures():
+    out = []
+    for cls in ("SSND2NetP", "SSND2Net"):
+        for sd in (2, 3):
+            if os.path.exists(os.path.join(GOLD, f"stages_{cls}_{sd}d.npz")):
+                out.append((cls, sd))
+    return out
+
+
+def _pattern(shape, freq, phase):
+    i = torch.arange(int(np.prod(shape)), dtype=torch.float64)
+    return torch.cos(freq * i + phase).float().reshape(shape)
+
+
+def test_stage_fixture_manifests_cover_the_network():
+    """the fixtures list every top-level child the reference's forward calls: the eleven MU stages, five patch mergings, five patch
+    expansions, four skip-fusion Linears, six side convolutions and the fuse convolution (32 calls)"""
+    assert ("SSND2NetP", 2) in _stage_fixtures()
+    for cls, sd in _stage_fixtures():
+        man = json.load(open(os.path.join(GOLD, f"stages_{cls}_{sd}d.json")))
+        names = [m["name"] for m in man["modules"]]
+        assert len(names) == 32 and names[0] == "stage1" and names[-1] == "outconv"
+        assert {f"stage{i}" for i in range(1, 7)} | {f"stage{i}d" for i in range(1, 6)} <= set(names)
+        recorded = [m for m in man["modules"] if "out_stride" in m]
+        assert len(recorded) >= 24 and all(m["sens"] < 5e-2 for m in man["modules"])   # no module is chaotic on its own
+        net = _build(cls, (man["patch"],) * sd)
+        for m in man["modules"]:
+            assert sum(p.numel() for p in getattr(net, m["name"]).parameters()) == m["params"], m["name"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,sd", _stage_fixtures())
+def test_every_stage_matches_the_reference_module_forward_and_backward(hip_lib, cls, sd):
+    """VERDICT r3 item 2a.  The whole network is chaotic at its seeded initialisation (the reference moves its own outputs by
+    40-96 % for a 1e-6 input perturbation, tools/make_golden_ssnd2net.py), so parity is taken per top-level module on the
+    REFERENCE's own input: output, dx and the L2 norm of every parameter gradient for a fixed output gradient; stage 1 - fed
+    the network input - is the end-to-end piece.  Parameters: torch.manual_seed(0) construction on both sides (bit-identical,
+    tests/golden/seeded_init.json).  Tolerance 2e-3 of the output scale, widened only by the module's own measured conditioning
+    (`sens`: the reference's relative output change for a 1e-6 input perturbation)."""
+    man = json.load(open(os.path.join(GOLD, f"stages_{cls}_{sd}d.json")))
+    g = np.load(os.path.join(GOLD, f"stages_{cls}_{sd}d.npz"))
+    patch = (man["patch"],) * sd
+    torch.manual_seed(0)
+    net = _build(cls, patch).cuda().eval()
+    checked = 0
+    for rec in man["modules"]:
+        name = rec["name"]
+        if "out_stride" not in rec:
+            continue          # full-resolution decoder-side module: statistics only in the fixture (same classes as below)
+        mod = getattr(net, name)
+        if name == "stage1":
+            ins = [torch.from_numpy(g["x"])]
+        else:
+            ins = [torch.from_numpy(g[f"in{k}_{name}"]) for k in range(len(rec["in_shapes"]))]
+        xin = [t.cuda().requires_grad_(True) for t in ins]
+        for p in mod.parameters():
+            p.grad = None
+        y = mod(*xin, **rec["kwargs"])
+        assert list(y.shape) == rec["out_shape"], name
+        ref = torch.from_numpy(g[f"out_{name}"])
+        got = y.detach().float().cpu().reshape(-1)[::rec["out_stride"]].reshape(ref.shape)
+        scale = ref.abs().max().item()
+        sens = rec["sens"]
+        err = (got - ref).abs().max().item()
+        assert err <= max(2e-3, 30 * sens) * scale, (name, err, scale, sens)
+        y.backward(_pattern(y.shape, 0.37, 0.5).cuda())
+        dref = torch.from_numpy(g[f"dx_{name}"])
+        dgot = xin[0].grad.float().cpu().reshape(-1)[::rec["dx_stride"]]
+        derr = (dgot - dref).abs().max().item()
+        assert derr <= max(5e-3, 100 * sens) * dref.abs().max().item(), (name, derr, dref.abs().max().item(), sens)
+        dn = float(xin[0].grad.double().pow(2).sum().sqrt())
+        assert abs(dn - rec["dx_norm"]) <= max(5e-3, 100 * sens) * rec["dx_norm"], (name, dn, rec["dx_norm"])
+        params = dict(mod.named_parameters())
+        norms = g[f"gn_{name}"]
+        assert [n for n in rec["grad_names"]] == [n for n, p in mod.named_parameters() if p.grad is not None], name
+        top = float(norms.max())
+        for n, want in zip(rec["grad_names"], norms):
+            have = float(params[n].grad.double().pow(2).sum().sqrt())
+            assert abs(have - want) <= max(2e-2, 300 * sens) * max(want, 1e-3 * top), (name, n, have, want)
+        checked += 1
+    assert checked >= 24
+
+
+@pytest.mark.gpu
+def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
+    """VERDICT r3 item 2b.  The 512^2 bench loss of round 3 looked flat (2.44 over 8 steps) because every one of those steps was
+    SKIPPED: the gradient norm of the seeded SSND2Net is ~3e4 (its logits reach +-27 at initialisation), so the fp16 backward
+    overflows until GradScaler has halved its scale from 65536 to <= 64 - ten skipped steps, the reference's own behaviour
+    (its trainer inherits the autocast + GradScaler step, nnUNetTrainer.py:1128-1139; tools/probes/ssnd2net_loss_probe.py logs
+    scale / skipped / norm per step; in fp32 the same net descends from the first step).  Here: the scale backs off, then the
+    loss falls."""
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerSSND2NetP
+    plans, cfg, dj = nnunet_plans(2, (128, 128), batch_size=2)
+    torch.manual_seed(0)
+    tr = nnUNetTrainerSSND2NetP(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    b = synthetic_batch(2, (128, 128), tr._get_deep_supervision_scales(), seed=3)
+    b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+    losses, scales = [], []
+    for _ in range(30):
+        losses.append(float(tr.train_step(b)["loss"]))
+        scales.append(float(tr.grad_scaler.get_scale()))
+    assert all(np.isfinite(l) for l in losses)
+    applied = [i for i in range(1, 30) if scales[i] >= scales[i - 1]]        # steps whose update was applied (no back-off)
+    assert len(applied) >= 10, scales
+    first = applied[0]
+    assert np.mean(losses[-3:]) < losses[first] - 0.05, (losses, scales)

@@ -75,3 +75,19 @@ def test_whole_net_and_trainer_step(hip_lib):
         assert all(np.isfinite(losses))
     finally:
         torch.backends.cudnn.enabled = prev
+
+
+def test_attention_outside_the_kernel_set_runs_on_the_library_and_says_so():
+    """monai's UNETR / ViT defaults (hidden 768, 12 heads = head_dim 64) and CPU tensors must still run - on
+    torch's SDPA, with the choice recorded on the module (never a silent fallback, never a raise).  CPU test."""
+    from nnuzoo_amd import backends
+    from nnuzoo_amd.nets.unetr2net import SABlock
+    torch.manual_seed(0)
+    blk = SABlock(768, 12)
+    x = torch.randn(2, 10, 768)
+    y = blk(x)
+    qkv = blk.qkv(x).view(2, 10, 3, 12, 64)
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    ref = blk.out_proj(((q @ k.transpose(-1, -2) * blk.scale).softmax(-1) @ v).transpose(1, 2).reshape(2, 10, 768))
+    assert torch.allclose(y, ref, atol=1e-5)
+    assert backends.report(blk) == {"SABlock.attention": {"library": 1}}

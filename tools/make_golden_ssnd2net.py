@@ -127,7 +127,9 @@ def main():
     ap.add_argument("classes", nargs="*", default=["SSND2NetP", "SSND2Net"])
     ap.add_argument("--dims", nargs="*", type=int, default=[2, 3])
     ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--max-io-floats", type=int, default=MAX_IO_FLOATS)
     a = ap.parse_args()
+    globals()["MAX_IO_FLOATS"] = a.max_io_floats
     torch.set_num_threads(a.threads)
     ref_shim.install()
     from nnunetv2.nets import ssnd2net as R
