@@ -542,8 +542,9 @@ int nnz_convT_forward_innorm(const void* in_raw_f16, const float* in_tab, float 
  * disables clipping.  Deterministic (fixed-point gradient norm), no host synchronisation. */
 int nnz_adam_chunk_bytes(void);
 int nnz_adamw_fused(const void* chunks_device, int nchunks, float* stats2, void* acc, void* counter,
-                    const float* inv_scale_device, float max_norm, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, float* steps, int nsteps, void* stream);
+                    const float* inv_scale_device, float max_norm, float lr, double beta1, double beta2 /* doubles: 1 - beta
+                    is formed in double like torch does */, float eps, float weight_decay, float* steps, int nsteps,
+                    void* stream);
 
 #ifdef __cplusplus
 }

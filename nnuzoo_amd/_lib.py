@@ -106,7 +106,7 @@ SIGNATURES = {
     "nnz_convT_forward": [_fp, _fp, _fp, _fp] + [_i] * 11 + [_vp],
     "nnz_convT_dgrad": [_fp, _fp, _fp] + [_i] * 11 + [_vp],
     "nnz_adam_chunk_bytes": [],
-    "nnz_adamw_fused": [_vp, _i, _fp, _vp, _vp, _fp, _f, _f, _f, _f, _f, _f, _fp, _i, _vp],
+    "nnz_adamw_fused": [_vp, _i, _fp, _vp, _vp, _fp, _f, _f, C.c_double, C.c_double, _f, _f, _fp, _i, _vp],
     "nnz_conv_tap_forward_innorm": [_vp, _vp, _vp, _fp, _dp, _fp, _i, _f, _vp, _vp, _fp, _fp, _f, _fp, _fp, _l, _vp],
     "nnz_conv_tap_wgrad_to_grad_innorm": [_vp, _vp, _fp, _l, _fp, _l, _l, _l, _ip, _i, _dp, _fp, _i, _f, _fp, _i, _f, _vp],
     "nnz_seg_head_forward_innorm": [_vp, _fp, _f, _fp, _fp, _vp, _i, _l, _i, _i, _i, _vp],

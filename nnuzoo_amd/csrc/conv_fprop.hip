@@ -145,7 +145,10 @@ struct ConvCfg {
 //   4  smallest Cin for knob 1                                                          (default 32)
 //   5  1 disables split-K over the reduction slices (the <= 8^3 levels; needs the *_ws entry points)  (default 0)
 //   6  epilogue experiments of the fused norm-backward launches (ConvDev::dbg)         (default 0)
-static int g_tuning[8] = {1, 1, 16, 1, 32, 0, 0, 0};
+//   7  stride-2 forward convolutions on >= 32^3 output grids take the 4x8x8 x 64-cout tile, one workgroup per CU   (default 1:
+//      32 -> 64 @128^3 0.238 -> 0.207 ms, 64 -> 128 @64^3 0.102 -> 0.093 ms, tools/bench_conv_layers.py --tuning 7=0/1)
+//   8  split-K applies to launches of fewer than this many workgroups                                                (default 128)
+static int g_tuning[12] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 0, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
@@ -153,8 +156,10 @@ static int g_tuning[8] = {1, 1, 16, 1, 32, 0, 0, 0};
 // instead of being re-read from LDS for each: 6 voxel + 3 weight fragments per (kh, kw) for 12 MFMAs = 0.75 KB of LDS
 // reads per MFMA against 1.25 KB in the tap-by-tap loop.  With Cout = 32 there is only one N block, so this is the only
 // reuse a voxel fragment can get; it takes the LDS array from ~75 % to ~50 % busy on the full-resolution layers.
-template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false>
-__global__ __launch_bounds__(256, 2) void conv_box_kernel(ConvDev p) {
+// MINB: workgroups per CU the register budget is sized for (2: <= 256 VGPRs; 1: the big stride-2 tile, whose 142 KB of box +
+// weights allow one workgroup per CU anyway, may use the whole file)
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   using C = ConvCfg<TD, TH, TW, NB>;
   static_assert(!DRE || (TD == 8 && TH == 8 && TW == 8 && NB == 1), "depth-reuse loop: 8x8x8 tile, one cout block");
   const G geo(p.d);
@@ -907,7 +912,7 @@ static int splitk_plan(const ConvDev& p, long ws_floats, int wgs_base, int* kper
   const nnz_conv_desc& d = p.d;
   const int nkc = d.Cin / 16;
   if (g_tuning[5] || !p.part || d.ngroups != 1 || d.out_stride[0] != 1 || d.out_stride[1] != 1 || d.out_stride[2] != 1 ||
-      nkc < 8 || wgs_base >= 128 || p.stats || p.bx)
+      nkc < 8 || wgs_base >= g_tuning[8] || p.stats || p.bx)
     return 1;
   int splits = (384 + wgs_base - 1) / wgs_base;
   if (splits > nkc / 2) splits = nkc / 2;          // at least two slices per workgroup
@@ -918,7 +923,7 @@ static int splitk_plan(const ConvDev& p, long ws_floats, int wgs_base, int* kper
   return (nkc + *kper - 1) / *kper;
 }
 
-template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false>
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false, int MINB = 2>
 static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   using C = ConvCfg<TD, TH, TW, NB>;
   ConvDev p = base;
@@ -949,7 +954,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   if (p.nsplit <= 1) p.part = nullptr;
   p.gz = p.d.N * p.d.ngroups * (p.nsplit > 1 ? p.nsplit : 1);
   p.cout_fastest = g_tuning[3] && p.gy > 1;
-  auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G, DRE, DFLIP>;
+  auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G, DRE, DFLIP, MINB>;
   static DynLdsCache lds_cache;  // per instantiation, per device
   {
     hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_cache);
@@ -1024,6 +1029,10 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
     //  spills and 1 workgroup per CU made it 7-13 % slower than 4x8x8 - measured, round 1)
     return launch_iso<4, 8, 8, 2, IS, EXT>(p, stream);
   } else {
+    // stride 2, large grids (knob 7): 4x8x8 voxels x 64 couts per workgroup - four times the MFMA work per staged slice and
+    // half the LDS fragment traffic per MFMA (2 x 2 register tile) of the 2x4x8 tile, at one workgroup per CU (142 KB of LDS)
+    if (g_tuning[7] && mvox >= 32L * 32 * 32)
+      return launch_cfg<4, 8, 8, 2, iso_lpt<4, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, false, false, 1>(p, stream);
     return launch_iso<2, 4, 8, 2, IS, EXT>(p, stream);  // N-split over waves: needs Cout % 64 == 0
   }
 }
@@ -1087,7 +1096,7 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
                                  const InNormArgs* inn = nullptr);
 
 extern "C" int nnz_conv_tuning(int knob, int value) {
-  if (knob < 0 || knob >= 8) return NNZ_EINVAL;
+  if (knob < 0 || knob >= 12) return NNZ_EINVAL;
   nnz::g_tuning[knob] = value;
   return NNZ_OK;
 }

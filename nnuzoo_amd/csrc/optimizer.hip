@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const AdamChunk* __rest
 
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, const float* __restrict__ stats2,
                                                     const float* __restrict__ inv_scale_dev, float max_norm, float lr,
-                                                    float b1, float b2, float eps, float wd,
+                                                    float b1, float b2, float omb1, float omb2, float eps, float wd,
                                                     const float* __restrict__ steps) {
   if (stats2[1] > 0.f) return;   // GradScaler semantics: parameters and moments untouched
   const float inv_scale = inv_scale_dev ? inv_scale_dev[0] : 1.f;
@@ -200,15 +200,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
   float clip = max_norm > 0.f ? max_norm / (total_norm + 1e-6f) : 1.f;
   clip = clip > 1.f ? 1.f : clip;
   const float mult = inv_scale * clip;
-  const float t = steps[0];                       // already advanced by pass 1
-  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  // bias corrections in double, once per workgroup: 1 - 0.999^t in fp32 (fast-math powf) loses four digits at small t
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const double t = (double)steps[0];            // already advanced by pass 1
+    bc[0] = (float)(1.0 - pow((double)b1, t));
+    bc[1] = (float)sqrt(1.0 - pow((double)b2, t));
+  }
+  __syncthreads();
+  const float bc1 = bc[0], bc2s = bc[1];
   const float step_size = lr / bc1, decay = 1.f - lr * wd;
   const AdamChunk c = chunks[blockIdx.x];
   for (int i = threadIdx.x; i < c.n; i += 256) {
     const float g = c.grad[i] * mult;
     const float p = c.param[i] * decay;
-    const float m = b1 * c.m[i] + (1.f - b1) * g;
-    const float v = b2 * c.v[i] + (1.f - b2) * g * g;
+    const float m = b1 * c.m[i] + omb1 * g;      // omb = 1 - beta formed in double by the host like torch does (1.f - 0.999f is
+    const float v = b2 * c.v[i] + omb2 * g * g;  // off by 1.3e-5 relative: visible in exp_avg_sq after a few steps)
     c.m[i] = m;
     c.v[i] = v;
     c.param[i] = p - step_size * (m / (sqrtf(v) / bc2s + eps));
@@ -223,15 +230,17 @@ extern "C" int nnz_adam_chunk_bytes(void) { return (int)sizeof(nnz::AdamChunk); 
 // fixed-point records + one zeroed word (left zero); steps: the parameters' step counters (fp32, one per parameter, advanced
 // here when the step is applied); inv_scale_device: 1 / loss scale (1 float on the device) or NULL; max_norm <= 0: no clipping
 extern "C" int nnz_adamw_fused(const void* chunks_device, int nchunks, float* stats2, void* acc, void* counter,
-                               const float* inv_scale_device, float max_norm, float lr, float beta1, float beta2, float eps,
+                               const float* inv_scale_device, float max_norm, float lr, double beta1d, double beta2d, float eps,
                                float weight_decay, float* steps, int nsteps, void* stream) {
   using namespace nnz;
+  const float beta1 = (float)beta1d, beta2 = (float)beta2d;
   if (!chunks_device || nchunks < 1 || !stats2 || !acc || !counter || !steps || nsteps < 1) return NNZ_EINVAL;
   const int blocks = nchunks < 512 ? nchunks : 512;
   NNZ_LAUNCH(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks_device, nchunks,
              stats2, (FxAcc*)acc, (unsigned*)counter, steps, nsteps);
   NNZ_LAUNCH(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks_device,
-             (const float*)stats2, inv_scale_device, max_norm, lr, beta1, beta2, eps, weight_decay, (const float*)steps);
+             (const float*)stats2, inv_scale_device, max_norm, lr, beta1, beta2, (float)(1.0 - (double)beta1d),
+             (float)(1.0 - (double)beta2d), eps, weight_decay, (const float*)steps);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

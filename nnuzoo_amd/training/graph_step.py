@@ -47,8 +47,10 @@ def capture_memset_free(fn: Callable, stream: torch.cuda.Stream):
 
 
 class GraphedForwardBackward:
-    def __init__(self, network: torch.nn.Module, loss_fn: Callable, grad_scaler, autocast: bool, warmup_iters: int = 2):
+    def __init__(self, network: torch.nn.Module, loss_fn: Callable, grad_scaler, autocast: bool, warmup_iters: int = 2,
+                 forward_fn: Optional[Callable] = None):
         self.network, self.loss_fn, self.scaler, self.autocast = network, loss_fn, grad_scaler, autocast
+        self.forward_fn = forward_fn if forward_fn is not None else network    # e.g. nnuzoo_amd.param_shadow.ParamShadow
         self.warmup_iters = warmup_iters
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_data = None
@@ -58,6 +60,7 @@ class GraphedForwardBackward:
         self._key = None
         self._static_grads = []        # [(parameter, the .grad tensor the captured backward writes)]
         self._static_arena = None      # explicit-schedule networks: (arena, layout, unused ids) the captured backward fills
+        self.generation = 0            # number of captures so far: (id(self), generation) names one set of static gradients
 
     def _loss(self, out, target):
         if isinstance(out, (tuple, list)):
@@ -67,9 +70,9 @@ class GraphedForwardBackward:
     def _fwd_bwd(self, data, target):
         if self.autocast:
             with torch.autocast('cuda'):
-                loss = self._loss(self.network(data), target)
+                loss = self._loss(self.forward_fn(data), target)
         else:
-            loss = self._loss(self.network(data), target)
+            loss = self._loss(self.forward_fn(data), target)
         from ..token_linear import deferred_wgrads
         with deferred_wgrads():      # fp32 Linear weight gradients of the pass run as ONE grouped launch at the end
             (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
@@ -109,6 +112,11 @@ class GraphedForwardBackward:
         if hasattr(self.network, "grad_arena") and self.network.grad_arena() is not None:
             self._static_arena = (self.network._last_arena, self.network._arena_layout, self.network._last_unused)
         self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
+        self.generation += 1
+
+    def grads_token(self):
+        """identifies the static gradient tensors the replay writes (see FusedAdamW.fused_step)"""
+        return (id(self), self.generation)
 
     def __call__(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
         """Runs forward+backward for (data, target); gradients are in p.grad afterwards.  Returns the loss tensor."""

@@ -87,6 +87,10 @@ class _X2Trainer(nnUNetTrainer):
             self.network = prepare_autograd_network_for_ddp(self.network)
             self.optimizer, self.lr_scheduler = self.configure_optimizers()
         self.loss = self._build_loss()
+        # fp16-autocast steps: one multi-tensor cast of the plain torch convolutions' parameters per step instead of one cast
+        # launch per parameter and direction (nnuzoo_amd/param_shadow.py)
+        from ..param_shadow import ParamShadow
+        self._forward = ParamShadow(self.network) if (self.device.type == 'cuda' and not self._fp32_step) else self.network
         self.was_initialized = True
 
     def _get_deep_supervision_scales(self):
@@ -112,7 +116,7 @@ class _X2Trainer(nnUNetTrainer):
                               betas=(0.9, 0.999), fused=fused)
         return optimizer, CosineAnnealingLR(optimizer, T_max=self.num_epochs, eta_min=1e-6)
 
-    def _optimizer_tail(self):
+    def _optimizer_tail(self, grads_token=None):
         """unscale_ -> clip_grad_norm_(12) -> step -> scaler update (nnUNetTrainer.py:1131-1139); the fused HIP tail when the
         optimizer offers it, torch's sequence otherwise"""
         from .nnUNetTrainer import _scaler_internals_ok
@@ -121,11 +125,11 @@ class _X2Trainer(nnUNetTrainer):
         if hip:
             if sc is not None:
                 inv_scale = sc._scale.double().reciprocal().float()
-                found_inf = opt.fused_step(inv_scale, 12)
+                found_inf = opt.fused_step(inv_scale, 12, grads_token)
                 torch._amp_update_scale_(sc._scale, sc._growth_tracker, found_inf, sc._growth_factor, sc._backoff_factor,
                                          sc._growth_interval)
             else:
-                opt.fused_step(None, 12)
+                opt.fused_step(None, 12, grads_token)
             return
         if sc is not None:
             sc.unscale_(opt)
@@ -155,12 +159,12 @@ class _X2Trainer(nnUNetTrainer):
             from .graph_step import GraphedForwardBackward
             if self._graphed is None:
                 self._graphed = GraphedForwardBackward(self.network, self.loss, self.grad_scaler,
-                                                       autocast=not self._fp32_step)
+                                                       autocast=not self._fp32_step, forward_fn=self._forward)
             tl = target if isinstance(target, list) else [target]
             l = self._graphed(data, tl)
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())
-            self._optimizer_tail()
+            self._optimizer_tail(self._graphed.grads_token())
             return {'loss': l.detach().cpu().numpy()}
         self.optimizer.zero_grad(set_to_none=True)
         if self._fp32_step:
@@ -173,7 +177,7 @@ class _X2Trainer(nnUNetTrainer):
             self._optimizer_tail()
         else:
             with torch.autocast('cuda'):
-                output = self.network(data)
+                output = self._forward(data)
                 l = self.loss(list(output) if isinstance(output, (tuple, list)) else output, target)
             self.grad_scaler.scale(l).backward()
             if self.is_ddp:

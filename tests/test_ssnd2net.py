@@ -180,7 +180,8 @@ def test_every_stage_matches_the_reference_module_forward_and_backward(hip_lib, 
 def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
     """VERDICT r3 item 2b.  The 512^2 bench loss of round 3 looked flat (2.44 over 8 steps) because every one of those steps was
     SKIPPED: the gradient norm of the seeded SSND2Net is ~3e4 (its logits reach +-27 at initialisation), so the fp16 backward
-    overflows until GradScaler has halved its scale from 65536 to <= 64 - ten skipped steps, the reference's own behaviour
+    overflows until GradScaler has halved its scale from 65536 far enough (<= 64 at 512^2, below 1 for this 128^2 SSND2NetP
+    case: 25 halvings) - ten to twenty-five skipped steps, the reference's own behaviour
     (its trainer inherits the autocast + GradScaler step, nnUNetTrainer.py:1128-1139; tools/probes/ssnd2net_loss_probe.py logs
     scale / skipped / norm per step; in fp32 the same net descends from the first step).  Here: the scale backs off, then the
     loss falls."""
@@ -193,11 +194,12 @@ def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
     b = synthetic_batch(2, (128, 128), tr._get_deep_supervision_scales(), seed=3)
     b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
     losses, scales = [], []
-    for _ in range(30):
+    nsteps = 56
+    for _ in range(nsteps):
         losses.append(float(tr.train_step(b)["loss"]))
         scales.append(float(tr.grad_scaler.get_scale()))
     assert all(np.isfinite(l) for l in losses)
-    applied = [i for i in range(1, 30) if scales[i] >= scales[i - 1]]        # steps whose update was applied (no back-off)
+    applied = [i for i in range(1, nsteps) if scales[i] >= scales[i - 1]]    # steps whose update was applied (no back-off)
     assert len(applied) >= 10, scales
     first = applied[0]
     assert np.mean(losses[-3:]) < losses[first] - 0.05, (losses, scales)

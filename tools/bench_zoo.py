@@ -29,8 +29,10 @@ def main():
         tr = cls(plans, cfg, 0, dj, device=torch.device("cuda"))
         tr.initialize()
         tr.use_hip_graph = bool(a.graph)
-        b = synthetic_batch(a.batch, (a.size, a.size), tr._get_deep_supervision_scales(), seed=3)
-        b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+        scales = tr._get_deep_supervision_scales()
+        b = synthetic_batch(a.batch, (a.size, a.size), scales if scales is not None else [[1.0, 1.0]], seed=3)
+        # single-output trainers (deep supervision off: SegMamba, LightMUNet, SwinTransformerUnet) take one target tensor
+        b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]] if scales is not None else b["target"][0].cuda()}
         losses = []
         for _ in range(a.warmup):
             losses.append(float(tr.train_step(b)["loss"]))

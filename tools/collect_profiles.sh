@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r03
+#   bash tools/collect_profiles.sh r04
 # Writes under gpurun_out/ (copy what is to be judged into profiles/).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-swt2net"
@@ -32,7 +32,17 @@ rm -rf $OUT/prof_stats $OUT/prof_f $OUT/prof_w $OUT/prof_zoo_pmc
 cd $GRAFT_REPO_ROOT
 python3 tools/bench_scan.py > $OUT/${TAG}_scan_bench.txt 2>&1
 python3 tools/bench_conv_layers.py > $OUT/${TAG}_conv_layers.txt 2>&1
-python3 tools/bench_zoo.py --models M2NetP,M2Net,SwT2Net,SSND2Net,MambaND2Net,UNETR2Net,LightMamba2Net,LightMamba2NetP --steps 5 --warmup 3 2>&1 | grep '"model"' > $OUT/${TAG}_zoo_bench.txt
+# (warm-up 14: the GradScaler of the autocast nets backs off for ~10 steps on the seeded SSND2Net - DESIGN section 2 - and the
+#  timed steps should be applied ones)
+python3 tools/bench_zoo.py --models M2NetP,M2Net,SwT2Net,SSND2Net,SSND2NetP,MambaND2Net,UNETR2Net,LightMamba2Net,LightMamba2NetP,LM2Net,SegMamba --steps 6 --warmup 14 2>&1 | grep '"model"' > $OUT/${TAG}_zoo_bench.txt
+# round 4: same-box A/B of the consumer-side norm (kernel stats of the primary bench under both settings); conv experiments
+bash tools/ab_kernel_stats.sh NNZ_CONSUMER_NORM 0 1 ${TAG}_ab
+cd $GRAFT_REPO_ROOT
+( for T in "7=0" "7=1" "8=128" "8=256"; do python3 tools/bench_conv_layers.py --tuning $T 2>&1 | grep -E "tuning|enc1.0|enc2.0|enc3.1|dec3.0|TOTAL"; done
+  echo "--- forward with a raw (consumer-normalised) input and flipped weight gradient: --innorm 0 / 1"
+  python3 tools/bench_conv_layers.py --innorm 0 2>&1 | grep -E "enc0.1|dec0.0|enc1.0|enc1.1|dec1.0|TOTAL"
+  python3 tools/bench_conv_layers.py --innorm 1 2>&1 | grep -E "enc0.1|dec0.0|enc1.0|enc1.1|dec1.0|TOTAL" ) > $OUT/${TAG}_conv_experiments.txt
+python3 tools/probes/ssnd2net_loss_probe.py --size 512 --steps 14 2>/dev/null | grep '^{' | cut -c1-260 > $OUT/${TAG}_ssnd2net_loss_probe.txt
 # 4b. the window-attention kernels: SQ counters over one SwT2Net run (eager: one dispatch per kernel)
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $OUT/prof_wa_pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models SwT2Net --steps 1 --warmup 1 --graph 0 > /dev/null 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_kernel_sums.py $(ls $OUT/prof_wa_pmc/*/*counter_collection.csv | head -1) win_attn dense32 > $OUT/${TAG}_swt2net_pmc_sq_summary.json 2>&1
