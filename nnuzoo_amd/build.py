@@ -45,12 +45,12 @@ def _digest(path: str) -> str:
     return h.hexdigest()
 
 
-def _compile(src: str) -> str:
+def _compile(src: str, force: bool = False, obj_dir: str = None) -> str:
     path = os.path.join(CSRC, src)
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    obj = os.path.join(obj_dir or OBJ, src.replace(".hip", ".o"))
     stamp = obj + ".sha1"
     dig = _digest(path)
-    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
     cmd = [HIPCC, *_flags(src), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -61,11 +61,20 @@ def _compile(src: str) -> str:
     return obj
 
 
-def build(verbose: bool = True, jobs: int = 4) -> str:
+# the two smallest sources: always recompiled by build(), so that every call exercises hipcc --offload-arch=gfx950 and the link
+# step even when the sha1 stamps of the (git-ignored, shipped) objects say everything is current
+ALWAYS = ("device_info.hip", "graph_tools.hip")
+
+
+def build(verbose: bool = True, jobs: int = 4, force: bool = None) -> str:
+    """force=True (or NNZ_BUILD_FORCE=1) recompiles every source; otherwise sources whose digest (file + headers + flags) matches
+    the stamp of their object are skipped - except ALWAYS."""
+    if force is None:
+        force = os.environ.get("NNZ_BUILD_FORCE", "0") == "1"
     os.makedirs(OBJ, exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(_compile, srcs))
+        objs = list(ex.map(lambda s_: _compile(s_, force or s_ in ALWAYS), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
@@ -73,10 +82,10 @@ def build(verbose: bool = True, jobs: int = 4) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"[nnuzoo_amd.build] {LIB} ({len(srcs)} HIP sources)")
+        print(f"[nnuzoo_amd.build] {LIB} ({len(srcs)} HIP sources{', all recompiled' if force else ''})")
     return LIB
 
 
 if __name__ == "__main__":
-    build()
+    build(force="--force" in sys.argv[1:] or None)
     sys.exit(0)
