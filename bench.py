@@ -325,6 +325,22 @@ def run_swt2net(steps: int, warmup: int):
     return out
 
 
+_REAL_STDOUT_FD = None
+
+
+def _emit(text: str):
+    """the contract line, on the process's real stdout (see main)"""
+    sys.stdout.flush()
+    if _REAL_STDOUT_FD is None:
+        print(text, flush=True)
+        return
+    import ctypes
+    ctypes.CDLL(None).fflush(None)            # whatever C code buffered for stdout so far leaves through stderr
+    os.dup2(_REAL_STDOUT_FD, 1)
+    os.write(1, (text + "\n").encode())
+    os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -351,6 +367,13 @@ def main():
     backend = os.environ.get("NNZ_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
     if os.environ.get("NNZ_BENCH_DRYRUN") == "1":
         return dryrun(a, world, rank)
+    # stdout carries ONE JSON line.  Libraries print there too (this RCCL build writes a version banner to C stdout, which
+    # surfaced BEHIND the JSON line when the buffer was flushed at exit): everything written to fd 1 during the run goes to
+    # stderr instead, the line is printed on the saved descriptor (_emit) and fd 1 points at stderr again afterwards.
+    global _REAL_STDOUT_FD
+    sys.stdout.flush()
+    _REAL_STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
     # NNZ_BENCH_SHARE_GPU=1: several ranks on one device (gloo only - RCCL refuses duplicate devices); used by the
     # 1-GPU box test that runs the real two-rank step
     share = os.environ.get("NNZ_BENCH_SHARE_GPU") == "1"
@@ -393,7 +416,11 @@ def main():
         torch.cuda.synchronize()
 
     losses = []
-    graph = bool(getattr(trainer, "use_hip_graph", False)) and world == 1 and not force_ddp
+    # N = 1: forward + loss + backward replayed as one hipGraph; N > 1 (or NNZ_BENCH_FORCE_DDP=1): eager step with the bucketed
+    # all-reduce overlapped with the backward (NNZ_DDP_GRAPH=1 opts into graph SEGMENTS with the RCCL collectives between them,
+    # training/graph_step.py GraphedDDPStep: +0.4 % at world size 1, see nnUNetTrainer.train_step)
+    graph = bool(getattr(trainer, "use_hip_graph", False)) and \
+        ((world == 1 and not force_ddp) or os.environ.get("NNZ_DDP_GRAPH", "0") == "1")
     trainer.use_hip_graph = graph
     for _ in range(a.warmup):
         losses.append(float(trainer.train_step(batch)["loss"]))
@@ -498,12 +525,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"nnUNet 3d_fullres, synthetic 1x{a.patch}^3 patches, batch {per_gpu_batch}/GPU, "
                                    f"6 stages 32-320 feat, deep supervision, full train_step"
-                                   + (" (forward+loss+backward replayed as one hipGraph)" if graph else " (eager)"),
+                                   + ((" (forward+loss+backward replayed as hipGraph segments, RCCL all-reduce between them)"
+                                       if getattr(trainer, "_graphed_ddp", None) is not None else
+                                       " (forward+loss+backward replayed as one hipGraph)") if graph else " (eager)"),
                        "global_batch": per_gpu_batch * world, "parallelism": f"dp{world}",
                        "conv_gflop_per_sample_fwd": round(fwd_flops / 1e9, 1)},
             "patches_per_s_per_gpu": round(patches / dt / world, 3),
             "final_loss": round(losses[-1], 5),
-            "hip_graph": graph, "rccl_ranks": rccl_ranks, "allreduce_buckets_per_step": buckets_per_step,
+            "hip_graph": graph, "hip_graph_segments": (len(trainer._graphed_ddp.segments)
+                                                        if getattr(trainer, "_graphed_ddp", None) is not None else (1 if graph else 0)),
+            "rccl_ranks": rccl_ranks, "allreduce_buckets_per_step": buckets_per_step,
             "roofline": roof,
             "h2d_inclusive": h2d,
         }
@@ -525,7 +556,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             if "secondary" in line:
                 line["secondary"]["cpu_baseline"] = cpu_scan_baseline()
-        print(json.dumps(line), flush=True)
+        _emit(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

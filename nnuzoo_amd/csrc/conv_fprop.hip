@@ -85,6 +85,7 @@ struct ConvDev {
   int in_c0;
   float in_slope;
   int intab_off;   // byte offset of the LDS table (launcher)
+  int tiles_per_wg;  // PERSIST instantiations: consecutive m-tiles (along W) per workgroup; gx counts workgroups' first tiles
 };
 
 // Box geometry policies.  GeoIso: input stride and tap extent are compile-time and equal on the three axes (the
@@ -148,7 +149,8 @@ struct ConvCfg {
 //   7  stride-2 forward convolutions on >= 32^3 output grids take the 4x8x8 x 64-cout tile, one workgroup per CU   (default 1:
 //      32 -> 64 @128^3 0.238 -> 0.207 ms, 64 -> 128 @64^3 0.102 -> 0.093 ms, tools/bench_conv_layers.py --tuning 7=0/1)
 //   8  split-K applies to launches of fewer than this many workgroups                                                (default 128)
-static int g_tuning[12] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 0, 0, 0};
+//   9  depth-reuse launches: most consecutive W tiles one (persistent) workgroup walks (power of two; 1 = off)    (default 4)
+static int g_tuning[12] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
@@ -158,7 +160,12 @@ static int g_tuning[12] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 0, 0, 0};
 // reuse a voxel fragment can get; it takes the LDS array from ~75 % to ~50 % busy on the full-resolution layers.
 // MINB: workgroups per CU the register budget is sized for (2: <= 256 VGPRs; 1: the big stride-2 tile, whose 142 KB of box +
 // weights allow one workgroup per CU anyway, may use the whole file)
-template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false, int MINB = 2>
+// PERSIST: a workgroup walks `tiles_per_wg` consecutive m-tiles along W (same sample, same cout block).  The per-workgroup set-up
+// (argument loads, tap tables, fragment addresses: ~2 000 instructions, ~1/4 of a 2-slice workgroup's time) is paid once, and
+// the next tile's first slice is requested while the current tile's last slice is still in its MFMA loop (forward launches: the
+// epilogue does not need the staging registers), so its HBM latency hides behind that loop and the epilogue.
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false, int MINB = 2,
+          bool PERSIST = false>
 __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   using C = ConvCfg<TD, TH, TW, NB>;
   static_assert(!DRE || (TD == 8 && TH == 8 && TW == 8 && NB == 1), "depth-reuse loop: 8x8x8 tile, one cout block");
@@ -176,7 +183,9 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const int hh = lane >> 5;
 
   // ---- workgroup -> (tile, cout block, sample, group) ---------------------------------------------
-  const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
+  const int TPW = PERSIST ? p.tiles_per_wg : 1;     // tiles per workgroup
+  const int gxw = p.gx / TPW;                        // workgroups along the m-tile index
+  const unsigned nwg = (unsigned)gxw * p.gy * p.gz;
   unsigned lin = xcd_remap(blockIdx.x, nwg);
   int bx, by;
   if (p.cout_fastest) {
@@ -184,14 +193,15 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     // find the tile's input box in L2 instead of HBM
     by = lin % p.gy;
     lin /= p.gy;
-    bx = lin % p.gx;
-    lin /= p.gx;
+    bx = lin % gxw;
+    lin /= gxw;
   } else {
-    bx = lin % p.gx;
-    lin /= p.gx;
+    bx = lin % gxw;
+    lin /= gxw;
     by = lin % p.gy;
     lin /= p.gy;
   }
+  bx *= TPW;
   int bz = lin;
   int split = 0;
   if (p.nsplit > 1) {
@@ -203,7 +213,8 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const int tw_i = bx % p.tiles[2];
   const int th_i = (bx / p.tiles[2]) % p.tiles[1];
   const int td_i = bx / (p.tiles[2] * p.tiles[1]);
-  const int m0d = td_i * TD, m0h = th_i * TH, m0w = tw_i * TW;
+  const int m0d = td_i * TD, m0h = th_i * TH;
+  int m0w = tw_i * TW;      // (PERSIST: advances by TW per tile; the launcher guarantees the run stays inside one W row)
   const int cb0 = by * NB;  // first 32-wide cout block
 
   const nnz_conv_group grp = p.d.groups[g];
@@ -241,6 +252,23 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       }
     }
   }
+  // PERSIST: the staging addresses of the tile that starts at W position `w0` - the piece's box coordinates are decoded from
+  // its LDS offset (stride-1 geometry only: bwp = bw), validity and global offset as above
+  auto set_box_goff = [&](int w0) {
+    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = w0 * ISW + p.d.lo[2];
+#pragma unroll
+    for (int i = 0; i < LPT_BOX; ++i) {
+      box_goff[i] = -1;
+      if (box_loff[i] >= 0) {
+        const int r = box_loff[i] >> 5;
+        const int bw = r % bg.PW, bh = (r / bg.PW) % bg.BH, bd = r / (bg.PW * bg.BH);
+        const int half = ((box_loff[i] >> 4) & 1) ^ (bh & 1);
+        const int id = lod + bd, ih = loh + bh, iw = low + bw;
+        if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
+          box_goff[i] = (((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + half * 8;
+      }
+    }
+  };
   const int nwchunks = NB * nt * 64;
 
   // ---- per-lane fragment addresses ----------------------------------------------------------------
@@ -254,6 +282,21 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     if constexpr (DRE) return ((4 * (wm >> 1) + i) * TH + 4 * (wm & 1) + (l31 >> 3)) * TW + (l31 & 7);
     return (wm * C::WM + i) * 32 + l31;
   };
+  auto set_out_vox = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::WM; ++i) {
+      const int v = frag_voxel(i);
+      const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+      const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
+      const int od = md * p.d.out_stride[0] + grp.ooff[0];
+      const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
+      const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
+      const bool ok = md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] &&
+                      od < p.d.out_dims[0] && oh < p.d.out_dims[1] && ow < p.d.out_dims[2];
+      out_vox[i] = ok ? (((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) * p.d.ldo
+                      : -1;
+    }
+  };
 #pragma unroll
   for (int i = 0; i < C::WM; ++i) {
     const int v = frag_voxel(i);
@@ -261,15 +304,8 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     const int base = (((td * ISD) * bg.BH + th * ISH) * bg.PW + tw) * 32;  // column tw of the (de-interleaved) image
     const int f = th & 1;
     vox_off[i] = base + ((hh ^ f) << 4);
-    const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-    const int od = md * p.d.out_stride[0] + grp.ooff[0];
-    const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
-    const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
-    const bool ok = md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] &&
-                    od < p.d.out_dims[0] && oh < p.d.out_dims[1] && ow < p.d.out_dims[2];
-    out_vox[i] = ok ? (((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) * p.d.ldo
-                    : -1;
   }
+  set_out_vox();
   // weights: lane reads row (l&31) of [nb][t][32][32B]
   const int w_lane = l31 * 32 + ((hh ^ ((lane >> 4) & 1)) << 4);
 
@@ -350,10 +386,11 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     for (int i = 0; i < LPT_BOX; ++i) breg[i][q] = norm_lrelu_pair(breg[i][q], tq[0], tq[1], tq[2], tq[3], sl);
   };
   bool padded_box;   // some piece of this thread's box lies outside the volume (uniform over the workgroup's tile)
-  {
-    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = m0w * ISW + p.d.lo[2];
+  auto set_padded_box = [&](int w0) {
+    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = w0 * ISW + p.d.lo[2];
     padded_box = lod < 0 || loh < 0 || low < 0 || lod + bg.BD > Di || loh + bg.BH > Hi || low + bg.BW > Wi;
-  }
+  };
+  set_padded_box(m0w);
   auto write_lds = [&](int kc) {
     if (p.in_tab) {
 #pragma unroll
@@ -474,14 +511,31 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
   issue_loads(kc0);
   load_tab(kc0);
+  bool prefetched = false;   // PERSIST: the next tile's first slice was requested inside this tile's last MFMA loop
+  auto tile_body = [&](bool last_tile) {
+#pragma unroll
+  for (int a = 0; a < C::WN; ++a)
+#pragma unroll
+    for (int b = 0; b < C::WM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   store_tab(kc0);
   if (kc0 + 1 < kc1) load_tab(kc0 + 1);
+  prefetched = false;
   for (int kc = kc0; kc < kc1; ++kc) {
     __syncthreads();  // all waves finished reading the previous slice
     write_lds(kc);
     __syncthreads();
     if (kc + 1 < kc1) issue_loads(kc + 1);
     if (kc + 2 < kc1) load_tab(kc + 2);
+    if (PERSIST && kc + 1 == kc1 && !last_tile && !bxmode) {
+      // forward launches: the epilogue leaves the staging registers alone - request the next tile's first slice now
+      set_box_goff(m0w + TW);
+      set_padded_box(m0w + TW);
+      issue_loads(kc0);
+      load_tab(kc0);
+      prefetched = true;
+    }
 
     if constexpr (DRE) {
       // Software pipeline by half rows: the reads of the NEXT half are issued as a group before the six MFMAs of the
@@ -704,7 +758,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       fx_add(p.acc, ch * 2, nrec, blockIdx.x, (double)S1);
       fx_add(p.acc, ch * 2 + 1, nrec, blockIdx.x, (double)S2);
     }
-    if (last_workgroup_wave(p.counter, nwg)) {
+    if (last_tile && last_workgroup_wave(p.counter, nwg)) {
       const double V = (double)p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2];
       for (int c = lane; c < Cout; c += 64) {
         double sg = 0.0, sb = 0.0;
@@ -788,7 +842,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         fx_add(p.acc, rec, nrec, blockIdx.x, (double)S1 + cnt * k);
         fx_add(p.acc, rec + 1, nrec, blockIdx.x, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
       }
-      if (last_workgroup_wave(p.counter, nwg)) {
+      if (last_tile && last_workgroup_wave(p.counter, nwg)) {
         const double V = (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
         const long nrec = (long)p.d.N * Cout * 2;
         for (int i = lane; i < p.d.N * Cout; i += 64) {
@@ -826,6 +880,21 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       for (int e = 0; e < 8; ++e) val[e] = (f16)((float)val[e] + (float)old[e]);
     }
     *reinterpret_cast<f16x8*>(dst) = val;
+  }
+  };   // tile_body
+
+  for (int it = 0; it < TPW; ++it) {
+    const bool last_tile = it + 1 == TPW;
+    tile_body(last_tile);
+    if (!last_tile) {
+      if (!prefetched) {   // data-gradient launches with the fused reductions: the epilogue used the staging registers
+        set_box_goff(m0w + TW);
+        set_padded_box(m0w + TW);
+        issue_loads(kc0);
+        load_tab(kc0);
+      }
+      m0w += TW;
+    }
   }
 }
 
@@ -923,7 +992,8 @@ static int splitk_plan(const ConvDev& p, long ws_floats, int wgs_base, int* kper
   return (nkc + *kper - 1) / *kper;
 }
 
-template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false, int MINB = 2>
+template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false, bool DFLIP = false, int MINB = 2,
+          bool PERSIST = false>
 static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   using C = ConvCfg<TD, TH, TW, NB>;
   ConvDev p = base;
@@ -954,13 +1024,23 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   if (p.nsplit <= 1) p.part = nullptr;
   p.gz = p.d.N * p.d.ngroups * (p.nsplit > 1 ? p.nsplit : 1);
   p.cout_fastest = g_tuning[3] && p.gy > 1;
-  auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G, DRE, DFLIP, MINB>;
+  // PERSIST: as many consecutive W tiles per workgroup as still leave >= 1024 workgroups (two rounds of the 512 resident
+  // slots), never across a W row; knob 9 caps it (1 = one tile per workgroup)
+  p.tiles_per_wg = 1;
+  if (PERSIST && p.nsplit <= 1) {
+    for (int t = g_tuning[9]; t > 1; t >>= 1)
+      if (p.tiles[2] % t == 0 && (long)(p.gx / t) * p.gy * p.gz >= 1024) {
+        p.tiles_per_wg = t;
+        break;
+      }
+  }
+  auto kern = conv_box_kernel<TD, TH, TW, NB, LPT_BOX, G, DRE, DFLIP, MINB, PERSIST>;
   static DynLdsCache lds_cache;  // per instantiation, per device
   {
     hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_cache);
     if (e != hipSuccess) return (int)e;
   }
-  const unsigned nwg = (unsigned)p.gx * p.gy * p.gz;
+  const unsigned nwg = (unsigned)(p.gx / p.tiles_per_wg) * p.gy * p.gz;
   NNZ_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, p);
   if (p.nsplit > 1) {
     SplitKFinish f = {};
@@ -1012,8 +1092,8 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
       const int flip = depth_reuse_flip(p.d);
       const long edge = g_tuning[2];
       if (flip >= 0 && mvox >= edge * edge * edge && ((!nb2 && g_tuning[0]) || (nb2 && g_tuning[1] && p.d.Cin >= g_tuning[4]))) {
-        if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true>(p, stream);
-        return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false>(p, stream);
+        if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true, 2, true>(p, stream);
+        return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false, 2, true>(p, stream);
       }
     }
     if (!nb2) {

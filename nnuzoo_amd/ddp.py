@@ -35,6 +35,10 @@ class BucketedAllReduce:
         self._slices = []              # (lo, hi) element ranges of the arena collectives launched in the current step
         self.slices_last_step = []     # ... of the most recent finished step (bench.py / tests read these)
         self.buckets_last_step = 0
+        # hipGraph capture of the data-parallel step (training/graph_step.py GraphedDDPStep): while set, a bucket that is
+        # ready is REPORTED through this callable - boundary(lo, hi, final) - instead of being all-reduced: the capture ends
+        # the current graph segment there and the replay launches the collective for the slice between two segments
+        self.capture_boundary = None
 
     def _launch(self):
         if not self._pending:
@@ -61,6 +65,11 @@ class BucketedAllReduce:
         is at least one bucket long."""
         lo = self._arena_lo
         if (filled - lo) * arena.element_size() >= self.bucket_bytes:
+            if self.capture_boundary is not None:
+                self.capture_boundary(lo, filled, False)
+                self._slices.append((lo, filled))
+                self._arena_lo = filled
+                return
             h = dist.all_reduce(arena[lo:filled], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._inflight.append((h, None, None))
             self._slices.append((lo, filled))
@@ -68,6 +77,14 @@ class BucketedAllReduce:
 
     def finish_arena(self, arena: torch.Tensor, filled: int):
         lo = self._arena_lo
+        if self.capture_boundary is not None:
+            if filled > lo:
+                self._slices.append((lo, filled))
+            self.capture_boundary(lo, filled, True)
+            self._arena_lo = 0
+            self.slices_last_step, self._slices = self._slices, []
+            self.buckets_last_step = len(self.slices_last_step)
+            return
         if filled > lo:
             h = dist.all_reduce(arena[lo:filled], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._inflight.append((h, None, None))
@@ -79,6 +96,11 @@ class BucketedAllReduce:
         self._arena_lo = 0
         self.slices_last_step, self._slices = self._slices, []
         self.buckets_last_step = len(self.slices_last_step)
+
+    def reduce_slice_async(self, arena: torch.Tensor, lo: int, hi: int):
+        """replay side of a captured step: the in-place SUM all-reduce of one recorded bucket (no averaging - the fused
+        optimizer folds 1 / world into its unscale factor)"""
+        return dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self, all_grads: List[torch.Tensor]):
         """Flush, wait for every collective and write the averaged gradients back in place."""

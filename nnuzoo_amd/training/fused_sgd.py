@@ -42,6 +42,10 @@ class FusedSGD(torch.optim.SGD):
     def fused_available(self) -> bool:
         return getattr(self._net, "grad_arena", None) is not None and self._net.grad_arena() is not None
 
+    def fused_available_static(self) -> bool:
+        """the network publishes a gradient arena at all (before the first backward has produced one)"""
+        return getattr(self._net, "grad_arena", None) is not None
+
     # ---- flat momentum + chunk table (rebuilt when storage moved: first step, load_state_dict, .to()) ------------
     def _build(self, layout: List[Tuple[torch.nn.Parameter, int]], device, unused=None):
         lib = _lib.load()

@@ -134,3 +134,122 @@ class GraphedForwardBackward:
             net = self.network
             net._last_arena, net._arena_layout, net._last_unused = self._static_arena
         return self.static_loss
+
+
+class GraphedDDPStep:
+    """The data-parallel step of an explicit-schedule network (PlainConvUNet) as hipGraph SEGMENTS with the RCCL collectives
+    between them (round 4).
+
+    Under DDP the step used to run eagerly, because the bucketed all-reduce is launched from inside the backward schedule so
+    that it overlaps the remaining backward - at ~300 launches per step that costs 3.6 % against the replayed N = 1 step before
+    any communication.  Capturing the collectives INSIDE one graph would remove that too, but a captured RCCL launch cannot be
+    tested on this one-GPU pool, and a hang at N = 8 is not an acceptable failure mode.  So the collectives stay ordinary
+    stream-ordered launches and the graph is cut where the schedule hands a bucket over:
+
+        capture   forward + loss + backward run once on a side stream; every time the reducer has a full bucket
+                  (`BucketedAllReduce.capture_boundary`) the current capture ends and the next one begins (same memory pool) ->
+                  segments S_0 .. S_k and the arena slices [lo_i, hi_i) that are final after S_i
+        replay    for i: S_i.replay(); all_reduce(arena[lo_i:hi_i], async)      (the collective waits for S_i on RCCL's stream and
+                  runs beside S_i+1)      then wait for all; the SUM is turned into the mean inside the fused optimizer
+                  (inv_scale / world): no extra pass over the arena.
+
+    The network part runs WITHOUT autograd: `_run_forward` -> leaf tensors for the logits -> loss + its backward (autograd, loss
+    ops only) -> `_run_backward(rec, dlogits)` in this thread, so that the segment boundaries are ordinary Python calls on the
+    capturing thread.  Parameter `.grad`s are not populated; the step must be finished by `FusedSGD.fused_step`, which reads
+    the gradient arena (the trainer checks that).  Requires a loss without collectives (batch_dice False: 3d_fullres)."""
+
+    def __init__(self, network: torch.nn.Module, loss_fn: Callable, grad_scaler, warmup_iters: int = 2):
+        if getattr(network, "grad_reducer", None) is None or not hasattr(network, "_run_backward"):
+            raise ValueError("GraphedDDPStep needs an explicit-schedule network with an attached BucketedAllReduce")
+        self.network, self.loss_fn, self.scaler, self.warmup_iters = network, loss_fn, grad_scaler, warmup_iters
+        self.segments: List[torch.cuda.CUDAGraph] = []
+        self.slices: List[Optional[tuple]] = []       # slice to reduce after segment i (None: nothing)
+        self.static_data = None
+        self.static_target: List[torch.Tensor] = []
+        self.static_loss = None
+        self._static_arena = None
+        self._key = None
+        self.memset_nodes_replaced = 0
+
+    def _fwd_bwd(self, data, target):
+        net = self.network
+        with torch.no_grad():
+            outs, rec = net._run_forward(data.float().contiguous(), save=True)
+        leaves = [o.detach().requires_grad_(True) for o in outs]
+        loss = self.loss_fn(leaves if net.decoder.deep_supervision else leaves[0], target)
+        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
+        with torch.no_grad():
+            net._run_backward(rec, [l.grad for l in leaves])
+        return loss.detach()
+
+    def _capture(self, data, target):
+        import ctypes as C
+        from .._lib import call
+        net, red = self.network, self.network.grad_reducer
+        self.static_data = data.clone()
+        self.static_target = [t.clone() for t in target]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup_iters):          # eager warm-up WITH the real collectives (every rank takes part)
+                self._fwd_bwd(self.static_data, self.static_target)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        pool = torch.cuda.graph_pool_handle()
+        self.segments, self.slices = [], []
+        cur = {"g": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph(keep_graph=True)
+            g.capture_begin(pool=pool, capture_error_mode="relaxed")   # the loss backward runs on autograd's thread
+            cur["g"] = g
+
+        def end(sl):
+            g = cur["g"]
+            g.capture_end()
+            n = C.c_int(0)
+            call("nnz_graph_replace_memsets", C.c_void_p(int(g.raw_cuda_graph())), C.byref(n))
+            self.memset_nodes_replaced += int(n.value)
+            g.instantiate()
+            self.segments.append(g)
+            self.slices.append(sl)
+
+        def boundary(lo, hi, final):
+            end((lo, hi) if hi > lo else None)
+            if not final:
+                begin()
+
+        red.capture_boundary = boundary
+        try:
+            with torch.cuda.stream(side):
+                begin()
+                self.static_loss = self._fwd_bwd(self.static_data, self.static_target)
+        finally:
+            red.capture_boundary = None
+        torch.cuda.current_stream().wait_stream(side)
+        self._static_arena = (net._last_arena, net._arena_layout, net._last_unused)
+        self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
+
+    def __call__(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
+        key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
+        if not self.segments or key != self._key:
+            self._capture(data, target)
+        self.static_data.copy_(data, non_blocking=True)
+        for s, t in zip(self.static_target, target):
+            s.copy_(t, non_blocking=True)
+        net, red = self.network, self.network.grad_reducer
+        arena = self._static_arena[0]
+        handles = []
+        for g, sl in zip(self.segments, self.slices):
+            g.replay()
+            if sl is not None:
+                handles.append(red.reduce_slice_async(arena, sl[0], sl[1]))
+        for h in handles:
+            h.wait()
+        red.slices_last_step = [sl for sl in self.slices if sl is not None]
+        red.buckets_last_step = len(red.slices_last_step)
+        net._last_arena, net._arena_layout, net._last_unused = self._static_arena
+        return self.static_loss

@@ -65,9 +65,11 @@ def test_child_failure_is_the_exit_status():
 @pytest.mark.gpu
 def test_two_ranks_real_step_one_gpu_gloo():
     r, lines = _run(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--patch", "64", "--no-secondary",
-                     "--no-cpu-baseline"], {"NNZ_BENCH_BACKEND": "gloo", "NNZ_BENCH_SHARE_GPU": "1"}, timeout=1200)
+                     "--no-cpu-baseline"], {"NNZ_BENCH_BACKEND": "gloo", "NNZ_BENCH_SHARE_GPU": "1", "NNZ_DDP_GRAPH": "1"}, timeout=1200)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = json.loads(lines[-1])
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["allreduce_buckets_per_step"] >= 4     # 5-stage net at 64^3
     assert j["config"]["global_batch"] == 4 and j["value"] > 0
     assert 0 < j["final_loss"] < 2.0 or j["final_loss"] < 0     # finite, a Dice+CE value
+    # round 4: the N > 1 step replays hipGraph segments with the all-reduces launched between them
+    assert j["hip_graph"] is True and j["hip_graph_segments"] >= j["allreduce_buckets_per_step"] >= 4

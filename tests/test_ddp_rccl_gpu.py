@@ -30,6 +30,24 @@ tr.initialize()
 assert tr.is_ddp and hasattr(tr.network, "grad_reducer")
 b = synthetic_batch(2, (32, 32, 32), tr._get_deep_supervision_scales(), seed=1)
 out["unet"] = [float(tr.train_step(b)["loss"]) for _ in range(3)]
+# round 4: the data-parallel step as hipGraph segments with the collectives between them - against the eager DDP step
+def run(graph):
+    os.environ["NNZ_DDP_GRAPH"] = "1" if graph else "0"
+    plans, cfg, dj = nnunet_plans(3, (32, 32, 32), batch_size=2)
+    torch.manual_seed(0)
+    t = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+    t.initialize()
+    ls = []
+    for i in range(4):
+        bb = synthetic_batch(2, (32, 32, 32), t._get_deep_supervision_scales(), seed=40 + i)
+        ls.append(float(t.train_step(bb)["loss"]))
+    return ls, [p.detach().clone() for p in t.network.parameters()], t
+le, pe, te = run(False)
+lg, pg, tg = run(True)
+assert te._graphed_ddp is None and tg._graphed_ddp is not None
+out["ddp_graph"] = {"segments": len(tg._graphed_ddp.segments), "buckets": tg.network.grad_reducer.buckets_last_step,
+                    "eager_buckets": te.network.grad_reducer.buckets_last_step, "losses_equal": le == lg,
+                    "params_equal": all(torch.equal(a, b) for a, b in zip(pe, pg)), "losses": lg}
 plans, cfg, dj = nnunet_plans(2, (64, 64), batch_size=2)
 torch.manual_seed(0)
 zt = Z.nnUNetTrainerM2NetP(plans, cfg, 0, dj, device=torch.device("cuda"))
@@ -54,3 +72,8 @@ def test_ddp_paths_on_rccl_world1(hip_lib):
     import math
     res = json.loads(lines[-1][7:])
     assert all(math.isfinite(v) for v in res["unet"] + res["zoo"]), res
+    # graph segments = buckets (+1 when the last segment carries no slice); at world size 1 the averaged and the summed
+    # gradients are the same numbers, so the segmented replay must equal the eager DDP step bit for bit
+    g = res["ddp_graph"]
+    assert g["segments"] >= 2 and g["buckets"] == g["eager_buckets"] >= 1, g
+    assert g["losses_equal"] and g["params_equal"], g
