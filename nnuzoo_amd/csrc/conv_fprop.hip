@@ -28,6 +28,7 @@
 //     one XCD's L2.
 #include "common.hpp"
 #include "conv_params.h"
+#include <stddef.h>
 
 namespace nnz {
 
@@ -86,6 +87,12 @@ struct ConvDev {
   float in_slope;
   int intab_off;   // byte offset of the LDS table (launcher)
   int tiles_per_wg;  // PERSIST instantiations: consecutive m-tiles (along W) per workgroup; gx counts workgroups' first tiles
+  // Tap tables made by the launcher (round 4): tapenc[t] = box byte offset of tap t | h-offset parity << 4, rowenc[r] the
+  // same for the nine (kh, kw) rows of the depth-reuse loop.  Lane t fetches its entry with ONE vector load from the kernel
+  // argument segment.  (Before, every wave built them in a 27 + 9 iteration loop of dependent scalar loads from the
+  // descriptor: ~36 scalar-cache round trips at the head of every workgroup.)
+  int tapenc[NNZ_MAX_TAPS];
+  int rowenc[12];
 };
 
 // Box geometry policies.  GeoIso: input stride and tap extent are compile-time and equal on the three axes (the
@@ -260,9 +267,12 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     for (int i = 0; i < LPT_BOX; ++i) {
       box_goff[i] = -1;
       if (box_loff[i] >= 0) {
-        const int r = box_loff[i] >> 5;
+        // (opaque copy: the decode is invariant across the tile loop and would otherwise be hoisted into ~32 live registers)
+        int lo_ = box_loff[i];
+        asm volatile("" : "+v"(lo_));
+        const int r = lo_ >> 5;
         const int bw = r % bg.PW, bh = (r / bg.PW) % bg.BH, bd = r / (bg.PW * bg.BH);
-        const int half = ((box_loff[i] >> 4) & 1) ^ (bh & 1);
+        const int half = ((lo_ >> 4) & 1) ^ (bh & 1);
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
           box_goff[i] = (((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + half * 8;
@@ -320,15 +330,10 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   // Tap table in a VGPR: lane t holds tap t's box offset (bytes, multiple of 32) | h-offset parity (bit 4: the
   // swizzle flips the 16-byte half).  The tap loop fetches it with v_readlane - no scalar loads (their lgkmcnt(0)
   // would drain the LDS queue) and no memory at all inside the MFMA loop.
+  typedef const int __attribute__((address_space(4))) * karg_ptr;                    // ConvDev is the only parameter
+  const karg_ptr kargs = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
   int tap_tab = 0;
-  for (int t = 0; t < nt; ++t) {
-    const nnz_conv_tap tp = p.d.taps[tb + t];
-    const int o0 = tp.off[0] - p.d.lo[0], o1 = tp.off[1] - p.d.lo[1], o2 = tp.off[2] - p.d.lo[2];
-    const int col = ISW == 2 ? (o2 >> 1) + (o2 & 1) * ((bg.BW + 1) >> 1) : o2;
-    const int flip = (ISH == 2 ? o1 >> 1 : o1) & 1;
-    const int enc = (((o0 * bg.BH + o1) * bg.PW + col) * 32) | (flip << 4);
-    tap_tab = lane == t ? enc : tap_tab;
-  }
+  if (lane < nt) tap_tab = kargs[offsetof(ConvDev, tapenc) / 4 + tb + lane];
 
   u32x4 breg[LPT_BOX];
   u32x4 wreg[C::LPT_W];
@@ -436,12 +441,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   // depth-reuse loop: per (kh, kw) row r the box offset without its depth part (lane r of rtab)
   int rtab = 0;
   if constexpr (DRE) {
-    for (int r = 0; r < 9; ++r) {
-      const nnz_conv_tap tp = p.d.taps[tb + r];
-      const int o1 = tp.off[1] - p.d.lo[1], o2 = tp.off[2] - p.d.lo[2];
-      const int enc = ((o1 * bg.PW + o2) * 32) | ((o1 & 1) << 4);
-      rtab = lane == r ? enc : rtab;
-    }
+    if (lane < 9) rtab = kargs[offsetof(ConvDev, rowenc) / 4 + lane];
   }
   const int plane_bytes = bg.BH * bg.PW * 32;
   // addresses: flip only toggles bit 4 of the lane's base (every other term is a multiple of 32), so the six planes and
@@ -485,6 +485,27 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   constexpr int BX_NIT = (TD * TH * TW + BX_PARTS - 1) / BX_PARTS;
   static_assert(BX_NIT <= LPT_BOX + C::LPT_W, "layer-below tile must fit the staging registers");
   const bool bxmode = p.acc && p.bx;
+  const int kc0 = p.nsplit > 1 ? split * p.kper : 0;
+  const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
+  issue_loads(kc0);
+  load_tab(kc0);
+  // (requesting the next tile's first slice inside this tile's last MFMA loop keeps 32 staging registers alive through the
+  //  epilogue, which then spills them: measured slower than the late request below)
+  constexpr bool EARLY_PREFETCH = false;
+  bool prefetched = false;   // PERSIST: the next tile's first slice was requested inside this tile's last MFMA loop
+  const int tid_outer = tid;
+  auto tile_body = [&](bool last_tile) {
+  // PERSIST: everything the epilogue derives from the thread index is recomputed per tile from an opaque copy - left to itself
+  // the compiler hoists those (loop-invariant) values out of the tile loop and spills ~180 registers (measured: 2.5x slower)
+  int tid = tid_outer;
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int hh = lane >> 5;
+  const int wm = wave % C::WAVES_M;
+  const int wn = wave / C::WAVES_M;
+  (void)l31; (void)wm; (void)wn;
   auto bx_index = [&](int k) -> long {   // row index of item k of this thread in the output / layer-below tensors, -1: none
     const int v = tid / PPV + k * BX_PARTS;
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
@@ -507,12 +528,6 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       else wreg[k >= LPT_BOX ? k - LPT_BOX : 0] = v;
     }
   };
-  const int kc0 = p.nsplit > 1 ? split * p.kper : 0;
-  const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
-  issue_loads(kc0);
-  load_tab(kc0);
-  bool prefetched = false;   // PERSIST: the next tile's first slice was requested inside this tile's last MFMA loop
-  auto tile_body = [&](bool last_tile) {
 #pragma unroll
   for (int a = 0; a < C::WN; ++a)
 #pragma unroll
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     __syncthreads();
     if (kc + 1 < kc1) issue_loads(kc + 1);
     if (kc + 2 < kc1) load_tab(kc + 2);
-    if (PERSIST && kc + 1 == kc1 && !last_tile && !bxmode) {
+    if (PERSIST && EARLY_PREFETCH && kc + 1 == kc1 && !last_tile && !bxmode) {
       // forward launches: the epilogue leaves the staging registers alone - request the next tile's first slice now
       set_box_goff(m0w + TW);
       set_padded_box(m0w + TW);
@@ -1024,6 +1039,21 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   if (p.nsplit <= 1) p.part = nullptr;
   p.gz = p.d.N * p.d.ngroups * (p.nsplit > 1 ? p.nsplit : 1);
   p.cout_fastest = g_tuning[3] && p.gy > 1;
+  {
+    const int ISH = geo.is(1), ISW = geo.is(2);
+    for (int t = 0; t < p.d.ntaps_total && t < NNZ_MAX_TAPS; ++t) {
+      const nnz_conv_tap& tp = p.d.taps[t];
+      const int o0 = tp.off[0] - p.d.lo[0], o1 = tp.off[1] - p.d.lo[1], o2 = tp.off[2] - p.d.lo[2];
+      const int col = ISW == 2 ? (o2 >> 1) + (o2 & 1) * ((bg.BW + 1) >> 1) : o2;
+      const int flip = (ISH == 2 ? o1 >> 1 : o1) & 1;
+      p.tapenc[t] = (((o0 * bg.BH + o1) * bg.PW + col) * 32) | (flip << 4);
+    }
+    for (int r = 0; r < 9 && r < p.d.ntaps_total; ++r) {   // depth-reuse loop: rows of the FIRST tap group
+      const nnz_conv_tap& tp = p.d.taps[p.d.groups[0].tap_begin + r];
+      const int o1 = tp.off[1] - p.d.lo[1], o2 = tp.off[2] - p.d.lo[2];
+      p.rowenc[r] = ((o1 * bg.PW + o2) * 32) | ((o1 & 1) << 4);
+    }
+  }
   // PERSIST: as many consecutive W tiles per workgroup as still leave >= 1024 workgroups (two rounds of the 512 resident
   // slots), never across a W row; knob 9 caps it (1 = one tile per workgroup)
   p.tiles_per_wg = 1;
@@ -1092,8 +1122,13 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
       const int flip = depth_reuse_flip(p.d);
       const long edge = g_tuning[2];
       if (flip >= 0 && mvox >= edge * edge * edge && ((!nb2 && g_tuning[0]) || (nb2 && g_tuning[1] && p.d.Cin >= g_tuning[4]))) {
-        if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true, 2, true>(p, stream);
-        return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false, 2, true>(p, stream);
+        // (PERSIST = true - one workgroup walking up to four consecutive W tiles - is built and bit-exact, and slower: the tile
+        //  loop makes the allocator spill 300-720 bytes per lane (next_free_vgpr 256 + scratch) whatever is done against
+        //  hoisting (opaque thread index inside the tile body, late instead of early prefetch); 32 -> 32 @128^3 forward
+        //  0.29 ms one tile per workgroup, 0.40-0.56 ms persistent.  tools/bench_conv_layers.py --tuning 9=T with the
+        //  template flag flipped reproduces it.)
+        if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true, 2, false>(p, stream);
+        return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false, 2, false>(p, stream);
       }
     }
     if (!nb2) {
