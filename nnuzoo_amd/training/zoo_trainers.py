@@ -414,6 +414,80 @@ class nnUNetTrainerSegMamba(_X2Trainer):
                                args, kwargs)
 
 
+class _FrozenEncoderEpochs:
+    """`on_train_epoch_start` of the Swin-UMamba plugins (nnUNetTrainerSwinUMamba.py:79-94): the VSSM encoder (except its patch
+    embedding) is frozen for the first `freeze_encoder_epochs` epochs.  A change of the trainable set invalidates the captured
+    step (the graph holds the autograd graph of the frozen configuration) and the optimizer's chunk table."""
+
+    def on_train_epoch_start(self):
+        freeze = self.current_epoch < self.freeze_encoder_epochs
+        net = self.network.module if hasattr(self.network, "module") else self.network
+        before = [p.requires_grad for p in net.parameters()]
+        if freeze:
+            net.freeze_encoder()
+        else:
+            net.unfreeze_encoder()
+        if before != [p.requires_grad for p in net.parameters()]:
+            self._graphed = None
+            for p in net.parameters():
+                if not p.requires_grad:
+                    p.grad = None
+        parent = getattr(super(), "on_train_epoch_start", None)   # the epoch loop itself is outside the hot path (DESIGN.md §1)
+        if parent is not None:
+            parent()
+
+
+class nnUNetTrainerSwinUMamba(_FrozenEncoderEpochs, _X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerSwinUMamba.py:18-113 (Swin-UMamba, 2-D; the base trainer's fp16-autocast
+    train_step; AdamW 1e-4 / wd 5e-2 / eps 1e-5, cosine to 1e-6; encoder frozen for 10 epochs; four deep-supervision outputs at
+    1, 1/2, 1/4, 1/8; built with use_pretrain=False as there)"""
+    _no_miopen = True
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250, **kwargs):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.freeze_encoder_epochs = 10
+        self.early_stop_epoch = 350
+
+    def _get_deep_supervision_scales(self):
+        return [[1.0, 1.0], [0.5, 0.5], [0.25, 0.25], [0.125, 0.125]] if self.enable_deep_supervision else None
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.swin_umamba import get_swin_umamba_from_plans
+        num_in, num_out, ds = _live_num_in_out(args, kwargs)
+        return get_swin_umamba_from_plans(num_out, num_in, deep_supervision=ds, use_pretrain=False)
+
+
+class nnUNetTrainerSwinUMambaD(_FrozenEncoderEpochs, _X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerSwinUMambaD.py:17-124 (Swin-UMamba-D: Mamba decoder; same optimizer and
+    freezing schedule; deep-supervision outputs at 1, 1/4, 1/8, 1/16 - the decoder's last stage expands by 4).  `load_checkpoint`
+    of a path containing "vmamba" loads VMamba ImageNet weights into the encoder (:30-57), anything else is a trainer
+    checkpoint."""
+    _no_miopen = True
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.freeze_encoder_epochs = 10
+
+    def _get_deep_supervision_scales(self):
+        return [[1.0, 1.0], [0.25, 0.25], [0.125, 0.125], [0.0625, 0.0625]] if self.enable_deep_supervision else None
+
+    def load_checkpoint(self, filename_or_checkpoint) -> None:
+        if isinstance(filename_or_checkpoint, str) and "vmamba" in filename_or_checkpoint:
+            from ..nets.swin_umamba import load_pretrained_ckpt
+            net = self.network.module if hasattr(self.network, "module") else self.network
+            load_pretrained_ckpt(net, filename_or_checkpoint, num_input_channels=next(net.parameters()).shape[1])
+        else:
+            super().load_checkpoint(filename_or_checkpoint)
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.swin_umamba import get_swin_umamba_d_from_plans
+        return _legacy_or_live(lambda *a, **k: get_swin_umamba_d_from_plans(*a, use_pretrain=True, **k), args, kwargs)
+
+
 class nnUNetTrainerU2Net(_X2Trainer):
     """reference: training/nnUNetTrainer/nnUNetTrainerU2Net.py:14-99 (U2NET; the base trainer's autocast train_step; AdamW
     1e-4 / wd 5e-2 / eps 1e-5, cosine to 1e-6; seven deep-supervision outputs, ALL at full resolution: scales [[1, 1]] * 7)"""
