@@ -37,6 +37,20 @@ struct TapDev {
   int hpar;     // parity of the tap's h offset (selects the swizzled half)
 };
 
+// -DNNZ_CONV_TIMESTAMPS=1 (tools/probes/conv_phase_probe.py builds its own library with it; never the shipped one): thread 0 of
+// every workgroup records s_memtime at the phase boundaries into ts[workgroup][16] - buffer address = knobs 10 (low) / 11 (high)
+#ifndef NNZ_CONV_TIMESTAMPS
+#define NNZ_CONV_TIMESTAMPS 0
+#endif
+#if NNZ_CONV_TIMESTAMPS
+#define NNZ_TS(slot)                                                                                   \
+  do {                                                                                                 \
+    if (p.ts && threadIdx.x == 0 && (slot) < 16) p.ts[(long)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define NNZ_TS(slot) do {} while (0)
+#endif
+
 struct ConvDev {
   const f16* in;
   f16* out;
@@ -64,6 +78,9 @@ struct ConvDev {
   float* dbeta;
   float slope;
   int ldbx;
+#if NNZ_CONV_TIMESTAMPS
+  unsigned long long* ts;
+#endif
   int dbg;  // nnz_conv_tuning(6, bits): epilogue experiments (tools/probes/normred_epilogue_probe.py); 0 in production
   // split-K over the 16-channel slices of the reduction (the <= 8^3 levels: 10-40 workgroups each walking 20-40 slices of
   // 55 KB of weights were 55 us of pure latency per launch): workgroup (.., split) covers slices [split * kper, ...) and
@@ -157,6 +174,9 @@ struct ConvCfg {
 //      32 -> 64 @128^3 0.238 -> 0.207 ms, 64 -> 128 @64^3 0.102 -> 0.093 ms, tools/bench_conv_layers.py --tuning 7=0/1)
 //   8  split-K applies to launches of fewer than this many workgroups                                                (default 128)
 //   9  depth-reuse launches: most consecutive W tiles one (persistent) workgroup walks (power of two; 1 = off)    (default 4)
+#ifndef NNZ_S2_PERSIST
+#define NNZ_S2_PERSIST false
+#endif
 static int g_tuning[12] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
@@ -175,6 +195,7 @@ template <int TD, int TH, int TW, int NB, int LPT_BOX, class G, bool DRE = false
           bool PERSIST = false>
 __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   using C = ConvCfg<TD, TH, TW, NB>;
+  NNZ_TS(0);
   static_assert(!DRE || (TD == 8 && TH == 8 && TW == 8 && NB == 1), "depth-reuse loop: 8x8x8 tile, one cout block");
   const G geo(p.d);
   const BoxGeom<TD, TH, TW, G> bg(geo);
@@ -487,6 +508,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const bool bxmode = p.acc && p.bx;
   const int kc0 = p.nsplit > 1 ? split * p.kper : 0;
   const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
+  NNZ_TS(1);
   issue_loads(kc0);
   load_tab(kc0);
   // (requesting the next tile's first slice inside this tile's last MFMA loop keeps 32 staging registers alive through the
@@ -541,6 +563,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     __syncthreads();  // all waves finished reading the previous slice
     write_lds(kc);
     __syncthreads();
+    NNZ_TS(2 + 2 * (kc - kc0) < 12 ? 2 + 2 * (kc - kc0) : 15);
     if (kc + 1 < kc1) issue_loads(kc + 1);
     if (kc + 2 < kc1) load_tab(kc + 2);
     if (PERSIST && EARLY_PREFETCH && kc + 1 == kc1 && !last_tile && !bxmode) {
@@ -595,6 +618,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       }
       if (t < nt) mfma_all(a0, b0);
     }
+    NNZ_TS(3 + 2 * (kc - kc0) < 12 ? 3 + 2 * (kc - kc0) : 15);
   }
 
   if (p.part) {
@@ -668,6 +692,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     }
   }
   lds_barrier();
+  NNZ_TS(12);
   if (NB != 1 && bxmode) bx_side_loads();
   constexpr int NPIECE = TD * TH * TW * PPV;
   if (p.stats) {
@@ -764,6 +789,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       }
     }
     __syncthreads();
+    NNZ_TS(13);
     if (wave != 0 || (p.dbg & 4)) return;
     const long nrec = (long)p.d.N * Cout * 2;
     for (int c = lane; c < NC; c += 64) {
@@ -792,6 +818,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         }
       }
     }
+    NNZ_TS(14);
     return;
   } else if (p.acc) {
     // Deterministic and cancellation-free variant: moments about a PILOT value per channel (the tile's first voxel), folded
@@ -875,6 +902,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       }
     }
   }
+  NNZ_TS(13);
 #pragma unroll 2
   for (int c = tid; c < NPIECE; c += 256) {
     const int v = c / PPV, part = c % PPV;
@@ -896,6 +924,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     }
     *reinterpret_cast<f16x8*>(dst) = val;
   }
+  NNZ_TS(14);
   };   // tile_body
 
   for (int it = 0; it < TPW; ++it) {
@@ -1147,8 +1176,8 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
     // stride 2, large grids (knob 7): 4x8x8 voxels x 64 couts per workgroup - four times the MFMA work per staged slice and
     // half the LDS fragment traffic per MFMA (2 x 2 register tile) of the 2x4x8 tile, at one workgroup per CU (142 KB of LDS)
     if (g_tuning[7] && mvox >= 32L * 32 * 32)
-      return launch_cfg<4, 8, 8, 2, iso_lpt<4, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, false, false, 1>(p, stream);
-    return launch_iso<2, 4, 8, 2, IS, EXT>(p, stream);  // N-split over waves: needs Cout % 64 == 0
+      return launch_cfg<4, 8, 8, 2, iso_lpt<4, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, false, false, 1, NNZ_S2_PERSIST>(p, stream);
+    return launch_cfg<2, 4, 8, 2, iso_lpt<2, 4, 8, IS, EXT>(), GeoIso<IS, EXT>, false, false, 2, NNZ_S2_PERSIST>(p, stream);  // N-split over waves: needs Cout % 64 == 0
   }
 }
 
@@ -1353,6 +1382,9 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
     p.slope = nr ? nr->slope : 0.f;
     p.ldbx = nr ? nr->ldbx : 0;
     p.dbg = g_tuning[6];
+#if NNZ_CONV_TIMESTAMPS
+    p.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)g_tuning[11] << 32) | (unsigned)g_tuning[10]);
+#endif
     p.in_tab = inn && inn->tab ? inn->tab + (size_t)n0 * (d.Cin - inn->c0) * 4 : nullptr;
     p.in_c0 = inn ? inn->c0 : 0;
     p.in_slope = inn ? inn->slope : 0.f;

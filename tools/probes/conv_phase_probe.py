@@ -1,0 +1,133 @@
+"""Where does a conv_box workgroup spend its time?  Phase timestamps (s_memtime of thread 0) of every workgroup of one launch.
+
+    python tools/probes/conv_phase_probe.py --build          # here or on the GPU box: the instrumented library (never the shipped one)
+    python tools/probes/conv_phase_probe.py [--only enc0.1]  # GPU box
+
+Builds tools/probes/_ts/libnnuzoo_hip_ts.so = the product objects with csrc/conv_fprop.hip recompiled under
+-DNNZ_CONV_TIMESTAMPS=1, loads it INSTEAD of libnnuzoo_hip.so in this process only, and runs single launches as the training step
+issues them (forward with the consumer-side norm and the statistics epilogue; data gradient plain).  Slots (conv_fprop.hip NNZ_TS):
+0 entry, 1 set-up done, 2 + 2k slice k staged in LDS (both barriers passed), 3 + 2k slice k's MFMA loop done, 12 accumulators
+transposed into LDS, 13 statistics / reductions done, 14 stores issued.  Printed: mean cycles per phase over the workgroups, the
+share of the workgroup's lifetime, and the launch's wall time against (workgroups / 512 resident) x mean lifetime."""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+TS_DIR = os.path.join(ROOT, "tools", "probes", "_ts")
+TS_LIB = os.path.join(TS_DIR, "libnnuzoo_hip_ts.so")
+
+
+def build():
+    from nnuzoo_amd import build as B
+    B.build(verbose=False)
+    os.makedirs(TS_DIR, exist_ok=True)
+    obj = os.path.join(TS_DIR, "conv_fprop.o")
+    cmd = [B.HIPCC, *B._flags("conv_fprop.hip"), "-DNNZ_CONV_TIMESTAMPS=1", "-c", os.path.join(B.CSRC, "conv_fprop.hip"), "-o", obj]
+    subprocess.run(cmd, check=True)
+    objs = [os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B._sources() if s != "conv_fprop.hip"] + [obj]
+    subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TS_LIB, *objs], check=True)
+    print("built", TS_LIB)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--tuning", default="")
+    a = ap.parse_args()
+    if a.build:
+        build()
+        return
+    if not os.path.exists(TS_LIB):
+        build()
+    import torch
+    from nnuzoo_amd import _lib
+    _lib.LIB_PATH = TS_LIB
+    from nnuzoo_amd import conv_plan as cp
+    from nnuzoo_amd import hip_ops as ops
+    from nnuzoo_amd.hip_ops import PreparedTable
+    for kv in filter(None, a.tuning.split(",")):
+        k, v = kv.split("=")
+        _lib.call("nnz_conv_tuning", int(k), int(v))
+    dev = torch.device("cuda")
+    N = 2
+    ts = torch.zeros(1 << 16, 16, dtype=torch.int64, device=dev)
+    addr = ts.data_ptr()
+
+    def arm(on):
+        lo, hi = (addr & 0xFFFFFFFF, addr >> 32) if on else (0, 0)
+        _lib.call("nnz_conv_tuning", 10, lo - (1 << 32) if lo >= (1 << 31) else lo)
+        _lib.call("nnz_conv_tuning", 11, hi)
+
+    names = {0: "entry->setup", 1: "setup->slice0 staged"}
+    layers = [("enc0.1", 32, 32, 128, 1), ("dec0.0", 64, 32, 128, 1), ("enc1.1", 64, 64, 64, 1), ("dec1.0", 128, 64, 64, 1),
+              ("enc1.0", 32, 64, 128, 2), ("enc2.1", 128, 128, 32, 1)]
+    for name, cin, cout, edge, stride in layers:
+        if a.only and a.only not in name:
+            continue
+        dims = (edge,) * 3
+        od = cp.conv_out_dims(dims, (3, 3, 3), stride)
+        V, Vo = edge ** 3, int(np.prod(od))
+        x = torch.randn(N, V, cin, device=dev).to(torch.float16)
+        dy = torch.randn(N, Vo, cout, device=dev).to(torch.float16)
+        w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
+        y = torch.empty(N, Vo, cout, device=dev, dtype=torch.float16)
+        dx = torch.empty(N, V, cin, device=dev, dtype=torch.float16)
+        pf = PreparedTable(cp.conv_forward(N, dims, cin, cout, stride=stride))
+        pd = PreparedTable(cp.conv_dgrad(N, dims, cin, cout, stride=stride))
+        wf = ops.pack_weight(w, pf, cin, cout, 27, cin * 27, 1)
+        wd = ops.pack_weight(w, pd, cout, cin, cin * 27, 27, 1)
+        tab = torch.randn(N, cin, 4, device=dev)
+        tab[:, :, 2] = 1.0 + 0.1 * tab[:, :, 2]
+        inn = ops.InNorm(tab, 0.01)
+        sc = ops.NormScratch(dev, N * max(cin, cout))
+        gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        nstat = torch.empty(N, cout, 4, device=dev)
+        runs = {"fwd+innorm+stats": lambda: ops.conv_tap_forward_norm(pf, x, wf, None, y, sc, gamma, beta, 1e-5, nstat, innorm=inn),
+                "fwd plain": lambda: ops.conv_tap_forward(pf, x, wf, None, y),
+                "dgrad plain": lambda: ops.conv_tap_forward(pd, dy, wd, None, dx)}
+        for what, fn in runs.items():
+            arm(False)
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            wall = s.elapsed_time(e) / 5 * 1e3          # us, uninstrumented pointer (the branch is still compiled in)
+            ts.zero_()
+            arm(True)
+            fn()
+            torch.cuda.synchronize()
+            arm(False)
+            t = ts.cpu().numpy().astype(np.int64)
+            live = t[:, 0] != 0
+            t = t[live]
+            nwg = len(t)
+            span = int(t[:, 14].max() - t[:, 0].min())
+            life = (t[:, 14] - t[:, 0]).astype(np.float64)
+            used = [s_ for s_ in range(16) if (t[:, s_] != 0).all()]
+            print(f"\n{name} {cin}->{cout} @{edge} s{stride}  {what}: {nwg} workgroups, wall {wall:.1f} us, launch span {span} ticks "
+                  f"-> {span / wall:.1f} ticks/us; mean workgroup lifetime {life.mean():.0f} ticks = {life.mean() / (span / wall):.2f} us, "
+                  f"rounds {nwg / 512:.1f} -> {nwg / 512 * life.mean() / (span / wall):.1f} us if perfectly packed")
+            prev = used[0]
+            for s_ in used[1:]:
+                d = (t[:, s_] - t[:, prev]).astype(np.float64)
+                label = names.get(prev) or (f"slice {(prev - 2) // 2} MFMA loop" if 2 <= prev < 12 and prev % 2 == 0 else
+                                            f"slice {(s_ - 2) // 2} wait + stage" if s_ < 12 and s_ % 2 == 0 else
+                                            {12: "last loop -> acc in LDS", 13: "statistics", 14: "stores"}.get(s_, f"{prev}->{s_}"))
+                print(f"   {prev:2d}->{s_:2d}  {label:28s} mean {d.mean():9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}"
+                      f"   {100 * d.mean() / life.mean():5.1f} %")
+                prev = s_
+
+
+if __name__ == "__main__":
+    main()
