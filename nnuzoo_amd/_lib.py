@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnnuzoo_hip.so")
+# NNZ_HIP_LIBRARY: another build of the same library (experiment builds of tools/probes; same symbols, checked at load)
+LIB_PATH = os.environ.get("NNZ_HIP_LIBRARY") or os.path.join(_HERE, "libnnuzoo_hip.so")
 
 NNZ_MAX_GROUPS = 8
 NNZ_MAX_TAPS = 32

@@ -38,7 +38,7 @@ struct TapDev {
 };
 
 // -DNNZ_CONV_TIMESTAMPS=1 (tools/probes/conv_phase_probe.py builds its own library with it; never the shipped one): thread 0 of
-// every workgroup records s_memtime at the phase boundaries into ts[workgroup][16] - buffer address = knobs 10 (low) / 11 (high)
+// every workgroup records s_memtime at the phase boundaries into ts[workgroup][16] - buffer address = knobs 12 (low) / 13 (high)
 #ifndef NNZ_CONV_TIMESTAMPS
 #define NNZ_CONV_TIMESTAMPS 0
 #endif
@@ -81,6 +81,10 @@ struct ConvDev {
 #if NNZ_CONV_TIMESTAMPS
   unsigned long long* ts;
 #endif
+  // ceil(2^32 / d) of the divisors of the workgroup-index decode (launcher): q = umulhi(n, m) is exact while n * d < 2^32
+  unsigned mg_gy, mg_gxw, mg_nsplit, mg_ngroups, mg_t2, mg_t1;
+  unsigned in_bytes, w_bytes, bx_bytes;  // extents of `in` / `w` / `bx` for the buffer descriptors of the staging loads (launcher; < 2^32 - 16)
+  int sep_finish;  // knob 10: no ticket in the epilogue, conv_stats_finish_kernel / conv_normred_finish_kernel follow the launch
   int dbg;  // nnz_conv_tuning(6, bits): epilogue experiments (tools/probes/normred_epilogue_probe.py); 0 in production
   // split-K over the 16-channel slices of the reduction (the <= 8^3 levels: 10-40 workgroups each walking 20-40 slices of
   // 55 KB of weights were 55 us of pure latency per launch): workgroup (.., split) covers slices [split * kper, ...) and
@@ -174,10 +178,18 @@ struct ConvCfg {
 //      32 -> 64 @128^3 0.238 -> 0.207 ms, 64 -> 128 @64^3 0.102 -> 0.093 ms, tools/bench_conv_layers.py --tuning 7=0/1)
 //   8  split-K applies to launches of fewer than this many workgroups                                                (default 128)
 //   9  depth-reuse launches: most consecutive W tiles one (persistent) workgroup walks (power of two; 1 = off)    (default 4)
+//  10  the fixed-point statistics / norm-backward reductions of a launch are turned into their tables by a separate finishing
+//      kernel (1) instead of by the launch's last workgroup behind a ticket (0)                                       (default 1:
+//      tools/probes/conv_phase_probe.py - wave 0 of EVERY workgroup sat ~10 000 cycles, a quarter of a 2-slice workgroup's
+//      lifetime, in the two dependent memory round trips of the protocol: adds acknowledged, ticket returned)
+//  12, 13  -DNNZ_CONV_TIMESTAMPS builds only: low / high half of the timestamp buffer's address
+#ifndef NNZ_DRE_PERSIST
+#define NNZ_DRE_PERSIST false
+#endif
 #ifndef NNZ_S2_PERSIST
 #define NNZ_S2_PERSIST false
 #endif
-static int g_tuning[12] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 0, 0};
+static int g_tuning[16] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 1, 0, 0, 0, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
@@ -211,36 +223,61 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const int hh = lane >> 5;
 
   // ---- workgroup -> (tile, cout block, sample, group) ---------------------------------------------
+  // Every kernel argument the decode and the staging addresses need is fetched in ONE batch here (the empty asm consumes them
+  // all, so their scalar loads are issued together and waited for once) - left to itself the compiler loads each next to its
+  // first use: eight dependent scalar round trips in front of the first global load.  The divisions of the decode use the
+  // launcher's reciprocals (one s_mul_hi each instead of a ~25-instruction float-reciprocal sequence, ten times).
   const int TPW = PERSIST ? p.tiles_per_wg : 1;     // tiles per workgroup
-  const int gxw = p.gx / TPW;                        // workgroups along the m-tile index
-  const unsigned nwg = (unsigned)gxw * p.gy * p.gz;
+  const int gx_ = p.gx, gy_ = p.gy, gz_ = p.gz, nsplit_ = p.nsplit, ngroups_ = p.d.ngroups, cf_ = p.cout_fastest;
+  const int t1_ = p.tiles[1], t2_ = p.tiles[2];
+  const unsigned mgy = p.mg_gy, mgx = p.mg_gxw, mgs = p.mg_nsplit, mgg = p.mg_ngroups, mgt2 = p.mg_t2, mgt1 = p.mg_t1;
+  const int lo0_ = p.d.lo[0], lo1_ = p.d.lo[1], lo2_ = p.d.lo[2], ldi_ = p.d.ldi;
+  const int Cin = p.d.Cin, Cout = p.d.Cout, T = p.d.ntaps_total;
+  const int Di = p.d.in_dims[0], Hi = p.d.in_dims[1], Wi = p.d.in_dims[2];
+  const f16* in_ = p.in;
+  const f16* w_ = p.w;
+  const unsigned in_bytes_ = p.in_bytes, w_bytes_ = p.w_bytes;
+  asm volatile("" ::"s"(in_), "s"(w_), "s"(in_bytes_), "s"(w_bytes_));
+  asm volatile("" ::"s"(gx_), "s"(gy_), "s"(gz_), "s"(nsplit_), "s"(ngroups_), "s"(cf_), "s"(t1_), "s"(t2_), "s"(mgy), "s"(mgx),
+               "s"(mgs), "s"(mgg), "s"(mgt2), "s"(mgt1), "s"(lo0_), "s"(lo1_), "s"(lo2_), "s"(ldi_), "s"(Cin), "s"(Cout), "s"(T),
+               "s"(Di), "s"(Hi), "s"(Wi), "s"(TPW));
+  auto udiv = [](unsigned n, int d, unsigned m) -> unsigned { return d == 1 ? n : __umulhi(n, m); };
+  const int gxw = PERSIST ? gx_ / TPW : gx_;          // workgroups along the m-tile index
+  const unsigned mgxw = mgx;                          // (the launcher's reciprocal is that of gx / tiles_per_wg)
+  const unsigned nwg = (unsigned)gxw * gy_ * gz_;
   unsigned lin = xcd_remap(blockIdx.x, nwg);
   int bx, by;
-  if (p.cout_fastest) {
+  if (cf_) {
     // the cout blocks of one m-tile are neighbours in launch order (same XCD, same time): the second .. gy-th of them
     // find the tile's input box in L2 instead of HBM
-    by = lin % p.gy;
-    lin /= p.gy;
-    bx = lin % gxw;
-    lin /= gxw;
+    unsigned q = udiv(lin, gy_, mgy);
+    by = lin - q * gy_;
+    lin = q;
+    q = udiv(lin, gxw, mgxw);
+    bx = lin - q * gxw;
+    lin = q;
   } else {
-    bx = lin % gxw;
-    lin /= gxw;
-    by = lin % p.gy;
-    lin /= p.gy;
+    unsigned q = udiv(lin, gxw, mgxw);
+    bx = lin - q * gxw;
+    lin = q;
+    q = udiv(lin, gy_, mgy);
+    by = lin - q * gy_;
+    lin = q;
   }
   bx *= TPW;
   int bz = lin;
   int split = 0;
-  if (p.nsplit > 1) {
-    split = bz % p.nsplit;
-    bz /= p.nsplit;
+  if (nsplit_ > 1) {
+    const unsigned q = udiv(bz, nsplit_, mgs);
+    split = bz - q * nsplit_;
+    bz = q;
   }
-  const int g = bz % p.d.ngroups;
-  const int n = bz / p.d.ngroups;
-  const int tw_i = bx % p.tiles[2];
-  const int th_i = (bx / p.tiles[2]) % p.tiles[1];
-  const int td_i = bx / (p.tiles[2] * p.tiles[1]);
+  const int n = udiv(bz, ngroups_, mgg);
+  const int g = bz - n * ngroups_;
+  const unsigned q2 = udiv(bx, t2_, mgt2);
+  const int tw_i = bx - q2 * t2_;
+  const int td_i = udiv(q2, t1_, mgt1);
+  const int th_i = q2 - td_i * t1_;
   const int m0d = td_i * TD, m0h = th_i * TH;
   int m0w = tw_i * TW;      // (PERSIST: advances by TW per tile; the launcher guarantees the run stays inside one W row)
   const int cb0 = by * NB;  // first 32-wide cout block
@@ -248,19 +285,36 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const nnz_conv_group grp = p.d.groups[g];
   const int nt = grp.ntaps;
   const int tb = grp.tap_begin;
-  const int T = p.d.ntaps_total;
-  const int Cin = p.d.Cin, Cout = p.d.Cout;
-  const int Di = p.d.in_dims[0], Hi = p.d.in_dims[1], Wi = p.d.in_dims[2];
+  // The scalars the epilogue's index arithmetic uses, fetched HERE and pinned in SGPRs.  Left to itself the compiler re-reads a
+  // kernel argument next to every use - inside the short-circuit bounds checks of the epilogue that was a scalar load plus a full
+  // lgkmcnt(0) wait per comparison: five dependent round trips in front of each of the eight layer-below loads of the fused
+  // norm-backward launches (tools/probes/conv_phase_probe.py: 10 000 cycles per workgroup between the last MFMA and the
+  // accumulators' LDS image).
+  const int mD0 = pin_uniform(p.d.m_dims[0]), mD1 = pin_uniform(p.d.m_dims[1]), mD2 = pin_uniform(p.d.m_dims[2]);
+  const int oD0 = pin_uniform(p.d.out_dims[0]), oD1 = pin_uniform(p.d.out_dims[1]), oD2 = pin_uniform(p.d.out_dims[2]);
+  const int oS0 = pin_uniform(p.d.out_stride[0]), oS1 = pin_uniform(p.d.out_stride[1]), oS2 = pin_uniform(p.d.out_stride[2]);
+  const int oO0 = pin_uniform(grp.ooff[0]), oO1 = pin_uniform(grp.ooff[1]), oO2 = pin_uniform(grp.ooff[2]);
+  const int ldo_ = pin_uniform(p.d.ldo), ldbx_ = pin_uniform(p.ldbx), accum_ = pin_uniform(p.d.accumulate);
+  const int dbg_ = pin_uniform(p.dbg);
 
   // ---- per-thread staging addresses (independent of the channel slice) ----------------------------
-  int box_goff[LPT_BOX];  // element offset into `in` (without channel slice), -1 = zero fill
+  // The staging loads are BUFFER loads (descriptor = base + extent in SGPRs, 32-bit byte offset per lane, the slice's offset in
+  // the scalar offset operand): a piece outside the volume carries an offset beyond the extent and the range check returns
+  // zeros - one instruction per piece.  (As flat loads every piece was an exec-masked branch around a 64-bit address add, ~10
+  // instructions each: tools/probes/conv_phase_probe.py priced the 15 loads of a slice at ~1 600 cycles in front of the MFMA
+  // loop, a quarter of a slice's time, and 37 VGPRs + 14 SGPR pairs of addresses and masks.)
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(in_), 0, (int)in_bytes_, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(w_), 0, (int)w_bytes_, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.bx), 0, (int)p.bx_bytes, 0x00020000);
+  unsigned box_goff[LPT_BOX];  // byte offset into `in` (without channel slice), OOB = zero fill
   int box_loff[LPT_BOX];  // LDS byte offset, -1 = nothing to do
   {
-    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = m0w * ISW + p.d.lo[2];
+    const int lod = m0d * ISD + lo0_, loh = m0h * ISH + lo1_, low = m0w * ISW + lo2_;
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
-      box_goff[i] = -1;
+      box_goff[i] = OOB;
       box_loff[i] = -1;
       if (c < bg.NBOXLOAD) {
         const int half = c & 1;
@@ -276,17 +330,17 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         const int swz = (ISH == 2 ? bh >> 1 : bh) & 1;
         box_loff[i] = ((bd * bg.BH + bh) * bg.PW + bwp) * 32 + ((half ^ swz) << 4);
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
-          box_goff[i] = (((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + half * 8;
+          box_goff[i] = ((unsigned)((((n * Di + id) * Hi + ih) * Wi + iw) * ldi_) + half * 8) * 2u;
       }
     }
   }
   // PERSIST: the staging addresses of the tile that starts at W position `w0` - the piece's box coordinates are decoded from
   // its LDS offset (stride-1 geometry only: bwp = bw), validity and global offset as above
   auto set_box_goff = [&](int w0) {
-    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = w0 * ISW + p.d.lo[2];
+    const int lod = m0d * ISD + lo0_, loh = m0h * ISH + lo1_, low = w0 * ISW + lo2_;
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i) {
-      box_goff[i] = -1;
+      box_goff[i] = OOB;
       if (box_loff[i] >= 0) {
         // (opaque copy: the decode is invariant across the tile loop and would otherwise be hoisted into ~32 live registers)
         int lo_ = box_loff[i];
@@ -296,11 +350,23 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         const int half = ((lo_ >> 4) & 1) ^ (bh & 1);
         const int id = lod + bd, ih = loh + bh, iw = low + bw;
         if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi)
-          box_goff[i] = (((n * Di + id) * Hi + ih) * Wi + iw) * p.d.ldi + half * 8;
+          box_goff[i] = ((unsigned)((((n * Di + id) * Hi + ih) * Wi + iw) * ldi_) + half * 8) * 2u;
       }
     }
   };
   const int nwchunks = NB * nt * 64;
+  unsigned w_goff[C::LPT_W];  // byte offset of the thread's weight pieces inside one slice's block, OOB = none
+#pragma unroll
+  for (int i = 0; i < C::LPT_W; ++i) {
+    const int c = tid + i * 256;
+    w_goff[i] = OOB;
+    if (c < nwchunks) {
+      const int nb = c / (nt * 64);
+      const int r = c - nb * nt * 64;
+      w_goff[i] = (unsigned)(((cb0 + nb) * T + tb) * 512 + r * 8) * 2u;
+    }
+  }
+  const unsigned w_slice_bytes = (unsigned)((Cout >> 5) * T) * 1024u;
 
   // ---- per-lane fragment addresses ----------------------------------------------------------------
   const int wm = wave % C::WAVES_M;
@@ -319,12 +385,12 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       const int v = frag_voxel(i);
       const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
       const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-      const int od = md * p.d.out_stride[0] + grp.ooff[0];
-      const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
-      const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
-      const bool ok = md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] &&
-                      od < p.d.out_dims[0] && oh < p.d.out_dims[1] && ow < p.d.out_dims[2];
-      out_vox[i] = ok ? (((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) * p.d.ldo
+      const int od = md * oS0 + oO0;
+      const int oh = mh * oS1 + oO1;
+      const int ow = mw * oS2 + oO2;
+      const bool ok = md < mD0 && mh < mD1 && mw < mD2 &&
+                      od < oD0 && oh < oD1 && ow < oD2;
+      out_vox[i] = ok ? (((n * oD0 + od) * oD1 + oh) * oD2 + ow) * ldo_
                       : -1;
     }
   };
@@ -377,23 +443,11 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   };
   auto issue_loads = [&](int kc) {
 #pragma unroll
-    for (int i = 0; i < LPT_BOX; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (box_goff[i] >= 0) v = *reinterpret_cast<const u32x4*>(p.in + (size_t)box_goff[i] + kc * 16);
-      breg[i] = v;
-    }
+    for (int i = 0; i < LPT_BOX; ++i)
+      breg[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)box_goff[i], kc * 32, 0);
 #pragma unroll
-    for (int i = 0; i < C::LPT_W; ++i) {
-      const int c = tid + i * 256;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (c < nwchunks) {
-        const int nb = c / (nt * 64);
-        const int r = c - nb * nt * 64;
-        const size_t base = ((size_t)(kc * (Cout >> 5) + cb0 + nb) * T + tb) * 512;
-        v = *reinterpret_cast<const u32x4*>(p.w + base + (size_t)r * 8);
-      }
-      wreg[i] = v;
-    }
+    for (int i = 0; i < C::LPT_W; ++i)
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)w_goff[i], (int)((unsigned)kc * w_slice_bytes), 0);
   };
   // Consumer-side norm of the staged pieces between the slice's two barriers, CHANNEL PAIR by channel pair (every piece of a
   // thread holds the same 8 channels of the slice: c = tid + 256 i -> half = tid & 1; dword q of every piece = channels 2q,
@@ -413,7 +467,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   };
   bool padded_box;   // some piece of this thread's box lies outside the volume (uniform over the workgroup's tile)
   auto set_padded_box = [&](int w0) {
-    const int lod = m0d * ISD + p.d.lo[0], loh = m0h * ISH + p.d.lo[1], low = w0 * ISW + p.d.lo[2];
+    const int lod = m0d * ISD + lo0_, loh = m0h * ISH + lo1_, low = w0 * ISW + lo2_;
     padded_box = lod < 0 || loh < 0 || low < 0 || lod + bg.BD > Di || loh + bg.BH > Hi || low + bg.BW > Wi;
   };
   set_padded_box(m0w);
@@ -424,7 +478,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       if (padded_box) {
 #pragma unroll
         for (int i = 0; i < LPT_BOX; ++i)
-          if (box_goff[i] < 0) breg[i] = u32x4{0u, 0u, 0u, 0u};
+          if (box_goff[i] == OOB) breg[i] = u32x4{0u, 0u, 0u, 0u};
       }
       store_tab(kc + 1);
     }
@@ -506,11 +560,13 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   constexpr int BX_NIT = (TD * TH * TW + BX_PARTS - 1) / BX_PARTS;
   static_assert(BX_NIT <= LPT_BOX + C::LPT_W, "layer-below tile must fit the staging registers");
   const bool bxmode = p.acc && p.bx;
-  const int kc0 = p.nsplit > 1 ? split * p.kper : 0;
-  const int kc1 = p.nsplit > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
+  const int kc0 = nsplit_ > 1 ? split * p.kper : 0;
+  const int kc1 = nsplit_ > 1 ? (kc0 + p.kper < nkc ? kc0 + p.kper : nkc) : nkc;
   NNZ_TS(1);
-  issue_loads(kc0);
+  // (table first: store_tab below then waits for the OLDEST load only - behind the slice's 15 loads it waited for all of them,
+  //  and the barrier + normalisation of slice 0 could not start before the last piece had landed)
   load_tab(kc0);
+  issue_loads(kc0);
   // (requesting the next tile's first slice inside this tile's last MFMA loop keeps 32 staging registers alive through the
   //  epilogue, which then spills them: measured slower than the late request below)
   constexpr bool EARLY_PREFETCH = false;
@@ -532,20 +588,20 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     const int v = tid / PPV + k * BX_PARTS;
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
     const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-    const int od = md * p.d.out_stride[0] + grp.ooff[0];
-    const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
-    const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
-    const bool ok = v < TD * TH * TW && md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] &&
-                    od < p.d.out_dims[0] && oh < p.d.out_dims[1] && ow < p.d.out_dims[2];
-    return ok ? ((long)((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) : -1;
+    const int od = md * oS0 + oO0;
+    const int oh = mh * oS1 + oO1;
+    const int ow = mw * oS2 + oO2;
+    const bool ok = (v < TD * TH * TW) & (md < mD0) & (mh < mD1) & (mw < mD2) & (od < oD0) & (oh < oD1) & (ow < oD2);
+    return ok ? ((long)((n * oD0 + od) * oD1 + oh) * oD2 + ow) : -1;
   };
   auto issue_bx = [&]() {
     const int co = cb0 * 32 + (tid % PPV) * 8;
 #pragma unroll
     for (int k = 0; k < BX_NIT; ++k) {
       const long idx = bx_index(k);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx >= 0 && !(p.dbg & 1)) v = *reinterpret_cast<const u32x4*>(p.bx + idx * p.ldbx + co);
+      // buffer load like the staging loads: rows outside the tile carry an offset beyond the extent and come back as zeros
+      const unsigned off = idx >= 0 ? ((unsigned)idx * (unsigned)ldbx_ + (unsigned)co) * 2u : OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc, (int)off, 0, 0);
       if (k < LPT_BOX) breg[k < LPT_BOX ? k : 0] = v;
       else wreg[k >= LPT_BOX ? k - LPT_BOX : 0] = v;
     }
@@ -564,14 +620,21 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     write_lds(kc);
     __syncthreads();
     NNZ_TS(2 + 2 * (kc - kc0) < 12 ? 2 + 2 * (kc - kc0) : 15);
-    if (kc + 1 < kc1) issue_loads(kc + 1);
+    // (table first: its destination register is rewritten here, and the compiler guards that with a wait for every load in
+    //  flight - before the slice's 15 loads are issued that wait is free, after them it would hold wave 0 until they land)
     if (kc + 2 < kc1) load_tab(kc + 2);
+    if (kc + 1 < kc1) issue_loads(kc + 1);
+    // fused norm-backward reductions: the layer-below tile is requested under the LAST slice's MFMA loop - the staging registers
+    // are free there (no next slice to prefetch) and the epilogue finds the rows landed instead of waiting a memory round trip
+    // (tools/probes/conv_phase_probe.py: ~5 000 cycles per workgroup between the last MFMA and the accumulators' LDS image)
+    // (depth-reuse instantiations only: elsewhere the longer live ranges cost a wave of occupancy or spill)
+    else if (DRE && bxmode) issue_bx();
     if (PERSIST && EARLY_PREFETCH && kc + 1 == kc1 && !last_tile && !bxmode) {
       // forward launches: the epilogue leaves the staging registers alone - request the next tile's first slice now
       set_box_goff(m0w + TW);
       set_padded_box(m0w + TW);
-      issue_loads(kc0);
       load_tab(kc0);
+      issue_loads(kc0);
       prefetched = true;
     }
 
@@ -623,19 +686,19 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
 
   if (p.part) {
     // split-K: the lane's accumulator quads are 4 consecutive couts of one voxel -> 16-byte fp32 stores, no transposition
-    const long vox_per_n = (long)p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2];
+    const long vox_per_n = (long)oD0 * oD1 * oD2;
 #pragma unroll
     for (int j = 0; j < C::WM; ++j) {
       const int v = frag_voxel(j);
       const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
       const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-      const int od = md * p.d.out_stride[0] + grp.ooff[0];
-      const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
-      const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
-      if (!(md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] && od < p.d.out_dims[0] &&
-            oh < p.d.out_dims[1] && ow < p.d.out_dims[2]))
+      const int od = md * oS0 + oO0;
+      const int oh = mh * oS1 + oO1;
+      const int ow = mw * oS2 + oO2;
+      if (!(md < mD0 && mh < mD1 && mw < mD2 && od < oD0 &&
+            oh < oD1 && ow < oD2))
         continue;
-      const long vox = ((long)od * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow;
+      const long vox = ((long)od * oD1 + oh) * oD2 + ow;
       float* dst = p.part + (((long)split * p.d.N + n) * vox_per_n + vox) * Cout;
 #pragma unroll
       for (int i = 0; i < C::WN; ++i) {
@@ -666,13 +729,14 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
 #pragma unroll
     for (int k = 0; k < BX_NIT; ++k) {
       boidx[k] = bx_index(k);
-      if (p.d.accumulate && boidx[k] >= 0) bold[k] = *reinterpret_cast<const f16x8*>(p.out + boidx[k] * p.d.ldo + co);
+      if (accum_ && boidx[k] >= 0) bold[k] = *reinterpret_cast<const f16x8*>(p.out + boidx[k] * ldo_ + co);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) btab[e] = *reinterpret_cast<const f32x4*>(p.bstat + ((size_t)n * Cout + co + e) * 4);
   };
-  if (bxmode) issue_bx();
+  if (!DRE && bxmode) issue_bx();
   if (NB == 1 && bxmode) bx_side_loads();
+  NNZ_TS(9);
   lds_barrier();  // every wave is done reading box / weights (LDS-only barrier: global loads stay in flight)
 #pragma unroll
   for (int i = 0; i < C::WN; ++i) {
@@ -695,6 +759,11 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   NNZ_TS(12);
   if (NB != 1 && bxmode) bx_side_loads();
   constexpr int NPIECE = TD * TH * TW * PPV;
+  // knob 10: wave 0's fixed-point adds are issued AFTER its share of the output stores.  In front of them the 128 adds (all
+  // workgroups of the launch hit the same 256 words) backed up the wave's memory queue and its stores - the workgroup's last -
+  // left twice as late (tools/probes/conv_phase_probe.py: 5 900 against 2 900 cycles)
+  long fx_rec = -1;
+  double fx_v1 = 0.0, fx_v2 = 0.0;
   if (p.stats) {
     // InstanceNorm statistics of this tile from the fp16 image (what the normalisation will read): a thread sums 8
     // channels over its share of the voxels, a [parts][2*NC] slab behind the image folds the shares, one atomic per
@@ -708,7 +777,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     for (int v = part; v < NVOX; v += PARTS) {
       const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
-      if (m0d + td < p.d.m_dims[0] && m0h + th < p.d.m_dims[1] && m0w + tw < p.d.m_dims[2]) {
+      if (m0d + td < mD0 && m0h + th < mD1 && m0w + tw < mD2) {
         const f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + c8 * 16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -753,12 +822,12 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       if (boidx[k] < 0) continue;
       const int v = part + k * BX_PARTS;
       f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + c8 * 16);
-      if (p.d.accumulate) {
+      if (accum_) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) val[e] = (f16)((float)val[e] + (float)bold[k][e]);
       }
-      *reinterpret_cast<f16x8*>(p.out + boidx[k] * p.d.ldo + co) = val;
-      if (p.dbg & 2) continue;
+      *reinterpret_cast<f16x8*>(p.out + boidx[k] * ldo_ + co) = val;
+      if (dbg_ & 2) continue;
       const u32x4 xraw = k < LPT_BOX ? breg[k < LPT_BOX ? k : 0] : wreg[k >= LPT_BOX ? k - LPT_BOX : 0];
       const f16x8 xk = __builtin_bit_cast(f16x8, xraw);
 #pragma unroll
@@ -772,6 +841,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         s2[e] += gp * (x - mean2[e]);   // times rstd once per channel, below
       }
     }
+    NNZ_TS(10);
 #pragma unroll
     for (int off = PPV; off < 64; off <<= 1)
 #pragma unroll
@@ -789,8 +859,8 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       }
     }
     __syncthreads();
-    NNZ_TS(13);
-    if (wave != 0 || (p.dbg & 4)) return;
+    NNZ_TS(11);
+    if (wave != 0 || (dbg_ & 4)) return;
     const long nrec = (long)p.d.N * Cout * 2;
     for (int c = lane; c < NC; c += 64) {
       const float S1 = (slab[c * 2] + slab[2 * NC + c * 2]) + (slab[4 * NC + c * 2] + slab[6 * NC + c * 2]);
@@ -799,8 +869,9 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       fx_add(p.acc, ch * 2, nrec, blockIdx.x, (double)S1);
       fx_add(p.acc, ch * 2 + 1, nrec, blockIdx.x, (double)S2);
     }
-    if (last_tile && last_workgroup_wave(p.counter, nwg)) {
-      const double V = (double)p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2];
+    NNZ_TS(13);
+    if (!p.sep_finish && last_tile && last_workgroup_wave(p.counter, nwg)) {
+      const double V = (double)oD0 * oD1 * oD2;
       for (int c = lane; c < Cout; c += 64) {
         double sg = 0.0, sb = 0.0;
         for (int nn = 0; nn < p.d.N; ++nn) {
@@ -840,7 +911,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     }
     for (int v = part; v < NVOX; v += PARTS) {
       const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
-      if (m0d + td < p.d.m_dims[0] && m0h + th < p.d.m_dims[1] && m0w + tw < p.d.m_dims[2]) {
+      if (m0d + td < mD0 && m0h + th < mD1 && m0w + tw < mD2) {
         const f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + c8 * 16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -850,6 +921,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         }
       }
     }
+    NNZ_TS(6);   // (sub-phase stamps 6..11 are meaningful for <= 2-slice launches only: deeper ones use these slots for slices)
     // fold the wave's 64 / PPV voxel shares with lane exchanges (fixed order), one slab row per wave, then wave 0 alone
     // finishes: per channel the four waves' sums, the double re-centring, the fixed-point adds, the ticket and - if this
     // was the launch's last workgroup - the table.  Waves 1-3 go straight on to the output stores: nobody waits for the
@@ -871,21 +943,29 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       }
     }
     __syncthreads();
+    NNZ_TS(7);
     if (wave == 0) {
       for (int c = lane; c < NC; c += 64) {
         const float S1 = (slab[c * 2] + slab[2 * NC + c * 2]) + (slab[4 * NC + c * 2] + slab[6 * NC + c * 2]);
         const float S2 = (slab[c * 2 + 1] + slab[2 * NC + c * 2 + 1]) + (slab[4 * NC + c * 2 + 1] + slab[6 * NC + c * 2 + 1]);
-        const int cd = p.d.m_dims[0] - m0d < TD ? p.d.m_dims[0] - m0d : TD;
-        const int ch = p.d.m_dims[1] - m0h < TH ? p.d.m_dims[1] - m0h : TH;
-        const int cw = p.d.m_dims[2] - m0w < TW ? p.d.m_dims[2] - m0w : TW;
+        const int cd = mD0 - m0d < TD ? mD0 - m0d : TD;
+        const int ch = mD1 - m0h < TH ? mD1 - m0h : TH;
+        const int cw = mD2 - m0w < TW ? mD2 - m0w : TW;
         const double cnt = (double)(cd * ch * cw);
         const double k = (double)(float)*reinterpret_cast<const f16*>(smem + c * 2);
         const long rec = ((long)n * Cout + cb0 * 32 + c) * 2, nrec = (long)p.d.N * Cout * 2;
-        fx_add(p.acc, rec, nrec, blockIdx.x, (double)S1 + cnt * k);
-        fx_add(p.acc, rec + 1, nrec, blockIdx.x, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
+        if (p.sep_finish) {   // (NC <= 64: one channel per lane) the adds follow this wave's stores, see below
+          fx_rec = rec;
+          fx_v1 = (double)S1 + cnt * k;
+          fx_v2 = (double)S2 + 2.0 * k * (double)S1 + cnt * k * k;
+        } else {
+          fx_add(p.acc, rec, nrec, blockIdx.x, (double)S1 + cnt * k);
+          fx_add(p.acc, rec + 1, nrec, blockIdx.x, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
+        }
       }
-      if (last_tile && last_workgroup_wave(p.counter, nwg)) {
-        const double V = (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2];
+      NNZ_TS(8);
+      if (!p.sep_finish && last_tile && last_workgroup_wave(p.counter, nwg)) {
+        const double V = (double)mD0 * mD1 * mD2;
         const long nrec = (long)p.d.N * Cout * 2;
         for (int i = lane; i < p.d.N * Cout; i += 64) {
           double mom[2];
@@ -908,21 +988,26 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     const int v = c / PPV, part = c % PPV;
     const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
     const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-    const int od = md * p.d.out_stride[0] + grp.ooff[0];
-    const int oh = mh * p.d.out_stride[1] + grp.ooff[1];
-    const int ow = mw * p.d.out_stride[2] + grp.ooff[2];
-    if (!(md < p.d.m_dims[0] && mh < p.d.m_dims[1] && mw < p.d.m_dims[2] && od < p.d.out_dims[0] &&
-          oh < p.d.out_dims[1] && ow < p.d.out_dims[2]))
+    const int od = md * oS0 + oO0;
+    const int oh = mh * oS1 + oO1;
+    const int ow = mw * oS2 + oO2;
+    if (!(md < mD0 && mh < mD1 && mw < mD2 && od < oD0 &&
+          oh < oD1 && ow < oD2))
       continue;
     const int co = cb0 * 32 + part * 8;
-    f16* dst = p.out + ((size_t)((n * p.d.out_dims[0] + od) * p.d.out_dims[1] + oh) * p.d.out_dims[2] + ow) * p.d.ldo + co;
+    f16* dst = p.out + ((size_t)((n * oD0 + od) * oD1 + oh) * oD2 + ow) * ldo_ + co;
     f16x8 val = *reinterpret_cast<const f16x8*>(smem + v * ROWB + part * 16);
-    if (p.d.accumulate) {
+    if (accum_) {
       const f16x8 old = *reinterpret_cast<const f16x8*>(dst);
 #pragma unroll
       for (int e = 0; e < 8; ++e) val[e] = (f16)((float)val[e] + (float)old[e]);
     }
     *reinterpret_cast<f16x8*>(dst) = val;
+  }
+  if (fx_rec >= 0) {
+    const long nrec = (long)p.d.N * Cout * 2;
+    fx_add(p.acc, fx_rec, nrec, blockIdx.x, fx_v1);
+    fx_add(p.acc, fx_rec + 1, nrec, blockIdx.x, fx_v2);
   }
   NNZ_TS(14);
   };   // tile_body
@@ -934,11 +1019,66 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       if (!prefetched) {   // data-gradient launches with the fused reductions: the epilogue used the staging registers
         set_box_goff(m0w + TW);
         set_padded_box(m0w + TW);
-        issue_loads(kc0);
         load_tab(kc0);
+        issue_loads(kc0);
       }
       m0w += TW;
     }
+  }
+}
+
+// Knob 10: what the launch's last workgroup did behind its ticket, as kernels of their own (same arithmetic, same bits).  The
+// kernel boundary orders them behind every workgroup's adds; one thread per record, so the read-and-reset round trips of all
+// records overlap instead of queueing in one wave (Cout = 320: ten dependent round trips in the launch's tail before).
+struct StatsFinish {
+  FxAcc* acc;
+  float* nstat;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int N, Cout;
+  double V;
+};
+__global__ __launch_bounds__(64) void conv_stats_finish_kernel(StatsFinish a) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.N * a.Cout) return;
+  const long nrec = (long)a.N * a.Cout * 2;
+  double mom[2];
+  fx_take_n<2>(a.acc, (long)i * 2, nrec, mom);
+  const double mean = mom[0] / a.V;
+  double var = mom[1] / a.V - mean * mean;
+  var = var < 0.0 ? 0.0 : var;  // (NaN stays NaN)
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const int c = i % a.Cout;
+  const float sc = rstd * a.gamma[c];
+  const f32x4 o = {(float)mean, rstd, sc, a.beta[c] - (float)mean * sc};
+  *reinterpret_cast<f32x4*>(a.nstat + (size_t)i * 4) = o;
+}
+struct NormRedFinish {
+  FxAcc* acc;
+  float* nred;
+  float* dgamma;
+  float* dbeta;
+  int N, Cout;
+  double V;
+};
+__global__ __launch_bounds__(64) void conv_normred_finish_kernel(NormRedFinish a) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= a.Cout) return;
+  const long nrec = (long)a.N * a.Cout * 2;
+  double sg = 0.0, sb = 0.0;
+  for (int nn = 0; nn < a.N; ++nn) {
+    const long i = (long)nn * a.Cout + c;
+    double r[2];
+    fx_take_n<2>(a.acc, i * 2, nrec, r);
+    a.nred[i * 2 + 0] = (float)(r[0] / a.V);
+    a.nred[i * 2 + 1] = (float)(r[1] / a.V);
+    sb += r[0];
+    sg += r[1];
+  }
+  if (a.dgamma) {
+    a.dgamma[c] = (float)sg;
+    a.dbeta[c] = (float)sb;
   }
 }
 
@@ -1100,7 +1240,35 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
   }
   const unsigned nwg = (unsigned)(p.gx / p.tiles_per_wg) * p.gy * p.gz;
+  p.sep_finish = g_tuning[10] && p.acc && p.nsplit <= 1;
+  {
+    auto magic = [](int d) -> unsigned { return d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u; };
+    const int gxw = p.gx / p.tiles_per_wg;
+    const int dmax = gxw > p.gy ? gxw : p.gy;
+    if ((unsigned long long)nwg * (unsigned long long)(dmax > p.gz ? dmax : p.gz) >= (1ull << 32)) return NNZ_EINVAL;
+    p.mg_gy = magic(p.gy); p.mg_gxw = magic(gxw); p.mg_nsplit = magic(p.nsplit); p.mg_ngroups = magic(p.d.ngroups);
+    p.mg_t2 = magic(p.tiles[2]); p.mg_t1 = magic(p.tiles[1]);
+  }
+  {
+    const unsigned long long ib = 2ull * p.d.N * p.d.in_dims[0] * p.d.in_dims[1] * p.d.in_dims[2] * (unsigned long long)p.d.ldi;
+    const unsigned long long wb = 2ull * (p.d.Cin / 16) * (p.d.Cout / 32) * (unsigned long long)p.d.ntaps_total * 512ull;
+    if (ib >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return NNZ_EINVAL;   // 32-bit byte offsets in the staging loads
+    const unsigned long long bb = p.bx ? 2ull * p.d.N * p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2] * (unsigned long long)p.ldbx : 0ull;
+    if (bb >= 0xFFFFFFF0ull) return NNZ_EINVAL;
+    p.in_bytes = (unsigned)ib;
+    p.w_bytes = (unsigned)wb;
+    p.bx_bytes = (unsigned)bb;
+  }
   NNZ_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, p);
+  if (p.sep_finish && p.bx) {
+    NormRedFinish f = {p.acc, p.nred, p.dgamma, p.dbeta, p.d.N, p.d.Cout,
+                       (double)p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2]};
+    NNZ_LAUNCH(conv_normred_finish_kernel, dim3((p.d.Cout + 63) / 64), dim3(64), 0, stream, f);
+  } else if (p.sep_finish) {
+    StatsFinish f = {p.acc, p.nstat, p.gamma, p.beta, p.eps, p.d.N, p.d.Cout,
+                     (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2]};
+    NNZ_LAUNCH(conv_stats_finish_kernel, dim3((p.d.N * p.d.Cout + 63) / 64), dim3(64), 0, stream, f);
+  }
   if (p.nsplit > 1) {
     SplitKFinish f = {};
     f.part = p.part; f.bias = p.bias; f.out = p.out; f.nstat = p.acc ? p.nstat : nullptr;
@@ -1156,8 +1324,8 @@ static int launch_tile(const ConvDev& p, hipStream_t stream) {
         //  hoisting (opaque thread index inside the tile body, late instead of early prefetch); 32 -> 32 @128^3 forward
         //  0.29 ms one tile per workgroup, 0.40-0.56 ms persistent.  tools/bench_conv_layers.py --tuning 9=T with the
         //  template flag flipped reproduces it.)
-        if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true, 2, false>(p, stream);
-        return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false, 2, false>(p, stream);
+        if (flip) return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, true, 2, NNZ_DRE_PERSIST>(p, stream);
+        return launch_cfg<8, 8, 8, 1, iso_lpt<8, 8, 8, IS, EXT>(), GeoIso<IS, EXT>, true, false, 2, NNZ_DRE_PERSIST>(p, stream);
       }
     }
     if (!nb2) {
@@ -1240,7 +1408,7 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
                                  const InNormArgs* inn = nullptr);
 
 extern "C" int nnz_conv_tuning(int knob, int value) {
-  if (knob < 0 || knob >= 12) return NNZ_EINVAL;
+  if (knob < 0 || knob >= 16) return NNZ_EINVAL;
   nnz::g_tuning[knob] = value;
   return NNZ_OK;
 }
@@ -1383,7 +1551,7 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
     p.ldbx = nr ? nr->ldbx : 0;
     p.dbg = g_tuning[6];
 #if NNZ_CONV_TIMESTAMPS
-    p.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)g_tuning[11] << 32) | (unsigned)g_tuning[10]);
+    p.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)g_tuning[13] << 32) | (unsigned)g_tuning[12]);
 #endif
     p.in_tab = inn && inn->tab ? inn->tab + (size_t)n0 * (d.Cin - inn->c0) * 4 : nullptr;
     p.in_c0 = inn ? inn->c0 : 0;

@@ -39,6 +39,7 @@ struct WgradDev {
   const float* q_tab;
   int p_c0, q_c0;
   float p_slope, q_slope;
+  unsigned p_bytes, q_bytes;  // extents of the operands for the staging loads' buffer descriptors (launcher; < 2^32 - 16)
 };
 
 // Box geometry policies (same split as conv_fprop.hip): compile-time isotropic stride/extent for the 3-D plans the
@@ -169,6 +170,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // staging loads = buffer loads: pieces outside the volume carry an offset beyond the extent and come back as zeros - no
+  // exec-masked branch per piece (see conv_fprop.hip)
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(Pp), 0, (int)p.p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(Qp), 0, (int)p.q_bytes, 0x00020000);
   u32x4 breg[LPT_BOX];
   u32x4 qreg[C::LPT_Q];
   unsigned bmask = 0, qmask = 0;   // pieces of the prefetched tile that came from memory (the others are zero padding)
@@ -190,41 +196,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
 #pragma unroll
     for (int i = 0; i < LPT_BOX; ++i) {
       const int c = tid + i * 256;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (c < gNBOXLOAD) {
-        const int part = c & 3;
-        const int s = c >> 2;
-        const int bwl = s % gBW;  // column of the LDS image
-        const int bh = (s / gBW) % gBH;
-        const int bd = s / (gBW * gBH);
-        const int hw = (gBW + 1) >> 1;
-        const int bw = ISW == 2 ? (bwl < hw ? 2 * bwl : 2 * (bwl - hw) + 1) : bwl;
-        const int id = lod + bd, ih = loh + bh, iw = low + bw;
-        if ((unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi) {
-          v = *reinterpret_cast<const u32x4*>(Pp + ((size_t)((n * Di + id) * Hi + ih) * Wi + iw) * ldi + part * 8);
-          bmask |= 1u << i;
-        }
-      }
-      breg[i] = v;
+      const int part = c & 3;
+      const int s = c >> 2;
+      const int bwl = s % gBW;  // column of the LDS image
+      const int bh = (s / gBW) % gBH;
+      const int bd = s / (gBW * gBH);
+      const int hw = (gBW + 1) >> 1;
+      const int bw = ISW == 2 ? (bwl < hw ? 2 * bwl : 2 * (bwl - hw) + 1) : bwl;
+      const int id = lod + bd, ih = loh + bh, iw = low + bw;
+      const bool ok = (c < gNBOXLOAD) & ((unsigned)id < (unsigned)Di) & ((unsigned)ih < (unsigned)Hi) & ((unsigned)iw < (unsigned)Wi);
+      const unsigned off = ((unsigned)((((n * Di + id) * Hi + ih) * Wi + iw) * ldi) + part * 8) * 2u;
+      breg[i] = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)(ok ? off : OOB), 0, 0);
+      bmask |= ok ? 1u << i : 0u;
     }
 #pragma unroll
     for (int i = 0; i < C::LPT_Q; ++i) {
       const int c = tid + i * 256;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (c < C::NQLOAD) {
-        const int part = c & 3;
-        const int s = c >> 2;
-        const int tw = s % TW, th = (s / TW) % TH, td = s / (TW * TH);
-        const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
-        const int od = md * os0 + oo0;
-        const int oh = mh * os1 + oo1;
-        const int ow = mw * os2 + oo2;
-        if (md < Dm && mh < Hm && mw < Wm && od < Do && oh < Ho && ow < Wo) {
-          v = *reinterpret_cast<const u32x4*>(Qp + ((size_t)((n * Do + od) * Ho + oh) * Wo + ow) * ldo + part * 8);
-          qmask |= 1u << i;
-        }
-      }
-      qreg[i] = v;
+      const int part = c & 3;
+      const int s = c >> 2;
+      const int tw = s % TW, th = (s / TW) % TH, td = s / (TW * TH);
+      const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
+      const int od = md * os0 + oo0;
+      const int oh = mh * os1 + oo1;
+      const int ow = mw * os2 + oo2;
+      const bool ok = (c < C::NQLOAD) & (md < Dm) & (mh < Hm) & (mw < Wm) & (od < Do) & (oh < Ho) & (ow < Wo);
+      const unsigned off = ((unsigned)((((n * Do + od) * Ho + oh) * Wo + ow) * ldo) + part * 8) * 2u;
+      qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, (int)(ok ? off : OOB), 0, 0);
+      qmask |= ok ? 1u << i : 0u;
     }
   };
   // Consumer-side norm of the staged tile between the two barriers, CHANNEL PAIR by channel pair (every piece of a thread holds
@@ -385,6 +383,13 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchO
   }
   p.splits = best;
   const int splits = best;
+  {
+    const unsigned long long pb = 2ull * p.d.N * p.d.in_dims[0] * p.d.in_dims[1] * p.d.in_dims[2] * (unsigned long long)p.d.ldi;
+    const unsigned long long qb = 2ull * p.d.N * p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2] * (unsigned long long)p.d.ldo;
+    if (pb >= 0xFFFFFFF0ull || qb >= 0xFFFFFFF0ull) return NNZ_EINVAL;   // 32-bit byte offsets in the staging loads
+    p.p_bytes = (unsigned)pb;
+    p.q_bytes = (unsigned)qb;
+  }
   auto kern = conv_wgrad_kernel<TD, TH, TW, LPT_BOX, MAXT, G>;
   static DynLdsCache lds_cache;  // per instantiation, per device
   {

@@ -271,7 +271,9 @@ def get_swin_umamba_d_from_plans(plans_manager, dataset_json: dict, configuratio
                                  deep_supervision: bool = True, use_pretrain: bool = True):
     """SwinUMambaD.py:697-732 (the pretrained load is commented out there: `use_pretrain` is accepted and ignored)"""
     if configuration_manager is not None:
-        assert len(configuration_manager.conv_kernel_sizes[0]) == 2, "Only 2D supported at the moment"
+        ks = getattr(configuration_manager, "conv_kernel_sizes", None)      # (the trainers' view of the plans exposes patch_size)
+        dim = len(ks[0]) if ks else len(configuration_manager.patch_size)
+        assert dim == 2, "Only 2D supported at the moment"
     vss_args = dict(in_chans=num_input_channels, patch_size=4, dims=96, drop_path_rate=0.2)
     decoder_args = dict(num_classes=_m2._heads(plans_manager, dataset_json), deep_supervision=deep_supervision,
                         drop_path_rate=0.2, d_state=16)

@@ -157,13 +157,16 @@ def test_ctypes_signatures_match_the_header_declarations():
             return "ptr"
         if re.search(r"\bfloat\b", p):
             return "float"
+        if re.search(r"\bdouble\b", p):
+            return "double"
         if re.search(r"\blong\b", p):
             return "long"
         assert re.search(r"\bint\b", p), p
         return "int"
 
     def kind_of_ctype(t):
-        return {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int: "int", ctypes.c_long: "long", ctypes.c_float: "float"}.get(
+        return {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int: "int", ctypes.c_long: "long", ctypes.c_float: "float",
+                ctypes.c_double: "double"}.get(
             t, "ptr" if isinstance(t, type) and issubclass(t, ctypes._Pointer) else str(t))
 
     for name, params in decls:
@@ -188,7 +191,7 @@ def test_header_matches_the_extern_c_definitions():
             if not p or p == "void":
                 continue
             out.append("ptr" if "*" in p else "float" if re.search(r"\bfloat\b", p) else
-                       "long" if re.search(r"\blong\b", p) else "int")
+                       "double" if re.search(r"\bdouble\b", p) else "long" if re.search(r"\blong\b", p) else "int")
         return out
 
     hdr = strip(open(os.path.join(ROOT, "include", "nnuzoo_hip.h")).read())

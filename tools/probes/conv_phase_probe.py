@@ -5,7 +5,8 @@
 
 Builds tools/probes/_ts/libnnuzoo_hip_ts.so = the product objects with csrc/conv_fprop.hip recompiled under
 -DNNZ_CONV_TIMESTAMPS=1, loads it INSTEAD of libnnuzoo_hip.so in this process only, and runs single launches as the training step
-issues them (forward with the consumer-side norm and the statistics epilogue; data gradient plain).  Slots (conv_fprop.hip NNZ_TS):
+issues them (forward with the consumer-side norm and the statistics epilogue; data gradient with the fused norm-backward
+reductions; both also plain).  Slots (conv_fprop.hip NNZ_TS):
 0 entry, 1 set-up done, 2 + 2k slice k staged in LDS (both barriers passed), 3 + 2k slice k's MFMA loop done, 12 accumulators
 transposed into LDS, 13 statistics / reductions done, 14 stores issued.  Printed: mean cycles per phase over the workgroups, the
 share of the workgroup's lifetime, and the launch's wall time against (workgroups / 512 resident) x mean lifetime."""
@@ -22,24 +23,31 @@ TS_DIR = os.path.join(ROOT, "tools", "probes", "_ts")
 TS_LIB = os.path.join(TS_DIR, "libnnuzoo_hip_ts.so")
 
 
-def build():
+def build(defines=("-DNNZ_CONV_TIMESTAMPS=1",), lib=TS_LIB):
+    """the product objects + csrc/conv_fprop.hip recompiled with `defines` -> `lib` (experiment builds; NNZ_HIP_LIBRARY=<lib> makes
+    any tool of the repo load it)"""
     from nnuzoo_amd import build as B
     B.build(verbose=False)
-    os.makedirs(TS_DIR, exist_ok=True)
-    obj = os.path.join(TS_DIR, "conv_fprop.o")
-    cmd = [B.HIPCC, *B._flags("conv_fprop.hip"), "-DNNZ_CONV_TIMESTAMPS=1", "-c", os.path.join(B.CSRC, "conv_fprop.hip"), "-o", obj]
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    obj = lib[:-3] + "_conv_fprop.o"
+    cmd = [B.HIPCC, *B._flags("conv_fprop.hip"), *defines, "-c", os.path.join(B.CSRC, "conv_fprop.hip"), "-o", obj]
     subprocess.run(cmd, check=True)
     objs = [os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B._sources() if s != "conv_fprop.hip"] + [obj]
-    subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TS_LIB, *objs], check=True)
-    print("built", TS_LIB)
+    subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
+    print("built", lib)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
+    ap.add_argument("--build-variant", default="", help="name=-DFLAG[,-DFLAG...]: tools/probes/_ts/libnnuzoo_hip_<name>.so with these defines")
     ap.add_argument("--only", default="")
     ap.add_argument("--tuning", default="")
     a = ap.parse_args()
+    if a.build_variant:
+        name, flags = a.build_variant.split("=", 1)
+        build(tuple(flags.split(",")), os.path.join(TS_DIR, f"libnnuzoo_hip_{name}.so"))
+        return
     if a.build:
         build()
         return
@@ -61,8 +69,8 @@ def main():
 
     def arm(on):
         lo, hi = (addr & 0xFFFFFFFF, addr >> 32) if on else (0, 0)
-        _lib.call("nnz_conv_tuning", 10, lo - (1 << 32) if lo >= (1 << 31) else lo)
-        _lib.call("nnz_conv_tuning", 11, hi)
+        _lib.call("nnz_conv_tuning", 12, lo - (1 << 32) if lo >= (1 << 31) else lo)
+        _lib.call("nnz_conv_tuning", 13, hi)
 
     names = {0: "entry->setup", 1: "setup->slice0 staged"}
     layers = [("enc0.1", 32, 32, 128, 1), ("dec0.0", 64, 32, 128, 1), ("enc1.1", 64, 64, 64, 1), ("dec1.0", 128, 64, 64, 1),
@@ -88,8 +96,11 @@ def main():
         sc = ops.NormScratch(dev, N * max(cin, cout))
         gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
         nstat = torch.empty(N, cout, 4, device=dev)
+        xstat = torch.randn(N, cin, 4, device=dev)
+        nred, dgam, dbet = torch.empty(N, cin, 2, device=dev), torch.empty(cin, device=dev), torch.empty(cin, device=dev)
         runs = {"fwd+innorm+stats": lambda: ops.conv_tap_forward_norm(pf, x, wf, None, y, sc, gamma, beta, 1e-5, nstat, innorm=inn),
                 "fwd plain": lambda: ops.conv_tap_forward(pf, x, wf, None, y),
+                "dgrad+normred": lambda: ops.conv_tap_dgrad_normred(pd, dy, wd, dx, x, cin, xstat, 0.01, sc, nred, dgam, dbet),
                 "dgrad plain": lambda: ops.conv_tap_forward(pd, dy, wd, None, dx)}
         for what, fn in runs.items():
             arm(False)
@@ -112,19 +123,28 @@ def main():
             live = t[:, 0] != 0
             t = t[live]
             nwg = len(t)
-            span = int(t[:, 14].max() - t[:, 0].min())
-            life = (t[:, 14] - t[:, 0]).astype(np.float64)
-            used = [s_ for s_ in range(16) if (t[:, s_] != 0).all()]
-            print(f"\n{name} {cin}->{cout} @{edge} s{stride}  {what}: {nwg} workgroups, wall {wall:.1f} us, launch span {span} ticks "
-                  f"-> {span / wall:.1f} ticks/us; mean workgroup lifetime {life.mean():.0f} ticks = {life.mean() / (span / wall):.2f} us, "
-                  f"rounds {nwg / 512:.1f} -> {nwg / 512 * life.mean() / (span / wall):.1f} us if perfectly packed")
+            life = (t[:, 14] - t[:, 0]).astype(np.float64)     # (the XCDs' counters are not synchronised: only differences
+            used = [s_ for s_ in range(15) if (t[:, s_] != 0).all()]   #  inside one workgroup mean anything)
+            used.sort(key=lambda s_: float((t[:, s_] - t[:, 0]).mean()))   # time order (slots 6..11 double as epilogue sub-phases)
+            print(f"\n{name} {cin}->{cout} @{edge} s{stride}  {what}: {nwg} workgroups, wall {wall:.1f} us, mean workgroup lifetime "
+                  f"{life.mean():.0f} ticks; {nwg / 512:.1f} rounds of 512 resident workgroups -> {wall / (nwg / 512) :.2f} us per round")
             prev = used[0]
             for s_ in used[1:]:
                 d = (t[:, s_] - t[:, prev]).astype(np.float64)
-                label = names.get(prev) or (f"slice {(prev - 2) // 2} MFMA loop" if 2 <= prev < 12 and prev % 2 == 0 else
-                                            f"slice {(s_ - 2) // 2} wait + stage" if s_ < 12 and s_ % 2 == 0 else
-                                            {12: "last loop -> acc in LDS", 13: "statistics", 14: "stores"}.get(s_, f"{prev}->{s_}"))
-                print(f"   {prev:2d}->{s_:2d}  {label:28s} mean {d.mean():9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}"
+                before_epilogue = 12 in used and used.index(s_) < used.index(12) and 9 not in used[:used.index(s_) + 1]
+                sub = {6: "stats: local sums", 7: "stats: lane fold + slab + barrier", 8: "stats: wave 0 fixed-point adds",
+                       9: "last loop -> layer-below loads issued", 10: "normred: local sums (+ stores)",
+                       11: "normred: lane fold + slab + barrier", 12: "last loop -> acc in LDS image", 13: "statistics / wave-0 adds",
+                       14: "stores / tail"}
+                if s_ == 1:
+                    label = "entry -> set-up done"
+                elif s_ == 2:
+                    label = "set-up -> slice 0 staged"
+                elif before_epilogue:
+                    label = f"slice {(s_ - 3) // 2} MFMA loop" if s_ % 2 == 1 else f"slice {(s_ - 2) // 2} wait + stage"
+                else:
+                    label = sub.get(s_, f"{prev}->{s_}")
+                print(f"   {prev:2d}->{s_:2d}  {label:38s} mean {d.mean():9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}"
                       f"   {100 * d.mean() / life.mean():5.1f} %")
                 prev = s_
 

@@ -1,0 +1,102 @@
+"""Where does a zoo step stop being bit-reproducible?  Two identical forward + backward passes (same seed for the stochastic-depth
+draws); every module output (forward order) and every gradient that reaches a module output (backward order) is reduced to an
+exact integer checksum; the first entries that differ between the two passes are printed with the entries before them.
+
+    python tools/probes/zoo_first_nondeterminism.py [--models SwT2Net,M2NetP] [--size 128]
+
+A gradient entry that differs while everything before it (in backward order) agrees means: the backward of a CONSUMER of that
+module's output is not deterministic.  Parameter gradients are compared at the end (they do not propagate)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+
+def checksum(t: torch.Tensor) -> int:
+    t = t.detach().contiguous()
+    if t.dtype in (torch.float16, torch.bfloat16):
+        return int(t.view(torch.int16).to(torch.int64).sum())
+    if t.dtype == torch.float32:
+        return int(t.view(torch.int32).to(torch.int64).sum())
+    return int(t.to(torch.int64).sum())
+
+
+def build(name):
+    from nnuzoo_amd.nets import m2net, swt2net, ssnd2net
+    if name == "SwT2Net":
+        return swt2net.SwT2Net(1, 2, True), False
+    if name == "M2NetP":
+        return m2net.M2NetP(1, 2, True), True
+    if name == "M2Net":
+        return m2net.M2Net(1, 2, True), True
+    if name.startswith("SSND2Net"):
+        return getattr(ssnd2net, name)(spatial_dims=2, factorization_type="cross-scan", in_ch=1, out_ch=2, deep_supervision=True,
+                                       input_patch_size=[128, 128]), True
+    raise SystemExit(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--models", default="SwT2Net,M2NetP")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--show", type=int, default=6)
+    a = ap.parse_args()
+    for name in a.models.split(","):
+        torch.manual_seed(0)
+        net, autocast = build(name)
+        net = net.cuda().train()
+        x = torch.randn(2, 1, a.size, a.size, device="cuda")
+        names = {m: n for n, m in net.named_modules()}
+        log = []
+
+        def fwd_hook(mod, inp, out):
+            outs = out if isinstance(out, (tuple, list)) else (out,)
+            for i, o in enumerate(outs):
+                if torch.is_tensor(o) and o.is_floating_point():
+                    tag = f"{names[mod]}[{type(mod).__name__}].out{i}"
+                    log.append(("F", tag, checksum(o)))
+                    if o.requires_grad:
+                        o.register_hook(lambda g, tag=tag: log.append(("B", tag, checksum(g))))
+
+        hs = [m.register_forward_hook(fwd_hook) for m in net.modules()]
+        runs, grads = [], []
+        for rep in range(2):
+            log.clear()
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+                outs = net(x)
+            sum((o.float() ** 2).mean() for o in outs).backward()
+            torch.cuda.synchronize()
+            runs.append(list(log))
+            grads.append({n: checksum(p.grad) for n, p in net.named_parameters() if p.grad is not None})
+        for h in hs:
+            h.remove()
+        r0, r1 = runs
+        print(f"== {name}: {len(r0)} / {len(r1)} entries; forward {sum(e[0] == 'F' for e in r0)}, backward {sum(e[0] == 'B' for e in r0)}")
+        if [e[:2] for e in r0] != [e[:2] for e in r1]:
+            print("   the two passes did not visit the same sequence")
+        bad = [i for i, (p, q) in enumerate(zip(r0, r1)) if p != q]
+        print(f"   entries that differ: {len(bad)} (forward {sum(r0[i][0] == 'F' for i in bad)}, backward {sum(r0[i][0] == 'B' for i in bad)})")
+        shown = 0
+        last = -10
+        for i in bad:
+            if i - last > 1 and shown < a.show:     # start of a run of differing entries
+                for j in range(max(0, i - 3), i):
+                    print(f"      ok   {j:6d} {r0[j][0]} {r0[j][1]}")
+                print(f"      DIFF {i:6d} {r0[i][0]} {r0[i][1]}")
+                shown += 1
+            last = i
+        pbad = [n for n in grads[0] if grads[0][n] != grads[1][n]]
+        fam = {}
+        for n in pbad:
+            k = ".".join(n.split(".")[-2:])
+            fam[k] = fam.get(k, 0) + 1
+        print(f"   parameter gradients that differ: {len(pbad)} of {len(grads[0])}: " +
+              ", ".join(f"{k} x{v}" for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:12]))
+
+
+if __name__ == "__main__":
+    main()
