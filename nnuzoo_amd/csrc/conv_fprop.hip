@@ -84,6 +84,7 @@ struct ConvDev {
   // ceil(2^32 / d) of the divisors of the workgroup-index decode (launcher): q = umulhi(n, m) is exact while n * d < 2^32
   unsigned mg_gy, mg_gxw, mg_nsplit, mg_ngroups, mg_t2, mg_t1;
   unsigned in_bytes, w_bytes, bx_bytes;  // extents of `in` / `w` / `bx` for the buffer descriptors of the staging loads (launcher; < 2^32 - 16)
+  int mfma_moments;  // knob 11: forward statistics of full tiles on the matrix cores
   int sep_finish;  // knob 10: no ticket in the epilogue, conv_stats_finish_kernel / conv_normred_finish_kernel follow the launch
   int dbg;  // nnz_conv_tuning(6, bits): epilogue experiments (tools/probes/normred_epilogue_probe.py); 0 in production
   // split-K over the 16-channel slices of the reduction (the <= 8^3 levels: 10-40 workgroups each walking 20-40 slices of
@@ -182,6 +183,8 @@ struct ConvCfg {
 //      kernel (1) instead of by the launch's last workgroup behind a ticket (0)                                       (default 1:
 //      tools/probes/conv_phase_probe.py - wave 0 of EVERY workgroup sat ~10 000 cycles, a quarter of a 2-slice workgroup's
 //      lifetime, in the two dependent memory round trips of the protocol: adds acknowledged, ticket returned)
+//  11  InstanceNorm statistics of the forward epilogue: tiles inside the volume form their moments with MFMAs (1) / VALU sums and
+//      lane shuffles everywhere (0)                                                                                    (default 1)
 //  12, 13  -DNNZ_CONV_TIMESTAMPS builds only: low / high half of the timestamp buffer's address
 #ifndef NNZ_DRE_PERSIST
 #define NNZ_DRE_PERSIST false
@@ -189,7 +192,7 @@ struct ConvCfg {
 #ifndef NNZ_S2_PERSIST
 #define NNZ_S2_PERSIST false
 #endif
-static int g_tuning[16] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 1, 0, 0, 0, 0, 0};
+static int g_tuning[16] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 1, 1, 0, 0, 0, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
@@ -899,6 +902,54 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     constexpr int NC = NB * 32, NVOX = TD * TH * TW;
     constexpr int PARTS = 256 / PPV;
     float* slab = reinterpret_cast<float*>(smem + NVOX * ROWB);
+    const bool full_tile = m0d + TD <= mD0 && m0h + TH <= mD1 && m0w + TW <= mD2;
+    if (full_tile && p.mfma_moments) {
+      // Tiles inside the volume (all but the last ones of an axis): the moments on the matrix cores.  A wave takes NVOX / 4
+      // voxels in 16-voxel steps; the transposed LDS read (ds_read_b64_tr_b16, as in conv_wgrad.hip) delivers the image as an
+      // MFMA fragment F[channel][voxel] - the same registers serve as A and as B operand - the pilot is subtracted in packed
+      // fp16 (d = x - K; rounds only when |d| needs more than 11 bits, far below what the statistics resolve), and
+      //   D2 = F F^T (diagonal: sum d^2)      D1 = F 1 (any column: sum d)
+      // accumulate in fp32 in the MFMA's fixed order.  16 transposed reads + 32 packed subtractions + 16 MFMAs per wave replace
+      // ~360 VALU instructions of convert / subtract / add / FMA per thread and the 64-shuffle lane fold
+      // (tools/probes/conv_phase_probe.py: 4 600 + 2 300 cycles per workgroup).  Channel c's two sums sit in lane (c, hh =
+      // (c >> 2) & 1), accumulator register (c & 3) + 4 (c >> 3).
+      constexpr int KB_W = NVOX / 64;   // 16-voxel steps per wave
+      static_assert(NVOX % 64 == 0, "voxel steps must split over the four waves");
+      const int qrow = (lane & 15) >> 2;
+      const int chan_byte = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+      const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const f16 kh = *reinterpret_cast<const f16*>(smem + (nb * 32 + l31) * 2);   // pilot of the lane's channel
+        const nnz_h2 k2 = {kh, kh};
+        f32x16 d1, d2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[r] = d2[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB_W; ++kb) {
+          const int v0 = (wave * KB_W + kb) * 16 + 8 * hh;
+          const char* src = smem + (v0 + qrow) * ROWB + nb * 64 + chan_byte;
+          union { i16x4 v[2]; nnz_h2 h[4]; f16x8 f; } u;
+          u.v[0] = lds_read_tr16(src);
+          u.v[1] = lds_read_tr16(src + 4 * ROWB);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) u.h[q] = u.h[q] - k2;
+          d2 = mfma32(u.f, u.f, d2);
+          d1 = mfma32(u.f, ones, d1);
+        }
+        const int rsel = (l31 & 3) + 4 * (l31 >> 3);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r == rsel) {
+            s1 = d1[r];
+            s2 = d2[r];
+          }
+        if (hh == ((l31 >> 2) & 1))
+          *reinterpret_cast<f32x2*>(slab + wave * (2 * NC) + (nb * 32 + l31) * 2) = f32x2{s1, s2};
+      }
+      NNZ_TS(6);
+    } else {
     const int part = tid / PPV, c8 = tid % PPV;
     float K[8], s1[8], s2[8];
     {
@@ -942,6 +993,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         slab[wave * (2 * NC) + (lane * 8 + e) * 2 + 1] = s2[e];
       }
     }
+    }   // VALU path
     __syncthreads();
     NNZ_TS(7);
     if (wave == 0) {
@@ -1241,6 +1293,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
   }
   const unsigned nwg = (unsigned)(p.gx / p.tiles_per_wg) * p.gy * p.gz;
   p.sep_finish = g_tuning[10] && p.acc && p.nsplit <= 1;
+  p.mfma_moments = g_tuning[11];
   {
     auto magic = [](int d) -> unsigned { return d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u; };
     const int gxw = p.gx / p.tiles_per_wg;

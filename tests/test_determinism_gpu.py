@@ -85,9 +85,21 @@ def test_stats_kernel_large_mean(hip_lib, ratio, N, V, C):
 @pytest.mark.parametrize("dims,cin,cout,stride", [((16, 16, 16), 32, 32, 1), ((64, 64, 64), 32, 32, 1),
                                                    ((16, 24, 8), 64, 64, 1), ((16, 16, 16), 32, 64, 2),
                                                    ((1, 64, 48), 32, 32, 1), ((12, 20, 28), 32, 64, 1)])
-def test_conv_epilogue_table_large_mean(hip_lib, dims, cin, cout, stride):
+@pytest.mark.parametrize("mfma_moments", [1, 0])
+def test_conv_epilogue_table_large_mean(hip_lib, dims, cin, cout, stride, mfma_moments):
     """the forward convolution's own statistics (all tile shapes incl. ragged edges and the depth-reuse loop) with a bias
-    that puts |mean| at 20 ... 200 std: table vs float64 on the stored fp16 outputs; outputs identical to the plain launch"""
+    that puts |mean| at 20 ... 200 std: table vs float64 on the stored fp16 outputs; outputs identical to the plain launch.
+    Both forms of the tile moments: on the matrix cores for tiles inside the volume (nnz_conv_tuning knob 11, the default) and the
+    VALU sums everywhere."""
+    from nnuzoo_amd import _lib
+    _lib.call("nnz_conv_tuning", 11, mfma_moments)
+    try:
+        _conv_epilogue_table_large_mean(dims, cin, cout, stride)
+    finally:
+        _lib.call("nnz_conv_tuning", 11, 1)
+
+
+def _conv_epilogue_table_large_mean(dims, cin, cout, stride):
     N = 2
     g = torch.Generator().manual_seed(sum(dims) + cout)
     x = torch.randn(N, int(np.prod(dims)), cin, generator=g).to(torch.float16).to(DEV)
