@@ -241,6 +241,12 @@ int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const float* du, 
                               long L, int cp, void* stream);
 int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L, int cp,
                               void* stream);
+/* Two-stage (bit-reproducible) forms of the weight gradients whose token range is spread over many workgroups: every workgroup
+ * stores its partial block into `workspace` (nnz_*_workspace_floats) and a second kernel folds the blocks in a fixed order;
+ * the gradient is WRITTEN (no pre-zeroing).  The plain entry points add with fp32 atomics (arrival order in the low bits). */
+long nnz_ss2d_xproj_backward_w_workspace_floats(int B, int Di, int C2, long L);
+int nnz_ss2d_xproj_backward_w_ws(const float* dP, const float* x2, float* dW, float* workspace, long ws_floats, int B,
+                                 int Di, int C2, long L, int cp, void* stream);
 
 /* ---- token-major Linear layers with many tokens and few features (VSS / SSND in_proj, out_proj, patch merge / expand:
  * /root/reference/nnunetv2/nets/m2net.py:97,103,258,300) under the autocast step: fp16 activations, fp32 master weight
@@ -255,6 +261,10 @@ int nnz_token_linear_forward(const void* in_f16, const float* W, const float* bi
 int nnz_token_linear_supported(int Kr, int Mo);
 int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, float* dW, float* db, long T, int N, int K,
                            void* stream);
+/* two-stage (bit-reproducible) form: dW / db are written from per-workgroup partial blocks folded in a fixed order */
+long nnz_token_linear_wgrad_workspace_floats(long T, int N, int K);
+int nnz_token_linear_wgrad_ws(const void* dy_f16, const void* x_f16, float* dW, float* db, float* workspace,
+                              long ws_floats, long T, int N, int K, void* stream);
 
 /* ---- fp32 token-major Linear layers on v_mfma_f32_32x32x2_f32 (csrc/dense32.hip, round 3) -----------------------------
  * The Swin / ViT trainers run without autocast (nnunetv2/training/nnUNetTrainer/nnUNetTrainerSwT2Net.py:112-130): qkv /
@@ -346,6 +356,11 @@ int nnz_ss2d_dwconv_silu_forward(const void* x_tokens, int x_is_f16, long x_row_
 int nnz_ss2d_dwconv_silu_backward(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
                                   const float* bias, const float* dx2, void* dx_tokens, float* dweight, float* dbias,
                                   int Bt, int D, int H, int W, void* stream);
+/* two-stage (bit-reproducible) weight / bias gradient: per-tile partial rows in `workspace`, fixed-order fold */
+long nnz_ss2d_dwconv_silu_backward_workspace_floats(int Bt, int D, int H, int W);
+int nnz_ss2d_dwconv_silu_backward_ws(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
+                                     const float* bias, const float* dx2, void* dx_tokens, float* dweight, float* dbias,
+                                     float* workspace, long ws_floats, int Bt, int D, int H, int W, void* stream);
 long nnz_ss2d_scan_state_floats(int Bt, int Dg, int L);
 long nnz_ss2d_scan_grad_state_floats(int Bt, int Dg, int L);
 long nnz_ss2d_scan_workspace_floats(int Bt, int Dg, int L);

@@ -119,6 +119,8 @@ SIGNATURES = {
     "nnz_ss2d_xproj_forward": [_fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
     "nnz_ss2d_xproj_backward_x": [_fp, _fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
     "nnz_ss2d_xproj_backward_w": [_fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
+    "nnz_ss2d_xproj_backward_w_ws": [_fp, _fp, _fp, _fp, _l, _i, _i, _i, _l, _i, _vp],
+    "nnz_ss2d_xproj_backward_w_workspace_floats": [_i, _i, _i, _l],
     "nnz_token_linear_forward": [_vp, _fp, _fp, _vp, _l, _i, _i, _i, _vp],
     "nnz_token_linear_supported": [_i, _i],
     "nnz_dense32_forward": [_fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp],
@@ -131,6 +133,8 @@ SIGNATURES = {
     "nnz_dense32_group_class": [_l, _i, _i],
     "nnz_dense32_group_launch": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp],
     "nnz_token_linear_wgrad": [_vp, _vp, _fp, _fp, _l, _i, _i, _vp],
+    "nnz_token_linear_wgrad_ws": [_vp, _vp, _fp, _fp, _fp, _l, _l, _i, _i, _vp],
+    "nnz_token_linear_wgrad_workspace_floats": [_l, _i, _i],
     "nnz_sgd_chunk_bytes": [],
     "nnz_sgd_chunk_fill": [_vp, _vp, _vp, _l, _i],
     "nnz_grad_sumsq_nonfinite": [_fp, _l, _fp, _vp],
@@ -145,6 +149,8 @@ SIGNATURES = {
     "nnz_ss2d_merge_dx": [_fp, _fp, _vp, _i, _i, _i, _i, _i, _vp],
     "nnz_ss2d_dwconv_silu_forward": [_vp, _i, _l, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
     "nnz_ss2d_dwconv_silu_backward": [_vp, _i, _l, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp],
+    "nnz_ss2d_dwconv_silu_backward_ws": [_vp, _i, _l, _fp, _fp, _fp, _vp, _fp, _fp, _fp, _l, _i, _i, _i, _i, _vp],
+    "nnz_ss2d_dwconv_silu_backward_workspace_floats": [_i, _i, _i, _i],
     "nnz_ss2d_scan_state_floats": [_i, _i, _i],
     "nnz_ss2d_scan_grad_state_floats": [_i, _i, _i],
     "nnz_ss2d_scan_workspace_floats": [_i, _i, _i],
@@ -192,7 +198,8 @@ SIGNATURES = {
 _LONG_RESULT = {"nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats", "nnz_ss2d_scan_workspace_floats",
                 "nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats",
                 "nnz_selective_scan_grad_state_floats", "nnz_dwconv2d_wgrad_workspace_floats", "nnz_conv_tap_wgrad_workspace_floats",
-                "nnz_dense32_wgrad_workspace_floats"}
+                "nnz_dense32_wgrad_workspace_floats", "nnz_token_linear_wgrad_workspace_floats",
+                "nnz_ss2d_xproj_backward_w_workspace_floats", "nnz_ss2d_dwconv_silu_backward_workspace_floats"}
 _lib = None
 
 

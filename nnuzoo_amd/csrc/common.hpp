@@ -287,6 +287,52 @@ inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Deterministic second stage of a cross-workgroup sum: out[e] = sum_p part[p * stride + e], p = 0 .. nparts - 1 in a FIXED
+// grouping (thread = (element, every 4th partial of its range), the four sums folded as (g0 + g1) + (g2 + g3)) - the form the
+// convolution weight gradients use (conv_wgrad.hip wgrad_reduce_kernel).  The first stage stores each workgroup's partial with
+// plain stores; nothing needs zero-filling and no float atomics are involved, so the result is bit-identical from run to run.
+// Grid row y folds partials [y * per, (y + 1) * per) into out + y * E: many partials of few elements (a per-channel sum over a
+// thousand tiles) go through two levels - fold_partials() does that when the caller's workspace has room behind the partials.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int nparts, long stride, long E,
+                                                            float* __restrict__ out, int per) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x;
+  const int el = tid & 63, sg = tid >> 6;
+  const long e = (long)blockIdx.x * 64 + el;
+  const int p0 = blockIdx.y * per;
+  const int p1 = p0 + per < nparts ? p0 + per : nparts;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < E) {
+    int q = p0 + sg;
+    for (; q + 4 < p1; q += 8) {  // two loads in flight
+      s0 += part[(size_t)q * stride + e];
+      s1 += part[(size_t)(q + 4) * stride + e];
+    }
+    if (q < p1) s0 += part[(size_t)q * stride + e];
+  }
+  red[sg][el] = s0 + s1;
+  __syncthreads();
+  if (sg == 0 && e < E) out[(size_t)blockIdx.y * E + e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+}
+constexpr int FOLD_GROUPS = 32;   // first-level groups of the two-level fold
+// floats of scratch the two-level fold wants behind the partials (0: one level)
+inline long fold_partials_scratch_floats(int nparts, long E) { return nparts > 8 * FOLD_GROUPS ? (long)FOLD_GROUPS * E : 0; }
+inline hipError_t fold_partials(const float* part, int nparts, long stride, long E, float* out, hipStream_t s,
+                                float* scratch = nullptr) {
+  if (E <= 0) return hipSuccess;
+  const unsigned gx = (unsigned)((E + 63) / 64);
+  if (scratch && nparts > 8 * FOLD_GROUPS) {
+    const int per = (nparts + FOLD_GROUPS - 1) / FOLD_GROUPS;
+    const int groups = (nparts + per - 1) / per;
+    NNZ_LAUNCH(fold_partials_kernel<0>, dim3(gx, groups), dim3(256), 0, s, part, nparts, stride, E, scratch, per);
+    NNZ_LAUNCH(fold_partials_kernel<0>, dim3(gx, 1), dim3(256), 0, s, (const float*)scratch, groups, E, E, out, groups);
+  } else {
+    NNZ_LAUNCH(fold_partials_kernel<0>, dim3(gx, 1), dim3(256), 0, s, part, nparts, stride, E, out, nparts);
+  }
+  return hipGetLastError();
+}
+
 // Dynamic-LDS opt-in above 64 KB (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE function attribute.  One
 // cache per kernel instantiation remembers the largest size registered on each device; atomics make concurrent host
 // threads safe (the worst case is a redundant, idempotent hipFuncSetAttribute call).

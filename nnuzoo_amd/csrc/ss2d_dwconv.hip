@@ -25,6 +25,7 @@ struct DwArgs {
   long x_stride;
   int x_is_f16;
   int B, D, H, W;
+  float* part;        // null, or [B * tiles][D * 10]: two-stage (deterministic) weight / bias gradient
 };
 
 __device__ __forceinline__ float dw_load(const DwArgs& a, long off) {
@@ -166,8 +167,14 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(DwArgs a) {
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += red[r][dd][t];
     if (d0 + dd < a.D) {
-      if (t < 9) atomicAdd(a.dw + (long)(d0 + dd) * 9 + t, s);
-      else if (a.dbias) atomicAdd(a.dbias + d0 + dd, s);
+      if (a.part) {   // two-stage mode: row (sample, tile) of the workspace, layout [D * 9 weights | D biases]
+        float* prow = a.part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * ((size_t)a.D * 10);
+        prow[t < 9 ? (long)(d0 + dd) * 9 + t : (long)a.D * 9 + d0 + dd] = s;
+      } else if (t < 9) {
+        atomicAdd(a.dw + (long)(d0 + dd) * 9 + t, s);
+      } else if (a.dbias) {
+        atomicAdd(a.dbias + d0 + dd, s);
+      }
     }
   }
 }
@@ -188,16 +195,20 @@ extern "C" int nnz_ss2d_dwconv_silu_forward(const void* x_tokens, int x_is_f16, 
   return NNZ_OK;
 }
 
-extern "C" int nnz_ss2d_dwconv_silu_backward(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
-                                             const float* bias, const float* dx2, void* dx_tokens, float* dweight,
-                                             float* dbias, int Bt, int D, int H, int W, void* stream) {
+static int dw_bwd_impl(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight, const float* bias,
+                       const float* dx2, void* dx_tokens, float* dweight, float* dbias, float* workspace, long ws_floats,
+                       int Bt, int D, int H, int W, void* stream) {
   using namespace nnz;
   if (!x_tokens || !weight || !dx2 || !dx_tokens || !dweight || Bt < 1 || D < 1 || H < 1 || W < 1 || Bt > 65535 ||
       (D + DC - 1) / DC > 65535)
     return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
-  if (dbias == dweight + (long)D * 9) {  // one buffer [D*9 + D]: one launch
+  dim3 grid(((H + DT - 1) / DT) * ((W + DT - 1) / DT), (D + DC - 1) / DC, Bt);
+  const long nparts = (long)grid.x * Bt;
+  if (workspace) {
+    if (ws_floats < nparts * (long)D * 10 + fold_partials_scratch_floats((int)nparts, (long)D * 10)) return NNZ_EINVAL;
+  } else if (dbias == dweight + (long)D * 9) {  // one buffer [D*9 + D]: one launch
     if ((e = zero_async(dweight, sizeof(float) * D * 10, s)) != hipSuccess) return (int)e;
   } else {
     if ((e = zero_async(dweight, sizeof(float) * D * 9, s)) != hipSuccess) return (int)e;
@@ -205,10 +216,40 @@ extern "C" int nnz_ss2d_dwconv_silu_backward(const void* x_tokens, int x_is_f16,
   }
   DwArgs a = {};
   a.x = x_tokens; a.x_is_f16 = x_is_f16; a.x_stride = x_row_stride; a.w = weight; a.bias = bias; a.dx2 = dx2;
-  a.dx = dx_tokens; a.dw = dweight; a.dbias = dbias;
+  a.dx = dx_tokens; a.dw = dweight; a.dbias = dbias; a.part = workspace;
   a.B = Bt; a.D = D; a.H = H; a.W = W;
-  dim3 grid(((H + DT - 1) / DT) * ((W + DT - 1) / DT), (D + DC - 1) / DC, Bt);
   NNZ_LAUNCH(dwconv_silu_bwd_kernel, grid, dim3(256), 0, s, a);
+  if (workspace) {
+    const long row = (long)D * 10;
+    float* scratch = fold_partials_scratch_floats((int)nparts, row) ? workspace + nparts * row : nullptr;
+    if ((e = fold_partials(workspace, (int)nparts, row, (long)D * 9, dweight, s, scratch)) != hipSuccess) return (int)e;
+    if (dbias && (e = fold_partials(workspace + (long)D * 9, (int)nparts, row, D, dbias, s, scratch)) != hipSuccess)
+      return (int)e;
+  }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+
+// weight / bias gradient: nnz_ss2d_dwconv_silu_backward zero-fills dweight / dbias and the tiles add with fp32 atomics;
+// nnz_ss2d_dwconv_silu_backward_ws WRITES them from per-tile partial rows in `workspace`
+// (nnz_ss2d_dwconv_silu_backward_workspace_floats) folded in a fixed order: bit-reproducible.
+extern "C" long nnz_ss2d_dwconv_silu_backward_workspace_floats(int Bt, int D, int H, int W) {
+  using namespace nnz;
+  if (Bt < 1 || D < 1 || H < 1 || W < 1) return 0;
+  const long nparts = (long)((H + DT - 1) / DT) * ((W + DT - 1) / DT) * Bt;
+  return nparts * (long)D * 10 + fold_partials_scratch_floats((int)nparts, (long)D * 10);
+}
+extern "C" int nnz_ss2d_dwconv_silu_backward(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
+                                             const float* bias, const float* dx2, void* dx_tokens, float* dweight,
+                                             float* dbias, int Bt, int D, int H, int W, void* stream) {
+  return dw_bwd_impl(x_tokens, x_is_f16, x_row_stride, weight, bias, dx2, dx_tokens, dweight, dbias, nullptr, 0, Bt, D, H, W,
+                     stream);
+}
+extern "C" int nnz_ss2d_dwconv_silu_backward_ws(const void* x_tokens, int x_is_f16, long x_row_stride, const float* weight,
+                                                const float* bias, const float* dx2, void* dx_tokens, float* dweight,
+                                                float* dbias, float* workspace, long ws_floats, int Bt, int D, int H, int W,
+                                                void* stream) {
+  if (!workspace) return NNZ_EINVAL;
+  return dw_bwd_impl(x_tokens, x_is_f16, x_row_stride, weight, bias, dx2, dx_tokens, dweight, dbias, workspace, ws_floats, Bt,
+                     D, H, W, stream);
 }

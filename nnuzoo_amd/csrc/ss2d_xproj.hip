@@ -36,6 +36,7 @@ struct XpArgs {
   // [j Cp, (j + 1) Cp) of source s's stacked matrix, C2 = 2 Cp) - no stacked copy of the weight per call, no un-stacking
   // copy of its gradient; Cp == 0: W / dW are [2][C2][Di]
   int Cp;
+  float* part;       // null, or [workgroups along x][2 * C2 * Di]: two-stage (deterministic) weight gradient
 };
 
 // row c2 of source s's projection matrix
@@ -199,7 +200,9 @@ __global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) {
   for (int e = tid; e < a.C2 * a.Di; e += 256) {
     float v = 0.f;
     for (int q = 0; q < TSL; ++q) v += sred[(long)q * C2p * a.Di + e];
-    atomicAdd(a.dW + xp_row(a, s, e / a.Di) + e % a.Di, v);
+    const long o = xp_row(a, s, e / a.Di) + e % a.Di;
+    if (a.part) a.part[(size_t)blockIdx.x * 2 * a.C2 * a.Di + o] = v;   // plain store; nnz::fold_partials sums the rows in order
+    else atomicAdd(a.dW + o, v);
   }
 }
 
@@ -247,10 +250,21 @@ extern "C" int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const 
   return NNZ_OK;
 }
 
-// dW[2][C2][Di] (pre-zeroed, fp32) += per-source token contraction.  Needs L % 64 == 0 and (ceil8(C2)/8)(Di/8) <= 256;
-// returns -22 otherwise (the caller keeps the library path for those shapes).
-extern "C" int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L,
-                                         int cp, void* stream) {
+// dW[2][C2][Di] += per-source token contraction.  Needs L % 64 == 0 and (ceil8(C2)/8)(Di/8) <= 256; returns -22 otherwise (the
+// caller keeps the library path for those shapes).  nnz_ss2d_xproj_backward_w: dW pre-zeroed, fp32 atomics over the token
+// ranges; nnz_ss2d_xproj_backward_w_ws: dW is WRITTEN - one partial matrix per workgroup in `workspace`
+// (nnz_ss2d_xproj_backward_w_workspace_floats) + a fixed-order fold: bit-reproducible.
+static long xp_bwd_w_tokens_per_wg(long T) {
+  long tpw = (T + 255) / 256;                              // ~256 workgroups per source (512 in all)
+  return (tpw + nnz::XPW_TOK - 1) / nnz::XPW_TOK * nnz::XPW_TOK;
+}
+extern "C" long nnz_ss2d_xproj_backward_w_workspace_floats(int B, int Di, int C2, long L) {
+  if (B < 1 || L < 1) return 0;
+  const long T = (long)B * L, tpw = xp_bwd_w_tokens_per_wg(T);
+  return ((T + tpw - 1) / tpw) * 2L * C2 * Di;
+}
+static int xp_bwd_w_impl(const float* dP, const float* x2, float* dW, float* workspace, long ws_floats, int B, int Di, int C2,
+                         long L, int cp, void* stream) {
   using namespace nnz;
   if (!dP || !x2 || !dW || !xp_shape_ok(B, Di, C2, L) || (L % XPW_TOK) || cp < 0 || (cp > 0 && 2 * cp != C2))
     return NNZ_EINVAL;
@@ -261,16 +275,32 @@ extern "C" int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float
   XpArgs a = {};
   a.dP = dP; a.x2 = x2; a.dW = dW; a.B = B; a.Di = Di; a.C2 = C2; a.L = L; a.Cp = cp;
   const long T = (long)B * L;
-  long tpw = (T + 255) / 256;                              // ~256 workgroups per source (512 in all)
-  tpw = (tpw + XPW_TOK - 1) / XPW_TOK * XPW_TOK;
+  const long tpw = xp_bwd_w_tokens_per_wg(T);
   a.tokens_per_wg = tpw;
   const long wgs = (T + tpw - 1) / tpw;
+  if (workspace) {
+    if (ws_floats < wgs * 2L * C2 * Di) return NNZ_EINVAL;
+    a.part = workspace;
+  }
   const size_t lds = sizeof(float) * ((size_t)(C2p + Di) * XPW_TOK + (size_t)TSL * C2p * Di);
   if (lds > 160 * 1024) return NNZ_EINVAL;
   static DynLdsCache cache;
   hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(xproj_bwd_w_kernel), (int)lds, cache);
   if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH(xproj_bwd_w_kernel, dim3((unsigned)wgs, 2), dim3(256), lds, (hipStream_t)stream, a);
+  if (workspace) {
+    e = fold_partials(workspace, (int)wgs, 2L * C2 * Di, 2L * C2 * Di, dW, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+extern "C" int nnz_ss2d_xproj_backward_w(const float* dP, const float* x2, float* dW, int B, int Di, int C2, long L,
+                                         int cp, void* stream) {
+  return xp_bwd_w_impl(dP, x2, dW, nullptr, 0, B, Di, C2, L, cp, stream);
+}
+extern "C" int nnz_ss2d_xproj_backward_w_ws(const float* dP, const float* x2, float* dW, float* workspace, long ws_floats,
+                                            int B, int Di, int C2, long L, int cp, void* stream) {
+  if (!workspace) return NNZ_EINVAL;
+  return xp_bwd_w_impl(dP, x2, dW, workspace, ws_floats, B, Di, C2, L, cp, stream);
 }

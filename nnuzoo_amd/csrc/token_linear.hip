@@ -169,6 +169,7 @@ struct TlWgArgs {
   long T;
   int N, K;
   long tokens_per_wg;
+  float* part;    // null, or [workgroups][N * K + N]: two-stage (deterministic) mode
 };
 
 // thread = (token slice ts, 8x8 block of dW); TSL token slices of the workgroup run in parallel over its token range and
@@ -238,16 +239,21 @@ __global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) {
       for (int i = 0; i < 8; ++i) sred[(long)TSL * N * K + ts * N + n0 + i] = accb[i];
   }
   __syncthreads();
+  // a.part (nnz_token_linear_wgrad_ws): the workgroup's sums go to its own row of the workspace with plain stores and a second
+  // kernel folds the rows in a fixed order - bit-reproducible; otherwise one fp32 atomic per entry into the pre-zeroed dW / db
+  float* prow = a.part ? a.part + (size_t)blockIdx.x * ((size_t)N * K + N) : nullptr;
   for (int e = tid; e < N * K; e += 256) {
     float v = 0.f;
     for (int s_ = 0; s_ < TSL; ++s_) v += sred[(long)s_ * N * K + e];
-    atomicAdd(a.dW + e, v);
+    if (prow) prow[e] = v;
+    else atomicAdd(a.dW + e, v);
   }
-  if (a.db)
+  if (a.db || prow)
     for (int e = tid; e < N; e += 256) {
       float v = 0.f;
       for (int s_ = 0; s_ < TSL; ++s_) v += sred[(long)TSL * N * K + s_ * N + e];
-      atomicAdd(a.db + e, v);
+      if (prow) prow[(size_t)N * K + e] = v;
+      else atomicAdd(a.db + e, v);
     }
 }
 
@@ -288,10 +294,24 @@ extern "C" int nnz_token_linear_supported(int Kr, int Mo) {
   return 1;
 }
 
-// dW[N][K] += sum_t dy[t][n] x[t][k];  db[n] += sum_t dy[t][n]  (dW / db pre-zeroed fp32; N, K multiples of 8,
-// (N/8)(K/8) <= 256)
-extern "C" int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, float* dW, float* db, long T, int N, int K,
-                                      void* stream) {
+// dW[N][K] += sum_t dy[t][n] x[t][k];  db[n] += sum_t dy[t][n]  (N, K multiples of 8, (N/8)(K/8) <= 256).
+// nnz_token_linear_wgrad: dW / db pre-zeroed fp32, workgroups add with fp32 atomics (the sum's low bits depend on arrival order).
+// nnz_token_linear_wgrad_ws: dW / db are WRITTEN (no pre-zeroing); `workspace` of nnz_token_linear_wgrad_workspace_floats(T, N, K)
+// floats receives one partial block per workgroup and a second kernel folds them in a fixed order: bit-reproducible.
+static long tl_wgrad_tokens_per_wg(long T) {
+  // ~512 workgroups (two per CU) whatever T is: the low-resolution levels have few tokens but large N x K, and a
+  // workgroup's serial loop is tokens x 64 FMAs per thread (the first version fixed 2048 tokens per workgroup: 16
+  // workgroups and 280 us for T = 32 768, N K = 16 384).
+  long tpw = (T + 511) / 512;
+  return (tpw + nnz::TLW_TOK - 1) / nnz::TLW_TOK * nnz::TLW_TOK;
+}
+extern "C" long nnz_token_linear_wgrad_workspace_floats(long T, int N, int K) {
+  if (T < 1 || N < 8 || K < 8) return 0;
+  const long tpw = tl_wgrad_tokens_per_wg(T);
+  return ((T + tpw - 1) / tpw) * ((long)N * K + N);
+}
+static int tl_wgrad_impl(const void* dy_f16, const void* x_f16, float* dW, float* db, float* workspace, long ws_floats,
+                         long T, int N, int K, void* stream) {
   using namespace nnz;
   if (!dy_f16 || !x_f16 || !dW || T < 1 || (N & 7) || (K & 7) || N < 8 || K < 8) return NNZ_EINVAL;
   const int nbk = (N >> 3) * (K >> 3);
@@ -300,19 +320,37 @@ extern "C" int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, flo
   TlWgArgs a = {};
   a.dy = (const f16*)dy_f16; a.x = (const f16*)x_f16; a.dW = dW; a.db = db;
   a.T = T; a.N = N; a.K = K;
-  // ~512 workgroups (two per CU) whatever T is: the low-resolution levels have few tokens but large N x K, and a
-  // workgroup's serial loop is tokens x 64 FMAs per thread (the first version fixed 2048 tokens per workgroup: 16
-  // workgroups and 280 us for T = 32 768, N K = 16 384).  One fp32 atomic per entry and workgroup: <= 8 M per call.
-  long tpw = (T + 511) / 512;
-  tpw = (tpw + TLW_TOK - 1) / TLW_TOK * TLW_TOK;
+  const long tpw = tl_wgrad_tokens_per_wg(T);
   a.tokens_per_wg = tpw;
   long wgs = (T + tpw - 1) / tpw;
+  if (workspace) {
+    if (ws_floats < wgs * ((long)N * K + N)) return NNZ_EINVAL;
+    a.part = workspace;
+  }
   const size_t lds = (size_t)TLW_TOK * (N + K) * 2 + (size_t)TSL * (N * K + N) * 4;
   if (lds > 160 * 1024) return NNZ_EINVAL;
   static DynLdsCache cache;
   hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(tl_wgrad_kernel), (int)lds, cache);
   if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH(tl_wgrad_kernel, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream, a);
+  if (workspace) {
+    const long row = (long)N * K + N;
+    e = fold_partials(workspace, (int)wgs, row, (long)N * K, dW, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (db) {
+      e = fold_partials(workspace + (size_t)N * K, (int)wgs, row, N, db, (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+extern "C" int nnz_token_linear_wgrad(const void* dy_f16, const void* x_f16, float* dW, float* db, long T, int N, int K,
+                                      void* stream) {
+  return tl_wgrad_impl(dy_f16, x_f16, dW, db, nullptr, 0, T, N, K, stream);
+}
+extern "C" int nnz_token_linear_wgrad_ws(const void* dy_f16, const void* x_f16, float* dW, float* db, float* workspace,
+                                         long ws_floats, long T, int N, int K, void* stream) {
+  if (!workspace) return NNZ_EINVAL;
+  return tl_wgrad_impl(dy_f16, x_f16, dW, db, workspace, ws_floats, T, N, K, stream);
 }

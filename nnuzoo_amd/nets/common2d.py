@@ -133,10 +133,13 @@ class _DepthwiseNativeFn(torch.autograd.Function):
             dw32, db32, ws = buf[:C * 9], buf[C * 9:C * 10], buf[C * 10:]
             call("nnz_dwconv2d_wgrad", ptr(x), ptr(dy), int(x.dtype == torch.float16), ptr(ws), ptr(dw32),
                  ptr(db32) if need_b else None, B, C, H, W, int(dilation[0]), stream_ptr())
+            if w.dtype != torch.float32:   # fp16 parameter shadow (param_shadow.py): ONE cast launch for weight + bias gradient
+                lo = buf[:C * 10].to(w.dtype)
+                dw32, db32 = lo[:C * 9], lo[C * 9:]
             if w.shape[-1] == 1:       # 1x1 depthwise (a per-channel scale): the centre tap of the 3x3 sums
                 dw32 = dw32.view(C, 9)[:, 4]
-            dw = dw32.reshape(w.shape).to(w.dtype) if need_w else None
-            db = db32.to(w.dtype) if need_b else None
+            dw = dw32.reshape(w.shape) if need_w else None
+            db = db32 if need_b else None
             need_w = need_b = False
         dx = dw2 = db2 = None
         if ctx.needs_input_grad[0] or need_w or need_b:

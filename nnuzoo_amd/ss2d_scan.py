@@ -104,8 +104,15 @@ class _DwConvSiluPrepareFn(torch.autograd.Function):
         dx = torch.empty((B, H, W, Di), dtype=x_tok.dtype, device=dx2.device)
         dwb = torch.empty(Di * 10, dtype=torch.float32, device=dx2.device)      # [Di][9] weights, then [Di] bias
         dw, db = dwb[:Di * 9], dwb[Di * 9:]
-        call("nnz_ss2d_dwconv_silu_backward", ptr(x_tok), int(x_tok.dtype == torch.float16), xs, ptr(w9), ptr(bv),
-             ptr(dx2), ptr(dx), ptr(dw), ptr(db), B, Di, H, W, stream_ptr())
+        from .token_linear import TWO_STAGE
+        if TWO_STAGE:     # per-tile partial rows + fixed-order fold instead of fp32 atomics (bit-reproducible)
+            nws = int(load().nnz_ss2d_dwconv_silu_backward_workspace_floats(B, Di, H, W))
+            ws = torch.empty(nws, dtype=torch.float32, device=dx2.device)
+            call("nnz_ss2d_dwconv_silu_backward_ws", ptr(x_tok), int(x_tok.dtype == torch.float16), xs, ptr(w9), ptr(bv),
+                 ptr(dx2), ptr(dx), ptr(dw), ptr(db), ptr(ws), nws, B, Di, H, W, stream_ptr())
+        else:
+            call("nnz_ss2d_dwconv_silu_backward", ptr(x_tok), int(x_tok.dtype == torch.float16), xs, ptr(w9), ptr(bv),
+                 ptr(dx2), ptr(dx), ptr(dw), ptr(db), B, Di, H, W, stream_ptr())
         return dx, dw.view(wshape), (db if bv is not None else None)
 
 
@@ -181,8 +188,16 @@ class _SS2DCrossScan(torch.autograd.Function):
                 # + the scans' own input gradients: direction k = 2j + s belongs to source s
                 dx2 += du.view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
             if _xproj_ok(Di, 2 * Cp) and L % 64 == 0 and ((2 * Cp + 7) // 8) * (Di // 8) <= 256:
-                d_xproj = torch.zeros((K, Cp, Di), **f32)                        # written in the module's layout
-                call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(d_xproj), B, Di, 2 * Cp, L, Cp, stream_ptr())
+                from .token_linear import TWO_STAGE
+                if TWO_STAGE:
+                    d_xproj = torch.empty((K, Cp, Di), **f32)                    # written in the module's layout
+                    nws = int(lib.nnz_ss2d_xproj_backward_w_workspace_floats(B, Di, 2 * Cp, L))
+                    ws = torch.empty(nws, **f32)
+                    call("nnz_ss2d_xproj_backward_w_ws", ptr(dP), ptr(x2), ptr(d_xproj), ptr(ws), nws, B, Di, 2 * Cp, L, Cp,
+                         stream_ptr())
+                else:
+                    d_xproj = torch.zeros((K, Cp, Di), **f32)
+                    call("nnz_ss2d_xproj_backward_w", ptr(dP), ptr(x2), ptr(d_xproj), B, Di, 2 * Cp, L, Cp, stream_ptr())
             else:
                 dWst = _proj_weight_grad(dP, x2)                                 # (2, 2Cp, Di)
                 d_xproj = dWst.view(2, 2, Cp, Di).transpose(0, 1).reshape(K, Cp, Di)

@@ -86,10 +86,20 @@ class _HipTokenLinearFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
             if (N // 8) * (K // 8) <= 256:
-                buf = torch.zeros(N * K + N, dtype=torch.float32, device=x.device)
-                dw, dbv = buf[:N * K].view(N, K), buf[N * K:]
-                call("nnz_token_linear_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(dbv) if need_b else None, T, N, K,
-                     stream_ptr())
+                if TWO_STAGE:
+                    # per-workgroup partial blocks + a fixed-order fold (csrc/common.hpp fold_partials): bit-reproducible, and
+                    # no zero-fill launch
+                    buf = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
+                    dw, dbv = buf[:N * K].view(N, K), buf[N * K:]
+                    nws = int(_lib.load().nnz_token_linear_wgrad_workspace_floats(T, N, K))
+                    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+                    call("nnz_token_linear_wgrad_ws", ptr(dy), ptr(x), ptr(dw), ptr(dbv) if need_b else None, ptr(ws), nws,
+                         T, N, K, stream_ptr())
+                else:
+                    buf = torch.zeros(N * K + N, dtype=torch.float32, device=x.device)
+                    dw, dbv = buf[:N * K].view(N, K), buf[N * K:]
+                    call("nnz_token_linear_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(dbv) if need_b else None, T, N, K,
+                         stream_ptr())
                 db = dbv if need_b else None
             else:
                 dy2, x2 = dy.reshape(-1, N), x.reshape(-1, K)
@@ -174,12 +184,28 @@ def dense32_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
 # do not sit on the data-gradient chain.  Results are bit-identical to the per-layer launches (same split rule, same
 # arithmetic, fixed fold order).  Outside the context (torch.autograd.grad, parity tests) nothing changes.
 GROUP_WGRAD = os.environ.get("NNZ_DENSE32_GROUP", "1") != "0"
+# weight gradients whose token ranges are spread over many workgroups (token Linear, x_proj, depthwise conv + SiLU):
+# NNZ_TWO_STAGE_WGRADS=1 - partial blocks + fixed-order fold, bit-reproducible (tests/test_two_stage_wgrads_gpu.py); default 0 -
+# fp32 atomics into a zero-filled gradient.  Measured at 512^2, batch 2 (profiles/r04_two_stage_wgrads.txt): the two-stage form
+# costs 0.9-1.4 % of an M2Net / M2NetP / SSND2Net step, and the steps of the Mamba nets stay non-reproducible either way (the scan
+# backward's cross-channel dB / dC / d-delta sums) - so it is an option, not the default.
+TWO_STAGE = os.environ.get("NNZ_TWO_STAGE_WGRADS", "0") == "1"
 _DEFER = {"on": False, "jobs": []}
 _GROUP_KEEP = []          # host tables captured into a hipGraph must outlive it
 _HOST_CACHE, _HOST_EVENTS = {}, {}
 
 
+def _has_grad_hooks(p: torch.Tensor) -> bool:
+    """tensor hooks / post-accumulate-grad hooks (DDP-style reducers, user hooks) only see gradients that autograd delivers: a
+    parameter that carries any keeps its weight gradient on the ordinary path"""
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 class deferred_wgrads:
+    """Valid around `.backward()` only: the queued Linear nodes return None for their weight / bias gradients and `.grad` is
+    assigned by the grouped launch at exit - `torch.autograd.grad(..., inputs=params)` inside the context gets nothing for them.
+    Every queued (dy, x) pair stays alive until the exit.  Process-global, not thread-local: one backward at a time."""
+
     def __enter__(self):
         self._outer = _DEFER["on"]
         _DEFER["on"] = GROUP_WGRAD or self._outer
@@ -285,7 +311,8 @@ def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None, bias
         dx = torch.empty((T, K), dtype=torch.float32, device=dy2.device)
         call("nnz_dense32_dgrad", ptr(dy2), ptr(weight), ptr(h), ptr(dx), T, K, N, stream_ptr())
     if need_w or need_b:
-        if _DEFER["on"] and need_w and weight.is_leaf and (bias is None or bias.is_leaf):
+        if _DEFER["on"] and need_w and weight.is_leaf and (bias is None or bias.is_leaf) and not _has_grad_hooks(weight) \
+                and not (bias is not None and _has_grad_hooks(bias)):
             _DEFER["jobs"].append((dy2, x2, weight, bias if need_b else None))
             return dx, None, None
         dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)

@@ -50,10 +50,19 @@ class _X2Trainer(nnUNetTrainer):
     # (`torch.backends.cudnn.flags`), never as a process-wide switch - other networks, predictors and tests in the same
     # process keep MIOpen.
     _no_miopen = False
+    _fp32_validation = False
 
     def _library_scope(self):
-        if self._no_miopen and self.device.type == 'cuda':
+        if self.device.type != 'cuda':
+            return contextlib.nullcontext()
+        # NNZ_LIBRARY_DETERMINISTIC=1: the convolutions that stay on the library (stage heads, 1-channel stems, small-channel
+        # blocks) are restricted to its deterministic solvers - tools/probes/zoo_module_determinism.py found them to be the only
+        # modules of the SwT2Net step whose forward / backward is not bit-reproducible from call to call
+        det = os.environ.get("NNZ_LIBRARY_DETERMINISTIC", "0")
+        if self._no_miopen or det == "2":           # 2: ATen's own kernels instead of the library (also reproducible)
             return torch.backends.cudnn.flags(enabled=False)
+        if det == "1":                              # 1: the library's deterministic solvers (measured: 11x slower steps)
+            return torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)
         return contextlib.nullcontext()
 
     def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
@@ -146,6 +155,13 @@ class _X2Trainer(nnUNetTrainer):
     def train_step(self, batch: dict) -> dict:
         with self._library_scope():
             return self._train_step(batch)
+
+    def _autocast_context(self):
+        # a plugin whose reference class overrides validation_step to run WITHOUT autocast (nnUNetTrainerLightMUNet.py) validates
+        # in fp32 here as well; the other fp32-step plugins inherit the base trainer's autocast validation there, and here
+        if self._fp32_validation:
+            return contextlib.nullcontext()
+        return super()._autocast_context()
 
     def validation_step(self, batch: dict) -> dict:
         with self._library_scope():
@@ -342,6 +358,7 @@ class nnUNetTrainerLightMUNet(_X2Trainer):
     without autocast / GradScaler :45-63; ONE output, deep supervision off :29, :127-128; Adam lr 1e-4 / wd 1e-5 / eps 1e-5,
     PolyLR exponent 0.9 :120-124; gradient clipping 12)"""
     _fp32_step = True
+    _fp32_validation = True
     _no_miopen = True   # small-channel fp32 convolutions, depthwise 3x3 / 1x1 (see MambaND2Net above)
 
     def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
