@@ -120,7 +120,8 @@ class UNETR(nn.Module):
     def __init__(self, spatial_dims, in_channels, out_channels, img_size, feature_size=16, hidden_size=768, mlp_dim=3072,
                  num_heads=12, proj_type="conv", norm_name="instance", conv_block=True, res_block=True,
                  dropout_rate=0.0, qkv_bias=False, save_attn=False, num_layers=7, patch_size=(16, 16, 16),
-                 decoder_scale=(2, 2, 2, 2), encoder_scale=(2, 2, 2), encoder_layers=(2, 1, 0), add_last=True):
+                 decoder_scale=(2, 2, 2, 2), encoder_scale=(2, 2, 2), encoder_layers=(2, 1, 0), add_last=True,
+                 out_indices=None):
         super().__init__()
         self.add_last = add_last
         if add_last:
@@ -135,7 +136,7 @@ class UNETR(nn.Module):
         self.patch_size = tuple(patch_size[:sd])
         self.feat_size = tuple(int(img_size[a] // self.patch_size[a]) for a in range(sd))
         self.classification = False
-        self.out_indices = [int(v) for v in np.linspace(2, num_layers - 1, 3)]
+        self.out_indices = [int(v) for v in (np.linspace(2, num_layers - 1, 3) if out_indices is None else out_indices)]
         self.vit = ViT(in_channels, img_size, self.patch_size, hidden_size, mlp_dim, num_layers, num_heads, proj_type,
                        False, dropout_rate, sd, qkv_bias, save_attn)
         f = feature_size
@@ -168,6 +169,22 @@ class UNETR(nn.Module):
         dec1 = self.decoder3(dec2, enc2)
         out = self.out(self.decoder2(dec1, enc1))
         return out + last_add if self.add_last else out
+
+
+class MonaiUNETR(UNETR):
+    """`monai.networks.nets.UNETR` as nnUNetTrainerUNETR instantiates it (/root/reference/nnunetv2/training/nnUNetTrainer/
+    nnUNetTrainerUNETR.py:10, :43-58): the stage class above in its original form - 12 transformer layers, 16-voxel patches, skip
+    features after layers 3, 6, 9, no residual input branch.  Same child names as monai's module (vit, encoder1..4, decoder5..2,
+    out).  monai is absent here: PARITY UNPINNED (nets/monai_blocks.py header); the attention, MLP and Linear layers are the
+    pinned ones of this file."""
+
+    def __init__(self, in_channels, out_channels, img_size, feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12,
+                 proj_type="conv", norm_name="instance", conv_block=True, res_block=True, dropout_rate=0.0, spatial_dims=3,
+                 qkv_bias=False, save_attn=False):
+        super().__init__(spatial_dims, in_channels, out_channels, img_size, feature_size=feature_size, hidden_size=hidden_size,
+                         mlp_dim=mlp_dim, num_heads=num_heads, proj_type=proj_type, norm_name=norm_name, conv_block=conv_block,
+                         res_block=res_block, dropout_rate=dropout_rate, qkv_bias=qkv_bias, save_attn=save_attn, num_layers=12,
+                         patch_size=(16, 16, 16), add_last=False, out_indices=(3, 6, 9))
 
 
 class UNETR2Net(_UnetrStageX2):

@@ -282,6 +282,50 @@ class nnUNetTrainerUNETR2Net(_X2Trainer):
         return _legacy_or_live(lambda *a, **k: get_unetr2net_from_plans(*a, small_mode=False, **k), args, kwargs)
 
 
+class nnUNetTrainerUNETR(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerUNETR.py:13-150 (monai's UNETR, 2-D or 3-D; patch size rounded up to
+    multiples of the ViT's 16-voxel patches :18-28; fp32 step without autocast / GradScaler, clip 12 :61-77; ONE output - deep
+    supervision off; AdamW 1e-4 / wd 0.01 / eps 1e-5 with PolyLR exponent 1.0 :138-141)"""
+    _fp32_step = True
+    _fp32_validation = True                    # the class overrides validation_step without autocast (:79-136)
+    _no_miopen = True                          # same small-channel UNETR conv blocks as MambaND2Net (see there)
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.enable_deep_supervision = False
+        old = list(self.configuration_manager.patch_size)
+        new = [round(v / 16 + 0.5) * 16 if (v / 16) < 1 or (v / 16) % 1 != 0 else v for v in old]
+        self.configuration_manager.configuration['patch_size'] = new
+        self.plans['configurations'][self.configuration_name]['patch_size'] = new
+        self.initial_lr = 1e-4
+        self.grad_scaler = None
+        self.weight_decay = 0.01
+
+    def _get_deep_supervision_scales(self):
+        return None
+
+    def set_deep_supervision_enabled(self, enabled: bool):
+        pass
+
+    def configure_optimizers(self):
+        from .lr_scheduler import PolyLRScheduler
+        fused = self.device.type == 'cuda' and os.environ.get("NNZ_FUSED_ADAMW", "1") != "0"
+        optimizer = AdamW(self.network.parameters(), lr=self.initial_lr, weight_decay=self.weight_decay, eps=1e-5, fused=fused)
+        return optimizer, PolyLRScheduler(optimizer, self.initial_lr, self.num_epochs, exponent=1.0)
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.unetr2net import MonaiUNETR
+        num_in, num_out, _ = _live_num_in_out(args, kwargs)
+        cm = next((a for a in list(args) + list(kwargs.values()) if hasattr(a, "patch_size")), None)
+        if cm is None:
+            raise ValueError("nnUNetTrainerUNETR.build_network_architecture needs the configuration manager (patch size)")
+        return MonaiUNETR(in_channels=num_in, out_channels=num_out, img_size=list(cm.patch_size), feature_size=16,
+                          hidden_size=768, mlp_dim=3072, num_heads=12, proj_type="conv", norm_name="instance", res_block=True,
+                          dropout_rate=0.0, spatial_dims=len(cm.patch_size), qkv_bias=False, save_attn=False)
+
+
 class nnUNetTrainerLightMamba2Net(_X2Trainer):
     """reference: training/nnUNetTrainer/nnUNetTrainerLightMamba2Net.py:18-131 (N-D; fp32 step without autocast /
     GradScaler :30-48; AdamW 1e-4 / wd 5e-2, cosine; deep-supervision scales from get_scales(min_size=8) :70-94)"""

@@ -42,6 +42,11 @@ cd $GRAFT_REPO_ROOT
   echo "--- forward with a raw (consumer-normalised) input and flipped weight gradient: --innorm 0 / 1"
   python3 tools/bench_conv_layers.py --innorm 0 2>&1 | grep -E "enc0.1|dec0.0|enc1.0|enc1.1|dec1.0|TOTAL"
   python3 tools/bench_conv_layers.py --innorm 1 2>&1 | grep -E "enc0.1|dec0.0|enc1.0|enc1.1|dec1.0|TOTAL" ) > $OUT/${TAG}_conv_experiments.txt
+# round 4: phase timestamps of a conv_box workgroup (instrumented library tools/probes/_ts/libnnuzoo_hip_ts.so, built on this box if
+# the snapshot does not carry it); knob 11 = 0 / 1: the forward statistics with VALU sums / on the matrix cores
+for K in 0 1; do python3 tools/probes/conv_phase_probe.py --only enc0.1 --tuning 11=$K 2>&1 | grep -v -E "amdgpu|Warning|_benchmark" > $OUT/${TAG}_conv_phases_moments$K.txt; done
+python3 tools/probes/conv_phase_probe.py --only enc1.1 2>&1 | grep -v -E "amdgpu|Warning|_benchmark" > $OUT/${TAG}_conv_phases_enc1_1.txt
+python3 tools/bench_zoo.py --models SwinUMambaD,SwinUMamba --steps 6 --warmup 10 2>&1 | grep '"model"' >> $OUT/${TAG}_zoo_bench.txt
 python3 tools/probes/ssnd2net_loss_probe.py --size 512 --steps 14 2>/dev/null | grep '^{' | cut -c1-260 > $OUT/${TAG}_ssnd2net_loss_probe.txt
 # 4b. the window-attention kernels: SQ counters over one SwT2Net run (eager: one dispatch per kernel)
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $OUT/prof_wa_pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_zoo.py --models SwT2Net --steps 1 --warmup 1 --graph 0 > /dev/null 2>&1
