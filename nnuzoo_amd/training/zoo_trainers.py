@@ -438,6 +438,24 @@ class nnUNetTrainerLightMUNet(_X2Trainer):
                           blocks_down=[1, 2, 2, 4], blocks_up=[1, 1, 1])
 
 
+class nnUNetTrainerLightSS2DMambaUNet(nnUNetTrainerLightMUNet):
+    """reference: training/nnUNetTrainer/nnUNetTrainerLightSS2DMambaUNet.py:17-140 (LightSS2DMambaUNet, 2-D: its Mamba layers
+    unpack (B, C, H, W); fp32 step without autocast / GradScaler, clip 12 :60-78; Adam 1e-4 / wd 1e-5 / eps 1e-5 + PolyLR 0.9
+    :128-133; fp32 validation_step :80-126).  The network returns ONE tensor; the reference's class leaves
+    `enable_deep_supervision` at the base default, with which its loss wrapper rejects that output - deep supervision is off
+    here, as in nnUNetTrainerLightMUNet."""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.light_ss2d_mamba_unet import LightSS2DMambaUNet
+        num_in, num_out, _ = _live_num_in_out(args, kwargs)
+        cm = next((a for a in list(args) + list(kwargs.values()) if hasattr(a, "patch_size")), None)
+        if cm is None:
+            raise ValueError("nnUNetTrainerLightSS2DMambaUNet.build_network_architecture needs the configuration manager "
+                             "(patch size -> spatial dims)")
+        return LightSS2DMambaUNet(spatial_dims=len(cm.patch_size), in_channels=num_in, out_channels=num_out)
+
+
 def _live_num_in_out(args, kwargs):
     """(num_input_channels, num_output_channels, deep_supervision) from the live calling convention
     (architecture_class_name, arch_init_kwargs, req_import, num_input_channels, num_output_channels, ds) or, for callers

@@ -1,0 +1,81 @@
+"""LightSS2DMambaUNet (reference nets/LightSS2DMambaUNet.py, trainer nnUNetTrainerLightSS2DMambaUNet) - round 4 - against the
+REFERENCE's own class (tools/make_golden_lm2net.py lightss2d; selective_scan_fn bound to the reference's selective_scan_ref):
+  CPU  state_dict names / shapes / order; the parameters of torch.manual_seed(0) + the file's factory BIT FOR BIT (digest)
+  GPU  forward of that seeded network (the reference moves 6e-6 under a 1e-6 input perturbation), dx and the parameter-gradient
+       norms within the reference's own conditioning (dx moves 1e-2, the norms 1.4e-3 in the median); a trainer step
+monai's get_conv_layer / get_upsample_layer / get_norm_layer / get_act_layer are restated identically on both sides (unpinned)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _seeded():
+    from nnuzoo_amd.nets.light_ss2d_mamba_unet import get_mamband2net_from_plans
+    torch.manual_seed(0)
+    return get_mamband2net_from_plans(2, 1, 3)
+
+
+def test_state_dict_and_seeded_parameters_match_the_reference():
+    man = json.load(open(os.path.join(G, "lightss2d_manifest.json")))
+    net = _seeded()
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == man["state_dict"]
+    h = hashlib.sha256()
+    for v in net.state_dict().values():
+        h.update(v.detach().contiguous().numpy().tobytes())
+    assert h.hexdigest() == man["seeded_sha256"]
+
+
+def test_namespace_and_factory():
+    from nnunetv2.nets.LightSS2DMambaUNet import LightSS2DMambaUNet, get_mamband2net_from_plans
+    from nnunetv2.training.nnUNetTrainer.nnUNetTrainerLightSS2DMambaUNet import nnUNetTrainerLightSS2DMambaUNet
+    from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+    assert issubclass(nnUNetTrainerLightSS2DMambaUNet, nnUNetTrainer)
+    assert isinstance(get_mamband2net_from_plans(2, 1, 2), LightSS2DMambaUNet)
+    with pytest.raises(NotImplementedError):
+        get_mamband2net_from_plans(2, 1, 2, small_mode=True)
+
+
+@pytest.mark.gpu
+def test_forward_backward_match_the_reference(hip_lib):
+    z = np.load(os.path.join(G, "net_LightSS2DMambaUNet_2d.npz"))
+    sens_y, sens_dx, sens_g = (float(v) for v in z["sens"])
+    net = _seeded().cuda().train()
+    x = torch.tensor(z["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    ref = torch.tensor(z["y"])
+    assert y.shape == ref.shape
+    err = (y.detach().float().cpu() - ref).abs().max().item()
+    assert err <= max(2e-4, 50 * sens_y) * ref.abs().max().item(), (err, ref.abs().max().item(), sens_y)
+    j = torch.arange(y.numel(), dtype=torch.float64)
+    ((y * torch.sin(0.37 * j).float().view_as(y).cuda()).sum() / y[0, 0].numel()).backward()
+    rdx = torch.tensor(z["dx"])
+    assert (x.grad.float().cpu() - rdx).abs().max().item() <= max(2e-3, 10 * sens_dx) * rdx.abs().max().item()
+    names = [str(n) for n in z["names"]]
+    assert [n for n, p in net.named_parameters() if p.grad is not None] == names
+    got = np.array([float(p.grad.double().pow(2).sum().sqrt()) for n, p in net.named_parameters() if p.grad is not None])
+    want = z["grad_norms"]
+    rel = np.abs(got - want) / (want + 1e-6 * want.max())
+    assert np.median(rel) <= max(1e-3, 10 * sens_g), (np.median(rel), sens_g)
+    assert rel.max() <= 0.5, rel.max()          # single ill-conditioned gradients may move, none may be structurally wrong
+
+
+@pytest.mark.gpu
+def test_trainer_steps(hip_lib):
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training import zoo_trainers as Z
+    plans, cfg, dj = nnunet_plans(2, (128, 128), batch_size=2)
+    torch.manual_seed(0)
+    tr = Z.nnUNetTrainerLightSS2DMambaUNet(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    assert type(tr.network).__name__ == "LightSS2DMambaUNet" and tr._get_deep_supervision_scales() is None
+    assert type(tr.optimizer).__name__ == "Adam" and tr.grad_scaler is None
+    b = synthetic_batch(2, (128, 128), [[1.0, 1.0]], seed=1)
+    b = {"data": b["data"].cuda(), "target": b["target"][0].cuda()}
+    losses = [float(tr.train_step(b)["loss"]) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -174,7 +174,51 @@ def light_munet():
         json.dump(man, f)
 
 
+def light_ss2d():
+    """nets/LightSS2DMambaUNet.py LightSS2DMambaUNet (round 4), the trainer's configuration (2-D, init_filters 8, blocks (1, 2, 2,
+    4) / (1, 1, 1)) built by the file's factory under torch.manual_seed(0), selective_scan_fn bound to the reference's
+    selective_scan_ref: state_dict manifest + digest of the seeded parameters, forward, dx, the L2 norm of every parameter
+    gradient and the reference's own response to a 1e-6 input perturbation (forward, dx, gradient norms)."""
+    import nnunetv2.nets.LightSS2DMambaUNet as R
+    R.selective_scan_fn = ref_shim.load_selective_scan_ref()
+    import hashlib
+    torch.manual_seed(0)
+    net = R.get_mamband2net_from_plans(2, 1, 3)        # seeded construction + InitWeights_He: the parameters of the fixture
+    man = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    h = hashlib.sha256()
+    for v in net.state_dict().values():
+        h.update(v.detach().contiguous().numpy().tobytes())
+    digest = h.hexdigest()
+    net.train()
+    x = torch.randn(1, 1, 64, 64, generator=torch.Generator().manual_seed(7))
+
+    def run(xin):
+        net.zero_grad(set_to_none=True)
+        xg = xin.clone().requires_grad_(True)
+        y = net(xg)
+        j = torch.arange(y.numel(), dtype=torch.float64)
+        ((y * torch.sin(0.37 * j).float().view_as(y)).sum() / y[0, 0].numel()).backward()
+        names = [n for n, p in net.named_parameters() if p.grad is not None]
+        norms = np.array([float(p.grad.double().pow(2).sum().sqrt()) for n, p in net.named_parameters() if p.grad is not None])
+        return y.detach(), xg.grad.clone(), names, norms
+
+    y, dx, names, norms = run(x)
+    i = torch.arange(x.numel(), dtype=torch.float64)
+    y2, dx2, _, norms2 = run(x + 1e-6 * float(x.std()) * torch.cos(1.3 * i + 0.2).float().view_as(x))
+    sens = {"y": float((y2 - y).abs().max() / y.abs().max()), "dx": float((dx2 - dx).abs().max() / dx.abs().max()),
+            "gnorm_median": float(np.median(np.abs(norms2 - norms) / (norms + 1e-12)))}
+    np.savez_compressed(os.path.join(OUT, "net_LightSS2DMambaUNet_2d.npz"), x=x.numpy(), y=y.numpy(), dx=dx.numpy(),
+                        names=np.array(names), grad_norms=norms, sens=np.array([sens["y"], sens["dx"], sens["gnorm_median"]]))
+    with open(os.path.join(OUT, "lightss2d_manifest.json"), "w") as f:
+        json.dump({"state_dict": man, "seeded_sha256": digest}, f)
+    print("LightSS2DMambaUNet params", sum(p.numel() for p in net.parameters()), "out", tuple(y.shape), "sens", sens, flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lightss2d":
+        bind()
+        light_ss2d()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lightmunet":
         bind()
         light_munet()
