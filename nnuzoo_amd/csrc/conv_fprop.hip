@@ -184,7 +184,12 @@ struct ConvCfg {
 //      tools/probes/conv_phase_probe.py - wave 0 of EVERY workgroup sat ~10 000 cycles, a quarter of a 2-slice workgroup's
 //      lifetime, in the two dependent memory round trips of the protocol: adds acknowledged, ticket returned)
 //  11  InstanceNorm statistics of the forward epilogue: tiles inside the volume form their moments with MFMAs (1) / VALU sums and
-//      lane shuffles everywhere (0)                                                                                    (default 1)
+//      lane shuffles everywhere (0)                                                                                    (default 1:
+//      +1.4 % on the training step, same box.  The pilot subtraction runs in packed fp16 - exact when the spread is small
+//      against the mean (the cancellation-prone case), rounded to 11 bits otherwise - so the launch keeps THREE sums per (sample,
+//      channel): the consistent pair of the rounded deviations for the variance and the exact sum of x for the mean.  Table
+//      against float64 on the stored outputs: mean 3e-6 like the VALU form, rstd within 1e-4 relative (VALU form 3e-6) -
+//      tests/test_determinism_gpu.py test_conv_epilogue_table_{large,small}_mean hold both forms.)
 //  12, 13  -DNNZ_CONV_TIMESTAMPS builds only: low / high half of the timestamp buffer's address
 #ifndef NNZ_DRE_PERSIST
 #define NNZ_DRE_PERSIST false
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   // workgroups of the launch hit the same 256 words) backed up the wave's memory queue and its stores - the workgroup's last -
   // left twice as late (tools/probes/conv_phase_probe.py: 5 900 against 2 900 cycles)
   long fx_rec = -1;
-  double fx_v1 = 0.0, fx_v2 = 0.0;
+  double fx_v1 = 0.0, fx_v2 = 0.0, fx_v3 = 0.0;
   if (p.stats) {
     // InstanceNorm statistics of this tile from the fp16 image (what the normalisation will read): a thread sums 8
     // channels over its share of the voxels, a [parts][2*NC] slab behind the image folds the shares, one atomic per
@@ -901,13 +906,16 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     // var = E[x^2] - mean^2 formed in double by the finalising workgroup stays good for |mean| / std up to ~1e4.
     constexpr int NC = NB * 32, NVOX = TD * TH * TW;
     constexpr int PARTS = 256 / PPV;
+    static_assert(PARTS * 2 * NC >= 12 * NC, "the statistics slab holds the four waves' pairs and their third sums");
     float* slab = reinterpret_cast<float*>(smem + NVOX * ROWB);
+    const int RPC = p.mfma_moments ? 3 : 2;   // accumulator records per (sample, channel)
     const bool full_tile = m0d + TD <= mD0 && m0h + TH <= mD1 && m0w + TW <= mD2;
     if (full_tile && p.mfma_moments) {
       // Tiles inside the volume (all but the last ones of an axis): the moments on the matrix cores.  A wave takes NVOX / 4
       // voxels in 16-voxel steps; the transposed LDS read (ds_read_b64_tr_b16, as in conv_wgrad.hip) delivers the image as an
       // MFMA fragment F[channel][voxel] - the same registers serve as A and as B operand - the pilot is subtracted in packed
-      // fp16 (d = x - K; rounds only when |d| needs more than 11 bits, far below what the statistics resolve), and
+      // fp16 (d = x - K: exact while x and K lie within a factor of two of each other, i.e. in the cancellation-prone case of
+      // a large mean; rounded to 11 bits otherwise - which is why the mean comes from a third, exact sum, see knob 11), and
       //   D2 = F F^T (diagonal: sum d^2)      D1 = F 1 (any column: sum d)
       // accumulate in fp32 in the MFMA's fixed order.  16 transposed reads + 32 packed subtractions + 16 MFMAs per wave replace
       // ~360 VALU instructions of convert / subtract / add / FMA per thread and the 64-shuffle lane fold
@@ -922,9 +930,9 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       for (int nb = 0; nb < NB; ++nb) {
         const f16 kh = *reinterpret_cast<const f16*>(smem + (nb * 32 + l31) * 2);   // pilot of the lane's channel
         const nnz_h2 k2 = {kh, kh};
-        f32x16 d1, d2;
+        f32x16 d1, d2, dx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d1[r] = d2[r] = 0.f;
+        for (int r = 0; r < 16; ++r) d1[r] = d2[r] = dx[r] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < KB_W; ++kb) {
           const int v0 = (wave * KB_W + kb) * 16 + 8 * hh;
@@ -932,21 +940,25 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
           union { i16x4 v[2]; nnz_h2 h[4]; f16x8 f; } u;
           u.v[0] = lds_read_tr16(src);
           u.v[1] = lds_read_tr16(src + 4 * ROWB);
+          dx = mfma32(u.f, ones, dx);        // sum x of the UNROUNDED values: the table's mean stays exact
 #pragma unroll
           for (int q = 0; q < 4; ++q) u.h[q] = u.h[q] - k2;
           d2 = mfma32(u.f, u.f, d2);
           d1 = mfma32(u.f, ones, d1);
         }
         const int rsel = (l31 & 3) + 4 * (l31 >> 3);
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, sx = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (r == rsel) {
             s1 = d1[r];
             s2 = d2[r];
+            sx = dx[r];
           }
-        if (hh == ((l31 >> 2) & 1))
+        if (hh == ((l31 >> 2) & 1)) {
           *reinterpret_cast<f32x2*>(slab + wave * (2 * NC) + (nb * 32 + l31) * 2) = f32x2{s1, s2};
+          slab[8 * NC + wave * NC + nb * 32 + l31] = sx;       // third sums behind the four waves' pairs
+        }
       }
       NNZ_TS(6);
     } else {
@@ -1005,25 +1017,40 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
         const int cw = mD2 - m0w < TW ? mD2 - m0w : TW;
         const double cnt = (double)(cd * ch * cw);
         const double k = (double)(float)*reinterpret_cast<const f16*>(smem + c * 2);
-        const long rec = ((long)n * Cout + cb0 * 32 + c) * 2, nrec = (long)p.d.N * Cout * 2;
+        // knob 11: THREE sums per (sample, channel) - sum and sum of squares of the pilot-centred values as the tiles formed
+        // them (fp16-rounded deviations on the MFMA path: a consistent pair, so the variance keeps its precision) and the exact
+        // sum of x for the mean (MFMA tiles: F 1 on the unrounded fragment; VALU tiles: the same number as the first sum)
+        const long rec = ((long)n * Cout + cb0 * 32 + c) * RPC, nrec = (long)p.d.N * Cout * RPC;
+        const double v1 = (double)S1 + cnt * k, v2 = (double)S2 + 2.0 * k * (double)S1 + cnt * k * k;
+        double v3 = v1;
+        if (full_tile && p.mfma_moments)
+          v3 = (double)((slab[8 * NC + c] + slab[9 * NC + c]) + (slab[10 * NC + c] + slab[11 * NC + c]));
         if (p.sep_finish) {   // (NC <= 64: one channel per lane) the adds follow this wave's stores, see below
           fx_rec = rec;
-          fx_v1 = (double)S1 + cnt * k;
-          fx_v2 = (double)S2 + 2.0 * k * (double)S1 + cnt * k * k;
+          fx_v1 = v1;
+          fx_v2 = v2;
+          fx_v3 = v3;
         } else {
-          fx_add(p.acc, rec, nrec, blockIdx.x, (double)S1 + cnt * k);
-          fx_add(p.acc, rec + 1, nrec, blockIdx.x, (double)S2 + 2.0 * k * (double)S1 + cnt * k * k);
+          fx_add(p.acc, rec, nrec, blockIdx.x, v1);
+          fx_add(p.acc, rec + 1, nrec, blockIdx.x, v2);
+          if (RPC == 3) fx_add(p.acc, rec + 2, nrec, blockIdx.x, v3);
         }
       }
       NNZ_TS(8);
       if (!p.sep_finish && last_tile && last_workgroup_wave(p.counter, nwg)) {
         const double V = (double)mD0 * mD1 * mD2;
-        const long nrec = (long)p.d.N * Cout * 2;
+        const long nrec = (long)p.d.N * Cout * RPC;
         for (int i = lane; i < p.d.N * Cout; i += 64) {
-          double mom[2];
-          fx_take_n<2>(p.acc, (long)i * 2, nrec, mom);
-          const double mean = mom[0] / V;
-          double var = mom[1] / V - mean * mean;
+          double mom[3];
+          if (RPC == 3) {
+            fx_take_n<3>(p.acc, (long)i * 3, nrec, mom);
+          } else {
+            double m2[2];
+            fx_take_n<2>(p.acc, (long)i * 2, nrec, m2);
+            mom[0] = m2[0]; mom[1] = m2[1]; mom[2] = m2[0];
+          }
+          const double mean = mom[2] / V, mean_r = mom[0] / V;
+          double var = mom[1] / V - mean_r * mean_r;
           var = var < 0.0 ? 0.0 : var;  // (NaN stays NaN)
           const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
           const int c = i % Cout;
@@ -1057,9 +1084,11 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     *reinterpret_cast<f16x8*>(dst) = val;
   }
   if (fx_rec >= 0) {
-    const long nrec = (long)p.d.N * Cout * 2;
+    const int rpc = p.mfma_moments ? 3 : 2;
+    const long nrec = (long)p.d.N * Cout * rpc;
     fx_add(p.acc, fx_rec, nrec, blockIdx.x, fx_v1);
     fx_add(p.acc, fx_rec + 1, nrec, blockIdx.x, fx_v2);
+    if (rpc == 3) fx_add(p.acc, fx_rec + 2, nrec, blockIdx.x, fx_v3);
   }
   NNZ_TS(14);
   };   // tile_body
@@ -1090,15 +1119,22 @@ struct StatsFinish {
   float eps;
   int N, Cout;
   double V;
+  int rpc;   // records per (sample, channel): 2, or 3 with the exact sum of x behind the pilot-centred pair (knob 11)
 };
 __global__ __launch_bounds__(64) void conv_stats_finish_kernel(StatsFinish a) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= a.N * a.Cout) return;
-  const long nrec = (long)a.N * a.Cout * 2;
-  double mom[2];
-  fx_take_n<2>(a.acc, (long)i * 2, nrec, mom);
-  const double mean = mom[0] / a.V;
-  double var = mom[1] / a.V - mean * mean;
+  const long nrec = (long)a.N * a.Cout * a.rpc;
+  double mom[3];
+  if (a.rpc == 3) {
+    fx_take_n<3>(a.acc, (long)i * 3, nrec, mom);
+  } else {
+    double m2[2];
+    fx_take_n<2>(a.acc, (long)i * 2, nrec, m2);
+    mom[0] = m2[0]; mom[1] = m2[1]; mom[2] = m2[0];
+  }
+  const double mean = mom[2] / a.V, mean_r = mom[0] / a.V;
+  double var = mom[1] / a.V - mean_r * mean_r;
   var = var < 0.0 ? 0.0 : var;  // (NaN stays NaN)
   const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
   const int c = i % a.Cout;
@@ -1319,7 +1355,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
     NNZ_LAUNCH(conv_normred_finish_kernel, dim3((p.d.Cout + 63) / 64), dim3(64), 0, stream, f);
   } else if (p.sep_finish) {
     StatsFinish f = {p.acc, p.nstat, p.gamma, p.beta, p.eps, p.d.N, p.d.Cout,
-                     (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2]};
+                     (double)p.d.m_dims[0] * p.d.m_dims[1] * p.d.m_dims[2], p.mfma_moments ? 3 : 2};
     NNZ_LAUNCH(conv_stats_finish_kernel, dim3((p.d.N * p.d.Cout + 63) / 64), dim3(64), 0, stream, f);
   }
   if (p.nsplit > 1) {

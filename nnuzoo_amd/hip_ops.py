@@ -127,7 +127,8 @@ class NormScratch:
     def __init__(self, device, n_times_c: int):
         nb = int(_lib.load().nnz_fxacc_bytes())
         n_times_c = max(int(n_times_c), 2816)   # also the stem (864) and seg-head (8 * 641) weight-gradient sums
-        self.acc = torch.zeros(n_times_c * 2 * nb // 8, dtype=torch.int64, device=device)
+        # (room for 4 records per unit of capacity: the conv epilogue keeps 2 or - with the matrix-core moments - 3 per (n, c))
+        self.acc = torch.zeros(n_times_c * 4 * nb // 8, dtype=torch.int64, device=device)
         self.counter = torch.zeros(2, dtype=torch.int32, device=device)
         self.capacity = n_times_c
         self.records = 2 * n_times_c

@@ -11,7 +11,7 @@ an autograd Function - its backward casts all fp16 gradients back the same way -
 substituted through `torch.func.functional_call`; autocast then finds fp16 operands and casts nothing.  Numerics are unchanged
 (the same fp32 -> fp16 rounding of the same values, the same fp16 -> fp32 widening of the gradients).
 Eligible: parameters owned directly by plain torch convolution modules (incl. `common2d._Conv2d`), outside the REBNCONV / RSU4F
-sub-trees (those run on the HIP conv path, which packs its weights from the fp32 master itself).  Everything else - TokenLinear,
+sub-trees of common2d.py AND u2net.py (those run on the HIP conv path, which packs its weights from the fp32 master itself).  Everything else - TokenLinear,
 LayerNorm, SS2D / SSND parameters - is read as fp32 by hand-written kernels and is left alone."""
 from __future__ import annotations
 
@@ -43,8 +43,11 @@ class _ShadowCast(torch.autograd.Function):
 
 def _eligible(network: nn.Module) -> Tuple[List[str], List[nn.Parameter]]:
     from .nets.common2d import REBNCONV, RSU4F, _Conv2d
+    from .nets.u2net import REBNCONV as _U2REBNCONV
     kinds = (nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d, _Conv2d)
-    skip = {id(m) for root in network.modules() if isinstance(root, (REBNCONV, RSU4F)) for m in root.modules()}
+    # every class whose convolution runs on the HIP conv path (nnuzoo_amd/rebnconv.py packs the fp32 master weight itself)
+    hip_conv = (REBNCONV, RSU4F, _U2REBNCONV)
+    skip = {id(m) for root in network.modules() if isinstance(root, hip_conv) for m in root.modules()}
     names, params = [], []
     for mname, m in network.named_modules():
         if id(m) in skip or type(m) not in kinds:
