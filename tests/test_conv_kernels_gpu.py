@@ -420,8 +420,11 @@ def test_conv_splitk_small_levels(hip_lib, N, dims, cin, cout, stride):
     mean, var = o64.mean(1), o64.var(1, unbiased=False)
     rstd = 1 / torch.sqrt(var + 1e-5)
     tab = outs[0][1].double()
-    assert torch.allclose(tab[..., 0], mean, rtol=1e-5, atol=1e-6) and torch.allclose(tab[..., 1], rstd, rtol=1e-5)
-    assert torch.allclose(tab[..., 2], rstd * gamma.double(), rtol=1e-5)
+    # (rstd / scale: where the table comes from the conv epilogue's matrix-core moments - nnz_conv_tuning knob 11, the default - the
+    #  variance is that of fp16-rounded deviations: within 1e-4 relative; the split-K finishing kernel and the VALU form hold 1e-5.
+    #  The mean is exact in all three.)
+    assert torch.allclose(tab[..., 0], mean, rtol=1e-5, atol=1e-6) and torch.allclose(tab[..., 1], rstd, rtol=1e-4)
+    assert torch.allclose(tab[..., 2], rstd * gamma.double(), rtol=1e-4)
     assert torch.allclose(tab[..., 3], beta.double() - mean * rstd * gamma.double(), rtol=1e-4, atol=1e-5)
     # data gradient (one tap group at stride 1): plain and accumulating
     if stride == 1:
