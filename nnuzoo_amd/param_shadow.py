@@ -48,6 +48,13 @@ def _eligible(network: nn.Module) -> Tuple[List[str], List[nn.Parameter]]:
     # every class whose convolution runs on the HIP conv path (nnuzoo_amd/rebnconv.py packs the fp32 master weight itself)
     hip_conv = (REBNCONV, RSU4F, _U2REBNCONV)
     skip = {id(m) for root in network.modules() if isinstance(root, hip_conv) for m in root.modules()}
+    # the depthwise convolution of an SS2D block is not a torch call either: csrc/ss2d_dwconv.hip reads its fp32 weight (an fp16
+    # shadow was cast straight back to fp32 there: 248 launches per SSND2Net step)
+    from .nets.m2net import SS2D
+    skip |= {id(root.conv2d) for root in network.modules() if isinstance(root, SS2D) and hasattr(root, "conv2d")}
+    from .nets.ssnd import SSND
+    skip |= {id(root.convnd.conv) for root in network.modules()
+             if isinstance(root, SSND) and root.spatial_dims == 2 and hasattr(root.convnd, "conv")}
     names, params = [], []
     for mname, m in network.named_modules():
         if id(m) in skip or type(m) not in kinds:

@@ -208,7 +208,7 @@ def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
     b = synthetic_batch(2, (128, 128), tr._get_deep_supervision_scales(), seed=3)
     b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
     losses, scales = [], []
-    nsteps = 56
+    nsteps = 96
     for _ in range(nsteps):
         losses.append(float(tr.train_step(b)["loss"]))
         scales.append(float(tr.grad_scaler.get_scale()))
@@ -216,4 +216,6 @@ def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
     applied = [i for i in range(1, nsteps) if scales[i] >= scales[i - 1]]    # steps whose update was applied (no back-off)
     assert len(applied) >= 10, scales
     first = applied[0]
-    assert np.mean(losses[-3:]) < losses[first] - 0.05, (losses, scales)
+    # (window means: single losses scatter by +-0.08 from step to step - stochastic depth on a chaotic net - and 56 steps with a
+    #  3-loss window failed one run in three on a margin of 0.02)
+    assert np.mean(losses[-8:]) < np.mean(losses[first:first + 8]) - 0.05, (losses, scales)
