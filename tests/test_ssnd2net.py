@@ -208,7 +208,7 @@ def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
     b = synthetic_batch(2, (128, 128), tr._get_deep_supervision_scales(), seed=3)
     b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
     losses, scales = [], []
-    nsteps = 96
+    nsteps = 160
     for _ in range(nsteps):
         losses.append(float(tr.train_step(b)["loss"]))
         scales.append(float(tr.grad_scaler.get_scale()))
@@ -216,6 +216,9 @@ def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
     applied = [i for i in range(1, nsteps) if scales[i] >= scales[i - 1]]    # steps whose update was applied (no back-off)
     assert len(applied) >= 10, scales
     first = applied[0]
-    # (window means: single losses scatter by +-0.08 from step to step - stochastic depth on a chaotic net - and 56 steps with a
-    #  3-loss window failed one run in three on a margin of 0.02)
-    assert np.mean(losses[-8:]) < np.mean(losses[first:first + 8]) - 0.05, (losses, scales)
+    # (window means: single losses scatter by +-0.08 from step to step - stochastic depth on a chaotic net.  56 steps with a
+    #  3-loss window failed one run in three, 96 steps with 8-loss windows one run in twelve on a margin of 0.003: at lr 1e-4 the
+    #  first 70 applied steps move the loss by ~0.05.  160 steps, 12-loss windows, and the printed numbers for the record.)
+    early, late = float(np.mean(losses[first:first + 12])), float(np.mean(losses[-12:]))
+    print(f"SSND2NetP 128^2: first applied step {first}, loss {early:.4f} -> {late:.4f} over {nsteps - first} applied steps")
+    assert late < early - 0.04, (losses, scales)
