@@ -50,6 +50,8 @@ int nnz_conv_tap_forward_stats(const void* in_f16, void* out_f16, const void* w_
  * knob 3 = workgroup order: cout block fastest (1, default) or m-tile fastest (0),
  * knob 4 = smallest Cin for knob 1 (default 32).  Process-wide. */
 int nnz_conv_tuning(int knob, int value);
+/* the current value of a knob (0 for an unknown one) */
+int nnz_conv_tuning_get(int knob);
 
 int nnz_conv_tap_wgrad(const void* boxed_f16, const void* plain_f16, float* dw /* [T][A][B] */,
                        const nnz_conv_desc* desc, int dw_pre_zeroed, void* stream);

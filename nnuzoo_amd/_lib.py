@@ -65,6 +65,7 @@ SIGNATURES = {
     "nnz_conv_tap_forward": [_vp, _vp, _vp, _fp, _dp, _vp],
     "nnz_conv_tap_forward_stats": [_vp, _vp, _vp, _fp, _dp, _fp, _vp],
     "nnz_conv_tuning": [_i, _i],
+    "nnz_conv_tuning_get": [_i],
     "nnz_conv_tap_wgrad": [_vp, _vp, _fp, _dp, _i, _vp],
     "nnz_conv_tap_wgrad_workspace_floats": [_dp],
     "nnz_conv_tap_wgrad_to_grad": [_vp, _vp, _fp, _l, _fp, _l, _l, _l, _ip, _i, _dp, _vp],

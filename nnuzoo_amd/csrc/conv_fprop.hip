@@ -1496,6 +1496,9 @@ static int conv_tap_forward_impl(const void* in, void* out, const void* w_packed
                                  float* workspace = nullptr, long ws_floats = 0, const NormRedArgs* nr = nullptr,
                                  const InNormArgs* inn = nullptr);
 
+// read-back (tests restore a knob they changed; conv_wgrad.hip's experiment build reads the timestamp buffer's address)
+extern "C" int nnz_conv_tuning_get(int knob) { return knob >= 0 && knob < 16 ? nnz::g_tuning[knob] : 0; }
+
 extern "C" int nnz_conv_tuning(int knob, int value) {
   if (knob < 0 || knob >= 16) return NNZ_EINVAL;
   nnz::g_tuning[knob] = value;

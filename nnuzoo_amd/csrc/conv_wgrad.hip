@@ -19,6 +19,13 @@
 
 namespace nnz {
 
+// -DNNZ_WGRAD_TIMESTAMPS=1 (tools/probes/conv_phase_probe.py --wgrad; never the shipped library): thread 0 of every workgroup
+// accumulates s_memtime differences per phase over its tiles and writes ts[workgroup][8] = {set-up, wait + stage, issuing the next
+// tile's loads, MFMA loop, flush, tiles} at the end - buffer address = conv tuning knobs 12 (low) / 13 (high)
+#ifndef NNZ_WGRAD_TIMESTAMPS
+#define NNZ_WGRAD_TIMESTAMPS 0
+#endif
+extern "C" int nnz_conv_tuning_get(int knob);
 struct WgradDev {
   const f16* p;  // boxed operand
   const f16* q;  // plain operand
@@ -40,6 +47,9 @@ struct WgradDev {
   int p_c0, q_c0;
   float p_slope, q_slope;
   unsigned p_bytes, q_bytes;  // extents of the operands for the staging loads' buffer descriptors (launcher; < 2^32 - 16)
+#if NNZ_WGRAD_TIMESTAMPS
+  unsigned long long* ts;
+#endif
 };
 
 // Box geometry policies (same split as conv_fprop.hip): compile-time isotropic stride/extent for the 3-D plans the
@@ -274,13 +284,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     }
   };
 
+#if NNZ_WGRAD_TIMESTAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0}, n_tiles = 0;
+#define NNZ_WTS(k) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[k] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define NNZ_WTS(k) do {} while (0)
+#endif
   int tile = split;
   if (tile < ntiles) issue_loads(tile);
+  NNZ_WTS(0);
   for (; tile < ntiles; tile += splits) {
     __syncthreads();
     write_lds(tile);
     __syncthreads();
+    NNZ_WTS(1);
     if (tile + splits < ntiles) issue_loads(tile + splits);
+    NNZ_WTS(2);
 
     for (int kb = 0; kb < C::KB; ++kb) {
       // voxel of (kb, kk = 8*hh + 4*s + qrow): two h-rows of 8 w per k-block
@@ -311,6 +330,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) acc[i] = mfma32(xa[i], bq, acc[i]);
     }
+#if NNZ_WGRAD_TIMESTAMPS
+    n_tiles += 1;
+#endif
+    NNZ_WTS(3);
   }
 
   // ---- flush: D[row = a][col = b]; row = (r&3) + 8(r>>2) + 4hh, col = lane&31 -----------------------
@@ -339,6 +362,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
       }
     }
   }
+#if NNZ_WGRAD_TIMESTAMPS
+  NNZ_WTS(4);
+  if (p.ts && threadIdx.x == 0) {
+    unsigned long long* o = p.ts + (size_t)blockIdx.x * 8;
+    for (int k = 0; k < 5; ++k) o[k] = t_acc[k];
+    o[5] = n_tiles;
+  }
+#endif
 }
 
 struct WgLaunchOpt {
@@ -383,6 +414,9 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchO
   }
   p.splits = best;
   const int splits = best;
+#if NNZ_WGRAD_TIMESTAMPS
+  p.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)nnz_conv_tuning_get(13) << 32) | (unsigned)nnz_conv_tuning_get(12));
+#endif
   {
     const unsigned long long pb = 2ull * p.d.N * p.d.in_dims[0] * p.d.in_dims[1] * p.d.in_dims[2] * (unsigned long long)p.d.ldi;
     const unsigned long long qb = 2ull * p.d.N * p.d.out_dims[0] * p.d.out_dims[1] * p.d.out_dims[2] * (unsigned long long)p.d.ldo;

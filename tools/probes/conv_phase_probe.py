@@ -23,6 +23,95 @@ TS_DIR = os.path.join(ROOT, "tools", "probes", "_ts")
 TS_LIB = os.path.join(TS_DIR, "libnnuzoo_hip_ts.so")
 
 
+def build_wgrad():
+    """the product objects + csrc/conv_wgrad.hip under -DNNZ_WGRAD_TIMESTAMPS=1 -> tools/probes/_ts/libnnuzoo_hip_wts.so"""
+    from nnuzoo_amd import build as B
+    B.build(verbose=False)
+    os.makedirs(TS_DIR, exist_ok=True)
+    obj = os.path.join(TS_DIR, "wts_conv_wgrad.o")
+    subprocess.run([B.HIPCC, *B._flags("conv_wgrad.hip"), "-DNNZ_WGRAD_TIMESTAMPS=1", "-c", os.path.join(B.CSRC, "conv_wgrad.hip"),
+                    "-o", obj], check=True)
+    objs = [os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B._sources() if s != "conv_wgrad.hip"] + [obj]
+    lib = os.path.join(TS_DIR, "libnnuzoo_hip_wts.so")
+    subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
+    print("built", lib)
+    return lib
+
+
+def wgrad_phases(a):
+    """per-phase cycle totals of the weight-gradient workgroups (thread 0, summed over the workgroup's tiles)"""
+    lib = os.path.join(TS_DIR, "libnnuzoo_hip_wts.so")
+    if not os.path.exists(lib):
+        build_wgrad()
+    import torch
+    from nnuzoo_amd import _lib
+    _lib.LIB_PATH = lib
+    from nnuzoo_amd import conv_plan as cp
+    from nnuzoo_amd import hip_ops as ops
+    from nnuzoo_amd.hip_ops import PreparedTable
+    dev = torch.device("cuda")
+    N = 2
+    ts = torch.zeros(1 << 14, 8, dtype=torch.int64, device=dev)
+    addr = ts.data_ptr()
+
+    def arm(on):
+        lo, hi = (addr & 0xFFFFFFFF, addr >> 32) if on else (0, 0)
+        _lib.call("nnz_conv_tuning", 12, lo - (1 << 32) if lo >= (1 << 31) else lo)
+        _lib.call("nnz_conv_tuning", 13, hi)
+
+    layers = [("enc0.1", 32, 32, 128, 1), ("dec0.0", 64, 32, 128, 1), ("enc1.1", 64, 64, 64, 1), ("dec1.0", 128, 64, 64, 1),
+              ("enc2.1", 128, 128, 32, 1), ("enc1.0", 32, 64, 128, 2)]
+    names = ["set-up + first loads issued", "wait + stage (2 barriers)", "issue next tile's loads", "MFMA loop", "flush"]
+    for name, cin, cout, edge, stride in layers:
+        if a.only and a.only not in name:
+            continue
+        dims = (edge,) * 3
+        od = cp.conv_out_dims(dims, (3, 3, 3), stride)
+        V, Vo = edge ** 3, int(np.prod(od))
+        x = torch.randn(N, V, cin, device=dev).to(torch.float16)
+        dy = torch.randn(N, Vo, cout, device=dev).to(torch.float16)
+        w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
+        gw = torch.empty_like(w)
+        tab = torch.randn(N, cin, 4, device=dev)
+        tab[:, :, 2] = 1.0 + 0.1 * tab[:, :, 2]
+        inn = ops.InNorm(tab, 0.01)
+        pw = PreparedTable(cp.conv_wgrad(N, dims, cin, cout, stride=stride))
+        ws = torch.empty(ops.conv_tap_wgrad_workspace_floats(pw), device=dev, dtype=torch.float32)
+        runs = {"plain": lambda: ops.conv_tap_wgrad_to_grad(pw, x, dy, ws, gw, 27, cin * 27, 1)}
+        if stride == 1:
+            pwf = PreparedTable(cp.conv_wgrad_flipped(N, dims, cin, cout))
+            runs["step form (flipped, plain operand normalised)"] = \
+                lambda: ops.conv_tap_wgrad_to_grad(pwf, dy, x, ws, gw, cin * 27, 27, 1, plain_norm=inn)
+        else:
+            runs["step form (boxed operand normalised)"] = lambda: ops.conv_tap_wgrad_to_grad(pw, x, dy, ws, gw, 27, cin * 27, 1, boxed_norm=inn)
+        for what, fn in runs.items():
+            arm(False)
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(5):
+                fn()
+            e0.record()
+            torch.cuda.synchronize()
+            wall = s0.elapsed_time(e0) / 5 * 1e3
+            ts.zero_()
+            arm(True)
+            fn()
+            torch.cuda.synchronize()
+            arm(False)
+            t = ts.cpu().numpy().astype(np.float64)
+            t = t[t[:, 5] > 0]
+            tot = t[:, :5].sum(1)
+            print(f"\n{name} {cin}->{cout} @{edge} s{stride}  wgrad {what}: {len(t)} workgroups x {t[:, 5].mean():.1f} tiles, wall {wall:.1f} us "
+                  f"(kernel + fold), mean workgroup lifetime {tot.mean():.0f} ticks")
+            for k, nm in enumerate(names):
+                per = t[:, k].mean() / (t[:, 5].mean() if k in (1, 2, 3) else 1.0)
+                print(f"   {nm:30s} {t[:, k].mean():10.0f} ticks  {100 * t[:, k].mean() / tot.mean():5.1f} %"
+                      + (f"   ({per:.0f} per tile)" if k in (1, 2, 3) else ""))
+
+
 def build(defines=("-DNNZ_CONV_TIMESTAMPS=1",), lib=TS_LIB):
     """the product objects + csrc/conv_fprop.hip recompiled with `defines` -> `lib` (experiment builds; NNZ_HIP_LIBRARY=<lib> makes
     any tool of the repo load it)"""
@@ -40,10 +129,17 @@ def build(defines=("-DNNZ_CONV_TIMESTAMPS=1",), lib=TS_LIB):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
+    ap.add_argument("--wgrad", action="store_true", help="phase totals of the weight-gradient kernel (-DNNZ_WGRAD_TIMESTAMPS build)")
     ap.add_argument("--build-variant", default="", help="name=-DFLAG[,-DFLAG...]: tools/probes/_ts/libnnuzoo_hip_<name>.so with these defines")
     ap.add_argument("--only", default="")
     ap.add_argument("--tuning", default="")
     a = ap.parse_args()
+    if a.wgrad:
+        if a.build:
+            build_wgrad()
+        else:
+            wgrad_phases(a)
+        return
     if a.build_variant:
         name, flags = a.build_variant.split("=", 1)
         build(tuple(flags.split(",")), os.path.join(TS_DIR, f"libnnuzoo_hip_{name}.so"))
