@@ -25,6 +25,9 @@ namespace nnz {
 #ifndef NNZ_WGRAD_TIMESTAMPS
 #define NNZ_WGRAD_TIMESTAMPS 0
 #endif
+#ifndef NNZ_WGRAD_AHEAD
+#define NNZ_WGRAD_AHEAD 3   // fragments requested ahead of the MFMA that consumes them (AHEAD + 1 register buffers)
+#endif
 extern "C" int nnz_conv_tuning_get(int knob);
 struct WgradDev {
   const f16* p;  // boxed operand
@@ -190,21 +193,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
   unsigned bmask = 0, qmask = 0;   // pieces of the prefetched tile that came from memory (the others are zero padding)
   bool ppad = false, qpad = false;  // the prefetched box / tile has pieces outside the volume (uniform over the workgroup)
 
-  auto issue_loads = [&](int tile) {
+  // The prefetch of a tile = prep_tile (uniform values of the tile) + one issue_piece per 16-byte piece of the thread.  Inside the
+  // tile loop the pieces of the NEXT tile are issued one by one between the MFMAs of the current one: issued as a block of 14
+  // in front of the MFMA loop they took 3 000-3 700 clocks per tile waiting for vector-memory queue slots - not for their address
+  // arithmetic, see profiles/r04_wgrad_phases.txt - during which the wave issued nothing else.
+  int t_n = 0, t_m0d = 0, t_m0h = 0, t_m0w = 0, t_lod = 0, t_loh = 0, t_low = 0;
+  bool t_live = false;
+  auto prep_tile = [&](int tile, bool live) {
     bmask = qmask = 0;
-    const int n = tile / tiles_per_n;
-    int r = tile - n * tiles_per_n;
+    t_live = live;
+    t_n = tile / tiles_per_n;
+    int r = tile - t_n * tiles_per_n;
     const int tw_i = r % tiles2;
     r /= tiles2;
     const int th_i = r % tiles1;
     const int td_i = r / tiles1;
-    const int m0d = td_i * TD, m0h = th_i * TH, m0w = tw_i * TW;
-    const int lod = m0d * ISD + lo0, loh = m0h * ISH + lo1, low = m0w * ISW + lo2;
-    ppad = lod < 0 || loh < 0 || low < 0 || lod + gBD > Di || loh + gBH > Hi || low + gBW > Wi;
-    qpad = m0d + TD > Dm || m0h + TH > Hm || m0w + TW > Wm || (m0d + TD - 1) * os0 + oo0 >= Do ||
-           (m0h + TH - 1) * os1 + oo1 >= Ho || (m0w + TW - 1) * os2 + oo2 >= Wo;
-#pragma unroll
-    for (int i = 0; i < LPT_BOX; ++i) {
+    t_m0d = td_i * TD, t_m0h = th_i * TH, t_m0w = tw_i * TW;
+    t_lod = t_m0d * ISD + lo0, t_loh = t_m0h * ISH + lo1, t_low = t_m0w * ISW + lo2;
+    ppad = t_lod < 0 || t_loh < 0 || t_low < 0 || t_lod + gBD > Di || t_loh + gBH > Hi || t_low + gBW > Wi;
+    qpad = t_m0d + TD > Dm || t_m0h + TH > Hm || t_m0w + TW > Wm || (t_m0d + TD - 1) * os0 + oo0 >= Do ||
+           (t_m0h + TH - 1) * os1 + oo1 >= Ho || (t_m0w + TW - 1) * os2 + oo2 >= Wo;
+  };
+  constexpr int NPIECES = LPT_BOX + C::LPT_Q;
+  auto issue_piece = [&](int j) {   // j is a compile-time constant at every call site
+    if (j < LPT_BOX) {
+      const int i = j;
       const int c = tid + i * 256;
       const int part = c & 3;
       const int s = c >> 2;
@@ -213,24 +226,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
       const int bd = s / (gBW * gBH);
       const int hw = (gBW + 1) >> 1;
       const int bw = ISW == 2 ? (bwl < hw ? 2 * bwl : 2 * (bwl - hw) + 1) : bwl;
-      const int id = lod + bd, ih = loh + bh, iw = low + bw;
-      const bool ok = (c < gNBOXLOAD) & ((unsigned)id < (unsigned)Di) & ((unsigned)ih < (unsigned)Hi) & ((unsigned)iw < (unsigned)Wi);
-      const unsigned off = ((unsigned)((((n * Di + id) * Hi + ih) * Wi + iw) * ldi) + part * 8) * 2u;
+      const int id = t_lod + bd, ih = t_loh + bh, iw = t_low + bw;
+      const bool ok = t_live & (c < gNBOXLOAD) & ((unsigned)id < (unsigned)Di) & ((unsigned)ih < (unsigned)Hi) & ((unsigned)iw < (unsigned)Wi);
+      const unsigned off = ((unsigned)((((t_n * Di + id) * Hi + ih) * Wi + iw) * ldi) + part * 8) * 2u;
       breg[i] = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)(ok ? off : OOB), 0, 0);
       bmask |= ok ? 1u << i : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < C::LPT_Q; ++i) {
+    } else {
+      const int i = j - LPT_BOX;
       const int c = tid + i * 256;
       const int part = c & 3;
       const int s = c >> 2;
       const int tw = s % TW, th = (s / TW) % TH, td = s / (TW * TH);
-      const int md = m0d + td, mh = m0h + th, mw = m0w + tw;
+      const int md = t_m0d + td, mh = t_m0h + th, mw = t_m0w + tw;
       const int od = md * os0 + oo0;
       const int oh = mh * os1 + oo1;
       const int ow = mw * os2 + oo2;
-      const bool ok = (c < C::NQLOAD) & (md < Dm) & (mh < Hm) & (mw < Wm) & (od < Do) & (oh < Ho) & (ow < Wo);
-      const unsigned off = ((unsigned)((((n * Do + od) * Ho + oh) * Wo + ow) * ldo) + part * 8) * 2u;
+      const bool ok = t_live & (c < C::NQLOAD) & (md < Dm) & (mh < Hm) & (mw < Wm) & (od < Do) & (oh < Ho) & (ow < Wo);
+      const unsigned off = ((unsigned)((((t_n * Do + od) * Ho + oh) * Wo + ow) * ldo) + part * 8) * 2u;
       qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, (int)(ok ? off : OOB), 0, 0);
       qmask |= ok ? 1u << i : 0u;
     }
@@ -286,49 +298,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
 
 #if NNZ_WGRAD_TIMESTAMPS
   unsigned long long t_prev = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0}, n_tiles = 0;
+  const unsigned long long t_start = wall_clock64();
 #define NNZ_WTS(k) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[k] += t_now - t_prev; t_prev = t_now; } while (0)
 #else
 #define NNZ_WTS(k) do {} while (0)
 #endif
   int tile = split;
-  if (tile < ntiles) issue_loads(tile);
+  prep_tile(tile < ntiles ? tile : 0, tile < ntiles);
+#pragma unroll
+  for (int j = 0; j < NPIECES; ++j) issue_piece(j);
   NNZ_WTS(0);
   for (; tile < ntiles; tile += splits) {
     __syncthreads();
     write_lds(tile);
     __syncthreads();
     NNZ_WTS(1);
-    if (tile + splits < ntiles) issue_loads(tile + splits);
+    // a workgroup's last tile "prefetches" with every piece marked absent (offset beyond the extent: no memory traffic)
+    prep_tile(tile + splits < ntiles ? tile + splits : 0, tile + splits < ntiles);
     NNZ_WTS(2);
 
-    for (int kb = 0; kb < C::KB; ++kb) {
-      // voxel of (kb, kk = 8*hh + 4*s + qrow): two h-rows of 8 w per k-block
-      const int v0 = kb * 16 + 8 * hh;  // first voxel of this lane-half's row; tw = 4*s + qrow
-      const int th = (v0 / TW) % TH, td = v0 / (TW * TH);
-      const int qbase = (v0 + qrow) * 64 + chan_byte;
-      const i16x4 q0 = lds_read_tr16(qt + qbase);
-      const i16x4 q1 = lds_read_tr16(qt + qbase + 4 * 64);
-      f16x8 bq;
-      {
+    // The tile's KB k-blocks x MAXT tap slots as ONE sequence of fragments s = kb * MAXT + i, software-pipelined by hand: fragment
+    // s + 3 is requested (two transposed reads into buffer (s + 3) & 3) right before the MFMA of fragment s is issued, so every
+    // MFMA waits for reads that are three MFMAs old.  Left to itself the scheduler kept two fragments in flight and waited with
+    // lgkmcnt(1) / (2) in front of every MFMA, draining to lgkmcnt(0) every second k-block: the loop took 7 000 clocks per tile
+    // for 3 600 clocks of MFMA issue, with or without a second workgroup on the CU (profiles/r04_wgrad_phases.txt).
+    // Voxel of (kb, kk = 8*hh + 4*s + qrow): two h-rows of 8 w per k-block -> td = kb / (TH/2), th = 2 (kb % (TH/2)) + hh.
+    // A tap slot beyond the wave's taps re-reads tap offset 0 and is never flushed.
+    {
+      constexpr int S = C::KB * MAXT, AHEAD = NNZ_WGRAD_AHEAD, NXB = AHEAD + 1;
+      constexpr int NBQ = MAXT > AHEAD ? 2 : 4;   // k-blocks whose plain-operand fragment is live at once: the current one and those the look-ahead reaches
+      static_assert(MAXT > AHEAD || (AHEAD + MAXT - 1) / MAXT + 1 <= NBQ, "plain-operand buffers");
+      static_assert(TH % 2 == 0 && S > AHEAD, "k-block map");
+      static_assert(NPIECES <= 2 * S, "at most two pieces of the next tile per fragment");
+      const char* xlane = box + ((hh * ISH * gBW + qrow) * 64 + chan_byte);
+      const char* qlane = qt + ((8 * hh + qrow) * 64 + chan_byte);
+      auto rd_q = [&](int kb) {
         union { i16x4 v[2]; f16x8 h; } u;
-        u.v[0] = q0;
-        u.v[1] = q1;
-        bq = u.h;
-      }
-      const int bbase = ((((td * ISD) * gBH + th * ISH) * gBW) + qrow) * 64 + chan_byte;
-      // branch-free over the wave's MAXT tap slots (a slot beyond the wave's taps re-reads tap offset 0 and is
-      // never flushed): all 2*MAXT transposed reads issue back to back ahead of the MFMAs instead of one
-      // read->wait->MFMA chain per tap (SQ_WAIT_INST_ANY was 36-58 % of the wave cycles with the guarded loop)
-      f16x8 xa[MAXT];
-#pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
+        u.v[0] = lds_read_tr16(qlane + kb * 1024);
+        u.v[1] = lds_read_tr16(qlane + kb * 1024 + 4 * 64);
+        return u.h;
+      };
+      auto rd_x = [&](int f) {
+        const int kb = f / MAXT, i = f % MAXT;
+        const int koff = (((kb / (TH / 2)) * ISD * gBH + 2 * (kb % (TH / 2)) * ISH) * gBW) * 64;
         union { i16x4 v[2]; f16x8 h; } u;
-        u.v[0] = lds_read_tr16(box + bbase + tap_off[i]);
-        u.v[1] = lds_read_tr16(box + bbase + tap_off[i] + 4 * 64);
-        xa[i] = u.h;
-      }
+        u.v[0] = lds_read_tr16(xlane + koff + tap_off[i]);
+        u.v[1] = lds_read_tr16(xlane + koff + tap_off[i] + 4 * 64);
+        return u.h;
+      };
+      f16x8 xb[NXB], bqb[NBQ];
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i) acc[i] = mfma32(xa[i], bq, acc[i]);
+      for (int f = 0; f < AHEAD; ++f) {
+        if (f % MAXT == 0) bqb[(f / MAXT) % NBQ] = rd_q(f / MAXT);
+        xb[f % NXB] = rd_x(f);
+      }
+#pragma clang loop unroll(full)
+      for (int f = 0; f < S; ++f) {
+        const int kb = f / MAXT, i = f % MAXT;
+        if (f + AHEAD < S) {
+          if ((f + AHEAD) % MAXT == 0) bqb[((f + AHEAD) / MAXT) % NBQ] = rd_q((f + AHEAD) / MAXT);
+          xb[(f + AHEAD) % NXB] = rd_x(f + AHEAD);
+          __builtin_amdgcn_sched_barrier(0);   // the reads go out BEFORE the MFMA (the scheduler put them behind it)
+        }
+        acc[i] = mfma32(xb[f % NXB], bqb[kb % NBQ], acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's pieces, spread evenly over the sequence
+        if (((f + 1) * NPIECES) / S > (f * NPIECES) / S) issue_piece((f * NPIECES) / S);
+        if (((f + 1) * NPIECES) / S > (f * NPIECES) / S + 1) issue_piece((f * NPIECES) / S + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #if NNZ_WGRAD_TIMESTAMPS
     n_tiles += 1;
@@ -368,6 +406,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     unsigned long long* o = p.ts + (size_t)blockIdx.x * 8;
     for (int k = 0; k < 5; ++k) o[k] = t_acc[k];
     o[5] = n_tiles;
+    // where the workgroup ran: HW_ID (id 4: cu_id bits 11:8, sh_id 12, se_id 15:13) and XCC_ID (id 20), full registers
+    o[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    o[7] = t_start;
   }
 #endif
 }
@@ -414,6 +455,10 @@ static int launch_wg_t(const WgradDev& base, hipStream_t stream, const WgLaunchO
   }
   p.splits = best;
   const int splits = best;
+  // Measured on the finished loop and dropped (profiles/r04_wgrad_phases.txt): (1) idling the second workgroup of every CU -
+  // blockIdx b and b + 256, confirmed from HW_ID - for half an MFMA loop at its start so that the two alternate between MFMA loop
+  // and staging; (2) an XCD-aware tile order (each XCD walks a contiguous eighth of every round of tiles, so that a box's halo is
+  // found in the XCD's own L2).  Neither moved the kernel or the step.
 #if NNZ_WGRAD_TIMESTAMPS
   p.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)nnz_conv_tuning_get(13) << 32) | (unsigned)nnz_conv_tuning_get(12));
 #endif

@@ -53,6 +53,9 @@ def wgrad_phases(a):
     N = 2
     ts = torch.zeros(1 << 14, 8, dtype=torch.int64, device=dev)
     addr = ts.data_ptr()
+    sweeps = [()]
+    if a.tuning:      # 'k=v,k=v;k=v,...': one table per ';'-separated setting
+        sweeps = [tuple((int(kv.split("=")[0]), int(kv.split("=")[1])) for kv in st.split(",") if kv) for st in a.tuning.split(";")]
 
     def arm(on):
         lo, hi = (addr & 0xFFFFFFFF, addr >> 32) if on else (0, 0)
@@ -84,7 +87,11 @@ def wgrad_phases(a):
                 lambda: ops.conv_tap_wgrad_to_grad(pwf, dy, x, ws, gw, cin * 27, 27, 1, plain_norm=inn)
         else:
             runs["step form (boxed operand normalised)"] = lambda: ops.conv_tap_wgrad_to_grad(pw, x, dy, ws, gw, 27, cin * 27, 1, boxed_norm=inn)
-        for what, fn in runs.items():
+        for what, fn, sweep in [(w_, f_, s_) for w_, f_ in runs.items() for s_ in sweeps]:
+            for k, v in sweep:
+                _lib.call("nnz_conv_tuning", k, v)
+            if sweep:
+                what = f"{what} [knobs {sweep}]"
             arm(False)
             for _ in range(3):
                 fn()
@@ -110,6 +117,25 @@ def wgrad_phases(a):
                 per = t[:, k].mean() / (t[:, 5].mean() if k in (1, 2, 3) else 1.0)
                 print(f"   {nm:30s} {t[:, k].mean():10.0f} ticks  {100 * t[:, k].mean() / tot.mean():5.1f} %"
                       + (f"   ({per:.0f} per tile)" if k in (1, 2, 3) else ""))
+            if a.residency:
+                # which workgroups shared a CU: (XCC, SE, SH, CU) from the hardware-id registers the workgroup read at its end
+                raw = ts.cpu().numpy()
+                live = np.nonzero(raw[:, 5] > 0)[0]
+                hw = raw[live, 6].astype(np.uint64)
+                xcc, hwid = (hw >> np.uint64(32)) & np.uint64(0xF), hw & np.uint64(0xFFFFFFFF)
+                cu = (xcc << np.uint64(8)) | ((hwid >> np.uint64(8)) & np.uint64(0xFF))
+                groups = {}
+                for b, c in zip(live, cu):
+                    groups.setdefault(int(c), []).append(int(b))
+                sizes = np.bincount([len(v) for v in groups.values()])
+                diffs = np.bincount([abs(v[1] - v[0]) for v in groups.values() if len(v) == 2])
+                top = np.argsort(-diffs)[:4]
+                print(f"   residency: {len(groups)} distinct CUs; workgroups per CU histogram {dict(enumerate(sizes.tolist()))}; "
+                      f"blockIdx distance of the pairs: {[(int(d), int(diffs[d])) for d in top if diffs[d]]}")
+                st = raw[live, 7].astype(np.float64)
+                print(f"   start spread over the launch (100 MHz clock): {(st.max() - st.min()) / 100:.1f} us")
+            for k, v in sweep:
+                _lib.call("nnz_conv_tuning", k, 0)
 
 
 def build(defines=("-DNNZ_CONV_TIMESTAMPS=1",), lib=TS_LIB):
@@ -132,7 +158,8 @@ def main():
     ap.add_argument("--wgrad", action="store_true", help="phase totals of the weight-gradient kernel (-DNNZ_WGRAD_TIMESTAMPS build)")
     ap.add_argument("--build-variant", default="", help="name=-DFLAG[,-DFLAG...]: tools/probes/_ts/libnnuzoo_hip_<name>.so with these defines")
     ap.add_argument("--only", default="")
-    ap.add_argument("--tuning", default="")
+    ap.add_argument("--tuning", default="", help="k=v[,k=v]: conv tuning knobs; --wgrad: ';' separates settings that are measured in turn")
+    ap.add_argument("--residency", action="store_true", help="--wgrad: report which workgroups shared a CU")
     a = ap.parse_args()
     if a.wgrad:
         if a.build:
