@@ -45,7 +45,12 @@ struct TapDev {
 #if NNZ_CONV_TIMESTAMPS
 #define NNZ_TS(slot)                                                                                   \
   do {                                                                                                 \
-    if (p.ts && threadIdx.x == 0 && (slot) < 16) p.ts[(long)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    if (p.ts && threadIdx.x == 0 && (slot) < 16) {                                                     \
+      p.ts[(long)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();                             \
+      /* slot 15 (launches of <= 2 slices): the workgroup's lifetime on the constant 100 MHz clock -> in-kernel shader clock */ \
+      if ((slot) == 0) p.ts[(long)blockIdx.x * 16 + 15] = wall_clock64();                              \
+      if ((slot) == 14) p.ts[(long)blockIdx.x * 16 + 15] = wall_clock64() - p.ts[(long)blockIdx.x * 16 + 15]; \
+    }                                                                                                  \
   } while (0)
 #else
 #define NNZ_TS(slot) do {} while (0)

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     o[5] = n_tiles;
     // where the workgroup ran: HW_ID (id 4: cu_id bits 11:8, sh_id 12, se_id 15:13) and XCC_ID (id 20), full registers
     o[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-    o[7] = t_start;
+    o[7] = wall_clock64() - t_start;   // lifetime on the constant 100 MHz clock -> in-kernel shader clock = sum of the phases / this
   }
 #endif
 }

@@ -11,6 +11,7 @@ reductions; both also plain).  Slots (conv_fprop.hip NNZ_TS):
 transposed into LDS, 13 statistics / reductions done, 14 stores issued.  Printed: mean cycles per phase over the workgroups, the
 share of the workgroup's lifetime, and the launch's wall time against (workgroups / 512 resident) x mean lifetime."""
 import argparse
+import time
 import os
 import subprocess
 import sys
@@ -103,6 +104,12 @@ def wgrad_phases(a):
             e0.record()
             torch.cuda.synchronize()
             wall = s0.elapsed_time(e0) / 5 * 1e3
+            if a.clock:     # DVFS steady state: back-to-back launches for a.clock seconds before the stamped one
+                t_end = time.time() + a.clock
+                while time.time() < t_end:
+                    for _ in range(50):
+                        fn()
+                    torch.cuda.synchronize()
             ts.zero_()
             arm(True)
             fn()
@@ -132,8 +139,10 @@ def wgrad_phases(a):
                 top = np.argsort(-diffs)[:4]
                 print(f"   residency: {len(groups)} distinct CUs; workgroups per CU histogram {dict(enumerate(sizes.tolist()))}; "
                       f"blockIdx distance of the pairs: {[(int(d), int(diffs[d])) for d in top if diffs[d]]}")
-                st = raw[live, 7].astype(np.float64)
-                print(f"   start spread over the launch (100 MHz clock): {(st.max() - st.min()) / 100:.1f} us")
+                pass
+            real = ts.cpu().numpy()[:, 7].astype(np.float64)[ts.cpu().numpy()[:, 5] > 0]
+            print(f"   in-kernel shader clock (phase ticks / lifetime on the 100 MHz clock, median over workgroups): "
+                  f"{np.median(tot / real * 0.1):.2f} GHz")
             for k, v in sweep:
                 _lib.call("nnz_conv_tuning", k, 0)
 
@@ -159,6 +168,8 @@ def main():
     ap.add_argument("--build-variant", default="", help="name=-DFLAG[,-DFLAG...]: tools/probes/_ts/libnnuzoo_hip_<name>.so with these defines")
     ap.add_argument("--only", default="")
     ap.add_argument("--tuning", default="", help="k=v[,k=v]: conv tuning knobs; --wgrad: ';' separates settings that are measured in turn")
+    ap.add_argument("--clock", type=float, default=0.0, help="seconds of back-to-back launches before the stamped one (DVFS steady state); "
+                    "the in-kernel clock is printed either way")
     ap.add_argument("--residency", action="store_true", help="--wgrad: report which workgroups shared a CU")
     a = ap.parse_args()
     if a.wgrad:
@@ -237,6 +248,12 @@ def main():
             e.record()
             torch.cuda.synchronize()
             wall = s.elapsed_time(e) / 5 * 1e3          # us, uninstrumented pointer (the branch is still compiled in)
+            if a.clock:     # DVFS steady state: back-to-back launches for a.clock seconds before the stamped one
+                t_end = time.time() + a.clock
+                while time.time() < t_end:
+                    for _ in range(50):
+                        fn()
+                    torch.cuda.synchronize()
             ts.zero_()
             arm(True)
             fn()
@@ -246,6 +263,9 @@ def main():
             live = t[:, 0] != 0
             t = t[live]
             nwg = len(t)
+            if (t[:, 15] > 0).all() and cin <= 32:   # <= 2 slices: slot 15 = lifetime on the constant 100 MHz clock
+                clk = np.median((t[:, 14] - t[:, 0]) / t[:, 15].astype(np.float64) * 0.1)
+                print(f"   [{what}] in-kernel shader clock (s_memtime ticks / 100 MHz lifetime, median over workgroups): {clk:.2f} GHz")
             life = (t[:, 14] - t[:, 0]).astype(np.float64)     # (the XCDs' counters are not synchronised: only differences
             used = [s_ for s_ in range(15) if (t[:, s_] != 0).all()]   #  inside one workgroup mean anything)
             used.sort(key=lambda s_: float((t[:, s_] - t[:, 0]).mean()))   # time order (slots 6..11 double as epilogue sub-phases)
