@@ -196,6 +196,9 @@ struct ConvCfg {
 //      against float64 on the stored outputs: mean 3e-6 like the VALU form, rstd within 1e-4 relative (VALU form 3e-6) -
 //      tests/test_determinism_gpu.py test_conv_epilogue_table_{large,small}_mean hold both forms.)
 //  12, 13  -DNNZ_CONV_TIMESTAMPS builds only: low / high half of the timestamp buffer's address
+#ifndef NNZ_SETPRIO
+#define NNZ_SETPRIO 0   // experiment: wave priority raised over the depth-reuse MFMA loop
+#endif
 #ifndef NNZ_DRE_PERSIST
 #define NNZ_DRE_PERSIST false
 #endif
@@ -657,6 +660,9 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       // compiler from sinking the reads next to their uses (it does, to save registers, and then every MFMA waits on
       // lgkmcnt(0) for a read issued just before it).
       f16x8 a0[3], a1[3], xa[3], xb[3];
+#if NNZ_SETPRIO
+      __builtin_amdgcn_s_setprio(NNZ_SETPRIO);
+#endif
       load_a(0, a0, xa);
 #pragma unroll
       for (int r = 0; r < 8; r += 2) {
@@ -681,6 +687,9 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
       __builtin_amdgcn_sched_barrier(0);
       mfma_half(a0, xa, 0);
       mfma_half(a0, xb, 3);
+#if NNZ_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     } else {
       // software pipeline over the taps: the LDS reads of tap t+1 are in flight while tap t's MFMAs issue
       f16x8 a0[C::WN], b0[C::WM], a1[C::WN], b1[C::WM];

@@ -25,6 +25,9 @@ namespace nnz {
 #ifndef NNZ_WGRAD_TIMESTAMPS
 #define NNZ_WGRAD_TIMESTAMPS 0
 #endif
+#ifndef NNZ_SETPRIO
+#define NNZ_SETPRIO 0   // experiment: wave priority raised over the MFMA sequence (measured: see profiles/r04_conv_ab_same_box.txt)
+#endif
 #ifndef NNZ_WGRAD_AHEAD
 #define NNZ_WGRAD_AHEAD 3   // fragments requested ahead of the MFMA that consumes them (AHEAD + 1 register buffers)
 #endif
@@ -347,6 +350,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         return u.h;
       };
       f16x8 xb[NXB], bqb[NBQ];
+#if NNZ_SETPRIO
+      __builtin_amdgcn_s_setprio(NNZ_SETPRIO);
+#endif
 #pragma unroll
       for (int f = 0; f < AHEAD; ++f) {
         if (f % MAXT == 0) bqb[(f / MAXT) % NBQ] = rd_q(f / MAXT);
@@ -367,6 +373,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
         if (((f + 1) * NPIECES) / S > (f * NPIECES) / S + 1) issue_piece((f * NPIECES) / S + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+#if NNZ_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
 #if NNZ_WGRAD_TIMESTAMPS
     n_tiles += 1;
