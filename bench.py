@@ -120,6 +120,48 @@ def cpu_scan_baseline(L: int = 8192):
                       f"sample - scan forward ONLY, an upper bound on any CPU step rate"}
 
 
+def cpu_m2net_step_baseline(budget_s: float = None):
+    """Full fp32 training step of the CPU oracle of M2Net (oracle/m2net.py, pinned by the reference's own whole-net outputs and
+    gradients: tests/test_oracle_m2net.py) - forward, deep-supervision Dice + CE, backward, clip, AdamW - on ONE patch: first at
+    64^2, then ("full step at 128^2") at 128^2 when 7 x the 64^2 time fits `budget_s` (NNZ_CPU_BASELINE_BUDGET_S,
+    default 150).  `value` extrapolates the largest size run to the 512^2 patch of the metric linearly in pixels - the scan's
+    time loop, which dominates, is linear in L; with that caveat."""
+    from oracle import m2net as om
+    from oracle.losses import deep_supervision_loss
+    from nnuzoo_amd.synthetic import synthetic_batch
+    if budget_s is None:
+        budget_s = float(os.environ.get("NNZ_CPU_BASELINE_BUDGET_S", "150"))
+    threads, logical = host_threads()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = om.M2Net(1, 2, True).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=5e-2, eps=1e-5)
+    scales = [[1, 1]] + [[1 / 2 ** i] * 2 for i in range(6)]
+
+    def step(size):
+        b = synthetic_batch(1, (size, size), scales, seed=7)
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss = deep_supervision_loss(list(net(b["data"])), b["target"], batch_dice=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+        opt.step()
+        return time.perf_counter() - t0
+
+    times = {64: step(64)}
+    if 7.0 * times[64] <= budget_s:
+        times[128] = step(128)
+    size = max(times)
+    dt = times[size]
+    return {"value": (1.0 / dt) * (size / 512.0) ** 2, "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": "CPU oracle of M2Net (plain torch fp32, selective_scan_ref semantics as a time loop), full train step "
+                      "(fwd + deep-supervision DC+CE + bwd + clip + AdamW) on one patch: "
+                      + ", ".join(f"{k}^2 in {v:.1f} s" for k, v in sorted(times.items()))
+                      + f"; value = the {size}^2 step extrapolated to one 512^2 patch linearly in pixels (the scan's time loop "
+                      f"dominates and is linear in L); torch {torch.__version__} CPU, {threads} threads ({logical} logical CPUs)",
+            "step_seconds": {str(k): round(v, 2) for k, v in times.items()}}
+
+
 def _profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     return json.load(open(path)) if os.path.exists(path) else None
@@ -555,7 +597,11 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             if "secondary" in line:
-                line["secondary"]["cpu_baseline"] = cpu_scan_baseline()
+                # the full oracle step (128^2 when the host finishes it inside the budget) with the forward-only scan figure
+                # at the metric's own sequence lengths beside it (SURVEY.md 8d asks for both)
+                sec = cpu_m2net_step_baseline()
+                sec["scan_forward_only"] = cpu_scan_baseline()
+                line["secondary"]["cpu_baseline"] = sec
         _emit(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()

@@ -1,0 +1,75 @@
+"""HIP M2NetP / M2Net against the CPU oracle (oracle/m2net.py, itself pinned by the reference's whole-net fixtures in
+tests/test_oracle_m2net.py) on the same seeded input and parameters in TRAINING mode - BatchNorm on batch statistics, which the
+eval-mode fixtures do not exercise - fp32, stochastic depth off.
+
+Training-mode BatchNorm over a handful of values (the 2x2 ... 4x4 maps of the deep stages, batch 2) is badly conditioned: the
+oracle itself answers a 1e-6 relative change of its input with up to 1e-4 (M2NetP 64^2) ... 5e-2 (M2Net 32^2) of an output's
+range, against 2e-6 ... 5e-6 in eval mode.  Every tolerance below is therefore the eval-mode one (5e-4 of the range, held by the
+fixture tests at that conditioning: ~100 x the oracle's own response) or 100 x the oracle's response measured here, whichever is
+larger; stage by stage - every U^2 stage fed the ORACLE's input, so nothing compounds - it stays near the eval-mode bound."""
+import pytest
+import torch
+
+from golden_util import det_fill
+
+pytestmark = pytest.mark.gpu
+PERT = 1e-6
+
+
+def _pair(name):
+    from oracle import m2net as om
+    from nnuzoo_amd.nets import m2net as pm
+    torch.manual_seed(0)
+    ref = getattr(om, name)(1, 2, True)
+    det_fill(ref)
+    net = getattr(pm, name)(1, 2, True)
+    net.load_state_dict(ref.state_dict())            # same names and shapes: the oracle's parameters load as they are
+    for m in list(ref.modules()) + list(net.modules()):
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+        if type(m).__name__ == "StochasticDepth":
+            m.p = 0.0
+    return ref.train(), net.cuda().train()
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+@pytest.mark.parametrize("name,size", [("M2NetP", 64), ("M2Net", 32)])
+def test_every_stage_in_training_mode_equals_the_oracle(hip_lib, name, size):
+    from nnuzoo_amd.synthetic import synthetic_batch
+    ref, net = _pair(name)
+    x = synthetic_batch(2, (size, size), [[1, 1]], seed=11)["data"]
+    seen = {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out, k=k: seen.__setitem__(k, (inp[0].detach(), out.detach())))
+             for k, m in ref.named_children() if k.startswith("stage")]
+    with torch.no_grad():
+        ref(x)
+    for h in hooks:
+        h.remove()
+    assert len(seen) == 11
+    report = []
+    for k, (inp, out) in seen.items():
+        with torch.no_grad():
+            sens = _rel(getattr(ref, k)(inp * (1 + PERT)), out)
+            got = getattr(net, k)(inp.cuda()).float().cpu()
+        err, tol = _rel(got, out), max(5e-4, 100 * sens)
+        report.append(f"{k}: err {err:.1e} (oracle's own response {sens:.1e}, tolerance {tol:.1e})")
+        assert err <= tol, report[-1]
+    print(f"{name} {size}^2 stages\n   " + "\n   ".join(report))
+
+
+def test_m2netp_training_mode_forward_equals_the_oracle(hip_lib):
+    """whole net, seven outputs (the backward of the whole net is held to the reference's own autograd by the eval-mode fixture,
+    tests/test_zoo_gpu.py::test_whole_net_backward_golden)"""
+    from nnuzoo_amd.synthetic import synthetic_batch
+    ref, net = _pair("M2NetP")
+    x = synthetic_batch(2, (64, 64), [[1, 1]], seed=11)["data"]
+    with torch.no_grad():
+        base = ref(x)
+        sens = [_rel(p, o) for p, o in zip(ref(x * (1 + PERT)), base)]
+    got = net(x.cuda().requires_grad_(True))      # with autograd recording, as the training step runs it
+    for i, (o, r) in enumerate(zip(got, base)):
+        err, tol = _rel(o.detach().float().cpu(), r), max(5e-4, 100 * sens[i])
+        assert err <= tol, (i, err, sens[i], tol)
