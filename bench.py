@@ -124,13 +124,13 @@ def cpu_m2net_step_baseline(budget_s: float = None):
     """Full fp32 training step of the CPU oracle of M2Net (oracle/m2net.py, pinned by the reference's own whole-net outputs and
     gradients: tests/test_oracle_m2net.py) - forward, deep-supervision Dice + CE, backward, clip, AdamW - on ONE patch: first at
     64^2, then ("full step at 128^2") at 128^2 when 7 x the 64^2 time fits `budget_s` (NNZ_CPU_BASELINE_BUDGET_S,
-    default 150).  `value` extrapolates the largest size run to the 512^2 patch of the metric linearly in pixels - the scan's
+    default 90).  `value` extrapolates the largest size run to the 512^2 patch of the metric linearly in pixels - the scan's
     time loop, which dominates, is linear in L; with that caveat."""
     from oracle import m2net as om
     from oracle.losses import deep_supervision_loss
     from nnuzoo_amd.synthetic import synthetic_batch
     if budget_s is None:
-        budget_s = float(os.environ.get("NNZ_CPU_BASELINE_BUDGET_S", "150"))
+        budget_s = float(os.environ.get("NNZ_CPU_BASELINE_BUDGET_S", "90"))
     threads, logical = host_threads()
     torch.set_num_threads(threads)
     torch.manual_seed(0)
