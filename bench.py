@@ -124,14 +124,15 @@ def cpu_m2net_step_baseline(budget_s: float = None):
     """Full fp32 training step of the CPU oracle of M2Net (oracle/m2net.py, pinned by the reference's own whole-net outputs and
     gradients: tests/test_oracle_m2net.py) - forward, deep-supervision Dice + CE, backward, clip, AdamW - on ONE patch: first at
     64^2, then ("full step at 128^2") at 128^2 when 7 x the 64^2 time fits `budget_s` (NNZ_CPU_BASELINE_BUDGET_S,
-    default 90).  `value` extrapolates the largest size run to the 512^2 patch of the metric linearly in pixels - the scan's
+    default 120).  `value` extrapolates the largest size run to the 512^2 patch of the metric linearly in pixels - the scan's
     time loop, which dominates, is linear in L; with that caveat."""
     from oracle import m2net as om
     from oracle.losses import deep_supervision_loss
     from nnuzoo_amd.synthetic import synthetic_batch
     if budget_s is None:
-        budget_s = float(os.environ.get("NNZ_CPU_BASELINE_BUDGET_S", "90"))
+        budget_s = float(os.environ.get("NNZ_CPU_BASELINE_BUDGET_S", "120"))
     threads, logical = host_threads()
+    threads = min(threads, 16)     # thousands of small tensor operations per scan: more threads only add fork / join time
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     net = om.M2Net(1, 2, True).train()
