@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradDev p) {
     prep_tile(tile + splits < ntiles ? tile + splits : 0, tile + splits < ntiles);
     NNZ_WTS(2);
 
-    // The tile's KB k-blocks x MAXT tap slots as ONE sequence of fragments s = kb * MAXT + i, software-pipelined by hand: fragment
-    // s + 3 is requested (two transposed reads into buffer (s + 3) & 3) right before the MFMA of fragment s is issued, so every
-    // MFMA waits for reads that are three MFMAs old.  Left to itself the scheduler kept two fragments in flight and waited with
+    // The tile's KB k-blocks x MAXT tap slots as ONE sequence of fragments f = kb * MAXT + i, software-pipelined by hand: fragment
+    // f + AHEAD (3) is requested (two transposed reads into buffer (f + AHEAD) % (AHEAD + 1)) right before the MFMA of fragment f
+    // is issued, so every MFMA waits for reads that are three MFMAs old (four: measured, no gain).  Left to itself the scheduler kept two fragments in flight and waited with
     // lgkmcnt(1) / (2) in front of every MFMA, draining to lgkmcnt(0) every second k-block: the loop took 7 000 clocks per tile
     // for 3 600 clocks of MFMA issue, with or without a second workgroup on the CU (profiles/r04_wgrad_phases.txt).
     // Voxel of (kb, kk = 8*hh + 4*s + qrow): two h-rows of 8 w per k-block -> td = kb / (TH/2), th = 2 (kb % (TH/2)) + hh.
