@@ -18,7 +18,8 @@ reference imports at :11 is absent).
 Module / parameter names and registration order equal the reference's, so that tests/golden_util.det_fill gives both the
 same parameters and state_dicts interchange.  PINNED by the reference's own outputs: tests/test_oracle_m2net.py runs these
 classes on tests/golden/net_M2NetP_64.npz, net_M2Net_64.npz (seven outputs of the reference's modules, eval mode) and
-netgrad_M2NetP_64.npz (its autograd: dx, samples and norms of every parameter gradient), and holds the state_dict keys to
+netgrad_M2NetP_64.npz, netgrad_M2Net_64.npz (their autograd: dx, samples and norms of every parameter gradient), and holds the
+state_dict keys to
 tests/golden/state_dict_manifest.json.
 """
 import math
