@@ -163,6 +163,37 @@ def cpu_m2net_step_baseline(budget_s: float = None):
             "step_seconds": {str(k): round(v, 2) for k, v in times.items()}}
 
 
+def cpu_swt2net_step_baseline(timed_steps: int = 2):
+    """Full fp32 training step of the CPU oracle of SwT2Net (oracle/swt2net.py, pinned by the reference's own whole-net outputs
+    and autograd: tests/test_oracle_swt2net.py) on the `swt2net` leg's OWN workload - batch 2 of 512^2, forward, deep-supervision
+    DC + CE, backward, clip, AdamW - one warm-up step, then `timed_steps` timed ones.  No extrapolation."""
+    from oracle.swt2net import SwT2Net
+    from oracle.losses import deep_supervision_loss
+    from nnuzoo_amd.synthetic import synthetic_batch
+    threads, logical = host_threads()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = SwT2Net(1, 2, True).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=5e-2, eps=1e-5)
+    b = synthetic_batch(2, (512, 512), [[1, 1]] + [[1 / 2 ** i] * 2 for i in range(6)], seed=7)
+
+    def step():
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss = deep_supervision_loss(list(net(b["data"])), b["target"], batch_dice=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+        opt.step()
+        return time.perf_counter() - t0
+
+    warm = step()
+    dt = sum(step() for _ in range(timed_steps)) / timed_steps
+    return {"value": 2.0 / dt, "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"CPU oracle of SwT2Net (plain torch fp32), full train step (fwd + deep-supervision DC+CE + bwd + clip + "
+                      f"AdamW) on the leg's own batch of 2 x 512^2: 1 warm-up step ({warm:.1f} s) + {timed_steps} timed steps "
+                      f"({dt:.2f} s each); torch {torch.__version__} CPU, {threads} threads ({logical} logical CPUs)"}
+
+
 def _profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     return json.load(open(path)) if os.path.exists(path) else None
@@ -603,6 +634,8 @@ def main():
                 sec = cpu_m2net_step_baseline()
                 sec["scan_forward_only"] = cpu_scan_baseline()
                 line["secondary"]["cpu_baseline"] = sec
+            if "swt2net" in line:
+                line["swt2net"]["cpu_baseline"] = cpu_swt2net_step_baseline()
         _emit(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()
