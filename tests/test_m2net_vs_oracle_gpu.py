@@ -73,3 +73,39 @@ def test_m2netp_training_mode_forward_equals_the_oracle(hip_lib):
     for i, (o, r) in enumerate(zip(got, base)):
         err, tol = _rel(o.detach().float().cpu(), r), max(5e-4, 100 * sens[i])
         assert err <= tol, (i, err, sens[i], tol)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("NNZ_UNVALIDATED_GPU_TESTS") != "1",
+                    reason="written after the round's GPU budget was spent: never run on a GPU yet (NNZ_UNVALIDATED_GPU_TESTS=1)")
+def test_every_swt2net_stage_in_training_mode_equals_the_oracle(hip_lib):
+    """the same stage-by-stage check for SwT2Net against oracle/swt2net.py (pinned on CPU by tests/test_oracle_swt2net.py)"""
+    from oracle.swt2net import SwT2Net as Ref
+    from nnuzoo_amd.nets.swt2net import SwT2Net
+    from nnuzoo_amd.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    ref = Ref(1, 2, True)
+    det_fill(ref)
+    net = SwT2Net(1, 2, True)
+    net.load_state_dict(ref.state_dict())
+    for m in list(ref.modules()) + list(net.modules()):
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+        if type(m).__name__ == "DropPath" and hasattr(m, "p"):
+            m.p = 0.0
+    ref.train()
+    net = net.cuda().train()
+    x = synthetic_batch(2, (64, 64), [[1, 1]], seed=11)["data"]
+    seen = {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out, k=k: seen.__setitem__(k, (inp[0].detach(), out.detach())))
+             for k, m in ref.named_children() if k.startswith("stage")]
+    with torch.no_grad():
+        ref(x)
+    for h in hooks:
+        h.remove()
+    assert len(seen) == 11
+    for k, (inp, out) in seen.items():
+        with torch.no_grad():
+            sens = _rel(getattr(ref, k)(inp * (1 + PERT)), out)
+            got = getattr(net, k)(inp.cuda()).float().cpu()
+        err, tol = _rel(got, out), max(5e-4, 100 * sens)
+        assert err <= tol, f"{k}: err {err:.1e} (oracle's own response {sens:.1e}, tolerance {tol:.1e})"
