@@ -46,6 +46,9 @@ cd $GRAFT_REPO_ROOT
 # the snapshot does not carry it); knob 11 = 0 / 1: the forward statistics with VALU sums / on the matrix cores
 for K in 0 1; do python3 tools/probes/conv_phase_probe.py --only enc0.1 --tuning 11=$K 2>&1 | grep -v -E "amdgpu|Warning|_benchmark" > $OUT/${TAG}_conv_phases_moments$K.txt; done
 python3 tools/probes/conv_phase_probe.py --only enc1.1 2>&1 | grep -v -E "amdgpu|Warning|_benchmark" > $OUT/${TAG}_conv_phases_enc1_1.txt
+# weight-gradient kernel: phases per tile (timestamp build tools/probes/_ts/libnnuzoo_hip_wts.so) and the in-kernel clocks of both kernels
+python3 tools/probes/conv_phase_probe.py --wgrad --clock 1.5 2>&1 | grep -v -E "amdgpu|Warning|_benchmark" > $OUT/${TAG}_wgrad_phases_now.txt
+python3 tools/probes/conv_phase_probe.py --only enc0.1 --clock 1.5 2>&1 | grep clock > $OUT/${TAG}_conv_box_clocks_now.txt
 python3 tools/bench_zoo.py --models SwinUMambaD,SwinUMamba --steps 6 --warmup 10 2>&1 | grep '"model"' >> $OUT/${TAG}_zoo_bench.txt
 python3 tools/probes/ssnd2net_loss_probe.py --size 512 --steps 14 2>/dev/null | grep '^{' | cut -c1-260 > $OUT/${TAG}_ssnd2net_loss_probe.txt
 # 4b. the window-attention kernels: SQ counters over one SwT2Net run (eager: one dispatch per kernel)
