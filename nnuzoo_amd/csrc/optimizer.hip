@@ -134,13 +134,18 @@ struct AdamChunk {
   float* m;
   float* v;
   int n;
-  int pad;
+  int owner;   // index of the parameter this chunk belongs to: its step counter is steps[owner]
 };
 
 __global__ __launch_bounds__(256) void adam_sumsq_kernel(const AdamChunk* __restrict__ chunks, int nchunks,
                                                          float* __restrict__ out2, FxAcc* acc, unsigned* counter,
-                                                         float* __restrict__ steps, int nsteps) {
+                                                         float* __restrict__ steps, int nsteps,
+                                                         const float* __restrict__ inv_scale_dev) {
   __shared__ float red[4][2];
+  // squares of the UNSCALED gradients (g / loss scale): with a gradient norm of ~3e4 (SSND2Net at initialisation) under a loss
+  // scale >= 2048 a workgroup's partial sum of the scaled squares leaves the fixed-point accumulator's range (2^52) although
+  // every fp32 gradient is finite - torch's unscale_ / clip / step would apply that step
+  const float inv_scale = inv_scale_dev ? inv_scale_dev[0] : 1.f;
   float s = 0.f, bad = 0.f;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     const AdamChunk ch = chunks[c];
@@ -151,13 +156,15 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const AdamChunk* __rest
       const f32x4 v = g4[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s += v[e] * v[e];
+        const float u = v[e] * inv_scale;
+        s += u * u;
         bad += (__builtin_isnan(v[e]) || __builtin_isinf(v[e])) ? 1.f : 0.f;
       }
     }
     for (int i = (n4 << 2) + threadIdx.x; i < ch.n; i += 256) {
       const float v = ch.grad[i];
-      s += v * v;
+      const float u = v * inv_scale;
+      s += u * u;
       bad += (__builtin_isnan(v) || __builtin_isinf(v)) ? 1.f : 0.f;
     }
   }
@@ -196,21 +203,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
                                                     const float* __restrict__ steps) {
   if (stats2[1] > 0.f) return;   // GradScaler semantics: parameters and moments untouched
   const float inv_scale = inv_scale_dev ? inv_scale_dev[0] : 1.f;
-  const float total_norm = sqrtf(stats2[0]) * inv_scale;
+  const float total_norm = sqrtf(stats2[0]);      // pass 1 summed the squares of the unscaled gradients
   float clip = max_norm > 0.f ? max_norm / (total_norm + 1e-6f) : 1.f;
   clip = clip > 1.f ? 1.f : clip;
   const float mult = inv_scale * clip;
   // bias corrections in double, once per workgroup: 1 - 0.999^t in fp32 (fast-math powf) loses four digits at small t
+  // The step counter is the chunk owner's own (torch keeps one per parameter): after a change of the member set - the encoder
+  // of the Swin-UMamba plugins unfrozen at epoch 10, a checkpoint with heterogeneous counters - parameters at step 1 sit beside
+  // parameters at step 2 500, and a shared t would give the new ones a first update 1 / (1 - beta1^2500) / (1 - beta1) too small
+  // or the old ones one 10 x too large.
+  const AdamChunk c = chunks[blockIdx.x];
   __shared__ float bc[2];
   if (threadIdx.x == 0) {
-    const double t = (double)steps[0];            // already advanced by pass 1
+    const double t = (double)steps[c.owner];      // already advanced by pass 1
     bc[0] = (float)(1.0 - pow((double)b1, t));
     bc[1] = (float)sqrt(1.0 - pow((double)b2, t));
   }
   __syncthreads();
   const float bc1 = bc[0], bc2s = bc[1];
   const float step_size = lr / bc1, decay = 1.f - lr * wd;
-  const AdamChunk c = chunks[blockIdx.x];
   for (int i = threadIdx.x; i < c.n; i += 256) {
     const float g = c.grad[i] * mult;
     const float p = c.param[i] * decay;
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
 
 extern "C" int nnz_adam_chunk_bytes(void) { return (int)sizeof(nnz::AdamChunk); }
 
-// stats2 (2 floats) is written: {sum of squares of the scaled gradients, > 0 if the step is skipped}; acc / counter: 2 zeroed
+// stats2 (2 floats) is written: {sum of squares of the UNSCALED gradients (g * inv_scale), > 0 if the step is skipped}; acc / counter: 2 zeroed
 // fixed-point records + one zeroed word (left zero); steps: the parameters' step counters (fp32, one per parameter, advanced
 // here when the step is applied); inv_scale_device: 1 / loss scale (1 float on the device) or NULL; max_norm <= 0: no clipping
 extern "C" int nnz_adamw_fused(const void* chunks_device, int nchunks, float* stats2, void* acc, void* counter,
@@ -237,7 +248,7 @@ extern "C" int nnz_adamw_fused(const void* chunks_device, int nchunks, float* st
   if (!chunks_device || nchunks < 1 || !stats2 || !acc || !counter || !steps || nsteps < 1) return NNZ_EINVAL;
   const int blocks = nchunks < 512 ? nchunks : 512;
   NNZ_LAUNCH(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks_device, nchunks,
-             stats2, (FxAcc*)acc, (unsigned*)counter, steps, nsteps);
+             stats2, (FxAcc*)acc, (unsigned*)counter, steps, nsteps, inv_scale_device);
   NNZ_LAUNCH(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks_device,
              (const float*)stats2, inv_scale_device, max_norm, lr, beta1, beta2, (float)(1.0 - (double)beta1d),
              (float)(1.0 - (double)beta2d), eps, weight_decay, (const float*)steps);

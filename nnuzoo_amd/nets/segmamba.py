@@ -20,7 +20,6 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..layer_norm import LayerNorm as _HipLayerNorm
 from ..utilities.network_initialization import InitWeights_He
@@ -48,27 +47,22 @@ class InstanceNorm(nn.Module):
         return self.layer(input)
 
 
-class LayerNorm(nn.Module):
-    """segmamba.py:40-62 (channels_last / channels_first); not instantiated by SegMamba itself, kept for API parity"""
+class LayerNorm(_HipLayerNorm):
+    """The `LayerNorm(normalized_shape, eps, data_format)` name of segmamba.py:40-62 on the shared HIP LayerNorm
+    (nnuzoo_amd/layer_norm.py): channels_last normalises the trailing axis as it stands; channels_first moves the channel axis
+    behind the spatial ones (the kernel packs the tokens), normalises, and moves it back.  SegMamba itself never
+    instantiates it; the name is part of the module's surface."""
 
     def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
-        super().__init__()
-        self.weight = nn.Parameter(torch.ones(normalized_shape))
-        self.bias = nn.Parameter(torch.zeros(normalized_shape))
-        self.eps = eps
-        self.data_format = data_format
-        if self.data_format not in ["channels_last", "channels_first"]:
+        if data_format not in ("channels_last", "channels_first"):
             raise NotImplementedError
-        self.normalized_shape = (normalized_shape,)
+        super().__init__(normalized_shape, eps=eps)
+        self.data_format = data_format
 
     def forward(self, x):
         if self.data_format == "channels_last":
-            return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
-        u = x.mean(1, keepdim=True)
-        s = (x - u).pow(2).mean(1, keepdim=True)
-        x = (x - u) / torch.sqrt(s + self.eps)
-        shape = (-1,) + (1,) * (x.dim() - 2)
-        return self.weight.view(shape) * x + self.bias.view(shape)
+            return super().forward(x)
+        return super().forward(x.movedim(1, -1)).movedim(-1, 1)
 
 
 class MambaLayer(nn.Module):

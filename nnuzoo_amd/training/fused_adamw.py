@@ -100,13 +100,14 @@ class FusedAdamW(torch.optim.AdamW):
         within = (np.arange(int(nck.sum())) - np.repeat(first, nck)) * CHUNK      # element offset inside the parameter
         n = np.minimum(CHUNK, sizes[owner] - within).astype(np.int32)
         rec = np.zeros(len(owner), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i4"),
-                                                   ("pad", "<i4")]))
+                                                   ("owner", "<i4")]))
         boff = (4 * within).astype(np.uint64)            # (uint64 + int64 would promote to float64)
         rec["p"] = pp[owner] + boff
         rec["g"] = gp[owner] + boff
         rec["m"] = self._flat_m.data_ptr() + 4 * (offs[owner] + within)
         rec["v"] = self._flat_v.data_ptr() + 4 * (offs[owner] + within)
         rec["n"] = n
+        rec["owner"] = owner.astype(np.int32)          # the kernel takes the bias corrections from steps[owner]
         self._table = torch.from_numpy(rec.view(np.uint8).copy()).to(members[0].device)
         self._nchunks = len(owner)
         self._ptrs = (pp.copy(), gp.copy())

@@ -17,10 +17,13 @@ semantics (/root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:1128
 """
 from __future__ import annotations
 
+import itertools
 import os
 from typing import Callable, List, Optional
 
 import torch
+
+_CAPTURE_TOKENS = itertools.count(1)      # one token per capture, process-wide (grads_token)
 
 
 def capture_memset_free(fn: Callable, stream: torch.cuda.Stream):
@@ -113,10 +116,14 @@ class GraphedForwardBackward:
             self._static_arena = (self.network._last_arena, self.network._arena_layout, self.network._last_unused)
         self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
         self.generation += 1
+        self._token = next(_CAPTURE_TOKENS)
 
     def grads_token(self):
-        """identifies the static gradient tensors the replay writes (see FusedAdamW.fused_step)"""
-        return (id(self), self.generation)
+        """identifies the static gradient tensors the replay writes (see FusedAdamW.fused_step).  Drawn from a process-wide
+        counter at every capture: `id(self)` can be handed to a NEW instance after this one is freed (the encoder-freezing hook
+        and the re-initialisation path drop and rebuild the captured step), and a recycled (id, generation) pair would let the
+        optimizer keep a chunk table that points into the destroyed graph's pool."""
+        return self._token
 
     def __call__(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
         """Runs forward+backward for (data, target); gradients are in p.grad afterwards.  Returns the loss tensor."""

@@ -508,6 +508,8 @@ class _FrozenEncoderEpochs:
             net.unfreeze_encoder()
         if before != [p.requires_grad for p in net.parameters()]:
             self._graphed = None
+            if hasattr(getattr(self, "optimizer", None), "_token"):
+                self.optimizer._token = None      # the chunk table of the old trainable set must not survive (FusedAdamW)
             for p in net.parameters():
                 if not p.requires_grad:
                     p.grad = None

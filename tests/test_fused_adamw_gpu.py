@@ -91,3 +91,45 @@ def test_state_dict_round_trip_and_static_gradients(hip_lib):
     for q, p in zip(ref.param_groups[0]["params"], ps):
         assert torch.allclose(q, p, rtol=2e-6, atol=2e-7)
     assert float(opt2.state[ps[0]]["step"]) == 5.0
+
+
+def test_freeze_then_unfreeze_keeps_every_parameters_own_step_counter(hip_lib):
+    """the bias corrections come from the chunk owner's OWN step counter.  Three steps with parameters 0-2 frozen (no
+    gradient, the Swin-UMamba plugins' first epochs), then three with everything trainable: the newly unfrozen parameters are at
+    step 1 while the others are at step 4 - against torch.optim.AdamW, which keeps one counter per parameter."""
+    from nnuzoo_amd.training.fused_adamw import FusedAdamW
+    pa, pb = _params(5), _params(5)
+    kw = dict(lr=3e-3, weight_decay=5e-2, eps=1e-5, betas=(0.9, 0.999))
+    ref, opt = torch.optim.AdamW(pa, **kw), FusedAdamW(pb, **kw)
+    for step in range(6):
+        for ps in (pa, pb):
+            _grads(ps, step, 1.0)
+            if step < 3:
+                for p in ps[:3]:
+                    p.grad = None
+        torch.nn.utils.clip_grad_norm_(pa, 12)
+        ref.step()
+        opt._token = None                           # what the trainers do when the trainable set changes
+        assert float(opt.fused_step(None, 12)) == 0
+    for i, (a, b) in enumerate(zip(pa[:-1], pb[:-1])):
+        assert float(opt.state[b]["step"]) == float(ref.state[a]["step"]) == (3.0 if i < 3 else 6.0)
+        assert torch.allclose(a, b, rtol=2e-6, atol=4e-7), (i, (a - b).abs().max().item())
+        assert torch.allclose(ref.state[a]["exp_avg_sq"], opt.state[b]["exp_avg_sq"], rtol=2e-6, atol=1e-10)
+
+
+def test_large_scaled_gradients_that_are_finite_are_not_skipped(hip_lib):
+    """gradient norm 3e4 under a loss scale of 65536 - every fp32 value finite, the sum of the SCALED squares (4e18) far
+    beyond the fixed-point accumulator's 2^52; torch's unscale_ / clip / step applies that step, so must the fused tail"""
+    from nnuzoo_amd.training.fused_adamw import FusedAdamW
+    p = torch.nn.Parameter(torch.zeros(1 << 20, device="cuda"))
+    q = torch.nn.Parameter(torch.zeros(1 << 20, device="cuda"))
+    g = torch.randn(1 << 20, generator=torch.Generator().manual_seed(3)).cuda() * (3e4 / 1024)     # norm ~3e4
+    scale = torch.full((1,), 65536.0, device="cuda")
+    p.grad = g * scale
+    q.grad = g.clone()
+    kw = dict(lr=1e-3, weight_decay=0.0, eps=1e-5)
+    opt, ref = FusedAdamW([p], **kw), torch.optim.AdamW([q], **kw)
+    assert float(opt.fused_step(scale.reciprocal(), 12)) == 0
+    torch.nn.utils.clip_grad_norm_([q], 12)
+    ref.step()
+    assert torch.allclose(p, q, rtol=1e-5, atol=1e-9)
