@@ -75,8 +75,6 @@ def test_m2netp_training_mode_forward_equals_the_oracle(hip_lib):
         assert err <= tol, (i, err, sens[i], tol)
 
 
-@pytest.mark.skipif(__import__("os").environ.get("NNZ_UNVALIDATED_GPU_TESTS") != "1",
-                    reason="written after the round's GPU budget was spent: never run on a GPU yet (NNZ_UNVALIDATED_GPU_TESTS=1)")
 def test_every_swt2net_stage_in_training_mode_equals_the_oracle(hip_lib):
     """the same stage-by-stage check for SwT2Net against oracle/swt2net.py (pinned on CPU by tests/test_oracle_swt2net.py)"""
     from oracle.swt2net import SwT2Net as Ref

@@ -128,7 +128,7 @@ def test_whole_net_forward_golden(hip_lib, force_scan_gen2, name):
     assert agree.all()
 
 
-@pytest.mark.parametrize("name", ["M2NetP", "SwT2Net", "M2NetP-gen2"])
+@pytest.mark.parametrize("name", ["M2NetP", "M2Net", "SwT2Net", "M2NetP-gen2"])
 def test_whole_net_backward_golden(hip_lib, force_scan_gen2, name):
     """whole-net BACKWARD against the reference's own autograd (tools/make_golden.py gen_nets: eval mode, loss =
     sum_i <out_i, G_i> / voxels with formula-made G_i): dx in full; of every parameter gradient the reference's <= 256
@@ -137,8 +137,9 @@ def test_whole_net_backward_golden(hip_lib, force_scan_gen2, name):
     import contextlib
     from nnuzoo_amd.nets import m2net, swt2net
     name, gen2 = name.split("-")[0], name.endswith("-gen2")
-    cls = {"M2NetP": m2net.M2NetP, "SwT2Net": swt2net.SwT2Net}[name]
-    z = np.load(os.path.join(G, f"netgrad_{name}_64.npz"))
+    cls = {"M2NetP": m2net.M2NetP, "M2Net": m2net.M2Net, "SwT2Net": swt2net.SwT2Net}[name]
+    z = np.load(os.path.join(G, f"netgrad_{name}_64.npz"))     # M2Net (the benchmark model): tools/make_golden_m2net_grad.py
+    nsamp = int(z["samples"]) if "samples" in z else 256
     x0 = np.load(os.path.join(G, f"net_{name}_64.npz"))["x"]
     torch.manual_seed(0)
     net = cls(1, 2, True)
@@ -158,16 +159,19 @@ def test_whole_net_backward_golden(hip_lib, force_scan_gen2, name):
     with_grad = [n for n, p in net.named_parameters() if p.grad is not None]
     assert with_grad == names                                   # the same parameters are reached by the backward
     worst = (0.0, "")
+    # gradients 8-11 orders below the net's largest are cancellation noise in the reference's own run (tests/test_oracle_m2net.py
+    # uses the same floor for the CPU oracle)
+    floor = 1e-8 * max(float(z[f"n{k}"]) for k, (n, p) in enumerate(net.named_parameters()) if p.grad is not None)
     for k, (n, p) in enumerate(net.named_parameters()):
         if p.grad is None:
             continue
         g = p.grad.reshape(-1)
         ref = torch.tensor(z[f"g{k}"])
-        got = g[::max(1, g.numel() // 256)][:256].float().cpu()
+        got = g[::max(1, g.numel() // nsamp)][:nsamp].float().cpu()
         scale = float(z[f"n{k}"]) / g.numel() ** 0.5 + 1e-12    # rms of the reference gradient
-        err = ((got - ref).abs().max() / max(scale, ref.abs().max().item())).item()
+        err = ((got - ref).abs().max() / max(scale, ref.abs().max().item(), floor)).item()
         worst = max(worst, (err, n))
-        assert abs(g.double().norm().item() - float(z[f"n{k}"])) <= 1e-2 * float(z[f"n{k}"]) + 1e-9, n
+        assert abs(g.double().norm().item() - float(z[f"n{k}"])) <= 1e-2 * float(z[f"n{k}"]) + 1e-9 + floor, n
     # measured over repeated runs on MI355X: 1.7e-3 .. 3.0e-3 (fp32 atomics make the runs differ); one run in eight went above
     # 5e-3 on a single near-zero-gradient norm parameter, hence 1e-2
     assert worst[0] < 1e-2, worst

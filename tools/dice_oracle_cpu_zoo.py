@@ -26,7 +26,13 @@ ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--heldout", type=int, default=16)
 ap.add_argument("--ref-json", default="")
 ap.add_argument("--out", default="")
+ap.add_argument("--threads", type=int, default=0, help="torch CPU threads (0: default); a second run with another count is a "
+                "second, equally valid fp32 summation order - the CPU-vs-CPU drift of the protocol")
+ap.add_argument("--fixture", default="", help="also write a test fixture (all losses + the packed held-out masks), e.g. "
+                "tests/golden/dice_oracle_m2netp_64.json")
 a = ap.parse_args()
+if a.threads:
+    torch.set_num_threads(a.threads)
 
 torch.manual_seed(0)
 if a.model == "SwT2Net":
@@ -90,6 +96,13 @@ if a.ref_json:
                 "loss_abs_delta_step0": abs(losses[0] - ref["losses"][0]),
                 "loss_abs_delta_max": float(np.max(np.abs(np.array(losses[:n]) - np.array(ref["losses"][:n])))),
                 "reference": a.ref_json})
+if a.fixture:
+    import base64
+    fx = {"model": a.model + " (CPU oracle oracle/" + ("swt2net" if a.model == "SwT2Net" else "m2net") + ".py, fp32)", "size": a.size,
+          "steps": a.steps, "heldout": a.heldout, "dice": res["dice"], "losses": losses, "threads": torch.get_num_threads(),
+          "masks_packed_b64": base64.b64encode(np.packbits(torch.cat(masks).numpy().reshape(-1)).tobytes()).decode(),
+          "generator": f"tools/dice_oracle_cpu_zoo.py --model {a.model} --size {a.size} --steps {a.steps} --fixture ..."}
+    json.dump(fx, open(a.fixture, "w"))
 print(json.dumps(res))
 if a.out:
     json.dump(res, open(a.out, "w"), indent=1)

@@ -15,7 +15,14 @@ Stage 1 is the end-to-end piece: its input is the network input itself.
 Per module the fixture also holds `sens`: the relative change of the reference's own output when its input is perturbed by
 1e-6 (relative): the conditioning the parity test scales its tolerance with (a module that amplifies 1e-6 to more than 5 % is
 marked chaotic and compared in structure and scale only).
-Large tensors (full-resolution decoder side) are stored as strided samples; inputs are always complete."""
+Large tensors (full-resolution decoder side) are stored as strided samples; inputs are always complete.
+
+Round 5: (1) `bsens` - the REFERENCE's own backward conditioning: the relative change of its dx when its input
+moves by 1e-6 (the same perturbation as `sens`); the parity test scales its backward tolerances with it instead of measuring the
+product's own response.  (2) The full-resolution decoder-side modules that were "statistics only" are now compared too, on an
+input the test can rebuild without storage: every input tensor = cos pattern scaled to the rms of the reference's own activation
+at that place (`synth_in_rms`); stored: strided samples of the output and of dx, the norms, every parameter-gradient norm, `sens`
+and `bsens` on that input (`synth_*` keys; all earlier arrays are unchanged and regenerate bit for bit)."""
 import argparse
 import json
 import os
@@ -36,6 +43,44 @@ MAX_IO_FLOATS = 420_000      # modules whose inputs + output are larger are reco
 def pattern(shape, freq, phase):
     i = torch.arange(int(np.prod(shape)), dtype=torch.float64)
     return torch.cos(freq * i + phase).float().reshape(shape)
+
+
+def synthetic_record(mod, name, ins, kwargs, rec, arrays):
+    """forward / backward of `mod` on formula-made inputs scaled to the rms of the reference's activations `ins`"""
+    rms = [float(t.double().pow(2).mean().sqrt()) for t in ins]
+    syn = [r * pattern(t.shape, 0.61 + 0.13 * k, 0.3) for k, (t, r) in enumerate(zip(ins, rms))]
+    rec["synth_in_rms"] = rms
+    xin = [t.clone().requires_grad_(True) for t in syn]
+    for p in mod.parameters():
+        p.grad = None
+    y = mod(*xin, **kwargs)
+    y.backward(pattern(y.shape, 0.37, 0.5))
+    out, dx = y.detach(), xin[0].grad
+    rec["synth_out_stride"] = int(max(1, out.numel() // 65536))
+    rec["synth_dx_stride"] = int(max(1, dx.numel() // 16384))
+    arrays[f"synth_out_{name}"] = out.reshape(-1)[::rec["synth_out_stride"]].numpy().copy()
+    arrays[f"synth_dx_{name}"] = dx.reshape(-1)[::rec["synth_dx_stride"]].numpy().copy()
+    rec["synth_out_rms"] = float(out.double().pow(2).mean().sqrt())
+    rec["synth_out_max"] = float(out.abs().max())
+    rec["synth_dx_norm"] = float(dx.double().pow(2).sum().sqrt())
+    rec["synth_dx_max"] = float(dx.abs().max())
+    names, norms = [], []
+    for pn, p in mod.named_parameters():
+        if p.grad is not None:
+            names.append(pn)
+            norms.append(float(p.grad.double().pow(2).sum().sqrt()))
+    rec["synth_grad_names"] = names
+    arrays[f"synth_gn_{name}"] = np.array(norms, dtype=np.float64)
+    for p in mod.parameters():
+        p.grad = None
+    pert = [syn[0] + 1e-6 * rms[0] * pattern(syn[0].shape, 1.3, 0.2)] + syn[1:]
+    xin2 = [t.clone().requires_grad_(True) for t in pert]
+    y2 = mod(*xin2, **kwargs)
+    y2.backward(pattern(y2.shape, 0.37, 0.5))
+    rec["synth_sens"] = float((y2.detach() - out).abs().max() / out.abs().max())
+    rec["synth_bsens"] = float((xin2[0].grad - dx).abs().max() / dx.abs().max())
+    for p in mod.parameters():
+        p.grad = None
 
 
 def run_case(R, cls, sd, P, out_prefix):
@@ -75,10 +120,13 @@ def run_case(R, cls, sd, P, out_prefix):
             o2 = mod(*pert, **kwargs)
             rec["sens"] = float((o2 - out).abs().max() / out.abs().max())
         if not small and name != "stage1":
-            # large decoder-side modules: same classes as recorded ones at lower resolution; keep the output statistics only
+            # large decoder-side modules: the reference's activations are too large to store - output statistics of the real call,
+            # and a full forward / backward record on a formula-made input of the same scale
             rec["out_rms"] = float(out.double().pow(2).mean().sqrt())
+            synthetic_record(mod, name, ins, kwargs, rec, arrays)
             man["modules"].append(rec)
-            print(f"  {name:20s} large ({nfl * 4 // 1024} KB): statistics only, sens {rec['sens']:.2e}", flush=True)
+            print(f"  {name:20s} large ({nfl * 4 // 1024} KB): formula-made input, sens {rec['synth_sens']:.2e} "
+                  f"bsens {rec['synth_bsens']:.2e}", flush=True)
             continue
         for k, t in enumerate(ins):
             if name == "stage1":
@@ -113,8 +161,15 @@ def run_case(R, cls, sd, P, out_prefix):
         arrays[f"gn_{name}"] = np.array(norms, dtype=np.float64)
         for p in mod.parameters():
             p.grad = None
+        # the reference's own backward conditioning: dx of the same output gradient at the perturbed input
+        xin2 = [pert[0].clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in ins[1:]]
+        y2 = mod(*xin2, **kwargs)
+        y2.backward(pattern(y2.shape, 0.37, 0.5))
+        rec["bsens"] = float((xin2[0].grad - dx).abs().max() / dx.abs().max())
+        for p in mod.parameters():
+            p.grad = None
         man["modules"].append(rec)
-        print(f"  {name:20s} sens {rec['sens']:.2e}  out_rms {rec['out_rms']:.3e}  dx_norm {rec['dx_norm']:.3e}  "
+        print(f"  {name:20s} sens {rec['sens']:.2e}  bsens {rec['bsens']:.2e}  out_rms {rec['out_rms']:.3e}  dx_norm {rec['dx_norm']:.3e}  "
               f"{len(names)} parameter gradients", flush=True)
     np.savez_compressed(out_prefix + ".npz", **arrays)
     with open(out_prefix + ".json", "w") as f:
