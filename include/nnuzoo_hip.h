@@ -563,6 +563,53 @@ int nnz_adamw_fused(const void* chunks_device, int nchunks, float* stats2, void*
                     is formed in double like torch does */, float eps, float weight_decay, float* steps, int nsteps,
                     void* stream);
 
+/* ---- round 5: the Swin block as five forward and seven backward launches (SwinTransformerBlock.forward,
+ * nnunetv2/nets/swt2net.py:622-661: F.pad -> norm1 -> WindowAttention (qkv, core, proj) -> DropPath + residual -> norm2 -> Mlp ->
+ * DropPath + residual -> crop; the block used to be 11 + 11 launches).  Host side: nnuzoo_amd/swin_block.py.
+ *   forward:  [pad gather + LayerNorm + qkv Linear] -> window attention (out on the unpadded grid) -> [proj Linear + DropPath +
+ *             residual] -> [LayerNorm + fc1 + GELU] -> [fc2 + DropPath + residual]
+ *   backward: [fc2 dgrad x DropPath x GELU'] -> fc1 dgrad -> [LayerNorm backward + skip] -> [proj dgrad x DropPath] -> window
+ *             attention backward (dout on the unpadded grid) -> qkv dgrad -> [LayerNorm backward + skip + crop]; the weight
+ *             gradients (DropPath folded into their dy operand) and the LayerNorm dgamma / dbeta folds ride in the pass's ONE
+ *             grouped launch.
+ * nnz_dense32_forward_fused: y = epilogue(LN?(x) W^T + bias), T = rows of y.
+ *   ln_mean != NULL: LayerNorm prologue over K (eps ln_eps, affine ln_gamma / ln_beta or NULL): writes ln_mean / ln_rstd [T] and,
+ *     when ln_y != NULL, the normalised rows [T][K]; pad_h > 0 (LayerNorm mode only): x is [B][pad_h][pad_w][K] and row r of y is
+ *     a token of the top / left padded grid (pad_h + pad_y) x (pad_w + pad_x); padded tokens are zero rows (normalised: beta);
+ *   res != NULL: y = res + s (x W^T + bias), res laid out like y; dp_rand != NULL: s = floor(dp_keep + dp_rand[row / dp_rps]) /
+ *     dp_keep over dp_nb samples (the reference's DropPath, swt2net.py:379-388), NULL: s = 1; gelu as in nnz_dense32_forward;
+ *   workspace: nnz_dense32_splitk_workspace_floats(T, K, N) floats or NULL.  Skinny products (< 192 tiles of 64 x 64, contraction
+ *     >= 256: the 8^2 ... 16^2 token levels of the Swin U-nets) are cut along the contraction into <= 16 ranges whose partials a
+ *     second launch folds in range order (bit-identical run to run) before the epilogue.
+ * nnz_dense32_dgrad_fused: dx = s (dy W) [* GELU'(h)], s as above; workspace: ..._floats(T, N, K) (contraction N, K columns). */
+long nnz_dense32_splitk_workspace_floats(long T, int contraction, int out_cols);
+int nnz_dense32_forward_fused(const float* x, const float* W, const float* bias, float* y, float* y_act, long T, int K, int N,
+                              int gelu, const float* ln_gamma, const float* ln_beta, float ln_eps, float* ln_mean,
+                              float* ln_rstd, float* ln_y, int pad_h, int pad_w, int pad_y, int pad_x, const float* res,
+                              const float* dp_rand, float dp_keep, int dp_rps, int dp_nb, float* workspace, void* stream);
+int nnz_dense32_dgrad_fused(const float* dy, const float* W, const float* h, float* dx, long T, int K, int N,
+                            const float* dp_rand, float dp_keep, int dp_rps, int dp_nb, float* workspace, void* stream);
+/* grouped weight gradient record with the DropPath scale on its dy operand (per token: s of sample token / dp_rps); and a
+ * fold-only record: dst[i] = sum_{q < parts} part[q * n + i] in part order (fold blocks: (n + 255) / 256) */
+int nnz_dense32_group_fill_scaled(void* job_host, void* fold_host, const float* dy, const float* x, float* dW, float* db,
+                                  float* workspace, long T, int K, int N, int wg_begin, int blk_begin, const float* dp_rand,
+                                  float dp_keep, int dp_rps, int dp_nb);
+int nnz_dense32_group_fill_fold(void* fold_host, const float* part, float* dst, long n, int parts, int blk_begin);
+/* window attention with qkv / dqkv on the block's top / left padded grid H x W and out / dout on the unpadded grid
+ * (H - py) x (W - px): rows of padded tokens are never written (forward) and read as zeros (backward) */
+int nnz_window_attention_forward_pad(const float* qkv, const float* bias_table, const int* bias_index, float* out, int B,
+                                     int H, int W, int C, int heads, int shift, float scale, int py, int px, void* stream);
+int nnz_window_attention_backward_pad(const float* qkv, const float* bias_table, const int* bias_index, const float* dout,
+                                      float* dqkv, float* dbias_table, void* acc, void* counter, int B, int H, int W, int C,
+                                      int heads, int shift, float scale, int py, int px, void* stream);
+/* LayerNorm backward (fp32) with dx = dres + ..., dgamma | dbeta as per-workgroup partials part[nnz_layer_norm_backward_parts(rows,
+ * C)][2 C] for a fold record, and - pad_h > 0 - rows on the top / left padded grid (dy, mean, rstd) with x / dres / dx on the
+ * unpadded [B][pad_h][pad_w] grid (padded tokens: x = 0, they still count in dgamma / dbeta, their dx is dropped) */
+long nnz_layer_norm_backward_parts(long rows, int C);
+int nnz_layer_norm_backward_partial(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                                    const float* dres, float* dx, float* part, long rows, int C, int pad_h, int pad_w,
+                                    int pad_y, int pad_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,9 +51,48 @@ struct D32Args {
   long ldo;
   int rows, cols, kc;   // problem size: rows x cols outputs, contraction length kc (per split for wgrad)
   int kc_total;         // wgrad: full contraction length (tokens); splits cut it into kc-sized ranges
-  long split_stride;    // wgrad: out + split * split_stride
+  long split_stride;    // wgrad / split-K: out + split * split_stride
   int epi;              // 0 none / bias, 1 GELU (dual output), 2 multiply by GELU'(aux)
+  // ---- fused pieces of the Swin block (round 5); all zero = the plain product -------------------------------------------
+  // LayerNorm prologue (forward kernels instantiated with LN = true): the A rows are normalised while they are staged,
+  //   row statistics by a pre-pass of the workgroup over its rows (two passes: mean, then centred squares - what
+  //   nnz_layer_norm_forward computes); the first column tile also writes mean / rstd / the normalised rows (ln_y, the x
+  //   operand of the weight gradient and what the LayerNorm backward needs)
+  const float* ln_gamma;
+  const float* ln_beta;
+  float* ln_mean;       // [rows]
+  float* ln_rstd;       // [rows]
+  float* ln_y;          // [rows][kc_full] or null
+  float ln_eps;
+  // pad gather (LN kernels): pad_h > 0 - A row r is token (b, y, x) of the top / left padded grid (pad_h + pad_y) x (pad_w + pad_x);
+  //   it reads source token (b, y - pad_y, x - pad_x) of the [B][pad_h][pad_w] tensor, or zeros (SwinTransformerBlock's F.pad,
+  //   swt2net.py:643-645, folded into the addressing)
+  int pad_h, pad_w, pad_y, pad_x;
+  // epilogue: out = res + s_b (acc + bias) [* GELU'(aux)]; s_b = dp_inv * floor(dp_keep + dp_rand[b]), b = row / dp_rps - the
+  //   residual add and the reference's DropPath (swt2net.py:379-388) without launches of their own.  In the weight gradient
+  //   dp_* scales the dy operand per token instead (the gradient of the dropped branch).
+  const float* res;
+  const float* dp_rand;
+  float dp_keep, dp_inv;
+  int dp_rps, dp_nb;
+  int ksplit;           // forward / dgrad: > 1 - split-K, raw partials to out + split * split_stride, epilogue in the fold kernel
+  int kc_full;          // forward / dgrad with ksplit > 1: the whole contraction length (kc = per split)
 };
+
+// drop-path scale of sample b
+__device__ __forceinline__ float d32_dp_scale(const D32Args& a, int b) {
+  b = b < a.dp_nb ? b : a.dp_nb - 1;
+  return a.dp_inv * floorf(a.dp_rand[b] + a.dp_keep);
+}
+
+// the epilogue of one output element (shared by the tile kernels and the split-K fold)
+__device__ __forceinline__ void d32_epilogue(const D32Args& a, float v, float bv, float sc, long o) {
+  v = (v + bv) * sc;
+  if (a.epi == 2) v *= gelu_grad_f(a.aux[o]);
+  if (a.res) v += a.res[o];
+  a.out[o] = v;
+  if (a.epi == 1) a.out2[o] = gelu_f(v);
+}
 
 // An operand tile of NR rows x D32_BK contraction steps.  Global loads are always 16 bytes along the axis that is
 // contiguous in MEMORY, and the LDS image keeps that axis contiguous too (16-byte LDS writes, no scattered transposition):
@@ -61,6 +100,14 @@ struct D32Args {
 //           its row are one ds_read_b128;
 //   !CONTIG (row index contiguous: W in the input gradient, dy / x in the weight gradient)   image [step][row], pitch
 //           NR + 4: a lane's four steps are four ds_read_b32 whose 32 lanes read consecutive words (conflict-free).
+// LN (CONTIG tiles of the forward's A operand): rows come through the workgroup's row table (source token or -1 = a padded
+// token, all zeros) and are normalised on their way into LDS with the row statistics of the pre-pass; a thread's pieces of
+// one block share their column (256 threads / 16 pieces per row), so gamma / beta are ONE 16-byte load each per block.
+struct D32Ln {
+  const int* src_row;     // LDS [NR]: source row of tile row r, -1 = zeros
+  const float* mean;      // LDS [NR]
+  const float* rstd;      // LDS [NR]
+};
 template <int NR, bool CONTIG, int BK>
 struct D32Tile {
   static constexpr int D32_BK = BK;
@@ -70,6 +117,7 @@ struct D32Tile {
   static constexpr int NV = NR * D32_BK / 4;                           // 16-byte pieces per tile
   static constexpr int LPT = (NV + 255) / 256;
   f32x4 reg[LPT];
+  f32x4 gm, bt;                                                        // LN: gamma / beta of this thread's column piece
   __device__ __forceinline__ void load(const float* src, long rs, long cs, int r0, int nrows, int c0, int nc, int tid) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
@@ -96,6 +144,41 @@ struct D32Tile {
       reg[i] = v;
     }
   }
+  // weight gradient, dy operand of a drop-path branch: step (= token) c0 + c is scaled by its sample's factor
+  __device__ __forceinline__ void scale_steps(const D32Args& a, int c0, int nc, int tid) {
+    const int b0 = c0 / a.dp_rps;                                      // wave-uniform
+    const float s0 = d32_dp_scale(a, b0);
+    const int e1 = (b0 + 1) * a.dp_rps;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int p = tid + i * 256;
+      if (p < NV) {
+        const int c = c0 + p / (NR / 4);
+        float sc = s0;
+        if (c >= e1) sc = d32_dp_scale(a, c / a.dp_rps);               // rare: a block that crosses into the next sample(s)
+        reg[i] = reg[i] * sc;
+      }
+    }
+  }
+  // LN tiles: rows through the row table; gamma / beta of the thread's column piece ride along
+  __device__ __forceinline__ void load_ln(const D32Args& a, const D32Ln& ln, int r0, int c0, int nc, int tid) {
+    static_assert(CONTIG, "LayerNorm prologue: contraction-contiguous rows only");
+    const int c4 = (tid % (D32_BK / 4)) * 4;
+    const bool cin = c0 + c4 < nc;
+    gm = (cin && a.ln_gamma) ? *reinterpret_cast<const f32x4*>(a.ln_gamma + c0 + c4) : f32x4{cin ? 1.f : 0.f, cin ? 1.f : 0.f, cin ? 1.f : 0.f, cin ? 1.f : 0.f};
+    bt = (cin && a.ln_beta) ? *reinterpret_cast<const f32x4*>(a.ln_beta + c0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int p = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < NV) {
+        const int r = p / (D32_BK / 4);
+        const int sr = ln.src_row[r];
+        if (sr >= 0 && cin) v = *reinterpret_cast<const f32x4*>(a.A + (long)sr * a.a_rs + (c0 + c4));
+      }
+      reg[i] = v;
+    }
+  }
   __device__ __forceinline__ void store(float* tile, int tid) const {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
@@ -108,6 +191,26 @@ struct D32Tile {
           const int c = p / (NR / 4), r4 = (p % (NR / 4)) * 4;
           *reinterpret_cast<f32x4*>(tile + c * TP + r4) = reg[i];
         }
+      }
+    }
+  }
+  // normalise, hand to LDS, and (first column tile) write the normalised rows out
+  __device__ __forceinline__ void store_ln(const D32Args& a, const D32Ln& ln, float* tile, int r0, int c0, int nc, int tid,
+                                           bool write_y) const {
+    const int c4 = (tid % (D32_BK / 4)) * 4;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int p = tid + i * 256;
+      if (p < NV) {
+        const int r = p / (D32_BK / 4);
+        const float mu = ln.mean[r], rs = ln.rstd[r];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (reg[i][e] - mu) * rs * gm[e] + bt[e];
+        if (r0 + r >= a.rows) o = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(tile + r * D32_PITCH + c4) = o;
+        if (write_y && r0 + r < a.rows && c0 + c4 < nc)
+          *reinterpret_cast<f32x4*>(a.ln_y + (long)(r0 + r) * a.kc_full + (c0 + c4)) = o;
       }
     }
   }
@@ -124,7 +227,10 @@ struct D32Tile {
 // with a prefetch distance of TWO blocks (two register sets, the loop unrolled by two): most calls of the Swin / ViT nets
 // are small (a few hundred workgroups, 12-96 blocks each), so a block's global-load latency must hide behind the LDS
 // hand-over and the MFMAs of two neighbouring blocks, not one.
-template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD>
+// `split`: weight gradient - the token range; forward / input gradient with a.ksplit > 1 - the range of the contraction
+// (split-K: skinny products of the deep Swin levels, 2 x 12 tiles of 64 x 64 over a contraction of 3 072, are otherwise one
+// 48-block chain per workgroup on a tenth of the chip); the partials are folded in split order by dense32_splitk_fold_kernel.
+template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD, bool LN>
 __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, const int split) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int D32_BK = (WM == 1 && WN == 1) ? 64 : 32;
@@ -132,6 +238,8 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
   using TB = D32Tile<BN, B_CONTIG, D32_BK>;
   __shared__ __attribute__((aligned(16))) float sA[TA::FLOATS];
   __shared__ __attribute__((aligned(16))) float sB[TB::FLOATS];
+  __shared__ float sMean[LN ? BM : 1], sRstd[LN ? BM : 1];
+  __shared__ int sSrc[LN ? BM : 1];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,10 +248,71 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
   const int ntc = (a.cols + BN - 1) / BN;
   const int r0 = (tile / ntc) * BM, c0 = (tile % ntc) * BN;
   int k_begin = 0, k_end = a.kc;
+  const bool ksplit = !WGRAD && a.ksplit > 1;
   if (WGRAD) {
     k_begin = split * a.kc;
     k_end = k_begin + a.kc < a.kc_total ? k_begin + a.kc : a.kc_total;
+  } else if (ksplit) {
+    k_begin = split * a.kc;
+    k_end = k_begin + a.kc < a.kc_full ? k_begin + a.kc : a.kc_full;
   }
+  const bool wscale = WGRAD && a.dp_rand != nullptr;
+  D32Ln ln = {sSrc, sMean, sRstd};
+
+  if (LN) {
+    // ---- pre-pass: source row and LayerNorm statistics of the tile's rows; TPR threads per row ------------------------
+    constexpr int TPR = 256 / BM;
+    const int r = tid / TPR, part = tid % TPR;
+    const int row = r0 + r;
+    int sr = -1;
+    if (row < a.rows) {
+      sr = row;
+      if (a.pad_h > 0) {
+        const int hp = a.pad_h + a.pad_y, wp = a.pad_w + a.pad_x;
+        const int b = row / (hp * wp), rem = row - b * (hp * wp);
+        const int y = rem / wp, x = rem - y * wp;
+        sr = (y >= a.pad_y && x >= a.pad_x) ? (b * a.pad_h + (y - a.pad_y)) * a.pad_w + (x - a.pad_x) : -1;
+      }
+    }
+    const int K = a.kc_full;
+    float mu = 0.f, rs = 0.f;
+    if (sr >= 0) {
+      const float* xr = a.A + (long)sr * a.a_rs;
+      float s0 = 0.f;
+      for (int c = 4 * part; c < K; c += 4 * TPR) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        s0 += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+#pragma unroll
+      for (int o = TPR / 2; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
+      mu = s0 / (float)K;
+      float ss = 0.f;
+      for (int c = 4 * part; c < K; c += 4 * TPR) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[e] - mu;
+          ss += d * d;
+        }
+      }
+#pragma unroll
+      for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      rs = 1.f / sqrtf(ss / (float)K + a.ln_eps);
+    } else {
+      rs = 1.f / sqrtf(a.ln_eps);                    // a zero row: mean 0, variance 0 - the normalised row is beta
+    }
+    if (part == 0) {
+      sSrc[r] = sr;
+      sMean[r] = mu;
+      sRstd[r] = rs;
+      if (c0 == 0 && split == 0 && row < a.rows) {
+        a.ln_mean[row] = mu;
+        a.ln_rstd[row] = rs;
+      }
+    }
+    __syncthreads();
+  }
+  const bool write_y = LN && c0 == 0 && a.ln_y != nullptr;
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -176,29 +345,43 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
           for (int j = 0; j < WN; ++j) acc[i][j] = mfma_f32x(fa[i][s], fb[j][s], acc[i][j]);
     }
   };
-  stA0.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k_begin, k_end, tid);
+  auto loadA = [&](TA& t, int k0) {
+    if constexpr (LN) {
+      t.load_ln(a, ln, r0, k0, k_end, tid);
+    } else {
+      t.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0, k_end, tid);
+      if constexpr (WGRAD && !A_CONTIG) {
+        if (wscale) t.scale_steps(a, k0, k_end, tid);
+      }
+    }
+  };
+  auto storeA = [&](const TA& t, int k0) {
+    if constexpr (LN) t.store_ln(a, ln, sA, r0, k0, k_end, tid, write_y);
+    else t.store(sA, tid);
+  };
+  loadA(stA0, k_begin);
   stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid);
   if (k_begin + D32_BK < k_end) {
-    stA1.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k_begin + D32_BK, k_end, tid);
+    loadA(stA1, k_begin + D32_BK);
     stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin + D32_BK, k_end, tid);
   }
   for (int k0 = k_begin; k0 < k_end; k0 += 2 * D32_BK) {
     __syncthreads();
-    stA0.store(sA, tid);
+    storeA(stA0, k0);
     stB0.store(sB, tid);
     __syncthreads();
     if (k0 + 2 * D32_BK < k_end) {
-      stA0.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0 + 2 * D32_BK, k_end, tid);
+      loadA(stA0, k0 + 2 * D32_BK);
       stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 2 * D32_BK, k_end, tid);
     }
     compute();
     if (k0 + D32_BK < k_end) {
       __syncthreads();
-      stA1.store(sA, tid);
+      storeA(stA1, k0 + D32_BK);
       stB1.store(sB, tid);
       __syncthreads();
       if (k0 + 3 * D32_BK < k_end) {
-        stA1.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0 + 3 * D32_BK, k_end, tid);
+        loadA(stA1, k0 + 3 * D32_BK);
         stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 3 * D32_BK, k_end, tid);
       }
       compute();
@@ -206,7 +389,36 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
   }
 
   // ---- epilogue: acc[i][j][r] = output (row = r0 + (wr WM + i) 32 + (r&3) + 8 (r>>2) + 4 hh, col = c0 + (wc WN + j) 32 + l31)
-  float* out = a.out + (WGRAD ? (long)split * a.split_stride : 0);
+  if (WGRAD || ksplit) {     // raw partial (or the whole weight gradient): no bias, no activation
+    float* out = a.out + (long)split * a.split_stride;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = c0 + (wc * WN + j) * 32 + l31;
+      if (col >= a.cols) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + (wr * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (row < a.rows) out[(long)row * a.ldo + col] = acc[i][j][r];
+        }
+    }
+    if (WGRAD && a.part_db && c0 == 0 && tid < BM && r0 + tid < a.rows) a.part_db[(long)split * a.rows + r0 + tid] = dbsum;
+    return;
+  }
+  // drop-path scale per row: the tile's rows span at most three samples when a sample has >= 64 rows (b0, b0 + 1, b0 + 2)
+  float s0 = 1.f, s1 = 1.f, s2 = 1.f;
+  int e1 = 0x7fffffff, e2 = 0x7fffffff;
+  const bool dp = a.dp_rand != nullptr;
+  const bool dp_div = dp && a.dp_rps < 64;
+  if (dp && !dp_div) {
+    const int b0 = r0 / a.dp_rps;
+    s0 = d32_dp_scale(a, b0);
+    s1 = d32_dp_scale(a, b0 + 1);
+    s2 = d32_dp_scale(a, b0 + 2);
+    e1 = (b0 + 1) * a.dp_rps;
+    e2 = e1 + a.dp_rps;
+  }
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = c0 + (wc * WN + j) * 32 + l31;
@@ -218,19 +430,33 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
       for (int r = 0; r < 16; ++r) {
         const int row = r0 + (wr * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (row >= a.rows) continue;
-        float v = acc[i][j][r] + bv;
-        const long o = (long)row * a.ldo + col;
-        if (a.epi == 2) v *= gelu_grad_f(a.aux[o]);
-        out[o] = v;
-        if (a.epi == 1) a.out2[o] = gelu_f(v);
+        float sc = row >= e2 ? s2 : (row >= e1 ? s1 : s0);
+        if (dp_div) sc = d32_dp_scale(a, row / a.dp_rps);
+        d32_epilogue(a, acc[i][j][r], bv, sc, (long)row * a.ldo + col);
       }
   }
-  if (WGRAD && a.part_db && c0 == 0 && tid < BM && r0 + tid < a.rows) a.part_db[(long)split * a.rows + r0 + tid] = dbsum;
 }
 
-template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD>
+template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD, bool LN = false>
 __global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
-  dense32_body<WM, WN, A_CONTIG, B_CONTIG, WGRAD>(a, blockIdx.x, blockIdx.y);
+  dense32_body<WM, WN, A_CONTIG, B_CONTIG, WGRAD, LN>(a, blockIdx.x, blockIdx.y);
+}
+
+// split-K second stage: out[row][col] = epilogue(sum_s part[s][row][col]) in split order (bit-identical run to run)
+__global__ __launch_bounds__(256) void dense32_splitk_fold_kernel(D32Args a, const float* __restrict__ part) {
+  const long n4 = (long)a.rows * a.cols / 4;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < n4; p += (long)gridDim.x * 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * p);
+    for (int q = 1; q < a.ksplit; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(part + (long)q * a.split_stride + 4 * p);
+      v += t;
+    }
+    const long e = 4 * p;
+    const int row = (int)(e / a.cols), col = (int)(e - (long)row * a.cols);
+    const float sc = a.dp_rand ? d32_dp_scale(a, row / a.dp_rps) : 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d32_epilogue(a, v[i], a.bias ? a.bias[col + i] : 0.f, sc, (long)row * a.ldo + col + i);
+  }
 }
 
 // ---- grouped weight gradients: ALL weight gradients of a backward pass in one launch ------------------------------------
@@ -254,6 +480,23 @@ struct D32FoldJob {
   int blk_begin;  // first 256-thread block of this job in the grouped fold launch
   int pad;
 };
+// sum of `splits` partials of element i (stride n) in split order; eight independent loads in flight (LayerNorm fold jobs have
+// up to 256 parts).  ONE function for every fold kernel, so that the grouped and the per-layer folds give the same bits.
+__device__ __forceinline__ float d32_fold_sum(const float* __restrict__ part, long n, int splits, long i) {
+#pragma clang fp reassociate(off)      // the sum runs in split order whatever -ffast-math would like to do with it
+  float s = 0.f;
+  int q = 0;
+  for (; q + 8 <= splits; q += 8) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = part[(long)(q + e) * n + i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += t[e];
+  }
+  for (; q < splits; ++q) s += part[(long)q * n + i];
+  return s;
+}
+
 template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void dense32_group_wgrad_kernel(const D32Job* __restrict__ jobs,
                                                                      const int* __restrict__ wg_job) {
@@ -262,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void dense32_group_wgrad_kernel(const D32Jo
   const D32Args a = jp->a;
   const int local = (int)blockIdx.x - jp->wg_begin;
   const int nt = jp->ntiles;
-  dense32_body<WM, WN, false, false, true>(a, local % nt, local / nt);
+  dense32_body<WM, WN, false, false, true, false>(a, local % nt, local / nt);
 }
 __global__ __launch_bounds__(256) void dense32_group_fold_kernel(const D32FoldJob* __restrict__ jobs,
                                                                  const int* __restrict__ blk_job) {
@@ -270,14 +513,10 @@ __global__ __launch_bounds__(256) void dense32_group_fold_kernel(const D32FoldJo
   const D32FoldJob f = jobs[j];
   const long i = (long)((int)blockIdx.x - f.blk_begin) * 256 + threadIdx.x;
   if (i < f.n) {
-    float s = 0.f;
-    for (int q = 0; q < f.splits; ++q) s += f.part[(long)q * f.n + i];
-    f.dst[i] = s;
+    f.dst[i] = d32_fold_sum(f.part, f.n, f.splits, i);
   } else if (f.db && i - f.n < f.nb) {
     const long jj = i - f.n;
-    float s = 0.f;
-    for (int q = 0; q < f.splits; ++q) s += f.part_db[(long)q * f.nb + jj];
-    f.db[jj] = s;
+    f.db[jj] = d32_fold_sum(f.part_db, f.nb, f.splits, jj);
   }
 }
 
@@ -287,28 +526,68 @@ __global__ __launch_bounds__(256) void dense32_fold_kernel(const float* __restri
                                                            int nb, float* __restrict__ db) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
-    float s = 0.f;
-    for (int q = 0; q < splits; ++q) s += part[(long)q * n + i];
-    dst[i] = s;
+    dst[i] = d32_fold_sum(part, n, splits, i);
   } else if (db && i - n < nb) {
     const long j = i - n;
-    float s = 0.f;
-    for (int q = 0; q < splits; ++q) s += part_db[(long)q * nb + j];
-    db[j] = s;
+    db[j] = d32_fold_sum(part_db, nb, splits, j);
   }
 }
 
-template <bool AC, bool BC, bool WG>
+template <bool AC, bool BC, bool WG, bool LN = false>
 static int d32_launch(const D32Args& a, int splits, hipStream_t s) {
   // tile choice: the largest tile that still gives the chip ~2 workgroups per CU
   auto wgs = [&](int bm, int bn) { return (long)((a.rows + bm - 1) / bm) * ((a.cols + bn - 1) / bn) * splits; };
   if (a.cols > 64 && a.rows > 64 && wgs(128, 128) >= 256) {
-    NNZ_LAUNCH((dense32_kernel<2, 2, AC, BC, WG>), dim3((unsigned)wgs(128, 128) / splits, splits), dim3(256), 0, s, a);
+    NNZ_LAUNCH((dense32_kernel<2, 2, AC, BC, WG, LN>), dim3((unsigned)wgs(128, 128) / splits, splits), dim3(256), 0, s, a);
   } else if (a.cols > 64 && wgs(64, 128) >= 192) {
-    NNZ_LAUNCH((dense32_kernel<1, 2, AC, BC, WG>), dim3((unsigned)wgs(64, 128) / splits, splits), dim3(256), 0, s, a);
+    NNZ_LAUNCH((dense32_kernel<1, 2, AC, BC, WG, LN>), dim3((unsigned)wgs(64, 128) / splits, splits), dim3(256), 0, s, a);
   } else {
-    NNZ_LAUNCH((dense32_kernel<1, 1, AC, BC, WG>), dim3((unsigned)wgs(64, 64) / splits, splits), dim3(256), 0, s, a);
+    NNZ_LAUNCH((dense32_kernel<1, 1, AC, BC, WG, LN>), dim3((unsigned)wgs(64, 64) / splits, splits), dim3(256), 0, s, a);
   }
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// split-K of the forward / input gradient: only products whose 64 x 64 tiling leaves most of the chip idle (< 192 workgroups)
+// and whose contraction is long enough to cut (>= 256); enough splits for ~384 workgroups, each at least 128 steps, at most 16.
+// per = steps per split (a multiple of the 64-step LDS block).  Returns the number of splits (1 = none).
+static int d32_ksplits(long T, int K, int N, int* per_out) {
+  const long tiles = ((T + 63) / 64) * ((N + 63) / 64);
+  int splits = 1;
+  if (tiles < 192 && K >= 256) {
+    splits = (int)((384 + tiles - 1) / tiles);
+    if (splits > K / 128) splits = K / 128;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+  }
+  int per = (K + splits - 1) / splits;
+  per = (per + 63) / 64 * 64;
+  if (per_out) *per_out = per;
+  return (K + per - 1) / per;
+}
+
+// one forward / input-gradient product with everything optional: `a` describes the whole problem (kc = the contraction)
+template <bool BC, bool LN>
+static int d32_run(D32Args a, float* workspace, hipStream_t s) {
+  int per = 0;
+  const int K = a.kc;
+  a.kc_full = K;
+  const int splits = workspace ? d32_ksplits(a.rows, K, a.cols, &per) : 1;
+  if (splits <= 1) {
+    a.ksplit = 1;
+    return d32_launch<true, BC, false, LN>(a, 1, s);
+  }
+  D32Args t = a;                         // the tile launch: raw partials [split][rows][cols] in the workspace
+  t.ksplit = splits; t.kc = per;
+  t.out = workspace; t.ldo = a.cols; t.split_stride = (long)a.rows * a.cols;
+  const long tiles = (long)((a.rows + 63) / 64) * ((a.cols + 63) / 64);
+  NNZ_LAUNCH((dense32_kernel<1, 1, true, BC, false, LN>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s, t);
+  D32Args f = a;                         // the fold: sums the partials in split order, then the epilogue
+  f.ksplit = splits; f.split_stride = t.split_stride;
+  const long n4 = (long)a.rows * a.cols / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  NNZ_LAUNCH(dense32_splitk_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, s, f, (const float*)workspace);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -339,6 +618,60 @@ extern "C" int nnz_dense32_dgrad(const float* dy, const float* W, const float* h
   a.out = dx; a.aux = h; a.ldo = K;
   a.rows = (int)T; a.cols = K; a.kc = N; a.epi = h ? 2 : 0;
   return d32_launch<true, false, false>(a, 1, (hipStream_t)stream);
+}
+
+// ---- the same two products with the fused pieces of a Swin block (round 5) and split-K for skinny shapes ------------------
+// workspace: nnz_dense32_splitk_workspace_floats(T, K, N) floats (contraction K, N output columns), or NULL = never split.
+extern "C" long nnz_dense32_splitk_workspace_floats(long T, int contraction, int out_cols) {
+  if (T < 1 || contraction < 1 || out_cols < 1) return 0;
+  const int splits = nnz::d32_ksplits(T, contraction, out_cols, nullptr);
+  return splits > 1 ? (long)splits * T * out_cols : 0;
+}
+
+// y = epilogue(LN?(x) W^T + bias).  T rows of the OUTPUT (with the pad gather: tokens of the padded grid).
+//   ln_gamma != NULL or ln_mean != NULL: LayerNorm prologue over K (eps ln_eps): writes ln_mean / ln_rstd [T] and, when ln_y is
+//     given, the normalised rows [T][K]; pad_h > 0: x is [B][pad_h][pad_w][K], row r is a token of the top / left padded grid
+//     (pad_h + pad_y) x (pad_w + pad_x) - padded tokens are zero rows (their normalised value is beta);
+//   res != NULL: y = res + s (x W^T + bias), res laid out like y;  dp_rand != NULL: s = floor(dp_keep + dp_rand[row / dp_rps])
+//     / dp_keep (dp_nb samples);  gelu as in nnz_dense32_forward.
+extern "C" int nnz_dense32_forward_fused(const float* x, const float* W, const float* bias, float* y, float* y_act, long T,
+                                         int K, int N, int gelu, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                         float* ln_mean, float* ln_rstd, float* ln_y, int pad_h, int pad_w, int pad_y,
+                                         int pad_x, const float* res, const float* dp_rand, float dp_keep, int dp_rps,
+                                         int dp_nb, float* workspace, void* stream) {
+  using namespace nnz;
+  if (!x || !W || !y || T < 1 || T > (1L << 30) || K < 4 || N < 4 || (K & 3) || (N & 3) || (gelu && !y_act)) return NNZ_EINVAL;
+  const bool ln = ln_mean != nullptr;
+  if (ln && !ln_rstd) return NNZ_EINVAL;
+  if (!ln && (pad_h > 0 || ln_gamma || ln_beta || ln_y)) return NNZ_EINVAL;
+  if (pad_h > 0 && (pad_w < 1 || pad_y < 0 || pad_x < 0 || T % ((long)(pad_h + pad_y) * (pad_w + pad_x)))) return NNZ_EINVAL;
+  if (dp_rand && (!(dp_keep > 0.f) || dp_rps < 1 || dp_nb < 1)) return NNZ_EINVAL;
+  D32Args a = {};
+  a.A = x; a.a_rs = K; a.a_cs = 1;
+  a.B = W; a.b_rs = K; a.b_cs = 1;
+  a.out = y; a.out2 = y_act; a.bias = bias; a.ldo = N;
+  a.rows = (int)T; a.cols = N; a.kc = K; a.epi = gelu ? 1 : 0;
+  a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_y = ln_y;
+  a.pad_h = pad_h; a.pad_w = pad_w; a.pad_y = pad_y; a.pad_x = pad_x;
+  a.res = res; a.dp_rand = dp_rand; a.dp_keep = dp_keep; a.dp_inv = dp_rand ? 1.f / dp_keep : 1.f; a.dp_rps = dp_rps;
+  a.dp_nb = dp_nb;
+  return ln ? d32_run<true, true>(a, workspace, (hipStream_t)stream) : d32_run<true, false>(a, workspace, (hipStream_t)stream);
+}
+
+// dx = s (dy W) [* GELU'(h)]: the input gradient of a branch that was added through DropPath (s as above, NULL = 1)
+extern "C" int nnz_dense32_dgrad_fused(const float* dy, const float* W, const float* h, float* dx, long T, int K, int N,
+                                       const float* dp_rand, float dp_keep, int dp_rps, int dp_nb, float* workspace,
+                                       void* stream) {
+  using namespace nnz;
+  if (!dy || !W || !dx || T < 1 || T > (1L << 30) || K < 4 || N < 4 || (N & 3) || (K & 3)) return NNZ_EINVAL;
+  if (dp_rand && (!(dp_keep > 0.f) || dp_rps < 1 || dp_nb < 1)) return NNZ_EINVAL;
+  D32Args a = {};
+  a.A = dy; a.a_rs = N; a.a_cs = 1;
+  a.B = W; a.b_rs = 1; a.b_cs = K;
+  a.out = dx; a.aux = h; a.ldo = K;
+  a.rows = (int)T; a.cols = K; a.kc = N; a.epi = h ? 2 : 0;
+  a.dp_rand = dp_rand; a.dp_keep = dp_keep; a.dp_inv = dp_rand ? 1.f / dp_keep : 1.f; a.dp_rps = dp_rps; a.dp_nb = dp_nb;
+  return d32_run<false, false>(a, workspace, (hipStream_t)stream);
 }
 
 // token splits of the weight gradient: none when the weight matrix alone gives >= 256 tiles of 64 x 64, otherwise enough
@@ -446,6 +779,32 @@ extern "C" int nnz_dense32_group_fill(void* job_host, void* fold_host, const flo
     *reinterpret_cast<D32FoldJob*>(fold_host) = f;
   }
   *reinterpret_cast<D32Job*>(job_host) = j;
+  return NNZ_OK;
+}
+// the same record for a branch that was added through DropPath: the dy operand is scaled per token by
+// s = floor(dp_keep + dp_rand[token / dp_rps]) / dp_keep while it is staged (dp_nb samples) - dW = sum_t s_t dy[t]^T x[t], and the
+// bias gradient (the column sums of the scaled tile) likewise
+extern "C" int nnz_dense32_group_fill_scaled(void* job_host, void* fold_host, const float* dy, const float* x, float* dW,
+                                             float* db, float* workspace, long T, int K, int N, int wg_begin, int blk_begin,
+                                             const float* dp_rand, float dp_keep, int dp_rps, int dp_nb) {
+  using namespace nnz;
+  if (dp_rand && (!(dp_keep > 0.f) || dp_rps < 1 || dp_nb < 1)) return NNZ_EINVAL;
+  const int rc = nnz_dense32_group_fill(job_host, fold_host, dy, x, dW, db, workspace, T, K, N, wg_begin, blk_begin);
+  if (rc != NNZ_OK) return rc;
+  D32Job* j = reinterpret_cast<D32Job*>(job_host);
+  j->a.dp_rand = dp_rand; j->a.dp_keep = dp_keep; j->a.dp_inv = dp_rand ? 1.f / dp_keep : 1.f; j->a.dp_rps = dp_rps;
+  j->a.dp_nb = dp_nb;
+  return NNZ_OK;
+}
+// a fold-only record (no product): dst[i] = sum_{q < parts} part[q * n + i], i < n, in part order - the LayerNorm backward of the
+// fused Swin block leaves its per-workgroup dgamma | dbeta partials ([parts][2 C]) to this launch instead of ending every
+// backward launch with fixed-point adds and a last-workgroup pass
+extern "C" int nnz_dense32_group_fill_fold(void* fold_host, const float* part, float* dst, long n, int parts, int blk_begin) {
+  using namespace nnz;
+  if (!fold_host || !part || !dst || n < 1 || parts < 1 || blk_begin < 0) return NNZ_EINVAL;
+  D32FoldJob f = {};
+  f.part = part; f.dst = dst; f.n = n; f.splits = parts; f.nb = 0; f.blk_begin = blk_begin;
+  *reinterpret_cast<D32FoldJob*>(fold_host) = f;
   return NNZ_OK;
 }
 // all jobs of one launch must be of the same class (nnz_dense32_group_class)

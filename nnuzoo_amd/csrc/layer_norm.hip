@@ -36,6 +36,13 @@ struct LnArgs {
   unsigned* counter;  // then WRITTEN by the launch's last workgroup (no zero fill, no float atomics)
   float* zero_buf;  // forward: [2][C] buffer the matching backward will accumulate dgamma / dbeta into - zeroed here, so the
                     // backward needs no zeroing launch of its own (may be null)
+  // round 5, backward of the fused Swin block (fp32): `part` != null - every workgroup WRITES its dgamma | dbeta partial sums to
+  // part[blockIdx.x][2 C] and returns (a fold job of the pass's grouped launch sums them in workgroup order: no fixed-point
+  // adds, no last-workgroup tail per launch).  pad_h > 0: the R rows are the tokens of the top / left padded grid
+  // (pad_h + pad_y) x (pad_w + pad_x) (dy, mean, rstd are laid out on it); x, dres and dx live on the unpadded [B][pad_h][pad_w]
+  // grid - padded tokens read x = 0, contribute to dgamma / dbeta, and their dx is dropped (the crop's backward).
+  float* part;
+  int pad_h, pad_w, pad_y, pad_x;
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
@@ -145,7 +152,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
     db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (long r = (long)blockIdx.x * GPW + g; r < a.R; r += (long)gridDim.x * GPW) {
-    const T* xr = (const T*)a.x + r * C;
+    long sr = r;                                  // row of x / dres / dx
+    if (a.pad_h > 0) {
+      const int hp = a.pad_h + a.pad_y, wp = a.pad_w + a.pad_x;
+      const int b = (int)(r / (hp * wp)), rem = (int)(r - (long)b * (hp * wp));
+      const int y = rem / wp, x = rem - y * wp;
+      sr = (y >= a.pad_y && x >= a.pad_x) ? ((long)b * a.pad_h + (y - a.pad_y)) * a.pad_w + (x - a.pad_x) : -1;
+    }
+    const T* xr = (const T*)a.x + (sr < 0 ? 0 : sr) * C;
     const long dyo = r * C;
     const float mu = a.mean[r], rs = a.rstd[r];
     f32x4 xh[IT], gy[IT];
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
     for (int i = 0; i < IT; ++i) {
       const int c = 4 * (q + LPR * i);
       if (c < C) {
-        const f32x4 xv = ld4(xr + c);
+        const f32x4 xv = sr < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(xr + c);
         f32x4 dv = a.dy_is_f16 ? ld4((const f16*)a.dy + dyo + c) : ld4((const float*)a.dy + dyo + c);
         if (a.z) {
           // out = n * silu(z), n = xhat * gamma + beta:  dn = dout * silu(z);  dz = dout * n * silu'(z)
@@ -184,7 +198,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
       }
     }
     const float m1 = group_sum<LPR>(s1) * invC, m2 = group_sum<LPR>(s2) * invC;
-    T* dxr = (T*)a.dx + r * C;
+    if (sr < 0) continue;                         // a padded token: its dx is cropped away
+    T* dxr = (T*)a.dx + sr * C;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = 4 * (q + LPR * i);
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
         if (a.dres) {
-          const f32x4 sk = ld4(a.dres + r * C + c);
+          const f32x4 sk = ld4(a.dres + sr * C + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = sk[e] + o[e];
         }
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
       }
     }
   }
-  if (!a.dgamma && !a.dbeta) return;
+  if (!a.dgamma && !a.dbeta && !a.part) return;
   // fold the lane groups' partials: fold[.][g][channel], then thread c sums over g
 #pragma unroll
   for (int i = 0; i < IT; ++i)
@@ -218,7 +233,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
       sg += fold[0][gg][c];
       sb += fold[1][gg][c];
     }
-    if (a.acc) {
+    if (a.part) {
+      a.part[(long)blockIdx.x * 2 * C + c] = sg;
+      a.part[(long)blockIdx.x * 2 * C + C + c] = sb;
+    } else if (a.acc) {
       fx_add(a.acc, c, 2L * C, blockIdx.x, (double)sg);
       fx_add(a.acc, (long)C + c, 2L * C, blockIdx.x, (double)sb);
     } else {
@@ -234,6 +252,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
     }
 }
 
+static int ln_lpr(int C) { return C <= 16 ? 4 : C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64; }
+static long ln_bwd_cap() {
+  static const long cap = [] { const char* e = getenv("NNZ_LN_BWD_CAP"); return e && atol(e) > 0 ? atol(e) : 256L; }();
+  return cap;
+}
+// workgroups of a backward launch over `rows` rows of C channels (= the number of dgamma | dbeta partials of the `part` mode)
+static long ln_bwd_grid(long rows, int C) {
+  const int gpw = 256 / ln_lpr(C);
+  const long want = (rows + gpw - 1) / gpw;
+  return want < ln_bwd_cap() ? (want < 1 ? 1 : want) : ln_bwd_cap();
+}
+
 template <class T, int LPR, int IT>
 static int ln_launch(const LnArgs& a, bool bwd, hipStream_t s) {
   constexpr int GPW = 256 / LPR;
@@ -242,8 +272,7 @@ static int ln_launch(const LnArgs& a, bool bwd, hipStream_t s) {
   // every workgroup ends with 2 C fixed-point adds and the last one waits for all of them, so the tail grows with the grid
   // (SwT2Net step at 1024 / 512 / 256 / 128 / 64 workgroups: 84.1 / 82.6 / 81.6 / 81.3 / 82.5 ms, M2Net 87.8 / 86.9 / 86.8 /
   // 88.4 / 91.5 ms; NNZ_LN_BWD_CAP overrides)
-  static const long bwd_cap = [] { const char* e = getenv("NNZ_LN_BWD_CAP"); return e && atol(e) > 0 ? atol(e) : 256L; }();
-  const long cap = bwd ? bwd_cap : 8192;
+  const long cap = bwd ? ln_bwd_cap() : 8192;
   const unsigned grid = (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
   if (bwd)
     NNZ_LAUNCH((ln_bwd_kernel<T, LPR, IT>), dim3(grid), dim3(256), 0, s, a);
@@ -369,4 +398,25 @@ extern "C" int nnz_layer_norm_backward_det_res(const void* x, int x_is_f16, cons
   if (!acc || !counter) return NNZ_EINVAL;
   return ln_backward_impl(x, x_is_f16, gamma, nullptr, nullptr, 0, 0, mean, rstd, dy, dy_is_f16, dx, nullptr, dgamma,
                           dbeta, 1, rows, C, stream, acc, counter, dres);
+}
+
+// ---- round 5: the LayerNorm backward of the fused Swin block (fp32) ---------------------------------------------------------
+// dx = dres + LayerNorm-backward(dy) like nnz_layer_norm_backward_det_res, but (1) dgamma | dbeta leave the launch as
+// per-workgroup partials part[nnz_layer_norm_backward_parts(rows, C)][2 C], to be summed in workgroup order by a fold job of the
+// backward pass's grouped launch (nnz_dense32_group_fill_fold), and (2) with pad_h > 0 the rows are the tokens of the block's
+// top / left padded grid (dy / mean / rstd on it) while x / dres / dx live on the unpadded [B][pad_h][pad_w] grid.
+extern "C" long nnz_layer_norm_backward_parts(long rows, int C) {
+  if (rows < 1 || C < 4 || C > 2048) return 0;
+  return nnz::ln_bwd_grid(rows, C);
+}
+extern "C" int nnz_layer_norm_backward_partial(const float* x, const float* gamma, const float* mean, const float* rstd,
+                                               const float* dy, const float* dres, float* dx, float* part, long rows, int C,
+                                               int pad_h, int pad_w, int pad_y, int pad_x, void* stream) {
+  using namespace nnz;
+  if (!x || !mean || !rstd || !dy || !dx || !part || rows < 1 || C < 4 || (C & 3) || C > 2048) return NNZ_EINVAL;
+  if (pad_h > 0 && (pad_w < 1 || pad_y < 0 || pad_x < 0 || rows % ((long)(pad_h + pad_y) * (pad_w + pad_x)))) return NNZ_EINVAL;
+  LnArgs a = {};
+  a.x = x; a.gamma = gamma; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dx = dx; a.dres = dres; a.part = part;
+  a.R = rows; a.C = C; a.pad_h = pad_h; a.pad_w = pad_w; a.pad_y = pad_y; a.pad_x = pad_x;
+  return ln_dispatch<float>(a, true, (hipStream_t)stream);
 }

@@ -51,6 +51,10 @@ struct AttnArgs {
   int B, H, W, C, heads, hd, shift;
   int nwin, wpb;       // windows in total, windows per workgroup
   float scale;
+  // round 5: H x W is the block's top / left padded grid (swt2net.py:643-645) and `out` / `dout` live on the UNPADDED grid
+  // (H - py) x (W - px): the block's crop (:660) and its backward (zero rows for padded tokens) are folded into the addressing.
+  // py = px = 0: out / dout on the same grid as qkv.
+  int py, px;
 };
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
@@ -59,7 +63,7 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
 __device__ __forceinline__ int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // token l of window `win`: element offset of its (b, y, x) position in units of one token row, and its shift-mask region
-__device__ __forceinline__ void token_map(const AttnArgs& a, int win, int l, int& base, int& region) {
+__device__ __forceinline__ void token_map(const AttnArgs& a, int win, int l, int& base, int& region, int& ubase) {
   const int nww = a.W / WA_WS, nwh = a.H / WA_WS;
   const int b = win / (nwh * nww);
   const int wi = (win / nww) % nwh, wj = win % nww;
@@ -68,6 +72,7 @@ __device__ __forceinline__ void token_map(const AttnArgs& a, int win, int l, int
   if (y >= a.H) y -= a.H;
   if (x >= a.W) x -= a.W;
   base = (b * a.H + y) * a.W + x;
+  ubase = (y >= a.py && x >= a.px) ? (b * (a.H - a.py) + (y - a.py)) * (a.W - a.px) + (x - a.px) : -1;
   region = 0;
   if (a.shift > 0) {
     const int hid = r < a.H - WA_WS ? 0 : (r < a.H - a.shift ? 1 : 2);
@@ -85,14 +90,16 @@ __device__ __forceinline__ void stage_image(const float* src, long row_len, int 
     const int q4 = hd >> 2;
     for (int i = lane; i < WA_L * q4; i += 64) {
       const int l = i / q4, c4 = (i - l * q4) * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)stok[l] * row_len + ch0 + c4);
+      const int t = stok[l];
+      const f32x4 v = t >= 0 ? *reinterpret_cast<const f32x4*>(src + (long)t * row_len + ch0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
       float* d = dst + l * WA_LD + c4;
       d[0] = v[0] * mul; d[1] = v[1] * mul; d[2] = v[2] * mul; d[3] = v[3] * mul;
     }
   } else {
     for (int i = lane; i < WA_L * hd; i += 64) {
       const int l = i / hd, c = i - l * hd;
-      dst[l * WA_LD + c] = src[(long)stok[l] * row_len + ch0 + c] * mul;
+      const int t = stok[l];
+      dst[l * WA_LD + c] = t >= 0 ? src[(long)t * row_len + ch0 + c] * mul : 0.f;
     }
   }
 }
@@ -161,11 +168,26 @@ __device__ __forceinline__ void store_cols(float* dst, const f32x16& o, int hh, 
   }
 }
 
-// the head's bias matrix, transposed: sbT[key j][query i] = table[index[i][j]][head]   (one gather per workgroup)
-__device__ __forceinline__ void stage_bias(const AttnArgs& a, int head, float* sbT, int tid, int nthreads) {
-  for (int e = tid; e < WA_L * WA_L; e += nthreads) {
-    const int i = e / WA_L, j = e - i * WA_L;
-    sbT[j * WA_BP + i] = a.bias[a.bidx[e] * a.heads + head];
+// the head's bias matrix, transposed: sbT[key j][query i] = table[index[i][j]][head]   (once per workgroup).
+// Round 5: the head's 169 table entries go to LDS first (`stab`, any 169 floats of LDS that nothing else uses before the caller's
+// next barrier) and the 2 401 index words are plain coalesced loads - two INDEPENDENT global round trips instead of ten rounds of
+// index load -> dependent table load (the gather alone was a third of the 12 us / 36 us floor of a launch).
+__device__ __forceinline__ void stage_bias(const AttnArgs& a, int head, float* sbT, float* stab, int tid, int nthreads) {
+  int idx[(WA_L * WA_L + 255) / 256];
+#pragma unroll
+  for (int q = 0; q < (WA_L * WA_L + 255) / 256; ++q) {
+    const int e = tid + q * 256;
+    idx[q] = e < WA_L * WA_L ? a.bidx[e] : 0;
+  }
+  for (int e = tid; e < WA_NBIAS; e += nthreads) stab[e] = a.bias[e * a.heads + head];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < (WA_L * WA_L + 255) / 256; ++q) {
+    const int e = tid + q * 256;
+    if (e < WA_L * WA_L) {
+      const int i = e / WA_L, j = e - i * WA_L;
+      sbT[j * WA_BP + i] = stab[idx[q]];
+    }
   }
 }
 
@@ -235,27 +257,29 @@ constexpr int WA_IMG = WA_L * WA_LD;  // floats of one [49][33] image
 __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sbT = smem;                                      // [49][64]
-  float* wbase = smem + WA_L * WA_BP;                     // per wave: sk, sv images | stok, sreg
+  float* wbase = smem + WA_L * WA_BP;                     // per wave: sk, sv images | stok, sreg, sutok
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
   const int head = blockIdx.y;
   const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
-  float* sk = wbase + wave * (2 * WA_IMG + 128);
+  float* sk = wbase + wave * (2 * WA_IMG + 192);
   float* sv = sk + WA_IMG;
   int* stok = reinterpret_cast<int*>(sv + WA_IMG);
   int* sreg = stok + 64;
-  stage_bias(a, head, sbT, tid, 256);
+  int* sutok = sreg + 64;      // token index on the unpadded grid of out / dout, -1 = a padded token
+  stage_bias(a, head, sbT, wbase, tid, 256);   // wbase: image space, unused until the barrier below
   __syncthreads();
   const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
   for (int win = blockIdx.x * a.wpb + wave; win < w_end; win += 4) {
     wave_sync();  // the previous window's readers are done with the images / stok / sreg
     {
-      int base = 0, region = 0;
-      if (lane < WA_L) token_map(a, win, lane, base, region);
+      int base = 0, region = 0, ubase = -1;
+      if (lane < WA_L) token_map(a, win, lane, base, region, ubase);
       stok[lane] = base;
       sreg[lane] = region;
+      sutok[lane] = ubase;
     }
     wave_sync();
     float qv[2][16];
@@ -284,7 +308,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o = mfma_f32(vc[r], p[tk][r], o);
       }
       const int i = tq * 32 + l31;
-      if (i < WA_L) store_cols(a.out + (long)stok[i] * a.C + head * hd, o, hh, hd, 1.f);
+      if (i < WA_L && sutok[i] >= 0) store_cols(a.out + (long)sutok[i] * a.C + head * hd, o, hh, hd, 1.f);
     }
   }
 }
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
 __global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sbT = smem;                                      // [49][64]
-  float* wbase = smem + WA_L * WA_BP;                     // per wave: sk, sv images | stok, sreg
+  float* wbase = smem + WA_L * WA_BP;                     // per wave: sk, sv images | stok, sreg, sutok
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,11 +326,12 @@ __global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
   const int head = blockIdx.y;
   const int C3 = 3 * a.C, hd = a.hd, steps = hd >> 1;
   const int pair = wave >> 1, role = wave & 1;
-  float* sk = wbase + pair * (2 * WA_IMG + 128);
+  float* sk = wbase + pair * (2 * WA_IMG + 192);
   float* sv = sk + WA_IMG;
   int* stok = reinterpret_cast<int*>(sv + WA_IMG);
   int* sreg = stok + 64;
-  stage_bias(a, head, sbT, tid, 256);
+  int* sutok = sreg + 64;      // token index on the unpadded grid of out / dout, -1 = a padded token
+  stage_bias(a, head, sbT, wbase, tid, 256);   // wbase: image space, unused until the barrier below
   __syncthreads();
   const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
   const int iters = (a.wpb + 1) / 2;
@@ -315,10 +340,11 @@ __global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
     const bool live = win < w_end;
     lds_barrier();  // the previous window's readers are done with the images / stok / sreg
     if (live && role == 0) {
-      int base = 0, region = 0;
-      if (lane < WA_L) token_map(a, win, lane, base, region);
+      int base = 0, region = 0, ubase = -1;
+      if (lane < WA_L) token_map(a, win, lane, base, region, ubase);
       stok[lane] = base;
       sreg[lane] = region;
+      sutok[lane] = ubase;
     }
     lds_barrier();
     float qv[16];
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o = mfma_f32(vc[r], p[tk][r], o);
       }
       const int i = tq * 32 + l31;
-      if (i < WA_L) store_cols(a.out + (long)stok[i] * a.C + head * hd, o, hh, hd, 1.f);
+      if (i < WA_L && sutok[i] >= 0) store_cols(a.out + (long)sutok[i] * a.C + head * hd, o, hh, hd, 1.f);
     }
   }
 }
@@ -359,7 +385,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
 // Row statistics cross from A to B through LDS.  LDS per workgroup: the head's bias matrix and per wave four operand images,
 // one [49][33] dS tile for the bias-gradient sums, the row statistics and the token map (~150 KB: one workgroup per CU).
 constexpr int WA_DSP = 33;                                    // pitch of the per-key-tile dS image [query][key - 32 tk]
-constexpr int WA_WAVE_FLOATS = 4 * WA_IMG + WA_L * WA_DSP + 3 * 64 + 2 * 64;  // sq sk sv sdo | sds | srow[3][64] | stok, sreg
+constexpr int WA_WAVE_FLOATS = 4 * WA_IMG + WA_L * WA_DSP + 3 * 64 + 3 * 64;  // sq sk sv sdo | sds | srow[3][64] | stok, sreg, sutok
 
 __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -380,9 +406,10 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
   float* srow = sds + WA_L * WA_DSP;                   // [3][64]: row max, 1 / sum, delta per query
   int* stok = reinterpret_cast<int*>(srow + 3 * 64);
   int* sreg = stok + 64;
+  int* sutok = sreg + 64;      // token index on the unpadded grid of out / dout, -1 = a padded token
   float* sdb = sdb_all + wave * 176;
   const int qo = head * hd, ko = a.C + head * hd, vo = 2 * a.C + head * hd;
-  stage_bias(a, head, sbT, tid, 256);
+  stage_bias(a, head, sbT, wbase, tid, 256);   // wbase: image space, unused until the barrier below
   // the wave's share of the bias-table gradient: lane owns table entries lane, lane + 64, lane + 128
   float db_acc[3] = {0.f, 0.f, 0.f};
   __syncthreads();
@@ -390,16 +417,17 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
   for (int win = blockIdx.x * a.wpb + wave; win < w_end; win += 4) {
     wave_sync();
     {
-      int base = 0, region = 0;
-      if (lane < WA_L) token_map(a, win, lane, base, region);
+      int base = 0, region = 0, ubase = -1;
+      if (lane < WA_L) token_map(a, win, lane, base, region, ubase);
       stok[lane] = base;
       sreg[lane] = region;
+      sutok[lane] = ubase;
     }
     wave_sync();
     stage_image(a.qkv, C3, qo, hd, stok, a.scale, sq, lane);
     stage_image(a.qkv, C3, ko, hd, stok, 1.f, sk, lane);
     stage_image(a.qkv, C3, vo, hd, stok, 1.f, sv, lane);
-    stage_image(a.dout, a.C, qo, hd, stok, 1.f, sdo, lane);
+    stage_image(a.dout, a.C, qo, hd, sutok, 1.f, sdo, lane);
     wave_sync();
 
     // ---------------- pass A: keys on rows, queries on lanes --------------------------------------------------------
@@ -573,7 +601,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
 // tile `role` in pass A and key tile `role` in pass B (each with its own dS tile).  The pair meets at workgroup barriers
 // (both pairs run the same number of iterations; a pair without a window idles through them).
 static_assert(WA_L * WA_DSP <= WA_IMG, "a dS tile must fit the image it replaces");
-constexpr int WA_PAIR_FLOATS = 4 * WA_IMG + 3 * 64 + 2 * 64;  // sq sk sv sdo (sk / sv double as the dS tiles) | srow[3][64] | stok, sreg
+constexpr int WA_PAIR_FLOATS = 4 * WA_IMG + 3 * 64 + 3 * 64;  // sq sk sv sdo (sk / sv double as the dS tiles) | srow[3][64] | stok, sreg, sutok
 
 __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -597,9 +625,10 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   float* srow = sdo + WA_IMG;                          // [3][64]: row max, 1 / sum, delta per query
   int* stok = reinterpret_cast<int*>(srow + 3 * 64);
   int* sreg = stok + 64;
+  int* sutok = sreg + 64;      // token index on the unpadded grid of out / dout, -1 = a padded token
   float* sdb = sdb_all + wave * 176;
   const int qo = head * hd, ko = a.C + head * hd, vo = 2 * a.C + head * hd;
-  stage_bias(a, head, sbT, tid, 256);
+  stage_bias(a, head, sbT, wbase, tid, 256);   // wbase: image space, unused until the barrier below
   // the wave's share of the bias-table gradient: lane owns table entries lane, lane + 64, lane + 128
   float db_acc[3] = {0.f, 0.f, 0.f};
   __syncthreads();
@@ -610,10 +639,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
     const bool live = win < w_end;
     lds_barrier();   // the previous window's readers are done with the images / stok / sreg
     if (live && role == 0) {
-      int base = 0, region = 0;
-      if (lane < WA_L) token_map(a, win, lane, base, region);
+      int base = 0, region = 0, ubase = -1;
+      if (lane < WA_L) token_map(a, win, lane, base, region, ubase);
       stok[lane] = base;
       sreg[lane] = region;
+      sutok[lane] = ubase;
     }
     lds_barrier();
     if (live) {
@@ -622,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
         stage_image(a.qkv, C3, ko, hd, stok, 1.f, sk, lane);
       } else {
         stage_image(a.qkv, C3, vo, hd, stok, 1.f, sv, lane);
-        stage_image(a.dout, a.C, qo, hd, stok, 1.f, sdo, lane);
+        stage_image(a.dout, a.C, qo, hd, sutok, 1.f, sdo, lane);
       }
     }
     lds_barrier();
@@ -812,21 +842,21 @@ static int windows_per_wg(int nwin, int heads) {
 
 }  // namespace nnz
 
-extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out,
-                                            int B, int H, int W, int C, int heads, int shift, float scale,
-                                            void* stream) {
+static int wa_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out, int B, int H, int W, int C,
+                      int heads, int shift, float scale, int py, int px, void* stream) {
   using namespace nnz;
-  if (!qkv || !bias_table || !bias_index || !out) return NNZ_EINVAL;
+  if (!qkv || !bias_table || !bias_index || !out || py < 0 || px < 0 || py >= H || px >= W) return NNZ_EINVAL;
   AttnArgs a = {};
   a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.out = out;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
+  a.py = py; a.px = px;
   if (int rc = check(a)) return rc;
   a.nwin = B * (H / WA_WS) * (W / WA_WS);
   static const int pair_mode = [] { const char* v = getenv("NNZ_WA_PAIR"); return v ? atoi(v) : 1; }();
   if (pair_mode) {
     a.wpb = a.nwin < 2 ? 1 : 2;
     while (a.wpb < 8 && (long)((a.nwin + 2 * a.wpb - 1) / (2 * a.wpb)) * heads >= 2048) a.wpb *= 2;
-    const int ldsp = (WA_L * WA_BP + 2 * (2 * WA_IMG + 128)) * (int)sizeof(float);
+    const int ldsp = (WA_L * WA_BP + 2 * (2 * WA_IMG + 192)) * (int)sizeof(float);
     static DynLdsCache cachep;
     hipError_t ep = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_fwd_pair_kernel), ldsp, cachep);
     if (ep != hipSuccess) return (int)ep;
@@ -835,7 +865,7 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
     return NNZ_OK;
   }
   a.wpb = windows_per_wg(a.nwin, heads);
-  const int lds = (WA_L * WA_BP + 4 * (2 * WA_IMG + 128)) * (int)sizeof(float);
+  const int lds = (WA_L * WA_BP + 4 * (2 * WA_IMG + 192)) * (int)sizeof(float);
   static DynLdsCache cache;
   hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(win_attn_fwd_kernel), lds, cache);
   if (e != hipSuccess) return (int)e;
@@ -847,15 +877,17 @@ extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_
 // acc: heads * 169 zeroed fixed-point records (nnz_fxacc_bytes() each) followed by `heads` zeroed 32-byte ticket records
 // (i.e. at least heads * 170 records of nnz_fxacc_bytes()); all left zero.  `counter` is unused (kept in the signature).
 // dbias_table is WRITTEN (no zero fill needed) and bit-identical run to run.
-extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index,
-                                             const float* dout, float* dqkv, float* dbias_table, void* acc, void* counter,
-                                             int B, int H, int W, int C, int heads, int shift, float scale, void* stream) {
+static int wa_backward(const float* qkv, const float* bias_table, const int* bias_index, const float* dout, float* dqkv,
+                       float* dbias_table, void* acc, void* counter, int B, int H, int W, int C, int heads, int shift,
+                       float scale, int py, int px, void* stream) {
   using namespace nnz;
-  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table || !acc) return NNZ_EINVAL;
+  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table || !acc || py < 0 || px < 0 || py >= H || px >= W)
+    return NNZ_EINVAL;
   AttnArgs a = {};
   a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.dout = dout; a.dqkv = dqkv; a.dbias = dbias_table;
   a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
+  a.py = py; a.px = px;
   if (int rc = check(a)) return rc;
   a.nwin = B * (H / WA_WS) * (W / WA_WS);
   a.wpb = windows_per_wg(a.nwin, heads);
@@ -882,4 +914,30 @@ extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias
   NNZ_LAUNCH(win_attn_bwd_kernel, dim3((a.nwin + a.wpb - 1) / a.wpb, heads), dim3(256), lds, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+
+extern "C" int nnz_window_attention_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out,
+                                            int B, int H, int W, int C, int heads, int shift, float scale,
+                                            void* stream) {
+  return wa_forward(qkv, bias_table, bias_index, out, B, H, W, C, heads, shift, scale, 0, 0, stream);
+}
+extern "C" int nnz_window_attention_backward(const float* qkv, const float* bias_table, const int* bias_index,
+                                             const float* dout, float* dqkv, float* dbias_table, void* acc, void* counter,
+                                             int B, int H, int W, int C, int heads, int shift, float scale, void* stream) {
+  return wa_backward(qkv, bias_table, bias_index, dout, dqkv, dbias_table, acc, counter, B, H, W, C, heads, shift, scale, 0, 0,
+                     stream);
+}
+// round 5: the same pair inside the fused Swin block - qkv / dqkv on the block's top / left padded grid H x W, out / dout on the
+// unpadded grid (H - py) x (W - px): the rows of padded tokens are never written (forward) and read as zeros (backward)
+extern "C" int nnz_window_attention_forward_pad(const float* qkv, const float* bias_table, const int* bias_index, float* out,
+                                                int B, int H, int W, int C, int heads, int shift, float scale, int py,
+                                                int px, void* stream) {
+  return wa_forward(qkv, bias_table, bias_index, out, B, H, W, C, heads, shift, scale, py, px, stream);
+}
+extern "C" int nnz_window_attention_backward_pad(const float* qkv, const float* bias_table, const int* bias_index,
+                                                 const float* dout, float* dqkv, float* dbias_table, void* acc,
+                                                 void* counter, int B, int H, int W, int C, int heads, int shift,
+                                                 float scale, int py, int px, void* stream) {
+  return wa_backward(qkv, bias_table, bias_index, dout, dqkv, dbias_table, acc, counter, B, H, W, C, heads, shift, scale, py,
+                     px, stream);
 }

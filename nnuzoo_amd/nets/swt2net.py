@@ -9,7 +9,9 @@ parameter / buffer names and shapes as /root/reference/nnunetv2/nets/swt2net.py,
 
 The attention core (roll, window partition, per-head softmax(q k^T + bias + mask) v, merge, un-partition, roll back)
 is ONE hand-written gfx950 MFMA kernel (nnuzoo_amd.window_attention, csrc/window_attention.hip) in fp32, as the
-reference's Swin trainers run without autocast; qkv/proj/MLP Linears and LayerNorms are library ops.
+reference's Swin trainers run without autocast; in the fp32 device step a whole SwinTransformerBlock is one autograd node of
+five forward and seven backward launches (nnuzoo_amd/swin_block.py: pad / crop, both LayerNorms, DropPath and the residual adds
+live in the prologues / epilogues of the fp32 MFMA Linear kernels, csrc/dense32.hip).
 """
 from __future__ import annotations
 
@@ -24,6 +26,7 @@ from ..layer_norm import LayerNorm, layer_norm_skip
 from ..token_linear import TokenLinear, mlp_gelu
 
 from ..utilities.network_initialization import InitWeights_He
+from ..swin_block import fused_block_ok, swin_block_forward
 from ..window_attention import window_attention_core
 from .common2d import Convolution, PatchExpand, PatchMerging2D, _ResidualDropPathFn, get_dwconv_layer
 from .common2d import RSU4F as _RSU4F
@@ -245,6 +248,8 @@ class SwinTransformerBlock(nn.Module):
         return _ResidualDropPathFn.apply(inp, y, None, 1.0)
 
     def forward(self, x):
+        if self.window_size == 7 and fused_block_ok(self, x):
+            return swin_block_forward(self, x)      # five launches forward, seven backward (nnuzoo_amd/swin_block.py)
         _, H, W, _ = x.shape
         ws = self.window_size
         pad = H % ws != 0 or W % ws != 0

@@ -190,7 +190,7 @@ GROUP_WGRAD = os.environ.get("NNZ_DENSE32_GROUP", "1") != "0"
 # costs 0.9-1.4 % of an M2Net / M2NetP / SSND2Net step, and the steps of the Mamba nets stay non-reproducible either way (the scan
 # backward's cross-channel dB / dC / d-delta sums) - so it is an option, not the default.
 TWO_STAGE = os.environ.get("NNZ_TWO_STAGE_WGRADS", "0") == "1"
-_DEFER = {"on": False, "jobs": []}
+_DEFER = {"on": False, "jobs": [], "folds": []}
 _GROUP_KEEP = []          # host tables captured into a hipGraph must outlive it
 _HOST_CACHE, _HOST_EVENTS = {}, {}
 
@@ -215,29 +215,48 @@ class deferred_wgrads:
         if not self._outer:
             _DEFER["on"] = False
             jobs, _DEFER["jobs"] = _DEFER["jobs"], []
+            folds, _DEFER["folds"] = _DEFER["folds"], []
             if et is None and jobs:
-                # one grouped launch per tile class (64 x 64 / 128 x 128 tiles; csrc/dense32.hip d32_group_class)
+                # one grouped launch per tile class (64 x 64 / 128 x 128 tiles; csrc/dense32.hip d32_group_class); the fold-only
+                # records (LayerNorm dgamma | dbeta partials of the fused Swin blocks) ride in the first one
                 lib = _lib.load()
                 for cls in (0, 1):
                     sub = [j for j in jobs if int(lib.nnz_dense32_group_class(j[1].shape[0], j[2].shape[1], j[2].shape[0])) == cls]
                     if sub:
-                        _flush_group(sub, cls)
+                        _flush_group(sub, cls, folds)
+                        folds = []
+            if et is None and folds:
+                for part, n, parts, assign in folds:        # no Linear job in this pass to ride with
+                    assign(part.view(parts, n).sum(0))
         return False
 
 
-def _flush_group(jobs, tile_class: int = 0) -> None:
+def defer_fold(part: torch.Tensor, n: int, parts: int, assign) -> bool:
+    """queue dst[i] = sum_q part[q][i] (q < parts, i < n) for the grouped launch at the end of the backward pass; `assign(dst)` is
+    called with the [n] result tensor right after the launch has been issued.  False outside deferred_wgrads()."""
+    if not _DEFER["on"]:
+        return False
+    _DEFER["folds"].append((part, n, parts, assign))
+    return True
+
+
+def _flush_group(jobs, tile_class: int = 0, folds=()) -> None:
+    """jobs: (dy2, x2, weight, bias or None[, (dp_rand, keep, rows_per_sample, samples)]) - the optional fifth entry scales the dy
+    operand per token (weight gradient of a DropPath branch, csrc/dense32.hip nnz_dense32_group_fill_scaled)"""
     import numpy as np
     lib = _lib.load()
     dev = jobs[0][0].device
     rb_job, rb_fold = int(lib.nnz_dense32_group_record_bytes(0)), int(lib.nnz_dense32_group_record_bytes(1))
     plans = []
     wgs, blks, ws_f = C.c_int(0), C.c_int(0), C.c_long(0)
-    for dy2, x2, w, b in jobs:
+    for job in jobs:
+        dy2, x2, w, b = job[:4]
         N, K = w.shape
         call("nnz_dense32_group_plan", x2.shape[0], K, N, C.addressof(wgs), C.addressof(blks), C.addressof(ws_f))
         plans.append((wgs.value, blks.value, ws_f.value))
-    nfold = sum(1 for p in plans if p[1] > 0)
-    total_wgs, total_blks = sum(p[0] for p in plans), sum(p[1] for p in plans)
+    fold_blks = [(n + 255) // 256 for _, n, _, _ in folds]
+    nfold = sum(1 for p in plans if p[1] > 0) + len(folds)
+    total_wgs, total_blks = sum(p[0] for p in plans), sum(p[1] for p in plans) + sum(fold_blks)
     ws = torch.empty(max(1, sum(p[2] for p in plans)), dtype=torch.float32, device=dev)
     # one pinned host buffer: [job records | fold records | workgroup -> job | fold block -> fold job]
     o_fold = (len(jobs) * rb_job + 15) // 16 * 16
@@ -247,7 +266,8 @@ def _flush_group(jobs, tile_class: int = 0) -> None:
     # that precede every capture leave their buffer in _HOST_CACHE under the pass's shape signature; a capturing flush TAKES
     # it (the captured copy node re-reads it at every replay, so no later flush may write to it).
     nbytes = o_blk + max(1, total_blks) * 4
-    key = (tile_class,) + tuple((x2.shape[0],) + tuple(w.shape) + (b is not None,) for _, x2, w, b in jobs)
+    key = (tile_class,) + tuple((j[1].shape[0],) + tuple(j[2].shape) + (j[3] is not None, len(j) > 4 and j[4] is not None)
+                                for j in jobs) + tuple((n, parts) for _, n, parts, _ in folds)
     capturing = torch.cuda.is_current_stream_capturing()
     host = _HOST_CACHE.pop(key, None)
     ev = _HOST_EVENTS.pop(key, None)
@@ -265,18 +285,33 @@ def _flush_group(jobs, tile_class: int = 0) -> None:
     wg0 = blk0 = fi = 0
     ws_off = 0
     outs = []
-    for j, ((dy2, x2, w, b), (nw, nb, nf)) in enumerate(zip(jobs, plans)):
+    for j, (job, (nw, nb, nf)) in enumerate(zip(jobs, plans)):
+        dy2, x2, w, b = job[:4]
+        dp = job[4] if len(job) > 4 else None
         N, K = w.shape
         dw = torch.empty((N, K), dtype=torch.float32, device=dev)
         db = torch.empty(N, dtype=torch.float32, device=dev) if b is not None else None
-        call("nnz_dense32_group_fill", hp + j * rb_job, (hp + o_fold + fi * rb_fold) if nb else None, ptr(dy2), ptr(x2),
-             ptr(dw), ptr(db), (ws.data_ptr() + 4 * ws_off) if nf else None, x2.shape[0], K, N, wg0, blk0)
+        if dp is None:
+            call("nnz_dense32_group_fill", hp + j * rb_job, (hp + o_fold + fi * rb_fold) if nb else None, ptr(dy2), ptr(x2),
+                 ptr(dw), ptr(db), (ws.data_ptr() + 4 * ws_off) if nf else None, x2.shape[0], K, N, wg0, blk0)
+        else:
+            call("nnz_dense32_group_fill_scaled", hp + j * rb_job, (hp + o_fold + fi * rb_fold) if nb else None, ptr(dy2),
+                 ptr(x2), ptr(dw), ptr(db), (ws.data_ptr() + 4 * ws_off) if nf else None, x2.shape[0], K, N, wg0, blk0,
+                 ptr(dp[0]), float(dp[1]), int(dp[2]), int(dp[3]))
         wg_job[wg0:wg0 + nw] = j
         if nb:
             blk_job[blk0:blk0 + nb] = fi
             fi += 1
         wg0, blk0, ws_off = wg0 + nw, blk0 + nb, ws_off + nf
         outs.append((w, dw, b, db))
+    fold_outs = []
+    for (part, n, parts, assign), nb in zip(folds, fold_blks):
+        dst = torch.empty(n, dtype=torch.float32, device=dev)
+        call("nnz_dense32_group_fill_fold", hp + o_fold + fi * rb_fold, ptr(part), ptr(dst), n, parts, blk0)
+        blk_job[blk0:blk0 + nb] = fi
+        fi += 1
+        blk0 += nb
+        fold_outs.append((assign, dst))
     tab = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
     tab.copy_(host, non_blocking=True)
     if capturing:
@@ -299,6 +334,8 @@ def _flush_group(jobs, tile_class: int = 0) -> None:
                 p.grad = g
             else:
                 p.grad.add_(g)
+    for assign, dst in fold_outs:
+        assign(dst)
 
 
 def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None, bias=None):

@@ -1,6 +1,13 @@
-"""Dice within +-0.01 for the SS2D^2Net path (BASELINE.json north_star): M2NetP trained twice on the GPU from the same
-seeded weights on the same synthetic batches - fused SS2D block + HIP LayerNorm (product path) vs the reference's op-by-op
-formulation of the block (pinned to the reference by tests/golden) - compared by foreground Dice on held-out patches."""
+"""Dice within +-0.01 for the SS2D^2Net path (BASELINE.json north_star; SURVEY.md 8d protocol) against the CPU ORACLE: the HIP M2NetP
+repeats, in fp32 on the GPU, the 60-step protocol that oracle/m2net.py ran on the CPU (tests/golden/dice_oracle_m2netp_64.json from
+tools/dice_oracle_cpu_zoo.py; the oracle is pinned by the reference's own outputs, autograd and 6-step training trajectory,
+tests/test_oracle_m2net.py) - same seeded parameters, same batches, same optimiser - and is compared by foreground Dice and by the
+argmax masks on the same 16 held-out patches.  (Rounds 1-4 compared the fused HIP block with the repo's own op-by-op HIP
+formulation: a self-comparison)
+
+The yardstick for the gate is what two CPU fp32 runs of the SAME algorithm show: the oracle run twice with a different thread
+count (another, equally valid, fp32 summation order; tools/dice_oracle_cpu_zoo.py --threads 3 against the 6-thread fixture,
+profiles/r05_dice_oracle_cpu_vs_cpu_m2netp_64.json)."""
 import os
 import sys
 
@@ -8,15 +15,19 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+FIX = os.path.join(ROOT, "tests", "golden", "dice_oracle_m2netp_64.json")
 
 
-def test_m2netp_dice_within_one_percent(hip_lib):
-    from dice_parity_zoo import run
-    r = run("M2NetP", size=128, steps=80, heldout=16)
+def test_m2netp_dice_against_the_cpu_oracle(hip_lib):
+    from dice_parity_zoo import run_vs_oracle
+    r = run_vs_oracle(FIX)
     print(r)
-    assert r["dice_reference_formulation"] > 0.5, "the synthetic task must be learnt for the comparison to mean anything"
-    # target +-0.01; two runs of ONE formulation already differ by up to ~0.01 after 80 steps (atomics -> rounding ->
-    # AdamW trajectories; measured 0.936 .. 0.946 over repeated runs), so the gate leaves room for that spread
-    assert r["abs_delta"] <= 0.02
-    assert r["mask_agreement"] >= 0.95
+    assert r["dice_oracle"] > 0.9, "the synthetic task must be learnt for the comparison to mean anything"
+    assert r["loss_abs_delta_step0"] < 2e-5          # same weights, same batch: forward + loss to fp32 rounding
+    assert r["abs_delta"] <= GATE, r
+    assert r["mask_agreement"] >= MASKS, r
+
+
+GATE, MASKS = 0.01, 0.99

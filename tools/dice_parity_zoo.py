@@ -71,11 +71,84 @@ def run(model="M2NetP", size=128, steps=80, heldout=16, seed=0):
             "loss_reference_last": l_ref[-1], "loss_first": l_ref[0]}
 
 
+def run_vs_oracle(fixture, autocast=False):
+    """SURVEY.md 8d Dice protocol with the CPU ORACLE on the other side: `fixture` =
+    tests/golden/dice_oracle_m2netp_64.json, written in the build container by tools/dice_oracle_cpu_zoo.py - oracle/m2net.py
+    (pinned by the reference's own outputs, gradients and 6-step training trajectory, tests/test_oracle_m2net.py) trained in fp32
+    from the seeded construction, its foreground Dice on the held-out patches, every loss and its argmax masks.  Here the HIP
+    M2NetP repeats the protocol on the GPU: same seeded parameters, same batches, HIP loss, AdamW 1e-4 / wd 5e-2 / eps 1e-5,
+    clip 12, DropPath off, fp32 (autocast=True: the product's fp16-autocast + GradScaler step, whose first updates are skipped
+    while the loss scale backs off - reported, not gated)."""
+    import base64
+    from nnuzoo_amd.nets.m2net import M2NetP
+    from nnuzoo_amd.training.loss import DC_and_CE_loss, DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss
+    ref = json.load(open(fixture))
+    size, steps, heldout = ref["size"], ref["steps"], ref["heldout"]
+    torch.manual_seed(0)
+    net = M2NetP(1, 2, True)
+    for m in net.modules():
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+    net = net.cuda().train()
+    scales = [[1.0, 1.0], [1.0, 1.0], [0.5, 0.5], [0.25, 0.25], [0.125, 0.125], [0.0625, 0.0625], [0.03125, 0.03125]]
+    w = np.array([1 / (2 ** i) for i in range(len(scales))])
+    w[-1] = 0
+    w = w / w.sum()
+    loss_fn = DeepSupervisionWrapper(DC_and_CE_loss({'batch_dice': True, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {},
+                                                    weight_ce=1, weight_dice=1, ignore_label=None,
+                                                    dice_class=MemoryEfficientSoftDiceLoss), w)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=5e-2, eps=1e-5, betas=(0.9, 0.999))
+    scaler = torch.amp.GradScaler("cuda") if autocast else None
+    losses = []
+    for it in range(steps):
+        b = synthetic_batch(2, (size, size), scales, seed=1000 + it)
+        data, target = b["data"].cuda(), [t.cuda() for t in b["target"]]
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", enabled=autocast):
+            l = loss_fn(list(net(data)), target)
+        if autocast:
+            scaler.scale(l).backward()
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+            scaler.step(opt)
+            scaler.update()
+        else:
+            l.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+            opt.step()
+        losses.append(float(l.detach()))
+    net.eval()
+    dice, masks = [], []
+    with torch.no_grad(), torch.autocast("cuda", enabled=autocast):
+        for i in range(heldout // 2):
+            b = synthetic_batch(2, (size, size), scales, seed=90000 + i)
+            gt = b["target"][0][:, 0]
+            pm = net(b["data"].cuda())[0].float().cpu().argmax(1)
+            masks.append(pm.to(torch.uint8))
+            dice += [dice_of(pm[k], gt[k]) for k in range(2)]
+    mine = np.packbits(torch.cat(masks).numpy().reshape(-1))
+    theirs = np.frombuffer(base64.b64decode(ref["masks_packed_b64"]), dtype=np.uint8)
+    agree = 1.0 - np.unpackbits(mine ^ theirs).sum() / (8.0 * len(mine))
+    d = float(np.mean(dice))
+    n = min(len(losses), len(ref["losses"]))
+    return {"model": "M2NetP", "size": size, "steps": steps, "heldout": heldout, "precision": "fp16 autocast" if autocast else "fp32",
+            "dice_hip": d, "dice_oracle": ref["dice"], "abs_delta": abs(d - ref["dice"]), "mask_agreement": float(agree),
+            "loss_abs_delta_step0": abs(losses[0] - ref["losses"][0]),
+            "loss_abs_delta_max": float(np.max(np.abs(np.array(losses[:n]) - np.array(ref["losses"][:n])))),
+            "loss_hip_last": losses[-1], "loss_oracle_last": ref["losses"][-1], "oracle": os.path.basename(fixture)}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="M2NetP")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--steps", type=int, default=80)
     ap.add_argument("--heldout", type=int, default=16)
+    ap.add_argument("--oracle-json", default="", help="tests/golden/dice_oracle_m2netp_64.json: the protocol against the CPU oracle")
+    ap.add_argument("--autocast", type=int, default=0)
+    ap.add_argument("--out", default="")
     a = ap.parse_args()
-    print(json.dumps(run(a.model, a.size, a.steps, a.heldout)))
+    r = run_vs_oracle(a.oracle_json, bool(a.autocast)) if a.oracle_json else run(a.model, a.size, a.steps, a.heldout)
+    print(json.dumps(r))
+    if a.out:
+        json.dump(r, open(a.out, "w"), indent=1)
