@@ -342,7 +342,10 @@ int nnz_sliding_window_finalize(void* logits_f16, const void* npred_f16, int K, 
  * floats.  chunk_state holds the forward's checkpoints (state entering every chunk and, for the channels-on-lanes
  * kernels of csrc/ss2d_scan_rl.hpp, every 16-step sub-block) and must reach the backward unchanged.
  * nnz_scan_tuning(knob, value): 0 = channels-on-lanes kernels on/off (default on; they need L % 16 == 0 and Dg = 32 or a
- * multiple of 64, other shapes take the time-on-lanes kernels), 1 = forced chunk length in 16-step sub-blocks (4/8/16).
+ * multiple of 64, other shapes take the time-on-lanes kernels), 1 = forced chunk length in 16-step sub-blocks (4/8/16),
+ * 4 = (round 5, default 1) where several workgroups share a (batch, direction) group's dB / dC / d dt rows - channel chunks of a
+ * wide group - each writes a slab of its own behind P / S in `workspace` and a fold launch sums the slabs in a fixed order:
+ * the backward is bit-identical from run to run (0: the fp32 atomics of rounds 1-4).
  * nnz_ss2d_merge: out (B, H, W, Dg) = y0 + y2 + (y1 + y3)^T;  nnz_ss2d_merge_dx: dx (B, Dg, H, W) = du0 + du2 + dx2[0]
  * + (du1 + du3 + dx2[1])^T in x's type (du may be NULL). */
 int nnz_ss2d_prepare(const void* x, int x_is_f16, float* x2, int Bt, int D, int H, int W, void* stream);
@@ -595,6 +598,29 @@ int nnz_dense32_group_fill_scaled(void* job_host, void* fold_host, const float* 
                                   float* workspace, long T, int K, int N, int wg_begin, int blk_begin, const float* dp_rand,
                                   float dp_keep, int dp_rps, int dp_nb);
 int nnz_dense32_group_fill_fold(void* fold_host, const float* part, float* dst, long n, int parts, int blk_begin);
+/* fold records alone (for grouped launches of other kernel families) */
+int nnz_group_fold_launch(const void* fold_dev, const int* blk_job_dev, int total_blks, void* stream);
+/* ---- grouped weight gradients of the fp16 token Linears (csrc/token_linear.hip, round 5): every nnz_token_linear_wgrad problem of
+ * a backward pass (in_proj / out_proj / patch merge / expand of the VSS blocks, m2net.py:97,103,258,300: ~160 per M2Net step) in
+ * ONE launch over a job table + ONE fold launch.  Protocol as nnz_dense32_group_*: _plan gives workgroups, dynamic LDS bytes and
+ * workspace floats (workgroups x (N K + N): each workgroup writes its partial dW | db block); _fill writes a HOST record of
+ * _record_bytes() bytes; the launch takes the LARGEST LDS size of its jobs; the partial blocks are summed in workgroup order by
+ * fold records (nnz_dense32_group_fill_fold, n = N K + N, parts = workgroups) and nnz_group_fold_launch: no zero fills, no float
+ * atomics - bit-identical from run to run. */
+int nnz_token_linear_wgrad_group_record_bytes(void);
+int nnz_token_linear_wgrad_group_plan(long T, int N, int K, int* wgs, int* lds_bytes, long* ws_floats);
+int nnz_token_linear_wgrad_group_fill(void* job_host, const void* dy_f16, const void* x_f16, float* workspace, long T, int N, int K,
+                                      int wg_begin);
+int nnz_token_linear_wgrad_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs, int max_lds_bytes,
+                                        void* stream);
+/* the same for the SS2D x_proj weight gradients (csrc/ss2d_xproj.hip, ~66 per M2Net step): workgroups = 2 sources x token ranges,
+ * workspace = one partial [2][C2][Di] matrix per token range; fold records with n = 2 C2 Di, parts = workgroups / 2 */
+int nnz_ss2d_xproj_backward_w_group_record_bytes(void);
+int nnz_ss2d_xproj_backward_w_group_plan(int B, int Di, int C2, long L, int* wgs, int* lds_bytes, long* ws_floats);
+int nnz_ss2d_xproj_backward_w_group_fill(void* job_host, const float* dP, const float* x2, float* workspace, int B, int Di, int C2,
+                                         long L, int cp, int wg_begin);
+int nnz_ss2d_xproj_backward_w_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs, int max_lds_bytes,
+                                           void* stream);
 /* window attention with qkv / dqkv on the block's top / left padded grid H x W and out / dout on the unpadded grid
  * (H - py) x (W - px): rows of padded tokens are never written (forward) and read as zeros (backward) */
 int nnz_window_attention_forward_pad(const float* qkv, const float* bias_table, const int* bias_index, float* out, int B,
@@ -602,6 +628,12 @@ int nnz_window_attention_forward_pad(const float* qkv, const float* bias_table, 
 int nnz_window_attention_backward_pad(const float* qkv, const float* bias_table, const int* bias_index, const float* dout,
                                       float* dqkv, float* dbias_table, void* acc, void* counter, int B, int H, int W, int C,
                                       int heads, int shift, float scale, int py, int px, void* stream);
+/* the backward with the bias-table gradient left as per-workgroup shares dpart[nnz_window_attention_backward_parts(B, H, W,
+ * heads)][169][heads] for a fold record (n = 169 * heads): no fixed-point adds, no last-workgroup pass in the launch */
+long nnz_window_attention_backward_parts(int B, int H, int W, int heads);
+int nnz_window_attention_backward_partial(const float* qkv, const float* bias_table, const int* bias_index, const float* dout,
+                                          float* dqkv, float* dpart, int B, int H, int W, int C, int heads, int shift,
+                                          float scale, int py, int px, void* stream);
 /* LayerNorm backward (fp32) with dx = dres + ..., dgamma | dbeta as per-workgroup partials part[nnz_layer_norm_backward_parts(rows,
  * C)][2 C] for a fold record, and - pad_h > 0 - rows on the top / left padded grid (dy, mean, rstd) with x / dres / dx on the
  * unpadded [B][pad_h][pad_w] grid (padded tokens: x = 0, they still count in dgamma / dbeta, their dx is dropped) */

@@ -133,6 +133,15 @@ SIGNATURES = {
     "nnz_dense32_group_fill": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _i],
     "nnz_dense32_group_class": [_l, _i, _i],
     "nnz_dense32_group_launch": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp],
+    "nnz_group_fold_launch": [_vp, _vp, _i, _vp],
+    "nnz_token_linear_wgrad_group_record_bytes": [],
+    "nnz_token_linear_wgrad_group_plan": [_l, _i, _i, _vp, _vp, _vp],
+    "nnz_token_linear_wgrad_group_fill": [_vp, _vp, _vp, _vp, _l, _i, _i, _i],
+    "nnz_token_linear_wgrad_group_launch": [_vp, _vp, _i, _i, _vp],
+    "nnz_ss2d_xproj_backward_w_group_record_bytes": [],
+    "nnz_ss2d_xproj_backward_w_group_plan": [_i, _i, _i, _l, _vp, _vp, _vp],
+    "nnz_ss2d_xproj_backward_w_group_fill": [_vp, _fp, _fp, _vp, _i, _i, _i, _l, _i, _i],
+    "nnz_ss2d_xproj_backward_w_group_launch": [_vp, _vp, _i, _i, _vp],
     "nnz_dense32_splitk_workspace_floats": [_l, _i, _i],
     "nnz_dense32_forward_fused": [_fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _fp, _fp, _f, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp,
                                   _f, _i, _i, _fp, _vp],
@@ -141,6 +150,8 @@ SIGNATURES = {
     "nnz_dense32_group_fill_fold": [_vp, _fp, _fp, _l, _i, _i],
     "nnz_window_attention_forward_pad": [_fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "nnz_window_attention_backward_pad": [_fp, _fp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "nnz_window_attention_backward_parts": [_i, _i, _i, _i],
+    "nnz_window_attention_backward_partial": [_fp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "nnz_layer_norm_backward_parts": [_l, _i],
     "nnz_layer_norm_backward_partial": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _i, _i, _vp],
     "nnz_token_linear_wgrad": [_vp, _vp, _fp, _fp, _l, _i, _i, _vp],
@@ -211,6 +222,7 @@ _LONG_RESULT = {"nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats",
                 "nnz_selective_scan_grad_state_floats", "nnz_dwconv2d_wgrad_workspace_floats", "nnz_conv_tap_wgrad_workspace_floats",
                 "nnz_dense32_wgrad_workspace_floats", "nnz_token_linear_wgrad_workspace_floats",
                 "nnz_dense32_splitk_workspace_floats", "nnz_layer_norm_backward_parts",
+                "nnz_window_attention_backward_parts",
                 "nnz_ss2d_xproj_backward_w_workspace_floats", "nnz_ss2d_dwconv_silu_backward_workspace_floats"}
 _lib = None
 

@@ -827,3 +827,13 @@ extern "C" int nnz_dense32_group_launch(const void* jobs_dev, const int* wg_job_
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
+
+// fold records alone (nnz_dense32_group_fill_fold), for grouped launches of other kernel families (csrc/token_linear.hip)
+extern "C" int nnz_group_fold_launch(const void* fold_dev, const int* blk_job_dev, int total_blks, void* stream) {
+  using namespace nnz;
+  if (!fold_dev || !blk_job_dev || total_blks < 1) return NNZ_EINVAL;
+  NNZ_LAUNCH(dense32_group_fold_kernel, dim3((unsigned)total_blks), dim3(256), 0, (hipStream_t)stream,
+             (const D32FoldJob*)fold_dev, blk_job_dev);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

@@ -60,6 +60,12 @@ struct ScanArgs {
   int a_is_log;         // A holds A_log: the kernels use -exp(A_log) and return dA_log = dA * A (m2net.py:196)
   float* xs_dP;
   int R, Cp;
+  // round 5: where several workgroups share one (batch, direction) group - channel chunks of a wide group - each writes its dB /
+  // dC / d dt rows to a slab of its own (slab + part * slab_stride, laid out like xs_dP, or dB then dC in plain mode) and a fold
+  // launch sums the slabs in part order: bit-identical from run to run, no zero fill, no float atomics (which run at 1.3 TB/s
+  // on this chip - the slabs cost no more).  null: the atomics of rounds 1-4 (nnz_scan_tuning knob 4 = 0).
+  float* slab;
+  long slab_stride;
 };
 
 constexpr int SS_RMAX = 8;          // largest dt_rank of the cross-scan mode
@@ -618,9 +624,13 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
   }
   if (FINAL) {
     __syncthreads();
-    float* gB = XS ? a.xs_dP + pk_off + (long)a.R * a.L : a.dB + (long)grp * SS_N * a.L;
-    float* gC = XS ? a.xs_dP + pk_off + (long)(a.R + SS_N) * a.L : a.dC + (long)grp * SS_N * a.L;
-    const bool sole = wgs_per_group == 1;  // this workgroup is the only writer of the tile: plain stores
+    // (slab mode: this workgroup's own copy of the tile - plain stores, folded afterwards)
+    float* dPbase = a.slab ? a.slab + (long)sub * a.slab_stride : a.xs_dP;
+    float* dBbase = a.slab ? a.slab + (long)sub * a.slab_stride : a.dB;
+    float* dCbase = a.slab ? dBbase + (long)a.Bt * a.K * SS_N * a.L : a.dC;
+    float* gB = XS ? dPbase + pk_off + (long)a.R * a.L : dBbase + (long)grp * SS_N * a.L;
+    float* gC = XS ? dPbase + pk_off + (long)(a.R + SS_N) * a.L : dCbase + (long)grp * SS_N * a.L;
+    const bool sole = wgs_per_group == 1 || a.slab != nullptr;  // the only writer of the tile: plain stores
     for (int i = threadIdx.x; i < SS_N * SS_CL; i += SS_NW * 64) {
       const int n = i / SS_CL, tt = i % SS_CL;
       const int li = i;
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(SS_NW * 64) void scan_bwd_kernel(ScanArgs a) {
         }
         __syncthreads();
       }
-      float* gT = a.xs_dP + pk_off;
+      float* gT = dPbase + pk_off;
       for (int i = threadIdx.x; i < a.R * SS_CL; i += SS_NW * 64) {
         const int rr = i / SS_CL, tt = i % SS_CL;
         if (t0 + tt < a.L) {
@@ -718,7 +728,8 @@ namespace nnz {
 //   1  forced sub-blocks per chunk (4 / 8 / .. / 64 = chunks of 64 .. 1024 steps), 0 = by size   (default 0)
 //   2  smallest problem (batch x 4 Dg x L row-steps) that takes the channels-on-lanes kernels   (default 2 M)
 //   3  (read-only use) number of channels-on-lanes launches so far: lets a test assert which generation ran
-static int g_scan_tuning[4] = {1, 0, 2 << 20, 0};
+//   4  deterministic slabs + fold for the shared dB / dC / d dt tiles (ScanArgs::slab) instead of fp32 atomics   (default 1)
+static int g_scan_tuning[5] = {1, 0, 2 << 20, 0, 1};
 
 constexpr int RL_MIN_CLB = 4;   // shortest chunk: 64 steps (sizes of the state / workspace buffers assume it)
 
@@ -756,6 +767,27 @@ static void rl_setup(ScanArgs& a, int& clb, dim3& grid, float* chunk_state, floa
   grid = dim3((a.nchunks + slots - 1) / slots, a.Bt * a.K * (a.Dg / Dl));
 }
 
+// floats of P + S at the front of the workspace (both generations); the slabs of the deterministic mode follow
+static long ws_ps_floats(int Bt, int KD, int L) { return 2L * Bt * KD * SS_N * rl_nch_max(L); }
+// one slab = one copy of what the backward accumulates across workgroups: dP (cross-scan) or dB | dC (plain)
+static long slab_floats(const ScanArgs& a, bool xs) {
+  return xs ? 4L * a.Bt * a.Cp * a.L : 2L * a.Bt * a.K * SS_N * a.L;
+}
+// point the kernel at `parts` slabs behind P / S; returns false (atomics) when the knob is off
+static bool slab_setup(ScanArgs& a, bool xs, int parts, float* workspace) {
+  if (!g_scan_tuning[4] || parts < 2) return false;
+  a.slab = workspace + ws_ps_floats(a.Bt, a.KD, a.L);
+  a.slab_stride = slab_floats(a, xs);
+  return true;
+}
+static hipError_t slab_fold(const ScanArgs& a, bool xs, int parts, hipStream_t s) {
+  if (xs) return fold_partials(a.slab, parts, a.slab_stride, a.slab_stride, a.xs_dP, s);
+  const long nB = (long)a.Bt * a.K * SS_N * a.L;
+  hipError_t e = fold_partials(a.slab, parts, a.slab_stride, nB, a.dB, s);
+  if (e != hipSuccess) return e;
+  return fold_partials(a.slab + nB, parts, a.slab_stride, nB, a.dC, s);
+}
+
 template <bool XS>
 static int rl_forward(ScanArgs& a, float* chunk_state, float* workspace, hipStream_t s) {
   ++g_scan_tuning[3];
@@ -790,7 +822,9 @@ static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state,
   rl_setup(a, clb, grid, const_cast<float*>(chunk_state), workspace, Hck);
   a.Gin = grad_state;
   const long rows = (long)a.Bt * a.KD;
-  const int atomic_dp = a.Dg > 64;      // several waves (channel groups of 64) add into one dP tile
+  const bool shared_dp = a.Dg > 64;     // several waves (channel groups of 64) write one dP tile
+  const bool slabs = shared_dp && slab_setup(a, XS, a.Dg / 64, workspace);
+  const int atomic_dp = shared_dp && !slabs;
   hipError_t e;
   if (atomic_dp) {
     if (XS) {
@@ -812,6 +846,7 @@ static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state,
   }
   NNZ_LAUNCH(xs_rl_bwd_kernel<XS>, grid, dim3(64), 0, s, a, clb, Hck, atomic_dp);
   NNZ_LAUNCH_CHECK();
+  if (slabs && (e = slab_fold(a, XS, a.Dg / 64, s)) != hipSuccess) return (int)e;
   NNZ_LAUNCH(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA, a.dbias,
              a.dD, a.Bt, a.KD, a.nchunks, dWdt, a.R, a.a_is_log ? a.A : (const float*)nullptr);
   NNZ_LAUNCH_CHECK();
@@ -821,11 +856,11 @@ static int rl_backward(ScanArgs& a, const float* chunk_state, float* grad_state,
 }  // namespace nnz
 
 extern "C" int nnz_scan_tuning(int knob, int value) {
-  if (knob < 0 || knob >= 4) return NNZ_EINVAL;
+  if (knob < 0 || knob >= 5) return NNZ_EINVAL;
   nnz::g_scan_tuning[knob] = value;
   return NNZ_OK;
 }
-extern "C" int nnz_scan_tuning_get(int knob) { return (knob < 0 || knob >= 4) ? -1 : nnz::g_scan_tuning[knob]; }
+extern "C" int nnz_scan_tuning_get(int knob) { return (knob < 0 || knob >= 5) ? -1 : nnz::g_scan_tuning[knob]; }
 
 // buffer sizes of the cross-scan entry points (cover both kernel generations)
 extern "C" long nnz_ss2d_scan_state_floats(int Bt, int Dg, int L) {
@@ -835,14 +870,27 @@ extern "C" long nnz_ss2d_scan_state_floats(int Bt, int Dg, int L) {
 extern "C" long nnz_ss2d_scan_grad_state_floats(int Bt, int Dg, int L) {
   return (long)Bt * 4 * Dg * nnz::SS_N * nnz::rl_nch_max(L);
 }
+// most slabs either generation can ask for on this shape (ScanArgs::slab): channel groups of 64 (channels-on-lanes) or the
+// time-on-lanes split of a group over workgroups
+static long scan_slab_parts(int Bt, int K, int Dg, int L) {
+  const long p2 = Dg > 64 ? Dg / 64 : 1;
+  const long p1 = Dg / nnz::pick_rows_per_wg(Dg, (long)Bt * K * ((L + nnz::SS_CL - 1) / nnz::SS_CL));
+  const long p = p1 > p2 ? p1 : p2;
+  return p >= 2 ? p : 0;
+}
 extern "C" long nnz_ss2d_scan_workspace_floats(int Bt, int Dg, int L) {
-  return 2L * Bt * 4 * Dg * nnz::SS_N * nnz::rl_nch_max(L);
+  if (Bt < 1 || Dg < nnz::SS_NW || L < 1) return 0;
+  return 2L * Bt * 4 * Dg * nnz::SS_N * nnz::rl_nch_max(L) +
+         scan_slab_parts(Bt, 4, Dg, L) * 4L * Bt * (nnz::SS_RMAX + 2 * nnz::SS_N) * L;
 }
 
 // buffer sizes of the plain entry points (cover both kernel generations: chunks as short as 64 steps, and the forward's
 // 16-step checkpoints behind the chunk-entry states)
 extern "C" long nnz_selective_scan_workspace_floats(int Bt, int KD, int L) {
-  return 2L * Bt * KD * nnz::SS_N * nnz::rl_nch_max(L);  // P and S
+  // P and S; behind them the slabs of the deterministic dB / dC fold.  K is not an argument here: with K >= 1 groups of KD / K
+  // channels the slab count is at most KD / SS_NW and one slab holds 2 Bt K N L floats, K (Dg / rows_per_wg) <= KD / SS_NW.
+  if (Bt < 1 || KD < 1 || L < 1) return 0;
+  return 2L * Bt * KD * nnz::SS_N * nnz::rl_nch_max(L) + 2L * Bt * (KD / nnz::SS_NW + 1) * nnz::SS_N * L;
 }
 extern "C" long nnz_selective_scan_state_floats(int Bt, int KD, int L) {
   const long rows = (long)Bt * KD;
@@ -892,7 +940,9 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
   a.Gin = grad_state;
   a.rows_per_wg = pick_rows_per_wg(a.Dg, (long)a.Bt * a.K * a.nchunks);
   hipError_t e;
-  if (a.rows_per_wg != a.Dg) {  // several workgroups add into one dB/dC (dP) tile
+  const int parts1 = a.Dg / a.rows_per_wg;
+  const bool slabs = slab_setup(a, XS, parts1, workspace);
+  if (a.rows_per_wg != a.Dg && !slabs) {  // several workgroups add into one dB/dC (dP) tile
     if (XS) {
       if ((e = nnz::zero_async(a.xs_dP, sizeof(float) * 2L * a.Bt * 2 * a.Cp * a.L, s)) != hipSuccess) return (int)e;
     } else {
@@ -918,6 +968,7 @@ static int scan_backward_impl(ScanArgs& a, const float* chunk_state, float* grad
   if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH((scan_bwd_kernel<true, XS>), grid, dim3(SS_NW * 64), lds_final, s, a);
   NNZ_LAUNCH_CHECK();
+  if (slabs && (e = slab_fold(a, XS, parts1, s)) != hipSuccess) return (int)e;
   NNZ_LAUNCH(scan_bwd_finalize_kernel, dim3((unsigned)((a.KD * SS_N + 3) / 4)), dim3(256), 0, s, a.P, a.S, a.dA,
                      a.dbias, a.dD, a.Bt, a.KD, a.nchunks, dWdt, XS ? a.R : 0,
                      (XS && a.a_is_log) ? a.A : (const float*)nullptr);

@@ -682,7 +682,11 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
     if constexpr (!XS) rl_rows_store<RL_T>(a, w, sDl, a.ddelta, toff);
     // the sub-block's dB / dC / d dt tiles (rows of dP; plain mode: rows of dB and dC)
     if (g.live) {
-      float* gP = XS ? a.xs_dP + w.pk_off : nullptr;
+      // slab mode (several channel groups per (batch, direction)): channel group rg writes its own copy with plain stores
+      float* dPbase = a.slab ? a.slab + (long)w.rg * a.slab_stride : a.xs_dP;
+      float* dBbase = a.slab ? a.slab + (long)w.rg * a.slab_stride : a.dB;
+      float* dCbase = a.slab ? dBbase + (long)a.Bt * a.K * SS_N * a.L : a.dC;
+      float* gP = XS ? dPbase + w.pk_off : nullptr;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int i = g.lis + p * w.Dl;          // 128 pieces of 4 steps: 32 rows (16 dB, 16 dC) x 4
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
           const int rowi = i >> 2, t4 = (i & 3) * 4;
           const f32x4 v = *reinterpret_cast<const f32x4*>(myOut + rowi * RL_T + t4);
           float* orow = XS ? gP + (long)(a.R + rowi) * a.L
-                           : (rowi < SS_N ? a.dB : a.dC) + w.pk_off + (long)(rowi & (SS_N - 1)) * a.L;
+                           : (rowi < SS_N ? dBbase : dCbase) + w.pk_off + (long)(rowi & (SS_N - 1)) * a.L;
           rl_add4(orow, tb + t4, a.L, w.rev, v, atomic_dp != 0);
         }
       }

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void xproj_bwd_x_kernel(XpArgs a) {
 // 8 x 8 block of dW); rows are staged as [row][64 tokens] tiles and read 4 tokens (16 bytes) at a time.
 constexpr int XPW_TOK = 64;
 
-__global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) {
+__device__ __forceinline__ void xproj_bwd_w_body(const XpArgs& a, const unsigned bx, const int s) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   const int C2p = (a.C2 + 7) & ~7;
   const int nbk = (C2p >> 3) * (a.Di >> 3);
@@ -141,7 +141,6 @@ __global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) {
   float* sX = sP + C2p * XPW_TOK;             // [Di][64]
   float* sred = sX + a.Di * XPW_TOK;          // [TSL][C2p * Di]
   const int tid = threadIdx.x;
-  const int s = blockIdx.y;
   const int blk = tid % nbk, ts = tid / nbk;
   const bool active = ts < TSL;
   const int c0 = (blk / (a.Di >> 3)) * 8, d0 = (blk % (a.Di >> 3)) * 8;
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
   const long T = (long)a.B * a.L;             // tokens of this source, (b, l) flattened: rows are [b][row][l]
-  const long t_begin = (long)blockIdx.x * a.tokens_per_wg;
+  const long t_begin = (long)bx * a.tokens_per_wg;
   long t_end = t_begin + a.tokens_per_wg;
   if (t_end > T) t_end = T;
   for (long tb = t_begin; tb < t_end; tb += XPW_TOK) {
@@ -201,9 +200,27 @@ __global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) {
     float v = 0.f;
     for (int q = 0; q < TSL; ++q) v += sred[(long)q * C2p * a.Di + e];
     const long o = xp_row(a, s, e / a.Di) + e % a.Di;
-    if (a.part) a.part[(size_t)blockIdx.x * 2 * a.C2 * a.Di + o] = v;   // plain store; nnz::fold_partials sums the rows in order
+    if (a.part) a.part[(size_t)bx * 2 * a.C2 * a.Di + o] = v;   // plain store; nnz::fold_partials sums the rows in order
     else atomicAdd(a.dW + o, v);
   }
+}
+
+__global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) { xproj_bwd_w_body(a, blockIdx.x, blockIdx.y); }
+
+// grouped form (round 5): the x_proj weight gradients of every SS2D block of a backward pass in ONE launch over a job table
+// (66 launches of 11-400 us per M2Net step, most of them a few hundred short workgroups), partial matrices per workgroup, one
+// fold launch (nnz_group_fold_launch) - see csrc/token_linear.hip tl_wgrad_group_kernel for the protocol
+struct XpJob {
+  XpArgs a;
+  int wg_begin;
+  int pad;
+};
+__global__ __launch_bounds__(256) void xproj_bwd_w_group_kernel(const XpJob* __restrict__ jobs, const int* __restrict__ wg_job) {
+  const int j = __builtin_amdgcn_readfirstlane(wg_job[blockIdx.x]);
+  const XpJob* jp = jobs + j;
+  const XpArgs a = jp->a;
+  const unsigned local = blockIdx.x - (unsigned)jp->wg_begin;
+  xproj_bwd_w_body(a, local >> 1, (int)(local & 1));
 }
 
 static bool xp_shape_ok(int B, int Di, int C2, long L) {
@@ -303,4 +320,50 @@ extern "C" int nnz_ss2d_xproj_backward_w_ws(const float* dP, const float* x2, fl
                                             int B, int Di, int C2, long L, int cp, void* stream) {
   if (!workspace) return NNZ_EINVAL;
   return xp_bwd_w_impl(dP, x2, dW, workspace, ws_floats, B, Di, C2, L, cp, stream);
+}
+
+// ---- grouped x_proj weight gradients: _plan gives workgroups (both sources), dynamic LDS bytes and workspace floats (one partial
+// [2][C2][Di] matrix per token range); _fill writes a HOST record; fold: rows of 2 C2 Di floats, parts = workgroups / 2.
+extern "C" int nnz_ss2d_xproj_backward_w_group_record_bytes(void) { return (int)sizeof(nnz::XpJob); }
+extern "C" int nnz_ss2d_xproj_backward_w_group_plan(int B, int Di, int C2, long L, int* wgs, int* lds_bytes, long* ws_floats) {
+  using namespace nnz;
+  if (!xp_shape_ok(B, Di, C2, L) || (L % XPW_TOK) || !wgs || !lds_bytes || !ws_floats) return NNZ_EINVAL;
+  const int C2p = (C2 + 7) & ~7;
+  const int nbk = (C2p >> 3) * (Di >> 3);
+  if (nbk > 256) return NNZ_EINVAL;
+  const int TSL = 256 / nbk;
+  const long T = (long)B * L, tpw = xp_bwd_w_tokens_per_wg(T);
+  const long ranges = (T + tpw - 1) / tpw;
+  const size_t lds = sizeof(float) * ((size_t)(C2p + Di) * XPW_TOK + (size_t)TSL * C2p * Di);
+  if (lds > 160 * 1024) return NNZ_EINVAL;
+  *wgs = (int)(2 * ranges);
+  *lds_bytes = (int)lds;
+  *ws_floats = ranges * 2L * C2 * Di;
+  return NNZ_OK;
+}
+extern "C" int nnz_ss2d_xproj_backward_w_group_fill(void* job_host, const float* dP, const float* x2, float* workspace, int B,
+                                                    int Di, int C2, long L, int cp, int wg_begin) {
+  using namespace nnz;
+  if (!job_host || !dP || !x2 || !workspace || !xp_shape_ok(B, Di, C2, L) || (L % XPW_TOK) || cp < 0 || (cp > 0 && 2 * cp != C2) ||
+      wg_begin < 0)
+    return NNZ_EINVAL;
+  XpJob j = {};
+  j.a.dP = dP; j.a.x2 = x2; j.a.B = B; j.a.Di = Di; j.a.C2 = C2; j.a.L = L; j.a.Cp = cp;
+  j.a.tokens_per_wg = xp_bwd_w_tokens_per_wg((long)B * L);
+  j.a.part = workspace;
+  j.wg_begin = wg_begin;
+  *reinterpret_cast<XpJob*>(job_host) = j;
+  return NNZ_OK;
+}
+extern "C" int nnz_ss2d_xproj_backward_w_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs,
+                                                      int max_lds_bytes, void* stream) {
+  using namespace nnz;
+  if (!jobs_dev || !wg_job_dev || total_wgs < 1 || max_lds_bytes < 1 || max_lds_bytes > 160 * 1024) return NNZ_EINVAL;
+  static DynLdsCache cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(xproj_bwd_w_group_kernel), max_lds_bytes, cache);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH(xproj_bwd_w_group_kernel, dim3((unsigned)total_wgs), dim3(256), max_lds_bytes, (hipStream_t)stream,
+             (const XpJob*)jobs_dev, wg_job_dev);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
 }

@@ -176,7 +176,7 @@ struct TlWgArgs {
 // are folded through LDS at the end.  Rows of dy / x are broadcast LDS reads (16 bytes = 8 fp16 per operand and token).
 constexpr int TLW_TOK = 64;  // tokens staged per round
 
-__global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) {
+__device__ __forceinline__ void tl_wgrad_body(const TlWgArgs& a, const unsigned bx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a.N, K = a.K;
   const int nbk = (N >> 3) * (K >> 3);         // 8x8 blocks of dW
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
   }
-  const long t_begin = (long)blockIdx.x * a.tokens_per_wg;
+  const long t_begin = (long)bx * a.tokens_per_wg;
   long t_end = t_begin + a.tokens_per_wg;
   if (t_end > a.T) t_end = a.T;
   const int pn = N >> 3, pk = K >> 3;  // 16-byte pieces per row
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) {
   __syncthreads();
   // a.part (nnz_token_linear_wgrad_ws): the workgroup's sums go to its own row of the workspace with plain stores and a second
   // kernel folds the rows in a fixed order - bit-reproducible; otherwise one fp32 atomic per entry into the pre-zeroed dW / db
-  float* prow = a.part ? a.part + (size_t)blockIdx.x * ((size_t)N * K + N) : nullptr;
+  float* prow = a.part ? a.part + (size_t)bx * ((size_t)N * K + N) : nullptr;
   for (int e = tid; e < N * K; e += 256) {
     float v = 0.f;
     for (int s_ = 0; s_ < TSL; ++s_) v += sred[(long)s_ * N * K + e];
@@ -255,6 +255,27 @@ __global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) {
       if (prow) prow[(size_t)N * K + e] = v;
       else atomicAdd(a.db + e, v);
     }
+}
+
+__global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) { tl_wgrad_body(a, blockIdx.x); }
+
+// ---- grouped weight gradients (round 5): ALL weight gradients of the fp16 token Linears of one backward pass in one launch -----
+// A Mamba-net step holds ~160 of them (in_proj / out_proj / patch merge / expand of every VSS block; 4 ms of an 83 ms M2Net step
+// as 160 launches of ~21 us each, almost all of it launch latency at a few hundred workgroups of a few microseconds).  They are
+// not on the data-gradient chain: the autograd nodes queue (dy, x, dW, db) and the end of the pass runs every problem in ONE launch
+// over a job table (workgroup -> job map in device memory), every workgroup writing its partial block to its job's slice of the
+// workspace, and ONE fold launch sums the blocks in workgroup order (nnz_group_fold_launch): no zero fills, no float atomics -
+// bit-identical from run to run.
+struct TlWgJob {
+  TlWgArgs a;
+  int wg_begin;
+  int pad;
+};
+__global__ __launch_bounds__(256) void tl_wgrad_group_kernel(const TlWgJob* __restrict__ jobs, const int* __restrict__ wg_job) {
+  const int j = __builtin_amdgcn_readfirstlane(wg_job[blockIdx.x]);
+  const TlWgJob* jp = jobs + j;
+  const TlWgArgs a = jp->a;
+  tl_wgrad_body(a, blockIdx.x - (unsigned)jp->wg_begin);
 }
 
 }  // namespace nnz
@@ -353,4 +374,51 @@ extern "C" int nnz_token_linear_wgrad_ws(const void* dy_f16, const void* x_f16, 
                                          long ws_floats, long T, int N, int K, void* stream) {
   if (!workspace) return NNZ_EINVAL;
   return tl_wgrad_impl(dy_f16, x_f16, dW, db, workspace, ws_floats, T, N, K, stream);
+}
+
+// ---- grouped form (see tl_wgrad_group_kernel).  Host protocol as for nnz_dense32_group_*: plan every queued problem (workgroups,
+// dynamic LDS bytes, workspace floats = workgroups * (N K + N)), lay the jobs out back to back, fill one record per job into a
+// HOST table of nnz_token_linear_wgrad_group_record_bytes() bytes each, build the int32 map workgroup -> job, copy both to the
+// device, launch with the LARGEST LDS size of the group; then fold each job's partial blocks (rows of N K + N floats: dW then db)
+// with fold records (nnz_dense32_group_fill_fold) and nnz_group_fold_launch.
+extern "C" int nnz_token_linear_wgrad_group_record_bytes(void) { return (int)sizeof(nnz::TlWgJob); }
+extern "C" int nnz_token_linear_wgrad_group_plan(long T, int N, int K, int* wgs, int* lds_bytes, long* ws_floats) {
+  using namespace nnz;
+  if (T < 1 || (N & 7) || (K & 7) || N < 8 || K < 8 || !wgs || !lds_bytes || !ws_floats) return NNZ_EINVAL;
+  const int nbk = (N >> 3) * (K >> 3);
+  if (nbk > 256) return NNZ_EINVAL;
+  const int TSL = 256 / nbk;
+  const long tpw = tl_wgrad_tokens_per_wg(T);
+  const long w = (T + tpw - 1) / tpw;
+  const size_t lds = (size_t)TLW_TOK * (N + K) * 2 + (size_t)TSL * (N * K + N) * 4;
+  if (lds > 160 * 1024 || w > (1L << 30)) return NNZ_EINVAL;
+  *wgs = (int)w;
+  *lds_bytes = (int)lds;
+  *ws_floats = w * ((long)N * K + N);
+  return NNZ_OK;
+}
+extern "C" int nnz_token_linear_wgrad_group_fill(void* job_host, const void* dy_f16, const void* x_f16, float* workspace, long T,
+                                                 int N, int K, int wg_begin) {
+  using namespace nnz;
+  if (!job_host || !dy_f16 || !x_f16 || !workspace || T < 1 || (N & 7) || (K & 7) || N < 8 || K < 8 || wg_begin < 0)
+    return NNZ_EINVAL;
+  TlWgJob j = {};
+  j.a.dy = (const f16*)dy_f16; j.a.x = (const f16*)x_f16; j.a.T = T; j.a.N = N; j.a.K = K;
+  j.a.tokens_per_wg = tl_wgrad_tokens_per_wg(T);
+  j.a.part = workspace;
+  j.wg_begin = wg_begin;
+  *reinterpret_cast<TlWgJob*>(job_host) = j;
+  return NNZ_OK;
+}
+extern "C" int nnz_token_linear_wgrad_group_launch(const void* jobs_dev, const int* wg_job_dev, int total_wgs, int max_lds_bytes,
+                                                   void* stream) {
+  using namespace nnz;
+  if (!jobs_dev || !wg_job_dev || total_wgs < 1 || max_lds_bytes < 1 || max_lds_bytes > 160 * 1024) return NNZ_EINVAL;
+  static DynLdsCache cache;
+  hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(tl_wgrad_group_kernel), max_lds_bytes, cache);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH(tl_wgrad_group_kernel, dim3((unsigned)total_wgs), dim3(256), max_lds_bytes, (hipStream_t)stream,
+             (const TlWgJob*)jobs_dev, wg_job_dev);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
 }

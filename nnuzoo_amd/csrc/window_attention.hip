@@ -34,7 +34,9 @@ namespace nnz {
 
 constexpr int WA_L = 49;   // tokens per window
 constexpr int WA_WS = 7;
-constexpr int WA_LD = 33;  // LDS row stride (floats) of a [token][channel] image: head_dim <= 32, +1 pad
+constexpr int WA_LD = 36;  // LDS row stride (floats) of a [token][channel] image: head_dim <= 32; 36 keeps rows 16-byte aligned
+                           // (one ds_write_b128 per staged piece, ds_read_b128 row operands: conflict-free in the 16-lane groups
+                           // of a b128 access, 36 l mod 64 being 16 different multiples of 4) - round 5, was 33 with 4-byte accesses
 constexpr int WA_NBIAS = (2 * WA_WS - 1) * (2 * WA_WS - 1);
 constexpr int WA_BP = 64;  // pitch of the transposed bias matrix sbT[key][query]
 
@@ -55,6 +57,10 @@ struct AttnArgs {
   // (H - py) x (W - px): the block's crop (:660) and its backward (zero rows for padded tokens) are folded into the addressing.
   // py = px = 0: out / dout on the same grid as qkv.
   int py, px;
+  // round 5: dpart != null - every workgroup WRITES its share of the bias-table gradient to dpart[blockIdx.x][169][heads] and
+  // is done (a fold record of the backward pass's grouped launch sums the shares in workgroup order); null: fixed-point adds +
+  // the head's last workgroup writes dbias
+  float* dpart;
 };
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
@@ -92,8 +98,7 @@ __device__ __forceinline__ void stage_image(const float* src, long row_len, int 
       const int l = i / q4, c4 = (i - l * q4) * 4;
       const int t = stok[l];
       const f32x4 v = t >= 0 ? *reinterpret_cast<const f32x4*>(src + (long)t * row_len + ch0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      float* d = dst + l * WA_LD + c4;
-      d[0] = v[0] * mul; d[1] = v[1] * mul; d[2] = v[2] * mul; d[3] = v[3] * mul;
+      *reinterpret_cast<f32x4*>(dst + l * WA_LD + c4) = v * mul;
     }
   } else {
     for (int i = lane; i < WA_L * hd; i += 64) {
@@ -106,13 +111,22 @@ __device__ __forceinline__ void stage_image(const float* src, long row_len, int 
 
 // "row" operand of one 32-token tile from an image: lane (token l31, half hh) gets channels hh*hd/2 + s, s = 0 .. hd/2 - 1
 // of its token's row (zeros for tokens >= 49): the contraction over channels visits them in this order for BOTH operands.
-// Pitch 33 makes the 32 tokens of a lane half hit 32 different banks.
+// Head dims that are multiples of 8 read whole 16-byte pieces (pitch 36); others word by word.
 __device__ __forceinline__ void load_rows(const float* img, int hd, int tile, int l31, int hh, float (&v)[16]) {
   const int l = tile * 32 + l31;
   const int half = hd >> 1;
   const float* p = img + (l < WA_L ? l : 0) * WA_LD + hh * half;
+  if ((hd & 7) == 0) {                       // half a multiple of 4: the lane's channels are whole 16-byte pieces
 #pragma unroll
-  for (int s = 0; s < 16; ++s) v[s] = (l < WA_L && s < half) ? p[s] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (l < WA_L && 4 * q < half) t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+      v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = (l < WA_L && s < half) ? p[s] : 0.f;
+  }
 }
 
 // the same row operand straight from global memory (forward: Q is used once per window, so it skips the image and the
@@ -252,7 +266,8 @@ __device__ __forceinline__ void scores_T(const float (&kv)[2][16], const float (
   inv_out = inv;
 }
 
-constexpr int WA_IMG = WA_L * WA_LD;  // floats of one [49][33] image
+constexpr int WA_IMG = WA_L * WA_LD;  // floats of one [49][WA_LD] image
+static_assert(WA_IMG % 4 == 0, "images must keep 16-byte alignment");
 
 __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -383,9 +398,10 @@ __global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
 // backward.  Pass A (transposed orientation, queries on lanes): P^T, dP^T, delta, dS^T -> dQ.
 //            Pass B (queries on rows, keys on lanes): P, dP, dS -> dV, dK, and dS -> the bias-table gradient.
 // Row statistics cross from A to B through LDS.  LDS per workgroup: the head's bias matrix and per wave four operand images,
-// one [49][33] dS tile for the bias-gradient sums, the row statistics and the token map (~150 KB: one workgroup per CU).
+// one [49][33] dS tile (its own pitch, WA_DSP) for the bias-gradient sums, the row statistics and the token map (~150 KB: one workgroup per CU).
 constexpr int WA_DSP = 33;                                    // pitch of the per-key-tile dS image [query][key - 32 tk]
-constexpr int WA_WAVE_FLOATS = 4 * WA_IMG + WA_L * WA_DSP + 3 * 64 + 3 * 64;  // sq sk sv sdo | sds | srow[3][64] | stok, sreg, sutok
+constexpr int WA_DS_FLOATS = (WA_L * WA_DSP + 3) / 4 * 4;      // the dS tile, rounded so that what follows stays 16-byte aligned
+constexpr int WA_WAVE_FLOATS = 4 * WA_IMG + WA_DS_FLOATS + 3 * 64 + 3 * 64;  // sq sk sv sdo | sds | srow[3][64] | stok, sreg, sutok
 
 __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
   float* sv = sk + WA_IMG;
   float* sdo = sv + WA_IMG;
   float* sds = sdo + WA_IMG;                           // dS[query][key - 32 tk] of the current key tile
-  float* srow = sds + WA_L * WA_DSP;                   // [3][64]: row max, 1 / sum, delta per query
+  float* srow = sds + WA_DS_FLOATS;                    // [3][64]: row max, 1 / sum, delta per query
   int* stok = reinterpret_cast<int*>(srow + 3 * 64);
   int* sreg = stok + 64;
   int* sutok = sreg + 64;      // token index on the unpadded grid of out / dout, -1 = a padded token
@@ -581,6 +597,12 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
   for (int e = 0; e < 3; ++e)
     if (lane + 64 * e < WA_NBIAS) sdb[lane + 64 * e] = db_acc[e];
   __syncthreads();
+  if (a.dpart) {      // deferred fold (fused Swin block): no atomics, no ticket
+    if (tid < WA_NBIAS)
+      a.dpart[((long)blockIdx.x * WA_NBIAS + tid) * a.heads + head] =
+          (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
+    return;
+  }
   if (tid < WA_NBIAS) {
     const float t = (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
     fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
@@ -812,6 +834,12 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   for (int e = 0; e < 3; ++e)
     if (lane + 64 * e < WA_NBIAS) sdb[lane + 64 * e] = db_acc[e];
   __syncthreads();
+  if (a.dpart) {      // deferred fold (fused Swin block): no atomics, no ticket
+    if (tid < WA_NBIAS)
+      a.dpart[((long)blockIdx.x * WA_NBIAS + tid) * a.heads + head] =
+          (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
+    return;
+  }
   if (tid < WA_NBIAS) {
     const float t = (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
     fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
@@ -877,17 +905,31 @@ static int wa_forward(const float* qkv, const float* bias_table, const int* bias
 // acc: heads * 169 zeroed fixed-point records (nnz_fxacc_bytes() each) followed by `heads` zeroed 32-byte ticket records
 // (i.e. at least heads * 170 records of nnz_fxacc_bytes()); all left zero.  `counter` is unused (kept in the signature).
 // dbias_table is WRITTEN (no zero fill needed) and bit-identical run to run.
+// workgroups along x of a backward launch (= the number of bias-gradient shares in `dpart` mode)
+static int wa_backward_groups(int nwin, int heads) {
+  static const int pair_mode = [] { const char* v = getenv("NNZ_WA_PAIR"); return v ? atoi(v) : 1; }();
+  int wpb;
+  if (pair_mode) {
+    wpb = nwin < 2 ? 1 : 2;
+    while (wpb < 8 && (long)((nwin + 2 * wpb - 1) / (2 * wpb)) * heads >= 1024) wpb *= 2;
+  } else {
+    wpb = nnz::windows_per_wg(nwin, heads);
+  }
+  return (nwin + wpb - 1) / wpb;
+}
+
 static int wa_backward(const float* qkv, const float* bias_table, const int* bias_index, const float* dout, float* dqkv,
                        float* dbias_table, void* acc, void* counter, int B, int H, int W, int C, int heads, int shift,
-                       float scale, int py, int px, void* stream) {
+                       float scale, int py, int px, void* stream, float* dpart = nullptr) {
   using namespace nnz;
-  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || !dbias_table || !acc || py < 0 || px < 0 || py >= H || px >= W)
+  if (!qkv || !bias_table || !bias_index || !dout || !dqkv || (!dpart && (!dbias_table || !acc)) || py < 0 || px < 0 || py >= H ||
+      px >= W)
     return NNZ_EINVAL;
   AttnArgs a = {};
   a.qkv = qkv; a.bias = bias_table; a.bidx = bias_index; a.dout = dout; a.dqkv = dqkv; a.dbias = dbias_table;
   a.acc = (FxAcc*)acc; a.counter = (unsigned*)counter;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.hd = heads > 0 ? C / heads : 0; a.shift = shift; a.scale = scale;
-  a.py = py; a.px = px;
+  a.py = py; a.px = px; a.dpart = dpart;
   if (int rc = check(a)) return rc;
   a.nwin = B * (H / WA_WS) * (W / WA_WS);
   a.wpb = windows_per_wg(a.nwin, heads);
@@ -940,4 +982,17 @@ extern "C" int nnz_window_attention_backward_pad(const float* qkv, const float* 
                                                  float scale, int py, int px, void* stream) {
   return wa_backward(qkv, bias_table, bias_index, dout, dqkv, dbias_table, acc, counter, B, H, W, C, heads, shift, scale, py,
                      px, stream);
+}
+// the backward with the bias-table gradient left as per-workgroup shares: dpart[nnz_window_attention_backward_parts(B, H, W,
+// heads)][169][heads], summed in share order by a fold record (nnz_dense32_group_fill_fold, n = 169 * heads)
+extern "C" long nnz_window_attention_backward_parts(int B, int H, int W, int heads) {
+  if (B < 1 || H < 7 || W < 7 || H % 7 || W % 7 || heads < 1) return 0;
+  return wa_backward_groups(B * (H / 7) * (W / 7), heads);
+}
+extern "C" int nnz_window_attention_backward_partial(const float* qkv, const float* bias_table, const int* bias_index,
+                                                     const float* dout, float* dqkv, float* dpart, int B, int H, int W, int C,
+                                                     int heads, int shift, float scale, int py, int px, void* stream) {
+  if (!dpart) return NNZ_EINVAL;
+  return wa_backward(qkv, bias_table, bias_index, dout, dqkv, nullptr, nullptr, nullptr, B, H, W, C, heads, shift, scale, py, px,
+                     stream, dpart);
 }

@@ -153,6 +153,7 @@ class _SS2DCrossScan(torch.autograd.Function):
             call("nnz_ss2d_merge", ptr(y), ptr(out), B, Di, H, W, stream_ptr())
         ctx.save_for_backward(x2, P, Wst, A, Wdt, bias, Dv, state)
         ctx.meta = (B, Di, H, W, R)
+        ctx.xproj_param = x_proj_weight          # the parameter object itself: the deferred weight gradient sets its .grad
         return out
 
     @staticmethod
@@ -188,8 +189,10 @@ class _SS2DCrossScan(torch.autograd.Function):
                 # + the scans' own input gradients: direction k = 2j + s belongs to source s
                 dx2 += du.view(B, 2, 2, Di, L).sum(1).transpose(0, 1)
             if _xproj_ok(Di, 2 * Cp) and L % 64 == 0 and ((2 * Cp + 7) // 8) * (Di // 8) <= 256:
-                from .token_linear import TWO_STAGE
-                if TWO_STAGE:
+                from .token_linear import TWO_STAGE, defer_xproj_wgrad
+                if ctx.needs_input_grad[2] and defer_xproj_wgrad(dP, x2, ctx.xproj_param):
+                    d_xproj = None      # queued: the pass's grouped launch writes x_proj_weight.grad (token_linear._XpKind)
+                elif TWO_STAGE:
                     d_xproj = torch.empty((K, Cp, Di), **f32)                    # written in the module's layout
                     nws = int(lib.nnz_ss2d_xproj_backward_w_workspace_floats(B, Di, 2 * Cp, L))
                     ws = torch.empty(nws, **f32)

@@ -103,6 +103,7 @@ class _SwinBlockFn(torch.autograd.Function):
         _fwd(act, fc2w, fc2b, x2, None, T, Hd, C, res=x1, dp=dp2)
         ctx.save_for_backward(x, qkv, n1, mean1, rstd1, ao, x1, n2, mean2, rstd2, h, act, draws1, draws2, table, idx32)
         ctx.params = (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b)
+        ctx.table_param = table
         ctx.geo = (B, H, W, C, py, px, heads, shift, scale, keep, padded)
         return x2.view(B, H, W, C)
 
@@ -172,10 +173,27 @@ class _SwinBlockFn(torch.autograd.Function):
         _dgrad(dx1, projw, None, dao, T, C, C, dp=dp1)
         wgrad(dx1, ao, projw, projb, dp1, 6, 7)
         dqkv = torch.empty((Tp, 3 * C), **f32)
-        dtable = torch.empty_like(table)
-        sc = det_scratch(dev, 170 * heads)
-        call("nnz_window_attention_backward_pad", ptr(qkv), ptr(table), ptr(idx32), ptr(dao), ptr(dqkv), ptr(dtable), ptr(sc.acc),
-             ptr(sc.counter), B, Hp, Wp, C, heads, shift, float(scale), py, px, stream_ptr())
+        dtable = None
+        tparam = ctx.table_param
+        if ni[5] and deferred and _deferrable((tparam,)):
+            # the bias-table gradient leaves the launch as per-workgroup shares; the pass's grouped launch folds them
+            tparts = int(lib.nnz_window_attention_backward_parts(B, Hp, Wp, heads))
+            tpart = torch.empty((tparts, 169 * heads), **f32)
+            call("nnz_window_attention_backward_partial", ptr(qkv), ptr(table), ptr(idx32), ptr(dao), ptr(dqkv), ptr(tpart), B, Hp,
+                 Wp, C, heads, shift, float(scale), py, px, stream_ptr())
+
+            def assign_table(dst):
+                g = dst.view(169, heads)
+                if tparam.grad is None:
+                    tparam.grad = g
+                else:
+                    tparam.grad.add_(g)
+            defer_fold(tpart, 169 * heads, tparts, assign_table)
+        else:
+            dtable = torch.empty_like(table)
+            sc = det_scratch(dev, 170 * heads)
+            call("nnz_window_attention_backward_pad", ptr(qkv), ptr(table), ptr(idx32), ptr(dao), ptr(dqkv), ptr(dtable),
+                 ptr(sc.acc), ptr(sc.counter), B, Hp, Wp, C, heads, shift, float(scale), py, px, stream_ptr())
         dn1 = torch.empty((Tp, C), **f32)
         _dgrad(dqkv, qkvw, None, dn1, Tp, C, 3 * C)
         wgrad(dqkv, n1, qkvw, qkvb, None, 3, 4)
@@ -187,7 +205,7 @@ class _SwinBlockFn(torch.autograd.Function):
         ln_fold(part1, parts1, n1w, n1b, 1, 2)
         out = [None] * 17
         out[0] = dx.view(B, H, W, C) if ni[0] else None
-        out[5] = dtable if ni[5] else None
+        out[5] = dtable if (ni[5] and dtable is not None) else None
         for k, g in grads.items():
             out[k] = g if (g is not None and ni[k]) else None
         return tuple(out)

@@ -67,6 +67,7 @@ class _HipTokenLinearFn(torch.autograd.Function):
         call("nnz_token_linear_forward", ptr(x), ptr(weight), ptr(bias), ptr(y), T, K, N, 0, stream_ptr())
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)             # the parameter objects themselves: the deferred path sets their .grad
         return y
 
     @staticmethod
@@ -85,6 +86,13 @@ class _HipTokenLinearFn(torch.autograd.Function):
                 dx = (dy.reshape(-1, N) @ weight.to(torch.float16)).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
+            wp, bp = ctx.params
+            if (N // 8) * (K // 8) <= 256 and GROUP_TL_WGRAD and _DEFER["on"] and need_w and wp.is_leaf \
+                    and (bp is None or bp.is_leaf) and not _has_grad_hooks(wp) and not (bp is not None and _has_grad_hooks(bp)):
+                # queued: ONE grouped launch + one fold launch at the end of the backward pass (csrc/token_linear.hip
+                # tl_wgrad_group_kernel) computes and assigns the gradients
+                _DEFER["tl_jobs"].append((dy, x, wp, bp if need_b else None))
+                return dx, None, None
             if (N // 8) * (K // 8) <= 256:
                 if TWO_STAGE:
                     # per-workgroup partial blocks + a fixed-order fold (csrc/common.hpp fold_partials): bit-reproducible, and
@@ -190,7 +198,8 @@ GROUP_WGRAD = os.environ.get("NNZ_DENSE32_GROUP", "1") != "0"
 # costs 0.9-1.4 % of an M2Net / M2NetP / SSND2Net step, and the steps of the Mamba nets stay non-reproducible either way (the scan
 # backward's cross-channel dB / dC / d-delta sums) - so it is an option, not the default.
 TWO_STAGE = os.environ.get("NNZ_TWO_STAGE_WGRADS", "0") == "1"
-_DEFER = {"on": False, "jobs": [], "folds": []}
+_DEFER = {"on": False, "jobs": [], "folds": [], "tl_jobs": [], "xp_jobs": []}
+GROUP_TL_WGRAD = os.environ.get("NNZ_TL_GROUP", "1") != "0"     # fp16 token Linears: weight gradients grouped like the fp32 ones
 _GROUP_KEEP = []          # host tables captured into a hipGraph must outlive it
 _HOST_CACHE, _HOST_EVENTS = {}, {}
 
@@ -216,6 +225,12 @@ class deferred_wgrads:
             _DEFER["on"] = False
             jobs, _DEFER["jobs"] = _DEFER["jobs"], []
             folds, _DEFER["folds"] = _DEFER["folds"], []
+            tl_jobs, _DEFER["tl_jobs"] = _DEFER["tl_jobs"], []
+            xp_jobs, _DEFER["xp_jobs"] = _DEFER["xp_jobs"], []
+            if et is None and tl_jobs:
+                _flush_table_group(_TlKind, tl_jobs)
+            if et is None and xp_jobs:
+                _flush_table_group(_XpKind, xp_jobs)
             if et is None and jobs:
                 # one grouped launch per tile class (64 x 64 / 128 x 128 tiles; csrc/dense32.hip d32_group_class); the fold-only
                 # records (LayerNorm dgamma | dbeta partials of the fused Swin blocks) ride in the first one
@@ -237,6 +252,148 @@ def defer_fold(part: torch.Tensor, n: int, parts: int, assign) -> bool:
     if not _DEFER["on"]:
         return False
     _DEFER["folds"].append((part, n, parts, assign))
+    return True
+
+
+def _host_table(key, nbytes: int):
+    """pinned host buffer for a job table.  Pinned memory cannot be allocated while a stream is capturing: the eager warm-up passes
+    that precede every capture leave their buffer in _HOST_CACHE under the pass's shape signature; a capturing flush TAKES it (the
+    captured copy node re-reads it at every replay, so no later flush may write to it)."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    host = _HOST_CACHE.pop(key, None)
+    ev = _HOST_EVENTS.pop(key, None)
+    if host is not None and ev is not None and not capturing:
+        ev.synchronize()                  # the previous copy out of this buffer has run
+    if host is None or host.numel() != nbytes:
+        if capturing:
+            raise RuntimeError("grouped weight gradients: no pinned table from a warm-up pass for this capture - run one "
+                               "eager pass with the same shapes before capturing")
+        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    return host, capturing
+
+
+def _table_to_device(host, key, capturing, dev):
+    tab = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
+    tab.copy_(host, non_blocking=True)
+    if capturing:
+        _GROUP_KEEP.append(host)          # the captured copy node reads this buffer at every replay
+    else:
+        ev = torch.cuda.Event()
+        ev.record()
+        _HOST_CACHE[key] = host
+        _HOST_EVENTS[key] = ev
+    return tab
+
+
+def _accumulate(p, g):
+    if p.grad is None:
+        p.grad = g
+    else:
+        p.grad.add_(g)
+
+
+class _TlKind:
+    """fp16 token Linear weight gradients: job = (dy f16 [T][N], x f16 [T][K], weight, bias or None)"""
+    name, rec, launch = "tl", "nnz_token_linear_wgrad_group_record_bytes", "nnz_token_linear_wgrad_group_launch"
+
+    @staticmethod
+    def sig(j):
+        return (j[1].numel() // j[2].shape[1],) + tuple(j[2].shape) + (j[3] is not None,)
+
+    @staticmethod
+    def plan(j, wgs, lds, wsf):
+        N, K = j[2].shape
+        call("nnz_token_linear_wgrad_group_plan", j[1].numel() // K, N, K, C.addressof(wgs), C.addressof(lds), C.addressof(wsf))
+        return N * K + N, wgs.value                      # floats of the folded result, partial blocks
+
+    @staticmethod
+    def fill(rec_ptr, j, part_ptr, wg0):
+        N, K = j[2].shape
+        call("nnz_token_linear_wgrad_group_fill", rec_ptr, ptr(j[0]), ptr(j[1]), part_ptr, j[1].numel() // K, N, K, wg0)
+
+    @staticmethod
+    def assign(j, dst):
+        N, K = j[2].shape
+        _accumulate(j[2], dst[:N * K].view(N, K))
+        if j[3] is not None:
+            _accumulate(j[3], dst[N * K:])
+
+
+class _XpKind:
+    """SS2D x_proj weight gradients: job = (dP [2][B][C2][L], x2 [2][B][Di][L], x_proj_weight parameter [4][Cp][Di])"""
+    name, rec, launch = "xp", "nnz_ss2d_xproj_backward_w_group_record_bytes", "nnz_ss2d_xproj_backward_w_group_launch"
+
+    @staticmethod
+    def sig(j):
+        return tuple(j[0].shape) + tuple(j[1].shape)
+
+    @staticmethod
+    def plan(j, wgs, lds, wsf):
+        _, B, C2, L = j[0].shape
+        Di = j[1].shape[2]
+        call("nnz_ss2d_xproj_backward_w_group_plan", B, Di, C2, L, C.addressof(wgs), C.addressof(lds), C.addressof(wsf))
+        return 2 * C2 * Di, wgs.value // 2
+
+    @staticmethod
+    def fill(rec_ptr, j, part_ptr, wg0):
+        _, B, C2, L = j[0].shape
+        Di = j[1].shape[2]
+        call("nnz_ss2d_xproj_backward_w_group_fill", rec_ptr, ptr(j[0]), ptr(j[1]), part_ptr, B, Di, C2, L, C2 // 2, wg0)
+
+    @staticmethod
+    def assign(j, dst):
+        _accumulate(j[2], dst.view(j[2].shape))
+
+
+def _flush_table_group(kind, jobs) -> None:
+    """one grouped launch (per-workgroup partial blocks into a workspace) + one fold launch for the queued jobs of one kernel
+    family; gradients are assigned / accumulated here.  Bit-identical from pass to pass (fixed partition, fixed fold order)."""
+    import numpy as np
+    lib = _lib.load()
+    dev = jobs[0][0].device
+    rb, rbf = int(getattr(lib, kind.rec)()), int(lib.nnz_dense32_group_record_bytes(1))
+    wgs, lds, wsf = C.c_int(0), C.c_int(0), C.c_long(0)
+    plans = []
+    for j in jobs:
+        n_out, parts = kind.plan(j, wgs, lds, wsf)
+        plans.append((wgs.value, lds.value, wsf.value, n_out, parts, (n_out + 255) // 256))
+    total_wgs, total_blks = sum(p[0] for p in plans), sum(p[5] for p in plans)
+    ws = torch.empty(sum(p[2] for p in plans), dtype=torch.float32, device=dev)
+    o_fold = (len(jobs) * rb + 15) // 16 * 16
+    o_wg = (o_fold + len(jobs) * rbf + 15) // 16 * 16
+    o_blk = o_wg + total_wgs * 4
+    nbytes = o_blk + total_blks * 4
+    key = (kind.name,) + tuple(kind.sig(j) for j in jobs)
+    host, capturing = _host_table(key, nbytes)
+    hp, hn = host.data_ptr(), host.numpy()
+    wg_job = hn[o_wg:o_wg + total_wgs * 4].view(np.int32)
+    blk_job = hn[o_blk:o_blk + total_blks * 4].view(np.int32)
+    wg0 = blk0 = ws_off = 0
+    outs = []
+    for i, (j, (nw, _, nf, n_out, parts, nb)) in enumerate(zip(jobs, plans)):
+        part = ws.data_ptr() + 4 * ws_off
+        dst = torch.empty(n_out, dtype=torch.float32, device=dev)
+        kind.fill(hp + i * rb, j, part, wg0)
+        call("nnz_dense32_group_fill_fold", hp + o_fold + i * rbf, part, ptr(dst), n_out, parts, blk0)
+        wg_job[wg0:wg0 + nw] = i
+        blk_job[blk0:blk0 + nb] = i
+        wg0, blk0, ws_off = wg0 + nw, blk0 + nb, ws_off + nf
+        outs.append((j, dst))
+    tab = _table_to_device(host, key, capturing, dev)
+    base = tab.data_ptr()
+    call(kind.launch, base, base + o_wg, total_wgs, max(p[1] for p in plans), stream_ptr())
+    call("nnz_group_fold_launch", base + o_fold, base + o_blk, total_blks, stream_ptr())
+    for j, dst in outs:
+        kind.assign(j, dst)
+
+
+def defer_xproj_wgrad(dP, x2, param) -> bool:
+    """queue the x_proj weight gradient of one SS2D block for the pass's grouped launch (False outside deferred_wgrads() or when the
+    parameter is not a plain leaf)"""
+    if not (GROUP_TL_WGRAD and _DEFER["on"] and isinstance(param, torch.Tensor) and param.is_leaf and param.requires_grad
+            and param.dtype == torch.float32 and not _has_grad_hooks(param)):
+        return False
+    _DEFER["xp_jobs"].append((dP, x2, param))
     return True
 
 
@@ -338,6 +495,20 @@ def _flush_group(jobs, tile_class: int = 0, folds=()) -> None:
         assign(dst)
 
 
+def _d32_forward(x2, weight, bias, y, y_act, T, K, N, gelu):
+    """y = x W^T + b on csrc/dense32.hip through the entry point that cuts skinny products along the contraction (split-K)"""
+    from .swin_block import _workspace
+    ws = _workspace(x2.device, int(_lib.load().nnz_dense32_splitk_workspace_floats(T, K, N)))
+    call("nnz_dense32_forward_fused", ptr(x2), ptr(weight), ptr(bias), ptr(y), ptr(y_act), T, K, N, int(gelu), None, None, 0.0, None,
+         None, None, 0, 0, 0, 0, None, None, 1.0, 1, 1, ptr(ws), stream_ptr())
+
+
+def _d32_dgrad(dy2, weight, h, dx, T, K, N):
+    from .swin_block import _workspace
+    ws = _workspace(dy2.device, int(_lib.load().nnz_dense32_splitk_workspace_floats(T, N, K)))
+    call("nnz_dense32_dgrad_fused", ptr(dy2), ptr(weight), ptr(h), ptr(dx), T, K, N, None, 1.0, 1, 1, ptr(ws), stream_ptr())
+
+
 def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None, bias=None):
     """the three products of a Linear's backward on csrc/dense32.hip: dx (optionally times GELU'(h)), dW, db.  Inside
     deferred_wgrads() the weight / bias gradients are queued for the grouped launch and returned as None"""
@@ -346,7 +517,7 @@ def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None, bias
     dx = dw = db = None
     if need_x:
         dx = torch.empty((T, K), dtype=torch.float32, device=dy2.device)
-        call("nnz_dense32_dgrad", ptr(dy2), ptr(weight), ptr(h), ptr(dx), T, K, N, stream_ptr())
+        _d32_dgrad(dy2, weight, h, dx, T, K, N)
     if need_w or need_b:
         if _DEFER["on"] and need_w and weight.is_leaf and (bias is None or bias.is_leaf) and not _has_grad_hooks(weight) \
                 and not (bias is not None and _has_grad_hooks(bias)):
@@ -372,7 +543,7 @@ class _Dense32LinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         T = x2.shape[0]
         y = torch.empty((T, N), dtype=torch.float32, device=x.device)
-        call("nnz_dense32_forward", ptr(x2), ptr(weight), ptr(bias), ptr(y), None, T, K, N, 0, stream_ptr())
+        _d32_forward(x2, weight, bias, y, None, T, K, N, 0)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)             # the parameter objects themselves (leaves): the deferred path sets their .grad
@@ -407,9 +578,9 @@ class _Dense32MlpFn(torch.autograd.Function):
         dev = x.device
         h = torch.empty((T, Hd), dtype=torch.float32, device=dev)
         a = torch.empty((T, Hd), dtype=torch.float32, device=dev)
-        call("nnz_dense32_forward", ptr(x2), ptr(w1), ptr(b1), ptr(h), ptr(a), T, K, Hd, 1, stream_ptr())
+        _d32_forward(x2, w1, b1, h, a, T, K, Hd, 1)
         y = torch.empty((T, N), dtype=torch.float32, device=dev)
-        call("nnz_dense32_forward", ptr(a), ptr(w2), ptr(b2), ptr(y), None, T, Hd, N, 0, stream_ptr())
+        _d32_forward(a, w2, b2, y, None, T, Hd, N, 0)
         ctx.save_for_backward(x2, w1, w2, h, a)
         ctx.params = (w1, b1, w2, b2)
         ctx.bias = (b1 is not None, b2 is not None)

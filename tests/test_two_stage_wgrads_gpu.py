@@ -92,3 +92,47 @@ def test_dwconv_silu_backward_two_stage(hip_lib):
         assert (dw.double() - wr.grad).abs().max().item() <= 5e-5 * wr.grad.abs().max().item() + 1e-3
         assert (db.double() - br.grad).abs().max().item() <= 5e-5 * br.grad.abs().max().item() + 1e-3
         assert (dx.double().permute(0, 3, 1, 2) - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
+
+
+def test_grouped_token_linear_weight_gradients(hip_lib):
+    """round 5: inside deferred_wgrads() the fp16 token Linears queue their weight gradients; ONE grouped launch + ONE fold launch
+    (csrc/token_linear.hip tl_wgrad_group_kernel) computes them: equal to float64, bit-identical from pass to pass, and equal to the
+    per-layer two-stage launches up to the fold order"""
+    from nnuzoo_amd import token_linear as TLm
+    from nnuzoo_amd.token_linear import TokenLinear, deferred_wgrads
+    torch.manual_seed(5)
+    shapes = [(4096, 32, 64), (70000, 16, 32), (1024, 128, 128), (2048, 64, 16), (1500, 96, 64)]   # T, K, N
+    lins = [TokenLinear(K, N, bias=(i % 2 == 0)).to(DEV) for i, (T, K, N) in enumerate(shapes)]
+    xs = [torch.randn(T, K, device=DEV) for T, K, N in shapes]
+
+    def run(deferred):
+        for l in lins:
+            l.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = sum((l(x).float() * (1 + i)).square().mean() for i, (l, x) in enumerate(zip(lins, xs)))
+        if deferred:
+            with deferred_wgrads():
+                loss.backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        assert all(l.backend == "hip-f16" for l in lins)
+        return [p.grad.clone() for l in lins for p in l.parameters()]
+
+    a, b = run(True), run(True)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    old = TLm.TWO_STAGE
+    try:
+        TLm.TWO_STAGE = True
+        c = run(False)
+    finally:
+        TLm.TWO_STAGE = old
+    for u, v in zip(a, c):
+        assert torch.allclose(u, v, rtol=2e-5, atol=2e-5 * v.abs().max().item())
+    # float64 reference of the first layer's weight gradient from the same fp16 operands
+    l, x = lins[0], xs[0]
+    xh = x.to(torch.float16)
+    y = (xh.double() @ l.weight.to(torch.float16).double().t() + l.bias.to(torch.float16).double()).to(torch.float16).float()
+    dy = (2 * y / y.numel()).to(torch.float16)
+    ref = dy.double().t() @ xh.double()
+    assert (a[0].double() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
