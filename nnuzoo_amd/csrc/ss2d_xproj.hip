@@ -128,6 +128,119 @@ __global__ __launch_bounds__(256) void xproj_bwd_x_kernel(XpArgs a) {
   }
 }
 
+// ---- round 5: forward and backward-x on the fp32 matrix cores ------------------------------------------------------------------
+// The FMA kernels above read their weights as wave-uniform LDS broadcasts: one ds_read_b128 per four FMAs, and with four SIMDs
+// issuing them the LDS pipe, not the FMAs and not HBM, sets the pace (forward 182 us for 32 channels @ 512^2, batch 2, where the
+// bytes take 75; backward-x 268 us for 118).  v_mfma_f32_32x32x2_f32 (exact fp32, the FMA rate) takes the weights as its A
+// operand - ONE register per (row tile, step) and lane, fetched once per 64 tokens - and tokens sit on the lanes:
+//   forward     P[c][l]  = sum_d W[c][d] x[d][l]      rows c (3 tiles of 32 cover C2 <= 80), contraction d, 16 steps per 32 channels
+//   backward-x  dx[d][l] = sum_c W[c][d] dP[c][l]     rows d (one tile per 32 channels), contraction c (C2 / 2 steps)
+// A wave owns 64 consecutive tokens as TWO column tiles: lane (l31, hh) holds tokens 2 l31 and 2 l31 + 1 of contraction row
+// 2 step + hh, i.e. one 8-byte load per step (256 contiguous bytes per half-wave), and stores token pairs the same way.
+// Needs an even L (8-byte alignment of every row); odd L keeps the FMA kernels (NNZ_XPROJ_MFMA=0 forces them).
+__device__ __forceinline__ f32x16 xp_mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int xp_crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// NRT row tiles per workgroup (3: all of C2 <= 96 in one go; 1: blockIdx.z picks the tile - few-token levels)
+template <int NRT>
+__global__ __launch_bounds__(256) void xproj_fwd_mfma_kernel(XpArgs a) {
+  constexpr int WP = 97;                                 // pitch of the image: the transposing stores hit 32 different banks
+  __shared__ float sW[XP_DC * WP];                       // [d of the chunk][c], zero beyond C2
+  const int sb = blockIdx.y, s = sb / a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int rt0 = NRT == 3 ? 0 : blockIdx.z;
+  if (rt0 * 32 >= a.C2) return;
+  const long tok = (long)blockIdx.x * 256 + wave * 64 + 2 * l31;   // this lane's token pair
+  const bool ok = tok < a.L;                                        // L is even: a pair is inside or outside as a whole
+  const float* x = a.x2 + (long)sb * a.Di * a.L + (ok ? tok : 0);
+  f32x16 acc[NRT][2];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+  for (int d0 = 0; d0 < a.Di; d0 += XP_DC) {
+    f32x2 xv[XP_DC / 2];
+#pragma unroll
+    for (int st = 0; st < XP_DC / 2; ++st)
+      xv[st] = ok ? *reinterpret_cast<const f32x2*>(x + (long)(d0 + 2 * st + hh) * a.L) : f32x2{0.f, 0.f};
+    __syncthreads();
+    for (int e = tid; e < XP_DC * 96; e += 256) {        // W[c][d0 + d], d fastest in memory; image [d][c]
+      const int c = e / XP_DC, d = e % XP_DC;
+      sW[d * WP + c] = c < a.C2 ? a.W[xp_row(a, s, c) + d0 + d] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < XP_DC / 2; ++st) {
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) {
+        const float w = sW[(2 * st + hh) * WP + (rt0 + i) * 32 + l31];      // 32 consecutive words per half-wave
+        acc[i][0] = xp_mfma(w, xv[st][0], acc[i][0]);
+        acc[i][1] = xp_mfma(w, xv[st][1], acc[i][1]);
+      }
+    }
+  }
+  if (!ok) return;
+  float* P = a.P + (long)sb * a.C2 * a.L + tok;
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (rt0 + i) * 32 + xp_crow(r, hh);
+      if (c < a.C2) *reinterpret_cast<f32x2*>(P + (long)c * a.L) = f32x2{acc[i][0][r], acc[i][1][r]};
+    }
+}
+
+// blockIdx.z = a slice of the Di output channels (multiples of 32)
+__global__ __launch_bounds__(256) void xproj_bwd_x_mfma_kernel(XpArgs a) {
+  __shared__ float sW[XP_CMAX * XP_DC];                  // [c][d of the chunk]: W's own layout, rows beyond C2 zero
+  const int sb = blockIdx.y, s = sb / a.B, b = sb % a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long tok = (long)blockIdx.x * 256 + wave * 64 + 2 * l31;
+  const bool ok = tok < a.L;
+  const float* dP = a.dP + (long)sb * a.C2 * a.L + (ok ? tok : 0);
+  f32x2 g[XP_CMAX / 2];                                   // dP[c = 2 step + hh][token pair]
+#pragma unroll
+  for (int st = 0; st < XP_CMAX / 2; ++st) {
+    const int c = 2 * st + hh;
+    g[st] = (ok && c < a.C2) ? *reinterpret_cast<const f32x2*>(dP + (long)c * a.L) : f32x2{0.f, 0.f};
+  }
+  const float* du0 = a.du + (((long)b * 4 + s) * a.Di) * a.L + (ok ? tok : 0);
+  const float* du1 = a.du + (((long)b * 4 + s + 2) * a.Di) * a.L + (ok ? tok : 0);
+  float* dx = a.dx2 + (long)sb * a.Di * a.L + tok;
+  const int dper = a.Di / gridDim.z;
+  for (int d0 = blockIdx.z * dper; d0 < (blockIdx.z + 1) * dper; d0 += XP_DC) {
+    __syncthreads();
+    for (int e = tid; e < XP_CMAX * XP_DC; e += 256) {
+      const int c = e / XP_DC, d = e % XP_DC;
+      sW[e] = c < a.C2 ? a.W[xp_row(a, s, c) + d0 + d] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < XP_CMAX / 2; ++st) {
+      const float w = sW[(2 * st + hh) * XP_DC + l31];    // A[row d = l31][k = c]: 32 consecutive words per half-wave
+      acc[0] = xp_mfma(w, g[st][0], acc[0]);
+      acc[1] = xp_mfma(w, g[st][1], acc[1]);
+    }
+    if (ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long o = (long)(d0 + xp_crow(r, hh)) * a.L;
+        const f32x2 u0 = *reinterpret_cast<const f32x2*>(du0 + o), u1 = *reinterpret_cast<const f32x2*>(du1 + o);
+        *reinterpret_cast<f32x2*>(dx + o) = f32x2{acc[0][r] + u0[0] + u1[0], acc[1][r] + u0[1] + u1[1]};
+      }
+    }
+  }
+}
+
 // dW[s][c][d] = sum over (b, l) of dP[c][l] x2[d][l].  Workgroup = one source s and a token range; thread = (token slice,
 // 8 x 8 block of dW); rows are staged as [row][64 tokens] tiles and read 4 tokens (16 bytes) at a time.
 constexpr int XPW_TOK = 64;
@@ -208,19 +321,134 @@ __device__ __forceinline__ void xproj_bwd_w_body(const XpArgs& a, const unsigned
 __global__ __launch_bounds__(256) void xproj_bwd_w_kernel(XpArgs a) { xproj_bwd_w_body(a, blockIdx.x, blockIdx.y); }
 
 // grouped form (round 5): the x_proj weight gradients of every SS2D block of a backward pass in ONE launch over a job table
-// (66 launches of 11-400 us per M2Net step, most of them a few hundred short workgroups), partial matrices per workgroup, one
-// fold launch (nnz_group_fold_launch) - see csrc/token_linear.hip tl_wgrad_group_kernel for the protocol
+// (66 launches of 11-400 us per M2Net step), partial matrices per workgroup, one fold launch (nnz_group_fold_launch) - see
+// csrc/token_linear.hip tl_wgrad_group_kernel for the protocol.  The grouped launch runs the product on the fp32 matrix cores:
+//   dW[c][d] = sum_l dP[c][l] x2[d][l]: rows c (<= 3 tiles of 32), columns d (Di / 32 tiles), contraction = tokens, which are
+//   CONTIGUOUS in both operands - both tiles go to LDS as [row][64 tokens] (pitch 65: lane = row reads hit 64 banks) and a lane's
+//   MFMA operand of step st is one word, image[row][2 st + hh].  A workgroup covers <= 16 blocks of 32 x 32 (4 per wave;
+//   <= 4 blocks: the waves split the round's 32 steps instead and are summed through LDS in wave order), blockIdx picks the
+//   source, the token range and the block group.  (The FMA kernel above: 8 x 8 register tiles + a [slices][C2 Di] LDS fold,
+//   3.5 ms for the 66 problems of an M2Net step even as one launch.)
+constexpr int XPM_BPW = 4;                      // blocks per wave
+constexpr int XPM_PITCH = XPW_TOK + 1;
+__device__ __forceinline__ void xproj_bwd_w_mfma_body(const XpArgs& a, const unsigned bx, const int s, const int ygroup) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int CB = (a.C2 + 31) >> 5, DB = a.Di >> 5, NBK = CB * DB;        // blocks bi = db * CB + cb
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int g_begin = ygroup * 4 * XPM_BPW;
+  const int g_n = NBK - g_begin < 4 * XPM_BPW ? NBK - g_begin : 4 * XPM_BPW;
+  const int db_lo = g_begin / CB, db_hi = (g_begin + g_n - 1) / CB;       // d blocks this group touches
+  const int nd = (db_hi - db_lo + 1) * 32;
+  float* sP = smem_f;                          // [CB * 32][65]  (rows beyond C2: zero)
+  float* sX = sP + CB * 32 * XPM_PITCH;        // [nd][65]
+  const bool split_steps = g_n <= XPM_BPW;
+  const int per = (g_n + 3) >> 2;
+  const int b_begin = g_begin + (split_steps ? 0 : wave * per);
+  int nblk = split_steps ? g_n : (g_n - wave * per < per ? g_n - wave * per : per);
+  if (nblk < 0) nblk = 0;
+  const int st_begin = split_steps ? wave * 8 : 0, st_end = split_steps ? wave * 8 + 8 : 32;
+  f32x16 acc[XPM_BPW];
+#pragma unroll
+  for (int j = 0; j < XPM_BPW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const long T = (long)a.B * a.L;
+  const long t_begin = (long)bx * a.tokens_per_wg;
+  long t_end = t_begin + a.tokens_per_wg;
+  if (t_end > T) t_end = T;
+  for (long tb = t_begin; tb < t_end; tb += XPW_TOK) {
+    const int b = (int)(tb / a.L);               // a 64-token round never straddles two samples (launcher)
+    const long l0 = tb - (long)b * a.L;
+    const float* dPb = a.dP + ((long)(s * a.B + b) * a.C2) * a.L + l0;
+    const float* xb = a.x2 + ((long)(s * a.B + b) * a.Di + db_lo * 32) * a.L + l0;
+    __syncthreads();
+    for (int e = tid; e < CB * 32 * (XPW_TOK / 4); e += 256) {
+      const int c = e / (XPW_TOK / 4), q = e % (XPW_TOK / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < a.C2) v = *reinterpret_cast<const f32x4*>(dPb + (long)c * a.L + q * 4);
+      float* d = sP + c * XPM_PITCH + q * 4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    for (int e = tid; e < nd * (XPW_TOK / 4); e += 256) {
+      const int dd = e / (XPW_TOK / 4), q = e % (XPW_TOK / 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)dd * a.L + q * 4);
+      float* d = sX + dd * XPM_PITCH + q * 4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int st = st_begin; st < st_end; ++st) {
+      const int k = 2 * st + hh;
+#pragma unroll
+      for (int j = 0; j < XPM_BPW; ++j) {
+        if (j < nblk) {                          // wave-uniform
+          const int bi = b_begin + j;
+          const int db = bi / CB, cb = bi - db * CB;
+          const float av = sP[(cb * 32 + l31) * XPM_PITCH + k];
+          const float bv = sX[((db - db_lo) * 32 + l31) * XPM_PITCH + k];
+          acc[j] = xp_mfma(av, bv, acc[j]);
+        }
+      }
+    }
+  }
+  // ---- the workgroup's partial matrix: rows of the module's weight layout -------------------------------------------------------
+  float* prow = a.part + (size_t)bx * 2 * a.C2 * a.Di;
+  __syncthreads();
+  float* red = smem_f;                           // [4][32][32] (the images are dead)
+  if (split_steps) {
+#pragma unroll
+    for (int j = 0; j < XPM_BPW; ++j) {
+      if (j < nblk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + xp_crow(r, hh)) * 32 + l31] = acc[j][r];
+        __syncthreads();
+        const int bi = b_begin + j, db = bi / CB, cb = bi - db * CB;
+        for (int e = tid; e < 1024; e += 256) {
+          const int c = cb * 32 + (e >> 5), d = db * 32 + (e & 31);
+          const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+          if (c < a.C2) prow[xp_row(a, s, c) + d] = v;
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < XPM_BPW; ++j) {
+      if (j < nblk) {
+        const int bi = b_begin + j, db = bi / CB, cb = bi - db * CB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = cb * 32 + xp_crow(r, hh);
+          if (c < a.C2) prow[xp_row(a, s, c) + db * 32 + l31] = acc[j][r];
+        }
+      }
+    }
+  }
+}
+static int xpm_ygroups(int Di, int C2) { return (((C2 + 31) / 32) * (Di / 32) + 4 * nnz::XPM_BPW - 1) / (4 * nnz::XPM_BPW); }
+static size_t xpm_lds_bytes(int Di, int C2) {
+  const int CB = (C2 + 31) / 32;
+  const int DBg = (4 * nnz::XPM_BPW + CB - 1) / CB + 1;                     // d blocks one group can touch (upper bound)
+  const int DB = Di / 32;
+  const size_t img = sizeof(float) * (size_t)nnz::XPM_PITCH * 32 * (CB + (DBg < DB ? DBg : DB));
+  return img > 16384 ? img : 16384;
+}
+
 struct XpJob {
   XpArgs a;
   int wg_begin;
-  int pad;
+  int ygroups;
 };
-__global__ __launch_bounds__(256) void xproj_bwd_w_group_kernel(const XpJob* __restrict__ jobs, const int* __restrict__ wg_job) {
+__global__ __launch_bounds__(256, 2) void xproj_bwd_w_group_kernel(const XpJob* __restrict__ jobs, const int* __restrict__ wg_job) {
   const int j = __builtin_amdgcn_readfirstlane(wg_job[blockIdx.x]);
   const XpJob* jp = jobs + j;
   const XpArgs a = jp->a;
-  const unsigned local = blockIdx.x - (unsigned)jp->wg_begin;
-  xproj_bwd_w_body(a, local >> 1, (int)(local & 1));
+  unsigned local = blockIdx.x - (unsigned)jp->wg_begin;
+  const unsigned yg = (unsigned)jp->ygroups;
+  const int ygroup = (int)(local % yg);
+  local /= yg;
+  xproj_bwd_w_mfma_body(a, local >> 1, (int)(local & 1), ygroup);
 }
 
 static bool xp_shape_ok(int B, int Di, int C2, long L) {
@@ -239,6 +467,13 @@ extern "C" int nnz_ss2d_xproj_forward(const float* x2, const float* W, float* P,
   // output groups until the launch has ~256 workgroups
   const long base_wgs = ((L + 255) / 256) * 2 * B;
   const dim3 g1((unsigned)((L + 255) / 256), 2 * B, 1);
+  static const bool use_mfma = [] { const char* e = getenv("NNZ_XPROJ_MFMA"); return !e || atoi(e) != 0; }();
+  if (use_mfma && (L & 1) == 0) {      // matrix-core form (round 5); row tiles over blockIdx.z where the tokens alone are few
+    if (base_wgs >= 128) NNZ_LAUNCH(xproj_fwd_mfma_kernel<3>, g1, dim3(256), 0, (hipStream_t)stream, a);
+    else NNZ_LAUNCH(xproj_fwd_mfma_kernel<1>, dim3(g1.x, g1.y, (C2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+    NNZ_LAUNCH_CHECK();
+    return NNZ_OK;
+  }
   if (base_wgs >= 128) {
     NNZ_LAUNCH(xproj_fwd_kernel<XP_CMAX>, g1, dim3(256), 0, (hipStream_t)stream, a);
   } else if (base_wgs >= 64) {
@@ -262,7 +497,11 @@ extern "C" int nnz_ss2d_xproj_backward_x(const float* dP, const float* W, const 
   const long base_wgs = ((L + 255) / 256) * 2 * B;
   int slices = 1;
   while (slices < 16 && base_wgs * slices < 256 && (Di / XP_DC) % (slices * 2) == 0) slices *= 2;
-  NNZ_LAUNCH(xproj_bwd_x_kernel, dim3((unsigned)((L + 255) / 256), 2 * B, slices), dim3(256), 0, (hipStream_t)stream, a);
+  static const bool use_mfma = [] { const char* e = getenv("NNZ_XPROJ_MFMA"); return !e || atoi(e) != 0; }();
+  if (use_mfma && (L & 1) == 0)
+    NNZ_LAUNCH(xproj_bwd_x_mfma_kernel, dim3((unsigned)((L + 255) / 256), 2 * B, slices), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    NNZ_LAUNCH(xproj_bwd_x_kernel, dim3((unsigned)((L + 255) / 256), 2 * B, slices), dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -328,15 +567,11 @@ extern "C" int nnz_ss2d_xproj_backward_w_group_record_bytes(void) { return (int)
 extern "C" int nnz_ss2d_xproj_backward_w_group_plan(int B, int Di, int C2, long L, int* wgs, int* lds_bytes, long* ws_floats) {
   using namespace nnz;
   if (!xp_shape_ok(B, Di, C2, L) || (L % XPW_TOK) || !wgs || !lds_bytes || !ws_floats) return NNZ_EINVAL;
-  const int C2p = (C2 + 7) & ~7;
-  const int nbk = (C2p >> 3) * (Di >> 3);
-  if (nbk > 256) return NNZ_EINVAL;
-  const int TSL = 256 / nbk;
   const long T = (long)B * L, tpw = xp_bwd_w_tokens_per_wg(T);
   const long ranges = (T + tpw - 1) / tpw;
-  const size_t lds = sizeof(float) * ((size_t)(C2p + Di) * XPW_TOK + (size_t)TSL * C2p * Di);
+  const size_t lds = xpm_lds_bytes(Di, C2);
   if (lds > 160 * 1024) return NNZ_EINVAL;
-  *wgs = (int)(2 * ranges);
+  *wgs = (int)(2 * ranges * xpm_ygroups(Di, C2));          // sources x token ranges x block groups
   *lds_bytes = (int)lds;
   *ws_floats = ranges * 2L * C2 * Di;
   return NNZ_OK;
@@ -352,6 +587,7 @@ extern "C" int nnz_ss2d_xproj_backward_w_group_fill(void* job_host, const float*
   j.a.tokens_per_wg = xp_bwd_w_tokens_per_wg((long)B * L);
   j.a.part = workspace;
   j.wg_begin = wg_begin;
+  j.ygroups = xpm_ygroups(Di, C2);
   *reinterpret_cast<XpJob*>(job_host) = j;
   return NNZ_OK;
 }

@@ -266,16 +266,177 @@ __global__ __launch_bounds__(256) void tl_wgrad_kernel(TlWgArgs a) { tl_wgrad_bo
 // over a job table (workgroup -> job map in device memory), every workgroup writing its partial block to its job's slice of the
 // workspace, and ONE fold launch sums the blocks in workgroup order (nnz_group_fold_launch): no zero fills, no float atomics -
 // bit-identical from run to run.
+// ---- the same product on the matrix cores (round 5; the grouped launch runs this body) ---------------------------------------
+// The FMA kernel above keeps 8 x 8 register blocks per thread and folds 256 / (N K / 64) token slices through a [slices][N K]
+// LDS buffer - 67 KB for a 16 x 32 weight, two workgroups per CU, a barrier pair per 64 tokens and 128 FMAs per thread between
+// them: grouped into one launch the ~160 problems of an M2Net step still took 3.1 ms (profiles/r05_m2net_graph_kernels_grouped_first.txt).
+// dW[n][k] = sum_t dy[t][n] x[t][k] is a GEMM whose contraction index (the token) is the SLOW axis of both operands - exactly what
+// ds_read_b64_tr_b16 is for: both token-major fp16 tiles go to LDS as they are (16-byte pieces), and the MFMA fragments
+// (feature on the lane, 8 consecutive tokens in the lane's elements) are transposed reads of them (as in csrc/conv_wgrad.hip).
+//   * the weight matrix is cut into 32 x 32 blocks (v_mfma_f32_32x32x16_f16, fp32 accumulate); a workgroup covers <= 32 blocks
+//     (blockIdx y picks the group for the 256 x 128 / 256 x 256 weights), a token range of tokens_per_wg tokens, 64 per round;
+//   * <= 8 blocks: the four waves split the round's four 16-token steps and their accumulators are summed through LDS at the
+//     end (in wave order); more: a wave owns <= 8 blocks and runs all four steps;
+//   * image pitch = 16 words (mod 32): the four rows x two 16-column groups of a 32-lane half land on 32 different banks;
+//   * bias gradient: column sums of the dy tile by 16-byte pieces on the vector ALU (four per thread and round at N = 256);
+//   * the workgroup's block goes to its row of the workspace (layout dW | db as before) - the fold kernel sums the rows in order.
+__device__ __forceinline__ int tlw_pitch_words(int cols) {          // cols = features rounded up to 32
+  const int w = cols >> 1;
+  return ((cols >> 5) & 1) ? w : w + 16;
+}
+__device__ __forceinline__ f16x8 tlw_frag(const char* img, int pitch_bytes, int row0, int colbyte0, int lane) {
+  const int q = (lane >> 2) & 3, p = lane & 3, g = (lane >> 4) & 1, hh = lane >> 5;
+  const char* a = img + (row0 + 8 * hh + q) * pitch_bytes + colbyte0 + g * 32 + p * 8;
+  union { i16x4 v[2]; f16x8 h; } u;
+  u.v[0] = lds_read_tr16(a);
+  u.v[1] = lds_read_tr16(a + 4 * pitch_bytes);
+  return u.h;
+}
+
+constexpr int TLM_TOK = 64;        // tokens per round (= TLW_TOK: the token ranges of tl_wgrad_tokens_per_wg are multiples of it)
+constexpr int TLM_BPW = 8;         // blocks per wave
+__device__ __forceinline__ void tl_wgrad_mfma_body(const TlWgArgs& a, const unsigned bx, const int ygroup) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.N, K = a.K;
+  const int NB = (N + 31) >> 5, KB = (K + 31) >> 5, NBK = NB * KB;
+  const int pn = tlw_pitch_words(NB * 32) * 4, pk = tlw_pitch_words(KB * 32) * 4;      // bytes
+  char* sdy = smem;
+  char* sx = smem + TLM_TOK * pn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  // this workgroup's blocks, and this wave's share of them / of the round's four 16-token steps
+  const int g_begin = ygroup * 4 * TLM_BPW;
+  const int g_n = NBK - g_begin < 4 * TLM_BPW ? NBK - g_begin : 4 * TLM_BPW;
+  const bool split_steps = g_n <= TLM_BPW;                 // few blocks: waves take steps, not blocks
+  const int per = (g_n + 3) >> 2;
+  const int b_begin = g_begin + (split_steps ? 0 : wave * per);
+  int nblk = split_steps ? g_n : (g_n - wave * per < per ? g_n - wave * per : per);
+  if (nblk < 0) nblk = 0;
+  const int ks_begin = split_steps ? wave : 0, ks_end = split_steps ? wave + 1 : 4;
+  f32x16 acc[TLM_BPW];
+#pragma unroll
+  for (int j = 0; j < TLM_BPW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // bias: thread = (16-byte piece of the row, token lane)
+  const int ppn = N >> 3, ppk = K >> 3;
+  const int bp = tid % ppn, btl = tid / ppn, bstep = 256 / ppn;
+  float accb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) accb[i] = 0.f;
+  // zero the images once: padding columns and rows beyond a short last round stay zero / are rewritten below
+  for (int e = tid * 16; e < TLM_TOK * (pn + pk); e += 256 * 16) *reinterpret_cast<u32x4*>(smem + e) = u32x4{0, 0, 0, 0};
+  const long t_begin = (long)bx * a.tokens_per_wg;
+  long t_end = t_begin + a.tokens_per_wg;
+  if (t_end > a.T) t_end = a.T;
+  for (long tb = t_begin; tb < t_end; tb += TLM_TOK) {
+    __syncthreads();
+    const int nt = (int)((t_end - tb) < TLM_TOK ? (t_end - tb) : TLM_TOK);
+    for (int p = tid; p < TLM_TOK * ppn; p += 256) {
+      const int t = p / ppn, c = p - t * ppn;
+      u32x4 v = {0, 0, 0, 0};
+      if (t < nt) v = *reinterpret_cast<const u32x4*>(a.dy + (tb + t) * N + c * 8);
+      *reinterpret_cast<u32x4*>(sdy + t * pn + c * 16) = v;
+    }
+    for (int p = tid; p < TLM_TOK * ppk; p += 256) {
+      const int t = p / ppk, c = p - t * ppk;
+      u32x4 v = {0, 0, 0, 0};
+      if (t < nt) v = *reinterpret_cast<const u32x4*>(a.x + (tb + t) * K + c * 8);
+      *reinterpret_cast<u32x4*>(sx + t * pk + c * 16) = v;
+    }
+    __syncthreads();
+    if (ygroup == 0 && btl < TLM_TOK) {
+      for (int t = btl; t < TLM_TOK; t += bstep) {
+        const f16x8 d8 = *reinterpret_cast<const f16x8*>(sdy + t * pn + bp * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) accb[i] += (float)d8[i];
+      }
+    }
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      int nb_cur = -1;
+      f16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < TLM_BPW; ++j) {
+        if (j < nblk) {                                    // wave-uniform
+          const int bi = b_begin + j;
+          const int nb = bi / KB, kb = bi - nb * KB;
+          if (nb != nb_cur) {
+            af = tlw_frag(sdy, pn, 16 * ks, nb * 64, lane);
+            nb_cur = nb;
+          }
+          const f16x8 bf = tlw_frag(sx, pk, 16 * ks, kb * 64, lane);
+          acc[j] = mfma32(af, bf, acc[j]);
+        }
+      }
+    }
+  }
+  // ---- results: dW block (row n = 32 nb + crow(r, hh), column k = 32 kb + l31), bias -------------------------------------------
+  float* prow = a.part + (size_t)bx * ((size_t)N * K + N);
+  __syncthreads();                                         // the images are dead: their space carries the cross-wave sums
+  float* red = reinterpret_cast<float*>(smem);
+  if (split_steps) {
+#pragma unroll
+    for (int j = 0; j < TLM_BPW; ++j) {
+      if (j < nblk) {                                      // workgroup-uniform (split_steps: every wave has the same blocks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + l31] = acc[j][r];
+        __syncthreads();
+        const int bi = b_begin + j, nb = bi / KB, kb = bi - nb * KB;
+        for (int e = tid; e < 1024; e += 256) {
+          const int n = nb * 32 + (e >> 5), k = kb * 32 + (e & 31);
+          const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+          if (n < N && k < K) prow[(size_t)n * K + k] = v;
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TLM_BPW; ++j) {
+      if (j < nblk) {
+        const int bi = b_begin + j, nb = bi / KB, kb = bi - nb * KB;
+        const int k = kb * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (n < N && k < K) prow[(size_t)n * K + k] = acc[j][r];
+        }
+      }
+    }
+  }
+  if (ygroup == 0) {                                       // bias: fold the token lanes of every piece in lane order
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[tid * 8 + i] = accb[i];
+    __syncthreads();
+    for (int c = tid; c < N; c += 256) {
+      const int piece = c >> 3, i = c & 7;
+      float v = 0.f;
+      for (int tl = 0; tl * ppn + piece < 256; ++tl) v += red[(tl * ppn + piece) * 8 + i];
+      prow[(size_t)N * K + c] = v;
+    }
+  }
+}
+// block groups (blockIdx y) and dynamic LDS of the matrix-core body
+static int tlm_ygroups(int N, int K) { return (((N + 31) / 32) * ((K + 31) / 32) + 4 * nnz::TLM_BPW - 1) / (4 * nnz::TLM_BPW); }
+static int tlm_pitch_words_host(int cols) { return (((cols >> 5) & 1) ? (cols >> 1) : (cols >> 1) + 16); }
+static size_t tlm_lds_bytes(int N, int K) {
+  const size_t img = (size_t)nnz::TLM_TOK * 4 * (tlm_pitch_words_host((N + 31) / 32 * 32) + tlm_pitch_words_host((K + 31) / 32 * 32));
+  return img > 16384 ? img : 16384;                        // >= the [4][32][32] cross-wave buffer and the [256][8] bias buffer
+}
+
 struct TlWgJob {
   TlWgArgs a;
   int wg_begin;
-  int pad;
+  int ygroups;
 };
-__global__ __launch_bounds__(256) void tl_wgrad_group_kernel(const TlWgJob* __restrict__ jobs, const int* __restrict__ wg_job) {
+__global__ __launch_bounds__(256, 2) void tl_wgrad_group_kernel(const TlWgJob* __restrict__ jobs, const int* __restrict__ wg_job) {
   const int j = __builtin_amdgcn_readfirstlane(wg_job[blockIdx.x]);
   const TlWgJob* jp = jobs + j;
   const TlWgArgs a = jp->a;
-  tl_wgrad_body(a, blockIdx.x - (unsigned)jp->wg_begin);
+  const unsigned local = blockIdx.x - (unsigned)jp->wg_begin;
+  const unsigned yg = (unsigned)jp->ygroups;
+  tl_wgrad_mfma_body(a, local / yg, (int)(local % yg));
 }
 
 }  // namespace nnz
@@ -379,20 +540,20 @@ extern "C" int nnz_token_linear_wgrad_ws(const void* dy_f16, const void* x_f16, 
 // ---- grouped form (see tl_wgrad_group_kernel).  Host protocol as for nnz_dense32_group_*: plan every queued problem (workgroups,
 // dynamic LDS bytes, workspace floats = workgroups * (N K + N)), lay the jobs out back to back, fill one record per job into a
 // HOST table of nnz_token_linear_wgrad_group_record_bytes() bytes each, build the int32 map workgroup -> job, copy both to the
-// device, launch with the LARGEST LDS size of the group; then fold each job's partial blocks (rows of N K + N floats: dW then db)
-// with fold records (nnz_dense32_group_fill_fold) and nnz_group_fold_launch.
+// device, launch with the LARGEST LDS size of the group; then fold each job's partial blocks (rows of N K + N floats: dW then db;
+// their number is ws_floats / (N K + N) - the plan's workgroup count also carries the block groups of wide weights)
+// with fold records (nnz_dense32_group_fill_fold) and nnz_group_fold_launch.  N, K <= 256, multiples of 8.
 extern "C" int nnz_token_linear_wgrad_group_record_bytes(void) { return (int)sizeof(nnz::TlWgJob); }
 extern "C" int nnz_token_linear_wgrad_group_plan(long T, int N, int K, int* wgs, int* lds_bytes, long* ws_floats) {
   using namespace nnz;
   if (T < 1 || (N & 7) || (K & 7) || N < 8 || K < 8 || !wgs || !lds_bytes || !ws_floats) return NNZ_EINVAL;
-  const int nbk = (N >> 3) * (K >> 3);
-  if (nbk > 256) return NNZ_EINVAL;
-  const int TSL = 256 / nbk;
+  if (N > 256 || K > 256) return NNZ_EINVAL;
   const long tpw = tl_wgrad_tokens_per_wg(T);
-  const long w = (T + tpw - 1) / tpw;
-  const size_t lds = (size_t)TLW_TOK * (N + K) * 2 + (size_t)TSL * (N * K + N) * 4;
-  if (lds > 160 * 1024 || w > (1L << 30)) return NNZ_EINVAL;
-  *wgs = (int)w;
+  const long w = (T + tpw - 1) / tpw;                      // token ranges = partial blocks to fold
+  const size_t lds = tlm_lds_bytes(N, K);
+  const int yg = tlm_ygroups(N, K);
+  if (lds > 160 * 1024 || w * yg > (1L << 30)) return NNZ_EINVAL;
+  *wgs = (int)(w * yg);                                    // workgroups: token ranges x block groups
   *lds_bytes = (int)lds;
   *ws_floats = w * ((long)N * K + N);
   return NNZ_OK;
@@ -407,6 +568,7 @@ extern "C" int nnz_token_linear_wgrad_group_fill(void* job_host, const void* dy_
   j.a.tokens_per_wg = tl_wgrad_tokens_per_wg(T);
   j.a.part = workspace;
   j.wg_begin = wg_begin;
+  j.ygroups = tlm_ygroups(N, K);
   *reinterpret_cast<TlWgJob*>(job_host) = j;
   return NNZ_OK;
 }

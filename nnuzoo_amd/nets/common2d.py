@@ -110,6 +110,10 @@ class _DepthwiseNativeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, groups):
+        # a permuted token tensor (the U^2 stages hand channels-last views to the depthwise stem of the next stage) is packed HERE:
+        # ATen's kernel would pack it anyway, and the saved copy keeps the weight gradient on csrc/depthwise_wgrad.hip (round 5:
+        # the four decoder-side stems of SwT2Net fell to ATen's 580 us weight-gradient kernel for want of a contiguous input)
+        x = x.contiguous()
         with torch.backends.cudnn.flags(enabled=False):
             y = F.conv2d(x, w, b, stride, padding, dilation, groups)
         ctx.save_for_backward(x, w)
@@ -150,11 +154,12 @@ class _DepthwiseNativeFn(torch.autograd.Function):
         return dx, (dw if dw is not None else dw2), (db if db is not None else db2), None, None, None, None
 
 
-def _dw_wgrad_ok(x, dy, w, stride, padding, dilation) -> bool:
+def _dw_wgrad_ok(x, dy, w, stride, padding, dilation, will_pack: bool = False) -> bool:
+    """will_pack: asked at dispatch time, before _DepthwiseNativeFn.forward has made the input contiguous"""
     k3 = tuple(w.shape[1:]) == (1, 3, 3) and dilation[0] == dilation[1] and tuple(padding) == tuple(dilation)
     k1 = tuple(w.shape[1:]) == (1, 1, 1) and tuple(padding) == (0, 0) and tuple(dilation) == (1, 1)
     return (os.environ.get("NNZ_DW_WGRAD", "1") != "0" and x.dim() == 4 and (k3 or k1) and tuple(stride) == (1, 1)
-            and x.dtype == dy.dtype and x.dtype in (torch.float16, torch.float32) and x.is_contiguous()
+            and x.dtype == dy.dtype and x.dtype in (torch.float16, torch.float32) and (will_pack or x.is_contiguous())
             and dy.shape == x.shape and x.shape[1] <= 65535)
 
 
@@ -178,8 +183,8 @@ class _Conv2d(nn.Conv2d):
             # forward / input gradient: ATen's direct depthwise kernels (chosen over MIOpen's batched-GEMM path); weight
             # gradient: csrc/depthwise_wgrad.hip where _dw_wgrad_ok
             _backends.note(self, "aten")
-            _backends.note(self, "hip" if _dw_wgrad_ok(x, x, w, self.stride, self.padding, self.dilation) else "aten",
-                           site="wgrad")
+            _backends.note(self, "hip" if _dw_wgrad_ok(x, x, w, self.stride, self.padding, self.dilation, will_pack=True)
+                           else "aten", site="wgrad")
             return _DepthwiseNativeFn.apply(x, w, b, self.stride, self.padding, self.dilation, self.groups)
         if self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda:
             _backends.note(self, "library", why="depthwise with NNZ_DW_NATIVE=0 or non-zero padding mode")

@@ -87,7 +87,7 @@ class _HipTokenLinearFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
             wp, bp = ctx.params
-            if (N // 8) * (K // 8) <= 256 and GROUP_TL_WGRAD and _DEFER["on"] and need_w and wp.is_leaf \
+            if N <= 256 and K <= 256 and N % 8 == 0 and K % 8 == 0 and GROUP_TL_WGRAD and _DEFER["on"] and need_w and wp.is_leaf \
                     and (bp is None or bp.is_leaf) and not _has_grad_hooks(wp) and not (bp is not None and _has_grad_hooks(bp)):
                 # queued: ONE grouped launch + one fold launch at the end of the backward pass (csrc/token_linear.hip
                 # tl_wgrad_group_kernel) computes and assigns the gradients
@@ -304,7 +304,7 @@ class _TlKind:
     def plan(j, wgs, lds, wsf):
         N, K = j[2].shape
         call("nnz_token_linear_wgrad_group_plan", j[1].numel() // K, N, K, C.addressof(wgs), C.addressof(lds), C.addressof(wsf))
-        return N * K + N, wgs.value                      # floats of the folded result, partial blocks
+        return N * K + N, wsf.value // (N * K + N)       # floats of the folded result, partial blocks (one per token range)
 
     @staticmethod
     def fill(rec_ptr, j, part_ptr, wg0):
@@ -332,7 +332,7 @@ class _XpKind:
         _, B, C2, L = j[0].shape
         Di = j[1].shape[2]
         call("nnz_ss2d_xproj_backward_w_group_plan", B, Di, C2, L, C.addressof(wgs), C.addressof(lds), C.addressof(wsf))
-        return 2 * C2 * Di, wgs.value // 2
+        return 2 * C2 * Di, wsf.value // (2 * C2 * Di)     # partial matrices: one per token range
 
     @staticmethod
     def fill(rec_ptr, j, part_ptr, wg0):

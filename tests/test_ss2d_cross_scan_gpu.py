@@ -134,7 +134,10 @@ def test_layout_kernels(hip_lib):
 @pytest.mark.parametrize("B,Di,R,L", [(2, 32, 1, 4096), (1, 64, 2, 1000), (2, 128, 4, 640), (1, 256, 8, 192),
                                       # round 3: every output-group / channel-slice variant of the small-token launches
                                       (2, 32, 1, 2048), (2, 32, 1, 16384), (2, 512, 8, 256), (2, 256, 8, 1024),
-                                      (2, 96, 3, 64)])
+                                      (2, 96, 3, 64),
+                                      # round 5: the matrix-core forward / backward-x (even L) incl. a ragged last token pair
+                                      # group and a full-resolution row; odd L keeps the FMA kernels
+                                      (2, 32, 1, 65536), (1, 64, 2, 1002), (1, 32, 1, 777)])
 def test_xproj_kernels_vs_einsum(hip_lib, B, Di, R, L):
     """csrc/ss2d_xproj.hip against the einsums they replace (fp32): projection, its input gradient with the scans' own
     input gradients folded in, and the weight gradient (token contraction); ragged L for the lane-per-token kernels; both
@@ -203,3 +206,37 @@ def test_scan_backward_is_bit_reproducible_where_workgroups_share_a_group(hip_li
         for k, v in enumerate(saved):
             if k != 3:
                 call("nnz_scan_tuning", k, v)
+
+
+@pytest.mark.parametrize("d_model,B,H,W", [(16, 2, 64, 64), (32, 2, 32, 32), (64, 1, 16, 32), (128, 2, 16, 16), (256, 1, 8, 8)])
+def test_grouped_xproj_and_token_linear_weight_gradients_inside_a_block(hip_lib, d_model, B, H, W):
+    """round 5: inside deferred_wgrads() the SS2D block queues the weight gradients of its x_proj (fp32 matrix cores, csrc/ss2d_xproj.hip
+    xproj_bwd_w_group_kernel) and of its fp16 token Linears (csrc/token_linear.hip tl_wgrad_group_kernel) for one grouped launch each:
+    same gradients as the per-layer launches up to the summation order, bit-identical from pass to pass; 32 ... 512 inner channels
+    cover one and several 32 x 32 blocks per wave, the split-step regime and several block groups per token range"""
+    from nnuzoo_amd.nets.m2net import SS2D
+    from nnuzoo_amd.token_linear import deferred_wgrads
+    torch.manual_seed(d_model + H)
+    blk = SS2D(d_model=d_model).cuda()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, d_model, generator=g).cuda()
+    dy = torch.randn(B, H, W, d_model, generator=g).cuda()
+
+    def run(deferred):
+        blk.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = blk(x)
+        if deferred:
+            with deferred_wgrads():
+                y.float().backward(dy)
+        else:
+            y.float().backward(dy)
+        return {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None}
+
+    ref = run(False)
+    a, b = run(True), run(True)
+    assert set(a) == set(ref)
+    for n in ref:
+        _close(a[n], ref[n], 2e-3, n)
+    for n in ("x_proj_weight", "in_proj.weight", "out_proj.weight"):
+        assert torch.equal(a[n], b[n]), n

@@ -101,7 +101,7 @@ def test_grouped_token_linear_weight_gradients(hip_lib):
     from nnuzoo_amd import token_linear as TLm
     from nnuzoo_amd.token_linear import TokenLinear, deferred_wgrads
     torch.manual_seed(5)
-    shapes = [(4096, 32, 64), (70000, 16, 32), (1024, 128, 128), (2048, 64, 16), (1500, 96, 64)]   # T, K, N
+    shapes = [(4096, 32, 64), (70000, 16, 32), (1024, 128, 128), (2048, 64, 16), (1500, 128, 64)]   # T, K, N
     lins = [TokenLinear(K, N, bias=(i % 2 == 0)).to(DEV) for i, (T, K, N) in enumerate(shapes)]
     xs = [torch.randn(T, K, device=DEV) for T, K, N in shapes]
 

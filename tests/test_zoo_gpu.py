@@ -159,11 +159,12 @@ def test_whole_net_backward_golden(hip_lib, force_scan_gen2, name):
     with_grad = [n for n, p in net.named_parameters() if p.grad is not None]
     assert with_grad == names                                   # the same parameters are reached by the backward
     worst = (0.0, "")
-    # gradients 7-11 orders below the net's largest are cancellation noise (tests/test_oracle_m2net.py uses 1e-8 of the largest
-    # norm for the CPU oracle; on the HIP path the one M2Net parameter between 1e-8 and 1e-7 - stage1d...layers.5.blocks.0.ln_1.bias,
-    # 1.7e-8 of the largest norm - moves by 5e-2 of its own size from run to run while the other 1 525 stay below 7e-3:
+    # gradients 6-11 orders below the net's largest are cancellation noise: ~10 fp32 ulps of the largest norm is the resolution of
+    # a sum that the large terms pass through (tests/test_oracle_m2net.py uses 1e-8 of the largest norm for the CPU oracle, whose
+    # sums run in one fixed order; on the HIP path the one M2Net parameter below 1e-7 - stage1d...layers.5.blocks.0.ln_1.bias,
+    # 1.7e-8 of the largest norm - moves by 1e-2 ... 5e-2 of its own size from run to run while the other 1 525 stay below 7e-3:
     # profiles/r05_m2net_grad_probe.txt)
-    floor = 1e-7 * max(float(z[f"n{k}"]) for k, (n, p) in enumerate(net.named_parameters()) if p.grad is not None)
+    floor = 1e-6 * max(float(z[f"n{k}"]) for k, (n, p) in enumerate(net.named_parameters()) if p.grad is not None)
     for k, (n, p) in enumerate(net.named_parameters()):
         if p.grad is None:
             continue
