@@ -549,12 +549,15 @@ static int d32_launch(const D32Args& a, int splits, hipStream_t s) {
 }
 
 // split-K of the forward / input gradient: only products whose 64 x 64 tiling leaves most of the chip idle (< 192 workgroups)
-// and whose contraction is long enough to cut (>= 256); enough splits for ~384 workgroups, each at least 128 steps, at most 16.
-// per = steps per split (a multiple of the 64-step LDS block).  Returns the number of splits (1 = none).
+// and whose contraction is long enough for the cut to pay for its fold launch (>= 768: a 64-step block costs a workgroup ~1.4 us,
+// the fold ~5 us - profiles/r05_swin_ops_before.txt; with the first threshold of 256 the 384 ... 512-step products of the
+// 16^2 / 32^2 levels were split for no gain and the SwT2Net step carried 613 fold launches); enough splits for ~384 workgroups,
+// each at least 128 steps, at most 16.  per = steps per split (a multiple of the 64-step LDS block).  Returns the splits (1 = none).
 static int d32_ksplits(long T, int K, int N, int* per_out) {
   const long tiles = ((T + 63) / 64) * ((N + 63) / 64);
   int splits = 1;
-  if (tiles < 192 && K >= 256) {
+  static const int kmin = [] { const char* e = getenv("NNZ_D32_SPLITK_MIN"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+  if (tiles < 192 && K >= kmin) {
     splits = (int)((384 + tiles - 1) / tiles);
     if (splits > K / 128) splits = K / 128;
     if (splits > 16) splits = 16;

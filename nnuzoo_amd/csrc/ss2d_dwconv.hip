@@ -37,6 +37,33 @@ template <int HALO>
 __device__ __forceinline__ void dw_stage_x(const DwArgs& a, float* X, int b, int h0, int w0, int d0) {
   constexpr int E = DT + 2 * HALO;
   constexpr int PITCH = E * DC + DPAD;
+  // whole 16-channel groups of 16-byte aligned rows: one 16-byte load per 8 (fp16) / 4 (fp32) channels of a token instead of one
+  // load per element (round 5: the element-wise form issued 25 load + index sequences per thread in front of the halo-2 tile)
+  const int cpp = a.x_is_f16 ? 8 : 4;                     // channels per 16-byte piece
+  const bool vec = d0 + DC <= a.D && (a.x_stride % cpp) == 0 && (((size_t)a.x) & 15) == 0 && (d0 % cpp) == 0;
+  if (vec) {
+    const int ppt = DC / cpp;                               // pieces per token
+    for (int i = threadIdx.x; i < E * E * ppt; i += 256) {
+      const int pc = i % ppt, tx = (i / ppt) % E, ty = i / (ppt * E);
+      const int h = h0 - HALO + ty, w = w0 - HALO + tx;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) {
+        const long off = ((long)(b * a.H + h) * a.W + w) * a.x_stride + d0 + pc * cpp;
+        if (a.x_is_f16) {
+          const f16x8 t = *reinterpret_cast<const f16x8*>((const f16*)a.x + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+        } else {
+          const f32x4 t = *reinterpret_cast<const f32x4*>((const float*)a.x + off);
+          v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        }
+      }
+      float* dst = X + ty * PITCH + tx * DC + pc * cpp;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      if (a.x_is_f16) *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < E * E * DC; i += 256) {
     const int d = i % DC, tx = (i / DC) % E, ty = i / (DC * E);
     const int h = h0 - HALO + ty, w = w0 - HALO + tx;
@@ -49,7 +76,7 @@ __device__ __forceinline__ void dw_stage_x(const DwArgs& a, float* X, int b, int
 
 __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(DwArgs a) {
   constexpr int E = DT + 2, PITCH = E * DC + DPAD;
-  __shared__ float X[E * PITCH];
+  __shared__ __attribute__((aligned(16))) float X[E * PITCH];
   __shared__ float T[DC * (DT * (DT + 1) + 1)];
   constexpr int TP = DT * (DT + 1) + 1;
   const int tiles_w = (a.W + DT - 1) / DT;
@@ -91,7 +118,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(DwArgs a) {
 __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(DwArgs a) {
   constexpr int E2 = DT + 4, P2 = E2 * DC + DPAD;  // input with halo 2
   constexpr int E1 = DT + 2, P1 = E1 * DC + DPAD;  // pre-activation gradient with halo 1
-  __shared__ float X[E2 * P2];
+  __shared__ __attribute__((aligned(16))) float X[E2 * P2];
   __shared__ float G[E1 * P1];
   __shared__ float red[16][DC][10];
   const int tiles_w = (a.W + DT - 1) / DT;
@@ -121,16 +148,30 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(DwArgs a) {
   for (int t = 0; t < 9; ++t) wv[t] = d0 + d < a.D ? a.w[(long)(d0 + d) * 9 + t] : 0.f;
   if (a.bias && d0 + d < a.D) bv = a.bias[d0 + d];
   __syncthreads();
-  // G <- d(pre-activation) = d(act) * silu'(pre), pre recomputed from the input image; thread (d, row) walks its row(s)
+  // G <- d(pre-activation) = d(act) * silu'(pre), pre recomputed from the input image; thread (d, row) walks its row(s) with
+  // a 3 x 3 window of the image in registers: three LDS reads per position instead of nine (round 5)
   for (int ty = th; ty < E1; ty += 16) {
+    float c0[3], c1[3], c2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      c0[i] = X[(ty + i) * P2 + 0 * DC + d];
+      c1[i] = X[(ty + i) * P2 + 1 * DC + d];
+    }
+#pragma unroll
     for (int tx = 0; tx < E1; ++tx) {
       float pre = bv;
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) pre += wv[i * 3 + j] * X[(ty + i) * P2 + (tx + j) * DC + d];
+      for (int i = 0; i < 3; ++i) {
+        c2[i] = X[(ty + i) * P2 + (tx + 2) * DC + d];
+        pre += wv[i * 3 + 0] * c0[i] + wv[i * 3 + 1] * c1[i] + wv[i * 3 + 2] * c2[i];
+      }
       const float sg = 1.f / (1.f + __expf(-pre));
       G[ty * P1 + tx * DC + d] *= sg * (1.f + pre * (1.f - sg));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        c0[i] = c1[i];
+        c1[i] = c2[i];
+      }
     }
   }
   __syncthreads();
@@ -139,24 +180,49 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(DwArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) pw[t] = 0.f;
   const int h = h0 + th;
-  for (int tw = 0; tw < DT; ++tw) {
-    const int w = w0 + tw;
-    float acc = 0.f;
+  {
+    // windows in registers, sliding along the row: G rows th .. th + 2, columns tw .. tw + 2 (the data gradient reads them
+    // mirrored); X rows th + 1 .. th + 3, columns tw + 1 .. tw + 3 (the taps of the tile's own output at (th, tw))
+    float g0[3], g1[3], g2[3], x0[3], x1[3], x2[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc += wv[i * 3 + j] * G[(th + 2 - i) * P1 + (tw + 2 - j) * DC + d];  // dpre[h-i+1][w-j+1]
-    if (h < a.H && w < a.W && d0 + d < a.D) {
-      const long o = ((long)(b * a.H + h) * a.W + w) * a.D + d0 + d;
-      if (a.x_is_f16) ((f16*)a.dx)[o] = (f16)acc;
-      else ((float*)a.dx)[o] = acc;
+    for (int i = 0; i < 3; ++i) {
+      g0[i] = G[(th + i) * P1 + 0 * DC + d];
+      g1[i] = G[(th + i) * P1 + 1 * DC + d];
+      x0[i] = X[(th + 1 + i) * P2 + 1 * DC + d];
+      x1[i] = X[(th + 1 + i) * P2 + 2 * DC + d];
     }
-    const float g = G[(th + 1) * P1 + (tw + 1) * DC + d];  // dpre of this thread's own output (0 outside the image)
-    pb += g;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int tw = 0; tw < DT; ++tw) {
+      const int w = w0 + tw;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) pw[i * 3 + j] += g * X[(th + 1 + i) * P2 + (tw + 1 + j) * DC + d];
+      for (int i = 0; i < 3; ++i) {
+        g2[i] = G[(th + i) * P1 + (tw + 2) * DC + d];
+        x2[i] = X[(th + 1 + i) * P2 + (tw + 3) * DC + d];
+      }
+      // dx[h][w] = sum_{i, j} w[i][j] dpre[h - i + 1][w - j + 1]: G row th + 2 - i, column tw + 2 - j
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        acc += wv[i * 3 + 0] * g2[2 - i] + wv[i * 3 + 1] * g1[2 - i] + wv[i * 3 + 2] * g0[2 - i];
+      if (h < a.H && w < a.W && d0 + d < a.D) {
+        const long o = ((long)(b * a.H + h) * a.W + w) * a.D + d0 + d;
+        if (a.x_is_f16) ((f16*)a.dx)[o] = (f16)acc;
+        else ((float*)a.dx)[o] = acc;
+      }
+      const float g = g1[1];  // dpre of this thread's own output (0 outside the image)
+      pb += g;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        pw[i * 3 + 0] += g * x0[i];
+        pw[i * 3 + 1] += g * x1[i];
+        pw[i * 3 + 2] += g * x2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        g0[i] = g1[i]; g1[i] = g2[i];
+        x0[i] = x1[i]; x1[i] = x2[i];
+      }
+    }
   }
 #pragma unroll
   for (int t = 0; t < 9; ++t) red[th][d][t] = pw[t];
