@@ -257,9 +257,15 @@ def run_secondary(steps: int, warmup: int):
     if "ss2d_scan_bwd" in summ:
         n, by, sec = summ["ss2d_scan_bwd"]
         ach = by / sec / 1e9
+        tjs = _profile_json("ss2d_scan_bwd_hbm_traffic.json")
         roof = {"bound": "hbm", "kernel": "ss2d cross-scan backward (summary + carry + final + finalize kernels per call: xs_rl_bwd_* for >= 2 M row-steps, scan_bwd_kernel below)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "launches_per_step": n // roof_steps, "avg_launch_us": round(sec / n * 1e6, 2),
+                "traffic": tjs.get("hbm_bytes_per_launch") if tjs else None,
+                "traffic_source": ("profiles/ss2d_scan_bwd_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                   "over one eager M2Net step, all kernels of the cross-scan backward per call, "
+                                   "tools/pmc_traffic.py; measured in round 5)") if tjs else None,
+                "algorithmic_bytes_per_launch": round(by / n),
+                "launches_per_step": n // roof_steps, "avg_launch_us": round(sec / n * 1e6, 2),
                 "bytes_per_launch": by / n, "ms_per_step": round(sec / roof_steps * 1e3, 3),
                 "timed_over": f"{roof_steps} eager steps after the timed region (same kernels; a replayed graph issues no "
                               f"per-launch events)"}
@@ -403,6 +409,11 @@ def run_swt2net(steps: int, warmup: int):
                 "bwd_avg_launch_us": round(sb / nb * 1e6, 2), "ms_per_step": round((sf + sb) / roof_steps * 1e3, 3),
                 "fwd_achieved": round(ff / sf / 1e12, 2), "bwd_achieved": round(fb / sb / 1e12, 2),
                 "timed_over": f"{roof_steps} eager steps after the timed region"}
+        tj = _profile_json("win_attn_hbm_traffic.json")
+        if tj:      # HBM bytes per window-attention launch (forward and backward launches together) from the PMC passes of record
+            roof["traffic"] = tj.get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/win_attn_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
+                                     "passes over one eager SwT2Net step, tools/pmc_traffic.py; measured in round 5)"
     from nnuzoo_amd import backends as _bk
     backends = _bk.report(tr.network)      # which kernel family every dispatching module took (nnuzoo_amd/backends.py)
     out = {"metric": "training patches/sec, SwT2Net 1x512^2 patches", "value": round(batch * steps / dt, 3),

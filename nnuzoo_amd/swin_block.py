@@ -91,8 +91,11 @@ class _SwinBlockFn(torch.autograd.Function):
         mean1, rstd1 = torch.empty(Tp, **f32), torch.empty(Tp, **f32)
         _fwd(x, qkvw, qkvb, qkv, None, Tp, C, 3 * C, ln=(n1w, n1b, eps1, mean1, rstd1, n1), pad=(H, W, py, px) if padded else None)
         ao = torch.empty((T, C), **f32)
-        call("nnz_window_attention_forward_pad", ptr(qkv), ptr(table), ptr(idx32), ptr(ao), B, Hp, Wp, C, heads, shift, float(scale),
-             py, px, stream_ptr())
+        from .hip_ops import TIMER
+        # algorithmic FLOPs of the attention core: 4 L^2 hd per (window, head), L = 49 - bench.py's roofline record
+        TIMER.wrap("win_attn_fwd", 4.0 * 49 * 49 * C * B * (Hp // 7) * (Wp // 7), lambda: call(
+            "nnz_window_attention_forward_pad", ptr(qkv), ptr(table), ptr(idx32), ptr(ao), B, Hp, Wp, C, heads, shift, float(scale),
+            py, px, stream_ptr()))
         x1 = torch.empty((T, C), **f32)
         _fwd(ao, projw, projb, x1, None, T, C, C, res=x, dp=dp1)
         Hd = fc1w.shape[0]
@@ -175,12 +178,15 @@ class _SwinBlockFn(torch.autograd.Function):
         dqkv = torch.empty((Tp, 3 * C), **f32)
         dtable = None
         tparam = ctx.table_param
+        from .hip_ops import TIMER
+        aflops = 8.0 * 49 * 49 * C * B * (Hp // 7) * (Wp // 7)    # dQ, dK, dV, dP (the recomputed q k^T is not counted)
         if ni[5] and deferred and _deferrable((tparam,)):
             # the bias-table gradient leaves the launch as per-workgroup shares; the pass's grouped launch folds them
             tparts = int(lib.nnz_window_attention_backward_parts(B, Hp, Wp, heads))
             tpart = torch.empty((tparts, 169 * heads), **f32)
-            call("nnz_window_attention_backward_partial", ptr(qkv), ptr(table), ptr(idx32), ptr(dao), ptr(dqkv), ptr(tpart), B, Hp,
-                 Wp, C, heads, shift, float(scale), py, px, stream_ptr())
+            TIMER.wrap("win_attn_bwd", aflops, lambda: call(
+                "nnz_window_attention_backward_partial", ptr(qkv), ptr(table), ptr(idx32), ptr(dao), ptr(dqkv), ptr(tpart), B, Hp,
+                Wp, C, heads, shift, float(scale), py, px, stream_ptr()))
 
             def assign_table(dst):
                 g = dst.view(169, heads)
@@ -192,8 +198,9 @@ class _SwinBlockFn(torch.autograd.Function):
         else:
             dtable = torch.empty_like(table)
             sc = det_scratch(dev, 170 * heads)
-            call("nnz_window_attention_backward_pad", ptr(qkv), ptr(table), ptr(idx32), ptr(dao), ptr(dqkv), ptr(dtable),
-                 ptr(sc.acc), ptr(sc.counter), B, Hp, Wp, C, heads, shift, float(scale), py, px, stream_ptr())
+            TIMER.wrap("win_attn_bwd", aflops, lambda: call(
+                "nnz_window_attention_backward_pad", ptr(qkv), ptr(table), ptr(idx32), ptr(dao), ptr(dqkv), ptr(dtable),
+                ptr(sc.acc), ptr(sc.counter), B, Hp, Wp, C, heads, shift, float(scale), py, px, stream_ptr()))
         dn1 = torch.empty((Tp, C), **f32)
         _dgrad(dqkv, qkvw, None, dn1, Tp, C, 3 * C)
         wgrad(dqkv, n1, qkvw, qkvb, None, 3, 4)

@@ -27,6 +27,7 @@ MIN_TOKENS = 65536
 HIP_MIN_TOKENS = int(os.environ.get("NNZ_TL_MIN_TOKENS", "1024"))   # below this the call is launch-bound either way (A/B: env)
 USE_HIP_KERNELS = os.environ.get("NNZ_TOKEN_LINEAR", "1") != "0"   # A/B switch for measurements
 MAX_FEATURES = 256
+SMALL_F32 = os.environ.get("NNZ_TL_SMALL_F32", "1") != "0"   # autocast calls outside the fp16 kernel's range: fp32 MFMA kernels, not the library
 
 
 def _chunks(T: int) -> int:
@@ -634,6 +635,18 @@ class TokenLinear(nn.Linear):
             why = "features"         # feature counts outside the f16 token kernel's set
         else:
             why = "other"            # CPU tensor, dtype / layout outside both kernel families, switched off by environment
+        # round 5: what the fp16 token kernel does not take under autocast - fewer than HIP_MIN_TOKENS tokens, feature counts
+        # outside its set (the 8^2 ... 32^2 levels of the Mamba nets: 97 of M2Net's 272 Linear layers) - runs on the fp32 matrix-core
+        # kernels (csrc/dense32.hip: fp32 operands from the fp32 master weights, split-K for the skinny shapes) instead of the GEMM
+        # library: at least the precision of the reference's fp16-autocast GEMM, output rounded to fp16 like autocast's, no weight
+        # cast launch, and its weight gradient joins the pass's grouped launch.  NNZ_TL_SMALL_F32=0 keeps the library path.
+        if SMALL_F32 and why in ("small", "features") and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.float16 \
+                and self.weight.dtype == torch.float32 and self.in_features % 4 == 0 and self.out_features % 4 == 0 \
+                and x.dtype in (torch.float16, torch.float32):
+            _backends.note(self, "hip-f32", why=why)
+            with torch.autocast("cuda", enabled=False):
+                y = _Dense32LinearFn.apply(x.float(), self.weight, self.bias)
+            return y.to(torch.float16)
         self.backend_why = why
         _backends.note(self, "library", why=why)
         if x.is_cuda and x.is_contiguous() and x.dtype in (torch.float16, torch.float32) \
