@@ -34,6 +34,7 @@ from .hip_ops import det_scratch
 
 USE_FUSED_BLOCK = os.environ.get("NNZ_SWIN_FUSED", "1") != "0"
 _WS = {}
+_WS_OUTGROWN = []      # a captured hipGraph keeps the ADDRESS of the buffer it was recorded with: outgrown buffers stay alive
 
 
 def _workspace(device, floats: int):
@@ -45,6 +46,8 @@ def _workspace(device, floats: int):
     if ws is None or ws.numel() < floats:
         if torch.cuda.is_current_stream_capturing() and ws is not None:
             raise RuntimeError("swin_block: the split-K workspace cannot grow during a capture - run an eager pass first")
+        if ws is not None:
+            _WS_OUTGROWN.append(ws)
         ws = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws

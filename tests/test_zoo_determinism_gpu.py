@@ -4,7 +4,9 @@ weight gradients of the fp16 token Linears and of x_proj leave their kernels as 
 grouped launches (csrc/token_linear.hip, ss2d_xproj.hip), the depthwise conv + SiLU backward takes its two-stage form
 (NNZ_TWO_STAGE_WGRADS=1, the one remaining opt-in: +0.3 % of a step), LayerNorm and the optimizer tail were fixed-point already.
 Two trainers built from the same seed and fed the same batches must therefore hold the SAME parameters, bit for bit, after
-several steps - eager and replayed as a hipGraph."""
+several steps - eager and replayed as a hipGraph.  What is NOT ours stays outside the claim: the library convolutions (the 1 x 1 side
+heads and the fuse convolution; MIOpen picks its solver per process, profiles/r04_zoo_module_determinism.txt) are replaced by ATen's
+kernels for the test, which is what `NNZ_LIBRARY_DETERMINISTIC=2` selects in the trainers."""
 import pytest
 import torch
 
@@ -35,8 +37,9 @@ def _run(graph: bool, steps: int = 4):
 def test_m2netp_training_steps_are_bit_reproducible(hip_lib, graph, monkeypatch):
     from nnuzoo_amd import token_linear
     monkeypatch.setattr(token_linear, "TWO_STAGE", True)        # depthwise conv + SiLU weight gradient: partial rows + fold
-    la, pa = _run(graph)
-    lb, pb = _run(graph)
+    with torch.backends.cudnn.flags(enabled=False):
+        la, pa = _run(graph)
+        lb, pb = _run(graph)
     assert la == lb, (la, lb)
     diff = [n for n in pa if not torch.equal(pa[n], pb[n])]
     assert not diff, (len(diff), diff[:8])

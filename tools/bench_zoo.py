@@ -37,14 +37,25 @@ def main():
         for _ in range(a.warmup):
             losses.append(float(tr.train_step(b)["loss"]))
         torch.cuda.synchronize()
+        # GradScaler bookkeeping of the timed window: a step whose fp16 backward overflowed is SKIPPED and halves the loss
+        # scale (growth: one doubling per 2 000 applied steps - none inside a bench window), so log2(scale before / after) counts
+        # the skipped steps; the seeded SSND2Net[P] nets back off for 10-25 steps before their first applied one
+        sc = getattr(tr, "grad_scaler", None)
+        scale0 = float(sc.get_scale()) if sc is not None else None
         t0 = time.perf_counter()
         for _ in range(a.steps):
             losses.append(float(tr.train_step(b)["loss"]))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
+        scale1 = float(sc.get_scale()) if sc is not None else None
+        skipped = None
+        if scale0 and scale1:
+            import math
+            skipped = max(0, int(round(math.log2(scale0 / scale1))))
         print(json.dumps({"model": name, "patch": a.size, "batch": a.batch, "ms_per_step": round(dt * 1e3, 2),
                           "patches_per_s": round(a.batch / dt, 3), "losses": [round(x, 4) for x in losses],
-                          "hip_graph": bool(a.graph), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+                          "hip_graph": bool(a.graph), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                          "loss_scale": [scale0, scale1], "skipped_steps_in_timed_window": skipped}), flush=True)
         del tr
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
