@@ -60,6 +60,9 @@ python3 tools/bench_zoo.py --models M2NetP,M2Net,SwT2Net,MambaND2Net,UNETR2Net,L
 # (the seeded SSND2Net / SSND2NetP skip their first 10-25 steps while the loss scale backs off: 30 warm-up steps, and every row
 #  reports the skipped steps of its timed window)
 python3 tools/bench_zoo.py --models SSND2Net,SSND2NetP --steps 6 --warmup 30 2>&1 | grep '"model"' >> $OUT/${TAG}_zoo_bench.txt
+# 6b. where the small ATen launches of the two zoo steps come from (dispatch tap with Python call sites; eager step)
+python3 tools/probes/m2net_small_op_sources.py M2Net 2>/dev/null | head -60 > $OUT/${TAG}_m2net_small_op_sources.txt
+python3 tools/probes/m2net_small_op_sources.py SwT2Net 2>/dev/null | head -60 > $OUT/${TAG}_swt2net_small_op_sources.txt
 # 7. Dice protocol of the SS2D^2Net path against the CPU oracle (fixture written in the build container)
 python3 tools/dice_parity_zoo.py --oracle-json tests/golden/dice_oracle_m2netp_64.json --out $OUT/${TAG}_dice_m2netp_64_vs_oracle.json > /dev/null 2>&1
 # 8. the bench line of record (defaults: all three legs, cpu_baseline); the traffic files of 2 / 2b are read from profiles/
