@@ -56,9 +56,10 @@ def host_threads():
 
 def cpu_baseline(edge: int = 64, timed_steps: int = 2, budget_s: float = None):
     """Full training steps of the CPU oracle (reference-equivalent torch-CPU path: fp32, no autocast) on ONE
-    patch.  First at edge^3 (one untimed warm-up step, `timed_steps` timed ones) - seconds; then, when a warm-up plus one timed
-    step at the metric's own 128^3 (8 x the voxels) fits `budget_s` (NNZ_CPU_BASELINE_BUDGET_S, default 120), exactly that: the
-    value is then MEASURED at 128^3, not scaled.  Otherwise the small size scaled by voxel count, as before."""
+    patch.  First at edge^3 (one untimed warm-up step, `timed_steps` timed ones) - seconds; then at the metric's own 128^3 unless
+    even the worst case (8 x the small step) would exceed twice `budget_s` (NNZ_CPU_BASELINE_BUDGET_S, default 120): one step,
+    and a second, timed one if it still fits the budget.  The value is then MEASURED at 128^3, not scaled.
+    Otherwise the small size scaled by voxel count, as before."""
     from oracle.plain_conv_unet import OraclePlainConvUNet, planner_arch_kwargs
     from oracle.losses import deep_supervision_loss
     from nnuzoo_amd.synthetic import synthetic_batch
@@ -96,16 +97,40 @@ def cpu_baseline(edge: int = 64, timed_steps: int = 2, budget_s: float = None):
     warm, dt = run(edge, timed_steps)
     tail = f"torch {torch.__version__} CPU, {threads} threads ({logical} logical CPUs visible)"
     small = (f"one {edge}^3 patch: 1 warm-up step ({warm:.1f} s) + {timed_steps} timed steps ({dt:.2f} s each)")
-    if edge < 128 and 2.2 * dt * (128.0 / edge) ** 3 <= budget_s:
-        warm128, dt128 = run(128, 1)
+    # The 128^3 step does not cost 8 x the 64^3 one on a many-core host (13.8 s against 6.3 s on 128 threads: the small step is
+    # dominated by per-operator overheads), so the guard is the WORST case - voxel scaling - against twice the budget, and the
+    # 128^3 warm-up step is itself a measurement: if no second step fits the budget after it, it is the value.
+    if edge < 128 and dt * (128.0 / edge) ** 3 <= 2 * budget_s:
+        t_begin = time.perf_counter()
+        b = synthetic_batch(1, (128, 128, 128), scales, seed=7)
+
+        def step128():
+            opt.zero_grad(set_to_none=True)
+            l = deep_supervision_loss(net(b['data']), b['target'], batch_dice=False)
+            l.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+            opt.step()
+            return float(l)
+
+        t0 = time.perf_counter()
+        step128()
+        warm128 = time.perf_counter() - t0
+        if (time.perf_counter() - t_begin) + 1.1 * warm128 <= budget_s:
+            t0 = time.perf_counter()
+            step128()
+            dt128 = time.perf_counter() - t0
+            how = f"1 warm-up step ({warm128:.1f} s) + 1 timed step ({dt128:.2f} s)"
+        else:
+            dt128 = warm128
+            how = f"one step ({warm128:.1f} s, the first at this size: a second one did not fit the {budget_s:.0f} s budget)"
         return {"value": 1.0 / dt128, "unit": "patches/s", "cores": threads, "kind": "port",
                 "sample": f"CPU oracle, full fp32 train step (fwd+loss+bwd+clip+SGD) on one 128^3 patch - the metric's own size, "
-                          f"measured, not scaled: 1 warm-up step ({warm128:.1f} s) + 1 timed step ({dt128:.2f} s); before it "
+                          f"measured, not scaled: {how}; before it "
                           f"{small}, which scaled by voxels would have given {(1.0 / dt) * (edge / 128.0) ** 3:.4f} patches/s; "
                           + tail}
     return {"value": (1.0 / dt) * (edge / 128.0) ** 3, "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"CPU oracle, full fp32 train step (fwd+loss+bwd+clip+SGD) on {small}, scaled to 128^3 by voxel count (a "
-                      f"measured 128^3 step did not fit the {budget_s:.0f} s budget); " + tail}
+            "sample": f"CPU oracle, full fp32 train step (fwd+loss+bwd+clip+SGD) on {small}, scaled to 128^3 by voxel count (even one "
+                      f"128^3 step would not fit twice the {budget_s:.0f} s budget on this host); " + tail}
 
 
 def cpu_scan_baseline(L: int = 8192):
