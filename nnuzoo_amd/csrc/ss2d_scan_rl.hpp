@@ -453,6 +453,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 constexpr int RL_CP = 33;            // pitch of the column-sum tile (32 columns + 1: conflict-free row and column access)
 constexpr int RL_BP = RL_T + 4;      // pitch of the backward's 16-step row tiles
 
+constexpr int RL_SP = 36;            // pitch of the column-sum tile (rows of 32 columns, 16-byte aligned; banks 4 r + c)
+
+// v_permlane{32,16}_swap_b32 (gfx950): the upper half (odd rows of 16 lanes) of x trades places with the lower half (even rows)
+// of y.  After it x + y is, in the lower lanes, x summed over the lane pair, and in the upper lanes y summed over the pair: one
+// butterfly stage of a lane reduction for TWO values.  (Inline asm: __builtin_amdgcn_permlane32_swap of this compiler returns
+// its first result twice - checked in the ISA - and the hazard recogniser does not look inside asm, hence the s_nop.)
+#define RL_SWAP8(OP, X, Y, O)                                                                                                 \
+  asm volatile("s_nop 1\n\t" OP " %0, %8\n\t" OP " %1, %9\n\t" OP " %2, %10\n\t" OP " %3, %11\n\t" OP " %4, %12\n\t" OP       \
+               " %5, %13\n\t" OP " %6, %14\n\t" OP " %7, %15\n\ts_nop 1"                                                     \
+               : "+v"(X[O]), "+v"(X[O + 1]), "+v"(X[O + 2]), "+v"(X[O + 3]), "+v"(X[O + 4]), "+v"(X[O + 5]), "+v"(X[O + 6]),  \
+                 "+v"(X[O + 7]), "+v"(Y[O]), "+v"(Y[O + 1]), "+v"(Y[O + 2]), "+v"(Y[O + 3]), "+v"(Y[O + 4]), "+v"(Y[O + 5]),  \
+                 "+v"(Y[O + 6]), "+v"(Y[O + 7]))
+
+// Sum over the lanes of a slot of 32 per-lane values: x[t] = column t, y[t] = column 16 + t.  The first one or two butterfly
+// stages run in registers (lane ^ 32, lane ^ 16), so the LDS tile holds 16 rows per slot instead of 32 or 64 - the column-sum
+// tile was half of this kernel's LDS traffic, and LDS, shared by the CU's waves, was its busiest unit.  Returns the sum of
+// column lane & 31: over all 64 lanes (one slot; every lane gets it) or over the lane's own 32 (two slots).  Ends with the
+// tile free (wave-level sync).
+__device__ __forceinline__ float rl_sum_columns(float (&x)[16], float (&y)[16], float* sT, int lane, bool one_slot) {
+  const int c = lane & 31, h = lane >> 5;
+  float s;
+  if (one_slot) {
+    RL_SWAP8("v_permlane32_swap_b32", x, y, 0);
+    RL_SWAP8("v_permlane32_swap_b32", x, y, 8);
+    float r[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) r[t] = x[t] + y[t];       // lanes < 32: column t, lanes >= 32: column 16 + t, over (l, l ^ 32)
+    float lo[8], hi[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      lo[t] = r[t];
+      hi[t] = r[t + 8];
+    }
+    RL_SWAP8("v_permlane16_swap_b32", lo, hi, 0);
+    float* row = sT + (lane & 15) * RL_SP + (lane >> 4) * 8;   // even rows of lanes: columns t, odd rows: t + 8, over four lanes
+    *reinterpret_cast<f32x4*>(row) = f32x4{lo[0] + hi[0], lo[1] + hi[1], lo[2] + hi[2], lo[3] + hi[3]};
+    *reinterpret_cast<f32x4*>(row + 4) = f32x4{lo[4] + hi[4], lo[5] + hi[5], lo[6] + hi[6], lo[7] + hi[7]};
+    rl_sync();
+    const float* p = sT + h * 8 * RL_SP + c;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s4[i & 3] += p[i * RL_SP];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    float o = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "+v"(o));
+    s += o;
+  } else {
+    RL_SWAP8("v_permlane16_swap_b32", x, y, 0);
+    RL_SWAP8("v_permlane16_swap_b32", x, y, 8);
+    float* row = sT + (h * 16 + (lane & 15)) * RL_SP + ((lane >> 4) & 1) * 16;   // even rows: columns t, odd rows: 16 + t
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(row + 4 * j) =
+          f32x4{x[4 * j] + y[4 * j], x[4 * j + 1] + y[4 * j + 1], x[4 * j + 2] + y[4 * j + 2], x[4 * j + 3] + y[4 * j + 3]};
+    rl_sync();
+    const float* p = sT + h * 16 * RL_SP + c;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s4[i & 3] += p[i * RL_SP];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
+  rl_sync();
+  return s;
+}
+
 template <bool XS>
 __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, const float* __restrict__ Hck, int atomic_dp) {
   __shared__ __attribute__((aligned(16))) float sU[64 * RL_BP];                  // u rows
@@ -462,7 +527,7 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
   __shared__ __attribute__((aligned(16))) float sDt[2][XS ? SS_RMAX * RL_T : 4];
   __shared__ __attribute__((aligned(16))) float sDl[XS ? 4 : 64 * RL_BP];        // plain mode: delta rows in, d delta out
   __shared__ float sG[SS_N][64], sdA[SS_N][64];                                  // per-state values of every lane
-  __shared__ float sT[64 * RL_CP];                                               // column-sum tile [lane][32]
+  __shared__ __attribute__((aligned(16))) float sT[32 * RL_SP];                  // column-sum tile: 16 rows per slot x 32 columns
   __shared__ __attribute__((aligned(16))) float sOut[2][2 * SS_N * RL_T];        // per slot: dB [n][t], then dC [n][t]
   __shared__ __attribute__((aligned(16))) float sOutDt[2][XS ? SS_RMAX * RL_T : 4];   // per slot: d dt [r][t]
   const int lane = threadIdx.x;
@@ -588,6 +653,7 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
       }
       float G = sG[n][lane];
       f32x2 dA2 = {0.f, 0.f};
+      float vB[RL_T], vC[RL_T];                        // this channel's share of dB_t[n], dC_t[n]
 #pragma unroll
       for (int k = RL_T / 2 - 1; k >= 0; --k) {
         const f32x2 cdy = Cn2[k] * dy2[k];
@@ -604,21 +670,16 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
         ddl2[k] += qa * An;
         const f32x2 dBv = gt * dlu2[k];               // dB_t[n] contribution of this channel
         const f32x2 dCv = dy2[k] * hc2[k];            // dC_t[n]
-        sT[lane * RL_CP + 2 * k] = dBv[0];
-        sT[lane * RL_CP + 2 * k + 1] = dBv[1];
-        sT[lane * RL_CP + RL_T + 2 * k] = dCv[0];
-        sT[lane * RL_CP + RL_T + 2 * k + 1] = dCv[1];
+        vB[2 * k] = dBv[0];
+        vB[2 * k + 1] = dBv[1];
+        vC[2 * k] = dCv[0];
+        vC[2 * k + 1] = dCv[1];
       }
       sG[n][lane] = G;
       sdA[n][lane] += dA2[0] + dA2[1];
-      rl_sync();
-      {   // column sums over the slot's channels
-        float s4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 32; ++i) s4[i & 3] += sT[(half * 32 + i) * RL_CP + col];
-        float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        if (one_slot) s += __shfl_xor(s, 32, 64);
-        // lanes of slot `half` (two slots) or lanes 0..31 (one slot) hold column `col`: dB for col < 16, dC after
+      {   // sums over the slot's channels: columns 0..15 = dB_t, 16..31 = dC_t
+        const float s = rl_sum_columns(vB, vC, sT, lane, one_slot);
+        // lanes of slot `half` (two slots) or lanes 0..31 (one slot) hold column `col`
         if (!one_slot || half == 0) {
           float* o = one_slot ? myOut : sOut[half];
           o[(col >> 4) * (SS_N * RL_T) + n * RL_T + (col & 15)] = s;
@@ -660,17 +721,13 @@ __global__ __launch_bounds__(64) void xs_rl_bwd_kernel(ScanArgs a, int clb, cons
 #pragma unroll
     for (int r0 = 0; r0 < SS_RMAX; r0 += 2) {
       if (!XS || r0 >= a.R) break;               // wave-uniform
+      float v0[RL_T], v1[RL_T];
 #pragma unroll
       for (int t = 0; t < RL_T; ++t) {
-        sT[lane * RL_CP + t] = wdt[r0] * dd[t];
-        sT[lane * RL_CP + RL_T + t] = wdt[r0 + 1] * dd[t];      // wdt[r] = 0 for r >= R
+        v0[t] = wdt[r0] * dd[t];
+        v1[t] = wdt[r0 + 1] * dd[t];      // wdt[r] = 0 for r >= R
       }
-      rl_sync();
-      float s4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 32; ++i) s4[i & 3] += sT[(half * 32 + i) * RL_CP + col];
-      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-      if (one_slot) s += __shfl_xor(s, 32, 64);
+      const float s = rl_sum_columns(v0, v1, sT, lane, one_slot);
       if ((!one_slot || half == 0) && r0 + (col >> 4) < a.R) {
         float* o = one_slot ? myOutDt : sOutDt[half];
         o[(r0 + (col >> 4)) * RL_T + (col & 15)] = s;
