@@ -592,6 +592,15 @@ int nnz_dense32_forward_fused(const float* x, const float* W, const float* bias,
                               const float* dp_rand, float dp_keep, int dp_rps, int dp_nb, float* workspace, void* stream);
 int nnz_dense32_dgrad_fused(const float* dy, const float* W, const float* h, float* dx, long T, int K, int N,
                             const float* dp_rand, float dp_keep, int dp_rps, int dp_nb, float* workspace, void* stream);
+/* The two products for fp16 activations (round 5): x, y, dy, dx are _Float16, W / bias fp32, fp32 accumulation - the token
+ * Linears of the autocast nets that the fp16 token kernel does not take (F.linear under torch.autocast, nnUNetTrainer.py:1128-1139;
+ * m2net.py:230-262 at the 8^2 .. 32^2 levels), without cast launches.  workspace as for the _fused entry points. */
+int nnz_dense32_forward_h16(const void* x, const float* W, const float* bias, void* y, long T, int K, int N, float* workspace,
+                            void* stream);
+int nnz_dense32_dgrad_h16(const void* dy, const float* W, void* dx, long T, int K, int N, float* workspace, void* stream);
+/* grouped weight-gradient record with dy and x as _Float16 (see nnz_dense32_group_fill) */
+int nnz_dense32_group_fill_h16(void* job_host, void* fold_host, const void* dy, const void* x, float* dW, float* db,
+                               float* workspace, long T, int K, int N, int wg_begin, int blk_begin);
 /* grouped weight gradient record with the DropPath scale on its dy operand (per token: s of sample token / dp_rps); and a
  * fold-only record: dst[i] = sum_{q < parts} part[q * n + i] in part order (fold blocks: (n + 255) / 256) */
 int nnz_dense32_group_fill_scaled(void* job_host, void* fold_host, const float* dy, const float* x, float* dW, float* db,

@@ -148,6 +148,9 @@ SIGNATURES = {
     "nnz_dense32_dgrad_fused": [_fp, _fp, _fp, _fp, _l, _i, _i, _fp, _f, _i, _i, _fp, _vp],
     "nnz_dense32_group_fill_scaled": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _i, _fp, _f, _i, _i],
     "nnz_dense32_group_fill_fold": [_vp, _fp, _fp, _l, _i, _i],
+    "nnz_dense32_forward_h16": [_vp, _fp, _fp, _vp, _l, _i, _i, _fp, _vp],
+    "nnz_dense32_dgrad_h16": [_vp, _fp, _vp, _l, _i, _i, _fp, _vp],
+    "nnz_dense32_group_fill_h16": [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _l, _i, _i, _i, _i],
     "nnz_window_attention_forward_pad": [_fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "nnz_window_attention_backward_pad": [_fp, _fp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "nnz_window_attention_backward_parts": [_i, _i, _i, _i],

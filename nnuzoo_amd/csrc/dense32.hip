@@ -77,6 +77,10 @@ struct D32Args {
   int dp_rps, dp_nb;
   int ksplit;           // forward / dgrad: > 1 - split-K, raw partials to out + split * split_stride, epilogue in the fold kernel
   int kc_full;          // forward / dgrad with ksplit > 1: the whole contraction length (kc = per split)
+  // fp16 operands / outputs (the token Linears of the autocast nets that the fp16 token kernel does not take: activations and
+  // their gradients stay fp16 in HBM - no cast launches around the product -, converted while they are staged; weights,
+  // accumulators, weight gradients and split-K partials are fp32).  A / B / out then point at _Float16.
+  int a_half, b_half, out_half;
 };
 
 // drop-path scale of sample b
@@ -90,7 +94,8 @@ __device__ __forceinline__ void d32_epilogue(const D32Args& a, float v, float bv
   v = (v + bv) * sc;
   if (a.epi == 2) v *= gelu_grad_f(a.aux[o]);
   if (a.res) v += a.res[o];
-  a.out[o] = v;
+  if (a.out_half) reinterpret_cast<_Float16*>(a.out)[o] = (_Float16)v;
+  else a.out[o] = v;
   if (a.epi == 1) a.out2[o] = gelu_f(v);
 }
 
@@ -118,7 +123,13 @@ struct D32Tile {
   static constexpr int LPT = (NV + 255) / 256;
   f32x4 reg[LPT];
   f32x4 gm, bt;                                                        // LN: gamma / beta of this thread's column piece
-  __device__ __forceinline__ void load(const float* src, long rs, long cs, int r0, int nrows, int c0, int nc, int tid) {
+  // half: src points at _Float16 (same strides in elements); four values are one 8-byte load.  The raw halves ride in the
+  // first two words of reg[i] and are converted in store(): a conversion here made every load of the prefetch wait for its data
+  // on the spot (the step's loads ran one after the other: grouped weight gradients 2.3 -> 3.2 ms per M2Net pass)
+  __device__ __forceinline__ void load(const float* src, long rs, long cs, int r0, int nrows, int c0, int nc, int tid,
+                                       bool half = false) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const _Float16* srch = reinterpret_cast<const _Float16*>(src);
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
       const int p = tid + i * 256;
@@ -126,23 +137,55 @@ struct D32Tile {
       if (p < NV) {
         if (CONTIG) {
           const int r = p / (D32_BK / 4), c4 = (p % (D32_BK / 4)) * 4;
-          if (r0 + r < nrows && c0 + c4 < nc) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * rs + (c0 + c4));
+          if (r0 + r < nrows && c0 + c4 < nc) {
+            const long o = (long)(r0 + r) * rs + (c0 + c4);
+            if (half) {
+              const f32x2_t raw = *reinterpret_cast<const f32x2_t*>(srch + o);
+              v[0] = raw[0];
+              v[1] = raw[1];
+            } else {
+              v = *reinterpret_cast<const f32x4*>(src + o);
+            }
+          }
         } else {
           const int c = p / (NR / 4), r4 = (p % (NR / 4)) * 4;         // consecutive lanes: consecutive rows of one step
           if (c0 + c < nc) {
-            const float* s = src + (long)(c0 + c) * cs + (r0 + r4);
+            const long o = (long)(c0 + c) * cs + (r0 + r4);
             if (r0 + r4 + 3 < nrows) {
-              v = *reinterpret_cast<const f32x4*>(s);
+              if (half) {
+                const f32x2_t raw = *reinterpret_cast<const f32x2_t*>(srch + o);
+                v[0] = raw[0];
+                v[1] = raw[1];
+              } else {
+                v = *reinterpret_cast<const f32x4*>(src + o);
+              }
+            } else if (half) {
+              _Float16 hv[4] = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (r0 + r4 + e < nrows) hv[e] = srch[o + e];
+              typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+              const f32x2_t raw = __builtin_bit_cast(f32x2_t, h16x4{hv[0], hv[1], hv[2], hv[3]});
+              v[0] = raw[0];
+              v[1] = raw[1];
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                if (r0 + r4 + e < nrows) v[e] = s[e];
+                if (r0 + r4 + e < nrows) v[e] = src[o + e];
             }
           }
         }
       }
       reg[i] = v;
     }
+  }
+  // the fp32 values of piece i (raw halves of a half operand are converted here)
+  __device__ __forceinline__ f32x4 piece(int i, bool half) const {
+    if (!half) return reg[i];
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    const h16x4 hv = __builtin_bit_cast(h16x4, f32x2_t{reg[i][0], reg[i][1]});
+    return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
   }
   // weight gradient, dy operand of a drop-path branch: step (= token) c0 + c is scaled by its sample's factor
   __device__ __forceinline__ void scale_steps(const D32Args& a, int c0, int nc, int tid) {
@@ -179,17 +222,17 @@ struct D32Tile {
       reg[i] = v;
     }
   }
-  __device__ __forceinline__ void store(float* tile, int tid) const {
+  __device__ __forceinline__ void store(float* tile, int tid, bool half = false) const {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
       const int p = tid + i * 256;
       if (p < NV) {
         if (CONTIG) {
           const int r = p / (D32_BK / 4), c4 = (p % (D32_BK / 4)) * 4;
-          *reinterpret_cast<f32x4*>(tile + r * D32_PITCH + c4) = reg[i];
+          *reinterpret_cast<f32x4*>(tile + r * D32_PITCH + c4) = piece(i, half);
         } else {
           const int c = p / (NR / 4), r4 = (p % (NR / 4)) * 4;
-          *reinterpret_cast<f32x4*>(tile + c * TP + r4) = reg[i];
+          *reinterpret_cast<f32x4*>(tile + c * TP + r4) = piece(i, half);
         }
       }
     }
@@ -349,7 +392,7 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
     if constexpr (LN) {
       t.load_ln(a, ln, r0, k0, k_end, tid);
     } else {
-      t.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0, k_end, tid);
+      t.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0, k_end, tid, a.a_half != 0);
       if constexpr (WGRAD && !A_CONTIG) {
         if (wscale) t.scale_steps(a, k0, k_end, tid);
       }
@@ -357,32 +400,32 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
   };
   auto storeA = [&](const TA& t, int k0) {
     if constexpr (LN) t.store_ln(a, ln, sA, r0, k0, k_end, tid, write_y);
-    else t.store(sA, tid);
+    else t.store(sA, tid, a.a_half != 0);
   };
   loadA(stA0, k_begin);
-  stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid);
+  stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid, a.b_half != 0);
   if (k_begin + D32_BK < k_end) {
     loadA(stA1, k_begin + D32_BK);
-    stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin + D32_BK, k_end, tid);
+    stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin + D32_BK, k_end, tid, a.b_half != 0);
   }
   for (int k0 = k_begin; k0 < k_end; k0 += 2 * D32_BK) {
     __syncthreads();
     storeA(stA0, k0);
-    stB0.store(sB, tid);
+    stB0.store(sB, tid, a.b_half != 0);
     __syncthreads();
     if (k0 + 2 * D32_BK < k_end) {
       loadA(stA0, k0 + 2 * D32_BK);
-      stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 2 * D32_BK, k_end, tid);
+      stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 2 * D32_BK, k_end, tid, a.b_half != 0);
     }
     compute();
     if (k0 + D32_BK < k_end) {
       __syncthreads();
       storeA(stA1, k0 + D32_BK);
-      stB1.store(sB, tid);
+      stB1.store(sB, tid, a.b_half != 0);
       __syncthreads();
       if (k0 + 3 * D32_BK < k_end) {
         loadA(stA1, k0 + 3 * D32_BK);
-        stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 3 * D32_BK, k_end, tid);
+        stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 3 * D32_BK, k_end, tid, a.b_half != 0);
       }
       compute();
     }
@@ -582,7 +625,7 @@ static int d32_run(D32Args a, float* workspace, hipStream_t s) {
   }
   D32Args t = a;                         // the tile launch: raw partials [split][rows][cols] in the workspace
   t.ksplit = splits; t.kc = per;
-  t.out = workspace; t.ldo = a.cols; t.split_stride = (long)a.rows * a.cols;
+  t.out = workspace; t.out_half = 0; t.ldo = a.cols; t.split_stride = (long)a.rows * a.cols;
   const long tiles = (long)((a.rows + 63) / 64) * ((a.cols + 63) / 64);
   NNZ_LAUNCH((dense32_kernel<1, 1, true, BC, false, LN>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s, t);
   D32Args f = a;                         // the fold: sums the partials in split order, then the epilogue
@@ -674,6 +717,34 @@ extern "C" int nnz_dense32_dgrad_fused(const float* dy, const float* W, const fl
   a.out = dx; a.aux = h; a.ldo = K;
   a.rows = (int)T; a.cols = K; a.kc = N; a.epi = h ? 2 : 0;
   a.dp_rand = dp_rand; a.dp_keep = dp_keep; a.dp_inv = dp_rand ? 1.f / dp_keep : 1.f; a.dp_rps = dp_rps; a.dp_nb = dp_nb;
+  return d32_run<false, false>(a, workspace, (hipStream_t)stream);
+}
+
+// The same two products for fp16 activations (x, y, dy, dx are _Float16; W, bias fp32; fp32 accumulation, split-K partials
+// fp32): y = fp16(x W^T + bias), dx = fp16(dy W).  What torch.autocast's F.linear computes with an fp16 copy of W, at fp32
+// weight precision and without the casts' launches.
+extern "C" int nnz_dense32_forward_h16(const void* x, const float* W, const float* bias, void* y, long T, int K, int N,
+                                       float* workspace, void* stream) {
+  using namespace nnz;
+  if (!x || !W || !y || T < 1 || T > (1L << 30) || K < 4 || N < 4 || (K & 3) || (N & 3)) return NNZ_EINVAL;
+  D32Args a = {};
+  a.A = reinterpret_cast<const float*>(x); a.a_rs = K; a.a_cs = 1; a.a_half = 1;
+  a.B = W; a.b_rs = K; a.b_cs = 1;
+  a.out = reinterpret_cast<float*>(y); a.out_half = 1; a.bias = bias; a.ldo = N;
+  a.rows = (int)T; a.cols = N; a.kc = K; a.epi = 0;
+  a.dp_inv = 1.f; a.dp_keep = 1.f; a.dp_rps = 1; a.dp_nb = 1;
+  return d32_run<true, false>(a, workspace, (hipStream_t)stream);
+}
+extern "C" int nnz_dense32_dgrad_h16(const void* dy, const float* W, void* dx, long T, int K, int N, float* workspace,
+                                     void* stream) {
+  using namespace nnz;
+  if (!dy || !W || !dx || T < 1 || T > (1L << 30) || K < 4 || N < 4 || (N & 3) || (K & 3)) return NNZ_EINVAL;
+  D32Args a = {};
+  a.A = reinterpret_cast<const float*>(dy); a.a_rs = N; a.a_cs = 1; a.a_half = 1;
+  a.B = W; a.b_rs = 1; a.b_cs = K;
+  a.out = reinterpret_cast<float*>(dx); a.out_half = 1; a.ldo = K;
+  a.rows = (int)T; a.cols = K; a.kc = N; a.epi = 0;
+  a.dp_inv = 1.f; a.dp_keep = 1.f; a.dp_rps = 1; a.dp_nb = 1;
   return d32_run<false, false>(a, workspace, (hipStream_t)stream);
 }
 
@@ -797,6 +868,18 @@ extern "C" int nnz_dense32_group_fill_scaled(void* job_host, void* fold_host, co
   D32Job* j = reinterpret_cast<D32Job*>(job_host);
   j->a.dp_rand = dp_rand; j->a.dp_keep = dp_keep; j->a.dp_inv = dp_rand ? 1.f / dp_keep : 1.f; j->a.dp_rps = dp_rps;
   j->a.dp_nb = dp_nb;
+  return NNZ_OK;
+}
+// the same record with dy and x as _Float16 (dW, db, partials fp32)
+extern "C" int nnz_dense32_group_fill_h16(void* job_host, void* fold_host, const void* dy, const void* x, float* dW, float* db,
+                                          float* workspace, long T, int K, int N, int wg_begin, int blk_begin) {
+  using namespace nnz;
+  const int rc = nnz_dense32_group_fill(job_host, fold_host, reinterpret_cast<const float*>(dy),
+                                        reinterpret_cast<const float*>(x), dW, db, workspace, T, K, N, wg_begin, blk_begin);
+  if (rc != NNZ_OK) return rc;
+  D32Job* j = reinterpret_cast<D32Job*>(job_host);
+  j->a.a_half = 1;
+  j->a.b_half = 1;
   return NNZ_OK;
 }
 // a fold-only record (no product): dst[i] = sum_{q < parts} part[q * n + i], i < n, in part order - the LayerNorm backward of the

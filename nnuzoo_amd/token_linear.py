@@ -24,6 +24,7 @@ from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 MIN_TOKENS = 65536
+H16_IO = os.environ.get("NNZ_TL_H16", "1") != "0"    # fp16 in / out on the fp32 matrix-core kernels (A/B: 0 = fp32 copies around them)
 HIP_MIN_TOKENS = int(os.environ.get("NNZ_TL_MIN_TOKENS", "1024"))   # below this the call is launch-bound either way (A/B: env)
 USE_HIP_KERNELS = os.environ.get("NNZ_TOKEN_LINEAR", "1") != "0"   # A/B switch for measurements
 MAX_FEATURES = 256
@@ -424,7 +425,8 @@ def _flush_group(jobs, tile_class: int = 0, folds=()) -> None:
     # that precede every capture leave their buffer in _HOST_CACHE under the pass's shape signature; a capturing flush TAKES
     # it (the captured copy node re-reads it at every replay, so no later flush may write to it).
     nbytes = o_blk + max(1, total_blks) * 4
-    key = (tile_class,) + tuple((j[1].shape[0],) + tuple(j[2].shape) + (j[3] is not None, len(j) > 4 and j[4] is not None)
+    key = (tile_class,) + tuple((j[1].shape[0],) + tuple(j[2].shape) + (j[3] is not None, len(j) > 4 and j[4] is not None,
+                                                                         j[0].dtype == torch.float16)
                                 for j in jobs) + tuple((n, parts) for _, n, parts, _ in folds)
     capturing = torch.cuda.is_current_stream_capturing()
     host = _HOST_CACHE.pop(key, None)
@@ -449,7 +451,11 @@ def _flush_group(jobs, tile_class: int = 0, folds=()) -> None:
         N, K = w.shape
         dw = torch.empty((N, K), dtype=torch.float32, device=dev)
         db = torch.empty(N, dtype=torch.float32, device=dev) if b is not None else None
-        if dp is None:
+        if dy2.dtype == torch.float16:
+            assert dp is None and x2.dtype == torch.float16
+            call("nnz_dense32_group_fill_h16", hp + j * rb_job, (hp + o_fold + fi * rb_fold) if nb else None, ptr(dy2), ptr(x2),
+                 ptr(dw), ptr(db), (ws.data_ptr() + 4 * ws_off) if nf else None, x2.shape[0], K, N, wg0, blk0)
+        elif dp is None:
             call("nnz_dense32_group_fill", hp + j * rb_job, (hp + o_fold + fi * rb_fold) if nb else None, ptr(dy2), ptr(x2),
                  ptr(dw), ptr(db), (ws.data_ptr() + 4 * ws_off) if nf else None, x2.shape[0], K, N, wg0, blk0)
         else:
@@ -500,6 +506,10 @@ def _d32_forward(x2, weight, bias, y, y_act, T, K, N, gelu):
     """y = x W^T + b on csrc/dense32.hip through the entry point that cuts skinny products along the contraction (split-K)"""
     from .swin_block import _workspace
     ws = _workspace(x2.device, int(_lib.load().nnz_dense32_splitk_workspace_floats(T, K, N)))
+    if x2.dtype == torch.float16:          # fp16 activations in and out, fp32 weights and accumulation (no cast launches)
+        assert y.dtype == torch.float16 and y_act is None and not gelu
+        call("nnz_dense32_forward_h16", ptr(x2), ptr(weight), ptr(bias), ptr(y), T, K, N, ptr(ws), stream_ptr())
+        return
     call("nnz_dense32_forward_fused", ptr(x2), ptr(weight), ptr(bias), ptr(y), ptr(y_act), T, K, N, int(gelu), None, None, 0.0, None,
          None, None, 0, 0, 0, 0, None, None, 1.0, 1, 1, ptr(ws), stream_ptr())
 
@@ -507,6 +517,10 @@ def _d32_forward(x2, weight, bias, y, y_act, T, K, N, gelu):
 def _d32_dgrad(dy2, weight, h, dx, T, K, N):
     from .swin_block import _workspace
     ws = _workspace(dy2.device, int(_lib.load().nnz_dense32_splitk_workspace_floats(T, N, K)))
+    if dy2.dtype == torch.float16:
+        assert dx.dtype == torch.float16 and h is None
+        call("nnz_dense32_dgrad_h16", ptr(dy2), ptr(weight), ptr(dx), T, K, N, ptr(ws), stream_ptr())
+        return
     call("nnz_dense32_dgrad_fused", ptr(dy2), ptr(weight), ptr(h), ptr(dx), T, K, N, None, 1.0, 1, 1, ptr(ws), stream_ptr())
 
 
@@ -517,13 +531,15 @@ def _d32_backward_products(dy2, x2, weight, need_x, need_w, need_b, h=None, bias
     T = x2.shape[0]
     dx = dw = db = None
     if need_x:
-        dx = torch.empty((T, K), dtype=torch.float32, device=dy2.device)
+        dx = torch.empty((T, K), dtype=dy2.dtype, device=dy2.device)
         _d32_dgrad(dy2, weight, h, dx, T, K, N)
     if need_w or need_b:
         if _DEFER["on"] and need_w and weight.is_leaf and (bias is None or bias.is_leaf) and not _has_grad_hooks(weight) \
                 and not (bias is not None and _has_grad_hooks(bias)):
             _DEFER["jobs"].append((dy2, x2, weight, bias if need_b else None))
             return dx, None, None
+        if dy2.dtype == torch.float16:     # outside a deferred pass (module-level tests): the fp32 entry point on fp32 copies
+            dy2, x2 = dy2.float(), x2.float()
         dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
         db = torch.empty(N, dtype=torch.float32, device=dy2.device) if need_b else None
         ws = _d32_workspace(dy2.device, int(_lib.load().nnz_dense32_wgrad_workspace_floats(T, K, N)))
@@ -543,7 +559,7 @@ class _Dense32LinearFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         T = x2.shape[0]
-        y = torch.empty((T, N), dtype=torch.float32, device=x.device)
+        y = torch.empty((T, N), dtype=x2.dtype, device=x.device)      # fp32, or fp16 in / fp16 out (autocast nets)
         _d32_forward(x2, weight, bias, y, None, T, K, N, 0)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
@@ -556,8 +572,8 @@ class _Dense32LinearFn(torch.autograd.Function):
         x2, weight = ctx.saved_tensors
         N, K = weight.shape
         dy2 = dy.reshape(-1, N)
-        if not dy2.is_contiguous() or dy2.dtype != torch.float32:
-            dy2 = dy2.float().contiguous()
+        if not dy2.is_contiguous() or dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype).contiguous()
         dx, dw, db = _d32_backward_products(dy2, x2, ctx.params[0], ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                             ctx.has_bias and ctx.needs_input_grad[2], bias=ctx.params[1])
         return (None if dx is None else dx.view(ctx.xshape)), (dw if ctx.needs_input_grad[1] else None), db
@@ -645,6 +661,8 @@ class TokenLinear(nn.Linear):
                 and x.dtype in (torch.float16, torch.float32):
             _backends.note(self, "hip-f32", why=why)
             with torch.autocast("cuda", enabled=False):
+                if x.dtype == torch.float16 and H16_IO:   # fp16 rows in, fp16 rows out: converted while staged / stored (no cast launches)
+                    return _Dense32LinearFn.apply(x, self.weight, self.bias)
                 y = _Dense32LinearFn.apply(x.float(), self.weight, self.bias)
             return y.to(torch.float16)
         self.backend_why = why

@@ -149,3 +149,47 @@ def test_grouped_deferred_weight_gradients_equal_per_layer_launches(hip_lib):
         p.grad = None
     sum(m(x).mean() for m, x in zip(net, xs)).backward()
     assert all(torch.allclose(e, g + p.grad, rtol=1e-6, atol=1e-7) for e, g, p in zip(extra, got, net.parameters()))
+
+
+@pytest.mark.parametrize("T,K,N", [(128, 768, 192), (512, 384, 96), (2048, 192, 768), (100, 96, 40), (4096, 1536, 384)])
+def test_half_activations_in_and_out(hip_lib, T, K, N):
+    """nnz_dense32_forward_h16 / _dgrad_h16 / the fp16 grouped weight-gradient record (round 5): the token Linears of the autocast
+    nets that the fp16 token kernel does not take.  Against float64 on the SAME fp16-rounded activations and fp32 weights: the
+    product is exact up to fp32 accumulation, the result is rounded once to fp16 (2^-11 relative) - tighter than
+    torch.autocast's F.linear, which also rounds W to fp16 (nnUNetTrainer.py:1128-1139)."""
+    g = torch.Generator().manual_seed(T + N)
+    x = torch.randn(T, K, generator=g).half().to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    dy = torch.randn(T, N, generator=g).half().to(DEV)
+    lib = _lib.load()
+    y = torch.empty(T, N, dtype=torch.float16, device=DEV)
+    ws = torch.empty(max(1, int(lib.nnz_dense32_splitk_workspace_floats(T, K, N))), device=DEV)
+    call("nnz_dense32_forward_h16", ptr(x), ptr(W), ptr(b), ptr(y), T, K, N, ptr(ws), stream_ptr())
+    ref = x.double() @ W.double().t() + b.double()
+    err = (y.double() - ref).abs().max().item()
+    assert err <= (2.0 ** -11 + 2e-6 * math.sqrt(K)) * ref.abs().max().item(), (err, ref.abs().max().item())
+    dx = torch.empty(T, K, dtype=torch.float16, device=DEV)
+    ws = torch.empty(max(1, int(lib.nnz_dense32_splitk_workspace_floats(T, N, K))), device=DEV)
+    call("nnz_dense32_dgrad_h16", ptr(dy), ptr(W), ptr(dx), T, K, N, ptr(ws), stream_ptr())
+    ref = dy.double() @ W.double()
+    err = (dx.double() - ref).abs().max().item()
+    assert err <= (2.0 ** -11 + 2e-6 * math.sqrt(N)) * ref.abs().max().item(), (err, ref.abs().max().item())
+    # the module path under autocast: fp16 rows in, fp16 rows out, weight gradient through the grouped launch
+    from nnuzoo_amd.token_linear import TokenLinear, deferred_wgrads
+    m = TokenLinear(K, N).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(W)
+        m.bias.copy_(b)
+    xr = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = m(xr.view(1, T, K))
+    if m.backend == "hip-f32":            # (shapes the fp16 token kernel takes keep that kernel: nothing to compare here)
+        assert out.dtype == torch.float16
+        with deferred_wgrads():
+            out.backward(dy.view(1, T, N))
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(T, N), y)
+        assert torch.equal(xr.grad, dx)
+        _close(m.weight.grad, dy.double().t() @ x.double(), T, "dW")
+        _close(m.bias.grad, dy.double().sum(0), T, "db")
