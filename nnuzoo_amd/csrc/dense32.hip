@@ -90,11 +90,12 @@ __device__ __forceinline__ float d32_dp_scale(const D32Args& a, int b) {
 }
 
 // the epilogue of one output element (shared by the tile kernels and the split-K fold)
+template <bool OUT_HALF = false>
 __device__ __forceinline__ void d32_epilogue(const D32Args& a, float v, float bv, float sc, long o) {
   v = (v + bv) * sc;
   if (a.epi == 2) v *= gelu_grad_f(a.aux[o]);
   if (a.res) v += a.res[o];
-  if (a.out_half) reinterpret_cast<_Float16*>(a.out)[o] = (_Float16)v;
+  if constexpr (OUT_HALF) reinterpret_cast<_Float16*>(a.out)[o] = (_Float16)v;
   else a.out[o] = v;
   if (a.epi == 1) a.out2[o] = gelu_f(v);
 }
@@ -126,8 +127,10 @@ struct D32Tile {
   // half: src points at _Float16 (same strides in elements); four values are one 8-byte load.  The raw halves ride in the
   // first two words of reg[i] and are converted in store(): a conversion here made every load of the prefetch wait for its data
   // on the spot (the step's loads ran one after the other: grouped weight gradients 2.3 -> 3.2 ms per M2Net pass)
-  __device__ __forceinline__ void load(const float* src, long rs, long cs, int r0, int nrows, int c0, int nc, int tid,
-                                       bool half = false) {
+  // (HALF is a template parameter: as a run-time flag the two forms of every load sat in branches of their own, the prefetch
+  //  loads of a step no longer went out back to back, and the fp32 SwT2Net step lost 5.6 ms of 57.6)
+  template <bool half = false>
+  __device__ __forceinline__ void load(const float* src, long rs, long cs, int r0, int nrows, int c0, int nc, int tid) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const _Float16* srch = reinterpret_cast<const _Float16*>(src);
 #pragma unroll
@@ -139,7 +142,7 @@ struct D32Tile {
           const int r = p / (D32_BK / 4), c4 = (p % (D32_BK / 4)) * 4;
           if (r0 + r < nrows && c0 + c4 < nc) {
             const long o = (long)(r0 + r) * rs + (c0 + c4);
-            if (half) {
+            if constexpr (half) {
               const f32x2_t raw = *reinterpret_cast<const f32x2_t*>(srch + o);
               v[0] = raw[0];
               v[1] = raw[1];
@@ -152,14 +155,14 @@ struct D32Tile {
           if (c0 + c < nc) {
             const long o = (long)(c0 + c) * cs + (r0 + r4);
             if (r0 + r4 + 3 < nrows) {
-              if (half) {
+              if constexpr (half) {
                 const f32x2_t raw = *reinterpret_cast<const f32x2_t*>(srch + o);
                 v[0] = raw[0];
                 v[1] = raw[1];
               } else {
                 v = *reinterpret_cast<const f32x4*>(src + o);
               }
-            } else if (half) {
+            } else if constexpr (half) {
               _Float16 hv[4] = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
 #pragma unroll
               for (int e = 0; e < 4; ++e)
@@ -180,8 +183,9 @@ struct D32Tile {
     }
   }
   // the fp32 values of piece i (raw halves of a half operand are converted here)
-  __device__ __forceinline__ f32x4 piece(int i, bool half) const {
-    if (!half) return reg[i];
+  template <bool half>
+  __device__ __forceinline__ f32x4 piece(int i) const {
+    if constexpr (!half) return reg[i];
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     const h16x4 hv = __builtin_bit_cast(h16x4, f32x2_t{reg[i][0], reg[i][1]});
@@ -222,17 +226,18 @@ struct D32Tile {
       reg[i] = v;
     }
   }
-  __device__ __forceinline__ void store(float* tile, int tid, bool half = false) const {
+  template <bool half = false>
+  __device__ __forceinline__ void store(float* tile, int tid) const {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
       const int p = tid + i * 256;
       if (p < NV) {
         if (CONTIG) {
           const int r = p / (D32_BK / 4), c4 = (p % (D32_BK / 4)) * 4;
-          *reinterpret_cast<f32x4*>(tile + r * D32_PITCH + c4) = piece(i, half);
+          *reinterpret_cast<f32x4*>(tile + r * D32_PITCH + c4) = piece<half>(i);
         } else {
           const int c = p / (NR / 4), r4 = (p % (NR / 4)) * 4;
-          *reinterpret_cast<f32x4*>(tile + c * TP + r4) = piece(i, half);
+          *reinterpret_cast<f32x4*>(tile + c * TP + r4) = piece<half>(i);
         }
       }
     }
@@ -273,7 +278,7 @@ struct D32Tile {
 // `split`: weight gradient - the token range; forward / input gradient with a.ksplit > 1 - the range of the contraction
 // (split-K: skinny products of the deep Swin levels, 2 x 12 tiles of 64 x 64 over a contraction of 3 072, are otherwise one
 // 48-block chain per workgroup on a tenth of the chip); the partials are folded in split order by dense32_splitk_fold_kernel.
-template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD, bool LN>
+template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD, bool LN, bool H16 = false>
 __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, const int split) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int D32_BK = (WM == 1 && WN == 1) ? 64 : 32;
@@ -392,7 +397,7 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
     if constexpr (LN) {
       t.load_ln(a, ln, r0, k0, k_end, tid);
     } else {
-      t.load(a.A, a.a_rs, a.a_cs, r0, a.rows, k0, k_end, tid, a.a_half != 0);
+      t.template load<H16>(a.A, a.a_rs, a.a_cs, r0, a.rows, k0, k_end, tid);
       if constexpr (WGRAD && !A_CONTIG) {
         if (wscale) t.scale_steps(a, k0, k_end, tid);
       }
@@ -400,32 +405,32 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
   };
   auto storeA = [&](const TA& t, int k0) {
     if constexpr (LN) t.store_ln(a, ln, sA, r0, k0, k_end, tid, write_y);
-    else t.store(sA, tid, a.a_half != 0);
+    else t.template store<H16>(sA, tid);
   };
   loadA(stA0, k_begin);
-  stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid, a.b_half != 0);
+  stB0.template load<H16 && WGRAD>(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin, k_end, tid);
   if (k_begin + D32_BK < k_end) {
     loadA(stA1, k_begin + D32_BK);
-    stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin + D32_BK, k_end, tid, a.b_half != 0);
+    stB1.template load<H16 && WGRAD>(a.B, a.b_rs, a.b_cs, c0, a.cols, k_begin + D32_BK, k_end, tid);
   }
   for (int k0 = k_begin; k0 < k_end; k0 += 2 * D32_BK) {
     __syncthreads();
     storeA(stA0, k0);
-    stB0.store(sB, tid, a.b_half != 0);
+    stB0.template store<H16 && WGRAD>(sB, tid);
     __syncthreads();
     if (k0 + 2 * D32_BK < k_end) {
       loadA(stA0, k0 + 2 * D32_BK);
-      stB0.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 2 * D32_BK, k_end, tid, a.b_half != 0);
+      stB0.template load<H16 && WGRAD>(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 2 * D32_BK, k_end, tid);
     }
     compute();
     if (k0 + D32_BK < k_end) {
       __syncthreads();
       storeA(stA1, k0 + D32_BK);
-      stB1.store(sB, tid, a.b_half != 0);
+      stB1.template store<H16 && WGRAD>(sB, tid);
       __syncthreads();
       if (k0 + 3 * D32_BK < k_end) {
         loadA(stA1, k0 + 3 * D32_BK);
-        stB1.load(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 3 * D32_BK, k_end, tid, a.b_half != 0);
+        stB1.template load<H16 && WGRAD>(a.B, a.b_rs, a.b_cs, c0, a.cols, k0 + 3 * D32_BK, k_end, tid);
       }
       compute();
     }
@@ -475,14 +480,14 @@ __device__ __forceinline__ void dense32_body(const D32Args& a, const int tile, c
         if (row >= a.rows) continue;
         float sc = row >= e2 ? s2 : (row >= e1 ? s1 : s0);
         if (dp_div) sc = d32_dp_scale(a, row / a.dp_rps);
-        d32_epilogue(a, acc[i][j][r], bv, sc, (long)row * a.ldo + col);
+        d32_epilogue<H16 && !WGRAD>(a, acc[i][j][r], bv, sc, (long)row * a.ldo + col);
       }
   }
 }
 
-template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD, bool LN = false>
+template <int WM, int WN, bool A_CONTIG, bool B_CONTIG, bool WGRAD, bool LN = false, bool H16 = false>
 __global__ __launch_bounds__(256, 2) void dense32_kernel(D32Args a) {
-  dense32_body<WM, WN, A_CONTIG, B_CONTIG, WGRAD, LN>(a, blockIdx.x, blockIdx.y);
+  dense32_body<WM, WN, A_CONTIG, B_CONTIG, WGRAD, LN, H16>(a, blockIdx.x, blockIdx.y);
 }
 
 // split-K second stage: out[row][col] = epilogue(sum_s part[s][row][col]) in split order (bit-identical run to run)
@@ -498,7 +503,10 @@ __global__ __launch_bounds__(256) void dense32_splitk_fold_kernel(D32Args a, con
     const int row = (int)(e / a.cols), col = (int)(e - (long)row * a.cols);
     const float sc = a.dp_rand ? d32_dp_scale(a, row / a.dp_rps) : 1.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) d32_epilogue(a, v[i], a.bias ? a.bias[col + i] : 0.f, sc, (long)row * a.ldo + col + i);
+    for (int i = 0; i < 4; ++i) {
+      if (a.out_half) d32_epilogue<true>(a, v[i], a.bias ? a.bias[col + i] : 0.f, sc, (long)row * a.ldo + col + i);
+      else d32_epilogue<false>(a, v[i], a.bias ? a.bias[col + i] : 0.f, sc, (long)row * a.ldo + col + i);
+    }
   }
 }
 
@@ -540,7 +548,7 @@ __device__ __forceinline__ float d32_fold_sum(const float* __restrict__ part, lo
   return s;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool H16 = false>
 __global__ __launch_bounds__(256, 2) void dense32_group_wgrad_kernel(const D32Job* __restrict__ jobs,
                                                                      const int* __restrict__ wg_job) {
   const int j = __builtin_amdgcn_readfirstlane(wg_job[blockIdx.x]);
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void dense32_group_wgrad_kernel(const D32Jo
   const D32Args a = jp->a;
   const int local = (int)blockIdx.x - jp->wg_begin;
   const int nt = jp->ntiles;
-  dense32_body<WM, WN, false, false, true, false>(a, local % nt, local / nt);
+  dense32_body<WM, WN, false, false, true, false, H16>(a, local % nt, local / nt);
 }
 __global__ __launch_bounds__(256) void dense32_group_fold_kernel(const D32FoldJob* __restrict__ jobs,
                                                                  const int* __restrict__ blk_job) {
@@ -576,16 +584,16 @@ __global__ __launch_bounds__(256) void dense32_fold_kernel(const float* __restri
   }
 }
 
-template <bool AC, bool BC, bool WG, bool LN = false>
+template <bool AC, bool BC, bool WG, bool LN = false, bool H16 = false>
 static int d32_launch(const D32Args& a, int splits, hipStream_t s) {
   // tile choice: the largest tile that still gives the chip ~2 workgroups per CU
   auto wgs = [&](int bm, int bn) { return (long)((a.rows + bm - 1) / bm) * ((a.cols + bn - 1) / bn) * splits; };
   if (a.cols > 64 && a.rows > 64 && wgs(128, 128) >= 256) {
-    NNZ_LAUNCH((dense32_kernel<2, 2, AC, BC, WG, LN>), dim3((unsigned)wgs(128, 128) / splits, splits), dim3(256), 0, s, a);
+    NNZ_LAUNCH((dense32_kernel<2, 2, AC, BC, WG, LN, H16>), dim3((unsigned)wgs(128, 128) / splits, splits), dim3(256), 0, s, a);
   } else if (a.cols > 64 && wgs(64, 128) >= 192) {
-    NNZ_LAUNCH((dense32_kernel<1, 2, AC, BC, WG, LN>), dim3((unsigned)wgs(64, 128) / splits, splits), dim3(256), 0, s, a);
+    NNZ_LAUNCH((dense32_kernel<1, 2, AC, BC, WG, LN, H16>), dim3((unsigned)wgs(64, 128) / splits, splits), dim3(256), 0, s, a);
   } else {
-    NNZ_LAUNCH((dense32_kernel<1, 1, AC, BC, WG, LN>), dim3((unsigned)wgs(64, 64) / splits, splits), dim3(256), 0, s, a);
+    NNZ_LAUNCH((dense32_kernel<1, 1, AC, BC, WG, LN, H16>), dim3((unsigned)wgs(64, 64) / splits, splits), dim3(256), 0, s, a);
   }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
@@ -613,7 +621,7 @@ static int d32_ksplits(long T, int K, int N, int* per_out) {
 }
 
 // one forward / input-gradient product with everything optional: `a` describes the whole problem (kc = the contraction)
-template <bool BC, bool LN>
+template <bool BC, bool LN, bool H16 = false>
 static int d32_run(D32Args a, float* workspace, hipStream_t s) {
   int per = 0;
   const int K = a.kc;
@@ -621,13 +629,13 @@ static int d32_run(D32Args a, float* workspace, hipStream_t s) {
   const int splits = workspace ? d32_ksplits(a.rows, K, a.cols, &per) : 1;
   if (splits <= 1) {
     a.ksplit = 1;
-    return d32_launch<true, BC, false, LN>(a, 1, s);
+    return d32_launch<true, BC, false, LN, H16>(a, 1, s);
   }
   D32Args t = a;                         // the tile launch: raw partials [split][rows][cols] in the workspace
   t.ksplit = splits; t.kc = per;
   t.out = workspace; t.out_half = 0; t.ldo = a.cols; t.split_stride = (long)a.rows * a.cols;
   const long tiles = (long)((a.rows + 63) / 64) * ((a.cols + 63) / 64);
-  NNZ_LAUNCH((dense32_kernel<1, 1, true, BC, false, LN>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s, t);
+  NNZ_LAUNCH((dense32_kernel<1, 1, true, BC, false, LN, H16>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s, t);
   D32Args f = a;                         // the fold: sums the partials in split order, then the epilogue
   f.ksplit = splits; f.split_stride = t.split_stride;
   const long n4 = (long)a.rows * a.cols / 4;
@@ -733,7 +741,7 @@ extern "C" int nnz_dense32_forward_h16(const void* x, const float* W, const floa
   a.out = reinterpret_cast<float*>(y); a.out_half = 1; a.bias = bias; a.ldo = N;
   a.rows = (int)T; a.cols = N; a.kc = K; a.epi = 0;
   a.dp_inv = 1.f; a.dp_keep = 1.f; a.dp_rps = 1; a.dp_nb = 1;
-  return d32_run<true, false>(a, workspace, (hipStream_t)stream);
+  return d32_run<true, false, true>(a, workspace, (hipStream_t)stream);
 }
 extern "C" int nnz_dense32_dgrad_h16(const void* dy, const float* W, void* dx, long T, int K, int N, float* workspace,
                                      void* stream) {
@@ -745,7 +753,7 @@ extern "C" int nnz_dense32_dgrad_h16(const void* dy, const float* W, void* dx, l
   a.out = reinterpret_cast<float*>(dx); a.out_half = 1; a.ldo = K;
   a.rows = (int)T; a.cols = K; a.kc = N; a.epi = 0;
   a.dp_inv = 1.f; a.dp_keep = 1.f; a.dp_rps = 1; a.dp_nb = 1;
-  return d32_run<false, false>(a, workspace, (hipStream_t)stream);
+  return d32_run<false, false, true>(a, workspace, (hipStream_t)stream);
 }
 
 // token splits of the weight gradient: none when the weight matrix alone gives >= 256 tiles of 64 x 64, otherwise enough
@@ -900,7 +908,15 @@ extern "C" int nnz_dense32_group_launch(const void* jobs_dev, const int* wg_job_
   if (!jobs_dev || !wg_job_dev || total_wgs < 1 || total_blks < 0 || (total_blks > 0 && (!fold_dev || !blk_job_dev)))
     return NNZ_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (tile_class == 1) {
+  // tile_class bit 0: 128 x 128 tiles; bit 1: the jobs' dy / x are _Float16 (nnz_dense32_group_fill_h16) - one launch holds jobs
+  // of one kind (the operand type is a template parameter of the kernel: see D32Tile::load)
+  if (tile_class == 3) {
+    NNZ_LAUNCH((dense32_group_wgrad_kernel<2, 2, true>), dim3((unsigned)total_wgs), dim3(256), 0, s, (const D32Job*)jobs_dev,
+               wg_job_dev);
+  } else if (tile_class == 2) {
+    NNZ_LAUNCH((dense32_group_wgrad_kernel<1, 1, true>), dim3((unsigned)total_wgs), dim3(256), 0, s, (const D32Job*)jobs_dev,
+               wg_job_dev);
+  } else if (tile_class == 1) {
     NNZ_LAUNCH((dense32_group_wgrad_kernel<2, 2>), dim3((unsigned)total_wgs), dim3(256), 0, s, (const D32Job*)jobs_dev,
                wg_job_dev);
   } else {

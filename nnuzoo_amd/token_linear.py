@@ -237,8 +237,12 @@ class deferred_wgrads:
                 # one grouped launch per tile class (64 x 64 / 128 x 128 tiles; csrc/dense32.hip d32_group_class); the fold-only
                 # records (LayerNorm dgamma | dbeta partials of the fused Swin blocks) ride in the first one
                 lib = _lib.load()
-                for cls in (0, 1):
-                    sub = [j for j in jobs if int(lib.nnz_dense32_group_class(j[1].shape[0], j[2].shape[1], j[2].shape[0])) == cls]
+                # (bit 1 of the class: fp16 dy / x - the operand type is a template parameter of the kernel)
+                def _cls(j):
+                    return int(lib.nnz_dense32_group_class(j[1].shape[0], j[2].shape[1], j[2].shape[0])) | \
+                        (2 if j[0].dtype == torch.float16 else 0)
+                for cls in (0, 1, 2, 3):
+                    sub = [j for j in jobs if _cls(j) == cls]
                     if sub:
                         _flush_group(sub, cls, folds)
                         folds = []
