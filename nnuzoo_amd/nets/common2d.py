@@ -315,6 +315,8 @@ class PatchMerging2D(nn.Module):
         self.scale = scale
         self.reduction = TokenLinear(self.input_feature_size, self.output_features, bias=False)
         self.norm = norm_layer(self.input_feature_size)
+        if isinstance(self.norm, LayerNorm):
+            self.norm.feeds_linear = True     # its only consumer is `reduction`: fp16 rows straight from the kernel under autocast
 
     def forward(self, x, permute=False):
         if permute:
