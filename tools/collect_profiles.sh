@@ -1,13 +1,17 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r05
+#   bash tools/collect_profiles.sh r05 [primary]      (primary: only steps 1 and 2 - kernel statistics and PMC passes of the primary leg)
 # Writes under gpurun_out/ (copy what is to be judged into profiles/).  ~40 GPU-minutes.
 set -u
 TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
+# (the profiled runs time the step's kernels only: the live Dice protocol of bench.py - 100 steps at 64^3 with the same kernel
+#  names - is switched off for them)
+export NNZ_BENCH_LIVE_DICE=0
 BENCH="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-swt2net"
+ONLY=${2:-all}
 # 1. kernel trace + stats of the primary bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $BENCH > $OUT/${TAG}_bench_n1_profiled_run.json 2>/dev/null
 cp $(ls $OUT/prof_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_n1_kernel_stats.csv
@@ -22,6 +26,8 @@ cp $(ls $OUT/prof_w/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_write_s
 unset NNZ_UNET_GRAPH
 python3 $R/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv conv_box_kernel > $OUT/conv_box_kernel_hbm_traffic.json
 rm -rf $OUT/prof_stats $OUT/prof_f $OUT/prof_w
+unset NNZ_BENCH_LIVE_DICE
+if [ "$ONLY" = primary ]; then ls -la $OUT | tail -8; exit 0; fi
 # 2b. the same two passes over ONE eager step of the two zoo legs: bytes per cross-scan backward call (all its kernels) and per
 #     window-attention launch - `secondary.roofline.traffic` / `swt2net.roofline.traffic` of bench.py
 for M in M2Net SwT2Net; do
