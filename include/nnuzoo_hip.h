@@ -230,6 +230,27 @@ int nnz_crop_pad_i16(const void* const* src, const int* shapes, const int* lbs, 
 int nnz_downsample_nearest_i16(const short* src, short* dst, long nc, int id, int ih, int iw, int od, int oh, int ow,
                                void* stream);
 
+/* ---- device-side training augmentations (round 5; csrc/augment.hip) -------------------------------------------------------
+ * The interpolating / intensity transforms of nnUNetTrainer.get_training_transforms (nnUNetTrainer.py:825-973: SpatialTransform
+ * :845-852, GaussianNoiseTransform :857-863, MultiplicativeBrightnessTransform :872-878, ContrastTransform :879-886,
+ * GammaTransform :897-914, RemoveLabelTansform :929-931) on a batch resident in HBM.  The transform classes are
+ * batchgeneratorsv2's (absent from the reference tree): arithmetic restated, parity unpinned. */
+/* dst[b][c][o] = src[b][c] sampled at M_b (o - centre) + centre + shift_b; mats = B x 12 HOST floats (3 x 4, rows z y x);
+ * f32 trilinear / i16 nearest, pad_value outside; D = 1 for 2-D batches; src != dst */
+int nnz_aug_affine_f32(const float* src, float* dst, const float* mats, int B, int C, int D, int H, int W, float pad_value,
+                       void* stream);
+int nnz_aug_affine_i16(const short* src, short* dst, const float* mats, int B, int C, int D, int H, int W, int pad_value,
+                       void* stream);
+/* stats[bc] = {mean, population std, min, max} of x[bc][0..n); workspace of nnz_aug_stats_workspace_floats(nbc) floats */
+long nnz_aug_stats_workspace_floats(int nbc);
+int nnz_aug_stats_f32(const float* x, long n, int nbc, float* workspace, float* stats, void* stream);
+/* in place over x[nbc][n]; rec = device [nbc][4] {active, p0, p1, -}; op 0 noise (sigma p0), 1 linear p0 v + p1, 2 contrast
+ * (factor p0, clamp to [min, max] of stats_a), 3 gamma (exponent p0 on the [min, max] range of stats_a), 4 restore the mean / std
+ * of stats_b given the current statistics stats_a */
+int nnz_aug_intensity_f32(float* x, long n, int nbc, int op, const float* rec, const float* stats_a, const float* stats_b,
+                          unsigned seed, void* stream);
+int nnz_aug_relabel_i16(short* x, long n, int from, int to, void* stream);
+
 /* ---- x_proj of the cross-scan SS2D block on channel-major fp32 activations (the einsum of SS2D.forward_core,
  * /root/reference/nnunetv2/nets/m2net.py:179-184, in the two-source formulation of nnz_ss2d_scan_*):
  *   forward     P[s][b][c][l]   = sum_d W[s][c][d] x2[s][b][d][l]                       c < C2 <= 80, Di % 32 == 0

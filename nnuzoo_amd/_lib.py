@@ -117,6 +117,12 @@ SIGNATURES = {
     "nnz_crop_pad_f32": [_vp, _ip, _ip, _ip, _fp, _i, _i, _i, _i, _i, _f, _vp],
     "nnz_crop_pad_i16": [_vp, _ip, _ip, _ip, _fp, _i, _i, _i, _i, _i, _i, _vp],
     "nnz_downsample_nearest_i16": [_fp, _fp, _l, _i, _i, _i, _i, _i, _i, _vp],
+    "nnz_aug_affine_f32": [_fp, _fp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "nnz_aug_affine_i16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "nnz_aug_stats_workspace_floats": [_i],
+    "nnz_aug_stats_f32": [_fp, _l, _i, _fp, _fp, _vp],
+    "nnz_aug_intensity_f32": [_fp, _l, _i, _i, _fp, _fp, _fp, C.c_uint, _vp],
+    "nnz_aug_relabel_i16": [_vp, _l, _i, _i, _vp],
     "nnz_ss2d_xproj_forward": [_fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
     "nnz_ss2d_xproj_backward_x": [_fp, _fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
     "nnz_ss2d_xproj_backward_w": [_fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],
@@ -220,7 +226,7 @@ SIGNATURES = {
     "nnz_selective_scan_backward": [_fp] * 18 + [_i] * 6 + [_vp],
 }
 
-_LONG_RESULT = {"nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats", "nnz_ss2d_scan_workspace_floats",
+_LONG_RESULT = {"nnz_aug_stats_workspace_floats", "nnz_ss2d_scan_state_floats", "nnz_ss2d_scan_grad_state_floats", "nnz_ss2d_scan_workspace_floats",
                 "nnz_selective_scan_workspace_floats", "nnz_selective_scan_state_floats",
                 "nnz_selective_scan_grad_state_floats", "nnz_dwconv2d_wgrad_workspace_floats", "nnz_conv_tap_wgrad_workspace_floats",
                 "nnz_dense32_wgrad_workspace_floats", "nnz_token_linear_wgrad_workspace_floats",

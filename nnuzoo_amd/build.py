@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffast-math", "
 
 
 # Files whose results must be bit-identical to IEEE half/float arithmetic (exact division, denormals kept): no fast-math.
-STRICT_FP = {"sliding_window.hip", "input_pipeline.hip"}
+STRICT_FP = {"sliding_window.hip", "input_pipeline.hip", "augment.hip"}
 
 
 def _flags(src: str):

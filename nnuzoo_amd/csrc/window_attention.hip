@@ -109,6 +109,81 @@ __device__ __forceinline__ void stage_image(const float* src, long row_len, int 
   }
 }
 
+// The same staging in two halves, for head dims 4 / 8 / 16 / 32 (SwT2Net: 32 at every level).  stage_image's loop has a run-time
+// trip count: every iteration is token-index read (LDS round trip) -> global load -> s_waitcnt vmcnt(0) -> LDS write, i.e. the seven
+// pieces of an image were seven SERIAL L2 / HBM round trips (round 5, found in the ISA; measured worth: forward launches 5 - 12 %,
+// the ~10 us launch floor itself did not move).  Here all pieces of all images of a wave are requested first -
+// unconditionally: a padded token reads token 0 and is zeroed at the LDS write, so that no load sits in a branch of its own - and
+// written afterwards: one round trip.
+constexpr int WA_SP = (WA_L * 8 + 63) / 64;          // 16-byte pieces per lane of one image at hd = 32
+__device__ __forceinline__ bool wa_split_ok(int hd) { return hd == 4 || hd == 8 || hd == 16 || hd == 32; }
+// pieces K0 .. K1-1 of an image: requests (v), then - after the caller has requested everything it wants in flight - the writes
+template <int K0, int K1>
+__device__ __forceinline__ void fetch_image(const float* src, long row_len, int ch0, int hd, const int* stok,
+                                            f32x4 (&v)[WA_SP], int lane) {
+  const int q4 = hd >> 2, total = WA_L * q4, sh = 31 - __builtin_clz(q4);
+  int t[WA_SP];
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const int i = lane + 64 * k;
+    t[k] = stok[(i < total ? i : lane) >> sh];
+  }
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const int i = lane + 64 * k;
+    const int c4 = ((i < total ? i : lane) & (q4 - 1)) * 4;
+    // 32-bit element offset from a wave-uniform base (the tensors of a launch are far below 2^32 bytes): one address register per
+    // piece instead of a 64-bit pair and a 64-bit multiply
+    const unsigned off = (unsigned)(t[k] >= 0 ? t[k] : 0) * (unsigned)row_len + (unsigned)(ch0 + c4);
+    v[k] = *reinterpret_cast<const f32x4*>(src + off);
+  }
+}
+template <int K0, int K1>
+__device__ __forceinline__ void commit_image(const f32x4 (&v)[WA_SP], int hd, const int* stok, float mul, float* dst, int lane) {
+  const int q4 = hd >> 2, total = WA_L * q4, sh = 31 - __builtin_clz(q4);
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const int i = lane + 64 * k;
+    if (i < total) {
+      const int l = i >> sh, c4 = (i & (q4 - 1)) * 4;
+      *reinterpret_cast<f32x4*>(dst + l * WA_LD + c4) = stok[l] >= 0 ? v[k] * mul : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+// two images of one wave.  ROUNDS = 1: all 14 pieces in flight at once; 2: pieces 0..3 of both, then 4..6 (the pair kernel of the
+// backward sits at its 256-register cap: 56 registers of pieces in flight spilled)
+template <int ROUNDS>
+__device__ __forceinline__ void stage_two(const float* srcA, long rlA, int chA, const int* stokA, float mulA, float* dstA,
+                                          const float* srcB, long rlB, int chB, const int* stokB, float mulB, float* dstB,
+                                          int hd, int lane) {
+  if (wa_split_ok(hd)) {
+    f32x4 pa[WA_SP], pb[WA_SP];
+    constexpr int H = ROUNDS == 1 ? WA_SP : 4;
+    fetch_image<0, H>(srcA, rlA, chA, hd, stokA, pa, lane);
+    fetch_image<0, H>(srcB, rlB, chB, hd, stokB, pb, lane);
+    commit_image<0, H>(pa, hd, stokA, mulA, dstA, lane);
+    commit_image<0, H>(pb, hd, stokB, mulB, dstB, lane);
+    if constexpr (ROUNDS == 2) {
+      fetch_image<H, WA_SP>(srcA, rlA, chA, hd, stokA, pa, lane);
+      fetch_image<H, WA_SP>(srcB, rlB, chB, hd, stokB, pb, lane);
+      commit_image<H, WA_SP>(pa, hd, stokA, mulA, dstA, lane);
+      commit_image<H, WA_SP>(pb, hd, stokB, mulB, dstB, lane);
+    }
+  } else {
+    stage_image(srcA, rlA, chA, hd, stokA, mulA, dstA, lane);
+    stage_image(srcB, rlB, chB, hd, stokB, mulB, dstB, lane);
+  }
+}
+__device__ __forceinline__ void stage_one(const float* src, long rl, int ch, const int* stok, float mul, float* dst, int hd, int lane) {
+  if (wa_split_ok(hd)) {
+    f32x4 pa[WA_SP];
+    fetch_image<0, WA_SP>(src, rl, ch, hd, stok, pa, lane);
+    commit_image<0, WA_SP>(pa, hd, stok, mul, dst, lane);
+  } else {
+    stage_image(src, rl, ch, hd, stok, mul, dst, lane);
+  }
+}
+
 // "row" operand of one 32-token tile from an image: lane (token l31, half hh) gets channels hh*hd/2 + s, s = 0 .. hd/2 - 1
 // of its token's row (zeros for tokens >= 49): the contraction over channels visits them in this order for BOTH operands.
 // Head dims that are multiples of 8 read whole 16-byte pieces (pitch 36); others word by word.
@@ -300,8 +375,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(AttnArgs a) {
     float qv[2][16];
     load_rows_global(a.qkv, C3, head * hd, hd, stok, 0, l31, hh, a.scale, qv[0]);
     load_rows_global(a.qkv, C3, head * hd, hd, stok, 1, l31, hh, a.scale, qv[1]);
-    stage_image(a.qkv, C3, a.C + head * hd, hd, stok, 1.f, sk, lane);
-    stage_image(a.qkv, C3, 2 * a.C + head * hd, hd, stok, 1.f, sv, lane);
+    stage_two<1>(a.qkv, C3, a.C + head * hd, stok, 1.f, sk, a.qkv, C3, 2 * a.C + head * hd, stok, 1.f, sv, hd, lane);
     wave_sync();
     float kv[2][16];
     load_rows(sk, hd, 0, l31, hh, kv[0]);
@@ -365,8 +439,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_pair_kernel(AttnArgs a) {
     float qv[16];
     if (live) {
       load_rows_global(a.qkv, C3, head * hd, hd, stok, role, l31, hh, a.scale, qv);
-      if (role == 0) stage_image(a.qkv, C3, a.C + head * hd, hd, stok, 1.f, sk, lane);
-      else stage_image(a.qkv, C3, 2 * a.C + head * hd, hd, stok, 1.f, sv, lane);
+      stage_one(a.qkv, C3, (role == 0 ? a.C : 2 * a.C) + head * hd, stok, 1.f, role == 0 ? sk : sv, hd, lane);
     }
     lds_barrier();
     if (!live) continue;
@@ -669,6 +742,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
     }
     lds_barrier();
     if (live) {
+      // (the batched staging of the forward kernels is not used here: this kernel sits at its 256-register cap, the pieces in
+      //  flight spilled, and the reloads between the loads made the 2 166-problem launches 8 % slower; the launch floor did not move)
       if (role == 0) {
         stage_image(a.qkv, C3, qo, hd, stok, a.scale, sq, lane);
         stage_image(a.qkv, C3, ko, hd, stok, 1.f, sk, lane);

@@ -1,0 +1,198 @@
+"""Device-side training augmentations: the interpolating and intensity transforms of the reference's
+training chain - `nnUNetTrainer.get_training_transforms`, /root/reference/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:825-973 -
+on a batch that `nnUNetDataLoaderDevice` has just cut in HBM, as HIP launches (csrc/augment.hip), no worker processes.
+
+Order, probabilities and parameter ranges are the call site's (line numbers of nnUNetTrainer.py):
+    SpatialTransform   :845-852  p_rotation 0.2 (angles from `rotation_for_DA`), p_scaling 0.2 in (0.7, 1.4), axes synchronised,
+                                 no elastic deformation, data bi/trilinear with zeros outside, segmentation nearest with -1 outside
+    GaussianNoise      :857-863  p 0.1, variance U(0, 0.1), one draw for all channels
+    GaussianBlur       :864-871  NOT BUILT
+    MultiplicativeBrightness :872-878  p 0.15, multiplier per channel from (0.75, 1.25)
+    Contrast           :879-886  p 0.15, factor per channel from (0.75, 1.25), range preserved
+    SimulateLowResolution :887-896  NOT BUILT
+    Gamma (inverted)   :897-905  p 0.1, gamma per channel from (0.7, 1.5), mean / std retained
+    Gamma              :906-914  p 0.3, the same without the inversion
+    (MirrorTransform :915-920 is folded into the loader's crop; DownsampleSegForDS :971 follows in the loader)
+    RemoveLabelTansform(-1, 0) :929-931
+Every `RandomTransform(..., apply_probability=p)` is decided per SAMPLE (the reference's workers push one sample at a time through
+the chain).  "(lo, hi)" ranges marked BGContrast at the call site draw from [lo, 1) with probability 1/2 and from [1, hi) otherwise.
+
+The transform classes are batchgeneratorsv2's (`pyproject.toml:51`), absent from /root/reference and from this image: what each
+one computes is restated here from its published algorithm and the call site - PARITY UNPINNED; `tests/test_device_augment_gpu.py`
+holds every launch to a plain torch fp32 formulation of the same arithmetic.  Host draws use a private numpy RandomState
+(reproducible from `seed`; not the reference's torch / numpy call sequence)."""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import call, ptr, stream_ptr
+
+OP_NOISE, OP_LINEAR, OP_CONTRAST, OP_GAMMA, OP_RESTORE = 0, 1, 2, 3, 4
+
+
+def _rot3(ax: int, t: float) -> np.ndarray:
+    c, s = np.cos(t), np.sin(t)
+    m = np.eye(3)
+    i, j = [(1, 2), (0, 2), (0, 1)][ax]          # rotation in the plane of the two OTHER axes of (z, y, x)
+    m[i, i], m[i, j], m[j, i], m[j, j] = c, -s, s, c
+    return m
+
+
+class DeviceAugmenter:
+    """`data, seg = augmenter(data, seg)`: data float32 (B, C, *patch) CUDA, seg int16 (B, 1, *patch) CUDA or None; both
+    contiguous; returns tensors of the same shapes (data is transformed in place where no resampling is drawn)."""
+
+    p_rotation, p_scaling, scaling = 0.2, 0.2, (0.7, 1.4)
+    p_noise, noise_variance = 0.1, (0.0, 0.1)
+    p_brightness, brightness = 0.15, (0.75, 1.25)
+    p_contrast, contrast = 0.15, (0.75, 1.25)
+    p_gamma_inverted, p_gamma, gamma = 0.1, 0.3, (0.7, 1.5)
+
+    def __init__(self, patch_size: Sequence[int], rotation_for_DA: Tuple[float, float], do_dummy_2d_data_aug: bool = False,
+                 seed: Optional[int] = None):
+        self.patch_size = tuple(int(i) for i in patch_size)
+        self.rotation = (float(rotation_for_DA[0]), float(rotation_for_DA[1]))
+        self.dummy_2d = bool(do_dummy_2d_data_aug)
+        self.rng = np.random.RandomState(seed)
+        self.last = {}                      # what the most recent call drew (tests, logging)
+        self._ws = None
+        self._calls = 0
+
+    # ---- draws ------------------------------------------------------------------------------------------------------------
+    def _bg_range(self, r):
+        lo, hi = r
+        if self.rng.uniform() < 0.5 and lo < 1:
+            return self.rng.uniform(lo, 1.0)
+        return self.rng.uniform(max(lo, 1.0), hi)
+
+    def _draw_matrix(self, nd: int):
+        """index-space map of one sample: source = M (out - centre) + centre; None = identity (nothing drawn)"""
+        m = np.eye(3)
+        drawn = False
+        if self.rng.uniform() < self.p_rotation:
+            drawn = True
+            if nd == 2 or self.dummy_2d:
+                m = _rot3(0, self.rng.uniform(*self.rotation)) @ m          # in-plane (y, x) only
+            else:
+                for ax in range(3):
+                    m = _rot3(ax, self.rng.uniform(*self.rotation)) @ m
+        if self.rng.uniform() < self.p_scaling:
+            drawn = True
+            lo, hi = self.scaling
+            sc = self.rng.uniform(lo, 1.0) if (self.rng.uniform() < 0.5 and lo < 1) else self.rng.uniform(max(lo, 1.0), hi)
+            s = np.diag([1.0 if (nd == 2 or self.dummy_2d) else sc, sc, sc])
+            m = m @ s
+        return m if drawn else None
+
+    # ---- launches ---------------------------------------------------------------------------------------------------------
+    def _stats(self, x: torch.Tensor, nbc: int, n: int) -> torch.Tensor:
+        lib = _lib.load()
+        need = int(lib.nnz_aug_stats_workspace_floats(nbc))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.float32, device=x.device)
+        st = torch.empty((nbc, 4), dtype=torch.float32, device=x.device)
+        call("nnz_aug_stats_f32", ptr(x), n, nbc, ptr(self._ws), ptr(st), stream_ptr())
+        return st
+
+    def _op(self, x, nbc, n, op, rec: np.ndarray, sa=None, sb=None, seed=0):
+        r = torch.tensor(rec, dtype=torch.float32).to(x.device)        # (a copy: `rec` is rewritten for the next transform)
+        call("nnz_aug_intensity_f32", ptr(x), n, nbc, op, ptr(r), ptr(sa), ptr(sb), int(seed) & 0xffffffff, stream_ptr())
+
+    def __call__(self, data: torch.Tensor, seg: Optional[torch.Tensor]):
+        if not data.is_cuda or data.dtype != torch.float32 or not data.is_contiguous():
+            raise RuntimeError("DeviceAugmenter: contiguous float32 CUDA data expected (there is no CPU path)")
+        if seg is not None and (not seg.is_cuda or seg.dtype != torch.int16 or not seg.is_contiguous()):
+            raise RuntimeError("DeviceAugmenter: contiguous int16 CUDA segmentation expected")
+        B, C = data.shape[:2]
+        sp = tuple(data.shape[2:])
+        nd = len(sp)
+        D, H, W = ((1,) + sp) if nd == 2 else sp
+        n, nbc = D * H * W, B * C
+        self._calls += 1
+        last = {"matrices": [None] * B}
+        # -- SpatialTransform
+        mats = [self._draw_matrix(nd) for _ in range(B)]
+        last["matrices"] = mats
+        if any(m is not None for m in mats):
+            flat = np.zeros((B, 12), dtype=np.float32)
+            for b, m in enumerate(mats):
+                mm = np.eye(3) if m is None else m
+                flat[b].reshape(3, 4)[:, :3] = mm
+            out = torch.empty_like(data)
+            call("nnz_aug_affine_f32", ptr(data), ptr(out), flat.ctypes.data, B, C, D, H, W, 0.0, stream_ptr())
+            data = out
+            if seg is not None:
+                so = torch.empty_like(seg)
+                call("nnz_aug_affine_i16", ptr(seg), ptr(so), flat.ctypes.data, B, seg.shape[1], D, H, W, -1, stream_ptr())
+                seg = so
+        rec = np.zeros((nbc, 4), dtype=np.float32)
+
+        def per_sample(p):
+            return [self.rng.uniform() < p for _ in range(B)]
+        # -- GaussianNoise (one variance per sample, all channels)
+        on = per_sample(self.p_noise)
+        last["noise_sigma"] = [None] * B
+        if any(on):
+            rec[:] = 0
+            for b in range(B):
+                if on[b]:
+                    sig = float(np.sqrt(self.rng.uniform(*self.noise_variance)))
+                    last["noise_sigma"][b] = sig
+                    rec[b * C:(b + 1) * C, 0], rec[b * C:(b + 1) * C, 1] = 1.0, sig
+            last["noise_seed"] = int(self.rng.randint(0, 2 ** 31 - 1))
+            self._op(data, nbc, n, OP_NOISE, rec, seed=last["noise_seed"])
+        # -- MultiplicativeBrightness (per channel)
+        on = per_sample(self.p_brightness)
+        last["brightness"] = np.full((B, C), np.nan)
+        if any(on):
+            rec[:] = 0
+            for b in range(B):
+                if on[b]:
+                    for c in range(C):
+                        mlt = self._bg_range(self.brightness)
+                        last["brightness"][b, c] = mlt
+                        rec[b * C + c, :3] = (1.0, mlt, 0.0)
+            self._op(data, nbc, n, OP_LINEAR, rec)
+        # -- Contrast (per channel, range preserved)
+        on = per_sample(self.p_contrast)
+        last["contrast"] = np.full((B, C), np.nan)
+        if any(on):
+            rec[:] = 0
+            for b in range(B):
+                if on[b]:
+                    for c in range(C):
+                        f = self._bg_range(self.contrast)
+                        last["contrast"][b, c] = f
+                        rec[b * C + c, :2] = (1.0, f)
+            self._op(data, nbc, n, OP_CONTRAST, rec, sa=self._stats(data, nbc, n))
+        # -- Gamma, inverted image first (:897-905), then plain (:906-914); mean / std retained
+        for name, p, invert in (("gamma_inverted", self.p_gamma_inverted, True), ("gamma", self.p_gamma, False)):
+            on = per_sample(p)
+            last[name] = np.full((B, C), np.nan)
+            if not any(on):
+                continue
+            rec[:] = 0
+            for b in range(B):
+                if on[b]:
+                    for c in range(C):
+                        g = self._bg_range(self.gamma)
+                        last[name][b, c] = g
+                        rec[b * C + c, :2] = (1.0, g)
+            neg = rec.copy()
+            neg[:, 1], neg[:, 2] = -1.0, 0.0
+            if invert:
+                self._op(data, nbc, n, OP_LINEAR, neg)
+            before = self._stats(data, nbc, n)
+            self._op(data, nbc, n, OP_GAMMA, rec, sa=before)
+            self._op(data, nbc, n, OP_RESTORE, rec, sa=self._stats(data, nbc, n), sb=before)
+            if invert:
+                self._op(data, nbc, n, OP_LINEAR, neg)
+        # -- RemoveLabelTansform(-1, 0)
+        if seg is not None:
+            call("nnz_aug_relabel_i16", ptr(seg), seg.numel(), -1, 0, stream_ptr())
+        self.last = last
+        return data, seg

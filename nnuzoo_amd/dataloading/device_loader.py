@@ -11,8 +11,11 @@ tests/golden/dataloader_bbox.json comes from the reference's function), and the 
 
 What is covered of the reference's transform chain (nnUNetTrainer.get_training_transforms, nnUNetTrainer.py:860-973): the
 voxel-moving transforms that need no interpolation - MirrorTransform (folded into the crop's index arithmetic) and
-DownsampleSegForDSTransform.  The intensity / spatial augmentations (batchgeneratorsv2, absent from the reference tree
-and from this image: PARITY UNPINNED, not built) can be appended as `transforms`, a callable on the device batch.
+DownsampleSegForDSTransform - and, since round 5, through `augmenter=DeviceAugmenter(...)` (dataloading/device_augment.py,
+csrc/augment.hip): SpatialTransform (rotation / scaling), Gaussian noise, multiplicative brightness, contrast, both gamma
+transforms and RemoveLabel(-1 -> 0) with the call site's probabilities and ranges (batchgeneratorsv2 is absent from the reference
+tree and from this image: arithmetic restated, PARITY UNPINNED; Gaussian blur and low-resolution simulation are not built).
+Anything else can be appended as `transforms`, a callable on the device batch.
 
 Same constructor arguments and batch contract as the reference class: `{'data': float32 (B, C, *patch), 'target': int16
 tensor or list of tensors per deep-supervision scale, 'keys'}` - but the tensors are CUDA tensors, ready for train_step.
@@ -107,7 +110,7 @@ class nnUNetDataLoader:
                  oversample_foreground_percent: float = 0.0, sampling_probabilities=None, pad_sides=None,
                  probabilistic_oversampling: bool = False, transforms=None, target_type: str = "segmentation",
                  deep_supervision_scales: Optional[Sequence[Sequence[float]]] = None,
-                 mirror_axes: Optional[Tuple[int, ...]] = None):
+                 mirror_axes: Optional[Tuple[int, ...]] = None, augmenter=None):
         if target_type != "segmentation":
             raise NotImplementedError("device loader: segmentation targets only (the training hot path)")
         if not isinstance(data, DeviceCaseStore):
@@ -139,6 +142,9 @@ class nnUNetDataLoader:
         self.get_do_oversample = self._probabilistic_oversampling if probabilistic_oversampling \
             else self._oversample_last_XX_percent
         self.transforms = transforms
+        # `augmenter(data, seg) -> (data, seg)` on the full-resolution device batch, BEFORE the deep-supervision targets are cut
+        # (dataloading/device_augment.DeviceAugmenter: the reference chain's spatial / intensity transforms as HIP launches)
+        self.augmenter = augmenter
         self.deep_supervision_scales = deep_supervision_scales
         self.mirror_axes = tuple(mirror_axes) if mirror_axes else None
         first = data.data[self.indices[0]]
@@ -219,6 +225,8 @@ class nnUNetDataLoader:
         if self.patch_size_was_2d:
             data_all = data_all[:, :, 0]
             seg_all = seg_all[:, :, 0] if seg_all is not None else None
+        if self.augmenter is not None:
+            data_all, seg_all = self.augmenter(data_all.contiguous(), seg_all.contiguous() if seg_all is not None else None)
         if seg_all is not None and self.deep_supervision_scales is not None:
             seg_all = downsample_seg_for_ds(seg_all, self.deep_supervision_scales)
         batch = {'data': data_all, 'target': seg_all, 'keys': selected_keys}

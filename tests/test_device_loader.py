@@ -172,3 +172,32 @@ def test_loader_batches_and_feeds_a_train_step(hip_lib):
     batch["target"] = [t.clamp_min(0) for t in batch["target"]]
     losses = [float(tr.train_step(dl_batch)["loss"]) for dl_batch in (batch, batch)]
     assert all(np.isfinite(losses))
+
+
+@pytest.mark.gpu
+def test_loader_with_the_device_augmenter_feeds_a_train_step(hip_lib):
+    """the `augmenter` hook (dataloading/device_augment.DeviceAugmenter, csrc/augment.hip): augmented full-resolution batch, the
+    deep-supervision targets cut AFTER it (they are down-samplings of the augmented segmentation), no -1 left in the targets"""
+    from nnuzoo_amd.dataloading.device_augment import DeviceAugmenter
+    from nnuzoo_amd.dataloading.device_loader import DeviceCaseStore, nnUNetDataLoader, downsample_seg_for_ds
+    from nnuzoo_amd.synthetic import nnunet_plans
+    from nnuzoo_amd.training.nnUNetTrainer import nnUNetTrainer
+    ds = _Cases([(40, 56, 48), (36, 36, 70), (50, 34, 34)], channels=1, seed=5)
+    plans, cfg, dj = nnunet_plans(3, (32, 32, 32), batch_size=2)
+    tr = nnUNetTrainer(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    scales = tr._get_deep_supervision_scales()
+    lm = types.SimpleNamespace(all_labels=[0, 1, 2], has_ignore_label=False)
+    aug = DeviceAugmenter((32, 32, 32), (-0.5236, 0.5236), seed=3)          # rotation_for_DA of the 3-D configuration: +-30 degrees
+    aug.p_rotation = aug.p_scaling = aug.p_gamma = 1.0                        # make sure the resampling and a statistics pass run
+    dl = nnUNetDataLoader(DeviceCaseStore(ds), 2, (40, 40, 40), (32, 32, 32), lm, oversample_foreground_percent=0.33,
+                          deep_supervision_scales=scales, mirror_axes=(0, 1, 2), augmenter=aug)
+    np.random.seed(11)
+    batch = dl.generate_train_batch()
+    assert batch["data"].shape == (2, 1, 32, 32, 32) and torch.isfinite(batch["data"]).all()
+    assert all(int((t < 0).sum()) == 0 for t in batch["target"])
+    again = downsample_seg_for_ds(batch["target"][0], scales)
+    assert all(torch.equal(a, b) for a, b in zip(again, batch["target"]))
+    assert all(m is not None for m in aug.last["matrices"])
+    losses = [float(tr.train_step(batch)["loss"]) for _ in range(2)]
+    assert all(np.isfinite(losses))
