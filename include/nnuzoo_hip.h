@@ -249,6 +249,12 @@ int nnz_aug_stats_f32(const float* x, long n, int nbc, float* workspace, float* 
  * of stats_b given the current statistics stats_a */
 int nnz_aug_intensity_f32(float* x, long n, int nbc, int op, const float* rec, const float* stats_a, const float* stats_b,
                           unsigned seed, void* stream);
+/* GaussianBlurTransform (:864-871), one axis (0 z, 1 y, 2 x) per launch: rec = device [nbc][4] {active, sigma_z, sigma_y, sigma_x};
+ * taps within 3 sigma (at most 4), edge voxels repeated; inactive rows are copied; src != dst */
+int nnz_aug_blur_axis_f32(const float* src, float* dst, int nbc, int D, int H, int W, int axis, const float* rec, void* stream);
+/* SimulateLowResolutionTransform (:887-896): nearest down-sampling to round(size * scale), linear up-sampling back, one pass;
+ * rec = device [nbc][4] {active, scale, -, -}; keep_z: 2-D / dummy-2-D batches */
+int nnz_aug_lowres_f32(const float* src, float* dst, int nbc, int D, int H, int W, int keep_z, const float* rec, void* stream);
 int nnz_aug_relabel_i16(short* x, long n, int from, int to, void* stream);
 
 /* ---- x_proj of the cross-scan SS2D block on channel-major fp32 activations (the einsum of SS2D.forward_core,

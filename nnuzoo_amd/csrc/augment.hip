@@ -7,7 +7,8 @@
 // The transform classes live in batchgeneratorsv2 (pyproject.toml:51 ">=0.2"), which is neither in /root/reference nor in this
 // image: the arithmetic below restates the published algorithm of each transform from its name and the call site's parameters -
 // PARITY UNPINNED - and is tested against plain torch fp32 formulations of the same arithmetic
-// (tests/test_device_augment_gpu.py).  GaussianBlurTransform and SimulateLowResolutionTransform (:864-871, :887-896) are not built.
+// (tests/test_device_augment_gpu.py).  Also here: GaussianBlurTransform (:864-871, separable, edge-replicating) and
+// SimulateLowResolutionTransform (:887-896, nearest down / linear up in one gather pass; the package interpolates the way up with a cubic).
 // Everything here is HBM-bound streaming over a 2 x C x 128^3 batch (tens of MB): one launch per transform, statistics as a
 // fixed-order two-stage reduction (no float atomics).  Built without fast-math (build.py STRICT_FP): powf / sqrtf / division as written.
 #include "common.hpp"
@@ -188,6 +189,98 @@ __global__ __launch_bounds__(256) void aug_intensity_kernel(float* __restrict__ 
   }
 }
 
+// ---- GaussianBlurTransform (:864-871): separable Gaussian, one axis per launch, sigma per (sample, channel) and axis ----------
+// rec[bc] = {active, sigma_z, sigma_y, sigma_x}; taps k = -R .. R with R = ceil(3 sigma) (<= AUG_BLUR_R), weights exp(-k^2 / 2 sigma^2)
+// normalised over the taps; the border repeats the edge voxel.  axis: 0 = z, 1 = y, 2 = x.  src != dst.
+constexpr int AUG_BLUR_R = 4;
+__global__ __launch_bounds__(256) void aug_blur_axis_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W,
+                                                            int axis, const float* __restrict__ rec) {
+  const int bc = blockIdx.y;
+  const long n = (long)D * H * W;
+  const float* s = src + (long)bc * n;
+  float* d = dst + (long)bc * n;
+  const float sigma = rec[4 * bc + 1 + axis];
+  const bool on = rec[4 * bc] != 0.f && sigma > 0.f && (axis == 0 ? D : (axis == 1 ? H : W)) > 1;
+  float w[2 * AUG_BLUR_R + 1];
+  int R = 0;
+  if (on) {
+    R = (int)ceilf(3.f * sigma);
+    R = R < 1 ? 1 : (R > AUG_BLUR_R ? AUG_BLUR_R : R);
+    float tot = 0.f;
+    for (int k = -R; k <= R; ++k) {
+      w[k + AUG_BLUR_R] = expf(-(float)(k * k) / (2.f * sigma * sigma));
+      tot += w[k + AUG_BLUR_R];
+    }
+    for (int k = -R; k <= R; ++k) w[k + AUG_BLUR_R] /= tot;
+  }
+  const int len = axis == 0 ? D : (axis == 1 ? H : W);
+  const long stride = axis == 0 ? (long)H * W : (axis == 1 ? W : 1);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (!on) { d[i] = s[i]; continue; }
+    const int pos = (int)((i / stride) % len);
+    float acc = 0.f;
+    for (int k = -R; k <= R; ++k) {
+      int q = pos + k;
+      q = q < 0 ? 0 : (q >= len ? len - 1 : q);
+      acc += w[k + AUG_BLUR_R] * s[i + (long)(q - pos) * stride];
+    }
+    d[i] = acc;
+  }
+}
+
+// ---- SimulateLowResolutionTransform (:887-896): nearest down-sampling to round(size * scale) per axis, linear up-sampling back -
+// rec[bc] = {active, scale, -, -} (axes synchronised; 2-D / dummy-2-D: the z axis keeps its size: `keep_z`).  One gather pass: the
+// low-resolution voxel j of an axis of n voxels sits at (j + 0.5) n / m - 0.5 and holds the original voxel floor((j + 0.5) n / m).
+__device__ __forceinline__ void aug_lr_axis(int i, int n, int m, int& j0, int& j1, float& t) {
+  float p = ((float)i + 0.5f) * (float)m / (float)n - 0.5f;       // position of output voxel i on the low-resolution grid
+  p = p < 0.f ? 0.f : (p > (float)(m - 1) ? (float)(m - 1) : p);
+  j0 = (int)floorf(p);
+  j1 = j0 + 1 < m ? j0 + 1 : m - 1;
+  t = p - (float)j0;
+}
+__device__ __forceinline__ int aug_lr_src(int j, int n, int m) {
+  const int s = (int)floorf(((float)j + 0.5f) * (float)n / (float)m);
+  return s < n - 1 ? s : n - 1;
+}
+__global__ __launch_bounds__(256) void aug_lowres_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W,
+                                                         int keep_z, const float* __restrict__ rec) {
+  const int bc = blockIdx.y;
+  const long n = (long)D * H * W;
+  const float* s = src + (long)bc * n;
+  float* d = dst + (long)bc * n;
+  const float scale = rec[4 * bc + 1];
+  const bool on = rec[4 * bc] != 0.f && scale > 0.f && scale < 1.f;
+  int mz = D, my = H, mx = W;
+  if (on) {
+    if (!keep_z && D > 1) { mz = (int)rintf((float)D * scale); mz = mz < 1 ? 1 : mz; }
+    my = (int)rintf((float)H * scale); my = my < 1 ? 1 : my;
+    mx = (int)rintf((float)W * scale); mx = mx < 1 ? 1 : mx;
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (!on) { d[i] = s[i]; continue; }
+    const int x = (int)(i % W);
+    const long r = i / W;
+    const int y = (int)(r % H), z = (int)(r / H);
+    int z0, z1, y0, y1, x0, x1;
+    float tz, ty, tx;
+    aug_lr_axis(z, D, mz, z0, z1, tz);
+    aug_lr_axis(y, H, my, y0, y1, ty);
+    aug_lr_axis(x, W, mx, x0, x1, tx);
+    const int sz[2] = {aug_lr_src(z0, D, mz), aug_lr_src(z1, D, mz)};
+    const int sy[2] = {aug_lr_src(y0, H, my), aug_lr_src(y1, H, my)};
+    const int sx[2] = {aug_lr_src(x0, W, mx), aug_lr_src(x1, W, mx)};
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int oz = q >> 2, oy = (q >> 1) & 1, ox = q & 1;
+      const float wgt = (oz ? tz : 1.f - tz) * (oy ? ty : 1.f - ty) * (ox ? tx : 1.f - tx);
+      if (wgt == 0.f) continue;
+      acc += wgt * s[((long)sz[oz] * H + sy[oy]) * W + sx[ox]];
+    }
+    d[i] = acc;
+  }
+}
+
 // seg: every `from` becomes `to` (RemoveLabelTansform(-1, 0), nnUNetTrainer.py:929-931)
 __global__ __launch_bounds__(256) void aug_relabel_i16_kernel(short* __restrict__ x, long n, int from, int to) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
@@ -253,6 +346,31 @@ extern "C" int nnz_aug_intensity_f32(float* x, long n, int nbc, int op, const fl
   if (blocks > 2048) blocks = 2048;
   NNZ_LAUNCH(aug_intensity_kernel, dim3((unsigned)blocks, (unsigned)nbc), dim3(256), 0, (hipStream_t)stream, x, n, op, rec,
              stats_a, stats_b, seed);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+// one axis of the separable Gaussian blur: dst[bc] = blur_axis(src[bc]) for active rows, a copy otherwise; rec = device [nbc][4]
+// {active, sigma_z, sigma_y, sigma_x}; src != dst; x is [nbc][D][H][W]
+extern "C" int nnz_aug_blur_axis_f32(const float* src, float* dst, int nbc, int D, int H, int W, int axis, const float* rec,
+                                     void* stream) {
+  using namespace nnz;
+  if (!src || !dst || src == dst || !rec || nbc < 1 || D < 1 || H < 1 || W < 1 || axis < 0 || axis > 2) return NNZ_EINVAL;
+  long blocks = ((long)D * H * W + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  NNZ_LAUNCH(aug_blur_axis_kernel, dim3((unsigned)blocks, (unsigned)nbc), dim3(256), 0, (hipStream_t)stream, src, dst, D, H, W, axis,
+             rec);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+// low-resolution simulation: rec = device [nbc][4] {active, scale in (0, 1), -, -}; keep_z != 0: the z axis is not resampled
+extern "C" int nnz_aug_lowres_f32(const float* src, float* dst, int nbc, int D, int H, int W, int keep_z, const float* rec,
+                                  void* stream) {
+  using namespace nnz;
+  if (!src || !dst || src == dst || !rec || nbc < 1 || D < 1 || H < 1 || W < 1) return NNZ_EINVAL;
+  long blocks = ((long)D * H * W + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  NNZ_LAUNCH(aug_lowres_kernel, dim3((unsigned)blocks, (unsigned)nbc), dim3(256), 0, (hipStream_t)stream, src, dst, D, H, W, keep_z,
+             rec);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

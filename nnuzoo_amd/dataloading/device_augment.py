@@ -6,10 +6,11 @@ Order, probabilities and parameter ranges are the call site's (line numbers of n
     SpatialTransform   :845-852  p_rotation 0.2 (angles from `rotation_for_DA`), p_scaling 0.2 in (0.7, 1.4), axes synchronised,
                                  no elastic deformation, data bi/trilinear with zeros outside, segmentation nearest with -1 outside
     GaussianNoise      :857-863  p 0.1, variance U(0, 0.1), one draw for all channels
-    GaussianBlur       :864-871  NOT BUILT
+    GaussianBlur       :864-871  p 0.2, then per channel p 0.5: sigma per channel AND axis from (0.5, 1), separable, edges repeated
     MultiplicativeBrightness :872-878  p 0.15, multiplier per channel from (0.75, 1.25)
     Contrast           :879-886  p 0.15, factor per channel from (0.75, 1.25), range preserved
-    SimulateLowResolution :887-896  NOT BUILT
+    SimulateLowResolution :887-896  p 0.25, then per channel p 0.5: scale from (0.5, 1) for all axes, nearest down / linear up
+                                 (the package goes up with a cubic)
     Gamma (inverted)   :897-905  p 0.1, gamma per channel from (0.7, 1.5), mean / std retained
     Gamma              :906-914  p 0.3, the same without the inversion
     (MirrorTransform :915-920 is folded into the loader's crop; DownsampleSegForDS :971 follows in the loader)
@@ -48,8 +49,10 @@ class DeviceAugmenter:
 
     p_rotation, p_scaling, scaling = 0.2, 0.2, (0.7, 1.4)
     p_noise, noise_variance = 0.1, (0.0, 0.1)
+    p_blur, p_blur_per_channel, blur_sigma = 0.2, 0.5, (0.5, 1.0)
     p_brightness, brightness = 0.15, (0.75, 1.25)
     p_contrast, contrast = 0.15, (0.75, 1.25)
+    p_lowres, p_lowres_per_channel, lowres_scale = 0.25, 0.5, (0.5, 1.0)
     p_gamma_inverted, p_gamma, gamma = 0.1, 0.3, (0.7, 1.5)
 
     def __init__(self, patch_size: Sequence[int], rotation_for_DA: Tuple[float, float], do_dummy_2d_data_aug: bool = False,
@@ -145,6 +148,28 @@ class DeviceAugmenter:
                     rec[b * C:(b + 1) * C, 0], rec[b * C:(b + 1) * C, 1] = 1.0, sig
             last["noise_seed"] = int(self.rng.randint(0, 2 ** 31 - 1))
             self._op(data, nbc, n, OP_NOISE, rec, seed=last["noise_seed"])
+        # -- GaussianBlur (per channel with probability 0.5; sigma per channel and axis)
+        on = per_sample(self.p_blur)
+        last["blur_sigma"] = np.full((B, C, 3), np.nan)
+        if any(on):
+            rec[:] = 0
+            for b in range(B):
+                if on[b]:
+                    for c in range(C):
+                        if self.rng.uniform() < self.p_blur_per_channel:
+                            sg = [self.rng.uniform(*self.blur_sigma) for _ in range(3)]
+                            if nd == 2 or self.dummy_2d:
+                                sg[0] = 0.0
+                            last["blur_sigma"][b, c] = sg
+                            rec[b * C + c] = (1.0, *sg)
+            if rec[:, 0].any():
+                r = torch.tensor(rec, dtype=torch.float32).to(data.device)
+                tmp = torch.empty_like(data)
+                for axis in range(3):
+                    if (D, H, W)[axis] == 1:
+                        continue
+                    call("nnz_aug_blur_axis_f32", ptr(data), ptr(tmp), nbc, D, H, W, axis, ptr(r), stream_ptr())
+                    data, tmp = tmp, data
         # -- MultiplicativeBrightness (per channel)
         on = per_sample(self.p_brightness)
         last["brightness"] = np.full((B, C), np.nan)
@@ -169,6 +194,23 @@ class DeviceAugmenter:
                         last["contrast"][b, c] = f
                         rec[b * C + c, :2] = (1.0, f)
             self._op(data, nbc, n, OP_CONTRAST, rec, sa=self._stats(data, nbc, n))
+        # -- SimulateLowResolution (per channel with probability 0.5; one scale for all axes)
+        on = per_sample(self.p_lowres)
+        last["lowres_scale"] = np.full((B, C), np.nan)
+        if any(on):
+            rec[:] = 0
+            for b in range(B):
+                if on[b]:
+                    for c in range(C):
+                        if self.rng.uniform() < self.p_lowres_per_channel:
+                            sc = self.rng.uniform(*self.lowres_scale)
+                            last["lowres_scale"][b, c] = sc
+                            rec[b * C + c, :2] = (1.0, sc)
+            if rec[:, 0].any():
+                r = torch.tensor(rec, dtype=torch.float32).to(data.device)
+                out = torch.empty_like(data)
+                call("nnz_aug_lowres_f32", ptr(data), ptr(out), nbc, D, H, W, int(nd == 2 or self.dummy_2d), ptr(r), stream_ptr())
+                data = out
         # -- Gamma, inverted image first (:897-905), then plain (:906-914); mean / std retained
         for name, p, invert in (("gamma_inverted", self.p_gamma_inverted, True), ("gamma", self.p_gamma, False)):
             on = per_sample(p)

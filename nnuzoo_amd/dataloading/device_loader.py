@@ -12,9 +12,9 @@ tests/golden/dataloader_bbox.json comes from the reference's function), and the 
 What is covered of the reference's transform chain (nnUNetTrainer.get_training_transforms, nnUNetTrainer.py:860-973): the
 voxel-moving transforms that need no interpolation - MirrorTransform (folded into the crop's index arithmetic) and
 DownsampleSegForDSTransform - and, since round 5, through `augmenter=DeviceAugmenter(...)` (dataloading/device_augment.py,
-csrc/augment.hip): SpatialTransform (rotation / scaling), Gaussian noise, multiplicative brightness, contrast, both gamma
-transforms and RemoveLabel(-1 -> 0) with the call site's probabilities and ranges (batchgeneratorsv2 is absent from the reference
-tree and from this image: arithmetic restated, PARITY UNPINNED; Gaussian blur and low-resolution simulation are not built).
+csrc/augment.hip): SpatialTransform (rotation / scaling), Gaussian noise, Gaussian blur, multiplicative brightness, contrast, low-resolution
+simulation, both gamma transforms and RemoveLabel(-1 -> 0) with the call site's probabilities and ranges (batchgeneratorsv2 is absent from the reference
+tree and from this image: arithmetic restated, PARITY UNPINNED), Gaussian blur and low-resolution simulation included.
 Anything else can be appended as `transforms`, a callable on the device batch.
 
 Same constructor arguments and batch contract as the reference class: `{'data': float32 (B, C, *patch), 'target': int16

@@ -159,10 +159,78 @@ def test_statistics_and_intensity_transforms(hip_lib):
     assert torch.equal(a[~on], x0[~on])
 
 
+def test_blur_and_low_resolution(hip_lib):
+    nbc, D, H, W = 4, 10, 14, 12
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(nbc, D, H, W, generator=g)
+    x = x0.to(DEV)
+    rec = torch.tensor([[1, 0.6, 0.9, 0.75], [0, 1, 1, 1], [1, 0.5, 0.0, 1.0], [1, 1.0, 1.0, 1.0]])
+    r = rec.to(DEV)
+    cur = x
+    for axis in range(3):
+        out = torch.empty_like(cur)
+        call("nnz_aug_blur_axis_f32", ptr(cur), ptr(out), nbc, D, H, W, axis, ptr(r), stream_ptr())
+        cur = out
+    got = cur.cpu()
+    want = x0.clone()
+    for bc in range(nbc):
+        if rec[bc, 0] == 0:
+            continue
+        v = x0[bc]
+        for axis in range(3):
+            sg = float(rec[bc, 1 + axis])
+            if sg <= 0:
+                continue
+            R = min(4, max(1, math.ceil(3 * sg)))
+            k = torch.arange(-R, R + 1, dtype=torch.float32)
+            w = torch.exp(-k * k / (2 * sg * sg))
+            w = w / w.sum()
+            n = v.shape[axis]
+            idx = (torch.arange(n)[:, None] + k.long()[None]).clamp(0, n - 1)          # (n, taps): edge voxels repeated
+            v = (v.movedim(axis, -1)[..., idx] * w).sum(-1).movedim(-1, axis)
+        want[bc] = v
+    assert torch.equal(got[1], x0[1])
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    # low resolution: nearest down to round(n * scale), linear up (positions (j + 0.5) n / m - 0.5, clamped)
+    rec = torch.tensor([[1, 0.5, 0, 0], [0, 0.7, 0, 0], [1, 0.83, 0, 0], [1, 1.0, 0, 0]])
+    r = rec.to(DEV)
+    out = torch.empty_like(x)
+    call("nnz_aug_lowres_f32", ptr(x), ptr(out), nbc, D, H, W, 0, ptr(r), stream_ptr())
+    got = out.cpu()
+    assert torch.equal(got[1], x0[1]) and torch.equal(got[3], x0[3])               # inactive row; scale 1 = nothing to do
+
+    def axis_maps(n, sc):
+        m = max(1, int(np.rint(np.float32(n) * np.float32(sc))))
+        j = np.arange(m, dtype=np.float32)
+        src = np.minimum(np.floor((j + np.float32(0.5)) * np.float32(n) / np.float32(m)).astype(np.int64), n - 1)
+        i = np.arange(n, dtype=np.float32)
+        p = np.clip((i + np.float32(0.5)) * np.float32(m) / np.float32(n) - np.float32(0.5), 0, m - 1).astype(np.float32)
+        j0 = np.floor(p).astype(np.int64)
+        j1 = np.minimum(j0 + 1, m - 1)
+        return src, j0, j1, torch.from_numpy((p - j0).astype(np.float32))
+    for bc in (0, 2):
+        sc = float(rec[bc, 1])
+        v = x0[bc]
+        for axis, n in enumerate((D, H, W)):
+            src, j0, j1, t = axis_maps(n, sc)
+            low = v.movedim(axis, -1)[..., src]
+            v = (low[..., j0] * (1 - t) + low[..., j1] * t).movedim(-1, axis)
+        assert torch.allclose(got[bc], v, rtol=1e-5, atol=1e-5)
+    out2 = torch.empty_like(x)
+    call("nnz_aug_lowres_f32", ptr(x), ptr(out2), nbc, D, H, W, 1, ptr(r), stream_ptr())      # keep_z: planes stay separate
+    v = x0[0]
+    for axis, n in ((1, H), (2, W)):
+        src, j0, j1, t = axis_maps(n, 0.5)
+        low = v.movedim(axis, -1)[..., src]
+        v = (low[..., j0] * (1 - t) + low[..., j1] * t).movedim(-1, axis)
+    assert torch.allclose(out2.cpu()[0], v, rtol=1e-5, atol=1e-5)
+
+
 def test_augmenter_chain_and_loader_hook(hip_lib):
     from nnuzoo_amd.dataloading.device_augment import DeviceAugmenter
     aug = DeviceAugmenter((32, 32, 32), (-0.5, 0.5), seed=11)
     aug.p_rotation = aug.p_scaling = aug.p_noise = aug.p_brightness = aug.p_contrast = aug.p_gamma = aug.p_gamma_inverted = 1.0
+    aug.p_blur = aug.p_blur_per_channel = aug.p_lowres = aug.p_lowres_per_channel = 1.0
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 2, 32, 32, 32, generator=g).to(DEV)
     seg = torch.randint(-1, 3, (2, 1, 32, 32, 32), generator=g).to(torch.int16).to(DEV)
@@ -170,9 +238,11 @@ def test_augmenter_chain_and_loader_hook(hip_lib):
     assert y.shape == x.shape and s.shape == seg.shape and torch.isfinite(y).all()
     assert int((s == -1).sum()) == 0 and set(torch.unique(s).tolist()) <= {0, 1, 2}
     assert all(m is not None for m in aug.last["matrices"]) and np.isfinite(aug.last["gamma"]).all()
+    assert np.isfinite(aug.last["blur_sigma"]).all() and np.isfinite(aug.last["lowres_scale"]).all()
     # nothing drawn: data untouched, only the -1 label is rewritten
     aug0 = DeviceAugmenter((32, 32, 32), (-0.5, 0.5), seed=1)
     aug0.p_rotation = aug0.p_scaling = aug0.p_noise = aug0.p_brightness = aug0.p_contrast = aug0.p_gamma = aug0.p_gamma_inverted = 0.0
+    aug0.p_blur = aug0.p_lowres = 0.0
     y0, s0 = aug0(x.clone(), seg.clone())
     assert torch.equal(y0, x) and torch.equal(s0, torch.where(seg == -1, torch.zeros_like(seg), seg))
     # same seed, same batch -> same result; default probabilities over many samples hit the call site's rates
