@@ -248,7 +248,7 @@ int nnz_aug_stats_f32(const float* x, long n, int nbc, float* workspace, float* 
  * (factor p0, clamp to [min, max] of stats_a), 3 gamma (exponent p0 on the [min, max] range of stats_a), 4 restore the mean / std
  * of stats_b given the current statistics stats_a */
 int nnz_aug_intensity_f32(float* x, long n, int nbc, int op, const float* rec, const float* stats_a, const float* stats_b,
-                          unsigned seed, void* stream);
+                          int seed, void* stream);
 /* GaussianBlurTransform (:864-871), one axis (0 z, 1 y, 2 x) per launch: rec = device [nbc][4] {active, sigma_z, sigma_y, sigma_x};
  * taps within 3 sigma (at most 4), edge voxels repeated; inactive rows are copied; src != dst */
 int nnz_aug_blur_axis_f32(const float* src, float* dst, int nbc, int D, int H, int W, int axis, const float* rec, void* stream);

@@ -121,7 +121,7 @@ SIGNATURES = {
     "nnz_aug_affine_i16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "nnz_aug_stats_workspace_floats": [_i],
     "nnz_aug_stats_f32": [_fp, _l, _i, _fp, _fp, _vp],
-    "nnz_aug_intensity_f32": [_fp, _l, _i, _i, _fp, _fp, _fp, C.c_uint, _vp],
+    "nnz_aug_intensity_f32": [_fp, _l, _i, _i, _fp, _fp, _fp, _i, _vp],
     "nnz_aug_relabel_i16": [_vp, _l, _i, _i, _vp],
     "nnz_aug_blur_axis_f32": [_fp, _fp, _i, _i, _i, _i, _i, _fp, _vp],
     "nnz_aug_lowres_f32": [_fp, _fp, _i, _i, _i, _i, _i, _fp, _vp],

@@ -337,7 +337,7 @@ extern "C" int nnz_aug_stats_f32(const float* x, long n, int nbc, float* workspa
 // in place over x[nbc][n]; rec: DEVICE [nbc][4] = {active, p0, p1, -}; stats_a / stats_b: device [nbc][4] from nnz_aug_stats_f32
 // (may be NULL for ops that do not read them); op: 0 noise, 1 linear, 2 contrast, 3 gamma, 4 restore statistics (see above)
 extern "C" int nnz_aug_intensity_f32(float* x, long n, int nbc, int op, const float* rec, const float* stats_a,
-                                     const float* stats_b, unsigned seed, void* stream) {
+                                     const float* stats_b, int seed, void* stream) {
   using namespace nnz;
   if (!x || !rec || n < 1 || nbc < 1 || op < 0 || op > 4) return NNZ_EINVAL;
   if ((op == 2 || op == 3 || op == 4) && !stats_a) return NNZ_EINVAL;
@@ -345,7 +345,7 @@ extern "C" int nnz_aug_intensity_f32(float* x, long n, int nbc, int op, const fl
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   NNZ_LAUNCH(aug_intensity_kernel, dim3((unsigned)blocks, (unsigned)nbc), dim3(256), 0, (hipStream_t)stream, x, n, op, rec,
-             stats_a, stats_b, seed);
+             stats_a, stats_b, (unsigned)seed);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -103,7 +103,7 @@ class DeviceAugmenter:
 
     def _op(self, x, nbc, n, op, rec: np.ndarray, sa=None, sb=None, seed=0):
         r = torch.tensor(rec, dtype=torch.float32).to(x.device)        # (a copy: `rec` is rewritten for the next transform)
-        call("nnz_aug_intensity_f32", ptr(x), n, nbc, op, ptr(r), ptr(sa), ptr(sb), int(seed) & 0xffffffff, stream_ptr())
+        call("nnz_aug_intensity_f32", ptr(x), n, nbc, op, ptr(r), ptr(sa), ptr(sb), int(seed) & 0x7fffffff, stream_ptr())
 
     def __call__(self, data: torch.Tensor, seg: Optional[torch.Tensor]):
         if not data.is_cuda or data.dtype != torch.float32 or not data.is_contiguous():
