@@ -30,6 +30,21 @@
 //     fixed-point integers (common.hpp FxAcc) - no float atomics anywhere.
 #include "common.hpp"
 
+// -DNNZ_WA_TIMESTAMPS=1 (tools/probes/wa_phase_probe.py builds its own library with it; never the shipped one): thread 0 of every
+// workgroup of win_attn_bwd_pair_kernel records s_memtime at its phase boundaries into g_wa_ts[workgroup][16]
+#ifndef NNZ_WA_TIMESTAMPS
+#define NNZ_WA_TIMESTAMPS 0
+#endif
+#if NNZ_WA_TIMESTAMPS
+__device__ unsigned long long* g_wa_ts_dev = nullptr;
+#define NNZ_WA_TS(slot)                                                                                        \
+  do {                                                                                                         \
+    if (g_wa_ts_dev && threadIdx.x == 0) g_wa_ts_dev[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define NNZ_WA_TS(slot) do {} while (0)
+#endif
+
 namespace nnz {
 
 constexpr int WA_L = 49;   // tokens per window
@@ -699,6 +714,7 @@ static_assert(WA_L * WA_DSP <= WA_IMG, "a dS tile must fit the image it replaces
 constexpr int WA_PAIR_FLOATS = 4 * WA_IMG + 3 * 64 + 3 * 64;  // sq sk sv sdo (sk / sv double as the dS tiles) | srow[3][64] | stok, sreg, sutok
 
 __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
+  NNZ_WA_TS(0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sbT = smem;                                   // [49][64]
   float* sdb_all = smem + WA_L * WA_BP;                // [4 waves][176]
@@ -723,12 +739,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   int* sutok = sreg + 64;      // token index on the unpadded grid of out / dout, -1 = a padded token
   float* sdb = sdb_all + wave * 176;
   const int qo = head * hd, ko = a.C + head * hd, vo = 2 * a.C + head * hd;
+  NNZ_WA_TS(1);
   stage_bias(a, head, sbT, wbase, tid, 256);   // wbase: image space, unused until the barrier below
   // the wave's share of the bias-table gradient: lane owns table entries lane, lane + 64, lane + 128
   float db_acc[3] = {0.f, 0.f, 0.f};
   __syncthreads();
   const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
   const int iters = (a.wpb + 1) / 2;
+  NNZ_WA_TS(2);
   for (int it = 0; it < iters; ++it) {
     const int win = blockIdx.x * a.wpb + pair + 2 * it;
     const bool live = win < w_end;
@@ -754,6 +772,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
     }
     lds_barrier();
 
+    if (it == 0) NNZ_WA_TS(3);
     // ---------------- pass A: keys on rows, queries on lanes --------------------------------------------------------
     if (live) {
       const int tq = role;
@@ -807,6 +826,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
       }
       if (i < WA_L) store_cols(a.dqkv + (long)stok[i] * C3 + qo, o, hh, hd, a.scale);
     }
+    if (it == 0) NNZ_WA_TS(4);
     lds_barrier();  // srow is complete (both query tiles)
 
     // ---------------- pass B: queries on rows, keys on lanes ---------------------------------------------------------
@@ -817,6 +837,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
       load_rows(sv, hd, role, l31, hh, vvB);
     }
     lds_barrier();  // both waves hold their K / V rows: the two images become the dS tiles
+    if (it == 0) NNZ_WA_TS(5);
     if (live) {
       const int tk = role;
       f32x16 s[2], dp[2];  // [tq]
@@ -904,6 +925,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
       }
     }
   }
+  NNZ_WA_TS(6);
   // ---- fold the four waves in wave order, one fixed-point add per table entry and workgroup, last workgroup writes ------
 #pragma unroll
   for (int e = 0; e < 3; ++e)
@@ -927,6 +949,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   unsigned* ticket = reinterpret_cast<unsigned*>(a.acc[(long)FX_REP * nrec + head].w);
   if (last_workgroup(ticket, gridDim.x) && tid < WA_NBIAS)
     a.dbias[tid * a.heads + head] = (float)fx_take(a.acc, (long)head * WA_NBIAS + tid, nrec);
+  NNZ_WA_TS(7);
 }
 
 static int check(const AttnArgs& a) {
@@ -944,6 +967,12 @@ static int windows_per_wg(int nwin, int heads) {
 }
 
 }  // namespace nnz
+
+#if NNZ_WA_TIMESTAMPS
+extern "C" int nnz_wa_set_timestamps(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wa_ts_dev), &buf, sizeof(buf));
+}
+#endif
 
 static int wa_forward(const float* qkv, const float* bias_table, const int* bias_index, float* out, int B, int H, int W, int C,
                       int heads, int shift, float scale, int py, int px, void* stream) {
