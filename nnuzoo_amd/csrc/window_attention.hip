@@ -668,12 +668,22 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(AttnArgs a) {
           const int dy = bx / 13 - 6, dx = bx % 13 - 6;
           const int y0 = dy > 0 ? dy : 0, y1 = dy < 0 ? WA_WS + dy : WA_WS;
           const int x0 = dx > 0 ? dx : 0, x1 = dx < 0 ? WA_WS + dx : WA_WS;
+          // (round 5, phase probe: this loop was a chain of up to ~90 dependent LDS reads on the lane that owns displacement (0, 0).
+          //  The seven reads of a row are now independent - invalid members read column 0 and add 0.0f, so the sum is the same
+          //  bits as before: members in (yi, xi) order)
           float t = 0.f;
-          for (int yi = y0; yi < y1; ++yi)
-            for (int xi = x0; xi < x1; ++xi) {
-              const int i = yi * WA_WS + xi, jj = (yi - dy) * WA_WS + (xi - dx) - 32 * tk;
-              if (jj >= 0 && jj < 32) t += sds[i * WA_DSP + jj];
+          for (int yi = y0; yi < y1; ++yi) {
+            float v[WA_WS];
+#pragma unroll
+            for (int xi = 0; xi < WA_WS; ++xi) {
+              const int jj = (yi - dy) * WA_WS + (xi - dx) - 32 * tk;
+              const bool ok = xi >= x0 && xi < x1 && jj >= 0 && jj < 32;
+              const float r = sds[(yi * WA_WS + xi) * WA_DSP + (ok ? jj : 0)];
+              v[xi] = ok ? r : 0.f;
             }
+#pragma unroll
+            for (int xi = 0; xi < WA_WS; ++xi) t += v[xi];
+          }
           db_acc[e] += t;
         }
       }
@@ -914,12 +924,22 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
           const int dy = bx / 13 - 6, dx = bx % 13 - 6;
           const int y0 = dy > 0 ? dy : 0, y1 = dy < 0 ? WA_WS + dy : WA_WS;
           const int x0 = dx > 0 ? dx : 0, x1 = dx < 0 ? WA_WS + dx : WA_WS;
+          // (round 5, phase probe: this loop was a chain of up to ~90 dependent LDS reads on the lane that owns displacement (0, 0).
+          //  The seven reads of a row are now independent - invalid members read column 0 and add 0.0f, so the sum is the same
+          //  bits as before: members in (yi, xi) order)
           float t = 0.f;
-          for (int yi = y0; yi < y1; ++yi)
-            for (int xi = x0; xi < x1; ++xi) {
-              const int i = yi * WA_WS + xi, jj = (yi - dy) * WA_WS + (xi - dx) - 32 * tk;
-              if (jj >= 0 && jj < 32) t += sds[i * WA_DSP + jj];
+          for (int yi = y0; yi < y1; ++yi) {
+            float v[WA_WS];
+#pragma unroll
+            for (int xi = 0; xi < WA_WS; ++xi) {
+              const int jj = (yi - dy) * WA_WS + (xi - dx) - 32 * tk;
+              const bool ok = xi >= x0 && xi < x1 && jj >= 0 && jj < 32;
+              const float r = sds[(yi * WA_WS + xi) * WA_DSP + (ok ? jj : 0)];
+              v[xi] = ok ? r : 0.f;
             }
+#pragma unroll
+            for (int xi = 0; xi < WA_WS; ++xi) t += v[xi];
+          }
           db_acc[e] += t;
         }
       }
