@@ -201,3 +201,33 @@ def test_loader_with_the_device_augmenter_feeds_a_train_step(hip_lib):
     assert all(m is not None for m in aug.last["matrices"])
     losses = [float(tr.train_step(batch)["loss"]) for _ in range(2)]
     assert all(np.isfinite(losses))
+
+
+def test_augmenter_host_draws():
+    """the host half of DeviceAugmenter (no GPU): drawn maps are rotation x isotropic scale inside the call site's ranges
+    (nnUNetTrainer.py:845-852), 2-D / dummy-2-D patches only turn in-plane, BGContrast ranges split at 1, draws repeat per seed"""
+    from nnuzoo_amd.dataloading.device_augment import DeviceAugmenter
+    a = DeviceAugmenter((32, 32, 32), (-0.5236, 0.5236), seed=1)
+    a.p_rotation = a.p_scaling = 1.0
+    for _ in range(50):
+        m = a._draw_matrix(3)
+        g = m @ m.T                                    # (R S)(R S)^T = s^2 I
+        s2 = g[0, 0]
+        assert np.allclose(g, s2 * np.eye(3), atol=1e-9) and 0.7 ** 2 - 1e-9 <= s2 <= 1.4 ** 2 + 1e-9
+        assert np.linalg.det(m) > 0
+    b = DeviceAugmenter((64, 64), (-3.14159, 3.14159), seed=2)
+    b.p_rotation = b.p_scaling = 1.0
+    for dummy in (False, True):
+        b.dummy_2d = dummy
+        m = b._draw_matrix(3 if dummy else 2)
+        assert m[0, 0] == 1.0 and np.all(m[0, 1:] == 0) and np.all(m[1:, 0] == 0)       # the z axis is left alone
+        assert 0.7 - 1e-9 <= np.sqrt(np.linalg.det(m[1:, 1:])) <= 1.4 + 1e-9
+    c = DeviceAugmenter((8, 8), (0, 0), seed=3)
+    draws = np.array([c._bg_range((0.75, 1.25)) for _ in range(4000)])
+    assert draws.min() >= 0.75 and draws.max() <= 1.25 and abs((draws < 1).mean() - 0.5) < 0.04
+    d1, d2 = DeviceAugmenter((8, 8), (-1, 1), seed=9), DeviceAugmenter((8, 8), (-1, 1), seed=9)
+    d1.p_rotation = d2.p_rotation = 1.0
+    assert all(np.array_equal(d1._draw_matrix(2), d2._draw_matrix(2)) for _ in range(5))
+    e = DeviceAugmenter((8, 8), (-1, 1), seed=4)
+    none = sum(e._draw_matrix(2) is None for _ in range(4000)) / 4000
+    assert abs(none - 0.64) < 0.03                      # (1 - 0.2)(1 - 0.2): neither rotation nor scaling drawn
