@@ -757,7 +757,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
   const int iters = (a.wpb + 1) / 2;
   NNZ_WA_TS(2);
+  const int lane_outer = lane;
   for (int it = 0; it < iters; ++it) {
+    // lane-derived values are recomputed per window: hoisted out of this loop they (LDS offsets of every row / column read
+    // below) held enough registers across it that the image pieces in flight spilled
+    int lane = lane_outer;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, hh = lane >> 5;
     const int win = blockIdx.x * a.wpb + pair + 2 * it;
     const bool live = win < w_end;
     lds_barrier();   // the previous window's readers are done with the images / stok / sreg
@@ -772,13 +778,9 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
     if (live) {
       // (the batched staging of the forward kernels is not used here: this kernel sits at its 256-register cap, the pieces in
       //  flight spilled, and the reloads between the loads made the 2 166-problem launches 8 % slower; the launch floor did not move)
-      if (role == 0) {
-        stage_image(a.qkv, C3, qo, hd, stok, a.scale, sq, lane);
-        stage_image(a.qkv, C3, ko, hd, stok, 1.f, sk, lane);
-      } else {
-        stage_image(a.qkv, C3, vo, hd, stok, 1.f, sv, lane);
-        stage_image(a.dout, a.C, qo, hd, sutok, 1.f, sdo, lane);
-      }
+      stage_two<1>(a.qkv, C3, role == 0 ? qo : vo, stok, role == 0 ? a.scale : 1.f, role == 0 ? sq : sv,
+                   role == 0 ? a.qkv : a.dout, role == 0 ? (long)C3 : (long)a.C, role == 0 ? ko : qo, role == 0 ? stok : sutok, 1.f,
+                   role == 0 ? sk : sdo, hd, lane);
     }
     lds_barrier();
 
