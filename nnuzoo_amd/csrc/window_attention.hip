@@ -991,7 +991,7 @@ static int windows_per_wg(int nwin, int heads) {
 }  // namespace nnz
 
 #if NNZ_WA_TIMESTAMPS
-extern "C" int nnz_wa_set_timestamps(void* buf) {
+extern "C" int wa_probe_set_timestamps(void* buf) {   // (probe builds only: not part of the C-ABI of include/nnuzoo_hip.h)
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wa_ts_dev), &buf, sizeof(buf));
 }
 #endif

@@ -39,7 +39,7 @@ def main():
     from nnuzoo_amd._lib import call, ptr, stream_ptr
     from nnuzoo_amd.hip_ops import det_scratch
     raw = C.CDLL(LIB)
-    raw.nnz_wa_set_timestamps.argtypes = [C.c_void_p]
+    raw.wa_probe_set_timestamps.argtypes = [C.c_void_p]
     ar = torch.arange(7)
     yy, xx = torch.meshgrid(ar, ar, indexing="ij")
     y, x = yy.flatten(), xx.flatten()
@@ -59,7 +59,7 @@ def main():
         def run():
             call("nnz_window_attention_backward", ptr(qkv), ptr(table), ptr(idx), ptr(dout), ptr(dqkv), ptr(dtable), ptr(sc.acc),
                  ptr(sc.counter), B, H, H, Cc, heads, 0, hd ** -0.5, stream_ptr())
-        raw.nnz_wa_set_timestamps(None)
+        raw.wa_probe_set_timestamps(None)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -70,10 +70,10 @@ def main():
         e.record()
         torch.cuda.synchronize()
         us = s.elapsed_time(e) / 20 * 1e3
-        raw.nnz_wa_set_timestamps(C.c_void_p(ts.data_ptr()))
+        raw.wa_probe_set_timestamps(C.c_void_p(ts.data_ptr()))
         run()
         torch.cuda.synchronize()
-        raw.nnz_wa_set_timestamps(None)
+        raw.wa_probe_set_timestamps(None)
         t = ts.cpu().numpy()
         live = t[:, 7] > 0
         t = t[live]
