@@ -230,12 +230,25 @@ class GraphedDDPStep:
                 begin()
 
         red.capture_boundary = boundary
+        done = False
         try:
             with torch.cuda.stream(side):
                 begin()
                 self.static_loss = self._fwd_bwd(self.static_data, self.static_target)
+            done = True
         finally:
             red.capture_boundary = None
+            if not done:
+                # an exception between begin() and the final boundary: the open capture is ended (its graph dropped)
+                # and nothing half-captured survives - the next call captures from scratch
+                g = cur["g"]
+                try:
+                    with torch.cuda.stream(side):
+                        if g is not None and torch.cuda.is_current_stream_capturing():
+                            g.capture_end()
+                except Exception:        # the original exception is the one to surface
+                    pass
+                self.segments, self.slices, self._key = [], [], None
         torch.cuda.current_stream().wait_stream(side)
         self._static_arena = (net._last_arena, net._arena_layout, net._last_unused)
         self._key = (tuple(data.shape), tuple(tuple(t.shape) for t in target))
