@@ -747,12 +747,17 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   int* stok = reinterpret_cast<int*>(srow + 3 * 64);
   int* sreg = stok + 64;
   int* sutok = sreg + 64;      // token index on the unpadded grid of out / dout, -1 = a padded token
-  float* sdb = sdb_all + wave * 176;
   const int qo = head * hd, ko = a.C + head * hd, vo = 2 * a.C + head * hd;
   NNZ_WA_TS(1);
   stage_bias(a, head, sbT, wbase, tid, 256);   // wbase: image space, unused until the barrier below
   // the wave's share of the bias-table gradient: lane owns table entries lane, lane + 64, lane + 128
-  float db_acc[3] = {0.f, 0.f, 0.f};
+  // the workgroup's share of the bias-table gradient: ONE table of 169 fixed-point sums in LDS (2^-40 units, 64-bit integer adds:
+  // associative, so the order the four waves' adds arrive in does not matter - bit-identical run to run).  Every dS value goes
+  // to its entry with one ds_add_u64 (the 64 lanes of an instruction hold distinct keys: at most 2-way conflicts between the two
+  // half-waves' rows) - 32 instructions per wave and window instead of the dS tile through LDS and a loop of per-entry sums
+  // (phase probe, round 5: that loop was the largest single piece of pass B)
+  unsigned long long* sfx = reinterpret_cast<unsigned long long*>(sdb_all);
+  if (tid < 176) sfx[tid] = 0ull;
   __syncthreads();
   const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
   const int iters = (a.wpb + 1) / 2;
@@ -876,6 +881,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
       }
       const int j = tk * 32 + l31;
       const int jc = j < WA_L ? j : WA_L - 1;
+      const int yj = (jc * 37) >> 8, xj = jc - 7 * yj;
       const int reg_j = a.shift ? sreg[jc] : 0;
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq)
@@ -891,7 +897,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
           }
           s[tq][r] = pv;    // P[query][key]
           dp[tq][r] = ds;   // dS[query][key]
-          if (i < WA_L) sds[i * WA_DSP + l31] = ds;
+          if (i < WA_L && j < WA_L) {
+            // entry (yi - yj + 6) * 13 + (xi - xj + 6); i / 7 = (i * 37) >> 8 for i < 64
+            const int yi = (i * 37) >> 8, xi = i - 7 * yi;
+            atomicAdd(sfx + ((yi - yj + 6) * 13 + (xi - xj + 6)), (unsigned long long)(long long)__float2ll_rn(ds * 0x1p40f));
+          }
         }
       // dV^T[c][key] = sum_query dO[query][c] P[query][key];  dK^T[c][key] = sum_query Qs[query][c] dS[query][key]
       f32x16 ov, ok;
@@ -916,51 +926,19 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
         store_cols(dst + ko, ok, hh, hd, 1.f);
         store_cols(dst + vo, ov, hh, hd, 1.f);
       }
-      // bias-table gradient, this key tile's share: every table entry sums its members (i, j) in raster order of i
-      wave_sync();
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        const int bx = lane + 64 * e;
-        if (bx < WA_NBIAS) {
-          // entry bx = (yi - yj + 6) * 13 + (xi - xj + 6): all (i, j) with that displacement
-          const int dy = bx / 13 - 6, dx = bx % 13 - 6;
-          const int y0 = dy > 0 ? dy : 0, y1 = dy < 0 ? WA_WS + dy : WA_WS;
-          const int x0 = dx > 0 ? dx : 0, x1 = dx < 0 ? WA_WS + dx : WA_WS;
-          // (round 5, phase probe: this loop was a chain of up to ~90 dependent LDS reads on the lane that owns displacement (0, 0).
-          //  The seven reads of a row are now independent - invalid members read column 0 and add 0.0f, so the sum is the same
-          //  bits as before: members in (yi, xi) order)
-          float t = 0.f;
-          for (int yi = y0; yi < y1; ++yi) {
-            float v[WA_WS];
-#pragma unroll
-            for (int xi = 0; xi < WA_WS; ++xi) {
-              const int jj = (yi - dy) * WA_WS + (xi - dx) - 32 * tk;
-              const bool ok = xi >= x0 && xi < x1 && jj >= 0 && jj < 32;
-              const float r = sds[(yi * WA_WS + xi) * WA_DSP + (ok ? jj : 0)];
-              v[xi] = ok ? r : 0.f;
-            }
-#pragma unroll
-            for (int xi = 0; xi < WA_WS; ++xi) t += v[xi];
-          }
-          db_acc[e] += t;
-        }
-      }
     }
   }
   NNZ_WA_TS(6);
   // ---- fold the four waves in wave order, one fixed-point add per table entry and workgroup, last workgroup writes ------
-#pragma unroll
-  for (int e = 0; e < 3; ++e)
-    if (lane + 64 * e < WA_NBIAS) sdb[lane + 64 * e] = db_acc[e];
   __syncthreads();
   if (a.dpart) {      // deferred fold (fused Swin block): no atomics, no ticket
     if (tid < WA_NBIAS)
       a.dpart[((long)blockIdx.x * WA_NBIAS + tid) * a.heads + head] =
-          (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
+          (float)((double)(long long)sfx[tid] * 0x1p-40);
     return;
   }
   if (tid < WA_NBIAS) {
-    const float t = (sdb_all[tid] + sdb_all[176 + tid]) + (sdb_all[2 * 176 + tid] + sdb_all[3 * 176 + tid]);
+    const float t = (float)((double)(long long)sfx[tid] * 0x1p-40);
     fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
   }
   // One ticket per HEAD (its counter lives behind the accumulator bank): the head's last workgroup reads its 169 entries -
