@@ -751,13 +751,15 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   NNZ_WA_TS(1);
   stage_bias(a, head, sbT, wbase, tid, 256);   // wbase: image space, unused until the barrier below
   // the wave's share of the bias-table gradient: lane owns table entries lane, lane + 64, lane + 128
-  // the workgroup's share of the bias-table gradient: ONE table of 169 fixed-point sums in LDS (2^-40 units, 64-bit integer adds:
-  // associative, so the order the four waves' adds arrive in does not matter - bit-identical run to run).  Every dS value goes
-  // to its entry with one ds_add_u64 (the 64 lanes of an instruction hold distinct keys: at most 2-way conflicts between the two
-  // half-waves' rows) - 32 instructions per wave and window instead of the dS tile through LDS and a loop of per-entry sums
-  // (phase probe, round 5: that loop was the largest single piece of pass B)
-  unsigned long long* sfx = reinterpret_cast<unsigned long long*>(sdb_all);
-  if (tid < 176) sfx[tid] = 0ull;
+  // the workgroup's share of the bias-table gradient: ONE table of 169 fixed-point sums in LDS, two 64-bit words per entry like
+  // common.hpp's FxAcc - coarse (units of 2^-10: |v| < 2^52) and fine (the remainder in units of 2^-58) - so that gradients of any
+  // fp32 magnitude keep 48 bits below the coarse unit (a single 2^-40 word saturated at |dS| > 8.4e6: the deep decoder stages of
+  // tests/test_u2net_swt.py reach that).  Integer adds are associative: the order the four waves' adds arrive in does not matter,
+  // the result is bit-identical run to run.  Every dS value goes to its entry with two ds_add_u64 (the 64 lanes of an instruction
+  // hold distinct keys: at most 2-way conflicts between the half-waves' rows) - 64 instructions per wave and window instead of the dS
+  // tile through LDS and a loop of per-entry sums (phase probe, round 5: that loop was the largest single piece of pass B)
+  unsigned long long* sfx = reinterpret_cast<unsigned long long*>(sdb_all);       // [176][2]
+  for (int e = tid; e < 2 * 176; e += 256) sfx[e] = 0ull;
   __syncthreads();
   const int w_end = (blockIdx.x + 1) * a.wpb < a.nwin ? (blockIdx.x + 1) * a.wpb : a.nwin;
   const int iters = (a.wpb + 1) / 2;
@@ -900,7 +902,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
           if (i < WA_L && j < WA_L) {
             // entry (yi - yj + 6) * 13 + (xi - xj + 6); i / 7 = (i * 37) >> 8 for i < 64
             const int yi = (i * 37) >> 8, xi = i - 7 * yi;
-            atomicAdd(sfx + ((yi - yj + 6) * 13 + (xi - xj + 6)), (unsigned long long)(long long)__float2ll_rn(ds * 0x1p40f));
+            const float hi = rintf(ds * 0x1p10f);                       // exact: |ds| < 2^52 / 2^10 is far beyond fp32 gradients that matter
+            const float lo = (ds - hi * 0x1p-10f) * 0x1p58f;            // |remainder| <= 2^-11: fits 2^47
+            unsigned long long* q = sfx + 2 * ((yi - yj + 6) * 13 + (xi - xj + 6));
+            atomicAdd(q, (unsigned long long)(long long)__float2ll_rn(hi));
+            atomicAdd(q + 1, (unsigned long long)(long long)__float2ll_rn(lo));
           }
         }
       // dV^T[c][key] = sum_query dO[query][c] P[query][key];  dK^T[c][key] = sum_query Qs[query][c] dS[query][key]
@@ -934,11 +940,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   if (a.dpart) {      // deferred fold (fused Swin block): no atomics, no ticket
     if (tid < WA_NBIAS)
       a.dpart[((long)blockIdx.x * WA_NBIAS + tid) * a.heads + head] =
-          (float)((double)(long long)sfx[tid] * 0x1p-40);
+          (float)((double)(long long)sfx[2 * tid] * 0x1p-10 + (double)(long long)sfx[2 * tid + 1] * 0x1p-58);
     return;
   }
   if (tid < WA_NBIAS) {
-    const float t = (float)((double)(long long)sfx[tid] * 0x1p-40);
+    const float t = (float)((double)(long long)sfx[2 * tid] * 0x1p-10 + (double)(long long)sfx[2 * tid + 1] * 0x1p-58);
     fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
   }
   // One ticket per HEAD (its counter lives behind the accumulator bank): the head's last workgroup reads its 169 entries -
