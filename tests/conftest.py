@@ -42,3 +42,33 @@ def force_scan_gen2():
             for k, v in enumerate(saved):
                 call("nnz_scan_tuning", k, v)
     return _force
+
+
+# ---- collection order ---------------------------------------------------------------------------------------
+# The driver runs `pytest -x`: a failure hides everything collected behind it.  Parity evidence (golden / oracle comparisons) is
+# therefore collected FIRST, self-consistency properties (determinism, fused-vs-composed, dispatch reports) second, and the
+# statistical protocols (training trajectories, Dice protocols, loss-descent checks - the only tests whose outcome depends on a
+# chaotic fp16 trajectory) LAST.  Within a tier the default (alphabetical / definition) order is kept.
+_TIER_BY_FILE = {
+    # tier 1: properties of the HIP path against itself / host plumbing
+    "test_ss2d_cross_scan_gpu.py": 1, "test_determinism_gpu.py": 1, "test_zoo_determinism_gpu.py": 1, "test_backends.py": 1,
+    "test_graph_replay_gpu.py": 1, "test_param_shadow_gpu.py": 1, "test_ddp_rccl_gpu.py": 1, "test_two_stage_wgrads_gpu.py": 1,
+    "test_bench_launch.py": 1, "test_profiles_consistency.py": 1, "test_device_augment_gpu.py": 1,
+    # tier 2: statistical protocols
+    "test_zoo_trajectory_gpu.py": 2, "test_dice_parity_gpu.py": 2, "test_dice_parity_zoo_gpu.py": 2,
+}
+_TIER_BY_NAME = {
+    "test_ssnd2net_training_descends_once_the_loss_scale_has_settled": 2,
+    "test_ssnd2net_fp32_descends_from_the_first_step": 2,
+}
+
+
+def collection_tier(item) -> int:
+    name = item.name.split("[")[0]
+    if name in _TIER_BY_NAME:
+        return _TIER_BY_NAME[name]
+    return _TIER_BY_FILE.get(os.path.basename(str(item.fspath)), 0)
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=collection_tier)          # stable: keeps the order inside a tier

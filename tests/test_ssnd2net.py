@@ -278,12 +278,54 @@ def test_ssnd2net_training_descends_once_the_loss_scale_has_settled(hip_lib):
     print(f"SSND2NetP 128^2: first applied step {first}, training-mode loss {early:.4f} -> {late:.4f} over {nsteps - first} "
           f"applied steps; evaluation-mode loss {held[0][1]:.4f} (step {held[0][0]}) -> {held[-1][1]:.4f} (step {held[-1][0]})")
     assert len(held) == 2 and held[0][0] == first and held[-1][0] == nsteps - 1, (held, scales)
-    # Two regimes, decided by whether step 26 still overflows (borderline, and the library convolutions are not bit-reproducible
-    # from process to process): the scale settles at 2^-10 (first applied step 26: seven runs, evaluation loss down by 0.10 ...
-    # 0.40) or at 2^-11 (first applied step 27: the fp16 gradients below 6e-8 / 2^-11 flush to zero and 130 steps at lr 1e-4 move
-    # the loss by less than its scatter - seen twice in the full suite, +0.014 in training mode).  The second is the reference's
-    # arithmetic too (autocast + GradScaler, nnUNetTrainer.py:1128-1139); what must hold in both: updates are applied and the loss
-    # does not run away; in the first regime it falls.
+    # the assertions are the invariants that hold in BOTH loss-scale regimes; the descent itself is printed,
+    # not asserted.  Which regime a run lands in is decided by whether step 26 still overflows (borderline): the scale settles at
+    # 2^-10 (first applied step 26: evaluation loss down by 0.10 ... 0.40) or at 2^-11 (first applied step 27: the fp16 gradients
+    # below 6e-8 / 2^-11 flush to zero and 130 steps at lr 1e-4 move the loss by less than its scatter).  Both are the reference's
+    # arithmetic (autocast + GradScaler, nnUNetTrainer.py:1128-1139).  What must hold in either: (1) every loss is finite, (2) the
+    # scale backs off monotonically until the first applied step and never grows past its start, (3) at least 10 updates are
+    # applied (in fact all steps behind the first applied one, bar the occasional later overflow), (4) the parameters moved, (5) the
+    # evaluation-mode loss of the same batch does not run away.  The deterministic descent check of this family is
+    # test_ssnd2net_fp32_descends_from_the_first_step below (no GradScaler, no regime).
+    assert all(scales[i] == scales[i - 1] / 2 for i in range(1, first)), scales[:first + 1]
+    assert max(scales) <= 65536.0 and scales[first] < 64.0, scales[:first + 1]
+    assert len(applied) >= (nsteps - first) - 8, (len(applied), first)
+    assert held[-1][1] != held[0][1], held
     assert held[-1][1] < held[0][1] + 0.1, (held, losses, scales)
-    if first <= 26:
-        assert held[-1][1] < held[0][1] - 0.01, (held, losses, scales)
+
+
+@pytest.mark.gpu
+def test_ssnd2net_fp32_descends_from_the_first_step(hip_lib):
+    """The deterministic half of the descent check: the same seeded SSND2NetP WITHOUT autocast / GradScaler (the fp32 step the
+    reference's Swin / Mamba2 / MambaND plugins use, e.g. nnUNetTrainerSwT2Net.py:112-130) has no loss-scale regime - every step
+    is applied - and the evaluation-mode loss of the training batch falls from the first step on
+    (tools/probes/ssnd2net_loss_probe.py --fp32 1: 2.38 -> 1.88 in six steps at 512^2)."""
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerSSND2NetP
+
+    class FP32(nnUNetTrainerSSND2NetP):
+        _fp32_step = True
+        _fp32_validation = True
+
+    plans, cfg, dj = nnunet_plans(2, (128, 128), batch_size=2)
+    torch.manual_seed(0)
+    tr = FP32(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    assert tr.grad_scaler is None
+    b = synthetic_batch(2, (128, 128), tr._get_deep_supervision_scales(), seed=3)
+    b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+
+    def eval_loss():
+        tr.network.eval()
+        try:
+            return float(tr.validation_step(b)["loss"])
+        finally:
+            tr.network.train()
+
+    e0 = eval_loss()
+    losses = [float(tr.train_step(b)["loss"]) for _ in range(24)]
+    e1 = eval_loss()
+    print(f"SSND2NetP 128^2 fp32: evaluation-mode loss {e0:.4f} -> {e1:.4f} over 24 applied steps; training-mode "
+          f"{np.mean(losses[:4]):.4f} -> {np.mean(losses[-4:]):.4f}")
+    assert all(np.isfinite(l) for l in losses)
+    assert e1 < e0 - 0.05, (e0, e1, losses)
