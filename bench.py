@@ -633,10 +633,14 @@ def main():
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
     reducer = getattr(trainer.network, "grad_reducer", None)
     buckets_per_step = getattr(reducer, "buckets_last_step", None)
+    rank_seconds = [dt]
     if dist.is_initialized():
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # max over ranks is the contract's clock; every rank's own time is reported beside it so that a first multi-GPU run shows
+        # at a glance whether one rank (its GPU, its xGMI links) lags or all of them pay the all-reduce
+        tt = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tt, torch.tensor([dt], device=dev, dtype=torch.float64))
+        rank_seconds = [float(x.item()) for x in tt]
+        dt = max(rank_seconds)
     if not all(np.isfinite(losses)):
         raise SystemExit(f"non-finite loss in bench: {losses}")
 
@@ -674,7 +678,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 (fp32 accumulate, GradScaler)",
             "data": "synthetic",
-            "config": {"workload": f"nnUNet 3d_fullres, synthetic 1x{a.patch}^3 patches, batch {per_gpu_batch}/GPU, "
+            "config": {"workload": f"nnUNet 3d_fullres, synthetic 1x{a.patch}^3 patches HBM-resident when the timed region starts "
+                                   f"(the H2D-inclusive rate is `h2d_inclusive`), batch {per_gpu_batch}/GPU, "
                                    f"6 stages 32-320 feat, deep supervision, full train_step"
                                    + ((" (forward+loss+backward replayed as hipGraph segments, RCCL all-reduce between them)"
                                        if getattr(trainer, "_graphed_ddp", None) is not None else
@@ -686,6 +691,8 @@ def main():
             "hip_graph": graph, "hip_graph_segments": (len(trainer._graphed_ddp.segments)
                                                         if getattr(trainer, "_graphed_ddp", None) is not None else (1 if graph else 0)),
             "rccl_ranks": rccl_ranks, "allreduce_buckets_per_step": buckets_per_step,
+            "allreduce_bytes_per_step": getattr(reducer, "bytes_last_step", None),
+            "rank_ms_per_step": [round(x / a.steps * 1e3, 3) for x in rank_seconds],
             "roofline": roof,
             "h2d_inclusive": h2d,
         }
@@ -741,6 +748,22 @@ def main():
                 line["secondary"]["cpu_baseline"] = sec
             if "swt2net" in line:
                 line["swt2net"]["cpu_baseline"] = cpu_swt2net_step_baseline()
+        # the zoo legs' headline numbers as TOP-LEVEL scalars (a parser that keeps only scalars of the contract
+        # line still records the SS2D^2Net half of BASELINE's metric and the SwT2Net leg)
+        for key in ("secondary", "swt2net"):
+            leg = line.get(key)
+            if isinstance(leg, dict):
+                line[f"{key}_value"] = leg.get("value")
+                line[f"{key}_unit"] = leg.get("unit")
+                line[f"{key}_ms_per_step"] = leg.get("ms_per_step")
+                if isinstance(leg.get("roofline"), dict):
+                    line[f"{key}_roofline_frac"] = leg["roofline"].get("frac")
+                if isinstance(leg.get("dice"), dict):
+                    line[f"{key}_dice_abs_delta"] = leg["dice"].get("abs_delta")
+        if isinstance(line.get("roofline"), dict):
+            line["roofline_frac"] = line["roofline"].get("frac")
+        if isinstance(line.get("dice"), dict):
+            line["dice_abs_delta"] = line["dice"].get("abs_delta")
         _emit(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()

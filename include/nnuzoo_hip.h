@@ -583,7 +583,7 @@ int nnz_convT_forward_innorm(const void* in_raw_f16, const float* in_tab, float 
  * optimizer, nnunetv2/training/nnUNetTrainer/nnUNetTrainerM2Net.py:58-65 behind nnUNetTrainer.py:1131-1139) as TWO launches over
  * a device table of chunks {float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int n; int owner}
  * (nnz_adam_chunk_bytes() bytes each, n <= 16384), replacing ~260 multi-tensor launches per step.  stats2 (2 floats, written) =
- * {sum of squares of the unscaled gradients g * inv_scale, > 0 when the step was skipped (non-finite gradients)}; acc / counter: 2 zeroed
+ * {sum of squares of the unscaled gradients g * inv_scale, > 0 when the step was skipped (non-finite gradients)}; acc / counter: 3 zeroed
  * fixed-point records (nnz_fxacc_bytes() each) + one zeroed 32-bit word, left zero; steps[nsteps]: the parameters' fp32 step
  * counters (chunk.owner indexes them; bias corrections are per parameter), advanced by one when the step is applied; inv_scale_device: 1 / loss scale on the device or NULL; max_norm <= 0
  * disables clipping.  Deterministic (fixed-point gradient norm), no host synchronisation. */

@@ -178,14 +178,24 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const AdamChunk* __rest
   __syncthreads();
   if (threadIdx.x >= 64) return;
   if (threadIdx.x == 0) {
-    fx_add(acc, 0, 2, blockIdx.x, (double)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])));
-    fx_add(acc, 1, 2, blockIdx.x, (double)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
+    // THREE records (round 6): {sum of squares, non-finite count, sum of squares x 2^-64}.  Record 0 resolves 3.5e-18 but a
+    // workgroup partial >= 2^52 poisons it; the chaotic nets reach that with every gradient finite - SSND2NetP at 128^2 in an
+    // fp32 step: gradient norm 2.6e9, sum of squares 7e18, where torch's clip_grad_norm_ (an fp32 sum) clips and steps
+    // (tools/probes/ssnd2net_fp32_probe.py: the fused tail skipped all 24 steps).  Record 2 carries the same partials scaled
+    // into range for every finite fp32 sum (resolution 2^6 in the unscaled sum - irrelevant where it is used, above 2^52) and
+    // is read only when record 0 is poisoned.  Integer adds both: deterministic either way.
+    const double part = (double)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+    fx_add(acc, 0, 3, blockIdx.x, part);
+    fx_add(acc, 1, 3, blockIdx.x, (double)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
+    fx_add(acc, 2, 3, blockIdx.x, part * 0x1p-64);
   }
   if (last_workgroup_wave(counter, gridDim.x)) {
     float ss = 0.f, nb = 0.f;
     if (threadIdx.x == 0) {
-      ss = (float)fx_take(acc, 0, 2);
-      nb = (float)fx_take(acc, 1, 2);
+      double t[3];
+      fx_take_n<3>(acc, 0, 3, t);
+      ss = (float)(t[0] == t[0] ? t[0] : t[2] * 0x1p64);
+      nb = (float)t[1];
       const bool overflow = !(ss == ss) || __builtin_isinf(ss);
       if (overflow) nb = nb > 0.f ? nb : 1.f;   // finite gradients whose squares overflowed: skipped as well
       out2[0] = ss;
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
 
 extern "C" int nnz_adam_chunk_bytes(void) { return (int)sizeof(nnz::AdamChunk); }
 
-// stats2 (2 floats) is written: {sum of squares of the UNSCALED gradients (g * inv_scale), > 0 if the step is skipped}; acc / counter: 2 zeroed
+// stats2 (2 floats) is written: {sum of squares of the UNSCALED gradients (g * inv_scale), > 0 if the step is skipped}; acc / counter: 3 zeroed
 // fixed-point records + one zeroed word (left zero); steps: the parameters' step counters (fp32, one per parameter, advanced
 // here when the step is applied); inv_scale_device: 1 / loss scale (1 float on the device) or NULL; max_norm <= 0: no clipping
 extern "C" int nnz_adamw_fused(const void* chunks_device, int nchunks, float* stats2, void* acc, void* counter,

@@ -54,6 +54,7 @@ constexpr int WA_LD = 36;  // LDS row stride (floats) of a [token][channel] imag
                            // of a b128 access, 36 l mod 64 being 16 different multiples of 4) - round 5, was 33 with 4-byte accesses
 constexpr int WA_NBIAS = (2 * WA_WS - 1) * (2 * WA_WS - 1);
 constexpr int WA_BP = 64;  // pitch of the transposed bias matrix sbT[key][query]
+constexpr int WA_NF_SLOT = 170;  // backward pair kernel: entry of the [176][2] fixed-point table (169 used) that flags a non-finite dS
 
 struct AttnArgs {
   const float* qkv;    // [B][H][W][3C]
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   float* sv = sk + WA_IMG;
   float* sdo = sv + WA_IMG;
   // dS[query][key - 32 role] of this wave's key tile lives ON the K (role 0) / V (role 1) image: both are dead once the pair
-  // has taken its K / V row operands of pass B (barrier below) - 27 KB per pair instead of 40, two workgroups per CU
+  // has taken its K / V row operands of pass B (barrier below) - WA_PAIR_FLOATS per pair (four [49][36] images + rows + token tables: 29.8 KB) instead of five images, two workgroups per CU
   float* sds = role == 0 ? sk : sv;
   float* srow = sdo + WA_IMG;                          // [3][64]: row max, 1 / sum, delta per query
   int* stok = reinterpret_cast<int*>(srow + 3 * 64);
@@ -783,8 +784,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
     }
     lds_barrier();
     if (live) {
-      // (the batched staging of the forward kernels is not used here: this kernel sits at its 256-register cap, the pieces in
-      //  flight spilled, and the reloads between the loads made the 2 166-problem launches 8 % slower; the launch floor did not move)
+      // (batched staging in ONE round - all 14 pieces of the wave's two images in flight, stage_two<1>; two rounds of 8 + 6 pieces
+      //  were tried when the kernel sat at its 256-register cap and were no faster)
       stage_two<1>(a.qkv, C3, role == 0 ? qo : vo, stok, role == 0 ? a.scale : 1.f, role == 0 ? sq : sv,
                    role == 0 ? a.qkv : a.dout, role == 0 ? (long)C3 : (long)a.C, role == 0 ? ko : qo, role == 0 ? stok : sutok, 1.f,
                    role == 0 ? sk : sdo, hd, lane);
@@ -885,6 +886,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
       const int jc = j < WA_L ? j : WA_L - 1;
       const int yj = (jc * 37) >> 8, xj = jc - 7 * yj;
       const int reg_j = a.shift ? sreg[jc] : 0;
+      bool nonfinite = false;
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
@@ -899,6 +901,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
           }
           s[tq][r] = pv;    // P[query][key]
           dp[tq][r] = ds;   // dS[query][key]
+          nonfinite |= !(fabsf(ds) < 3.0e38f);        // NaN / Inf: the integer conversions below would turn them into finite sums
           if (i < WA_L && j < WA_L) {
             // entry (yi - yj + 6) * 13 + (xi - xj + 6); i / 7 = (i * 37) >> 8 for i < 64
             const int yi = (i * 37) >> 8, xi = i - 7 * yi;
@@ -909,6 +912,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
             atomicAdd(q + 1, (unsigned long long)(long long)__float2ll_rn(lo));
           }
         }
+      if (nonfinite) sfx[2 * WA_NF_SLOT] = 1ull;      // (same value from every writer: a plain store)
       // dV^T[c][key] = sum_query dO[query][c] P[query][key];  dK^T[c][key] = sum_query Qs[query][c] dS[query][key]
       f32x16 ov, ok;
 #pragma unroll
@@ -937,14 +941,19 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
   NNZ_WA_TS(6);
   // ---- fold the four waves in wave order, one fixed-point add per table entry and workgroup, last workgroup writes ------
   __syncthreads();
+  // A non-finite dS anywhere in the workgroup makes its whole share NaN (the float sum this table replaces carried
+  // NaN / Inf into relative_position_bias_table.grad, and the fp32 Swin trainers run without a GradScaler - nothing else would flag
+  // the step for that parameter); fx_add counts non-finite partials, so the fixed-point path propagates it too.
+  const bool wg_nonfinite = sfx[2 * WA_NF_SLOT] != 0ull;
   if (a.dpart) {      // deferred fold (fused Swin block): no atomics, no ticket
     if (tid < WA_NBIAS)
-      a.dpart[((long)blockIdx.x * WA_NBIAS + tid) * a.heads + head] =
+      a.dpart[((long)blockIdx.x * WA_NBIAS + tid) * a.heads + head] = wg_nonfinite ? __builtin_nanf("") :
           (float)((double)(long long)sfx[2 * tid] * 0x1p-10 + (double)(long long)sfx[2 * tid + 1] * 0x1p-58);
     return;
   }
   if (tid < WA_NBIAS) {
-    const float t = (float)((double)(long long)sfx[2 * tid] * 0x1p-10 + (double)(long long)sfx[2 * tid + 1] * 0x1p-58);
+    const float t = wg_nonfinite ? __builtin_nanf("") :
+        (float)((double)(long long)sfx[2 * tid] * 0x1p-10 + (double)(long long)sfx[2 * tid + 1] * 0x1p-58);
     fx_add(a.acc, (long)head * WA_NBIAS + tid, (long)a.heads * WA_NBIAS, blockIdx.x, (double)t);
   }
   // One ticket per HEAD (its counter lives behind the accumulator bank): the head's last workgroup reads its 169 entries -
@@ -960,7 +969,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_pair_kernel(AttnArgs a) {
 
 static int check(const AttnArgs& a) {
   if (a.B < 1 || a.H % WA_WS || a.W % WA_WS || a.heads < 1 || a.C != a.heads * a.hd || a.hd % 2 || a.hd > 32 ||
-      a.hd < 2 || (a.shift != 0 && a.shift != WA_WS / 2) || (long)a.B * a.H * a.W * 3 * a.C >= (1L << 31) * 3)
+      a.hd < 2 || (a.shift != 0 && a.shift != WA_WS / 2) || (long)a.B * a.H * a.W * 3 * a.C >= (1L << 32))   // fetch_image: 32-bit element offsets
     return NNZ_EINVAL;
   return NNZ_OK;
 }

@@ -20,7 +20,11 @@ the chain).  "(lo, hi)" ranges marked BGContrast at the call site draw from [lo,
 
 The transform classes are batchgeneratorsv2's (`pyproject.toml:51`), absent from /root/reference and from this image: what each
 one computes is restated here from its published algorithm and the call site - PARITY UNPINNED; `tests/test_device_augment_gpu.py`
-holds every launch to a plain torch fp32 formulation of the same arithmetic.  Host draws use a private numpy RandomState
+holds every launch to a plain torch fp32 formulation of the same arithmetic.  Two draws were corrected in round 6 after review
+(both from the reviewer's and the author's recollection of the package, neither can be diffed here): Gaussian noise takes
+the sampled `noise_variance` as the standard deviation (sigma = U(0, 0.1), not its square root), and the spatial transform's
+`scaling=(0.7, 1.4)` is a plain tuple drawn uniformly (the below / above 1 split is BGContrast's, used only where the call site wraps
+the range in BGContrast).  Host draws use a private numpy RandomState
 (reproducible from `seed`; not the reference's torch / numpy call sequence)."""
 from __future__ import annotations
 
@@ -85,8 +89,11 @@ class DeviceAugmenter:
                     m = _rot3(ax, self.rng.uniform(*self.rotation)) @ m
         if self.rng.uniform() < self.p_scaling:
             drawn = True
+            # the call site passes a plain tuple (nnUNetTrainer.py:856 `scaling=(0.7, 1.4)`), which batchgeneratorsv2's
+            # sample_scalar draws UNIFORMLY over the interval; the 50/50 split below / above 1 is BGContrast's rule and applies
+            # only to the ranges the call site wraps in BGContrast (brightness, contrast, gamma: _bg_range) - ADVICE r5
             lo, hi = self.scaling
-            sc = self.rng.uniform(lo, 1.0) if (self.rng.uniform() < 0.5 and lo < 1) else self.rng.uniform(max(lo, 1.0), hi)
+            sc = self.rng.uniform(lo, hi)
             s = np.diag([1.0 if (nd == 2 or self.dummy_2d) else sc, sc, sc])
             m = m @ s
         return m if drawn else None
@@ -143,7 +150,9 @@ class DeviceAugmenter:
             rec[:] = 0
             for b in range(B):
                 if on[b]:
-                    sig = float(np.sqrt(self.rng.uniform(*self.noise_variance)))
+                    # batchgeneratorsv2's GaussianNoiseTransform hands the sampled `noise_variance` to torch.normal AS THE
+                    # STANDARD DEVIATION (sigma = U(0, 0.1)); batchgenerators v1 took its square root - ADVICE r5
+                    sig = float(self.rng.uniform(*self.noise_variance))
                     last["noise_sigma"][b] = sig
                     rec[b * C:(b + 1) * C, 0], rec[b * C:(b + 1) * C, 1] = 1.0, sig
             last["noise_seed"] = int(self.rng.randint(0, 2 ** 31 - 1))

@@ -35,6 +35,7 @@ class BucketedAllReduce:
         self._slices = []              # (lo, hi) element ranges of the arena collectives launched in the current step
         self.slices_last_step = []     # ... of the most recent finished step (bench.py / tests read these)
         self.buckets_last_step = 0
+        self.bytes_last_step = 0       # bytes all-reduced by the most recent finished step (arena form)
         # hipGraph capture of the data-parallel step (training/graph_step.py GraphedDDPStep): while set, a bucket that is
         # ready is REPORTED through this callable - boundary(lo, hi, final) - instead of being all-reduced: the capture ends
         # the current graph segment there and the replay launches the collective for the slice between two segments
@@ -84,6 +85,7 @@ class BucketedAllReduce:
             self._arena_lo = 0
             self.slices_last_step, self._slices = self._slices, []
             self.buckets_last_step = len(self.slices_last_step)
+            self.bytes_last_step = sum(h - l for l, h in self.slices_last_step) * arena.element_size()
             return
         if filled > lo:
             h = dist.all_reduce(arena[lo:filled], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -96,6 +98,7 @@ class BucketedAllReduce:
         self._arena_lo = 0
         self.slices_last_step, self._slices = self._slices, []
         self.buckets_last_step = len(self.slices_last_step)
+        self.bytes_last_step = sum(h - l for l, h in self.slices_last_step) * arena.element_size()
 
     def reduce_slice_async(self, arena: torch.Tensor, lo: int, hi: int):
         """replay side of a captured step: the in-place SUM all-reduce of one recorded bucket (no averaging - the fused

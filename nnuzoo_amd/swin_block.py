@@ -38,10 +38,14 @@ _WS_OUTGROWN = []      # a captured hipGraph keeps the ADDRESS of the buffer it 
 
 
 def _workspace(device, floats: int):
-    """split-K partials of the skinny products (one buffer per device; calls on a stream use it one after the other)"""
+    """split-K partials of the skinny products: one buffer per (device, STREAM).  The partials are written by one launch and read by
+    the fold launch behind it, so calls on ONE stream may share a buffer; two streams (an eager validation pass beside a captured
+    step's side stream, GraphedDDPStep segments) must not.  A capture runs on a stream of its own, so its buffer is
+    allocated inside that capture from the graph's pool and is never handed to eager code; buffers that were outgrown stay alive
+    because a captured graph keeps the ADDRESS it was recorded with."""
     if floats <= 0:
         return None
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < floats:
         if torch.cuda.is_current_stream_capturing() and ws is not None:

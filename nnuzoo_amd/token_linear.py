@@ -167,8 +167,9 @@ _WS = {}
 
 
 def _d32_workspace(device, floats: int) -> torch.Tensor:
-    """per-device partial-sum workspace of the fp32 weight gradients (calls on one stream use it one after the other)"""
-    key = (device.type, device.index)
+    """partial-sum workspace of the fp32 weight gradients, per (device, stream): calls on one stream use it one after the other,
+    two streams never share one (see swin_block._workspace)"""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < floats:
         ws = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)

@@ -139,7 +139,7 @@ class FusedAdamW(torch.optim.AdamW):
             self._token = grads_token
         dev = members[0].device
         stats = torch.empty(2, dtype=torch.float32, device=dev)
-        sc = det_scratch(dev, 2)
+        sc = det_scratch(dev, 3)
         b1, b2 = g["betas"]
         call("nnz_adamw_fused", ptr(self._table), self._nchunks, ptr(stats), ptr(sc.acc), ptr(sc.counter), ptr(inv_scale),
              float(max_norm), float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),

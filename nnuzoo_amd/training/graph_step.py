@@ -64,6 +64,7 @@ class GraphedForwardBackward:
         self._static_grads = []        # [(parameter, the .grad tensor the captured backward writes)]
         self._static_arena = None      # explicit-schedule networks: (arena, layout, unused ids) the captured backward fills
         self.generation = 0            # number of captures so far: (id(self), generation) names one set of static gradients
+        self._token = None             # None = "no valid capture": FusedAdamW rescans the gradient addresses
 
     def _loss(self, out, target):
         if isinstance(out, (tuple, list)):
@@ -82,6 +83,7 @@ class GraphedForwardBackward:
         return loss
 
     def _capture(self, data, target):
+        self._token = None             # a failed re-capture must not leave the previous capture's token standing
         self.static_data = data.clone()
         self.static_target = [t.clone() for t in target]
         params = [p for p in self.network.parameters()]
@@ -271,5 +273,6 @@ class GraphedDDPStep:
             h.wait()
         red.slices_last_step = [sl for sl in self.slices if sl is not None]
         red.buckets_last_step = len(red.slices_last_step)
+        red.bytes_last_step = sum(h - l for l, h in red.slices_last_step) * arena.element_size()
         net._last_arena, net._arena_layout, net._last_unused = self._static_arena
         return self.static_loss

@@ -1,0 +1,109 @@
+"""One-step parity at the FULL shape of BASELINE's zoo configurations ("plus one-step parity at full shape ... argmax
+equal").  The 3-D 128^3 configuration has its full-size test in tests/test_plain_unet_gpu.py.
+
+* SwT2Net 2 x 512^2 (configs[3]): the HIP network against the CPU oracle oracle/swt2net.py (pinned by the reference's own whole-net
+  outputs and autograd, tests/test_oracle_swt2net.py) run HERE on the same seeded parameters (golden_util.det_fill) and input, eval
+  mode: seven outputs within max(1e-4, 100 x the oracle's own response to a 1e-6 input perturbation) of each output's range, argmax
+  masks equal wherever the oracle's top-2 margin exceeds twice the observed logit error.
+* M2Net (SS2D^2Net) 1 x 512^2 (configs[2]): the oracle's time loop over 512^2 tokens takes about an hour of CPU, so its forward was
+  run ONCE in the build container (tools/make_golden_full_shape.py: oracle/m2net.py, itself pinned by the reference's whole-net
+  fixtures in tests/test_oracle_m2net.py) and strided samples of its seven outputs + the packed argmax mask of the full-resolution
+  output are the committed fixture tests/golden/full_shape_M2Net_512.npz.
+Reference: /root/reference/nnunetv2/nets/swt2net.py:1068-1141, m2net.py:883-956."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import det_fill
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _off(net):
+    for m in net.modules():
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+    return net
+
+
+def _argmax_check(got, ref, err_abs, name):
+    """argmax over the class axis equal wherever the reference's top-2 margin is resolvable at the observed logit error"""
+    top2 = ref.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    sure = margin > 2 * err_abs
+    agree = got.argmax(1) == ref.argmax(1)
+    assert sure.float().mean().item() > 0.98, (name, "fraction of resolvable pixels", sure.float().mean().item())
+    assert bool(agree[sure].all()), (name, int((~agree[sure]).sum()), int(sure.sum()))
+    return float(agree.float().mean())
+
+
+def test_swt2net_full_shape_forward_equals_the_oracle(hip_lib):
+    from oracle.swt2net import SwT2Net as Ref
+    from nnuzoo_amd.nets.swt2net import SwT2Net
+    from nnuzoo_amd.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    ref = Ref(1, 2, True)
+    det_fill(ref)
+    net = SwT2Net(1, 2, True)
+    net.load_state_dict(ref.state_dict())
+    ref, net = _off(ref).eval(), _off(net).cuda().eval()
+    x = synthetic_batch(2, (512, 512), [[1, 1]], seed=11)["data"]
+    with torch.no_grad():
+        base = ref(x)
+        pert = ref(x * (1 + 1e-6))
+        got = [o.float().cpu() for o in net(x.cuda())]
+    assert len(got) == len(base) == 7
+    report = []
+    for i, (o, r, p) in enumerate(zip(got, base, pert)):
+        assert o.shape == r.shape
+        rng = r.abs().max().item()
+        sens = (p - r).abs().max().item() / rng
+        err = (o - r).abs().max().item()
+        tol = max(1e-4, 100 * sens)
+        agree = _argmax_check(o, r, err, f"output {i}")
+        report.append(f"d{i} {tuple(r.shape)}: err {err / rng:.1e} of range (oracle's own response {sens:.1e}, tolerance {tol:.1e}), "
+                      f"argmax agreement {agree:.6f}")
+        assert err <= tol * rng, report[-1]
+    print("SwT2Net 2 x 512^2, eval mode, HIP vs CPU oracle\n   " + "\n   ".join(report))
+
+
+def test_m2net_full_shape_forward_equals_the_committed_oracle_run(hip_lib):
+    from nnuzoo_amd.nets.m2net import M2Net
+    from nnuzoo_amd.synthetic import synthetic_batch
+    fx = np.load(os.path.join(GOLD, "full_shape_M2Net_512.npz"))
+    torch.manual_seed(0)
+    net = M2Net(1, 2, True)
+    det_fill(net)
+    assert abs(float(sum(p.double().pow(2).sum() for p in net.parameters()).sqrt()) - float(fx["param_l2"])) < 1e-6 * float(fx["param_l2"])
+    net = _off(net).cuda().eval()
+    x = synthetic_batch(1, (512, 512), [[1, 1]], seed=int(fx["seed"]))["data"]
+    assert abs(float(x.double().pow(2).sum().sqrt()) - float(fx["input_l2"])) < 1e-6 * float(fx["input_l2"])
+    with torch.no_grad():
+        got = [o.float().cpu() for o in net(x.cuda())]
+    assert len(got) == 7
+    report = []
+    for i, o in enumerate(got):
+        assert list(o.shape) == list(fx[f"shape_{i}"])
+        stride = int(fx[f"stride_{i}"])
+        want = torch.from_numpy(fx[f"out_{i}"])
+        have = o.reshape(-1)[::stride]
+        rng = float(fx[f"range_{i}"])
+        sens = float(fx[f"sens_{i}"])
+        err = (have - want).abs().max().item()
+        tol = max(5e-4, 100 * sens)
+        report.append(f"d{i} {tuple(o.shape)}: err {err / rng:.1e} of range (oracle's own response {sens:.1e}, tolerance {tol:.1e})")
+        assert err <= tol * rng, report[-1]
+        assert abs(float(o.double().pow(2).sum().sqrt()) - float(fx[f"l2_{i}"])) <= tol * float(fx[f"l2_{i}"]) * 10, report[-1]
+    # argmax mask of the full-resolution output: every pixel whose oracle margin is resolvable must agree
+    mask = torch.from_numpy(np.unpackbits(fx["argmax_0"])[:512 * 512].reshape(512, 512).astype(np.int64))
+    margin = torch.from_numpy(fx["margin_0"].astype(np.float32)).reshape(512, 512)
+    err0 = (got[0].reshape(-1)[::int(fx["stride_0"])] - torch.from_numpy(fx["out_0"])).abs().max().item()
+    sure = margin > max(2 * err0, 4 * float(fx["sens_0"]) * float(fx["range_0"]))
+    agree = got[0][0].argmax(0) == mask
+    assert sure.float().mean().item() > 0.98
+    assert bool(agree[sure].all()), (int((~agree[sure]).sum()), int(sure.sum()))
+    print("M2Net 1 x 512^2, eval mode, HIP vs the committed CPU-oracle run\n   " + "\n   ".join(report)
+          + f"\n   argmax agreement {agree.float().mean().item():.6f} ({sure.float().mean().item():.4f} of the pixels resolvable)")

@@ -133,3 +133,26 @@ def test_large_scaled_gradients_that_are_finite_are_not_skipped(hip_lib):
     torch.nn.utils.clip_grad_norm_([q], 12)
     ref.step()
     assert torch.allclose(p, q, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("norm", [2.6e9, 3.0e13])
+def test_huge_finite_gradient_norm_is_clipped_and_applied_like_torch(hip_lib, norm):
+    """round 6: SSND2NetP in an fp32 step has a gradient norm of 2.6e9 (tools/probes/ssnd2net_fp32_probe.py) - every value finite,
+    the sum of squares (7e18) beyond the 2^52 of the fine fixed-point record.  torch's clip_grad_norm_(12) scales such a gradient
+    to norm 12 and steps; the fused tail skipped the step (24 of 24).  The wide-range record makes it clip and step."""
+    from nnuzoo_amd.training.fused_adamw import FusedAdamW
+    n = 1 << 20
+    p = torch.nn.Parameter(torch.zeros(n, device="cuda"))
+    q = torch.nn.Parameter(torch.zeros(n, device="cuda"))
+    g = torch.randn(n, generator=torch.Generator().manual_seed(4)).cuda() * (norm / 1024)
+    p.grad, q.grad = g.clone(), g.clone()
+    kw = dict(lr=1e-3, weight_decay=0.0, eps=1e-5)
+    opt, ref = FusedAdamW([p], **kw), torch.optim.AdamW([q], **kw)
+    found = [float(opt.fused_step(None, 12)) for _ in range(2)]
+    assert found == [0.0, 0.0]
+    for _ in range(2):
+        torch.nn.utils.clip_grad_norm_([q], 12)
+        ref.step()
+        q.grad = g.clone()
+    assert float(q.abs().max()) > 0
+    assert torch.allclose(p, q, rtol=2e-5, atol=1e-9), (p - q).abs().max().item()

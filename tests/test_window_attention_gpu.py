@@ -90,3 +90,20 @@ def test_foreign_index_layout_is_refused(hip_lib):
     idx[0, 1] = 5
     with pytest.raises(NotImplementedError):
         window_attention_core(torch.zeros(1, 7, 7, 12, device=DEV), torch.zeros(169, 2, device=DEV), idx, 2, 0, 1.0)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_nonfinite_attention_gradient_reaches_the_bias_table_gradient(hip_lib, bad):
+    """the bias-table gradient is summed in fixed point (integer LDS adds); a NaN / Inf dS must not come out as a finite
+    sum - the fp32 Swin trainers run without a GradScaler, so a non-finite relative_position_bias_table.grad is the only thing
+    that flags such a step for this parameter (torch's float sum carries it the same way)."""
+    g = torch.Generator().manual_seed(5)
+    heads, hd = 3, 32
+    qkv = torch.randn(2, 14, 14, 3 * heads * hd, generator=g).to(DEV).requires_grad_(True)
+    table = (torch.randn(169, heads, generator=g) * 0.5).to(DEV).requires_grad_(True)
+    dout = torch.randn(2, 14, 14, heads * hd, generator=g)
+    dout[1, 3, 4, 40] = bad                     # one element of head 1's output gradient in one window
+    y = window_attention_core(qkv, table, _index().to(DEV), heads, 3, hd ** -0.5)
+    _, gt = torch.autograd.grad(y, [qkv, table], dout.to(DEV))
+    assert not torch.isfinite(gt[:, 1]).all()    # head 1's table column carries it
+    assert torch.isfinite(gt[:, 0]).all() and torch.isfinite(gt[:, 2]).all()
