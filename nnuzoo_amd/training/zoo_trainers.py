@@ -598,6 +598,76 @@ class nnUNetTrainerU2NetP(nnUNetTrainerU2Net):
         return get_u2netp_from_plans(num_out, num_in, deep_supervision=ds, use_pretrain=False)
 
 
+class nnUNetTrainerU2NetMulti(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerU2NetMulti.py:14-103 (the N-D U^2-Net of nets/u2net_multi.py on monai's
+    Convolution unit; the base trainer's autocast train_step; AdamW 1e-4 / wd 5e-2 / eps 1e-5, cosine to 1e-6; seven
+    deep-supervision outputs, ALL at full resolution: [[1.0] * dims] * 7, :48-56).  The reference's build_network_architecture
+    passes (plans_manager, dataset_json, configuration_manager, num_input_channels, deep_supervision=...) to a factory declared as
+    (spatial_dims, num_segmentation_heads, num_input_channels, deep_supervision, ...) - a TypeError as written (:37-44 vs
+    u2net_multi.py:699-705); here the factory receives what it is declared with."""
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.early_stop_epoch = 10
+        self.spatial_dims = len(self.configuration_manager.patch_size)
+
+    def _get_deep_supervision_scales(self):
+        return [[1.0] * self.spatial_dims] * 7 if self.enable_deep_supervision else None
+
+    @staticmethod
+    def _dims(args, kwargs) -> int:
+        cm = kwargs.get("configuration_manager")
+        if cm is None and len(args) > 2 and not isinstance(args[0], str):
+            cm = args[2]
+        if cm is None:
+            raise ValueError("nnUNetTrainerU2NetMulti.build_network_architecture needs the configuration_manager (patch size -> 2-D / 3-D)")
+        return len(cm.patch_size)
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.u2net_multi import get_u2net_from_plans
+        num_in, num_out, ds = _live_num_in_out(args, kwargs)
+        return get_u2net_from_plans(nnUNetTrainerU2NetMulti._dims(args, kwargs), num_out, num_in, deep_supervision=ds,
+                                    use_pretrain=False)
+
+
+class nnUNetTrainerU2NetMultiP(nnUNetTrainerU2NetMulti):
+    """reference :106-194 (U2NETP of nets/u2net_multi.py through get_u2netp_from_plans, whose signature IS the plans-style one)"""
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from ..nets.u2net_multi import get_u2netp_from_plans
+        return _legacy_or_live(get_u2netp_from_plans, args, kwargs)
+
+
+class nnUNetTrainerSwUNETR(_X2Trainer):
+    """reference: training/nnUNetTrainer/nnUNetTrainerSwUNETR.py:13-99 - monai's SwinUNETR (feature_size 48) behind the base
+    trainer's autocast step, deep supervision off, AdamW 1e-4 / wd 5e-2 / eps 1e-5, cosine.  NOTHING of the network is defined in
+    the reference: the class is `monai.networks.nets.SwinUNETR`, imported at module level (:4), and monai is absent from
+    /root/reference and from this image.  The plugin therefore exists under its name with the reference's
+    hyper-parameters and fails where the reference fails without monai - at the import - with the same exception type; with monai
+    installed it builds monai's network exactly as the reference does (library kernels: no HIP path is claimed for it)."""
+
+    def __init__(self, plans: dict, configuration: str, fold: int, dataset_json: dict, unpack_dataset: bool = True,
+                 device: torch.device = torch.device('cuda'), num_epochs: int = 250, **kwargs):
+        super().__init__(plans, configuration, fold, dataset_json, unpack_dataset, device, num_epochs=num_epochs)
+        self.enable_deep_supervision = False
+
+    def _get_deep_supervision_scales(self):
+        return [[1.0, 1.0]] * 7 if self.enable_deep_supervision else None
+
+    @staticmethod
+    def build_network_architecture(*args, **kwargs):
+        from monai.networks.nets import SwinUNETR      # ModuleNotFoundError without monai, like the reference's module import
+        num_in, num_out, _ = _live_num_in_out(args, kwargs)
+        cm = kwargs.get("configuration_manager")
+        if cm is None and len(args) > 2 and not isinstance(args[0], str):
+            cm = args[2]
+        return SwinUNETR(img_size=cm.patch_size[0], in_channels=num_in, out_channels=num_out,
+                         spatial_dims=len(cm.patch_size), feature_size=48, drop_rate=0.0, attn_drop_rate=0.0)
+
+
 class nnUNetTrainerSwinTransformerUnet(_X2Trainer):
     """reference: training/nnUNetTrainer/nnUNetTrainerSwinTransformerUnet.py:17-108 (the single Swin U-net of nets/swt.py; deep
     supervision OFF - one output -, AdamW 1e-4 / wd 5e-2, cosine; the base trainer's autocast train_step).  The reference's
