@@ -77,7 +77,9 @@ def _fwd_bwd(name, nd, dev, rtol_out, rtol_grad):
 
 @pytest.mark.parametrize("name,nd", CASES)
 def test_cpu_forward_backward_golden(name, nd):
-    _fwd_bwd(name, nd, "cpu", 2e-5, 2e-4)
+    # 3-D: the PReLU slope / norm gradients are fp32 sums over 64^3 x 64 values; two CPU runs with different thread counts differ by
+    # 1.2e-3 there (the generator ran on 2 threads)
+    _fwd_bwd(name, nd, "cpu", 2e-5, 2e-4 if nd == 2 else 1e-3)
 
 
 @pytest.mark.gpu
