@@ -83,13 +83,20 @@ class Convolution(nn.Sequential):
         if not conv_only:
             self.add_module("adn", ADN(spatial_dims, out_channels, act, norm))
 
+    def hip_capable(self) -> bool:
+        """the unit's STRUCTURE fits the MFMA conv path: conv k3 (dilation 1 / 2 / 4 / 8, channels in multiples of 32) -> BatchNorm2d ->
+        ReLU.  (param_shadow.py leaves the fp32 master weights of such units alone: rebnconv.py packs them itself.)"""
+        adn = self._modules.get("adn")
+        return adn is not None and isinstance(adn.N, nn.BatchNorm2d) and isinstance(adn.A, nn.ReLU) \
+            and isinstance(self.conv, nn.Conv2d) and _rb.supported(self.conv, adn.N)
+
     def _hip_unit(self, x: torch.Tensor) -> bool:
         """conv -> BatchNorm2d -> ReLU on the MFMA conv kernels (rebnconv.py) - same conditions as nets/u2net.py REBNCONV"""
-        adn = self._modules.get("adn")
-        if adn is None or not isinstance(adn.N, nn.BatchNorm2d) or not isinstance(adn.A, nn.ReLU):
+        if not self.hip_capable():
             return False
+        adn = self.adn
         if not (_rb.USE_HIP and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
-                and torch.get_autocast_dtype("cuda") == torch.float16 and _rb.supported(self.conv, adn.N)):
+                and torch.get_autocast_dtype("cuda") == torch.float16):
             return False
         if not adn.N.training and torch.is_grad_enabled() and \
                 (x.requires_grad or any(p.requires_grad for p in self.parameters())):

@@ -55,6 +55,8 @@ def _eligible(network: nn.Module) -> Tuple[List[str], List[nn.Parameter]]:
     from .nets.ssnd import SSND
     skip |= {id(root.convnd.conv) for root in network.modules()
              if isinstance(root, SSND) and root.spatial_dims == 2 and hasattr(root.convnd, "conv")}
+    from .nets.u2net_multi import Convolution as _MonaiUnit
+    skip |= {id(root.conv) for root in network.modules() if isinstance(root, _MonaiUnit) and root.hip_capable()}
     names, params = [], []
     for mname, m in network.named_modules():
         if id(m) in skip or type(m) not in kinds:

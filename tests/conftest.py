@@ -59,7 +59,7 @@ _TIER_BY_FILE = {
 }
 _TIER_BY_NAME = {
     "test_ssnd2net_training_descends_once_the_loss_scale_has_settled": 2,
-    "test_ssnd2net_fp32_descends_from_the_first_step": 2,
+    "test_ssnd2net_fp32_step_applies_its_updates_at_a_gradient_norm_of_1e9": 2,
 }
 
 
