@@ -95,8 +95,13 @@ def residual_drop_path(inp: torch.Tensor, x: torch.Tensor, drop_path: "DropPath"
     if drop_path.drop_prob == 0. or not drop_path.training:
         return _ResidualDropPathFn.apply(inp, x, None, 1.0)
     keep = 1 - drop_path.drop_prob
-    mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
     scale = 1.0 / keep if (keep > 0.0 and drop_path.scale_by_keep) else 1.0
+    from ..droppath_draws import _ACTIVE, uniform
+    if _ACTIVE and keep > 0.0:
+        # a row of the pass's draw table (ONE torch.rand per forward, droppath_draws.py); the 0 / 1 mask floor(keep + u) - a
+        # Bernoulli(keep) variable like timm's bernoulli_(keep) below - is formed inside the residual kernel
+        return _ResidualDropPathFn.apply(inp, x, uniform(x.shape[0], x.device), scale, keep)
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
     return _ResidualDropPathFn.apply(inp, x, mask, scale)
 
 

@@ -372,6 +372,11 @@ class _U2Forward:
         raise NotImplementedError
 
     def forward(self, x):
+        from ..droppath_draws import DrawTable
+        with DrawTable(self, x.shape[0], x.device):      # every stochastic-depth draw of the pass from one launch
+            return self._forward(x)
+
+    def _forward(self, x):
         h1 = self.stage1(x)
         h2 = self.stage2(self.patch_merging1(h1, permute=True))
         h3 = self.stage3(self.patch_merging2(h2, permute=True))

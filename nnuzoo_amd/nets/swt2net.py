@@ -241,7 +241,8 @@ class SwinTransformerBlock(nn.Module):
             return inp + dp(y)
         if isinstance(dp, DropPath) and dp.drop_prob > 0. and dp.training:
             keep = 1 - dp.drop_prob
-            draws = torch.rand((y.shape[0],) + (1,) * (y.ndim - 1), dtype=y.dtype, device=y.device)
+            from ..droppath_draws import uniform
+            draws = uniform(y.shape[0], y.device)
             if keep > 0.0:   # floor(keep + draws) is made inside the residual kernel (fp32 add, then floor, like torch's)
                 return _ResidualDropPathFn.apply(inp, y, draws, 1.0 / keep, keep)
             return _ResidualDropPathFn.apply(inp, y, (keep + draws).floor_(), 1.0)

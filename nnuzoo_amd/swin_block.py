@@ -253,15 +253,16 @@ def fused_block_ok(blk, x: torch.Tensor) -> bool:
 
 def swin_block_forward(blk, x: torch.Tensor) -> torch.Tensor:
     """`SwinTransformerBlock.forward` on the fused node; the per-sample DropPath draws are made exactly like the reference's
-    DropPath (torch.rand of shape (B, 1, 1, 1) per branch, attention branch first), so the RNG stream is the module path's"""
+    DropPath (B uniform draws per branch, attention branch first: droppath_draws.uniform, the same call the module path makes)"""
     a, m, dp = blk.attn, blk.mlp, blk.drop_path
     B = x.shape[0]
     draws1 = draws2 = None
     keep = 1.0
     if hasattr(dp, "drop_prob") and dp.drop_prob > 0. and blk.training:
         keep = 1.0 - dp.drop_prob
-        draws1 = torch.rand((B, 1, 1, 1), dtype=x.dtype, device=x.device)
-        draws2 = torch.rand((B, 1, 1, 1), dtype=x.dtype, device=x.device)
+        from .droppath_draws import uniform      # rows of the pass's draw table (one launch per forward) when one is open
+        draws1 = uniform(B, x.device)
+        draws2 = uniform(B, x.device)
     for lin in (a.qkv, a.proj, m.fc1, m.fc2):
         _backends.note(lin, "hip-f32")
     cfg = (a.num_heads, a.shift_size, a.scale, keep, blk.norm1.eps, blk.norm2.eps, a._index_i32())

@@ -128,8 +128,12 @@ def test_trainer_steps(hip_lib, trainer, nd):
     before = [p.detach().clone() for p in tr.network.parameters()]
     losses = [float(tr.train_step(b)["loss"]) for _ in range(16)]
     assert all(np.isfinite(losses)), losses
-    moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, tr.network.parameters()))
-    assert moved > 0.9 * len(before), (moved, len(before), losses, tr.grad_scaler.get_scale())
+    # (a conv bias in front of BatchNorm has an identically zero gradient - mean removal - and He init leaves it at zero: AdamW's
+    #  decay of zero is zero, so those tensors legitimately stay put; everything else must move at lr 1e-4)
+    pairs = [(a, p.detach()) for a, p in zip(before, tr.network.parameters()) if bool(a.any()) or bool(p.detach().any())]
+    moved = sum(int(not torch.equal(a, p)) for a, p in pairs)
+    assert len(pairs) > 0.75 * len(before) and moved > 0.9 * len(pairs), (moved, len(pairs), len(before), losses,
+                                                                          tr.grad_scaler.get_scale())
 
 
 def test_swunetr_plugin_fails_like_the_reference_without_monai():
