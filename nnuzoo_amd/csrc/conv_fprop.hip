@@ -102,6 +102,13 @@ struct ConvDev {
   int tiles[3];
   int gx, gy, gz;
   int cout_fastest;  // workgroup order: cout block index fastest (1) or m-tile index fastest (0)
+  // knob 14 (round 6): m-tiles in BRICK order - 4 x 4 x 4 bricks of tiles, bricks in (d, h, w) order - instead of the linear
+  // (d, h, w) order.  The 64 workgroups an XCD runs at a time (32 CUs x 2) are then one brick (or half of one when two cout
+  // blocks share a tile) whose boxes overlap on all three axes: the halo a tile shares with its d-neighbours is fetched while the
+  // neighbour is resident instead of 256 tiles later, when the XCD's 4 MB L2 has long dropped it (a 16 x 16 plane of 8^3 tiles
+  // at 32 channels is 8.4 MB).  Launcher: only when all three tile counts are multiples of 4.
+  int brick;
+  unsigned mg_b2, mg_b1;   // reciprocals of tiles[2] / 4 and tiles[1] / 4
   // Consumer-side InstanceNorm + LeakyReLU (nnz_conv_tap_forward_innorm): `in` is the RAW conv output of the producer block(s)
   // and is normalised while the box is staged, y = lrelu(x * scale + shift) with {scale, shift} = in_tab[n][c - in_c0][2..3]
   // (the producer's table, written by its own launch's last workgroup); channels [0, in_c0) - the transposed-conv half of a
@@ -196,6 +203,7 @@ struct ConvCfg {
 //      against float64 on the stored outputs: mean 3e-6 like the VALU form, rstd within 1e-4 relative (VALU form 3e-6) -
 //      tests/test_determinism_gpu.py test_conv_epilogue_table_{large,small}_mean hold both forms.)
 //  12, 13  -DNNZ_CONV_TIMESTAMPS builds only: low / high half of the timestamp buffer's address
+//  14  m-tiles in 4 x 4 x 4 brick order where all three tile counts are multiples of 4 (ConvDev::brick)               (default 1)
 #ifndef NNZ_SETPRIO
 #define NNZ_SETPRIO 0   // experiment: wave priority raised over the depth-reuse MFMA loop
 #endif
@@ -205,7 +213,7 @@ struct ConvCfg {
 #ifndef NNZ_S2_PERSIST
 #define NNZ_S2_PERSIST false
 #endif
-static int g_tuning[16] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 1, 1, 0, 0, 0, 0};
+static int g_tuning[16] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 1, 1, 0, 0, 1, 0};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
@@ -247,6 +255,8 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const int gx_ = p.gx, gy_ = p.gy, gz_ = p.gz, nsplit_ = p.nsplit, ngroups_ = p.d.ngroups, cf_ = p.cout_fastest;
   const int t1_ = p.tiles[1], t2_ = p.tiles[2];
   const unsigned mgy = p.mg_gy, mgx = p.mg_gxw, mgs = p.mg_nsplit, mgg = p.mg_ngroups, mgt2 = p.mg_t2, mgt1 = p.mg_t1;
+  const unsigned mgb2 = p.mg_b2, mgb1 = p.mg_b1;
+  const int brick_ = p.brick;
   const int lo0_ = p.d.lo[0], lo1_ = p.d.lo[1], lo2_ = p.d.lo[2], ldi_ = p.d.ldi;
   const int Cin = p.d.Cin, Cout = p.d.Cout, T = p.d.ntaps_total;
   const int Di = p.d.in_dims[0], Hi = p.d.in_dims[1], Wi = p.d.in_dims[2];
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   asm volatile("" ::"s"(in_), "s"(w_), "s"(in_bytes_), "s"(w_bytes_));
   asm volatile("" ::"s"(gx_), "s"(gy_), "s"(gz_), "s"(nsplit_), "s"(ngroups_), "s"(cf_), "s"(t1_), "s"(t2_), "s"(mgy), "s"(mgx),
                "s"(mgs), "s"(mgg), "s"(mgt2), "s"(mgt1), "s"(lo0_), "s"(lo1_), "s"(lo2_), "s"(ldi_), "s"(Cin), "s"(Cout), "s"(T),
-               "s"(Di), "s"(Hi), "s"(Wi), "s"(TPW));
+               "s"(Di), "s"(Hi), "s"(Wi), "s"(TPW), "s"(mgb2), "s"(mgb1), "s"(brick_));
   auto udiv = [](unsigned n, int d, unsigned m) -> unsigned { return d == 1 ? n : __umulhi(n, m); };
   const int gxw = PERSIST ? gx_ / TPW : gx_;          // workgroups along the m-tile index
   const unsigned mgxw = mgx;                          // (the launcher's reciprocal is that of gx / tiles_per_wg)
@@ -290,10 +300,23 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   }
   const int n = udiv(bz, ngroups_, mgg);
   const int g = bz - n * ngroups_;
-  const unsigned q2 = udiv(bx, t2_, mgt2);
-  const int tw_i = bx - q2 * t2_;
-  const int td_i = udiv(q2, t1_, mgt1);
-  const int th_i = q2 - td_i * t1_;
+  int tw_i, td_i, th_i;
+  if (!PERSIST && brick_) {
+    const unsigned b = (unsigned)bx >> 6, r = (unsigned)bx & 63u;
+    const int nb2 = t2_ >> 2, nb1 = t1_ >> 2;
+    const unsigned qb = udiv(b, nb2, mgb2);
+    const int bw = b - qb * nb2;
+    const int bd = udiv(qb, nb1, mgb1);
+    const int bh = qb - bd * nb1;
+    tw_i = bw * 4 + (r & 3);
+    th_i = bh * 4 + ((r >> 2) & 3);
+    td_i = bd * 4 + (r >> 4);
+  } else {
+    const unsigned q2 = udiv(bx, t2_, mgt2);
+    tw_i = bx - q2 * t2_;
+    td_i = udiv(q2, t1_, mgt1);
+    th_i = q2 - td_i * t1_;
+  }
   const int m0d = td_i * TD, m0h = th_i * TH;
   int m0w = tw_i * TW;      // (PERSIST: advances by TW per tile; the launcher guarantees the run stays inside one W row)
   const int cb0 = by * NB;  // first 32-wide cout block
@@ -1351,6 +1374,8 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
     if ((unsigned long long)nwg * (unsigned long long)(dmax > p.gz ? dmax : p.gz) >= (1ull << 32)) return NNZ_EINVAL;
     p.mg_gy = magic(p.gy); p.mg_gxw = magic(gxw); p.mg_nsplit = magic(p.nsplit); p.mg_ngroups = magic(p.d.ngroups);
     p.mg_t2 = magic(p.tiles[2]); p.mg_t1 = magic(p.tiles[1]);
+    p.brick = g_tuning[14] && !PERSIST && p.tiles[0] % 4 == 0 && p.tiles[1] % 4 == 0 && p.tiles[2] % 4 == 0;
+    p.mg_b2 = magic(p.tiles[2] / 4); p.mg_b1 = magic(p.tiles[1] / 4);
   }
   {
     const unsigned long long ib = 2ull * p.d.N * p.d.in_dims[0] * p.d.in_dims[1] * p.d.in_dims[2] * (unsigned long long)p.d.ldi;

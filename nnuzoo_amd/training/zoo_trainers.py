@@ -195,7 +195,8 @@ class _X2Trainer(nnUNetTrainer):
             with torch.autocast('cuda'):
                 output = self._forward(data)
                 l = self.loss(list(output) if isinstance(output, (tuple, list)) else output, target)
-            self.grad_scaler.scale(l).backward()
+            with deferred_wgrads():  # the same grouped weight-gradient launches as the captured step (training/graph_step.py)
+                self.grad_scaler.scale(l).backward()
             if self.is_ddp:
                 allreduce_gradients(self.network.parameters())    # scaled gradients, like torch DDP under AMP
             self._optimizer_tail()

@@ -45,8 +45,11 @@ def test_draws_come_from_one_table_per_pass(hip_lib, name):
     assert n_requests > 10 and first >= n_requests       # every stochastic block asked once per branch
     # ... and the second pass made ONE call for all of them (plus whatever calls did not go through the table in the first pass)
     assert table_calls.count((n_requests, 2)) == 1 and len(table_calls) == 1 + (first - n_requests), (table_calls[:4], first)
-    assert all(torch.equal(p, q) for p, q in zip(a, b))
-    assert any(not torch.equal(p, q) for p, q in zip(a, c))
+    # equal seeds -> equal masks -> equal outputs up to the library convolutions' run-to-run noise; another seed drops other blocks
+    def near(p, q):
+        return (p - q).abs().max().item() <= 1e-3 * p.abs().max().item()
+    assert all(near(p, q) for p, q in zip(a, b)), [(p - q).abs().max().item() / p.abs().max().item() for p, q in zip(a, b)]
+    assert any(not near(p, q) for p, q in zip(a, c))
     net.eval()
     calls.clear()
     torch.rand = counting
