@@ -423,6 +423,25 @@ int nnz_residual_droppath_rand_forward(const void* input, int input_is_f16, cons
 int nnz_residual_droppath_rand_backward(const void* dout, int dout_is_f16, const float* rand, float keep, float scale,
                                         void* dx, int dx_is_f16, int B, long per_sample, void* stream);
 
+/* ---- depthwise-separable conv -> BatchNorm -> ReLU unit of SwT2Net's RSU4F stages, fp32 channels-last (csrc/sepconv32.hip).
+ * Replaces, for /root/reference/nnunetv2/nets/swt2net.py:17-31 REBNCONV (get_dwconv_layer -> nn.BatchNorm2d -> ReLU) inside RSU4F
+ * (:873-905), the cuDNN / MIOpen calls of the reference's fp32 step; the pointwise 1x1 between them is nnz_dense32_forward_fused.
+ * x / y [B][H][W][C] fp32, C % 4 == 0; w [C][3][3] (torch's [C, 1, 3, 3]); flip = 1: the input gradient (x = dy, y = dx). */
+int nnz_dw3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int flip,
+                       void* stream);
+long nnz_dw3x3_nhwc_wgrad_workspace_floats(int B, int H, int W, int C);
+/* dw [C][3][3] is written (no zero fill); per-range partials + fixed-order fold: deterministic */
+int nnz_dw3x3_nhwc_wgrad_f32(const float* x, const float* dy, float* workspace, float* dw, int B, int H, int W, int C,
+                             void* stream);
+/* y = relu(batch_norm(x)) on [T][C] fp32: training != 0 - batch statistics (two-pass), running estimates updated in place with
+ * torch.nn.BatchNorm2d's rule (momentum, unbiased variance); 0 - the running estimates.  mean / rstd [C] are written. */
+int nnz_bn_relu_nhwc_forward_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float* mean, float* rstd, float* y, long T, int C, int training, float momentum, float eps,
+                                 void* stream);
+/* backward of the training-mode unit: dx [T][C], dgamma / dbeta [C] written; fixed-order reductions */
+int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                                  const float* rstd, float* dx, float* dgamma, float* dbeta, long T, int C, void* stream);
+
 /* ---- top / left zero padding of a channels-last fp32 map to the window multiple and the crop back (SwinTransformerBlock.forward,
  * swt2net.py:643-645 F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0)) and :660 x[:, -H:, -W:, :]; each is the other's
  * backward).  small [B][H][W][C], big [B][H + py][W + px][C], C % 4 == 0, B * (H + py) <= 65535; one launch each. */

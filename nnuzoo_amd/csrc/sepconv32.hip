@@ -1,0 +1,277 @@
+// The depthwise-separable conv -> BatchNorm -> ReLU unit of SwT2Net's RSU4F stages in fp32, channels-last (round 6).
+//
+// Reference: /root/reference/nnunetv2/nets/swt2net.py:17-31 `REBNCONV` = get_dwconv_layer (depthwise 3x3, then pointwise 1x1,
+// both bias-free) -> nn.BatchNorm2d -> ReLU, eight of them per RSU4F (:873-905), three RSU4F stages in SwT2Net (512 / 1024
+// channels on 32^2 and 16^2 maps at a 512^2 patch).  The reference's trainer runs them in fp32 (nnUNetTrainerSwT2Net.py:112-130, no
+// autocast) through cuDNN; on this stack that is MIOpen: Winograd / implicit-GEMM solvers picked per process for the 1x1 (the
+// SwT2Net step differed by 7 % from box to box on that choice alone, DESIGN 5 of round 5), NCHW <-> NHWC transposes around them,
+// MIOpenBatchNorm{Fwd,Bwd}Spatial and ATen's depthwise kernels - ~140 library launches and 2.5 ms of a 56 ms step
+// (profiles/r05_swt2net_graph_kernels.txt).
+//
+// Here the RSU4F keeps its activations token-major ([B, H, W, C] fp32, the layout the Swin stages around it already use):
+//   * the pointwise 1x1 convolution IS a token Linear: csrc/dense32.hip (fp32 MFMA, its grouped weight gradients);
+//   * the depthwise 3x3 and the BatchNorm + ReLU are the small kernels below.  With channels innermost a lane owns 4 channels of a
+//     token (16-byte accesses, a wave covers 64 x 4 consecutive floats = whole lines); the maps are tiny (512 ... 2 048 tokens), so
+//     these are latency-sized launches - the point is one launch per operator, no layout changes, no library.
+// Everything reduces in a fixed order (no atomics): the unit is bit-reproducible from run to run.
+#include "common.hpp"
+
+namespace nnz {
+
+struct DwArgs32 {
+  const float* x;     // [B][H][W][C]
+  const float* w;     // [C][3][3] (torch's [C, 1, 3, 3])
+  const float* bias;  // [C] or null
+  float* y;           // [B][H][W][C]
+  int B, H, W, C;
+};
+
+// FLIP = false: y[t][c] = b[c] + sum_k w[c][k] x[t + off_k][c] (zero padding 1).  FLIP = true: the input gradient - the same
+// sum with the kernel rotated by 180 degrees (and no bias).  Thread = (token, channel quad).
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dw3x3_nhwc_kernel(DwArgs32 a) {
+  const int C4 = a.C >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)a.B * a.H * a.W * C4;
+  if (i >= total) return;
+  const int q = (int)(i % C4);
+  const long t = i / C4;
+  const int xw = (int)(t % a.W);
+  const int yh = (int)((t / a.W) % a.H);
+  const int c = q * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (!FLIP && a.bias) acc = *reinterpret_cast<const f32x4*>(a.bias + c);
+  const float* wp = a.w + (long)c * 9;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = yh + ky - 1;
+    if ((unsigned)yy >= (unsigned)a.H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = xw + kx - 1;
+      if ((unsigned)xx >= (unsigned)a.W) continue;
+      const int k = FLIP ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + (t + (long)(ky - 1) * a.W + (kx - 1)) * a.C + c);
+      acc[0] += wp[k] * v[0];
+      acc[1] += wp[9 + k] * v[1];
+      acc[2] += wp[18 + k] * v[2];
+      acc[3] += wp[27 + k] * v[3];
+    }
+  }
+  *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = acc;
+}
+
+// Weight gradient: dW[c][k] = sum_t dy[t][c] x[t + off_k][c].  Workgroup = 64 channels x 4 token groups of one token range
+// (blockIdx.y); per-range partials [range][C][9] go to the workspace and fold_partials() sums the ranges in a fixed order.
+__global__ __launch_bounds__(256) void dw3x3_nhwc_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ part, int B, int H, int W, int C,
+                                                               long tokens_per_range) {
+  __shared__ float red[4][64][9];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long T = (long)B * H * W;
+  const long t0 = (long)blockIdx.y * tokens_per_range;
+  const long t1 = t0 + tokens_per_range < T ? t0 + tokens_per_range : T;
+  float acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+  if (c < C) {
+    for (long t = t0 + g; t < t1; t += 4) {
+      const int xw = (int)(t % W);
+      const int yh = (int)((t / W) % H);
+      const float gy = dy[t * C + c];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = yh + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = xw + kx - 1;
+          if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+            acc[ky * 3 + kx] += gy * x[(t + (long)(ky - 1) * W + (kx - 1)) * C + c];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) red[g][cl][k] = acc[k];
+  __syncthreads();
+  if (g == 0 && c < C) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      part[((long)blockIdx.y * C + c) * 9 + k] = (red[0][cl][k] + red[1][cl][k]) + (red[2][cl][k] + red[3][cl][k]);
+  }
+}
+
+// ---- BatchNorm (training or running statistics) + ReLU on [T][C] -------------------------------------------------------------
+// Workgroup = 32 channels x 8 token groups.  Training statistics are two-pass (mean, then squared deviations) like torch's
+// (a sum of squares minus the squared mean loses the variance of a channel whose mean is large against its spread); the block of
+// 32 channels x T tokens is re-read from L2.  The eight groups are folded in a fixed order.
+struct BnArgs32 {
+  const float* x;
+  const float* dy;      // backward only
+  const float* gamma;
+  const float* beta;
+  float* running_mean;  // forward, training: updated in place (momentum); eval: read
+  float* running_var;
+  float* mean;          // [C] saved statistics (forward writes, backward reads)
+  float* rstd;
+  float* y;             // forward output / backward dx
+  float* dgamma;
+  float* dbeta;
+  long T;
+  int C;
+  int training;
+  float momentum, eps;
+};
+
+__device__ __forceinline__ float bn_fold8(float (*red)[32], int cl, int g, float v) {
+  red[g][cl] = v;
+  __syncthreads();
+  const float s = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_nhwc_fwd_kernel(BnArgs32 a) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool live = c < a.C;
+  float mean, rstd;
+  if (a.training) {
+    float s = 0.f;
+    if (live)
+      for (long t = g; t < a.T; t += 8) s += a.x[t * a.C + c];
+    mean = bn_fold8(red, cl, g, s) / (float)a.T;
+    float q = 0.f;
+    if (live)
+      for (long t = g; t < a.T; t += 8) {
+        const float d = a.x[t * a.C + c] - mean;
+        q += d * d;
+      }
+    const float var = bn_fold8(red, cl, g, q) / (float)a.T;
+    rstd = 1.f / sqrtf(var + a.eps);
+    if (live && g == 0) {
+      const float unb = a.T > 1 ? var * ((float)a.T / (float)(a.T - 1)) : var;
+      a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+      a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+    }
+  } else {
+    mean = live ? a.running_mean[c] : 0.f;
+    rstd = live ? 1.f / sqrtf(a.running_var[c] + a.eps) : 0.f;
+  }
+  if (!live) return;
+  if (g == 0) {
+    a.mean[c] = mean;
+    a.rstd[c] = rstd;
+  }
+  const float sc = rstd * a.gamma[c], sh = a.beta[c] - mean * sc;
+  for (long t = g; t < a.T; t += 8) {
+    const float v = a.x[t * a.C + c] * sc + sh;
+    a.y[t * a.C + c] = v > 0.f ? v : 0.f;
+  }
+}
+
+// dx = gamma rstd (g - mean(g) - xhat mean(g xhat)),  g = dy [pre > 0],  pre = xhat gamma + beta;  dgamma = sum g xhat,  dbeta = sum g
+__global__ __launch_bounds__(256) void bn_relu_nhwc_bwd_kernel(BnArgs32 a) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool live = c < a.C;
+  const float mean = live ? a.mean[c] : 0.f, rstd = live ? a.rstd[c] : 0.f;
+  const float ga = live ? a.gamma[c] : 0.f, be = live ? a.beta[c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (live)
+    for (long t = g; t < a.T; t += 8) {
+      const float xh = (a.x[t * a.C + c] - mean) * rstd;
+      const float gg = (xh * ga + be) > 0.f ? a.dy[t * a.C + c] : 0.f;
+      s1 += gg;
+      s2 += gg * xh;
+    }
+  const float sum_g = bn_fold8(red, cl, g, s1);
+  const float sum_gx = bn_fold8(red, cl, g, s2);
+  if (!live) return;
+  if (g == 0) {
+    a.dgamma[c] = sum_gx;
+    a.dbeta[c] = sum_g;
+  }
+  const float inv_t = 1.f / (float)a.T;
+  const float m1 = sum_g * inv_t, m2 = sum_gx * inv_t, k = ga * rstd;
+  for (long t = g; t < a.T; t += 8) {
+    const float xh = (a.x[t * a.C + c] - mean) * rstd;
+    const float gg = (xh * ga + be) > 0.f ? a.dy[t * a.C + c] : 0.f;
+    a.y[t * a.C + c] = k * (gg - m1 - xh * m2);
+  }
+}
+
+}  // namespace nnz
+
+// x, y: [B][H][W][C] fp32 (C a multiple of 4, 16-byte aligned); w: [C][3][3]; bias: [C] or NULL.  flip = 1: the input gradient
+// (x = dy, y = dx; the bias is ignored).
+extern "C" int nnz_dw3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
+                                  int flip, void* stream) {
+  using namespace nnz;
+  if (!x || !w || !y || B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || ((size_t)x & 15) || ((size_t)y & 15)) return NNZ_EINVAL;
+  DwArgs32 a = {x, w, flip ? nullptr : bias, y, B, H, W, C};
+  const long total = (long)B * H * W * (C >> 2);
+  const long blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffL) return NNZ_EINVAL;
+  if (flip) NNZ_LAUNCH(dw3x3_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else NNZ_LAUNCH(dw3x3_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+static int dw3x3_ranges(long T) {
+  long r = (T + 511) / 512;          // >= 512 tokens per range (128 per token group)
+  return (int)(r < 1 ? 1 : (r > 64 ? 64 : r));
+}
+extern "C" long nnz_dw3x3_nhwc_wgrad_workspace_floats(int B, int H, int W, int C) {
+  if (B < 1 || H < 1 || W < 1 || C < 1) return 0;
+  return (long)dw3x3_ranges((long)B * H * W) * C * 9;
+}
+// dw: [C][3][3] is WRITTEN (no zero fill); workspace: nnz_dw3x3_nhwc_wgrad_workspace_floats floats.  Deterministic.
+extern "C" int nnz_dw3x3_nhwc_wgrad_f32(const float* x, const float* dy, float* workspace, float* dw, int B, int H, int W, int C,
+                                        void* stream) {
+  using namespace nnz;
+  if (!x || !dy || !workspace || !dw || B < 1 || H < 1 || W < 1 || C < 1) return NNZ_EINVAL;
+  const long T = (long)B * H * W;
+  const int ranges = dw3x3_ranges(T);
+  const long per = (T + ranges - 1) / ranges;
+  NNZ_LAUNCH(dw3x3_nhwc_wgrad_kernel, dim3((C + 63) / 64, ranges), dim3(256), 0, (hipStream_t)stream, x, dy, workspace, B, H, W, C,
+             per);
+  hipError_t e = fold_partials(workspace, ranges, (long)C * 9, (long)C * 9, dw, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// y = relu(batch_norm(x)) on [T][C] fp32.  training != 0: batch statistics (biased variance for the normalisation, the running
+// estimates updated in place with `momentum` and the unbiased variance - torch.nn.BatchNorm2d's rule); training == 0: the running
+// estimates.  mean / rstd [C] are written for the backward.
+extern "C" int nnz_bn_relu_nhwc_forward_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                            float* running_var, float* mean, float* rstd, float* y, long T, int C, int training,
+                                            float momentum, float eps, void* stream) {
+  using namespace nnz;
+  if (!x || !gamma || !beta || !running_mean || !running_var || !mean || !rstd || !y || T < 1 || C < 1) return NNZ_EINVAL;
+  BnArgs32 a = {};
+  a.x = x; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var; a.mean = mean; a.rstd = rstd;
+  a.y = y; a.T = T; a.C = C; a.training = training; a.momentum = momentum; a.eps = eps;
+  NNZ_LAUNCH(bn_relu_nhwc_fwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// backward of the training-mode unit: dx [T][C], dgamma / dbeta [C] are WRITTEN.  Deterministic.
+extern "C" int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                             const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, long T,
+                                             int C, void* stream) {
+  using namespace nnz;
+  if (!x || !dy || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || T < 1 || C < 1) return NNZ_EINVAL;
+  BnArgs32 a = {};
+  a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
+  a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.T = T; a.C = C;
+  NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}

@@ -293,7 +293,12 @@ class RSU4F(nn.Module):
         self.rebnconv1d = B(mid_ch * 2, out_ch, dirate=1)
 
     def forward(self, x):
-        from .. import rebnconv
+        from .. import rebnconv, sepconv32
+        if sepconv32.hip_path_ok(self, x):
+            # the depthwise-separable fp32 unit of swt2net.py: depthwise 3x3, pointwise 1x1 on the fp32 MFMA Linear kernels, batch-stat
+            # norm + ReLU - token-major inside the block, no library call (nnuzoo_amd/sepconv32.py)
+            _backends.note(self, "hip-f32")
+            return sepconv32.rsu4f_forward(self, x)
         _backends.note(self, "hip" if rebnconv.USE_HIP and rebnconv.hip_path_ok(self, x) else "library",
                        why="RSU4F outside fp16 autocast / unsupported channels / eval with autograd")
         if rebnconv.USE_HIP and rebnconv.hip_path_ok(self, x):

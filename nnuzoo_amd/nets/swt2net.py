@@ -353,7 +353,16 @@ class SwinTransformerUnet(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward(self, x):
-        res = self.rebnconvin(x) if self.add_last else None
+        from .. import backends as _backends
+        from .. import sepconv32
+        res = None
+        if self.add_last:
+            if sepconv32.stem_ok(self.rebnconvin, x):
+                # depthwise 3x3 + pointwise 1x1 of the stage's residual branch, token-major on csrc/sepconv32.hip / dense32.hip
+                _backends.note(self.rebnconvin, "hip-f32")
+                res = sepconv32.stem_forward(self.rebnconvin, x)
+            else:
+                res = self.rebnconvin(x)
         x = self.pos_drop(self.patch_embed(x))
         saved = []
         for layer in self.layers:
@@ -365,7 +374,11 @@ class SwinTransformerUnet(nn.Module):
             x = x[:, :skip.shape[1], :skip.shape[2], :]  # drop the rows/cols that came from odd-size padding
             x = layer(self.skip_connection_layers[i](torch.cat([x, skip], -1)))
         x = self.final_patch_expanding(self.norm_up(x))
-        x = self.head(x.permute(0, 3, 1, 2))
+        if sepconv32.pointwise_ok(self.head, x):
+            _backends.note(self.head, "hip-f32")          # the 1x1 head IS a token Linear (fp32 MFMA, csrc/dense32.hip)
+            x = sepconv32.pointwise_tokens(self.head, x).permute(0, 3, 1, 2)
+        else:
+            x = self.head(x.permute(0, 3, 1, 2))
         return x + res if self.add_last else x
 
 

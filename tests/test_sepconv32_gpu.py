@@ -1,0 +1,106 @@
+"""The fp32 depthwise-separable conv -> BatchNorm -> ReLU unit of SwT2Net's RSU4F stages on hand-written kernels
+(nnuzoo_amd/sepconv32.py, csrc/sepconv32.hip + the fp32 MFMA Linear kernels) against the torch modules the reference's classes are
+made of (/root/reference/nnunetv2/nets/swt2net.py:17-31 REBNCONV, :873-905 RSU4F) in float64 on the CPU.  The whole-net goldens of
+tests/test_zoo_gpu.py (SwT2Net forward / backward from the reference's own class) run through the same path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, ref, tol, what):
+    ref = ref.to(torch.float64)
+    err = (got.detach().double().cpu() - ref).abs().max().item()
+    assert err <= tol * max(ref.abs().max().item(), 1e-12), (what, err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 512), (1, 8, 8, 1024), (2, 9, 13, 36), (1, 1, 5, 4), (2, 64, 64, 64)])
+def test_depthwise_3x3_forward_backward(hip_lib, B, H, W, C):
+    from nnuzoo_amd.sepconv32 import _Dw3x3Fn
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g)
+    dy = torch.randn(B, H, W, C, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1, groups=C).permute(0, 2, 3, 1)
+    rx, rw, rb = torch.autograd.grad(ref, [xr, wr, br], dy.double())
+    runs = []
+    for _ in range(2):
+        xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        y = _Dw3x3Fn.apply(xd, wd, bd)
+        runs.append((y.detach(),) + torch.autograd.grad(y, [xd, wd, bd], dy.to(DEV)))
+    for name, got, want in zip(("y", "dx", "dw", "db"), runs[0], (ref.detach(), rx, rw, rb)):
+        _close(got, want, 2e-5, name)
+    assert all(torch.equal(p, q) for p, q in zip(runs[0], runs[1]))          # fixed-order reductions
+
+
+@pytest.mark.parametrize("T,C,training", [(512, 512, True), (128, 1024, True), (77, 36, True), (300, 40, False), (2, 4, True)])
+def test_batchnorm_relu_forward_backward(hip_lib, T, C, training):
+    from nnuzoo_amd.sepconv32 import _BnReluFn
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(T, C, generator=g) * 1.7 + torch.randn(C, generator=g) * 3        # means large against the spread too
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(T, C, generator=g)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    ref = F.relu(F.batch_norm(xr, rm64, rv64, gr, br, training, 0.1, 1e-5))
+    xd, gd, bd = (t.to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    y = _BnReluFn.apply(xd, gd, bd, rmd, rvd, 0.1, 1e-5, training)
+    _close(y, ref.detach(), 2e-5, "y")
+    _close(rmd, rm64, 1e-5, "running_mean")
+    _close(rvd, rv64, 1e-5, "running_var")
+    if training:
+        want = torch.autograd.grad(ref, [xr, gr, br], dy.double())
+        got = torch.autograd.grad(y, [xd, gd, bd], dy.to(DEV))
+        for name, a, b in zip(("dx", "dgamma", "dbeta"), got, want):
+            _close(a, b, 5e-5, name)
+
+
+def _rsu(mid, cin, cout):
+    from nnuzoo_amd.nets.swt2net import RSU4F
+    torch.manual_seed(3)
+    m = RSU4F(cin, mid, cout)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.uniform_(0.5, 1.5) if p is not None and p.mean() > 0.5 else p.normal_(0, 0.2)
+    return m
+
+
+@pytest.mark.parametrize("cin,mid,cout,size", [(64, 32, 64, 16), (512, 256, 512, 8)])
+def test_rsu4f_matches_the_torch_modules(hip_lib, cin, mid, cout, size):
+    """the whole stage: HIP path on the device vs the module path (stock torch convolutions / batch norm) in float64 on the CPU -
+    output, dx, every parameter gradient, the running statistics; bit-identical run to run"""
+    import copy
+    from nnuzoo_amd import sepconv32
+    ref = _rsu(mid, cin, cout).double().train()
+    x = torch.randn(2, cin, size, size, generator=torch.Generator().manual_seed(5))
+    dy = torch.randn(2, cout, size, size, generator=torch.Generator().manual_seed(6))
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double())
+    runs = []
+    for _ in range(2):
+        net = _rsu(mid, cin, cout).to(DEV).train()
+        xd = x.to(DEV).requires_grad_(True)
+        assert sepconv32.hip_path_ok(net, xd)
+        y = net(xd)
+        assert net.backend == "hip-f32"
+        y.backward(dy.to(DEV))
+        runs.append((net, y.detach(), xd.grad))
+    net, y, dx = runs[0]
+    _close(y, yr.detach(), 1e-4, "y")
+    _close(dx, xr.grad, 3e-4, "dx")
+    top = max(p.grad.abs().max().item() for p in ref.parameters())
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        err = (p.grad.double().cpu() - q.grad).abs().max().item()
+        assert err <= 3e-4 * max(q.grad.abs().max().item(), 1e-3 * top), (n, err, q.grad.abs().max().item())
+    for (n, b), (_, c) in zip(net.named_buffers(), ref.named_buffers()):
+        _close(b.double() if b.is_floating_point() else b.double(), c.double(), 1e-5, n)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert all(torch.equal(p.grad, q.grad) for p, q in zip(runs[0][0].parameters(), runs[1][0].parameters()))
