@@ -222,13 +222,17 @@ extern "C" int nnz_dw3x3_nhwc_f32(const float* x, const float* w, const float* b
   return NNZ_OK;
 }
 
+// token ranges of the weight gradient: 256 tokens each (64 per token group) so that the full-resolution stems (524 288 tokens of 32
+// channels) spread over ~2 000 workgroups - with 64 ranges (first version) they were 64 workgroups walking 2 048 tokens per thread
+// and the SwT2Net step went from 56 to 76 ms.  More than 256 ranges fold in two levels (scratch behind the partials).
 static int dw3x3_ranges(long T) {
-  long r = (T + 511) / 512;          // >= 512 tokens per range (128 per token group)
-  return (int)(r < 1 ? 1 : (r > 64 ? 64 : r));
+  long r = (T + 255) / 256;
+  return (int)(r < 1 ? 1 : (r > 8192 ? 8192 : r));
 }
 extern "C" long nnz_dw3x3_nhwc_wgrad_workspace_floats(int B, int H, int W, int C) {
   if (B < 1 || H < 1 || W < 1 || C < 1) return 0;
-  return (long)dw3x3_ranges((long)B * H * W) * C * 9;
+  const int ranges = dw3x3_ranges((long)B * H * W);
+  return (long)ranges * C * 9 + nnz::fold_partials_scratch_floats(ranges, (long)C * 9);
 }
 // dw: [C][3][3] is WRITTEN (no zero fill); workspace: nnz_dw3x3_nhwc_wgrad_workspace_floats floats.  Deterministic.
 extern "C" int nnz_dw3x3_nhwc_wgrad_f32(const float* x, const float* dy, float* workspace, float* dw, int B, int H, int W, int C,
@@ -240,7 +244,8 @@ extern "C" int nnz_dw3x3_nhwc_wgrad_f32(const float* x, const float* dy, float* 
   const long per = (T + ranges - 1) / ranges;
   NNZ_LAUNCH(dw3x3_nhwc_wgrad_kernel, dim3((C + 63) / 64, ranges), dim3(256), 0, (hipStream_t)stream, x, dy, workspace, B, H, W, C,
              per);
-  hipError_t e = fold_partials(workspace, ranges, (long)C * 9, (long)C * 9, dw, (hipStream_t)stream);
+  float* scratch = fold_partials_scratch_floats(ranges, (long)C * 9) ? workspace + (long)ranges * C * 9 : nullptr;
+  hipError_t e = fold_partials(workspace, ranges, (long)C * 9, (long)C * 9, dw, (hipStream_t)stream, scratch);
   if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
