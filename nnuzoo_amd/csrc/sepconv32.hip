@@ -61,25 +61,38 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc_kernel(DwArgs32 a) {
   *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = acc;
 }
 
-// Weight gradient: dW[c][k] = sum_t dy[t][c] x[t + off_k][c].  Workgroup = 64 channels x 4 token groups of one token range
-// (blockIdx.y); per-range partials [range][C][9] go to the workspace and fold_partials() sums the ranges in a fixed order.
+// Lane geometry of the reducing kernels below: a workgroup owns 16 consecutive channels - lane quad q = tid & 3 holds channels
+// 4 q .. 4 q + 3 of a token as one 16-byte access - and 64 token groups tg = tid >> 2 (16 per wave).  Sums over tokens fold in
+// three fixed stages: the lanes of a wave that share q (shuffles over lane bits 2 .. 5), the four waves through LDS, and - across
+// workgroups - per-range partials summed by fold_partials().  (First version: 32 / 64 channels x 8 / 4 token groups, one 4-byte load
+// per token and thread - 16 workgroups walking 64 tokens each for a 512 x 512 map: 96 - 190 us per launch where the bytes take 1.)
+__device__ __forceinline__ float sep_wave_fold(float v) {
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// Weight gradient: dW[c][k] = sum_t dy[t][c] x[t + off_k][c].  Workgroup = 16 channels (blockIdx.x) x one range of 256 tokens
+// (blockIdx.y): four tokens per thread; per-range partials [range][C][9] go to the workspace and fold_partials() sums the ranges.
 __global__ __launch_bounds__(256) void dw3x3_nhwc_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ part, int B, int H, int W, int C,
                                                                long tokens_per_range) {
-  __shared__ float red[4][64][9];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float red[4][16][9];
+  const int q = threadIdx.x & 3, tg = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + q * 4;
   const long T = (long)B * H * W;
   const long t0 = (long)blockIdx.y * tokens_per_range;
   const long t1 = t0 + tokens_per_range < T ? t0 + tokens_per_range : T;
-  float acc[9];
+  f32x4 acc[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+  for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    for (long t = t0 + g; t < t1; t += 4) {
+    for (long t = t0 + tg; t < t1; t += 64) {
       const int xw = (int)(t % W);
       const int yh = (int)((t / W) % H);
-      const float gy = dy[t * C + c];
+      const f32x4 gy = *reinterpret_cast<const f32x4*>(dy + t * C + c);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int yy = yh + ky - 1;
@@ -87,25 +100,30 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc_wgrad_kernel(const float* __re
         for (int kx = 0; kx < 3; ++kx) {
           const int xx = xw + kx - 1;
           if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-            acc[ky * 3 + kx] += gy * x[(t + (long)(ky - 1) * W + (kx - 1)) * C + c];
+            acc[ky * 3 + kx] += gy * *reinterpret_cast<const f32x4*>(x + (t + (long)(ky - 1) * W + (kx - 1)) * C + c);
         }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) red[g][cl][k] = acc[k];
-  __syncthreads();
-  if (g == 0 && c < C) {
+  for (int k = 0; k < 9; ++k)
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-      part[((long)blockIdx.y * C + c) * 9 + k] = (red[0][cl][k] + red[1][cl][k]) + (red[2][cl][k] + red[3][cl][k]);
+    for (int e = 0; e < 4; ++e) {
+      const float v = sep_wave_fold(acc[k][e]);
+      if ((threadIdx.x & 63) < 4) red[wave][q * 4 + e][k] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 144) {
+    const int ch = threadIdx.x / 9, k = threadIdx.x - ch * 9;
+    if (blockIdx.x * 16 + ch < C)
+      part[((long)blockIdx.y * C + blockIdx.x * 16 + ch) * 9 + k] = (red[0][ch][k] + red[1][ch][k]) + (red[2][ch][k] + red[3][ch][k]);
   }
 }
 
 // ---- BatchNorm (training or running statistics) + ReLU on [T][C] -------------------------------------------------------------
-// Workgroup = 32 channels x 8 token groups.  Training statistics are two-pass (mean, then squared deviations) like torch's
-// (a sum of squares minus the squared mean loses the variance of a channel whose mean is large against its spread); the block of
-// 32 channels x T tokens is re-read from L2.  The eight groups are folded in a fixed order.
+// Workgroup = 16 channels x 64 token groups (geometry above), the whole token axis: these maps are 128 ... 2 048 tokens.  Training
+// statistics are two-pass (mean, then squared deviations) like torch's (a sum of squares minus the squared mean loses the variance
+// of a channel whose mean is large against its spread); the 16 channels x T tokens are re-read from L2.
 struct BnArgs32 {
   const float* x;
   const float* dy;      // backward only
@@ -124,83 +142,107 @@ struct BnArgs32 {
   float momentum, eps;
 };
 
-__device__ __forceinline__ float bn_fold8(float (*red)[32], int cl, int g, float v) {
-  red[g][cl] = v;
+// sum over all tokens of a per-thread f32x4 (the thread's four channels); every thread gets its channels' totals
+__device__ __forceinline__ f32x4 bn_fold(float (*red)[16], int q, f32x4 v) {
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float s = sep_wave_fold(v[e]);
+    if ((threadIdx.x & 63) < 4) red[wave][q * 4 + e] = s;
+  }
   __syncthreads();
-  const float s = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (red[0][q * 4 + e] + red[1][q * 4 + e]) + (red[2][q * 4 + e] + red[3][q * 4 + e]);
   __syncthreads();
-  return s;
+  return o;
 }
 
 __global__ __launch_bounds__(256) void bn_relu_nhwc_fwd_kernel(BnArgs32 a) {
-  __shared__ float red[8][32];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float red[4][16];
+  const int q = threadIdx.x & 3, tg = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + q * 4;
   const bool live = c < a.C;
-  float mean, rstd;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = mean;
   if (a.training) {
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (live)
-      for (long t = g; t < a.T; t += 8) s += a.x[t * a.C + c];
-    mean = bn_fold8(red, cl, g, s) / (float)a.T;
-    float q = 0.f;
+      for (long t = tg; t < a.T; t += 64) s += *reinterpret_cast<const f32x4*>(a.x + t * a.C + c);
+    mean = bn_fold(red, q, s) * (1.f / (float)a.T);
+    f32x4 d2 = {0.f, 0.f, 0.f, 0.f};
     if (live)
-      for (long t = g; t < a.T; t += 8) {
-        const float d = a.x[t * a.C + c] - mean;
-        q += d * d;
+      for (long t = tg; t < a.T; t += 64) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(a.x + t * a.C + c) - mean;
+        d2 += d * d;
       }
-    const float var = bn_fold8(red, cl, g, q) / (float)a.T;
-    rstd = 1.f / sqrtf(var + a.eps);
-    if (live && g == 0) {
-      const float unb = a.T > 1 ? var * ((float)a.T / (float)(a.T - 1)) : var;
-      a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-      a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+    const f32x4 var = bn_fold(red, q, d2) * (1.f / (float)a.T);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(var[e] + a.eps);
+    if (live && tg == 0) {
+      const float k = a.T > 1 ? (float)a.T / (float)(a.T - 1) : 1.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a.running_mean[c + e] = (1.f - a.momentum) * a.running_mean[c + e] + a.momentum * mean[e];
+        a.running_var[c + e] = (1.f - a.momentum) * a.running_var[c + e] + a.momentum * var[e] * k;
+      }
     }
-  } else {
-    mean = live ? a.running_mean[c] : 0.f;
-    rstd = live ? 1.f / sqrtf(a.running_var[c] + a.eps) : 0.f;
+  } else if (live) {
+    mean = *reinterpret_cast<const f32x4*>(a.running_mean + c);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(a.running_var + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(rv[e] + a.eps);
   }
   if (!live) return;
-  if (g == 0) {
-    a.mean[c] = mean;
-    a.rstd[c] = rstd;
+  if (tg == 0) {
+    *reinterpret_cast<f32x4*>(a.mean + c) = mean;
+    *reinterpret_cast<f32x4*>(a.rstd + c) = rstd;
   }
-  const float sc = rstd * a.gamma[c], sh = a.beta[c] - mean * sc;
-  for (long t = g; t < a.T; t += 8) {
-    const float v = a.x[t * a.C + c] * sc + sh;
-    a.y[t * a.C + c] = v > 0.f ? v : 0.f;
+  const f32x4 sc = rstd * *reinterpret_cast<const f32x4*>(a.gamma + c);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(a.beta + c) - mean * sc;
+  for (long t = tg; t < a.T; t += 64) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.x + t * a.C + c) * sc + sh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = v;
   }
 }
 
 // dx = gamma rstd (g - mean(g) - xhat mean(g xhat)),  g = dy [pre > 0],  pre = xhat gamma + beta;  dgamma = sum g xhat,  dbeta = sum g
 __global__ __launch_bounds__(256) void bn_relu_nhwc_bwd_kernel(BnArgs32 a) {
-  __shared__ float red[8][32];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float red[4][16];
+  const int q = threadIdx.x & 3, tg = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + q * 4;
   const bool live = c < a.C;
-  const float mean = live ? a.mean[c] : 0.f, rstd = live ? a.rstd[c] : 0.f;
-  const float ga = live ? a.gamma[c] : 0.f, be = live ? a.beta[c] : 0.f;
-  float s1 = 0.f, s2 = 0.f;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 mean = live ? *reinterpret_cast<const f32x4*>(a.mean + c) : z, rstd = live ? *reinterpret_cast<const f32x4*>(a.rstd + c) : z;
+  const f32x4 ga = live ? *reinterpret_cast<const f32x4*>(a.gamma + c) : z, be = live ? *reinterpret_cast<const f32x4*>(a.beta + c) : z;
+  f32x4 s1 = z, s2 = z;
   if (live)
-    for (long t = g; t < a.T; t += 8) {
-      const float xh = (a.x[t * a.C + c] - mean) * rstd;
-      const float gg = (xh * ga + be) > 0.f ? a.dy[t * a.C + c] : 0.f;
+    for (long t = tg; t < a.T; t += 64) {
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.x + t * a.C + c) - mean) * rstd;
+      f32x4 gg = *reinterpret_cast<const f32x4*>(a.dy + t * a.C + c);
+      const f32x4 pre = xh * ga + be;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gg[e] = pre[e] > 0.f ? gg[e] : 0.f;
       s1 += gg;
       s2 += gg * xh;
     }
-  const float sum_g = bn_fold8(red, cl, g, s1);
-  const float sum_gx = bn_fold8(red, cl, g, s2);
+  const f32x4 sum_g = bn_fold(red, q, s1);
+  const f32x4 sum_gx = bn_fold(red, q, s2);
   if (!live) return;
-  if (g == 0) {
-    a.dgamma[c] = sum_gx;
-    a.dbeta[c] = sum_g;
+  if (tg == 0) {
+    *reinterpret_cast<f32x4*>(a.dgamma + c) = sum_gx;
+    *reinterpret_cast<f32x4*>(a.dbeta + c) = sum_g;
   }
   const float inv_t = 1.f / (float)a.T;
-  const float m1 = sum_g * inv_t, m2 = sum_gx * inv_t, k = ga * rstd;
-  for (long t = g; t < a.T; t += 8) {
-    const float xh = (a.x[t * a.C + c] - mean) * rstd;
-    const float gg = (xh * ga + be) > 0.f ? a.dy[t * a.C + c] : 0.f;
-    a.y[t * a.C + c] = k * (gg - m1 - xh * m2);
+  const f32x4 m1 = sum_g * inv_t, m2 = sum_gx * inv_t, k = ga * rstd;
+  for (long t = tg; t < a.T; t += 64) {
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.x + t * a.C + c) - mean) * rstd;
+    f32x4 gg = *reinterpret_cast<const f32x4*>(a.dy + t * a.C + c);
+    const f32x4 pre = xh * ga + be;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gg[e] = pre[e] > 0.f ? gg[e] : 0.f;
+    *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = k * (gg - m1 - xh * m2);
   }
 }
 
@@ -238,11 +280,12 @@ extern "C" long nnz_dw3x3_nhwc_wgrad_workspace_floats(int B, int H, int W, int C
 extern "C" int nnz_dw3x3_nhwc_wgrad_f32(const float* x, const float* dy, float* workspace, float* dw, int B, int H, int W, int C,
                                         void* stream) {
   using namespace nnz;
-  if (!x || !dy || !workspace || !dw || B < 1 || H < 1 || W < 1 || C < 1) return NNZ_EINVAL;
+  if (!x || !dy || !workspace || !dw || B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || ((size_t)x & 15) || ((size_t)dy & 15))
+    return NNZ_EINVAL;
   const long T = (long)B * H * W;
   const int ranges = dw3x3_ranges(T);
   const long per = (T + ranges - 1) / ranges;
-  NNZ_LAUNCH(dw3x3_nhwc_wgrad_kernel, dim3((C + 63) / 64, ranges), dim3(256), 0, (hipStream_t)stream, x, dy, workspace, B, H, W, C,
+  NNZ_LAUNCH(dw3x3_nhwc_wgrad_kernel, dim3((C + 15) / 16, ranges), dim3(256), 0, (hipStream_t)stream, x, dy, workspace, B, H, W, C,
              per);
   float* scratch = fold_partials_scratch_floats(ranges, (long)C * 9) ? workspace + (long)ranges * C * 9 : nullptr;
   hipError_t e = fold_partials(workspace, ranges, (long)C * 9, (long)C * 9, dw, (hipStream_t)stream, scratch);
@@ -251,18 +294,18 @@ extern "C" int nnz_dw3x3_nhwc_wgrad_f32(const float* x, const float* dy, float* 
   return NNZ_OK;
 }
 
-// y = relu(batch_norm(x)) on [T][C] fp32.  training != 0: batch statistics (biased variance for the normalisation, the running
+// y = relu(batch_norm(x)) on [T][C] fp32, C % 4 == 0.  training != 0: batch statistics (biased variance for the normalisation, the running
 // estimates updated in place with `momentum` and the unbiased variance - torch.nn.BatchNorm2d's rule); training == 0: the running
 // estimates.  mean / rstd [C] are written for the backward.
 extern "C" int nnz_bn_relu_nhwc_forward_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                             float* running_var, float* mean, float* rstd, float* y, long T, int C, int training,
                                             float momentum, float eps, void* stream) {
   using namespace nnz;
-  if (!x || !gamma || !beta || !running_mean || !running_var || !mean || !rstd || !y || T < 1 || C < 1) return NNZ_EINVAL;
+  if (!x || !gamma || !beta || !running_mean || !running_var || !mean || !rstd || !y || T < 1 || C < 4 || (C & 3)) return NNZ_EINVAL;
   BnArgs32 a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var; a.mean = mean; a.rstd = rstd;
   a.y = y; a.T = T; a.C = C; a.training = training; a.momentum = momentum; a.eps = eps;
-  NNZ_LAUNCH(bn_relu_nhwc_fwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(bn_relu_nhwc_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -272,11 +315,11 @@ extern "C" int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, co
                                              const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, long T,
                                              int C, void* stream) {
   using namespace nnz;
-  if (!x || !dy || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || T < 1 || C < 1) return NNZ_EINVAL;
+  if (!x || !dy || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || T < 1 || C < 4 || (C & 3)) return NNZ_EINVAL;
   BnArgs32 a = {};
   a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
   a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.T = T; a.C = C;
-  NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
