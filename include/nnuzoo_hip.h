@@ -442,6 +442,12 @@ int nnz_bn_relu_nhwc_forward_f32(const float* x, const float* gamma, const float
 int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, long T, int C, void* stream);
 
+/* weight gradient of a pointwise convolution with few channels over many tokens: dW [N][K] = dy^T x, dy [T][N], x [T][K] fp32,
+ * N, K multiples of 4 and <= 64 (the full-resolution stems / heads of the Swin U-net stages, swt2net.py:757, 795: a streaming
+ * reduction, VALU 4 x 4 register blocks from LDS-staged token chunks).  dW is written; per-range partials + fixed-order folds. */
+long nnz_pw_wgrad_small_workspace_floats(long T, int N, int K);
+int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* workspace, float* dW, long T, int N, int K, void* stream);
+
 /* ---- top / left zero padding of a channels-last fp32 map to the window multiple and the crop back (SwinTransformerBlock.forward,
  * swt2net.py:643-645 F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0)) and :660 x[:, -H:, -W:, :]; each is the other's
  * backward).  small [B][H][W][C], big [B][H + py][W + px][C], C % 4 == 0, B * (H + py) <= 65535; one launch each. */

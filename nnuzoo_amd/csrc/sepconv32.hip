@@ -246,6 +246,74 @@ __global__ __launch_bounds__(256) void bn_relu_nhwc_bwd_kernel(BnArgs32 a) {
   }
 }
 
+// ---- weight gradient of a pointwise convolution with few channels over MANY tokens -----------------------------------------
+// dW[n][k] = sum_t dy[t][n] x[t][k], N, K <= 64, T = 32 768 ... 524 288: the stems and heads of the Swin U-net stages at
+// full resolution (32 -> 32 at 512^2, 64 -> 64 at 256^2, ...).  A 64-wide MFMA tile is half empty at these widths and the grouped
+// fp32 weight-gradient launch of csrc/dense32.hip spent ~140 us per such problem (~1 TB/s); the problem is a streaming reduction of
+// 2 x T x 32 floats.  Here: a workgroup owns a range of 1 024 tokens, stages 64 tokens of dy and x at a time in LDS (coalesced
+// 16-byte loads), a thread owns a 4 x 4 block of dW and a share of the 64 tokens (256 / (N K / 16) shares); shares fold through LDS
+// in a fixed order, ranges through fold_partials(): deterministic.
+constexpr int PW_TR = 1024;   // tokens per workgroup
+__global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             float* __restrict__ part, long T, int N, int K, int shares) {
+  __shared__ __attribute__((aligned(16))) float sD[64 * 64];
+  __shared__ __attribute__((aligned(16))) float sX[64 * 64];
+  const int tid = threadIdx.x;
+  const int tk = K >> 2, tiles = (N >> 2) * tk;
+  const int tile = tid % tiles, sp = tid / tiles;
+  const bool work = sp < shares;
+  const int n0 = (tile / tk) * 4, k0 = (tile % tk) * 4;
+  const long t0 = (long)blockIdx.x * PW_TR;
+  const long t1 = t0 + PW_TR < T ? t0 + PW_TR : T;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const int n4 = N >> 2, k4 = K >> 2;
+  for (long tc = t0; tc < t1; tc += 64) {
+    const int nt = t1 - tc < 64 ? (int)(t1 - tc) : 64;
+    for (int i = tid; i < 64 * n4; i += 256) {
+      const int tt = i / n4, q = i - tt * n4;
+      *reinterpret_cast<f32x4*>(sD + tt * N + 4 * q) =
+          tt < nt ? *reinterpret_cast<const f32x4*>(dy + (tc + tt) * N + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = tid; i < 64 * k4; i += 256) {
+      const int tt = i / k4, q = i - tt * k4;
+      *reinterpret_cast<f32x4*>(sX + tt * K + 4 * q) =
+          tt < nt ? *reinterpret_cast<const f32x4*>(x + (tc + tt) * K + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (work) {
+      for (int tt = sp; tt < 64; tt += shares) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(sD + tt * N + n0);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sX + tt * K + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += d[i] * v[j];
+      }
+    }
+    __syncthreads();
+  }
+  // fold the token shares: share s of tile `tile` parks its block at sD[(s * tiles + tile) * 16 ...] (shares * tiles <= 256 blocks
+  // of 16 floats = the 4 096 floats of sD), share 0 sums them in share order
+  if (work) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(sD + (sp * tiles + tile) * 16 + 4 * i) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+  }
+  __syncthreads();
+  if (work && sp == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(sD + tile * 16 + 4 * i);
+      for (int q = 1; q < shares; ++q) s += *reinterpret_cast<const f32x4*>(sD + (q * tiles + tile) * 16 + 4 * i);
+      *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * N * K + (long)(n0 + i) * K + k0) = s;
+    }
+  }
+}
+
 }  // namespace nnz
 
 // x, y: [B][H][W][C] fp32 (C a multiple of 4, 16-byte aligned); w: [C][3][3]; bias: [C] or NULL.  flip = 1: the input gradient
@@ -320,6 +388,32 @@ extern "C" int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, co
   a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
   a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.T = T; a.C = C;
   NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// dW [N][K] = dy^T x over T tokens; N, K multiples of 4, <= 64; dy [T][N], x [T][K] fp32.  workspace:
+// nnz_pw_wgrad_small_workspace_floats(T, N, K) floats.  dW is WRITTEN; deterministic (fixed-order folds).
+extern "C" long nnz_pw_wgrad_small_workspace_floats(long T, int N, int K) {
+  if (T < 1 || N < 4 || K < 4) return 0;
+  const long ranges = (T + nnz::PW_TR - 1) / nnz::PW_TR;
+  return ranges * N * K + nnz::fold_partials_scratch_floats((int)ranges, (long)N * K);
+}
+extern "C" int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* workspace, float* dW, long T, int N, int K,
+                                      void* stream) {
+  using namespace nnz;
+  if (!dy || !x || !workspace || !dW || T < 1 || N < 4 || K < 4 || N > 64 || K > 64 || (N & 3) || (K & 3) || ((size_t)dy & 15) ||
+      ((size_t)x & 15))
+    return NNZ_EINVAL;
+  const long ranges = (T + PW_TR - 1) / PW_TR;
+  if (ranges > 0x7fffffffL) return NNZ_EINVAL;
+  const int tiles = (N >> 2) * (K >> 2);
+  int shares = 256 / tiles;
+  if (shares > 16) shares = 16;
+  NNZ_LAUNCH(pw_wgrad_small_kernel, dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, dy, x, workspace, T, N, K, shares);
+  float* scratch = fold_partials_scratch_floats((int)ranges, (long)N * K) ? workspace + ranges * N * K : nullptr;
+  hipError_t e = fold_partials(workspace, (int)ranges, (long)N * K, (long)N * K, dW, (hipStream_t)stream, scratch);
+  if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -104,3 +104,26 @@ def test_rsu4f_matches_the_torch_modules(hip_lib, cin, mid, cout, size):
         _close(b.double() if b.is_floating_point() else b.double(), c.double(), 1e-5, n)
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     assert all(torch.equal(p.grad, q.grad) for p, q in zip(runs[0][0].parameters(), runs[1][0].parameters()))
+
+
+@pytest.mark.parametrize("T,K,N", [(2 * 128 * 128, 32, 32), (40000, 64, 64), (17000, 36, 8), (2 * 512 * 512, 32, 32)])
+def test_pointwise_1x1_forward_backward(hip_lib, T, K, N):
+    """the 1x1 convolution as a token Linear; at these sizes its weight gradient takes the small-channel streaming kernel"""
+    from nnuzoo_amd import sepconv32
+    g = torch.Generator().manual_seed(T % 1000 + K)
+    x = torch.randn(1, 1, T, K, generator=g)
+    w = torch.randn(N, K, 1, 1, generator=g) * 0.2
+    dy = torch.randn(1, 1, T, N, generator=g)
+    assert T >= sepconv32.SMALL_WGRAD_MIN_TOKENS
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = xr @ wr.view(N, K).t()
+    rx, rw = torch.autograd.grad(ref, [xr, wr], dy.double())
+    runs = []
+    for _ in range(2):
+        xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        y = sepconv32._Pointwise1x1Fn.apply(xd, wd, None)
+        runs.append((y.detach(),) + torch.autograd.grad(y, [xd, wd], dy.to(DEV)))
+    _close(runs[0][0], ref.detach(), 2e-5, "y")
+    _close(runs[0][1], rx, 2e-5, "dx")
+    _close(runs[0][2], rw, 1e-4, "dw")
+    assert all(torch.equal(p, q) for p, q in zip(runs[0], runs[1]))
