@@ -158,23 +158,48 @@ __device__ __forceinline__ f32x4 bn_fold(float (*red)[16], int q, f32x4 v) {
   return o;
 }
 
+// RT = tokens a thread keeps in REGISTERS (T <= 64 RT): the thread's rows are loaded once - all loads in flight together, one
+// memory round trip - and the mean, the squared deviations and the output come from registers.  RT = 0: the three passes re-read
+// the rows (any T).  (The re-reading form was three to five DEPENDENT round trips per launch: ~20 us for a 512 x 512 map
+// where MIOpen's kernel took 5.)
+template <int RT>
 __global__ __launch_bounds__(256) void bn_relu_nhwc_fwd_kernel(BnArgs32 a) {
   __shared__ float red[4][16];
   const int q = threadIdx.x & 3, tg = threadIdx.x >> 2;
   const int c = blockIdx.x * 16 + q * 4;
   const bool live = c < a.C;
-  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = mean;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 rows[RT > 0 ? RT : 1];
+  if (RT > 0) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const long t = tg + 64L * i;
+      rows[i] = (live && t < a.T) ? *reinterpret_cast<const f32x4*>(a.x + t * a.C + c) : z;
+    }
+  }
+  f32x4 mean = z, rstd = z;
   if (a.training) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (live)
+    f32x4 s = z;
+    if (RT > 0) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i) s += rows[i];
+    } else if (live) {
       for (long t = tg; t < a.T; t += 64) s += *reinterpret_cast<const f32x4*>(a.x + t * a.C + c);
+    }
     mean = bn_fold(red, q, s) * (1.f / (float)a.T);
-    f32x4 d2 = {0.f, 0.f, 0.f, 0.f};
-    if (live)
+    f32x4 d2 = z;
+    if (RT > 0) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const f32x4 d = rows[i] - mean;
+        if (tg + 64L * i < a.T) d2 += d * d;
+      }
+    } else if (live) {
       for (long t = tg; t < a.T; t += 64) {
         const f32x4 d = *reinterpret_cast<const f32x4*>(a.x + t * a.C + c) - mean;
         d2 += d * d;
       }
+    }
     const f32x4 var = bn_fold(red, q, d2) * (1.f / (float)a.T);
 #pragma unroll
     for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(var[e] + a.eps);
@@ -199,15 +224,28 @@ __global__ __launch_bounds__(256) void bn_relu_nhwc_fwd_kernel(BnArgs32 a) {
   }
   const f32x4 sc = rstd * *reinterpret_cast<const f32x4*>(a.gamma + c);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(a.beta + c) - mean * sc;
-  for (long t = tg; t < a.T; t += 64) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.x + t * a.C + c) * sc + sh;
+  if (RT > 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-    *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = v;
+    for (int i = 0; i < RT; ++i) {
+      const long t = tg + 64L * i;
+      f32x4 v = rows[i] * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      if (t < a.T) *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = v;
+    }
+  } else {
+    for (long t = tg; t < a.T; t += 64) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.x + t * a.C + c) * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = v;
+    }
   }
 }
 
 // dx = gamma rstd (g - mean(g) - xhat mean(g xhat)),  g = dy [pre > 0],  pre = xhat gamma + beta;  dgamma = sum g xhat,  dbeta = sum g
+// RT as above: xhat and g of the thread's rows stay in registers between the reduction and the output pass
+template <int RT>
 __global__ __launch_bounds__(256) void bn_relu_nhwc_bwd_kernel(BnArgs32 a) {
   __shared__ float red[4][16];
   const int q = threadIdx.x & 3, tg = threadIdx.x >> 2;
@@ -216,17 +254,37 @@ __global__ __launch_bounds__(256) void bn_relu_nhwc_bwd_kernel(BnArgs32 a) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   const f32x4 mean = live ? *reinterpret_cast<const f32x4*>(a.mean + c) : z, rstd = live ? *reinterpret_cast<const f32x4*>(a.rstd + c) : z;
   const f32x4 ga = live ? *reinterpret_cast<const f32x4*>(a.gamma + c) : z, be = live ? *reinterpret_cast<const f32x4*>(a.beta + c) : z;
+  auto masked = [&](f32x4 xh, f32x4 gg) {
+    const f32x4 pre = xh * ga + be;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gg[e] = pre[e] > 0.f ? gg[e] : 0.f;
+    return gg;
+  };
+  f32x4 xh_r[RT > 0 ? RT : 1], g_r[RT > 0 ? RT : 1];
   f32x4 s1 = z, s2 = z;
-  if (live)
+  if (RT > 0) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const long t = tg + 64L * i;
+      const bool ok = live && t < a.T;
+      xh_r[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + t * a.C + c) : mean;
+      g_r[i] = ok ? *reinterpret_cast<const f32x4*>(a.dy + t * a.C + c) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      xh_r[i] = (xh_r[i] - mean) * rstd;
+      g_r[i] = masked(xh_r[i], g_r[i]);
+      s1 += g_r[i];
+      s2 += g_r[i] * xh_r[i];
+    }
+  } else if (live) {
     for (long t = tg; t < a.T; t += 64) {
       const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.x + t * a.C + c) - mean) * rstd;
-      f32x4 gg = *reinterpret_cast<const f32x4*>(a.dy + t * a.C + c);
-      const f32x4 pre = xh * ga + be;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) gg[e] = pre[e] > 0.f ? gg[e] : 0.f;
+      const f32x4 gg = masked(xh, *reinterpret_cast<const f32x4*>(a.dy + t * a.C + c));
       s1 += gg;
       s2 += gg * xh;
     }
+  }
   const f32x4 sum_g = bn_fold(red, q, s1);
   const f32x4 sum_gx = bn_fold(red, q, s2);
   if (!live) return;
@@ -236,13 +294,18 @@ __global__ __launch_bounds__(256) void bn_relu_nhwc_bwd_kernel(BnArgs32 a) {
   }
   const float inv_t = 1.f / (float)a.T;
   const f32x4 m1 = sum_g * inv_t, m2 = sum_gx * inv_t, k = ga * rstd;
-  for (long t = tg; t < a.T; t += 64) {
-    const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.x + t * a.C + c) - mean) * rstd;
-    f32x4 gg = *reinterpret_cast<const f32x4*>(a.dy + t * a.C + c);
-    const f32x4 pre = xh * ga + be;
+  if (RT > 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) gg[e] = pre[e] > 0.f ? gg[e] : 0.f;
-    *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = k * (gg - m1 - xh * m2);
+    for (int i = 0; i < RT; ++i) {
+      const long t = tg + 64L * i;
+      if (t < a.T) *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = k * (g_r[i] - m1 - xh_r[i] * m2);
+    }
+  } else {
+    for (long t = tg; t < a.T; t += 64) {
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.x + t * a.C + c) - mean) * rstd;
+      const f32x4 gg = masked(xh, *reinterpret_cast<const f32x4*>(a.dy + t * a.C + c));
+      *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = k * (gg - m1 - xh * m2);
+    }
   }
 }
 
@@ -373,7 +436,10 @@ extern "C" int nnz_bn_relu_nhwc_forward_f32(const float* x, const float* gamma, 
   BnArgs32 a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var; a.mean = mean; a.rstd = rstd;
   a.y = y; a.T = T; a.C = C; a.training = training; a.momentum = momentum; a.eps = eps;
-  NNZ_LAUNCH(bn_relu_nhwc_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((C + 15) / 16);
+  if (T <= 64 * 8) NNZ_LAUNCH(bn_relu_nhwc_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (T <= 64 * 32) NNZ_LAUNCH(bn_relu_nhwc_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else NNZ_LAUNCH(bn_relu_nhwc_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
@@ -387,7 +453,10 @@ extern "C" int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, co
   BnArgs32 a = {};
   a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
   a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.T = T; a.C = C;
-  NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((C + 15) / 16);
+  if (T <= 64 * 8) NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (T <= 64 * 24) NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else NNZ_LAUNCH(bn_relu_nhwc_bwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
