@@ -27,38 +27,51 @@ struct DwArgs32 {
 };
 
 // FLIP = false: y[t][c] = b[c] + sum_k w[c][k] x[t + off_k][c] (zero padding 1).  FLIP = true: the input gradient - the same
-// sum with the kernel rotated by 180 degrees (and no bias).  Thread = (token, channel quad).
+// sum with the kernel rotated by 180 degrees (and no bias).  Thread = one channel quad (fixed: its 36 weights sit in registers) x
+// DW_TOK tokens, DW_TOK consecutive workgroup rows apart.  (First version: one token per thread with the weights fetched per
+// token - 45 vector-memory instructions per output quad, 1.3 TB/s on the 512^2 x 32 stem.)
+constexpr int DW_TOK = 4;
 template <bool FLIP>
-__global__ __launch_bounds__(256) void dw3x3_nhwc_kernel(DwArgs32 a) {
+__global__ __launch_bounds__(256) void dw3x3_nhwc_kernel(DwArgs32 a, int cq, int tl) {
+  // cq = channel quads per workgroup (<= 256), tl = 256 / cq token lanes
   const int C4 = a.C >> 2;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)a.B * a.H * a.W * C4;
-  if (i >= total) return;
-  const int q = (int)(i % C4);
-  const long t = i / C4;
-  const int xw = (int)(t % a.W);
-  const int yh = (int)((t / a.W) % a.H);
+  const int ql = threadIdx.x % cq, tk = threadIdx.x / cq;
+  const int q = blockIdx.y * cq + ql;
+  if (q >= C4 || tk >= tl) return;
   const int c = q * 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (!FLIP && a.bias) acc = *reinterpret_cast<const f32x4*>(a.bias + c);
-  const float* wp = a.w + (long)c * 9;
+  const long T = (long)a.B * a.H * a.W;
+  float w[4][9];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int yy = yh + ky - 1;
-    if ((unsigned)yy >= (unsigned)a.H) continue;
+  for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int xx = xw + kx - 1;
-      if ((unsigned)xx >= (unsigned)a.W) continue;
-      const int k = FLIP ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + (t + (long)(ky - 1) * a.W + (kx - 1)) * a.C + c);
-      acc[0] += wp[k] * v[0];
-      acc[1] += wp[9 + k] * v[1];
-      acc[2] += wp[18 + k] * v[2];
-      acc[3] += wp[27 + k] * v[3];
+    for (int k = 0; k < 9; ++k) w[e][k] = a.w[(long)(c + e) * 9 + (FLIP ? 8 - k : k)];
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+  if (!FLIP && a.bias) b0 = *reinterpret_cast<const f32x4*>(a.bias + c);
+#pragma unroll
+  for (int j = 0; j < DW_TOK; ++j) {
+    const long t = ((long)blockIdx.x * DW_TOK + j) * tl + tk;
+    if (t >= T) break;
+    const int xw = (int)(t % a.W);
+    const int yh = (int)((t / a.W) % a.H);
+    f32x4 acc = b0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = yh + ky - 1;
+      if ((unsigned)yy >= (unsigned)a.H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = xw + kx - 1;
+        if ((unsigned)xx >= (unsigned)a.W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + (t + (long)(ky - 1) * a.W + (kx - 1)) * a.C + c);
+        const int k = ky * 3 + kx;
+        acc[0] += w[0][k] * v[0];
+        acc[1] += w[1][k] * v[1];
+        acc[2] += w[2][k] * v[2];
+        acc[3] += w[3][k] * v[3];
+      }
     }
+    *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = acc;
   }
-  *reinterpret_cast<f32x4*>(a.y + t * a.C + c) = acc;
 }
 
 // Lane geometry of the reducing kernels below: a workgroup owns 16 consecutive channels - lane quad q = tid & 3 holds channels
@@ -386,18 +399,19 @@ extern "C" int nnz_dw3x3_nhwc_f32(const float* x, const float* w, const float* b
   using namespace nnz;
   if (!x || !w || !y || B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || ((size_t)x & 15) || ((size_t)y & 15)) return NNZ_EINVAL;
   DwArgs32 a = {x, w, flip ? nullptr : bias, y, B, H, W, C};
-  const long total = (long)B * H * W * (C >> 2);
-  const long blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffL) return NNZ_EINVAL;
-  if (flip) NNZ_LAUNCH(dw3x3_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else NNZ_LAUNCH(dw3x3_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  const int C4 = C >> 2;
+  const int cq = C4 < 256 ? C4 : 256;
+  const int tl = 256 / cq;
+  const long T = (long)B * H * W;
+  const long bx = (T + (long)tl * DW_TOK - 1) / ((long)tl * DW_TOK);
+  const int by = (C4 + cq - 1) / cq;
+  if (bx > 0x7fffffffL || by > 65535) return NNZ_EINVAL;
+  if (flip) NNZ_LAUNCH(dw3x3_nhwc_kernel<true>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, a, cq, tl);
+  else NNZ_LAUNCH(dw3x3_nhwc_kernel<false>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, a, cq, tl);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
 
-// token ranges of the weight gradient: 256 tokens each (64 per token group) so that the full-resolution stems (524 288 tokens of 32
-// channels) spread over ~2 000 workgroups - with 64 ranges (first version) they were 64 workgroups walking 2 048 tokens per thread
-// and the SwT2Net step went from 56 to 76 ms.  More than 256 ranges fold in two levels (scratch behind the partials).
 static int dw3x3_ranges(long T) {
   long r = (T + 255) / 256;
   return (int)(r < 1 ? 1 : (r > 8192 ? 8192 : r));
