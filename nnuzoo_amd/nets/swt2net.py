@@ -362,6 +362,9 @@ class SwinTransformerUnet(nn.Module):
                 _backends.note(self.rebnconvin, "hip-f32")
                 res = sepconv32.stem_forward(self.rebnconvin, x)
             else:
+                if x.is_cuda:
+                    _backends.note(self.rebnconvin, "library", why="stem with a channel count that is not a multiple of 4 (the "
+                                                                   "1-channel network input) / autocast / non-fp32")
                 res = self.rebnconvin(x)
         x = self.pos_drop(self.patch_embed(x))
         saved = []
