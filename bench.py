@@ -575,19 +575,14 @@ def main():
     trainer.use_hip_graph = graph
     for _ in range(a.warmup):
         losses.append(float(trainer.train_step(batch)["loss"]))
-    # Per-launch HIP events (the roofline leg).  Eager steps (N > 1: the data-parallel step is eager, its all-reduce is
-    # overlapped with the backward schedule): events inside the timed region on every 4th step - an event pair around each
-    # of ~90 launches costs the step 5 % when taken on every step (147 vs 139 patches/s, same box).  Graph replay (N = 1): a
-    # replayed graph issues no per-launch events, so the same kernels are timed over eager steps right after the timed
-    # region, as the SS2D^2Net and SwT2Net legs do.
+    # Per-launch HIP events (the roofline leg) are NOT taken inside the timed region: a replayed graph (N = 1) issues none, and on
+    # eager steps (N > 1) an event pair around each of ~90 launches costs the step 5 % (147 vs 139 patches/s, same box).  The same
+    # kernels are timed over eager steps right after the region, as the SS2D^2Net and SwT2Net legs do.
     hip_ops.TIMER.records = []
     timed_steps_with_events = 0
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        if not graph and not a.no_launch_timer:
-            hip_ops.TIMER.enabled = i % 4 == 0
-            timed_steps_with_events += int(i % 4 == 0)
         losses.append(float(trainer.train_step(batch)["loss"]))
     barrier()
     dt = time.perf_counter() - t0
@@ -612,9 +607,12 @@ def main():
                "batch_bytes": int(sum(t.numel() * t.element_size() for t in [host["data"]] + host["target"])),
                "note": "same step fed from pinned host memory every step (H2D inside the timed region, SURVEY.md 8d); max over "
                        "ranks not taken: rank 0's own clock"}
-    roof_note = f"HIP events around every launch on every 4th step of the timed region ({timed_steps_with_events} steps)"
+    roof_note = ""
     eager_ms = None
-    if graph and not a.no_launch_timer:
+    if not a.no_launch_timer:
+        # the per-launch events are taken over eager steps AFTER the timed region at every N (round 6; at N > 1 they used to ride on
+        # every 4th step inside it: ~1.2 % of the rate the driver computes its scaling efficiency from).  All ranks run these
+        # steps - they contain the same collectives as any other step.
         trainer.use_hip_graph = False
         trainer.train_step(batch)
         timed_steps_with_events = min(8, a.steps)
@@ -626,10 +624,10 @@ def main():
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - te) / timed_steps_with_events * 1e3   # incl. the event pairs around every launch
         hip_ops.TIMER.enabled = False
-        trainer.use_hip_graph = True
+        trainer.use_hip_graph = graph
         roof_note = (f"HIP events around every launch over {timed_steps_with_events} EAGER steps right after the timed region "
-                     f"(the timed region replays the step as one hipGraph: no per-launch events exist there; same kernels, "
-                     f"same data)")
+                     + ("(the timed region replays the step as one hipGraph: no per-launch events exist there; same kernels, "
+                        "same data)" if graph else "(the timed region itself carries no events)"))
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
     reducer = getattr(trainer.network, "grad_reducer", None)
     buckets_per_step = getattr(reducer, "buckets_last_step", None)

@@ -256,6 +256,18 @@ int nnz_aug_blur_axis_f32(const float* src, float* dst, int nbc, int D, int H, i
  * rec = device [nbc][4] {active, scale, -, -}; keep_z: 2-D / dummy-2-D batches */
 int nnz_aug_lowres_f32(const float* src, float* dst, int nbc, int D, int H, int W, int keep_z, const float* rec, void* stream);
 int nnz_aug_relabel_i16(short* x, long n, int from, int to, void* stream);
+/* Label-side transforms whose arithmetic the reference defines itself (training/data_augmentation/custom_transforms/):
+ *   ConvertSegmentationToRegionsTransform (region_based_training.py:7-39; chain: nnUNetTrainer.py:961-969): out [B][R][n] int16 =
+ *     1 where seg[b][seg_channel] is one of region r's labels (labels[begin[r] .. begin[r + 1]), host arrays, <= 64 labels in all);
+ *   MoveSegAsOneHotToData (cascade_transforms.py:10-39; chain :932-939): channels c0 .. c0 + K - 1 of data [B][Cd][n] float are
+ *     written with (seg[b][seg_channel] == labels[k]); the caller has allocated the widened tensor and copied the image channels;
+ *   MaskTransform (masking.py:6-24; chain :921-927): data[b][c][seg[b][mask_channel] < 0] = value for the channels in the bit set. */
+int nnz_aug_seg_to_regions_i16(const short* seg, short* out, int B, int Cs, int seg_channel, long n, const int* begin,
+                               const int* labels, int R, void* stream);
+int nnz_aug_seg_onehot_to_data_f32(const short* seg, float* data, int B, int Cs, int seg_channel, int Cd, int c0, long n,
+                                   const int* labels, int K, void* stream);
+int nnz_aug_mask_outside_f32(float* data, const short* seg, int B, int Cd, int Cs, int mask_channel, long n,
+                             long channels, float value, void* stream);
 
 /* ---- x_proj of the cross-scan SS2D block on channel-major fp32 activations (the einsum of SS2D.forward_core,
  * /root/reference/nnunetv2/nets/m2net.py:179-184, in the two-source formulation of nnz_ss2d_scan_*):

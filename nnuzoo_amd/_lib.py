@@ -123,6 +123,9 @@ SIGNATURES = {
     "nnz_aug_stats_f32": [_fp, _l, _i, _fp, _fp, _vp],
     "nnz_aug_intensity_f32": [_fp, _l, _i, _i, _fp, _fp, _fp, _i, _vp],
     "nnz_aug_relabel_i16": [_vp, _l, _i, _i, _vp],
+    "nnz_aug_seg_to_regions_i16": [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _i, _vp],
+    "nnz_aug_seg_onehot_to_data_f32": [_vp, _vp, _i, _i, _i, _i, _i, _l, _vp, _i, _vp],
+    "nnz_aug_mask_outside_f32": [_vp, _vp, _i, _i, _i, _i, _l, _l, _f, _vp],
     "nnz_aug_blur_axis_f32": [_fp, _fp, _i, _i, _i, _i, _i, _fp, _vp],
     "nnz_aug_lowres_f32": [_fp, _fp, _i, _i, _i, _i, _i, _fp, _vp],
     "nnz_ss2d_xproj_forward": [_fp, _fp, _fp, _i, _i, _i, _l, _i, _vp],

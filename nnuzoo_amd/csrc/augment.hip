@@ -309,6 +309,55 @@ static int affine_launch(const void* src, void* dst, const float* mats, int B, i
   return NNZ_OK;
 }
 
+// ---- label-side transforms of the training chain whose arithmetic the REFERENCE defines itself (round 6) -------------------
+// /root/reference/nnunetv2/training/data_augmentation/custom_transforms/: region_based_training.py:7-39
+// (ConvertSegmentationToRegionsTransform), cascade_transforms.py:10-39 (MoveSegAsOneHotToData), masking.py:6-24 (MaskTransform);
+// the trainer chain calls their batchgeneratorsv2 namesakes at nnUNetTrainer.py:921-927, 932-939, 961-969.  Element-wise on the
+// resident batch; label lists travel as kernel arguments (<= AUG_MAXL entries).
+constexpr int AUG_MAXL = 64;
+struct LabelTable {
+  int n;                   // regions / labels
+  int begin[AUG_MAXL + 1]; // regions: labels [begin[r], begin[r + 1]) belong to region r
+  int label[AUG_MAXL];
+};
+// out[b][r][i] = 1 where seg[b][seg_channel][i] is one of region r's labels, else 0   (seg [B][Cs][n], out [B][R][n], int16)
+__global__ __launch_bounds__(256) void aug_regions_kernel(const short* __restrict__ seg, short* __restrict__ out, long n, int Cs,
+                                                          int seg_channel, LabelTable t) {
+  const int b = blockIdx.y;
+  const short* sp = seg + ((long)b * Cs + seg_channel) * n;
+  short* op = out + (long)b * t.n * n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int v = sp[i];
+    for (int r = 0; r < t.n; ++r) {
+      short hit = 0;
+      for (int k = t.begin[r]; k < t.begin[r + 1]; ++k) hit |= (short)(t.label[k] == v);
+      op[(long)r * n + i] = hit;
+    }
+  }
+}
+// data[b][c0 + k][i] = (seg[b][seg_channel][i] == label[k]) as float, k < K   (data [B][Cd][n] float, seg [B][Cs][n] int16)
+__global__ __launch_bounds__(256) void aug_onehot_kernel(const short* __restrict__ seg, float* __restrict__ data, long n, int Cs,
+                                                         int seg_channel, int Cd, int c0, LabelTable t) {
+  const int b = blockIdx.y;
+  const short* sp = seg + ((long)b * Cs + seg_channel) * n;
+  float* dp = data + ((long)b * Cd + c0) * n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int v = sp[i];
+    for (int k = 0; k < t.n; ++k) dp[(long)k * n + i] = t.label[k] == v ? 1.f : 0.f;
+  }
+}
+// data[b][c][i] = value where seg[b][mask_channel][i] < 0, for the channels whose bit is set in `channels`
+__global__ __launch_bounds__(256) void aug_mask_kernel(float* __restrict__ data, const short* __restrict__ seg, long n, int Cd, int Cs,
+                                                       int mask_channel, unsigned long long channels, float value) {
+  const int b = blockIdx.y;
+  const short* sp = seg + ((long)b * Cs + mask_channel) * n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (sp[i] < 0)
+      for (int c = 0; c < Cd; ++c)
+        if ((channels >> c) & 1ull) data[((long)b * Cd + c) * n + i] = value;
+  }
+}
+
 }  // namespace nnz
 
 // dst[b][c][o] = interpolation of src[b][c] at M_b (o - centre) + centre + shift_b (index space, centre = (size - 1) / 2 per axis);
@@ -380,6 +429,54 @@ extern "C" int nnz_aug_relabel_i16(short* x, long n, int from, int to, void* str
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   NNZ_LAUNCH(aug_relabel_i16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, from, to);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// ConvertSegmentationToRegionsTransform: out [B][R][n] int16 (written); region r = labels[begin[r] .. begin[r + 1]); host arrays
+extern "C" int nnz_aug_seg_to_regions_i16(const short* seg, short* out, int B, int Cs, int seg_channel, long n, const int* begin,
+                                          const int* labels, int R, void* stream) {
+  using namespace nnz;
+  if (!seg || !out || !begin || !labels || B < 1 || Cs < 1 || seg_channel < 0 || seg_channel >= Cs || n < 1 || R < 1 || R > AUG_MAXL ||
+      begin[R] > AUG_MAXL || begin[0] != 0)
+    return NNZ_EINVAL;
+  LabelTable t = {};
+  t.n = R;
+  for (int r = 0; r <= R; ++r) t.begin[r] = begin[r];
+  for (int k = 0; k < begin[R]; ++k) t.label[k] = labels[k];
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  NNZ_LAUNCH(aug_regions_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, seg, out, n, Cs, seg_channel, t);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+// MoveSegAsOneHotToData: channels c0 .. c0 + K - 1 of data [B][Cd][n] are written with the one-hot encoding of
+// seg[:, seg_channel] over `labels` (K host ints); the caller allocates the widened data tensor and copies the image channels
+extern "C" int nnz_aug_seg_onehot_to_data_f32(const short* seg, float* data, int B, int Cs, int seg_channel, int Cd, int c0, long n,
+                                              const int* labels, int K, void* stream) {
+  using namespace nnz;
+  if (!seg || !data || !labels || B < 1 || Cs < 1 || seg_channel < 0 || seg_channel >= Cs || K < 1 || K > AUG_MAXL || c0 < 0 ||
+      c0 + K > Cd || n < 1)
+    return NNZ_EINVAL;
+  LabelTable t = {};
+  t.n = K;
+  for (int k = 0; k < K; ++k) t.label[k] = labels[k];
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  NNZ_LAUNCH(aug_onehot_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, seg, data, n, Cs, seg_channel, Cd,
+             c0, t);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+// MaskTransform: data[:, c][seg[:, mask_channel] < 0] = value for the channels in the bit set `channels` (bit c = channel c, Cd <= 63); in place
+extern "C" int nnz_aug_mask_outside_f32(float* data, const short* seg, int B, int Cd, int Cs, int mask_channel, long n,
+                                        long channels, float value, void* stream) {
+  using namespace nnz;
+  if (!data || !seg || B < 1 || Cd < 1 || Cd > 63 || Cs < 1 || mask_channel < 0 || mask_channel >= Cs || n < 1) return NNZ_EINVAL;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  NNZ_LAUNCH(aug_mask_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, data, seg, n, Cd, Cs, mask_channel,
+             (unsigned long long)channels, value);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }

@@ -60,7 +60,19 @@ class DeviceAugmenter:
     p_gamma_inverted, p_gamma, gamma = 0.1, 0.3, (0.7, 1.5)
 
     def __init__(self, patch_size: Sequence[int], rotation_for_DA: Tuple[float, float], do_dummy_2d_data_aug: bool = False,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, use_mask_for_norm: Optional[Sequence[bool]] = None,
+                 cascade_labels: Optional[Sequence[int]] = None, regions: Optional[Sequence] = None,
+                 ignore_label: Optional[int] = None):
+        """use_mask_for_norm / cascade_labels (`foreground_labels` of a cascaded configuration) / regions / ignore_label: the arguments
+        of nnUNetTrainer.get_training_transforms (:825-835) that switch on MaskTransform (:921-927), MoveSegAsOneHotToData (:932-939)
+        and ConvertSegmentationToRegionsTransform (:961-969).  The two random morphology transforms of the cascade (:940-959:
+        skimage / connected components on the CPU) are not built; the one-hot move itself is."""
+        self.use_mask_for_norm = list(use_mask_for_norm) if use_mask_for_norm is not None and any(use_mask_for_norm) else None
+        self.cascade_labels = [int(v) for v in cascade_labels] if cascade_labels else None
+        self.regions = None
+        if regions is not None:
+            regs = list(regions) + ([ignore_label] if ignore_label is not None else [])
+            self.regions = [tuple(int(v) for v in (r if isinstance(r, (list, tuple)) else (r,))) for r in regs]
         self.patch_size = tuple(int(i) for i in patch_size)
         self.rotation = (float(rotation_for_DA[0]), float(rotation_for_DA[1]))
         self.dummy_2d = bool(do_dummy_2d_data_aug)
@@ -242,8 +254,70 @@ class DeviceAugmenter:
             self._op(data, nbc, n, OP_RESTORE, rec, sa=self._stats(data, nbc, n), sb=before)
             if invert:
                 self._op(data, nbc, n, OP_LINEAR, neg)
+        # -- MaskTransform (:921-927): normalisation masks - everything outside the mask (seg < 0) back to 0 in the masked channels
+        if self.use_mask_for_norm is not None and seg is not None:
+            data = mask_outside(data, seg, [i for i, m in enumerate(self.use_mask_for_norm) if m], 0, 0.0)
         # -- RemoveLabelTansform(-1, 0)
         if seg is not None:
             call("nnz_aug_relabel_i16", ptr(seg), seg.numel(), -1, 0, stream_ptr())
+        # -- cascade: the previous stage's segmentation (seg channel 1) as one-hot image channels (:932-939)
+        if self.cascade_labels is not None and seg is not None:
+            data, seg = move_seg_as_onehot_to_data(data, seg, 1, self.cascade_labels, remove_from_origin=True)
+        # -- region-based training (:961-969): label map -> one binary map per region (the ignore label as the last region)
+        if self.regions is not None and seg is not None:
+            seg = seg_to_regions(seg, self.regions, 0)
         self.last = last
         return data, seg
+
+
+# ---- label-side transforms the reference defines itself (custom_transforms/*.py), as launches on the resident batch -------------
+def _flat(t: torch.Tensor):
+    return t.shape[0], t.shape[1], int(np.prod(t.shape[2:]))
+
+
+def seg_to_regions(seg: torch.Tensor, regions, seg_channel: int = 0) -> torch.Tensor:
+    """ConvertSegmentationToRegionsTransform (region_based_training.py:7-39): (B, Cs, *sp) int16 -> (B, R, *sp) int16 of 0 / 1"""
+    import ctypes as C
+    if not seg.is_cuda or seg.dtype != torch.int16 or not seg.is_contiguous():
+        raise RuntimeError("seg_to_regions: contiguous int16 CUDA segmentation expected (there is no CPU path)")
+    B, Cs, n = _flat(seg)
+    regs = [tuple(r) if isinstance(r, (list, tuple)) else (r,) for r in regions]
+    begin = np.zeros(len(regs) + 1, dtype=np.int32)
+    begin[1:] = np.cumsum([len(r) for r in regs])
+    labels = np.array([v for r in regs for v in r], dtype=np.int32)
+    out = torch.empty((B, len(regs)) + tuple(seg.shape[2:]), dtype=torch.int16, device=seg.device)
+    call("nnz_aug_seg_to_regions_i16", ptr(seg), ptr(out), B, Cs, int(seg_channel), n, begin.ctypes.data, labels.ctypes.data, len(regs),
+         stream_ptr())
+    return out
+
+
+def move_seg_as_onehot_to_data(data: torch.Tensor, seg: torch.Tensor, index_in_origin: int, all_labels,
+                               remove_from_origin: bool = True):
+    """MoveSegAsOneHotToData (cascade_transforms.py:10-39): one-hot of seg[:, index_in_origin] over `all_labels` appended to data"""
+    if not (data.is_cuda and seg.is_cuda and data.dtype == torch.float32 and seg.dtype == torch.int16 and data.is_contiguous()
+            and seg.is_contiguous()):
+        raise RuntimeError("move_seg_as_onehot_to_data: contiguous float32 data / int16 seg on the device expected")
+    B, Cd, n = _flat(data)
+    _, Cs, _ = _flat(seg)
+    labels = np.array([int(v) for v in all_labels], dtype=np.int32)
+    wide = torch.empty((B, Cd + len(labels)) + tuple(data.shape[2:]), dtype=torch.float32, device=data.device)
+    wide[:, :Cd].copy_(data)
+    call("nnz_aug_seg_onehot_to_data_f32", ptr(seg), ptr(wide), B, Cs, int(index_in_origin), Cd + len(labels), Cd, n,
+         labels.ctypes.data, len(labels), stream_ptr())
+    if remove_from_origin:
+        seg = seg[:, [i for i in range(Cs) if i != index_in_origin]].contiguous()
+    return wide, seg
+
+
+def mask_outside(data: torch.Tensor, seg: torch.Tensor, apply_to_channels, mask_idx_in_seg: int = 0, set_outside_to: float = 0.0):
+    """MaskTransform (masking.py:6-24): data[:, c][seg[:, mask_idx_in_seg] < 0] = set_outside_to, in place"""
+    if not (data.is_cuda and seg.is_cuda and data.dtype == torch.float32 and seg.dtype == torch.int16 and data.is_contiguous()
+            and seg.is_contiguous()):
+        raise RuntimeError("mask_outside: contiguous float32 data / int16 seg on the device expected")
+    B, Cd, n = _flat(data)
+    bits = 0
+    for c in apply_to_channels:
+        bits |= 1 << int(c)
+    call("nnz_aug_mask_outside_f32", ptr(data), ptr(seg), B, Cd, seg.shape[1], int(mask_idx_in_seg), n, bits, float(set_outside_to),
+         stream_ptr())
+    return data
