@@ -3,7 +3,7 @@
 #   bash tools/collect_profiles.sh r05 [primary]      (primary: only steps 1 and 2 - kernel statistics and PMC passes of the primary leg)
 # Writes under gpurun_out/ (copy what is to be judged into profiles/).  ~40 GPU-minutes.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
