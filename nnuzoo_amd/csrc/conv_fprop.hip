@@ -109,6 +109,12 @@ struct ConvDev {
   // at 32 channels is 8.4 MB).  Launcher: only when all three tile counts are multiples of 4.
   int brick;
   unsigned mg_b2, mg_b1;   // reciprocals of tiles[2] / 4 and tiles[1] / 4
+  // knob 15 (round 6): the tap GROUPS of a multi-group launch (the eight output-parity classes of a stride-2 data gradient, the
+  // eight positions of a transposed convolution) as the FASTEST index of the workgroup order instead of the slowest: the groups of
+  // one m-tile read the same input box (with different taps) and interleave their output voxels on the same cache lines, and were
+  // 1/8 of the launch apart - the 32 -> 64 stride-2 data gradient at 128^3 fetched 2.0 GB for a 67 MB input + 268 MB of layer-below
+  // rows (profiles/r06_pmc_fetch_size.csv) and ran at the fabric's bandwidth.
+  int group_fastest;
   // Consumer-side InstanceNorm + LeakyReLU (nnz_conv_tap_forward_innorm): `in` is the RAW conv output of the producer block(s)
   // and is normalised while the box is staged, y = lrelu(x * scale + shift) with {scale, shift} = in_tab[n][c - in_c0][2..3]
   // (the producer's table, written by its own launch's last workgroup); channels [0, in_c0) - the transposed-conv half of a
@@ -204,6 +210,7 @@ struct ConvCfg {
 //      tests/test_determinism_gpu.py test_conv_epilogue_table_{large,small}_mean hold both forms.)
 //  12, 13  -DNNZ_CONV_TIMESTAMPS builds only: low / high half of the timestamp buffer's address
 //  14  m-tiles in 4 x 4 x 4 brick order where all three tile counts are multiples of 4 (ConvDev::brick)               (default 1)
+//  15  tap groups of a multi-group launch as the fastest workgroup index (ConvDev::group_fastest)                         (default 1)
 #ifndef NNZ_SETPRIO
 #define NNZ_SETPRIO 0   // experiment: wave priority raised over the depth-reuse MFMA loop
 #endif
@@ -213,7 +220,7 @@ struct ConvCfg {
 #ifndef NNZ_S2_PERSIST
 #define NNZ_S2_PERSIST false
 #endif
-static int g_tuning[16] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 1, 1, 0, 0, 1, 0};
+static int g_tuning[16] = {1, 1, 16, 1, 32, 0, 0, 1, 128, 4, 1, 1, 0, 0, 1, 1};
 
 // LPT_BOX: 16-byte box pieces per thread (register staging bound; the launcher checks it covers the geometry)
 // DRE ("depth reuse", k3 s1 tables only, 8x8x8 x 32-cout tile): a wave owns four consecutive depth planes of one h-half.
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   const int t1_ = p.tiles[1], t2_ = p.tiles[2];
   const unsigned mgy = p.mg_gy, mgx = p.mg_gxw, mgs = p.mg_nsplit, mgg = p.mg_ngroups, mgt2 = p.mg_t2, mgt1 = p.mg_t1;
   const unsigned mgb2 = p.mg_b2, mgb1 = p.mg_b1;
-  const int brick_ = p.brick;
+  const int brick_ = p.brick, gfast_ = p.group_fastest;
   const int lo0_ = p.d.lo[0], lo1_ = p.d.lo[1], lo2_ = p.d.lo[2], ldi_ = p.d.ldi;
   const int Cin = p.d.Cin, Cout = p.d.Cout, T = p.d.ntaps_total;
   const int Di = p.d.in_dims[0], Hi = p.d.in_dims[1], Wi = p.d.in_dims[2];
@@ -266,13 +273,19 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
   asm volatile("" ::"s"(in_), "s"(w_), "s"(in_bytes_), "s"(w_bytes_));
   asm volatile("" ::"s"(gx_), "s"(gy_), "s"(gz_), "s"(nsplit_), "s"(ngroups_), "s"(cf_), "s"(t1_), "s"(t2_), "s"(mgy), "s"(mgx),
                "s"(mgs), "s"(mgg), "s"(mgt2), "s"(mgt1), "s"(lo0_), "s"(lo1_), "s"(lo2_), "s"(ldi_), "s"(Cin), "s"(Cout), "s"(T),
-               "s"(Di), "s"(Hi), "s"(Wi), "s"(TPW), "s"(mgb2), "s"(mgb1), "s"(brick_));
+               "s"(Di), "s"(Hi), "s"(Wi), "s"(TPW), "s"(mgb2), "s"(mgb1), "s"(brick_), "s"(gfast_));
   auto udiv = [](unsigned n, int d, unsigned m) -> unsigned { return d == 1 ? n : __umulhi(n, m); };
   const int gxw = PERSIST ? gx_ / TPW : gx_;          // workgroups along the m-tile index
   const unsigned mgxw = mgx;                          // (the launcher's reciprocal is that of gx / tiles_per_wg)
   const unsigned nwg = (unsigned)gxw * gy_ * gz_;
   unsigned lin = xcd_remap(blockIdx.x, nwg);
   int bx, by;
+  int g_fast = -1;
+  if (gfast_) {
+    const unsigned q = udiv(lin, ngroups_, mgg);
+    g_fast = lin - q * ngroups_;
+    lin = q;
+  }
   if (cf_) {
     // the cout blocks of one m-tile are neighbours in launch order (same XCD, same time): the second .. gy-th of them
     // find the tile's input box in L2 instead of HBM
@@ -298,8 +311,8 @@ __global__ __launch_bounds__(256, MINB) void conv_box_kernel(ConvDev p) {
     split = bz - q * nsplit_;
     bz = q;
   }
-  const int n = udiv(bz, ngroups_, mgg);
-  const int g = bz - n * ngroups_;
+  const int n = gfast_ ? bz : (int)udiv(bz, ngroups_, mgg);
+  const int g = gfast_ ? g_fast : bz - n * ngroups_;
   int tw_i, td_i, th_i;
   if (!PERSIST && brick_) {
     const unsigned b = (unsigned)bx >> 6, r = (unsigned)bx & 63u;
@@ -1376,6 +1389,7 @@ static int launch_cfg(const ConvDev& base, hipStream_t stream) {
     p.mg_t2 = magic(p.tiles[2]); p.mg_t1 = magic(p.tiles[1]);
     p.brick = g_tuning[14] && !PERSIST && p.tiles[0] % 4 == 0 && p.tiles[1] % 4 == 0 && p.tiles[2] % 4 == 0;
     p.mg_b2 = magic(p.tiles[2] / 4); p.mg_b1 = magic(p.tiles[1] / 4);
+    p.group_fastest = g_tuning[15] && p.d.ngroups > 1 && p.nsplit <= 1;
   }
   {
     const unsigned long long ib = 2ull * p.d.N * p.d.in_dims[0] * p.d.in_dims[1] * p.d.in_dims[2] * (unsigned long long)p.d.ldi;

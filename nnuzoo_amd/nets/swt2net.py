@@ -111,6 +111,13 @@ class PatchEmbedding(nn.Module):
         # at 512^2 in fp32: `profiles/r01_swt2net_step_kernels.txt`)
         B, C, H, W = x.shape
         x = x.view(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
+        from .. import backends as _backends
+        from .. import sepconv32
+        if sepconv32.patch_embed_ok(self.proj, x):
+            _backends.note(self.proj, "hip-f32")       # fp32 MFMA Linear kernels (csrc/dense32.hip), weight gradient in the grouped launch
+            return self.norm(sepconv32.pointwise_tokens(self.proj, x))
+        if x.is_cuda:
+            _backends.note(self.proj, "library", why="patch embedding outside the fp32 device step / K not a multiple of 4")
         return self.norm(F.linear(x, self.proj.weight.view(self.proj.out_channels, -1), self.proj.bias))
 
 

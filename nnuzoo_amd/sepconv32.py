@@ -60,7 +60,7 @@ class _Conv1x1Param:
 
     def __init__(self, p: torch.nn.Parameter):
         self.p = p
-        self.shape = (p.shape[0], p.shape[1])
+        self.shape = (p.shape[0], p[0].numel())
 
     @property
     def grad(self):
@@ -73,12 +73,14 @@ class _Conv1x1Param:
 
 
 class _Pointwise1x1Fn(torch.autograd.Function):
-    """y[t] = W x[t] (+ b) over the tokens of x [B, H, W, K]; W is the conv parameter [N, K, 1, 1]"""
+    """y[t] = W x[t] (+ b) over the tokens of x [B, H, W, K]; W is a conv parameter [N, ...] read as the [N, K] matrix it is in memory:
+    [N, K, 1, 1] of a pointwise convolution, or [N, C, p, p] of a kernel = stride patch embedding applied to space-to-depth tokens
+    (K = C p p)"""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         from .token_linear import _d32_forward
-        N, K = weight.shape[0], weight.shape[1]
+        N, K = weight.shape[0], weight[0].numel()
         x2 = x.reshape(-1, K)
         T = x2.shape[0]
         y = torch.empty((T, N), dtype=torch.float32, device=x.device)
@@ -93,7 +95,7 @@ class _Pointwise1x1Fn(torch.autograd.Function):
         from .token_linear import _DEFER, _d32_dgrad, _d32_workspace, _has_grad_hooks
         x2, weight = ctx.saved_tensors
         wp, bp = ctx.params
-        N, K = weight.shape[0], weight.shape[1]
+        N, K = weight.shape[0], weight[0].numel()
         T = x2.shape[0]
         dy2 = dy.reshape(-1, N)
         if not dy2.is_contiguous():
@@ -247,3 +249,11 @@ def pointwise_ok(conv, x_tokens: torch.Tensor) -> bool:
 
 def pointwise_tokens(conv, x_tokens: torch.Tensor) -> torch.Tensor:
     return _Pointwise1x1Fn.apply(x_tokens.contiguous(), conv.weight, conv.bias)
+
+
+def patch_embed_ok(conv, x_tokens: torch.Tensor) -> bool:
+    """a kernel = stride convolution applied as ONE token Linear to space-to-depth tokens [B, H / p, W / p, C p p] (fp32 device step)"""
+    return _fp32_device(x_tokens) and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == conv.stride and conv.groups == 1 \
+        and conv.padding == (0, 0) and conv.weight.dtype == torch.float32 and conv.weight[0].numel() % 4 == 0 \
+        and conv.out_channels % 4 == 0 and x_tokens.shape[-1] == conv.weight[0].numel() \
+        and x_tokens.numel() // x_tokens.shape[-1] >= 64
