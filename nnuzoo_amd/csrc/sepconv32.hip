@@ -347,19 +347,32 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
   const int n4 = N >> 2, k4 = K >> 2;
-  for (long tc = t0; tc < t1; tc += 64) {
+  // the next chunk's pieces are requested BEFORE the current chunk's products (register double buffer): without it every chunk
+  // exposed a full memory round trip between its two barriers (16 per workgroup: ~100 us per launch where the bytes take 30)
+  constexpr int PCS = 4;                       // 64 tokens x <= 16 quads = <= 1 024 pieces per operand: <= 4 per thread
+  f32x4 rd[PCS], rx[PCS];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](long tc) {
     const int nt = t1 - tc < 64 ? (int)(t1 - tc) : 64;
-    for (int i = tid; i < 64 * n4; i += 256) {
-      const int tt = i / n4, q = i - tt * n4;
-      *reinterpret_cast<f32x4*>(sD + tt * N + 4 * q) =
-          tt < nt ? *reinterpret_cast<const f32x4*>(dy + (tc + tt) * N + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < PCS; ++j) {
+      const int i = tid + 256 * j;
+      const int ttd = i / n4, qd = i - ttd * n4;
+      rd[j] = (i < 64 * n4 && ttd < nt) ? *reinterpret_cast<const f32x4*>(dy + (tc + ttd) * N + 4 * qd) : z4;
+      const int ttx = i / k4, qx = i - ttx * k4;
+      rx[j] = (i < 64 * k4 && ttx < nt) ? *reinterpret_cast<const f32x4*>(x + (tc + ttx) * K + 4 * qx) : z4;
     }
-    for (int i = tid; i < 64 * k4; i += 256) {
-      const int tt = i / k4, q = i - tt * k4;
-      *reinterpret_cast<f32x4*>(sX + tt * K + 4 * q) =
-          tt < nt ? *reinterpret_cast<const f32x4*>(x + (tc + tt) * K + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  if (t0 < t1) fetch(t0);
+  for (long tc = t0; tc < t1; tc += 64) {
+#pragma unroll
+    for (int j = 0; j < PCS; ++j) {
+      const int i = tid + 256 * j;
+      if (i < 64 * n4) *reinterpret_cast<f32x4*>(sD + (i / n4) * N + 4 * (i % n4)) = rd[j];
+      if (i < 64 * k4) *reinterpret_cast<f32x4*>(sX + (i / k4) * K + 4 * (i % k4)) = rx[j];
     }
     __syncthreads();
+    if (tc + 64 < t1) fetch(tc + 64);
     if (work) {
       for (int tt = sp; tt < 64; tt += shares) {
         const f32x4 d = *reinterpret_cast<const f32x4*>(sD + tt * N + n0);
