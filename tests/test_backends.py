@@ -65,7 +65,8 @@ def test_swt2net_bench_configuration_runs_on_hip(hip_lib):
     rep = bk.assert_hip(tr.network, allow=("Sequential",))
     assert rep["TokenLinear"] == {"hip-f32": sum(type(m).__name__ == "TokenLinear" for m in tr.network.modules())}
     assert rep["RSU4F"] == {"hip-f32": 3}
-    # stems of stages 2 ... 1d on the HIP path, stage 1's 1-channel stem on the library; the 1x1 heads of all eight stages on HIP;
+    # stems of stages 2 ... 1d on the HIP path, stage 1's 1-channel stem on the library; the 1x1 heads and patch embeddings of all eight stages on HIP;
     # no depthwise convolution left on ATen's kernels
-    assert rep["Sequential"] == {"hip-f32": 7, "library": 1} and rep["Conv2d"] == {"hip-f32": 8}
+    # (Conv2d: the 1x1 heads and the kernel = stride patch embeddings of the eight Swin U-net stages, both as token Linears)
+    assert rep["Sequential"] == {"hip-f32": 7, "library": 1} and rep["Conv2d"] == {"hip-f32": 16}
     assert "_Conv2d" not in rep and "_Conv2d.wgrad" not in rep
