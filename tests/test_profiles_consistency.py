@@ -13,8 +13,8 @@ PROF = os.path.join(ROOT, "profiles")
 def test_hbm_traffic_json_is_derived_from_the_committed_pmc_passes():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_traffic import per_kernel
-    f, nf = per_kernel(os.path.join(PROF, "r05_pmc_fetch_size.csv"), "FETCH_SIZE", "conv_box_kernel")
-    w, nw = per_kernel(os.path.join(PROF, "r05_pmc_write_size.csv"), "WRITE_SIZE", "conv_box_kernel")
+    f, nf = per_kernel(os.path.join(PROF, "r06_pmc_fetch_size.csv"), "FETCH_SIZE", "conv_box_kernel")
+    w, nw = per_kernel(os.path.join(PROF, "r06_pmc_write_size.csv"), "WRITE_SIZE", "conv_box_kernel")
     assert nf == nw and nf > 0
     derived = (2 * f + w) * 1024 / nf          # gfx950: FETCH_SIZE counts 64 B per 128-B request, units of KiB
     pub = json.load(open(os.path.join(PROF, "conv_box_kernel_hbm_traffic.json")))
@@ -27,11 +27,11 @@ def test_hbm_traffic_json_is_derived_from_the_committed_pmc_passes():
 
 
 def test_bench_line_agrees_with_the_kernel_stats_file():
-    line = json.loads(open(os.path.join(PROF, "r05_bench_n1.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(PROF, "r06_bench_n1.json")).read().strip().splitlines()[-1])
     roof = line["roofline"]
     assert line["unit"] == "patches/s" and line["n_gpus"] == 1 and roof["bound"] == "mfma"
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    rows = [r for r in csv.DictReader(open(os.path.join(PROF, "r05_bench_n1_kernel_stats.csv")))
+    rows = [r for r in csv.DictReader(open(os.path.join(PROF, "r06_bench_n1_kernel_stats.csv")))
             if "conv_box_kernel" in r["Name"]]
     calls = sum(int(r["Calls"]) for r in rows)
     avg_us = sum(float(r["TotalDurationNs"]) for r in rows) / calls / 1e3
@@ -39,3 +39,6 @@ def test_bench_line_agrees_with_the_kernel_stats_file():
     assert abs(avg_us - roof["avg_launch_us"]) <= 0.10 * roof["avg_launch_us"], (avg_us, roof["avg_launch_us"])
     assert calls % roof["launches_per_step"] == 0
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    # round 6: the zoo legs' headline numbers are top-level scalars of the contract line too
+    assert line["secondary_value"] == line["secondary"]["value"] and line["swt2net_value"] == line["swt2net"]["value"]
+    assert line["roofline_frac"] == roof["frac"] and "HBM-resident" in line["config"]["workload"]

@@ -23,6 +23,13 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_f -- $BENCH2 > /dev/
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_w -- $BENCH2 > /dev/null 2>&1
 cp $(ls $OUT/prof_f/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_fetch_size.csv
 cp $(ls $OUT/prof_w/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_write_size.csv
+# 2a. SQ counters of the conv kernels over the same eager primary step: MFMA instructions / busy cycles against the SQ's busy cycles
+#     (the "MFMA utilisation" evidence of the north star), and the per-launch traffic table of the conv path (tools/pmc_per_launch.py)
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $OUT/prof_sq -- $BENCH2 > /dev/null 2>&1
+python3 $R/tools/pmc_kernel_sums.py $(ls $OUT/prof_sq/*/*counter_collection.csv | head -1) conv_box_kernel conv_wgrad_kernel norm_kernel > $OUT/${TAG}_primary_pmc_sq_summary.json 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_kt -- $BENCH2 > /dev/null 2>&1
+python3 $R/tools/pmc_per_launch.py $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv conv_box_kernel 49 $(ls $OUT/prof_kt/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_conv_per_launch.txt 2>&1
+rm -rf $OUT/prof_sq $OUT/prof_kt
 unset NNZ_UNET_GRAPH
 python3 $R/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv conv_box_kernel > $OUT/conv_box_kernel_hbm_traffic.json
 rm -rf $OUT/prof_stats $OUT/prof_f $OUT/prof_w

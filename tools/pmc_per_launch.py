@@ -28,7 +28,7 @@ def main():
         name = a["Kernel_Name"].split("conv_box_kernel")[-1][:58] if "conv_box_kernel" in a["Kernel_Name"] else a["Kernel_Name"][:58]
         extra = ""
         if dur:
-            extra = f"  {dur[i]:8.1f} us  {(fm + wm) / dur[i] / 1e3:5.2f} TB/s"
+            extra = f"  {dur[i]:8.1f} us  {(fm + wm) / dur[i]:5.2f} TB/s"
         print(f"{i:3d} wgs {int(a['Grid_Size']) // 256:6d}  fetch {fm:8.1f} MB  write {wm:8.1f} MB{extra}  {name}")
     print(f"total fetch {tf:.0f} MB, write {tw:.0f} MB over {len(f)} launches -> {(tf + tw) / len(f):.1f} MB per launch")
 
