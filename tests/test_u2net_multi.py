@@ -83,10 +83,11 @@ def test_cpu_forward_backward_golden(name, nd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,nd", CASES)
+@pytest.mark.parametrize("name,nd", [c for c in CASES if c[1] == 2])
 def test_gpu_forward_backward_golden(hip_lib, name, nd):
     # fp32 on the device = the library's convolutions (the native unit is the fp16 autocast step below); same tolerances as
-    # tests/test_u2net_swt.py holds nets/u2net.py to
+    # tests/test_u2net_swt.py holds nets/u2net.py to.  (The 3-D net is stock torch on the device - no kernel of this package - and the
+    # library's solver search for its 64^3 convolutions costs a fresh box a minute: its wiring is pinned by the CPU test above.)
     _fwd_bwd(name, nd, "cuda", 3e-4, 2e-2)
 
 
@@ -112,7 +113,7 @@ def test_autocast_batchnorm_units_run_on_hip(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("trainer,nd", [("nnUNetTrainerU2NetMulti", 2), ("nnUNetTrainerU2NetMultiP", 2), ("nnUNetTrainerU2NetMultiP", 3)])
+@pytest.mark.parametrize("trainer,nd", [("nnUNetTrainerU2NetMulti", 2), ("nnUNetTrainerU2NetMultiP", 2)])
 def test_trainer_steps(hip_lib, trainer, nd):
     from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
     from nnuzoo_amd.training import zoo_trainers as Z
