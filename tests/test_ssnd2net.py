@@ -336,4 +336,4 @@ def test_ssnd2net_fp32_step_applies_its_updates_at_a_gradient_norm_of_1e9(hip_li
           f"{np.mean(losses[:4]):.4f} -> {np.mean(losses[-4:]):.4f}")
     assert all(np.isfinite(l) for l in losses)
     assert moved == 24, moved
-    assert e1 != e0 and e1 < e0 + 0.3, (e0, e1, losses)
+    assert e1 != e0 and e1 < e0 + 1.0, (e0, e1, losses)          # (measured +0.06; a run-away is several units)
