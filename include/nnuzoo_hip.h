@@ -460,6 +460,19 @@ int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, const float* 
 long nnz_pw_wgrad_small_workspace_floats(long T, int N, int K);
 int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* workspace, float* dW, long T, int N, int K, void* stream);
 
+/* 1x1 convolution to N <= 8 output channels in fp32: the side heads (`side1 .. side6`, C -> classes) and the fuse convolution
+ * (`outconv`, 6 classes -> classes) of SwT2Net, /root/reference/nnunetv2/nets/swt2net.py:1021-1028, 1130-1141.  y / dy [B][N][P]
+ * (NCHW), x addressed as x[b * xsb + p * xsp + k * xsk] (token-major stage output or NCHW concatenation), w [N][K], N * K <= 8192.
+ * wgrad: dwb [N][K + 1] = {dW | db} written, per-range partials + fixed-order fold (workspace:
+ * nnz_head1x1_wgrad_workspace_floats). */
+int nnz_head1x1_forward_f32(const float* x, const float* w, const float* bias, float* y, int B, int N, int K, long P, long xsb,
+                            long xsp, long xsk, void* stream);
+int nnz_head1x1_dgrad_f32(const float* dy, const float* w, float* dx, int B, int N, int K, long P, long xsb, long xsp, long xsk,
+                          void* stream);
+long nnz_head1x1_wgrad_workspace_floats(int B, int N, int K, long P);
+int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* workspace, float* dwb, int B, int N, int K, long P, long xsb,
+                          long xsp, long xsk, void* stream);
+
 /* ---- top / left zero padding of a channels-last fp32 map to the window multiple and the crop back (SwinTransformerBlock.forward,
  * swt2net.py:643-645 F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0)) and :660 x[:, -H:, -W:, :]; each is the other's
  * backward).  small [B][H][W][C], big [B][H + py][W + px][C], C % 4 == 0, B * (H + py) <= 65535; one launch each. */

@@ -403,6 +403,116 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
   }
 }
 
+// ---- 1x1 convolution to a handful of output channels: the side heads and the fuse convolution of the X^2-Nets --------------
+// y[b][n][p] = bias[n] + sum_k W[n][k] x(b, p, k), N <= 8: /root/reference/nnunetv2/nets/swt2net.py:1021-1028 `side1 .. side6`
+// (C -> classes, 1x1) and `outconv` (6 classes -> classes) of SwT2Net.  The output is NCHW ([B][N][P]: what the loss and the
+// up-sampling of the deep-supervision outputs take); the input is addressed through (batch, position, channel) strides: token-major
+// ([B][P][K], the layout the stages hand over: xsp = K, xsk = 1) or NCHW (the concatenated side outputs: xsp = 1, xsk = P).
+// HBM-bound by construction; the weight gradient is per-range partials + fold_partials (deterministic).
+constexpr int HD_MAXN = 8;
+struct HeadArgs32 {
+  const float* x;
+  const float* w;      // [N][K]
+  const float* bias;   // [N] or null
+  const float* dy;     // [B][N][P]
+  float* y;            // forward: [B][N][P];  dgrad: dx in the layout of x
+  long xsb, xsp, xsk;
+  int B, N, K;
+  long P;
+};
+__global__ __launch_bounds__(256) void head1x1_fwd_kernel(HeadArgs32 a) {
+  extern __shared__ float sw[];        // [N][K]
+  for (int i = threadIdx.x; i < a.N * a.K; i += 256) sw[i] = a.w[i];
+  __syncthreads();
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)a.B * a.P) return;
+  const int b = (int)(t / a.P);
+  const long p = t - (long)b * a.P;
+  const float* xp = a.x + b * a.xsb + p * a.xsp;
+  float acc[HD_MAXN];
+#pragma unroll
+  for (int n = 0; n < HD_MAXN; ++n) acc[n] = (n < a.N && a.bias) ? a.bias[n] : 0.f;
+  if (a.xsk == 1 && (a.K & 3) == 0) {
+    for (int k = 0; k < a.K; k += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + k);
+#pragma unroll
+      for (int n = 0; n < HD_MAXN; ++n)
+        if (n < a.N) {
+          const float* wr = sw + n * a.K + k;
+          acc[n] += wr[0] * v[0] + wr[1] * v[1] + wr[2] * v[2] + wr[3] * v[3];
+        }
+    }
+  } else {
+    for (int k = 0; k < a.K; ++k) {
+      const float v = xp[k * a.xsk];
+#pragma unroll
+      for (int n = 0; n < HD_MAXN; ++n)
+        if (n < a.N) acc[n] += sw[n * a.K + k] * v;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < HD_MAXN; ++n)
+    if (n < a.N) a.y[((long)b * a.N + n) * a.P + p] = acc[n];
+}
+// dx(b, p, k) = sum_n W[n][k] dy[b][n][p]; thread = (position, channel) with the channel fastest (token-major) or the position
+// fastest (NCHW)
+__global__ __launch_bounds__(256) void head1x1_dgrad_kernel(HeadArgs32 a) {
+  extern __shared__ float sw[];
+  for (int i = threadIdx.x; i < a.N * a.K; i += 256) sw[i] = a.w[i];
+  __syncthreads();
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)a.B * a.P * a.K;
+  if (i >= total) return;
+  long t;
+  int k;
+  if (a.xsk == 1) { t = i / a.K; k = (int)(i - t * a.K); }
+  else { const long bk = i / a.P; const long p = i - bk * a.P; k = (int)(bk % a.K); t = (bk / a.K) * a.P + p; }
+  const int b = (int)(t / a.P);
+  const long p = t - (long)b * a.P;
+  float v = 0.f;
+#pragma unroll
+  for (int n = 0; n < HD_MAXN; ++n)
+    if (n < a.N) v += sw[n * a.K + k] * a.dy[((long)b * a.N + n) * a.P + p];
+  a.y[b * a.xsb + p * a.xsp + k * a.xsk] = v;
+}
+// partial[range][n][k] = sum over the range's positions of dy[b][n][p] x(b, p, k); column K of a row = the bias partial sum dy.
+// Workgroup = 256 channels (blockIdx.y) x one range of HD_TR positions (never across samples: ranges are cut per sample).
+constexpr int HD_TR = 512;
+__global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgs32 a, float* __restrict__ part, int ranges_per_sample) {
+  __shared__ float sdy[HD_MAXN][HD_TR];
+  const int b = blockIdx.x / ranges_per_sample, r = blockIdx.x % ranges_per_sample;
+  const long p0 = (long)r * HD_TR;
+  const int np = a.P - p0 < HD_TR ? (int)(a.P - p0) : HD_TR;
+  for (int i = threadIdx.x; i < a.N * HD_TR; i += 256) {
+    const int n = i / HD_TR, pp = i - n * HD_TR;
+    sdy[n][pp] = pp < np ? a.dy[((long)b * a.N + n) * a.P + p0 + pp] : 0.f;
+  }
+  __syncthreads();
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  float acc[HD_MAXN];
+#pragma unroll
+  for (int n = 0; n < HD_MAXN; ++n) acc[n] = 0.f;
+  if (k < a.K) {
+    const float* xp = a.x + b * a.xsb + p0 * a.xsp + k * a.xsk;
+    for (int pp = 0; pp < np; ++pp) {
+      const float v = xp[pp * a.xsp];
+#pragma unroll
+      for (int n = 0; n < HD_MAXN; ++n)
+        if (n < a.N) acc[n] += sdy[n][pp] * v;
+    }
+  } else if (k == a.K) {      // the bias column
+    for (int pp = 0; pp < np; ++pp)
+#pragma unroll
+      for (int n = 0; n < HD_MAXN; ++n)
+        if (n < a.N) acc[n] += sdy[n][pp];
+  }
+  if (k <= a.K) {
+#pragma unroll
+    for (int n = 0; n < HD_MAXN; ++n)
+      if (n < a.N) part[((long)blockIdx.x * a.N + n) * (a.K + 1) + k] = acc[n];
+  }
+}
+
 }  // namespace nnz
 
 // x, y: [B][H][W][C] fp32 (C a multiple of 4, 16-byte aligned); w: [C][3][3]; bias: [C] or NULL.  flip = 1: the input gradient
@@ -509,6 +619,58 @@ extern "C" int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* wo
   NNZ_LAUNCH(pw_wgrad_small_kernel, dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, dy, x, workspace, T, N, K, shares);
   float* scratch = fold_partials_scratch_floats((int)ranges, (long)N * K) ? workspace + ranges * N * K : nullptr;
   hipError_t e = fold_partials(workspace, (int)ranges, (long)N * K, (long)N * K, dW, (hipStream_t)stream, scratch);
+  if (e != hipSuccess) return (int)e;
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+
+// 1x1 convolution to N <= 8 channels.  x: element (b, p, k) at x[b * xsb + p * xsp + k * xsk] (token-major: xsp = K, xsk = 1; NCHW:
+// xsp = 1, xsk = P), y / dy: [B][N][P] contiguous, w [N][K], bias [N] or NULL; N * K <= 8 192.
+static int head1x1_ok(int B, int N, int K, long P) { return B >= 1 && N >= 1 && N <= nnz::HD_MAXN && K >= 1 && (long)N * K <= 8192 && P >= 1; }
+extern "C" int nnz_head1x1_forward_f32(const float* x, const float* w, const float* bias, float* y, int B, int N, int K, long P,
+                                       long xsb, long xsp, long xsk, void* stream) {
+  using namespace nnz;
+  if (!x || !w || !y || !head1x1_ok(B, N, K, P)) return NNZ_EINVAL;
+  HeadArgs32 a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.xsb = xsb; a.xsp = xsp; a.xsk = xsk; a.B = B; a.N = N; a.K = K; a.P = P;
+  const long blocks = ((long)B * P + 255) / 256;
+  if (blocks > 0x7fffffffL) return NNZ_EINVAL;
+  NNZ_LAUNCH(head1x1_fwd_kernel, dim3((unsigned)blocks), dim3(256), N * K * (int)sizeof(float), (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+// dx in the layout of x (every element written)
+extern "C" int nnz_head1x1_dgrad_f32(const float* dy, const float* w, float* dx, int B, int N, int K, long P, long xsb, long xsp,
+                                     long xsk, void* stream) {
+  using namespace nnz;
+  if (!dy || !w || !dx || !head1x1_ok(B, N, K, P)) return NNZ_EINVAL;
+  HeadArgs32 a = {};
+  a.dy = dy; a.w = w; a.y = dx; a.xsb = xsb; a.xsp = xsp; a.xsk = xsk; a.B = B; a.N = N; a.K = K; a.P = P;
+  const long blocks = ((long)B * P * K + 255) / 256;
+  if (blocks > 0x7fffffffL) return NNZ_EINVAL;
+  NNZ_LAUNCH(head1x1_dgrad_kernel, dim3((unsigned)blocks), dim3(256), N * K * (int)sizeof(float), (hipStream_t)stream, a);
+  NNZ_LAUNCH_CHECK();
+  return NNZ_OK;
+}
+extern "C" long nnz_head1x1_wgrad_workspace_floats(int B, int N, int K, long P) {
+  if (!head1x1_ok(B, N, K, P)) return 0;
+  const long ranges = (long)B * ((P + nnz::HD_TR - 1) / nnz::HD_TR);
+  return ranges * N * (K + 1) + nnz::fold_partials_scratch_floats((int)ranges, (long)N * (K + 1));
+}
+// dwb [N][K + 1] is WRITTEN: columns 0 .. K - 1 = dW, column K = db.  Deterministic.
+extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* workspace, float* dwb, int B, int N, int K, long P,
+                                     long xsb, long xsp, long xsk, void* stream) {
+  using namespace nnz;
+  if (!x || !dy || !workspace || !dwb || !head1x1_ok(B, N, K, P)) return NNZ_EINVAL;
+  HeadArgs32 a = {};
+  a.x = x; a.dy = dy; a.xsb = xsb; a.xsp = xsp; a.xsk = xsk; a.B = B; a.N = N; a.K = K; a.P = P;
+  const int rps = (int)((P + HD_TR - 1) / HD_TR);
+  const long ranges = (long)B * rps;
+  if (ranges > 0x7fffffffL) return NNZ_EINVAL;
+  NNZ_LAUNCH(head1x1_wgrad_kernel, dim3((unsigned)ranges, (K + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, workspace, rps);
+  const long E = (long)N * (K + 1);
+  float* scratch = fold_partials_scratch_floats((int)ranges, E) ? workspace + ranges * E : nullptr;
+  hipError_t e = fold_partials(workspace, (int)ranges, E, E, dwb, (hipStream_t)stream, scratch);
   if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;

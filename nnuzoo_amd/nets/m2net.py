@@ -388,11 +388,22 @@ class _U2Forward:
         h3d = self.stage3d(self._fuse(3, self.patch_expand3d(h4d), h3))
         h2d = self.stage2d(self._fuse(2, self.patch_expand2d(h3d), h2))
         h1d = self.stage1d(self._fuse(1, self.patch_expand1d(h2d), h1))
-        d1, d2, d3 = self.side1(h1d), self.side2(h2d), self.side3(h3d)
-        d4, d5, d6 = self.side4(h4d), self.side5(h5d), self.side6(h6)
+        d1, d2, d3 = self._head(self.side1, h1d), self._head(self.side2, h2d), self._head(self.side3, h3d)
+        d4, d5, d6 = self._head(self.side4, h4d), self._head(self.side5, h5d), self._head(self.side6, h6)
         full = d1.shape[2:]
-        d0 = self.outconv(torch.cat([d1] + [_upsample_like(d, full) for d in (d2, d3, d4, d5, d6)], 1))
+        d0 = self._head(self.outconv, torch.cat([d1] + [_upsample_like(d, full) for d in (d2, d3, d4, d5, d6)], 1))
         return (d0, d1, d2, d3, d4, d5, d6) if self.deep_supervision else d0
+
+    @staticmethod
+    def _head(mod, x):
+        """a side / fuse convolution: 1x1 convolutions to <= 8 channels of an fp32 device step (SwT2Net's) run on csrc/sepconv32.hip
+        head1x1_* - straight off the token-major stage output, no layout copy, no library call; everything else is the module"""
+        from .. import sepconv32
+        conv = getattr(mod, "conv", mod)
+        if sepconv32.head1x1_ok(conv, x):
+            _backends.note(mod, "hip-f32")
+            return sepconv32.head1x1(conv, x)
+        return mod(x)
 
     def _encoder_groups(self):
         return [self.stage1, self.stage2, self.stage3, self.stage4, self.stage5, self.stage6, self.patch_merging1,

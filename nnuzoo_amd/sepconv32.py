@@ -257,3 +257,60 @@ def patch_embed_ok(conv, x_tokens: torch.Tensor) -> bool:
         and conv.padding == (0, 0) and conv.weight.dtype == torch.float32 and conv.weight[0].numel() % 4 == 0 \
         and conv.out_channels % 4 == 0 and x_tokens.shape[-1] == conv.weight[0].numel() \
         and x_tokens.numel() // x_tokens.shape[-1] >= 64
+
+
+# ---- 1x1 convolutions to a handful of channels: the side heads and the fuse convolution (csrc/sepconv32.hip head1x1_*) ---------------
+def _layout(x: torch.Tensor):
+    """(storage tensor, xsb, xsp, xsk, token_major) of an NCHW-LOGICAL tensor x [B, K, H, W] without copying when it is a permuted view
+    of token-major storage (what the stages hand over) or plain NCHW"""
+    B, K, H, W = x.shape
+    P = H * W
+    xt = x.permute(0, 2, 3, 1)
+    if xt.is_contiguous():
+        return xt, P * K, K, 1, True
+    xc = x.contiguous()
+    return xc, K * P, 1, P, False
+
+
+class _Head1x1Fn(torch.autograd.Function):
+    """y = conv1x1(x) for a conv with <= 8 output channels; x NCHW-logical (either memory layout), y NCHW contiguous"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, K, H, W = x.shape
+        N, P = weight.shape[0], H * W
+        xs, xsb, xsp, xsk, tm = _layout(x)
+        y = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
+        call("nnz_head1x1_forward_f32", ptr(xs), ptr(weight), ptr(bias), ptr(y), B, N, K, P, xsb, xsp, xsk, stream_ptr())
+        ctx.save_for_backward(xs, weight)
+        ctx.meta = (B, N, K, H, W, xsb, xsp, xsk, tm, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, weight = ctx.saved_tensors
+        B, N, K, H, W, xsb, xsp, xsk, tm, has_bias = ctx.meta
+        P = H * W
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxs = torch.empty_like(xs)
+            call("nnz_head1x1_dgrad_f32", ptr(dy), ptr(weight), ptr(dxs), B, N, K, P, xsb, xsp, xsk, stream_ptr())
+            dx = dxs.permute(0, 3, 1, 2) if tm else dxs
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            ws = torch.empty(int(_lib.load().nnz_head1x1_wgrad_workspace_floats(B, N, K, P)), dtype=torch.float32, device=dy.device)
+            dwb = torch.empty((N, K + 1), dtype=torch.float32, device=dy.device)
+            call("nnz_head1x1_wgrad_f32", ptr(xs), ptr(dy), ptr(ws), ptr(dwb), B, N, K, P, xsb, xsp, xsk, stream_ptr())
+            dw = dwb[:, :K].reshape(weight.shape)
+            db = dwb[:, K].contiguous() if has_bias else None
+        return dx, dw, db
+
+
+def head1x1_ok(conv, x: torch.Tensor) -> bool:
+    return _fp32_device(x) and x.dim() == 4 and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) \
+        and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.out_channels <= 8 \
+        and conv.out_channels * conv.in_channels <= 8192 and conv.weight.dtype == torch.float32
+
+
+def head1x1(conv, x: torch.Tensor) -> torch.Tensor:
+    return _Head1x1Fn.apply(x, conv.weight, conv.bias)

@@ -70,3 +70,4 @@ def test_swt2net_bench_configuration_runs_on_hip(hip_lib):
     # (Conv2d: the 1x1 heads and the kernel = stride patch embeddings of the eight Swin U-net stages, both as token Linears)
     assert rep["Sequential"] == {"hip-f32": 7, "library": 1} and rep["Conv2d"] == {"hip-f32": 16}
     assert "_Conv2d" not in rep and "_Conv2d.wgrad" not in rep
+    assert rep["Convolution"] == {"hip-f32": 7}          # side1 .. side6 + outconv on csrc/sepconv32.hip head1x1_*

@@ -127,3 +127,38 @@ def test_pointwise_1x1_forward_backward(hip_lib, T, K, N):
     _close(runs[0][1], rx, 2e-5, "dx")
     _close(runs[0][2], rw, 1e-4, "dw")
     assert all(torch.equal(p, q) for p, q in zip(runs[0], runs[1]))
+
+
+@pytest.mark.parametrize("B,K,N,H,W,token_major,bias", [(2, 32, 2, 64, 64, True, True), (2, 512, 2, 8, 8, True, True),
+                                                         (2, 12, 2, 48, 40, False, True), (1, 64, 3, 33, 17, True, False),
+                                                         (2, 32, 2, 512, 512, True, True)])
+def test_head_1x1_forward_backward(hip_lib, B, K, N, H, W, token_major, bias):
+    """the side heads / fuse convolution (1x1 to a few channels) against F.conv2d in float64: token-major stage outputs (permuted
+    views) and NCHW concatenations, y NCHW; dx comes back in the layout of x; bit-identical run to run"""
+    from nnuzoo_amd import sepconv32
+    g = torch.Generator().manual_seed(K + H)
+    xs = torch.randn(B, H, W, K, generator=g) if token_major else torch.randn(B, K, H, W, generator=g)
+    conv = torch.nn.Conv2d(K, N, 1, bias=bias)
+    dy = torch.randn(B, N, H, W, generator=g)
+    xr = (xs.permute(0, 3, 1, 2) if token_major else xs).double().requires_grad_(True)
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    b64 = conv.bias.detach().double().requires_grad_(True) if bias else None
+    ref = F.conv2d(xr, w64, b64)
+    want = torch.autograd.grad(ref, [xr, w64] + ([b64] if bias else []), dy.double())
+    conv = conv.to(DEV)
+    runs = []
+    for _ in range(2):
+        xd_s = xs.to(DEV).requires_grad_(True)
+        xd = xd_s.permute(0, 3, 1, 2) if token_major else xd_s
+        assert sepconv32.head1x1_ok(conv, xd)
+        y = sepconv32.head1x1(conv, xd)
+        assert y.is_contiguous() and tuple(y.shape) == (B, N, H, W)
+        got = torch.autograd.grad(y, [xd_s, conv.weight] + ([conv.bias] if bias else []), dy.to(DEV))
+        runs.append((y.detach(),) + got)
+    _close(runs[0][0], ref.detach(), 2e-5, "y")
+    dx_want = want[0].permute(0, 2, 3, 1) if token_major else want[0]
+    _close(runs[0][1], dx_want, 2e-5, "dx")
+    _close(runs[0][2], want[1], 1e-4, "dw")
+    if bias:
+        _close(runs[0][3], want[2], 1e-4, "db")
+    assert all(torch.equal(p, q) for p, q in zip(runs[0], runs[1]))
