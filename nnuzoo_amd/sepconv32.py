@@ -306,8 +306,11 @@ class _Head1x1Fn(torch.autograd.Function):
         return dx, dw, db
 
 
+USE_HEAD1X1 = os.environ.get("NNZ_HEAD1X1", "1") != "0"        # A/B switch
+
+
 def head1x1_ok(conv, x: torch.Tensor) -> bool:
-    return _fp32_device(x) and x.dim() == 4 and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) \
+    return USE_HEAD1X1 and _fp32_device(x) and x.dim() == 4 and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) \
         and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.out_channels <= 8 \
         and conv.out_channels * conv.in_channels <= 8192 and conv.weight.dtype == torch.float32
 
