@@ -513,6 +513,60 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgs32 a, float*
   }
 }
 
+// The same partials for FEW input channels (K + 1 <= 128: the full-resolution heads - 32 channels over 262 144 positions per sample -
+// and the 12-channel fuse convolution): with one thread per channel 13 ... 33 lanes of a workgroup worked (184 us per launch).  Here a
+// chunk of 64 positions of x goes through LDS ([pos][K], loaded coalesced in either layout) and the threads are (channel, position
+// group): Kp = K + 1 rounded up to a power of two, 256 / Kp groups that split the chunk's positions, folded through LDS at the end.
+__global__ __launch_bounds__(256) void head1x1_wgrad_small_kernel(HeadArgs32 a, float* __restrict__ part, int ranges_per_sample, int Kp) {
+  __shared__ float sdy[HD_MAXN][64];
+  __shared__ __attribute__((aligned(16))) float sx[64 * 128];       // [pos][K], reused as the fold buffer [g][n][Kp]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / ranges_per_sample, r = blockIdx.x % ranges_per_sample;
+  const long p0 = (long)r * HD_TR;
+  const int np = a.P - p0 < HD_TR ? (int)(a.P - p0) : HD_TR;
+  const int k = tid % Kp, g = tid / Kp, G = 256 / Kp;
+  float acc[HD_MAXN];
+#pragma unroll
+  for (int n = 0; n < HD_MAXN; ++n) acc[n] = 0.f;
+  const float* xb = a.x + b * a.xsb;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int nc = np - c0 < 64 ? np - c0 : 64;
+    for (int i = tid; i < a.N * 64; i += 256) {
+      const int n = i >> 6, pp = i & 63;
+      sdy[n][pp] = pp < nc ? a.dy[((long)b * a.N + n) * a.P + p0 + c0 + pp] : 0.f;
+    }
+    for (int i = tid; i < 64 * a.K; i += 256) {
+      int pp, kk;
+      if (a.xsk == 1) { pp = i / a.K; kk = i - pp * a.K; }
+      else { kk = i >> 6; pp = i & 63; }
+      sx[pp * a.K + kk] = pp < nc ? xb[(p0 + c0 + pp) * a.xsp + kk * a.xsk] : 0.f;
+    }
+    __syncthreads();
+    if (k <= a.K) {
+      for (int pp = g; pp < 64; pp += G) {
+        const float v = k < a.K ? sx[pp * a.K + k] : 1.f;          // column K: the bias gradient, sum of dy
+#pragma unroll
+        for (int n = 0; n < HD_MAXN; ++n)
+          if (n < a.N) acc[n] += sdy[n][pp] * v;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < HD_MAXN; ++n)
+    if (n < a.N) sx[(g * HD_MAXN + n) * Kp + k] = acc[n];
+  __syncthreads();
+  if (g == 0 && k <= a.K) {
+#pragma unroll
+    for (int n = 0; n < HD_MAXN; ++n)
+      if (n < a.N) {
+        float t = 0.f;
+        for (int q = 0; q < G; ++q) t += sx[(q * HD_MAXN + n) * Kp + k];
+        part[((long)blockIdx.x * a.N + n) * (a.K + 1) + k] = t;
+      }
+  }
+}
+
 }  // namespace nnz
 
 // x, y: [B][H][W][C] fp32 (C a multiple of 4, 16-byte aligned); w: [C][3][3]; bias: [C] or NULL.  flip = 1: the input gradient
@@ -667,7 +721,13 @@ extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* wor
   const int rps = (int)((P + HD_TR - 1) / HD_TR);
   const long ranges = (long)B * rps;
   if (ranges > 0x7fffffffL) return NNZ_EINVAL;
-  NNZ_LAUNCH(head1x1_wgrad_kernel, dim3((unsigned)ranges, (K + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, workspace, rps);
+  if (K + 1 <= 128) {
+    int Kp = 1;
+    while (Kp < K + 1) Kp <<= 1;
+    NNZ_LAUNCH(head1x1_wgrad_small_kernel, dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, a, workspace, rps, Kp);
+  } else {
+    NNZ_LAUNCH(head1x1_wgrad_kernel, dim3((unsigned)ranges, (K + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, workspace, rps);
+  }
   const long E = (long)N * (K + 1);
   float* scratch = fold_partials_scratch_floats((int)ranges, E) ? workspace + ranges * E : nullptr;
   hipError_t e = fold_partials(workspace, (int)ranges, E, E, dwb, (hipStream_t)stream, scratch);
