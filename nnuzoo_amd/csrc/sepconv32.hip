@@ -478,13 +478,15 @@ __global__ __launch_bounds__(256) void head1x1_dgrad_kernel(HeadArgs32 a) {
 // partial[range][n][k] = sum over the range's positions of dy[b][n][p] x(b, p, k); column K of a row = the bias partial sum dy.
 // Workgroup = 256 channels (blockIdx.y) x one range of HD_TR positions (never across samples: ranges are cut per sample).
 constexpr int HD_TR = 512;
-__global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgs32 a, float* __restrict__ part, int ranges_per_sample) {
+// (tr = positions per range, <= HD_TR: 64 for these wide heads - their maps are small (128^2 ... 16^2), and with 512 positions per
+//  range 64 workgroups walked 512 dependent-latency iterations each: 146 us per launch)
+__global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgs32 a, float* __restrict__ part, int ranges_per_sample, int tr) {
   __shared__ float sdy[HD_MAXN][HD_TR];
   const int b = blockIdx.x / ranges_per_sample, r = blockIdx.x % ranges_per_sample;
-  const long p0 = (long)r * HD_TR;
-  const int np = a.P - p0 < HD_TR ? (int)(a.P - p0) : HD_TR;
-  for (int i = threadIdx.x; i < a.N * HD_TR; i += 256) {
-    const int n = i / HD_TR, pp = i - n * HD_TR;
+  const long p0 = (long)r * tr;
+  const int np = a.P - p0 < tr ? (int)(a.P - p0) : tr;
+  for (int i = threadIdx.x; i < a.N * tr; i += 256) {
+    const int n = i / tr, pp = i - n * tr;
     sdy[n][pp] = pp < np ? a.dy[((long)b * a.N + n) * a.P + p0 + pp] : 0.f;
   }
   __syncthreads();
@@ -706,9 +708,11 @@ extern "C" int nnz_head1x1_dgrad_f32(const float* dy, const float* w, float* dx,
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
+static int head1x1_range(int K) { return K + 1 <= 128 ? nnz::HD_TR : 64; }
 extern "C" long nnz_head1x1_wgrad_workspace_floats(int B, int N, int K, long P) {
   if (!head1x1_ok(B, N, K, P)) return 0;
-  const long ranges = (long)B * ((P + nnz::HD_TR - 1) / nnz::HD_TR);
+  const int tr = head1x1_range(K);
+  const long ranges = (long)B * ((P + tr - 1) / tr);
   return ranges * N * (K + 1) + nnz::fold_partials_scratch_floats((int)ranges, (long)N * (K + 1));
 }
 // dwb [N][K + 1] is WRITTEN: columns 0 .. K - 1 = dW, column K = db.  Deterministic.
@@ -718,7 +722,8 @@ extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* wor
   if (!x || !dy || !workspace || !dwb || !head1x1_ok(B, N, K, P)) return NNZ_EINVAL;
   HeadArgs32 a = {};
   a.x = x; a.dy = dy; a.xsb = xsb; a.xsp = xsp; a.xsk = xsk; a.B = B; a.N = N; a.K = K; a.P = P;
-  const int rps = (int)((P + HD_TR - 1) / HD_TR);
+  const int tr = head1x1_range(K);
+  const int rps = (int)((P + tr - 1) / tr);
   const long ranges = (long)B * rps;
   if (ranges > 0x7fffffffL) return NNZ_EINVAL;
   if (K + 1 <= 128) {
@@ -726,7 +731,7 @@ extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* wor
     while (Kp < K + 1) Kp <<= 1;
     NNZ_LAUNCH(head1x1_wgrad_small_kernel, dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, a, workspace, rps, Kp);
   } else {
-    NNZ_LAUNCH(head1x1_wgrad_kernel, dim3((unsigned)ranges, (K + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, workspace, rps);
+    NNZ_LAUNCH(head1x1_wgrad_kernel, dim3((unsigned)ranges, (K + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, workspace, rps, tr);
   }
   const long E = (long)N * (K + 1);
   float* scratch = fold_partials_scratch_floats((int)ranges, E) ? workspace + ranges * E : nullptr;
