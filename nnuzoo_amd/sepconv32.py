@@ -227,17 +227,29 @@ def stem_ok(seq, x: torch.Tensor) -> bool:
     if not isinstance(dw, torch.nn.Conv2d) or not isinstance(pw, torch.nn.Conv2d):
         return False
     return dw.groups == dw.in_channels == dw.out_channels and dw.kernel_size == (3, 3) and dw.stride == (1, 1) \
-        and dw.padding == (1, 1) and dw.dilation == (1, 1) and dw.padding_mode == "zeros" and dw.in_channels % 4 == 0 \
+        and dw.padding == (1, 1) and dw.dilation == (1, 1) and dw.padding_mode == "zeros" \
+        and (dw.in_channels % 4 == 0 or dw.in_channels < 4) \
         and pw.kernel_size == (1, 1) and pw.stride == (1, 1) and pw.padding == (0, 0) and pw.groups == 1 \
         and pw.out_channels % 4 == 0 and dw.weight.dtype == torch.float32 and pw.weight.dtype == torch.float32 \
         and x.shape[0] * x.shape[2] * x.shape[3] >= 64
 
 
 def stem_forward(seq, x: torch.Tensor) -> torch.Tensor:
-    """NCHW in, NCHW view of token-major storage out"""
+    """NCHW in, NCHW view of token-major storage out.  A stem with fewer than four channels (the 1-channel network input of stage 1)
+    runs with its channels zero-padded to four: the image and the two small weights are padded on the fly (the extra channels
+    contribute exact zeros; autograd slices the gradients back), so the same kernels serve it"""
     dw, pw = seq[0].conv, seq[1].conv
-    h = _Dw3x3Fn.apply(x.permute(0, 2, 3, 1).contiguous(), dw.weight, dw.bias)
-    return _Pointwise1x1Fn.apply(h, pw.weight, pw.bias).permute(0, 3, 1, 2)
+    xt = x.permute(0, 2, 3, 1)
+    wd, bd, wp = dw.weight, dw.bias, pw.weight
+    C = dw.in_channels
+    if C % 4:
+        pad = 4 - C % 4
+        xt = torch.nn.functional.pad(xt, (0, pad))
+        wd = torch.nn.functional.pad(wd, (0, 0, 0, 0, 0, 0, 0, pad))
+        bd = torch.nn.functional.pad(bd, (0, pad)) if bd is not None else None
+        wp = torch.nn.functional.pad(wp, (0, 0, 0, 0, 0, pad))
+    h = _Dw3x3Fn.apply(xt.contiguous(), wd, bd)
+    return _Pointwise1x1Fn.apply(h, wp, pw.bias).permute(0, 3, 1, 2)
 
 
 def pointwise_ok(conv, x_tokens: torch.Tensor) -> bool:

@@ -162,3 +162,33 @@ def test_head_1x1_forward_backward(hip_lib, B, K, N, H, W, token_major, bias):
     if bias:
         _close(runs[0][3], want[2], 1e-4, "db")
     assert all(torch.equal(p, q) for p, q in zip(runs[0], runs[1]))
+
+
+@pytest.mark.parametrize("cin,cout,size", [(1, 32, 64), (64, 64, 32), (3, 16, 24)])
+def test_stage_stem_matches_the_torch_modules(hip_lib, cin, cout, size):
+    """get_dwconv_layer (depthwise 3x3 + pointwise 1x1) of a Swin U-net stage, incl. the 1-channel stem of stage 1 (zero-padded to four
+    channels): output, dx and both weight gradients against the module's own torch path in float64"""
+    from nnuzoo_amd import sepconv32
+    from nnuzoo_amd.nets.common2d import get_dwconv_layer
+    torch.manual_seed(cin + cout)
+    seq = get_dwconv_layer(2, cin, cout)
+    x = torch.randn(2, cin, size, size)
+    dy = torch.randn(2, cout, size, size)
+    ref = copy_double(seq)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double())
+    seq = seq.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    assert sepconv32.stem_ok(seq, xd)
+    y = sepconv32.stem_forward(seq, xd)
+    y.backward(dy.to(DEV))
+    _close(y, yr.detach(), 2e-5, "y")
+    _close(xd.grad, xr.grad, 5e-5, "dx")
+    for (n, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 2e-4, n)
+
+
+def copy_double(m):
+    import copy
+    return copy.deepcopy(m).double()
