@@ -22,7 +22,7 @@ launch (265); `cpu_baseline` {j['cpu_baseline']['value']:.3f} patches/s; `dice` 
 `swt2net` **{w['value']:.1f} patches/s** ({w['ms_per_step']:.1f} ms; 35.4), window attention {w['roofline']['frac']:.3f} of the fp32 MFMA peak (forward {w['roofline']['fwd_avg_launch_us']:.1f}, backward {w['roofline']['bwd_avg_launch_us']:.1f} us average
 launch).  Zoo (`profiles/r06_zoo_bench.txt`, 512^2, batch 2, graph replay, patches/s): {', '.join(zoo)}.
 The step times of the two zoo legs no longer depend on MIOpen's solver choice for the RSU4F stages (SwT2Net) - what is left on the
-library there is one 1-channel stem and the two small matmuls of the bilinear up-sampling's backward.
+library there is the two small matmuls of the bilinear up-sampling's backward.
 """
 p = os.path.join(ROOT, "DESIGN.md")
 d = open(p).read()
