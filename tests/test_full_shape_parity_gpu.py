@@ -107,3 +107,50 @@ def test_m2net_full_shape_forward_equals_the_committed_oracle_run(hip_lib):
     assert bool(agree[sure].all()), (int((~agree[sure]).sum()), int(sure.sum()))
     print("M2Net 1 x 512^2, eval mode, HIP vs the committed CPU-oracle run\n   " + "\n   ".join(report)
           + f"\n   argmax agreement {agree.float().mean().item():.6f} ({sure.float().mean().item():.4f} of the pixels resolvable)")
+
+
+def test_swt2net_full_shape_backward_equals_the_oracle(hip_lib):
+    """the backward half of the one-step comparison at 2 x 512^2: a fixed linear functional of the seven outputs (training mode -
+    BatchNorm on batch statistics -, stochastic depth off), dx and the L2 norm of every parameter gradient against the CPU oracle's
+    autograd.  This is where the large-token paths of the round-6 kernels (depthwise / pointwise / head weight gradients over
+    524 288 tokens, two-level folds) meet the whole network."""
+    from oracle.swt2net import SwT2Net as Ref
+    from nnuzoo_amd.nets.swt2net import SwT2Net
+    from nnuzoo_amd.synthetic import synthetic_batch
+    from nnuzoo_amd.token_linear import deferred_wgrads
+    torch.manual_seed(0)
+    ref = Ref(1, 2, True)
+    det_fill(ref)
+    net = SwT2Net(1, 2, True)
+    net.load_state_dict(ref.state_dict())
+    ref, net = _off(ref).train(), _off(net).cuda().train()
+    x = synthetic_batch(2, (512, 512), [[1, 1]], seed=11)["data"]
+
+    def functional(outs, dev):
+        tot = 0
+        for i, o in enumerate(outs):
+            j = torch.arange(o.numel(), dtype=torch.float64)
+            tot = tot + (o.float() * torch.sin(0.37 * j + i).float().view_as(o).to(dev)).sum() / o[0, 0].numel()
+        return tot
+
+    xr = x.clone().requires_grad_(True)
+    functional(ref(xr), "cpu").backward()
+    xd = x.cuda().requires_grad_(True)
+    with deferred_wgrads():
+        functional(net(xd), "cuda").backward()
+    dref = xr.grad
+    derr = (xd.grad.cpu() - dref).abs().max().item()
+    assert derr <= 2e-3 * dref.abs().max().item(), ("dx", derr, dref.abs().max().item())
+    want = {n: p.grad.double().norm().item() for n, p in ref.named_parameters() if p.grad is not None}
+    top = max(want.values())
+    worst = (0.0, "")
+    for n, p in net.named_parameters():
+        if n not in want:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        have = p.grad.double().norm().item()
+        rel = abs(have - want[n]) / max(want[n], 1e-4 * top)
+        worst = max(worst, (rel, n))
+        assert rel <= 5e-3, (n, have, want[n])
+    print(f"SwT2Net 2 x 512^2 backward: dx err {derr / dref.abs().max().item():.1e} of range, worst parameter-gradient norm "
+          f"deviation {worst[0]:.1e} ({worst[1]}) over {len(want)} parameters")
