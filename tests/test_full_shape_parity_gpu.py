@@ -110,10 +110,14 @@ def test_m2net_full_shape_forward_equals_the_committed_oracle_run(hip_lib):
 
 
 def test_swt2net_full_shape_backward_equals_the_oracle(hip_lib):
-    """the backward half of the one-step comparison at 2 x 512^2: a fixed linear functional of the seven outputs (training mode -
-    BatchNorm on batch statistics -, stochastic depth off), dx and the L2 norm of every parameter gradient against the CPU oracle's
-    autograd.  This is where the large-token paths of the round-6 kernels (depthwise / pointwise / head weight gradients over
-    524 288 tokens, two-level folds) meet the whole network."""
+    """the backward half of the one-step comparison at 2 x 512^2: a fixed linear functional of the seven outputs, dx and the L2 norm of
+    every parameter gradient against the CPU oracle's autograd - in EVAL mode (BatchNorm on its running estimates, stochastic depth
+    off).  In training mode with these formula-made parameters the backward is chaotic: the ORACLE's own dx moves by 0.5 (128^2) ...
+    1.7 (512^2) of its range when the input moves by 1e-6 (batch statistics over 16^2 / 8^2 maps; tools/probes/
+    swt2net_fullshape_bwd_probe.py), so there is nothing to compare; in eval mode its response is 1.6e-4 and the HIP path sits at
+    2.1e-4.  Tolerances are the oracle's own response to that perturbation x 50 (dx) and x 200 per parameter, floors 2e-3 / 5e-3.
+    This is where the large-token paths of the round-6 kernels (depthwise / pointwise / head weight gradients over 524 288 tokens,
+    two-level folds) meet the whole network."""
     from oracle.swt2net import SwT2Net as Ref
     from nnuzoo_amd.nets.swt2net import SwT2Net
     from nnuzoo_amd.synthetic import synthetic_batch
@@ -123,7 +127,7 @@ def test_swt2net_full_shape_backward_equals_the_oracle(hip_lib):
     det_fill(ref)
     net = SwT2Net(1, 2, True)
     net.load_state_dict(ref.state_dict())
-    ref, net = _off(ref).train(), _off(net).cuda().train()
+    ref, net = _off(ref).eval(), _off(net).cuda().eval()
     x = synthetic_batch(2, (512, 512), [[1, 1]], seed=11)["data"]
 
     def functional(outs, dev):
@@ -133,24 +137,33 @@ def test_swt2net_full_shape_backward_equals_the_oracle(hip_lib):
             tot = tot + (o.float() * torch.sin(0.37 * j + i).float().view_as(o).to(dev)).sum() / o[0, 0].numel()
         return tot
 
-    xr = x.clone().requires_grad_(True)
-    functional(ref(xr), "cpu").backward()
+    def oracle(xin):
+        ref.zero_grad(set_to_none=True)
+        xr = xin.clone().requires_grad_(True)
+        functional(ref(xr), "cpu").backward()
+        return xr.grad, {n: p.grad.double().norm().item() for n, p in ref.named_parameters() if p.grad is not None}
+
+    dref, want = oracle(x)
+    dpert, wpert = oracle(x * (1 + 1e-6))
+    rng = dref.abs().max().item()
+    bsens = (dpert - dref).abs().max().item() / rng
+    top = max(want.values())
+    floor = 1e-3 * top
     xd = x.cuda().requires_grad_(True)
     with deferred_wgrads():
         functional(net(xd), "cuda").backward()
-    dref = xr.grad
-    derr = (xd.grad.cpu() - dref).abs().max().item()
-    assert derr <= 2e-3 * dref.abs().max().item(), ("dx", derr, dref.abs().max().item())
-    want = {n: p.grad.double().norm().item() for n, p in ref.named_parameters() if p.grad is not None}
-    top = max(want.values())
-    worst = (0.0, "")
+    derr = (xd.grad.cpu() - dref).abs().max().item() / rng
+    assert derr <= max(2e-3, 50 * bsens), ("dx", derr, bsens)
+    worst = (0.0, "", 0.0)
     for n, p in net.named_parameters():
         if n not in want:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         have = p.grad.double().norm().item()
-        rel = abs(have - want[n]) / max(want[n], 1e-4 * top)
-        worst = max(worst, (rel, n))
-        assert rel <= 5e-3, (n, have, want[n])
-    print(f"SwT2Net 2 x 512^2 backward: dx err {derr / dref.abs().max().item():.1e} of range, worst parameter-gradient norm "
-          f"deviation {worst[0]:.1e} ({worst[1]}) over {len(want)} parameters")
+        rel = abs(have - want[n]) / max(want[n], floor)
+        cond = abs(wpert[n] - want[n]) / max(want[n], floor)
+        worst = max(worst, (rel, n, cond))
+        assert rel <= max(5e-3, 200 * cond), (n, have, want[n], cond)
+    print(f"SwT2Net 2 x 512^2 backward (eval mode): dx err {derr:.1e} of range (the oracle's own response to a 1e-6 input change "
+          f"{bsens:.1e}); worst parameter-gradient norm deviation {worst[0]:.1e} ({worst[1]}; the oracle's own {worst[2]:.1e}) over "
+          f"{len(want)} parameters")
