@@ -43,3 +43,36 @@ def test_m2netp_training_steps_are_bit_reproducible(hip_lib, graph, monkeypatch)
     assert la == lb, (la, lb)
     diff = [n for n in pa if not torch.equal(pa[n], pb[n])]
     assert not diff, (len(diff), diff[:8])
+
+
+def _run_swt(graph: bool, steps: int = 4):
+    from nnuzoo_amd.synthetic import nnunet_plans, synthetic_batch
+    from nnuzoo_amd.training.zoo_trainers import nnUNetTrainerSwT2Net
+    plans, cfg, dj = nnunet_plans(2, (128, 128), batch_size=2)
+    torch.manual_seed(0)
+    tr = nnUNetTrainerSwT2Net(plans, cfg, 0, dj, device=torch.device("cuda"))
+    tr.initialize()
+    tr.use_hip_graph = graph
+    scales = tr._get_deep_supervision_scales()
+    losses = []
+    torch.manual_seed(1)            # DropPath draws
+    for it in range(steps):
+        b = synthetic_batch(2, (128, 128), scales, seed=100 + it)
+        b = {"data": b["data"].cuda(), "target": [t.cuda() for t in b["target"]]}
+        losses.append(float(tr.train_step(b)["loss"]))
+    torch.cuda.synchronize()
+    return losses, {n: p.detach().clone() for n, p in tr.network.named_parameters()}
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_swt2net_training_steps_are_bit_reproducible_in_the_default_mode(hip_lib, graph):
+    """round 6: with the RSU4F stages, the stage stems / heads / patch embeddings and the side heads on csrc/sepconv32.hip no
+    convolution of the SwT2Net step goes to MIOpen any more, so the step needs no `NNZ_LIBRARY_DETERMINISTIC` switch: two trainers
+    built from one seed hold bit-identical parameters after four steps in the DEFAULT library mode (what is left on a library - the
+    two small matmuls of the bilinear up-sampling's backward - is a plain GEMM)"""
+    from nnuzoo_amd import backends as bk
+    la, pa = _run_swt(graph)
+    lb, pb = _run_swt(graph)
+    assert la == lb, (la, lb)
+    diff = [n for n in pa if not torch.equal(pa[n], pb[n])]
+    assert not diff, (len(diff), diff[:8])
