@@ -4,7 +4,8 @@ equal").  The 3-D 128^3 configuration has its full-size test 
 * SwT2Net 2 x 512^2 (configs[3]): the HIP network against the CPU oracle oracle/swt2net.py (pinned by the reference's own whole-net
   outputs and autograd, tests/test_oracle_swt2net.py) run HERE on the same seeded parameters (golden_util.det_fill) and input, eval
   mode: seven outputs within max(1e-4, 100 x the oracle's own response to a 1e-6 input perturbation) of each output's range, argmax
-  masks equal wherever the oracle's top-2 margin exceeds twice the observed logit error.
+  masks equal wherever the oracle's top-2 margin exceeds twice the observed logit error; and the backward of a fixed functional of
+  the outputs (dx, every parameter-gradient norm) on tolerances from the oracle's own response to the same perturbation.
 * M2Net (SS2D^2Net) 1 x 512^2 (configs[2]): the oracle's time loop over 512^2 tokens takes about an hour of CPU, so its forward was
   run ONCE in the build container (tools/make_golden_full_shape.py: oracle/m2net.py, itself pinned by the reference's whole-net
   fixtures in tests/test_oracle_m2net.py) and strided samples of its seven outputs + the packed argmax mask of the full-resolution
@@ -38,36 +39,6 @@ def _argmax_check(got, ref, err_abs, name):
     assert sure.float().mean().item() > 0.98, (name, "fraction of resolvable pixels", sure.float().mean().item())
     assert bool(agree[sure].all()), (name, int((~agree[sure]).sum()), int(sure.sum()))
     return float(agree.float().mean())
-
-
-def test_swt2net_full_shape_forward_equals_the_oracle(hip_lib):
-    from oracle.swt2net import SwT2Net as Ref
-    from nnuzoo_amd.nets.swt2net import SwT2Net
-    from nnuzoo_amd.synthetic import synthetic_batch
-    torch.manual_seed(0)
-    ref = Ref(1, 2, True)
-    det_fill(ref)
-    net = SwT2Net(1, 2, True)
-    net.load_state_dict(ref.state_dict())
-    ref, net = _off(ref).eval(), _off(net).cuda().eval()
-    x = synthetic_batch(2, (512, 512), [[1, 1]], seed=11)["data"]
-    with torch.no_grad():
-        base = ref(x)
-        pert = ref(x * (1 + 1e-6))
-        got = [o.float().cpu() for o in net(x.cuda())]
-    assert len(got) == len(base) == 7
-    report = []
-    for i, (o, r, p) in enumerate(zip(got, base, pert)):
-        assert o.shape == r.shape
-        rng = r.abs().max().item()
-        sens = (p - r).abs().max().item() / rng
-        err = (o - r).abs().max().item()
-        tol = max(1e-4, 100 * sens)
-        agree = _argmax_check(o, r, err, f"output {i}")
-        report.append(f"d{i} {tuple(r.shape)}: err {err / rng:.1e} of range (oracle's own response {sens:.1e}, tolerance {tol:.1e}), "
-                      f"argmax agreement {agree:.6f}")
-        assert err <= tol * rng, report[-1]
-    print("SwT2Net 2 x 512^2, eval mode, HIP vs CPU oracle\n   " + "\n   ".join(report))
 
 
 def test_m2net_full_shape_forward_equals_the_committed_oracle_run(hip_lib):
@@ -109,9 +80,11 @@ def test_m2net_full_shape_forward_equals_the_committed_oracle_run(hip_lib):
           + f"\n   argmax agreement {agree.float().mean().item():.6f} ({sure.float().mean().item():.4f} of the pixels resolvable)")
 
 
-def test_swt2net_full_shape_backward_equals_the_oracle(hip_lib):
-    """the backward half of the one-step comparison at 2 x 512^2: a fixed linear functional of the seven outputs, dx and the L2 norm of
-    every parameter gradient against the CPU oracle's autograd - in EVAL mode (BatchNorm on its running estimates, stochastic depth
+def test_swt2net_full_shape_forward_and_backward_equal_the_oracle(hip_lib):
+    """one step at 2 x 512^2 against the CPU oracle run HERE (two oracle passes: the input and a 1e-6 perturbed input, the yardstick).
+    FORWARD: seven outputs within max(1e-4, 100 x the oracle's own response) of each output's range, argmax masks equal wherever the
+    oracle's top-2 margin exceeds twice the observed logit error.  BACKWARD: a fixed linear functional of the seven outputs, dx and the
+    L2 norm of every parameter gradient against the CPU oracle's autograd - in EVAL mode (BatchNorm on its running estimates, stochastic depth
     off).  In training mode with these formula-made parameters the backward is chaotic: the ORACLE's own dx moves by 0.5 (128^2) ...
     1.7 (512^2) of its range when the input moves by 1e-6 (batch statistics over 16^2 / 8^2 maps; tools/probes/
     swt2net_fullshape_bwd_probe.py), so there is nothing to compare; in eval mode its response is 1.6e-4 and the HIP path sits at
@@ -140,18 +113,35 @@ def test_swt2net_full_shape_backward_equals_the_oracle(hip_lib):
     def oracle(xin):
         ref.zero_grad(set_to_none=True)
         xr = xin.clone().requires_grad_(True)
-        functional(ref(xr), "cpu").backward()
-        return xr.grad, {n: p.grad.double().norm().item() for n, p in ref.named_parameters() if p.grad is not None}
+        outs = ref(xr)
+        functional(outs, "cpu").backward()
+        return [o.detach() for o in outs], xr.grad, {n: p.grad.double().norm().item() for n, p in ref.named_parameters()
+                                                       if p.grad is not None}
 
-    dref, want = oracle(x)
-    dpert, wpert = oracle(x * (1 + 1e-6))
+    base, dref, want = oracle(x)
+    pert, dpert, wpert = oracle(x * (1 + 1e-6))
     rng = dref.abs().max().item()
     bsens = (dpert - dref).abs().max().item() / rng
     top = max(want.values())
     floor = 1e-3 * top
     xd = x.cuda().requires_grad_(True)
+    outs = net(xd)
     with deferred_wgrads():
-        functional(net(xd), "cuda").backward()
+        functional(outs, "cuda").backward()
+    got = [o.detach().float().cpu() for o in outs]
+    assert len(got) == len(base) == 7
+    report = []
+    for i, (o, r, p) in enumerate(zip(got, base, pert)):
+        assert o.shape == r.shape
+        orng = r.abs().max().item()
+        sens = (p - r).abs().max().item() / orng
+        err = (o - r).abs().max().item()
+        tol = max(1e-4, 100 * sens)
+        agree = _argmax_check(o, r, err, f"output {i}")
+        report.append(f"d{i} {tuple(r.shape)}: err {err / orng:.1e} of range (oracle's own response {sens:.1e}, tolerance {tol:.1e}), "
+                      f"argmax agreement {agree:.6f}")
+        assert err <= tol * orng, report[-1]
+    print("SwT2Net 2 x 512^2, eval mode, HIP vs CPU oracle\n   " + "\n   ".join(report))
     derr = (xd.grad.cpu() - dref).abs().max().item() / rng
     assert derr <= max(2e-3, 50 * bsens), ("dx", derr, bsens)
     worst = (0.0, "", 0.0)
