@@ -60,11 +60,12 @@ def test_forward_backward_parity(hip_lib, n_stages, feats, patch, geom):
     _check_forward_backward(ref, net, x, n_stages, g)
 
 
-def test_full_size_3d_fullres_128(hip_lib):
-    """BASELINE configs[1] at its FULL size: the 6-stage 3d_fullres network (kwargs from the pinned manifest,
-    tests/golden/plainconv_manifest.json) on one 1x128^3 patch - forward logits + argmax and one backward with every
-    parameter gradient against the fp32 CPU oracle.  This is the only place the 8x8x8 conv tile, the 128^3 norm / head /
-    stem launches and the full-depth schedule meet in one run (batch 1 keeps the CPU side to about a minute)."""
+YARDSTICK_128 = "plainconv_128_autocast_yardstick.json"
+
+
+def full_size_case():
+    """the 6-stage 3d_fullres pair (CPU oracle, HIP net), the 1x128^3 patch and the generator the backward's G tensors
+    continue from - shared with tools/make_golden_autocast_yardstick.py"""
     import json
     import os
     import pydoc
@@ -87,13 +88,30 @@ def test_full_size_3d_fullres_128(hip_lib):
     net = PlainConvUNet(1, num_classes=2, deep_supervision=True, **kw)
     assert sum(p.numel() for p in net.parameters()) == case["parameter_count"]
     net.load_state_dict(ref.state_dict())
-    net = net.cuda()
     x = torch.randn(1, 1, 128, 128, 128, generator=g)
-    outs = _check_forward_backward(ref, net, x, 6, g)
+    return case, ref, net, x, g
+
+
+def test_full_size_3d_fullres_128(hip_lib):
+    """BASELINE configs[1] at its FULL size: the 6-stage 3d_fullres network (kwargs from the pinned manifest,
+    tests/golden/plainconv_manifest.json) on one 1x128^3 patch - forward logits + argmax and one backward with every
+    parameter gradient against the fp32 CPU oracle.  This is the only place the 8x8x8 conv tile, the 128^3 norm / head /
+    stem launches and the full-depth schedule meet in one run (batch 1 keeps the CPU side to ~10 s).
+
+    The yardstick of the gradient tolerance - what torch's own fp16-autocast step (MIOpen kernels) loses against the same
+    fp32 oracle on the same tensors - is read from tests/golden/plainconv_128_autocast_yardstick.json, recorded on an
+    MI355X by tools/make_golden_autocast_yardstick.py: measuring it live costs 220 s of MIOpen solver probing at 128^3
+    for 10 s of comparison (NNZ_LIVE_YARDSTICK=1 measures it live as before)."""
+    import json
+    import os
+    case, ref, net, x, g = full_size_case()
+    live = os.environ.get("NNZ_LIVE_YARDSTICK") == "1"
+    table = None if live else json.load(open(os.path.join(os.path.dirname(__file__), "golden", YARDSTICK_128)))["rel16"]
+    outs = _check_forward_backward(ref, net.cuda(), x, 6, g, yardstick=live, recorded=table)
     assert [list(o.shape[1:]) for o in outs] == case["deep_supervision_output_shapes"]
 
 
-def _check_forward_backward(ref, net, x, n_stages, g, yardstick=True):
+def _check_forward_backward(ref, net, x, n_stages, g, yardstick=True, recorded=None):
     outs_ref = ref(x)
     outs = net(x.cuda())
     assert len(outs) == len(outs_ref) == n_stages - 1
@@ -147,7 +165,10 @@ def _check_forward_backward(ref, net, x, n_stages, g, yardstick=True):
             continue
         denom = gr.norm().item() + 1e-12
         rel = (got - gr).norm().item() / denom
-        rel16 = (ac_params[name].grad.float().cpu() - gr).norm().item() / denom if ac_params is not None else 0.0
+        if ac_params is not None:
+            rel16 = (ac_params[name].grad.float().cpu() - gr).norm().item() / denom
+        else:
+            rel16 = recorded[name] if recorded is not None else 0.0
         report.append((rel, rel16, name))
     report.sort(reverse=True)
     print("relative gradient error vs fp32 oracle (ours, torch-autocast yardstick):")
