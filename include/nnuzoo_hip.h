@@ -472,6 +472,14 @@ int nnz_head1x1_dgrad_f32(const float* dy, const float* w, float* dx, int B, int
 long nnz_head1x1_wgrad_workspace_floats(int B, int N, int K, long P);
 int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* workspace, float* dwb, int B, int N, int K, long P, long xsb,
                           long xsp, long xsk, void* stream);
+/* the same three with fp16 activations (x, y, dy, dx: IEEE half), fp32 weights / bias / sums / dwb: the fuse convolution of the
+ * fp16-autocast X^2-Nets (`outconv`, /root/reference/nnunetv2/nets/m2net.py:881, 948-950), whose operands autocast rounds to fp16 */
+int nnz_head1x1_forward_f16(const void* x, const float* w, const float* bias, void* y, int B, int N, int K, long P, long xsb,
+                            long xsp, long xsk, void* stream);
+int nnz_head1x1_dgrad_f16(const void* dy, const float* w, void* dx, int B, int N, int K, long P, long xsb, long xsp, long xsk,
+                          void* stream);
+int nnz_head1x1_wgrad_f16(const void* x, const void* dy, float* workspace, float* dwb, int B, int N, int K, long P, long xsb,
+                          long xsp, long xsk, void* stream);
 
 /* ---- top / left zero padding of a channels-last fp32 map to the window multiple and the crop back (SwinTransformerBlock.forward,
  * swt2net.py:643-645 F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0)) and :660 x[:, -H:, -W:, :]; each is the other's

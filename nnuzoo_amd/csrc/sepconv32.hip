@@ -410,17 +410,21 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
 // ([B][P][K], the layout the stages hand over: xsp = K, xsk = 1) or NCHW (the concatenated side outputs: xsp = 1, xsk = P).
 // HBM-bound by construction; the weight gradient is per-range partials + fold_partials (deterministic).
 constexpr int HD_MAXN = 8;
-struct HeadArgs32 {
-  const float* x;
+// T = float (the fp32 device step of SwT2Net) or _Float16 (activations of the fp16-autocast steps: M2Net's fuse convolution); the
+// weights, the bias and every sum are fp32 either way.
+template <typename T>
+struct HeadArgsT {
+  const T* x;
   const float* w;      // [N][K]
   const float* bias;   // [N] or null
-  const float* dy;     // [B][N][P]
-  float* y;            // forward: [B][N][P];  dgrad: dx in the layout of x
+  const T* dy;         // [B][N][P]
+  T* y;                // forward: [B][N][P];  dgrad: dx in the layout of x
   long xsb, xsp, xsk;
   int B, N, K;
   long P;
 };
-__global__ __launch_bounds__(256) void head1x1_fwd_kernel(HeadArgs32 a) {
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_fwd_kernel(HeadArgsT<T> a) {
   extern __shared__ float sw[];        // [N][K]
   for (int i = threadIdx.x; i < a.N * a.K; i += 256) sw[i] = a.w[i];
   __syncthreads();
@@ -428,13 +432,13 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(HeadArgs32 a) {
   if (t >= (long)a.B * a.P) return;
   const int b = (int)(t / a.P);
   const long p = t - (long)b * a.P;
-  const float* xp = a.x + b * a.xsb + p * a.xsp;
+  const T* xp = a.x + b * a.xsb + p * a.xsp;
   float acc[HD_MAXN];
 #pragma unroll
   for (int n = 0; n < HD_MAXN; ++n) acc[n] = (n < a.N && a.bias) ? a.bias[n] : 0.f;
-  if (a.xsk == 1 && (a.K & 3) == 0) {
+  if (sizeof(T) == 4 && a.xsk == 1 && (a.K & 3) == 0) {
     for (int k = 0; k < a.K; k += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + k);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xp) + k);
 #pragma unroll
       for (int n = 0; n < HD_MAXN; ++n)
         if (n < a.N) {
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(HeadArgs32 a) {
     }
   } else {
     for (int k = 0; k < a.K; ++k) {
-      const float v = xp[k * a.xsk];
+      const float v = (float)xp[k * a.xsk];
 #pragma unroll
       for (int n = 0; n < HD_MAXN; ++n)
         if (n < a.N) acc[n] += sw[n * a.K + k] * v;
@@ -452,11 +456,12 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(HeadArgs32 a) {
   }
 #pragma unroll
   for (int n = 0; n < HD_MAXN; ++n)
-    if (n < a.N) a.y[((long)b * a.N + n) * a.P + p] = acc[n];
+    if (n < a.N) a.y[((long)b * a.N + n) * a.P + p] = (T)acc[n];
 }
 // dx(b, p, k) = sum_n W[n][k] dy[b][n][p]; thread = (position, channel) with the channel fastest (token-major) or the position
 // fastest (NCHW)
-__global__ __launch_bounds__(256) void head1x1_dgrad_kernel(HeadArgs32 a) {
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_dgrad_kernel(HeadArgsT<T> a) {
   extern __shared__ float sw[];
   for (int i = threadIdx.x; i < a.N * a.K; i += 256) sw[i] = a.w[i];
   __syncthreads();
@@ -472,22 +477,23 @@ __global__ __launch_bounds__(256) void head1x1_dgrad_kernel(HeadArgs32 a) {
   float v = 0.f;
 #pragma unroll
   for (int n = 0; n < HD_MAXN; ++n)
-    if (n < a.N) v += sw[n * a.K + k] * a.dy[((long)b * a.N + n) * a.P + p];
-  a.y[b * a.xsb + p * a.xsp + k * a.xsk] = v;
+    if (n < a.N) v += sw[n * a.K + k] * (float)a.dy[((long)b * a.N + n) * a.P + p];
+  a.y[b * a.xsb + p * a.xsp + k * a.xsk] = (T)v;
 }
 // partial[range][n][k] = sum over the range's positions of dy[b][n][p] x(b, p, k); column K of a row = the bias partial sum dy.
 // Workgroup = 256 channels (blockIdx.y) x one range of HD_TR positions (never across samples: ranges are cut per sample).
 constexpr int HD_TR = 512;
 // (tr = positions per range, <= HD_TR: 64 for these wide heads - their maps are small (128^2 ... 16^2), and with 512 positions per
 //  range 64 workgroups walked 512 dependent-latency iterations each: 146 us per launch)
-__global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgs32 a, float* __restrict__ part, int ranges_per_sample, int tr) {
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgsT<T> a, float* __restrict__ part, int ranges_per_sample, int tr) {
   __shared__ float sdy[HD_MAXN][HD_TR];
   const int b = blockIdx.x / ranges_per_sample, r = blockIdx.x % ranges_per_sample;
   const long p0 = (long)r * tr;
   const int np = a.P - p0 < tr ? (int)(a.P - p0) : tr;
   for (int i = threadIdx.x; i < a.N * tr; i += 256) {
     const int n = i / tr, pp = i - n * tr;
-    sdy[n][pp] = pp < np ? a.dy[((long)b * a.N + n) * a.P + p0 + pp] : 0.f;
+    sdy[n][pp] = pp < np ? (float)a.dy[((long)b * a.N + n) * a.P + p0 + pp] : 0.f;
   }
   __syncthreads();
   const int k = blockIdx.y * 256 + threadIdx.x;
@@ -495,9 +501,9 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgs32 a, float*
 #pragma unroll
   for (int n = 0; n < HD_MAXN; ++n) acc[n] = 0.f;
   if (k < a.K) {
-    const float* xp = a.x + b * a.xsb + p0 * a.xsp + k * a.xsk;
+    const T* xp = a.x + b * a.xsb + p0 * a.xsp + k * a.xsk;
     for (int pp = 0; pp < np; ++pp) {
-      const float v = xp[pp * a.xsp];
+      const float v = (float)xp[pp * a.xsp];
 #pragma unroll
       for (int n = 0; n < HD_MAXN; ++n)
         if (n < a.N) acc[n] += sdy[n][pp] * v;
@@ -519,7 +525,8 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(HeadArgs32 a, float*
 // and the 12-channel fuse convolution): with one thread per channel 13 ... 33 lanes of a workgroup worked (184 us per launch).  Here a
 // chunk of 64 positions of x goes through LDS ([pos][K], loaded coalesced in either layout) and the threads are (channel, position
 // group): Kp = K + 1 rounded up to a power of two, 256 / Kp groups that split the chunk's positions, folded through LDS at the end.
-__global__ __launch_bounds__(256) void head1x1_wgrad_small_kernel(HeadArgs32 a, float* __restrict__ part, int ranges_per_sample, int Kp) {
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_wgrad_small_kernel(HeadArgsT<T> a, float* __restrict__ part, int ranges_per_sample, int Kp) {
   __shared__ float sdy[HD_MAXN][64];
   __shared__ __attribute__((aligned(16))) float sx[64 * 128];       // [pos][K], reused as the fold buffer [g][n][Kp]
   const int tid = threadIdx.x;
@@ -530,18 +537,18 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_small_kernel(HeadArgs32 a, 
   float acc[HD_MAXN];
 #pragma unroll
   for (int n = 0; n < HD_MAXN; ++n) acc[n] = 0.f;
-  const float* xb = a.x + b * a.xsb;
+  const T* xb = a.x + b * a.xsb;
   for (int c0 = 0; c0 < np; c0 += 64) {
     const int nc = np - c0 < 64 ? np - c0 : 64;
     for (int i = tid; i < a.N * 64; i += 256) {
       const int n = i >> 6, pp = i & 63;
-      sdy[n][pp] = pp < nc ? a.dy[((long)b * a.N + n) * a.P + p0 + c0 + pp] : 0.f;
+      sdy[n][pp] = pp < nc ? (float)a.dy[((long)b * a.N + n) * a.P + p0 + c0 + pp] : 0.f;
     }
     for (int i = tid; i < 64 * a.K; i += 256) {
       int pp, kk;
       if (a.xsk == 1) { pp = i / a.K; kk = i - pp * a.K; }
       else { kk = i >> 6; pp = i & 63; }
-      sx[pp * a.K + kk] = pp < nc ? xb[(p0 + c0 + pp) * a.xsp + kk * a.xsk] : 0.f;
+      sx[pp * a.K + kk] = pp < nc ? (float)xb[(p0 + c0 + pp) * a.xsp + kk * a.xsk] : 0.f;
     }
     __syncthreads();
     if (k <= a.K) {
@@ -683,30 +690,49 @@ extern "C" int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* wo
 // 1x1 convolution to N <= 8 channels.  x: element (b, p, k) at x[b * xsb + p * xsp + k * xsk] (token-major: xsp = K, xsk = 1; NCHW:
 // xsp = 1, xsk = P), y / dy: [B][N][P] contiguous, w [N][K], bias [N] or NULL; N * K <= 8 192.
 static int head1x1_ok(int B, int N, int K, long P) { return B >= 1 && N >= 1 && N <= nnz::HD_MAXN && K >= 1 && (long)N * K <= 8192 && P >= 1; }
-extern "C" int nnz_head1x1_forward_f32(const float* x, const float* w, const float* bias, float* y, int B, int N, int K, long P,
-                                       long xsb, long xsp, long xsk, void* stream) {
+template <typename T>
+static int head1x1_forward_t(const T* x, const float* w, const float* bias, T* y, int B, int N, int K, long P, long xsb, long xsp,
+                             long xsk, void* stream) {
   using namespace nnz;
   if (!x || !w || !y || !head1x1_ok(B, N, K, P)) return NNZ_EINVAL;
-  HeadArgs32 a = {};
+  HeadArgsT<T> a = {};
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.xsb = xsb; a.xsp = xsp; a.xsk = xsk; a.B = B; a.N = N; a.K = K; a.P = P;
   const long blocks = ((long)B * P + 255) / 256;
   if (blocks > 0x7fffffffL) return NNZ_EINVAL;
-  NNZ_LAUNCH(head1x1_fwd_kernel, dim3((unsigned)blocks), dim3(256), N * K * (int)sizeof(float), (hipStream_t)stream, a);
+  NNZ_LAUNCH(head1x1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), N * K * (int)sizeof(float), (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
 }
+extern "C" int nnz_head1x1_forward_f32(const float* x, const float* w, const float* bias, float* y, int B, int N, int K, long P,
+                                       long xsb, long xsp, long xsk, void* stream) {
+  return head1x1_forward_t<float>(x, w, bias, y, B, N, K, P, xsb, xsp, xsk, stream);
+}
+// the same with fp16 activations in and out (x, y: IEEE half), fp32 weights / bias / sums: the fuse convolution of an fp16-autocast
+// step (/root/reference/nnunetv2/nets/m2net.py:881 `outconv`)
+extern "C" int nnz_head1x1_forward_f16(const void* x, const float* w, const float* bias, void* y, int B, int N, int K, long P,
+                                       long xsb, long xsp, long xsk, void* stream) {
+  return head1x1_forward_t<_Float16>((const _Float16*)x, w, bias, (_Float16*)y, B, N, K, P, xsb, xsp, xsk, stream);
+}
 // dx in the layout of x (every element written)
-extern "C" int nnz_head1x1_dgrad_f32(const float* dy, const float* w, float* dx, int B, int N, int K, long P, long xsb, long xsp,
-                                     long xsk, void* stream) {
+template <typename T>
+static int head1x1_dgrad_t(const T* dy, const float* w, T* dx, int B, int N, int K, long P, long xsb, long xsp, long xsk, void* stream) {
   using namespace nnz;
   if (!dy || !w || !dx || !head1x1_ok(B, N, K, P)) return NNZ_EINVAL;
-  HeadArgs32 a = {};
+  HeadArgsT<T> a = {};
   a.dy = dy; a.w = w; a.y = dx; a.xsb = xsb; a.xsp = xsp; a.xsk = xsk; a.B = B; a.N = N; a.K = K; a.P = P;
   const long blocks = ((long)B * P * K + 255) / 256;
   if (blocks > 0x7fffffffL) return NNZ_EINVAL;
-  NNZ_LAUNCH(head1x1_dgrad_kernel, dim3((unsigned)blocks), dim3(256), N * K * (int)sizeof(float), (hipStream_t)stream, a);
+  NNZ_LAUNCH(head1x1_dgrad_kernel<T>, dim3((unsigned)blocks), dim3(256), N * K * (int)sizeof(float), (hipStream_t)stream, a);
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+extern "C" int nnz_head1x1_dgrad_f32(const float* dy, const float* w, float* dx, int B, int N, int K, long P, long xsb, long xsp,
+                                     long xsk, void* stream) {
+  return head1x1_dgrad_t<float>(dy, w, dx, B, N, K, P, xsb, xsp, xsk, stream);
+}
+extern "C" int nnz_head1x1_dgrad_f16(const void* dy, const float* w, void* dx, int B, int N, int K, long P, long xsb, long xsp,
+                                     long xsk, void* stream) {
+  return head1x1_dgrad_t<_Float16>((const _Float16*)dy, w, (_Float16*)dx, B, N, K, P, xsb, xsp, xsk, stream);
 }
 static int head1x1_range(int K) { return K + 1 <= 128 ? nnz::HD_TR : 64; }
 extern "C" long nnz_head1x1_wgrad_workspace_floats(int B, int N, int K, long P) {
@@ -716,11 +742,12 @@ extern "C" long nnz_head1x1_wgrad_workspace_floats(int B, int N, int K, long P) 
   return ranges * N * (K + 1) + nnz::fold_partials_scratch_floats((int)ranges, (long)N * (K + 1));
 }
 // dwb [N][K + 1] is WRITTEN: columns 0 .. K - 1 = dW, column K = db.  Deterministic.
-extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* workspace, float* dwb, int B, int N, int K, long P,
-                                     long xsb, long xsp, long xsk, void* stream) {
+template <typename T>
+static int head1x1_wgrad_t(const T* x, const T* dy, float* workspace, float* dwb, int B, int N, int K, long P, long xsb, long xsp,
+                           long xsk, void* stream) {
   using namespace nnz;
   if (!x || !dy || !workspace || !dwb || !head1x1_ok(B, N, K, P)) return NNZ_EINVAL;
-  HeadArgs32 a = {};
+  HeadArgsT<T> a = {};
   a.x = x; a.dy = dy; a.xsb = xsb; a.xsp = xsp; a.xsk = xsk; a.B = B; a.N = N; a.K = K; a.P = P;
   const int tr = head1x1_range(K);
   const int rps = (int)((P + tr - 1) / tr);
@@ -729,9 +756,9 @@ extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* wor
   if (K + 1 <= 128) {
     int Kp = 1;
     while (Kp < K + 1) Kp <<= 1;
-    NNZ_LAUNCH(head1x1_wgrad_small_kernel, dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, a, workspace, rps, Kp);
+    NNZ_LAUNCH(head1x1_wgrad_small_kernel<T>, dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, a, workspace, rps, Kp);
   } else {
-    NNZ_LAUNCH(head1x1_wgrad_kernel, dim3((unsigned)ranges, (K + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, workspace, rps, tr);
+    NNZ_LAUNCH(head1x1_wgrad_kernel<T>, dim3((unsigned)ranges, (K + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, workspace, rps, tr);
   }
   const long E = (long)N * (K + 1);
   float* scratch = fold_partials_scratch_floats((int)ranges, E) ? workspace + ranges * E : nullptr;
@@ -739,4 +766,13 @@ extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* wor
   if (e != hipSuccess) return (int)e;
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+extern "C" int nnz_head1x1_wgrad_f32(const float* x, const float* dy, float* workspace, float* dwb, int B, int N, int K, long P,
+                                     long xsb, long xsp, long xsk, void* stream) {
+  return head1x1_wgrad_t<float>(x, dy, workspace, dwb, B, N, K, P, xsb, xsp, xsk, stream);
+}
+// fp16 x / dy, fp32 partial sums and result (same workspace size)
+extern "C" int nnz_head1x1_wgrad_f16(const void* x, const void* dy, float* workspace, float* dwb, int B, int N, int K, long P,
+                                     long xsb, long xsp, long xsk, void* stream) {
+  return head1x1_wgrad_t<_Float16>((const _Float16*)x, (const _Float16*)dy, workspace, dwb, B, N, K, P, xsb, xsp, xsk, stream);
 }

@@ -272,6 +272,12 @@ class REBNCONV(nn.Module):
         self.relu_s1 = nn.ReLU(inplace=True)
 
     def forward(self, x):
+        from .. import rebnconv
+        if rebnconv.unit_ok(self, x):
+            # on its own (the `rebnconvin` of an MU stage): the same tap-table conv + batch-stat norm + ReLU kernels as inside an RSU4F;
+            # the result is an NCHW view of channels-last fp16 storage
+            _backends.note(self, "hip")
+            return rebnconv.unit_nchw(self, x)
         return self.relu_s1(self.bn_s1(self.conv_s1(x)))
 
 

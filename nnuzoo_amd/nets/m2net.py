@@ -212,10 +212,19 @@ class PatchEmbed2D(nn.Module):
         if isinstance(patch_size, int):
             patch_size = (patch_size, patch_size)
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.proj._nnz_fp32_master = patch_size == (1, 1)     # read as fp32 by the token kernels: no fp16 shadow (param_shadow.py)
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
     def forward(self, x):
-        x = self.proj(x).permute(0, 2, 3, 1)
+        from .. import sepconv32
+        xt = x.permute(0, 2, 3, 1)
+        if xt.is_contiguous() and sepconv32.pointwise_ok(self.proj, xt):
+            # patch size 1 (every MU stage of the X^2-Nets): a Linear over the channels of token-major activations - the fp32 MFMA
+            # Linear kernels on the rows as they lie (fp16 rows in / out under autocast), no layout copy, no library call
+            _backends.note(self.proj, "hip-f32")
+            x = sepconv32.pointwise_tokens(self.proj, xt)
+        else:
+            x = self.proj(x).permute(0, 2, 3, 1)
         return self.norm(x) if self.norm is not None else x
 
 
@@ -302,10 +311,14 @@ class VSSMDecoder(nn.Module):
                                    d_state=math.ceil(2 * skip / 6) if d_state is None else d_state,
                                    norm_layer=LayerNorm, downsample=None, use_checkpoint=False))
             segs.append(nn.Conv2d(skip, num_classes, 1, 1, 0, bias=True))
+            segs[-1]._nnz_fp32_master = True
             fuse.append(TokenLinear(2 * skip, skip))      # nn.Linear subclass: MFMA token kernels under fp16 autocast
         expands.append(PatchExpand(dim=chans[0], scale=patch_size, norm_layer=LayerNorm))
+        if isinstance(expands[-1].norm, LayerNorm):
+            expands[-1].norm.feeds_linear = True     # its only consumer is the 1x1 output convolution: fp16 rows straight from the kernel
         stages.append(nn.Identity())
         segs.append(nn.Conv2d(skip, num_classes, 1, 1, 0, bias=True))
+        segs[-1]._nnz_fp32_master = True
         self.stages = nn.ModuleList(stages)
         self.expand_layers = nn.ModuleList(expands)
         self.seg_layers = nn.ModuleList(segs)
@@ -322,14 +335,24 @@ class VSSMDecoder(nn.Module):
                 x = self.expand_layers[s](low)
             if s < last:
                 x = self.concat_back_dim[s](torch.cat((x, skips[-(s + 2)].permute(0, 2, 3, 1)), -1))
-            x = self.stages[s](x).permute(0, 3, 1, 2)
+            xt = self.stages[s](x)
+            x = xt.permute(0, 3, 1, 2)
             if self.deep_supervision:
-                outs.append(self.seg_layers[s](x))
+                outs.append(self._seg(self.seg_layers[s], xt, x))
             elif s == last:
-                outs.append(self.seg_layers[-1](x))
+                outs.append(self._seg(self.seg_layers[-1], xt, x))
             low = x
         outs = outs[::-1]
         return outs if self.deep_supervision else outs[0]
+
+    @staticmethod
+    def _seg(conv, tokens, nchw):
+        """the 1x1 output convolution of a stage, on the stage's token-major rows when the token kernels take them"""
+        from .. import sepconv32
+        if tokens.is_contiguous() and sepconv32.pointwise_ok(conv, tokens):
+            _backends.note(conv, "hip-f32")
+            return sepconv32.pointwise_tokens(conv, tokens).permute(0, 3, 1, 2)
+        return conv(nchw)
 
 
 class MU(nn.Module):
@@ -398,12 +421,21 @@ class _U2Forward:
     def _head(mod, x):
         """a side / fuse convolution: 1x1 convolutions to <= 8 channels of an fp32 device step (SwT2Net's) run on csrc/sepconv32.hip
         head1x1_* - straight off the token-major stage output, no layout copy, no library call; everything else is the module"""
-        from .. import sepconv32
+        from .. import rebnconv, sepconv32
         conv = getattr(mod, "conv", mod)
         if sepconv32.head1x1_ok(conv, x):
             _backends.note(mod, "hip-f32")
             return sepconv32.head1x1(conv, x)
+        if rebnconv.head3x3_ok(conv, x):
+            # 3x3 side head of an fp16-autocast step (m2net.py:874-880): one 32-channel block of the tap-table conv kernels
+            _backends.note(mod, "hip")
+            return rebnconv.head3x3(conv, x)
         return mod(x)
+
+    def _mark_heads(self):
+        """the side / fuse convolutions are read as fp32 master weights by the HIP head kernels: no fp16 shadow (param_shadow.py)"""
+        for name in ("side1", "side2", "side3", "side4", "side5", "side6", "outconv"):
+            getattr(self, name)._nnz_fp32_master = True
 
     def _encoder_groups(self):
         return [self.stage1, self.stage2, self.stage3, self.stage4, self.stage5, self.stage6, self.patch_merging1,
@@ -457,6 +489,7 @@ class M2Net(_U2Forward, nn.Module):
         for i, c in enumerate([32, 64, 128, 256, 512, 512], 1):
             setattr(self, f"side{i}", nn.Conv2d(c, out_ch, 3, padding=1))
         self.outconv = nn.Conv2d(6 * out_ch, out_ch, 1)
+        self._mark_heads()
 
     def _fuse(self, k, up_tokens, skip_nchw):
         lin = getattr(self, f"concat_back_dim{k}d")
@@ -494,6 +527,7 @@ class M2NetP(_U2Forward, nn.Module):
         for i, c in enumerate([128, 128, 128, 128, 128, 64], 1):
             setattr(self, f"side{i}", nn.Conv2d(c, out_ch, 3, padding=1))
         self.outconv = nn.Conv2d(6 * out_ch, out_ch, 1)
+        self._mark_heads()
 
     def _fuse(self, k, up_tokens, skip_nchw):
         return torch.cat([up_tokens.permute(0, 3, 1, 2), skip_nchw], 1)

@@ -57,6 +57,9 @@ def _eligible(network: nn.Module) -> Tuple[List[str], List[nn.Parameter]]:
              if isinstance(root, SSND) and root.spatial_dims == 2 and hasattr(root.convnd, "conv")}
     from .nets.u2net_multi import Convolution as _MonaiUnit
     skip |= {id(root.conv) for root in network.modules() if isinstance(root, _MonaiUnit) and root.hip_capable()}
+    # convolutions a net marked as read by hand-written kernels from the fp32 master (1x1 patch embeddings / stage outputs on the token
+    # Linear kernels, side / fuse heads: nets/m2net.py)
+    skip |= {id(m) for m in network.modules() if getattr(m, "_nnz_fp32_master", False)}
     names, params = [], []
     for mname, m in network.named_modules():
         if id(m) in skip or type(m) not in kinds:

@@ -50,6 +50,13 @@ def supported(conv: torch.nn.Conv2d, bn: torch.nn.Module) -> bool:
         and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.bias is not None
 
 
+# NNZ_REBNCONV_DET=0: the batch statistics and the backward reductions through fp32 atomics in the conv epilogue / reduce launch
+# (rounds 2-5: their value depends on the order the workgroups finish in - one fp16 ulp of difference in a unit's output from run to run
+# as soon as a map spans several workgroups, found by tools/probes/m2netp_repro_probe.py).  Default since round 6: the deterministic
+# statistics pass (fixed-point cross-workgroup sums, moments about a pilot value) over the batch as ONE instance of N * V voxels.
+DETERMINISTIC = os.environ.get("NNZ_REBNCONV_DET", "1") != "0"
+
+
 class _RebnConvFn(torch.autograd.Function):
     """x: (N, H, W, Cin) fp16 channels-last -> relu(bn(conv(x))): (N, H, W, Cout) fp16"""
 
@@ -62,15 +69,34 @@ class _RebnConvFn(torch.autograd.Function):
         fwd, dgrad, wgrad = _tables(N, H, W, cin, cout, dil)
         wp = ops.pack_weight(weight.detach(), fwd, cin, cout, 9, cin * 9, 1)
         raw = torch.empty((N, V, cout), dtype=torch.float16, device=dev)
-        stats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
-        ops.conv_tap_forward(fwd, x.view(N, V, cin), wp, bias.detach(), raw, stats=stats if training else None)
         n = N * V
-        if training:
+        det = DETERMINISTIC
+        stats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev) if training and not det else None
+        ops.conv_tap_forward(fwd, x.view(N, V, cin), wp, bias.detach(), raw, stats=stats)
+        fast_running = running_mean.dtype == torch.float32 and running_var.dtype == torch.float32 \
+            and running_mean.is_contiguous() and running_var.is_contiguous()
+        nstat = None
+        if training and det:
+            # one deterministic pass over the raw output: the norm table {mean, rstd, scale, shift} of the batch and its {sum, sumsq}
+            nstat = torch.empty((1, cout, 4), dtype=torch.float32, device=dev)
+            bstats = torch.empty((1, cout, 2), dtype=torch.float32, device=dev)
+            ops.instnorm_stats_det(raw, 1, n, cout, cout, ops.det_scratch(dev, 2 * cout), gamma.detach(), beta.detach(), float(eps),
+                                   nstat=nstat, sums=bstats)
+            if fast_running:
+                scratch_out = torch.empty((1, cout, 2), dtype=torch.float32, device=dev)
+                _call("nnz_bn_batch_stats_finish", _ptr(bstats), 1, cout, float(n), float(momentum), _ptr(scratch_out),
+                      _ptr(running_mean), _ptr(running_var), _stream_ptr())
+            else:
+                with torch.no_grad():
+                    mean = bstats[0, :, 0] / n
+                    var = (bstats[0, :, 1] / n - mean * mean).clamp_min_(0)
+                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        elif training:
             # batch statistics (one instance of N * V voxels) + the running estimates (F.batch_norm's update rule) in ONE
             # launch (csrc/norm_act.hip bn_stats_finish_kernel; ten element-wise launches per unit before: 24 units in M2Net)
             bstats = torch.empty((1, cout, 2), dtype=torch.float32, device=dev)
-            if running_mean.dtype == torch.float32 and running_var.dtype == torch.float32 \
-                    and running_mean.is_contiguous() and running_var.is_contiguous():
+            if fast_running:
                 _call("nnz_bn_batch_stats_finish", _ptr(stats), N, cout, float(n), float(momentum), _ptr(bstats),
                       _ptr(running_mean), _ptr(running_var), _stream_ptr())
             else:
@@ -84,15 +110,19 @@ class _RebnConvFn(torch.autograd.Function):
             rm, rv = running_mean.float(), running_var.float()
             bstats = torch.stack([rm * n, (rv + rm * rm) * n], dim=1).unsqueeze(0).contiguous()
         y = torch.empty((N, H, W, cout), dtype=torch.float16, device=dev)
-        ops.instnorm_lrelu_apply(raw, bstats, gamma.detach(), beta.detach(), y, 1, n, cout, cout, cout, float(eps), 0.0)
-        ctx.save_for_backward(x, weight, raw, bstats, gamma, beta)
-        ctx.cfg = (dil, float(eps), bool(training))
+        if nstat is not None:
+            ops.instnorm_lrelu_apply_tab(raw, nstat, y, 1, n, cout, cout, cout, 0.0)
+            ctx.save_for_backward(x, weight, raw, nstat, gamma, beta)
+        else:
+            ops.instnorm_lrelu_apply(raw, bstats, gamma.detach(), beta.detach(), y, 1, n, cout, cout, cout, float(eps), 0.0)
+            ctx.save_for_backward(x, weight, raw, bstats, gamma, beta)
+        ctx.cfg = (dil, float(eps), bool(training), nstat is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, raw, bstats, gamma, beta = ctx.saved_tensors
-        dil, eps, training = ctx.cfg
+        dil, eps, training, det = ctx.cfg
         if not training:
             raise RuntimeError("nnuzoo_amd REBNCONV: backward through eval-mode BatchNorm statistics is not supported")
         N, H, W, cin = x.shape
@@ -103,11 +133,16 @@ class _RebnConvFn(torch.autograd.Function):
         gy = gy.contiguous()
         if gy.dtype != torch.float16:
             gy = gy.to(torch.float16)
-        red = torch.zeros((1, cout, 2), dtype=torch.float32, device=dev)
         draw = torch.empty((N, V, cout), dtype=torch.float16, device=dev)
         dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
-        ops.instnorm_lrelu_bwd(raw, gy.view(N, V, cout), bstats, gamma.detach(), beta.detach(), red, draw, 1, n, cout,
-                               cout, cout, cout, eps, 0.0, pre_zeroed=True, dgamma=dgb[0], dbeta=dgb[1])
+        if det:     # bstats is the norm table here; reductions as fixed-point sums, dgamma / dbeta written by the last workgroup
+            nred = torch.empty((1, cout, 2), dtype=torch.float32, device=dev)
+            ops.instnorm_lrelu_bwd_tab(raw, gy.view(N, V, cout), bstats, ops.det_scratch(dev, 2 * cout), nred, draw, 1, n, cout, cout,
+                                       cout, cout, 0.0, dgamma=dgb[0], dbeta=dgb[1])
+        else:
+            red = torch.zeros((1, cout, 2), dtype=torch.float32, device=dev)
+            ops.instnorm_lrelu_bwd(raw, gy.view(N, V, cout), bstats, gamma.detach(), beta.detach(), red, draw, 1, n, cout,
+                                   cout, cout, cout, eps, 0.0, pre_zeroed=True, dgamma=dgb[0], dbeta=dgb[1])
         gw = torch.empty_like(weight, dtype=torch.float32)
         ws = torch.empty(ops.conv_tap_wgrad_workspace_floats(wgrad), dtype=torch.float32, device=dev)
         ops.conv_tap_wgrad_to_grad(wgrad, x.view(N, V, cin), draw, ws, gw, 9, cin * 9, 1)
@@ -157,3 +192,143 @@ def rsu4f_forward(rsu, x: torch.Tensor) -> torch.Tensor:
     d2 = rebnconv_cl(rsu.rebnconv2d, torch.cat((d3, e2), -1))
     d1 = rebnconv_cl(rsu.rebnconv1d, torch.cat((d2, e1), -1))
     return (d1 + xin).permute(0, 3, 1, 2)
+
+
+# ---- a REBNCONV on its own (the `rebnconvin` of every MU stage, m2net.py:447-449, 467-470) ---------------------------------------
+def unit_ok(mod, x: torch.Tensor) -> bool:
+    """one conv_s1 / bn_s1 unit outside an RSU4F, NCHW in: the same kernels; fewer than 32 input channels (the 1-channel network input
+    of stage 1) run zero-padded to 32"""
+    if not (USE_HIP and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.float16 and x.dtype in (torch.float16, torch.float32)):
+        return False
+    conv, bn = getattr(mod, "conv_s1", None), getattr(mod, "bn_s1", None)
+    if not (type(conv) is torch.nn.Conv2d and type(bn) is torch.nn.BatchNorm2d and conv.weight.dtype == torch.float32):
+        return False
+    cin = conv.in_channels
+    if not (supported(conv, bn) if cin % 32 == 0 else (cin < 32 and _supported_but_cin(conv, bn))):
+        return False
+    if not bn.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
+        return False
+    return True
+
+
+def _supported_but_cin(conv, bn) -> bool:
+    return type(bn) is torch.nn.BatchNorm2d and bn.affine and bn.track_running_stats and bn.momentum is not None \
+        and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 \
+        and conv.dilation[0] == conv.dilation[1] and conv.dilation[0] in (1, 2, 4, 8) \
+        and conv.padding == conv.dilation and conv.padding_mode == "zeros" \
+        and conv.out_channels % 32 == 0 and conv.bias is not None
+
+
+class _ToChannelsLastF16(torch.autograd.Function):
+    """NCHW (either type) -> channels-last fp16 with the channels zero-padded to `cpad`: ONE copy (two with padding)"""
+
+    @staticmethod
+    def forward(ctx, x, cpad):
+        N, C, H, W = x.shape
+        ctx.meta = (C, x.dtype)
+        xt = x.permute(0, 2, 3, 1)
+        if cpad == C:
+            return xt.to(torch.float16).contiguous()
+        out = torch.zeros((N, H, W, cpad), dtype=torch.float16, device=x.device)
+        out[..., :C].copy_(xt)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C, dt = ctx.meta
+        return g[..., :C].permute(0, 3, 1, 2).to(dt), None
+
+
+def unit_nchw(mod, x: torch.Tensor) -> torch.Tensor:
+    """REBNCONV.forward on the tap-table conv kernels: NCHW in, NCHW VIEW of channels-last fp16 storage out (what the patch embedding
+    behind it reads as tokens without a copy)"""
+    conv, bn = mod.conv_s1, mod.bn_s1
+    cin = conv.in_channels
+    cpad = (cin + 31) // 32 * 32
+    xc = _ToChannelsLastF16.apply(x, cpad)
+    w = conv.weight if cpad == cin else torch.nn.functional.pad(conv.weight, (0, 0, 0, 0, 0, cpad - cin))
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    y = _RebnConvFn.apply(xc, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.dilation[0], bn.eps,
+                          bn.momentum, bn.training)
+    return y.permute(0, 3, 1, 2)
+
+
+# ---- 3x3 side heads (m2net.py:874-880 `side1 .. side6`: Conv2d(C, classes, 3, padding=1)) ----------------------------------------
+# The tap-table conv kernels work on 32-channel output blocks; a head with <= 32 classes runs as ONE block whose unused rows of the
+# packed weight are zero - 2 of 32 MFMA columns useful, but these six launches are ~0.3 % of an M2Net step and with them no
+# convolution of the step reaches MIOpen (whose solver choice per process was the last source of run-to-run differences).
+HEAD_CPAD = 32
+_HEAD_PADS: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def head3x3_ok(conv, x: torch.Tensor) -> bool:
+    return USE_HIP and isinstance(conv, torch.nn.Conv2d) and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled() \
+        and torch.get_autocast_dtype("cuda") == torch.float16 and x.dtype in (torch.float16, torch.float32) \
+        and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) \
+        and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels <= HEAD_CPAD \
+        and conv.weight.dtype == torch.float32 and conv.bias is not None and conv.bias.dtype == torch.float32
+
+
+class _Head3x3Fn(torch.autograd.Function):
+    """y = conv3x3(x) + b for <= 32 output channels: x NCHW-logical fp16 / fp32, y NCHW fp16 (autocast's output type)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, cin, H, W = x.shape
+        cout = weight.shape[0]
+        V = H * W
+        dev = x.device
+        fwd, dgrad, wgrad = _tables(N, H, W, cin, HEAD_CPAD, 1)
+        xc = x.permute(0, 2, 3, 1)
+        xc = (xc if xc.dtype == torch.float16 else xc.to(torch.float16)).contiguous()
+        key = (dev.index, cin, cout)
+        pads = _HEAD_PADS.get(key)
+        if pads is None:
+            pads = (torch.zeros((HEAD_CPAD, cin, 3, 3), dtype=torch.float32, device=dev),
+                    torch.zeros(HEAD_CPAD, dtype=torch.float32, device=dev))
+            _HEAD_PADS[key] = pads
+        wpad, bpad = pads          # rows >= cout stay zero; rows < cout are rewritten by every call (shared between heads of one shape)
+        wpad[:cout].copy_(weight.detach())
+        bpad[:cout].copy_(bias.detach())
+        wp = ops.pack_weight(wpad, fwd, cin, HEAD_CPAD, 9, cin * 9, 1)
+        raw = torch.empty((N, V, HEAD_CPAD), dtype=torch.float16, device=dev)
+        ops.conv_tap_forward(fwd, xc.view(N, V, cin), wp, bpad, raw, stats=None)
+        ctx.save_for_backward(xc, weight)
+        ctx.xdtype = x.dtype
+        return raw.view(N, H, W, HEAD_CPAD)[..., :cout].permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, weight = ctx.saved_tensors
+        N, H, W, cin = xc.shape
+        cout = weight.shape[0]
+        V = H * W
+        dev = xc.device
+        fwd, dgrad, wgrad = _tables(N, H, W, cin, HEAD_CPAD, 1)
+        draw = torch.zeros((N, H, W, HEAD_CPAD), dtype=torch.float16, device=dev)
+        draw[..., :cout].copy_(gy.permute(0, 2, 3, 1))
+        draw = draw.view(N, V, HEAD_CPAD)
+        gw = gb = dx = None
+        if ctx.needs_input_grad[1]:
+            gwp = torch.empty((HEAD_CPAD, cin, 3, 3), dtype=torch.float32, device=dev)
+            ws = torch.empty(ops.conv_tap_wgrad_workspace_floats(wgrad), dtype=torch.float32, device=dev)
+            ops.conv_tap_wgrad_to_grad(wgrad, xc.view(N, V, cin), draw, ws, gwp, 9, cin * 9, 1)
+            gw = gwp[:cout].contiguous()
+        if ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3), dtype=torch.float32)
+        if ctx.needs_input_grad[0]:
+            wpad = _HEAD_PADS[(dev.index, cin, cout)][0]       # stream-ordered reuse: rows < cout rewritten, packed right away
+            wpad[:cout].copy_(weight.detach())
+            wpd = ops.pack_weight(wpad, dgrad, HEAD_CPAD, cin, cin * 9, 9, 1)
+            dxc = torch.empty((N, H, W, cin), dtype=torch.float16, device=dev)
+            ops.conv_tap_forward(dgrad, draw, wpd, None, dxc.view(N, V, cin))
+            dx = dxc.permute(0, 3, 1, 2)
+            if ctx.xdtype != torch.float16:
+                dx = dx.to(ctx.xdtype)
+        return dx, gw, gb
+
+
+def head3x3(conv, x: torch.Tensor) -> torch.Tensor:
+    return _Head3x3Fn.apply(x, conv.weight, conv.bias)

@@ -83,7 +83,7 @@ class _Pointwise1x1Fn(torch.autograd.Function):
         N, K = weight.shape[0], weight[0].numel()
         x2 = x.reshape(-1, K)
         T = x2.shape[0]
-        y = torch.empty((T, N), dtype=torch.float32, device=x.device)
+        y = torch.empty((T, N), dtype=x2.dtype, device=x.device)      # fp32, or fp16 rows in / fp16 rows out (autocast nets)
         _d32_forward(x2, weight, bias, y, None, T, K, N, 0)
         ctx.save_for_backward(x2, weight)
         ctx.params = (weight, bias)
@@ -98,15 +98,15 @@ class _Pointwise1x1Fn(torch.autograd.Function):
         N, K = weight.shape[0], weight[0].numel()
         T = x2.shape[0]
         dy2 = dy.reshape(-1, N)
-        if not dy2.is_contiguous():
-            dy2 = dy2.contiguous()
+        if not dy2.is_contiguous() or dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype).contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((T, K), dtype=torch.float32, device=dy.device)
+            dx = torch.empty((T, K), dtype=x2.dtype, device=dy.device)
             _d32_dgrad(dy2, weight.view(N, K), None, dx, T, K, N)
             dx = dx.view(ctx.xshape)
         need_w, need_b = ctx.needs_input_grad[1], bp is not None and ctx.needs_input_grad[2]
-        if need_w and bp is None and N <= 64 and K <= 64 and T >= SMALL_WGRAD_MIN_TOKENS:
+        if need_w and bp is None and N <= 64 and K <= 64 and T >= SMALL_WGRAD_MIN_TOKENS and x2.dtype == torch.float32:
             # few channels over very many tokens (stems / heads of the full-resolution stages): a streaming reduction on its own
             # kernel (csrc/sepconv32.hip pw_wgrad_small_kernel) - half-empty 64-wide MFMA tiles cost ~140 us per problem
             ws = torch.empty(int(_lib.load().nnz_pw_wgrad_small_workspace_floats(T, N, K)), dtype=torch.float32, device=dy.device)
@@ -118,6 +118,8 @@ class _Pointwise1x1Fn(torch.autograd.Function):
                     and not (bp is not None and _has_grad_hooks(bp)):
                 _DEFER["jobs"].append((dy2, x2, _Conv1x1Param(wp), bp if need_b else None))
                 return dx, None, None
+            if dy2.dtype == torch.float16:     # outside a deferred pass (module-level tests): the fp32 entry point on fp32 copies
+                dy2, x2 = dy2.float(), x2.float()
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             db = torch.empty(N, dtype=torch.float32, device=dy.device) if need_b else None
             ws = _d32_workspace(dy.device, int(_lib.load().nnz_dense32_wgrad_workspace_floats(T, K, N)))
@@ -219,6 +221,18 @@ def _fp32_device(x: torch.Tensor) -> bool:
     return USE_HIP and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
 
 
+def _h16_autocast(x: torch.Tensor) -> bool:
+    """a device tensor inside an fp16-autocast region (the step of the Mamba / U^2 nets): the kernels read fp16 activations (an fp32
+    tensor is rounded to fp16 first - what autocast does in front of its convolution) and the fp32 master weights, and write
+    autocast's output type"""
+    return USE_HIP and x.is_cuda and x.dtype in (torch.float16, torch.float32) and torch.is_autocast_enabled() \
+        and torch.get_autocast_dtype("cuda") == torch.float16
+
+
+def _h16(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float16) if x.dtype == torch.float32 and torch.is_autocast_enabled() else x
+
+
 def stem_ok(seq, x: torch.Tensor) -> bool:
     """get_dwconv_layer (depthwise 3x3 + pointwise 1x1, no norm) of a Swin U-net stage on a fp32 NCHW device tensor"""
     if not (_fp32_device(x) and x.dim() == 4 and isinstance(seq, torch.nn.Sequential) and len(seq) == 2):
@@ -253,14 +267,16 @@ def stem_forward(seq, x: torch.Tensor) -> torch.Tensor:
 
 
 def pointwise_ok(conv, x_tokens: torch.Tensor) -> bool:
-    """a 1x1 nn.Conv2d applied to token-major fp32 activations [B, H, W, K]"""
-    return _fp32_device(x_tokens) and x_tokens.dim() == 4 and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) \
-        and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.in_channels % 4 == 0 \
-        and conv.out_channels % 4 == 0 and conv.weight.dtype == torch.float32 and x_tokens.numel() // x_tokens.shape[-1] >= 64
+    """a 1x1 nn.Conv2d applied to token-major activations [B, H, W, K]: fp32 of a fp32 device step, or fp16 inside an fp16-autocast
+    region (fp16 rows in and out, the fp32 master weight as it is: csrc/dense32.hip *_h16)"""
+    return (_fp32_device(x_tokens) or _h16_autocast(x_tokens)) and x_tokens.dim() == 4 and isinstance(conv, torch.nn.Conv2d) \
+        and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 \
+        and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0 and conv.weight.dtype == torch.float32 \
+        and (conv.bias is None or conv.bias.dtype == torch.float32) and x_tokens.numel() // x_tokens.shape[-1] >= 64
 
 
 def pointwise_tokens(conv, x_tokens: torch.Tensor) -> torch.Tensor:
-    return _Pointwise1x1Fn.apply(x_tokens.contiguous(), conv.weight, conv.bias)
+    return _Pointwise1x1Fn.apply(_h16(x_tokens).contiguous(), conv.weight, conv.bias)
 
 
 def patch_embed_ok(conv, x_tokens: torch.Tensor) -> bool:
@@ -285,34 +301,37 @@ def _layout(x: torch.Tensor):
 
 
 class _Head1x1Fn(torch.autograd.Function):
-    """y = conv1x1(x) for a conv with <= 8 output channels; x NCHW-logical (either memory layout), y NCHW contiguous"""
+    """y = conv1x1(x) for a conv with <= 8 output channels; x NCHW-logical (either memory layout), y NCHW contiguous.  fp32 (SwT2Net's
+    device step) or fp16 activations with the fp32 master weights (the fuse convolution of the fp16-autocast nets: autocast's output
+    type, fp32 sums)"""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         B, K, H, W = x.shape
         N, P = weight.shape[0], H * W
         xs, xsb, xsp, xsk, tm = _layout(x)
-        y = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
-        call("nnz_head1x1_forward_f32", ptr(xs), ptr(weight), ptr(bias), ptr(y), B, N, K, P, xsb, xsp, xsk, stream_ptr())
+        sfx = "f16" if xs.dtype == torch.float16 else "f32"
+        y = torch.empty((B, N, H, W), dtype=xs.dtype, device=x.device)
+        call("nnz_head1x1_forward_" + sfx, ptr(xs), ptr(weight), ptr(bias), ptr(y), B, N, K, P, xsb, xsp, xsk, stream_ptr())
         ctx.save_for_backward(xs, weight)
-        ctx.meta = (B, N, K, H, W, xsb, xsp, xsk, tm, bias is not None)
+        ctx.meta = (B, N, K, H, W, xsb, xsp, xsk, tm, bias is not None, sfx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xs, weight = ctx.saved_tensors
-        B, N, K, H, W, xsb, xsp, xsk, tm, has_bias = ctx.meta
+        B, N, K, H, W, xsb, xsp, xsk, tm, has_bias, sfx = ctx.meta
         P = H * W
-        dy = dy.contiguous()
+        dy = dy.contiguous() if dy.dtype == xs.dtype else dy.to(xs.dtype).contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dxs = torch.empty_like(xs)
-            call("nnz_head1x1_dgrad_f32", ptr(dy), ptr(weight), ptr(dxs), B, N, K, P, xsb, xsp, xsk, stream_ptr())
+            call("nnz_head1x1_dgrad_" + sfx, ptr(dy), ptr(weight), ptr(dxs), B, N, K, P, xsb, xsp, xsk, stream_ptr())
             dx = dxs.permute(0, 3, 1, 2) if tm else dxs
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             ws = torch.empty(int(_lib.load().nnz_head1x1_wgrad_workspace_floats(B, N, K, P)), dtype=torch.float32, device=dy.device)
             dwb = torch.empty((N, K + 1), dtype=torch.float32, device=dy.device)
-            call("nnz_head1x1_wgrad_f32", ptr(xs), ptr(dy), ptr(ws), ptr(dwb), B, N, K, P, xsb, xsp, xsk, stream_ptr())
+            call("nnz_head1x1_wgrad_" + sfx, ptr(xs), ptr(dy), ptr(ws), ptr(dwb), B, N, K, P, xsb, xsp, xsk, stream_ptr())
             dw = dwb[:, :K].reshape(weight.shape)
             db = dwb[:, K].contiguous() if has_bias else None
         return dx, dw, db
@@ -322,10 +341,11 @@ USE_HEAD1X1 = os.environ.get("NNZ_HEAD1X1", "1") != "0"        # A/B switch
 
 
 def head1x1_ok(conv, x: torch.Tensor) -> bool:
-    return USE_HEAD1X1 and _fp32_device(x) and x.dim() == 4 and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) \
-        and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.out_channels <= 8 \
-        and conv.out_channels * conv.in_channels <= 8192 and conv.weight.dtype == torch.float32
+    return USE_HEAD1X1 and (_fp32_device(x) or _h16_autocast(x)) and x.dim() == 4 and isinstance(conv, torch.nn.Conv2d) \
+        and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 \
+        and conv.out_channels <= 8 and conv.out_channels * conv.in_channels <= 8192 and conv.weight.dtype == torch.float32 \
+        and (conv.bias is None or conv.bias.dtype == torch.float32)
 
 
 def head1x1(conv, x: torch.Tensor) -> torch.Tensor:
-    return _Head1x1Fn.apply(x, conv.weight, conv.bias)
+    return _Head1x1Fn.apply(_h16(x), conv.weight, conv.bias)

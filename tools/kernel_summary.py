@@ -24,6 +24,29 @@ def main():
     print(f"kernels {len(rows)}  busy {tot / 1e6:.2f} ms  span {span / 1e6:.2f} ms")
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print(f"{t / 1e6:9.3f} ms {n:6d} calls {t / n / 1e3:9.2f} us  {name[:110]}")
+    # every kernel that is NOT this package's (no `nnz` namespace in the name), by family - the whole list, not the top N:
+    # what a library (MIOpen / rocBLAS / hipBLASLt / CK) or ATen still contributes to the profiled steps
+    def family(name):
+        for key, fam in (("Cijk_", "rocBLAS / hipBLASLt (Cijk_*)"), ("igemm", "MIOpen igemm"), ("miopen", "MIOpen"),
+                         ("MIOpen", "MIOpen"), ("ck::", "composable_kernel"), ("Gridwise", "composable_kernel"),
+                         ("rccl", "RCCL"), ("nccl", "RCCL"), ("at::native", "ATen"), ("__amd_rocclr", "runtime copy / fill")):
+            if key in name:
+                return fam
+        return "other"
+    foreign = defaultdict(lambda: [0, 0, []])
+    for name, (n, t) in agg.items():
+        if "nnz" in name:
+            continue
+        f = foreign[family(name)]
+        f[0] += n
+        f[1] += t
+        f[2].append((t, n, name))
+    ftot = sum(v[1] for v in foreign.values())
+    print(f"kernels of other origin than this package: {ftot / 1e6:.3f} ms of {tot / 1e6:.2f} ms busy ({100.0 * ftot / max(tot, 1):.1f} %)")
+    for fam, (n, t, members) in sorted(foreign.items(), key=lambda kv: -kv[1][1]):
+        print(f"{t / 1e6:9.3f} ms {n:6d} calls  {fam}  ({len(members)} distinct)")
+        for mt, mn, name in sorted(members, reverse=True)[:6 if fam == "ATen" else 40]:
+            print(f"      {mt / 1e6:9.3f} ms {mn:6d} calls  {name[:100]}")
     # idle gaps between consecutive kernels (host-bound stretches): histogram + the kernels that follow the largest gaps
     gaps = []
     end = int(rows[0]["End_Timestamp"])
