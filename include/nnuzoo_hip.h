@@ -481,6 +481,13 @@ int nnz_head1x1_dgrad_f16(const void* dy, const float* w, void* dx, int B, int N
 int nnz_head1x1_wgrad_f16(const void* x, const void* dy, float* workspace, float* dwb, int B, int N, int K, long P, long xsb,
                           long xsp, long xsk, void* stream);
 
+/* ---- bilinear up-sampling of the side outputs and its adjoint (`_upsample_like`, /root/reference/nnunetv2/nets/m2net.py:33-36 =
+ * F.interpolate(src, size, mode='bilinear'), align_corners=False; called at :948-950 and in u2net.py / swt2net.py alike).
+ * src [B][h][w] -> dst [B][H][W], B = samples x channels, fp32 or IEEE half (is_f16), fp32 arithmetic, ATen's source-index rule.
+ * backward: din [B][h][w] is WRITTEN with the adjoint as a fixed-order gather (no atomics, no library GEMM). */
+int nnz_bilinear_up_forward(const void* src, void* dst, int is_f16, int B, int h, int w, int H, int W, void* stream);
+int nnz_bilinear_up_backward(const void* dout, void* din, int is_f16, int B, int h, int w, int H, int W, void* stream);
+
 /* ---- top / left zero padding of a channels-last fp32 map to the window multiple and the crop back (SwinTransformerBlock.forward,
  * swt2net.py:643-645 F.pad(x, (0, 0, ws - W % ws, 0, ws - H % ws, 0)) and :660 x[:, -H:, -W:, :]; each is the other's
  * backward).  small [B][H][W][C], big [B][H + py][W + px][C], C % 4 == 0, B * (H + py) <= 65535; one launch each. */

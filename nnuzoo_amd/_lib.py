@@ -210,6 +210,8 @@ SIGNATURES = {
     "nnz_head1x1_dgrad_f32": [_fp, _fp, _fp, _i, _i, _i, _l, _l, _l, _l, _vp],
     "nnz_head1x1_wgrad_workspace_floats": [_i, _i, _i, _l],
     "nnz_head1x1_wgrad_f32": [_fp, _fp, _fp, _fp, _i, _i, _i, _l, _l, _l, _l, _vp],
+    "nnz_bilinear_up_forward": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "nnz_bilinear_up_backward": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "nnz_head1x1_forward_f16": [_vp, _fp, _fp, _vp, _i, _i, _i, _l, _l, _l, _l, _vp],
     "nnz_head1x1_dgrad_f16": [_vp, _fp, _vp, _i, _i, _i, _l, _l, _l, _l, _vp],
     "nnz_head1x1_wgrad_f16": [_vp, _vp, _fp, _fp, _i, _i, _i, _l, _l, _l, _l, _vp],

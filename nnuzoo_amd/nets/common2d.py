@@ -237,20 +237,40 @@ def _interp_matrix(n_in: int, n_out: int, device) -> torch.Tensor:
     return _INTERP_MATRICES[key]
 
 
+USE_HIP_UPSAMPLE = os.environ.get("NNZ_UPSAMPLE_HIP", "1") != "0"      # A/B switch: 0 = torch forward + two-GEMM adjoint (rounds 2-5)
+
+
 class _BilinearUpFn(torch.autograd.Function):
-    """F.interpolate(bilinear, align_corners=False) with its backward written as the adjoint of the separable interpolation,
-    dIn = Wy^T dOut Wx (two small matmuls).  ATen's backward scatters every output pixel into its 4 sources with atomics:
-    for the 32x side outputs of the X^2-Nets that is 438 us per call on a 4 MB tensor (profiles/r02_m2net_graph_kernels.txt:
-    1.7 ms of the 101 ms M2Net step, the same in SwT2Net); the forward is torch's own (bit-identical values)."""
+    """F.interpolate(bilinear, align_corners=False) and its backward as the ADJOINT of the interpolation written as a gather
+    (csrc/upsample.hip: every input pixel sums the output pixels that read it, fixed order).  ATen's backward scatters every output
+    pixel into its 4 sources with atomics: for the 32x side outputs of the X^2-Nets that is 438 us per call on a 4 MB tensor
+    (profiles/r02_m2net_graph_kernels.txt: 1.7 ms of the 101 ms M2Net step, the same in SwT2Net).  Rounds 2-5: dIn = Wy^T dOut Wx as two
+    small library GEMMs behind torch's own forward - still available as NNZ_UPSAMPLE_HIP=0."""
 
     @staticmethod
     def forward(ctx, src, size):
-        ctx.meta = (tuple(src.shape[2:]), tuple(size), src.dtype)
-        return F.interpolate(src, size=size, mode='bilinear', align_corners=False)
+        hip = USE_HIP_UPSAMPLE and src.is_cuda and src.dtype in (torch.float16, torch.float32) and src.dim() == 4 \
+            and src.shape[0] * src.shape[1] <= 65535 and size[1] <= 16384
+        ctx.meta = (tuple(src.shape[2:]), tuple(size), src.dtype, hip)
+        if not hip:
+            return F.interpolate(src, size=size, mode='bilinear', align_corners=False)
+        from .._lib import call, ptr, stream_ptr
+        sc = src.contiguous()
+        N, Cc, h, w = sc.shape
+        out = torch.empty((N, Cc, size[0], size[1]), dtype=sc.dtype, device=sc.device)
+        call("nnz_bilinear_up_forward", ptr(sc), ptr(out), int(sc.dtype == torch.float16), N * Cc, h, w, size[0], size[1], stream_ptr())
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        (h, w), (H, W), dtype = ctx.meta
+        (h, w), (H, W), dtype, hip = ctx.meta
+        if hip:
+            from .._lib import call, ptr, stream_ptr
+            gc = (g if g.dtype == dtype else g.to(dtype)).contiguous()
+            N, Cc = gc.shape[:2]
+            gin = torch.empty((N, Cc, h, w), dtype=dtype, device=g.device)
+            call("nnz_bilinear_up_backward", ptr(gc), ptr(gin), int(dtype == torch.float16), N * Cc, h, w, H, W, stream_ptr())
+            return gin, None
         with torch.autocast("cuda", enabled=False):
             Wy, Wx = _interp_matrix(h, H, g.device), _interp_matrix(w, W, g.device)
             gin = torch.matmul(torch.matmul(Wy.t(), g.float()), Wx)
