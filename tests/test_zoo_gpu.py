@@ -340,8 +340,9 @@ def test_depthwise_wgrad_kernel_matches_float64(hip_lib, B, C, H, W, dil, half, 
 @pytest.mark.parametrize("shape,size", [((2, 2, 16, 16), (512, 512)), ((1, 3, 7, 12), (40, 31)), ((2, 5, 64, 64), (128, 128)),
                                         ((1, 2, 33, 20), (33, 20))])
 def test_upsample_like_adjoint_backward_equals_autograd(hip_lib, shape, size):
-    """common2d._upsample_like: forward = F.interpolate itself (bit-identical), backward = Wy^T g Wx; compared with autograd's
-    own backward of F.interpolate"""
+    """common2d._upsample_like: forward = csrc/upsample.hip with ATen's source-index rule and blend expression (equal to F.interpolate
+    up to the compiler's choice of fused multiply-adds: a few fp32 ulps), backward = the adjoint as a fixed-order gather; compared with
+    autograd's own backward of F.interpolate (more cases: tests/test_upsample_gpu.py)"""
     from nnuzoo_amd.nets.common2d import _upsample_like
     torch.manual_seed(1)
     x = torch.randn(*shape, device="cuda", requires_grad=True)
@@ -349,7 +350,7 @@ def test_upsample_like_adjoint_backward_equals_autograd(hip_lib, shape, size):
     y = _upsample_like(x, size)
     assert type(y.grad_fn).__name__.startswith("_BilinearUpFn")
     ref = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
-    assert torch.equal(y, ref)
+    assert (y - ref).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
     (gx,) = torch.autograd.grad(y, x, g)
     (gr,) = torch.autograd.grad(ref, x, g)
     close(gx, gr.cpu(), "dx", rtol=2e-5)
