@@ -41,6 +41,12 @@ class Tap(TorchDispatchMode):
                 if "nnuzoo_amd/" in fr.filename and "probes" not in fr.filename:
                     site = f"{fr.filename.split('nnuzoo_amd/')[-1]}:{fr.lineno} {fr.name}"
                     break
+            if os.environ.get("NNZ_PROBE_SHAPES") == "1" and site.startswith("(autograd"):
+                t = next((a for a in args if torch.is_tensor(a)), None)
+                if t is None and args and isinstance(args[0], (list, tuple)) and args[0] and torch.is_tensor(args[0][0]):
+                    t = args[0][0]
+                if t is not None:
+                    site = f"engine {str(t.dtype).replace('torch.', '')} {tuple(t.shape)} contiguous={t.is_contiguous()}"
             cnt[(name, site)] += 1
         return func(*args, **(kwargs or {}))
 
@@ -48,5 +54,5 @@ class Tap(TorchDispatchMode):
 with Tap():
     tr.train_step(b)
     torch.cuda.synchronize()
-for (op, site), n in cnt.most_common(70):
+for (op, site), n in cnt.most_common(70 if os.environ.get("NNZ_PROBE_SHAPES") != "1" else 200):
     print(f"{n:5d}  {op:14s} {site}")
