@@ -14,15 +14,16 @@ for line in open(os.path.join(src, "r06_zoo_bench.txt")):
     if line.startswith("{"):
         z = json.loads(line)
         zoo.append(f"{z['model']} {z['patches_per_s']:.1f}")
-text = f"""Round-6 numbers (`profiles/r06_bench_n1.json`, `profiles/README.md`; round 5 in brackets - other boxes: this round's boxes ran the unchanged
-kernels ~1.5 % slower than round 5's, e.g. 158.4 - 158.8 patches/s for the round-5 conv order): primary **{j['value']:.1f} patches/s** ({j['ms_per_step']:.2f} ms per
+text = f"""Round-6 numbers (`profiles/r06_bench_n1.json`, `profiles/README.md`; round 5 in brackets - other boxes: boxes differ by ~±1.5 % for the unchanged
+primary kernels, e.g. 158.4 - 158.8 patches/s for the round-5 conv order on this round's first boxes): primary **{j['value']:.1f} patches/s** ({j['ms_per_step']:.2f} ms per
 step; 161.6), conv_box **{r['frac']:.3f}** of the f16 MFMA peak ({r['avg_launch_us']:.1f} us average launch, {r['ms_per_step']:.2f} ms per step; 0.233), traffic {r['traffic'] / 1e6:.0f} MB per
 launch (265); `cpu_baseline` {j['cpu_baseline']['value']:.3f} patches/s; `dice` HIP {j['dice']['hip']:.5f} vs oracle {j['dice']['oracle']:.5f} (masks {100 * j['dice']['mask_agreement']:.3f} %); `h2d_inclusive` {j['h2d_inclusive']['value']:.1f}.
 `secondary` (M2Net) **{s['value']:.1f} patches/s** ({s['ms_per_step']:.1f} ms; 26.4), cross-scan backward {s['roofline']['frac']:.3f} of HBM, `dice` {s['dice']['hip']:.4f} vs {s['dice']['cpu_oracle']:.4f};
 `swt2net` **{w['value']:.1f} patches/s** ({w['ms_per_step']:.1f} ms; 35.4), window attention {w['roofline']['frac']:.3f} of the fp32 MFMA peak (forward {w['roofline']['fwd_avg_launch_us']:.1f}, backward {w['roofline']['bwd_avg_launch_us']:.1f} us average
 launch).  Zoo (`profiles/r06_zoo_bench.txt`, 512^2, batch 2, graph replay, patches/s): {', '.join(zoo)}.
-The step times of the two zoo legs no longer depend on MIOpen's solver choice for the RSU4F stages (SwT2Net) - what is left on the
-library there is the two small matmuls of the bilinear up-sampling's backward.
+Neither zoo leg runs a library convolution or GEMM any more (`profiles/r06_m2net_graph_kernels.txt` and `r06_swt2net_graph_kernels.txt` list every kernel of
+other origin: ATen element-wise / concatenation kernels and runtime copies only), so their step times no longer depend on MIOpen's
+solver choice per process.
 """
 p = os.path.join(ROOT, "DESIGN.md")
 d = open(p).read()
