@@ -598,10 +598,11 @@ int nnz_layer_norm_gate_backward_det(const void* x, int x_is_f16, const float* g
                                      int z_is_f16, long z_row_stride, const float* mean, const float* rstd,
                                      const void* dy, int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta,
                                      void* acc, void* counter, long rows, int C, void* stream);
-/* nnz_layer_norm_backward_det with dx = dres + (LayerNorm backward): dres [rows][C] f32 is the gradient arriving on the
- * residual stream x that the block also normalised (x + f(LayerNorm(x)), swt2net.py:646-659); NULL = the plain backward. */
+/* nnz_layer_norm_backward_det with dx = dres + (LayerNorm backward): dres [rows][C], of the type of x / dx, is the gradient
+ * arriving on the residual stream x that the block also normalised (x + f(LayerNorm(x)), swt2net.py:646-659, m2net.py:530);
+ * NULL = the plain backward. */
 int nnz_layer_norm_backward_det_res(const void* x, int x_is_f16, const float* gamma, const float* mean, const float* rstd,
-                                    const void* dy, int dy_is_f16, const float* dres, void* dx, float* dgamma,
+                                    const void* dy, int dy_is_f16, const void* dres, void* dx, float* dgamma,
                                     float* dbeta, void* acc, void* counter, long rows, int C, void* stream);
 
 /* ---- global (ViT) multi-head self-attention core, fp32 MFMA, flash-style (csrc/global_attention.hip, round 3) -----------

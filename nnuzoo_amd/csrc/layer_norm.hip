@@ -18,7 +18,7 @@ struct LnArgs {
   float* rstd;        // [R]
   const void* dy;     // [R][C] f32 or f16 (dy_is_f16)
   void* dx;           // [R][C] same type as x
-  const float* dres;  // backward, optional: [R][C] f32 gradient of the residual stream the normalised tensor was taken from -
+  const void* dres;   // backward, optional: [R][C] gradient (type of x) of the residual stream the normalised tensor was taken from -
                       // dx = dres + (LayerNorm backward), the sum autograd would make with an add launch of its own
   float* dgamma;      // [C] atomic, zeroed by the launcher; may be null
   float* dbeta;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
         if (a.dres) {
-          const f32x4 sk = ld4(a.dres + sr * C + c);
+          const f32x4 sk = ld4((const T*)a.dres + sr * C + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = sk[e] + o[e];
         }
@@ -314,7 +314,7 @@ static int ln_backward_impl(const void* x, int x_is_f16, const float* gamma, con
                             int z_is_f16, long z_stride, const float* mean, const float* rstd, const void* dy,
                             int dy_is_f16, void* dx, void* dz, float* dgamma, float* dbeta, int pre_zeroed, long rows,
                             int C, void* stream, void* acc = nullptr, void* counter = nullptr,
-                            const float* dres = nullptr) {
+                            const void* dres = nullptr) {
   using namespace nnz;
   if (acc) pre_zeroed = 1;   // dgamma / dbeta are written, not accumulated
   if (!x || !mean || !rstd || !dy || !dx || rows < 0 || C < 4 || (C & 3) || C > 2048 || (z && (!dz || (z_stride & 3))))
@@ -388,11 +388,11 @@ extern "C" int nnz_layer_norm_gate_backward_det(const void* x, int x_is_f16, con
                           dbeta, 1, rows, C, stream, acc, counter);
 }
 
-// nnz_layer_norm_backward_det with the residual stream's gradient added into dx (dres: [rows][C] f32, may alias nothing
+// nnz_layer_norm_backward_det with the residual stream's gradient added into dx (dres: [rows][C] of x's type, may alias nothing
 // else; null = the plain backward): x -> (LayerNorm(x), x) is how every Swin / VSS block uses its norm, and the two
 // gradients of x meet here instead of in an add launch
 extern "C" int nnz_layer_norm_backward_det_res(const void* x, int x_is_f16, const float* gamma, const float* mean,
-                                               const float* rstd, const void* dy, int dy_is_f16, const float* dres,
+                                               const float* rstd, const void* dy, int dy_is_f16, const void* dres,
                                                void* dx, float* dgamma, float* dbeta, void* acc, void* counter,
                                                long rows, int C, void* stream) {
   if (!acc || !counter) return NNZ_EINVAL;

@@ -64,20 +64,22 @@ class _LayerNormFn(torch.autograd.Function):
 
 
 class _LayerNormSkipFn(torch.autograd.Function):
-    """x -> (LayerNorm(x), x) for the pre-norm residual blocks (x + f(norm(x)): swt2net.py:646-659).  The second output is x
-    itself; taking the residual stream from it instead of from the caller's x brings both gradients of x into ONE backward
-    call, where the kernel adds them (nnz_layer_norm_backward_det_res) - autograd's accumulation is an add launch per norm,
-    288 per SwT2Net step.  fp32 contiguous device tensors only."""
+    """x -> (LayerNorm(x), x) for the pre-norm residual blocks (x + f(norm(x)): swt2net.py:646-659, m2net.py:530).  The second
+    output is x itself; taking the residual stream from it instead of from the caller's x brings both gradients of x into ONE
+    backward call, where the kernel adds them (nnz_layer_norm_backward_det_res) - autograd's accumulation is an add launch per
+    norm, 288 per SwT2Net step, 80 per M2Net step.  fp32 or fp16 contiguous device tensors; `half_out`: fp16 rows for an autocast
+    Linear (LayerNorm.feeds_linear)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, half_out):
         C = x.shape[-1]
         rows = x.numel() // C
-        y = torch.empty_like(x)
+        xh = int(x.dtype == torch.float16)
+        y = torch.empty(x.shape, dtype=torch.float16 if half_out else torch.float32, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        call("nnz_layer_norm_forward", ptr(x), 0, ptr(weight), ptr(bias), ptr(y), 0, ptr(mean), ptr(rstd), None, rows, C,
-             float(eps), stream_ptr())
+        call("nnz_layer_norm_forward", ptr(x), xh, ptr(weight), ptr(bias), ptr(y), int(half_out), ptr(mean), ptr(rstd), None, rows,
+             C, float(eps), stream_ptr())
         ctx.save_for_backward(x, weight, mean, rstd)
         ctx.has_bias = bias is not None
         ctx.set_materialize_grads(False)
@@ -86,34 +88,37 @@ class _LayerNormSkipFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dskip):
         if dy is None:
-            return dskip, None, None, None
+            return dskip, None, None, None, None
         x, weight, mean, rstd = ctx.saved_tensors
         C = x.shape[-1]
         rows = x.numel() // C
         dy = _dy(dy)
-        if dskip is not None and (dskip.dtype != torch.float32 or not dskip.is_contiguous()):
-            dskip = dskip.float().contiguous()
+        if dskip is not None and (dskip.dtype != x.dtype or not dskip.is_contiguous()):
+            dskip = dskip.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
         dw, db, _ = _affine_grads(weight, ctx.has_bias, ctx.needs_input_grad[1], ctx.needs_input_grad[2], C, x.device)
         from .hip_ops import det_scratch
         sc = det_scratch(x.device, 2 * C)
-        call("nnz_layer_norm_backward_det_res", ptr(x), 0, ptr(weight), ptr(mean), ptr(rstd), ptr(dy),
+        call("nnz_layer_norm_backward_det_res", ptr(x), int(x.dtype == torch.float16), ptr(weight), ptr(mean), ptr(rstd), ptr(dy),
              int(dy.dtype == torch.float16), ptr(dskip), ptr(dx), ptr(dw), ptr(db), ptr(sc.acc), ptr(sc.counter), rows, C,
              stream_ptr())
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def layer_norm_skip(norm: "nn.LayerNorm", x: torch.Tensor):
     """(norm(x), x) with the two gradients of x summed inside the LayerNorm backward kernel; falls back to (norm(x), x) when
-    the tensor is not an fp32 contiguous device tensor the kernel takes"""
+    the tensor is not a contiguous fp32 / fp16 device tensor the kernel takes.  Output type as `layer_norm`: fp32, or fp16 rows
+    under fp16 autocast when the norm feeds an autocast Linear (`feeds_linear`)."""
     C = x.shape[-1]
-    ok = isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and x.is_cuda and x.dtype == torch.float32 \
-        and x.is_contiguous() and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == C \
-        and C % 4 == 0 and C <= 2048 and not torch.is_autocast_enabled() and torch.is_grad_enabled() and x.requires_grad \
-        and (norm.weight is None or norm.weight.dtype == torch.float32)
+    ac = torch.is_autocast_enabled()
+    ok = isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and x.is_cuda and x.is_contiguous() \
+        and (x.dtype == torch.float32 or (x.dtype == torch.float16 and ac)) \
+        and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == C \
+        and C % 4 == 0 and C <= 2048 and torch.is_grad_enabled() and x.requires_grad \
+        and (norm.weight is None or norm.weight.dtype == torch.float32) and _LN_DET
     if not ok:
         return norm(x), x
-    return _LayerNormSkipFn.apply(x, norm.weight, norm.bias, norm.eps)
+    return _LayerNormSkipFn.apply(x, norm.weight, norm.bias, norm.eps, _half_for_linear(getattr(norm, "feeds_linear", False)))
 
 
 def _affine_grads(weight, has_bias, need_w, need_b, C, device, prezeroed=None):

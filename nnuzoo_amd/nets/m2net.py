@@ -28,7 +28,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..token_linear import TokenLinear
-from ..layer_norm import LayerNorm, layer_norm_gate
+from ..layer_norm import LayerNorm, layer_norm_gate, layer_norm_skip
 
 from .. import ss2d_scan
 from ..selective_scan import selective_scan_fn
@@ -177,7 +177,10 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, input: torch.Tensor):
-        return residual_drop_path(input, self.self_attention(self.ln_1(input)), self.drop_path)
+        # (ln_1(input), input): the residual stream is taken from the norm's second output so that both gradients of `input` meet
+        # inside the LayerNorm backward kernel instead of in an add launch of the autograd engine (80 per M2Net step)
+        y, skip = layer_norm_skip(self.ln_1, input)
+        return residual_drop_path(skip, self.self_attention(y), self.drop_path)
 
 
 class VSSLayer(nn.Module):

@@ -182,3 +182,40 @@ def test_layer_norm_skip_sums_both_gradients_in_the_kernel(hip_lib, shape):
     x2 = x0.clone().requires_grad_(True)
     (g3,) = torch.autograd.grad(norm(x2 * 1.0), x2, dout)
     assert torch.equal(g2, g3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,feeds", [((2, 16, 16, 32), True), ((2, 64, 64, 16), True), ((2, 32, 32, 256), False), ((2, 128, 128, 16), True)])
+@pytest.mark.parametrize("xdtype", [torch.float16, torch.float32])
+def test_layer_norm_skip_under_fp16_autocast(hip_lib, shape, feeds, xdtype):
+    """the VSS block's use (m2net.py:530 `input + drop_path(self_attention(ln_1(input)))`): an fp16 or fp32 residual stream inside an
+    fp16-autocast region, fp16 rows out when the norm feeds an autocast Linear.  Against the un-fused form (the plain module + autograd's
+    own add): identical forward bits; dx to the rounding of the stream's type (the fused sum is formed in fp32 and rounded once)."""
+    from nnuzoo_amd.layer_norm import LayerNorm, layer_norm_skip
+    torch.manual_seed(1)
+    C = shape[-1]
+    norm = LayerNorm(C).cuda()
+    norm.feeds_linear = feeds
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x0 = torch.randn(*shape, device="cuda").to(xdtype)
+    w = (torch.randn(C, C, device="cuda") / C ** 0.5)
+    dout = torch.randn(*shape, device="cuda").to(xdtype)
+    res = []
+    with torch.autocast("cuda", dtype=torch.float16):
+        for fused in (True, False):
+            x = x0.clone().requires_grad_(True)
+            h = x * 1.0
+            n, s = layer_norm_skip(norm, h) if fused else (norm(h), h)
+            if fused:
+                assert type(n.grad_fn).__name__.startswith("_LayerNormSkipFn")
+            assert n.dtype == (torch.float16 if feeds else torch.float32)
+            out = s + torch.tanh(torch.nn.functional.linear(n, w)).to(s.dtype)
+            gx, gw, gb = torch.autograd.grad(out, [x, norm.weight, norm.bias], dout)
+            res.append((out.detach(), gx, gw, gb))
+    assert torch.equal(res[0][0], res[1][0])
+    eps = 2.0 ** -10 if xdtype == torch.float16 else 1e-6
+    for u, v, name in zip(res[0][1:], res[1][1:], ("dx", "dgamma", "dbeta")):
+        tol = (2 * eps if name == "dx" else 1e-5) * max(1.0, v.float().abs().max().item())
+        assert (u.float() - v.float()).abs().max().item() <= tol, (name, (u.float() - v.float()).abs().max().item())
