@@ -288,7 +288,8 @@ class _Head3x3Fn(torch.autograd.Function):
         if pads is None:
             pads = (torch.zeros((HEAD_CPAD, cin, 3, 3), dtype=torch.float32, device=dev),
                     torch.zeros(HEAD_CPAD, dtype=torch.float32, device=dev))
-            _HEAD_PADS[key] = pads
+            if not torch.cuda.is_current_stream_capturing():     # a buffer from a graph's private pool must not outlive into eager code
+                _HEAD_PADS[key] = pads
         wpad, bpad = pads          # rows >= cout stay zero; rows < cout are rewritten by every call (shared between heads of one shape)
         wpad[:cout].copy_(weight.detach())
         bpad[:cout].copy_(bias.detach())
@@ -319,7 +320,8 @@ class _Head3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32)
         if ctx.needs_input_grad[0]:
-            wpad = _HEAD_PADS[(dev.index, cin, cout)][0]       # stream-ordered reuse: rows < cout rewritten, packed right away
+            pads = _HEAD_PADS.get((dev.index, cin, cout))      # stream-ordered reuse: rows < cout rewritten, packed right away
+            wpad = pads[0] if pads is not None else torch.zeros((HEAD_CPAD, cin, 3, 3), dtype=torch.float32, device=dev)
             wpad[:cout].copy_(weight.detach())
             wpd = ops.pack_weight(wpad, dgrad, HEAD_CPAD, cin, cin * 9, 9, 1)
             dxc = torch.empty((N, H, W, cin), dtype=torch.float16, device=dev)
