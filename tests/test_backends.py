@@ -45,6 +45,9 @@ def test_m2net_bench_configuration_runs_on_hip(hip_lib):
     tr = _step(nnUNetTrainerM2Net, size=512)
     rep = bk.assert_hip(tr.network, allow=("TokenLinear",))
     assert rep["SS2D"] == {"hip": 80} and rep["RSU4F"] == {"hip": 3}
+    # round 6: the eight MU stems (REBNCONV on its own) and the six 3x3 side heads on the tap-table conv kernels; the eight 1x1 patch
+    # embeddings, the eight 1x1 stage outputs and the fuse convolution on the fp32 MFMA Linear / head1x1 kernels with fp16 activations
+    assert rep["REBNCONV"] == {"hip": 8} and rep["Conv2d"] == {"hip-f32": 17, "hip": 6}, rep
     # 272 Linear layers: the ones on the fp16 token-major MFMA kernel carry the work (measured 175); the deep levels of the inner
     # U structures (fewer than 1024 tokens) and the feature counts that kernel does not take (512 / 1024-wide bottlenecks) run on
     # the fp32 MFMA kernels since round 5 (97, were on the GEMM library); only feature counts that are not multiples of 4 (none
