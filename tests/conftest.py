@@ -60,6 +60,8 @@ _TIER_BY_FILE = {
 _TIER_BY_NAME = {
     "test_ssnd2net_training_descends_once_the_loss_scale_has_settled": 2,
     "test_ssnd2net_fp32_step_applies_its_updates_at_a_gradient_norm_of_1e9": 2,
+    "test_m2net_steps_call_no_torch_convolution_or_batchnorm_module": 1, "test_side_head_3x3_repeats_bit_for_bit": 1,
+    "test_adjoint_identity_and_repeatability": 1,
 }
 
 
