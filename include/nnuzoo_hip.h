@@ -459,6 +459,12 @@ int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, const float* 
  * reduction, VALU 4 x 4 register blocks from LDS-staged token chunks).  dW is written; per-range partials + fixed-order folds. */
 long nnz_pw_wgrad_small_workspace_floats(long T, int N, int K);
 int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* workspace, float* dW, long T, int N, int K, void* stream);
+/* the same for fp32 or IEEE-half token rows (is_f16: the 1x1 patch embeddings / stage outputs of the fp16-autocast X^2-Nets,
+ * m2net.py:486-512 `PatchEmbed2D.proj`, :431-473 `seg_layers`) and, db != NULL, the bias gradient db [N] = sum_t dy[t] from the same
+ * pass; workspace: nnz_pw_wgrad_small_workspace_floats_b(T, N, K, db != NULL) floats.  dW / db are written; fixed-order folds. */
+long nnz_pw_wgrad_small_workspace_floats_b(long T, int N, int K, int with_bias);
+int nnz_pw_wgrad_small(const void* dy, const void* x, int is_f16, float* workspace, float* dW, float* db, long T, int N, int K,
+                       void* stream);
 
 /* 1x1 convolution to N <= 8 output channels in fp32: the side heads (`side1 .. side6`, C -> classes) and the fuse convolution
  * (`outconv`, 6 classes -> classes) of SwT2Net, /root/reference/nnunetv2/nets/swt2net.py:1021-1028, 1130-1141.  y / dy [B][N][P]

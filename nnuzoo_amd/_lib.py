@@ -206,6 +206,8 @@ SIGNATURES = {
     "nnz_bn_relu_nhwc_backward_f32": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _vp],
     "nnz_pw_wgrad_small_workspace_floats": [_l, _i, _i],
     "nnz_pw_wgrad_small_f32": [_fp, _fp, _fp, _fp, _l, _i, _i, _vp],
+    "nnz_pw_wgrad_small_workspace_floats_b": [_l, _i, _i, _i],
+    "nnz_pw_wgrad_small": [_vp, _vp, _i, _fp, _fp, _fp, _l, _i, _i, _vp],
     "nnz_head1x1_forward_f32": [_fp, _fp, _fp, _fp, _i, _i, _i, _l, _l, _l, _l, _vp],
     "nnz_head1x1_dgrad_f32": [_fp, _fp, _fp, _i, _i, _i, _l, _l, _l, _l, _vp],
     "nnz_head1x1_wgrad_workspace_floats": [_i, _i, _i, _l],
@@ -255,7 +257,7 @@ _LONG_RESULT = {"nnz_aug_stats_workspace_floats", "nnz_ss2d_scan_state_floats", 
                 "nnz_window_attention_backward_parts",
                 "nnz_ss2d_xproj_backward_w_workspace_floats", "nnz_ss2d_dwconv_silu_backward_workspace_floats",
                 "nnz_dw3x3_nhwc_wgrad_workspace_floats", "nnz_pw_wgrad_small_workspace_floats",
-                "nnz_head1x1_wgrad_workspace_floats"}
+                "nnz_head1x1_wgrad_workspace_floats", "nnz_pw_wgrad_small_workspace_floats_b"}
 _lib = None
 
 

@@ -330,7 +330,19 @@ __global__ __launch_bounds__(256) void bn_relu_nhwc_bwd_kernel(BnArgs32 a) {
 // 16-byte loads), a thread owns a 4 x 4 block of dW and a share of the 64 tokens (256 / (N K / 16) shares); shares fold through LDS
 // in a fixed order, ranges through fold_partials(): deterministic.
 constexpr int PW_TR = 1024;   // tokens per workgroup
-__global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// TA = float, or _Float16 rows of an fp16-autocast step (converted while staged; the sums are fp32 either way); BIAS: the partials
+// carry N more floats behind the N x K block - db[n] = sum_t dy[t][n], summed by the threads that own a tile's first column block.
+template <typename TA>
+__device__ __forceinline__ f32x4 pw_ld4(const TA* p);
+template <>
+__device__ __forceinline__ f32x4 pw_ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 pw_ld4<_Float16>(const _Float16* p) {
+  const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <typename TA, bool BIAS>
+__global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const TA* __restrict__ dy, const TA* __restrict__ x,
                                                              float* __restrict__ part, long T, int N, int K, int shares) {
   __shared__ __attribute__((aligned(16))) float sD[64 * 64];
   __shared__ __attribute__((aligned(16))) float sX[64 * 64];
@@ -346,6 +358,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool bias_owner = BIAS && k0 == 0;
+  const long E = (long)N * K + (BIAS ? N : 0);
   const int n4 = N >> 2, k4 = K >> 2;
   // the next chunk's pieces are requested BEFORE the current chunk's products (register double buffer): without it every chunk
   // exposed a full memory round trip between its two barriers (16 per workgroup: ~100 us per launch where the bytes take 30)
@@ -358,9 +373,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
     for (int j = 0; j < PCS; ++j) {
       const int i = tid + 256 * j;
       const int ttd = i / n4, qd = i - ttd * n4;
-      rd[j] = (i < 64 * n4 && ttd < nt) ? *reinterpret_cast<const f32x4*>(dy + (tc + ttd) * N + 4 * qd) : z4;
+      rd[j] = (i < 64 * n4 && ttd < nt) ? pw_ld4<TA>(dy + (tc + ttd) * N + 4 * qd) : z4;
       const int ttx = i / k4, qx = i - ttx * k4;
-      rx[j] = (i < 64 * k4 && ttx < nt) ? *reinterpret_cast<const f32x4*>(x + (tc + ttx) * K + 4 * qx) : z4;
+      rx[j] = (i < 64 * k4 && ttx < nt) ? pw_ld4<TA>(x + (tc + ttx) * K + 4 * qx) : z4;
     }
   };
   if (t0 < t1) fetch(t0);
@@ -381,6 +396,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] += d[i] * v[j];
+        if (bias_owner) bsum += d;
       }
     }
     __syncthreads();
@@ -391,6 +407,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       *reinterpret_cast<f32x4*>(sD + (sp * tiles + tile) * 16 + 4 * i) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    if (bias_owner) *reinterpret_cast<f32x4*>(sX + (sp * n4 + (n0 >> 2)) * 4) = bsum;     // sX is free behind the loop's last barrier
   }
   __syncthreads();
   if (work && sp == 0) {
@@ -398,7 +415,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_small_kernel(const float* __rest
     for (int i = 0; i < 4; ++i) {
       f32x4 s = *reinterpret_cast<const f32x4*>(sD + tile * 16 + 4 * i);
       for (int q = 1; q < shares; ++q) s += *reinterpret_cast<const f32x4*>(sD + (q * tiles + tile) * 16 + 4 * i);
-      *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * N * K + (long)(n0 + i) * K + k0) = s;
+      *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * E + (long)(n0 + i) * K + k0) = s;
+    }
+    if (bias_owner) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(sX + (n0 >> 2) * 4);
+      for (int q = 1; q < shares; ++q) s += *reinterpret_cast<const f32x4*>(sX + (q * n4 + (n0 >> 2)) * 4);
+      *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * E + (long)N * K + n0) = s;
     }
   }
 }
@@ -663,28 +685,48 @@ extern "C" int nnz_bn_relu_nhwc_backward_f32(const float* x, const float* dy, co
 
 // dW [N][K] = dy^T x over T tokens; N, K multiples of 4, <= 64; dy [T][N], x [T][K] fp32.  workspace:
 // nnz_pw_wgrad_small_workspace_floats(T, N, K) floats.  dW is WRITTEN; deterministic (fixed-order folds).
-extern "C" long nnz_pw_wgrad_small_workspace_floats(long T, int N, int K) {
+extern "C" long nnz_pw_wgrad_small_workspace_floats_b(long T, int N, int K, int with_bias) {
   if (T < 1 || N < 4 || K < 4) return 0;
   const long ranges = (T + nnz::PW_TR - 1) / nnz::PW_TR;
-  return ranges * N * K + nnz::fold_partials_scratch_floats((int)ranges, (long)N * K);
+  const long E = (long)N * K + (with_bias ? N : 0);
+  return ranges * E + nnz::fold_partials_scratch_floats((int)ranges, (long)N * K);
 }
-extern "C" int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* workspace, float* dW, long T, int N, int K,
-                                      void* stream) {
+extern "C" long nnz_pw_wgrad_small_workspace_floats(long T, int N, int K) { return nnz_pw_wgrad_small_workspace_floats_b(T, N, K, 0); }
+template <typename TA>
+static int pw_wgrad_small_t(const TA* dy, const TA* x, float* workspace, float* dW, float* db, long T, int N, int K, void* stream) {
   using namespace nnz;
-  if (!dy || !x || !workspace || !dW || T < 1 || N < 4 || K < 4 || N > 64 || K > 64 || (N & 3) || (K & 3) || ((size_t)dy & 15) ||
-      ((size_t)x & 15))
+  const size_t al = sizeof(TA) == 4 ? 15 : 7;
+  if (!dy || !x || !workspace || !dW || T < 1 || N < 4 || K < 4 || N > 64 || K > 64 || (N & 3) || (K & 3) || ((size_t)dy & al) ||
+      ((size_t)x & al))
     return NNZ_EINVAL;
   const long ranges = (T + PW_TR - 1) / PW_TR;
   if (ranges > 0x7fffffffL) return NNZ_EINVAL;
   const int tiles = (N >> 2) * (K >> 2);
   int shares = 256 / tiles;
   if (shares > 16) shares = 16;
-  NNZ_LAUNCH(pw_wgrad_small_kernel, dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, dy, x, workspace, T, N, K, shares);
-  float* scratch = fold_partials_scratch_floats((int)ranges, (long)N * K) ? workspace + ranges * N * K : nullptr;
-  hipError_t e = fold_partials(workspace, (int)ranges, (long)N * K, (long)N * K, dW, (hipStream_t)stream, scratch);
+  const long NK = (long)N * K, E = NK + (db ? N : 0);
+  if (db) NNZ_LAUNCH((pw_wgrad_small_kernel<TA, true>), dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, dy, x, workspace, T, N, K, shares);
+  else NNZ_LAUNCH((pw_wgrad_small_kernel<TA, false>), dim3((unsigned)ranges), dim3(256), 0, (hipStream_t)stream, dy, x, workspace, T, N, K, shares);
+  float* scratch = fold_partials_scratch_floats((int)ranges, NK) ? workspace + ranges * E : nullptr;
+  hipError_t e = fold_partials(workspace, (int)ranges, E, NK, dW, (hipStream_t)stream, scratch);
   if (e != hipSuccess) return (int)e;
+  if (db) {
+    e = fold_partials(workspace + NK, (int)ranges, E, (long)N, db, (hipStream_t)stream, scratch);
+    if (e != hipSuccess) return (int)e;
+  }
   NNZ_LAUNCH_CHECK();
   return NNZ_OK;
+}
+extern "C" int nnz_pw_wgrad_small_f32(const float* dy, const float* x, float* workspace, float* dW, long T, int N, int K,
+                                      void* stream) {
+  return pw_wgrad_small_t<float>(dy, x, workspace, dW, nullptr, T, N, K, stream);
+}
+// the same for fp32 or fp16 (is_f16) token rows and, db != NULL, the bias gradient db [N] = sum_t dy[t] from the same pass
+// (workspace: nnz_pw_wgrad_small_workspace_floats_b(T, N, K, db != NULL))
+extern "C" int nnz_pw_wgrad_small(const void* dy, const void* x, int is_f16, float* workspace, float* dW, float* db, long T, int N,
+                                  int K, void* stream) {
+  return is_f16 ? pw_wgrad_small_t<_Float16>((const _Float16*)dy, (const _Float16*)x, workspace, dW, db, T, N, K, stream)
+                : pw_wgrad_small_t<float>((const float*)dy, (const float*)x, workspace, dW, db, T, N, K, stream);
 }
 
 // 1x1 convolution to N <= 8 channels.  x: element (b, p, k) at x[b * xsb + p * xsp + k * xsk] (token-major: xsp = K, xsk = 1; NCHW:

@@ -106,13 +106,16 @@ class _Pointwise1x1Fn(torch.autograd.Function):
             _d32_dgrad(dy2, weight.view(N, K), None, dx, T, K, N)
             dx = dx.view(ctx.xshape)
         need_w, need_b = ctx.needs_input_grad[1], bp is not None and ctx.needs_input_grad[2]
-        if need_w and bp is None and N <= 64 and K <= 64 and T >= SMALL_WGRAD_MIN_TOKENS and x2.dtype == torch.float32:
-            # few channels over very many tokens (stems / heads of the full-resolution stages): a streaming reduction on its own
-            # kernel (csrc/sepconv32.hip pw_wgrad_small_kernel) - half-empty 64-wide MFMA tiles cost ~140 us per problem
-            ws = torch.empty(int(_lib.load().nnz_pw_wgrad_small_workspace_floats(T, N, K)), dtype=torch.float32, device=dy.device)
+        if need_w and N <= 64 and K <= 64 and T >= SMALL_WGRAD_MIN_TOKENS:
+            # few channels over very many tokens (stems / heads / 1x1 embeddings of the full-resolution stages): a streaming reduction on
+            # its own kernel (csrc/sepconv32.hip pw_wgrad_small_kernel; fp32 or fp16 rows, the bias gradient from the same pass) -
+            # half-empty 64-wide MFMA tiles cost ~140 us per problem in the grouped launch
+            lib = _lib.load()
+            ws = torch.empty(int(lib.nnz_pw_wgrad_small_workspace_floats_b(T, N, K, int(need_b))), dtype=torch.float32, device=dy.device)
             dw = torch.empty_like(weight)
-            call("nnz_pw_wgrad_small_f32", ptr(dy2), ptr(x2), ptr(ws), ptr(dw), T, N, K, stream_ptr())
-            return dx, dw, None
+            db = torch.empty(N, dtype=torch.float32, device=dy.device) if need_b else None
+            call("nnz_pw_wgrad_small", ptr(dy2), ptr(x2), int(x2.dtype == torch.float16), ptr(ws), ptr(dw), ptr(db), T, N, K, stream_ptr())
+            return dx, dw, db
         if need_w or need_b:
             if _DEFER["on"] and need_w and wp.is_leaf and (bp is None or bp.is_leaf) and not _has_grad_hooks(wp) \
                     and not (bp is not None and _has_grad_hooks(bp)):

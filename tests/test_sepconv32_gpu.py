@@ -192,3 +192,32 @@ def test_stage_stem_matches_the_torch_modules(hip_lib, cin, cout, size):
 def copy_double(m):
     import copy
     return copy.deepcopy(m).double()
+
+
+@pytest.mark.parametrize("T,N,K", [(32768, 16, 32), (20000, 64, 64), (16384 + 77, 4, 8), (524288, 32, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("bias", [False, True])
+def test_small_channel_weight_gradient_kernel_with_bias_and_fp16_rows(hip_lib, T, N, K, dtype, bias):
+    """csrc/sepconv32.hip pw_wgrad_small_kernel<TA, BIAS> through nnz_pw_wgrad_small: dW = dy^T x and db = sum_t dy[t] for fp32 or fp16
+    token rows against the fp64 products of the same (rounded) rows; two launches give the same bits (fixed-order folds)"""
+    import ctypes as C
+    from nnuzoo_amd import _lib
+    from nnuzoo_amd._lib import call, ptr, stream_ptr
+    torch.manual_seed(T % 97 + N + K)
+    dy = torch.randn(T, N, device="cuda").to(dtype)
+    x = torch.randn(T, K, device="cuda").to(dtype)
+    lib = _lib.load()
+    outs = []
+    for _ in range(2):
+        ws = torch.empty(int(lib.nnz_pw_wgrad_small_workspace_floats_b(T, N, K, int(bias))), dtype=torch.float32, device="cuda")
+        dw = torch.empty(N, K, device="cuda")
+        db = torch.empty(N, device="cuda") if bias else None
+        call("nnz_pw_wgrad_small", ptr(dy), ptr(x), int(dtype == torch.float16), ptr(ws), ptr(dw), ptr(db), T, N, K, stream_ptr())
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and (not bias or torch.equal(outs[0][1], outs[1][1]))
+    ref = dy.double().t() @ x.double()
+    tol = 2e-5 * float(T) ** 0.5
+    assert (outs[0][0].double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / float(T) ** 0.5)
+    if bias:
+        rb = dy.double().sum(0)
+        assert (outs[0][1].double() - rb).abs().max().item() <= tol
