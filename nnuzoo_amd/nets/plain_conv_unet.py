@@ -25,6 +25,7 @@ runs; both forms give the same bits, tests/test_plain_unet_gpu.py).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional, Sequence, Tuple, Type, Union
 
@@ -310,6 +311,17 @@ class _Plan:
             self.pack_dual.add(w, u.wp_fwd, u.wp_dgrad, u.cin, u.cout, nk, False, u.fwd, u.dgrad)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _check_supported(net: "PlainConvUNet"):
     enc = net.encoder
     if enc.conv_op not in (nn.Conv2d, nn.Conv3d):
@@ -406,6 +418,11 @@ class PlainConvUNet(nn.Module):
         # data-gradient launches also close the InstanceNorm-backward reductions of the layer below (see _conv_block_bwd);
         # NNZ_FUSE_NORM_REDUCE=0 keeps the separate reducing launches (A/B runs, tests)
         self.fuse_norm_reduce = os.environ.get("NNZ_FUSE_NORM_REDUCE", "1") != "0"
+        # NNZ_WGRAD_SIDE_MAXV > 0: the weight gradients of the conv blocks with at most that many output voxels per sample run on a
+        # SIDE stream (they depend on the block's norm-backward output only, not on the data-gradient chain): the under-filled launches
+        # of the deep levels overlap the chain instead of extending it; captured as a parallel branch when the step is a hipGraph.
+        # Not with a gradient reducer (N > 1: the hand-over points expect the block's gradients in stream order).
+        self.wgrad_side_maxv = int(os.environ.get("NNZ_WGRAD_SIDE_MAXV", "0"))
         # consumers normalise + activate raw conv outputs while staging them; no apply pass, no activated tensors (module doc)
         self.consumer_norm = os.environ.get("NNZ_CONSUMER_NORM", "1") != "0"
 
@@ -589,10 +606,20 @@ class PlainConvUNet(nn.Module):
                                            b.cin * nk, 1)
                 gw.copy_(b.gw_pad[:, :b.cin_w].reshape(gw.shape))
             else:
-                if b.wgrad_flipped:   # dW[t][cout][cin]: a = cout (stride cin*nk), b = cin (stride nk)
-                    ops.conv_tap_wgrad_to_grad(b.wgrad, draw, x_in, self._wgrad_ws, gw, b.cin * nk, nk, 1, plain_norm=x_norm)
+                side = self._side if (self._side is not None and b.V <= self.wgrad_side_maxv) else None
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream(dev))      # draw (and the arena's zero fill) are complete
+                    draw.record_stream(side)
+                    ws = self._side_ws
                 else:
-                    ops.conv_tap_wgrad_to_grad(b.wgrad, x_in, draw, self._wgrad_ws, gw, nk, b.cin * nk, 1, boxed_norm=x_norm)
+                    ws = self._wgrad_ws
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    if b.wgrad_flipped:   # dW[t][cout][cin]: a = cout (stride cin*nk), b = cin (stride nk)
+                        ops.conv_tap_wgrad_to_grad(b.wgrad, draw, x_in, ws, gw, b.cin * nk, nk, 1, plain_norm=x_norm)
+                    else:
+                        ops.conv_tap_wgrad_to_grad(b.wgrad, x_in, draw, ws, gw, nk, b.cin * nk, 1, boxed_norm=x_norm)
+                if side is not None:
+                    self._side_used = True
                 if b.zero_dx and not dx_acc:
                     dx_out.zero_()  # k1 s2 axes: odd input positions are outside every output's footprint
                 pt = b.dgrad_acc if dx_acc else b.dgrad
@@ -662,6 +689,12 @@ class PlainConvUNet(nn.Module):
         if plan.wgrad_ws is None:
             plan.wgrad_ws = torch.empty(plan.wgrad_ws_floats, dtype=torch.float32, device=dev)
         self._wgrad_ws = plan.wgrad_ws
+        self._side, self._side_used = None, False
+        if self.wgrad_side_maxv > 0 and self.grad_reducer is None and dev.type == "cuda":
+            self._side = _side_stream(dev)
+            if getattr(plan, "wgrad_ws_side", None) is None:      # its own workspace: the main stream's split-K launches use the other
+                plan.wgrad_ws_side = torch.empty(plan.wgrad_ws_floats, dtype=torch.float32, device=dev)
+            self._side_ws = plan.wgrad_ws_side
         gout_by_level = {lvl: g for lvl, g in zip(rec["out_levels"], gouts)}
         g_cur = None  # gradient wrt the current decoder stage output (act), contiguous [N, V, C]
         g_cats = [None] * (S - 1)
@@ -760,6 +793,9 @@ class PlainConvUNet(nn.Module):
             out.append(None if id(p) in self._arena_unused else gp)
         if self.grad_reducer is not None:
             self.grad_reducer.finish_arena(self._arena, self._arena_off)
+        if self._side_used:
+            torch.cuda.current_stream(dev).wait_stream(self._side)     # join: every weight gradient is complete for the caller
+        self._side = None
         self._arena_layout = self._arena_trace
         self._last_arena = self._arena
         self._last_unused = self._arena_unused
