@@ -195,12 +195,13 @@ def dense32_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
 # do not sit on the data-gradient chain.  Results are bit-identical to the per-layer launches (same split rule, same
 # arithmetic, fixed fold order).  Outside the context (torch.autograd.grad, parity tests) nothing changes.
 GROUP_WGRAD = os.environ.get("NNZ_DENSE32_GROUP", "1") != "0"
-# weight gradients whose token ranges are spread over many workgroups (token Linear, x_proj, depthwise conv + SiLU):
-# NNZ_TWO_STAGE_WGRADS=1 - partial blocks + fixed-order fold, bit-reproducible (tests/test_two_stage_wgrads_gpu.py); default 0 -
-# fp32 atomics into a zero-filled gradient.  Measured at 512^2, batch 2 (profiles/r04_two_stage_wgrads.txt): the two-stage form
-# costs 0.9-1.4 % of an M2Net / M2NetP / SSND2Net step, and the steps of the Mamba nets stay non-reproducible either way (the scan
-# backward's cross-channel dB / dC / d-delta sums) - so it is an option, not the default.
-TWO_STAGE = os.environ.get("NNZ_TWO_STAGE_WGRADS", "0") == "1"
+# weight gradients whose token ranges are spread over many workgroups (token Linear outside the grouped launches, x_proj, depthwise
+# conv + SiLU): partial blocks + fixed-order fold, bit-reproducible (tests/test_two_stage_wgrads_gpu.py).  Default since the end of
+# round 6: with the grouped launches carrying most of these gradients the two-stage form costs nothing any more (same-box A/B at 512^2,
+# batch 2: M2Net 73.77 / 73.86 ms with it, 73.83 / 73.91 without; M2NetP 56.16 vs 56.23) and it is what makes the M2Net training step
+# bit-identical run to run in the DEFAULT mode (tests/test_zoo_determinism_gpu.py).  NNZ_TWO_STAGE_WGRADS=0: fp32 atomics into a
+# zero-filled gradient (rounds 2-5; 0.9 - 1.4 % faster in round 4, before the grouped launches).
+TWO_STAGE = os.environ.get("NNZ_TWO_STAGE_WGRADS", "1") != "0"
 _DEFER = {"on": False, "jobs": [], "folds": [], "tl_jobs": [], "xp_jobs": []}
 GROUP_TL_WGRAD = os.environ.get("NNZ_TL_GROUP", "1") != "0"     # fp16 token Linears: weight gradients grouped like the fp32 ones
 _GROUP_KEEP = []          # host tables captured into a hipGraph must outlive it

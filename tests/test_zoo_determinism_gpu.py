@@ -2,7 +2,7 @@
 step: the scan backward writes per-workgroup slabs and folds them in a fixed order (csrc/selective_scan.hip, ss2d_scan_rl.hpp), the
 weight gradients of the fp16 token Linears and of x_proj leave their kernels as per-workgroup partial blocks folded by the pass's
 grouped launches (csrc/token_linear.hip, ss2d_xproj.hip), the depthwise conv + SiLU backward takes its two-stage form
-(NNZ_TWO_STAGE_WGRADS=1, the one remaining opt-in: +0.3 % of a step), LayerNorm and the optimizer tail were fixed-point already.
+(the default since the end of round 6: it costs nothing any more; NNZ_TWO_STAGE_WGRADS=0 restores the atomics), LayerNorm and the optimizer tail were fixed-point already.
 Two trainers built from the same seed and fed the same batches must therefore hold the SAME parameters, bit for bit, after
 several steps - eager and replayed as a hipGraph.  What is NOT ours stays outside the claim: the library convolutions (the 1 x 1 side
 heads and the fuse convolution; MIOpen picks its solver per process, profiles/r04_zoo_module_determinism.txt) are replaced by ATen's
@@ -36,7 +36,7 @@ def _run(graph: bool, steps: int = 4, trainer: str = "nnUNetTrainerM2NetP"):
 @pytest.mark.parametrize("graph", [False, True])
 def test_m2netp_training_steps_are_bit_reproducible(hip_lib, graph, monkeypatch):
     from nnuzoo_amd import token_linear
-    monkeypatch.setattr(token_linear, "TWO_STAGE", True)        # depthwise conv + SiLU weight gradient: partial rows + fold
+    assert token_linear.TWO_STAGE       # the default since the end of round 6: depthwise conv + SiLU weight gradient as partial rows + fold
     with torch.backends.cudnn.flags(enabled=False):
         la, pa = _run(graph)
         lb, pb = _run(graph)
@@ -79,14 +79,16 @@ def test_swt2net_training_steps_are_bit_reproducible_in_the_default_mode(hip_lib
 
 
 @pytest.mark.parametrize("graph", [False, True])
-def test_m2net_training_steps_are_bit_reproducible_with_the_library_enabled(hip_lib, graph, monkeypatch):
+def test_m2net_training_steps_are_bit_reproducible_in_the_default_mode(hip_lib, graph, monkeypatch):
     """round 6, the net of bench.py's secondary leg: the MU stems, 1x1 patch embeddings / stage outputs, 3x3 side heads and the fuse
-    convolution run on this package's kernels (nnuzoo_amd/rebnconv.py unit_nchw / head3x3, sepconv32.py pointwise_tokens / head1x1) and
-    the REBNCONV batch statistics are fixed-point sums, so no convolution of the M2Net step reaches MIOpen and the claim above holds
-    WITHOUT replacing the library: same seed, same batches, bit-identical parameters.  (M2NetP keeps its 16-channel RSU4F units on the
-    library - the tap-table kernels work on 32-channel blocks - hence the ATen switch in its test above.)"""
+    convolution run on this package's kernels (nnuzoo_amd/rebnconv.py unit_nchw / head3x3, sepconv32.py pointwise_tokens / head1x1),
+    the REBNCONV batch statistics are fixed-point sums and the depthwise conv + SiLU weight gradient takes its two-stage form by
+    default - no convolution of the M2Net step reaches MIOpen, no float atomic is left in it, and NOTHING is switched for this test:
+    same seed, same batches, bit-identical parameters after four steps in the trainer's default mode, eager and replayed.
+    (M2NetP keeps its 16-channel RSU4F units on the library - the tap-table kernels work on 32-channel blocks - hence the ATen
+    switch in its test above.)"""
     from nnuzoo_amd import token_linear
-    monkeypatch.setattr(token_linear, "TWO_STAGE", True)
+    assert token_linear.TWO_STAGE       # nothing is switched for this test: the trainer's default mode
     la, pa = _run(graph, trainer="nnUNetTrainerM2Net")
     lb, pb = _run(graph, trainer="nnUNetTrainerM2Net")
     assert la == lb, (la, lb)
